@@ -1,0 +1,309 @@
+/*
+ * lentil_hip.h -- C-ABI of liblentil_hip.so: the MI355X (gfx950) implementation of
+ * lentil's bidirectional bokeh redistribution + polynomial-optics ray transfer.
+ *
+ * This is the drop-in boundary.  A `Camera` object of the
+ * reference plugin (src/lentil.h:92-196) keeps owning all render state; instead of
+ * accumulating into std::vector buffers from `filter_pixel` it owns one
+ * `lentil_hip_ctx` and drives it with the calls below.  Every entry point names the
+ * reference code it replaces.  Plain pointers and sizes only: no torch, no HIP and no
+ * Arnold types appear in any signature.
+ *
+ * Conventions
+ *   - All functions return LENTIL_OK (0) or a negative LENTIL_ERR_* code; the text of
+ *     the last error is available from lentil_hip_last_error().  Nothing aborts or
+ *     exits (the reference's failures on this path are per-draw rejects, and
+ *     AiRenderAbort on setup errors, src/lentil.h:225-228).
+ *   - A context is bound to one GPU and one HIP stream.  Calls on one context must be
+ *     serialised by the caller (the reference takes l_critsec only around
+ *     setup_camera, src/lentil.h:212,235); different contexts are independent
+ *     (multi-GPU = one context per device, one process per GPU).
+ *   - "visit" = one (pixel, AOV-sample) pair yielded by the filter's sample iterator
+ *     (src/lentil_filter.cpp:105); "draw" = one backward trace attempt for a visit
+ *     (src/lentil_filter.cpp:248,311).
+ */
+#ifndef LENTIL_HIP_H
+#define LENTIL_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LENTIL_ABI_VERSION 1
+
+#define LENTIL_OK 0
+#define LENTIL_ERR_INVALID (-1)     /* bad argument / call order */
+#define LENTIL_ERR_HIP (-2)         /* a HIP runtime call failed */
+#define LENTIL_ERR_UNSUPPORTED (-3) /* parameter combination not implemented on the GPU */
+#define LENTIL_ERR_NOMEM (-4)
+
+/* enum CameraType, src/lentil.h:75-78 */
+#define LENTIL_THINLENS 0
+#define LENTIL_POLYNOMIAL_OPTICS 1
+/* enum UnitModel, src/lentil.h:67-72 */
+#define LENTIL_UNIT_MM 0
+#define LENTIL_UNIT_CM 1
+#define LENTIL_UNIT_DM 2
+#define LENTIL_UNIT_M 3
+/* AOVData::original_filter, src/aov_data.h:120, src/lentil.h:189-191 */
+#define LENTIL_FILTER_GAUSSIAN 0
+#define LENTIL_FILTER_CLOSEST 1
+#define LENTIL_FILTER_VARIANCE 2
+/* pupil geometry strings "cyl-y" / "cyl-x" / anything else, src/lentil.h:387-389 */
+#define LENTIL_GEOM_SPHERICAL 0
+#define LENTIL_GEOM_CYL_Y 1
+#define LENTIL_GEOM_CYL_X 2
+
+#define LENTIL_MAX_AOVS 16 /* RGBA + up to 15 more redistributed AOVs */
+
+/* ------------------------------------------------------------------------------------
+ * Camera state the kernels need: the fields of `struct Camera` (src/lentil.h:92-196,
+ * SURVEY.md appendix B) that filter_pixel / trace_ray_bw_po / add_to_buffer read, with
+ * the reference's own names and float/double widths (appendix C.10).  Values are the
+ * ones *after* get_lentil_camera_params() clamping (src/lentil.h:1189-1243) and
+ * camera_model_specific_setup() (src/lentil.h:1568-1670): e.g. PO focus_distance is
+ * already x10 (mm), bokeh_anamorphic is already 1 - param.
+ * ---------------------------------------------------------------------------------- */
+typedef struct lentil_params {
+  int32_t cameraType;      /* LENTIL_THINLENS | LENTIL_POLYNOMIAL_OPTICS */
+  int32_t unitModel;       /* LENTIL_UNIT_* */
+  int32_t enable_dof;
+  int32_t vignetting_retries;      /* default 15, src/lentil_camera.cpp:44 */
+  int32_t bokeh_aperture_blades;
+  int32_t bokeh_enable_image;
+  int32_t bidir_sample_mult;
+  int32_t enable_bidir_transmission;
+  int32_t enable_skydome;
+  int32_t abb_chromatic_type;
+  int32_t adaptive_sampling;       /* options.enable_adaptive_sampling, src/lentil_filter.cpp:74 */
+  int32_t samples_override;        /* 0: reference draw-count formula (src/lentil_filter.cpp:177-202);
+                                      >0: fixed accepted-draw count per redistributed visit (bench configs) */
+  uint32_t xres, yres;             /* buffer size incl. the +1 quirk, src/lentil.h:1079-1080 */
+  uint32_t xres_without_region, yres_without_region;
+  int32_t region_min_x, region_min_y;
+
+  double sensor_width;
+  double focus_distance;
+  double aperture_radius;
+  double sensor_shift;
+  double bidir_add_energy_minimum_luminance;
+
+  float focal_length;
+  float bidir_add_energy;
+  float bidir_add_energy_transition;
+  float abb_spherical;
+  float abb_coma;
+  float abb_distortion;
+  float abb_chromatic;
+  float circle_to_square;
+  float bokeh_anamorphic;
+  float optical_vignetting_distance;
+  float optical_vignetting_radius;
+  float filter_width;
+  float inverse_sample_density;    /* 1/AA^2 as computed at src/lentil_filter.cpp:83-84 (non-adaptive) */
+  float lambda_bw;                 /* 0.55, src/lentil_filter.cpp:254 */
+
+  /* AiWorldToCameraMatrix(camera, time) of a static camera, row-vector convention
+   * (p' = p * M, translation in row 3), src/lentil_filter.cpp:143-144 */
+  float world_to_camera[4][4];
+} lentil_params;
+
+/* ------------------------------------------------------------------------------------
+ * Lens table: replaces the generated `case <lens>: {...}` bodies spliced in at
+ * src/lentil.h:1262,1278,1308,1576 (absent from the reference tree).  One sparse
+ * 5-variate polynomial per output; a term is  c * x^e0 * y^e1 * dx^e2 * dy^e3 * lambda^e4
+ * with integer powers evaluated like lens_ipow (src/lens.h:226-233), terms summed in
+ * table order.  Partial derivatives are derived from these terms inside the library.
+ * ---------------------------------------------------------------------------------- */
+typedef struct lentil_term {
+  double c;
+  uint8_t e[5];
+  uint8_t pad[3];
+} lentil_term;
+
+typedef struct lentil_poly {
+  uint32_t first; /* index of first term in lentil_lens_table::terms */
+  uint32_t count;
+} lentil_poly;
+
+typedef struct lentil_lens_table {
+  /* lens constants, src/lentil.h:106-120 */
+  double lens_outer_pupil_radius;
+  double lens_inner_pupil_radius;
+  double lens_length;
+  double lens_back_focal_length;
+  double lens_effective_focal_length;
+  double lens_aperture_pos;
+  double lens_aperture_housing_radius;
+  double lens_inner_pupil_curvature_radius;
+  double lens_outer_pupil_curvature_radius;
+  double lens_field_of_view;
+  double lens_fstop;
+  double lens_aperture_radius_at_fstop;
+  int32_t lens_inner_pupil_geometry; /* LENTIL_GEOM_* */
+  int32_t lens_outer_pupil_geometry;
+  lentil_poly out[5]; /* outer pupil x, y, dx, dy, transmittance (pt_evaluate) */
+  lentil_poly ap[4];  /* aperture plane x, y, dx, dy (pt_evaluate_aperture) */
+  uint32_t n_terms;
+  uint32_t reserved;
+  const lentil_term *terms; /* host pointer, copied by lentil_hip_set_lens */
+} lentil_lens_table;
+
+/* Bokeh-image importance tables exactly as imageData::bokehProbability leaves them
+ * (src/imagebokeh.h:143-338); host pointers, copied by lentil_hip_set_bokeh. */
+typedef struct lentil_bokeh_table {
+  int32_t x, y;
+  const float *cdfRow;          /* y   */
+  const int32_t *rowIndices;    /* y   */
+  const float *cdfColumn;       /* x*y */
+  const int32_t *columnIndices; /* x*y */
+} lentil_bokeh_table;
+
+/* ------------------------------------------------------------------------------------
+ * Visit stream: what filter_pixel gathers per AOV sample (src/lentil_filter.cpp:115-164,
+ * 206-234), as fp32 columns of 4 floats per visit (16-byte rows, so one wave reads
+ * 1 KiB per column per load):
+ *     rgba          : sample RGBA                                   (:115)
+ *     pos_z         : P world space .xyz, Z                         (:116-117)
+ *     raydir_time   : lentil_raydir .xyz, lentil_time               (:121,141)
+ *     volume_ignore : volume .rgb, lentil_ignore                    (:135,162)
+ *     transmission  : transmission RGBA                             (:152)
+ *     extra[k]      : AOV k+1 already widened to RGBA               (:214-232)
+ * = 80 + 16*K bytes per visit.  Visits are pixel-major in iterator order.
+ *
+ * Pixel mapping.  visits_per_pixel > 0: uniform footprint; visit v belongs to source
+ * pixel p = v / visits_per_pixel with  px = pixel_x0 + p % pixels_per_row,
+ * py = pixel_y0 + (p / pixels_per_row) * pixel_row_stride  (region-relative, i.e. after
+ * src/lentil_filter.cpp:100-101; row_stride > 1 expresses a row-interleaved multi-GPU
+ * partition).  visits_per_pixel == 0: `pixel` holds px | (py << 16) per visit and
+ * `inv_density` (optional) the per-visit inverse sample density (adaptive sampling or
+ * ragged footprints, src/lentil_filter.cpp:83-84,109).
+ * ---------------------------------------------------------------------------------- */
+typedef struct lentil_visits {
+  uint64_t n;
+  uint32_t visits_per_pixel;
+  uint32_t pixels_per_row;
+  int32_t pixel_x0, pixel_y0;
+  uint32_t pixel_row_stride;
+  uint32_t n_extra;           /* K: number of extra AOV columns */
+  const float *rgba;
+  const float *pos_z;
+  const float *raydir_time;
+  const float *volume_ignore;
+  const float *transmission;
+  const float *extra[LENTIL_MAX_AOVS - 1];
+  const uint32_t *pixel;      /* optional, see above */
+  const float *inv_density;   /* optional */
+} lentil_visits;
+
+/* counters of the last lentil_hip_redistribute (device-side, fetched on demand) */
+typedef struct lentil_counters {
+  uint64_t visits;
+  uint64_t redistributed_visits; /* visits that entered the draw loop */
+  uint64_t attempted_draws;      /* total_samples_taken summed, src/lentil_filter.cpp:248 */
+  uint64_t accepted_draws;
+  uint64_t worklist_overflow;    /* non-zero => work list too small, results incomplete */
+} lentil_counters;
+
+/* one accepted draw, for index-parity tests: (visit, attempt n, linear pixel) */
+typedef struct lentil_draw_record {
+  uint32_t visit;
+  uint32_t attempt;
+  uint32_t pixel;
+} lentil_draw_record;
+
+typedef struct lentil_hip_ctx lentil_hip_ctx;
+
+/* --- lifetime ----------------------------------------------------------------------
+ * replaces `new Camera()` / `delete camera_data` buffer ownership
+ * (src/lentil_camera.cpp:58-61,70-75; Camera::destroy_buffers src/lentil.h:1143-1148). */
+int lentil_hip_abi_version(void);
+int lentil_hip_create(int device, lentil_hip_ctx **out_ctx);
+int lentil_hip_destroy(lentil_hip_ctx *ctx);
+const char *lentil_hip_last_error(const lentil_hip_ctx *ctx);
+
+/* --- setup (once per render) -------------------------------------------------------
+ * set_params : Camera::get_lentil_camera_params + camera_model_specific_setup results
+ *              (src/lentil.h:1189-1243,1568-1670)
+ * set_lens   : load_lens_constants.h / load_lt_sample_aperture.h / load_pt_evaluate.h
+ *              splices (src/lentil.h:1262,1278,1308,1576)
+ * set_bokeh  : imageData tables (src/imagebokeh.h:30-37) after bokehProbability
+ * alloc_frame: Camera::setup_filter + AOVData::allocate_regular_buffers
+ *              (src/lentil.h:1096-1121, src/aov_data.h:140-143).  AOV 0 is "RGBA" and is
+ *              the one that feeds filter_weight_buffer (src/lentil.h:827-828).
+ *              xres/yres are taken from the params. */
+int lentil_hip_set_params(lentil_hip_ctx *ctx, const lentil_params *params);
+int lentil_hip_set_lens(lentil_hip_ctx *ctx, const lentil_lens_table *lens);
+int lentil_hip_set_bokeh(lentil_hip_ctx *ctx, const lentil_bokeh_table *bokeh);
+int lentil_hip_alloc_frame(lentil_hip_ctx *ctx, uint32_t n_aovs, const uint8_t *aov_filter_kind);
+
+/* --- visit stream ------------------------------------------------------------------
+ * upload_visits: host columns -> library-owned device memory (what the capturing
+ *                filter_pixel hands over once per frame).
+ * bind_visits  : columns already resident in HBM (device pointers owned by the caller). */
+int lentil_hip_upload_visits(lentil_hip_ctx *ctx, const lentil_visits *host_visits);
+int lentil_hip_bind_visits(lentil_hip_ctx *ctx, const lentil_visits *device_visits);
+
+/* --- the hot path ------------------------------------------------------------------
+ * clear_frame : zero-initialisation done by std::vector::resize (src/lentil.h:1096-1098)
+ * redistribute: the filter_pixel visit loop (src/lentil_filter.cpp:91-451) for every bound
+ *               visit: predicate + draw count, trace_ray_bw_po / thin-lens draws,
+ *               add_to_buffer / filter_and_add_to_buffer_new (src/lentil.h:823-851,938-955).
+ *               Accumulates on top of whatever the frame holds (call clear_frame first).
+ *               Asynchronous on the context's stream.
+ * resolve     : driver_process_bucket's normalisation (src/lentil_imager.cpp:112-118,169-186)
+ *               into a separate resolved image (the accumulators stay intact). */
+int lentil_hip_clear_frame(lentil_hip_ctx *ctx);
+int lentil_hip_redistribute(lentil_hip_ctx *ctx);
+int lentil_hip_resolve(lentil_hip_ctx *ctx);
+int lentil_hip_sync(lentil_hip_ctx *ctx);
+
+/* --- results -----------------------------------------------------------------------
+ * download_aov     : resolved AOV as xres*yres RGBA floats (what the imager writes into
+ *                    bucket_data, src/lentil_imager.cpp:178,182)
+ * download_accum   : raw accumulators: AOVData::buffer (xres*yres*4) and
+ *                    filter_weight_buffer (xres*yres); either pointer may be NULL */
+int lentil_hip_download_aov(lentil_hip_ctx *ctx, uint32_t aov, float *host_rgba);
+int lentil_hip_download_accum(lentil_hip_ctx *ctx, uint32_t aov, float *host_rgba, float *host_weight);
+
+/* --- multi-GPU ---------------------------------------------------------------------
+ * accum_buffer: device pointer + float count of the contiguous block of all gaussian
+ *               accumulators followed by the weight buffer; a sum all-reduce over it
+ *               (RCCL) merges the cross-tile splats of all GPUs.  The
+ *               reference has no counterpart (single process, shared buffers). */
+int lentil_hip_accum_buffer(lentil_hip_ctx *ctx, void **device_ptr, uint64_t *n_floats);
+int lentil_hip_stream(lentil_hip_ctx *ctx, void **hip_stream);
+
+/* --- instrumentation ----------------------------------------------------------------
+ * timings are HIP-event times on the context's stream for the last redistribute/resolve:
+ * ms[0] scan+compaction+direct accumulate, ms[1] draw/splat kernel, ms[2] resolve. */
+int lentil_hip_get_counters(lentil_hip_ctx *ctx, lentil_counters *out);
+int lentil_hip_last_timing(lentil_hip_ctx *ctx, float ms[3]);
+int lentil_hip_set_draw_log(lentil_hip_ctx *ctx, uint64_t capacity); /* 0 disables */
+int lentil_hip_download_draw_log(lentil_hip_ctx *ctx, lentil_draw_record *out, uint64_t capacity,
+                                 uint64_t *n_records);
+
+/* --- single-function device tests (parity of the optics primitives) -----------------
+ * Runs n independent evaluations on the GPU; host pointers in/out.
+ * lt_sample_aperture: Camera::lens_lt_sample_aperture (src/lentil.h:1296-1313) for
+ *    scene[n][3], ap[n][2] -> sensor[n][5], out[n][5], transmittance[n]
+ * trace_bw_po: Camera::trace_ray_bw_po (src/lentil.h:573-661) for target[n][3]
+ *    (already -P_cs*10), px[n], py[n], attempt[n] -> sensor_xy[n][2], ok[n]
+ * aperture_sample: the aperture draw of trace_ray_bw_po (src/lentil.h:596-609) for
+ *    seed pairs (a[n] = px*py+px, b[n] = total_samples_taken+tries) -> xy[n][2] */
+int lentil_hip_test_lt_sample_aperture(lentil_hip_ctx *ctx, uint64_t n, const double *scene,
+                                       const double *ap, double lambda, double *sensor,
+                                       double *out, double *transmittance);
+int lentil_hip_test_trace_bw_po(lentil_hip_ctx *ctx, uint64_t n, const double *target,
+                                const int32_t *px, const int32_t *py, const int32_t *attempt,
+                                double *sensor_xy, int32_t *ok);
+int lentil_hip_test_aperture_sample(lentil_hip_ctx *ctx, uint64_t n, const uint32_t *a,
+                                    const uint32_t *b, double *xy);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LENTIL_HIP_H */

@@ -1,0 +1,1023 @@
+/*
+ * lentil_oracle.cpp -- TEST INFRASTRUCTURE ONLY.
+ *
+ * CPU restatement of the reference's (zpelgrims/pota, "lentil") bidirectional
+ * redistribution hot path, used as the parity oracle for the HIP implementation and
+ * as the "port" CPU baseline of bench.py.  Only tests/, __graft_entry__.smoke() and
+ * bench.py's cpu_baseline leg may load this library; the product path
+ * (pota_amd/, liblentil_hip.so) never does.
+ *
+ * Every function cites the reference file:line it follows (paths relative to
+ * /root/reference).  Conventions pinned: GCC right-to-left
+ * evaluation of the rng() call arguments, no FP contraction (-ffp-contract=off, the
+ * reference is built -O3 for baseline x86-64 = no FMA), sequential pixel-major visit
+ * order, AiTraceProbe == false, explicit buffer stride xres.
+ *
+ * PARITY STATUS
+ *  - pinned against the reference's own data: tea<8>/rng/xor128 known answers
+ *    (produced from src/global.h), and the per-iteration
+ *    Newton-solver trace tests/aperture_sampling_debug/writout.txt (2x2 inverses, update
+ *    steps incl. the 0.72 damping, sphereToCs, csToSphere, normalise, error-flag rules).
+ *  - PARITY UNPINNED for polynomial values: the generated lens code
+ *    (zpelgrims/polynomial-optics, database/lenses/<lens>/<fl>/code/<file>.h; no pinned version,
+ *    not a submodule) is absent from the reference tree, so the polynomial tables are the
+ *    build's own (tools/fit_lens.py) and the solver body restates the published
+ *    polynomial-optics generator output as evidenced by that trace.
+ *  - PARITY UNPINNED for Arnold SDK inline helpers (AiV3Normalize, AiM4PointByMatrixMult,
+ *    AiBias, AI_* constants): the SDK is absent; they are restated from its public headers
+ *    as recalled.
+ *  The reference itself is unbuildable here (needs <ai.h>, Eigen, CryptomatteArnold and
+ *  the generated lens code), so there is no oracle/_ref.
+ *
+ * Written as C-style C++ (g++) on purpose: std::pow / std::abs / std::ceil / std::min
+ * overload resolution and std::sort / std::upper_bound tie behaviour are then the very
+ * ones the reference gets from libstdc++.
+ */
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "../include/lentil_hip.h"
+
+#define ORC_API extern "C" __attribute__((visibility("default")))
+
+/* Arnold SDK constants (ai_constants.h; SDK absent, recalled -- SURVEY appendix C.16) */
+static const float AI_PI_F = 3.14159265358979323846f;
+static const float AI_PIOVER2_F = 1.57079632679489661923f;
+static const float AI_EPSILON_F = 1.0e-4f;
+static const float AI_INFINITE_F = 1.0e30f;
+#ifndef M_PI
+#define M_PI 3.14159265358979323846
+#endif
+
+/* =====================================================================================
+ * a6 -- src/global.h:22-57
+ * ===================================================================================== */
+ORC_API uint32_t orc_tea8(uint32_t val0, uint32_t val1) {      /* tea<8>, src/global.h:32-46 */
+  uint32_t v0 = val0, v1 = val1, s0 = 0;
+  for (int n = 0; n < 8; ++n) {
+    s0 += 0x9e3779b9u;
+    v0 += ((v1 << 4) + 0xA341316Cu) ^ (v1 + s0) ^ ((v1 >> 5) + 0xC8013EA4u);
+    v1 += ((v0 << 4) + 0xAD90777Du) ^ (v0 + s0) ^ ((v0 >> 5) + 0x7E95761Eu);
+  }
+  return v0;
+}
+
+ORC_API float orc_rng(uint32_t *state) {                        /* rng, src/global.h:51-57 */
+  *state = *state * 1664525u + 1013904223u;
+  return float(*state & 0x00FFFFFFu) / float(0x01000000u);
+}
+
+ORC_API uint32_t orc_xor128(uint32_t st[4]) {                   /* xor128, src/global.h:22-27 */
+  uint32_t t = st[0] ^ (st[0] << 11);
+  st[0] = st[1]; st[1] = st[2]; st[2] = st[3];
+  return st[3] = (st[3] ^ (st[3] >> 19) ^ t ^ (t >> 8));
+}
+ORC_API void orc_xor128_init(uint32_t st[4]) {
+  st[0] = 123456789u; st[1] = 362436069u; st[2] = 521288629u; st[3] = 88675123u;
+}
+
+static inline float lerpf(float perc, float a, float b) { return a + perc * (b - a); } /* global.h:3-5 */
+static inline float clampf(float in, float lo, float hi) {                              /* global.h:8-12 */
+  if (in < lo) in = lo;
+  if (in > hi) in = hi;
+  return in;
+}
+
+/* =====================================================================================
+ * a9 -- src/lens.h:17-37 (fast trig), :309-333 (PO disk), :477-514 (thin-lens disk)
+ * ===================================================================================== */
+ORC_API float orc_fast_sin(float x) {
+  x = fmod(x + AI_PI_F, AI_PI_F * 2) - AI_PI_F;
+  const float B = 4.0f / AI_PI_F;
+  const float C = -4.0f / (AI_PI_F * AI_PI_F);
+  float y = B * x + C * x * std::abs(x);
+  const float P = 0.225f;
+  return P * (y * std::abs(y) - y) + y;
+}
+ORC_API float orc_fast_cos(float x) {
+  x += AI_PI_F * 0.5;
+  x = fmod(x + AI_PI_F, AI_PI_F * 2) - AI_PI_F;
+  const float B = 4.0f / AI_PI_F;
+  const float C = -4.0f / (AI_PI_F * AI_PI_F);
+  float y = B * x + C * x * std::abs(x);
+  const float P = 0.225f;
+  return P * (y * std::abs(y) - y) + y;
+}
+
+/* concentric_disk_sample(ox, oy, unit_disk, fast_trigo=true), src/lens.h:309-333 */
+ORC_API void orc_concentric_disk_sample(double ox, double oy, double disk[2]) {
+  double phi, r;
+  double a = 2.0 * ox - 1.0;
+  double b = 2.0 * oy - 1.0;
+  if ((a * a) > (b * b)) {
+    r = a;
+    phi = (0.78539816339) * (b / a);
+  } else {
+    r = b;
+    phi = (M_PI / 2.0) - (0.78539816339) * (a / b);
+  }
+  disk[0] = r * orc_fast_cos(phi);   /* phi narrows to float at the call, appendix C.11 */
+  disk[1] = r * orc_fast_sin(phi);
+}
+
+/* AiBias (ai_math / SDK, recalled -- appendix C.16) */
+static inline float ai_bias(float a, float b) {
+  return (a > 0) ? ((b > 0) ? powf(a, logf(b) * -1.442695041f) : 0.0f) : 0.0f;
+}
+
+/* concentricDiskSample(ox, oy, lens, bias, squarelerp, squeeze_x), src/lens.h:477-514 */
+ORC_API void orc_concentricDiskSample(float ox, float oy, double lens[2], float bias,
+                                      float squarelerp) {
+  if (ox == 0.0 && oy == 0.0) { lens[0] = 0.0; lens[1] = 0.0; return; }
+  float phi, r;
+  const float a = 2.0 * ox - 1.0;
+  const float b = 2.0 * oy - 1.0;
+  if ((a * a) > (b * b)) {
+    r = a;
+    phi = 0.78539816339 * (b / a);
+  } else {
+    r = b;
+    phi = (AI_PIOVER2_F) - ((0.78539816339) * (a / b));
+  }
+  if (bias != 0.5) r = ai_bias(std::abs(r), bias) * (r < 0 ? -1 : 1);
+  const float cos_phi = orc_fast_cos(phi);
+  const float sin_phi = orc_fast_sin(phi);
+  lens[0] = r * cos_phi;
+  lens[1] = r * sin_phi;
+  if (squarelerp > 0.0) {
+    lens[0] = lerpf(squarelerp, lens[0], a);   /* double -> float args, float result */
+    lens[1] = lerpf(squarelerp, lens[1], b);
+  }
+}
+
+/* a10 -- Camera::lens_sample_triangular_aperture, src/lentil.h:964-982 */
+ORC_API void orc_triangular_aperture(double *x, double *y, double r1, double r2, double radius,
+                                     int blades) {
+  const int tri = (int)(r1 * blades);
+  r1 = r1 * blades - tri;
+  double a = std::sqrt(r1);
+  double b = (1.0f - r2) * a;
+  double c = r2 * a;
+  double p1[2], p2[2];
+  double ph1 = 2.0f * AI_PI_F / blades * (tri + 1);   /* float expression, widened at the call */
+  double ph2 = 2.0f * AI_PI_F / blades * tri;
+  p1[0] = std::sin(ph1); p1[1] = std::cos(ph1);       /* common_sincosf, src/lens.h:40-43 */
+  p2[0] = std::sin(ph2); p2[1] = std::cos(ph2);
+  *x = radius * (b * p1[1] + c * p2[1]);
+  *y = radius * (b * p1[0] + c * p2[0]);
+}
+
+/* =====================================================================================
+ * a14 -- src/lens.h:47-60 (helpers), :99-221 (pupil transforms), :226-233 (lens_ipow)
+ * ===================================================================================== */
+static inline double dot3(const double u[3], const double v[3]) {
+  return u[0] * v[0] + u[1] * v[1] + u[2] * v[2];
+}
+static inline void cross3(double r[3], const double u[3], const double v[3]) {
+  r[0] = u[1] * v[2] - u[2] * v[1];
+  r[1] = u[2] * v[0] - u[0] * v[2];
+  r[2] = u[0] * v[1] - u[1] * v[0];
+}
+ORC_API void orc_normalise(double v[3]) {                       /* raytrace_normalise */
+  const double ilen = 1.0f / std::sqrt(dot3(v, v));
+  for (int k = 0; k < 3; k++) v[k] *= ilen;
+}
+
+ORC_API void orc_sphereToCs(const double inpos[2], const double indir[2], double outpos[3],
+                            double outdir[3], double center, double R) {
+  const double normal[3] = {
+      inpos[0] / R, inpos[1] / R,
+      std::sqrt(std::max(0.0, R * R - inpos[0] * inpos[0] - inpos[1] * inpos[1])) / std::abs(R)};
+  const double tempDir[3] = {
+      indir[0], indir[1],
+      std::sqrt(std::max(0.0, 1.0 - indir[0] * indir[0] - indir[1] * indir[1]))};
+  double ex[3] = {normal[2], 0, -normal[0]};
+  orc_normalise(ex);
+  double ey[3];
+  cross3(ey, normal, ex);
+  outdir[0] = tempDir[0] * ex[0] + tempDir[1] * ey[0] + tempDir[2] * normal[0];
+  outdir[1] = tempDir[0] * ex[1] + tempDir[1] * ey[1] + tempDir[2] * normal[1];
+  outdir[2] = tempDir[0] * ex[2] + tempDir[1] * ey[2] + tempDir[2] * normal[2];
+  outpos[0] = inpos[0];
+  outpos[1] = inpos[1];
+  outpos[2] = normal[2] * R + center;
+}
+
+ORC_API void orc_csToSphere(const double inpos[3], const double indir[3], double outpos[2],
+                            double outdir[2], double center, double R) {
+  const double normal[3] = {inpos[0] / R, inpos[1] / R, std::abs((inpos[2] - center) / R)};
+  double tempDir[3] = {indir[0], indir[1], indir[2]};
+  orc_normalise(tempDir);
+  double ex[3] = {normal[2], 0, -normal[0]};
+  orc_normalise(ex);
+  double ey[3];
+  cross3(ey, normal, ex);
+  outdir[0] = dot3(tempDir, ex);
+  outdir[1] = dot3(tempDir, ey);
+  outpos[0] = inpos[0];
+  outpos[1] = inpos[1];
+}
+
+ORC_API void orc_cylinderToCs(const double inpos[2], const double indir[2], double outpos[3],
+                              double outdir[3], double center, double R, int cyl_y) {
+  double normal[3] = {0, 0, 0};
+  if (cyl_y) {
+    normal[0] = inpos[0] / R;
+    normal[2] = std::sqrt(std::max(0.0, R * R - inpos[0] * inpos[0])) / std::abs(R);
+  } else {
+    normal[1] = inpos[1] / R;
+    normal[2] = std::sqrt(std::max(0.0, R * R - inpos[1] * inpos[1])) / std::abs(R);
+  }
+  const double tempDir[3] = {
+      indir[0], indir[1],
+      std::sqrt(std::max(0.0, 1.0 - indir[0] * indir[0] - indir[1] * indir[1]))};
+  double ex[3] = {normal[2], 0, -normal[0]};
+  orc_normalise(ex);
+  double ey[3];
+  cross3(ey, normal, ex);
+  orc_normalise(ey);
+  outdir[0] = tempDir[0] * ex[0] + tempDir[1] * ey[0] + tempDir[2] * normal[0];
+  outdir[1] = tempDir[0] * ex[1] + tempDir[1] * ey[1] + tempDir[2] * normal[1];
+  outdir[2] = tempDir[0] * ex[2] + tempDir[1] * ey[2] + tempDir[2] * normal[2];
+  outpos[0] = inpos[0];
+  outpos[1] = inpos[1];
+  outpos[2] = normal[2] * R + center;
+}
+
+ORC_API void orc_csToCylinder(const double inpos[3], const double indir[3], double outpos[2],
+                              double outdir[2], double center, double R, int cyl_y) {
+  double normal[3] = {0, 0, 0};
+  if (cyl_y) {
+    normal[0] = inpos[0] / R;
+    normal[2] = std::abs((inpos[2] - center) / R);
+  } else {
+    normal[1] = inpos[1] / R;
+    normal[2] = std::abs((inpos[2] - center) / R);
+  }
+  double tempDir[3] = {indir[0], indir[1], indir[2]};
+  orc_normalise(tempDir);
+  double ex[3] = {normal[2], 0, -normal[0]};     /* not normalised here, src/lens.h:171 */
+  double ey[3];
+  cross3(ey, normal, ex);
+  orc_normalise(ey);
+  outdir[0] = dot3(tempDir, ex);
+  outdir[1] = dot3(tempDir, ey);
+  outpos[0] = inpos[0];
+  outpos[1] = inpos[1];
+}
+
+ORC_API double orc_lens_ipow(double x, int exp) {               /* src/lens.h:226-233 */
+  if (exp == 0) return 1.0f;
+  if (exp == 1) return x;
+  if (exp == 2) return x * x;
+  const double p2 = orc_lens_ipow(x, exp / 2);
+  if (exp & 1) return x * p2 * p2;
+  return p2 * p2;
+}
+
+/* =====================================================================================
+ * Polynomial tables (stand-in for the generated code spliced at src/lentil.h:1262,1278,1308).
+ * Evaluation mirrors how polynomial-optics prints a polynomial:
+ *     out = + c0*<factors> + c1*<factors> ...   (left to right)
+ * a factor is the bare variable for exponent 1, lens_ipow(v, e) otherwise, in variable
+ * order x, y, dx, dy, lambda.   PARITY UNPINNED (generator output absent).
+ * ===================================================================================== */
+struct OrcPoly { std::vector<lentil_term> t; };
+
+struct OrcLens {
+  lentil_lens_table k;          /* constants (terms pointer unused) */
+  OrcPoly out[5], ap[4];
+  OrcPoly dap[2][2];            /* d ap_{x,y} / d {dx,dy}   ("dx1_domega0") */
+  OrcPoly dout[2][2];           /* d out_{dx,dy} / d {x,y}  ("domega2_dx0") */
+};
+
+static OrcPoly derive(const OrcPoly &p, int var) {
+  /* derivative term: coefficient * exponent, exponent - 1; zero-exponent terms vanish */
+  OrcPoly d;
+  for (const lentil_term &t : p.t) {
+    if (t.e[var] == 0) continue;
+    lentil_term n = t;
+    n.c = t.c * (double)t.e[var];
+    n.e[var] = (uint8_t)(t.e[var] - 1);
+    d.t.push_back(n);
+  }
+  return d;
+}
+
+static inline double eval_poly(const OrcPoly &p, const double v[5]) {
+  double sum = 0.0;
+  bool first = true;
+  for (const lentil_term &t : p.t) {
+    double term = t.c;
+    for (int i = 0; i < 5; i++) {
+      if (t.e[i] == 0) continue;
+      term = term * (t.e[i] == 1 ? v[i] : orc_lens_ipow(v[i], t.e[i]));
+    }
+    if (first) { sum = term; first = false; } else { sum = sum + term; }
+  }
+  return sum;
+}
+
+ORC_API OrcLens *orc_lens_create(const lentil_lens_table *tab) {
+  OrcLens *L = new OrcLens();
+  L->k = *tab;
+  L->k.terms = nullptr;
+  for (int i = 0; i < 5; i++)
+    L->out[i].t.assign(tab->terms + tab->out[i].first, tab->terms + tab->out[i].first + tab->out[i].count);
+  for (int i = 0; i < 4; i++)
+    L->ap[i].t.assign(tab->terms + tab->ap[i].first, tab->terms + tab->ap[i].first + tab->ap[i].count);
+  for (int i = 0; i < 2; i++)
+    for (int j = 0; j < 2; j++) {
+      L->dap[i][j] = derive(L->ap[i], 2 + j);
+      L->dout[i][j] = derive(L->out[2 + i], j);
+    }
+  return L;
+}
+ORC_API void orc_lens_destroy(OrcLens *L) { delete L; }
+
+ORC_API double orc_poly_eval(const OrcLens *L, int which, const double v[5]) {
+  /* which: 0-4 out, 5-8 ap, 9-12 dap[i][j], 13-16 dout[i][j] */
+  if (which < 5) return eval_poly(L->out[which], v);
+  if (which < 9) return eval_poly(L->ap[which - 5], v);
+  if (which < 13) return eval_poly(L->dap[(which - 9) / 2][(which - 9) % 2], v);
+  return eval_poly(L->dout[(which - 13) / 2][(which - 13) % 2], v);
+}
+
+/* 2x2 inverse exactly as the generated solvers write it (trace order [0][0],[1][1],[0][1],[1][0]) */
+ORC_API void orc_inv2x2(const double J[2][2], double inv[2][2], double *invdet_out) {
+  const double invdet = 1.0f / (J[0][0] * J[1][1] - J[0][1] * J[1][0]);
+  inv[0][0] = J[1][1] * invdet;
+  inv[1][1] = J[0][0] * invdet;
+  inv[0][1] = -J[0][1] * invdet;
+  inv[1][0] = -J[1][0] * invdet;
+  if (invdet_out) *invdet_out = invdet;
+}
+
+/* the two Newton update steps, separately callable for the writout.txt known answers */
+ORC_API void orc_newton_step(const double inv[2][2], const double delta[2], double damping,
+                             double *a, double *b) {
+  for (int i = 0; i < 2; i++) {
+    *a += damping * inv[0][i] * delta[i];
+    *b += damping * inv[1][i] * delta[i];
+  }
+}
+
+ORC_API int orc_newton_error_bits(double sqr_err, double prev_sqr_err, double sqr_ap_err,
+                                  double prev_sqr_ap_err, double out0, double out2, double out3) {
+  int error = 0;
+  if (sqr_err > prev_sqr_err) error |= 1;
+  if (sqr_ap_err > prev_sqr_ap_err) error |= 2;
+  if (out0 != out0) error |= 4;
+  if (out2 * out2 + out3 * out3 > 1.0) error |= 8;
+  return error;
+}
+
+static inline void pupil_to_cs(const lentil_lens_table &k, const double inpos[2], const double indir[2],
+                               double pos[3], double dir[3]) {
+  const double R = k.lens_outer_pupil_curvature_radius;
+  if (k.lens_outer_pupil_geometry == LENTIL_GEOM_CYL_Y) orc_cylinderToCs(inpos, indir, pos, dir, -R, R, 1);
+  else if (k.lens_outer_pupil_geometry == LENTIL_GEOM_CYL_X) orc_cylinderToCs(inpos, indir, pos, dir, -R, R, 0);
+  else orc_sphereToCs(inpos, indir, pos, dir, -R, R);
+}
+static inline void cs_to_pupil(const lentil_lens_table &k, const double inpos[3], const double indir[3],
+                               double pos[2], double dir[2]) {
+  const double R = k.lens_outer_pupil_curvature_radius;
+  if (k.lens_outer_pupil_geometry == LENTIL_GEOM_CYL_Y) orc_csToCylinder(inpos, indir, pos, dir, -R, R, 1);
+  else if (k.lens_outer_pupil_geometry == LENTIL_GEOM_CYL_X) orc_csToCylinder(inpos, indir, pos, dir, -R, R, 0);
+  else orc_csToSphere(inpos, indir, pos, dir, -R, R);
+}
+
+/* -------------------------------------------------------------------------------------
+ * a12 -- Camera::lens_lt_sample_aperture, src/lentil.h:1296-1313, with the generated body
+ * restated from tests/aperture_sampling_debug/writout.txt (all polynomials of one iteration
+ * are evaluated at the state the iteration *began* with -- "begin_x ... begin_lambda",
+ * writout.txt:13-17; aperture step undamped :19-24; outer-pupil step damped by 0.72 :33-39
+ * and newton-w4.py:45; error bits reset while k<10 :40; stop when both squared errors
+ * <= 1e-8, as in the converged trace ending at k=10 :302-333).
+ * `out` is in/out like the reference's Eigen::VectorXd &out (appendix C.7).
+ * ------------------------------------------------------------------------------------- */
+ORC_API double orc_lt_sample_aperture(const OrcLens *L, const double scene[3], const double ap[2],
+                                      double sensor[5], double out[5], double lambda,
+                                      int *iterations) {
+  const lentil_lens_table &k = L->k;
+  double x = 0, y = 0, dx = 0, dy = 0;
+  int error = 0;
+  const double eps = 1e-8;
+  double sqr_err = 1e30, sqr_ap_err = 1e30;
+  double prev_sqr_err = 1e32, prev_sqr_ap_err = 1e32;
+  int it = 0;
+  for (int kk = 0; kk < 100 && (sqr_err > eps || sqr_ap_err > eps) && error == 0; kk++) {
+    prev_sqr_err = sqr_err;
+    prev_sqr_ap_err = sqr_ap_err;
+    const double begin[5] = {x, y, dx, dy, lambda};
+    const double pred_ap[2] = {eval_poly(L->ap[0], begin), eval_poly(L->ap[1], begin)};
+    const double delta_ap[2] = {ap[0] - pred_ap[0], ap[1] - pred_ap[1]};
+    sqr_ap_err = delta_ap[0] * delta_ap[0] + delta_ap[1] * delta_ap[1];
+    double J[2][2], inv[2][2];
+    J[0][0] = eval_poly(L->dap[0][0], begin);
+    J[0][1] = eval_poly(L->dap[0][1], begin);
+    J[1][0] = eval_poly(L->dap[1][0], begin);
+    J[1][1] = eval_poly(L->dap[1][1], begin);
+    orc_inv2x2(J, inv, nullptr);
+    for (int i = 0; i < 2; i++) {
+      dx += inv[0][i] * delta_ap[i];
+      dy += inv[1][i] * delta_ap[i];
+    }
+    out[0] = eval_poly(L->out[0], begin);
+    out[1] = eval_poly(L->out[1], begin);
+    out[2] = eval_poly(L->out[2], begin);
+    out[3] = eval_poly(L->out[3], begin);
+    double pos[3], dir[3];
+    pupil_to_cs(k, out, out + 2, pos, dir);
+    double view[3] = {scene[0] - pos[0], scene[1] - pos[1], scene[2] - pos[2]};
+    orc_normalise(view);
+    double out_new[4];
+    cs_to_pupil(k, pos, view, out_new, out_new + 2);
+    const double delta_out[2] = {out_new[2] - out[2], out_new[3] - out[3]};
+    sqr_err = delta_out[0] * delta_out[0] + delta_out[1] * delta_out[1];
+    J[0][0] = eval_poly(L->dout[0][0], begin);
+    J[0][1] = eval_poly(L->dout[0][1], begin);
+    J[1][0] = eval_poly(L->dout[1][0], begin);
+    J[1][1] = eval_poly(L->dout[1][1], begin);
+    orc_inv2x2(J, inv, nullptr);
+    for (int i = 0; i < 2; i++) {
+      x += 0.72 * inv[0][i] * delta_out[i];
+      y += 0.72 * inv[1][i] * delta_out[i];
+    }
+    error |= orc_newton_error_bits(sqr_err, prev_sqr_err, sqr_ap_err, prev_sqr_ap_err, out[0], out[2], out[3]);
+    if (kk < 10) error = 0;
+    it = kk + 1;
+  }
+  if (out[0] * out[0] + out[1] * out[1] > k.lens_outer_pupil_radius * k.lens_outer_pupil_radius) error |= 16;
+  if (error == 0) {
+    const double begin[5] = {x, y, dx, dy, lambda};
+    out[4] = eval_poly(L->out[4], begin);
+  } else {
+    out[4] = 0.0f;
+  }
+  if (iterations) *iterations = it;
+  sensor[0] = x; sensor[1] = y; sensor[2] = dx; sensor[3] = dy; sensor[4] = lambda;  /* lentil.h:1311 */
+  return std::max(0.0, out[4]);                                                     /* lentil.h:1312 */
+}
+
+/* a13 -- Camera::lens_evaluate, src/lentil.h:1257-1266 */
+ORC_API double orc_lens_evaluate(const OrcLens *L, const double in[5], double out[5]) {
+  for (int i = 0; i < 4; i++) out[i] = eval_poly(L->out[i], in);
+  const double t = eval_poly(L->out[4], in);
+  return std::max(0.0, t);
+}
+
+/* a13 -- Camera::lens_pt_sample_aperture, src/lentil.h:1272-1291; body restated from the
+ * polynomial-optics generator (<=5 Newton steps on the aperture position, tolerance 1e-4).
+ * PARITY UNPINNED.  in/out are [x,y,dx,dy,lambda]; solves in[2..3]. */
+ORC_API void orc_pt_sample_aperture(const OrcLens *L, double in[5], double out[5], double dist) {
+  double out_x = out[0], out_y = out[1], out_dx = out[2], out_dy = out[3];
+  double x = in[0], y = in[1], dx = in[2], dy = in[3], lambda = in[4];
+  double pred_x, pred_y, pred_dx = 0, pred_dy = 0;
+  double sqr_err = 3.4028234663852886e38;
+  for (int k = 0; k < 5 && sqr_err > 1e-4; k++) {
+    const double begin[5] = {x + dist * dx, y + dist * dy, dx, dy, lambda};
+    pred_x = eval_poly(L->ap[0], begin);
+    pred_y = eval_poly(L->ap[1], begin);
+    pred_dx = eval_poly(L->ap[2], begin);
+    pred_dy = eval_poly(L->ap[3], begin);
+    /* the Jacobian wrt (dx,dy) includes the dist*d/dx chain term of the shifted start point */
+    double J[2][2], inv[2][2];
+    for (int i = 0; i < 2; i++)
+      for (int j = 0; j < 2; j++) {
+        OrcPoly dpos = derive(L->ap[i], j);
+        J[i][j] = eval_poly(L->dap[i][j], begin) + dist * eval_poly(dpos, begin);
+      }
+    orc_inv2x2(J, inv, nullptr);
+    const double dx1[2] = {out_x - pred_x, out_y - pred_y};
+    for (int i = 0; i < 2; i++) {
+      dx += inv[0][i] * dx1[i];
+      dy += inv[1][i] * dx1[i];
+    }
+    sqr_err = dx1[0] * dx1[0] + dx1[1] * dx1[1];
+  }
+  out_dx = pred_dx;
+  out_dy = pred_dy;
+  out[0] = out_x; out[1] = out_y; out[2] = out_dx; out[3] = out_dy;
+  in[0] = x; in[1] = y; in[2] = dx; in[3] = dy;
+}
+
+/* =====================================================================================
+ * a7/a8 -- imageData, src/imagebokeh.h:143-412
+ * ===================================================================================== */
+struct OrcBokeh {
+  int x = 0, y = 0;
+  std::vector<float> cdfRow, cdfColumn;
+  std::vector<int> rowIndices, columnIndices;
+};
+
+namespace {
+struct arrayCompare {                                           /* src/imagebokeh.h:21-27 */
+  const float *values;
+  explicit arrayCompare(const float *v) : values(v) {}
+  bool operator()(int l, int r) const { return values[l] > values[r]; }
+};
+}
+
+/* bokehProbability, src/imagebokeh.h:143-338; pixelData = x*y*nchannels floats */
+ORC_API OrcBokeh *orc_bokeh_create(const float *pixelData, int x, int y, int nchannels) {
+  if (!(x * y * nchannels > 0 && nchannels >= 3) || x != y) return nullptr;
+  OrcBokeh *B = new OrcBokeh();
+  B->x = x; B->y = y;
+  const int npixels = x * y;
+  const int o1 = (nchannels >= 2 ? 1 : 0);
+  const int o2 = (nchannels >= 3 ? 2 : o1);
+  std::vector<float> pixelValues(npixels), normalized(npixels), summedRow(y), perRow(npixels);
+  float totalValue = 0.0f;
+  for (int i = 0, j = 0; i < npixels; ++i, j += nchannels) {
+    pixelValues[i] = pixelData[j] * 0.3f + pixelData[j + o1] * 0.59f + pixelData[j + o2] * 0.11f;
+    totalValue += pixelValues[i];
+  }
+  float invTotalValue = 1.0f / totalValue;
+  for (int i = 0; i < npixels; ++i) normalized[i] = pixelValues[i] * invTotalValue;
+  for (int i = 0, k = 0; i < y; ++i) {
+    summedRow[i] = 0.0f;
+    for (int j = 0; j < x; ++j, ++k) summedRow[i] += normalized[k];
+  }
+  B->rowIndices.resize(y);
+  for (int i = 0; i < y; ++i) B->rowIndices[i] = i;
+  std::sort(B->rowIndices.begin(), B->rowIndices.end(), arrayCompare(summedRow.data()));
+  B->cdfRow.resize(y);
+  float prevVal = 0.0f;
+  for (int i = 0; i < y; ++i) {
+    B->cdfRow[i] = prevVal + summedRow[B->rowIndices[i]];
+    prevVal = B->cdfRow[i];
+  }
+  for (int r = 0, i = 0; r < y; ++r)
+    for (int c = 0; c < x; ++c, ++i) {
+      if ((normalized[i] != 0) && (summedRow[r] != 0)) perRow[i] = normalized[i] / summedRow[r];
+      else perRow[i] = 0;
+    }
+  B->columnIndices.resize(npixels);
+  for (int i = 0; i < npixels; i++) B->columnIndices[i] = i;
+  for (int i = 0; i < npixels; i += x)
+    std::sort(B->columnIndices.begin() + i, B->columnIndices.begin() + i + x, arrayCompare(perRow.data()));
+  B->cdfColumn.resize(npixels);
+  for (int r = 0, i = 0; r < y; ++r) {
+    prevVal = 0.0f;
+    for (int c = 0; c < x; ++c, ++i) {
+      B->cdfColumn[i] = prevVal + perRow[B->columnIndices[i]];
+      prevVal = B->cdfColumn[i];
+    }
+  }
+  return B;
+}
+ORC_API OrcBokeh *orc_bokeh_from_tables(const lentil_bokeh_table *t) {
+  OrcBokeh *B = new OrcBokeh();
+  B->x = t->x; B->y = t->y;
+  B->cdfRow.assign(t->cdfRow, t->cdfRow + t->y);
+  B->rowIndices.assign(t->rowIndices, t->rowIndices + t->y);
+  B->cdfColumn.assign(t->cdfColumn, t->cdfColumn + (size_t)t->x * t->y);
+  B->columnIndices.assign(t->columnIndices, t->columnIndices + (size_t)t->x * t->y);
+  return B;
+}
+ORC_API void orc_bokeh_destroy(OrcBokeh *B) { delete B; }
+ORC_API void orc_bokeh_tables(const OrcBokeh *B, float *cdfRow, int *rowIndices, float *cdfColumn,
+                              int *columnIndices) {
+  memcpy(cdfRow, B->cdfRow.data(), sizeof(float) * B->y);
+  memcpy(rowIndices, B->rowIndices.data(), sizeof(int) * B->y);
+  memcpy(cdfColumn, B->cdfColumn.data(), sizeof(float) * B->x * B->y);
+  memcpy(columnIndices, B->columnIndices.data(), sizeof(int) * B->x * B->y);
+}
+
+/* bokehSample, src/imagebokeh.h:341-412 (stratification inputs unused, :407-411) */
+ORC_API void orc_bokeh_sample(const OrcBokeh *B, float randomNumberRow, float randomNumberColumn,
+                              double lens[2]) {
+  const int x = B->x, y = B->y;
+  const float *cdfRow = B->cdfRow.data();
+  const float *cdfColumn = B->cdfColumn.data();
+  const float *pUpperBound = std::upper_bound(cdfRow, cdfRow + y, randomNumberRow);
+  int r = 0;
+  pUpperBound >= (cdfRow + y) ? r = y - 1 : r = static_cast<int>(pUpperBound - cdfRow);
+  int actualPixelRow = B->rowIndices[r];
+  int recalulatedPixelRow = actualPixelRow - ((x - 1) / 2);
+  int startPixel = actualPixelRow * x;
+  const float *pUpperBoundColumn =
+      std::upper_bound(cdfColumn + startPixel, cdfColumn + startPixel + x, randomNumberColumn);
+  int c = 0;
+  pUpperBoundColumn >= cdfColumn + startPixel + x ? c = startPixel + x - 1
+                                                  : c = static_cast<int>(pUpperBoundColumn - cdfColumn);
+  int actualPixelColumn = B->columnIndices[c];
+  int relativePixelColumn = actualPixelColumn - startPixel;
+  int recalulatedPixelColumn = relativePixelColumn - ((y - 1) / 2);
+  float flippedRow = static_cast<float>(recalulatedPixelColumn);
+  float flippedColumn = recalulatedPixelRow * -1.0f;
+  lens[0] = static_cast<float>(flippedRow) / static_cast<float>(x) * 2.0;
+  lens[1] = static_cast<float>(flippedColumn) / static_cast<float>(y) * 2.0;
+}
+
+/* =====================================================================================
+ * a11 -- aperture draw + Camera::trace_ray_bw_po, src/lentil.h:573-661
+ * GCC evaluates the rng(seed) arguments right to left:
+ *   bokehSample(rng#4, rng#3, disk, rng#2, rng#1);  concentric_disk_sample(rng#2, rng#1, ...)
+ *   lens_sample_triangular_aperture(.., r1 = rng#2, r2 = rng#1, ...)
+ * ===================================================================================== */
+ORC_API void orc_po_aperture_sample(const lentil_params *P, const OrcBokeh *B, uint32_t seed_a,
+                                    uint32_t seed_b, double aperture[2]) {
+  if (!P->enable_dof) { aperture[0] = aperture[1] = 0.0; return; }
+  uint32_t seed = orc_tea8(seed_a, seed_b);
+  if (P->bokeh_aperture_blades <= 2) {
+    double unit_disk[2] = {0.0, 0.0};
+    if (P->bokeh_enable_image) {
+      const float d1 = orc_rng(&seed), d2 = orc_rng(&seed), d3 = orc_rng(&seed), d4 = orc_rng(&seed);
+      (void)d1; (void)d2;
+      orc_bokeh_sample(B, d4, d3, unit_disk);
+    } else {
+      const float d1 = orc_rng(&seed), d2 = orc_rng(&seed);
+      orc_concentric_disk_sample(d2, d1, unit_disk);
+    }
+    aperture[0] = unit_disk[0] * P->aperture_radius;
+    aperture[1] = unit_disk[1] * P->aperture_radius;
+  } else {
+    const float d1 = orc_rng(&seed), d2 = orc_rng(&seed);
+    orc_triangular_aperture(&aperture[0], &aperture[1], d2, d1, P->aperture_radius,
+                            P->bokeh_aperture_blades);
+  }
+}
+
+ORC_API int orc_trace_ray_bw_po(const lentil_params *P, const OrcLens *L, const OrcBokeh *B,
+                                const double target[3], double sensor_position[2], int px, int py,
+                                int total_samples_taken, float lambda_in, int *tries_out) {
+  int tries = 0;
+  bool ray_succes = false;
+  double sensor[5] = {0, 0, 0, 0, lambda_in};
+  double out[5] = {0, 0, 0, 0, lambda_in};
+  double aperture[2] = {0, 0};
+  while (ray_succes == false && tries <= P->vignetting_retries) {
+    if (!P->enable_dof) aperture[0] = aperture[1] = 0.0;
+    else orc_po_aperture_sample(P, B, (uint32_t)(px * py + px), (uint32_t)(total_samples_taken + tries), aperture);
+    /* AiTraceProbe == false (SURVEY section 7 "Occlusion probe"), src/lentil.h:613-629 */
+    sensor[0] = sensor[1] = 0.0;
+    float transmittance = orc_lt_sample_aperture(L, target, aperture, sensor, out, lambda_in, nullptr);
+    if (transmittance <= 0) { ++tries; continue; }
+    const double ipx = sensor[0] + sensor[2] * L->k.lens_back_focal_length;
+    const double ipy = sensor[1] + sensor[3] * L->k.lens_back_focal_length;
+    if (ipx * ipx + ipy * ipy > L->k.lens_inner_pupil_radius * L->k.lens_inner_pupil_radius) { ++tries; continue; }
+    ray_succes = true;
+  }
+  if (tries_out) *tries_out = tries;
+  if (!ray_succes) return 0;
+  sensor[0] += sensor[2] * -P->sensor_shift;
+  sensor[1] += sensor[3] * -P->sensor_shift;
+  sensor_position[0] = sensor[0];
+  sensor_position[1] = sensor[1];
+  return 1;
+}
+
+/* =====================================================================================
+ * a3/a4/a5 -- scalar helpers of the visit prologue
+ * ===================================================================================== */
+ORC_API float orc_get_coc_thinlens(const lentil_params *P, float z_cs) {   /* src/lentil.h:674-692 */
+  float _focus_distance = P->focus_distance;
+  float _aperture_radius = P->aperture_radius;
+  if (P->cameraType == LENTIL_POLYNOMIAL_OPTICS) _focus_distance /= 10.0;
+  else _aperture_radius *= 10.0;
+  const float focal_length = P->focal_length;
+  const float image_dist_samplepos = (-focal_length * z_cs) / (-focal_length + z_cs);
+  const float image_dist_focusdist = (-focal_length * -_focus_distance) / (-focal_length + -_focus_distance);
+  return std::abs((_aperture_radius * (image_dist_samplepos - image_dist_focusdist)) / image_dist_samplepos);
+}
+
+ORC_API float orc_additional_luminance_soft_trans(const lentil_params *P, float sample_luminance) { /* lentil.h:1128-1138 */
+  const double lo = P->bidir_add_energy_minimum_luminance;
+  const float tr = P->bidir_add_energy_transition;
+  if (sample_luminance > lo && sample_luminance < lo + tr) {
+    float perc = (sample_luminance - lo) / tr;
+    return P->bidir_add_energy * perc;
+  } else if (sample_luminance > lo + tr) {
+    return P->bidir_add_energy;
+  }
+  return 0.0;
+}
+
+/* draw count, src/lentil_filter.cpp:177-202 */
+ORC_API int orc_draw_count(const lentil_params *P, float sample_luminance, float circle_of_confusion,
+                           float inverse_sample_density) {
+  float luminance_mult = std::max(0.0, std::pow(std::min(sample_luminance, 20.0f), 0.5) * P->bidir_sample_mult);
+  const float coc_squared_pixels = std::pow(circle_of_confusion * P->yres, 2) * std::pow(luminance_mult, 2) * 0.00001;
+  int samples = std::ceil(coc_squared_pixels * inverse_sample_density);
+  samples = clampf(samples, 4, 2000);
+  if (P->samples_override > 0) samples = P->samples_override;     /* bench extension, not in the reference */
+  return samples;
+}
+
+/* AiM4PointByMatrixMult (SDK, recalled): row-vector convention */
+static inline void m4_point(const float m[4][4], const float p[3], float o[3]) {
+  o[0] = p[0] * m[0][0] + p[1] * m[1][0] + p[2] * m[2][0] + m[3][0];
+  o[1] = p[0] * m[0][1] + p[1] * m[1][1] + p[2] * m[2][1] + m[3][1];
+  o[2] = p[0] * m[0][2] + p[1] * m[1][2] + p[2] * m[2][2] + m[3][2];
+}
+/* AiV3Normalize / AiV3Length (SDK, recalled) */
+static inline float v3len(const float v[3]) { return sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]); }
+static inline void v3norm(const float v[3], float o[3]) {
+  float t = v3len(v);
+  if (t != 0) t = 1 / t;
+  o[0] = v[0] * t; o[1] = v[1] * t; o[2] = v[2] * t;
+}
+
+/* =====================================================================================
+ * The frame: buffers of Camera::setup_filter (src/lentil.h:1096-1121) and the whole
+ * filter_pixel visit loop (src/lentil_filter.cpp:91-451) over a visit stream.
+ * ===================================================================================== */
+struct OrcFrame {
+  uint32_t xres, yres, n_aovs;
+  uint8_t kind[LENTIL_MAX_AOVS];
+  std::vector<float> buffer[LENTIL_MAX_AOVS];   /* AOVData::buffer, RGBA */
+  std::vector<float> weight;                    /* filter_weight_buffer */
+  std::vector<float> zbuffer;
+  std::vector<double> buffer64[LENTIL_MAX_AOVS];/* fp64 shadow accumulation (tolerance studies) */
+  std::vector<double> weight64;
+  lentil_counters ctr;
+  std::vector<lentil_draw_record> log;
+  bool keep_log = false;
+};
+
+ORC_API OrcFrame *orc_frame_create(uint32_t xres, uint32_t yres, uint32_t n_aovs, const uint8_t *kind,
+                                   int keep_log) {
+  OrcFrame *F = new OrcFrame();
+  F->xres = xres; F->yres = yres; F->n_aovs = n_aovs;
+  const size_t np = (size_t)xres * yres;
+  for (uint32_t a = 0; a < n_aovs; a++) {
+    F->kind[a] = kind ? kind[a] : LENTIL_FILTER_GAUSSIAN;
+    F->buffer[a].assign(np * 4, 0.0f);
+    F->buffer64[a].assign(np * 4, 0.0);
+  }
+  F->weight.assign(np, 0.0f);
+  F->weight64.assign(np, 0.0);
+  F->zbuffer.assign(np, 0.0f);
+  memset(&F->ctr, 0, sizeof(F->ctr));
+  F->keep_log = keep_log != 0;
+  return F;
+}
+ORC_API void orc_frame_destroy(OrcFrame *F) { delete F; }
+ORC_API const float *orc_frame_buffer(const OrcFrame *F, uint32_t aov) { return F->buffer[aov].data(); }
+ORC_API const float *orc_frame_weight(const OrcFrame *F) { return F->weight.data(); }
+ORC_API const double *orc_frame_buffer64(const OrcFrame *F, uint32_t aov) { return F->buffer64[aov].data(); }
+ORC_API const double *orc_frame_weight64(const OrcFrame *F) { return F->weight64.data(); }
+ORC_API void orc_frame_counters(const OrcFrame *F, lentil_counters *c) { *c = F->ctr; }
+ORC_API uint64_t orc_frame_log(const OrcFrame *F, lentil_draw_record *out, uint64_t cap) {
+  uint64_t n = std::min<uint64_t>(cap, F->log.size());
+  if (out && n) memcpy(out, F->log.data(), n * sizeof(lentil_draw_record));
+  return F->log.size();
+}
+ORC_API void orc_frame_merge(OrcFrame *dst, const OrcFrame *src) {   /* per-thread private buffers summed */
+  for (uint32_t a = 0; a < dst->n_aovs; a++)
+    for (size_t i = 0; i < dst->buffer[a].size(); i++) dst->buffer[a][i] += src->buffer[a][i];
+  for (size_t i = 0; i < dst->weight.size(); i++) dst->weight[i] += src->weight[i];
+  dst->ctr.visits += src->ctr.visits;
+  dst->ctr.redistributed_visits += src->ctr.redistributed_visits;
+  dst->ctr.attempted_draws += src->ctr.attempted_draws;
+  dst->ctr.accepted_draws += src->ctr.accepted_draws;
+}
+
+/* Camera::add_to_buffer, src/lentil.h:823-851 (rgb_weight is white on this path) */
+static inline void add_to_buffer(OrcFrame *F, uint32_t aov, uint32_t px, const float value[4],
+                                 float add_energy, float depth, float filter_weight) {
+  if (F->kind[aov] == LENTIL_FILTER_GAUSSIAN) {
+    if (aov == 0) { F->weight[px] += filter_weight; F->weight64[px] += (double)filter_weight; }
+    for (int c = 0; c < 4; c++) {
+      const float add = (value[c] + add_energy) * filter_weight * 1.0f;
+      F->buffer[aov][(size_t)px * 4 + c] += add;
+      F->buffer64[aov][(size_t)px * 4 + c] += (double)add;
+    }
+  } else if (F->kind[aov] == LENTIL_FILTER_CLOSEST) {
+    if ((std::abs(depth) <= F->zbuffer[px]) || F->zbuffer[px] == 0.0) {
+      for (int c = 0; c < 4; c++) {
+        F->buffer[aov][(size_t)px * 4 + c] = value[c];
+        F->buffer64[aov][(size_t)px * 4 + c] = value[c];
+      }
+      F->zbuffer[px] = std::abs(depth);
+    }
+  }
+}
+
+static inline float maxrgb(const float *c) { return std::max(std::max(c[0], c[1]), c[2]); }  /* AiColorMaxRGB */
+
+/* One visit of filter_pixel's loop body, src/lentil_filter.cpp:105-448. */
+static void do_visit(const lentil_params *P, const OrcLens *L, const OrcBokeh *B, OrcFrame *F,
+                     const lentil_visits *V, uint64_t v, int px, int py, float inverse_sample_density) {
+  const double xres = (double)P->xres, yres = (double)P->yres;
+  const double frame_aspect_ratio_without_region = (double)P->xres_without_region / (double)P->yres_without_region;
+  bool redistribute = true;
+  if (P->adaptive_sampling) { if (inverse_sample_density > 0.2) redistribute = false; }   /* :108-113 */
+
+  float sample[4] = {V->rgba[v * 4], V->rgba[v * 4 + 1], V->rgba[v * 4 + 2], V->rgba[v * 4 + 3]};
+  float sample_pos_ws[3] = {V->pos_z[v * 4], V->pos_z[v * 4 + 1], V->pos_z[v * 4 + 2]};
+  double depth = V->pos_z[v * 4 + 3];
+  const float *raydir = &V->raydir_time[v * 4];
+  const bool small = std::abs(sample_pos_ws[0]) < AI_EPSILON_F && std::abs(sample_pos_ws[1]) < AI_EPSILON_F &&
+                     std::abs(sample_pos_ws[2]) < AI_EPSILON_F;      /* AiV3IsSmall */
+  if ((depth == AI_INFINITE_F || small) && P->enable_skydome) {       /* :122-129 */
+    if (raydir[0] == 0 && raydir[1] == 0 && raydir[2] == 0) redistribute = false;
+    else for (int i = 0; i < 3; i++) sample_pos_ws[i] = raydir[i] * (float)99999999.0;  /* AtVector * float */
+  }
+  if ((depth == AI_INFINITE_F || small) && !P->enable_skydome) redistribute = false;   /* :130-133 */
+  if (maxrgb(&V->volume_ignore[v * 4]) > 0.0) redistribute = false;                 /* :135-137 */
+
+  float cs[3];
+  m4_point(P->world_to_camera, sample_pos_ws, cs);                                  /* :144 */
+  switch (P->unitModel) {                                                           /* :145-150 */
+    /* AtVector::operator*=(float): the double literals narrow to float at the call */
+    case LENTIL_UNIT_MM: for (int i = 0; i < 3; i++) cs[i] *= 0.1f; break;
+    case LENTIL_UNIT_CM: for (int i = 0; i < 3; i++) cs[i] *= 1.0f; break;
+    case LENTIL_UNIT_DM: for (int i = 0; i < 3; i++) cs[i] *= 10.0f; break;
+    case LENTIL_UNIT_M: for (int i = 0; i < 3; i++) cs[i] *= 100.0f; break;
+  }
+  const float *tr = &V->transmission[v * 4];
+  bool transmitted = P->enable_bidir_transmission ? false : (maxrgb(tr) > 0.0);     /* :152-159 */
+  if (transmitted) { sample[0] -= tr[0]; sample[1] -= tr[1]; sample[2] -= tr[2]; redistribute = false; }
+  const float sample_luminance = (sample[0] + sample[1] + sample[2]) / 3.0;         /* :161 */
+  if (V->volume_ignore[v * 4 + 3] > 0.0) redistribute = false;                      /* :162-164 */
+
+  float fitted_bidir_add_energy = 0.0;                                              /* :173-174 */
+  if (P->bidir_add_energy > 0.0) fitted_bidir_add_energy = orc_additional_luminance_soft_trans(P, sample_luminance);
+
+  float circle_of_confusion = orc_get_coc_thinlens(P, cs[2]);                       /* :178 */
+  if (circle_of_confusion < 0.4f) redistribute = false;                             /* :183-187 */
+  int samples = orc_draw_count(P, sample_luminance, circle_of_confusion, inverse_sample_density);
+  float inv_samples = 1.0 / static_cast<float>(samples);                            /* :199 */
+  unsigned int total_samples_taken = 0;
+  unsigned int max_total_samples = samples * 5;
+
+  /* aov_values, :206-234 -- AOV 0 is RGBA (the possibly transmission-reduced `sample` is NOT what is
+   * stored: the reference re-reads the RGBA AOV through AiAOVSampleIteratorGetAOVRGBA, :216) */
+  float aov_values[LENTIL_MAX_AOVS][4];
+  for (int c = 0; c < 4; c++) aov_values[0][c] = V->rgba[v * 4 + c];
+  for (uint32_t a = 1; a < F->n_aovs; a++)
+    for (int c = 0; c < 4; c++) aov_values[a][c] = V->extra[a - 1][v * 4 + c];
+
+  if (P->cameraType == LENTIL_POLYNOMIAL_OPTICS)
+    if (std::abs(cs[2]) < (L->k.lens_length * 0.1)) redistribute = false;           /* :240 */
+
+  F->ctr.visits++;
+  if (!redistribute) {                                                              /* :243-246 / :306-309 */
+    const uint32_t pixelnumber = P->xres * py + px;                                 /* lentil.h:945 */
+    for (uint32_t a = 0; a < F->n_aovs; a++)
+      add_to_buffer(F, a, pixelnumber, aov_values[a], 0.0, depth, 1.0f * inverse_sample_density);
+    return;
+  }
+  F->ctr.redistributed_visits++;
+
+  if (P->cameraType == LENTIL_POLYNOMIAL_OPTICS) {
+    for (int count = 0; count < samples && total_samples_taken < max_total_samples; ++count, ++total_samples_taken) {
+      double sensor_position[2] = {0, 0};
+      const double target[3] = {-(double)cs[0] * 10.0, -(double)cs[1] * 10.0, -(double)cs[2] * 10.0};  /* :271 */
+      F->ctr.attempted_draws++;
+      if (!orc_trace_ray_bw_po(P, L, B, target, sensor_position, px, py, (int)total_samples_taken,
+                               P->lambda_bw, nullptr)) { --count; continue; }
+      const double s0 = sensor_position[0] / (P->sensor_width * 0.5);                                   /* :276 */
+      const double s1 = sensor_position[1] / (P->sensor_width * 0.5) * frame_aspect_ratio_without_region;
+      const double pixel0 = (((s0 + 1.0) / 2.0) * P->xres_without_region) - P->region_min_x;            /* :277-278 */
+      const double pixel1 = (((-s1 + 1.0) / 2.0) * P->yres_without_region) - P->region_min_y;
+      if ((pixel0 >= xres) || (pixel0 < 0) || (pixel1 >= yres) || (pixel1 < 0) || (pixel0 != pixel0) ||
+          (pixel1 != pixel1)) { --count; continue; }                                                    /* :282-287 */
+      const int ix = floor(pixel0), iy = floor(pixel1);
+      const unsigned pixelnumber = ix + (iy * P->xres);                                                 /* :290, lentil.h:958-960 */
+      for (uint32_t a = 0; a < F->n_aovs; a++)                                                          /* :295-298 */
+        add_to_buffer(F, a, pixelnumber, aov_values[a], fitted_bidir_add_energy, depth,
+                      1.0f * inverse_sample_density * inv_samples);
+      F->ctr.accepted_draws++;
+      if (F->keep_log) F->log.push_back({(uint32_t)v, total_samples_taken, pixelnumber});
+    }
+    return;
+  }
+
+  /* ---- ThinLens, src/lentil_filter.cpp:303-447 (abb_coma == 0 and abb_chromatic == 0 only:
+   * coma goes through Eigen AngleAxisd and chromatic through the global xor128 state) ---- */
+  for (int count = 0; count < samples && total_samples_taken < max_total_samples; ++count, ++total_samples_taken) {
+    F->ctr.attempted_draws++;
+    unsigned int seed = orc_tea8((uint32_t)(px * py + px), total_samples_taken);
+    const float focal_length = P->focal_length;
+    float image_dist_samplepos = (-focal_length * cs[2]) / (-focal_length + cs[2]);
+    double unit_disk[2] = {0, 0};
+    if (P->bokeh_enable_image) {
+      const float d1 = orc_rng(&seed), d2 = orc_rng(&seed), d3 = orc_rng(&seed), d4 = orc_rng(&seed);
+      (void)d1; (void)d2;
+      orc_bokeh_sample(B, d4, d3, unit_disk);
+    } else if (P->bokeh_aperture_blades < 2) {
+      const float d1 = orc_rng(&seed), d2 = orc_rng(&seed);
+      orc_concentricDiskSample(d2, d1, unit_disk, P->abb_spherical, P->circle_to_square);
+    } else {
+      const float d1 = orc_rng(&seed), d2 = orc_rng(&seed);
+      orc_triangular_aperture(&unit_disk[0], &unit_disk[1], d2, d1, 1.0, P->bokeh_aperture_blades);
+    }
+    unit_disk[0] *= P->bokeh_anamorphic;                                                    /* :322 */
+    const float lens[3] = {(float)(unit_disk[0] * P->aperture_radius), (float)(unit_disk[1] * P->aperture_radius), 0.0f};
+    float dir_from_center[3];
+    v3norm(cs, dir_from_center);                                                            /* :327 */
+    /* abb_coma == 0: the rotation is exactly the identity, so dir_lens_to_P := dir_from_center (:333-334) */
+    float dir_lens_to_P[3] = {dir_from_center[0], dir_from_center[1], dir_from_center[2]};
+    const float len = v3len(cs);
+    float perturbed[3] = {len * dir_lens_to_P[0], len * dir_lens_to_P[1], len * dir_lens_to_P[2]};   /* :336 */
+    v3norm(perturbed, dir_from_center);                                                     /* :337 */
+    float samplepos_image_intersection = std::abs(image_dist_samplepos / dir_from_center[2]);
+    float samplepos_image_point[3] = {dir_from_center[0] * samplepos_image_intersection,
+                                      dir_from_center[1] * samplepos_image_intersection,
+                                      dir_from_center[2] * samplepos_image_intersection};
+    float tmp[3] = {samplepos_image_point[0] - lens[0], samplepos_image_point[1] - lens[1], samplepos_image_point[2] - lens[2]};
+    float dir_from_lens_to_image_sample[3];
+    v3norm(tmp, dir_from_lens_to_image_sample);                                             /* :344 */
+    /* probe == false (:356-375) */
+    if (P->optical_vignetting_distance > 0.0) {                                             /* :379-386, lens.h:529-543 */
+      float t2[3] = {perturbed[0] - lens[0], perturbed[1] - lens[1], perturbed[2] - lens[2]};
+      v3norm(t2, dir_lens_to_P);
+      const float squarebias = 1.0 + std::log(1.0 + P->circle_to_square) * std::exp(P->circle_to_square * 3.0);
+      float intersection = std::abs(P->optical_vignetting_distance / dir_lens_to_P[2]);
+      float ovx = dir_lens_to_P[0] * intersection - lens[0];
+      float ovy = dir_lens_to_P[1] * intersection - lens[1];
+      float power = 1.0 + squarebias;
+      float radius = (float)P->aperture_radius * P->optical_vignetting_radius;
+      float dist = std::pow(std::abs(ovx), power) + std::pow(std::abs(ovy), power);
+      if (dist > std::pow(radius, power)) { --count; continue; }
+    }
+    const float image_dist_focusdist = (-focal_length * -P->focus_distance) / (-focal_length + -P->focus_distance); /* lentil.h:665-667 */
+    float focusdist_intersection = std::abs(image_dist_focusdist / dir_from_lens_to_image_sample[2]);     /* :389 */
+    float fip[3] = {lens[0] + dir_from_lens_to_image_sample[0] * focusdist_intersection,
+                    lens[1] + dir_from_lens_to_image_sample[1] * focusdist_intersection,
+                    lens[2] + dir_from_lens_to_image_sample[2] * focusdist_intersection};               /* :409 */
+    float sp[2] = {fip[0] / fip[2], fip[1] / fip[2]};                                                     /* :413-414 */
+    /* AtVector2::operator/=(float) multiplies by 1.0f/f (SDK, recalled) */
+    const float div = (P->sensor_width * 0.5) / -focal_length;                                            /* :416 */
+    { const float inv = 1.0f / div; sp[0] *= inv; sp[1] *= inv; }
+    if (P->abb_distortion > 0.0) {                                                                        /* :420, lens.h:550-559 */
+      float b = P->abb_distortion;
+      float l = sqrtf(sp[0] * sp[0] + sp[1] * sp[1]);
+      float x0 = std::pow(9. * b * b * l + std::sqrt(3.) * std::sqrt(27. * b * b * b * b * l * l + 4. * b * b * b), 1. / 3.);
+      float xx = x0 / (std::pow(2., 1. / 3.) * std::pow(3., 2. / 3.) * b) - std::pow(2. / 3., 1. / 3.) / x0;
+      sp[0] = sp[0] * (xx / l); sp[1] = sp[1] * (xx / l);
+    }
+    const double s0 = sp[0], s1 = sp[1] * frame_aspect_ratio_without_region;                              /* :424 */
+    const float pixel_x = (((s0 + 1.0) / 2.0) * P->xres_without_region) - P->region_min_x;               /* :425-426 */
+    const float pixel_y = (((-s1 + 1.0) / 2.0) * P->yres_without_region) - P->region_min_y;
+    if ((pixel_x >= xres) || (pixel_x < 0) || (pixel_y >= yres) || (pixel_y < 0)) { --count; continue; }  /* :429-432 */
+    const int ix = floor(pixel_x), iy = floor(pixel_y);
+    const unsigned pixelnumber = ix + (iy * P->xres);                                                     /* :434 */
+    for (uint32_t a = 0; a < F->n_aovs; a++)                                                              /* :442-445 */
+      add_to_buffer(F, a, pixelnumber, aov_values[a], fitted_bidir_add_energy, depth,
+                    1.0f * inverse_sample_density * inv_samples);
+    F->ctr.accepted_draws++;
+    if (F->keep_log) F->log.push_back({(uint32_t)v, total_samples_taken, pixelnumber});
+  }
+}
+
+/* visit -> source pixel (see lentil_visits in include/lentil_hip.h) */
+static inline void visit_pixel(const lentil_visits *V, uint64_t v, int *px, int *py) {
+  if (V->visits_per_pixel) {
+    const uint64_t p = v / V->visits_per_pixel;
+    *px = V->pixel_x0 + (int)(p % V->pixels_per_row);
+    *py = V->pixel_y0 + (int)(p / V->pixels_per_row) * (int)V->pixel_row_stride;
+  } else {
+    *px = (int)(V->pixel[v] & 0xFFFFu);
+    *py = (int)(V->pixel[v] >> 16);
+  }
+}
+
+/* Runs visits [v_begin, v_end) in order.  Returns 0, or LENTIL_ERR_UNSUPPORTED. */
+ORC_API int orc_redistribute(const lentil_params *P, const OrcLens *L, const OrcBokeh *B, OrcFrame *F,
+                             const lentil_visits *V, uint64_t v_begin, uint64_t v_end) {
+  if (P->cameraType == LENTIL_THINLENS && (P->abb_coma != 0.0f || P->abb_chromatic > 0.0f)) return LENTIL_ERR_UNSUPPORTED;
+  if (P->cameraType == LENTIL_POLYNOMIAL_OPTICS && (P->abb_chromatic > 0.0f || !L)) return LENTIL_ERR_UNSUPPORTED;
+  if (P->bokeh_enable_image && !B) return LENTIL_ERR_INVALID;
+  for (uint64_t v = v_begin; v < v_end; v++) {
+    int px, py;
+    visit_pixel(V, v, &px, &py);
+    const float inv_density = V->inv_density ? V->inv_density[v] : P->inverse_sample_density;
+    do_visit(P, L, B, F, V, v, px, py, inv_density);
+  }
+  return 0;
+}
+
+/* a20 -- driver_process_bucket resolve, src/lentil_imager.cpp:112-118,169-186; out = xres*yres*4 */
+ORC_API void orc_resolve(const OrcFrame *F, uint32_t aov, float *out) {
+  const size_t np = (size_t)F->xres * F->yres;
+  for (size_t p = 0; p < np; p++) {
+    const float *b = &F->buffer[aov][p * 4];
+    if (F->kind[aov] == LENTIL_FILTER_GAUSSIAN) {
+      float r = b[0], g = b[1], bl = b[2], a = b[3];
+      /* AtRGBA::operator/=(float) multiplies by 1.0f/f (SDK, recalled) */
+      if (F->weight[p] != 0.0) { const float c = 1.0f / F->weight[p]; r *= c; g *= c; bl *= c; a *= c; }
+      out[p * 4] = r; out[p * 4 + 1] = g; out[p * 4 + 2] = bl; out[p * 4 + 3] = a;
+    } else {
+      out[p * 4] = b[0]; out[p * 4 + 1] = b[1]; out[p * 4 + 2] = b[2]; out[p * 4 + 3] = 1.0f;
+    }
+  }
+}
+
+/* a1 -- visit prologue, src/lentil_filter.cpp:79-88: AA and inverse density from the footprint count */
+ORC_API float orc_inverse_sample_density(int samples_counter, float filter_width, int aa_samples_set_by_user,
+                                         int *redistribution_ok) {
+  float AA_samples = std::sqrt(samples_counter) / filter_width;
+  float inverse_sample_density = 1.0 / (AA_samples * AA_samples);
+  if (redistribution_ok)
+    *redistribution_ok = !(static_cast<int>(std::round(AA_samples)) != aa_samples_set_by_user || (aa_samples_set_by_user < 3));
+  return inverse_sample_density;
+}

@@ -1,0 +1,132 @@
+"""ctypes binding of oracle/liblentil_oracle.so -- TEST INFRASTRUCTURE (the checker)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from pota_amd import _abi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_SO = os.path.join(ROOT, "oracle", "liblentil_oracle.so")
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle")])
+
+
+def load():
+    if not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(
+            os.path.join(ROOT, "oracle", "lentil_oracle.cpp")):
+        build()
+    L = C.CDLL(_SO)
+    d, f, i, u32, u64, vp = C.c_double, C.c_float, C.c_int, C.c_uint32, C.c_uint64, C.c_void_p
+    pd = C.POINTER(C.c_double)
+    sig = {
+        "orc_tea8": (u32, [u32, u32]),
+        "orc_rng": (f, [C.POINTER(u32)]),
+        "orc_xor128": (u32, [C.POINTER(u32)]),
+        "orc_xor128_init": (None, [C.POINTER(u32)]),
+        "orc_fast_sin": (f, [f]), "orc_fast_cos": (f, [f]),
+        "orc_concentric_disk_sample": (None, [d, d, pd]),
+        "orc_concentricDiskSample": (None, [f, f, pd, f, f]),
+        "orc_triangular_aperture": (None, [pd, pd, d, d, d, i]),
+        "orc_normalise": (None, [pd]),
+        "orc_sphereToCs": (None, [pd, pd, pd, pd, d, d]),
+        "orc_csToSphere": (None, [pd, pd, pd, pd, d, d]),
+        "orc_cylinderToCs": (None, [pd, pd, pd, pd, d, d, i]),
+        "orc_csToCylinder": (None, [pd, pd, pd, pd, d, d, i]),
+        "orc_lens_ipow": (d, [d, i]),
+        "orc_lens_create": (vp, [C.POINTER(_abi.LensTable)]),
+        "orc_lens_destroy": (None, [vp]),
+        "orc_poly_eval": (d, [vp, i, pd]),
+        "orc_inv2x2": (None, [pd, pd, pd]),
+        "orc_newton_step": (None, [pd, pd, d, pd, pd]),
+        "orc_newton_error_bits": (i, [d, d, d, d, d, d, d]),
+        "orc_lt_sample_aperture": (d, [vp, pd, pd, pd, pd, d, C.POINTER(i)]),
+        "orc_lens_evaluate": (d, [vp, pd, pd]),
+        "orc_pt_sample_aperture": (None, [vp, pd, pd, d]),
+        "orc_bokeh_create": (vp, [vp, i, i, i]),
+        "orc_bokeh_from_tables": (vp, [C.POINTER(_abi.BokehTable)]),
+        "orc_bokeh_destroy": (None, [vp]),
+        "orc_bokeh_tables": (None, [vp, vp, vp, vp, vp]),
+        "orc_bokeh_sample": (None, [vp, f, f, pd]),
+        "orc_po_aperture_sample": (None, [C.POINTER(_abi.Params), vp, u32, u32, pd]),
+        "orc_trace_ray_bw_po": (i, [C.POINTER(_abi.Params), vp, vp, pd, pd, i, i, i, f, C.POINTER(i)]),
+        "orc_get_coc_thinlens": (f, [C.POINTER(_abi.Params), f]),
+        "orc_additional_luminance_soft_trans": (f, [C.POINTER(_abi.Params), f]),
+        "orc_draw_count": (i, [C.POINTER(_abi.Params), f, f, f]),
+        "orc_frame_create": (vp, [u32, u32, u32, vp, i]),
+        "orc_frame_destroy": (None, [vp]),
+        "orc_frame_buffer": (C.POINTER(f), [vp, u32]),
+        "orc_frame_weight": (C.POINTER(f), [vp]),
+        "orc_frame_buffer64": (pd, [vp, u32]),
+        "orc_frame_weight64": (pd, [vp]),
+        "orc_frame_counters": (None, [vp, C.POINTER(_abi.Counters)]),
+        "orc_frame_log": (u64, [vp, vp, u64]),
+        "orc_frame_merge": (None, [vp, vp]),
+        "orc_redistribute": (i, [C.POINTER(_abi.Params), vp, vp, vp, C.POINTER(_abi.Visits), u64, u64]),
+        "orc_resolve": (None, [vp, u32, vp]),
+        "orc_inverse_sample_density": (f, [i, f, i, C.POINTER(i)]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(L, name)
+        fn.restype = res
+        fn.argtypes = args
+    return L
+
+
+def darr(*vals):
+    return (C.c_double * len(vals))(*vals)
+
+
+class Frame:
+    """Oracle frame wrapper: run visits, read buffers as numpy."""
+
+    def __init__(self, lib, params, n_aovs=1, kinds=None, keep_log=False):
+        self.lib, self.params, self.n_aovs = lib, params, n_aovs
+        k = (C.c_uint8 * n_aovs)(*(kinds or [0] * n_aovs))
+        self.h = lib.orc_frame_create(params.xres, params.yres, n_aovs, C.cast(k, C.c_void_p), int(keep_log))
+        self.np = params.xres * params.yres
+
+    def run(self, lens, bokeh, visits, v0=0, v1=None):
+        v1 = visits.n if v1 is None else v1
+        rc = self.lib.orc_redistribute(C.byref(self.params), lens, bokeh, self.h, C.byref(visits), v0, v1)
+        if rc:
+            raise RuntimeError("oracle redistribute rc=%d" % rc)
+
+    def buffer(self, aov=0):
+        return np.ctypeslib.as_array(self.lib.orc_frame_buffer(self.h, aov), (self.np, 4)).copy()
+
+    def weight(self):
+        return np.ctypeslib.as_array(self.lib.orc_frame_weight(self.h), (self.np,)).copy()
+
+    def buffer64(self, aov=0):
+        return np.ctypeslib.as_array(self.lib.orc_frame_buffer64(self.h, aov), (self.np, 4)).copy()
+
+    def weight64(self):
+        return np.ctypeslib.as_array(self.lib.orc_frame_weight64(self.h), (self.np,)).copy()
+
+    def resolve(self, aov=0):
+        out = np.empty((self.np, 4), np.float32)
+        self.lib.orc_resolve(self.h, aov, out.ctypes.data)
+        return out
+
+    def counters(self):
+        c = _abi.Counters()
+        self.lib.orc_frame_counters(self.h, C.byref(c))
+        return c
+
+    def log(self):
+        n = self.lib.orc_frame_log(self.h, None, 0)
+        rec = np.empty((n, 3), np.uint32)
+        self.lib.orc_frame_log(self.h, rec.ctypes.data, n)
+        return rec
+
+    def close(self):
+        if self.h:
+            self.lib.orc_frame_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
