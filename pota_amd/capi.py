@@ -1,0 +1,258 @@
+"""ctypes binding of liblentil_hip.so (the C-ABI declared in include/lentil_hip.h).
+
+The product path: no CPU fallback.  If the HIP library is missing or no GPU is present the
+calls fail loudly.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _abi
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "liblentil_hip.so")
+
+EXPORTS = [
+    "lentil_hip_abi_version", "lentil_hip_create", "lentil_hip_destroy", "lentil_hip_last_error",
+    "lentil_hip_set_params", "lentil_hip_set_lens", "lentil_hip_set_bokeh", "lentil_hip_alloc_frame",
+    "lentil_hip_upload_visits", "lentil_hip_bind_visits", "lentil_hip_clear_frame",
+    "lentil_hip_redistribute", "lentil_hip_resolve", "lentil_hip_sync", "lentil_hip_download_aov",
+    "lentil_hip_download_accum", "lentil_hip_accum_buffer", "lentil_hip_stream",
+    "lentil_hip_get_counters", "lentil_hip_last_timing", "lentil_hip_set_draw_log",
+    "lentil_hip_download_draw_log", "lentil_hip_test_lt_sample_aperture",
+    "lentil_hip_test_trace_bw_po", "lentil_hip_test_aperture_sample",
+]
+
+_lib = None
+
+
+class LentilError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("lentil_hip error %d: %s" % (code, msg))
+        self.code = code
+
+
+def load_library():
+    """dlopen liblentil_hip.so; raises if it has not been built (python __graft_entry__.py)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise FileNotFoundError(
+            "%s is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'`" % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    vp, u32, u64, i = C.c_void_p, C.c_uint32, C.c_uint64, C.c_int
+    sig = {
+        "lentil_hip_abi_version": (i, []),
+        "lentil_hip_create": (i, [i, C.POINTER(vp)]),
+        "lentil_hip_destroy": (i, [vp]),
+        "lentil_hip_last_error": (C.c_char_p, [vp]),
+        "lentil_hip_set_params": (i, [vp, C.POINTER(_abi.Params)]),
+        "lentil_hip_set_lens": (i, [vp, C.POINTER(_abi.LensTable)]),
+        "lentil_hip_set_bokeh": (i, [vp, C.POINTER(_abi.BokehTable)]),
+        "lentil_hip_alloc_frame": (i, [vp, u32, vp]),
+        "lentil_hip_upload_visits": (i, [vp, C.POINTER(_abi.Visits)]),
+        "lentil_hip_bind_visits": (i, [vp, C.POINTER(_abi.Visits)]),
+        "lentil_hip_clear_frame": (i, [vp]),
+        "lentil_hip_redistribute": (i, [vp]),
+        "lentil_hip_resolve": (i, [vp]),
+        "lentil_hip_sync": (i, [vp]),
+        "lentil_hip_download_aov": (i, [vp, u32, vp]),
+        "lentil_hip_download_accum": (i, [vp, u32, vp, vp]),
+        "lentil_hip_accum_buffer": (i, [vp, C.POINTER(vp), C.POINTER(u64)]),
+        "lentil_hip_stream": (i, [vp, C.POINTER(vp)]),
+        "lentil_hip_get_counters": (i, [vp, C.POINTER(_abi.Counters)]),
+        "lentil_hip_last_timing": (i, [vp, C.POINTER(C.c_float)]),
+        "lentil_hip_set_draw_log": (i, [vp, u64]),
+        "lentil_hip_download_draw_log": (i, [vp, vp, u64, C.POINTER(u64)]),
+        "lentil_hip_test_lt_sample_aperture": (i, [vp, u64, vp, vp, C.c_double, vp, vp, vp]),
+        "lentil_hip_test_trace_bw_po": (i, [vp, u64, vp, vp, vp, vp, vp, vp]),
+        "lentil_hip_test_aperture_sample": (i, [vp, u64, vp, vp, vp]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    if lib.lentil_hip_abi_version() != 1:
+        raise RuntimeError("liblentil_hip.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def make_visits(cols, visits_per_pixel=0, pixels_per_row=0, pixel_x0=0, pixel_y0=0, pixel_row_stride=1,
+                ptr=lambda a: a.ctypes.data):
+    """Fill a lentil_visits from a dict of columns (numpy arrays, or anything `ptr` understands).
+
+    cols: rgba, pos_z, raydir_time, volume_ignore, transmission [n,4] fp32; optional extra (list),
+    pixel (uint32 [n]), inv_density (fp32 [n]).  Returns (Visits, keepalive)."""
+    v = _abi.Visits()
+    n = int(cols["rgba"].shape[0])
+    v.n = n
+    v.visits_per_pixel = visits_per_pixel
+    v.pixels_per_row = pixels_per_row
+    v.pixel_x0, v.pixel_y0 = pixel_x0, pixel_y0
+    v.pixel_row_stride = pixel_row_stride
+    extra = list(cols.get("extra", []))
+    v.n_extra = len(extra)
+    for name in ("rgba", "pos_z", "raydir_time", "volume_ignore", "transmission"):
+        setattr(v, name, ptr(cols[name]) if n else None)
+    for k, e in enumerate(extra):
+        v.extra[k] = ptr(e) if n else None
+    if cols.get("pixel") is not None:
+        v.pixel = ptr(cols["pixel"])
+    if cols.get("inv_density") is not None:
+        v.inv_density = ptr(cols["inv_density"])
+    return v, cols
+
+
+class Context:
+    """One lentil_hip_ctx: one GPU, one stream (mirrors the ownership of the reference's Camera)."""
+
+    def __init__(self, device=0):
+        self.lib = load_library()
+        self.h = C.c_void_p()
+        rc = self.lib.lentil_hip_create(device, C.byref(self.h))
+        if rc:
+            raise LentilError(rc, (self.lib.lentil_hip_last_error(None) or b"").decode())
+        self.params = None
+        self.n_aovs = 0
+        self._keep = {}
+
+    def _chk(self, rc):
+        if rc:
+            raise LentilError(rc, (self.lib.lentil_hip_last_error(self.h) or b"").decode())
+
+    def close(self):
+        if self.h:
+            self.lib.lentil_hip_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # --- setup
+    def set_params(self, params):
+        self._chk(self.lib.lentil_hip_set_params(self.h, C.byref(params)))
+        self.params = params
+
+    def set_lens(self, table):
+        self._chk(self.lib.lentil_hip_set_lens(self.h, C.byref(table)))
+
+    def set_bokeh(self, tables):
+        """tables: dict with x, y, cdfRow, rowIndices, cdfColumn, columnIndices (numpy) or None."""
+        if tables is None:
+            self._chk(self.lib.lentil_hip_set_bokeh(self.h, None))
+            return
+        b = _abi.BokehTable()
+        b.x, b.y = int(tables["x"]), int(tables["y"])
+        arrs = {k: np.ascontiguousarray(tables[k]) for k in ("cdfRow", "rowIndices", "cdfColumn", "columnIndices")}
+        assert arrs["cdfRow"].dtype == np.float32 and arrs["rowIndices"].dtype == np.int32
+        assert arrs["cdfColumn"].dtype == np.float32 and arrs["columnIndices"].dtype == np.int32
+        for k, a in arrs.items():
+            setattr(b, k, a.ctypes.data)
+        self._chk(self.lib.lentil_hip_set_bokeh(self.h, C.byref(b)))
+
+    def alloc_frame(self, n_aovs=1, kinds=None):
+        k = (C.c_uint8 * n_aovs)(*(kinds or [0] * n_aovs))
+        self._chk(self.lib.lentil_hip_alloc_frame(self.h, n_aovs, C.cast(k, C.c_void_p)))
+        self.n_aovs = n_aovs
+
+    # --- visits
+    def upload_visits(self, visits):
+        self._chk(self.lib.lentil_hip_upload_visits(self.h, C.byref(visits)))
+
+    def bind_visits(self, visits, keepalive=None):
+        self._chk(self.lib.lentil_hip_bind_visits(self.h, C.byref(visits)))
+        self._keep["visits"] = keepalive
+
+    # --- hot path
+    def clear_frame(self):
+        self._chk(self.lib.lentil_hip_clear_frame(self.h))
+
+    def redistribute(self):
+        self._chk(self.lib.lentil_hip_redistribute(self.h))
+
+    def resolve(self):
+        self._chk(self.lib.lentil_hip_resolve(self.h))
+
+    def sync(self):
+        self._chk(self.lib.lentil_hip_sync(self.h))
+
+    # --- results
+    @property
+    def n_pixels(self):
+        return int(self.params.xres) * int(self.params.yres)
+
+    def download_aov(self, aov=0):
+        out = np.empty((self.n_pixels, 4), np.float32)
+        self._chk(self.lib.lentil_hip_download_aov(self.h, aov, out.ctypes.data))
+        return out
+
+    def download_accum(self, aov=0):
+        buf = np.empty((self.n_pixels, 4), np.float32)
+        w = np.empty((self.n_pixels,), np.float32)
+        self._chk(self.lib.lentil_hip_download_accum(self.h, aov, buf.ctypes.data, w.ctypes.data))
+        return buf, w
+
+    def accum_buffer(self):
+        p, n = C.c_void_p(), C.c_uint64()
+        self._chk(self.lib.lentil_hip_accum_buffer(self.h, C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    def stream(self):
+        s = C.c_void_p()
+        self._chk(self.lib.lentil_hip_stream(self.h, C.byref(s)))
+        return s.value
+
+    def counters(self):
+        c = _abi.Counters()
+        self._chk(self.lib.lentil_hip_get_counters(self.h, C.byref(c)))
+        return c
+
+    def last_timing(self):
+        ms = (C.c_float * 3)()
+        self._chk(self.lib.lentil_hip_last_timing(self.h, ms))
+        return float(ms[0]), float(ms[1]), float(ms[2])
+
+    def set_draw_log(self, capacity):
+        self._chk(self.lib.lentil_hip_set_draw_log(self.h, capacity))
+
+    def draw_log(self):
+        n = C.c_uint64()
+        self._chk(self.lib.lentil_hip_download_draw_log(self.h, None, 0, C.byref(n)))
+        rec = np.empty((n.value, 3), np.uint32)
+        if n.value:
+            self._chk(self.lib.lentil_hip_download_draw_log(self.h, rec.ctypes.data, n.value, C.byref(n)))
+        return rec
+
+    # --- primitive tests
+    def test_lt_sample_aperture(self, scene, ap, lam):
+        scene = np.ascontiguousarray(scene, np.float64)
+        ap = np.ascontiguousarray(ap, np.float64)
+        n = scene.shape[0]
+        sensor = np.empty((n, 5)); out = np.empty((n, 5)); T = np.empty((n,))
+        self._chk(self.lib.lentil_hip_test_lt_sample_aperture(
+            self.h, n, scene.ctypes.data, ap.ctypes.data, lam, sensor.ctypes.data, out.ctypes.data, T.ctypes.data))
+        return sensor, out, T
+
+    def test_trace_bw_po(self, target, px, py, attempt):
+        target = np.ascontiguousarray(target, np.float64)
+        px = np.ascontiguousarray(px, np.int32); py = np.ascontiguousarray(py, np.int32)
+        attempt = np.ascontiguousarray(attempt, np.int32)
+        n = target.shape[0]
+        xy = np.empty((n, 2)); ok = np.empty((n,), np.int32)
+        self._chk(self.lib.lentil_hip_test_trace_bw_po(
+            self.h, n, target.ctypes.data, px.ctypes.data, py.ctypes.data, attempt.ctypes.data,
+            xy.ctypes.data, ok.ctypes.data))
+        return xy, ok
+
+    def test_aperture_sample(self, a, b):
+        a = np.ascontiguousarray(a, np.uint32); b = np.ascontiguousarray(b, np.uint32)
+        xy = np.empty((a.shape[0], 2))
+        self._chk(self.lib.lentil_hip_test_aperture_sample(self.h, a.shape[0], a.ctypes.data, b.ctypes.data,
+                                                           xy.ctypes.data))
+        return xy

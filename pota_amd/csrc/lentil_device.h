@@ -1,0 +1,636 @@
+// lentil_device.h -- gfx950 device functions of the redistribution path.
+//
+// Arithmetic mirrors the reference operation by operation (float where the reference is
+// float, double where it is double; build with -ffp-contract=off) so that pixel indices
+// come out bit-identical.  Reference citations are relative to the upstream tree.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/lentil_hip.h"
+
+#define LD_DEV __device__ __forceinline__
+
+namespace lentil {
+
+// Arnold SDK constants (ai_constants.h)
+constexpr float kAiPi = 3.14159265358979323846f;
+constexpr float kAiPiOver2 = 1.57079632679489661923f;
+constexpr float kAiEpsilon = 1.0e-4f;
+constexpr float kAiInfinite = 1.0e30f;
+constexpr double kPi = 3.14159265358979323846;
+
+// ---------------------------------------------------------------------------------------
+// Device-side lens table.  17 polynomials: out[5], ap[4], d ap_{x,y}/d{dx,dy}, d out_{dx,dy}/d{x,y}.
+// A term packs its five exponents in 4 bits each (x | y<<4 | dx<<8 | dy<<12 | lambda<<16).
+// ---------------------------------------------------------------------------------------
+enum PolyId {
+  P_OUT_X = 0, P_OUT_Y, P_OUT_DX, P_OUT_DY, P_OUT_T,
+  P_AP_X, P_AP_Y, P_AP_DX, P_AP_DY,
+  P_DAP_00, P_DAP_01, P_DAP_10, P_DAP_11,      // d ap_x/d dx, d ap_x/d dy, d ap_y/d dx, d ap_y/d dy
+  P_DOUT_00, P_DOUT_01, P_DOUT_10, P_DOUT_11,  // d out_dx/d x, d out_dx/d y, d out_dy/d x, d out_dy/d y
+  P_COUNT
+};
+
+struct DevTerm {
+  double c;
+  uint32_t e;
+  uint32_t pad;
+};
+
+constexpr int kMaxTerms = 1536;   // 24 KiB of LDS
+constexpr int kMaxExp = 15;
+
+struct DevLens {
+  double outer_pupil_radius, inner_pupil_radius, length, back_focal_length;
+  double outer_pupil_curvature_radius;
+  int32_t outer_pupil_geometry;
+  uint32_t n_terms;
+  uint16_t first[P_COUNT];
+  uint16_t count[P_COUNT];
+  double lambda_pow[kMaxExp + 1];   // lens_ipow(lambda, e), computed on the host with the same recursion
+};
+
+struct DevBokeh {
+  int32_t x, y;
+  const float *cdfRow;
+  const int32_t *rowIndices;
+  const float *cdfColumn;
+  const int32_t *columnIndices;
+};
+
+// ---------------------------------------------------------------------------------------
+// a6 -- tea<8> / rng, src/global.h:32-57
+// ---------------------------------------------------------------------------------------
+LD_DEV uint32_t tea8(uint32_t v0, uint32_t v1) {
+  uint32_t s0 = 0;
+#pragma unroll
+  for (int n = 0; n < 8; ++n) {
+    s0 += 0x9e3779b9u;
+    v0 += ((v1 << 4) + 0xA341316Cu) ^ (v1 + s0) ^ ((v1 >> 5) + 0xC8013EA4u);
+    v1 += ((v0 << 4) + 0xAD90777Du) ^ (v0 + s0) ^ ((v0 >> 5) + 0x7E95761Eu);
+  }
+  return v0;
+}
+LD_DEV float lcg(uint32_t &s) {
+  s = s * 1664525u + 1013904223u;
+  return float(s & 0x00FFFFFFu) / float(0x01000000u);
+}
+
+// ---------------------------------------------------------------------------------------
+// a9 -- fast trig + disk samplers, src/lens.h:17-37,309-333,477-514
+// ---------------------------------------------------------------------------------------
+LD_DEV float fast_sin(float x) {
+  x = fmodf(x + kAiPi, kAiPi * 2) - kAiPi;
+  const float B = 4.0f / kAiPi;
+  const float C = -4.0f / (kAiPi * kAiPi);
+  float y = B * x + C * x * fabsf(x);
+  const float P = 0.225f;
+  return P * (y * fabsf(y) - y) + y;
+}
+LD_DEV float fast_cos(float x) {
+  x = (float)((double)x + (double)kAiPi * 0.5);
+  x = fmodf(x + kAiPi, kAiPi * 2) - kAiPi;
+  const float B = 4.0f / kAiPi;
+  const float C = -4.0f / (kAiPi * kAiPi);
+  float y = B * x + C * x * fabsf(x);
+  const float P = 0.225f;
+  return P * (y * fabsf(y) - y) + y;
+}
+
+LD_DEV void concentric_disk_sample(double ox, double oy, double &ux, double &uy) {
+  double phi, r;
+  const double a = 2.0 * ox - 1.0;
+  const double b = 2.0 * oy - 1.0;
+  if ((a * a) > (b * b)) {
+    r = a;
+    phi = (0.78539816339) * (b / a);
+  } else {
+    r = b;
+    phi = (kPi / 2.0) - (0.78539816339) * (a / b);
+  }
+  ux = r * (double)fast_cos((float)phi);
+  uy = r * (double)fast_sin((float)phi);
+}
+
+LD_DEV float ai_bias(float a, float b) {
+  return (a > 0) ? ((b > 0) ? powf(a, logf(b) * -1.442695041f) : 0.0f) : 0.0f;
+}
+LD_DEV float lerpf(float perc, float a, float b) { return a + perc * (b - a); }
+
+LD_DEV void concentricDiskSample_tl(float ox, float oy, double &lx, double &ly, float bias, float squarelerp) {
+  if (ox == 0.0f && oy == 0.0f) { lx = 0.0; ly = 0.0; return; }
+  float phi, r;
+  const float a = (float)(2.0 * (double)ox - 1.0);
+  const float b = (float)(2.0 * (double)oy - 1.0);
+  if ((a * a) > (b * b)) {
+    r = a;
+    phi = (float)(0.78539816339 * (double)(b / a));
+  } else {
+    r = b;
+    phi = (float)((double)kAiPiOver2 - ((0.78539816339) * (double)(a / b)));
+  }
+  if ((double)bias != 0.5) r = ai_bias(fabsf(r), bias) * (float)(r < 0 ? -1 : 1);
+  const float cos_phi = fast_cos(phi);
+  const float sin_phi = fast_sin(phi);
+  lx = (double)(r * cos_phi);
+  ly = (double)(r * sin_phi);
+  if (squarelerp > 0.0f) {
+    lx = (double)lerpf(squarelerp, (float)lx, a);
+    ly = (double)lerpf(squarelerp, (float)ly, b);
+  }
+}
+
+// a10 -- Camera::lens_sample_triangular_aperture, src/lentil.h:964-982
+LD_DEV void triangular_aperture(double &x, double &y, double r1, double r2, double radius, int blades) {
+  const int tri = (int)(r1 * blades);
+  r1 = r1 * blades - tri;
+  const double a = sqrt(r1);
+  const double b = (1.0 - r2) * a;
+  const double c = r2 * a;
+  const double ph1 = (double)(2.0f * kAiPi / (float)blades * (float)(tri + 1));
+  const double ph2 = (double)(2.0f * kAiPi / (float)blades * (float)tri);
+  const double s1 = sin(ph1), c1 = cos(ph1), s2 = sin(ph2), c2 = cos(ph2);
+  x = radius * (b * c1 + c * c2);
+  y = radius * (b * s1 + c * s2);
+}
+
+// a7 -- imageData::bokehSample, src/imagebokeh.h:341-412.  upper_bound = first element > value.
+template <typename T>
+LD_DEV int upper_bound_f(const T *a, int n, float v) {
+  int lo = 0, len = n;
+  while (len > 0) {
+    const int half = len >> 1;
+    if (!(v < a[lo + half])) { lo += half + 1; len -= half + 1; } else { len = half; }
+  }
+  return lo;
+}
+LD_DEV void bokeh_sample(const DevBokeh &B, const float *cdfRow, float uRow, float uCol, double &lx, double &ly) {
+  const int x = B.x, y = B.y;
+  int r = upper_bound_f(cdfRow, y, uRow);
+  if (r >= y) r = y - 1;
+  const int actualPixelRow = B.rowIndices[r];
+  const int recalulatedPixelRow = actualPixelRow - ((x - 1) / 2);
+  const int startPixel = actualPixelRow * x;
+  int c = upper_bound_f(B.cdfColumn + startPixel, x, uCol);
+  c = (c >= x) ? startPixel + x - 1 : startPixel + c;
+  const int actualPixelColumn = B.columnIndices[c];
+  const int relativePixelColumn = actualPixelColumn - startPixel;
+  const int recalulatedPixelColumn = relativePixelColumn - ((y - 1) / 2);
+  const float flippedRow = (float)recalulatedPixelColumn;
+  const float flippedColumn = (float)recalulatedPixelRow * -1.0f;
+  lx = (double)(flippedRow / (float)x) * 2.0;
+  ly = (double)(flippedColumn / (float)y) * 2.0;
+}
+
+// ---------------------------------------------------------------------------------------
+// a14 -- pupil transforms, src/lens.h:99-221
+// ---------------------------------------------------------------------------------------
+LD_DEV void normalise3(double &x, double &y, double &z) {
+  const double ilen = 1.0 / sqrt(x * x + y * y + z * z);
+  x *= ilen; y *= ilen; z *= ilen;
+}
+
+LD_DEV void sphereToCs(double ipx, double ipy, double idx, double idy, double pos[3], double dir[3],
+                       double center, double R) {
+  const double n0 = ipx / R, n1 = ipy / R;
+  const double n2 = sqrt(fmax(0.0, R * R - ipx * ipx - ipy * ipy)) / fabs(R);
+  const double t2 = sqrt(fmax(0.0, 1.0 - idx * idx - idy * idy));
+  double ex0 = n2, ex1 = 0.0, ex2 = -n0;
+  normalise3(ex0, ex1, ex2);
+  const double ey0 = n1 * ex2 - n2 * ex1;
+  const double ey1 = n2 * ex0 - n0 * ex2;
+  const double ey2 = n0 * ex1 - n1 * ex0;
+  dir[0] = idx * ex0 + idy * ey0 + t2 * n0;
+  dir[1] = idx * ex1 + idy * ey1 + t2 * n1;
+  dir[2] = idx * ex2 + idy * ey2 + t2 * n2;
+  pos[0] = ipx;
+  pos[1] = ipy;
+  pos[2] = n2 * R + center;
+}
+
+LD_DEV void csToSphere(const double pos[3], double vx, double vy, double vz, double &odx, double &ody,
+                       double center, double R) {
+  const double n0 = pos[0] / R, n1 = pos[1] / R, n2 = fabs((pos[2] - center) / R);
+  normalise3(vx, vy, vz);
+  double ex0 = n2, ex1 = 0.0, ex2 = -n0;
+  normalise3(ex0, ex1, ex2);
+  const double ey0 = n1 * ex2 - n2 * ex1;
+  const double ey1 = n2 * ex0 - n0 * ex2;
+  const double ey2 = n0 * ex1 - n1 * ex0;
+  odx = vx * ex0 + vy * ex1 + vz * ex2;
+  ody = vx * ey0 + vy * ey1 + vz * ey2;
+}
+
+LD_DEV void cylinderToCs(double ipx, double ipy, double idx, double idy, double pos[3], double dir[3],
+                         double center, double R, bool cyl_y) {
+  double n0 = 0.0, n1 = 0.0, n2;
+  if (cyl_y) { n0 = ipx / R; n2 = sqrt(fmax(0.0, R * R - ipx * ipx)) / fabs(R); }
+  else { n1 = ipy / R; n2 = sqrt(fmax(0.0, R * R - ipy * ipy)) / fabs(R); }
+  const double t2 = sqrt(fmax(0.0, 1.0 - idx * idx - idy * idy));
+  double ex0 = n2, ex1 = 0.0, ex2 = -n0;
+  normalise3(ex0, ex1, ex2);
+  double ey0 = n1 * ex2 - n2 * ex1;
+  double ey1 = n2 * ex0 - n0 * ex2;
+  double ey2 = n0 * ex1 - n1 * ex0;
+  normalise3(ey0, ey1, ey2);
+  dir[0] = idx * ex0 + idy * ey0 + t2 * n0;
+  dir[1] = idx * ex1 + idy * ey1 + t2 * n1;
+  dir[2] = idx * ex2 + idy * ey2 + t2 * n2;
+  pos[0] = ipx;
+  pos[1] = ipy;
+  pos[2] = n2 * R + center;
+}
+
+LD_DEV void csToCylinder(const double pos[3], double vx, double vy, double vz, double &odx, double &ody,
+                         double center, double R, bool cyl_y) {
+  double n0 = 0.0, n1 = 0.0;
+  if (cyl_y) n0 = pos[0] / R; else n1 = pos[1] / R;
+  const double n2 = fabs((pos[2] - center) / R);
+  normalise3(vx, vy, vz);
+  const double ex0 = n2, ex1 = 0.0, ex2 = -n0;     // not normalised, src/lens.h:171
+  double ey0 = n1 * ex2 - n2 * ex1;
+  double ey1 = n2 * ex0 - n0 * ex2;
+  double ey2 = n0 * ex1 - n1 * ex0;
+  normalise3(ey0, ey1, ey2);
+  odx = vx * ex0 + vy * ex1 + vz * ex2;
+  ody = vx * ey0 + vy * ey1 + vz * ey2;
+}
+
+// lens_ipow, src/lens.h:226-233, unrolled: e is wave-uniform (it comes from the lens table)
+LD_DEV double ipow_u(double x, uint32_t e) {
+  uint32_t odd = 0, n = 0;
+  while (e > 2) { odd = (odd << 1) | (e & 1u); ++n; e >>= 1; }
+  double p = (e == 2) ? x * x : x;
+  for (uint32_t i = 0; i < n; ++i) {
+    p = (odd & 1u) ? (x * p) * p : p * p;
+    odd >>= 1;
+  }
+  return p;
+}
+
+// ---------------------------------------------------------------------------------------
+// Table-driven polynomial evaluation: terms in LDS, exponents read through readfirstlane so
+// that all control flow is scalar.  sum = t0 + t1 + ... left to right, term = c*f1*f2*...
+// ---------------------------------------------------------------------------------------
+struct LdsLens {
+  const DevTerm *terms;   // LDS
+  const DevLens *k;       // LDS copy of the header
+
+  LD_DEV double eval(int pid, const double v[4]) const {
+    const uint32_t first = k->first[pid], count = k->count[pid];
+    double sum = 0.0;
+    for (uint32_t i = 0; i < count; ++i) {
+      const DevTerm t = terms[first + i];
+      const uint32_t e = __builtin_amdgcn_readfirstlane(t.e);
+      double term = t.c;
+#pragma unroll
+      for (int var = 0; var < 4; ++var) {
+        const uint32_t ev = (e >> (4 * var)) & 15u;
+        if (ev == 1) term = term * v[var];
+        else if (ev > 1) term = term * ipow_u(v[var], ev);
+      }
+      const uint32_t el = (e >> 16) & 15u;
+      if (el) term = term * k->lambda_pow[el];
+      sum = (i == 0) ? term : sum + term;
+    }
+    return sum;
+  }
+
+  // everything one Newton iteration of lt_sample_aperture needs, all at the same point
+  LD_DEV void eval_bw(const double v[4], double pred_ap[2], double Jap[4], double out[4], double Jout[4]) const {
+    pred_ap[0] = eval(P_AP_X, v);
+    pred_ap[1] = eval(P_AP_Y, v);
+    Jap[0] = eval(P_DAP_00, v); Jap[1] = eval(P_DAP_01, v);
+    Jap[2] = eval(P_DAP_10, v); Jap[3] = eval(P_DAP_11, v);
+    out[0] = eval(P_OUT_X, v); out[1] = eval(P_OUT_Y, v);
+    out[2] = eval(P_OUT_DX, v); out[3] = eval(P_OUT_DY, v);
+    Jout[0] = eval(P_DOUT_00, v); Jout[1] = eval(P_DOUT_01, v);
+    Jout[2] = eval(P_DOUT_10, v); Jout[3] = eval(P_DOUT_11, v);
+  }
+  LD_DEV double transmittance(const double v[4]) const { return eval(P_OUT_T, v); }
+  LD_DEV const DevLens &consts() const { return *k; }
+};
+
+// ---------------------------------------------------------------------------------------
+// a12 -- lens_lt_sample_aperture (src/lentil.h:1296-1313) with the generated Newton body as
+// evidenced by tests/aperture_sampling_debug/writout.txt: all polynomials of an iteration
+// at the iteration's begin state; aperture step undamped; outer-pupil step damped 0.72;
+// error bits reset while k < 10; tolerance 1e-8 on both squared errors.
+// Returns the transmittance (>= 0).  sensor = (x, y, dx, dy).
+// ---------------------------------------------------------------------------------------
+template <class Lens>
+LD_DEV double lt_sample_aperture(const Lens &L, const double scene[3], double ap_x, double ap_y,
+                                 double sensor[4], double out[5], int *iters = nullptr) {
+  const DevLens &k = L.consts();
+  const double R = k.outer_pupil_curvature_radius;
+  double x = 0, y = 0, dx = 0, dy = 0;
+  int error = 0;
+  const double eps = 1e-8;
+  double sqr_err = 1e30, sqr_ap_err = 1e30;
+  double prev_sqr_err = 1e32, prev_sqr_ap_err = 1e32;
+  int kk = 0;
+  for (; kk < 100 && (sqr_err > eps || sqr_ap_err > eps) && error == 0; kk++) {
+    prev_sqr_err = sqr_err;
+    prev_sqr_ap_err = sqr_ap_err;
+    const double begin[4] = {x, y, dx, dy};
+    double pred_ap[2], Jap[4], Jout[4];
+    L.eval_bw(begin, pred_ap, Jap, out, Jout);
+    const double d0 = ap_x - pred_ap[0], d1 = ap_y - pred_ap[1];
+    sqr_ap_err = d0 * d0 + d1 * d1;
+    {
+      const double invdet = 1.0 / (Jap[0] * Jap[3] - Jap[1] * Jap[2]);
+      const double i00 = Jap[3] * invdet, i11 = Jap[0] * invdet;
+      const double i01 = -Jap[1] * invdet, i10 = -Jap[2] * invdet;
+      dx += i00 * d0; dy += i10 * d0;
+      dx += i01 * d1; dy += i11 * d1;
+    }
+    double pos[3], dir[3];
+    double on_dx, on_dy;
+    // the view vector is normalised once here and once more inside csTo*, like the generated code
+    if (k.outer_pupil_geometry == LENTIL_GEOM_SPHERICAL) {
+      sphereToCs(out[0], out[1], out[2], out[3], pos, dir, -R, R);
+      double vx = scene[0] - pos[0], vy = scene[1] - pos[1], vz = scene[2] - pos[2];
+      normalise3(vx, vy, vz);
+      csToSphere(pos, vx, vy, vz, on_dx, on_dy, -R, R);
+    } else {
+      const bool cy = k.outer_pupil_geometry == LENTIL_GEOM_CYL_Y;
+      cylinderToCs(out[0], out[1], out[2], out[3], pos, dir, -R, R, cy);
+      double vx = scene[0] - pos[0], vy = scene[1] - pos[1], vz = scene[2] - pos[2];
+      normalise3(vx, vy, vz);
+      csToCylinder(pos, vx, vy, vz, on_dx, on_dy, -R, R, cy);
+    }
+    const double e0 = on_dx - out[2], e1 = on_dy - out[3];
+    sqr_err = e0 * e0 + e1 * e1;
+    {
+      const double invdet = 1.0 / (Jout[0] * Jout[3] - Jout[1] * Jout[2]);
+      const double i00 = Jout[3] * invdet, i11 = Jout[0] * invdet;
+      const double i01 = -Jout[1] * invdet, i10 = -Jout[2] * invdet;
+      x += 0.72 * i00 * e0; y += 0.72 * i10 * e0;
+      x += 0.72 * i01 * e1; y += 0.72 * i11 * e1;
+    }
+    if (sqr_err > prev_sqr_err) error |= 1;
+    if (sqr_ap_err > prev_sqr_ap_err) error |= 2;
+    if (out[0] != out[0]) error |= 4;
+    if (out[2] * out[2] + out[3] * out[3] > 1.0) error |= 8;
+    if (kk < 10) error = 0;
+  }
+  if (out[0] * out[0] + out[1] * out[1] > k.outer_pupil_radius * k.outer_pupil_radius) error |= 16;
+  if (error == 0) {
+    const double begin[4] = {x, y, dx, dy};
+    out[4] = L.transmittance(begin);
+  } else {
+    out[4] = 0.0;
+  }
+  if (iters) *iters = kk;
+  sensor[0] = x; sensor[1] = y; sensor[2] = dx; sensor[3] = dy;
+  return fmax(0.0, out[4]);
+}
+
+// ---------------------------------------------------------------------------------------
+// Aperture draw of trace_ray_bw_po, src/lentil.h:596-609 (GCC argument order: see oracle)
+// ---------------------------------------------------------------------------------------
+LD_DEV void po_aperture_sample(const lentil_params &P, const DevBokeh &B, const float *cdfRow, uint32_t a,
+                               uint32_t b, double &ax, double &ay) {
+  if (!P.enable_dof) { ax = 0.0; ay = 0.0; return; }
+  uint32_t seed = tea8(a, b);
+  if (P.bokeh_aperture_blades <= 2) {
+    double ux = 0.0, uy = 0.0;
+    if (P.bokeh_enable_image) {
+      lcg(seed); lcg(seed);
+      const float d3 = lcg(seed), d4 = lcg(seed);
+      bokeh_sample(B, cdfRow, d4, d3, ux, uy);
+    } else {
+      const float d1 = lcg(seed), d2 = lcg(seed);
+      concentric_disk_sample((double)d2, (double)d1, ux, uy);
+    }
+    ax = ux * P.aperture_radius;
+    ay = uy * P.aperture_radius;
+  } else {
+    const float d1 = lcg(seed), d2 = lcg(seed);
+    triangular_aperture(ax, ay, (double)d2, (double)d1, P.aperture_radius, P.bokeh_aperture_blades);
+  }
+}
+
+// a11 -- Camera::trace_ray_bw_po, src/lentil.h:573-661 (AiTraceProbe == false)
+template <class Lens>
+LD_DEV bool trace_ray_bw_po(const lentil_params &P, const Lens &L, const DevBokeh &B, const float *cdfRow,
+                            const double target[3], int px, int py, int total_samples_taken,
+                            double &sx, double &sy) {
+  const DevLens &k = L.consts();
+  int tries = 0;
+  bool ray_succes = false;
+  double sensor[4] = {0, 0, 0, 0};
+  double out[5] = {0, 0, 0, 0, (double)P.lambda_bw};
+  double ax = 0.0, ay = 0.0;
+  while (ray_succes == false && tries <= P.vignetting_retries) {
+    po_aperture_sample(P, B, cdfRow, (uint32_t)(px * py + px), (uint32_t)(total_samples_taken + tries), ax, ay);
+    const float transmittance = (float)lt_sample_aperture(L, target, ax, ay, sensor, out);
+    if (transmittance <= 0) { ++tries; continue; }
+    const double ipx = sensor[0] + sensor[2] * k.back_focal_length;
+    const double ipy = sensor[1] + sensor[3] * k.back_focal_length;
+    if (ipx * ipx + ipy * ipy > k.inner_pupil_radius * k.inner_pupil_radius) { ++tries; continue; }
+    ray_succes = true;
+  }
+  if (!ray_succes) return false;
+  sx = sensor[0] + sensor[2] * -P.sensor_shift;
+  sy = sensor[1] + sensor[3] * -P.sensor_shift;
+  return true;
+}
+
+// a15 -- sensor -> pixel, src/lentil_filter.cpp:276-290 (fp64, explicit NaN test)
+LD_DEV bool po_sensor_to_pixel(const lentil_params &P, double sx, double sy, uint32_t &pixelnumber) {
+  const double xres = (double)P.xres, yres = (double)P.yres;
+  const double aspect = (double)P.xres_without_region / (double)P.yres_without_region;
+  const double s0 = sx / (P.sensor_width * 0.5);
+  const double s1 = sy / (P.sensor_width * 0.5) * aspect;
+  const double pixel0 = (((s0 + 1.0) / 2.0) * P.xres_without_region) - P.region_min_x;
+  const double pixel1 = (((-s1 + 1.0) / 2.0) * P.yres_without_region) - P.region_min_y;
+  if ((pixel0 >= xres) || (pixel0 < 0) || (pixel1 >= yres) || (pixel1 < 0) || (pixel0 != pixel0) ||
+      (pixel1 != pixel1))
+    return false;
+  const int ix = (int)floor(pixel0), iy = (int)floor(pixel1);
+  pixelnumber = (uint32_t)(ix + (iy * (int)P.xres));
+  return true;
+}
+
+// ---------------------------------------------------------------------------------------
+// a3/a4/a5 -- scalar helpers of the visit prologue
+// ---------------------------------------------------------------------------------------
+LD_DEV float get_coc_thinlens(const lentil_params &P, float z_cs) {   // src/lentil.h:674-692
+  float _focus_distance = (float)P.focus_distance;
+  float _aperture_radius = (float)P.aperture_radius;
+  if (P.cameraType == LENTIL_POLYNOMIAL_OPTICS) _focus_distance = (float)((double)_focus_distance / 10.0);
+  else _aperture_radius = (float)((double)_aperture_radius * 10.0);
+  const float f = P.focal_length;
+  const float image_dist_samplepos = (-f * z_cs) / (-f + z_cs);
+  const float image_dist_focusdist = (-f * -_focus_distance) / (-f + -_focus_distance);
+  return fabsf((_aperture_radius * (image_dist_samplepos - image_dist_focusdist)) / image_dist_samplepos);
+}
+
+LD_DEV float additional_luminance_soft_trans(const lentil_params &P, float lum) {   // src/lentil.h:1128-1138
+  const double lo = P.bidir_add_energy_minimum_luminance;
+  const float tr = P.bidir_add_energy_transition;
+  if ((double)lum > lo && (double)lum < lo + (double)tr) {
+    const float perc = (float)(((double)lum - lo) / (double)tr);
+    return P.bidir_add_energy * perc;
+  } else if ((double)lum > lo + (double)tr) {
+    return P.bidir_add_energy;
+  }
+  return 0.0f;
+}
+
+// draw count, src/lentil_filter.cpp:177-202.  pow(x, 0.5) on a float-valued double is taken as the
+// correctly rounded sqrt, and pow(x, 2) of a float-valued double is exact.
+LD_DEV int draw_count(const lentil_params &P, float lum, float coc, float inv_density) {
+  const float luminance_mult = (float)fmax(0.0, sqrt((double)fminf(lum, 20.0f)) * (double)P.bidir_sample_mult);
+  const float cy = coc * (float)P.yres;
+  const float coc_squared_pixels =
+      (float)((((double)cy * (double)cy) * ((double)luminance_mult * (double)luminance_mult)) * 0.00001);
+  // `int samples = std::ceil(float)`: x86 cvttss2si yields INT_MIN for out-of-range / NaN inputs
+  const float cf = ceilf(coc_squared_pixels * inv_density);
+  const int si = (cf >= 2147483648.0f || cf < -2147483648.0f || cf != cf) ? (int)0x80000000 : (int)cf;
+  float s = (float)si;
+  if (s < 4.0f) s = 4.0f;
+  if (s > 2000.0f) s = 2000.0f;
+  int samples = (int)s;
+  if (P.samples_override > 0) samples = P.samples_override;
+  return samples;
+}
+
+LD_DEV float v3len(float x, float y, float z) { return sqrtf(x * x + y * y + z * z); }
+LD_DEV void v3norm(float &x, float &y, float &z) {    // AiV3Normalize
+  float t = v3len(x, y, z);
+  if (t != 0) t = 1 / t;
+  x *= t; y *= t; z *= t;
+}
+
+// ---------------------------------------------------------------------------------------
+// Visit prologue shared by the scan kernel and the draw kernels:
+// src/lentil_filter.cpp:105-165,173-202,240.
+// ---------------------------------------------------------------------------------------
+struct VisitInfo {
+  bool redistribute;
+  int samples;
+  float cs[3];          // camera-space position after unit scaling
+  float add_energy;     // fitted_bidir_add_energy
+  float depth;
+};
+
+LD_DEV VisitInfo visit_prologue(const lentil_params &P, double lens_length, float4 rgba, float4 pos_z,
+                                float4 raydir_time, float4 volume_ignore, float4 transmission,
+                                float inv_density) {
+  VisitInfo I;
+  bool redistribute = true;
+  if (P.adaptive_sampling) { if (inv_density > 0.2f) redistribute = false; }
+  float wx = pos_z.x, wy = pos_z.y, wz = pos_z.z;
+  const float depth = pos_z.w;
+  const bool small = fabsf(wx) < kAiEpsilon && fabsf(wy) < kAiEpsilon && fabsf(wz) < kAiEpsilon;
+  const bool far = ((double)depth == (double)kAiInfinite) || small;
+  if (far && P.enable_skydome) {
+    if (raydir_time.x == 0.0f && raydir_time.y == 0.0f && raydir_time.z == 0.0f) redistribute = false;
+    else { wx = raydir_time.x * 100000000.0f; wy = raydir_time.y * 100000000.0f; wz = raydir_time.z * 100000000.0f; }
+  }
+  if (far && !P.enable_skydome) redistribute = false;
+  if (fmaxf(fmaxf(volume_ignore.x, volume_ignore.y), volume_ignore.z) > 0.0f) redistribute = false;
+
+  const float(*m)[4] = P.world_to_camera;
+  float cx = wx * m[0][0] + wy * m[1][0] + wz * m[2][0] + m[3][0];
+  float cy = wx * m[0][1] + wy * m[1][1] + wz * m[2][1] + m[3][1];
+  float cz = wx * m[0][2] + wy * m[1][2] + wz * m[2][2] + m[3][2];
+  float scale = 1.0f;
+  if (P.unitModel == LENTIL_UNIT_MM) scale = 0.1f;
+  else if (P.unitModel == LENTIL_UNIT_DM) scale = 10.0f;
+  else if (P.unitModel == LENTIL_UNIT_M) scale = 100.0f;
+  cx *= scale; cy *= scale; cz *= scale;
+
+  float r = rgba.x, g = rgba.y, b = rgba.z;
+  const bool transmitted = P.enable_bidir_transmission
+                               ? false
+                               : (fmaxf(fmaxf(transmission.x, transmission.y), transmission.z) > 0.0f);
+  if (transmitted) { r -= transmission.x; g -= transmission.y; b -= transmission.z; redistribute = false; }
+  const float lum = (float)((double)(r + g + b) / 3.0);
+  if (volume_ignore.w > 0.0f) redistribute = false;
+
+  float add_energy = 0.0f;
+  if (P.bidir_add_energy > 0.0f) add_energy = additional_luminance_soft_trans(P, lum);
+  const float coc = get_coc_thinlens(P, cz);
+  if (coc < 0.4f) redistribute = false;
+  I.samples = draw_count(P, lum, coc, inv_density);
+  if (P.cameraType == LENTIL_POLYNOMIAL_OPTICS)
+    if ((double)fabsf(cz) < (lens_length * 0.1)) redistribute = false;
+  I.redistribute = redistribute;
+  I.cs[0] = cx; I.cs[1] = cy; I.cs[2] = cz;
+  I.add_energy = add_energy;
+  I.depth = depth;
+  return I;
+}
+
+// a16 -- one thin-lens draw, src/lentil_filter.cpp:311-434 (abb_coma == 0, abb_chromatic == 0)
+LD_DEV bool thinlens_draw(const lentil_params &P, const DevBokeh &B, const float *cdfRow, const float cs[3],
+                          int px, int py, uint32_t total_samples_taken, uint32_t &pixelnumber) {
+  uint32_t seed = tea8((uint32_t)(px * py + px), total_samples_taken);
+  const float f = P.focal_length;
+  const float image_dist_samplepos = (-f * cs[2]) / (-f + cs[2]);
+  double ux = 0.0, uy = 0.0;
+  if (P.bokeh_enable_image) {
+    lcg(seed); lcg(seed);
+    const float d3 = lcg(seed), d4 = lcg(seed);
+    bokeh_sample(B, cdfRow, d4, d3, ux, uy);
+  } else if (P.bokeh_aperture_blades < 2) {
+    const float d1 = lcg(seed), d2 = lcg(seed);
+    concentricDiskSample_tl(d2, d1, ux, uy, P.abb_spherical, P.circle_to_square);
+  } else {
+    const float d1 = lcg(seed), d2 = lcg(seed);
+    triangular_aperture(ux, uy, (double)d2, (double)d1, 1.0, P.bokeh_aperture_blades);
+  }
+  ux *= (double)P.bokeh_anamorphic;
+  const float lx = (float)(ux * P.aperture_radius), ly = (float)(uy * P.aperture_radius), lz = 0.0f;
+  float dcx = cs[0], dcy = cs[1], dcz = cs[2];
+  v3norm(dcx, dcy, dcz);
+  const float len = v3len(cs[0], cs[1], cs[2]);
+  const float ppx = len * dcx, ppy = len * dcy, ppz = len * dcz;
+  dcx = ppx; dcy = ppy; dcz = ppz;
+  v3norm(dcx, dcy, dcz);
+  const float sii = fabsf(image_dist_samplepos / dcz);
+  const float ipx = dcx * sii, ipy = dcy * sii, ipz = dcz * sii;
+  float dlx = ipx - lx, dly = ipy - ly, dlz = ipz - lz;
+  v3norm(dlx, dly, dlz);
+  if (P.optical_vignetting_distance > 0.0f) {
+    float qx = ppx - lx, qy = ppy - ly, qz = ppz - lz;
+    v3norm(qx, qy, qz);
+    const float squarebias = (float)(1.0 + log(1.0 + (double)P.circle_to_square) * exp((double)P.circle_to_square * 3.0));
+    const float inter = fabsf(P.optical_vignetting_distance / qz);
+    const float ovx = qx * inter - lx, ovy = qy * inter - ly;
+    const float power = (float)(1.0 + (double)squarebias);
+    const float radius = (float)P.aperture_radius * P.optical_vignetting_radius;
+    const float dist = powf(fabsf(ovx), power) + powf(fabsf(ovy), power);
+    if (dist > powf(radius, power)) return false;
+  }
+  const float image_dist_focusdist =
+      (float)(((double)-f * -P.focus_distance) / ((double)-f + -P.focus_distance));
+  const float fi = fabsf(image_dist_focusdist / dlz);
+  const float fx = lx + dlx * fi, fy = ly + dly * fi, fz = lz + dlz * fi;
+  float spx = fx / fz, spy = fy / fz;
+  const float div = (float)((P.sensor_width * 0.5) / (double)-f);
+  { const float inv = 1.0f / div; spx *= inv; spy *= inv; }
+  if (P.abb_distortion > 0.0f) {
+    const double b = (double)P.abb_distortion;
+    const float l = sqrtf(spx * spx + spy * spy);
+    const double bl = (double)l;
+    const float x0 = (float)pow(9. * b * b * bl + sqrt(3.) * sqrt(27. * b * b * b * b * bl * bl + 4. * b * b * b), 1. / 3.);
+    const float xx = (float)((double)x0 / (pow(2., 1. / 3.) * pow(3., 2. / 3.) * b) - pow(2. / 3., 1. / 3.) / (double)x0);
+    spx = spx * (xx / l); spy = spy * (xx / l);
+  }
+  const double aspect = (double)P.xres_without_region / (double)P.yres_without_region;
+  const double s0 = (double)spx, s1 = (double)spy * aspect;
+  const float pixel_x = (float)((((s0 + 1.0) / 2.0) * P.xres_without_region) - P.region_min_x);
+  const float pixel_y = (float)((((-s1 + 1.0) / 2.0) * P.yres_without_region) - P.region_min_y);
+  const double xres = (double)P.xres, yres = (double)P.yres;
+  if (((double)pixel_x >= xres) || (pixel_x < 0) || ((double)pixel_y >= yres) || (pixel_y < 0)) return false;
+  const int ix = (int)floorf(pixel_x), iy = (int)floorf(pixel_y);
+  pixelnumber = (uint32_t)(ix + (iy * (int)P.xres));
+  return true;
+}
+
+}  // namespace lentil

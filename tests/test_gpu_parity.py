@@ -1,0 +1,311 @@
+"""GPU parity: the HIP path (through the C-ABI) against the oracle on identical inputs.
+
+Bars (BASELINE.json north_star): accepted-draw lists (visit, attempt, pixel) bit-identical;
+accumulated radiance / weights within 1e-5 relative (fp32 atomic summation order differs from the
+sequential reference).  The oracle also keeps an fp64 shadow accumulation, so the error of each
+side against the exact sum can be told apart.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import common
+import oracle_lib
+from pota_amd import _abi, bokeh, capi
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-5
+
+
+def gpu_run(ctx, p, table, visits, n_aovs=1, bokeh_tables=None, log_cap=1 << 22):
+    ctx.set_params(p)
+    if table is not None:
+        ctx.set_lens(table)
+    ctx.set_bokeh(bokeh_tables)
+    ctx.alloc_frame(n_aovs)
+    ctx.set_draw_log(log_cap)
+    ctx.upload_visits(visits)
+    ctx.clear_frame()
+    ctx.redistribute()
+    ctx.resolve()
+    ctx.sync()
+    c = ctx.counters()
+    assert c.worklist_overflow == 0
+    return c
+
+
+def check_frame(ctx, ref, n_aovs=1, tol=TOL):
+    """accumulators + weight + resolved image vs oracle; returns the worst relative error."""
+    worst = 0.0
+    rw = ref.weight()
+    rw64 = ref.weight64()
+    for a in range(n_aovs):
+        buf, w = ctx.download_accum(a)
+        rb = ref.buffer(a)
+        # relative to the exact (fp64) sum; every contribution on this path is non-negative
+        exact = ref.buffer64(a)
+        m = exact != 0
+        assert np.array_equal(buf == 0, rb == 0) or np.allclose(buf[~m], 0, atol=1e-30)
+        e = float(np.max(np.abs(buf[m].astype(np.float64) - exact[m]) / np.abs(exact[m]))) if m.any() else 0.0
+        worst = max(worst, e)
+        if a == 0:
+            mw = rw64 != 0
+            ew = float(np.max(np.abs(w[mw].astype(np.float64) - rw64[mw]) / rw64[mw])) if mw.any() else 0.0
+            worst = max(worst, ew)
+            assert np.array_equal(w != 0, rw != 0)
+        img = ctx.download_aov(a)
+        rimg = ref.resolve(a)
+        mi = rimg != 0
+        ei = float(np.max(np.abs(img[mi].astype(np.float64) - rimg[mi]) / np.abs(rimg[mi]))) if mi.any() else 0.0
+        worst = max(worst, ei)
+    assert worst < tol, "max relative error %.3e" % worst
+    return worst
+
+
+def check_logs(ctx, ref):
+    g = common.sort_log(ctx.draw_log())
+    r = common.sort_log(ref.log())
+    assert g.shape == r.shape, "accepted draws: gpu %d vs oracle %d" % (g.shape[0], r.shape[0])
+    assert np.array_equal(g, r), "accepted-draw (visit, attempt, pixel) lists differ"
+
+
+# --------------------------------------------------------------------------------------------------
+# primitives
+# --------------------------------------------------------------------------------------------------
+def test_aperture_sample_disk_bit_exact(orc, gpu_ctx_factory):
+    p, model, table, keep = common.po_setup(64, 48)
+    ctx = gpu_ctx_factory()
+    ctx.set_params(p)
+    rng = np.random.default_rng(1)
+    a = rng.integers(0, 2 ** 32, 20000, dtype=np.uint64).astype(np.uint32)
+    b = rng.integers(0, 4000, 20000, dtype=np.uint64).astype(np.uint32)
+    got = ctx.test_aperture_sample(a, b)
+    exp = np.empty_like(got)
+    tmp = (C.c_double * 2)()
+    for i in range(a.shape[0]):
+        orc.orc_po_aperture_sample(C.byref(p), None, int(a[i]), int(b[i]), tmp)
+        exp[i] = tmp[0], tmp[1]
+    assert np.array_equal(got, exp)
+
+
+def test_lt_sample_aperture_bit_exact(orc, gpu_ctx_factory):
+    p, model, table, keep = common.po_setup(64, 48)
+    ctx = gpu_ctx_factory()
+    ctx.set_params(p)
+    ctx.set_lens(table)
+    rng = np.random.default_rng(2)
+    n = 4096
+    scene = np.stack([rng.uniform(-4000, 4000, n), rng.uniform(-3000, 3000, n), rng.uniform(400, 20000, n)], 1)
+    ap = rng.uniform(-1, 1, (n, 2)) * p.aperture_radius
+    lam = float(np.float32(0.55))
+    sensor, out, T = ctx.test_lt_sample_aperture(scene, ap, lam)
+    lens = orc.orc_lens_create(C.byref(table))
+    es, eo, eT = np.empty_like(sensor), np.empty_like(out), np.empty_like(T)
+    s5, o5 = (C.c_double * 5)(), (C.c_double * 5)()
+    for i in range(n):
+        for k in range(5):
+            o5[k] = 0.0
+        o5[4] = lam
+        eT[i] = orc.orc_lt_sample_aperture(lens, oracle_lib.darr(*scene[i]), oracle_lib.darr(*ap[i]), s5, o5, lam, None)
+        es[i] = list(s5)
+        eo[i] = list(o5)
+    orc.orc_lens_destroy(lens)
+    assert (eT > 0).mean() > 0.3
+    # NaN-aware exact comparison
+    assert np.array_equal(T, eT, equal_nan=True)
+    assert np.array_equal(sensor, es, equal_nan=True)
+    assert np.array_equal(out, eo, equal_nan=True)
+
+
+def test_trace_bw_po_bit_exact(orc, gpu_ctx_factory):
+    p, model, table, keep = common.po_setup(64, 48)
+    ctx = gpu_ctx_factory()
+    ctx.set_params(p)
+    ctx.set_lens(table)
+    rng = np.random.default_rng(3)
+    n = 4096
+    target = np.stack([rng.uniform(-600, 600, n), rng.uniform(-400, 400, n), rng.uniform(500, 5000, n)], 1)
+    px = rng.integers(0, 64, n).astype(np.int32)
+    py = rng.integers(0, 48, n).astype(np.int32)
+    att = rng.integers(0, 3000, n).astype(np.int32)
+    xy, ok = ctx.test_trace_bw_po(target, px, py, att)
+    lens = orc.orc_lens_create(C.byref(table))
+    exy, eok = np.zeros_like(xy), np.zeros_like(ok)
+    sp = (C.c_double * 2)()
+    for i in range(n):
+        eok[i] = orc.orc_trace_ray_bw_po(C.byref(p), lens, None, oracle_lib.darr(*target[i]), sp, int(px[i]),
+                                         int(py[i]), int(att[i]), p.lambda_bw, None)
+        if eok[i]:
+            exy[i] = sp[0], sp[1]
+    orc.orc_lens_destroy(lens)
+    assert np.array_equal(ok, eok)
+    assert np.array_equal(xy[ok == 1], exy[ok == 1])
+
+
+# --------------------------------------------------------------------------------------------------
+# whole path
+# --------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("override", [0, 64])
+def test_po_redistribute_parity(orc, gpu_ctx_factory, override):
+    W, H, M = 96, 64, 9
+    p, model, table, keep = common.po_setup(W, H, samples_override=override)
+    visits, cols = common.make_stream(p, W, H, M, f_hi=0.02)
+    ref = common.run_oracle(orc, p, table, visits)
+    ctx = gpu_ctx_factory()
+    c = gpu_run(ctx, p, table, visits)
+    rc = ref.counters()
+    assert (c.redistributed_visits, c.attempted_draws, c.accepted_draws) == (
+        rc.redistributed_visits, rc.attempted_draws, rc.accepted_draws)
+    check_logs(ctx, ref)
+    check_frame(ctx, ref)
+
+
+def test_direct_accumulation_is_bit_exact(orc, gpu_ctx_factory):
+    """No highlights: every pixel only receives its own visits, summed in iterator order -> the
+    accumulators must equal the sequential reference bit for bit."""
+    W, H, M = 80, 40, 9
+    p, model, table, keep = common.po_setup(W, H)
+    visits, cols = common.make_stream(p, W, H, M, f_hi=0.0, n_extra=2)
+    ref = common.run_oracle(orc, p, table, visits, n_aovs=3)
+    ctx = gpu_ctx_factory()
+    c = gpu_run(ctx, p, table, visits, n_aovs=3)
+    assert c.redistributed_visits == 0
+    for a in range(3):
+        buf, w = ctx.download_accum(a)
+        assert np.array_equal(buf, ref.buffer(a))
+        assert np.array_equal(w, ref.weight())
+        assert np.array_equal(ctx.download_aov(a), ref.resolve(a))
+
+
+def test_po_extra_aovs_and_m36(orc, gpu_ctx_factory):
+    """K = 3 extra AOVs, 36 visits per pixel (AA 4, filter width 1.5 -> inv density 1/16)."""
+    W, H, M = 40, 30, 36
+    p, model, table, keep = common.po_setup(W, H, aa=4, filter_width=1.5, samples_override=32)
+    visits, cols = common.make_stream(p, W, H, M, f_hi=0.01, n_extra=3)
+    ref = common.run_oracle(orc, p, table, visits, n_aovs=4)
+    ctx = gpu_ctx_factory()
+    gpu_run(ctx, p, table, visits, n_aovs=4)
+    check_logs(ctx, ref)
+    check_frame(ctx, ref, n_aovs=4)
+
+
+def test_po_ragged_pixels_and_inv_density(orc, gpu_ctx_factory):
+    """Explicit per-visit pixel + per-visit inverse density (ragged footprints / adaptive sampling)."""
+    W, H, M = 48, 32, 9
+    p, model, table, keep = common.po_setup(W, H, samples_override=16)
+    visits, cols = common.make_stream(p, W, H, M, f_hi=0.03)
+    n = cols["rgba"].shape[0]
+    rng = np.random.default_rng(7)
+    px = rng.integers(0, W, n).astype(np.uint32)
+    py = rng.integers(0, H, n).astype(np.uint32)
+    cols["pixel"] = (px | (py << 16)).astype(np.uint32)
+    cols["inv_density"] = rng.choice(np.array([1 / 9., 1 / 16., 0.14], np.float32), n).astype(np.float32)
+    visits, keepv = capi.make_visits(cols, visits_per_pixel=0)
+    ref = common.run_oracle(orc, p, table, visits)
+    ctx = gpu_ctx_factory()
+    gpu_run(ctx, p, table, visits)
+    check_logs(ctx, ref)
+    check_frame(ctx, ref)
+
+
+def test_po_bokeh_image(orc, gpu_ctx_factory):
+    """imagebokeh CDF aperture draws (config 3's sampler) from the reference's example kernel."""
+    import os
+    tex = np.load(os.path.join(common.ROOT, "tests", "golden", "example_bokeh_kernel_u8.npy")).astype(np.float32) / np.float32(255)
+    tables = bokeh.build_tables(tex)
+    W, H, M = 64, 48, 9
+    p, model, table, keep = common.po_setup(W, H, samples_override=48, bokeh_enable_image=1)
+    visits, cols = common.make_stream(p, W, H, M, f_hi=0.02)
+    bt = _abi.BokehTable()
+    bt.x, bt.y = tables["x"], tables["y"]
+    for k in ("cdfRow", "rowIndices", "cdfColumn", "columnIndices"):
+        setattr(bt, k, tables[k].ctypes.data)
+    ob = orc.orc_bokeh_from_tables(C.byref(bt))
+    ref = common.run_oracle(orc, p, table, visits, bokeh=ob)
+    ctx = gpu_ctx_factory()
+    gpu_run(ctx, p, table, visits, bokeh_tables=tables)
+    check_logs(ctx, ref)
+    check_frame(ctx, ref)
+    orc.orc_bokeh_destroy(ob)
+
+
+@pytest.mark.parametrize("override", [0, 64])
+def test_thinlens_redistribute_parity(orc, gpu_ctx_factory, override):
+    """BASELINE config 1 shape (thin lens, 64 draws, beauty only) at test size."""
+    W, H, M = 96, 64, 9
+    p = common.tl_setup(W, H, samples_override=override)
+    visits, cols = common.make_stream(p, W, H, M, f_hi=0.02)
+    ref = common.run_oracle(orc, p, None, visits)
+    ctx = gpu_ctx_factory()
+    c = gpu_run(ctx, p, None, visits)
+    assert c.accepted_draws == ref.counters().accepted_draws
+    check_logs(ctx, ref)
+    check_frame(ctx, ref)
+
+
+def test_empty_stream_and_error_paths(gpu_ctx_factory):
+    p, model, table, keep = common.po_setup(32, 16)
+    ctx = gpu_ctx_factory()
+    with pytest.raises(capi.LentilError):
+        ctx.redistribute()                      # nothing set up yet
+    ctx.set_params(p)
+    ctx.set_lens(table)
+    ctx.alloc_frame(1)
+    visits, cols = common.make_stream(p, 32, 16, 9, f_hi=0.0, v_end=0)
+    ctx.upload_visits(visits)
+    ctx.clear_frame()
+    ctx.redistribute()
+    ctx.resolve()
+    buf, w = ctx.download_accum(0)
+    assert not buf.any() and not w.any()
+    bad = common.po_setup(32, 16)[0]
+    bad.abb_chromatic = 0.5
+    with pytest.raises(capi.LentilError) as ei:
+        ctx.set_params(bad)
+    assert ei.value.code == _abi.ERR_UNSUPPORTED
+
+
+def test_full_size_properties(gpu_ctx_factory):
+    """1920x1080, 9 visits/pixel, 256 draws (BASELINE config 2): size-independent properties.
+    - every visit's weight lands somewhere or is counted rejected: sum(weight) = sum over visits of
+      inv_density * accepted/samples  (energy bookkeeping), checked through the counters;
+    - linearity: doubling the radiance doubles the accumulators (weights unchanged);
+    - the resolved image is finite and equals acc/weight."""
+    import torch
+    from pota_amd import workload
+    W, H, M = 1920, 1080, 9
+    p, model, table, keep = common.po_setup(W, H, samples_override=256)
+    dev = torch.device("cuda:0")
+    n = W * H * M
+    cols = workload.generate(torch, 0, n, W, H, M, f_hi=2.0 ** -12, focus_dist=150.0,
+                             tan_half_fov=common.tan_half_fov(p), device=dev)
+    ctx = gpu_ctx_factory()
+    ctx.set_params(p)
+    ctx.set_lens(table)
+    ctx.set_bokeh(None)
+    ctx.alloc_frame(1)
+    ctx.set_draw_log(0)
+    visits, keepv = capi.make_visits(cols, visits_per_pixel=M, pixels_per_row=W, ptr=lambda t: t.data_ptr())
+    torch.cuda.synchronize()
+    ctx.bind_visits(visits, keepv)
+    ctx.clear_frame(); ctx.redistribute(); ctx.resolve(); ctx.sync()
+    c = ctx.counters()
+    assert c.worklist_overflow == 0 and c.redistributed_visits > 0
+    buf1, w1 = ctx.download_accum(0)
+    direct = (n - c.redistributed_visits) * float(p.inverse_sample_density)
+    splat = c.accepted_draws * float(p.inverse_sample_density) / 256.0
+    assert abs(float(w1.astype(np.float64).sum()) - (direct + splat)) / (direct + splat) < 1e-5
+    img = ctx.download_aov(0)
+    assert np.isfinite(img).all()
+    m = w1 != 0
+    assert np.allclose(img[m], buf1[m] * (np.float32(1) / w1[m])[:, None], rtol=1e-6)
+    # linearity in radiance (alpha stays 1)
+    cols["rgba"][:, :3] *= 2.0
+    torch.cuda.synchronize()
+    ctx.clear_frame(); ctx.redistribute(); ctx.sync()
+    buf2, w2 = ctx.download_accum(0)
+    assert float(np.abs(w2.astype(np.float64) - w1).max()) <= 1e-5 * float(w1.max())
+    mm = buf1[:, 0] > 0
+    assert np.allclose(buf2[mm, :3], 2.0 * buf1[mm, :3], rtol=2e-5)
