@@ -1,0 +1,246 @@
+#!/usr/bin/env python3
+"""bench.py -- bidirectional redistribution throughput (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = one redistribution pass over one frame's worth of synthetic AOV-sample visits that are
+already resident in HBM: clear accumulators -> scan/compact/direct-accumulate -> draw/splat ->
+(N>1: RCCL sum all-reduce of the accumulators) -> resolve.  `value` = visits consumed by all ranks
+per second (Msamples/s; 1 sample = 1 visit record of 80+16K bytes).
+
+Workload at N=1: the configuration the metric is quoted on -- double-gauss 50 mm polynomial optics,
+3840x2160, 9 visits/pixel (AA 3), 1024 redistribution draws per redistributed visit, beauty only,
+highlight fraction f_hi (default 2^-16, the scan-dominated regime of SURVEY.md section 8d; the
+highlight-heavy regime 1.6e-3 is reported beside it in "regimes").  N>1 keeps the per-GPU work fixed
+(weak scaling): the frame grows to N x 2160 rows, rank r owns rows r mod N.
+
+The printed JSON line also carries
+  roofline     -- the HBM-bound scan kernel: algorithmic bytes (visits x 80 B) / its mean duration,
+                  measured with HIP events on the library's stream, against 8 TB/s
+  cpu_baseline -- the oracle (a port of the reference CPU path) timed on this box's host cores on a
+                  bounded row sample of the same workload (rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import threading
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+FP64_VECTOR_PEAK_TFLOPS = 78.6
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--width", type=int, default=3840)
+    ap.add_argument("--height", type=int, default=2160)
+    ap.add_argument("--visits-per-pixel", type=int, default=9)
+    ap.add_argument("--samples", type=int, default=1024)
+    ap.add_argument("--f-hi", type=float, default=2.0 ** -16)
+    ap.add_argument("--aovs", type=int, default=0, help="extra (non-beauty) AOVs")
+    ap.add_argument("--lens", default="double_gauss_50mm")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-second-regime", action="store_true")
+    ap.add_argument("--cpu-row-step", type=int, default=0, help="CPU baseline samples every n-th row (0 = auto)")
+    return ap.parse_args()
+
+
+def cpu_baseline(args, p, table, M, tan_half_fov):
+    """Oracle ("port" of the reference CPU path) on a bounded sample: every row_step-th image row of
+    the same frame, threaded over rows with per-thread private accumulators merged at the end."""
+    import ctypes as C
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib
+    from pota_amd import capi, workload
+
+    lib = oracle_lib.load()
+    W, H = args.width, args.height
+    threads = max(1, min(os.cpu_count() or 1, 32))
+    # bound the CPU work to roughly 10-30 s: ~0.1 us per scanned visit, ~35 us per draw attempt per core
+    est_full = W * H * M * (0.1e-6 + args.f_hi * args.samples * 35e-6 * 1.1)
+    row_step = args.cpu_row_step or max(1, int(round(est_full / (20.0 * threads))))
+    rows = list(range(0, H, row_step))
+    n = len(rows) * W * M
+    cols = workload.generate(np, 0, n, W, H, M, f_hi=args.f_hi, focus_dist=150.0, tan_half_fov=tan_half_fov,
+                             n_extra=args.aovs, row_stride=row_step, row_offset=0)
+    visits, keep = capi.make_visits(cols, visits_per_pixel=M, pixels_per_row=W, pixel_row_stride=row_step)
+    lens = lib.orc_lens_create(C.byref(table))
+    frames = [oracle_lib.Frame(lib, p, n_aovs=1 + args.aovs, shadow=False) for _ in range(threads)]
+    # contiguous row blocks per thread
+    bounds = [int(round(i * len(rows) / threads)) * W * M for i in range(threads + 1)]
+
+    def work(i):
+        frames[i].run(lens, None, visits, bounds[i], bounds[i + 1])
+
+    t0 = time.perf_counter()
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(threads)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    for f in frames[1:]:
+        lib.orc_frame_merge(frames[0].h, f.h)
+    dt = time.perf_counter() - t0
+    c = frames[0].counters()
+    lib.orc_lens_destroy(lens)
+    for f in frames:
+        f.close()
+    return {
+        "value": round(n / dt / 1e6, 4), "unit": "Msamples/s", "cores": threads, "kind": "port",
+        "sample": "every %d-th row of the same %dx%d frame: %d visits, %d redistributed, %d draw attempts, %.1f s"
+                  % (row_step, W, H, n, c.redistributed_visits, c.attempted_draws, dt),
+    }
+
+
+def load_traffic(workload_tag):
+    """HBM bytes per scan launch from a separate rocprofv3 --pmc pass (profiles/pmc_scan_latest.json)."""
+    path = os.path.join(ROOT, "profiles", "pmc_scan_latest.json")
+    try:
+        with open(path) as f:
+            d = json.load(f)
+        if d.get("workload") == workload_tag:
+            return d.get("hbm_bytes_per_launch")
+    except Exception:
+        pass
+    return None
+
+
+def main():
+    args = parse()
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from pota_amd import camera, capi, distributed, lens_io, workload
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs torch.distributed.run with %d ranks" % (args.gpus, args.gpus))
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    dev = torch.device("cuda", local_rank)
+
+    W, Hr, M = args.width, args.height, args.visits_per_pixel
+    H = Hr * world                                  # weak scaling: per-GPU rows stay fixed
+    p = camera.default_params()
+    camera.setup_filter(p, W, H, filter_width=1.0, aa_samples=3)
+    p, model = camera.setup_po(p, args.lens, focus_dist=150.0)
+    p.samples_override = args.samples
+    table, keep = lens_io.make_lens_table(model.spec)
+    tan_half_fov = float(p.sensor_width) * 0.5 / float(p.focal_length)
+
+    ctx = capi.Context(local_rank)
+    ctx.set_params(p)
+    ctx.set_lens(table)
+    ctx.alloc_frame(1 + args.aovs)
+    engine = distributed.HipEngine(ctx)
+    n_local = workload.frame_visit_count(W, H, M, world, rank)
+    bytes_per_visit = 80 + 16 * args.aovs
+
+    def bind(f_hi):
+        cols = workload.generate(torch, 0, n_local, W, H, M, f_hi=f_hi, focus_dist=150.0, tan_half_fov=tan_half_fov,
+                                 n_extra=args.aovs, device=dev, row_stride=world, row_offset=rank)
+        torch.cuda.synchronize()
+        v, kv = capi.make_visits(cols, visits_per_pixel=M, pixels_per_row=W, pixel_y0=rank, pixel_row_stride=world,
+                                 ptr=lambda t: t.data_ptr())
+        ctx.bind_visits(v, kv)
+        return cols
+
+    def run(steps, warmup):
+        for _ in range(warmup):
+            distributed.frame_step(engine, dist)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        scan_ms = draw_ms = res_ms = 0.0
+        for _ in range(steps):
+            distributed.frame_step(engine, dist)
+            # HIP-event times of this step's kernels (the call waits for the step's stream work, which
+            # the step would have to finish anyway before the next clear)
+            a, b, c = ctx.last_timing()
+            scan_ms += a; draw_ms += b; res_ms += c
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt, scan_ms / steps, draw_ms / steps, res_ms / steps
+
+    cols = bind(args.f_hi)
+    dt, scan_ms, draw_ms, res_ms = run(args.steps, args.warmup)
+    ctr = ctx.counters()
+    n_total = workload.frame_visit_count(W, H, M)         # all ranks
+    value = n_total * args.steps / dt / 1e6
+    ms_per_step = dt / args.steps * 1e3
+
+    workload_tag = "%s %dx%d M=%d samples=%d aovs=%d f_hi=%.3g" % (args.lens, W, Hr, M, args.samples, 1 + args.aovs, args.f_hi)
+    achieved = n_local * bytes_per_visit / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
+    out = {
+        "metric": "bidir redistribution Msamples/s at 4K, double-gauss 50mm",
+        "value": round(value, 3), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+        "config": {
+            "workload": "polynomial-optics %s (self-fitted table), %dx%d per GPU, %d visits/pixel, %d redistribution "
+                        "draws per redistributed visit, %d AOV(s), highlight fraction f_hi=%.3g, rows interleaved over %d GPU(s)"
+                        % (args.lens, W, Hr, M, args.samples, 1 + args.aovs, args.f_hi, world),
+            "visits_per_gpu": n_local, "bytes_per_visit": bytes_per_visit,
+            "redistributed_visits_rank0": int(ctr.redistributed_visits),
+            "attempted_draws_rank0": int(ctr.attempted_draws), "accepted_draws_rank0": int(ctr.accepted_draws),
+            "parallelism": "rows%%%d + allreduce" % world if world > 1 else "single GPU",
+        },
+        "kernels_ms": {"scan": round(scan_ms, 4), "draw": round(draw_ms, 4), "resolve": round(res_ms, 4)},
+        "roofline": {
+            "kernel": "scan_uniform_kernel", "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+            "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": load_traffic(workload_tag),
+            "whole_step_frac": round(n_local * bytes_per_visit / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+        },
+        "draw_kernel": {"Mdraws_per_s_attempted": round(ctr.attempted_draws / (draw_ms * 1e-3) / 1e6, 3) if draw_ms > 0 else None},
+    }
+
+    if not args.no_second_regime and world == 1:
+        del cols
+        torch.cuda.empty_cache()
+        f2 = 1.6e-3
+        cols = bind(f2)
+        st = max(1, min(args.steps, 2))
+        dt2, s2, d2, r2 = run(st, 1)
+        c2 = ctx.counters()
+        out["regimes"] = {"highlight_heavy": {
+            "f_hi": f2, "value": round(n_total * st / dt2 / 1e6, 3), "unit": "Msamples/s", "steps": st,
+            "kernels_ms": {"scan": round(s2, 4), "draw": round(d2, 4), "resolve": round(r2, 4)},
+            "attempted_draws": int(c2.attempted_draws),
+            "Mdraws_per_s_attempted": round(c2.attempted_draws / (d2 * 1e-3) / 1e6, 3) if d2 > 0 else None}}
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        try:
+            out["cpu_baseline"] = cpu_baseline(args, p, table, M, tan_half_fov)
+        except Exception as e:      # the GPU number must still be reported
+            out["cpu_baseline"] = {"value": None, "unit": "Msamples/s", "cores": 0, "kind": "port",
+                                   "sample": "failed: %r" % (e,)}
+    if rank == 0:
+        print(json.dumps(out))
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

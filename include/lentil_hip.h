@@ -206,6 +206,9 @@ typedef struct lentil_counters {
   uint64_t attempted_draws;      /* total_samples_taken summed, src/lentil_filter.cpp:248 */
   uint64_t accepted_draws;
   uint64_t worklist_overflow;    /* non-zero => work list too small, results incomplete */
+  uint64_t newton_iterations;    /* lane-iterations of the lt_sample_aperture solver (PO draw kernel) */
+  uint64_t tries;                /* aperture draws = solves started (attempts x vignetting retries) */
+  uint64_t lane_rounds;          /* 64 x scheduler rounds: iteration slots offered (utilisation = iterations / this) */
 } lentil_counters;
 
 /* one accepted draw, for index-parity tests: (visit, attempt n, linear pixel) */
@@ -238,6 +241,14 @@ const char *lentil_hip_last_error(const lentil_hip_ctx *ctx);
 int lentil_hip_set_params(lentil_hip_ctx *ctx, const lentil_params *params);
 int lentil_hip_set_lens(lentil_hip_ctx *ctx, const lentil_lens_table *lens);
 int lentil_hip_set_bokeh(lentil_hip_ctx *ctx, const lentil_bokeh_table *bokeh);
+/* The reference compiles every lens into the plugin (switch(lensModel) over generated code,
+ * src/lentil.h:1262,1278,1308); liblentil_hip likewise carries straight-line kernels for the lens
+ * tables it ships (tools/gen_lens_code.py) and recognises them by a hash of the table passed to
+ * set_lens.  Any other table runs through the LDS table interpreter (same arithmetic, slower).
+ * lens_is_compiled: 1 if the current table has a compiled-in kernel.  set_lens_mode: 0 = auto,
+ * 1 = always interpret the table (parity tests compare the two). */
+int lentil_hip_lens_is_compiled(lentil_hip_ctx *ctx);
+int lentil_hip_set_lens_mode(lentil_hip_ctx *ctx, int mode);
 int lentil_hip_alloc_frame(lentil_hip_ctx *ctx, uint32_t n_aovs, const uint8_t *aov_filter_kind);
 
 /* --- visit stream ------------------------------------------------------------------

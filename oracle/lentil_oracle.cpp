@@ -739,6 +739,7 @@ struct OrcFrame {
   lentil_counters ctr;
   std::vector<lentil_draw_record> log;
   bool keep_log = false;
+  bool shadow = true;             /* keep the fp64 shadow accumulators */
 };
 
 ORC_API OrcFrame *orc_frame_create(uint32_t xres, uint32_t yres, uint32_t n_aovs, const uint8_t *kind,
@@ -746,16 +747,17 @@ ORC_API OrcFrame *orc_frame_create(uint32_t xres, uint32_t yres, uint32_t n_aovs
   OrcFrame *F = new OrcFrame();
   F->xres = xres; F->yres = yres; F->n_aovs = n_aovs;
   const size_t np = (size_t)xres * yres;
+  F->keep_log = (keep_log & 1) != 0;
+  F->shadow = (keep_log & 2) == 0;      /* flag bit 1: timing runs skip the fp64 shadows */
   for (uint32_t a = 0; a < n_aovs; a++) {
     F->kind[a] = kind ? kind[a] : LENTIL_FILTER_GAUSSIAN;
     F->buffer[a].assign(np * 4, 0.0f);
-    F->buffer64[a].assign(np * 4, 0.0);
+    if (F->shadow) F->buffer64[a].assign(np * 4, 0.0);
   }
   F->weight.assign(np, 0.0f);
-  F->weight64.assign(np, 0.0);
+  if (F->shadow) F->weight64.assign(np, 0.0);
   F->zbuffer.assign(np, 0.0f);
   memset(&F->ctr, 0, sizeof(F->ctr));
-  F->keep_log = keep_log != 0;
   return F;
 }
 ORC_API void orc_frame_destroy(OrcFrame *F) { delete F; }
@@ -783,17 +785,17 @@ ORC_API void orc_frame_merge(OrcFrame *dst, const OrcFrame *src) {   /* per-thre
 static inline void add_to_buffer(OrcFrame *F, uint32_t aov, uint32_t px, const float value[4],
                                  float add_energy, float depth, float filter_weight) {
   if (F->kind[aov] == LENTIL_FILTER_GAUSSIAN) {
-    if (aov == 0) { F->weight[px] += filter_weight; F->weight64[px] += (double)filter_weight; }
+    if (aov == 0) { F->weight[px] += filter_weight; if (F->shadow) F->weight64[px] += (double)filter_weight; }
     for (int c = 0; c < 4; c++) {
       const float add = (value[c] + add_energy) * filter_weight * 1.0f;
       F->buffer[aov][(size_t)px * 4 + c] += add;
-      F->buffer64[aov][(size_t)px * 4 + c] += (double)add;
+      if (F->shadow) F->buffer64[aov][(size_t)px * 4 + c] += (double)add;
     }
   } else if (F->kind[aov] == LENTIL_FILTER_CLOSEST) {
     if ((std::abs(depth) <= F->zbuffer[px]) || F->zbuffer[px] == 0.0) {
       for (int c = 0; c < 4; c++) {
         F->buffer[aov][(size_t)px * 4 + c] = value[c];
-        F->buffer64[aov][(size_t)px * 4 + c] = value[c];
+        if (F->shadow) F->buffer64[aov][(size_t)px * 4 + c] = value[c];
       }
       F->zbuffer[px] = std::abs(depth);
     }

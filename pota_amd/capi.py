@@ -22,6 +22,7 @@ EXPORTS = [
     "lentil_hip_get_counters", "lentil_hip_last_timing", "lentil_hip_set_draw_log",
     "lentil_hip_download_draw_log", "lentil_hip_test_lt_sample_aperture",
     "lentil_hip_test_trace_bw_po", "lentil_hip_test_aperture_sample",
+    "lentil_hip_lens_is_compiled", "lentil_hip_set_lens_mode",
 ]
 
 _lib = None
@@ -38,6 +39,15 @@ def load_library():
     global _lib
     if _lib is not None:
         return _lib
+    # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64.so.7 (same SONAME as
+    # /opt/rocm's).  If torch is going to be used in this process (device memory, RCCL) it must be
+    # loaded first so that this library binds to the runtime torch uses; loading /opt/rocm's runtime
+    # first leaves torch without a visible GPU.
+    if os.environ.get("LENTIL_NO_TORCH") != "1":
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
     if not os.path.exists(LIB_PATH):
         raise FileNotFoundError(
             "%s is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'`" % LIB_PATH)
@@ -69,6 +79,8 @@ def load_library():
         "lentil_hip_test_lt_sample_aperture": (i, [vp, u64, vp, vp, C.c_double, vp, vp, vp]),
         "lentil_hip_test_trace_bw_po": (i, [vp, u64, vp, vp, vp, vp, vp, vp]),
         "lentil_hip_test_aperture_sample": (i, [vp, u64, vp, vp, vp]),
+        "lentil_hip_lens_is_compiled": (i, [vp]),
+        "lentil_hip_set_lens_mode": (i, [vp, i]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)
@@ -141,6 +153,13 @@ class Context:
 
     def set_lens(self, table):
         self._chk(self.lib.lentil_hip_set_lens(self.h, C.byref(table)))
+
+    def lens_is_compiled(self):
+        return bool(self.lib.lentil_hip_lens_is_compiled(self.h))
+
+    def set_lens_mode(self, mode):
+        """0 = compiled-in kernel when the table is a shipped lens, 1 = always the table interpreter."""
+        self._chk(self.lib.lentil_hip_set_lens_mode(self.h, mode))
 
     def set_bokeh(self, tables):
         """tables: dict with x, y, cdfRow, rowIndices, cdfColumn, columnIndices (numpy) or None."""

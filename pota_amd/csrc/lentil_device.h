@@ -317,75 +317,118 @@ struct LdsLens {
 // evidenced by tests/aperture_sampling_debug/writout.txt: all polynomials of an iteration
 // at the iteration's begin state; aperture step undamped; outer-pupil step damped 0.72;
 // error bits reset while k < 10; tolerance 1e-8 on both squared errors.
-// Returns the transmittance (>= 0).  sensor = (x, y, dx, dy).
+// Split into init / continue? / one iteration / finish so that the draw kernel can advance
+// many independent solves in lock step (one iteration per lane per round).
 // ---------------------------------------------------------------------------------------
+struct NewtonState {
+  double x, y, dx, dy;
+  double sqr_err, sqr_ap_err;
+  double out[4];
+  int k, error;
+};
+
+LD_DEV void newton_init(NewtonState &s) {
+  s.x = 0; s.y = 0; s.dx = 0; s.dy = 0;
+  s.sqr_err = 1e30; s.sqr_ap_err = 1e30;
+  s.out[0] = s.out[1] = s.out[2] = s.out[3] = 0.0;
+  s.k = 0; s.error = 0;
+}
+
+LD_DEV bool newton_continue(const NewtonState &s) {
+  const double eps = 1e-8;
+  return s.k < 100 && (s.sqr_err > eps || s.sqr_ap_err > eps) && s.error == 0;
+}
+
+template <class Lens>
+LD_DEV void newton_iter(const Lens &L, const double scene[3], double ap_x, double ap_y, NewtonState &s) {
+  const DevLens &k = L.consts();
+  const double R = k.outer_pupil_curvature_radius;
+  const double prev_sqr_err = s.sqr_err, prev_sqr_ap_err = s.sqr_ap_err;
+  const double begin[4] = {s.x, s.y, s.dx, s.dy};
+  double pred_ap[2], Jap[4], Jout[4];
+  L.eval_bw(begin, pred_ap, Jap, s.out, Jout);
+  const double d0 = ap_x - pred_ap[0], d1 = ap_y - pred_ap[1];
+  s.sqr_ap_err = d0 * d0 + d1 * d1;
+  {
+    const double invdet = 1.0 / (Jap[0] * Jap[3] - Jap[1] * Jap[2]);
+    const double i00 = Jap[3] * invdet, i11 = Jap[0] * invdet;
+    const double i01 = -Jap[1] * invdet, i10 = -Jap[2] * invdet;
+    s.dx += i00 * d0; s.dy += i10 * d0;
+    s.dx += i01 * d1; s.dy += i11 * d1;
+  }
+  double pos[3], dir[3];
+  double on_dx, on_dy;
+  // the view vector is normalised once here and once more inside csTo*, like the generated code
+  if (k.outer_pupil_geometry == LENTIL_GEOM_SPHERICAL) {
+    sphereToCs(s.out[0], s.out[1], s.out[2], s.out[3], pos, dir, -R, R);
+    double vx = scene[0] - pos[0], vy = scene[1] - pos[1], vz = scene[2] - pos[2];
+    normalise3(vx, vy, vz);
+    csToSphere(pos, vx, vy, vz, on_dx, on_dy, -R, R);
+  } else {
+    const bool cy = k.outer_pupil_geometry == LENTIL_GEOM_CYL_Y;
+    cylinderToCs(s.out[0], s.out[1], s.out[2], s.out[3], pos, dir, -R, R, cy);
+    double vx = scene[0] - pos[0], vy = scene[1] - pos[1], vz = scene[2] - pos[2];
+    normalise3(vx, vy, vz);
+    csToCylinder(pos, vx, vy, vz, on_dx, on_dy, -R, R, cy);
+  }
+  const double e0 = on_dx - s.out[2], e1 = on_dy - s.out[3];
+  s.sqr_err = e0 * e0 + e1 * e1;
+  {
+    const double invdet = 1.0 / (Jout[0] * Jout[3] - Jout[1] * Jout[2]);
+    const double i00 = Jout[3] * invdet, i11 = Jout[0] * invdet;
+    const double i01 = -Jout[1] * invdet, i10 = -Jout[2] * invdet;
+    s.x += 0.72 * i00 * e0; s.y += 0.72 * i10 * e0;
+    s.x += 0.72 * i01 * e1; s.y += 0.72 * i11 * e1;
+  }
+  int error = s.error;
+  if (s.sqr_err > prev_sqr_err) error |= 1;
+  if (s.sqr_ap_err > prev_sqr_ap_err) error |= 2;
+  if (s.out[0] != s.out[0]) error |= 4;
+  if (s.out[2] * s.out[2] + s.out[3] * s.out[3] > 1.0) error |= 8;
+  if (s.k < 10) error = 0;
+  s.error = error;
+  s.k += 1;
+}
+
+// after the loop: outer-pupil radius test + transmittance (0 on error); returns max(0, T)
+template <class Lens>
+LD_DEV double newton_finish(const Lens &L, const NewtonState &s, double &out4) {
+  const DevLens &k = L.consts();
+  int error = s.error;
+  if (s.out[0] * s.out[0] + s.out[1] * s.out[1] > k.outer_pupil_radius * k.outer_pupil_radius) error |= 16;
+  if (error == 0) {
+    const double begin[4] = {s.x, s.y, s.dx, s.dy};
+    out4 = L.transmittance(begin);
+  } else {
+    out4 = 0.0;
+  }
+  return fmax(0.0, out4);
+}
+
+// Returns the transmittance (>= 0).  sensor = (x, y, dx, dy).
 template <class Lens>
 LD_DEV double lt_sample_aperture(const Lens &L, const double scene[3], double ap_x, double ap_y,
                                  double sensor[4], double out[5], int *iters = nullptr) {
-  const DevLens &k = L.consts();
-  const double R = k.outer_pupil_curvature_radius;
-  double x = 0, y = 0, dx = 0, dy = 0;
-  int error = 0;
-  const double eps = 1e-8;
-  double sqr_err = 1e30, sqr_ap_err = 1e30;
-  double prev_sqr_err = 1e32, prev_sqr_ap_err = 1e32;
-  int kk = 0;
-  for (; kk < 100 && (sqr_err > eps || sqr_ap_err > eps) && error == 0; kk++) {
-    prev_sqr_err = sqr_err;
-    prev_sqr_ap_err = sqr_ap_err;
-    const double begin[4] = {x, y, dx, dy};
-    double pred_ap[2], Jap[4], Jout[4];
-    L.eval_bw(begin, pred_ap, Jap, out, Jout);
-    const double d0 = ap_x - pred_ap[0], d1 = ap_y - pred_ap[1];
-    sqr_ap_err = d0 * d0 + d1 * d1;
-    {
-      const double invdet = 1.0 / (Jap[0] * Jap[3] - Jap[1] * Jap[2]);
-      const double i00 = Jap[3] * invdet, i11 = Jap[0] * invdet;
-      const double i01 = -Jap[1] * invdet, i10 = -Jap[2] * invdet;
-      dx += i00 * d0; dy += i10 * d0;
-      dx += i01 * d1; dy += i11 * d1;
-    }
-    double pos[3], dir[3];
-    double on_dx, on_dy;
-    // the view vector is normalised once here and once more inside csTo*, like the generated code
-    if (k.outer_pupil_geometry == LENTIL_GEOM_SPHERICAL) {
-      sphereToCs(out[0], out[1], out[2], out[3], pos, dir, -R, R);
-      double vx = scene[0] - pos[0], vy = scene[1] - pos[1], vz = scene[2] - pos[2];
-      normalise3(vx, vy, vz);
-      csToSphere(pos, vx, vy, vz, on_dx, on_dy, -R, R);
-    } else {
-      const bool cy = k.outer_pupil_geometry == LENTIL_GEOM_CYL_Y;
-      cylinderToCs(out[0], out[1], out[2], out[3], pos, dir, -R, R, cy);
-      double vx = scene[0] - pos[0], vy = scene[1] - pos[1], vz = scene[2] - pos[2];
-      normalise3(vx, vy, vz);
-      csToCylinder(pos, vx, vy, vz, on_dx, on_dy, -R, R, cy);
-    }
-    const double e0 = on_dx - out[2], e1 = on_dy - out[3];
-    sqr_err = e0 * e0 + e1 * e1;
-    {
-      const double invdet = 1.0 / (Jout[0] * Jout[3] - Jout[1] * Jout[2]);
-      const double i00 = Jout[3] * invdet, i11 = Jout[0] * invdet;
-      const double i01 = -Jout[1] * invdet, i10 = -Jout[2] * invdet;
-      x += 0.72 * i00 * e0; y += 0.72 * i10 * e0;
-      x += 0.72 * i01 * e1; y += 0.72 * i11 * e1;
-    }
-    if (sqr_err > prev_sqr_err) error |= 1;
-    if (sqr_ap_err > prev_sqr_ap_err) error |= 2;
-    if (out[0] != out[0]) error |= 4;
-    if (out[2] * out[2] + out[3] * out[3] > 1.0) error |= 8;
-    if (kk < 10) error = 0;
-  }
-  if (out[0] * out[0] + out[1] * out[1] > k.outer_pupil_radius * k.outer_pupil_radius) error |= 16;
-  if (error == 0) {
-    const double begin[4] = {x, y, dx, dy};
-    out[4] = L.transmittance(begin);
-  } else {
-    out[4] = 0.0;
-  }
-  if (iters) *iters = kk;
-  sensor[0] = x; sensor[1] = y; sensor[2] = dx; sensor[3] = dy;
-  return fmax(0.0, out[4]);
+  NewtonState s;
+  newton_init(s);
+  while (newton_continue(s)) newton_iter(L, scene, ap_x, ap_y, s);
+  const double T = newton_finish(L, s, out[4]);
+  out[0] = s.out[0]; out[1] = s.out[1]; out[2] = s.out[2]; out[3] = s.out[3];
+  if (iters) *iters = s.k;
+  sensor[0] = s.x; sensor[1] = s.y; sensor[2] = s.dx; sensor[3] = s.dy;
+  return T;
 }
+
+// Compiled-in lens (tools/gen_lens_code.py): coefficients are literals, nothing read from LDS.
+template <class Gen>
+struct GenLens {
+  const DevLens *k;       // LDS copy of the header (constants + lambda powers)
+  LD_DEV void eval_bw(const double v[4], double pred_ap[2], double Jap[4], double out[4], double Jout[4]) const {
+    Gen::eval_bw(v, k->lambda_pow, pred_ap, Jap, out, Jout);
+  }
+  LD_DEV double transmittance(const double v[4]) const { return Gen::transmittance(v, k->lambda_pow); }
+  LD_DEV const DevLens &consts() const { return *k; }
+};
 
 // ---------------------------------------------------------------------------------------
 // Aperture draw of trace_ray_bw_po, src/lentil.h:596-609 (GCC argument order: see oracle)

@@ -11,12 +11,14 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
 #include <vector>
 
 #include "lentil_device.h"
+#include "generated/lens_registry.h"
 
 using namespace lentil;
 
@@ -34,6 +36,9 @@ struct DevCounters {
   unsigned long long accepted;
   unsigned long long overflow;
   unsigned long long log_count;
+  unsigned long long newton_iters;   // lane-iterations of the Newton solver (draw kernel)
+  unsigned long long tries;          // aperture draws / solves started
+  unsigned long long lane_rounds;    // 64 x scheduler rounds (issue slots offered)
 };
 
 struct VisitsDev {
@@ -274,59 +279,227 @@ __global__ __launch_bounds__(256) void scan_ragged_kernel(ScanArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------
-// K3/K4/K5: draws.  One wave per work item; lanes are consecutive attempts n.  A chunk never
-// holds more attempts than accepted draws are still missing, so "the first `samples` successes
-// in attempt order" (src/lentil_filter.cpp:248,272,285) is reproduced exactly without ranking.
+// K3/K4/K5: draws.  One wave per work item (redistributed visit).
+//
+// Acceptance rule of the reference (src/lentil_filter.cpp:248,272,285): the accepted draws are the
+// first `samples` successes among attempts n = 0 .. 5*samples-1, in attempt order.  Both variants
+// below start attempts strictly in increasing n and never have more attempts outstanding than
+// accepted draws are still missing, so every success they see belongs to that set -- no ranking,
+// no ordered commit.
+//
+// Polynomial optics (draw_po_kernel): a lane-level scheduler.  Every round each busy lane advances
+// its own Newton solve by ONE iteration (the straight-line polynomial block, ~2k fp64 ops, runs
+// with a full exec mask); lanes whose solve ended finish it (pupil tests, retry with the next
+// aperture draw, or sensor->pixel + atomic splat) and are refilled with the next attempt.  Solves
+// that need 11 or 40 iterations, or 1 or 16 vignetting retries, no longer hold 63 other lanes.
 // ---------------------------------------------------------------------------------------
 constexpr int kMaxBokehRows = 2048;
 
-template <int MODE>   // 0: polynomial optics, table-driven; 1: thin lens
-__global__ __launch_bounds__(256) void draw_kernel(DrawArgs a) {
-  __shared__ DevTerm s_terms[MODE == 0 ? kMaxTerms : 1];
+struct Splat {
+  const DrawArgs &a;
+  uint32_t visit;
+  float4 rgba;
+  float ae, w;
+  LD_DEV void operator()(uint32_t pix, uint32_t attempt) const {
+    // Camera::add_to_buffer, src/lentil.h:827-830
+    float *d = a.F.acc + (size_t)pix * 4;
+    atomicAdd(d + 0, (rgba.x + ae) * w);
+    atomicAdd(d + 1, (rgba.y + ae) * w);
+    atomicAdd(d + 2, (rgba.z + ae) * w);
+    atomicAdd(d + 3, (rgba.w + ae) * w);
+    atomicAdd(a.F.weight + pix, w);
+    for (uint32_t k = 0; k < a.V.n_extra; ++k) {
+      const float4 c = a.V.extra[k][visit];
+      float *dk = a.F.acc + ((size_t)(k + 1) * a.F.np + pix) * 4;
+      atomicAdd(dk + 0, (c.x + ae) * w);
+      atomicAdd(dk + 1, (c.y + ae) * w);
+      atomicAdd(dk + 2, (c.z + ae) * w);
+      atomicAdd(dk + 3, (c.w + ae) * w);
+    }
+    if (a.log_cap) {
+      const unsigned long long li = atomicAdd(&a.ctr->log_count, 1ull);
+      if (li < a.log_cap) { a.log[li].visit = visit; a.log[li].attempt = attempt; a.log[li].pixel = pix; }
+    }
+  }
+};
+
+struct ItemHeader {
+  uint32_t visit, samples;
+  int px, py;
+  VisitInfo I;
+  float4 rgba;
+  float w;
+};
+
+LD_DEV ItemHeader load_item(const DrawArgs &a, unsigned long long item, double lens_length) {
+  ItemHeader h;
+  const uint2 wi = a.work[item];
+  h.visit = __builtin_amdgcn_readfirstlane(wi.x);
+  h.samples = __builtin_amdgcn_readfirstlane(wi.y);
+  const uint32_t v = h.visit;
+  h.rgba = a.V.rgba[v];
+  const float invd = a.V.inv_density ? a.V.inv_density[v] : a.P.inverse_sample_density;
+  h.I = visit_prologue(a.P, lens_length, h.rgba, a.V.pos_z[v], a.V.raydir_time[v], a.V.volume_ignore[v],
+                       a.V.transmission[v], invd);
+  visit_pixel(a.V, v, h.px, h.py);
+  const float inv_samples = (float)(1.0 / (double)(float)(int)h.samples);
+  h.w = 1.0f * invd * inv_samples;              // src/lentil_filter.cpp:297
+  return h;
+}
+
+template <class LensT>
+LD_DEV void po_item(const DrawArgs &a, const LensT &L, const float *cdfRow, const ItemHeader &h,
+                    unsigned long long &tot_attempted, unsigned long long &tot_accepted, uint32_t &st_iters,
+                    uint32_t &st_tries, uint32_t &st_rounds) {
+  const lentil_params &P = a.P;
+  const DevLens &k = L.consts();
+  const uint32_t lane = lane_id();
+  const unsigned long long lt_mask = (1ull << lane) - 1ull;
+  const double target[3] = {-(double)h.I.cs[0] * 10.0, -(double)h.I.cs[1] * 10.0, -(double)h.I.cs[2] * 10.0};
+  const Splat splat{a, h.visit, h.rgba, h.I.add_energy, h.w};
+  const uint32_t samples = h.samples, max_total = samples * 5u;
+  const uint32_t seed_a = (uint32_t)(h.px * h.py + h.px);
+
+  uint32_t accepted = 0, next_attempt = 0, last_ok = 0;
+  bool busy = false, need_init = false;
+  uint32_t n = 0;
+  int t = 0;
+  double ap_x = 0.0, ap_y = 0.0;
+  NewtonState s;
+  newton_init(s);
+
+  while (true) {
+    // ---- refill idle lanes with the next attempts
+    const unsigned long long busy_mask = __ballot(busy);
+    const uint32_t inflight = (uint32_t)__builtin_popcountll(busy_mask);
+    uint32_t nstart = samples - accepted - inflight;
+    if (nstart > max_total - next_attempt) nstart = max_total - next_attempt;
+    const unsigned long long idle_mask = ~busy_mask;
+    const uint32_t n_idle = 64u - inflight;
+    if (nstart > n_idle) nstart = n_idle;
+    if (!busy) {
+      const uint32_t my_rank = (uint32_t)__builtin_popcountll(idle_mask & lt_mask);
+      if (my_rank < nstart) { busy = true; need_init = true; n = next_attempt + my_rank; t = 0; }
+    }
+    next_attempt += nstart;
+    if (inflight + nstart == 0u) break;
+
+    // ---- (re)start a solve: aperture draw for (attempt n, try t), src/lentil.h:596-609
+    if (busy && need_init) {
+      po_aperture_sample(P, a.bokeh, cdfRow, seed_a, n + (uint32_t)t, ap_x, ap_y);
+      newton_init(s);
+      need_init = false;
+      ++st_tries;
+    }
+    // ---- one Newton iteration for every busy lane
+    if (busy) { newton_iter(L, target, ap_x, ap_y, s); ++st_iters; }
+    ++st_rounds;
+
+    // ---- lanes whose solve ended
+    bool succ = false;
+    if (busy && !newton_continue(s)) {
+      double out4;
+      const float transmittance = (float)newton_finish(L, s, out4);
+      bool try_ok = !(transmittance <= 0);
+      if (try_ok) {
+        const double ipx = s.x + s.dx * k.back_focal_length;
+        const double ipy = s.y + s.dy * k.back_focal_length;
+        if (ipx * ipx + ipy * ipy > k.inner_pupil_radius * k.inner_pupil_radius) try_ok = false;
+      }
+      if (try_ok) {
+        const double sx = s.x + s.dx * -P.sensor_shift;
+        const double sy = s.y + s.dy * -P.sensor_shift;
+        uint32_t pix;
+        if (po_sensor_to_pixel(P, sx, sy, pix)) {
+          succ = true;
+          splat(pix, n);
+          if (n > last_ok) last_ok = n;
+        }
+        busy = false;
+      } else {
+        ++t;
+        if (t > P.vignetting_retries) busy = false; else need_init = true;
+      }
+    }
+    accepted += (uint32_t)__builtin_popcountll(__ballot(succ));
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    const uint32_t o = __shfl_down(last_ok, off);
+    if (o > last_ok) last_ok = o;
+  }
+  last_ok = __shfl(last_ok, 0);
+  tot_attempted += (accepted == samples) ? (unsigned long long)last_ok + 1ull : (unsigned long long)max_total;
+  tot_accepted += accepted;
+}
+
+template <class LensT, bool kTables>
+__global__ __launch_bounds__(256) void draw_po_kernel(DrawArgs a) {
+  __shared__ DevTerm s_terms[kTables ? kMaxTerms : 1];
   __shared__ DevLens s_k;
   __shared__ float s_cdfRow[kMaxBokehRows];
-
-  if (MODE == 0) {
+  if (kTables) {
     const uint32_t nt = a.lens->n_terms;
     for (uint32_t i = threadIdx.x; i < nt; i += blockDim.x) s_terms[i] = a.terms[i];
-    if (threadIdx.x == 0) s_k = *a.lens;
   }
+  if (threadIdx.x == 0) s_k = *a.lens;
   const bool row_in_lds = a.P.bokeh_enable_image && a.bokeh.y <= kMaxBokehRows;
   if (row_in_lds)
     for (int i = threadIdx.x; i < a.bokeh.y; i += blockDim.x) s_cdfRow[i] = a.bokeh.cdfRow[i];
   __syncthreads();
   const float *cdfRow = row_in_lds ? s_cdfRow : a.bokeh.cdfRow;
-  const LdsLens L{s_terms, &s_k};
+  LensT L;
+  if constexpr (kTables) { L.terms = s_terms; L.k = &s_k; } else { L.k = &s_k; }
 
   const uint32_t lane = threadIdx.x & 63u;
-  const VisitsDev &V = a.V;
-  const lentil_params &P = a.P;
   unsigned long long n_items = a.ctr->work_count;
   if (n_items > a.work_cap) n_items = a.work_cap;
   unsigned long long tot_attempted = 0, tot_accepted = 0;
-
+  uint32_t st_iters = 0, st_tries = 0, st_rounds = 0;
   while (true) {
     unsigned long long item = 0;
     if (lane == 0) item = atomicAdd(&a.ctr->queue_head, 1ull);
     item = __shfl(item, 0);
     if (item >= n_items) break;
-    const uint2 wi = a.work[item];
-    const uint32_t v = __builtin_amdgcn_readfirstlane(wi.x);
-    const uint32_t samples = __builtin_amdgcn_readfirstlane(wi.y);
+    const ItemHeader h = load_item(a, item, s_k.length);
+    po_item(a, L, cdfRow, h, tot_attempted, tot_accepted, st_iters, st_tries, st_rounds);
+  }
+  unsigned long long it64 = st_iters, tr64 = st_tries, rd64 = st_rounds;
+  for (int off = 32; off > 0; off >>= 1) {
+    it64 += __shfl_down(it64, off);
+    tr64 += __shfl_down(tr64, off);
+    rd64 += __shfl_down(rd64, off);
+  }
+  if (lane == 0) {
+    if (tot_attempted) atomicAdd(&a.ctr->attempted, tot_attempted);
+    if (tot_accepted) atomicAdd(&a.ctr->accepted, tot_accepted);
+    if (it64) atomicAdd(&a.ctr->newton_iters, it64);
+    if (tr64) atomicAdd(&a.ctr->tries, tr64);
+    if (rd64) atomicAdd(&a.ctr->lane_rounds, rd64);
+  }
+}
 
-    const float4 rgba = V.rgba[v];
-    const float invd = V.inv_density ? V.inv_density[v] : P.inverse_sample_density;
-    const VisitInfo I = visit_prologue(P, MODE == 0 ? s_k.length : 0.0, rgba, V.pos_z[v], V.raydir_time[v],
-                                       V.volume_ignore[v], V.transmission[v], invd);
-    int px, py;
-    visit_pixel(V, v, px, py);
-    const double target[3] = {-(double)I.cs[0] * 10.0, -(double)I.cs[1] * 10.0, -(double)I.cs[2] * 10.0};
-    const float inv_samples = (float)(1.0 / (double)(float)(int)samples);
-    const float w = 1.0f * invd * inv_samples;              // src/lentil_filter.cpp:297
-    const float ae = I.add_energy;
-
+// Thin lens (K4): closed form, no retries -- lanes are consecutive attempts, a chunk never holds
+// more attempts than accepted draws are still missing.
+__global__ __launch_bounds__(256) void draw_thinlens_kernel(DrawArgs a) {
+  __shared__ float s_cdfRow[kMaxBokehRows];
+  const bool row_in_lds = a.P.bokeh_enable_image && a.bokeh.y <= kMaxBokehRows;
+  if (row_in_lds)
+    for (int i = threadIdx.x; i < a.bokeh.y; i += blockDim.x) s_cdfRow[i] = a.bokeh.cdfRow[i];
+  __syncthreads();
+  const float *cdfRow = row_in_lds ? s_cdfRow : a.bokeh.cdfRow;
+  const uint32_t lane = threadIdx.x & 63u;
+  unsigned long long n_items = a.ctr->work_count;
+  if (n_items > a.work_cap) n_items = a.work_cap;
+  unsigned long long tot_attempted = 0, tot_accepted = 0;
+  while (true) {
+    unsigned long long item = 0;
+    if (lane == 0) item = atomicAdd(&a.ctr->queue_head, 1ull);
+    item = __shfl(item, 0);
+    if (item >= n_items) break;
+    const ItemHeader h = load_item(a, item, 0.0);
+    const Splat splat{a, h.visit, h.rgba, h.I.add_energy, h.w};
     uint32_t accepted = 0, n_base = 0;
-    const uint32_t max_total = samples * 5u;
+    const uint32_t samples = h.samples, max_total = samples * 5u;
     while (accepted < samples && n_base < max_total) {
       uint32_t chunk = samples - accepted;
       if (chunk > 64u) chunk = 64u;
@@ -334,36 +507,8 @@ __global__ __launch_bounds__(256) void draw_kernel(DrawArgs a) {
       const uint32_t n = n_base + lane;
       bool ok = false;
       uint32_t pix = 0;
-      if (lane < chunk) {
-        if (MODE == 0) {
-          double sx, sy;
-          ok = trace_ray_bw_po(P, L, a.bokeh, cdfRow, target, px, py, (int)n, sx, sy);
-          if (ok) ok = po_sensor_to_pixel(P, sx, sy, pix);
-        } else {
-          ok = thinlens_draw(P, a.bokeh, cdfRow, I.cs, px, py, n, pix);
-        }
-      }
-      if (ok) {
-        // Camera::add_to_buffer, src/lentil.h:827-830
-        float *d = a.F.acc + (size_t)pix * 4;
-        atomicAdd(d + 0, (rgba.x + ae) * w);
-        atomicAdd(d + 1, (rgba.y + ae) * w);
-        atomicAdd(d + 2, (rgba.z + ae) * w);
-        atomicAdd(d + 3, (rgba.w + ae) * w);
-        atomicAdd(a.F.weight + pix, w);
-        for (uint32_t k = 0; k < V.n_extra; ++k) {
-          const float4 c = V.extra[k][v];
-          float *dk = a.F.acc + ((size_t)(k + 1) * a.F.np + pix) * 4;
-          atomicAdd(dk + 0, (c.x + ae) * w);
-          atomicAdd(dk + 1, (c.y + ae) * w);
-          atomicAdd(dk + 2, (c.z + ae) * w);
-          atomicAdd(dk + 3, (c.w + ae) * w);
-        }
-        if (a.log_cap) {
-          const unsigned long long li = atomicAdd(&a.ctr->log_count, 1ull);
-          if (li < a.log_cap) { a.log[li].visit = v; a.log[li].attempt = n; a.log[li].pixel = pix; }
-        }
-      }
+      if (lane < chunk) ok = thinlens_draw(a.P, a.bokeh, cdfRow, h.I.cs, h.px, h.py, n, pix);
+      if (ok) splat(pix, n);
       accepted += (uint32_t)__builtin_popcountll(__ballot(ok));
       n_base += chunk;
     }
@@ -471,6 +616,8 @@ struct lentil_hip_ctx {
   DevLens *d_lens = nullptr;
   DevTerm *d_terms = nullptr;
   bool have_lens = false;
+  unsigned long long lens_hash = 0;   // FNV-1a of the base table, matches gen::Lens_*::kTableHash
+  bool use_generated = true;          // LENTIL_FORCE_TABLES=1 forces the table interpreter
 
   DevBokeh bokeh{};
   bool have_bokeh = false;
@@ -537,6 +684,7 @@ LENTIL_API int lentil_hip_create(int device, lentil_hip_ctx **out_ctx) {
   for (auto &ev : ctx->ev) HIP_TRY(ctx, hipEventCreate(&ev));
   HIP_TRY(ctx, hipMalloc(&ctx->d_ctr, sizeof(DevCounters)));
   HIP_TRY(ctx, hipMemsetAsync(ctx->d_ctr, 0, sizeof(DevCounters), ctx->stream));
+  if (const char *ft = getenv("LENTIL_FORCE_TABLES")) ctx->use_generated = !(ft[0] == '1');
   *out_ctx = ctx;
   return LENTIL_OK;
 }
@@ -660,6 +808,25 @@ LENTIL_API int lentil_hip_set_lens(lentil_hip_ctx *ctx, const lentil_lens_table 
   h.outer_pupil_curvature_radius = t->lens_outer_pupil_curvature_radius;
   h.outer_pupil_geometry = t->lens_outer_pupil_geometry;
   h.n_terms = (uint32_t)terms.size();
+  {  // FNV-1a over the base table (tools/gen_lens_code.py: table_hash) -> compiled-in specialisation
+    unsigned long long hs = 0xCBF29CE484222325ull;
+    auto mix = [&](const void *p, size_t n) {
+      const unsigned char *b = (const unsigned char *)p;
+      for (size_t i = 0; i < n; ++i) hs = (hs ^ b[i]) * 0x100000001B3ull;
+    };
+    auto poly = [&](const lentil_poly &pl) {
+      for (uint32_t i = 0; i < pl.count; ++i) {
+        const lentil_term &tt = t->terms[pl.first + i];
+        mix(&tt.c, 8);
+        mix(tt.e, 5);
+      }
+      const unsigned char sep = 0xFF;
+      mix(&sep, 1);
+    };
+    for (int i = 0; i < 5; ++i) poly(t->out[i]);
+    for (int i = 0; i < 4; ++i) poly(t->ap[i]);
+    ctx->lens_hash = hs;
+  }
   const double lam = ctx->have_params ? (double)ctx->P.lambda_bw : (double)0.55f;
   for (int e = 0; e <= kMaxExp; ++e) h.lambda_pow[e] = host_ipow(lam, e);
   HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -671,6 +838,21 @@ LENTIL_API int lentil_hip_set_lens(lentil_hip_ctx *ctx, const lentil_lens_table 
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   ctx->have_lens = true;
   return LENTIL_OK;
+}
+
+LENTIL_API int lentil_hip_set_lens_mode(lentil_hip_ctx *ctx, int mode) {
+  CHECK_CTX(ctx);
+  if (mode != 0 && mode != 1) return fail(ctx, LENTIL_ERR_INVALID, "lens mode must be 0 (auto) or 1 (tables)");
+  ctx->use_generated = (mode == 0);
+  return LENTIL_OK;
+}
+
+LENTIL_API int lentil_hip_lens_is_compiled(lentil_hip_ctx *ctx) {
+  if (!ctx || !ctx->have_lens) return 0;
+#define LENTIL_HASH_MATCH(NAME) if (ctx->lens_hash == gen::Lens_##NAME::kTableHash) return 1;
+  LENTIL_GENERATED_LENSES(LENTIL_HASH_MATCH)
+#undef LENTIL_HASH_MATCH
+  return 0;
 }
 
 LENTIL_API int lentil_hip_set_bokeh(lentil_hip_ctx *ctx, const lentil_bokeh_table *b) {
@@ -891,10 +1073,21 @@ LENTIL_API int lentil_hip_redistribute(lentil_hip_ctx *ctx) {
     da.log = ctx->d_log;
     da.log_cap = ctx->log_cap;
     const unsigned blocks = (unsigned)ctx->num_cu * 4;
-    if (P.cameraType == LENTIL_POLYNOMIAL_OPTICS)
-      hipLaunchKernelGGL(draw_kernel<0>, dim3(blocks), dim3(256), 0, ctx->stream, da);
-    else
-      hipLaunchKernelGGL(draw_kernel<1>, dim3(blocks), dim3(256), 0, ctx->stream, da);
+    if (P.cameraType == LENTIL_POLYNOMIAL_OPTICS) {
+      bool launched = false;
+#define LENTIL_LAUNCH_GEN(NAME)                                                                        \
+      if (!launched && ctx->use_generated && ctx->lens_hash == gen::Lens_##NAME::kTableHash) {          \
+        hipLaunchKernelGGL((draw_po_kernel<GenLens<gen::Lens_##NAME>, false>), dim3(blocks), dim3(256), 0, \
+                           ctx->stream, da);                                                           \
+        launched = true;                                                                               \
+      }
+      LENTIL_GENERATED_LENSES(LENTIL_LAUNCH_GEN)
+#undef LENTIL_LAUNCH_GEN
+      if (!launched)
+        hipLaunchKernelGGL((draw_po_kernel<LdsLens, true>), dim3(blocks), dim3(256), 0, ctx->stream, da);
+    } else {
+      hipLaunchKernelGGL(draw_thinlens_kernel, dim3(blocks), dim3(256), 0, ctx->stream, da);
+    }
     HIP_TRY(ctx, hipGetLastError());
   }
   HIP_TRY(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
@@ -975,6 +1168,9 @@ LENTIL_API int lentil_hip_get_counters(lentil_hip_ctx *ctx, lentil_counters *out
   out->attempted_draws = c.attempted;
   out->accepted_draws = c.accepted;
   out->worklist_overflow = c.overflow;
+  out->newton_iterations = c.newton_iters;
+  out->tries = c.tries;
+  out->lane_rounds = c.lane_rounds;
   return LENTIL_OK;
 }
 

@@ -83,10 +83,10 @@ def darr(*vals):
 class Frame:
     """Oracle frame wrapper: run visits, read buffers as numpy."""
 
-    def __init__(self, lib, params, n_aovs=1, kinds=None, keep_log=False):
+    def __init__(self, lib, params, n_aovs=1, kinds=None, keep_log=False, shadow=True):
         self.lib, self.params, self.n_aovs = lib, params, n_aovs
         k = (C.c_uint8 * n_aovs)(*(kinds or [0] * n_aovs))
-        self.h = lib.orc_frame_create(params.xres, params.yres, n_aovs, C.cast(k, C.c_void_p), int(keep_log))
+        self.h = lib.orc_frame_create(params.xres, params.yres, n_aovs, C.cast(k, C.c_void_p), int(bool(keep_log)) | (0 if shadow else 2))
         self.np = params.xres * params.yres
 
     def run(self, lens, bokeh, visits, v0=0, v1=None):

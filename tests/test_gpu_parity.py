@@ -19,10 +19,12 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-5
 
 
-def gpu_run(ctx, p, table, visits, n_aovs=1, bokeh_tables=None, log_cap=1 << 22):
+def gpu_run(ctx, p, table, visits, n_aovs=1, bokeh_tables=None, log_cap=1 << 22, lens_mode=0):
     ctx.set_params(p)
+    ctx.set_lens_mode(lens_mode)
     if table is not None:
         ctx.set_lens(table)
+        assert ctx.lens_is_compiled()        # shipped lenses have a compiled-in kernel
     ctx.set_bokeh(bokeh_tables)
     ctx.alloc_frame(n_aovs)
     ctx.set_draw_log(log_cap)
@@ -147,14 +149,16 @@ def test_trace_bw_po_bit_exact(orc, gpu_ctx_factory):
 # --------------------------------------------------------------------------------------------------
 # whole path
 # --------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("lens_mode", [0, 1], ids=["compiled", "tables"])
 @pytest.mark.parametrize("override", [0, 64])
-def test_po_redistribute_parity(orc, gpu_ctx_factory, override):
+def test_po_redistribute_parity(orc, gpu_ctx_factory, override, lens_mode):
+    """compiled = straight-line generated kernel of the shipped lens; tables = LDS table interpreter."""
     W, H, M = 96, 64, 9
     p, model, table, keep = common.po_setup(W, H, samples_override=override)
     visits, cols = common.make_stream(p, W, H, M, f_hi=0.02)
     ref = common.run_oracle(orc, p, table, visits)
     ctx = gpu_ctx_factory()
-    c = gpu_run(ctx, p, table, visits)
+    c = gpu_run(ctx, p, table, visits, lens_mode=lens_mode)
     rc = ref.counters()
     assert (c.redistributed_visits, c.attempted_draws, c.accepted_draws) == (
         rc.redistributed_visits, rc.attempted_draws, rc.accepted_draws)

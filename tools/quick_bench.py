@@ -1,0 +1,30 @@
+"""Ad-hoc timing of the kernels (development aid; the contract benchmark is bench.py)."""
+import sys, os, time
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "tests"))
+import numpy as np, torch
+import common
+from pota_amd import capi, workload
+
+W, H, M = int(sys.argv[1]), int(sys.argv[2]), 9
+override = int(sys.argv[3]); f_hi = float(sys.argv[4]); K = int(sys.argv[5]) if len(sys.argv) > 5 else 0
+p, model, table, keep = common.po_setup(W, H, samples_override=override)
+dev = torch.device("cuda:0")
+n = W * H * M
+cols = workload.generate(torch, 0, n, W, H, M, f_hi=f_hi, focus_dist=150.0, tan_half_fov=common.tan_half_fov(p), n_extra=K, device=dev)
+torch.cuda.synchronize()
+ctx = capi.Context(0)
+ctx.set_params(p); ctx.set_lens(table); ctx.alloc_frame(1 + K)
+visits, kv = capi.make_visits(cols, visits_per_pixel=M, pixels_per_row=W, ptr=lambda t: t.data_ptr())
+ctx.bind_visits(visits, kv)
+for it in range(4):
+    ctx.clear_frame(); ctx.redistribute(); ctx.resolve(); ctx.sync()
+    ms = ctx.last_timing(); c = ctx.counters()
+    bytes_ = n * (80 + 16 * K)
+    print("iter %d: scan %.3f ms (%.1f GB/s) draw %.3f ms (%.2f Mdraws/s att) resolve %.3f ms | redis %d att %d acc %d"
+          % (it, ms[0], bytes_ / ms[0] / 1e6, ms[1], c.attempted_draws / max(ms[1], 1e-9) / 1e3, ms[2],
+             c.redistributed_visits, c.attempted_draws, c.accepted_draws))
+    if c.tries:
+        print("        tries/attempt %.2f iters/try %.1f lane-utilisation %.2f  -> %.1f G lane-iters/s"
+              % (c.tries / c.attempted_draws, c.newton_iterations / c.tries, c.newton_iterations / max(c.lane_rounds, 1),
+                 c.newton_iterations / ms[1] / 1e6))
