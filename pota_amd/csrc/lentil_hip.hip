@@ -41,6 +41,16 @@ struct DevCounters {
   unsigned long long lane_rounds;    // 64 x scheduler rounds (issue slots offered)
 };
 
+// Shared scheduling state of one work item (redistributed visit); any number of waves may serve the
+// same item.  slots = accepted + in-flight attempts (never exceeds `samples`), next = next attempt
+// index to hand out (attempts are started strictly in increasing order).
+struct ItemState {
+  uint32_t slots;
+  uint32_t next;
+  uint32_t accepted;
+  uint32_t last_ok;    // highest accepted attempt index
+};
+
 struct VisitsDev {
   uint64_t n;
   uint32_t visits_per_pixel, pixels_per_row;
@@ -65,6 +75,7 @@ struct ScanArgs {
   VisitsDev V;
   FrameDev F;
   uint2 *work;
+  ItemState *state;
   uint64_t work_cap;
   DevCounters *ctr;
   uint32_t ppt;      // pixels per wave tile (uniform mode)
@@ -79,6 +90,7 @@ struct DrawArgs {
   VisitsDev V;
   FrameDev F;
   const uint2 *work;
+  ItemState *state;
   uint64_t work_cap;
   DevCounters *ctr;
   lentil_draw_record *log;
@@ -100,7 +112,8 @@ LD_DEV void visit_pixel(const VisitsDev &V, uint64_t v, int &px, int &py) {
 LD_DEV uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 
 // wave-ballot + prefix-sum compaction of flagged lanes into the work list (K2)
-LD_DEV void push_work(bool flagged, uint32_t visit, uint32_t samples, uint2 *work, uint64_t cap, DevCounters *ctr) {
+LD_DEV void push_work(bool flagged, uint32_t visit, uint32_t samples, uint2 *work, ItemState *state, uint64_t cap,
+                      DevCounters *ctr) {
   const unsigned long long mask = __ballot(flagged);
   if (mask == 0ull) return;
   const uint32_t lane = lane_id();
@@ -110,8 +123,12 @@ LD_DEV void push_work(bool flagged, uint32_t visit, uint32_t samples, uint2 *wor
   base = __shfl(base, (int)leader);
   if (flagged) {
     const unsigned long long idx = base + (unsigned long long)__builtin_popcountll(mask & ((1ull << lane) - 1ull));
-    if (idx < cap) work[idx] = make_uint2(visit, samples);
-    else atomicAdd(&ctr->overflow, 1ull);
+    if (idx < cap) {
+      work[idx] = make_uint2(visit, samples);
+      reinterpret_cast<uint4 *>(state)[idx] = make_uint4(0u, 0u, 0u, 0u);
+    } else {
+      atomicAdd(&ctr->overflow, 1ull);
+    }
   }
 }
 
@@ -166,7 +183,7 @@ __global__ __launch_bounds__(256) void scan_uniform_kernel(ScanArgs a) {
           val = make_float4((rgba.x + 0.0f) * w, (rgba.y + 0.0f) * w, (rgba.z + 0.0f) * w, (rgba.w + 0.0f) * w);
         }
       }
-      push_work(flagged, (uint32_t)v, (uint32_t)samples, a.work, a.work_cap, a.ctr);
+      push_work(flagged, (uint32_t)v, (uint32_t)samples, a.work, a.state, a.work_cap, a.ctr);
       n_redis += flagged ? 1ull : 0ull;
       if (e < TV) { sval[e] = val; sw[e] = w; }
     }
@@ -271,7 +288,7 @@ __global__ __launch_bounds__(256) void scan_ragged_kernel(ScanArgs a) {
         }
       }
     }
-    push_work(flagged, (uint32_t)v, (uint32_t)samples, a.work, a.work_cap, a.ctr);
+    push_work(flagged, (uint32_t)v, (uint32_t)samples, a.work, a.state, a.work_cap, a.ctr);
     n_redis += flagged ? 1ull : 0ull;
   }
   for (int off = 32; off > 0; off >>= 1) n_redis += __shfl_down(n_redis, off);
@@ -347,10 +364,18 @@ LD_DEV ItemHeader load_item(const DrawArgs &a, unsigned long long item, double l
   return h;
 }
 
+// One wave serving (part of) one work item.  Any number of waves may serve the same item
+// concurrently; they coordinate through the item's ItemState in global memory:
+//   - a lane may only start an attempt after reserving a slot (slots <= samples), so the number of
+//     successes can never exceed `samples`;
+//   - attempt indices come from one fetch-add counter, so the started attempts always form a prefix
+//     0..next-1 and every started attempt is run to its end;
+//   => the successes are exactly "the first `samples` successes in attempt order" of the reference.
+// A failed attempt gives its slot back; the wave that owned it re-acquires on its next round, so an
+// item always has a wave working on it while it is incomplete.
 template <class LensT>
-LD_DEV void po_item(const DrawArgs &a, const LensT &L, const float *cdfRow, const ItemHeader &h,
-                    unsigned long long &tot_attempted, unsigned long long &tot_accepted, uint32_t &st_iters,
-                    uint32_t &st_tries, uint32_t &st_rounds) {
+LD_DEV void po_item(const DrawArgs &a, const LensT &L, const float *cdfRow, const ItemHeader &h, ItemState *st,
+                    uint32_t &st_iters, uint32_t &st_tries, uint32_t &st_rounds) {
   const lentil_params &P = a.P;
   const DevLens &k = L.consts();
   const uint32_t lane = lane_id();
@@ -360,29 +385,44 @@ LD_DEV void po_item(const DrawArgs &a, const LensT &L, const float *cdfRow, cons
   const uint32_t samples = h.samples, max_total = samples * 5u;
   const uint32_t seed_a = (uint32_t)(h.px * h.py + h.px);
 
-  uint32_t accepted = 0, next_attempt = 0, last_ok = 0;
-  bool busy = false, need_init = false;
-  uint32_t n = 0;
+  bool busy = false, need_init = false, exhausted = false;
+  uint32_t n = 0, backoff = 0;
   int t = 0;
   double ap_x = 0.0, ap_y = 0.0;
   NewtonState s;
   newton_init(s);
 
   while (true) {
-    // ---- refill idle lanes with the next attempts
+    // ---- acquire attempts for the idle lanes
     const unsigned long long busy_mask = __ballot(busy);
     const uint32_t inflight = (uint32_t)__builtin_popcountll(busy_mask);
-    uint32_t nstart = samples - accepted - inflight;
-    if (nstart > max_total - next_attempt) nstart = max_total - next_attempt;
-    const unsigned long long idle_mask = ~busy_mask;
     const uint32_t n_idle = 64u - inflight;
-    if (nstart > n_idle) nstart = n_idle;
-    if (!busy) {
-      const uint32_t my_rank = (uint32_t)__builtin_popcountll(idle_mask & lt_mask);
-      if (my_rank < nstart) { busy = true; need_init = true; n = next_attempt + my_rank; t = 0; }
+    uint32_t grant = 0, base = 0;
+    if (n_idle > 0 && !exhausted && backoff == 0) {
+      if (lane == 0) {
+        const uint32_t old = atomicAdd(&st->slots, n_idle);
+        uint32_t g = (old >= samples) ? 0u : (samples - old < n_idle ? samples - old : n_idle);
+        if (g < n_idle) atomicSub(&st->slots, n_idle - g);
+        if (g > 0) {
+          const uint32_t b = atomicAdd(&st->next, g);
+          const uint32_t g2 = (b >= max_total) ? 0u : (max_total - b < g ? max_total - b : g);
+          if (g2 < g) atomicSub(&st->slots, g - g2);
+          if (g2 == 0) grant = 0xFFFFFFFFu;      // no attempts left at all
+          else { grant = g2; base = b; }
+        }
+      }
+      grant = __builtin_amdgcn_readfirstlane(grant);
+      base = __builtin_amdgcn_readfirstlane(base);
+      if (grant == 0xFFFFFFFFu) { exhausted = true; grant = 0; }
+      else if (grant == 0) backoff = 4;            // item full right now: do not hammer the counter
+    } else if (backoff) {
+      --backoff;
     }
-    next_attempt += nstart;
-    if (inflight + nstart == 0u) break;
+    if (!busy) {
+      const uint32_t my_rank = (uint32_t)__builtin_popcountll(~busy_mask & lt_mask);
+      if (my_rank < grant) { busy = true; need_init = true; n = base + my_rank; t = 0; }
+    }
+    if (inflight + grant == 0u) break;             // nothing in flight here and nothing to get
 
     // ---- (re)start a solve: aperture draw for (attempt n, try t), src/lentil.h:596-609
     if (busy && need_init) {
@@ -396,7 +436,7 @@ LD_DEV void po_item(const DrawArgs &a, const LensT &L, const float *cdfRow, cons
     ++st_rounds;
 
     // ---- lanes whose solve ended
-    bool succ = false;
+    bool succ = false, failed = false;
     if (busy && !newton_continue(s)) {
       double out4;
       const float transmittance = (float)newton_finish(L, s, out4);
@@ -413,23 +453,34 @@ LD_DEV void po_item(const DrawArgs &a, const LensT &L, const float *cdfRow, cons
         if (po_sensor_to_pixel(P, sx, sy, pix)) {
           succ = true;
           splat(pix, n);
-          if (n > last_ok) last_ok = n;
+        } else {
+          failed = true;
         }
         busy = false;
       } else {
         ++t;
-        if (t > P.vignetting_retries) busy = false; else need_init = true;
+        if (t > P.vignetting_retries) { busy = false; failed = true; } else need_init = true;
       }
     }
-    accepted += (uint32_t)__builtin_popcountll(__ballot(succ));
+    const unsigned long long succ_mask = __ballot(succ);
+    const unsigned long long fail_mask = __ballot(failed);
+    if (succ_mask | fail_mask) {
+      // highest successful attempt index of this round (attempt indices grow with the lane rank only
+      // within one grant, so take a real max)
+      uint32_t mx = succ ? n : 0u;
+      for (int off = 32; off > 0; off >>= 1) {
+        const uint32_t o = __shfl_down(mx, off);
+        if (o > mx) mx = o;
+      }
+      if (lane == 0) {
+        const uint32_t nf = (uint32_t)__builtin_popcountll(fail_mask);
+        const uint32_t ns = (uint32_t)__builtin_popcountll(succ_mask);
+        if (nf) atomicSub(&st->slots, nf);
+        if (ns) { atomicAdd(&st->accepted, ns); atomicMax(&st->last_ok, mx); }
+      }
+      if (fail_mask) backoff = 0;                  // a slot just became free
+    }
   }
-  for (int off = 32; off > 0; off >>= 1) {
-    const uint32_t o = __shfl_down(last_ok, off);
-    if (o > last_ok) last_ok = o;
-  }
-  last_ok = __shfl(last_ok, 0);
-  tot_attempted += (accepted == samples) ? (unsigned long long)last_ok + 1ull : (unsigned long long)max_total;
-  tot_accepted += accepted;
 }
 
 template <class LensT, bool kTables>
@@ -453,15 +504,31 @@ __global__ __launch_bounds__(256) void draw_po_kernel(DrawArgs a) {
   const uint32_t lane = threadIdx.x & 63u;
   unsigned long long n_items = a.ctr->work_count;
   if (n_items > a.work_cap) n_items = a.work_cap;
-  unsigned long long tot_attempted = 0, tot_accepted = 0;
+  // Tickets: ticket q serves item q % n_items as its (q / n_items)-th helper wave, so every item gets a
+  // first wave before any item gets a second one.  An item with `samples` draws can use at most
+  // ceil(samples / 64) waves at once.
+  const uint32_t max_samples = a.P.samples_override > 0 ? (uint32_t)a.P.samples_override : 2000u;
+  const unsigned long long max_helpers = (max_samples + 63u) / 64u;
+  const unsigned long long n_tickets = n_items * max_helpers;
   uint32_t st_iters = 0, st_tries = 0, st_rounds = 0;
   while (true) {
-    unsigned long long item = 0;
-    if (lane == 0) item = atomicAdd(&a.ctr->queue_head, 1ull);
-    item = __shfl(item, 0);
-    if (item >= n_items) break;
+    unsigned long long q = 0;
+    if (lane == 0) q = atomicAdd(&a.ctr->queue_head, 1ull);
+    q = __shfl(q, 0);
+    if (q >= n_tickets) break;
+    const unsigned long long item = q % n_items;
+    const uint32_t helper = (uint32_t)(q / n_items);
+    const uint32_t samples = __builtin_amdgcn_readfirstlane(a.work[item].y);
+    if (helper * 64u >= samples) continue;
+    ItemState *st = a.state + item;
+    if (helper > 0) {
+      // cheap look before doing the full item set-up: complete or fully reserved items need no helper
+      const uint32_t sl = __hip_atomic_load(&st->slots, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const uint32_t nx = __hip_atomic_load(&st->next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (sl >= samples || nx >= samples * 5u) continue;
+    }
     const ItemHeader h = load_item(a, item, s_k.length);
-    po_item(a, L, cdfRow, h, tot_attempted, tot_accepted, st_iters, st_tries, st_rounds);
+    po_item(a, L, cdfRow, h, st, st_iters, st_tries, st_rounds);
   }
   unsigned long long it64 = st_iters, tr64 = st_tries, rd64 = st_rounds;
   for (int off = 32; off > 0; off >>= 1) {
@@ -470,11 +537,32 @@ __global__ __launch_bounds__(256) void draw_po_kernel(DrawArgs a) {
     rd64 += __shfl_down(rd64, off);
   }
   if (lane == 0) {
-    if (tot_attempted) atomicAdd(&a.ctr->attempted, tot_attempted);
-    if (tot_accepted) atomicAdd(&a.ctr->accepted, tot_accepted);
     if (it64) atomicAdd(&a.ctr->newton_iters, it64);
     if (tr64) atomicAdd(&a.ctr->tries, tr64);
     if (rd64) atomicAdd(&a.ctr->lane_rounds, rd64);
+  }
+}
+
+// total_samples_taken / accepted statistics of the PO items (src/lentil_filter.cpp:248): one thread
+// per item after the draw kernel.
+__global__ __launch_bounds__(256) void po_item_stats_kernel(DrawArgs a) {
+  unsigned long long n_items = a.ctr->work_count;
+  if (n_items > a.work_cap) n_items = a.work_cap;
+  unsigned long long att = 0, acc = 0;
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_items; i += stride) {
+    const ItemState st = a.state[i];
+    const uint32_t samples = a.work[i].y;
+    acc += st.accepted;
+    att += (st.accepted >= samples) ? (unsigned long long)st.last_ok + 1ull : (unsigned long long)samples * 5ull;
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    att += __shfl_down(att, off);
+    acc += __shfl_down(acc, off);
+  }
+  if ((threadIdx.x & 63u) == 0) {
+    if (att) atomicAdd(&a.ctr->attempted, att);
+    if (acc) atomicAdd(&a.ctr->accepted, acc);
   }
 }
 
@@ -632,6 +720,7 @@ struct lentil_hip_ctx {
   std::vector<void *> owned_visit_mem;
 
   uint2 *d_work = nullptr;
+  ItemState *d_state = nullptr;
   uint64_t work_cap = 0;
   DevCounters *d_ctr = nullptr;
   lentil_draw_record *d_log = nullptr;
@@ -716,6 +805,7 @@ LENTIL_API int lentil_hip_destroy(lentil_hip_ctx *ctx) {
   (void)hipFree(ctx->F.acc);
   (void)hipFree(ctx->d_resolved);
   (void)hipFree(ctx->d_work);
+  (void)hipFree(ctx->d_state);
   (void)hipFree(ctx->d_ctr);
   (void)hipFree(ctx->d_log);
   for (auto &ev : ctx->ev) if (ev) (void)hipEventDestroy(ev);
@@ -945,10 +1035,13 @@ static void to_dev(VisitsDev &d, const lentil_visits *v) {
 static int ensure_worklist(lentil_hip_ctx *ctx, uint64_t n) {
   if (n <= ctx->work_cap && ctx->d_work) return LENTIL_OK;
   (void)hipFree(ctx->d_work);
+  (void)hipFree(ctx->d_state);
   ctx->d_work = nullptr;
+  ctx->d_state = nullptr;
   ctx->work_cap = 0;
   const uint64_t cap = n < 1024 ? 1024 : n;
   HIP_TRY(ctx, hipMalloc(&ctx->d_work, cap * sizeof(uint2)));
+  HIP_TRY(ctx, hipMalloc(&ctx->d_state, cap * sizeof(ItemState)));
   ctx->work_cap = cap;
   return LENTIL_OK;
 }
@@ -1031,6 +1124,7 @@ LENTIL_API int lentil_hip_redistribute(lentil_hip_ctx *ctx) {
     sa.V = ctx->V;
     sa.F = ctx->F;
     sa.work = ctx->d_work;
+    sa.state = ctx->d_state;
     sa.work_cap = ctx->work_cap;
     sa.ctr = ctx->d_ctr;
     if (ctx->V.visits_per_pixel) {
@@ -1068,6 +1162,7 @@ LENTIL_API int lentil_hip_redistribute(lentil_hip_ctx *ctx) {
     da.V = ctx->V;
     da.F = ctx->F;
     da.work = ctx->d_work;
+    da.state = ctx->d_state;
     da.work_cap = ctx->work_cap;
     da.ctr = ctx->d_ctr;
     da.log = ctx->d_log;
@@ -1085,6 +1180,7 @@ LENTIL_API int lentil_hip_redistribute(lentil_hip_ctx *ctx) {
 #undef LENTIL_LAUNCH_GEN
       if (!launched)
         hipLaunchKernelGGL((draw_po_kernel<LdsLens, true>), dim3(blocks), dim3(256), 0, ctx->stream, da);
+      hipLaunchKernelGGL(po_item_stats_kernel, dim3((unsigned)ctx->num_cu), dim3(256), 0, ctx->stream, da);
     } else {
       hipLaunchKernelGGL(draw_thinlens_kernel, dim3(blocks), dim3(256), 0, ctx->stream, da);
     }

@@ -44,9 +44,11 @@ def table_hash(spec):
 
 
 class Emitter:
-    def __init__(self):
+    def __init__(self, coef, cname):
         self.lines = []
         self.pows = {}     # (var, e) -> name
+        self.coef = coef   # shared coefficient list (constant memory, read with scalar loads)
+        self.cname = cname
 
     def power(self, var, e):
         """Name of lens_ipow(var, e), e >= 2, emitting the recursion's intermediate powers once."""
@@ -78,7 +80,8 @@ class Emitter:
                     self.power(var, e[var])
         parts = []
         for c, e in terms:
-            f = [float(c).hex()]
+            self.coef.append(float(c))
+            f = ["%s[%d]" % (self.cname, len(self.coef) - 1)]
             for var in range(4):
                 if e[var] == 1:
                     f.append(VARS[var])
@@ -87,6 +90,9 @@ class Emitter:
             if e[4] >= 1:
                 f.append("lp[%d]" % e[4])
             parts.append(" * ".join(f))
+        # re-launder the coefficient pointer: keeps this polynomial's scalar loads from being clustered
+        # with every other polynomial's at the top of the block (SGPR pressure)
+        self.lines.append("  asm volatile(\"\" : \"+s\"(C));")
         expr = parts[0]
         for p_ in parts[1:]:
             expr = "(%s) + %s" % (expr, p_) if False else expr + "\n      + " + p_
@@ -97,7 +103,9 @@ def gen_lens(name, spec):
     polys = spec["polys"]
     dap = [[derive(polys["ap_" + a], 2 + j) for j in range(2)] for a in ("x", "y")]
     dout = [[derive(polys["out_" + a], j) for j in range(2)] for a in ("dx", "dy")]
-    em = Emitter()
+    coef = []
+    cname = "kCoef_%s" % name
+    em = Emitter(coef, "C")
     em.poly("pred_ap[0]", polys["ap_x"])
     em.poly("pred_ap[1]", polys["ap_y"])
     for i in range(2):
@@ -108,7 +116,7 @@ def gen_lens(name, spec):
     for i in range(2):
         for j in range(2):
             em.poly("Jout[%d]" % (i * 2 + j), dout[i][j])
-    et = Emitter()
+    et = Emitter(coef, "C")
     et.poly("const double t", polys["out_t"])
     n_terms = sum(len(polys[n]) for n in OUT_NAMES + AP_NAMES)
     h = table_hash(spec)
@@ -117,17 +125,32 @@ def gen_lens(name, spec):
     src.append("// Straight-line evaluation of the lens polynomials; same operation order as the table")
     src.append("// interpreter (LdsLens::eval) and the oracle.  %d base terms, table hash 0x%016x." % (n_terms, h))
     src.append("#pragma once")
+    src.append("#ifndef LENTIL_COEF_PTR")
+    src.append("// A constant-address-space pointer laundered through an empty asm: the coefficient loads stay")
+    src.append("// scalar (s_load) but are not hoisted out of the solver loop (which would spill ~800 SGPRs).")
+    src.append("#define LENTIL_COEF_PTR(NAME, ARR) \\")
+    src.append("  const __attribute__((address_space(4))) double *NAME = (const __attribute__((address_space(4))) double *)(ARR); \\")
+    src.append("  asm volatile(\"\" : \"+s\"(NAME))")
+    src.append("#endif")
     src.append("namespace lentil { namespace gen {")
+    src.append("// coefficients in order of use (base terms and c*e derivative terms); constant address space,")
+    src.append("// uniform indices -> the compiler fetches them with wide scalar loads (s_load_dwordx8/x16)")
+    src.append("__device__ __constant__ double %s[%d] = {" % (cname, len(coef)))
+    for i in range(0, len(coef), 4):
+        src.append("    " + " ".join("%s," % v.hex() for v in coef[i:i + 4]))
+    src.append("};")
     src.append("struct Lens_%s {" % name)
     src.append("  static constexpr unsigned long long kTableHash = 0x%016xull;" % h)
     src.append("  // v = (x, y, dx, dy); lp[e] = lens_ipow(lambda, e)")
     src.append("  static __device__ __forceinline__ void eval_bw(const double v[4], const double *lp, double pred_ap[2],")
     src.append("                                                 double Jap[4], double out[4], double Jout[4]) {")
     src.append("  const double x = v[0], y = v[1], dx = v[2], dy = v[3];")
+    src.append("  LENTIL_COEF_PTR(C, %s);" % cname)
     src.extend(em.lines)
     src.append("  }")
     src.append("  static __device__ __forceinline__ double transmittance(const double v[4], const double *lp) {")
     src.append("  const double x = v[0], y = v[1], dx = v[2], dy = v[3];")
+    src.append("  LENTIL_COEF_PTR(C, %s);" % cname)
     src.extend(et.lines)
     src.append("  return t;")
     src.append("  }")
