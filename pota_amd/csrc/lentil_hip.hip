@@ -1,13 +1,4 @@
-// lentil_hip.hip -- kernels + C-ABI of liblentil_hip.so (gfx950 only).
-//
-// Kernels (SURVEY.md section 8a/8d names):
-//   scan_kernel      K1+K2+K6: reads the visit columns (80+16K B/visit, HBM-bound), evaluates the
-//                    redistribute predicate and draw count, wave-ballot/prefix-sum compacts the
-//                    redistributed visits into a work list, and accumulates the non-redistributed
-//                    visits of each source pixel in reference order through wave-private LDS.
-//   draw_kernel      K3/K4/K5: one wave per redistributed visit, lanes = backward-trace attempts;
-//                    polynomial tables and the bokeh row CDF staged in LDS; fp32 atomic splat.
-//   resolve_kernel   K7: weight normalisation.
+// lentil_hip.hip -- C-ABI of liblentil_hip.so (gfx950 only): host side.  Kernels: lentil_kernels.h.
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
@@ -17,675 +8,9 @@
 #include <string>
 #include <vector>
 
-#include "lentil_device.h"
-#include "generated/lens_registry.h"
-
-using namespace lentil;
+#include "lentil_kernels.h"
 
 #define LENTIL_API extern "C" __attribute__((visibility("default")))
-
-// ---------------------------------------------------------------------------------------
-// device-side bookkeeping
-// ---------------------------------------------------------------------------------------
-struct DevCounters {
-  unsigned long long work_count;     // entries pushed by the scan kernel
-  unsigned long long queue_head;     // next work item to hand out
-  unsigned long long visits;
-  unsigned long long redistributed;
-  unsigned long long attempted;
-  unsigned long long accepted;
-  unsigned long long overflow;
-  unsigned long long log_count;
-  unsigned long long newton_iters;   // lane-iterations of the Newton solver (draw kernel)
-  unsigned long long tries;          // aperture draws / solves started
-  unsigned long long lane_rounds;    // 64 x scheduler rounds (issue slots offered)
-};
-
-// Shared scheduling state of one work item (redistributed visit); any number of waves may serve the
-// same item.  slots = accepted + in-flight attempts (never exceeds `samples`), next = next attempt
-// index to hand out (attempts are started strictly in increasing order).
-struct ItemState {
-  uint32_t slots;
-  uint32_t next;
-  uint32_t accepted;
-  uint32_t last_ok;    // highest accepted attempt index
-};
-
-struct VisitsDev {
-  uint64_t n;
-  uint32_t visits_per_pixel, pixels_per_row;
-  int32_t pixel_x0, pixel_y0;
-  uint32_t pixel_row_stride, n_extra;
-  const float4 *rgba, *pos_z, *raydir_time, *volume_ignore, *transmission;
-  const float4 *extra[LENTIL_MAX_AOVS - 1];
-  const uint32_t *pixel;
-  const float *inv_density;
-};
-
-struct FrameDev {
-  float *acc;        // [n_aovs][np][4]
-  float *weight;     // [np]
-  uint32_t n_aovs;
-  uint64_t np;       // xres*yres
-};
-
-struct ScanArgs {
-  lentil_params P;
-  double lens_length;
-  VisitsDev V;
-  FrameDev F;
-  uint2 *work;
-  ItemState *state;
-  uint64_t work_cap;
-  DevCounters *ctr;
-  uint32_t ppt;      // pixels per wave tile (uniform mode)
-  uint32_t tv_pad;   // staging entries per wave (>= ppt * visits_per_pixel)
-};
-
-struct DrawArgs {
-  lentil_params P;
-  const DevLens *lens;     // header, global memory
-  const DevTerm *terms;    // global memory
-  DevBokeh bokeh;
-  VisitsDev V;
-  FrameDev F;
-  const uint2 *work;
-  ItemState *state;
-  uint64_t work_cap;
-  DevCounters *ctr;
-  lentil_draw_record *log;
-  uint64_t log_cap;
-};
-
-LD_DEV void visit_pixel(const VisitsDev &V, uint64_t v, int &px, int &py) {
-  if (V.visits_per_pixel) {
-    const uint64_t p = v / V.visits_per_pixel;
-    px = V.pixel_x0 + (int)(p % V.pixels_per_row);
-    py = V.pixel_y0 + (int)(p / V.pixels_per_row) * (int)V.pixel_row_stride;
-  } else {
-    const uint32_t q = V.pixel[v];
-    px = (int)(q & 0xFFFFu);
-    py = (int)(q >> 16);
-  }
-}
-
-LD_DEV uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
-
-// wave-ballot + prefix-sum compaction of flagged lanes into the work list (K2)
-LD_DEV void push_work(bool flagged, uint32_t visit, uint32_t samples, uint2 *work, ItemState *state, uint64_t cap,
-                      DevCounters *ctr) {
-  const unsigned long long mask = __ballot(flagged);
-  if (mask == 0ull) return;
-  const uint32_t lane = lane_id();
-  const uint32_t leader = (uint32_t)__builtin_ctzll(mask);
-  unsigned long long base = 0;
-  if (lane == leader) base = atomicAdd(&ctr->work_count, (unsigned long long)__builtin_popcountll(mask));
-  base = __shfl(base, (int)leader);
-  if (flagged) {
-    const unsigned long long idx = base + (unsigned long long)__builtin_popcountll(mask & ((1ull << lane) - 1ull));
-    if (idx < cap) {
-      work[idx] = make_uint2(visit, samples);
-      reinterpret_cast<uint4 *>(state)[idx] = make_uint4(0u, 0u, 0u, 0u);
-    } else {
-      atomicAdd(&ctr->overflow, 1ull);
-    }
-  }
-}
-
-// ---------------------------------------------------------------------------------------
-// K1+K2+K6, uniform footprints.  One wave owns a tile of `ppt` consecutive source pixels
-// (= ppt*M consecutive visits, read as fully coalesced 1 KiB column loads), stages the weighted
-// contributions in wave-private LDS, then lane p adds up pixel p's M entries in iterator order --
-// the order the reference accumulates them (filter_and_add_to_buffer_new, src/lentil.h:938-955).
-// ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void scan_uniform_kernel(ScanArgs a) {
-  extern __shared__ float4 smem[];
-  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-  const uint32_t waves_per_block = blockDim.x >> 6;
-  float4 *sval = smem + (size_t)wave * a.tv_pad;
-  float *sw = reinterpret_cast<float *>(smem + (size_t)waves_per_block * a.tv_pad) + (size_t)wave * a.tv_pad;
-
-  const VisitsDev &V = a.V;
-  const uint32_t M = V.visits_per_pixel;
-  const uint32_t ppt = a.ppt;
-  const uint32_t TV = ppt * M;
-  const uint64_t n_pixels = (V.n + M - 1) / M;
-  const uint64_t n_tiles = (n_pixels + ppt - 1) / ppt;
-  const uint64_t wave_global = (uint64_t)blockIdx.x * waves_per_block + wave;
-  const uint64_t wave_stride = (uint64_t)gridDim.x * waves_per_block;
-  const uint32_t xres = a.P.xres;
-  unsigned long long n_redis = 0;
-
-  for (uint64_t tile = wave_global; tile < n_tiles; tile += wave_stride) {
-    const uint64_t pix0 = tile * ppt;
-    const uint64_t v0 = pix0 * M;
-    for (uint32_t eb = 0; eb < TV; eb += 64) {
-      const uint32_t e = eb + lane;
-      const uint64_t v = v0 + e;
-      const bool valid = (e < TV) && (v < V.n);
-      float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
-      float w = 0.f;
-      bool flagged = false;
-      int samples = 0;
-      if (valid) {
-        const float4 rgba = V.rgba[v];
-        const float4 pz = V.pos_z[v];
-        const float4 rt = V.raydir_time[v];
-        const float4 vi = V.volume_ignore[v];
-        const float4 tr = V.transmission[v];
-        const float invd = V.inv_density ? V.inv_density[v] : a.P.inverse_sample_density;
-        const VisitInfo I = visit_prologue(a.P, a.lens_length, rgba, pz, rt, vi, tr, invd);
-        if (I.redistribute) {
-          flagged = true;
-          samples = I.samples;
-        } else {
-          w = 1.0f * invd;                              // filter_weight * inv_density, lentil.h:949-953
-          val = make_float4((rgba.x + 0.0f) * w, (rgba.y + 0.0f) * w, (rgba.z + 0.0f) * w, (rgba.w + 0.0f) * w);
-        }
-      }
-      push_work(flagged, (uint32_t)v, (uint32_t)samples, a.work, a.state, a.work_cap, a.ctr);
-      n_redis += flagged ? 1ull : 0ull;
-      if (e < TV) { sval[e] = val; sw[e] = w; }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-
-    const uint64_t pix = pix0 + lane;
-    const bool own = (lane < ppt) && (pix < n_pixels);
-    uint64_t lin = 0;
-    if (own) {
-      const int px = V.pixel_x0 + (int)(pix % V.pixels_per_row);
-      const int py = V.pixel_y0 + (int)(pix / V.pixels_per_row) * (int)V.pixel_row_stride;
-      lin = (uint64_t)px + (uint64_t)py * xres;
-      float4 s = reinterpret_cast<float4 *>(a.F.acc)[lin];
-      float ws = a.F.weight[lin];
-      for (uint32_t j = 0; j < M; ++j) {
-        const float4 c = sval[lane * M + j];
-        const float cw = sw[lane * M + j];
-        if (cw != 0.0f) { s.x += c.x; s.y += c.y; s.z += c.z; s.w += c.w; ws += cw; }
-      }
-      reinterpret_cast<float4 *>(a.F.acc)[lin] = s;
-      a.F.weight[lin] = ws;
-    }
-    // extra AOVs: same weights, one column at a time through the same staging area
-    for (uint32_t k = 0; k < V.n_extra; ++k) {
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      for (uint32_t eb = 0; eb < TV; eb += 64) {
-        const uint32_t e = eb + lane;
-        const uint64_t v = v0 + e;
-        if (e < TV) {
-          const float w = sw[e];
-          float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (v < V.n && w != 0.0f) {
-            const float4 c = V.extra[k][v];
-            x = make_float4((c.x + 0.0f) * w, (c.y + 0.0f) * w, (c.z + 0.0f) * w, (c.w + 0.0f) * w);
-          }
-          sval[e] = x;
-        }
-      }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      if (own) {
-        float4 *dst = reinterpret_cast<float4 *>(a.F.acc) + (size_t)(k + 1) * a.F.np + lin;
-        float4 s = *dst;
-        for (uint32_t j = 0; j < M; ++j) {
-          if (sw[lane * M + j] != 0.0f) {
-            const float4 c = sval[lane * M + j];
-            s.x += c.x; s.y += c.y; s.z += c.z; s.w += c.w;
-          }
-        }
-        *dst = s;
-      }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-  }
-  // counters: one atomic per wave
-  for (int off = 32; off > 0; off >>= 1) n_redis += __shfl_down(n_redis, off);
-  if (lane == 0 && n_redis) atomicAdd(&a.ctr->redistributed, n_redis);
-}
-
-// K1+K2+K6 for ragged footprints (explicit per-visit pixel): lane per visit, fp32 atomics for the
-// direct accumulation.
-__global__ __launch_bounds__(256) void scan_ragged_kernel(ScanArgs a) {
-  const VisitsDev &V = a.V;
-  const uint32_t lane = threadIdx.x & 63u;
-  unsigned long long n_redis = 0;
-  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-  const uint64_t n_round = (V.n + 63ull) & ~63ull;
-  for (uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; v < n_round; v += stride) {
-    bool flagged = false;
-    int samples = 0;
-    if (v < V.n) {
-      const float4 rgba = V.rgba[v];
-      const float invd = V.inv_density ? V.inv_density[v] : a.P.inverse_sample_density;
-      const VisitInfo I = visit_prologue(a.P, a.lens_length, rgba, V.pos_z[v], V.raydir_time[v],
-                                         V.volume_ignore[v], V.transmission[v], invd);
-      if (I.redistribute) {
-        flagged = true;
-        samples = I.samples;
-      } else {
-        int px, py;
-        visit_pixel(V, v, px, py);
-        const uint64_t lin = (uint64_t)px + (uint64_t)py * a.P.xres;
-        const float w = 1.0f * invd;
-        float *d = a.F.acc + lin * 4;
-        atomicAdd(d + 0, (rgba.x + 0.0f) * w);
-        atomicAdd(d + 1, (rgba.y + 0.0f) * w);
-        atomicAdd(d + 2, (rgba.z + 0.0f) * w);
-        atomicAdd(d + 3, (rgba.w + 0.0f) * w);
-        atomicAdd(a.F.weight + lin, w);
-        for (uint32_t k = 0; k < V.n_extra; ++k) {
-          const float4 c = V.extra[k][v];
-          float *dk = a.F.acc + ((size_t)(k + 1) * a.F.np + lin) * 4;
-          atomicAdd(dk + 0, (c.x + 0.0f) * w);
-          atomicAdd(dk + 1, (c.y + 0.0f) * w);
-          atomicAdd(dk + 2, (c.z + 0.0f) * w);
-          atomicAdd(dk + 3, (c.w + 0.0f) * w);
-        }
-      }
-    }
-    push_work(flagged, (uint32_t)v, (uint32_t)samples, a.work, a.state, a.work_cap, a.ctr);
-    n_redis += flagged ? 1ull : 0ull;
-  }
-  for (int off = 32; off > 0; off >>= 1) n_redis += __shfl_down(n_redis, off);
-  if (lane == 0 && n_redis) atomicAdd(&a.ctr->redistributed, n_redis);
-}
-
-// ---------------------------------------------------------------------------------------
-// K3/K4/K5: draws.  One wave per work item (redistributed visit).
-//
-// Acceptance rule of the reference (src/lentil_filter.cpp:248,272,285): the accepted draws are the
-// first `samples` successes among attempts n = 0 .. 5*samples-1, in attempt order.  Both variants
-// below start attempts strictly in increasing n and never have more attempts outstanding than
-// accepted draws are still missing, so every success they see belongs to that set -- no ranking,
-// no ordered commit.
-//
-// Polynomial optics (draw_po_kernel): a lane-level scheduler.  Every round each busy lane advances
-// its own Newton solve by ONE iteration (the straight-line polynomial block, ~2k fp64 ops, runs
-// with a full exec mask); lanes whose solve ended finish it (pupil tests, retry with the next
-// aperture draw, or sensor->pixel + atomic splat) and are refilled with the next attempt.  Solves
-// that need 11 or 40 iterations, or 1 or 16 vignetting retries, no longer hold 63 other lanes.
-// ---------------------------------------------------------------------------------------
-constexpr int kMaxBokehRows = 2048;
-
-struct Splat {
-  const DrawArgs &a;
-  uint32_t visit;
-  float4 rgba;
-  float ae, w;
-  LD_DEV void operator()(uint32_t pix, uint32_t attempt) const {
-    // Camera::add_to_buffer, src/lentil.h:827-830
-    float *d = a.F.acc + (size_t)pix * 4;
-    atomicAdd(d + 0, (rgba.x + ae) * w);
-    atomicAdd(d + 1, (rgba.y + ae) * w);
-    atomicAdd(d + 2, (rgba.z + ae) * w);
-    atomicAdd(d + 3, (rgba.w + ae) * w);
-    atomicAdd(a.F.weight + pix, w);
-    for (uint32_t k = 0; k < a.V.n_extra; ++k) {
-      const float4 c = a.V.extra[k][visit];
-      float *dk = a.F.acc + ((size_t)(k + 1) * a.F.np + pix) * 4;
-      atomicAdd(dk + 0, (c.x + ae) * w);
-      atomicAdd(dk + 1, (c.y + ae) * w);
-      atomicAdd(dk + 2, (c.z + ae) * w);
-      atomicAdd(dk + 3, (c.w + ae) * w);
-    }
-    if (a.log_cap) {
-      const unsigned long long li = atomicAdd(&a.ctr->log_count, 1ull);
-      if (li < a.log_cap) { a.log[li].visit = visit; a.log[li].attempt = attempt; a.log[li].pixel = pix; }
-    }
-  }
-};
-
-struct ItemHeader {
-  uint32_t visit, samples;
-  int px, py;
-  VisitInfo I;
-  float4 rgba;
-  float w;
-};
-
-LD_DEV ItemHeader load_item(const DrawArgs &a, unsigned long long item, double lens_length) {
-  ItemHeader h;
-  const uint2 wi = a.work[item];
-  h.visit = __builtin_amdgcn_readfirstlane(wi.x);
-  h.samples = __builtin_amdgcn_readfirstlane(wi.y);
-  const uint32_t v = h.visit;
-  h.rgba = a.V.rgba[v];
-  const float invd = a.V.inv_density ? a.V.inv_density[v] : a.P.inverse_sample_density;
-  h.I = visit_prologue(a.P, lens_length, h.rgba, a.V.pos_z[v], a.V.raydir_time[v], a.V.volume_ignore[v],
-                       a.V.transmission[v], invd);
-  visit_pixel(a.V, v, h.px, h.py);
-  const float inv_samples = (float)(1.0 / (double)(float)(int)h.samples);
-  h.w = 1.0f * invd * inv_samples;              // src/lentil_filter.cpp:297
-  return h;
-}
-
-// One wave serving (part of) one work item.  Any number of waves may serve the same item
-// concurrently; they coordinate through the item's ItemState in global memory:
-//   - a lane may only start an attempt after reserving a slot (slots <= samples), so the number of
-//     successes can never exceed `samples`;
-//   - attempt indices come from one fetch-add counter, so the started attempts always form a prefix
-//     0..next-1 and every started attempt is run to its end;
-//   => the successes are exactly "the first `samples` successes in attempt order" of the reference.
-// A failed attempt gives its slot back; the wave that owned it re-acquires on its next round, so an
-// item always has a wave working on it while it is incomplete.
-template <class LensT>
-LD_DEV void po_item(const DrawArgs &a, const LensT &L, const float *cdfRow, const ItemHeader &h, ItemState *st,
-                    uint32_t &st_iters, uint32_t &st_tries, uint32_t &st_rounds) {
-  const lentil_params &P = a.P;
-  const DevLens &k = L.consts();
-  const uint32_t lane = lane_id();
-  const unsigned long long lt_mask = (1ull << lane) - 1ull;
-  const double target[3] = {-(double)h.I.cs[0] * 10.0, -(double)h.I.cs[1] * 10.0, -(double)h.I.cs[2] * 10.0};
-  const Splat splat{a, h.visit, h.rgba, h.I.add_energy, h.w};
-  const uint32_t samples = h.samples, max_total = samples * 5u;
-  const uint32_t seed_a = (uint32_t)(h.px * h.py + h.px);
-
-  bool busy = false, need_init = false, exhausted = false;
-  uint32_t n = 0, backoff = 0;
-  int t = 0;
-  double ap_x = 0.0, ap_y = 0.0;
-  NewtonState s;
-  newton_init(s);
-
-  while (true) {
-    // ---- acquire attempts for the idle lanes
-    const unsigned long long busy_mask = __ballot(busy);
-    const uint32_t inflight = (uint32_t)__builtin_popcountll(busy_mask);
-    const uint32_t n_idle = 64u - inflight;
-    uint32_t grant = 0, base = 0;
-    if (n_idle > 0 && !exhausted && backoff == 0) {
-      if (lane == 0) {
-        const uint32_t old = atomicAdd(&st->slots, n_idle);
-        uint32_t g = (old >= samples) ? 0u : (samples - old < n_idle ? samples - old : n_idle);
-        if (g < n_idle) atomicSub(&st->slots, n_idle - g);
-        if (g > 0) {
-          const uint32_t b = atomicAdd(&st->next, g);
-          const uint32_t g2 = (b >= max_total) ? 0u : (max_total - b < g ? max_total - b : g);
-          if (g2 < g) atomicSub(&st->slots, g - g2);
-          if (g2 == 0) grant = 0xFFFFFFFFu;      // no attempts left at all
-          else { grant = g2; base = b; }
-        }
-      }
-      grant = __builtin_amdgcn_readfirstlane(grant);
-      base = __builtin_amdgcn_readfirstlane(base);
-      if (grant == 0xFFFFFFFFu) { exhausted = true; grant = 0; }
-      else if (grant == 0) backoff = 4;            // item full right now: do not hammer the counter
-    } else if (backoff) {
-      --backoff;
-    }
-    if (!busy) {
-      const uint32_t my_rank = (uint32_t)__builtin_popcountll(~busy_mask & lt_mask);
-      if (my_rank < grant) { busy = true; need_init = true; n = base + my_rank; t = 0; }
-    }
-    if (inflight + grant == 0u) break;             // nothing in flight here and nothing to get
-
-    // ---- (re)start a solve: aperture draw for (attempt n, try t), src/lentil.h:596-609
-    if (busy && need_init) {
-      po_aperture_sample(P, a.bokeh, cdfRow, seed_a, n + (uint32_t)t, ap_x, ap_y);
-      newton_init(s);
-      need_init = false;
-      ++st_tries;
-    }
-    // ---- one Newton iteration for every busy lane
-    if (busy) { newton_iter(L, target, ap_x, ap_y, s); ++st_iters; }
-    ++st_rounds;
-
-    // ---- lanes whose solve ended
-    bool succ = false, failed = false;
-    if (busy && !newton_continue(s)) {
-      double out4;
-      const float transmittance = (float)newton_finish(L, s, out4);
-      bool try_ok = !(transmittance <= 0);
-      if (try_ok) {
-        const double ipx = s.x + s.dx * k.back_focal_length;
-        const double ipy = s.y + s.dy * k.back_focal_length;
-        if (ipx * ipx + ipy * ipy > k.inner_pupil_radius * k.inner_pupil_radius) try_ok = false;
-      }
-      if (try_ok) {
-        const double sx = s.x + s.dx * -P.sensor_shift;
-        const double sy = s.y + s.dy * -P.sensor_shift;
-        uint32_t pix;
-        if (po_sensor_to_pixel(P, sx, sy, pix)) {
-          succ = true;
-          splat(pix, n);
-        } else {
-          failed = true;
-        }
-        busy = false;
-      } else {
-        ++t;
-        if (t > P.vignetting_retries) { busy = false; failed = true; } else need_init = true;
-      }
-    }
-    const unsigned long long succ_mask = __ballot(succ);
-    const unsigned long long fail_mask = __ballot(failed);
-    if (succ_mask | fail_mask) {
-      // highest successful attempt index of this round (attempt indices grow with the lane rank only
-      // within one grant, so take a real max)
-      uint32_t mx = succ ? n : 0u;
-      for (int off = 32; off > 0; off >>= 1) {
-        const uint32_t o = __shfl_down(mx, off);
-        if (o > mx) mx = o;
-      }
-      if (lane == 0) {
-        const uint32_t nf = (uint32_t)__builtin_popcountll(fail_mask);
-        const uint32_t ns = (uint32_t)__builtin_popcountll(succ_mask);
-        if (nf) atomicSub(&st->slots, nf);
-        if (ns) { atomicAdd(&st->accepted, ns); atomicMax(&st->last_ok, mx); }
-      }
-      if (fail_mask) backoff = 0;                  // a slot just became free
-    }
-  }
-}
-
-template <class LensT, bool kTables>
-__global__ __launch_bounds__(256) void draw_po_kernel(DrawArgs a) {
-  __shared__ DevTerm s_terms[kTables ? kMaxTerms : 1];
-  __shared__ DevLens s_k;
-  __shared__ float s_cdfRow[kMaxBokehRows];
-  if (kTables) {
-    const uint32_t nt = a.lens->n_terms;
-    for (uint32_t i = threadIdx.x; i < nt; i += blockDim.x) s_terms[i] = a.terms[i];
-  }
-  if (threadIdx.x == 0) s_k = *a.lens;
-  const bool row_in_lds = a.P.bokeh_enable_image && a.bokeh.y <= kMaxBokehRows;
-  if (row_in_lds)
-    for (int i = threadIdx.x; i < a.bokeh.y; i += blockDim.x) s_cdfRow[i] = a.bokeh.cdfRow[i];
-  __syncthreads();
-  const float *cdfRow = row_in_lds ? s_cdfRow : a.bokeh.cdfRow;
-  LensT L;
-  if constexpr (kTables) { L.terms = s_terms; L.k = &s_k; } else { L.k = &s_k; }
-
-  const uint32_t lane = threadIdx.x & 63u;
-  unsigned long long n_items = a.ctr->work_count;
-  if (n_items > a.work_cap) n_items = a.work_cap;
-  // Tickets: ticket q serves item q % n_items as its (q / n_items)-th helper wave, so every item gets a
-  // first wave before any item gets a second one.  An item with `samples` draws can use at most
-  // ceil(samples / 64) waves at once.
-  const uint32_t max_samples = a.P.samples_override > 0 ? (uint32_t)a.P.samples_override : 2000u;
-  const unsigned long long max_helpers = (max_samples + 63u) / 64u;
-  const unsigned long long n_tickets = n_items * max_helpers;
-  uint32_t st_iters = 0, st_tries = 0, st_rounds = 0;
-  while (true) {
-    unsigned long long q = 0;
-    if (lane == 0) q = atomicAdd(&a.ctr->queue_head, 1ull);
-    q = __shfl(q, 0);
-    if (q >= n_tickets) break;
-    const unsigned long long item = q % n_items;
-    const uint32_t helper = (uint32_t)(q / n_items);
-    const uint32_t samples = __builtin_amdgcn_readfirstlane(a.work[item].y);
-    if (helper * 64u >= samples) continue;
-    ItemState *st = a.state + item;
-    if (helper > 0) {
-      // cheap look before doing the full item set-up: complete or fully reserved items need no helper
-      const uint32_t sl = __hip_atomic_load(&st->slots, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const uint32_t nx = __hip_atomic_load(&st->next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (sl >= samples || nx >= samples * 5u) continue;
-    }
-    const ItemHeader h = load_item(a, item, s_k.length);
-    po_item(a, L, cdfRow, h, st, st_iters, st_tries, st_rounds);
-  }
-  unsigned long long it64 = st_iters, tr64 = st_tries, rd64 = st_rounds;
-  for (int off = 32; off > 0; off >>= 1) {
-    it64 += __shfl_down(it64, off);
-    tr64 += __shfl_down(tr64, off);
-    rd64 += __shfl_down(rd64, off);
-  }
-  if (lane == 0) {
-    if (it64) atomicAdd(&a.ctr->newton_iters, it64);
-    if (tr64) atomicAdd(&a.ctr->tries, tr64);
-    if (rd64) atomicAdd(&a.ctr->lane_rounds, rd64);
-  }
-}
-
-// total_samples_taken / accepted statistics of the PO items (src/lentil_filter.cpp:248): one thread
-// per item after the draw kernel.
-__global__ __launch_bounds__(256) void po_item_stats_kernel(DrawArgs a) {
-  unsigned long long n_items = a.ctr->work_count;
-  if (n_items > a.work_cap) n_items = a.work_cap;
-  unsigned long long att = 0, acc = 0;
-  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_items; i += stride) {
-    const ItemState st = a.state[i];
-    const uint32_t samples = a.work[i].y;
-    acc += st.accepted;
-    att += (st.accepted >= samples) ? (unsigned long long)st.last_ok + 1ull : (unsigned long long)samples * 5ull;
-  }
-  for (int off = 32; off > 0; off >>= 1) {
-    att += __shfl_down(att, off);
-    acc += __shfl_down(acc, off);
-  }
-  if ((threadIdx.x & 63u) == 0) {
-    if (att) atomicAdd(&a.ctr->attempted, att);
-    if (acc) atomicAdd(&a.ctr->accepted, acc);
-  }
-}
-
-// Thin lens (K4): closed form, no retries -- lanes are consecutive attempts, a chunk never holds
-// more attempts than accepted draws are still missing.
-__global__ __launch_bounds__(256) void draw_thinlens_kernel(DrawArgs a) {
-  __shared__ float s_cdfRow[kMaxBokehRows];
-  const bool row_in_lds = a.P.bokeh_enable_image && a.bokeh.y <= kMaxBokehRows;
-  if (row_in_lds)
-    for (int i = threadIdx.x; i < a.bokeh.y; i += blockDim.x) s_cdfRow[i] = a.bokeh.cdfRow[i];
-  __syncthreads();
-  const float *cdfRow = row_in_lds ? s_cdfRow : a.bokeh.cdfRow;
-  const uint32_t lane = threadIdx.x & 63u;
-  unsigned long long n_items = a.ctr->work_count;
-  if (n_items > a.work_cap) n_items = a.work_cap;
-  unsigned long long tot_attempted = 0, tot_accepted = 0;
-  while (true) {
-    unsigned long long item = 0;
-    if (lane == 0) item = atomicAdd(&a.ctr->queue_head, 1ull);
-    item = __shfl(item, 0);
-    if (item >= n_items) break;
-    const ItemHeader h = load_item(a, item, 0.0);
-    const Splat splat{a, h.visit, h.rgba, h.I.add_energy, h.w};
-    uint32_t accepted = 0, n_base = 0;
-    const uint32_t samples = h.samples, max_total = samples * 5u;
-    while (accepted < samples && n_base < max_total) {
-      uint32_t chunk = samples - accepted;
-      if (chunk > 64u) chunk = 64u;
-      if (chunk > max_total - n_base) chunk = max_total - n_base;
-      const uint32_t n = n_base + lane;
-      bool ok = false;
-      uint32_t pix = 0;
-      if (lane < chunk) ok = thinlens_draw(a.P, a.bokeh, cdfRow, h.I.cs, h.px, h.py, n, pix);
-      if (ok) splat(pix, n);
-      accepted += (uint32_t)__builtin_popcountll(__ballot(ok));
-      n_base += chunk;
-    }
-    tot_attempted += n_base;
-    tot_accepted += accepted;
-  }
-  if (lane == 0) {
-    if (tot_attempted) atomicAdd(&a.ctr->attempted, tot_attempted);
-    if (tot_accepted) atomicAdd(&a.ctr->accepted, tot_accepted);
-  }
-}
-
-// K7 -- driver_process_bucket's normalisation, src/lentil_imager.cpp:169-186
-__global__ __launch_bounds__(256) void resolve_kernel(FrameDev F, float *resolved) {
-  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-  const uint64_t total = F.np * F.n_aovs;
-  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
-    const uint64_t p = i % F.np;
-    float4 c = reinterpret_cast<const float4 *>(F.acc)[i];
-    const float wt = F.weight[p];
-    if (wt != 0.0f) {                      // AtRGBA /= float multiplies by 1.0f/f
-      const float inv = 1.0f / wt;
-      c.x *= inv; c.y *= inv; c.z *= inv; c.w *= inv;
-    }
-    reinterpret_cast<float4 *>(resolved)[i] = c;
-  }
-}
-
-// ---------------------------------------------------------------------------------------
-// single-function test kernels
-// ---------------------------------------------------------------------------------------
-struct TestArgs {
-  lentil_params P;
-  const DevLens *lens;
-  const DevTerm *terms;
-  DevBokeh bokeh;
-  uint64_t n;
-  const double *in0;   // scene / target
-  const double *in1;   // ap
-  const int32_t *i0, *i1, *i2;
-  const uint32_t *u0, *u1;
-  double lambda;
-  double *o0, *o1, *o2;
-  int32_t *oi;
-};
-
-template <int WHAT>
-__global__ __launch_bounds__(256) void test_kernel(TestArgs t) {
-  __shared__ DevTerm s_terms[kMaxTerms];
-  __shared__ DevLens s_k;
-  if (t.lens) {
-    const uint32_t nt = t.lens->n_terms;
-    for (uint32_t i = threadIdx.x; i < nt; i += blockDim.x) s_terms[i] = t.terms[i];
-    if (threadIdx.x == 0) {
-      s_k = *t.lens;
-      if (WHAT == 0) {   // explicit lambda: recompute lens_ipow(lambda, e) exactly like the host does
-        s_k.lambda_pow[0] = 1.0; s_k.lambda_pow[1] = t.lambda;
-        for (uint32_t e = 2; e <= kMaxExp; ++e) s_k.lambda_pow[e] = ipow_u(t.lambda, e);
-      }
-    }
-  }
-  __syncthreads();
-  const LdsLens L{s_terms, &s_k};
-  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  // keep whole waves converged: table reads go through readfirstlane
-  const uint64_t ii = i < t.n ? i : t.n - 1;
-  if (WHAT == 0) {
-    double sensor[4], out[5] = {0, 0, 0, 0, t.lambda};
-    const double scene[3] = {t.in0[ii * 3], t.in0[ii * 3 + 1], t.in0[ii * 3 + 2]};
-    int iters = 0;
-    const double T = lt_sample_aperture(L, scene, t.in1[ii * 2], t.in1[ii * 2 + 1], sensor, out, &iters);
-    if (i < t.n) {
-      for (int c = 0; c < 4; ++c) t.o0[i * 5 + c] = sensor[c];
-      t.o0[i * 5 + 4] = t.lambda;
-      for (int c = 0; c < 5; ++c) t.o1[i * 5 + c] = out[c];
-      t.o2[i] = T;
-      if (t.oi) t.oi[i] = iters;
-    }
-  } else if (WHAT == 1) {
-    const double target[3] = {t.in0[ii * 3], t.in0[ii * 3 + 1], t.in0[ii * 3 + 2]};
-    double sx = 0, sy = 0;
-    const bool ok = trace_ray_bw_po(t.P, L, t.bokeh, t.bokeh.cdfRow, target, t.i0[ii], t.i1[ii], t.i2[ii], sx, sy);
-    if (i < t.n) { t.o0[i * 2] = sx; t.o0[i * 2 + 1] = sy; t.oi[i] = ok ? 1 : 0; }
-  } else {
-    double ax, ay;
-    po_aperture_sample(t.P, t.bokeh, t.bokeh.cdfRow, t.u0[ii], t.u1[ii], ax, ay);
-    if (i < t.n) { t.o0[i * 2] = ax; t.o0[i * 2 + 1] = ay; }
-  }
-}
 
 // =======================================================================================
 // host side
@@ -720,8 +45,18 @@ struct lentil_hip_ctx {
   std::vector<void *> owned_visit_mem;
 
   uint2 *d_work = nullptr;
-  ItemState *d_state = nullptr;
   uint64_t work_cap = 0;
+  // draw pipeline buffers (grow-only)
+  ItemHdr *d_hdr = nullptr;
+  ItemProg *d_prog = nullptr;
+  uint32_t *d_active[2] = {nullptr, nullptr};
+  uint64_t item_cap = 0;
+  Task *d_tasks[2] = {nullptr, nullptr};
+  uint64_t task_cap = 0;
+  uint32_t *d_pool[2] = {nullptr, nullptr};
+  uint64_t pool_cap = 0;
+  uint64_t max_pool_units = 1ull << 32;    // 16 GiB per pool at most (LENTIL_MAX_POOL_UNITS overrides)
+  int last_rounds = 0;
   DevCounters *d_ctr = nullptr;
   lentil_draw_record *d_log = nullptr;
   uint64_t log_cap = 0;
@@ -774,6 +109,7 @@ LENTIL_API int lentil_hip_create(int device, lentil_hip_ctx **out_ctx) {
   HIP_TRY(ctx, hipMalloc(&ctx->d_ctr, sizeof(DevCounters)));
   HIP_TRY(ctx, hipMemsetAsync(ctx->d_ctr, 0, sizeof(DevCounters), ctx->stream));
   if (const char *ft = getenv("LENTIL_FORCE_TABLES")) ctx->use_generated = !(ft[0] == '1');
+  if (const char *mp = getenv("LENTIL_MAX_POOL_UNITS")) ctx->max_pool_units = strtoull(mp, nullptr, 10);
   *out_ctx = ctx;
   return LENTIL_OK;
 }
@@ -805,7 +141,13 @@ LENTIL_API int lentil_hip_destroy(lentil_hip_ctx *ctx) {
   (void)hipFree(ctx->F.acc);
   (void)hipFree(ctx->d_resolved);
   (void)hipFree(ctx->d_work);
-  (void)hipFree(ctx->d_state);
+  (void)hipFree(ctx->d_hdr);
+  (void)hipFree(ctx->d_prog);
+  for (int i = 0; i < 2; ++i) {
+    (void)hipFree(ctx->d_active[i]);
+    (void)hipFree(ctx->d_tasks[i]);
+    (void)hipFree(ctx->d_pool[i]);
+  }
   (void)hipFree(ctx->d_ctr);
   (void)hipFree(ctx->d_log);
   for (auto &ev : ctx->ev) if (ev) (void)hipEventDestroy(ev);
@@ -1035,13 +377,10 @@ static void to_dev(VisitsDev &d, const lentil_visits *v) {
 static int ensure_worklist(lentil_hip_ctx *ctx, uint64_t n) {
   if (n <= ctx->work_cap && ctx->d_work) return LENTIL_OK;
   (void)hipFree(ctx->d_work);
-  (void)hipFree(ctx->d_state);
   ctx->d_work = nullptr;
-  ctx->d_state = nullptr;
   ctx->work_cap = 0;
   const uint64_t cap = n < 1024 ? 1024 : n;
   HIP_TRY(ctx, hipMalloc(&ctx->d_work, cap * sizeof(uint2)));
-  HIP_TRY(ctx, hipMalloc(&ctx->d_state, cap * sizeof(ItemState)));
   ctx->work_cap = cap;
   return LENTIL_OK;
 }
@@ -1104,6 +443,133 @@ LENTIL_API int lentil_hip_clear_frame(lentil_hip_ctx *ctx) {
   return LENTIL_OK;
 }
 
+template <typename T>
+static int grow(lentil_hip_ctx *ctx, T **p, uint64_t *cap, uint64_t need, uint64_t *shared_cap = nullptr) {
+  (void)shared_cap;
+  if (*p && *cap >= need) return LENTIL_OK;
+  (void)hipFree(*p);
+  *p = nullptr;
+  HIP_TRY(ctx, hipMalloc((void **)p, need * sizeof(T)));
+  *cap = need;
+  return LENTIL_OK;
+}
+
+// prep -> { solve -> accept } until every item has its draws (or ran out of attempts)
+static int run_draw_pipeline(lentil_hip_ctx *ctx) {
+  const lentil_params &P = ctx->P;
+  // the only host round trip of the pass: how many items did the scan find, and how many draws do they ask for
+  DevCounters c;
+  HIP_TRY(ctx, hipMemcpyAsync(&c, ctx->d_ctr, sizeof(c), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  uint64_t n_items = c.work_count < ctx->work_cap ? c.work_count : ctx->work_cap;
+  ctx->last_rounds = 0;
+  if (n_items == 0) return LENTIL_OK;
+  const bool po = P.cameraType == LENTIL_POLYNOMIAL_OPTICS;
+  const uint32_t retries = po ? (uint32_t)(P.vignetting_retries < 0 ? 0 : P.vignetting_retries) : 0u;
+  // round 0 needs sum(samples + retries) results; later rounds at most 2*remaining + 16 + retries per item
+  const uint64_t units0 = c.sum_samples + (uint64_t)retries * n_items;
+  const uint64_t units = 2 * c.sum_samples + (uint64_t)(2 * retries + 32) * n_items;
+  if (units > ctx->max_pool_units)
+    return fail(ctx, LENTIL_ERR_NOMEM, "draw result pool would exceed LENTIL_MAX_POOL_UNITS; split the visit stream");
+  (void)units0;
+  const uint64_t tasks = units / 64 + 2 * n_items + 64;
+  if (tasks > 0xFFFFFFF0ull) return fail(ctx, LENTIL_ERR_NOMEM, "too many solve tasks; split the visit stream");
+  int rc;
+  uint64_t cap;
+  if (n_items > ctx->item_cap) {
+    (void)hipFree(ctx->d_hdr); (void)hipFree(ctx->d_prog); (void)hipFree(ctx->d_active[0]); (void)hipFree(ctx->d_active[1]);
+    ctx->d_hdr = nullptr; ctx->d_prog = nullptr; ctx->d_active[0] = ctx->d_active[1] = nullptr;
+    ctx->item_cap = 0;
+    const uint64_t nc = n_items + n_items / 4 + 1024;
+    HIP_TRY(ctx, hipMalloc(&ctx->d_hdr, nc * sizeof(ItemHdr)));
+    HIP_TRY(ctx, hipMalloc(&ctx->d_prog, nc * sizeof(ItemProg)));
+    HIP_TRY(ctx, hipMalloc(&ctx->d_active[0], nc * sizeof(uint32_t)));
+    HIP_TRY(ctx, hipMalloc(&ctx->d_active[1], nc * sizeof(uint32_t)));
+    ctx->item_cap = nc;
+  }
+  if (tasks > ctx->task_cap) {
+    cap = 0;
+    const uint64_t nc = tasks + tasks / 4;
+    if ((rc = grow(ctx, &ctx->d_tasks[0], &cap, nc))) return rc;
+    cap = 0;
+    if ((rc = grow(ctx, &ctx->d_tasks[1], &cap, nc))) return rc;
+    ctx->task_cap = nc;
+  }
+  if (units > ctx->pool_cap) {
+    cap = 0;
+    const uint64_t nc = units + units / 4;
+    if ((rc = grow(ctx, &ctx->d_pool[0], &cap, nc))) return rc;
+    cap = 0;
+    if ((rc = grow(ctx, &ctx->d_pool[1], &cap, nc))) return rc;
+    ctx->pool_cap = nc;
+  }
+
+  DrawArgs da{};
+  da.P = P;
+  da.lens = po ? ctx->d_lens : nullptr;
+  da.terms = ctx->d_terms;
+  da.bokeh = ctx->bokeh;
+  da.V = ctx->V;
+  da.F = ctx->F;
+  da.work = ctx->d_work;
+  da.n_items = n_items;
+  da.ctr = ctx->d_ctr;
+  da.hdr = ctx->d_hdr;
+  da.prog = ctx->d_prog;
+  for (int i = 0; i < 2; ++i) { da.tasks[i] = ctx->d_tasks[i]; da.active[i] = ctx->d_active[i]; da.pool[i] = ctx->d_pool[i]; }
+  da.task_cap = (uint32_t)(ctx->task_cap > 0xFFFFFFF0ull ? 0xFFFFFFF0ull : ctx->task_cap);
+  da.pool_cap = ctx->pool_cap < 0xFFFFFFFFull ? ctx->pool_cap : 0xFFFFFFFFull;
+  da.log = ctx->d_log;
+  da.log_cap = ctx->log_cap;
+  da.retries = (int32_t)retries;
+  da.parity = 0;
+
+  hipLaunchKernelGGL(prep_items_kernel, dim3((unsigned)((n_items + 255) / 256)), dim3(256), 0, ctx->stream, da);
+  HIP_TRY(ctx, hipGetLastError());
+  const unsigned solve_blocks = (unsigned)ctx->num_cu * 4;
+  const size_t q_off = offsetof(DevCounters, n_tasks);
+  for (int round = 0; round < 64; ++round) {
+    const int par = round & 1, nxt = par ^ 1;
+    da.parity = par;
+    if (po) {
+      bool launched = false;
+#define LENTIL_LAUNCH_GEN(NAME)                                                                          \
+      if (!launched && ctx->use_generated && ctx->lens_hash == gen::Lens_##NAME::kTableHash) {            \
+        hipLaunchKernelGGL((solve_po_kernel<GenLens<gen::Lens_##NAME>, false>), dim3(solve_blocks), dim3(256), 0, \
+                           ctx->stream, da);                                                             \
+        launched = true;                                                                                 \
+      }
+      LENTIL_GENERATED_LENSES(LENTIL_LAUNCH_GEN)
+#undef LENTIL_LAUNCH_GEN
+      if (!launched)
+        hipLaunchKernelGGL((solve_po_kernel<LdsLens, true>), dim3(solve_blocks), dim3(256), 0, ctx->stream, da);
+    } else {
+      hipLaunchKernelGGL(solve_thinlens_kernel, dim3(solve_blocks), dim3(256), 0, ctx->stream, da);
+    }
+    HIP_TRY(ctx, hipGetLastError());
+    // reset the next round's queues, then accept
+    {
+      unsigned int zero = 0;
+      (void)zero;
+      HIP_TRY(ctx, hipMemsetAsync((char *)ctx->d_ctr + q_off + sizeof(unsigned int) * (0 + nxt), 0, sizeof(unsigned int), ctx->stream));
+      HIP_TRY(ctx, hipMemsetAsync((char *)ctx->d_ctr + q_off + sizeof(unsigned int) * (2 + nxt), 0, sizeof(unsigned int), ctx->stream));
+      HIP_TRY(ctx, hipMemsetAsync((char *)ctx->d_ctr + q_off + sizeof(unsigned int) * (4 + nxt), 0, sizeof(unsigned int), ctx->stream));
+      HIP_TRY(ctx, hipMemsetAsync((char *)ctx->d_ctr + q_off + sizeof(unsigned int) * (6 + nxt), 0, sizeof(unsigned int), ctx->stream));
+      HIP_TRY(ctx, hipMemsetAsync((char *)ctx->d_ctr + offsetof(DevCounters, pool_used) + sizeof(unsigned long long) * nxt, 0,
+                                  sizeof(unsigned long long), ctx->stream));
+    }
+    hipLaunchKernelGGL(accept_kernel, dim3((unsigned)ctx->num_cu * 2), dim3(256), 0, ctx->stream, da);
+    HIP_TRY(ctx, hipGetLastError());
+    ctx->last_rounds = round + 1;
+    unsigned int n_next = 0;
+    HIP_TRY(ctx, hipMemcpyAsync(&n_next, (char *)ctx->d_ctr + q_off + sizeof(unsigned int) * (4 + nxt), sizeof(unsigned int),
+                                hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (n_next == 0) break;
+  }
+  return LENTIL_OK;
+}
+
 LENTIL_API int lentil_hip_redistribute(lentil_hip_ctx *ctx) {
   CHECK_CTX(ctx);
   if (!ctx->have_params || !ctx->have_frame || !ctx->have_visits)
@@ -1124,7 +590,6 @@ LENTIL_API int lentil_hip_redistribute(lentil_hip_ctx *ctx) {
     sa.V = ctx->V;
     sa.F = ctx->F;
     sa.work = ctx->d_work;
-    sa.state = ctx->d_state;
     sa.work_cap = ctx->work_cap;
     sa.ctr = ctx->d_ctr;
     if (ctx->V.visits_per_pixel) {
@@ -1154,37 +619,8 @@ LENTIL_API int lentil_hip_redistribute(lentil_hip_ctx *ctx) {
   }
   HIP_TRY(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
   if (ctx->V.n) {
-    DrawArgs da{};
-    da.P = P;
-    da.lens = ctx->d_lens;
-    da.terms = ctx->d_terms;
-    da.bokeh = ctx->bokeh;
-    da.V = ctx->V;
-    da.F = ctx->F;
-    da.work = ctx->d_work;
-    da.state = ctx->d_state;
-    da.work_cap = ctx->work_cap;
-    da.ctr = ctx->d_ctr;
-    da.log = ctx->d_log;
-    da.log_cap = ctx->log_cap;
-    const unsigned blocks = (unsigned)ctx->num_cu * 4;
-    if (P.cameraType == LENTIL_POLYNOMIAL_OPTICS) {
-      bool launched = false;
-#define LENTIL_LAUNCH_GEN(NAME)                                                                        \
-      if (!launched && ctx->use_generated && ctx->lens_hash == gen::Lens_##NAME::kTableHash) {          \
-        hipLaunchKernelGGL((draw_po_kernel<GenLens<gen::Lens_##NAME>, false>), dim3(blocks), dim3(256), 0, \
-                           ctx->stream, da);                                                           \
-        launched = true;                                                                               \
-      }
-      LENTIL_GENERATED_LENSES(LENTIL_LAUNCH_GEN)
-#undef LENTIL_LAUNCH_GEN
-      if (!launched)
-        hipLaunchKernelGGL((draw_po_kernel<LdsLens, true>), dim3(blocks), dim3(256), 0, ctx->stream, da);
-      hipLaunchKernelGGL(po_item_stats_kernel, dim3((unsigned)ctx->num_cu), dim3(256), 0, ctx->stream, da);
-    } else {
-      hipLaunchKernelGGL(draw_thinlens_kernel, dim3(blocks), dim3(256), 0, ctx->stream, da);
-    }
-    HIP_TRY(ctx, hipGetLastError());
+    const int rc = run_draw_pipeline(ctx);
+    if (rc) return rc;
   }
   HIP_TRY(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
   ctx->timed_draw = true;

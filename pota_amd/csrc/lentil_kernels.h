@@ -1,0 +1,739 @@
+// lentil_kernels.h -- the gfx950 kernels of the redistribution path.
+//
+//   scan_*_kernel      K1+K2+K6: reads the visit columns (80+16K B/visit, HBM-bound), evaluates the
+//                      redistribute predicate and the draw count, wave-ballot/prefix-sum compacts the
+//                      redistributed visits ("items") into a work list and accumulates the
+//                      non-redistributed visits of each source pixel in reference order.
+//   prep_items_kernel  per item: camera-space target, seed, first batch of solve tasks.
+//   solve_*_kernel     K3/K4/K5: one backward trace per (item, m) -- see "solve once" below.
+//   accept_kernel      ordered acceptance of the traced draws + fp32 atomic splat; schedules the next
+//                      batch of solves for items that still miss accepted draws.
+//   resolve_kernel     K7: weight normalisation.
+#pragma once
+#include "lentil_device.h"
+#include "generated/lens_registry.h"
+
+using namespace lentil;
+
+// ---------------------------------------------------------------------------------------
+// device-side bookkeeping
+// ---------------------------------------------------------------------------------------
+struct DevCounters {
+  unsigned long long work_count;     // items pushed by the scan kernel
+  unsigned long long sum_samples;    // sum of the items' draw counts
+  unsigned long long redistributed;
+  unsigned long long attempted;
+  unsigned long long accepted;
+  unsigned long long overflow;       // work list / task list / result pool overflow (results incomplete)
+  unsigned long long log_count;
+  unsigned long long newton_iters;   // lane-iterations of the Newton solver
+  unsigned long long tries;          // solves started
+  unsigned long long lane_rounds;    // 64 x scheduler rounds (iteration slots offered)
+  // per-round queues, double buffered by round parity
+  unsigned int n_tasks[2];
+  unsigned int task_head[2];
+  unsigned int n_active[2];
+  unsigned int active_head[2];
+  unsigned long long pool_used[2];
+};
+
+struct VisitsDev {
+  uint64_t n;
+  uint32_t visits_per_pixel, pixels_per_row;
+  int32_t pixel_x0, pixel_y0;
+  uint32_t pixel_row_stride, n_extra;
+  const float4 *rgba, *pos_z, *raydir_time, *volume_ignore, *transmission;
+  const float4 *extra[LENTIL_MAX_AOVS - 1];
+  const uint32_t *pixel;
+  const float *inv_density;
+};
+
+struct FrameDev {
+  float *acc;        // [n_aovs][np][4]
+  float *weight;     // [np]
+  uint32_t n_aovs;
+  uint64_t np;       // xres*yres
+};
+
+struct ScanArgs {
+  lentil_params P;
+  double lens_length;
+  VisitsDev V;
+  FrameDev F;
+  uint2 *work;       // (visit, samples) per item
+  uint64_t work_cap;
+  DevCounters *ctr;
+  uint32_t ppt;      // pixels per wave tile (uniform mode)
+  uint32_t tv_pad;   // staging entries per wave (>= ppt * visits_per_pixel)
+};
+
+LD_DEV void visit_pixel(const VisitsDev &V, uint64_t v, int &px, int &py) {
+  if (V.visits_per_pixel) {
+    const uint64_t p = v / V.visits_per_pixel;
+    px = V.pixel_x0 + (int)(p % V.pixels_per_row);
+    py = V.pixel_y0 + (int)(p / V.pixels_per_row) * (int)V.pixel_row_stride;
+  } else {
+    const uint32_t q = V.pixel[v];
+    px = (int)(q & 0xFFFFu);
+    py = (int)(q >> 16);
+  }
+}
+
+LD_DEV uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+
+// wave-ballot + prefix-sum compaction of flagged lanes into the work list (K2)
+LD_DEV void push_work(bool flagged, uint32_t visit, uint32_t samples, uint2 *work, uint64_t cap, DevCounters *ctr) {
+  const unsigned long long mask = __ballot(flagged);
+  if (mask == 0ull) return;
+  const uint32_t lane = lane_id();
+  const uint32_t leader = (uint32_t)__builtin_ctzll(mask);
+  unsigned long long ssum = flagged ? samples : 0u;
+  for (int off = 32; off > 0; off >>= 1) ssum += __shfl_down(ssum, off);
+  ssum = __shfl(ssum, 0);
+  unsigned long long base = 0;
+  if (lane == leader) {
+    base = atomicAdd(&ctr->work_count, (unsigned long long)__builtin_popcountll(mask));
+    atomicAdd(&ctr->sum_samples, ssum);
+  }
+  base = __shfl(base, (int)leader);
+  if (flagged) {
+    const unsigned long long idx = base + (unsigned long long)__builtin_popcountll(mask & ((1ull << lane) - 1ull));
+    if (idx < cap) work[idx] = make_uint2(visit, samples);
+    else atomicAdd(&ctr->overflow, 1ull);
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// K1+K2+K6, uniform footprints.  One wave owns a tile of `ppt` consecutive source pixels
+// (= ppt*M consecutive visits, read as fully coalesced 1 KiB column loads), stages the weighted
+// contributions in wave-private LDS, then lane p adds up pixel p's M entries in iterator order --
+// the order the reference accumulates them (filter_and_add_to_buffer_new, src/lentil.h:938-955).
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void scan_uniform_kernel(ScanArgs a) {
+  extern __shared__ float4 smem[];
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  const uint32_t waves_per_block = blockDim.x >> 6;
+  float4 *sval = smem + (size_t)wave * a.tv_pad;
+  float *sw = reinterpret_cast<float *>(smem + (size_t)waves_per_block * a.tv_pad) + (size_t)wave * a.tv_pad;
+
+  const VisitsDev &V = a.V;
+  const uint32_t M = V.visits_per_pixel;
+  const uint32_t ppt = a.ppt;
+  const uint32_t TV = ppt * M;
+  const uint64_t n_pixels = (V.n + M - 1) / M;
+  const uint64_t n_tiles = (n_pixels + ppt - 1) / ppt;
+  const uint64_t wave_global = (uint64_t)blockIdx.x * waves_per_block + wave;
+  const uint64_t wave_stride = (uint64_t)gridDim.x * waves_per_block;
+  const uint32_t xres = a.P.xres;
+  unsigned long long n_redis = 0;
+
+  for (uint64_t tile = wave_global; tile < n_tiles; tile += wave_stride) {
+    const uint64_t pix0 = tile * ppt;
+    const uint64_t v0 = pix0 * M;
+    for (uint32_t eb = 0; eb < TV; eb += 64) {
+      const uint32_t e = eb + lane;
+      const uint64_t v = v0 + e;
+      const bool valid = (e < TV) && (v < V.n);
+      float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+      float w = 0.f;
+      bool flagged = false;
+      int samples = 0;
+      if (valid) {
+        const float4 rgba = V.rgba[v];
+        const float4 pz = V.pos_z[v];
+        const float4 rt = V.raydir_time[v];
+        const float4 vi = V.volume_ignore[v];
+        const float4 tr = V.transmission[v];
+        const float invd = V.inv_density ? V.inv_density[v] : a.P.inverse_sample_density;
+        const VisitInfo I = visit_prologue(a.P, a.lens_length, rgba, pz, rt, vi, tr, invd);
+        if (I.redistribute) {
+          flagged = true;
+          samples = I.samples;
+        } else {
+          w = 1.0f * invd;                              // filter_weight * inv_density, lentil.h:949-953
+          val = make_float4((rgba.x + 0.0f) * w, (rgba.y + 0.0f) * w, (rgba.z + 0.0f) * w, (rgba.w + 0.0f) * w);
+        }
+      }
+      push_work(flagged, (uint32_t)v, (uint32_t)samples, a.work, a.work_cap, a.ctr);
+      n_redis += flagged ? 1ull : 0ull;
+      if (e < TV) { sval[e] = val; sw[e] = w; }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+    const uint64_t pix = pix0 + lane;
+    const bool own = (lane < ppt) && (pix < n_pixels);
+    uint64_t lin = 0;
+    if (own) {
+      const int px = V.pixel_x0 + (int)(pix % V.pixels_per_row);
+      const int py = V.pixel_y0 + (int)(pix / V.pixels_per_row) * (int)V.pixel_row_stride;
+      lin = (uint64_t)px + (uint64_t)py * xres;
+      float4 s = reinterpret_cast<float4 *>(a.F.acc)[lin];
+      float ws = a.F.weight[lin];
+      for (uint32_t j = 0; j < M; ++j) {
+        const float4 c = sval[lane * M + j];
+        const float cw = sw[lane * M + j];
+        if (cw != 0.0f) { s.x += c.x; s.y += c.y; s.z += c.z; s.w += c.w; ws += cw; }
+      }
+      reinterpret_cast<float4 *>(a.F.acc)[lin] = s;
+      a.F.weight[lin] = ws;
+    }
+    // extra AOVs: same weights, one column at a time through the same staging area
+    for (uint32_t k = 0; k < V.n_extra; ++k) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      for (uint32_t eb = 0; eb < TV; eb += 64) {
+        const uint32_t e = eb + lane;
+        const uint64_t v = v0 + e;
+        if (e < TV) {
+          const float w = sw[e];
+          float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (v < V.n && w != 0.0f) {
+            const float4 c = V.extra[k][v];
+            x = make_float4((c.x + 0.0f) * w, (c.y + 0.0f) * w, (c.z + 0.0f) * w, (c.w + 0.0f) * w);
+          }
+          sval[e] = x;
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      if (own) {
+        float4 *dst = reinterpret_cast<float4 *>(a.F.acc) + (size_t)(k + 1) * a.F.np + lin;
+        float4 s = *dst;
+        for (uint32_t j = 0; j < M; ++j) {
+          if (sw[lane * M + j] != 0.0f) {
+            const float4 c = sval[lane * M + j];
+            s.x += c.x; s.y += c.y; s.z += c.z; s.w += c.w;
+          }
+        }
+        *dst = s;
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+  // counters: one atomic per wave
+  for (int off = 32; off > 0; off >>= 1) n_redis += __shfl_down(n_redis, off);
+  if (lane == 0 && n_redis) atomicAdd(&a.ctr->redistributed, n_redis);
+}
+
+// K1+K2+K6 for ragged footprints (explicit per-visit pixel): lane per visit, fp32 atomics for the
+// direct accumulation.
+__global__ __launch_bounds__(256) void scan_ragged_kernel(ScanArgs a) {
+  const VisitsDev &V = a.V;
+  const uint32_t lane = threadIdx.x & 63u;
+  unsigned long long n_redis = 0;
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  const uint64_t n_round = (V.n + 63ull) & ~63ull;
+  for (uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; v < n_round; v += stride) {
+    bool flagged = false;
+    int samples = 0;
+    if (v < V.n) {
+      const float4 rgba = V.rgba[v];
+      const float invd = V.inv_density ? V.inv_density[v] : a.P.inverse_sample_density;
+      const VisitInfo I = visit_prologue(a.P, a.lens_length, rgba, V.pos_z[v], V.raydir_time[v],
+                                         V.volume_ignore[v], V.transmission[v], invd);
+      if (I.redistribute) {
+        flagged = true;
+        samples = I.samples;
+      } else {
+        int px, py;
+        visit_pixel(V, v, px, py);
+        const uint64_t lin = (uint64_t)px + (uint64_t)py * a.P.xres;
+        const float w = 1.0f * invd;
+        float *d = a.F.acc + lin * 4;
+        atomicAdd(d + 0, (rgba.x + 0.0f) * w);
+        atomicAdd(d + 1, (rgba.y + 0.0f) * w);
+        atomicAdd(d + 2, (rgba.z + 0.0f) * w);
+        atomicAdd(d + 3, (rgba.w + 0.0f) * w);
+        atomicAdd(a.F.weight + lin, w);
+        for (uint32_t k = 0; k < V.n_extra; ++k) {
+          const float4 c = V.extra[k][v];
+          float *dk = a.F.acc + ((size_t)(k + 1) * a.F.np + lin) * 4;
+          atomicAdd(dk + 0, (c.x + 0.0f) * w);
+          atomicAdd(dk + 1, (c.y + 0.0f) * w);
+          atomicAdd(dk + 2, (c.z + 0.0f) * w);
+          atomicAdd(dk + 3, (c.w + 0.0f) * w);
+        }
+      }
+    }
+    push_work(flagged, (uint32_t)v, (uint32_t)samples, a.work, a.work_cap, a.ctr);
+    n_redis += flagged ? 1ull : 0ull;
+  }
+  for (int off = 32; off > 0; off >>= 1) n_redis += __shfl_down(n_redis, off);
+  if (lane == 0 && n_redis) atomicAdd(&a.ctr->redistributed, n_redis);
+}
+// ---------------------------------------------------------------------------------------
+// K3/K4/K5: draws -- "solve once".
+//
+// Reference semantics (src/lentil_filter.cpp:248-299, src/lentil.h:592-648): attempt n of an item
+// tries aperture draws seeded tea<8>(px*py+px, n+t), t = 0..vignetting_retries, until one traces
+// through the lens; then the sensor point must fall inside the frame, else the attempt fails.  The
+// accepted draws are the first `samples` successful attempts in attempt order, n < 5*samples.
+//
+// The seed -- and with it the whole backward trace -- depends on n+t only, so
+// try t of attempt n IS try 0 of attempt n+t.  Define for m = 0,1,2,...
+//     R(m) = FAIL       the trace with seed (.., m) fails (transmittance <= 0 / pupil clipping)
+//            OUT        it succeeds but lands outside the frame (or NaN)
+//            pixel p    it succeeds and lands on pixel p
+// then attempt n yields the first non-FAIL entry of R(n .. n+retries) (and fails if that is OUT or
+// there is none).  Every R(m) is computed exactly once, all of them independently:
+//   solve kernel : fills R for a batch of m per item.  Lanes are independent Newton solves advanced
+//                  one iteration per round; a lane that finishes is refilled with the next (item, m)
+//                  unit, so neither iteration counts (10..100) nor failing draws stall a wave, and the
+//                  parallelism is the number of draws, not the number of items.
+//   accept kernel: one wave per item walks the attempts in order, applies the rule above, accepts
+//                  successes until `samples` are reached, splats them, and -- if draws are still
+//                  missing because attempts failed -- schedules the next batch of m (over-provisioned;
+//                  the surplus is simply never accepted).
+// Thin lens (no retries): R(m) is the closed-form draw of attempt m.
+// ---------------------------------------------------------------------------------------
+constexpr int kMaxBokehRows = 2048;
+constexpr uint32_t kCodeFail = 0xFFFFFFFFu;
+constexpr uint32_t kCodeOut = 0xFFFFFFFEu;
+
+struct ItemHdr {          // 32 B, written by prep_items_kernel
+  double tx, ty, tz;      // PO: -P_cs * 10 (src/lentil_filter.cpp:271); thin lens: P_cs (floats, exactly)
+  uint32_t seed_a;        // (unsigned)(px*py+px)
+  int32_t px_py;          // px | py << 16
+};
+
+struct ItemProg {         // 32 B, progress of an item across rounds
+  uint32_t n_done;        // attempts resolved so far (all earlier attempts are final)
+  uint32_t accepted;
+  uint32_t m_lo, m_hi;    // R(m) of the current round covers [m_lo, m_hi); any R(m < m_lo) still needed is FAIL
+  uint32_t res_off;       // offset of R(m_lo) in the current round's result pool
+  uint32_t last_ok;       // highest accepted attempt index
+  uint32_t pad0, pad1;
+};
+
+struct Task {             // up to 64 consecutive m of one item
+  uint32_t item, m_base, res_off, count;
+};
+
+struct DrawArgs {
+  lentil_params P;
+  const DevLens *lens;     // header, global memory (null for the thin lens)
+  const DevTerm *terms;    // global memory
+  DevBokeh bokeh;
+  VisitsDev V;
+  FrameDev F;
+  const uint2 *work;
+  uint64_t n_items;
+  DevCounters *ctr;
+  ItemHdr *hdr;
+  ItemProg *prog;
+  Task *tasks[2];
+  uint32_t task_cap;
+  uint32_t *active[2];
+  uint32_t *pool[2];
+  uint64_t pool_cap;
+  lentil_draw_record *log;
+  uint64_t log_cap;
+  int32_t retries;         // vignetting_retries for PO, 0 for the thin lens
+  int32_t parity;
+};
+
+struct ItemVisit {
+  uint32_t visit, samples;
+  int px, py;
+  VisitInfo I;
+  float4 rgba;
+  float w;
+};
+
+LD_DEV ItemVisit load_item_visit(const DrawArgs &a, uint32_t item, double lens_length) {
+  ItemVisit h;
+  const uint2 wi = a.work[item];
+  h.visit = wi.x;
+  h.samples = wi.y;
+  const uint32_t v = h.visit;
+  h.rgba = a.V.rgba[v];
+  const float invd = a.V.inv_density ? a.V.inv_density[v] : a.P.inverse_sample_density;
+  h.I = visit_prologue(a.P, lens_length, h.rgba, a.V.pos_z[v], a.V.raydir_time[v], a.V.volume_ignore[v],
+                       a.V.transmission[v], invd);
+  visit_pixel(a.V, v, h.px, h.py);
+  const float inv_samples = (float)(1.0 / (double)(float)(int)h.samples);
+  h.w = 1.0f * invd * inv_samples;              // src/lentil_filter.cpp:297
+  return h;
+}
+
+// emit the solve tasks for m in [m_lo, m_hi) of `item` into the queues of round parity `par`
+LD_DEV bool emit_tasks(const DrawArgs &a, uint32_t par, uint32_t item, uint32_t m_lo, uint32_t m_hi, uint32_t &res_off) {
+  const uint32_t count = m_hi - m_lo;
+  const unsigned long long off = atomicAdd(&a.ctr->pool_used[par], (unsigned long long)count);
+  const uint32_t nt = (count + 63u) / 64u;
+  const uint32_t tb = atomicAdd(&a.ctr->n_tasks[par], nt);
+  if (off + count > a.pool_cap || (unsigned long long)tb + nt > a.task_cap) {
+    atomicAdd(&a.ctr->overflow, 1ull);
+    return false;
+  }
+  res_off = (uint32_t)off;
+  for (uint32_t t = 0; t < nt; ++t) {
+    Task k;
+    k.item = item;
+    k.m_base = m_lo + t * 64u;
+    k.res_off = (uint32_t)off + t * 64u;
+    k.count = (count - t * 64u) < 64u ? (count - t * 64u) : 64u;
+    a.tasks[par][tb + t] = k;
+  }
+  return true;
+}
+
+// one thread per item: header + first batch R(0 .. samples-1+retries)
+__global__ __launch_bounds__(256) void prep_items_kernel(DrawArgs a) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i == 0) a.ctr->n_active[0] = (unsigned int)a.n_items;
+  if (i >= a.n_items) return;
+  const uint32_t item = (uint32_t)i;
+  const ItemVisit h = load_item_visit(a, item, a.lens ? a.lens->length : 0.0);
+  ItemHdr hd;
+  if (a.P.cameraType == LENTIL_POLYNOMIAL_OPTICS) {
+    hd.tx = -(double)h.I.cs[0] * 10.0; hd.ty = -(double)h.I.cs[1] * 10.0; hd.tz = -(double)h.I.cs[2] * 10.0;
+  } else {
+    hd.tx = (double)h.I.cs[0]; hd.ty = (double)h.I.cs[1]; hd.tz = (double)h.I.cs[2];
+  }
+  hd.seed_a = (uint32_t)(h.px * h.py + h.px);
+  hd.px_py = (h.px & 0xFFFF) | (h.py << 16);
+  a.hdr[item] = hd;
+  const uint32_t samples = h.samples, max_total = samples * 5u;
+  const uint32_t m_limit = max_total + (uint32_t)a.retries;
+  uint32_t m_hi = samples + (uint32_t)a.retries;
+  if (m_hi > m_limit) m_hi = m_limit;
+  ItemProg pg{};
+  pg.m_lo = 0;
+  pg.m_hi = m_hi;
+  uint32_t off = 0;
+  if (!emit_tasks(a, 0u, item, 0u, m_hi, off)) pg.m_hi = 0;
+  pg.res_off = off;
+  a.prog[item] = pg;
+  a.active[0][item] = item;
+}
+
+// ---- solve, polynomial optics ------------------------------------------------------------------
+template <class LensT, bool kTables>
+__global__ __launch_bounds__(256) void solve_po_kernel(DrawArgs a) {
+  __shared__ DevTerm s_terms[kTables ? kMaxTerms : 1];
+  __shared__ DevLens s_k;
+  __shared__ float s_cdfRow[kMaxBokehRows];
+  if (kTables) {
+    const uint32_t nt = a.lens->n_terms;
+    for (uint32_t i = threadIdx.x; i < nt; i += blockDim.x) s_terms[i] = a.terms[i];
+  }
+  if (threadIdx.x == 0) s_k = *a.lens;
+  const bool row_in_lds = a.P.bokeh_enable_image && a.bokeh.y <= kMaxBokehRows;
+  if (row_in_lds)
+    for (int i = threadIdx.x; i < a.bokeh.y; i += blockDim.x) s_cdfRow[i] = a.bokeh.cdfRow[i];
+  __syncthreads();
+  const float *cdfRow = row_in_lds ? s_cdfRow : a.bokeh.cdfRow;
+  LensT L;
+  if constexpr (kTables) { L.terms = s_terms; L.k = &s_k; } else { L.k = &s_k; }
+  const DevLens &k = s_k;
+  const lentil_params &P = a.P;
+
+  const uint32_t par = (uint32_t)a.parity;
+  const Task *tasks = a.tasks[par];
+  uint32_t *res = a.pool[par];
+  const uint32_t n_tasks = a.ctr->n_tasks[par] < a.task_cap ? a.ctr->n_tasks[par] : a.task_cap;
+  const uint32_t lane = lane_id();
+  const unsigned long long lt_mask = (1ull << lane) - 1ull;
+
+  // wave-uniform cursor into the current task
+  uint32_t cur_item = 0, cur_m = 0, cur_res = 0, cur_left = 0;
+  bool no_more = false;
+  // per-lane solve
+  bool busy = false, need_init = false;
+  uint32_t m = 0, res_idx = 0, seed_a = 0;
+  double target[3] = {0, 0, 1};
+  double ap_x = 0.0, ap_y = 0.0;
+  NewtonState s;
+  newton_init(s);
+  uint32_t st_iters = 0, st_tries = 0, st_rounds = 0;
+
+  while (true) {
+    const unsigned long long busy_mask = __ballot(busy);
+    const uint32_t inflight = (uint32_t)__builtin_popcountll(busy_mask);
+    const uint32_t n_idle = 64u - inflight;
+    const uint32_t my_rank = (uint32_t)__builtin_popcountll(~busy_mask & lt_mask);
+    uint32_t filled = 0;
+    while (filled < n_idle) {
+      if (cur_left == 0) {
+        if (no_more) break;
+        uint32_t q = 0;
+        if (lane == 0) q = atomicAdd(&a.ctr->task_head[par], 1u);
+        q = __builtin_amdgcn_readfirstlane(q);
+        if (q >= n_tasks) { no_more = true; break; }
+        const Task t = tasks[q];
+        cur_item = __builtin_amdgcn_readfirstlane(t.item);
+        cur_m = __builtin_amdgcn_readfirstlane(t.m_base);
+        cur_res = __builtin_amdgcn_readfirstlane(t.res_off);
+        cur_left = __builtin_amdgcn_readfirstlane(t.count);
+      }
+      uint32_t take = n_idle - filled;
+      if (take > cur_left) take = cur_left;
+      if (!busy && my_rank >= filled && my_rank < filled + take) {
+        const uint32_t j = my_rank - filled;
+        m = cur_m + j;
+        res_idx = cur_res + j;
+        const ItemHdr hd = a.hdr[cur_item];
+        target[0] = hd.tx; target[1] = hd.ty; target[2] = hd.tz;
+        seed_a = hd.seed_a;
+        busy = true;
+        need_init = true;
+      }
+      cur_m += take; cur_res += take; cur_left -= take; filled += take;
+    }
+    if (inflight + filled == 0u) break;
+
+    // aperture draw of the reference's try with seed (seed_a, m), src/lentil.h:596-609
+    if (busy && need_init) {
+      po_aperture_sample(P, a.bokeh, cdfRow, seed_a, m, ap_x, ap_y);
+      newton_init(s);
+      need_init = false;
+      ++st_tries;
+    }
+    if (busy) { newton_iter(L, target, ap_x, ap_y, s); ++st_iters; }
+    ++st_rounds;
+
+    if (busy && !newton_continue(s)) {
+      double out4;
+      const float transmittance = (float)newton_finish(L, s, out4);
+      uint32_t code = kCodeFail;
+      bool try_ok = !(transmittance <= 0);                                   // src/lentil.h:633-637
+      if (try_ok) {
+        const double ipx = s.x + s.dx * k.back_focal_length;                // :640-645
+        const double ipy = s.y + s.dy * k.back_focal_length;
+        if (ipx * ipx + ipy * ipy > k.inner_pupil_radius * k.inner_pupil_radius) try_ok = false;
+      }
+      if (try_ok) {
+        const double sx = s.x + s.dx * -P.sensor_shift;                     // :654-655
+        const double sy = s.y + s.dy * -P.sensor_shift;
+        uint32_t pix;
+        code = po_sensor_to_pixel(P, sx, sy, pix) ? pix : kCodeOut;         // src/lentil_filter.cpp:276-290
+      }
+      res[res_idx] = code;
+      busy = false;
+    }
+  }
+  unsigned long long it64 = st_iters, tr64 = st_tries, rd64 = st_rounds;
+  for (int off = 32; off > 0; off >>= 1) {
+    it64 += __shfl_down(it64, off);
+    tr64 += __shfl_down(tr64, off);
+    rd64 += __shfl_down(rd64, off);
+  }
+  if (lane == 0) {
+    if (it64) atomicAdd(&a.ctr->newton_iters, it64);
+    if (tr64) atomicAdd(&a.ctr->tries, tr64);
+    if (rd64) atomicAdd(&a.ctr->lane_rounds, rd64);
+  }
+}
+
+// ---- solve, thin lens (K4): closed form, one wave per task ---------------------------------------
+__global__ __launch_bounds__(256) void solve_thinlens_kernel(DrawArgs a) {
+  __shared__ float s_cdfRow[kMaxBokehRows];
+  const bool row_in_lds = a.P.bokeh_enable_image && a.bokeh.y <= kMaxBokehRows;
+  if (row_in_lds)
+    for (int i = threadIdx.x; i < a.bokeh.y; i += blockDim.x) s_cdfRow[i] = a.bokeh.cdfRow[i];
+  __syncthreads();
+  const float *cdfRow = row_in_lds ? s_cdfRow : a.bokeh.cdfRow;
+  const uint32_t par = (uint32_t)a.parity;
+  const uint32_t n_tasks = a.ctr->n_tasks[par] < a.task_cap ? a.ctr->n_tasks[par] : a.task_cap;
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
+  for (uint32_t q = wave; q < n_tasks; q += n_waves) {
+    const Task t = a.tasks[par][q];
+    if (lane < t.count) {
+      const ItemHdr hd = a.hdr[t.item];
+      const float cs[3] = {(float)hd.tx, (float)hd.ty, (float)hd.tz};
+      const int px = hd.px_py & 0xFFFF, py = hd.px_py >> 16;
+      uint32_t pix;
+      const bool ok = thinlens_draw(a.P, a.bokeh, cdfRow, cs, px, py, t.m_base + lane, pix);
+      a.pool[par][t.res_off + lane] = ok ? pix : kCodeOut;     // no retries: a failed draw ends the attempt
+    }
+  }
+}
+
+// ---- ordered acceptance + splat -------------------------------------------------------------------
+__global__ __launch_bounds__(256) void accept_kernel(DrawArgs a) {
+  const uint32_t par = (uint32_t)a.parity, nxt = par ^ 1u;
+  const uint32_t n_active = a.ctr->n_active[par];
+  const uint32_t lane = threadIdx.x & 63u;
+  const unsigned long long lt_mask = (1ull << lane) - 1ull;
+  const uint32_t *res = a.pool[par];
+  const uint32_t retries = (uint32_t)a.retries;
+  const double lens_length = a.lens ? a.lens->length : 0.0;
+  unsigned long long tot_attempted = 0, tot_accepted = 0;
+  while (true) {
+    uint32_t ai = 0;
+    if (lane == 0) ai = atomicAdd(&a.ctr->active_head[par], 1u);
+    ai = __builtin_amdgcn_readfirstlane(ai);
+    if (ai >= n_active) break;
+    const uint32_t item = __builtin_amdgcn_readfirstlane(a.active[par][ai]);
+    const ItemProg pg = a.prog[item];
+    const ItemVisit h = load_item_visit(a, item, lens_length);
+    const uint32_t S = h.samples, max_total = S * 5u, m_limit = max_total + retries;
+    const float ae = h.I.add_energy, w = h.w;
+    uint32_t n = pg.n_done, acc = pg.accepted, last_ok = pg.last_ok;
+    bool stalled = false;
+    while (!stalled && acc < S && n < max_total) {
+      const uint32_t my_n = n + lane;
+      const bool valid = my_n < max_total;
+      uint32_t code = kCodeFail;
+      bool unresolved = false;
+      if (valid) {
+        for (uint32_t t = 0; t <= retries; ++t) {
+          const uint32_t m = my_n + t;
+          if (m >= pg.m_hi) { unresolved = (pg.m_hi < m_limit); break; }
+          const uint32_t c = (m < pg.m_lo) ? kCodeFail : res[pg.res_off + (m - pg.m_lo)];
+          if (c != kCodeFail) { code = c; break; }
+        }
+      }
+      const unsigned long long umask = __ballot(valid && unresolved);
+      const uint32_t first_u = umask ? (uint32_t)__builtin_ctzll(umask) : 64u;
+      uint32_t limit = max_total - n < 64u ? max_total - n : 64u;
+      if (first_u < limit) { limit = first_u; stalled = true; }
+      const bool succ = lane < limit && code < kCodeOut;
+      const unsigned long long smask = __ballot(succ);
+      const uint32_t rank = acc + (uint32_t)__builtin_popcountll(smask & lt_mask);
+      const bool take = succ && rank < S;
+      if (take) {
+        // Camera::add_to_buffer, src/lentil.h:827-830
+        const uint32_t pix = code;
+        float *d = a.F.acc + (size_t)pix * 4;
+        atomicAdd(d + 0, (h.rgba.x + ae) * w);
+        atomicAdd(d + 1, (h.rgba.y + ae) * w);
+        atomicAdd(d + 2, (h.rgba.z + ae) * w);
+        atomicAdd(d + 3, (h.rgba.w + ae) * w);
+        atomicAdd(a.F.weight + pix, w);
+        for (uint32_t kx = 0; kx < a.V.n_extra; ++kx) {
+          const float4 c = a.V.extra[kx][h.visit];
+          float *dk = a.F.acc + ((size_t)(kx + 1) * a.F.np + pix) * 4;
+          atomicAdd(dk + 0, (c.x + ae) * w);
+          atomicAdd(dk + 1, (c.y + ae) * w);
+          atomicAdd(dk + 2, (c.z + ae) * w);
+          atomicAdd(dk + 3, (c.w + ae) * w);
+        }
+        if (a.log_cap) {
+          const unsigned long long li = atomicAdd(&a.ctr->log_count, 1ull);
+          if (li < a.log_cap) { a.log[li].visit = h.visit; a.log[li].attempt = my_n; a.log[li].pixel = pix; }
+        }
+      }
+      const unsigned long long tmask = __ballot(take);
+      if (tmask) {
+        acc += (uint32_t)__builtin_popcountll(tmask);
+        last_ok = n + (63u - (uint32_t)__builtin_clzll(tmask));
+      }
+      n += limit;
+    }
+    if (acc < S && n < max_total && pg.m_hi < m_limit && pg.m_hi > 0) {
+      // draws are still missing: schedule the next batch (over-provisioned x2 + a margin)
+      const uint32_t remaining = S - acc;
+      unsigned long long n_target = (unsigned long long)n + 2ull * remaining + 16ull;
+      if (n_target > max_total) n_target = max_total;
+      uint32_t new_hi = (uint32_t)n_target + retries;
+      if (new_hi > m_limit) new_hi = m_limit;
+      if (lane == 0) {
+        uint32_t off = 0;
+        ItemProg np_ = pg;
+        np_.n_done = n; np_.accepted = acc; np_.last_ok = last_ok;
+        np_.m_lo = pg.m_hi; np_.m_hi = new_hi;
+        if (emit_tasks(a, nxt, item, pg.m_hi, new_hi, off)) {
+          np_.res_off = off;
+          a.prog[item] = np_;
+          const uint32_t slot = atomicAdd(&a.ctr->n_active[nxt], 1u);
+          a.active[nxt][slot] = item;
+        }
+      }
+    } else {
+      // total_samples_taken when the reference's loop ends, src/lentil_filter.cpp:248
+      tot_attempted += (acc >= S) ? (unsigned long long)last_ok + 1ull : (unsigned long long)max_total;
+      tot_accepted += acc;
+    }
+  }
+  if (lane == 0) {
+    if (tot_attempted) atomicAdd(&a.ctr->attempted, tot_attempted);
+    if (tot_accepted) atomicAdd(&a.ctr->accepted, tot_accepted);
+  }
+}
+
+// K7 -- driver_process_bucket's normalisation, src/lentil_imager.cpp:169-186
+__global__ __launch_bounds__(256) void resolve_kernel(FrameDev F, float *resolved) {
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  const uint64_t total = F.np * F.n_aovs;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const uint64_t p = i % F.np;
+    float4 c = reinterpret_cast<const float4 *>(F.acc)[i];
+    const float wt = F.weight[p];
+    if (wt != 0.0f) {                      // AtRGBA /= float multiplies by 1.0f/f
+      const float inv = 1.0f / wt;
+      c.x *= inv; c.y *= inv; c.z *= inv; c.w *= inv;
+    }
+    reinterpret_cast<float4 *>(resolved)[i] = c;
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// single-function test kernels
+// ---------------------------------------------------------------------------------------
+struct TestArgs {
+  lentil_params P;
+  const DevLens *lens;
+  const DevTerm *terms;
+  DevBokeh bokeh;
+  uint64_t n;
+  const double *in0;   // scene / target
+  const double *in1;   // ap
+  const int32_t *i0, *i1, *i2;
+  const uint32_t *u0, *u1;
+  double lambda;
+  double *o0, *o1, *o2;
+  int32_t *oi;
+};
+
+template <int WHAT>
+__global__ __launch_bounds__(256) void test_kernel(TestArgs t) {
+  __shared__ DevTerm s_terms[kMaxTerms];
+  __shared__ DevLens s_k;
+  if (t.lens) {
+    const uint32_t nt = t.lens->n_terms;
+    for (uint32_t i = threadIdx.x; i < nt; i += blockDim.x) s_terms[i] = t.terms[i];
+    if (threadIdx.x == 0) {
+      s_k = *t.lens;
+      if (WHAT == 0) {   // explicit lambda: recompute lens_ipow(lambda, e) exactly like the host does
+        s_k.lambda_pow[0] = 1.0; s_k.lambda_pow[1] = t.lambda;
+        for (uint32_t e = 2; e <= kMaxExp; ++e) s_k.lambda_pow[e] = ipow_u(t.lambda, e);
+      }
+    }
+  }
+  __syncthreads();
+  const LdsLens L{s_terms, &s_k};
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  // keep whole waves converged: table reads go through readfirstlane
+  const uint64_t ii = i < t.n ? i : t.n - 1;
+  if (WHAT == 0) {
+    double sensor[4], out[5] = {0, 0, 0, 0, t.lambda};
+    const double scene[3] = {t.in0[ii * 3], t.in0[ii * 3 + 1], t.in0[ii * 3 + 2]};
+    int iters = 0;
+    const double T = lt_sample_aperture(L, scene, t.in1[ii * 2], t.in1[ii * 2 + 1], sensor, out, &iters);
+    if (i < t.n) {
+      for (int c = 0; c < 4; ++c) t.o0[i * 5 + c] = sensor[c];
+      t.o0[i * 5 + 4] = t.lambda;
+      for (int c = 0; c < 5; ++c) t.o1[i * 5 + c] = out[c];
+      t.o2[i] = T;
+      if (t.oi) t.oi[i] = iters;
+    }
+  } else if (WHAT == 1) {
+    const double target[3] = {t.in0[ii * 3], t.in0[ii * 3 + 1], t.in0[ii * 3 + 2]};
+    double sx = 0, sy = 0;
+    const bool ok = trace_ray_bw_po(t.P, L, t.bokeh, t.bokeh.cdfRow, target, t.i0[ii], t.i1[ii], t.i2[ii], sx, sy);
+    if (i < t.n) { t.o0[i * 2] = sx; t.o0[i * 2 + 1] = sy; t.oi[i] = ok ? 1 : 0; }
+  } else {
+    double ax, ay;
+    po_aperture_sample(t.P, t.bokeh, t.bokeh.cdfRow, t.u0[ii], t.u1[ii], ax, ay);
+    if (i < t.n) { t.o0[i * 2] = ax; t.o0[i * 2 + 1] = ay; }
+  }
+}
+
