@@ -468,7 +468,8 @@ static int run_draw_pipeline(lentil_hip_ctx *ctx) {
   const uint32_t retries = po ? (uint32_t)(P.vignetting_retries < 0 ? 0 : P.vignetting_retries) : 0u;
   // round 0 needs sum(samples + retries) results; later rounds at most 2*remaining + 16 + retries per item
   const uint64_t units0 = c.sum_samples + (uint64_t)retries * n_items;
-  const uint64_t units = 2 * c.sum_samples + (uint64_t)(2 * retries + 32) * n_items;
+  // a later round asks for at most the attempts an item has left: 4*samples (+ retries) per item
+  const uint64_t units = 4 * c.sum_samples + (uint64_t)(2 * retries + 32) * n_items;
   if (units > ctx->max_pool_units)
     return fail(ctx, LENTIL_ERR_NOMEM, "draw result pool would exceed LENTIL_MAX_POOL_UNITS; split the visit stream");
   (void)units0;
@@ -601,7 +602,7 @@ LENTIL_API int lentil_hip_redistribute(lentil_hip_ctx *ctx) {
         return fail(ctx, LENTIL_ERR_UNSUPPORTED, "visits_per_pixel too large for the LDS staging area");
       sa.ppt = ppt;
       sa.tv_pad = ppt * M;
-      const size_t lds = (size_t)sa.tv_pad * 20 * 4;
+      const size_t lds = (size_t)sa.tv_pad * 20 * 4 + 4 * kWaveQueue * sizeof(uint2);
       const uint64_t n_pixels = (ctx->V.n + M - 1) / M;
       const uint64_t n_tiles = (n_pixels + ppt - 1) / ppt;
       uint64_t blocks = (n_tiles + 3) / 4;

@@ -81,27 +81,62 @@ LD_DEV void visit_pixel(const VisitsDev &V, uint64_t v, int &px, int &py) {
 
 LD_DEV uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 
-// wave-ballot + prefix-sum compaction of flagged lanes into the work list (K2)
-LD_DEV void push_work(bool flagged, uint32_t visit, uint32_t samples, uint2 *work, uint64_t cap, DevCounters *ctr) {
-  const unsigned long long mask = __ballot(flagged);
-  if (mask == 0ull) return;
-  const uint32_t lane = lane_id();
-  const uint32_t leader = (uint32_t)__builtin_ctzll(mask);
-  unsigned long long ssum = flagged ? samples : 0u;
-  for (int off = 32; off > 0; off >>= 1) ssum += __shfl_down(ssum, off);
-  ssum = __shfl(ssum, 0);
-  unsigned long long base = 0;
-  if (lane == leader) {
-    base = atomicAdd(&ctr->work_count, (unsigned long long)__builtin_popcountll(mask));
-    atomicAdd(&ctr->sum_samples, ssum);
+// K2: wave-ballot + prefix-sum compaction of flagged lanes into the work list.  Each wave collects
+// its items in a private 128-entry LDS queue (slot = popcount of the ballot below the lane) and
+// reserves space in the global list with ONE returning atomic per flush (queue more than half full,
+// or end of the wave) -- a single hot counter only sustains ~90 returning atomics per microsecond.
+constexpr uint32_t kWaveQueue = 128;
+
+struct WaveQueue {
+  uint2 *q;                 // wave-private LDS, kWaveQueue entries
+  uint32_t n;               // wave-uniform fill
+  unsigned long long sum_samples, n_items;   // per-lane partial sums, reduced in finish()
+
+  LD_DEV void init(uint2 *lds) { q = lds; n = 0; sum_samples = 0; n_items = 0; }
+
+  LD_DEV void flush(uint2 *work, uint64_t cap, DevCounters *ctr) {
+    if (n == 0) return;
+    const uint32_t lane = lane_id();
+    unsigned long long base = 0;
+    if (lane == 0) base = atomicAdd(&ctr->work_count, (unsigned long long)n);
+    base = __shfl(base, 0);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    for (uint32_t i = lane; i < n; i += 64u) {
+      if (base + i < cap) work[base + i] = q[i];
+      else atomicAdd(&ctr->overflow, 1ull);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    n = 0;
   }
-  base = __shfl(base, (int)leader);
-  if (flagged) {
-    const unsigned long long idx = base + (unsigned long long)__builtin_popcountll(mask & ((1ull << lane) - 1ull));
-    if (idx < cap) work[idx] = make_uint2(visit, samples);
-    else atomicAdd(&ctr->overflow, 1ull);
+
+  LD_DEV void push(bool flagged, uint32_t visit, uint32_t samples, uint2 *work, uint64_t cap, DevCounters *ctr) {
+    const unsigned long long mask = __ballot(flagged);
+    if (mask == 0ull) return;
+    const uint32_t lane = lane_id();
+    if (flagged) {
+      q[n + (uint32_t)__builtin_popcountll(mask & ((1ull << lane) - 1ull))] = make_uint2(visit, samples);
+      sum_samples += samples;
+      n_items += 1;
+    }
+    n += (uint32_t)__builtin_popcountll(mask);
+    if (n > kWaveQueue - 64u) flush(work, cap, ctr);
   }
-}
+
+  LD_DEV void finish(uint2 *work, uint64_t cap, DevCounters *ctr) {
+    flush(work, cap, ctr);
+    for (int off = 32; off > 0; off >>= 1) {
+      sum_samples += __shfl_down(sum_samples, off);
+      n_items += __shfl_down(n_items, off);
+    }
+    if (lane_id() == 0 && n_items) {
+      atomicAdd(&ctr->sum_samples, sum_samples);
+      atomicAdd(&ctr->redistributed, n_items);
+    }
+  }
+};
 
 // ---------------------------------------------------------------------------------------
 // K1+K2+K6, uniform footprints.  One wave owns a tile of `ppt` consecutive source pixels
@@ -115,6 +150,11 @@ __global__ __launch_bounds__(256) void scan_uniform_kernel(ScanArgs a) {
   const uint32_t waves_per_block = blockDim.x >> 6;
   float4 *sval = smem + (size_t)wave * a.tv_pad;
   float *sw = reinterpret_cast<float *>(smem + (size_t)waves_per_block * a.tv_pad) + (size_t)wave * a.tv_pad;
+  // wave queues live behind the staging area: [4 x tv_pad float4][4 x tv_pad float][4 x kWaveQueue uint2]
+  uint2 *qmem = reinterpret_cast<uint2 *>(reinterpret_cast<float *>(smem + (size_t)waves_per_block * a.tv_pad) +
+                                          (size_t)waves_per_block * a.tv_pad);
+  WaveQueue wq;
+  wq.init(qmem + (size_t)wave * kWaveQueue);
 
   const VisitsDev &V = a.V;
   const uint32_t M = V.visits_per_pixel;
@@ -125,7 +165,6 @@ __global__ __launch_bounds__(256) void scan_uniform_kernel(ScanArgs a) {
   const uint64_t wave_global = (uint64_t)blockIdx.x * waves_per_block + wave;
   const uint64_t wave_stride = (uint64_t)gridDim.x * waves_per_block;
   const uint32_t xres = a.P.xres;
-  unsigned long long n_redis = 0;
 
   for (uint64_t tile = wave_global; tile < n_tiles; tile += wave_stride) {
     const uint64_t pix0 = tile * ppt;
@@ -154,8 +193,7 @@ __global__ __launch_bounds__(256) void scan_uniform_kernel(ScanArgs a) {
           val = make_float4((rgba.x + 0.0f) * w, (rgba.y + 0.0f) * w, (rgba.z + 0.0f) * w, (rgba.w + 0.0f) * w);
         }
       }
-      push_work(flagged, (uint32_t)v, (uint32_t)samples, a.work, a.work_cap, a.ctr);
-      n_redis += flagged ? 1ull : 0ull;
+      wq.push(flagged, (uint32_t)v, (uint32_t)samples, a.work, a.work_cap, a.ctr);
       if (e < TV) { sval[e] = val; sw[e] = w; }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -214,17 +252,16 @@ __global__ __launch_bounds__(256) void scan_uniform_kernel(ScanArgs a) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
   }
-  // counters: one atomic per wave
-  for (int off = 32; off > 0; off >>= 1) n_redis += __shfl_down(n_redis, off);
-  if (lane == 0 && n_redis) atomicAdd(&a.ctr->redistributed, n_redis);
+  wq.finish(a.work, a.work_cap, a.ctr);
 }
 
 // K1+K2+K6 for ragged footprints (explicit per-visit pixel): lane per visit, fp32 atomics for the
 // direct accumulation.
 __global__ __launch_bounds__(256) void scan_ragged_kernel(ScanArgs a) {
   const VisitsDev &V = a.V;
-  const uint32_t lane = threadIdx.x & 63u;
-  unsigned long long n_redis = 0;
+  __shared__ uint2 s_queue[4 * kWaveQueue];
+  WaveQueue wq;
+  wq.init(s_queue + (threadIdx.x >> 6) * kWaveQueue);
   const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
   const uint64_t n_round = (V.n + 63ull) & ~63ull;
   for (uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; v < n_round; v += stride) {
@@ -259,11 +296,9 @@ __global__ __launch_bounds__(256) void scan_ragged_kernel(ScanArgs a) {
         }
       }
     }
-    push_work(flagged, (uint32_t)v, (uint32_t)samples, a.work, a.work_cap, a.ctr);
-    n_redis += flagged ? 1ull : 0ull;
+    wq.push(flagged, (uint32_t)v, (uint32_t)samples, a.work, a.work_cap, a.ctr);
   }
-  for (int off = 32; off > 0; off >>= 1) n_redis += __shfl_down(n_redis, off);
-  if (lane == 0 && n_redis) atomicAdd(&a.ctr->redistributed, n_redis);
+  wq.finish(a.work, a.work_cap, a.ctr);
 }
 // ---------------------------------------------------------------------------------------
 // K3/K4/K5: draws -- "solve once".
@@ -629,9 +664,12 @@ __global__ __launch_bounds__(256) void accept_kernel(DrawArgs a) {
       n += limit;
     }
     if (acc < S && n < max_total && pg.m_hi < m_limit && pg.m_hi > 0) {
-      // draws are still missing: schedule the next batch (over-provisioned x2 + a margin)
+      // draws are still missing: schedule the next batch, sized from the item's own success rate so far
+      // (+25 % + 32; a surplus is simply never accepted, a shortfall costs another round)
       const uint32_t remaining = S - acc;
-      unsigned long long n_target = (unsigned long long)n + 2ull * remaining + 16ull;
+      unsigned long long need = acc ? ((unsigned long long)remaining * n + acc - 1) / acc : (unsigned long long)(max_total - n);
+      need += need / 4 + 32;
+      unsigned long long n_target = (unsigned long long)n + need;
       if (n_target > max_total) n_target = max_total;
       uint32_t new_hi = (uint32_t)n_target + retries;
       if (new_hi > m_limit) new_hi = m_limit;

@@ -49,6 +49,9 @@ class Emitter:
         self.pows = {}     # (var, e) -> name
         self.coef = coef   # shared coefficient list (constant memory, read with scalar loads)
         self.cname = cname
+        self.nacc = 0
+        self.dep = "x"     # value the next coefficient-pointer fence depends on
+    CHUNK = 12
 
     def power(self, var, e):
         """Name of lens_ipow(var, e), e >= 2, emitting the recursion's intermediate powers once."""
@@ -90,13 +93,21 @@ class Emitter:
             if e[4] >= 1:
                 f.append("lp[%d]" % e[4])
             parts.append(" * ".join(f))
-        # re-launder the coefficient pointer: keeps this polynomial's scalar loads from being clustered
-        # with every other polynomial's at the top of the block (SGPR pressure)
-        self.lines.append("  asm volatile(\"\" : \"+s\"(C));")
-        expr = parts[0]
-        for p_ in parts[1:]:
-            expr = "(%s) + %s" % (expr, p_) if False else expr + "\n      + " + p_
-        self.lines.append("  %s = %s;" % (target, expr))
+        # Sum left to right in chunks of CHUNK terms.  Before each chunk the coefficient pointer is
+        # laundered through an empty asm that also *consumes* the value computed just before, so the
+        # chunk's scalar loads can neither be hoisted out of the solver loop nor be clustered at the top of
+        # the iteration (either would need ~800 live SGPRs and spill them through VGPR lanes).
+        tmp = "acc%d" % self.nacc
+        self.nacc += 1
+        for i in range(0, len(parts), self.CHUNK):
+            chunk = parts[i:i + self.CHUNK]
+            self.lines.append("  asm volatile(\"\" : \"+s\"(C) : \"v\"(%s));" % self.dep)
+            if i == 0:
+                self.lines.append("  double %s = %s;" % (tmp, "\n      + ".join(chunk)))
+            else:
+                self.lines.append("  %s = %s\n      + %s;" % (tmp, tmp, "\n      + ".join(chunk)))
+            self.dep = tmp
+        self.lines.append("  %s = %s;" % (target, tmp))
 
 
 def gen_lens(name, spec):
