@@ -195,6 +195,22 @@ def test_po_extra_aovs_and_m36(orc, gpu_ctx_factory):
     check_frame(ctx, ref, n_aovs=4)
 
 
+def test_petzval_8_aovs(orc, gpu_ctx_factory):
+    """BASELINE config 4 shape at test size: petzval-class table (degree-9 terms, heavy vignetting ->
+    many failing draws and several acceptance rounds), beauty + 8 AOVs."""
+    W, H, M = 48, 32, 9
+    p, model, table, keep = common.po_setup(W, H, lens="petzval_58mm", samples_override=32)
+    visits, cols = common.make_stream(p, W, H, M, f_hi=0.02, n_extra=8)
+    ref = common.run_oracle(orc, p, table, visits, n_aovs=9)
+    ctx = gpu_ctx_factory()
+    c = gpu_run(ctx, p, table, visits, n_aovs=9)
+    rc = ref.counters()
+    assert (c.attempted_draws, c.accepted_draws) == (rc.attempted_draws, rc.accepted_draws)
+    assert rc.attempted_draws > 1.2 * rc.accepted_draws        # the failure paths are exercised
+    check_logs(ctx, ref)
+    check_frame(ctx, ref, n_aovs=9)
+
+
 def test_po_ragged_pixels_and_inv_density(orc, gpu_ctx_factory):
     """Explicit per-visit pixel + per-visit inverse density (ragged footprints / adaptive sampling)."""
     W, H, M = 48, 32, 9

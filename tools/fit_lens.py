@@ -62,7 +62,7 @@ _PZ = [
     (55.9, 7.2, BK7, 20.5),
     (-43.7, 2.2, F2, 20.5),
     (460.4, 22.0, AIR, 20.0),
-    ("stop", 18.0, AIR, 14.5),
+    ("stop", 18.0, AIR, 19.0),
     (110.6, 2.0, SF2, 17.0),
     (38.9, 3.2, AIR, 17.0),
     (48.0, 6.5, K5, 18.0),
@@ -72,7 +72,7 @@ _PZ = [
 LENSES = {
     # name: (prescription, scale, max_degree, n_terms, sensor half-extent used for the fit [mm])
     "double_gauss_50mm": dict(rx=_DG, scale=0.5, degree=7, terms=36, field=18.0),
-    "petzval_58mm": dict(rx=_PZ, scale=1.0, degree=9, terms=48, field=18.0),
+    "petzval_58mm": dict(rx=_PZ, scale=0.4745, degree=9, terms=48, field=16.0, refocus=True),
 }
 
 
@@ -86,8 +86,25 @@ def cauchy(nd, vd, lam):
     return A + B / lam ** 2
 
 
+def paraxial_bfl(rx, lam=0.5876):
+    """Back focal distance (last surface -> paraxial focus of an axial object at infinity)."""
+    y, nu, n = 1.0, 0.0, 1.0          # ray height, n*u, current index
+    for i, (R, t, glass, sd) in enumerate(rx):
+        n2 = float(cauchy(*glass, np.array([lam]))[0])
+        if R != "stop" and R != 0.0:
+            nu = nu - y * (n2 - n) / R
+        n = n2 if R != "stop" else n
+        if i < len(rx) - 1:
+            y = y + (nu / n) * t
+    return -y / (nu / n)
+
+
 class Lens:
-    def __init__(self, rx, scale):
+    def __init__(self, rx, scale, refocus=False):
+        if refocus:     # put the sensor at the paraxial focus for infinity
+            rx = list(rx)
+            rx[-1] = (rx[-1][0], paraxial_bfl(rx), rx[-1][2], rx[-1][3])
+        self.rx = rx
         self.surf = []
         z = 0.0
         for (R, t, glass, sd) in rx:
@@ -96,7 +113,7 @@ class Lens:
                                   sd=sd * scale, stop=stop))
             z += t * scale
         self.z_sensor = z            # standard frame: surface 1 vertex at z=0, sensor at +z
-        self.bfl = rx[-1][1] * scale
+        self.bfl = self.rx[-1][1] * scale
         self.i_stop = [i for i, s in enumerate(self.surf) if s["stop"]][0]
 
     def trace(self, x, y, dx, dy, lam, to_aperture=False):
@@ -212,7 +229,7 @@ def omp_fit(X, y, exps, n_terms):
 
 
 def build(name, spec, seed=1234, n_rays=400000, n_fit=40000):
-    lens = Lens(spec["rx"], spec["scale"])
+    lens = Lens(spec["rx"], spec["scale"], refocus=spec.get("refocus", False))
     rng = np.random.default_rng(seed)
     F = spec["field"]
     x = rng.uniform(-F, F, n_rays)
