@@ -139,6 +139,7 @@ LENTIL_API int lentil_hip_destroy(lentil_hip_ctx *ctx) {
   (void)hipFree(ctx->d_lens);
   (void)hipFree(ctx->d_terms);
   (void)hipFree(ctx->F.acc);
+  (void)hipFree(ctx->F.zkey);
   (void)hipFree(ctx->d_resolved);
   (void)hipFree(ctx->d_work);
   (void)hipFree(ctx->d_hdr);
@@ -318,13 +319,16 @@ LENTIL_API int lentil_hip_alloc_frame(lentil_hip_ctx *ctx, uint32_t n_aovs, cons
   if (n_aovs < 1 || n_aovs > LENTIL_MAX_AOVS) return fail(ctx, LENTIL_ERR_INVALID, "n_aovs out of range");
   for (uint32_t i = 0; i < n_aovs; ++i) {
     const uint8_t k = kind ? kind[i] : LENTIL_FILTER_GAUSSIAN;
-    if (k != LENTIL_FILTER_GAUSSIAN)
-      return fail(ctx, LENTIL_ERR_UNSUPPORTED, "only gaussian-original AOVs are redistributed on the GPU so far");
+    if (k != LENTIL_FILTER_GAUSSIAN && k != LENTIL_FILTER_CLOSEST)
+      return fail(ctx, LENTIL_ERR_UNSUPPORTED, "variance-original AOVs are a no-op in the reference (src/lentil.h:848-850)");
+    if (i == 0 && k != LENTIL_FILTER_GAUSSIAN)
+      return fail(ctx, LENTIL_ERR_UNSUPPORTED, "AOV 0 (RGBA, the weight-buffer AOV) must be gaussian-filtered");
     ctx->kind[i] = k;
   }
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   (void)hipFree(ctx->F.acc);
+  (void)hipFree(ctx->F.zkey);
   (void)hipFree(ctx->d_resolved);
   ctx->F = FrameDev{};
   ctx->d_resolved = nullptr;
@@ -336,6 +340,12 @@ LENTIL_API int lentil_hip_alloc_frame(lentil_hip_ctx *ctx, uint32_t n_aovs, cons
   ctx->F.weight = ctx->F.acc + np * 4 * n_aovs;
   ctx->F.n_aovs = n_aovs;
   ctx->F.np = np;
+  ctx->F.closest_mask = 0;
+  for (uint32_t i = 0; i < n_aovs; ++i) if (ctx->kind[i] == LENTIL_FILTER_CLOSEST) ctx->F.closest_mask |= 1u << i;
+  if (ctx->F.closest_mask) {
+    HIP_TRY(ctx, hipMalloc(&ctx->F.zkey, np * sizeof(unsigned long long)));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->F.zkey, 0xFF, np * sizeof(unsigned long long), ctx->stream));
+  }
   ctx->have_frame = true;
   HIP_TRY(ctx, hipMemsetAsync(ctx->F.acc, 0, nfl * sizeof(float), ctx->stream));
   return LENTIL_OK;
@@ -440,6 +450,7 @@ LENTIL_API int lentil_hip_clear_frame(lentil_hip_ctx *ctx) {
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   const uint64_t nfl = ctx->F.np * 4 * ctx->F.n_aovs + ctx->F.np;
   HIP_TRY(ctx, hipMemsetAsync(ctx->F.acc, 0, nfl * sizeof(float), ctx->stream));
+  if (ctx->F.zkey) HIP_TRY(ctx, hipMemsetAsync(ctx->F.zkey, 0xFF, ctx->F.np * sizeof(unsigned long long), ctx->stream));
   return LENTIL_OK;
 }
 
@@ -622,6 +633,11 @@ LENTIL_API int lentil_hip_redistribute(lentil_hip_ctx *ctx) {
   if (ctx->V.n) {
     const int rc = run_draw_pipeline(ctx);
     if (rc) return rc;
+  }
+  if (ctx->F.zkey && ctx->V.n) {
+    // closest-filter AOVs: the winners of this pass (one pass per frame: the keys index the bound stream)
+    hipLaunchKernelGGL(closest_gather_kernel, dim3((unsigned)ctx->num_cu * 8), dim3(256), 0, ctx->stream, ctx->F, ctx->V);
+    HIP_TRY(ctx, hipGetLastError());
   }
   HIP_TRY(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
   ctx->timed_draw = true;

@@ -51,9 +51,18 @@ struct VisitsDev {
 struct FrameDev {
   float *acc;        // [n_aovs][np][4]
   float *weight;     // [np]
+  // closest-filter AOVs (src/lentil.h:832-837): per pixel the winning candidate as one 64-bit key,
+  // (bits of |Z|) << 32 | (0xFFFFFFFF - visit), reduced with atomicMin: smallest depth wins, equal depths
+  // go to the later visit -- exactly what the reference's sequential "depth <= zbuffer" test leaves.
+  unsigned long long *zkey;   // [np], null when the frame has no closest AOV
   uint32_t n_aovs;
+  uint32_t closest_mask;      // bit k: AOV k is closest-filtered (never bit 0)
   uint64_t np;       // xres*yres
 };
+
+LD_DEV unsigned long long closest_key(float depth, uint32_t visit) {
+  return ((unsigned long long)__float_as_uint(fabsf(depth)) << 32) | (unsigned long long)(0xFFFFFFFFu - visit);
+}
 
 struct ScanArgs {
   lentil_params P;
@@ -216,9 +225,22 @@ __global__ __launch_bounds__(256) void scan_uniform_kernel(ScanArgs a) {
       }
       reinterpret_cast<float4 *>(a.F.acc)[lin] = s;
       a.F.weight[lin] = ws;
+      if (a.F.zkey) {
+        // closest AOVs: this pixel's own (non-redistributed) visits compete with their depth
+        unsigned long long kmin = ~0ull;
+        for (uint32_t j = 0; j < M; ++j) {
+          if (sw[lane * M + j] != 0.0f) {
+            const uint64_t vv = v0 + (uint64_t)lane * M + j;
+            const unsigned long long key = closest_key(V.pos_z[vv].w, (uint32_t)vv);
+            if (key < kmin) kmin = key;
+          }
+        }
+        if (kmin != ~0ull) atomicMin(a.F.zkey + lin, kmin);
+      }
     }
     // extra AOVs: same weights, one column at a time through the same staging area
     for (uint32_t k = 0; k < V.n_extra; ++k) {
+      if (a.F.closest_mask & (2u << k)) continue;       // closest AOVs are gathered from the winners later
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       for (uint32_t eb = 0; eb < TV; eb += 64) {
@@ -286,7 +308,9 @@ __global__ __launch_bounds__(256) void scan_ragged_kernel(ScanArgs a) {
         atomicAdd(d + 2, (rgba.z + 0.0f) * w);
         atomicAdd(d + 3, (rgba.w + 0.0f) * w);
         atomicAdd(a.F.weight + lin, w);
+        if (a.F.zkey) atomicMin(a.F.zkey + lin, closest_key(V.pos_z[v].w, (uint32_t)v));
         for (uint32_t k = 0; k < V.n_extra; ++k) {
+          if (a.F.closest_mask & (2u << k)) continue;
           const float4 c = V.extra[k][v];
           float *dk = a.F.acc + ((size_t)(k + 1) * a.F.np + lin) * 4;
           atomicAdd(dk + 0, (c.x + 0.0f) * w);
@@ -643,7 +667,9 @@ __global__ __launch_bounds__(256) void accept_kernel(DrawArgs a) {
         atomicAdd(d + 2, (h.rgba.z + ae) * w);
         atomicAdd(d + 3, (h.rgba.w + ae) * w);
         atomicAdd(a.F.weight + pix, w);
+        if (a.F.zkey) atomicMin(a.F.zkey + pix, closest_key(h.I.depth, h.visit));
         for (uint32_t kx = 0; kx < a.V.n_extra; ++kx) {
+          if (a.F.closest_mask & (2u << kx)) continue;
           const float4 c = a.V.extra[kx][h.visit];
           float *dk = a.F.acc + ((size_t)(kx + 1) * a.F.np + pix) * 4;
           atomicAdd(dk + 0, (c.x + ae) * w);
@@ -697,17 +723,35 @@ __global__ __launch_bounds__(256) void accept_kernel(DrawArgs a) {
   }
 }
 
+// closest-filter AOVs: copy the winning visit's value into AOVData::buffer (src/lentil.h:835)
+__global__ __launch_bounds__(256) void closest_gather_kernel(FrameDev F, VisitsDev V) {
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; p < F.np; p += stride) {
+    const unsigned long long key = F.zkey[p];
+    if (key == ~0ull) continue;
+    const uint32_t visit = 0xFFFFFFFFu - (uint32_t)(key & 0xFFFFFFFFull);
+    for (uint32_t k = 1; k < F.n_aovs; ++k)
+      if (F.closest_mask & (1u << k))
+        reinterpret_cast<float4 *>(F.acc)[(uint64_t)k * F.np + p] = V.extra[k - 1][visit];
+  }
+}
+
 // K7 -- driver_process_bucket's normalisation, src/lentil_imager.cpp:169-186
 __global__ __launch_bounds__(256) void resolve_kernel(FrameDev F, float *resolved) {
   const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
   const uint64_t total = F.np * F.n_aovs;
   for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
     const uint64_t p = i % F.np;
+    const uint32_t aov = (uint32_t)(i / F.np);
     float4 c = reinterpret_cast<const float4 *>(F.acc)[i];
-    const float wt = F.weight[p];
-    if (wt != 0.0f) {                      // AtRGBA /= float multiplies by 1.0f/f
-      const float inv = 1.0f / wt;
-      c.x *= inv; c.y *= inv; c.z *= inv; c.w *= inv;
+    if (F.closest_mask & (1u << aov)) {
+      c.w = 1.0f;                          // closest: (r, g, b, 1), src/lentil_imager.cpp:181-186
+    } else {
+      const float wt = F.weight[p];
+      if (wt != 0.0f) {                    // AtRGBA /= float multiplies by 1.0f/f
+        const float inv = 1.0f / wt;
+        c.x *= inv; c.y *= inv; c.z *= inv; c.w *= inv;
+      }
     }
     reinterpret_cast<float4 *>(resolved)[i] = c;
   }

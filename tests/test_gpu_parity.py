@@ -19,14 +19,14 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-5
 
 
-def gpu_run(ctx, p, table, visits, n_aovs=1, bokeh_tables=None, log_cap=1 << 22, lens_mode=0):
+def gpu_run(ctx, p, table, visits, n_aovs=1, bokeh_tables=None, log_cap=1 << 22, lens_mode=0, kinds=None):
     ctx.set_params(p)
     ctx.set_lens_mode(lens_mode)
     if table is not None:
         ctx.set_lens(table)
         assert ctx.lens_is_compiled()        # shipped lenses have a compiled-in kernel
     ctx.set_bokeh(bokeh_tables)
-    ctx.alloc_frame(n_aovs)
+    ctx.alloc_frame(n_aovs, kinds)
     ctx.set_draw_log(log_cap)
     ctx.upload_visits(visits)
     ctx.clear_frame()
@@ -209,6 +209,39 @@ def test_petzval_8_aovs(orc, gpu_ctx_factory):
     assert rc.attempted_draws > 1.2 * rc.accepted_draws        # the failure paths are exercised
     check_logs(ctx, ref)
     check_frame(ctx, ref, n_aovs=9)
+
+
+@pytest.mark.parametrize("ragged", [False, True])
+def test_closest_filter_aovs(orc, gpu_ctx_factory, ragged):
+    """closest-original AOVs (e.g. P, N, Z; src/lentil.h:832-837): per pixel the candidate with the
+    smallest |Z| wins, later visits win ties; resolved as (r, g, b, 1).  Mixed with gaussian AOVs."""
+    W, H, M = 64, 40, 9
+    kinds = [0, 1, 0, 1]
+    p, model, table, keep = common.po_setup(W, H, samples_override=48)
+    visits, cols = common.make_stream(p, W, H, M, f_hi=0.03, n_extra=3)
+    if ragged:
+        n = cols["rgba"].shape[0]
+        rng = np.random.default_rng(11)
+        cols["pixel"] = (rng.integers(0, W, n) | (rng.integers(0, H, n) << 16)).astype(np.uint32)
+        visits, keepv = capi.make_visits(cols, visits_per_pixel=0)
+    lens = orc.orc_lens_create(C.byref(table))
+    ref = oracle_lib.Frame(orc, p, n_aovs=4, kinds=kinds, keep_log=True)
+    ref.run(lens, None, visits)
+    orc.orc_lens_destroy(lens)
+    ctx = gpu_ctx_factory()
+    gpu_run(ctx, p, table, visits, n_aovs=4, kinds=kinds)
+    check_logs(ctx, ref)
+    for a in (1, 3):                      # closest: exact
+        buf, _ = ctx.download_accum(a)
+        assert np.array_equal(buf, ref.buffer(a))
+        img = ctx.download_aov(a)
+        assert np.array_equal(img, ref.resolve(a))
+        assert np.all(img[buf.any(axis=1), 3] == 1.0)
+    for a in (0, 2):                      # gaussian: tolerance
+        buf, w = ctx.download_accum(a)
+        exact = ref.buffer64(a)
+        m = exact != 0
+        assert float(np.max(np.abs(buf[m] - exact[m]) / np.abs(exact[m]))) < TOL
 
 
 def test_po_ragged_pixels_and_inv_density(orc, gpu_ctx_factory):
