@@ -46,15 +46,26 @@ struct lentil_hip_ctx {
 
   uint2 *d_work = nullptr;
   uint64_t work_cap = 0;
-  // draw pipeline buffers (grow-only)
-  ItemHdr *d_hdr = nullptr;
-  ItemProg *d_prog = nullptr;
-  uint32_t *d_active[2] = {nullptr, nullptr};
-  uint64_t item_cap = 0;
-  Task *d_tasks[2] = {nullptr, nullptr};
-  uint64_t task_cap = 0;
-  uint32_t *d_pool[2] = {nullptr, nullptr};
-  uint64_t pool_cap = 0;
+  // The visit stream is processed in n_chunks contiguous chunks.  All scans run back to back on the
+  // main stream; each chunk's draw pipeline (prep, solve/accept rounds) runs on its own stream as soon
+  // as its scan has finished, so the HBM-bound scan of chunk i+1 overlaps the fp64-bound solves of
+  // chunk i, and the latency-bound tails of different chunks overlap each other.
+  struct Chunk {
+    hipStream_t stream = nullptr;
+    hipEvent_t scanned = nullptr, done = nullptr;
+    uint64_t v_begin = 0, v_end = 0, tile_begin = 0, tile_end = 0;
+    uint64_t n_items = 0;
+    ItemHdr *hdr = nullptr;
+    ItemProg *prog = nullptr;
+    uint32_t *active[2] = {nullptr, nullptr};
+    uint64_t item_cap = 0;
+    Task *tasks[2] = {nullptr, nullptr};
+    uint64_t task_cap = 0;
+    uint32_t *pool[2] = {nullptr, nullptr};
+    uint64_t pool_cap = 0;
+  };
+  std::vector<Chunk> chunks;
+  int n_chunks = 2;
   uint64_t max_pool_units = 1ull << 32;    // 16 GiB per pool at most (LENTIL_MAX_POOL_UNITS overrides)
   int last_rounds = 0;
   DevCounters *d_ctr = nullptr;
@@ -106,8 +117,18 @@ LENTIL_API int lentil_hip_create(int device, lentil_hip_ctx **out_ctx) {
   ctx->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
   for (auto &ev : ctx->ev) HIP_TRY(ctx, hipEventCreate(&ev));
-  HIP_TRY(ctx, hipMalloc(&ctx->d_ctr, sizeof(DevCounters)));
-  HIP_TRY(ctx, hipMemsetAsync(ctx->d_ctr, 0, sizeof(DevCounters), ctx->stream));
+  if (const char *nc = getenv("LENTIL_CHUNKS")) { ctx->n_chunks = atoi(nc); }
+  if (ctx->n_chunks < 1) ctx->n_chunks = 1;
+  if (ctx->n_chunks > 16) ctx->n_chunks = 16;
+  // one DevCounters per chunk + one shared (draw-log cursor)
+  HIP_TRY(ctx, hipMalloc(&ctx->d_ctr, sizeof(DevCounters) * (ctx->n_chunks + 1)));
+  HIP_TRY(ctx, hipMemsetAsync(ctx->d_ctr, 0, sizeof(DevCounters) * (ctx->n_chunks + 1), ctx->stream));
+  ctx->chunks.resize(ctx->n_chunks);
+  for (auto &ch : ctx->chunks) {
+    HIP_TRY(ctx, hipStreamCreateWithFlags(&ch.stream, hipStreamNonBlocking));
+    HIP_TRY(ctx, hipEventCreateWithFlags(&ch.scanned, hipEventDisableTiming));
+    HIP_TRY(ctx, hipEventCreateWithFlags(&ch.done, hipEventDisableTiming));
+  }
   if (const char *ft = getenv("LENTIL_FORCE_TABLES")) ctx->use_generated = !(ft[0] == '1');
   if (const char *mp = getenv("LENTIL_MAX_POOL_UNITS")) ctx->max_pool_units = strtoull(mp, nullptr, 10);
   *out_ctx = ctx;
@@ -142,12 +163,13 @@ LENTIL_API int lentil_hip_destroy(lentil_hip_ctx *ctx) {
   (void)hipFree(ctx->F.zkey);
   (void)hipFree(ctx->d_resolved);
   (void)hipFree(ctx->d_work);
-  (void)hipFree(ctx->d_hdr);
-  (void)hipFree(ctx->d_prog);
-  for (int i = 0; i < 2; ++i) {
-    (void)hipFree(ctx->d_active[i]);
-    (void)hipFree(ctx->d_tasks[i]);
-    (void)hipFree(ctx->d_pool[i]);
+  for (auto &ch : ctx->chunks) {
+    if (ch.stream) (void)hipStreamSynchronize(ch.stream);
+    (void)hipFree(ch.hdr); (void)hipFree(ch.prog);
+    for (int i = 0; i < 2; ++i) { (void)hipFree(ch.active[i]); (void)hipFree(ch.tasks[i]); (void)hipFree(ch.pool[i]); }
+    if (ch.scanned) (void)hipEventDestroy(ch.scanned);
+    if (ch.done) (void)hipEventDestroy(ch.done);
+    if (ch.stream) (void)hipStreamDestroy(ch.stream);
   }
   (void)hipFree(ctx->d_ctr);
   (void)hipFree(ctx->d_log);
@@ -455,129 +477,97 @@ LENTIL_API int lentil_hip_clear_frame(lentil_hip_ctx *ctx) {
 }
 
 template <typename T>
-static int grow(lentil_hip_ctx *ctx, T **p, uint64_t *cap, uint64_t need, uint64_t *shared_cap = nullptr) {
-  (void)shared_cap;
-  if (*p && *cap >= need) return LENTIL_OK;
+static int grow(lentil_hip_ctx *ctx, T **p, uint64_t need) {
   (void)hipFree(*p);
   *p = nullptr;
   HIP_TRY(ctx, hipMalloc((void **)p, need * sizeof(T)));
-  *cap = need;
   return LENTIL_OK;
 }
 
-// prep -> { solve -> accept } until every item has its draws (or ran out of attempts)
-static int run_draw_pipeline(lentil_hip_ctx *ctx) {
+static void launch_solve(lentil_hip_ctx *ctx, const DrawArgs &da, hipStream_t st, unsigned blocks) {
+  if (da.P.cameraType == LENTIL_POLYNOMIAL_OPTICS) {
+    bool launched = false;
+#define LENTIL_LAUNCH_GEN(NAME)                                                                          \
+    if (!launched && ctx->use_generated && ctx->lens_hash == gen::Lens_##NAME::kTableHash) {              \
+      hipLaunchKernelGGL((solve_po_kernel<GenLens<gen::Lens_##NAME>, false>), dim3(blocks), dim3(256), 0, st, da); \
+      launched = true;                                                                                   \
+    }
+    LENTIL_GENERATED_LENSES(LENTIL_LAUNCH_GEN)
+#undef LENTIL_LAUNCH_GEN
+    if (!launched) hipLaunchKernelGGL((solve_po_kernel<LdsLens, true>), dim3(blocks), dim3(256), 0, st, da);
+  } else {
+    hipLaunchKernelGGL(solve_thinlens_kernel, dim3(blocks), dim3(256), 0, st, da);
+  }
+}
+
+// Size one chunk's draw-pipeline buffers from its scan result and enqueue prep + `blind_rounds`
+// solve/accept rounds on the chunk's stream (no host round trip between the rounds: every kernel
+// reads its queue lengths from device memory; a round with empty queues costs a few microseconds).
+static int enqueue_chunk_draws(lentil_hip_ctx *ctx, int ci, DrawArgs &da, int blind_rounds) {
+  lentil_hip_ctx::Chunk &ch = ctx->chunks[ci];
   const lentil_params &P = ctx->P;
-  // the only host round trip of the pass: how many items did the scan find, and how many draws do they ask for
+  DevCounters *dctr = ctx->d_ctr + ci;
+  // wait for this chunk's scan only (later chunks keep scanning meanwhile), fetch its item count / draw sum
+  HIP_TRY(ctx, hipEventSynchronize(ch.scanned));
   DevCounters c;
-  HIP_TRY(ctx, hipMemcpyAsync(&c, ctx->d_ctr, sizeof(c), hipMemcpyDeviceToHost, ctx->stream));
-  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-  uint64_t n_items = c.work_count < ctx->work_cap ? c.work_count : ctx->work_cap;
-  ctx->last_rounds = 0;
+  HIP_TRY(ctx, hipMemcpyAsync(&c, dctr, sizeof(c), hipMemcpyDeviceToHost, ch.stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ch.stream));
+  const uint64_t cap = ch.v_end - ch.v_begin;
+  const uint64_t n_items = c.work_count < cap ? c.work_count : cap;
+  ch.n_items = n_items;
   if (n_items == 0) return LENTIL_OK;
   const bool po = P.cameraType == LENTIL_POLYNOMIAL_OPTICS;
   const uint32_t retries = po ? (uint32_t)(P.vignetting_retries < 0 ? 0 : P.vignetting_retries) : 0u;
-  // round 0 needs sum(samples + retries) results; later rounds at most 2*remaining + 16 + retries per item
-  const uint64_t units0 = c.sum_samples + (uint64_t)retries * n_items;
-  // a later round asks for at most the attempts an item has left: 4*samples (+ retries) per item
+  // round 0 needs sum(samples + retries) results; a later round at most the attempts an item has left
   const uint64_t units = 4 * c.sum_samples + (uint64_t)(2 * retries + 32) * n_items;
   if (units > ctx->max_pool_units)
     return fail(ctx, LENTIL_ERR_NOMEM, "draw result pool would exceed LENTIL_MAX_POOL_UNITS; split the visit stream");
-  (void)units0;
   const uint64_t tasks = units / 64 + 2 * n_items + 64;
   if (tasks > 0xFFFFFFF0ull) return fail(ctx, LENTIL_ERR_NOMEM, "too many solve tasks; split the visit stream");
   int rc;
-  uint64_t cap;
-  if (n_items > ctx->item_cap) {
-    (void)hipFree(ctx->d_hdr); (void)hipFree(ctx->d_prog); (void)hipFree(ctx->d_active[0]); (void)hipFree(ctx->d_active[1]);
-    ctx->d_hdr = nullptr; ctx->d_prog = nullptr; ctx->d_active[0] = ctx->d_active[1] = nullptr;
-    ctx->item_cap = 0;
+  if (n_items > ch.item_cap) {
     const uint64_t nc = n_items + n_items / 4 + 1024;
-    HIP_TRY(ctx, hipMalloc(&ctx->d_hdr, nc * sizeof(ItemHdr)));
-    HIP_TRY(ctx, hipMalloc(&ctx->d_prog, nc * sizeof(ItemProg)));
-    HIP_TRY(ctx, hipMalloc(&ctx->d_active[0], nc * sizeof(uint32_t)));
-    HIP_TRY(ctx, hipMalloc(&ctx->d_active[1], nc * sizeof(uint32_t)));
-    ctx->item_cap = nc;
+    if ((rc = grow(ctx, &ch.hdr, nc))) return rc;
+    if ((rc = grow(ctx, &ch.prog, nc))) return rc;
+    if ((rc = grow(ctx, &ch.active[0], nc))) return rc;
+    if ((rc = grow(ctx, &ch.active[1], nc))) return rc;
+    ch.item_cap = nc;
   }
-  if (tasks > ctx->task_cap) {
-    cap = 0;
+  if (tasks > ch.task_cap) {
     const uint64_t nc = tasks + tasks / 4;
-    if ((rc = grow(ctx, &ctx->d_tasks[0], &cap, nc))) return rc;
-    cap = 0;
-    if ((rc = grow(ctx, &ctx->d_tasks[1], &cap, nc))) return rc;
-    ctx->task_cap = nc;
+    if ((rc = grow(ctx, &ch.tasks[0], nc))) return rc;
+    if ((rc = grow(ctx, &ch.tasks[1], nc))) return rc;
+    ch.task_cap = nc;
   }
-  if (units > ctx->pool_cap) {
-    cap = 0;
+  if (units > ch.pool_cap) {
     const uint64_t nc = units + units / 4;
-    if ((rc = grow(ctx, &ctx->d_pool[0], &cap, nc))) return rc;
-    cap = 0;
-    if ((rc = grow(ctx, &ctx->d_pool[1], &cap, nc))) return rc;
-    ctx->pool_cap = nc;
+    if ((rc = grow(ctx, &ch.pool[0], nc))) return rc;
+    if ((rc = grow(ctx, &ch.pool[1], nc))) return rc;
+    ch.pool_cap = nc;
   }
-
-  DrawArgs da{};
-  da.P = P;
-  da.lens = po ? ctx->d_lens : nullptr;
-  da.terms = ctx->d_terms;
-  da.bokeh = ctx->bokeh;
-  da.V = ctx->V;
-  da.F = ctx->F;
-  da.work = ctx->d_work;
+  da.work = ctx->d_work + ch.v_begin;
   da.n_items = n_items;
-  da.ctr = ctx->d_ctr;
-  da.hdr = ctx->d_hdr;
-  da.prog = ctx->d_prog;
-  for (int i = 0; i < 2; ++i) { da.tasks[i] = ctx->d_tasks[i]; da.active[i] = ctx->d_active[i]; da.pool[i] = ctx->d_pool[i]; }
-  da.task_cap = (uint32_t)(ctx->task_cap > 0xFFFFFFF0ull ? 0xFFFFFFF0ull : ctx->task_cap);
-  da.pool_cap = ctx->pool_cap < 0xFFFFFFFFull ? ctx->pool_cap : 0xFFFFFFFFull;
-  da.log = ctx->d_log;
-  da.log_cap = ctx->log_cap;
+  da.ctr = dctr;
+  da.hdr = ch.hdr;
+  da.prog = ch.prog;
+  for (int i = 0; i < 2; ++i) { da.tasks[i] = ch.tasks[i]; da.active[i] = ch.active[i]; da.pool[i] = ch.pool[i]; }
+  da.task_cap = (uint32_t)(ch.task_cap > 0xFFFFFFF0ull ? 0xFFFFFFF0ull : ch.task_cap);
+  da.pool_cap = ch.pool_cap < 0xFFFFFFFFull ? ch.pool_cap : 0xFFFFFFFFull;
   da.retries = (int32_t)retries;
   da.parity = 0;
-
-  hipLaunchKernelGGL(prep_items_kernel, dim3((unsigned)((n_items + 255) / 256)), dim3(256), 0, ctx->stream, da);
+  hipLaunchKernelGGL(prep_items_kernel, dim3((unsigned)((n_items + 255) / 256)), dim3(256), 0, ch.stream, da);
   HIP_TRY(ctx, hipGetLastError());
-  const unsigned solve_blocks = (unsigned)ctx->num_cu * 4;
-  const size_t q_off = offsetof(DevCounters, n_tasks);
-  for (int round = 0; round < 64; ++round) {
-    const int par = round & 1, nxt = par ^ 1;
-    da.parity = par;
-    if (po) {
-      bool launched = false;
-#define LENTIL_LAUNCH_GEN(NAME)                                                                          \
-      if (!launched && ctx->use_generated && ctx->lens_hash == gen::Lens_##NAME::kTableHash) {            \
-        hipLaunchKernelGGL((solve_po_kernel<GenLens<gen::Lens_##NAME>, false>), dim3(solve_blocks), dim3(256), 0, \
-                           ctx->stream, da);                                                             \
-        launched = true;                                                                                 \
-      }
-      LENTIL_GENERATED_LENSES(LENTIL_LAUNCH_GEN)
-#undef LENTIL_LAUNCH_GEN
-      if (!launched)
-        hipLaunchKernelGGL((solve_po_kernel<LdsLens, true>), dim3(solve_blocks), dim3(256), 0, ctx->stream, da);
-    } else {
-      hipLaunchKernelGGL(solve_thinlens_kernel, dim3(solve_blocks), dim3(256), 0, ctx->stream, da);
-    }
+  // enough persistent waves for the chunk's first batch, at most 4 blocks per CU
+  uint64_t want = (c.sum_samples / 64 + n_items + 3) / 4;
+  const uint64_t max_blocks = (uint64_t)ctx->num_cu * 4;
+  const unsigned solve_blocks = (unsigned)(want < 1 ? 1 : (want > max_blocks ? max_blocks : want));
+  uint64_t awant = n_items;            // one block per item
+  const unsigned accept_blocks = (unsigned)(awant < 1 ? 1 : (awant > (uint64_t)ctx->num_cu * 2 ? (uint64_t)ctx->num_cu * 2 : awant));
+  for (int round = 0; round < blind_rounds; ++round) {
+    da.parity = round & 1;
+    launch_solve(ctx, da, ch.stream, round == 0 ? solve_blocks : (solve_blocks > 256 ? 256 : solve_blocks));
+    hipLaunchKernelGGL(accept_kernel, dim3(accept_blocks), dim3(256), 0, ch.stream, da);
     HIP_TRY(ctx, hipGetLastError());
-    // reset the next round's queues, then accept
-    {
-      unsigned int zero = 0;
-      (void)zero;
-      HIP_TRY(ctx, hipMemsetAsync((char *)ctx->d_ctr + q_off + sizeof(unsigned int) * (0 + nxt), 0, sizeof(unsigned int), ctx->stream));
-      HIP_TRY(ctx, hipMemsetAsync((char *)ctx->d_ctr + q_off + sizeof(unsigned int) * (2 + nxt), 0, sizeof(unsigned int), ctx->stream));
-      HIP_TRY(ctx, hipMemsetAsync((char *)ctx->d_ctr + q_off + sizeof(unsigned int) * (4 + nxt), 0, sizeof(unsigned int), ctx->stream));
-      HIP_TRY(ctx, hipMemsetAsync((char *)ctx->d_ctr + q_off + sizeof(unsigned int) * (6 + nxt), 0, sizeof(unsigned int), ctx->stream));
-      HIP_TRY(ctx, hipMemsetAsync((char *)ctx->d_ctr + offsetof(DevCounters, pool_used) + sizeof(unsigned long long) * nxt, 0,
-                                  sizeof(unsigned long long), ctx->stream));
-    }
-    hipLaunchKernelGGL(accept_kernel, dim3((unsigned)ctx->num_cu * 2), dim3(256), 0, ctx->stream, da);
-    HIP_TRY(ctx, hipGetLastError());
-    ctx->last_rounds = round + 1;
-    unsigned int n_next = 0;
-    HIP_TRY(ctx, hipMemcpyAsync(&n_next, (char *)ctx->d_ctr + q_off + sizeof(unsigned int) * (4 + nxt), sizeof(unsigned int),
-                                hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    if (n_next == 0) break;
   }
   return LENTIL_OK;
 }
@@ -593,19 +583,22 @@ LENTIL_API int lentil_hip_redistribute(lentil_hip_ctx *ctx) {
   if (ctx->V.n_extra + 1 != ctx->F.n_aovs)
     return fail(ctx, LENTIL_ERR_INVALID, "visit stream carries a different number of AOVs than the frame");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
-  HIP_TRY(ctx, hipMemsetAsync(ctx->d_ctr, 0, sizeof(DevCounters), ctx->stream));
+  const int C = ctx->n_chunks;
+  HIP_TRY(ctx, hipMemsetAsync(ctx->d_ctr, 0, sizeof(DevCounters) * (C + 1), ctx->stream));
   HIP_TRY(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
+  ctx->last_rounds = 0;
   if (ctx->V.n) {
+    // ---- scans: all chunks back to back on the main stream
     ScanArgs sa{};
     sa.P = P;
     sa.lens_length = ctx->have_lens ? ctx->hlens.length : 0.0;
     sa.V = ctx->V;
     sa.F = ctx->F;
-    sa.work = ctx->d_work;
-    sa.work_cap = ctx->work_cap;
-    sa.ctr = ctx->d_ctr;
-    if (ctx->V.visits_per_pixel) {
-      const uint32_t M = ctx->V.visits_per_pixel;
+    const uint64_t max_blocks = (uint64_t)ctx->num_cu * 8;
+    size_t lds = 0;
+    uint64_t n_tiles = 0;
+    const uint32_t M = ctx->V.visits_per_pixel;
+    if (M) {
       // staging: 20 B per visit per wave, 4 waves per block, keep a block under ~48 KiB
       uint32_t ppt = 64;
       while (ppt > 1 && (uint64_t)ppt * M * 20ull * 4ull > 48ull * 1024ull) ppt >>= 1;
@@ -613,26 +606,87 @@ LENTIL_API int lentil_hip_redistribute(lentil_hip_ctx *ctx) {
         return fail(ctx, LENTIL_ERR_UNSUPPORTED, "visits_per_pixel too large for the LDS staging area");
       sa.ppt = ppt;
       sa.tv_pad = ppt * M;
-      const size_t lds = (size_t)sa.tv_pad * 20 * 4 + 4 * kWaveQueue * sizeof(uint2);
+      lds = (size_t)sa.tv_pad * 20 * 4 + 4 * kWaveQueue * sizeof(uint2);
       const uint64_t n_pixels = (ctx->V.n + M - 1) / M;
-      const uint64_t n_tiles = (n_pixels + ppt - 1) / ppt;
-      uint64_t blocks = (n_tiles + 3) / 4;
-      const uint64_t max_blocks = (uint64_t)ctx->num_cu * 8;
-      if (blocks > max_blocks) blocks = max_blocks;
-      if (blocks < 1) blocks = 1;
-      hipLaunchKernelGGL(scan_uniform_kernel, dim3((unsigned)blocks), dim3(256), lds, ctx->stream, sa);
-    } else {
-      uint64_t blocks = (ctx->V.n + 255) / 256;
-      const uint64_t max_blocks = (uint64_t)ctx->num_cu * 8;
-      if (blocks > max_blocks) blocks = max_blocks;
-      hipLaunchKernelGGL(scan_ragged_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, sa);
+      n_tiles = (n_pixels + ppt - 1) / ppt;
     }
-    HIP_TRY(ctx, hipGetLastError());
+    for (int ci = 0; ci < C; ++ci) {
+      lentil_hip_ctx::Chunk &ch = ctx->chunks[ci];
+      if (M) {
+        ch.tile_begin = n_tiles * ci / C;
+        ch.tile_end = n_tiles * (ci + 1) / C;
+        ch.v_begin = ch.tile_begin * sa.ppt * M;
+        ch.v_end = ch.tile_end * sa.ppt * M;
+        if (ch.v_begin > ctx->V.n) ch.v_begin = ctx->V.n;
+        if (ch.v_end > ctx->V.n) ch.v_end = ctx->V.n;
+      } else {
+        ch.v_begin = ((ctx->V.n * ci / C) + 63) & ~63ull;
+        ch.v_end = ci == C - 1 ? ctx->V.n : (((ctx->V.n * (ci + 1) / C) + 63) & ~63ull);
+        if (ch.v_begin > ctx->V.n) ch.v_begin = ctx->V.n;
+        if (ch.v_end > ctx->V.n) ch.v_end = ctx->V.n;
+      }
+      sa.work = ctx->d_work + ch.v_begin;
+      sa.work_cap = ch.v_end - ch.v_begin;
+      sa.ctr = ctx->d_ctr + ci;
+      sa.tile_begin = ch.tile_begin; sa.tile_end = ch.tile_end;
+      sa.v_begin = ch.v_begin; sa.v_end = ch.v_end;
+      if (ch.v_end > ch.v_begin) {
+        if (M) {
+          uint64_t blocks = (ch.tile_end - ch.tile_begin + 3) / 4;
+          if (blocks > max_blocks) blocks = max_blocks;
+          hipLaunchKernelGGL(scan_uniform_kernel, dim3((unsigned)blocks), dim3(256), lds, ctx->stream, sa);
+        } else {
+          uint64_t blocks = (ch.v_end - ch.v_begin + 255) / 256;
+          if (blocks > max_blocks) blocks = max_blocks;
+          hipLaunchKernelGGL(scan_ragged_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, sa);
+        }
+        HIP_TRY(ctx, hipGetLastError());
+      }
+      HIP_TRY(ctx, hipEventRecord(ch.scanned, ctx->stream));
+    }
   }
   HIP_TRY(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
   if (ctx->V.n) {
-    const int rc = run_draw_pipeline(ctx);
-    if (rc) return rc;
+    // ---- draws: per chunk on its own stream
+    DrawArgs da{};
+    da.P = P;
+    da.lens = P.cameraType == LENTIL_POLYNOMIAL_OPTICS ? ctx->d_lens : nullptr;
+    da.terms = ctx->d_terms;
+    da.bokeh = ctx->bokeh;
+    da.V = ctx->V;
+    da.F = ctx->F;
+    da.log = ctx->d_log;
+    da.log_cap = ctx->log_cap;
+    da.log_count = &ctx->d_ctr[C].log_count;
+    const int blind_rounds = 3;
+    std::vector<DrawArgs> das(C, da);
+    for (int ci = 0; ci < C; ++ci) {
+      HIP_TRY(ctx, hipStreamWaitEvent(ctx->chunks[ci].stream, ctx->chunks[ci].scanned, 0));
+      const int rc = enqueue_chunk_draws(ctx, ci, das[ci], blind_rounds);
+      if (rc) return rc;
+    }
+    // ---- any chunk with items still missing draws after the blind rounds continues round by round
+    int max_rounds = blind_rounds;
+    for (int ci = 0; ci < C; ++ci) {
+      lentil_hip_ctx::Chunk &ch = ctx->chunks[ci];
+      HIP_TRY(ctx, hipStreamSynchronize(ch.stream));
+      if (ch.n_items == 0) continue;
+      for (int round = blind_rounds; round < 64; ++round) {
+        unsigned int n_act = 0;
+        HIP_TRY(ctx, hipMemcpyAsync(&n_act, (char *)(ctx->d_ctr + ci) + offsetof(DevCounters, n_active) +
+                                                sizeof(unsigned int) * (round & 1),
+                                    sizeof(unsigned int), hipMemcpyDeviceToHost, ch.stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ch.stream));
+        if (n_act == 0) break;
+        das[ci].parity = round & 1;
+        launch_solve(ctx, das[ci], ch.stream, 256);
+        hipLaunchKernelGGL(accept_kernel, dim3(64), dim3(256), 0, ch.stream, das[ci]);
+        HIP_TRY(ctx, hipGetLastError());
+        if (round + 1 > max_rounds) max_rounds = round + 1;
+      }
+      HIP_TRY(ctx, hipStreamSynchronize(ch.stream));
+    }
+    ctx->last_rounds = max_rounds;
   }
   if (ctx->F.zkey && ctx->V.n) {
     // closest-filter AOVs: the winners of this pass (one pass per frame: the keys index the bound stream)
@@ -708,18 +762,21 @@ LENTIL_API int lentil_hip_stream(lentil_hip_ctx *ctx, void **hip_stream) {
 LENTIL_API int lentil_hip_get_counters(lentil_hip_ctx *ctx, lentil_counters *out) {
   CHECK_CTX(ctx);
   if (!out) return fail(ctx, LENTIL_ERR_INVALID, "out is null");
-  DevCounters c;
+  std::vector<DevCounters> c(ctx->n_chunks + 1);
   HIP_TRY(ctx, hipSetDevice(ctx->device));
-  HIP_TRY(ctx, hipMemcpyAsync(&c, ctx->d_ctr, sizeof(c), hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  HIP_TRY(ctx, hipMemcpy(c.data(), ctx->d_ctr, sizeof(DevCounters) * c.size(), hipMemcpyDeviceToHost));
+  memset(out, 0, sizeof(*out));
   out->visits = ctx->have_visits ? ctx->V.n : 0;
-  out->redistributed_visits = c.redistributed;
-  out->attempted_draws = c.attempted;
-  out->accepted_draws = c.accepted;
-  out->worklist_overflow = c.overflow;
-  out->newton_iterations = c.newton_iters;
-  out->tries = c.tries;
-  out->lane_rounds = c.lane_rounds;
+  for (int i = 0; i < ctx->n_chunks; ++i) {
+    out->redistributed_visits += c[i].redistributed;
+    out->attempted_draws += c[i].attempted;
+    out->accepted_draws += c[i].accepted;
+    out->worklist_overflow += c[i].overflow;
+    out->newton_iterations += c[i].newton_iters;
+    out->tries += c[i].tries;
+    out->lane_rounds += c[i].lane_rounds;
+  }
   return LENTIL_OK;
 }
 
@@ -757,7 +814,7 @@ LENTIL_API int lentil_hip_download_draw_log(lentil_hip_ctx *ctx, lentil_draw_rec
   if (!n_records) return fail(ctx, LENTIL_ERR_INVALID, "n_records is null");
   DevCounters c;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
-  HIP_TRY(ctx, hipMemcpyAsync(&c, ctx->d_ctr, sizeof(c), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(&c, ctx->d_ctr + ctx->n_chunks, sizeof(c), hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   *n_records = c.log_count;
   uint64_t n = c.log_count < ctx->log_cap ? c.log_count : ctx->log_cap;

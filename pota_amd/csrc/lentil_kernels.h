@@ -74,6 +74,8 @@ struct ScanArgs {
   DevCounters *ctr;
   uint32_t ppt;      // pixels per wave tile (uniform mode)
   uint32_t tv_pad;   // staging entries per wave (>= ppt * visits_per_pixel)
+  uint64_t tile_begin, tile_end;   // uniform mode: this launch's range of pixel tiles
+  uint64_t v_begin, v_end;         // ragged mode: this launch's range of visits
 };
 
 LD_DEV void visit_pixel(const VisitsDev &V, uint64_t v, int &px, int &py) {
@@ -170,8 +172,8 @@ __global__ __launch_bounds__(256) void scan_uniform_kernel(ScanArgs a) {
   const uint32_t ppt = a.ppt;
   const uint32_t TV = ppt * M;
   const uint64_t n_pixels = (V.n + M - 1) / M;
-  const uint64_t n_tiles = (n_pixels + ppt - 1) / ppt;
-  const uint64_t wave_global = (uint64_t)blockIdx.x * waves_per_block + wave;
+  const uint64_t n_tiles = a.tile_end;
+  const uint64_t wave_global = a.tile_begin + (uint64_t)blockIdx.x * waves_per_block + wave;
   const uint64_t wave_stride = (uint64_t)gridDim.x * waves_per_block;
   const uint32_t xres = a.P.xres;
 
@@ -285,11 +287,11 @@ __global__ __launch_bounds__(256) void scan_ragged_kernel(ScanArgs a) {
   WaveQueue wq;
   wq.init(s_queue + (threadIdx.x >> 6) * kWaveQueue);
   const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-  const uint64_t n_round = (V.n + 63ull) & ~63ull;
-  for (uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; v < n_round; v += stride) {
+  const uint64_t n_round = a.v_begin + ((a.v_end - a.v_begin + 63ull) & ~63ull);
+  for (uint64_t v = a.v_begin + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; v < n_round; v += stride) {
     bool flagged = false;
     int samples = 0;
-    if (v < V.n) {
+    if (v < a.v_end) {
       const float4 rgba = V.rgba[v];
       const float invd = V.inv_density ? V.inv_density[v] : a.P.inverse_sample_density;
       const VisitInfo I = visit_prologue(a.P, a.lens_length, rgba, V.pos_z[v], V.raydir_time[v],
@@ -391,6 +393,7 @@ struct DrawArgs {
   uint64_t pool_cap;
   lentil_draw_record *log;
   uint64_t log_cap;
+  unsigned long long *log_count;   // shared by all chunks
   int32_t retries;         // vignetting_retries for PO, 0 for the thin lens
   int32_t parity;
 };
@@ -492,6 +495,12 @@ __global__ __launch_bounds__(256) void solve_po_kernel(DrawArgs a) {
   const DevLens &k = s_k;
   const lentil_params &P = a.P;
 
+  // round r+1's queues are filled by this round's accept kernel: reset them here (nothing else touches them now)
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    const uint32_t nx = (uint32_t)a.parity ^ 1u;
+    a.ctr->n_tasks[nx] = 0; a.ctr->task_head[nx] = 0; a.ctr->n_active[nx] = 0; a.ctr->active_head[nx] = 0;
+    a.ctr->pool_used[nx] = 0;
+  }
   const uint32_t par = (uint32_t)a.parity;
   const Task *tasks = a.tasks[par];
   uint32_t *res = a.pool[par];
@@ -597,6 +606,12 @@ __global__ __launch_bounds__(256) void solve_thinlens_kernel(DrawArgs a) {
     for (int i = threadIdx.x; i < a.bokeh.y; i += blockDim.x) s_cdfRow[i] = a.bokeh.cdfRow[i];
   __syncthreads();
   const float *cdfRow = row_in_lds ? s_cdfRow : a.bokeh.cdfRow;
+  // round r+1's queues are filled by this round's accept kernel: reset them here (nothing else touches them now)
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    const uint32_t nx = (uint32_t)a.parity ^ 1u;
+    a.ctr->n_tasks[nx] = 0; a.ctr->task_head[nx] = 0; a.ctr->n_active[nx] = 0; a.ctr->active_head[nx] = 0;
+    a.ctr->pool_used[nx] = 0;
+  }
   const uint32_t par = (uint32_t)a.parity;
   const uint32_t n_tasks = a.ctr->n_tasks[par] < a.task_cap ? a.ctr->n_tasks[par] : a.task_cap;
   const uint32_t lane = threadIdx.x & 63u;
@@ -616,29 +631,39 @@ __global__ __launch_bounds__(256) void solve_thinlens_kernel(DrawArgs a) {
 }
 
 // ---- ordered acceptance + splat -------------------------------------------------------------------
+// One 256-thread block per item; each step resolves 256 consecutive attempts (wave w: attempts
+// n + 64w .. n + 64w + 63) and ranks the successes across the four waves through LDS, so that exactly
+// the first `samples` successes in attempt order are accepted.
 __global__ __launch_bounds__(256) void accept_kernel(DrawArgs a) {
+  __shared__ uint32_t s_item;
+  __shared__ uint32_t s_first_u[4];
+  __shared__ uint32_t s_nsucc[4];
+  __shared__ uint32_t s_top[4];
   const uint32_t par = (uint32_t)a.parity, nxt = par ^ 1u;
   const uint32_t n_active = a.ctr->n_active[par];
-  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
   const unsigned long long lt_mask = (1ull << lane) - 1ull;
   const uint32_t *res = a.pool[par];
   const uint32_t retries = (uint32_t)a.retries;
   const double lens_length = a.lens ? a.lens->length : 0.0;
   unsigned long long tot_attempted = 0, tot_accepted = 0;
   while (true) {
-    uint32_t ai = 0;
-    if (lane == 0) ai = atomicAdd(&a.ctr->active_head[par], 1u);
-    ai = __builtin_amdgcn_readfirstlane(ai);
+    __syncthreads();
+    if (threadIdx.x == 0) s_item = atomicAdd(&a.ctr->active_head[par], 1u);
+    __syncthreads();
+    const uint32_t ai = s_item;
     if (ai >= n_active) break;
-    const uint32_t item = __builtin_amdgcn_readfirstlane(a.active[par][ai]);
+    const uint32_t item = a.active[par][ai];
     const ItemProg pg = a.prog[item];
     const ItemVisit h = load_item_visit(a, item, lens_length);
     const uint32_t S = h.samples, max_total = S * 5u, m_limit = max_total + retries;
     const float ae = h.I.add_energy, w = h.w;
+    const unsigned long long zk = a.F.zkey ? closest_key(h.I.depth, h.visit) : 0ull;
     uint32_t n = pg.n_done, acc = pg.accepted, last_ok = pg.last_ok;
     bool stalled = false;
     while (!stalled && acc < S && n < max_total) {
-      const uint32_t my_n = n + lane;
+      const uint32_t my_i = wave * 64u + lane;              // position inside this 256-attempt step
+      const uint32_t my_n = n + my_i;
       const bool valid = my_n < max_total;
       uint32_t code = kCodeFail;
       bool unresolved = false;
@@ -650,13 +675,25 @@ __global__ __launch_bounds__(256) void accept_kernel(DrawArgs a) {
           if (c != kCodeFail) { code = c; break; }
         }
       }
+      // first unresolved attempt of the step (all later ones are unresolved too)
       const unsigned long long umask = __ballot(valid && unresolved);
-      const uint32_t first_u = umask ? (uint32_t)__builtin_ctzll(umask) : 64u;
-      uint32_t limit = max_total - n < 64u ? max_total - n : 64u;
-      if (first_u < limit) { limit = first_u; stalled = true; }
-      const bool succ = lane < limit && code < kCodeOut;
+      if (lane == 0) s_first_u[wave] = umask ? wave * 64u + (uint32_t)__builtin_ctzll(umask) : 256u;
+      __syncthreads();
+      uint32_t limit = max_total - n < 256u ? max_total - n : 256u;
+      {
+        uint32_t fu = s_first_u[0];
+        if (s_first_u[1] < fu) fu = s_first_u[1];
+        if (s_first_u[2] < fu) fu = s_first_u[2];
+        if (s_first_u[3] < fu) fu = s_first_u[3];
+        if (fu < limit) { limit = fu; stalled = true; }
+      }
+      const bool succ = my_i < limit && code < kCodeOut;
       const unsigned long long smask = __ballot(succ);
-      const uint32_t rank = acc + (uint32_t)__builtin_popcountll(smask & lt_mask);
+      if (lane == 0) s_nsucc[wave] = (uint32_t)__builtin_popcountll(smask);
+      __syncthreads();
+      uint32_t before = 0, total = 0;
+      for (uint32_t k = 0; k < 4; ++k) { if (k < wave) before += s_nsucc[k]; total += s_nsucc[k]; }
+      const uint32_t rank = acc + before + (uint32_t)__builtin_popcountll(smask & lt_mask);
       const bool take = succ && rank < S;
       if (take) {
         // Camera::add_to_buffer, src/lentil.h:827-830
@@ -667,7 +704,7 @@ __global__ __launch_bounds__(256) void accept_kernel(DrawArgs a) {
         atomicAdd(d + 2, (h.rgba.z + ae) * w);
         atomicAdd(d + 3, (h.rgba.w + ae) * w);
         atomicAdd(a.F.weight + pix, w);
-        if (a.F.zkey) atomicMin(a.F.zkey + pix, closest_key(h.I.depth, h.visit));
+        if (a.F.zkey) atomicMin(a.F.zkey + pix, zk);
         for (uint32_t kx = 0; kx < a.V.n_extra; ++kx) {
           if (a.F.closest_mask & (2u << kx)) continue;
           const float4 c = a.V.extra[kx][h.visit];
@@ -678,14 +715,22 @@ __global__ __launch_bounds__(256) void accept_kernel(DrawArgs a) {
           atomicAdd(dk + 3, (c.w + ae) * w);
         }
         if (a.log_cap) {
-          const unsigned long long li = atomicAdd(&a.ctr->log_count, 1ull);
+          const unsigned long long li = atomicAdd(a.log_count, 1ull);
           if (li < a.log_cap) { a.log[li].visit = h.visit; a.log[li].attempt = my_n; a.log[li].pixel = pix; }
         }
       }
+      // highest accepted attempt of the step
       const unsigned long long tmask = __ballot(take);
-      if (tmask) {
-        acc += (uint32_t)__builtin_popcountll(tmask);
-        last_ok = n + (63u - (uint32_t)__builtin_clzll(tmask));
+      if (lane == 0) s_top[wave] = tmask ? n + wave * 64u + (63u - (uint32_t)__builtin_clzll(tmask)) : 0u;
+      __syncthreads();
+      uint32_t taken = total < S - acc ? total : S - acc;
+      if (taken) {
+        uint32_t top = s_top[0];
+        if (s_top[1] > top) top = s_top[1];
+        if (s_top[2] > top) top = s_top[2];
+        if (s_top[3] > top) top = s_top[3];
+        last_ok = top;
+        acc += taken;
       }
       n += limit;
     }
@@ -699,7 +744,7 @@ __global__ __launch_bounds__(256) void accept_kernel(DrawArgs a) {
       if (n_target > max_total) n_target = max_total;
       uint32_t new_hi = (uint32_t)n_target + retries;
       if (new_hi > m_limit) new_hi = m_limit;
-      if (lane == 0) {
+      if (threadIdx.x == 0) {
         uint32_t off = 0;
         ItemProg np_ = pg;
         np_.n_done = n; np_.accepted = acc; np_.last_ok = last_ok;
@@ -711,13 +756,13 @@ __global__ __launch_bounds__(256) void accept_kernel(DrawArgs a) {
           a.active[nxt][slot] = item;
         }
       }
-    } else {
+    } else if (threadIdx.x == 0) {
       // total_samples_taken when the reference's loop ends, src/lentil_filter.cpp:248
       tot_attempted += (acc >= S) ? (unsigned long long)last_ok + 1ull : (unsigned long long)max_total;
       tot_accepted += acc;
     }
   }
-  if (lane == 0) {
+  if (threadIdx.x == 0) {
     if (tot_attempted) atomicAdd(&a.ctr->attempted, tot_attempted);
     if (tot_accepted) atomicAdd(&a.ctr->accepted, tot_accepted);
   }
