@@ -281,10 +281,10 @@ int lentil_hip_download_aov(lentil_hip_ctx *ctx, uint32_t aov, float *host_rgba)
 int lentil_hip_download_accum(lentil_hip_ctx *ctx, uint32_t aov, float *host_rgba, float *host_weight);
 
 /* --- multi-GPU ---------------------------------------------------------------------
- * accum_buffer: device pointer + float count of the contiguous block of all gaussian
- *               accumulators followed by the weight buffer; a sum all-reduce over it
- *               (RCCL) merges the cross-tile splats of all GPUs.  The
- *               reference has no counterpart (single process, shared buffers). */
+ * accum_buffer: device pointer + float count of the contiguous accumulator block (one record per
+ *               pixel: n_aovs x RGBA, the filter weight, padding to a multiple of 8 floats); a sum
+ *               all-reduce over it (RCCL) merges the cross-tile splats of all GPUs (SURVEY.md
+ *               section 8e).  The reference has no counterpart (single process, shared buffers). */
 int lentil_hip_accum_buffer(lentil_hip_ctx *ctx, void **device_ptr, uint64_t *n_floats);
 int lentil_hip_stream(lentil_hip_ctx *ctx, void **hip_stream);
 

@@ -356,10 +356,11 @@ LENTIL_API int lentil_hip_alloc_frame(lentil_hip_ctx *ctx, uint32_t n_aovs, cons
   ctx->d_resolved = nullptr;
   ctx->have_frame = false;
   const uint64_t np = (uint64_t)ctx->P.xres * ctx->P.yres;
-  const uint64_t nfl = np * 4 * n_aovs + np;
+  const uint32_t rec = ((4u * n_aovs + 1u) + 7u) & ~7u;      // floats per pixel record
+  const uint64_t nfl = np * rec;
   HIP_TRY(ctx, hipMalloc(&ctx->F.acc, nfl * sizeof(float)));
   HIP_TRY(ctx, hipMalloc(&ctx->d_resolved, np * 4 * n_aovs * sizeof(float)));
-  ctx->F.weight = ctx->F.acc + np * 4 * n_aovs;
+  ctx->F.stride = rec;
   ctx->F.n_aovs = n_aovs;
   ctx->F.np = np;
   ctx->F.closest_mask = 0;
@@ -470,7 +471,7 @@ LENTIL_API int lentil_hip_clear_frame(lentil_hip_ctx *ctx) {
   CHECK_CTX(ctx);
   if (!ctx->have_frame) return fail(ctx, LENTIL_ERR_INVALID, "no frame allocated");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
-  const uint64_t nfl = ctx->F.np * 4 * ctx->F.n_aovs + ctx->F.np;
+  const uint64_t nfl = ctx->F.np * ctx->F.stride;
   HIP_TRY(ctx, hipMemsetAsync(ctx->F.acc, 0, nfl * sizeof(float), ctx->stream));
   if (ctx->F.zkey) HIP_TRY(ctx, hipMemsetAsync(ctx->F.zkey, 0xFF, ctx->F.np * sizeof(unsigned long long), ctx->stream));
   return LENTIL_OK;
@@ -601,7 +602,9 @@ LENTIL_API int lentil_hip_redistribute(lentil_hip_ctx *ctx) {
     if (M) {
       // staging: 20 B per visit per wave, 4 waves per block, keep a block under ~48 KiB
       uint32_t ppt = 64;
-      while (ppt > 1 && (uint64_t)ppt * M * 20ull * 4ull > 48ull * 1024ull) ppt >>= 1;
+      uint64_t lds_budget = 48ull * 1024ull;
+      if (const char *e = getenv("LENTIL_SCAN_LDS_KB")) lds_budget = strtoull(e, nullptr, 10) * 1024ull;
+      while (ppt > 1 && (uint64_t)ppt * M * 20ull * 4ull > lds_budget) ppt >>= 1;
       if ((uint64_t)ppt * M * 20ull * 4ull > 150ull * 1024ull)
         return fail(ctx, LENTIL_ERR_UNSUPPORTED, "visits_per_pixel too large for the LDS staging area");
       sa.ppt = ppt;
@@ -703,7 +706,7 @@ LENTIL_API int lentil_hip_resolve(lentil_hip_ctx *ctx) {
   if (!ctx->have_frame) return fail(ctx, LENTIL_ERR_INVALID, "no frame allocated");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   HIP_TRY(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
-  const uint64_t total = ctx->F.np * ctx->F.n_aovs;
+  const uint64_t total = ctx->F.np;
   uint64_t blocks = (total + 255) / 256;
   const uint64_t max_blocks = (uint64_t)ctx->num_cu * 8;
   if (blocks > max_blocks) blocks = max_blocks;
@@ -735,12 +738,16 @@ LENTIL_API int lentil_hip_download_accum(lentil_hip_ctx *ctx, uint32_t aov, floa
   CHECK_CTX(ctx);
   if (!ctx->have_frame || aov >= ctx->F.n_aovs) return fail(ctx, LENTIL_ERR_INVALID, "bad download_accum arguments");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
-  if (host_rgba)
-    HIP_TRY(ctx, hipMemcpyAsync(host_rgba, ctx->F.acc + (size_t)aov * ctx->F.np * 4, ctx->F.np * 16,
-                                hipMemcpyDeviceToHost, ctx->stream));
-  if (host_weight)
-    HIP_TRY(ctx, hipMemcpyAsync(host_weight, ctx->F.weight, ctx->F.np * 4, hipMemcpyDeviceToHost, ctx->stream));
+  // debugging / test path: fetch the interleaved pixel records and pick the requested columns on the host
+  const uint64_t np = ctx->F.np;
+  const uint32_t rec = ctx->F.stride;
+  std::vector<float> tmp(np * rec);
+  HIP_TRY(ctx, hipMemcpyAsync(tmp.data(), ctx->F.acc, tmp.size() * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  for (uint64_t p = 0; p < np; ++p) {
+    if (host_rgba) memcpy(host_rgba + p * 4, tmp.data() + p * rec + 4u * aov, 16);
+    if (host_weight) host_weight[p] = tmp[p * rec + 4u * ctx->F.n_aovs];
+  }
   return LENTIL_OK;
 }
 
@@ -748,7 +755,7 @@ LENTIL_API int lentil_hip_accum_buffer(lentil_hip_ctx *ctx, void **device_ptr, u
   CHECK_CTX(ctx);
   if (!ctx->have_frame || !device_ptr || !n_floats) return fail(ctx, LENTIL_ERR_INVALID, "bad accum_buffer arguments");
   *device_ptr = ctx->F.acc;
-  *n_floats = ctx->F.np * 4 * ctx->F.n_aovs + ctx->F.np;
+  *n_floats = ctx->F.np * ctx->F.stride;
   return LENTIL_OK;
 }
 

@@ -49,8 +49,12 @@ struct VisitsDev {
 };
 
 struct FrameDev {
-  float *acc;        // [n_aovs][np][4]
-  float *weight;     // [np]
+  // One record per pixel: n_aovs x RGBA (AOVData::buffer), then filter_weight_buffer, padded to a multiple
+  // of 8 floats (32 B).  Everything one accepted draw touches is contiguous, so the accept kernel can
+  // issue its fp32 atomics "transposed" (consecutive lanes = consecutive floats of one record): the
+  // memory side executes atomics per 64-B request, and a draw then costs 1-3 requests instead of 5-37.
+  float *acc;        // [np][stride]
+  uint32_t stride;   // floats per record
   // closest-filter AOVs (src/lentil.h:832-837): per pixel the winning candidate as one 64-bit key,
   // (bits of |Z|) << 32 | (0xFFFFFFFF - visit), reduced with atomicMin: smallest depth wins, equal depths
   // go to the later visit -- exactly what the reference's sequential "depth <= zbuffer" test leaves.
@@ -58,6 +62,8 @@ struct FrameDev {
   uint32_t n_aovs;
   uint32_t closest_mask;      // bit k: AOV k is closest-filtered (never bit 0)
   uint64_t np;       // xres*yres
+  LD_DEV float4 *aov(uint64_t p, uint32_t a) const { return reinterpret_cast<float4 *>(acc + p * stride + 4u * a); }
+  LD_DEV float *wt(uint64_t p) const { return acc + p * stride + 4u * n_aovs; }
 };
 
 LD_DEV unsigned long long closest_key(float depth, uint32_t visit) {
@@ -218,15 +224,15 @@ __global__ __launch_bounds__(256) void scan_uniform_kernel(ScanArgs a) {
       const int px = V.pixel_x0 + (int)(pix % V.pixels_per_row);
       const int py = V.pixel_y0 + (int)(pix / V.pixels_per_row) * (int)V.pixel_row_stride;
       lin = (uint64_t)px + (uint64_t)py * xres;
-      float4 s = reinterpret_cast<float4 *>(a.F.acc)[lin];
-      float ws = a.F.weight[lin];
+      float4 s = *a.F.aov(lin, 0);
+      float ws = *a.F.wt(lin);
       for (uint32_t j = 0; j < M; ++j) {
         const float4 c = sval[lane * M + j];
         const float cw = sw[lane * M + j];
         if (cw != 0.0f) { s.x += c.x; s.y += c.y; s.z += c.z; s.w += c.w; ws += cw; }
       }
-      reinterpret_cast<float4 *>(a.F.acc)[lin] = s;
-      a.F.weight[lin] = ws;
+      *a.F.aov(lin, 0) = s;
+      *a.F.wt(lin) = ws;
       if (a.F.zkey) {
         // closest AOVs: this pixel's own (non-redistributed) visits compete with their depth
         unsigned long long kmin = ~0ull;
@@ -262,7 +268,7 @@ __global__ __launch_bounds__(256) void scan_uniform_kernel(ScanArgs a) {
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       if (own) {
-        float4 *dst = reinterpret_cast<float4 *>(a.F.acc) + (size_t)(k + 1) * a.F.np + lin;
+        float4 *dst = a.F.aov(lin, k + 1);
         float4 s = *dst;
         for (uint32_t j = 0; j < M; ++j) {
           if (sw[lane * M + j] != 0.0f) {
@@ -304,17 +310,17 @@ __global__ __launch_bounds__(256) void scan_ragged_kernel(ScanArgs a) {
         visit_pixel(V, v, px, py);
         const uint64_t lin = (uint64_t)px + (uint64_t)py * a.P.xres;
         const float w = 1.0f * invd;
-        float *d = a.F.acc + lin * 4;
+        float *d = reinterpret_cast<float *>(a.F.aov(lin, 0));
         atomicAdd(d + 0, (rgba.x + 0.0f) * w);
         atomicAdd(d + 1, (rgba.y + 0.0f) * w);
         atomicAdd(d + 2, (rgba.z + 0.0f) * w);
         atomicAdd(d + 3, (rgba.w + 0.0f) * w);
-        atomicAdd(a.F.weight + lin, w);
+        atomicAdd(a.F.wt(lin), w);
         if (a.F.zkey) atomicMin(a.F.zkey + lin, closest_key(V.pos_z[v].w, (uint32_t)v));
         for (uint32_t k = 0; k < V.n_extra; ++k) {
           if (a.F.closest_mask & (2u << k)) continue;
           const float4 c = V.extra[k][v];
-          float *dk = a.F.acc + ((size_t)(k + 1) * a.F.np + lin) * 4;
+          float *dk = reinterpret_cast<float *>(a.F.aov(lin, k + 1));
           atomicAdd(dk + 0, (c.x + 0.0f) * w);
           atomicAdd(dk + 1, (c.y + 0.0f) * w);
           atomicAdd(dk + 2, (c.z + 0.0f) * w);
@@ -639,6 +645,9 @@ __global__ __launch_bounds__(256) void accept_kernel(DrawArgs a) {
   __shared__ uint32_t s_first_u[4];
   __shared__ uint32_t s_nsucc[4];
   __shared__ uint32_t s_top[4];
+  __shared__ uint32_t s_pix[4][64];
+  __shared__ float s_val[4 * LENTIL_MAX_AOVS + 1];      // what one accepted draw of the item adds, float by float
+  __shared__ uint32_t s_off[4 * LENTIL_MAX_AOVS + 1];   // ... and where inside the pixel record
   const uint32_t par = (uint32_t)a.parity, nxt = par ^ 1u;
   const uint32_t n_active = a.ctr->n_active[par];
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
@@ -659,6 +668,22 @@ __global__ __launch_bounds__(256) void accept_kernel(DrawArgs a) {
     const uint32_t S = h.samples, max_total = S * 5u, m_limit = max_total + retries;
     const float ae = h.I.add_energy, w = h.w;
     const unsigned long long zk = a.F.zkey ? closest_key(h.I.depth, h.visit) : 0ull;
+    // per-item add table: gaussian AOVs' (value + add_energy) * w, then the weight itself
+    uint32_t U = 1;
+    for (uint32_t k = 0; k < a.F.n_aovs; ++k) if (!(a.F.closest_mask & (1u << k))) U += 4;
+    if (threadIdx.x < a.F.n_aovs * 4u) {
+      const uint32_t k = threadIdx.x >> 2, c = threadIdx.x & 3u;
+      if (!(a.F.closest_mask & (1u << k))) {
+        uint32_t slot = 0;
+        for (uint32_t j = 0; j < k; ++j) if (!(a.F.closest_mask & (1u << j))) slot += 4;
+        const float4 v = k == 0 ? h.rgba : a.V.extra[k - 1][h.visit];
+        const float vc = c == 0 ? v.x : (c == 1 ? v.y : (c == 2 ? v.z : v.w));
+        s_val[slot + c] = (vc + ae) * w;
+        s_off[slot + c] = 4u * k + c;
+      }
+    }
+    if (threadIdx.x == 0) { s_val[U - 1] = w; s_off[U - 1] = 4u * a.F.n_aovs; }
+    __syncthreads();
     uint32_t n = pg.n_done, acc = pg.accepted, last_ok = pg.last_ok;
     bool stalled = false;
     while (!stalled && acc < S && n < max_total) {
@@ -695,32 +720,31 @@ __global__ __launch_bounds__(256) void accept_kernel(DrawArgs a) {
       for (uint32_t k = 0; k < 4; ++k) { if (k < wave) before += s_nsucc[k]; total += s_nsucc[k]; }
       const uint32_t rank = acc + before + (uint32_t)__builtin_popcountll(smask & lt_mask);
       const bool take = succ && rank < S;
+      // Camera::add_to_buffer, src/lentil.h:827-830 -- transposed: the wave's accepted pixels go through
+      // LDS, then lane q adds float (q % U) of accepted draw (q / U): consecutive lanes hit consecutive
+      // floats of one pixel record.
+      const unsigned long long tmask0 = __ballot(take);
+      const uint32_t T = (uint32_t)__builtin_popcountll(tmask0);
       if (take) {
-        // Camera::add_to_buffer, src/lentil.h:827-830
         const uint32_t pix = code;
-        float *d = a.F.acc + (size_t)pix * 4;
-        atomicAdd(d + 0, (h.rgba.x + ae) * w);
-        atomicAdd(d + 1, (h.rgba.y + ae) * w);
-        atomicAdd(d + 2, (h.rgba.z + ae) * w);
-        atomicAdd(d + 3, (h.rgba.w + ae) * w);
-        atomicAdd(a.F.weight + pix, w);
+        s_pix[wave][(uint32_t)__builtin_popcountll(tmask0 & lt_mask)] = pix;
         if (a.F.zkey) atomicMin(a.F.zkey + pix, zk);
-        for (uint32_t kx = 0; kx < a.V.n_extra; ++kx) {
-          if (a.F.closest_mask & (2u << kx)) continue;
-          const float4 c = a.V.extra[kx][h.visit];
-          float *dk = a.F.acc + ((size_t)(kx + 1) * a.F.np + pix) * 4;
-          atomicAdd(dk + 0, (c.x + ae) * w);
-          atomicAdd(dk + 1, (c.y + ae) * w);
-          atomicAdd(dk + 2, (c.z + ae) * w);
-          atomicAdd(dk + 3, (c.w + ae) * w);
-        }
         if (a.log_cap) {
           const unsigned long long li = atomicAdd(a.log_count, 1ull);
           if (li < a.log_cap) { a.log[li].visit = h.visit; a.log[li].attempt = my_n; a.log[li].pixel = pix; }
         }
       }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      for (uint32_t q = lane; q < T * U; q += 64u) {
+        const uint32_t d = q / U, ch = q - d * U;
+        atomicAdd(a.F.acc + (size_t)s_pix[wave][d] * a.F.stride + s_off[ch], s_val[ch]);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
       // highest accepted attempt of the step
-      const unsigned long long tmask = __ballot(take);
+      const unsigned long long tmask = tmask0;
       if (lane == 0) s_top[wave] = tmask ? n + wave * 64u + (63u - (uint32_t)__builtin_clzll(tmask)) : 0u;
       __syncthreads();
       uint32_t taken = total < S - acc ? total : S - acc;
@@ -777,28 +801,26 @@ __global__ __launch_bounds__(256) void closest_gather_kernel(FrameDev F, VisitsD
     const uint32_t visit = 0xFFFFFFFFu - (uint32_t)(key & 0xFFFFFFFFull);
     for (uint32_t k = 1; k < F.n_aovs; ++k)
       if (F.closest_mask & (1u << k))
-        reinterpret_cast<float4 *>(F.acc)[(uint64_t)k * F.np + p] = V.extra[k - 1][visit];
+        *F.aov(p, k) = V.extra[k - 1][visit];
   }
 }
 
-// K7 -- driver_process_bucket's normalisation, src/lentil_imager.cpp:169-186
+// K7 -- driver_process_bucket's normalisation, src/lentil_imager.cpp:169-186.  Reads the pixel records,
+// writes one planar RGBA image per AOV (what the imager copies into Arnold's buckets).
 __global__ __launch_bounds__(256) void resolve_kernel(FrameDev F, float *resolved) {
   const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-  const uint64_t total = F.np * F.n_aovs;
-  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
-    const uint64_t p = i % F.np;
-    const uint32_t aov = (uint32_t)(i / F.np);
-    float4 c = reinterpret_cast<const float4 *>(F.acc)[i];
-    if (F.closest_mask & (1u << aov)) {
-      c.w = 1.0f;                          // closest: (r, g, b, 1), src/lentil_imager.cpp:181-186
-    } else {
-      const float wt = F.weight[p];
-      if (wt != 0.0f) {                    // AtRGBA /= float multiplies by 1.0f/f
-        const float inv = 1.0f / wt;
+  for (uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; p < F.np; p += stride) {
+    const float wt = *F.wt(p);
+    const float inv = wt != 0.0f ? 1.0f / wt : 1.0f;        // AtRGBA /= float multiplies by 1.0f/f
+    for (uint32_t a = 0; a < F.n_aovs; ++a) {
+      float4 c = *F.aov(p, a);
+      if (F.closest_mask & (1u << a)) {
+        c.w = 1.0f;                                        // closest: (r, g, b, 1), src/lentil_imager.cpp:181-186
+      } else if (wt != 0.0f) {
         c.x *= inv; c.y *= inv; c.z *= inv; c.w *= inv;
       }
+      reinterpret_cast<float4 *>(resolved)[(uint64_t)a * F.np + p] = c;
     }
-    reinterpret_cast<float4 *>(resolved)[i] = c;
   }
 }
 
