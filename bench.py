@@ -128,9 +128,12 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus %d needs torch.distributed.run with %d ranks" % (args.gpus, args.gpus))
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    force_dist = os.environ.get("LENTIL_FORCE_DIST") == "1"     # exercise the RCCL plumbing on one GPU
+    if world > 1 or force_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     dev = torch.device("cuda", local_rank)
 
     W, Hr, M = args.width, args.height, args.visits_per_pixel
@@ -235,11 +238,18 @@ def main():
         except Exception as e:      # the GPU number must still be reported
             out["cpu_baseline"] = {"value": None, "unit": "Msamples/s", "cores": 0, "kind": "port",
                                    "sample": "failed: %r" % (e,)}
-    if rank == 0:
-        print(json.dumps(out))
     ctx.close()
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
+    if rank == 0:
+        # the single JSON line is the last thing on stdout (RCCL prints a banner of its own)
+        sys.stdout.flush()
+        print(json.dumps(out), flush=True)
+    # RCCL prints a three-line banner to stdout from a library destructor; leave without running those so
+    # that the JSON line stays the last line of output on every rank
+    sys.stdout.flush()
+    sys.stderr.flush()
+    os._exit(0)
 
 
 if __name__ == "__main__":

@@ -8,6 +8,9 @@ The step logic is engine-agnostic so that the N>1 path is covered by world_size-
 CPU (tests/test_multi_gpu.py); the product engine is HipEngine (liblentil_hip.so).
 """
 import ctypes as C
+import os
+
+FORCE_COLLECTIVE = os.environ.get("LENTIL_FORCE_DIST") == "1"
 
 
 class _CudaArrayView:
@@ -56,7 +59,7 @@ def frame_step(engine, dist=None):
     """One redistribution pass over the rank's visits incl. the cross-rank merge and the resolve."""
     engine.clear()
     engine.redistribute()
-    if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
+    if dist is not None and dist.is_initialized() and (dist.get_world_size() > 1 or FORCE_COLLECTIVE):
         engine.finish_local()
         dist.all_reduce(engine.accum, op=dist.ReduceOp.SUM)
         engine.before_resolve()
