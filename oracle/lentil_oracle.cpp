@@ -1023,3 +1023,227 @@ ORC_API float orc_inverse_sample_density(int samples_counter, float filter_width
     *redistribution_ok = !(static_cast<int>(std::round(AA_samples)) != aa_samples_set_by_user || (aa_samples_set_by_user < 3));
   return inverse_sample_density;
 }
+
+/* =====================================================================================
+ * Host-side camera setup -- src/lentil.h:1316-1460,1568-1670
+ * ===================================================================================== */
+/* line_plane_intersection with the fixed y = 0 plane, src/lens.h:412-419; returns the z component */
+static double line_plane_y0_z(const double o[3], const double d_in[3]) {
+  double d[3] = {d_in[0], d_in[1], d_in[2]};
+  const double n = std::sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);   /* Eigen normalize(): v / norm */
+  d[0] /= n; d[1] /= n; d[2] /= n;
+  /* coord = normalized (100,0,100); coord.dot(planeNormal) = 0 exactly; planeNormal = (0,1,0) */
+  /* rayOrigin + (rayDirection * (A - B)) / C : the vector is scaled first, then divided */
+  return o[2] + (d[2] * (0.0 - o[1])) / d[1];
+}
+
+/* Camera::camera_get_y0_intersection_distance, src/lentil.h:1361-1386 */
+ORC_API double orc_camera_get_y0_intersection_distance(const OrcLens *L, double sensor_shift, double lambda) {
+  double sensor[5] = {0, 0, 0, 0, lambda};
+  double aperture[5] = {0, L->k.lens_aperture_housing_radius * 0.25, 0, 0, 0};
+  double out[5] = {0, 0, 0, 0, 0};
+  orc_pt_sample_aperture(L, sensor, aperture, sensor_shift);
+  sensor[0] += sensor[2] * sensor_shift;
+  sensor[1] += sensor[3] * sensor_shift;
+  orc_lens_evaluate(L, sensor, out);
+  double pos[3], dir[3];
+  pupil_to_cs(L->k, out, out + 2, pos, dir);
+  return line_plane_y0_z(pos, dir);
+}
+
+/* logarithmic_values, src/lens.h:395-407 + Camera::logarithmic_focus_search, src/lentil.h:1445-1460 */
+ORC_API double orc_logarithmic_focus_search(const OrcLens *L, double focal_distance, double lambda) {
+  double closest_distance = 999999999.0;
+  double best_sensor_shift = 0.0;
+  for (double i = -1.0; i <= 1.0; i += 0.0001) {
+    const double sensorshift = (i < 0 ? -1 : 1) * std::pow(i, 2.0) * (45.0 - 0.0) + 0.0;
+    const double intersection_distance = orc_camera_get_y0_intersection_distance(L, sensorshift, lambda);
+    const double new_distance = focal_distance - intersection_distance;
+    if (new_distance < closest_distance && new_distance > 0.0) {
+      closest_distance = new_distance;
+      best_sensor_shift = sensorshift;
+    }
+  }
+  return best_sensor_shift;
+}
+
+/* Camera::trace_backwards_for_fstop, src/lentil.h:1390-1441 (AI_BIG = 1.0e12f) */
+ORC_API void orc_trace_backwards_for_fstop(const OrcLens *L, double fstop_target, double lambda,
+                                           double *calculated_fstop, double *calculated_aperture_radius) {
+  const int maxrays = 1000;
+  double best_valid_fstop = 0.0, best_valid_aperture_radius = 0.0;
+  const lentil_lens_table &k = L->k;
+  for (int i = 1; i < maxrays; i++) {
+    const double parallel_ray_height = (static_cast<double>(i) / static_cast<double>(maxrays)) * k.lens_outer_pupil_radius;
+    const double target[3] = {0, parallel_ray_height, (double)1.0e12f};
+    double sensor[5] = {0, 0, 0, 0, lambda};
+    double out[5] = {0, 0, 0, 0, 0};
+    const double aperture[2] = {0.01, parallel_ray_height};
+    if (orc_lt_sample_aperture(L, target, aperture, sensor, out, lambda, nullptr) <= 0.0) continue;
+    const double px = sensor[0] + (sensor[2] * k.lens_back_focal_length);
+    const double py = sensor[1] + (sensor[3] * k.lens_back_focal_length);
+    if (px * px + py * py > k.lens_inner_pupil_radius * k.lens_inner_pupil_radius) continue;
+    double pos[3], dir[3];
+    const double Ri = k.lens_inner_pupil_curvature_radius;
+    if (k.lens_inner_pupil_geometry == LENTIL_GEOM_CYL_Y) orc_cylinderToCs(out, out + 2, pos, dir, -Ri + k.lens_back_focal_length, Ri, 1);
+    else if (k.lens_inner_pupil_geometry == LENTIL_GEOM_CYL_X) orc_cylinderToCs(out, out + 2, pos, dir, -Ri + k.lens_back_focal_length, Ri, 0);
+    else orc_sphereToCs(out, out + 2, pos, dir, -Ri + k.lens_back_focal_length, Ri);
+    const double theta = std::atan(pos[1] / pos[2]);
+    const double fstop = 1.0 / (std::sin(theta) * 2.0);
+    if (fstop < fstop_target) {
+      *calculated_fstop = best_valid_fstop;
+      *calculated_aperture_radius = best_valid_aperture_radius;
+      return;
+    } else {
+      best_valid_fstop = fstop;
+      best_valid_aperture_radius = parallel_ray_height;
+    }
+  }
+  *calculated_fstop = best_valid_fstop;
+  *calculated_aperture_radius = best_valid_aperture_radius;
+}
+
+/* Camera::trace_ray_focus_check, src/lentil.h:1316-1357 */
+ORC_API int orc_trace_ray_focus_check(const OrcLens *L, double sensor_shift, double lambda, double *test_focus_distance) {
+  const lentil_lens_table &k = L->k;
+  double sensor[5] = {0, 0, 0, 0, lambda};
+  double aperture[5] = {0, k.lens_aperture_housing_radius * 0.25, 0, 0, 0};
+  double out[5] = {0, 0, 0, 0, 0};
+  orc_pt_sample_aperture(L, sensor, aperture, sensor_shift);
+  sensor[0] += sensor[2] * sensor_shift;
+  sensor[1] += sensor[3] * sensor_shift;
+  const double transmittance = orc_lens_evaluate(L, sensor, out);
+  if (transmittance <= 0.0) return 0;
+  if (out[0] * out[0] + out[1] * out[1] > k.lens_outer_pupil_radius * k.lens_outer_pupil_radius) return 0;
+  const double px = sensor[0] + sensor[2] * k.lens_back_focal_length;
+  const double py = sensor[1] + sensor[3] * k.lens_back_focal_length;
+  if (px * px + py * py > k.lens_inner_pupil_radius * k.lens_inner_pupil_radius) return 0;
+  double pos[3], dir[3];
+  pupil_to_cs(k, out, out + 2, pos, dir);
+  *test_focus_distance = line_plane_y0_z(pos, dir);
+  return 1;
+}
+
+/* =====================================================================================
+ * Forward camera rays -- src/lentil.h:283-569.
+ * xor128 state is explicit (the reference keeps it in function-local statics, src/global.h:22-27).
+ * ===================================================================================== */
+ORC_API void orc_trace_ray_fw_po(const lentil_params *P, const OrcLens *L, const OrcBokeh *B, uint32_t rng[4],
+                                 double lambda, double sx, double sy, double *r1, double *r2, int deriv_ray,
+                                 float origin[3], float direction[3], float weight[3], int *tries_out) {
+  const lentil_lens_table &k = L->k;
+  int tries = 0;
+  bool ray_succes = false;
+  double sensor[5] = {0, 0, 0, 0, 0}, aperture[5] = {0, 0, 0, 0, 0}, out[5] = {0, 0, 0, 0, 0};
+  while (!ray_succes && tries <= P->vignetting_retries) {
+    sensor[0] = sx * (P->sensor_width * 0.5);
+    sensor[1] = sy * (P->sensor_width * 0.5);
+    sensor[2] = sensor[3] = 0.0;
+    sensor[4] = lambda;
+    for (int i = 0; i < 5; i++) { aperture[i] = 0; out[i] = 0; }
+    double unit_disk[2] = {0.0, 0.0};
+    if (P->enable_dof) {
+      if (!deriv_ray && tries > 0) {
+        *r1 = orc_xor128(rng) / 4294967296.0;
+        *r2 = orc_xor128(rng) / 4294967296.0;
+      }
+      if (P->bokeh_enable_image) {
+        orc_xor128(rng); orc_xor128(rng);                 /* the two unused stratification draws */
+        orc_bokeh_sample(B, *r1, *r2, unit_disk);
+      } else if (P->bokeh_aperture_blades < 2) {
+        orc_concentric_disk_sample(*r1, *r2, unit_disk);
+      } else {
+        orc_triangular_aperture(&unit_disk[0], &unit_disk[1], *r1, *r2, 1.0, P->bokeh_aperture_blades);
+      }
+    }
+    aperture[0] = unit_disk[0] * P->aperture_radius;
+    aperture[1] = unit_disk[1] * P->aperture_radius;
+    if (P->enable_dof) orc_pt_sample_aperture(L, sensor, aperture, P->sensor_shift);
+    sensor[0] += sensor[2] * P->sensor_shift;
+    sensor[1] += sensor[3] * P->sensor_shift;
+    const double transmittance = orc_lens_evaluate(L, sensor, out);
+    if (transmittance <= 0.0) { ++tries; continue; }
+    if (out[0] * out[0] + out[1] * out[1] > k.lens_outer_pupil_radius * k.lens_outer_pupil_radius) { ++tries; continue; }
+    const double px = sensor[0] + sensor[2] * k.lens_back_focal_length;
+    const double py = sensor[1] + sensor[3] * k.lens_back_focal_length;
+    if (px * px + py * py > k.lens_inner_pupil_radius * k.lens_inner_pupil_radius) { ++tries; continue; }
+    ray_succes = true;
+  }
+  if (!ray_succes) weight[0] = weight[1] = weight[2] = 0.0f;
+  double pos[3], dir[3];
+  pupil_to_cs(k, out, out + 2, pos, dir);
+  float o[3] = {(float)pos[0], (float)pos[1], (float)pos[2]};
+  float d[3] = {(float)dir[0], (float)dir[1], (float)dir[2]};
+  float s = -1.0f;                                           /* src/lentil.h:395-416 */
+  if (P->unitModel == LENTIL_UNIT_CM) s = -0.1f;
+  else if (P->unitModel == LENTIL_UNIT_DM) s = -0.01f;
+  else if (P->unitModel == LENTIL_UNIT_M) s = -0.001f;
+  for (int i = 0; i < 3; i++) { o[i] *= s; d[i] *= s; }
+  v3norm(d, d);
+  for (int i = 0; i < 3; i++) { origin[i] = o[i]; direction[i] = d[i]; }
+  if (o[0] != o[0] || o[1] != o[1] || o[2] != o[2] || d[0] != d[0] || d[1] != d[1] || d[2] != d[2])
+    weight[0] = weight[1] = weight[2] = 0.0f;
+  if (tries_out) *tries_out = tries;
+}
+
+/* abb_coma == 0 only (the coma rotation goes through Eigen and is the identity then) */
+ORC_API void orc_trace_ray_fw_thinlens(const lentil_params *P, const OrcBokeh *B, uint32_t rng[4], double sx, double sy,
+                                       double *r1, double *r2, int deriv_ray, float origin[3], float dir[3],
+                                       float weight[3], int *tries_out) {
+  int tries = 0;
+  bool ray_succes = false;
+  float o[3] = {0, 0, 0}, dd[3] = {0, 0, 0};
+  while (!ray_succes && tries <= P->vignetting_retries) {
+    float s[3] = {(float)sx, (float)sy, 0.0f};
+    if (P->abb_distortion > 0.0) {                           /* barrelDistortion, src/lens.h:545-548 */
+      float ux = sx, uy = sy;
+      const float f = 1. + (ux * ux + uy * uy) * P->abb_distortion;
+      s[0] = ux * f; s[1] = uy * f;
+    }
+    const float p[3] = {(float)(s[0] * (P->sensor_width * 0.5)), (float)(s[1] * (P->sensor_width * 0.5)), -P->focal_length};
+    float dir_from_center[3];
+    v3norm(p, dir_from_center);
+    double unit_disk[2] = {0, 0};
+    if (P->enable_dof) {
+      if (!deriv_ray && tries > 0) {
+        *r1 = orc_xor128(rng) / 4294967296.0;
+        *r2 = orc_xor128(rng) / 4294967296.0;
+      }
+      if (P->bokeh_enable_image) {
+        orc_xor128(rng); orc_xor128(rng);
+        orc_bokeh_sample(B, *r1, *r2, unit_disk);
+      } else if (P->bokeh_aperture_blades < 2) {
+        orc_concentricDiskSample(*r1, *r2, unit_disk, P->abb_spherical, P->circle_to_square);
+      } else {
+        orc_triangular_aperture(&unit_disk[0], &unit_disk[1], *r1, *r2, 1.0, P->bokeh_aperture_blades);
+      }
+    }
+    unit_disk[0] *= P->bokeh_anamorphic;
+    const float lens[3] = {(float)(unit_disk[0] * P->aperture_radius), (float)(unit_disk[1] * P->aperture_radius), 0.0f};
+    const float intersection = std::abs(P->focus_distance / lerpf(0.0f, dir_from_center[2], 1.0));
+    const float focusPoint[3] = {dir_from_center[0] * intersection, dir_from_center[1] * intersection, dir_from_center[2] * intersection};
+    const float t[3] = {focusPoint[0] - lens[0], focusPoint[1] - lens[1], focusPoint[2] - lens[2]};
+    float dir_from_lens[3];
+    v3norm(t, dir_from_lens);
+    if (P->optical_vignetting_distance > 0.0 && !deriv_ray) {     /* src/lens.h:529-543 */
+      const float squarebias = 1.0 + std::log(1.0 + P->circle_to_square) * std::exp(P->circle_to_square * 3.0);
+      float inter = std::abs(P->optical_vignetting_distance / dir_from_lens[2]);
+      float ovx = dir_from_lens[0] * inter - lens[0];
+      float ovy = dir_from_lens[1] * inter - lens[1];
+      float power = 1.0 + squarebias;
+      float radius = (float)P->aperture_radius * P->optical_vignetting_radius;
+      float dist = std::pow(std::abs(ovx), power) + std::pow(std::abs(ovy), power);
+      if (dist > std::pow(radius, power)) { ++tries; continue; }
+    }
+    float sc = 1.0f;                                          /* src/lentil.h:540-561 */
+    if (P->unitModel == LENTIL_UNIT_MM) sc = 10.0f;
+    else if (P->unitModel == LENTIL_UNIT_DM) sc = 0.1f;
+    else if (P->unitModel == LENTIL_UNIT_M) sc = 0.01f;
+    for (int i = 0; i < 3; i++) { o[i] = lens[i] * sc; dd[i] = dir_from_lens[i] * sc; }
+    ray_succes = true;
+  }
+  v3norm(dd, dd);
+  for (int i = 0; i < 3; i++) { origin[i] = o[i]; dir[i] = dd[i]; }
+  if (!ray_succes) weight[0] = weight[1] = weight[2] = 0.0f;
+  if (tries_out) *tries_out = tries;
+}

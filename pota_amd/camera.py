@@ -118,9 +118,11 @@ class LensModel:
         out, _ = self.lens_evaluate(sx, sy, dx, dy, lam)
         R = self.k["lens_outer_pupil_curvature_radius"]
         pos, d = sphere_to_cs(out[:2], out[2:], -R, R)
-        d = _normalise(d)          # line_plane_intersection normalises the direction, src/lens.h:412-419
-        t = (0.0 - pos[1]) / d[1]
-        return pos[2] + d[2] * t
+        # line_plane_intersection, src/lens.h:412-419: Eigen's normalize() divides by the norm, and the
+        # result is rayOrigin + (rayDirection * (0 - origin.y)) / rayDirection.y
+        nrm = np.sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2])
+        d = [d[0] / nrm, d[1] / nrm, d[2] / nrm]
+        return pos[2] + (d[2] * (0.0 - pos[1])) / d[1]
 
     def logarithmic_focus_search(self, focal_distance, lam):
         """Camera::logarithmic_focus_search, src/lentil.h:1445-1460 + logarithmic_values, src/lens.h:395-407."""
@@ -194,27 +196,31 @@ def setup_filter(p, width, height, region=None, filter_width=1.5, aa_samples=3):
 
 
 def setup_thinlens(p, focal_length=35.0, fstop=1.4, focus_dist=150.0, sensor_width=36.0):
-    """ThinLens branch of camera_model_specific_setup, src/lentil.h:1663-1668."""
+    """ThinLens branch of camera_model_specific_setup, src/lentil.h:1663-1668 (host library)."""
+    from . import hostlib
     p.cameraType = _abi.THINLENS
     p.sensor_width = float(np.float32(sensor_width))
-    p.focal_length = max(np.float32(focal_length), np.float32(0.01))
+    p.focal_length = max(np.float32(focal_length), np.float32(0.01))        # clamp_min, src/lentil.h:1217
     p.focus_distance = float(np.float32(focus_dist))
-    input_fstop = float(max(np.float32(fstop), np.float32(0.01)))
-    p.aperture_radius = (float(p.focal_length) / (2.0 * input_fstop)) / 10.0
+    input_fstop = float(max(np.float32(fstop), np.float32(0.01)))           # src/lentil.h:1206
+    hostlib.camera_model_specific_setup(p, None, input_fstop)
     return p
 
 
 def setup_po(p, lens, focus_dist=150.0, sensor_width=36.0, focal_length=None, wavelength_nm=550.0,
-             extra_sensor_shift=0.0):
-    """PolynomialOptics branch of camera_model_specific_setup, src/lentil.h:1571-1662 (fstop = 0:
-    aperture_radius = lens_aperture_radius_at_fstop)."""
+             extra_sensor_shift=0.0, fstop=0.0):
+    """PolynomialOptics branch of camera_model_specific_setup, src/lentil.h:1571-1662, run by the host
+    library (liblentil_host.so): focus_distance cm -> mm, aperture radius (fstop 0 = wide open, else the
+    backward f-stop trace), logarithmic focus search for the sensor shift."""
+    from . import hostlib
     model = lens if isinstance(lens, LensModel) else LensModel(lens)
     p.cameraType = _abi.POLYNOMIAL_OPTICS
     p.sensor_width = float(np.float32(sensor_width))
-    p.focus_distance = float(np.float32(focus_dist)) * 10.0                 # :1573 (cm -> mm)
-    lam = float(np.float32(wavelength_nm)) * 0.001                          # :1213
-    p.aperture_radius = model.k["lens_aperture_radius_at_fstop"]           # :1604-1605
-    p.sensor_shift = model.logarithmic_focus_search(p.focus_distance, lam) + float(np.float32(extra_sensor_shift))
+    p.focus_distance = float(np.float32(focus_dist))                       # cm; the setup multiplies by 10 (:1573)
     # get_coc_thinlens uses the thin-lens focal length even in PO mode (src/lentil.h:674-692)
     p.focal_length = np.float32(focal_length if focal_length is not None else model.k["lens_effective_focal_length"])
+    hl = hostlib.HostLens(model.spec)
+    input_fstop = float(max(np.float32(fstop), np.float32(0.01))) if fstop else 0.0
+    hostlib.camera_model_specific_setup(p, hl, input_fstop, wavelength_nm, extra_sensor_shift)
+    hl.close()
     return p, model

@@ -68,6 +68,14 @@ def load():
         "orc_redistribute": (i, [C.POINTER(_abi.Params), vp, vp, vp, C.POINTER(_abi.Visits), u64, u64]),
         "orc_resolve": (None, [vp, u32, vp]),
         "orc_inverse_sample_density": (f, [i, f, i, C.POINTER(i)]),
+        "orc_camera_get_y0_intersection_distance": (d, [vp, d, d]),
+        "orc_logarithmic_focus_search": (d, [vp, d, d]),
+        "orc_trace_backwards_for_fstop": (None, [vp, d, d, pd, pd]),
+        "orc_trace_ray_focus_check": (i, [vp, d, d, pd]),
+        "orc_trace_ray_fw_po": (None, [C.POINTER(_abi.Params), vp, vp, C.POINTER(u32), d, d, d, pd, pd, i,
+                                       C.POINTER(f), C.POINTER(f), C.POINTER(f), C.POINTER(i)]),
+        "orc_trace_ray_fw_thinlens": (None, [C.POINTER(_abi.Params), vp, C.POINTER(u32), d, d, pd, pd, i,
+                                             C.POINTER(f), C.POINTER(f), C.POINTER(f), C.POINTER(i)]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)
