@@ -504,27 +504,9 @@ static void launch_solve(lentil_hip_ctx *ctx, const DrawArgs &da, hipStream_t st
 // Size one chunk's draw-pipeline buffers from its scan result and enqueue prep + `blind_rounds`
 // solve/accept rounds on the chunk's stream (no host round trip between the rounds: every kernel
 // reads its queue lengths from device memory; a round with empty queues costs a few microseconds).
-static int enqueue_chunk_draws(lentil_hip_ctx *ctx, int ci, DrawArgs &da, int blind_rounds) {
-  lentil_hip_ctx::Chunk &ch = ctx->chunks[ci];
-  const lentil_params &P = ctx->P;
-  DevCounters *dctr = ctx->d_ctr + ci;
-  // wait for this chunk's scan only (later chunks keep scanning meanwhile), fetch its item count / draw sum
-  HIP_TRY(ctx, hipEventSynchronize(ch.scanned));
-  DevCounters c;
-  HIP_TRY(ctx, hipMemcpyAsync(&c, dctr, sizeof(c), hipMemcpyDeviceToHost, ch.stream));
-  HIP_TRY(ctx, hipStreamSynchronize(ch.stream));
-  const uint64_t cap = ch.v_end - ch.v_begin;
-  const uint64_t n_items = c.work_count < cap ? c.work_count : cap;
-  ch.n_items = n_items;
-  if (n_items == 0) return LENTIL_OK;
-  const bool po = P.cameraType == LENTIL_POLYNOMIAL_OPTICS;
-  const uint32_t retries = po ? (uint32_t)(P.vignetting_retries < 0 ? 0 : P.vignetting_retries) : 0u;
-  // round 0 needs sum(samples + retries) results; a later round at most the attempts an item has left
-  const uint64_t units = 4 * c.sum_samples + (uint64_t)(2 * retries + 32) * n_items;
-  if (units > ctx->max_pool_units)
-    return fail(ctx, LENTIL_ERR_NOMEM, "draw result pool would exceed LENTIL_MAX_POOL_UNITS; split the visit stream");
+static int size_chunk_buffers(lentil_hip_ctx *ctx, lentil_hip_ctx::Chunk &ch, uint64_t n_items, uint64_t units) {
   const uint64_t tasks = units / 64 + 2 * n_items + 64;
-  if (tasks > 0xFFFFFFF0ull) return fail(ctx, LENTIL_ERR_NOMEM, "too many solve tasks; split the visit stream");
+  if (tasks > 0xFFFFFFF0ull) return fail(ctx, LENTIL_ERR_NOMEM, "too many solve tasks in one batch");
   int rc;
   if (n_items > ch.item_cap) {
     const uint64_t nc = n_items + n_items / 4 + 1024;
@@ -546,30 +528,109 @@ static int enqueue_chunk_draws(lentil_hip_ctx *ctx, int ci, DrawArgs &da, int bl
     if ((rc = grow(ctx, &ch.pool[1], nc))) return rc;
     ch.pool_cap = nc;
   }
-  da.work = ctx->d_work + ch.v_begin;
-  da.n_items = n_items;
-  da.ctr = dctr;
+  return LENTIL_OK;
+}
+
+static void bind_chunk_buffers(const lentil_hip_ctx::Chunk &ch, DrawArgs &da) {
   da.hdr = ch.hdr;
   da.prog = ch.prog;
   for (int i = 0; i < 2; ++i) { da.tasks[i] = ch.tasks[i]; da.active[i] = ch.active[i]; da.pool[i] = ch.pool[i]; }
   da.task_cap = (uint32_t)(ch.task_cap > 0xFFFFFFF0ull ? 0xFFFFFFF0ull : ch.task_cap);
   da.pool_cap = ch.pool_cap < 0xFFFFFFFFull ? ch.pool_cap : 0xFFFFFFFFull;
-  da.retries = (int32_t)retries;
-  da.parity = 0;
-  hipLaunchKernelGGL(prep_items_kernel, dim3((unsigned)((n_items + 255) / 256)), dim3(256), 0, ch.stream, da);
-  HIP_TRY(ctx, hipGetLastError());
-  // enough persistent waves for the chunk's first batch, at most 4 blocks per CU
-  uint64_t want = (c.sum_samples / 64 + n_items + 3) / 4;
-  const uint64_t max_blocks = (uint64_t)ctx->num_cu * 4;
-  const unsigned solve_blocks = (unsigned)(want < 1 ? 1 : (want > max_blocks ? max_blocks : want));
-  uint64_t awant = n_items;            // one block per item
-  const unsigned accept_blocks = (unsigned)(awant < 1 ? 1 : (awant > (uint64_t)ctx->num_cu * 2 ? (uint64_t)ctx->num_cu * 2 : awant));
-  for (int round = 0; round < blind_rounds; ++round) {
+}
+
+// rounds with a host check after each (used when the blind rounds did not finish a chunk, and for
+// the sub-batches of very large chunks); returns the number of rounds run from `first_round` on
+static int finish_rounds(lentil_hip_ctx *ctx, int ci, DrawArgs &da, int first_round, int *rounds_out) {
+  lentil_hip_ctx::Chunk &ch = ctx->chunks[ci];
+  int round = first_round;
+  for (; round < 64; ++round) {
+    unsigned int n_act = 0;
+    HIP_TRY(ctx, hipMemcpyAsync(&n_act, (char *)(ctx->d_ctr + ci) + offsetof(DevCounters, n_active) +
+                                            sizeof(unsigned int) * (round & 1),
+                                sizeof(unsigned int), hipMemcpyDeviceToHost, ch.stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ch.stream));
+    if (n_act == 0) break;
     da.parity = round & 1;
-    launch_solve(ctx, da, ch.stream, round == 0 ? solve_blocks : (solve_blocks > 256 ? 256 : solve_blocks));
-    hipLaunchKernelGGL(accept_kernel, dim3(accept_blocks), dim3(256), 0, ch.stream, da);
+    launch_solve(ctx, da, ch.stream, 256);
+    hipLaunchKernelGGL(accept_kernel, dim3(n_act < 512u ? n_act : 512u), dim3(256), 0, ch.stream, da);
     HIP_TRY(ctx, hipGetLastError());
   }
+  HIP_TRY(ctx, hipStreamSynchronize(ch.stream));
+  if (rounds_out) *rounds_out = round;
+  return LENTIL_OK;
+}
+
+// Size one chunk's draw-pipeline buffers from its scan result and enqueue prep + `blind_rounds`
+// solve/accept rounds on the chunk's stream (no host round trip between the rounds: every kernel
+// reads its queue lengths from device memory; a round with empty queues costs a few microseconds).
+// A chunk whose result pool would exceed max_pool_units is processed in sub-batches of items, each
+// run to completion before the next reuses the buffers.
+static int enqueue_chunk_draws(lentil_hip_ctx *ctx, int ci, DrawArgs &da, int blind_rounds) {
+  lentil_hip_ctx::Chunk &ch = ctx->chunks[ci];
+  const lentil_params &P = ctx->P;
+  DevCounters *dctr = ctx->d_ctr + ci;
+  // wait for this chunk's scan only (later chunks keep scanning meanwhile), fetch its item count / draw sum
+  HIP_TRY(ctx, hipEventSynchronize(ch.scanned));
+  DevCounters c;
+  HIP_TRY(ctx, hipMemcpyAsync(&c, dctr, sizeof(c), hipMemcpyDeviceToHost, ch.stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ch.stream));
+  const uint64_t cap = ch.v_end - ch.v_begin;
+  const uint64_t n_items = c.work_count < cap ? c.work_count : cap;
+  ch.n_items = n_items;
+  if (n_items == 0) return LENTIL_OK;
+  const bool po = P.cameraType == LENTIL_POLYNOMIAL_OPTICS;
+  const uint32_t retries = po ? (uint32_t)(P.vignetting_retries < 0 ? 0 : P.vignetting_retries) : 0u;
+  da.ctr = dctr;
+  da.retries = (int32_t)retries;
+  // round 0 needs sum(samples + retries) results; a later round at most the attempts an item has left
+  const uint64_t units = 4 * c.sum_samples + (uint64_t)(2 * retries + 32) * n_items;
+  const uint64_t max_blocks = (uint64_t)ctx->num_cu * 4;
+  int rc;
+  if (units <= ctx->max_pool_units) {
+    if ((rc = size_chunk_buffers(ctx, ch, n_items, units))) return rc;
+    bind_chunk_buffers(ch, da);
+    da.work = ctx->d_work + ch.v_begin;
+    da.n_items = n_items;
+    da.parity = 0;
+    hipLaunchKernelGGL(prep_items_kernel, dim3((unsigned)((n_items + 255) / 256)), dim3(256), 0, ch.stream, da);
+    HIP_TRY(ctx, hipGetLastError());
+    // enough persistent waves for the chunk's first batch, at most 4 blocks per CU
+    const uint64_t want = (c.sum_samples / 64 + n_items + 3) / 4;
+    const unsigned solve_blocks = (unsigned)(want < 1 ? 1 : (want > max_blocks ? max_blocks : want));
+    const unsigned accept_blocks = (unsigned)(n_items > (uint64_t)ctx->num_cu * 2 ? (uint64_t)ctx->num_cu * 2 : n_items);
+    for (int round = 0; round < blind_rounds; ++round) {
+      da.parity = round & 1;
+      launch_solve(ctx, da, ch.stream, round == 0 ? solve_blocks : (solve_blocks > 256 ? 256 : solve_blocks));
+      hipLaunchKernelGGL(accept_kernel, dim3(accept_blocks), dim3(256), 0, ch.stream, da);
+      HIP_TRY(ctx, hipGetLastError());
+    }
+    return LENTIL_OK;
+  }
+  // ---- too many draws for one result pool: sub-batches of items, bounded by the per-item worst case
+  const uint64_t max_samples = P.samples_override > 0 ? (uint64_t)P.samples_override : 2000ull;
+  const uint64_t per_item = 4 * max_samples + 2 * retries + 32;
+  uint64_t batch_items = ctx->max_pool_units / per_item;
+  if (batch_items < 1) return fail(ctx, LENTIL_ERR_NOMEM, "LENTIL_MAX_POOL_UNITS is too small for a single item");
+  for (uint64_t i0 = 0; i0 < n_items; i0 += batch_items) {
+    const uint64_t ni = n_items - i0 < batch_items ? n_items - i0 : batch_items;
+    if ((rc = size_chunk_buffers(ctx, ch, ni, ni * per_item))) return rc;
+    bind_chunk_buffers(ch, da);
+    // fresh queues for this batch
+    HIP_TRY(ctx, hipMemsetAsync((char *)dctr + offsetof(DevCounters, n_tasks), 0,
+                                sizeof(DevCounters) - offsetof(DevCounters, n_tasks), ch.stream));
+    da.work = ctx->d_work + ch.v_begin + i0;
+    da.n_items = ni;
+    da.parity = 0;
+    hipLaunchKernelGGL(prep_items_kernel, dim3((unsigned)((ni + 255) / 256)), dim3(256), 0, ch.stream, da);
+    launch_solve(ctx, da, ch.stream, (unsigned)max_blocks);
+    hipLaunchKernelGGL(accept_kernel, dim3((unsigned)ctx->num_cu * 2), dim3(256), 0, ch.stream, da);
+    HIP_TRY(ctx, hipGetLastError());
+    int rounds = 0;
+    if ((rc = finish_rounds(ctx, ci, da, 1, &rounds))) return rc;
+    if (rounds > ctx->last_rounds) ctx->last_rounds = rounds;
+  }
+  ch.n_items = 0;       // complete: nothing left for the continuation loop
   return LENTIL_OK;
 }
 
@@ -669,25 +730,15 @@ LENTIL_API int lentil_hip_redistribute(lentil_hip_ctx *ctx) {
       if (rc) return rc;
     }
     // ---- any chunk with items still missing draws after the blind rounds continues round by round
-    int max_rounds = blind_rounds;
+    int max_rounds = ctx->last_rounds > blind_rounds ? ctx->last_rounds : blind_rounds;
     for (int ci = 0; ci < C; ++ci) {
       lentil_hip_ctx::Chunk &ch = ctx->chunks[ci];
       HIP_TRY(ctx, hipStreamSynchronize(ch.stream));
       if (ch.n_items == 0) continue;
-      for (int round = blind_rounds; round < 64; ++round) {
-        unsigned int n_act = 0;
-        HIP_TRY(ctx, hipMemcpyAsync(&n_act, (char *)(ctx->d_ctr + ci) + offsetof(DevCounters, n_active) +
-                                                sizeof(unsigned int) * (round & 1),
-                                    sizeof(unsigned int), hipMemcpyDeviceToHost, ch.stream));
-        HIP_TRY(ctx, hipStreamSynchronize(ch.stream));
-        if (n_act == 0) break;
-        das[ci].parity = round & 1;
-        launch_solve(ctx, das[ci], ch.stream, 256);
-        hipLaunchKernelGGL(accept_kernel, dim3(64), dim3(256), 0, ch.stream, das[ci]);
-        HIP_TRY(ctx, hipGetLastError());
-        if (round + 1 > max_rounds) max_rounds = round + 1;
-      }
-      HIP_TRY(ctx, hipStreamSynchronize(ch.stream));
+      int rounds = blind_rounds;
+      const int rc = finish_rounds(ctx, ci, das[ci], blind_rounds, &rounds);
+      if (rc) return rc;
+      if (rounds > max_rounds) max_rounds = rounds;
     }
     ctx->last_rounds = max_rounds;
   }

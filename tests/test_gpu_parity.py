@@ -298,6 +298,27 @@ def test_thinlens_redistribute_parity(orc, gpu_ctx_factory, override):
     check_frame(ctx, ref)
 
 
+def test_sub_batches_when_the_result_pool_is_small(orc, monkeypatch):
+    """A chunk whose draws do not fit the result pool is processed in sub-batches of items (and single
+    chunk / many chunks give the same answer)."""
+    W, H, M = 96, 64, 9
+    p, model, table, keep = common.po_setup(W, H, samples_override=64)
+    visits, cols = common.make_stream(p, W, H, M, f_hi=0.02)
+    ref = common.run_oracle(orc, p, table, visits)
+    for chunks, pool in (("1", "40000"), ("5", "20000")):
+        monkeypatch.setenv("LENTIL_CHUNKS", chunks)
+        monkeypatch.setenv("LENTIL_MAX_POOL_UNITS", pool)
+        ctx = capi.Context(0)
+        try:
+            c = gpu_run(ctx, p, table, visits)
+            rc = ref.counters()
+            assert (c.attempted_draws, c.accepted_draws) == (rc.attempted_draws, rc.accepted_draws)
+            check_logs(ctx, ref)
+            check_frame(ctx, ref)
+        finally:
+            ctx.close()
+
+
 def test_empty_stream_and_error_paths(gpu_ctx_factory):
     p, model, table, keep = common.po_setup(32, 16)
     ctx = gpu_ctx_factory()
