@@ -239,17 +239,20 @@ def main():
             out["cpu_baseline"] = {"value": None, "unit": "Msamples/s", "cores": 0, "kind": "port",
                                    "sample": "failed: %r" % (e,)}
     ctx.close()
-    if dist.is_initialized():
+    used_rccl = dist.is_initialized()
+    if used_rccl:
         dist.destroy_process_group()
     if rank == 0:
         # the single JSON line is the last thing on stdout (RCCL prints a banner of its own)
         sys.stdout.flush()
         print(json.dumps(out), flush=True)
     # RCCL prints a three-line banner to stdout from a library destructor; leave without running those so
-    # that the JSON line stays the last line of output on every rank
+    # that the JSON line stays the last line of output on every rank.  Single-process runs exit normally
+    # (rocprofv3 writes its output files from an exit handler).
     sys.stdout.flush()
     sys.stderr.flush()
-    os._exit(0)
+    if used_rccl:
+        os._exit(0)
 
 
 if __name__ == "__main__":

@@ -63,15 +63,9 @@ struct lentil_hip_ctx {
     uint64_t task_cap = 0;
     uint32_t *pool[2] = {nullptr, nullptr};
     uint64_t pool_cap = 0;
-    uint32_t *ready = nullptr;       // persistent pipeline: ready-item queue
-    uint64_t ready_cap = 0;
-    int items_open_init = 0;         // staging for the H2D copy of DevCounters::items_open
-    bool persistent_launched = false;
   };
   std::vector<Chunk> chunks;
   int n_chunks = 2;
-  bool share_solve_grid = false;
-  bool persistent = true;            // LENTIL_PERSISTENT=0 selects the round-based draw pipeline
   uint64_t max_pool_units = 1ull << 32;    // 16 GiB per pool at most (LENTIL_MAX_POOL_UNITS overrides)
   int last_rounds = 0;
   DevCounters *d_ctr = nullptr;
@@ -124,8 +118,6 @@ LENTIL_API int lentil_hip_create(int device, lentil_hip_ctx **out_ctx) {
   HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
   for (auto &ev : ctx->ev) HIP_TRY(ctx, hipEventCreate(&ev));
   if (const char *nc = getenv("LENTIL_CHUNKS")) { ctx->n_chunks = atoi(nc); }
-  if (const char *sh = getenv("LENTIL_SOLVE_SHARE")) ctx->share_solve_grid = sh[0] == '1';
-  if (const char *pe = getenv("LENTIL_PERSISTENT")) ctx->persistent = pe[0] != '0';
   if (ctx->n_chunks < 1) ctx->n_chunks = 1;
   if (ctx->n_chunks > 16) ctx->n_chunks = 16;
   // one DevCounters per chunk + one shared (draw-log cursor)
@@ -175,7 +167,6 @@ LENTIL_API int lentil_hip_destroy(lentil_hip_ctx *ctx) {
     if (ch.stream) (void)hipStreamSynchronize(ch.stream);
     (void)hipFree(ch.hdr); (void)hipFree(ch.prog);
     for (int i = 0; i < 2; ++i) { (void)hipFree(ch.active[i]); (void)hipFree(ch.tasks[i]); (void)hipFree(ch.pool[i]); }
-    (void)hipFree(ch.ready);
     if (ch.scanned) (void)hipEventDestroy(ch.scanned);
     if (ch.done) (void)hipEventDestroy(ch.done);
     if (ch.stream) (void)hipStreamDestroy(ch.stream);
@@ -510,18 +501,6 @@ static void launch_solve(lentil_hip_ctx *ctx, const DrawArgs &da, hipStream_t st
   }
 }
 
-static void launch_persistent(lentil_hip_ctx *ctx, const DrawArgs &da, hipStream_t st, unsigned blocks) {
-  bool launched = false;
-#define LENTIL_LAUNCH_GEN(NAME)                                                                          \
-  if (!launched && ctx->use_generated && ctx->lens_hash == gen::Lens_##NAME::kTableHash) {                \
-    hipLaunchKernelGGL((draw_persistent_kernel<GenLens<gen::Lens_##NAME>, false>), dim3(blocks), dim3(256), 0, st, da); \
-    launched = true;                                                                                     \
-  }
-  LENTIL_GENERATED_LENSES(LENTIL_LAUNCH_GEN)
-#undef LENTIL_LAUNCH_GEN
-  if (!launched) hipLaunchKernelGGL((draw_persistent_kernel<LdsLens, true>), dim3(blocks), dim3(256), 0, st, da);
-}
-
 // Size one chunk's draw-pipeline buffers from its scan result and enqueue prep + `blind_rounds`
 // solve/accept rounds on the chunk's stream (no host round trip between the rounds: every kernel
 // reads its queue lengths from device memory; a round with empty queues costs a few microseconds).
@@ -608,43 +587,6 @@ static int enqueue_chunk_draws(lentil_hip_ctx *ctx, int ci, DrawArgs &da, int bl
   const uint64_t units = 4 * c.sum_samples + (uint64_t)(2 * retries + 32) * n_items;
   const uint64_t max_blocks = (uint64_t)ctx->num_cu * 4;
   int rc;
-  ch.persistent_launched = false;
-  // worst case over a whole pass (the persistent pipeline never recycles result space within a pass)
-  const uint64_t units_total = 5 * c.sum_samples + (uint64_t)(8 * retries + 64) * n_items;
-  if (po && ctx->persistent && units_total <= ctx->max_pool_units) {
-    if ((rc = size_chunk_buffers(ctx, ch, n_items, units_total))) return rc;
-    const uint64_t rcap = 16 * n_items + 1024;
-    if (rcap > ch.ready_cap) {
-      if ((rc = grow(ctx, &ch.ready, rcap + rcap / 4))) return rc;
-      ch.ready_cap = rcap + rcap / 4;
-    }
-    bind_chunk_buffers(ch, da);
-    da.ready = ch.ready;
-    da.ready_cap = (uint32_t)(ch.ready_cap > 0xFFFFFFF0ull ? 0xFFFFFFF0ull : ch.ready_cap);
-    da.work = ctx->d_work + ch.v_begin;
-    da.n_items = n_items;
-    da.parity = 0;
-    // valid flags of the task slots and the ready queue start at zero; the pipeline opens with n_items items
-    HIP_TRY(ctx, hipMemsetAsync(ch.tasks[0], 0, ch.task_cap * sizeof(Task), ch.stream));
-    HIP_TRY(ctx, hipMemsetAsync(ch.ready, 0, ch.ready_cap * sizeof(uint32_t), ch.stream));
-    ch.items_open_init = (int)n_items;
-    HIP_TRY(ctx, hipMemcpyAsync(&dctr->items_open, &ch.items_open_init, sizeof(int), hipMemcpyHostToDevice, ch.stream));
-    hipLaunchKernelGGL(prep_items_persistent_kernel, dim3((unsigned)((n_items + 255) / 256)), dim3(256), 0, ch.stream, da);
-    HIP_TRY(ctx, hipGetLastError());
-    uint64_t accept_blocks = n_items / 8 + 8;
-    uint64_t amax = 96, smax = (uint64_t)ctx->num_cu * 2;
-    if (const char *e = getenv("LENTIL_PERSIST_ACCEPT_BLOCKS")) amax = strtoull(e, nullptr, 10);
-    if (const char *e = getenv("LENTIL_PERSIST_SOLVE_BLOCKS")) smax = strtoull(e, nullptr, 10);
-    if (accept_blocks > amax) accept_blocks = amax;
-    const uint64_t want = (c.sum_samples / 64 + n_items + 3) / 4;
-    uint64_t solve_blocks = want < 1 ? 1 : want;
-    if (solve_blocks > smax) solve_blocks = smax;
-    da.n_accept_blocks = (uint32_t)accept_blocks;
-    launch_persistent(ctx, da, ch.stream, (unsigned)(accept_blocks + solve_blocks));
-    HIP_TRY(ctx, hipGetLastError());
-    ch.persistent_launched = true;
-    return LENTIL_OK;
-  }
   if (units <= ctx->max_pool_units) {
     if ((rc = size_chunk_buffers(ctx, ch, n_items, units))) return rc;
     bind_chunk_buffers(ch, da);
@@ -656,11 +598,6 @@ static int enqueue_chunk_draws(lentil_hip_ctx *ctx, int ci, DrawArgs &da, int bl
     // enough persistent waves for the chunk's first batch, at most 4 blocks per CU
     const uint64_t want = (c.sum_samples / 64 + n_items + 3) / 4;
     unsigned solve_blocks = (unsigned)(want < 1 ? 1 : (want > max_blocks ? max_blocks : want));
-    if (ctx->share_solve_grid && ctx->n_chunks > 1) {
-      // leave room for the other chunks' pipelines (and the scan): all chunks together fill 3 blocks per CU
-      const unsigned share = (unsigned)((ctx->num_cu * 3 + ctx->n_chunks - 1) / ctx->n_chunks);
-      if (solve_blocks > share) solve_blocks = share;
-    }
     const unsigned accept_blocks = (unsigned)(n_items > (uint64_t)ctx->num_cu * 2 ? (uint64_t)ctx->num_cu * 2 : n_items);
     for (int round = 0; round < blind_rounds; ++round) {
       da.parity = round & 1;
@@ -726,7 +663,8 @@ LENTIL_API int lentil_hip_redistribute(lentil_hip_ctx *ctx) {
     if (M) {
       // staging: 20 B per visit per wave, 4 waves per block, keep a block under ~48 KiB
       uint32_t ppt = 64;
-      uint64_t lds_budget = 48ull * 1024ull;
+      // extra AOV columns are streamed one at a time: more, smaller tiles keep enough loads in flight
+      uint64_t lds_budget = (ctx->V.n_extra ? 24ull : 48ull) * 1024ull;
       if (const char *e = getenv("LENTIL_SCAN_LDS_KB")) lds_budget = strtoull(e, nullptr, 10) * 1024ull;
       while (ppt > 1 && (uint64_t)ppt * M * 20ull * 4ull > lds_budget) ppt >>= 1;
       if ((uint64_t)ppt * M * 20ull * 4ull > 150ull * 1024ull)
@@ -798,13 +736,6 @@ LENTIL_API int lentil_hip_redistribute(lentil_hip_ctx *ctx) {
       lentil_hip_ctx::Chunk &ch = ctx->chunks[ci];
       HIP_TRY(ctx, hipStreamSynchronize(ch.stream));
       if (ch.n_items == 0) continue;
-      if (ch.persistent_launched) {
-        DevCounters cc;
-        HIP_TRY(ctx, hipMemcpy(&cc, ctx->d_ctr + ci, sizeof(cc), hipMemcpyDeviceToHost));
-        if (cc.stuck || cc.items_open != 0)
-          return fail(ctx, LENTIL_ERR_HIP, "persistent draw pipeline did not drain (bounded spin expired)");
-        continue;
-      }
       int rounds = blind_rounds;
       const int rc = finish_rounds(ctx, ci, das[ci], blind_rounds, &rounds);
       if (rc) return rc;

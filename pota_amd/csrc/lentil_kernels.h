@@ -35,12 +35,6 @@ struct DevCounters {
   unsigned int n_active[2];
   unsigned int active_head[2];
   unsigned long long pool_used[2];
-  // persistent pipeline (draw_persistent_kernel): dynamic task / ready queues
-  unsigned int tq_tail, tq_head;     // solve tasks: reserved slots / next ticket
-  unsigned int rq_tail, rq_head;     // items whose batch is complete, waiting for the accept role
-  int items_open;                    // items that are not final yet
-  unsigned int role_counter;         // blocks take their role in arrival order
-  unsigned int stuck;                // a bounded spin expired (host reports an error)
   unsigned int pad_q;
 };
 
@@ -258,17 +252,26 @@ __global__ __launch_bounds__(256) void scan_uniform_kernel(ScanArgs a) {
       if (a.F.closest_mask & (2u << k)) continue;       // closest AOVs are gathered from the winners later
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
-      for (uint32_t eb = 0; eb < TV; eb += 64) {
-        const uint32_t e = eb + lane;
-        const uint64_t v = v0 + e;
-        if (e < TV) {
-          const float w = sw[e];
-          float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (v < V.n && w != 0.0f) {
-            const float4 c = V.extra[k][v];
-            x = make_float4((c.x + 0.0f) * w, (c.y + 0.0f) * w, (c.z + 0.0f) * w, (c.w + 0.0f) * w);
-          }
-          sval[e] = x;
+      // four independent 16 B loads in flight per lane (one column has no other source of memory parallelism)
+      const float4 *col = V.extra[k];
+      for (uint32_t eb = 0; eb < TV; eb += 256) {
+        float4 c[4];
+        float w[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const uint32_t e = eb + 64u * u + lane;
+          const uint64_t v = v0 + e;
+          w[u] = (e < TV) ? sw[e] : 0.0f;
+          c[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (e < TV && v < V.n && w[u] != 0.0f) c[u] = col[v];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const uint32_t e = eb + 64u * u + lane;
+          if (e < TV)
+            sval[e] = (w[u] != 0.0f) ? make_float4((c[u].x + 0.0f) * w[u], (c[u].y + 0.0f) * w[u],
+                                                   (c[u].z + 0.0f) * w[u], (c[u].w + 0.0f) * w[u])
+                                     : make_float4(0.f, 0.f, 0.f, 0.f);
         }
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -380,8 +383,7 @@ struct ItemProg {         // 32 B, progress of an item across rounds
   uint32_t m_lo, m_hi;    // R(m) of the current round covers [m_lo, m_hi); any R(m < m_lo) still needed is FAIL
   uint32_t res_off;       // offset of R(m_lo) in the current round's result pool
   uint32_t last_ok;       // highest accepted attempt index
-  uint32_t tasks_left;    // persistent pipeline: solve tasks of the current batch not finished yet
-  uint32_t pad1;
+  uint32_t pad0, pad1;
 };
 
 struct Task {             // up to 64 consecutive m of one item
@@ -405,9 +407,6 @@ struct DrawArgs {
   uint32_t *active[2];
   uint32_t *pool[2];
   uint64_t pool_cap;
-  uint32_t *ready;         // persistent pipeline: ready-item queue (zeroed per pass), ready_cap entries
-  uint32_t ready_cap;
-  uint32_t n_accept_blocks;
   lentil_draw_record *log;
   uint64_t log_cap;
   unsigned long long *log_count;   // shared by all chunks
@@ -831,320 +830,6 @@ __global__ __launch_bounds__(256) void accept_kernel(DrawArgs a) {
   if (threadIdx.x == 0) {
     if (tot_attempted) atomicAdd(&a.ctr->attempted, tot_attempted);
     if (tot_accepted) atomicAdd(&a.ctr->accepted, tot_accepted);
-  }
-}
-
-// ---------------------------------------------------------------------------------------
-// Persistent draw pipeline (polynomial optics): ONE launch per chunk, no round barriers.
-//
-// The round-based pipeline above waits for the slowest solve of a whole round before any item of the
-// round is accepted, and each extra round costs at least one full solve latency (a non-converging
-// Newton solve runs 100 iterations ~ 0.7 ms).  Here the dependencies are per item:
-//   solve role  (most blocks): waves pull 64-solve tasks from a device-side queue (ticket = atomicAdd on
-//               the head; a slot becomes valid when its `count` word is published), run the lane
-//               scheduler as before; when the last solve of a task has written its result the wave
-//               releases (agent scope) and decrements the item's tasks_left -- the wave that brings it to
-//               zero pushes the item into the ready queue.
-//   accept role (a few blocks): blocks pull ready items, acquire, run accept_item, and either retire the
-//               item (items_open--) or reserve result space, publish the item's next tasks and go on.
-// Everything ends when items_open reaches zero.  Inter-workgroup hand-offs follow the agent-scope
-// release/acquire protocol (cdna_hip_programming.md, Guideline 16); every spin is bounded.
-// ---------------------------------------------------------------------------------------
-constexpr uint32_t kSpinLimit = 1u << 24;     // x ~0.5 us sleep: several seconds, then give up loudly
-
-LD_DEV uint32_t ld_agent(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-LD_DEV int ld_agent(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-LD_DEV void st_agent(uint32_t *p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-
-// publish the solve tasks for m in [m_lo, m_hi) of `item` (single thread).  The item's tasks_left must
-// already be stored; fields first, release, then the `count` words that make the slots valid.
-LD_DEV bool publish_tasks(const DrawArgs &a, uint32_t item, uint32_t m_lo, uint32_t m_hi, uint32_t res_off) {
-  const uint32_t count = m_hi - m_lo;
-  const uint32_t nt = (count + 63u) / 64u;
-  const uint32_t tb = atomicAdd(&a.ctr->tq_tail, nt);
-  if ((unsigned long long)tb + nt > a.task_cap) { atomicAdd(&a.ctr->overflow, 1ull); return false; }
-  Task *tq = a.tasks[0];
-  for (uint32_t t = 0; t < nt; ++t) {
-    tq[tb + t].item = item;
-    tq[tb + t].m_base = m_lo + t * 64u;
-    tq[tb + t].res_off = res_off + t * 64u;
-  }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  for (uint32_t t = 0; t < nt; ++t) {
-    const uint32_t c = (count - t * 64u) < 64u ? (count - t * 64u) : 64u;
-    st_agent(&tq[tb + t].count, c);
-  }
-  return true;
-}
-
-// one thread per item: header, first batch, tasks_left; thread 0 also opens the pipeline
-__global__ __launch_bounds__(256) void prep_items_persistent_kernel(DrawArgs a) {
-  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= a.n_items) return;
-  const uint32_t item = (uint32_t)i;
-  const ItemVisit h = load_item_visit(a, item, a.lens ? a.lens->length : 0.0);
-  ItemHdr hd;
-  hd.tx = -(double)h.I.cs[0] * 10.0; hd.ty = -(double)h.I.cs[1] * 10.0; hd.tz = -(double)h.I.cs[2] * 10.0;
-  hd.seed_a = (uint32_t)(h.px * h.py + h.px);
-  hd.px_py = (h.px & 0xFFFF) | (h.py << 16);
-  a.hdr[item] = hd;
-  const uint32_t samples = h.samples, max_total = samples * 5u;
-  const uint32_t m_limit = max_total + (uint32_t)a.retries;
-  uint32_t m_hi = samples + (uint32_t)a.retries;
-  if (m_hi > m_limit) m_hi = m_limit;
-  ItemProg pg{};
-  pg.m_lo = 0;
-  pg.m_hi = m_hi;
-  const unsigned long long off = atomicAdd(&a.ctr->pool_used[0], (unsigned long long)m_hi);
-  bool ok = off + m_hi <= a.pool_cap;
-  pg.res_off = (uint32_t)off;
-  pg.tasks_left = (m_hi + 63u) / 64u;
-  a.prog[item] = pg;
-  if (ok) ok = publish_tasks(a, item, 0u, m_hi, (uint32_t)off);
-  if (!ok) { atomicAdd(&a.ctr->overflow, 1ull); atomicSub(&a.ctr->items_open, 1); }
-}
-
-template <class LensT, bool kTables>
-__global__ __launch_bounds__(256) void draw_persistent_kernel(DrawArgs a) {
-  __shared__ DevTerm s_terms[kTables ? kMaxTerms : 1];
-  __shared__ DevLens s_k;
-  __shared__ float s_cdfRow[kMaxBokehRows];
-  __shared__ AcceptShared s_acc;
-  __shared__ uint32_t s_role, s_item;
-  if (threadIdx.x == 0) s_role = atomicAdd(&a.ctr->role_counter, 1u);
-  if (kTables) {
-    const uint32_t nt = a.lens->n_terms;
-    for (uint32_t i = threadIdx.x; i < nt; i += blockDim.x) s_terms[i] = a.terms[i];
-  }
-  if (threadIdx.x == 0) s_k = *a.lens;
-  const bool row_in_lds = a.P.bokeh_enable_image && a.bokeh.y <= kMaxBokehRows;
-  if (row_in_lds)
-    for (int i = threadIdx.x; i < a.bokeh.y; i += blockDim.x) s_cdfRow[i] = a.bokeh.cdfRow[i];
-  __syncthreads();
-  DevCounters *q = a.ctr;
-  uint32_t *res = a.pool[0];
-
-  if (s_role < a.n_accept_blocks) {
-    // ================= accept role =================
-    unsigned long long tot_attempted = 0, tot_accepted = 0;
-    while (true) {
-      __syncthreads();
-      if (threadIdx.x == 0) {
-        uint32_t got = 0xFFFFFFFFu;
-        const uint32_t ticket = atomicAdd(&q->rq_head, 1u);
-        if (ticket < a.ready_cap) {
-          for (uint32_t spin = 0;; ++spin) {
-            const uint32_t v = ld_agent(&a.ready[ticket]);
-            if (v) { got = v - 1u; break; }
-            if (ld_agent(&q->items_open) <= 0) break;
-            if (spin > kSpinLimit) { st_agent(&q->stuck, 1u); break; }
-            __builtin_amdgcn_s_sleep(32);
-          }
-        } else {
-          atomicAdd(&q->overflow, 1ull);
-        }
-        if (got != 0xFFFFFFFFu) {
-          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        s_item = got;
-      }
-      __syncthreads();
-      const uint32_t item = s_item;
-      if (item == 0xFFFFFFFFu) break;
-      const ItemProg pg = a.prog[item];
-      const AcceptResult r = accept_item(a, s_acc, item, pg, res);
-      if (threadIdx.x == 0) {
-        bool retire = !r.more;
-        if (r.more) {
-          const uint32_t cnt = r.new_hi - r.new_lo;
-          const unsigned long long off = atomicAdd(&q->pool_used[0], (unsigned long long)cnt);
-          if (off + cnt > a.pool_cap) {
-            atomicAdd(&q->overflow, 1ull);
-            retire = true;
-          } else {
-            ItemProg np_ = r.prog;
-            np_.m_lo = r.new_lo; np_.m_hi = r.new_hi;
-            np_.res_off = (uint32_t)off;
-            np_.tasks_left = (cnt + 63u) / 64u;
-            a.prog[item] = np_;
-            if (!publish_tasks(a, item, r.new_lo, r.new_hi, (uint32_t)off)) retire = true;
-          }
-        }
-        if (retire) {
-          // total_samples_taken when the reference's loop ends, src/lentil_filter.cpp:248
-          tot_attempted += (r.prog.accepted >= r.samples) ? (unsigned long long)r.prog.last_ok + 1ull
-                                                           : (unsigned long long)r.samples * 5ull;
-          tot_accepted += r.prog.accepted;
-          atomicSub(&q->items_open, 1);
-        }
-      }
-    }
-    if (threadIdx.x == 0) {
-      if (tot_attempted) atomicAdd(&q->attempted, tot_attempted);
-      if (tot_accepted) atomicAdd(&q->accepted, tot_accepted);
-    }
-    return;
-  }
-
-  // ================= solve role =================
-  const float *cdfRow = row_in_lds ? s_cdfRow : a.bokeh.cdfRow;
-  LensT L;
-  if constexpr (kTables) { L.terms = s_terms; L.k = &s_k; } else { L.k = &s_k; }
-  const DevLens &k = s_k;
-  const lentil_params &P = a.P;
-  const Task *tq = a.tasks[0];
-  const uint32_t lane = lane_id();
-  const unsigned long long lt_mask = (1ull << lane) - 1ull;
-
-  // wave-uniform: cursor into the task being handed out, the ticket being waited for, and up to four
-  // tasks in flight (item, solves not finished yet)
-  uint32_t cur_item = 0, cur_m = 0, cur_res = 0, cur_left = 0, cur_slot = 0;
-  uint32_t ticket = 0xFFFFFFFFu;
-  uint32_t fl_item[4] = {0, 0, 0, 0}, fl_left[4] = {0, 0, 0, 0};
-  uint32_t idle_spins = 0;
-  // per-lane solve
-  bool busy = false, need_init = false;
-  uint32_t m = 0, res_idx = 0, seed_a = 0, my_slot = 0;
-  double target[3] = {0, 0, 1};
-  double ap_x = 0.0, ap_y = 0.0;
-  NewtonState s;
-  newton_init(s);
-  uint32_t st_iters = 0, st_tries = 0, st_rounds = 0;
-
-  while (true) {
-    const unsigned long long busy_mask = __ballot(busy);
-    const uint32_t inflight = (uint32_t)__builtin_popcountll(busy_mask);
-    const uint32_t n_idle = 64u - inflight;
-    const uint32_t my_rank = (uint32_t)__builtin_popcountll(~busy_mask & lt_mask);
-    uint32_t filled = 0;
-    while (filled < n_idle) {
-      if (cur_left == 0) {
-        // a free in-flight slot is needed to take another task
-        uint32_t fs = 4;
-        for (uint32_t i = 0; i < 4; ++i) if (fl_left[i] == 0) { fs = i; break; }
-        if (fs == 4) break;
-        if (ticket == 0xFFFFFFFFu) {
-          uint32_t t = 0;
-          if (lane == 0) t = atomicAdd(&q->tq_head, 1u);
-          ticket = __builtin_amdgcn_readfirstlane(t);
-        }
-        if (ticket >= a.task_cap) break;
-        uint32_t cnt = 0;
-        if (lane == 0) cnt = ld_agent(&tq[ticket].count);
-        cnt = __builtin_amdgcn_readfirstlane(cnt);
-        if (cnt == 0) break;                                   // not published (yet)
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        uint32_t ti = 0, tm = 0, tr = 0;
-        if (lane == 0) { ti = ld_agent(&tq[ticket].item); tm = ld_agent(&tq[ticket].m_base); tr = ld_agent(&tq[ticket].res_off); }
-        cur_item = __builtin_amdgcn_readfirstlane(ti);
-        cur_m = __builtin_amdgcn_readfirstlane(tm);
-        cur_res = __builtin_amdgcn_readfirstlane(tr);
-        cur_left = cnt;
-        cur_slot = fs;
-        fl_item[fs] = cur_item;
-        fl_left[fs] = cnt;
-        ticket = 0xFFFFFFFFu;
-        idle_spins = 0;
-      }
-      uint32_t take = n_idle - filled;
-      if (take > cur_left) take = cur_left;
-      if (!busy && my_rank >= filled && my_rank < filled + take) {
-        const uint32_t j = my_rank - filled;
-        m = cur_m + j;
-        res_idx = cur_res + j;
-        my_slot = cur_slot;
-        const ItemHdr hd = a.hdr[cur_item];
-        target[0] = hd.tx; target[1] = hd.ty; target[2] = hd.tz;
-        seed_a = hd.seed_a;
-        busy = true;
-        need_init = true;
-      }
-      cur_m += take; cur_res += take; cur_left -= take; filled += take;
-    }
-    if (inflight + filled == 0u) {
-      // nothing to do right now: done, or waiting for tasks that an accept block has yet to publish
-      int open = 0;
-      if (lane == 0) open = ld_agent(&q->items_open);
-      open = __builtin_amdgcn_readfirstlane(open);
-      if (open <= 0) break;
-      if (++idle_spins > kSpinLimit) { if (lane == 0) st_agent(&q->stuck, 1u); break; }
-      __builtin_amdgcn_s_sleep(32);
-      continue;
-    }
-
-    // aperture draw of the reference's try with seed (seed_a, m), src/lentil.h:596-609
-    if (busy && need_init) {
-      po_aperture_sample(P, a.bokeh, cdfRow, seed_a, m, ap_x, ap_y);
-      newton_init(s);
-      need_init = false;
-      ++st_tries;
-    }
-    if (busy) { newton_iter(L, target, ap_x, ap_y, s); ++st_iters; }
-    ++st_rounds;
-
-    bool finished = false;
-    if (busy && !newton_continue(s)) {
-      double out4;
-      const float transmittance = (float)newton_finish(L, s, out4);
-      uint32_t code = kCodeFail;
-      bool try_ok = !(transmittance <= 0);                                   // src/lentil.h:633-637
-      if (try_ok) {
-        const double ipx = s.x + s.dx * k.back_focal_length;                // :640-645
-        const double ipy = s.y + s.dy * k.back_focal_length;
-        if (ipx * ipx + ipy * ipy > k.inner_pupil_radius * k.inner_pupil_radius) try_ok = false;
-      }
-      if (try_ok) {
-        const double sx = s.x + s.dx * -P.sensor_shift;                     // :654-655
-        const double sy = s.y + s.dy * -P.sensor_shift;
-        uint32_t pix;
-        code = po_sensor_to_pixel(P, sx, sy, pix) ? pix : kCodeOut;         // src/lentil_filter.cpp:276-290
-      }
-      res[res_idx] = code;
-      busy = false;
-      finished = true;
-    }
-    // ---- task accounting: when the last solve of a task is done, hand its results over
-    if (__ballot(finished)) {
-      bool any_done = false;
-      for (uint32_t sl = 0; sl < 4; ++sl) {
-        const uint32_t nfin = (uint32_t)__builtin_popcountll(__ballot(finished && my_slot == sl));
-        if (nfin) {
-          fl_left[sl] -= nfin;
-          if (fl_left[sl] == 0) any_done = true; else continue;
-          fl_left[sl] = 0xFFFFFFFFu;                           // marks "complete, hand-off pending" until the fence below
-        }
-      }
-      if (any_done) {
-        // release: every lane's result stores, then (one lane) the counters
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        for (uint32_t sl = 0; sl < 4; ++sl) {
-          if (fl_left[sl] != 0xFFFFFFFFu) continue;
-          fl_left[sl] = 0;
-          if (lane == 0) {
-            const uint32_t it = fl_item[sl];
-            if (atomicSub(&a.prog[it].tasks_left, 1u) == 1u) {
-              const uint32_t slot = atomicAdd(&q->rq_tail, 1u);
-              if (slot < a.ready_cap) st_agent(&a.ready[slot], it + 1u);
-              else atomicAdd(&q->overflow, 1ull);
-            }
-          }
-        }
-      }
-    }
-  }
-  unsigned long long it64 = st_iters, tr64 = st_tries, rd64 = st_rounds;
-  for (int off = 32; off > 0; off >>= 1) {
-    it64 += __shfl_down(it64, off);
-    tr64 += __shfl_down(tr64, off);
-    rd64 += __shfl_down(rd64, off);
-  }
-  if (lane == 0) {
-    if (it64) atomicAdd(&q->newton_iters, it64);
-    if (tr64) atomicAdd(&q->tries, tr64);
-    if (rd64) atomicAdd(&q->lane_rounds, rd64);
   }
 }
 
