@@ -194,7 +194,11 @@ def main():
     ms_per_step = dt / args.steps * 1e3
 
     workload_tag = "%s %dx%d M=%d samples=%d aovs=%d f_hi=%.3g" % (args.lens, W, Hr, M, args.samples, 1 + args.aovs, args.f_hi)
-    achieved = n_local * bytes_per_visit / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
+    # the scan runs as one launch per chunk of the visit stream; bytes and duration below are per launch
+    scan_launches = max(1, ctx.last_launches()[0])
+    launch_bytes = n_local * bytes_per_visit / scan_launches
+    launch_ms = scan_ms / scan_launches
+    achieved = launch_bytes / (launch_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
     out = {
         "metric": "bidir redistribution Msamples/s at 4K, double-gauss 50mm",
         "value": round(value, 3), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -213,6 +217,8 @@ def main():
         "roofline": {
             "kernel": "scan_uniform_kernel", "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": load_traffic(workload_tag),
+            "launches_per_step": scan_launches, "algorithmic_bytes_per_launch": round(launch_bytes),
+            "avg_launch_ms": round(launch_ms, 4),
             "whole_step_frac": round(n_local * bytes_per_visit / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
         },
         "draw_kernel": {"Mdraws_per_s_attempted": round(ctr.attempted_draws / (draw_ms * 1e-3) / 1e6, 3) if draw_ms > 0 else None},

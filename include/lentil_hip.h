@@ -293,6 +293,9 @@ int lentil_hip_stream(lentil_hip_ctx *ctx, void **hip_stream);
  * ms[0] scan+compaction+direct accumulate, ms[1] draw/splat kernel, ms[2] resolve. */
 int lentil_hip_get_counters(lentil_hip_ctx *ctx, lentil_counters *out);
 int lentil_hip_last_timing(lentil_hip_ctx *ctx, float ms[3]);
+/* kernel launches of the last redistribute: n[0] scan launches (one per chunk of the visit stream; ms[0]
+ * of last_timing covers all of them), n[1] solve/accept rounds of the chunk that needed most. */
+int lentil_hip_last_launches(lentil_hip_ctx *ctx, uint32_t n[2]);
 int lentil_hip_set_draw_log(lentil_hip_ctx *ctx, uint64_t capacity); /* 0 disables */
 int lentil_hip_download_draw_log(lentil_hip_ctx *ctx, lentil_draw_record *out, uint64_t capacity,
                                  uint64_t *n_records);

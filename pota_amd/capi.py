@@ -19,7 +19,7 @@ EXPORTS = [
     "lentil_hip_upload_visits", "lentil_hip_bind_visits", "lentil_hip_clear_frame",
     "lentil_hip_redistribute", "lentil_hip_resolve", "lentil_hip_sync", "lentil_hip_download_aov",
     "lentil_hip_download_accum", "lentil_hip_accum_buffer", "lentil_hip_stream",
-    "lentil_hip_get_counters", "lentil_hip_last_timing", "lentil_hip_set_draw_log",
+    "lentil_hip_get_counters", "lentil_hip_last_timing", "lentil_hip_last_launches", "lentil_hip_set_draw_log",
     "lentil_hip_download_draw_log", "lentil_hip_test_lt_sample_aperture",
     "lentil_hip_test_trace_bw_po", "lentil_hip_test_aperture_sample",
     "lentil_hip_lens_is_compiled", "lentil_hip_set_lens_mode",
@@ -74,6 +74,7 @@ def load_library():
         "lentil_hip_stream": (i, [vp, C.POINTER(vp)]),
         "lentil_hip_get_counters": (i, [vp, C.POINTER(_abi.Counters)]),
         "lentil_hip_last_timing": (i, [vp, C.POINTER(C.c_float)]),
+        "lentil_hip_last_launches": (i, [vp, C.POINTER(C.c_uint32)]),
         "lentil_hip_set_draw_log": (i, [vp, u64]),
         "lentil_hip_download_draw_log": (i, [vp, vp, u64, C.POINTER(u64)]),
         "lentil_hip_test_lt_sample_aperture": (i, [vp, u64, vp, vp, C.c_double, vp, vp, vp]),
@@ -236,6 +237,11 @@ class Context:
         ms = (C.c_float * 3)()
         self._chk(self.lib.lentil_hip_last_timing(self.h, ms))
         return float(ms[0]), float(ms[1]), float(ms[2])
+
+    def last_launches(self):
+        n = (C.c_uint32 * 2)()
+        self._chk(self.lib.lentil_hip_last_launches(self.h, n))
+        return int(n[0]), int(n[1])
 
     def set_draw_log(self, capacity):
         self._chk(self.lib.lentil_hip_set_draw_log(self.h, capacity))

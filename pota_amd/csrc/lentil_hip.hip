@@ -66,8 +66,11 @@ struct lentil_hip_ctx {
   };
   std::vector<Chunk> chunks;
   int n_chunks = 2;
+  double first_chunk_frac = 0.5;             // LENTIL_FIRST_CHUNK_FRAC
+  uint64_t early_cap_samples = 4ull << 20;   // LENTIL_EARLY_CAP_SAMPLES
   uint64_t max_pool_units = 1ull << 32;    // 16 GiB per pool at most (LENTIL_MAX_POOL_UNITS overrides)
   int last_rounds = 0;
+  uint32_t last_scan_launches = 0;
   DevCounters *d_ctr = nullptr;
   lentil_draw_record *d_log = nullptr;
   uint64_t log_cap = 0;
@@ -130,6 +133,11 @@ LENTIL_API int lentil_hip_create(int device, lentil_hip_ctx **out_ctx) {
     HIP_TRY(ctx, hipEventCreateWithFlags(&ch.done, hipEventDisableTiming));
   }
   if (const char *ft = getenv("LENTIL_FORCE_TABLES")) ctx->use_generated = !(ft[0] == '1');
+  if (const char *fc = getenv("LENTIL_FIRST_CHUNK_FRAC")) {
+    const double f = atof(fc);
+    if (f > 0.0 && f < 1.0) ctx->first_chunk_frac = f;
+  }
+  if (const char *ec = getenv("LENTIL_EARLY_CAP_SAMPLES")) ctx->early_cap_samples = strtoull(ec, nullptr, 10);
   if (const char *mp = getenv("LENTIL_MAX_POOL_UNITS")) ctx->max_pool_units = strtoull(mp, nullptr, 10);
   *out_ctx = ctx;
   return LENTIL_OK;
@@ -598,6 +606,12 @@ static int enqueue_chunk_draws(lentil_hip_ctx *ctx, int ci, DrawArgs &da, int bl
     // enough persistent waves for the chunk's first batch, at most 4 blocks per CU
     const uint64_t want = (c.sum_samples / 64 + n_items + 3) / 4;
     unsigned solve_blocks = (unsigned)(want < 1 ? 1 : (want > max_blocks ? max_blocks : want));
+    if (ci + 1 < ctx->n_chunks && c.sum_samples < ctx->early_cap_samples) {
+      // Later chunks are still being scanned and this chunk's solves are a fraction of a scan's worth of
+      // work: one block per CU (one wave per SIMD still issues fp64 back to back) leaves the register
+      // file to the scan's waves, which otherwise wait for the persistent solve blocks to drain.
+      if (solve_blocks > (unsigned)ctx->num_cu) solve_blocks = (unsigned)ctx->num_cu;
+    }
     const unsigned accept_blocks = (unsigned)(n_items > (uint64_t)ctx->num_cu * 2 ? (uint64_t)ctx->num_cu * 2 : n_items);
     for (int round = 0; round < blind_rounds; ++round) {
       da.parity = round & 1;
@@ -649,6 +663,7 @@ LENTIL_API int lentil_hip_redistribute(lentil_hip_ctx *ctx) {
   HIP_TRY(ctx, hipMemsetAsync(ctx->d_ctr, 0, sizeof(DevCounters) * (C + 1), ctx->stream));
   HIP_TRY(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
   ctx->last_rounds = 0;
+  ctx->last_scan_launches = 0;
   if (ctx->V.n) {
     // ---- scans: all chunks back to back on the main stream
     ScanArgs sa{};
@@ -678,8 +693,17 @@ LENTIL_API int lentil_hip_redistribute(lentil_hip_ctx *ctx) {
     for (int ci = 0; ci < C; ++ci) {
       lentil_hip_ctx::Chunk &ch = ctx->chunks[ci];
       if (M) {
-        ch.tile_begin = n_tiles * ci / C;
-        ch.tile_end = n_tiles * (ci + 1) / C;
+        // chunk boundaries: the first chunk takes first_chunk_frac of the tiles, the others share the rest
+        auto bound = [&](int i) -> uint64_t {
+          if (i <= 0) return 0;
+          if (i >= C) return n_tiles;
+          const double f0 = C > 1 ? ctx->first_chunk_frac : 1.0;
+          const double x = f0 + (1.0 - f0) * (double)(i - 1) / (double)(C - 1);
+          const uint64_t b = (uint64_t)((double)n_tiles * x);
+          return b > n_tiles ? n_tiles : b;
+        };
+        ch.tile_begin = bound(ci);
+        ch.tile_end = bound(ci + 1);
         ch.v_begin = ch.tile_begin * sa.ppt * M;
         ch.v_end = ch.tile_end * sa.ppt * M;
         if (ch.v_begin > ctx->V.n) ch.v_begin = ctx->V.n;
@@ -706,6 +730,7 @@ LENTIL_API int lentil_hip_redistribute(lentil_hip_ctx *ctx) {
           hipLaunchKernelGGL(scan_ragged_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, sa);
         }
         HIP_TRY(ctx, hipGetLastError());
+        ++ctx->last_scan_launches;
       }
       HIP_TRY(ctx, hipEventRecord(ch.scanned, ctx->stream));
     }
@@ -850,6 +875,14 @@ LENTIL_API int lentil_hip_last_timing(lentil_hip_ctx *ctx, float ms[3]) {
     HIP_TRY(ctx, hipEventElapsedTime(&ms[1], ctx->ev[1], ctx->ev[2]));
   }
   if (ctx->timed_resolve) HIP_TRY(ctx, hipEventElapsedTime(&ms[2], ctx->ev[3], ctx->ev[4]));
+  return LENTIL_OK;
+}
+
+LENTIL_API int lentil_hip_last_launches(lentil_hip_ctx *ctx, uint32_t n[2]) {
+  CHECK_CTX(ctx);
+  if (!n) return fail(ctx, LENTIL_ERR_INVALID, "n is null");
+  n[0] = ctx->last_scan_launches;
+  n[1] = (uint32_t)ctx->last_rounds;
   return LENTIL_OK;
 }
 
