@@ -280,6 +280,18 @@ int lentil_hip_sync(lentil_hip_ctx *ctx);
 int lentil_hip_download_aov(lentil_hip_ctx *ctx, uint32_t aov, float *host_rgba);
 int lentil_hip_download_accum(lentil_hip_ctx *ctx, uint32_t aov, float *host_rgba, float *host_weight);
 
+/* Closest-filtered AOVs across GPUs (the reference's single z-buffer, src/lentil.h:832-837).
+ * deferred != 0: lentil_hip_redistribute leaves the per-pixel winner keys -- (bits of |Z|) << 32 |
+ * (0xFFFFFFFF - frame-wide visit id), empty = all ones -- in lentil_hip_zkey_buffer instead of gathering
+ * the winners' values.  The caller takes the unsigned 64-bit minimum of that buffer over all GPUs, then
+ * calls lentil_hip_closest_gather on each: a GPU writes the values of the winners it owns and leaves the
+ * others zero, so the sum all-reduce of lentil_hip_accum_buffer completes the closest AOVs too.
+ * Frame-wide visit ids: uniform streams derive them from pixel_y0 / pixel_row_stride (the id a single
+ * process walking the whole frame would give the visit); ragged streams use visit_id_base + index. */
+int lentil_hip_set_closest_exchange(lentil_hip_ctx *ctx, int deferred, uint32_t visit_id_base);
+int lentil_hip_zkey_buffer(lentil_hip_ctx *ctx, void **device_ptr, uint64_t *n_keys);
+int lentil_hip_closest_gather(lentil_hip_ctx *ctx);
+
 /* --- multi-GPU ---------------------------------------------------------------------
  * accum_buffer: device pointer + float count of the contiguous accumulator block (one record per
  *               pixel: n_aovs x RGBA, the filter weight, padding to a multiple of 8 floats); a sum

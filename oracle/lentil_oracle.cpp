@@ -734,6 +734,8 @@ struct OrcFrame {
   std::vector<float> buffer[LENTIL_MAX_AOVS];   /* AOVData::buffer, RGBA */
   std::vector<float> weight;                    /* filter_weight_buffer */
   std::vector<float> zbuffer;
+  std::vector<uint32_t> zvisit;                 /* visit that wrote zbuffer last (multi-rank merge tests) */
+  uint32_t cur_visit = 0;
   std::vector<double> buffer64[LENTIL_MAX_AOVS];/* fp64 shadow accumulation (tolerance studies) */
   std::vector<double> weight64;
   lentil_counters ctr;
@@ -757,12 +759,15 @@ ORC_API OrcFrame *orc_frame_create(uint32_t xres, uint32_t yres, uint32_t n_aovs
   F->weight.assign(np, 0.0f);
   if (F->shadow) F->weight64.assign(np, 0.0);
   F->zbuffer.assign(np, 0.0f);
+  F->zvisit.assign(np, 0xFFFFFFFFu);
   memset(&F->ctr, 0, sizeof(F->ctr));
   return F;
 }
 ORC_API void orc_frame_destroy(OrcFrame *F) { delete F; }
 ORC_API const float *orc_frame_buffer(const OrcFrame *F, uint32_t aov) { return F->buffer[aov].data(); }
 ORC_API const float *orc_frame_weight(const OrcFrame *F) { return F->weight.data(); }
+ORC_API const float *orc_frame_zbuffer(const OrcFrame *F) { return F->zbuffer.data(); }
+ORC_API const uint32_t *orc_frame_zvisit(const OrcFrame *F) { return F->zvisit.data(); }
 ORC_API const double *orc_frame_buffer64(const OrcFrame *F, uint32_t aov) { return F->buffer64[aov].data(); }
 ORC_API const double *orc_frame_weight64(const OrcFrame *F) { return F->weight64.data(); }
 ORC_API void orc_frame_counters(const OrcFrame *F, lentil_counters *c) { *c = F->ctr; }
@@ -798,6 +803,7 @@ static inline void add_to_buffer(OrcFrame *F, uint32_t aov, uint32_t px, const f
         if (F->shadow) F->buffer64[aov][(size_t)px * 4 + c] = value[c];
       }
       F->zbuffer[px] = std::abs(depth);
+      F->zvisit[px] = F->cur_visit;
     }
   }
 }
@@ -810,6 +816,7 @@ static void do_visit(const lentil_params *P, const OrcLens *L, const OrcBokeh *B
   const double xres = (double)P->xres, yres = (double)P->yres;
   const double frame_aspect_ratio_without_region = (double)P->xres_without_region / (double)P->yres_without_region;
   bool redistribute = true;
+  F->cur_visit = (uint32_t)v;
   if (P->adaptive_sampling) { if (inverse_sample_density > 0.2) redistribute = false; }   /* :108-113 */
 
   float sample[4] = {V->rgba[v * 4], V->rgba[v * 4 + 1], V->rgba[v * 4 + 2], V->rgba[v * 4 + 3]};

@@ -19,6 +19,7 @@ EXPORTS = [
     "lentil_hip_upload_visits", "lentil_hip_bind_visits", "lentil_hip_clear_frame",
     "lentil_hip_redistribute", "lentil_hip_resolve", "lentil_hip_sync", "lentil_hip_download_aov",
     "lentil_hip_download_accum", "lentil_hip_accum_buffer", "lentil_hip_stream",
+    "lentil_hip_set_closest_exchange", "lentil_hip_zkey_buffer", "lentil_hip_closest_gather",
     "lentil_hip_get_counters", "lentil_hip_last_timing", "lentil_hip_last_launches", "lentil_hip_set_draw_log",
     "lentil_hip_download_draw_log", "lentil_hip_test_lt_sample_aperture",
     "lentil_hip_test_trace_bw_po", "lentil_hip_test_aperture_sample",
@@ -72,6 +73,9 @@ def load_library():
         "lentil_hip_download_accum": (i, [vp, u32, vp, vp]),
         "lentil_hip_accum_buffer": (i, [vp, C.POINTER(vp), C.POINTER(u64)]),
         "lentil_hip_stream": (i, [vp, C.POINTER(vp)]),
+        "lentil_hip_set_closest_exchange": (i, [vp, i, u32]),
+        "lentil_hip_zkey_buffer": (i, [vp, C.POINTER(vp), C.POINTER(u64)]),
+        "lentil_hip_closest_gather": (i, [vp]),
         "lentil_hip_get_counters": (i, [vp, C.POINTER(_abi.Counters)]),
         "lentil_hip_last_timing": (i, [vp, C.POINTER(C.c_float)]),
         "lentil_hip_last_launches": (i, [vp, C.POINTER(C.c_uint32)]),
@@ -222,6 +226,17 @@ class Context:
         p, n = C.c_void_p(), C.c_uint64()
         self._chk(self.lib.lentil_hip_accum_buffer(self.h, C.byref(p), C.byref(n)))
         return p.value, n.value
+
+    def set_closest_exchange(self, deferred, visit_id_base=0):
+        self._chk(self.lib.lentil_hip_set_closest_exchange(self.h, 1 if deferred else 0, visit_id_base))
+
+    def zkey_buffer(self):
+        p, n = C.c_void_p(), C.c_uint64()
+        self._chk(self.lib.lentil_hip_zkey_buffer(self.h, C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    def closest_gather(self):
+        self._chk(self.lib.lentil_hip_closest_gather(self.h))
 
     def stream(self):
         s = C.c_void_p()

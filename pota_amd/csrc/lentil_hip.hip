@@ -71,6 +71,8 @@ struct lentil_hip_ctx {
   uint64_t max_pool_units = 1ull << 32;    // 16 GiB per pool at most (LENTIL_MAX_POOL_UNITS overrides)
   int last_rounds = 0;
   uint32_t last_scan_launches = 0;
+  bool closest_deferred = false;     // multi-GPU: the caller min-reduces the keys before the gather
+  uint32_t visit_id_base = 0;
   DevCounters *d_ctr = nullptr;
   lentil_draw_record *d_log = nullptr;
   uint64_t log_cap = 0;
@@ -394,6 +396,16 @@ static int check_visits(lentil_hip_ctx *ctx, const lentil_visits *v) {
     return fail(ctx, LENTIL_ERR_INVALID, "visits_per_pixel == 0 needs the per-visit pixel array");
   if (v->visits_per_pixel && (v->pixels_per_row == 0 || v->pixel_row_stride == 0))
     return fail(ctx, LENTIL_ERR_INVALID, "pixels_per_row / pixel_row_stride must be non-zero");
+  if (v->visits_per_pixel && v->pixel_row_stride > 1) {
+    // frame-wide visit ids (closest AOV tie-break) are 32 bits: (last row + 1) * visits per row
+    if (v->pixel_y0 < 0) return fail(ctx, LENTIL_ERR_INVALID, "pixel_y0 < 0 with a row-interleaved partition");
+    const uint64_t row_visits = (uint64_t)v->pixels_per_row * v->visits_per_pixel;
+    const uint64_t rows = (v->n + row_visits - 1) / row_visits;
+    if (((uint64_t)v->pixel_y0 + rows * v->pixel_row_stride) * row_visits > 0xFFFFFFFFull)
+      return fail(ctx, LENTIL_ERR_UNSUPPORTED, "frame-wide visit ids exceed 32 bits");
+  } else if ((uint64_t)ctx->visit_id_base + v->n > 0x100000000ull) {
+    return fail(ctx, LENTIL_ERR_UNSUPPORTED, "visit_id_base + n exceeds 32 bits");
+  }
   return LENTIL_OK;
 }
 
@@ -413,6 +425,7 @@ static void to_dev(VisitsDev &d, const lentil_visits *v) {
   for (int k = 0; k < LENTIL_MAX_AOVS - 1; ++k) d.extra[k] = (const float4 *)v->extra[k];
   d.pixel = v->pixel;
   d.inv_density = v->inv_density;
+  d.id_base = 0;
 }
 
 static int ensure_worklist(lentil_hip_ctx *ctx, uint64_t n) {
@@ -434,6 +447,7 @@ LENTIL_API int lentil_hip_bind_visits(lentil_hip_ctx *ctx, const lentil_visits *
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   free_visits(ctx);
   to_dev(ctx->V, v);
+  ctx->V.id_base = ctx->visit_id_base;
   rc = ensure_worklist(ctx, v->n);
   if (rc) return rc;
   ctx->have_visits = true;
@@ -469,6 +483,7 @@ LENTIL_API int lentil_hip_upload_visits(lentil_hip_ctx *ctx, const lentil_visits
   if ((rc = up(v->pixel, (size_t)v->n * 4, (const void **)&d.pixel))) return rc;
   if ((rc = up(v->inv_density, (size_t)v->n * 4, (const void **)&d.inv_density))) return rc;
   to_dev(ctx->V, &d);
+  ctx->V.id_base = ctx->visit_id_base;
   rc = ensure_worklist(ctx, v->n);
   if (rc) return rc;
   ctx->have_visits = true;
@@ -768,13 +783,39 @@ LENTIL_API int lentil_hip_redistribute(lentil_hip_ctx *ctx) {
     }
     ctx->last_rounds = max_rounds;
   }
-  if (ctx->F.zkey && ctx->V.n) {
+  if (ctx->F.zkey && ctx->V.n && !ctx->closest_deferred) {
     // closest-filter AOVs: the winners of this pass (one pass per frame: the keys index the bound stream)
     hipLaunchKernelGGL(closest_gather_kernel, dim3((unsigned)ctx->num_cu * 8), dim3(256), 0, ctx->stream, ctx->F, ctx->V);
     HIP_TRY(ctx, hipGetLastError());
   }
   HIP_TRY(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
   ctx->timed_draw = true;
+  return LENTIL_OK;
+}
+
+LENTIL_API int lentil_hip_set_closest_exchange(lentil_hip_ctx *ctx, int deferred, uint32_t visit_id_base) {
+  CHECK_CTX(ctx);
+  ctx->closest_deferred = deferred != 0;
+  ctx->visit_id_base = visit_id_base;
+  ctx->V.id_base = visit_id_base;
+  return LENTIL_OK;
+}
+
+LENTIL_API int lentil_hip_zkey_buffer(lentil_hip_ctx *ctx, void **device_ptr, uint64_t *n_keys) {
+  CHECK_CTX(ctx);
+  if (!ctx->have_frame) return fail(ctx, LENTIL_ERR_INVALID, "no frame allocated");
+  if (device_ptr) *device_ptr = ctx->F.zkey;
+  if (n_keys) *n_keys = ctx->F.zkey ? ctx->F.np : 0;
+  return LENTIL_OK;
+}
+
+LENTIL_API int lentil_hip_closest_gather(lentil_hip_ctx *ctx) {
+  CHECK_CTX(ctx);
+  if (!ctx->have_frame) return fail(ctx, LENTIL_ERR_INVALID, "no frame allocated");
+  if (!ctx->F.zkey || !ctx->V.n) return LENTIL_OK;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  hipLaunchKernelGGL(closest_gather_kernel, dim3((unsigned)ctx->num_cu * 8), dim3(256), 0, ctx->stream, ctx->F, ctx->V);
+  HIP_TRY(ctx, hipGetLastError());
   return LENTIL_OK;
 }
 

@@ -47,7 +47,30 @@ struct VisitsDev {
   const float4 *extra[LENTIL_MAX_AOVS - 1];
   const uint32_t *pixel;
   const float *inv_density;
+  uint32_t id_base;       // ragged streams: frame-wide id of visit 0 (multi-GPU partitions)
 };
+
+// Frame-wide visit id: the position of a visit in the order a single process would walk the whole frame
+// in.  Closest-filtered AOVs break depth ties by it (the later visit wins, src/lentil.h:833), so every
+// GPU of a row-interleaved partition must number its visits like the undivided stream does.
+LD_DEV uint32_t visit_gid(const VisitsDev &V, uint32_t v) {
+  if (V.visits_per_pixel == 0 || V.pixel_row_stride <= 1) return V.id_base + v;
+  const uint32_t row_visits = V.pixels_per_row * V.visits_per_pixel;
+  const uint32_t ly = v / row_visits;
+  return ((uint32_t)V.pixel_y0 + ly * V.pixel_row_stride) * row_visits + (v - ly * row_visits);
+}
+// inverse; false when the visit belongs to another GPU's partition
+LD_DEV bool visit_from_gid(const VisitsDev &V, uint32_t gid, uint32_t &v) {
+  if (V.visits_per_pixel == 0 || V.pixel_row_stride <= 1) {
+    v = gid - V.id_base;
+    return gid >= V.id_base && (uint64_t)v < V.n;
+  }
+  const uint32_t row_visits = V.pixels_per_row * V.visits_per_pixel;
+  const uint32_t py = gid / row_visits;
+  if (py < (uint32_t)V.pixel_y0 || (py - (uint32_t)V.pixel_y0) % V.pixel_row_stride) return false;
+  v = ((py - (uint32_t)V.pixel_y0) / V.pixel_row_stride) * row_visits + (gid - py * row_visits);
+  return (uint64_t)v < V.n;
+}
 
 struct FrameDev {
   // One record per pixel: n_aovs x RGBA (AOVData::buffer), then filter_weight_buffer, padded to a multiple
@@ -240,7 +263,7 @@ __global__ __launch_bounds__(256) void scan_uniform_kernel(ScanArgs a) {
         for (uint32_t j = 0; j < M; ++j) {
           if (sw[lane * M + j] != 0.0f) {
             const uint64_t vv = v0 + (uint64_t)lane * M + j;
-            const unsigned long long key = closest_key(V.pos_z[vv].w, (uint32_t)vv);
+            const unsigned long long key = closest_key(V.pos_z[vv].w, visit_gid(V, (uint32_t)vv));
             if (key < kmin) kmin = key;
           }
         }
@@ -326,7 +349,7 @@ __global__ __launch_bounds__(256) void scan_ragged_kernel(ScanArgs a) {
         atomicAdd(d + 2, (rgba.z + 0.0f) * w);
         atomicAdd(d + 3, (rgba.w + 0.0f) * w);
         atomicAdd(a.F.wt(lin), w);
-        if (a.F.zkey) atomicMin(a.F.zkey + lin, closest_key(V.pos_z[v].w, (uint32_t)v));
+        if (a.F.zkey) atomicMin(a.F.zkey + lin, closest_key(V.pos_z[v].w, visit_gid(V, (uint32_t)v)));
         for (uint32_t k = 0; k < V.n_extra; ++k) {
           if (a.F.closest_mask & (2u << k)) continue;
           const float4 c = V.extra[k][v];
@@ -679,7 +702,7 @@ LD_DEV AcceptResult accept_item(const DrawArgs &a, AcceptShared &sh, uint32_t it
     const ItemVisit h = load_item_visit(a, item, lens_length);
     const uint32_t S = h.samples, max_total = S * 5u, m_limit = max_total + retries;
     const float ae = h.I.add_energy, w = h.w;
-    const unsigned long long zk = a.F.zkey ? closest_key(h.I.depth, h.visit) : 0ull;
+    const unsigned long long zk = a.F.zkey ? closest_key(h.I.depth, visit_gid(a.V, h.visit)) : 0ull;
     // per-item add table: gaussian AOVs' (value + add_energy) * w, then the weight itself
     uint32_t U = 1;
     for (uint32_t k = 0; k < a.F.n_aovs; ++k) if (!(a.F.closest_mask & (1u << k))) U += 4;
@@ -839,7 +862,8 @@ __global__ __launch_bounds__(256) void closest_gather_kernel(FrameDev F, VisitsD
   for (uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; p < F.np; p += stride) {
     const unsigned long long key = F.zkey[p];
     if (key == ~0ull) continue;
-    const uint32_t visit = 0xFFFFFFFFu - (uint32_t)(key & 0xFFFFFFFFull);
+    uint32_t visit;
+    if (!visit_from_gid(V, 0xFFFFFFFFu - (uint32_t)(key & 0xFFFFFFFFull), visit)) continue;   // another GPU's visit won
     for (uint32_t k = 1; k < F.n_aovs; ++k)
       if (F.closest_mask & (1u << k))
         *F.aov(p, k) = V.extra[k - 1][visit];

@@ -60,6 +60,8 @@ def load():
         "orc_frame_destroy": (None, [vp]),
         "orc_frame_buffer": (C.POINTER(f), [vp, u32]),
         "orc_frame_weight": (C.POINTER(f), [vp]),
+        "orc_frame_zbuffer": (C.POINTER(f), [vp]),
+        "orc_frame_zvisit": (C.POINTER(u32), [vp]),
         "orc_frame_buffer64": (pd, [vp, u32]),
         "orc_frame_weight64": (pd, [vp]),
         "orc_frame_counters": (None, [vp, C.POINTER(_abi.Counters)]),
@@ -108,6 +110,12 @@ class Frame:
 
     def weight(self):
         return np.ctypeslib.as_array(self.lib.orc_frame_weight(self.h), (self.np,)).copy()
+
+    def zbuffer(self):
+        return np.ctypeslib.as_array(self.lib.orc_frame_zbuffer(self.h), (self.np,)).copy()
+
+    def zvisit(self):
+        return np.ctypeslib.as_array(self.lib.orc_frame_zvisit(self.h), (self.np,)).copy()
 
     def buffer64(self, aov=0):
         return np.ctypeslib.as_array(self.lib.orc_frame_buffer64(self.h, aov), (self.np, 4)).copy()

@@ -244,6 +244,122 @@ def test_closest_filter_aovs(orc, gpu_ctx_factory, ragged):
         assert float(np.max(np.abs(buf[m] - exact[m]) / np.abs(exact[m]))) < TOL
 
 
+class _TwoEngineCollective:
+    """Stands in for torch.distributed between two HipEngines living in this process (one GPU):
+    all_reduce(t) is called once per engine in lock step; the reduction is applied to both tensors when
+    the second call arrives.  Lets frame_step's multi-rank path run on a single MI355X."""
+
+    class ReduceOp:
+        SUM, MIN = "sum", "min"
+
+    def __init__(self):
+        self.pending = None
+
+    def is_initialized(self):
+        return True
+
+    def get_world_size(self):
+        return 2
+
+    def all_reduce(self, t, op):
+        import torch
+        if self.pending is None:
+            self.pending = t
+            return
+        a, b = self.pending, t
+        torch.cuda.synchronize()
+        r = torch.minimum(a, b) if op == "min" else a + b
+        a.copy_(r); b.copy_(r)
+        torch.cuda.synchronize()
+        self.pending = None
+
+
+def test_two_partitions_on_one_gpu_match_the_whole_frame(orc, gpu_ctx_factory):
+    """Multi-GPU logic on one device: rows r mod 2 in two contexts, closest-AOV key
+    exchange + owner gather, sum of the accumulators, local resolve -- against one context that
+    processes the whole frame (which test_closest_filter_aovs pins to the oracle)."""
+    import threading
+    from pota_amd import distributed, workload
+    W, H, M = 64, 40, 9
+    kinds = [0, 1, 0]
+    p, model, table, keep = common.po_setup(W, H, samples_override=48)
+    visits, cols = common.make_stream(p, W, H, M, f_hi=0.03, n_extra=2)
+    whole = gpu_ctx_factory()
+    gpu_run(whole, p, table, visits, n_aovs=3, kinds=kinds)
+
+    engines, keepalive = [], []
+    for rank in range(2):
+        n_local = workload.frame_visit_count(W, H, M, 2, rank)
+        c = workload.generate(np, 0, n_local, W, H, M, f_hi=0.03, focus_dist=150.0,
+                              tan_half_fov=common.tan_half_fov(p), row_stride=2, row_offset=rank, n_extra=2)
+        v, kv = capi.make_visits(c, visits_per_pixel=M, pixels_per_row=W, pixel_y0=rank, pixel_row_stride=2)
+        ctx = gpu_ctx_factory()
+        ctx.set_params(p); ctx.set_lens(table); ctx.set_bokeh(None)
+        ctx.alloc_frame(3, kinds)
+        ctx.upload_visits(v)
+        keepalive.append((c, v, kv))
+        engines.append(distributed.HipEngine(ctx))
+    assert engines[0].zkey is not None
+
+    # drive both "ranks" through frame_step in lock step (two threads, one collective object)
+    coll = _TwoEngineCollective()
+    barrier = threading.Barrier(2)
+    errors = []
+
+    class _Dist:
+        ReduceOp = _TwoEngineCollective.ReduceOp
+
+        def __init__(self, rank):
+            self.rank = rank
+
+        def is_initialized(self):
+            return True
+
+        def get_world_size(self):
+            return 2
+
+        def all_reduce(self, t, op):
+            # rank 0 registers first, rank 1 completes the reduction; both return afterwards
+            if self.rank == 0:
+                coll.all_reduce(t, op)
+                barrier.wait()
+                barrier.wait()
+            else:
+                barrier.wait()
+                coll.all_reduce(t, op)
+                barrier.wait()
+
+    def run(rank):
+        try:
+            distributed.frame_step(engines[rank], _Dist(rank))
+            engines[rank].ctx.sync()
+        except Exception as e:          # pragma: no cover
+            errors.append(e)
+            barrier.abort()
+
+    th = [threading.Thread(target=run, args=(r,)) for r in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=120)
+    assert not errors, errors
+
+    for rank in range(2):
+        ctx = engines[rank].ctx
+        buf, _ = ctx.download_accum(1)                       # closest: identical winners and values
+        ref, _ = whole.download_accum(1)
+        assert np.array_equal(buf, ref)
+        assert np.array_equal(ctx.download_aov(1), whole.download_aov(1))
+        assert np.count_nonzero(ref) > 0
+        for a in (0, 2):                                     # gaussian: fp32 summation order differs
+            buf, w = ctx.download_accum(a)
+            ref, rw = whole.download_accum(a)
+            m = ref != 0
+            assert np.array_equal(buf != 0, m)
+            assert float(np.max(np.abs(buf[m] - ref[m]) / np.abs(ref[m]))) < TOL
+            assert float(np.max(np.abs(w[rw != 0] - rw[rw != 0]) / rw[rw != 0])) < TOL
+
+
 def test_po_ragged_pixels_and_inv_density(orc, gpu_ctx_factory):
     """Explicit per-visit pixel + per-visit inverse density (ragged footprints / adaptive sampling)."""
     W, H, M = 48, 32, 9
