@@ -59,7 +59,7 @@ int lentil_host_camera_model_specific_setup(lentil_params *params, const lentil_
 /* Forward camera rays: Camera::trace_ray_fw_po / trace_ray_fw_thinlens (src/lentil.h:283-569).
  * rng: the xor128 state (src/global.h:22-27; the reference keeps it in function statics -- pass
  * lentil_host_xor128_init'ed storage, one per thread).  r1, r2: Arnold's lens samples, replaced by
- * xor128 draws on retries.  weight is set to 0 when every try is vignetted.  thin lens: abb_coma must be 0. */
+ * xor128 draws on retries.  weight is set to 0 when every try is vignetted. */
 void lentil_host_xor128_init(uint32_t state[4]);
 void lentil_host_trace_ray_fw_po(const lentil_params *params, const lentil_host_lens *lens,
                                  const lentil_bokeh_table *bokeh, uint32_t rng[4], double lambda, double sx, double sy,

@@ -724,6 +724,85 @@ static inline void v3norm(const float v[3], float o[3]) {
   o[0] = v[0] * t; o[1] = v[1] * t; o[2] = v[2] * t;
 }
 
+/* -------------------------------------------------------------------------------------
+ * Thin-lens coma, src/lens.h:563-582.  The rotation goes through Eigen (AngleAxisd ->
+ * Matrix3d, Matrix3d::inverse(), Matrix3d * Vector3d).  Eigen is not part of the reference
+ * tree (it is included by relative path from a sibling checkout, src/lens.h:5-6, no version
+ * pinned), so the three Eigen operations are restated from Eigen's published sources
+ * (3.3/3.4, Geometry/AngleAxis.h toRotationMatrix, LU/InverseImpl.h compute_inverse<.,.,3>,
+ * the coefficient-based product with its unrolled 3-term reduction a0 + (a1 + a2)):
+ * parity unpinned for this branch beyond that restatement.
+ * ------------------------------------------------------------------------------------- */
+static inline float v3dot(const float a[3], const float b[3]) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+
+ORC_API float orc_abb_coma_multipliers(float sensor_width, float focal_length, const float dir_from_center[3],
+                                       const double unit_disk[2]) {                 /* src/lens.h:563-571 */
+  const float maximal_perturbed_ray[3] = {(float)(1.0 * (sensor_width * 0.5)), (float)(1.0 * (sensor_width * 0.5)),
+                                          -focal_length};
+  const float minus_z[3] = {0.0f, 0.0f, -1.0f};
+  float n[3];
+  v3norm(maximal_perturbed_ray, n);
+  float maximal_projection = v3dot(n, minus_z);
+  float current_projection = v3dot(dir_from_center, minus_z);
+  float projection_perc = ((current_projection - maximal_projection) / (1.0 - maximal_projection) - 0.5) * 2.0;
+  float dist_from_sensor_center = 1.0 - projection_perc;
+  float dist_from_aperture = std::sqrt(unit_disk[0] * unit_disk[0] + unit_disk[1] * unit_disk[1]);  /* Vector2d::norm */
+  return dist_from_sensor_center * dist_from_aperture;
+}
+
+/* Eigen::AngleAxisd(angle, axis).toRotationMatrix() */
+static inline void angle_axis_matrix(double angle, const double axis[3], double res[3][3]) {
+  const double s = std::sin(angle), c = std::cos(angle);
+  const double sin_axis[3] = {s * axis[0], s * axis[1], s * axis[2]};
+  const double cos1_axis[3] = {(1.0 - c) * axis[0], (1.0 - c) * axis[1], (1.0 - c) * axis[2]};
+  double tmp;
+  tmp = cos1_axis[0] * axis[1];
+  res[0][1] = tmp - sin_axis[2];
+  res[1][0] = tmp + sin_axis[2];
+  tmp = cos1_axis[0] * axis[2];
+  res[0][2] = tmp + sin_axis[1];
+  res[2][0] = tmp - sin_axis[1];
+  tmp = cos1_axis[1] * axis[2];
+  res[1][2] = tmp - sin_axis[0];
+  res[2][1] = tmp + sin_axis[0];
+  for (int i = 0; i < 3; i++) res[i][i] = cos1_axis[i] * axis[i] + c;
+}
+/* Eigen::Matrix3d::inverse(): cofactors, det from column 0, everything scaled by 1/det */
+static inline double cofactor3(const double m[3][3], int i, int j) {
+  const int i1 = (i + 1) % 3, i2 = (i + 2) % 3, j1 = (j + 1) % 3, j2 = (j + 2) % 3;
+  return m[i1][j1] * m[i2][j2] - m[i1][j2] * m[i2][j1];
+}
+static inline void inverse3(const double m[3][3], double r[3][3]) {
+  const double c0[3] = {cofactor3(m, 0, 0), cofactor3(m, 1, 0), cofactor3(m, 2, 0)};
+  const double det = c0[0] * m[0][0] + (c0[1] * m[1][0] + c0[2] * m[2][0]);
+  const double invdet = 1.0 / det;
+  r[1][0] = cofactor3(m, 0, 1) * invdet;
+  r[1][1] = cofactor3(m, 1, 1) * invdet;
+  r[2][0] = cofactor3(m, 0, 2) * invdet;
+  r[1][2] = cofactor3(m, 2, 1) * invdet;
+  r[2][1] = cofactor3(m, 1, 2) * invdet;
+  r[2][2] = cofactor3(m, 2, 2) * invdet;
+  r[0][0] = c0[0] * invdet; r[0][1] = c0[1] * invdet; r[0][2] = c0[2] * invdet;
+}
+
+ORC_API void orc_abb_coma_perturb(const float dir_from_lens[3], const float ray_to_perturb[3], float abb_coma,
+                                  int reverse, float out[3]) {                      /* src/lens.h:575-582 */
+  const float minus_z[3] = {0.0f, 0.0f, -1.0f};
+  const float cr[3] = {dir_from_lens[1] * minus_z[2] - dir_from_lens[2] * minus_z[1],
+                       dir_from_lens[2] * minus_z[0] - dir_from_lens[0] * minus_z[2],
+                       dir_from_lens[0] * minus_z[1] - dir_from_lens[1] * minus_z[0]};     /* AiV3Cross */
+  float axis_tmp[3];
+  v3norm(cr, axis_tmp);
+  const double axis[3] = {axis_tmp[0], axis_tmp[1], axis_tmp[2]};
+  const double angle = (abb_coma * 2.3456 * AI_PI_F) / 180.0;
+  double rot[3][3], inv[3][3];
+  angle_axis_matrix(angle, axis, rot);
+  const double (*m)[3] = rot;
+  if (reverse) { inverse3(rot, inv); m = inv; }
+  const double raydir[3] = {ray_to_perturb[0], ray_to_perturb[1], ray_to_perturb[2]};
+  for (int i = 0; i < 3; i++) out[i] = (float)(m[i][0] * raydir[0] + (m[i][1] * raydir[1] + m[i][2] * raydir[2]));
+}
+
 /* =====================================================================================
  * The frame: buffers of Camera::setup_filter (src/lentil.h:1096-1121) and the whole
  * filter_pixel visit loop (src/lentil_filter.cpp:91-451) over a visit stream.
@@ -900,8 +979,8 @@ static void do_visit(const lentil_params *P, const OrcLens *L, const OrcBokeh *B
     return;
   }
 
-  /* ---- ThinLens, src/lentil_filter.cpp:303-447 (abb_coma == 0 and abb_chromatic == 0 only:
-   * coma goes through Eigen AngleAxisd and chromatic through the global xor128 state) ---- */
+  /* ---- ThinLens, src/lentil_filter.cpp:303-447 (abb_chromatic == 0 only: the chromatic branch draws
+   * its channel from the process-wide xor128 state, :397) ---- */
   for (int count = 0; count < samples && total_samples_taken < max_total_samples; ++count, ++total_samples_taken) {
     F->ctr.attempted_draws++;
     unsigned int seed = orc_tea8((uint32_t)(px * py + px), total_samples_taken);
@@ -923,8 +1002,16 @@ static void do_visit(const lentil_params *P, const OrcLens *L, const OrcBokeh *B
     const float lens[3] = {(float)(unit_disk[0] * P->aperture_radius), (float)(unit_disk[1] * P->aperture_radius), 0.0f};
     float dir_from_center[3];
     v3norm(cs, dir_from_center);                                                            /* :327 */
-    /* abb_coma == 0: the rotation is exactly the identity, so dir_lens_to_P := dir_from_center (:333-334) */
-    float dir_lens_to_P[3] = {dir_from_center[0], dir_from_center[1], dir_from_center[2]};
+    float dir_lens_to_P[3];
+    { const float d[3] = {cs[0] - lens[0], cs[1] - lens[1], cs[2] - lens[2]}; v3norm(d, dir_lens_to_P); }  /* :328 */
+    /* coma: the centre ray rotated about the axis orthogonal to the lens ray (:333-334) */
+    {
+      const float abb_coma_multiplied = P->abb_coma * orc_abb_coma_multipliers(P->sensor_width, P->focal_length,
+                                                                               dir_from_center, unit_disk);
+      float rotated[3];
+      orc_abb_coma_perturb(dir_lens_to_P, dir_from_center, abb_coma_multiplied, 1, rotated);
+      dir_lens_to_P[0] = rotated[0]; dir_lens_to_P[1] = rotated[1]; dir_lens_to_P[2] = rotated[2];
+    }
     const float len = v3len(cs);
     float perturbed[3] = {len * dir_lens_to_P[0], len * dir_lens_to_P[1], len * dir_lens_to_P[2]};   /* :336 */
     v3norm(perturbed, dir_from_center);                                                     /* :337 */
@@ -993,7 +1080,7 @@ static inline void visit_pixel(const lentil_visits *V, uint64_t v, int *px, int 
 /* Runs visits [v_begin, v_end) in order.  Returns 0, or LENTIL_ERR_UNSUPPORTED. */
 ORC_API int orc_redistribute(const lentil_params *P, const OrcLens *L, const OrcBokeh *B, OrcFrame *F,
                              const lentil_visits *V, uint64_t v_begin, uint64_t v_end) {
-  if (P->cameraType == LENTIL_THINLENS && (P->abb_coma != 0.0f || P->abb_chromatic > 0.0f)) return LENTIL_ERR_UNSUPPORTED;
+  if (P->cameraType == LENTIL_THINLENS && P->abb_chromatic > 0.0f) return LENTIL_ERR_UNSUPPORTED;
   if (P->cameraType == LENTIL_POLYNOMIAL_OPTICS && (P->abb_chromatic > 0.0f || !L)) return LENTIL_ERR_UNSUPPORTED;
   if (P->bokeh_enable_image && !B) return LENTIL_ERR_INVALID;
   for (uint64_t v = v_begin; v < v_end; v++) {
@@ -1193,7 +1280,6 @@ ORC_API void orc_trace_ray_fw_po(const lentil_params *P, const OrcLens *L, const
   if (tries_out) *tries_out = tries;
 }
 
-/* abb_coma == 0 only (the coma rotation goes through Eigen and is the identity then) */
 ORC_API void orc_trace_ray_fw_thinlens(const lentil_params *P, const OrcBokeh *B, uint32_t rng[4], double sx, double sy,
                                        double *r1, double *r2, int deriv_ray, float origin[3], float dir[3],
                                        float weight[3], int *tries_out) {
@@ -1232,6 +1318,13 @@ ORC_API void orc_trace_ray_fw_thinlens(const lentil_params *P, const OrcBokeh *B
     const float t[3] = {focusPoint[0] - lens[0], focusPoint[1] - lens[1], focusPoint[2] - lens[2]};
     float dir_from_lens[3];
     v3norm(t, dir_from_lens);
+    {                                                            /* coma, src/lentil.h:490-491 */
+      const float abb_coma_multiplied = P->abb_coma * orc_abb_coma_multipliers(P->sensor_width, P->focal_length,
+                                                                               dir_from_center, unit_disk);
+      float rotated[3];
+      orc_abb_coma_perturb(dir_from_lens, dir_from_lens, abb_coma_multiplied, 0, rotated);
+      dir_from_lens[0] = rotated[0]; dir_from_lens[1] = rotated[1]; dir_from_lens[2] = rotated[2];
+    }
     if (P->optical_vignetting_distance > 0.0 && !deriv_ray) {     /* src/lens.h:529-543 */
       const float squarebias = 1.0 + std::log(1.0 + P->circle_to_square) * std::exp(P->circle_to_square * 3.0);
       float inter = std::abs(P->optical_vignetting_distance / dir_from_lens[2]);

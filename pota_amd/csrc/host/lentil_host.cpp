@@ -479,6 +479,51 @@ HOST_API void lentil_host_trace_ray_fw_po(const lentil_params *P, const lentil_h
   if (tries_out) *tries_out = tries;
 }
 
+// Coma of the thin-lens model, src/lens.h:563-582: how far the centre ray is from the sensor's corner ray
+// and how far the lens sample is from the aperture centre scale a rotation of the ray about the axis
+// orthogonal to it and -z.  Eigen's AngleAxisd::toRotationMatrix / Matrix3d::inverse / Matrix3d * Vector3d
+// are written out (operation order of Eigen 3.3/3.4).
+static float coma_amount(const lentil_params *P, const float dc[3], double ux, double uy) {
+  float corner[3] = {(float)(1.0 * (P->sensor_width * 0.5)), (float)(1.0 * (P->sensor_width * 0.5)), -P->focal_length};
+  normalize3f(corner);
+  const float max_proj = corner[0] * 0.0f + corner[1] * 0.0f + corner[2] * -1.0f;
+  const float cur_proj = dc[0] * 0.0f + dc[1] * 0.0f + dc[2] * -1.0f;
+  const float perc = (float)((((double)(cur_proj - max_proj) / (1.0 - (double)max_proj)) - 0.5) * 2.0);
+  const float from_center = (float)(1.0 - (double)perc);
+  const float from_aperture = (float)std::sqrt(ux * ux + uy * uy);
+  return from_center * from_aperture;
+}
+
+static void coma_rotate(const float about[3], const float ray[3], float amount, bool inverse, float out[3]) {
+  float ax[3] = {about[1] * -1.0f - about[2] * 0.0f, about[2] * 0.0f - about[0] * -1.0f, about[0] * 0.0f - about[1] * 0.0f};
+  normalize3f(ax);
+  const double a[3] = {ax[0], ax[1], ax[2]};
+  const double angle = ((double)amount * 2.3456 * (double)3.14159265358979323846f) / 180.0;
+  const double sn = std::sin(angle), cs = std::cos(angle);
+  double R[3][3], I[3][3];
+  const double sa[3] = {sn * a[0], sn * a[1], sn * a[2]};
+  const double ca[3] = {(1.0 - cs) * a[0], (1.0 - cs) * a[1], (1.0 - cs) * a[2]};
+  double t = ca[0] * a[1];  R[0][1] = t - sa[2];  R[1][0] = t + sa[2];
+  t = ca[0] * a[2];         R[0][2] = t + sa[1];  R[2][0] = t - sa[1];
+  t = ca[1] * a[2];         R[1][2] = t - sa[0];  R[2][1] = t + sa[0];
+  for (int i = 0; i < 3; ++i) R[i][i] = ca[i] * a[i] + cs;
+  const double (*M)[3] = R;
+  if (inverse) {
+    auto cof = [&](int i, int j) {
+      const int i1 = (i + 1) % 3, i2 = (i + 2) % 3, j1 = (j + 1) % 3, j2 = (j + 2) % 3;
+      return R[i1][j1] * R[i2][j2] - R[i1][j2] * R[i2][j1];
+    };
+    const double c0[3] = {cof(0, 0), cof(1, 0), cof(2, 0)};
+    const double invdet = 1.0 / (c0[0] * R[0][0] + (c0[1] * R[1][0] + c0[2] * R[2][0]));
+    I[1][0] = cof(0, 1) * invdet; I[1][1] = cof(1, 1) * invdet; I[2][0] = cof(0, 2) * invdet;
+    I[1][2] = cof(2, 1) * invdet; I[2][1] = cof(1, 2) * invdet; I[2][2] = cof(2, 2) * invdet;
+    I[0][0] = c0[0] * invdet; I[0][1] = c0[1] * invdet; I[0][2] = c0[2] * invdet;
+    M = I;
+  }
+  const double r[3] = {ray[0], ray[1], ray[2]};
+  for (int i = 0; i < 3; ++i) out[i] = (float)(M[i][0] * r[0] + (M[i][1] * r[1] + M[i][2] * r[2]));
+}
+
 HOST_API void lentil_host_trace_ray_fw_thinlens(const lentil_params *P, const lentil_bokeh_table *B, uint32_t rng[4],
                                                 double sx, double sy, double *r1, double *r2, int deriv_ray,
                                                 float origin[3], float direction[3], float weight[3], int *tries_out) {
@@ -505,6 +550,11 @@ HOST_API void lentil_host_trace_ray_fw_thinlens(const lentil_params *P, const le
     const float hit = (float)std::fabs(P->focus_distance / (double)lerp1(0.0f, dc[2], 1.0f));
     float dl[3] = {dc[0] * hit - lens[0], dc[1] * hit - lens[1], dc[2] * hit - lens[2]};
     normalize3f(dl);
+    {                                                                   // src/lentil.h:490-491
+      float rot[3];
+      coma_rotate(dl, dl, P->abb_coma * coma_amount(P, dc, ux, uy), false, rot);
+      dl[0] = rot[0]; dl[1] = rot[1]; dl[2] = rot[2];
+    }
     if (P->optical_vignetting_distance > 0.0f && !deriv_ray) {          // src/lens.h:529-543
       const float squarebias = (float)(1.0 + std::log(1.0 + (double)P->circle_to_square) * std::exp((double)P->circle_to_square * 3.0));
       const float inter = std::fabs(P->optical_vignetting_distance / dl[2]);

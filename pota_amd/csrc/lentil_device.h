@@ -609,7 +609,68 @@ LD_DEV VisitInfo visit_prologue(const lentil_params &P, double lens_length, floa
   return I;
 }
 
-// a16 -- one thin-lens draw, src/lentil_filter.cpp:311-434 (abb_coma == 0, abb_chromatic == 0)
+// Thin-lens coma, src/lens.h:563-582.  The rotation is Eigen's AngleAxisd -> Matrix3d, Matrix3d::inverse()
+// and Matrix3d * Vector3d, restated from Eigen's published sources (3.3/3.4; Eigen is not in the reference
+// tree, it is included from a sibling checkout, src/lens.h:5-6): Geometry/AngleAxis.h toRotationMatrix,
+// LU/InverseImpl.h compute_inverse<.,.,3>, coefficient-based product with the reduction a0 + (a1 + a2).
+LD_DEV float abb_coma_multipliers(float sensor_width, float focal_length, float dcx, float dcy, float dcz,
+                                  double ux, double uy) {
+  float mx = (float)(1.0 * ((double)sensor_width * 0.5)), my = mx, mz = -focal_length;
+  v3norm(mx, my, mz);
+  const float maximal_projection = mx * 0.0f + my * 0.0f + mz * -1.0f;
+  const float current_projection = dcx * 0.0f + dcy * 0.0f + dcz * -1.0f;
+  const float projection_perc =
+      (float)((((double)(current_projection - maximal_projection) / (1.0 - (double)maximal_projection)) - 0.5) * 2.0);
+  const float dist_from_sensor_center = (float)(1.0 - (double)projection_perc);
+  const float dist_from_aperture = (float)sqrt(ux * ux + uy * uy);
+  return dist_from_sensor_center * dist_from_aperture;
+}
+
+LD_DEV double cofactor3(const double m[3][3], int i, int j) {
+  const int i1 = (i + 1) % 3, i2 = (i + 2) % 3, j1 = (j + 1) % 3, j2 = (j + 2) % 3;
+  return m[i1][j1] * m[i2][j2] - m[i1][j2] * m[i2][j1];
+}
+
+// rotates ray_to_perturb about normalize(cross(dir_from_lens, -z)) by -/+ abb_coma * 2.3456 degrees
+LD_DEV void abb_coma_perturb(float lx, float ly, float lz, float rx, float ry, float rz, float abb_coma,
+                             bool reverse, float &ox, float &oy, float &oz) {
+  float ax = ly * -1.0f - lz * 0.0f, ay = lz * 0.0f - lx * -1.0f, az = lx * 0.0f - ly * 0.0f;   // AiV3Cross(l, (0,0,-1))
+  v3norm(ax, ay, az);
+  const double axis[3] = {(double)ax, (double)ay, (double)az};
+  const double angle = ((double)abb_coma * 2.3456 * (double)kAiPi) / 180.0;
+  const double sn = sin(angle), c = cos(angle);
+  const double sin_axis[3] = {sn * axis[0], sn * axis[1], sn * axis[2]};
+  const double cos1_axis[3] = {(1.0 - c) * axis[0], (1.0 - c) * axis[1], (1.0 - c) * axis[2]};
+  double rot[3][3], inv[3][3];
+  double tmp = cos1_axis[0] * axis[1];
+  rot[0][1] = tmp - sin_axis[2]; rot[1][0] = tmp + sin_axis[2];
+  tmp = cos1_axis[0] * axis[2];
+  rot[0][2] = tmp + sin_axis[1]; rot[2][0] = tmp - sin_axis[1];
+  tmp = cos1_axis[1] * axis[2];
+  rot[1][2] = tmp - sin_axis[0]; rot[2][1] = tmp + sin_axis[0];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) rot[i][i] = cos1_axis[i] * axis[i] + c;
+  const double(*m)[3] = rot;
+  if (reverse) {
+    const double c0[3] = {cofactor3(rot, 0, 0), cofactor3(rot, 1, 0), cofactor3(rot, 2, 0)};
+    const double det = c0[0] * rot[0][0] + (c0[1] * rot[1][0] + c0[2] * rot[2][0]);
+    const double invdet = 1.0 / det;
+    inv[1][0] = cofactor3(rot, 0, 1) * invdet;
+    inv[1][1] = cofactor3(rot, 1, 1) * invdet;
+    inv[2][0] = cofactor3(rot, 0, 2) * invdet;
+    inv[1][2] = cofactor3(rot, 2, 1) * invdet;
+    inv[2][1] = cofactor3(rot, 1, 2) * invdet;
+    inv[2][2] = cofactor3(rot, 2, 2) * invdet;
+    inv[0][0] = c0[0] * invdet; inv[0][1] = c0[1] * invdet; inv[0][2] = c0[2] * invdet;
+    m = inv;
+  }
+  const double r[3] = {(double)rx, (double)ry, (double)rz};
+  ox = (float)(m[0][0] * r[0] + (m[0][1] * r[1] + m[0][2] * r[2]));
+  oy = (float)(m[1][0] * r[0] + (m[1][1] * r[1] + m[1][2] * r[2]));
+  oz = (float)(m[2][0] * r[0] + (m[2][1] * r[1] + m[2][2] * r[2]));
+}
+
+// a16 -- one thin-lens draw, src/lentil_filter.cpp:311-434 (abb_chromatic == 0)
 LD_DEV bool thinlens_draw(const lentil_params &P, const DevBokeh &B, const float *cdfRow, const float cs[3],
                           int px, int py, uint32_t total_samples_taken, uint32_t &pixelnumber) {
   uint32_t seed = tea8((uint32_t)(px * py + px), total_samples_taken);
@@ -631,8 +692,17 @@ LD_DEV bool thinlens_draw(const lentil_params &P, const DevBokeh &B, const float
   const float lx = (float)(ux * P.aperture_radius), ly = (float)(uy * P.aperture_radius), lz = 0.0f;
   float dcx = cs[0], dcy = cs[1], dcz = cs[2];
   v3norm(dcx, dcy, dcz);
+  float ptx = dcx, pty = dcy, ptz = dcz;
+  if (P.abb_coma != 0.0f) {
+    // coma: the centre ray rotated about the axis orthogonal to the lens ray, :328-334 (zero coma rotates
+    // by exactly the identity, so the branch only saves work)
+    float qx = cs[0] - lx, qy = cs[1] - ly, qz = cs[2] - lz;
+    v3norm(qx, qy, qz);
+    const float mult = P.abb_coma * abb_coma_multipliers(P.sensor_width, P.focal_length, dcx, dcy, dcz, ux, uy);
+    abb_coma_perturb(qx, qy, qz, dcx, dcy, dcz, mult, true, ptx, pty, ptz);
+  }
   const float len = v3len(cs[0], cs[1], cs[2]);
-  const float ppx = len * dcx, ppy = len * dcy, ppz = len * dcz;
+  const float ppx = len * ptx, ppy = len * pty, ppz = len * ptz;
   dcx = ppx; dcy = ppy; dcz = ppz;
   v3norm(dcx, dcy, dcz);
   const float sii = fabsf(image_dist_samplepos / dcz);

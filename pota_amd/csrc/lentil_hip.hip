@@ -202,8 +202,6 @@ LENTIL_API int lentil_hip_set_params(lentil_hip_ctx *ctx, const lentil_params *p
   if (p->abb_chromatic > 0.0f)
     return fail(ctx, LENTIL_ERR_UNSUPPORTED,
                 "abb_chromatic > 0 is not implemented on the GPU (per-channel traces / global xor128 state)");
-  if (p->cameraType == LENTIL_THINLENS && p->abb_coma != 0.0f)
-    return fail(ctx, LENTIL_ERR_UNSUPPORTED, "thin-lens abb_coma != 0 is not implemented on the GPU");
   if (p->samples_override < 0 || p->samples_override > (1 << 24))
     return fail(ctx, LENTIL_ERR_INVALID, "samples_override out of range");
   if (ctx->have_frame && (p->xres != ctx->P.xres || p->yres != ctx->P.yres))

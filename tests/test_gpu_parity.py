@@ -414,6 +414,25 @@ def test_thinlens_redistribute_parity(orc, gpu_ctx_factory, override):
     check_frame(ctx, ref)
 
 
+@pytest.mark.parametrize("coma", [0.35, 1.0])
+def test_thinlens_coma_vignetting_distortion(orc, gpu_ctx_factory, coma):
+    """The thin-lens draw's optional branches together (src/lentil_filter.cpp:328-337,379-386,420):
+    coma rotation (Eigen AngleAxisd restated), optical vignetting, inverse barrel distortion, hexagonal
+    aperture."""
+    W, H, M = 96, 64, 9
+    p = common.tl_setup(W, H, samples_override=48, abb_coma=coma, optical_vignetting_distance=2.0,
+                        optical_vignetting_radius=1.5, abb_distortion=0.15, bokeh_aperture_blades=6)
+    visits, cols = common.make_stream(p, W, H, M, f_hi=0.02)
+    ref = common.run_oracle(orc, p, None, visits)
+    assert ref.counters().accepted_draws > 10000
+    ctx = gpu_ctx_factory()
+    c = gpu_run(ctx, p, None, visits)
+    assert c.accepted_draws == ref.counters().accepted_draws
+    assert c.attempted_draws == ref.counters().attempted_draws
+    check_logs(ctx, ref)
+    check_frame(ctx, ref)
+
+
 def test_sub_batches_when_the_result_pool_is_small(orc, monkeypatch):
     """A chunk whose draws do not fit the result pool is processed in sub-batches of items (and single
     chunk / many chunks give the same answer)."""

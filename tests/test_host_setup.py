@@ -190,10 +190,12 @@ def test_forward_po_rays_bitwise(orc, both):
     assert n_retry > 0          # the vignetting-retry path was exercised
 
 
-def test_forward_thinlens_rays_bitwise(orc):
+@pytest.mark.parametrize("coma", [0.0, 0.6])
+def test_forward_thinlens_rays_bitwise(orc, coma):
     lib = hostlib.load()
     p = camera.setup_thinlens(camera.setup_filter(camera.default_params(), 640, 360))
     p.optical_vignetting_distance = 2.0        # exercises retries
+    p.abb_coma = coma                          # src/lentil.h:490-491
     rng = np.random.default_rng(10)
     n_retry = 0
     for _ in range(300):
