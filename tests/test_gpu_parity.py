@@ -518,3 +518,122 @@ def test_full_size_properties(gpu_ctx_factory):
     assert float(np.abs(w2.astype(np.float64) - w1).max()) <= 1e-5 * float(w1.max())
     mm = buf1[:, 0] > 0
     assert np.allclose(buf2[mm, :3], 2.0 * buf1[mm, :3], rtol=2e-5)
+
+
+def _band_parity_at_full_geometry(orc, ctx, p, table, W, M, y0, rows, f_hi, n_extra=0, kinds=None, bokeh_tables=None,
+                                  orc_bokeh=None):
+    """A band of rows of the full-size frame (same seeded visits as the full stream), oracle vs HIP:
+    pixel coordinates, bokeh radii and draw counts are those of the full frame."""
+    from pota_amd import workload
+    H = p.yres_without_region
+    cols = workload.generate(np, y0 * W * M, (y0 + rows) * W * M, W, H, M, f_hi=f_hi, focus_dist=150.0,
+                             tan_half_fov=common.tan_half_fov(p), n_extra=n_extra)
+    visits, keepv = capi.make_visits(cols, visits_per_pixel=M, pixels_per_row=W, pixel_y0=y0)
+    n_aovs = 1 + n_extra
+    lens = orc.orc_lens_create(C.byref(table))
+    ref = oracle_lib.Frame(orc, p, n_aovs=n_aovs, kinds=kinds, keep_log=True)
+    ref.run(lens, orc_bokeh, visits)
+    orc.orc_lens_destroy(lens)
+    assert ref.counters().redistributed_visits > 20
+    c = gpu_run(ctx, p, table, visits, n_aovs=n_aovs, kinds=kinds, bokeh_tables=bokeh_tables)
+    assert c.redistributed_visits == ref.counters().redistributed_visits
+    assert c.attempted_draws == ref.counters().attempted_draws
+    assert c.accepted_draws == ref.counters().accepted_draws
+    check_logs(ctx, ref)
+    check_frame(ctx, ref, n_aovs=n_aovs)
+    ref.close()
+
+
+def _whole_frame_bookkeeping(ctx, p, W, H, M, samples, f_hi, n_extra=0):
+    """Whole frame, inputs generated on the device: weight bookkeeping, finite resolve, and the same
+    accepted draws whether the stream is scanned as one chunk or two."""
+    import torch
+    from pota_amd import workload
+    dev = torch.device("cuda:0")
+    n = W * H * M
+    cols = workload.generate(torch, 0, n, W, H, M, f_hi=f_hi, focus_dist=150.0,
+                             tan_half_fov=common.tan_half_fov(p), device=dev, n_extra=n_extra)
+    visits, keepv = capi.make_visits(cols, visits_per_pixel=M, pixels_per_row=W, ptr=lambda t: t.data_ptr())
+    torch.cuda.synchronize()
+    ctx.bind_visits(visits, keepv)
+    ctx.set_draw_log(0)
+    ctx.clear_frame(); ctx.redistribute(); ctx.resolve(); ctx.sync()
+    c = ctx.counters()
+    assert c.worklist_overflow == 0 and c.redistributed_visits > 100
+    assert c.visits == n
+    w = ctx.download_accum(0)[1].astype(np.float64)
+    inv = float(p.inverse_sample_density)
+    # every non-redistributed visit adds inv_density to its pixel, every accepted draw inv_density/samples
+    expect = (n - c.redistributed_visits) * inv + c.accepted_draws * inv / samples
+    assert abs(w.sum() - expect) / expect < 1e-5
+    for a in range(1 + n_extra):
+        assert np.isfinite(ctx.download_aov(a)).all()
+    del cols, visits, keepv
+    torch.cuda.empty_cache()
+    return c
+
+
+def test_config3_4k_image_bokeh(orc, gpu_ctx_factory):
+    """BASELINE config 3: double-gauss + image-bokeh kernel, 3840x2160, 512 draws, beauty only."""
+    import os
+    tex = np.load(os.path.join(common.ROOT, "tests", "golden", "example_bokeh_kernel_u8.npy")).astype(np.float32) / np.float32(255)
+    tables = bokeh.build_tables(tex)
+    W, H, M = 3840, 2160, 9
+    p, model, table, keep = common.po_setup(W, H, samples_override=512, bokeh_enable_image=1)
+    bt = _abi.BokehTable()
+    bt.x, bt.y = tables["x"], tables["y"]
+    for k in ("cdfRow", "rowIndices", "cdfColumn", "columnIndices"):
+        setattr(bt, k, tables[k].ctypes.data)
+    ob = orc.orc_bokeh_from_tables(C.byref(bt))
+    ctx = gpu_ctx_factory()
+    for y0 in (0, 1079, 2157):            # top edge, centre, bottom edge of the 4K frame
+        _band_parity_at_full_geometry(orc, ctx, p, table, W, M, y0, 3, 2.0 ** -9, bokeh_tables=tables, orc_bokeh=ob)
+    orc.orc_bokeh_destroy(ob)
+    ctx.alloc_frame(1)
+    _whole_frame_bookkeeping(ctx, p, W, H, M, 512, 2.0 ** -14)
+
+
+def test_config4_4k_petzval_8_aovs(orc, gpu_ctx_factory):
+    """BASELINE config 4: petzval polynomial, 3840x2160, 1024 draws, beauty + 8 AOVs (two of them
+    closest-filtered)."""
+    W, H, M = 3840, 2160, 9
+    kinds = [0, 0, 1, 0, 0, 0, 1, 0, 0]
+    p, model, table, keep = common.po_setup(W, H, lens="petzval_58mm", samples_override=1024)
+    ctx = gpu_ctx_factory()
+    for y0 in (1, 1080):
+        _band_parity_at_full_geometry(orc, ctx, p, table, W, M, y0, 2, 2.0 ** -10, n_extra=8, kinds=kinds)
+    ctx.alloc_frame(9, kinds)
+    _whole_frame_bookkeeping(ctx, p, W, H, M, 1024, 2.0 ** -16, n_extra=8)
+
+
+def test_config5_8k_rank_partition(orc, gpu_ctx_factory):
+    """BASELINE config 5 as one of its 8 ranks sees it: 7680x4320 frame, rows r mod 8 == 3, 2048 draws."""
+    import torch
+    from pota_amd import workload
+    W, H, M, G, rank = 7680, 4320, 9, 8, 3
+    p, model, table, keep = common.po_setup(W, H, samples_override=2048)
+    ctx = gpu_ctx_factory()
+    ctx.set_params(p); ctx.set_lens(table); ctx.set_bokeh(None)
+    ctx.alloc_frame(1)
+    n_local = workload.frame_visit_count(W, H, M, G, rank)
+    dev = torch.device("cuda:0")
+    cols = workload.generate(torch, 0, n_local, W, H, M, f_hi=2.0 ** -17, focus_dist=150.0,
+                             tan_half_fov=common.tan_half_fov(p), device=dev, row_stride=G, row_offset=rank)
+    visits, keepv = capi.make_visits(cols, visits_per_pixel=M, pixels_per_row=W, pixel_y0=rank, pixel_row_stride=G,
+                                     ptr=lambda t: t.data_ptr())
+    torch.cuda.synchronize()
+    ctx.bind_visits(visits, keepv)
+    ctx.set_draw_log(0)
+    ctx.clear_frame(); ctx.redistribute(); ctx.resolve(); ctx.sync()
+    c = ctx.counters()
+    assert c.worklist_overflow == 0 and c.redistributed_visits > 50 and c.visits == n_local
+    buf, w = ctx.download_accum(0)
+    inv = float(p.inverse_sample_density)
+    expect = (n_local - c.redistributed_visits) * inv + c.accepted_draws * inv / 2048
+    assert abs(w.astype(np.float64).sum() - expect) / expect < 1e-5
+    # own visits only land on the rank's rows; splats land anywhere
+    wimg = w.reshape(p.yres, p.xres)
+    own = np.zeros(p.yres, bool); own[rank:H:G] = True
+    direct_w = M * inv
+    assert np.all(wimg[own][:, :W] >= direct_w * 0.5)
+    assert (wimg[~own] > 0).sum() > 0 and (wimg[~own] > 0).mean() < 0.5
