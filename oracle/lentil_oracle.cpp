@@ -866,12 +866,14 @@ ORC_API void orc_frame_merge(OrcFrame *dst, const OrcFrame *src) {   /* per-thre
 }
 
 /* Camera::add_to_buffer, src/lentil.h:823-851 (rgb_weight is white on this path) */
+static const float kWhite[3] = {1.0f, 1.0f, 1.0f};
+/* rgb_weight: AtRGBA * AtRGB goes through AtRGBA(const AtRGB&, float a = 1) (SDK, recalled): alpha x 1 */
 static inline void add_to_buffer(OrcFrame *F, uint32_t aov, uint32_t px, const float value[4],
-                                 float add_energy, float depth, float filter_weight) {
+                                 float add_energy, float depth, float filter_weight, const float rgb_weight[3] = kWhite) {
   if (F->kind[aov] == LENTIL_FILTER_GAUSSIAN) {
     if (aov == 0) { F->weight[px] += filter_weight; if (F->shadow) F->weight64[px] += (double)filter_weight; }
     for (int c = 0; c < 4; c++) {
-      const float add = (value[c] + add_energy) * filter_weight * 1.0f;
+      const float add = (value[c] + add_energy) * filter_weight * (c < 3 ? rgb_weight[c] : 1.0f);
       F->buffer[aov][(size_t)px * 4 + c] += add;
       if (F->shadow) F->buffer64[aov][(size_t)px * 4 + c] += (double)add;
     }
@@ -960,21 +962,39 @@ static void do_visit(const lentil_params *P, const OrcLens *L, const OrcBokeh *B
       double sensor_position[2] = {0, 0};
       const double target[3] = {-(double)cs[0] * 10.0, -(double)cs[1] * 10.0, -(double)cs[2] * 10.0};  /* :271 */
       F->ctr.attempted_draws++;
-      if (!orc_trace_ray_bw_po(P, L, B, target, sensor_position, px, py, (int)total_samples_taken,
-                               P->lambda_bw, nullptr)) { --count; continue; }
-      const double s0 = sensor_position[0] / (P->sensor_width * 0.5);                                   /* :276 */
-      const double s1 = sensor_position[1] / (P->sensor_width * 0.5) * frame_aspect_ratio_without_region;
-      const double pixel0 = (((s0 + 1.0) / 2.0) * P->xres_without_region) - P->region_min_x;            /* :277-278 */
-      const double pixel1 = (((-s1 + 1.0) / 2.0) * P->yres_without_region) - P->region_min_y;
-      if ((pixel0 >= xres) || (pixel0 < 0) || (pixel1 >= yres) || (pixel1 < 0) || (pixel0 != pixel0) ||
-          (pixel1 != pixel1)) { --count; continue; }                                                    /* :282-287 */
-      const int ix = floor(pixel0), iy = floor(pixel1);
-      const unsigned pixelnumber = ix + (iy * P->xres);                                                 /* :290, lentil.h:958-960 */
-      for (uint32_t a = 0; a < F->n_aovs; a++)                                                          /* :295-298 */
-        add_to_buffer(F, a, pixelnumber, aov_values[a], fitted_bidir_add_energy, depth,
-                      1.0f * inverse_sample_density * inv_samples);
-      F->ctr.accepted_draws++;
-      if (F->keep_log) F->log.push_back({(uint32_t)v, total_samples_taken, pixelnumber});
+      float lambda_per_sample = P->lambda_bw;                                                           /* :254, 0.55 */
+      for (int channel = -1; channel <= 1; channel++) {                                                 /* :255-268 */
+        float rgb_weight[3] = {1.0f, 1.0f, 1.0f};
+        if (P->abb_chromatic > 0.0) {
+          if (channel == -1) {
+            rgb_weight[0] = 3; rgb_weight[1] = 0; rgb_weight[2] = 0;
+            lambda_per_sample = lerpf(1.0 - P->abb_chromatic, 0.35, 0.55);
+          } else if (channel == 0) {
+            rgb_weight[0] = 0; rgb_weight[1] = 3; rgb_weight[2] = 0;
+            lambda_per_sample = 0.55;
+          } else {
+            rgb_weight[0] = 0; rgb_weight[1] = 0; rgb_weight[2] = 3;
+            lambda_per_sample = lerpf(P->abb_chromatic, 0.55, 0.85);
+          }
+        } else if (P->abb_chromatic == 0.0 && channel > -1) continue;
+        if (!orc_trace_ray_bw_po(P, L, B, target, sensor_position, px, py, (int)total_samples_taken,
+                                 lambda_per_sample, nullptr)) { --count; continue; }
+        const double s0 = sensor_position[0] / (P->sensor_width * 0.5);                                 /* :276 */
+        const double s1 = sensor_position[1] / (P->sensor_width * 0.5) * frame_aspect_ratio_without_region;
+        const double pixel0 = (((s0 + 1.0) / 2.0) * P->xres_without_region) - P->region_min_x;          /* :277-278 */
+        const double pixel1 = (((-s1 + 1.0) / 2.0) * P->yres_without_region) - P->region_min_y;
+        if ((pixel0 >= xres) || (pixel0 < 0) || (pixel1 >= yres) || (pixel1 < 0) || (pixel0 != pixel0) ||
+            (pixel1 != pixel1)) { --count; continue; }                                                  /* :282-287 */
+        const int ix = floor(pixel0), iy = floor(pixel1);
+        const unsigned pixelnumber = ix + (iy * P->xres);                                               /* :290, lentil.h:958-960 */
+        for (uint32_t a = 0; a < F->n_aovs; a++)                                                        /* :295-298 */
+          add_to_buffer(F, a, pixelnumber, aov_values[a], fitted_bidir_add_energy, depth,
+                        1.0f * inverse_sample_density * inv_samples, rgb_weight);
+        F->ctr.accepted_draws++;
+        /* chromatic mode: the channel (0..2) rides in the attempt's top two bits */
+        if (F->keep_log) F->log.push_back({(uint32_t)v, total_samples_taken | ((uint32_t)(P->abb_chromatic != 0.0 ? channel + 1 : 0) << 30),
+                                           pixelnumber});
+      }
     }
     return;
   }
@@ -1081,7 +1101,7 @@ static inline void visit_pixel(const lentil_visits *V, uint64_t v, int *px, int 
 ORC_API int orc_redistribute(const lentil_params *P, const OrcLens *L, const OrcBokeh *B, OrcFrame *F,
                              const lentil_visits *V, uint64_t v_begin, uint64_t v_end) {
   if (P->cameraType == LENTIL_THINLENS && P->abb_chromatic > 0.0f) return LENTIL_ERR_UNSUPPORTED;
-  if (P->cameraType == LENTIL_POLYNOMIAL_OPTICS && (P->abb_chromatic > 0.0f || !L)) return LENTIL_ERR_UNSUPPORTED;
+  if (P->cameraType == LENTIL_POLYNOMIAL_OPTICS && !L) return LENTIL_ERR_UNSUPPORTED;
   if (P->bokeh_enable_image && !B) return LENTIL_ERR_INVALID;
   for (uint64_t v = v_begin; v < v_end; v++) {
     int px, py;

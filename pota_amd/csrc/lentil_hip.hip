@@ -199,9 +199,9 @@ LENTIL_API int lentil_hip_set_params(lentil_hip_ctx *ctx, const lentil_params *p
   if (p->cameraType != LENTIL_THINLENS && p->cameraType != LENTIL_POLYNOMIAL_OPTICS)
     return fail(ctx, LENTIL_ERR_INVALID, "cameraType must be ThinLens or PolynomialOptics");
   if (p->xres == 0 || p->yres == 0) return fail(ctx, LENTIL_ERR_INVALID, "xres/yres must be non-zero");
-  if (p->abb_chromatic > 0.0f)
+  if (p->cameraType == LENTIL_THINLENS && p->abb_chromatic > 0.0f)
     return fail(ctx, LENTIL_ERR_UNSUPPORTED,
-                "abb_chromatic > 0 is not implemented on the GPU (per-channel traces / global xor128 state)");
+                "thin-lens abb_chromatic > 0 is not implemented on the GPU (the channel comes from the process-wide xor128 state)");
   if (p->samples_override < 0 || p->samples_override > (1 << 24))
     return fail(ctx, LENTIL_ERR_INVALID, "samples_override out of range");
   if (ctx->have_frame && (p->xres != ctx->P.xres || p->yres != ctx->P.yres))
@@ -507,7 +507,18 @@ static int grow(lentil_hip_ctx *ctx, T **p, uint64_t need) {
 }
 
 static void launch_solve(lentil_hip_ctx *ctx, const DrawArgs &da, hipStream_t st, unsigned blocks) {
-  if (da.P.cameraType == LENTIL_POLYNOMIAL_OPTICS) {
+  if (da.P.cameraType == LENTIL_POLYNOMIAL_OPTICS && da.n_channels == 3) {
+    // chromatic aberration: three wavelength channels per attempt
+    bool launched = false;
+#define LENTIL_LAUNCH_GEN(NAME)                                                                          \
+    if (!launched && ctx->use_generated && ctx->lens_hash == gen::Lens_##NAME::kTableHash) {              \
+      hipLaunchKernelGGL((solve_po_kernel<GenLens<gen::Lens_##NAME>, false, true>), dim3(blocks), dim3(256), 0, st, da); \
+      launched = true;                                                                                   \
+    }
+    LENTIL_GENERATED_LENSES(LENTIL_LAUNCH_GEN)
+#undef LENTIL_LAUNCH_GEN
+    if (!launched) hipLaunchKernelGGL((solve_po_kernel<LdsLens, true, true>), dim3(blocks), dim3(256), 0, st, da);
+  } else if (da.P.cameraType == LENTIL_POLYNOMIAL_OPTICS) {
     bool launched = false;
 #define LENTIL_LAUNCH_GEN(NAME)                                                                          \
     if (!launched && ctx->use_generated && ctx->lens_hash == gen::Lens_##NAME::kTableHash) {              \
@@ -604,8 +615,10 @@ static int enqueue_chunk_draws(lentil_hip_ctx *ctx, int ci, DrawArgs &da, int bl
   const uint32_t retries = po ? (uint32_t)(P.vignetting_retries < 0 ? 0 : P.vignetting_retries) : 0u;
   da.ctr = dctr;
   da.retries = (int32_t)retries;
-  // round 0 needs sum(samples + retries) results; a later round at most the attempts an item has left
-  const uint64_t units = 4 * c.sum_samples + (uint64_t)(2 * retries + 32) * n_items;
+  // round 0 needs sum(samples + retries) results per wavelength channel; a later round at most the attempts
+  // an item has left (chromatic mode re-solves up to `retries` results of a stalled attempt)
+  const uint64_t nch = (uint64_t)da.n_channels;
+  const uint64_t units = nch * (4 * c.sum_samples + (uint64_t)(3 * retries + 32) * n_items);
   const uint64_t max_blocks = (uint64_t)ctx->num_cu * 4;
   int rc;
   if (units <= ctx->max_pool_units) {
@@ -617,7 +630,7 @@ static int enqueue_chunk_draws(lentil_hip_ctx *ctx, int ci, DrawArgs &da, int bl
     hipLaunchKernelGGL(prep_items_kernel, dim3((unsigned)((n_items + 255) / 256)), dim3(256), 0, ch.stream, da);
     HIP_TRY(ctx, hipGetLastError());
     // enough persistent waves for the chunk's first batch, at most 4 blocks per CU
-    const uint64_t want = (c.sum_samples / 64 + n_items + 3) / 4;
+    const uint64_t want = (nch * (c.sum_samples / 64 + n_items) + 3) / 4;
     unsigned solve_blocks = (unsigned)(want < 1 ? 1 : (want > max_blocks ? max_blocks : want));
     if (ci + 1 < ctx->n_chunks && c.sum_samples < ctx->early_cap_samples) {
       // Later chunks are still being scanned and this chunk's solves are a fraction of a scan's worth of
@@ -636,7 +649,7 @@ static int enqueue_chunk_draws(lentil_hip_ctx *ctx, int ci, DrawArgs &da, int bl
   }
   // ---- too many draws for one result pool: sub-batches of items, bounded by the per-item worst case
   const uint64_t max_samples = P.samples_override > 0 ? (uint64_t)P.samples_override : 2000ull;
-  const uint64_t per_item = 4 * max_samples + 2 * retries + 32;
+  const uint64_t per_item = nch * (4 * max_samples + 3 * retries + 32);
   uint64_t batch_items = ctx->max_pool_units / per_item;
   if (batch_items < 1) return fail(ctx, LENTIL_ERR_NOMEM, "LENTIL_MAX_POOL_UNITS is too small for a single item");
   for (uint64_t i0 = 0; i0 < n_items; i0 += batch_items) {
@@ -753,6 +766,18 @@ LENTIL_API int lentil_hip_redistribute(lentil_hip_ctx *ctx) {
     // ---- draws: per chunk on its own stream
     DrawArgs da{};
     da.P = P;
+    // wavelength channels of the polynomial-optics draw loop, src/lentil_filter.cpp:254-268 (float arithmetic of
+    // linear_interpolate, src/global.h:3-5); abb_chromatic < 0 runs three white channels at 0.55, like upstream
+    da.n_channels = (P.cameraType == LENTIL_POLYNOMIAL_OPTICS && P.abb_chromatic != 0.0f) ? 3 : 1;
+    da.chroma_weights = P.abb_chromatic > 0.0f ? 1 : 0;
+    da.lambda[0] = da.lambda[1] = da.lambda[2] = (double)P.lambda_bw;
+    if (da.n_channels == 3 && da.chroma_weights) {
+      const float c = P.abb_chromatic;
+      const float p0 = (float)(1.0 - (double)c);
+      da.lambda[0] = (double)(0.35f + p0 * (0.55f - 0.35f));
+      da.lambda[1] = (double)0.55f;
+      da.lambda[2] = (double)(0.55f + c * (0.85f - 0.55f));
+    }
     da.lens = P.cameraType == LENTIL_POLYNOMIAL_OPTICS ? ctx->d_lens : nullptr;
     da.terms = ctx->d_terms;
     da.bokeh = ctx->bokeh;

@@ -406,11 +406,12 @@ struct ItemProg {         // 32 B, progress of an item across rounds
   uint32_t m_lo, m_hi;    // R(m) of the current round covers [m_lo, m_hi); any R(m < m_lo) still needed is FAIL
   uint32_t res_off;       // offset of R(m_lo) in the current round's result pool
   uint32_t last_ok;       // highest accepted attempt index
-  uint32_t pad0, pad1;
+  uint32_t splats;        // chromatic mode: accepted (attempt, channel) pairs so far
+  uint32_t pad1;
 };
 
-struct Task {             // up to 64 consecutive m of one item
-  uint32_t item, m_base, res_off, count;
+struct Task {             // up to 64 consecutive m of one item (and one wavelength channel)
+  uint32_t item, m_base, res_off, count;   // count: bits 0-7 number of m, bits 8-9 channel
 };
 
 struct DrawArgs {
@@ -435,6 +436,11 @@ struct DrawArgs {
   unsigned long long *log_count;   // shared by all chunks
   int32_t retries;         // vignetting_retries for PO, 0 for the thin lens
   int32_t parity;
+  // chromatic aberration of the polynomial-optics path (src/lentil_filter.cpp:255-268): three traces per
+  // attempt, one wavelength each; n_channels is 1 when abb_chromatic == 0
+  int32_t n_channels;
+  int32_t chroma_weights;  // abb_chromatic > 0: channel c only feeds colour component c, three-fold
+  double lambda[3];
 };
 
 struct ItemVisit {
@@ -464,21 +470,25 @@ LD_DEV ItemVisit load_item_visit(const DrawArgs &a, uint32_t item, double lens_l
 // emit the solve tasks for m in [m_lo, m_hi) of `item` into the queues of round parity `par`
 LD_DEV bool emit_tasks(const DrawArgs &a, uint32_t par, uint32_t item, uint32_t m_lo, uint32_t m_hi, uint32_t &res_off) {
   const uint32_t count = m_hi - m_lo;
-  const unsigned long long off = atomicAdd(&a.ctr->pool_used[par], (unsigned long long)count);
+  const uint32_t nch = (uint32_t)a.n_channels;
+  // channel c's results of the batch live at res_off + c * count
+  const unsigned long long off = atomicAdd(&a.ctr->pool_used[par], (unsigned long long)count * nch);
   const uint32_t nt = (count + 63u) / 64u;
-  const uint32_t tb = atomicAdd(&a.ctr->n_tasks[par], nt);
-  if (off + count > a.pool_cap || (unsigned long long)tb + nt > a.task_cap) {
+  const uint32_t tb = atomicAdd(&a.ctr->n_tasks[par], nt * nch);
+  if (off + (unsigned long long)count * nch > a.pool_cap || (unsigned long long)tb + nt * nch > a.task_cap) {
     atomicAdd(&a.ctr->overflow, 1ull);
     return false;
   }
   res_off = (uint32_t)off;
-  for (uint32_t t = 0; t < nt; ++t) {
-    Task k;
-    k.item = item;
-    k.m_base = m_lo + t * 64u;
-    k.res_off = (uint32_t)off + t * 64u;
-    k.count = (count - t * 64u) < 64u ? (count - t * 64u) : 64u;
-    a.tasks[par][tb + t] = k;
+  for (uint32_t c = 0; c < nch; ++c) {
+    for (uint32_t t = 0; t < nt; ++t) {
+      Task k;
+      k.item = item;
+      k.m_base = m_lo + t * 64u;
+      k.res_off = (uint32_t)off + c * count + t * 64u;
+      k.count = ((count - t * 64u) < 64u ? (count - t * 64u) : 64u) | (c << 8);
+      a.tasks[par][tb + c * nt + t] = k;
+    }
   }
   return true;
 }
@@ -514,16 +524,26 @@ __global__ __launch_bounds__(256) void prep_items_kernel(DrawArgs a) {
 }
 
 // ---- solve, polynomial optics ------------------------------------------------------------------
-template <class LensT, bool kTables>
+// kChroma: tasks carry a wavelength channel (src/lentil_filter.cpp:255-268); every lane then reads the lens
+// header through its own pointer into three LDS copies that differ in the lambda powers only.
+template <class LensT, bool kTables, bool kChroma = false>
 __global__ __launch_bounds__(256) void solve_po_kernel(DrawArgs a) {
   __shared__ DevTerm s_terms[kTables ? kMaxTerms : 1];
   __shared__ DevLens s_k;
+  __shared__ DevLens s_kc[kChroma ? 3 : 1];
   __shared__ float s_cdfRow[kMaxBokehRows];
   if (kTables) {
     const uint32_t nt = a.lens->n_terms;
     for (uint32_t i = threadIdx.x; i < nt; i += blockDim.x) s_terms[i] = a.terms[i];
   }
   if (threadIdx.x == 0) s_k = *a.lens;
+  if (kChroma && threadIdx.x < 3) {
+    DevLens h = *a.lens;
+    const double lam = a.lambda[threadIdx.x];
+    h.lambda_pow[0] = 1.0; h.lambda_pow[1] = lam;
+    for (uint32_t e = 2; e <= kMaxExp; ++e) h.lambda_pow[e] = ipow_u(lam, e);     // lens_ipow, like the host
+    s_kc[threadIdx.x] = h;
+  }
   const bool row_in_lds = a.P.bokeh_enable_image && a.bokeh.y <= kMaxBokehRows;
   if (row_in_lds)
     for (int i = threadIdx.x; i < a.bokeh.y; i += blockDim.x) s_cdfRow[i] = a.bokeh.cdfRow[i];
@@ -548,7 +568,8 @@ __global__ __launch_bounds__(256) void solve_po_kernel(DrawArgs a) {
   const unsigned long long lt_mask = (1ull << lane) - 1ull;
 
   // wave-uniform cursor into the current task
-  uint32_t cur_item = 0, cur_m = 0, cur_res = 0, cur_left = 0;
+  uint32_t cur_item = 0, cur_m = 0, cur_res = 0, cur_left = 0, cur_chan = 0;
+  (void)cur_chan;
   bool no_more = false;
   // per-lane solve
   bool busy = false, need_init = false;
@@ -576,7 +597,8 @@ __global__ __launch_bounds__(256) void solve_po_kernel(DrawArgs a) {
         cur_item = __builtin_amdgcn_readfirstlane(t.item);
         cur_m = __builtin_amdgcn_readfirstlane(t.m_base);
         cur_res = __builtin_amdgcn_readfirstlane(t.res_off);
-        cur_left = __builtin_amdgcn_readfirstlane(t.count);
+        cur_left = __builtin_amdgcn_readfirstlane(t.count) & 0xFFu;
+        if (kChroma) cur_chan = (__builtin_amdgcn_readfirstlane(t.count) >> 8) & 3u;
       }
       uint32_t take = n_idle - filled;
       if (take > cur_left) take = cur_left;
@@ -589,6 +611,7 @@ __global__ __launch_bounds__(256) void solve_po_kernel(DrawArgs a) {
         seed_a = hd.seed_a;
         busy = true;
         need_init = true;
+        if constexpr (kChroma) L.k = &s_kc[cur_chan];
       }
       cur_m += take; cur_res += take; cur_left -= take; filled += take;
     }
@@ -815,6 +838,169 @@ LD_DEV AcceptResult accept_item(const DrawArgs &a, AcceptShared &sh, uint32_t it
     return r;
 }
 
+// Chromatic mode (abb_chromatic != 0), src/lentil_filter.cpp:248-299: every attempt traces three
+// wavelength channels with the same aperture draws; each channel that gets through and lands inside the
+// frame is splatted (into its own colour component, three-fold, when abb_chromatic > 0), each one that
+// does not takes one off `count`, and the attempt itself adds one: count += successes - 2.  The loop
+// runs while count < samples and attempts < 5 * samples, so count can go down and an attempt is
+// executed iff the running count was below `samples` before it -- a block-wide prefix sum and the
+// first index where it reaches `samples` (steps are at most +1, so it is hit exactly).
+LD_DEV AcceptResult accept_item_chroma(const DrawArgs &a, AcceptShared &sh, uint32_t item, const ItemProg pg,
+                                       const uint32_t *res) {
+  uint32_t(*s_pix)[64] = sh.pix;
+  float *s_val = sh.val;
+  uint32_t *s_off = sh.off;
+  int *s_sum = reinterpret_cast<int *>(sh.nsucc);
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  const unsigned long long lt_mask = (1ull << lane) - 1ull;
+  const uint32_t retries = (uint32_t)a.retries;
+  const double lens_length = a.lens ? a.lens->length : 0.0;
+  const ItemVisit h = load_item_visit(a, item, lens_length);
+  const uint32_t S = h.samples, max_total = S * 5u, m_limit = max_total + retries;
+  const float ae = h.I.add_energy, w = h.w;
+  const unsigned long long zk = a.F.zkey ? closest_key(h.I.depth, visit_gid(a.V, h.visit)) : 0ull;
+  uint32_t U = 1;
+  for (uint32_t k = 0; k < a.F.n_aovs; ++k) if (!(a.F.closest_mask & (1u << k))) U += 4;
+  if (threadIdx.x < a.F.n_aovs * 4u) {
+    const uint32_t k = threadIdx.x >> 2, c = threadIdx.x & 3u;
+    if (!(a.F.closest_mask & (1u << k))) {
+      uint32_t slot = 0;
+      for (uint32_t j = 0; j < k; ++j) if (!(a.F.closest_mask & (1u << j))) slot += 4;
+      const float4 v = k == 0 ? h.rgba : a.V.extra[k - 1][h.visit];
+      const float vc = c == 0 ? v.x : (c == 1 ? v.y : (c == 2 ? v.z : v.w));
+      s_val[slot + c] = (vc + ae) * w;
+      s_off[slot + c] = 4u * k + c;
+    }
+  }
+  if (threadIdx.x == 0) { s_val[U - 1] = w; s_off[U - 1] = 4u * a.F.n_aovs; }
+  __syncthreads();
+  const uint32_t cnt = pg.m_hi - pg.m_lo;          // results per channel in this batch
+  uint32_t n = pg.n_done, last_ok = pg.last_ok, splats = pg.splats;
+  int count = (int)pg.accepted;
+  bool stalled = false;
+  while (!stalled && count < (int)S && n < max_total) {
+    const uint32_t my_i = wave * 64u + lane;
+    const uint32_t my_n = n + my_i;
+    const bool valid = my_n < max_total;
+    uint32_t code[3] = {kCodeFail, kCodeFail, kCodeFail};
+    bool unresolved = false;
+    if (valid) {
+#pragma unroll
+      for (uint32_t c = 0; c < 3; ++c) {
+        for (uint32_t t = 0; t <= retries; ++t) {
+          const uint32_t m = my_n + t;                 // m >= n_done == m_lo: a stalled batch is re-solved from n_done
+          if (m >= pg.m_hi) { unresolved = unresolved || (pg.m_hi < m_limit); break; }
+          const uint32_t r = (m < pg.m_lo) ? kCodeFail : res[pg.res_off + c * cnt + (m - pg.m_lo)];
+          if (r != kCodeFail) { code[c] = r; break; }
+        }
+      }
+    }
+    const unsigned long long umask = __ballot(valid && unresolved);
+    if (lane == 0) sh.first_u[wave] = umask ? wave * 64u + (uint32_t)__builtin_ctzll(umask) : 256u;
+    __syncthreads();
+    uint32_t limit = max_total - n < 256u ? max_total - n : 256u;
+    {
+      uint32_t fu = sh.first_u[0];
+      if (sh.first_u[1] < fu) fu = sh.first_u[1];
+      if (sh.first_u[2] < fu) fu = sh.first_u[2];
+      if (sh.first_u[3] < fu) fu = sh.first_u[3];
+      if (fu < limit) { limit = fu; stalled = true; }
+    }
+    const bool in_step = my_i < limit;
+    bool ok[3];
+    int delta = 0;
+#pragma unroll
+    for (uint32_t c = 0; c < 3; ++c) { ok[c] = in_step && code[c] < kCodeOut; delta += ok[c] ? 1 : 0; }
+    delta = in_step ? delta - 2 : 0;
+    // block-wide inclusive prefix sum of delta
+    int incl = delta;
+    for (int off = 1; off < 64; off <<= 1) {
+      const int up = __shfl_up(incl, off);
+      if ((int)lane >= off) incl += up;
+    }
+    if (lane == 63) s_sum[wave] = incl;
+    __syncthreads();
+    int before = 0;
+    for (uint32_t k = 0; k < wave; ++k) before += s_sum[k];
+    const int running = count + before + incl;                  // count after attempt my_i
+    const unsigned long long rmask = __ballot(in_step && running >= (int)S);
+    if (lane == 0) sh.top[wave] = rmask ? wave * 64u + (uint32_t)__builtin_ctzll(rmask) : 256u;
+    __syncthreads();
+    uint32_t istar = sh.top[0];
+    if (sh.top[1] < istar) istar = sh.top[1];
+    if (sh.top[2] < istar) istar = sh.top[2];
+    if (sh.top[3] < istar) istar = sh.top[3];
+    const bool reached = istar < 256u;
+    const bool executed = in_step && (!reached || my_i <= istar);
+    uint32_t my_splats = 0;
+#pragma unroll
+    for (uint32_t c = 0; c < 3; ++c) {
+      const bool take = executed && ok[c];
+      my_splats += take ? 1u : 0u;
+      const unsigned long long tmask = __ballot(take);
+      const uint32_t T = (uint32_t)__builtin_popcountll(tmask);
+      if (take) {
+        const uint32_t pix = code[c];
+        s_pix[wave][(uint32_t)__builtin_popcountll(tmask & lt_mask)] = pix;
+        if (a.F.zkey) atomicMin(a.F.zkey + pix, zk);
+        if (a.log_cap) {
+          const unsigned long long li = atomicAdd(a.log_count, 1ull);
+          if (li < a.log_cap) { a.log[li].visit = h.visit; a.log[li].attempt = my_n | (c << 30); a.log[li].pixel = pix; }
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      for (uint32_t q = lane; q < T * U; q += 64u) {
+        const uint32_t d = q / U, ch = q - d * U;
+        float val = s_val[ch];
+        if (a.chroma_weights && ch != U - 1u) {
+          const uint32_t comp = s_off[ch] & 3u;                // r, g, b, a of the AOV
+          if (comp < 3u) {
+            if (comp != c) continue;                            // rgb_weight is 0 there: nothing to add
+            val = val * 3.0f;                                   // (value + add_energy) * w * rgb_weight
+          }
+        }
+        atomicAdd(a.F.acc + (size_t)s_pix[wave][d] * a.F.stride + s_off[ch], val);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
+    // block totals: splats, and the count after the last executed attempt
+    int sp = (int)my_splats;
+    int dsum = executed ? delta : 0;
+    for (int off = 32; off > 0; off >>= 1) { sp += __shfl_down(sp, off); dsum += __shfl_down(dsum, off); }
+    __syncthreads();
+    if (lane == 0) { s_sum[wave] = sp; reinterpret_cast<int *>(sh.first_u)[wave] = dsum; }
+    __syncthreads();
+    splats += (uint32_t)(s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3]);
+    const int *s_d = reinterpret_cast<const int *>(sh.first_u);
+    count += s_d[0] + s_d[1] + s_d[2] + s_d[3];
+    if (reached) { n += istar + 1u; last_ok = n - 1u; }
+    else n += limit;
+    __syncthreads();
+  }
+  AcceptResult r;
+  r.samples = S;
+  r.prog = pg;
+  r.prog.n_done = n; r.prog.accepted = (uint32_t)count; r.prog.last_ok = last_ok; r.prog.splats = splats;
+  r.more = count < (int)S && n < max_total && pg.m_hi < m_limit && pg.m_hi > 0;
+  r.new_lo = n;            // re-solve from the stalled attempt: a channel resolved in the old batch must stay readable
+  r.new_hi = pg.m_hi;
+  if (r.more) {
+    const uint32_t remaining = S - (uint32_t)(count > 0 ? count : 0);
+    unsigned long long need = count > 0 ? ((unsigned long long)remaining * n + (uint32_t)count - 1) / (uint32_t)count
+                                        : (unsigned long long)(max_total - n);
+    need += need / 4 + 32;
+    unsigned long long n_target = (unsigned long long)n + need;
+    if (n_target > max_total) n_target = max_total;
+    uint32_t new_hi = (uint32_t)n_target + retries;
+    if (new_hi > m_limit) new_hi = m_limit;
+    r.new_hi = new_hi;
+  }
+  return r;
+}
+
 __global__ __launch_bounds__(256) void accept_kernel(DrawArgs a) {
   __shared__ uint32_t s_item;
   __shared__ AcceptShared sh;
@@ -830,7 +1016,8 @@ __global__ __launch_bounds__(256) void accept_kernel(DrawArgs a) {
     if (ai >= n_active) break;
     const uint32_t item = a.active[par][ai];
     const ItemProg pg = a.prog[item];
-    const AcceptResult r = accept_item(a, sh, item, pg, res);
+    const bool chroma = a.n_channels == 3;
+    const AcceptResult r = chroma ? accept_item_chroma(a, sh, item, pg, res) : accept_item(a, sh, item, pg, res);
     if (threadIdx.x == 0) {
       if (r.more) {
         uint32_t off = 0;
@@ -844,9 +1031,9 @@ __global__ __launch_bounds__(256) void accept_kernel(DrawArgs a) {
         }
       } else {
         // total_samples_taken when the reference's loop ends, src/lentil_filter.cpp:248
-        tot_attempted += (r.prog.accepted >= r.samples) ? (unsigned long long)r.prog.last_ok + 1ull
-                                                         : (unsigned long long)r.samples * 5ull;
-        tot_accepted += r.prog.accepted;
+        tot_attempted += ((int)r.prog.accepted >= (int)r.samples) ? (unsigned long long)r.prog.last_ok + 1ull
+                                                                   : (unsigned long long)r.samples * 5ull;
+        tot_accepted += chroma ? r.prog.splats : r.prog.accepted;
       }
     }
   }
