@@ -149,29 +149,51 @@ def main():
     ctx.set_params(p)
     ctx.set_lens(table)
     ctx.alloc_frame(1 + args.aovs)
-    engine = distributed.HipEngine(ctx)
-    n_local = workload.frame_visit_count(W, H, M, world, rank)
+    engine = distributed.HipEngine(ctx, rows=p.yres)
+    # N > 1: every rank owns a band of consecutive rows (its visits and its tile of the output) and sends the
+    # rows its draws touched outside the band to their owners; LENTIL_PARTITION=interleaved selects rows
+    # r mod N with one sum all-reduce over the whole frame instead
+    tiled = (world > 1 or force_dist) and os.environ.get("LENTIL_PARTITION", "bands") != "interleaved"
+    if tiled:
+        band = distributed.band_of(rank, world, H, p.yres)
+        v_begin, v_end = band[0] * W * M, min(band[1], H) * W * M
+        n_local = v_end - v_begin
+    else:
+        n_local = workload.frame_visit_count(W, H, M, world, rank)
     bytes_per_visit = 80 + 16 * args.aovs
 
     def bind(f_hi):
-        cols = workload.generate(torch, 0, n_local, W, H, M, f_hi=f_hi, focus_dist=150.0, tan_half_fov=tan_half_fov,
-                                 n_extra=args.aovs, device=dev, row_stride=world, row_offset=rank)
-        torch.cuda.synchronize()
-        v, kv = capi.make_visits(cols, visits_per_pixel=M, pixels_per_row=W, pixel_y0=rank, pixel_row_stride=world,
-                                 ptr=lambda t: t.data_ptr())
+        if tiled:
+            cols = workload.generate(torch, v_begin, v_end, W, H, M, f_hi=f_hi, focus_dist=150.0,
+                                     tan_half_fov=tan_half_fov, n_extra=args.aovs, device=dev)
+            torch.cuda.synchronize()
+            v, kv = capi.make_visits(cols, visits_per_pixel=M, pixels_per_row=W, pixel_y0=band[0],
+                                     ptr=lambda t: t.data_ptr())
+        else:
+            cols = workload.generate(torch, 0, n_local, W, H, M, f_hi=f_hi, focus_dist=150.0, tan_half_fov=tan_half_fov,
+                                     n_extra=args.aovs, device=dev, row_stride=world, row_offset=rank)
+            torch.cuda.synchronize()
+            v, kv = capi.make_visits(cols, visits_per_pixel=M, pixels_per_row=W, pixel_y0=rank, pixel_row_stride=world,
+                                     ptr=lambda t: t.data_ptr())
         ctx.bind_visits(v, kv)
         return cols
 
+    def step():
+        if tiled:
+            distributed.frame_step_bands(engine, dist, H, p.yres)
+        else:
+            distributed.frame_step(engine, dist)
+
     def run(steps, warmup):
         for _ in range(warmup):
-            distributed.frame_step(engine, dist)
+            step()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         scan_ms = draw_ms = res_ms = 0.0
         for _ in range(steps):
-            distributed.frame_step(engine, dist)
+            step()
             # HIP-event times of this step's kernels (the call waits for the step's stream work, which
             # the step would have to finish anyway before the next clear)
             a, b, c = ctx.last_timing()
@@ -206,12 +228,14 @@ def main():
         "dtype": "f64", "data": "synthetic",
         "config": {
             "workload": "polynomial-optics %s (self-fitted table), %dx%d per GPU, %d visits/pixel, %d redistribution "
-                        "draws per redistributed visit, %d AOV(s), highlight fraction f_hi=%.3g, rows interleaved over %d GPU(s)"
+                        "draws per redistributed visit, %d AOV(s), highlight fraction f_hi=%.3g, frame rows split over %d GPU(s)"
                         % (args.lens, W, Hr, M, args.samples, 1 + args.aovs, args.f_hi, world),
             "visits_per_gpu": n_local, "bytes_per_visit": bytes_per_visit,
             "redistributed_visits_rank0": int(ctr.redistributed_visits),
             "attempted_draws_rank0": int(ctr.attempted_draws), "accepted_draws_rank0": int(ctr.accepted_draws),
-            "parallelism": "rows%%%d + allreduce" % world if world > 1 else "single GPU",
+            "parallelism": ("single GPU" if world == 1 else
+                            "%d row bands, rows touched outside a band sent to its owner (p2p), tiled output" % world if tiled else
+                            "rows%%%d + allreduce" % world),
         },
         "kernels_ms": {"scan": round(scan_ms, 4), "draw": round(draw_ms, 4), "resolve": round(res_ms, 4)},
         "roofline": {

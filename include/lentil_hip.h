@@ -287,10 +287,29 @@ int lentil_hip_download_accum(lentil_hip_ctx *ctx, uint32_t aov, float *host_rgb
  * calls lentil_hip_closest_gather on each: a GPU writes the values of the winners it owns and leaves the
  * others zero, so the sum all-reduce of lentil_hip_accum_buffer completes the closest AOVs too.
  * Frame-wide visit ids: uniform streams derive them from pixel_y0 / pixel_row_stride (the id a single
- * process walking the whole frame would give the visit); ragged streams use visit_id_base + index. */
+ * process walking the whole frame would give the visit -- row bands and row-interleaved partitions alike);
+ * ragged streams use visit_id_base + index. */
 int lentil_hip_set_closest_exchange(lentil_hip_ctx *ctx, int deferred, uint32_t visit_id_base);
 int lentil_hip_zkey_buffer(lentil_hip_ctx *ctx, void **device_ptr, uint64_t *n_keys);
 int lentil_hip_closest_gather(lentil_hip_ctx *ctx);
+
+/* --- multi-GPU, tiled output (BASELINE north_star: "the output frame tiles across the GPUs,
+ * cross-tile splat contributions are exchanged") ------------------------------------------------------
+ * Every GPU processes the visits of its band of rows into full-frame accumulators; what its draws add
+ * outside the band belongs to the band's owner.
+ * touched_rows : [row_lo, row_hi) of the frame the last redistribute added anything to (own visits and
+ *                splats; 0,0 when nothing).  Also lets the next clear_frame wipe only those rows.
+ * merge_rows   : merges n_rows rows, starting at row_begin, of another GPU's accumulator block (device
+ *                memory, same record layout: xres * stride floats per row; stride = n_floats of
+ *                accum_buffer / (xres * yres)) into this frame: gaussian slots and the weight add up,
+ *                closest-filtered slots follow the smaller winner key (dev_key_rows: the matching rows of
+ *                the sender's lentil_hip_zkey_buffer, required iff the frame has closest AOVs; the sender
+ *                must have gathered its local winners, i.e. not be in deferred mode).
+ * resolve_rows : lentil_hip_resolve restricted to a band of rows. */
+int lentil_hip_touched_rows(lentil_hip_ctx *ctx, int32_t *row_lo, int32_t *row_hi);
+int lentil_hip_merge_rows(lentil_hip_ctx *ctx, uint32_t row_begin, uint32_t n_rows, const void *dev_acc_rows,
+                          const void *dev_key_rows);
+int lentil_hip_resolve_rows(lentil_hip_ctx *ctx, uint32_t row_begin, uint32_t n_rows);
 
 /* --- multi-GPU ---------------------------------------------------------------------
  * accum_buffer: device pointer + float count of the contiguous accumulator block (one record per

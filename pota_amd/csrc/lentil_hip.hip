@@ -71,6 +71,10 @@ struct lentil_hip_ctx {
   uint64_t max_pool_units = 1ull << 32;    // 16 GiB per pool at most (LENTIL_MAX_POOL_UNITS overrides)
   int last_rounds = 0;
   uint32_t last_scan_launches = 0;
+  // rows that may be non-zero since the last clear_frame (only trusted when dirty_known)
+  int32_t dirty_lo = 0, dirty_hi = 0;
+  bool dirty_known = false;
+  bool pass_pending = false;         // a redistribute ran whose rows have not been asked for yet
   bool closest_deferred = false;     // multi-GPU: the caller min-reduces the keys before the gather
   uint32_t visit_id_base = 0;
   DevCounters *d_ctr = nullptr;
@@ -379,6 +383,7 @@ LENTIL_API int lentil_hip_alloc_frame(lentil_hip_ctx *ctx, uint32_t n_aovs, cons
   }
   ctx->have_frame = true;
   HIP_TRY(ctx, hipMemsetAsync(ctx->F.acc, 0, nfl * sizeof(float), ctx->stream));
+  ctx->dirty_lo = ctx->dirty_hi = 0; ctx->dirty_known = true; ctx->pass_pending = false;
   return LENTIL_OK;
 }
 
@@ -394,9 +399,10 @@ static int check_visits(lentil_hip_ctx *ctx, const lentil_visits *v) {
     return fail(ctx, LENTIL_ERR_INVALID, "visits_per_pixel == 0 needs the per-visit pixel array");
   if (v->visits_per_pixel && (v->pixels_per_row == 0 || v->pixel_row_stride == 0))
     return fail(ctx, LENTIL_ERR_INVALID, "pixels_per_row / pixel_row_stride must be non-zero");
-  if (v->visits_per_pixel && v->pixel_row_stride > 1) {
+  if (v->visits_per_pixel && v->pixel_row_stride > 1 && v->pixel_y0 < 0)
+    return fail(ctx, LENTIL_ERR_INVALID, "pixel_y0 < 0 with a row-interleaved partition");
+  if (v->visits_per_pixel && v->pixel_y0 >= 0) {
     // frame-wide visit ids (closest AOV tie-break) are 32 bits: (last row + 1) * visits per row
-    if (v->pixel_y0 < 0) return fail(ctx, LENTIL_ERR_INVALID, "pixel_y0 < 0 with a row-interleaved partition");
     const uint64_t row_visits = (uint64_t)v->pixels_per_row * v->visits_per_pixel;
     const uint64_t rows = (v->n + row_visits - 1) / row_visits;
     if (((uint64_t)v->pixel_y0 + rows * v->pixel_row_stride) * row_visits > 0xFFFFFFFFull)
@@ -492,9 +498,22 @@ LENTIL_API int lentil_hip_clear_frame(lentil_hip_ctx *ctx) {
   CHECK_CTX(ctx);
   if (!ctx->have_frame) return fail(ctx, LENTIL_ERR_INVALID, "no frame allocated");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
-  const uint64_t nfl = ctx->F.np * ctx->F.stride;
-  HIP_TRY(ctx, hipMemsetAsync(ctx->F.acc, 0, nfl * sizeof(float), ctx->stream));
-  if (ctx->F.zkey) HIP_TRY(ctx, hipMemsetAsync(ctx->F.zkey, 0xFF, ctx->F.np * sizeof(unsigned long long), ctx->stream));
+  // rows known to hold everything added since the last clear (lentil_hip_touched_rows was asked after the
+  // pass): wipe only those; otherwise the whole frame
+  uint64_t p0 = 0, p1 = ctx->F.np;
+  if (ctx->dirty_known && !ctx->pass_pending) {
+    p0 = (uint64_t)(ctx->dirty_lo < 0 ? 0 : ctx->dirty_lo) * ctx->P.xres;
+    p1 = (uint64_t)(ctx->dirty_hi < ctx->dirty_lo ? ctx->dirty_lo : ctx->dirty_hi) * ctx->P.xres;
+    if (p1 > ctx->F.np) p1 = ctx->F.np;
+    if (p0 > p1) p0 = p1;
+  }
+  if (p1 > p0) {
+    HIP_TRY(ctx, hipMemsetAsync(ctx->F.acc + p0 * ctx->F.stride, 0, (p1 - p0) * ctx->F.stride * sizeof(float), ctx->stream));
+    if (ctx->F.zkey) HIP_TRY(ctx, hipMemsetAsync(ctx->F.zkey + p0, 0xFF, (p1 - p0) * sizeof(unsigned long long), ctx->stream));
+  }
+  ctx->dirty_lo = ctx->dirty_hi = 0;
+  ctx->dirty_known = true;      // clean frame: nothing is dirty
+  ctx->pass_pending = false;
   return LENTIL_OK;
 }
 
@@ -686,6 +705,8 @@ LENTIL_API int lentil_hip_redistribute(lentil_hip_ctx *ctx) {
     return fail(ctx, LENTIL_ERR_INVALID, "visit stream carries a different number of AOVs than the frame");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   const int C = ctx->n_chunks;
+  if (ctx->pass_pending) ctx->dirty_known = false;   // an earlier pass's rows were never asked for: unknown until a full clear
+  ctx->pass_pending = true;
   HIP_TRY(ctx, hipMemsetAsync(ctx->d_ctr, 0, sizeof(DevCounters) * (C + 1), ctx->stream));
   HIP_TRY(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
   ctx->last_rounds = 0;
@@ -842,19 +863,106 @@ LENTIL_API int lentil_hip_closest_gather(lentil_hip_ctx *ctx) {
   return LENTIL_OK;
 }
 
+static int resolve_range(lentil_hip_ctx *ctx, uint64_t p_begin, uint64_t p_end) {
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  HIP_TRY(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
+  const uint64_t total = p_end - p_begin;
+  if (total) {
+    uint64_t blocks = (total + 255) / 256;
+    const uint64_t max_blocks = (uint64_t)ctx->num_cu * 8;
+    if (blocks > max_blocks) blocks = max_blocks;
+    hipLaunchKernelGGL(resolve_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, ctx->F, ctx->d_resolved, p_begin, p_end);
+    HIP_TRY(ctx, hipGetLastError());
+  }
+  HIP_TRY(ctx, hipEventRecord(ctx->ev[4], ctx->stream));
+  ctx->timed_resolve = true;
+  return LENTIL_OK;
+}
+
 LENTIL_API int lentil_hip_resolve(lentil_hip_ctx *ctx) {
   CHECK_CTX(ctx);
   if (!ctx->have_frame) return fail(ctx, LENTIL_ERR_INVALID, "no frame allocated");
+  return resolve_range(ctx, 0, ctx->F.np);
+}
+
+static int check_rows(lentil_hip_ctx *ctx, uint32_t row_begin, uint32_t n_rows) {
+  if (!ctx->have_frame) return fail(ctx, LENTIL_ERR_INVALID, "no frame allocated");
+  if ((uint64_t)row_begin + n_rows > (uint64_t)ctx->P.yres) return fail(ctx, LENTIL_ERR_INVALID, "row range exceeds the frame");
+  return LENTIL_OK;
+}
+
+LENTIL_API int lentil_hip_resolve_rows(lentil_hip_ctx *ctx, uint32_t row_begin, uint32_t n_rows) {
+  CHECK_CTX(ctx);
+  const int rc = check_rows(ctx, row_begin, n_rows);
+  if (rc) return rc;
+  return resolve_range(ctx, (uint64_t)row_begin * ctx->P.xres, (uint64_t)(row_begin + n_rows) * ctx->P.xres);
+}
+
+LENTIL_API int lentil_hip_merge_rows(lentil_hip_ctx *ctx, uint32_t row_begin, uint32_t n_rows, const void *dev_acc_rows,
+                                     const void *dev_key_rows) {
+  CHECK_CTX(ctx);
+  int rc = check_rows(ctx, row_begin, n_rows);
+  if (rc) return rc;
+  if (!n_rows) return LENTIL_OK;
+  if (!dev_acc_rows) return fail(ctx, LENTIL_ERR_INVALID, "dev_acc_rows is null");
+  if (ctx->F.zkey && !dev_key_rows) return fail(ctx, LENTIL_ERR_INVALID, "the frame has closest-filtered AOVs: key rows are required");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
-  HIP_TRY(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
-  const uint64_t total = ctx->F.np;
-  uint64_t blocks = (total + 255) / 256;
+  const uint64_t p_begin = (uint64_t)row_begin * ctx->P.xres, n_pix = (uint64_t)n_rows * ctx->P.xres;
+  uint64_t blocks = (n_pix * ctx->F.stride + 255) / 256;
   const uint64_t max_blocks = (uint64_t)ctx->num_cu * 8;
   if (blocks > max_blocks) blocks = max_blocks;
-  hipLaunchKernelGGL(resolve_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, ctx->F, ctx->d_resolved);
+  hipLaunchKernelGGL(merge_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, ctx->F, p_begin, n_pix,
+                     (const float *)dev_acc_rows, ctx->F.zkey ? (const unsigned long long *)dev_key_rows : nullptr);
   HIP_TRY(ctx, hipGetLastError());
-  HIP_TRY(ctx, hipEventRecord(ctx->ev[4], ctx->stream));
-  ctx->timed_resolve = true;
+  if (ctx->F.zkey) {
+    uint64_t kb = (n_pix + 255) / 256;
+    if (kb > max_blocks) kb = max_blocks;
+    hipLaunchKernelGGL(merge_keys_kernel, dim3((unsigned)kb), dim3(256), 0, ctx->stream, ctx->F, p_begin, n_pix,
+                       (const unsigned long long *)dev_key_rows);
+    HIP_TRY(ctx, hipGetLastError());
+  }
+  if (ctx->dirty_known) {
+    if ((int32_t)row_begin < ctx->dirty_lo || ctx->dirty_hi <= ctx->dirty_lo) ctx->dirty_lo = (int32_t)row_begin;
+    if ((int32_t)(row_begin + n_rows) > ctx->dirty_hi) ctx->dirty_hi = (int32_t)(row_begin + n_rows);
+  }
+  return LENTIL_OK;
+}
+
+LENTIL_API int lentil_hip_touched_rows(lentil_hip_ctx *ctx, int32_t *row_lo, int32_t *row_hi) {
+  CHECK_CTX(ctx);
+  if (!ctx->have_frame) return fail(ctx, LENTIL_ERR_INVALID, "no frame allocated");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  std::vector<DevCounters> c((size_t)ctx->n_chunks);
+  HIP_TRY(ctx, hipMemcpy(c.data(), ctx->d_ctr, sizeof(DevCounters) * (size_t)ctx->n_chunks, hipMemcpyDeviceToHost));
+  int64_t lo = INT32_MAX, hi = 0;
+  for (const DevCounters &k : c) {
+    if (!k.row_max_p1) continue;
+    const int64_t l = 0x7FFFFFFFll - (int64_t)k.inv_row_min;
+    if (l < lo) lo = l;
+    if ((int64_t)k.row_max_p1 > hi) hi = (int64_t)k.row_max_p1;
+  }
+  // a uniform stream adds every non-redistributed visit to its own pixel: the rows of the stream itself
+  const VisitsDev &vh = ctx->V;
+  if (vh.n && vh.visits_per_pixel) {
+    const uint64_t row_visits = (uint64_t)vh.pixels_per_row * vh.visits_per_pixel;
+    const uint64_t rows = (vh.n + row_visits - 1) / row_visits;
+    const int64_t l = vh.pixel_y0, h = (int64_t)vh.pixel_y0 + (int64_t)(rows - 1) * vh.pixel_row_stride + 1;
+    if (l < lo) lo = l;
+    if (h > hi) hi = h;
+  }
+  if (hi <= lo) { lo = 0; hi = 0; }
+  if (hi > (int64_t)ctx->P.yres) hi = ctx->P.yres;
+  if (lo < 0) lo = 0;
+  if (row_lo) *row_lo = (int32_t)lo;
+  if (row_hi) *row_hi = (int32_t)hi;
+  // everything added since the last clear lies in these rows: the next clear_frame only has to wipe them
+  if (ctx->dirty_known && ctx->dirty_hi > ctx->dirty_lo) {
+    if (ctx->dirty_lo < lo) lo = ctx->dirty_lo;
+    if (ctx->dirty_hi > hi) hi = ctx->dirty_hi;
+  }
+  ctx->dirty_lo = (int32_t)lo; ctx->dirty_hi = (int32_t)hi;
+  ctx->pass_pending = false;
   return LENTIL_OK;
 }
 

@@ -35,8 +35,22 @@ struct DevCounters {
   unsigned int n_active[2];
   unsigned int active_head[2];
   unsigned long long pool_used[2];
-  unsigned int pad_q;
+  // rows of the frame this pass has added to (zero-initialised: "none"): max over (INT_MAX - row), max over (row + 1)
+  unsigned int inv_row_min, row_max_p1;
 };
+
+// per-thread running row range -> one pair of atomics per wave
+LD_DEV void flush_row_range(DevCounters *ctr, uint32_t rmin, uint32_t rmax_p1) {
+  for (int off = 32; off > 0; off >>= 1) {
+    const uint32_t a = __shfl_down(rmin, off), b = __shfl_down(rmax_p1, off);
+    rmin = a < rmin ? a : rmin;
+    rmax_p1 = b > rmax_p1 ? b : rmax_p1;
+  }
+  if ((threadIdx.x & 63u) == 0u && rmax_p1) {
+    atomicMax(&ctr->inv_row_min, 0x7FFFFFFFu - rmin);
+    atomicMax(&ctr->row_max_p1, rmax_p1);
+  }
+}
 
 struct VisitsDev {
   uint64_t n;
@@ -54,14 +68,14 @@ struct VisitsDev {
 // in.  Closest-filtered AOVs break depth ties by it (the later visit wins, src/lentil.h:833), so every
 // GPU of a row-interleaved partition must number its visits like the undivided stream does.
 LD_DEV uint32_t visit_gid(const VisitsDev &V, uint32_t v) {
-  if (V.visits_per_pixel == 0 || V.pixel_row_stride <= 1) return V.id_base + v;
+  if (V.visits_per_pixel == 0 || V.pixel_y0 < 0) return V.id_base + v;
   const uint32_t row_visits = V.pixels_per_row * V.visits_per_pixel;
   const uint32_t ly = v / row_visits;
   return ((uint32_t)V.pixel_y0 + ly * V.pixel_row_stride) * row_visits + (v - ly * row_visits);
 }
 // inverse; false when the visit belongs to another GPU's partition
 LD_DEV bool visit_from_gid(const VisitsDev &V, uint32_t gid, uint32_t &v) {
-  if (V.visits_per_pixel == 0 || V.pixel_row_stride <= 1) {
+  if (V.visits_per_pixel == 0 || V.pixel_y0 < 0) {
     v = gid - V.id_base;
     return gid >= V.id_base && (uint64_t)v < V.n;
   }
@@ -327,6 +341,7 @@ __global__ __launch_bounds__(256) void scan_ragged_kernel(ScanArgs a) {
   wq.init(s_queue + (threadIdx.x >> 6) * kWaveQueue);
   const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
   const uint64_t n_round = a.v_begin + ((a.v_end - a.v_begin + 63ull) & ~63ull);
+  uint32_t rmin = 0x7FFFFFFFu, rmax_p1 = 0u;
   for (uint64_t v = a.v_begin + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; v < n_round; v += stride) {
     bool flagged = false;
     int samples = 0;
@@ -341,6 +356,8 @@ __global__ __launch_bounds__(256) void scan_ragged_kernel(ScanArgs a) {
       } else {
         int px, py;
         visit_pixel(V, v, px, py);
+        rmin = (uint32_t)py < rmin ? (uint32_t)py : rmin;
+        rmax_p1 = (uint32_t)py + 1u > rmax_p1 ? (uint32_t)py + 1u : rmax_p1;
         const uint64_t lin = (uint64_t)px + (uint64_t)py * a.P.xres;
         const float w = 1.0f * invd;
         float *d = reinterpret_cast<float *>(a.F.aov(lin, 0));
@@ -364,6 +381,7 @@ __global__ __launch_bounds__(256) void scan_ragged_kernel(ScanArgs a) {
     wq.push(flagged, (uint32_t)v, (uint32_t)samples, a.work, a.work_cap, a.ctr);
   }
   wq.finish(a.work, a.work_cap, a.ctr);
+  flush_row_range(a.ctr, rmin, rmax_p1);
 }
 // ---------------------------------------------------------------------------------------
 // K3/K4/K5: draws -- "solve once".
@@ -713,7 +731,8 @@ struct AcceptResult {
 };
 
 // Processes the current result batch of `item` (block-cooperative; must be called by all 256 threads).
-LD_DEV AcceptResult accept_item(const DrawArgs &a, AcceptShared &sh, uint32_t item, const ItemProg pg, const uint32_t *res) {
+LD_DEV AcceptResult accept_item(const DrawArgs &a, AcceptShared &sh, uint32_t item, const ItemProg pg, const uint32_t *res,
+                                uint32_t &rmin, uint32_t &rmax_p1) {
   uint32_t *s_first_u = sh.first_u, *s_nsucc = sh.nsucc, *s_top = sh.top;
   uint32_t(*s_pix)[64] = sh.pix;
   float *s_val = sh.val;
@@ -785,6 +804,9 @@ LD_DEV AcceptResult accept_item(const DrawArgs &a, AcceptShared &sh, uint32_t it
       const uint32_t T = (uint32_t)__builtin_popcountll(tmask0);
       if (take) {
         const uint32_t pix = code;
+        const uint32_t row = pix / a.P.xres;
+        rmin = row < rmin ? row : rmin;
+        rmax_p1 = row + 1u > rmax_p1 ? row + 1u : rmax_p1;
         s_pix[wave][(uint32_t)__builtin_popcountll(tmask0 & lt_mask)] = pix;
         if (a.F.zkey) atomicMin(a.F.zkey + pix, zk);
         if (a.log_cap) {
@@ -846,7 +868,7 @@ LD_DEV AcceptResult accept_item(const DrawArgs &a, AcceptShared &sh, uint32_t it
 // executed iff the running count was below `samples` before it -- a block-wide prefix sum and the
 // first index where it reaches `samples` (steps are at most +1, so it is hit exactly).
 LD_DEV AcceptResult accept_item_chroma(const DrawArgs &a, AcceptShared &sh, uint32_t item, const ItemProg pg,
-                                       const uint32_t *res) {
+                                       const uint32_t *res, uint32_t &rmin, uint32_t &rmax_p1) {
   uint32_t(*s_pix)[64] = sh.pix;
   float *s_val = sh.val;
   uint32_t *s_off = sh.off;
@@ -941,6 +963,9 @@ LD_DEV AcceptResult accept_item_chroma(const DrawArgs &a, AcceptShared &sh, uint
       const uint32_t T = (uint32_t)__builtin_popcountll(tmask);
       if (take) {
         const uint32_t pix = code[c];
+        const uint32_t row = pix / a.P.xres;
+        rmin = row < rmin ? row : rmin;
+        rmax_p1 = row + 1u > rmax_p1 ? row + 1u : rmax_p1;
         s_pix[wave][(uint32_t)__builtin_popcountll(tmask & lt_mask)] = pix;
         if (a.F.zkey) atomicMin(a.F.zkey + pix, zk);
         if (a.log_cap) {
@@ -1008,6 +1033,7 @@ __global__ __launch_bounds__(256) void accept_kernel(DrawArgs a) {
   const uint32_t n_active = a.ctr->n_active[par];
   const uint32_t *res = a.pool[par];
   unsigned long long tot_attempted = 0, tot_accepted = 0;
+  uint32_t rmin = 0x7FFFFFFFu, rmax_p1 = 0u;       // rows this thread's accepted draws went to
   while (true) {
     __syncthreads();
     if (threadIdx.x == 0) s_item = atomicAdd(&a.ctr->active_head[par], 1u);
@@ -1017,7 +1043,8 @@ __global__ __launch_bounds__(256) void accept_kernel(DrawArgs a) {
     const uint32_t item = a.active[par][ai];
     const ItemProg pg = a.prog[item];
     const bool chroma = a.n_channels == 3;
-    const AcceptResult r = chroma ? accept_item_chroma(a, sh, item, pg, res) : accept_item(a, sh, item, pg, res);
+    const AcceptResult r = chroma ? accept_item_chroma(a, sh, item, pg, res, rmin, rmax_p1)
+                                  : accept_item(a, sh, item, pg, res, rmin, rmax_p1);
     if (threadIdx.x == 0) {
       if (r.more) {
         uint32_t off = 0;
@@ -1041,6 +1068,7 @@ __global__ __launch_bounds__(256) void accept_kernel(DrawArgs a) {
     if (tot_attempted) atomicAdd(&a.ctr->attempted, tot_attempted);
     if (tot_accepted) atomicAdd(&a.ctr->accepted, tot_accepted);
   }
+  flush_row_range(a.ctr, rmin, rmax_p1);
 }
 
 // closest-filter AOVs: copy the winning visit's value into AOVData::buffer (src/lentil.h:835)
@@ -1057,11 +1085,42 @@ __global__ __launch_bounds__(256) void closest_gather_kernel(FrameDev F, VisitsD
   }
 }
 
+// Multi-GPU tiles: rows of another GPU's accumulators (same record layout) are merged into
+// this GPU's: gaussian slots and the weight add up; closest-filtered slots follow the smaller winner key.
+// The keys themselves are merged by a second launch (every float of a pixel reads both keys first).
+__global__ __launch_bounds__(256) void merge_rows_kernel(FrameDev F, uint64_t p_begin, uint64_t n_pix,
+                                                         const float *src, const unsigned long long *src_keys) {
+  const uint64_t total = n_pix * F.stride;
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  const uint32_t used = 4u * F.n_aovs + 1u;
+  for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
+    const uint64_t i = t / F.stride;
+    const uint32_t j = (uint32_t)(t - i * F.stride);
+    if (j >= used) continue;
+    float *dst = F.acc + (p_begin + i) * F.stride + j;
+    const uint32_t aov = j >> 2;
+    if (j < 4u * F.n_aovs && (F.closest_mask & (1u << aov))) {
+      if (src_keys && src_keys[i] < F.zkey[p_begin + i]) *dst = src[t];
+    } else {
+      *dst += src[t];
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void merge_keys_kernel(FrameDev F, uint64_t p_begin, uint64_t n_pix,
+                                                         const unsigned long long *src_keys) {
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_pix; i += stride) {
+    const unsigned long long k = src_keys[i];
+    if (k < F.zkey[p_begin + i]) F.zkey[p_begin + i] = k;
+  }
+}
+
 // K7 -- driver_process_bucket's normalisation, src/lentil_imager.cpp:169-186.  Reads the pixel records,
 // writes one planar RGBA image per AOV (what the imager copies into Arnold's buckets).
-__global__ __launch_bounds__(256) void resolve_kernel(FrameDev F, float *resolved) {
+__global__ __launch_bounds__(256) void resolve_kernel(FrameDev F, float *resolved, uint64_t p_begin, uint64_t p_end) {
   const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-  for (uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; p < F.np; p += stride) {
+  for (uint64_t p = p_begin + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; p < p_end; p += stride) {
     const float wt = *F.wt(p);
     const float inv = wt != 0.0f ? 1.0f / wt : 1.0f;        // AtRGBA /= float multiplies by 1.0f/f
     for (uint32_t a = 0; a < F.n_aovs; ++a) {

@@ -9,6 +9,14 @@ before the sum: the per-pixel winner keys (|Z| bits, then the later frame-wide v
 every rank then writes the values of the winners it owns into otherwise zero accumulator slots, and the
 sum all-reduce carries them to everybody.
 
+Tiled output (`frame_step_bands`, the default of bench.py for N > 1): rank r owns a band of consecutive
+rows -- its visits and its part of the output.  A draw lands within a bokeh radius of its visit, so
+what a rank adds outside its band is confined to a few rows next to it.  After the pass the ranks tell
+each other which rows they touched (one tiny all-gather), send exactly those foreign rows to their
+owners (point-to-point over xGMI, neighbours only in practice) and each owner merges what it receives
+(`lentil_hip_merge_rows`: sums, and the smaller winner key for closest-filtered AOVs) and resolves its
+band.  The exchanged volume is 2 x reach x row size per rank instead of the whole frame.
+
 The step logic is engine-agnostic so that the N>1 path is covered by world_size-2 gloo tests on
 CPU (tests/test_multi_gpu.py); the product engine is HipEngine (liblentil_hip.so).
 """
@@ -30,10 +38,12 @@ class _CudaArrayView:
 class HipEngine:
     """Adapter: capi.Context -> the interface frame_step() drives."""
 
-    def __init__(self, ctx):
+    def __init__(self, ctx, rows=None):
         import torch
         self.ctx = ctx
+        self.rows = rows             # yres of the frame (needed for the row views of the tiled mode)
         dev = torch.device("cuda", torch.cuda.current_device())
+        self.device = dev
         ptr, n = ctx.accum_buffer()
         self._view = _CudaArrayView(ptr, n)
         self.accum = torch.as_tensor(self._view, device=dev)
@@ -45,6 +55,25 @@ class HipEngine:
             self._kview = _CudaArrayView(kptr, kn, "<i8")
             self.zkey = torch.as_tensor(self._kview, device=dev)
             assert self.zkey.data_ptr() == kptr and self.zkey.numel() == kn
+
+    # ---- tiled output: row views of the accumulator block / key buffer, merge, band resolve
+    def touched_rows(self):
+        return self.ctx.touched_rows()
+
+    def acc_rows(self, lo, hi):
+        per_row = self.accum.numel() // self.rows
+        return self.accum[lo * per_row:hi * per_row]
+
+    def key_rows(self, lo, hi):
+        per_row = self.zkey.numel() // self.rows
+        return self.zkey[lo * per_row:hi * per_row]
+
+    def merge_rows(self, lo, acc, keys):
+        per_row = self.accum.numel() // self.rows
+        self.ctx.merge_rows(lo, acc.numel() // per_row, acc.data_ptr(), keys.data_ptr() if keys is not None else None)
+
+    def resolve_rows(self, lo, hi):
+        self.ctx.resolve_rows(lo, hi - lo)
 
     def set_deferred_closest(self, on):
         self.ctx.set_closest_exchange(on)
@@ -107,3 +136,58 @@ def frame_step(engine, dist=None):
         dist.all_reduce(engine.accum, op=dist.ReduceOp.SUM)
         engine.before_resolve()
     engine.resolve()
+
+
+def band_of(rank, world, visit_rows, frame_rows):
+    """Rows [lo, hi) of the frame owned by `rank`: consecutive visit rows split evenly; the last band also owns the
+    rows beyond the visits (the reference allocates yres = H + 1, src/lentil.h:1069-1080)."""
+    lo = visit_rows * rank // world
+    hi = visit_rows * (rank + 1) // world
+    if rank == world - 1:
+        hi = frame_rows
+    return lo, hi
+
+
+def frame_step_bands(engine, dist, visit_rows, frame_rows):
+    """One pass with tiled output: redistribute the rank's band, exchange the rows touched outside the own band with
+    their owners, merge what arrives, resolve the own band.  Returns the band."""
+    import torch
+    world, rank = dist.get_world_size(), dist.get_rank()
+    zkey = getattr(engine, "zkey", None)
+    if zkey is not None:
+        engine.set_deferred_closest(False)        # local winners are gathered by the pass; keys travel with the rows
+    engine.clear()
+    engine.redistribute()
+    engine.finish_local()
+    band = band_of(rank, world, visit_rows, frame_rows)
+    lo, hi = engine.touched_rows()
+    mine = torch.tensor([lo, hi], dtype=torch.int64, device=engine.device)
+    info = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(info, mine)
+    info = [(int(t[0]), int(t[1])) for t in info]
+    ops, incoming, keep = [], [], []
+    for q in range(world):
+        if q == rank:
+            continue
+        q_lo, q_hi = band_of(q, world, visit_rows, frame_rows)
+        s_lo, s_hi = max(lo, q_lo), min(hi, q_hi)                  # rows of q's band this rank added to
+        if s_hi > s_lo:
+            ops.append(dist.P2POp(dist.isend, engine.acc_rows(s_lo, s_hi), q))
+            if zkey is not None:
+                ops.append(dist.P2POp(dist.isend, engine.key_rows(s_lo, s_hi), q))
+        r_lo, r_hi = max(info[q][0], band[0]), min(info[q][1], band[1])   # rows of this band q added to
+        if r_hi > r_lo:
+            acc = torch.empty_like(engine.acc_rows(r_lo, r_hi))
+            keys = torch.empty_like(engine.key_rows(r_lo, r_hi)) if zkey is not None else None
+            ops.append(dist.P2POp(dist.irecv, acc, q))
+            if keys is not None:
+                ops.append(dist.P2POp(dist.irecv, keys, q))
+            incoming.append((r_lo, acc, keys))
+    if ops:
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+    engine.before_resolve()                                        # received rows complete before the merge kernels
+    for r_lo, acc, keys in incoming:
+        engine.merge_rows(r_lo, acc, keys)
+    engine.resolve_rows(band[0], band[1])
+    return band

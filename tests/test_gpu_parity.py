@@ -244,41 +244,129 @@ def test_closest_filter_aovs(orc, gpu_ctx_factory, ragged):
         assert float(np.max(np.abs(buf[m] - exact[m]) / np.abs(exact[m]))) < TOL
 
 
-class _TwoEngineCollective:
-    """Stands in for torch.distributed between two HipEngines living in this process (one GPU):
-    all_reduce(t) is called once per engine in lock step; the reduction is applied to both tensors when
-    the second call arrives.  Lets frame_step's multi-rank path run on a single MI355X."""
+class _InProcessDist:
+    """Stands in for torch.distributed between HipEngines living in this process (one GPU, one thread per
+    "rank"): all_reduce / all_gather / batch_isend_irecv with the call signatures frame_step and
+    frame_step_bands use.  Lets the multi-rank paths run on a single MI355X."""
 
     class ReduceOp:
         SUM, MIN = "sum", "min"
 
-    def __init__(self):
-        self.pending = None
+    class _Req:
+        def wait(self):
+            return None
+
+    class _Shared:
+        def __init__(self, world):
+            import threading
+            self.world = world
+            self.barrier = threading.Barrier(world)
+            self.slots = [None] * world
+            self.mail = {}
+
+    isend, irecv = "isend", "irecv"
+
+    @staticmethod
+    def P2POp(op, tensor, peer):
+        return (op, tensor, peer)
+
+    def __init__(self, shared, rank):
+        self.sh, self.rank = shared, rank
 
     def is_initialized(self):
         return True
 
     def get_world_size(self):
-        return 2
+        return self.sh.world
+
+    def get_rank(self):
+        return self.rank
+
+    def _sync(self):
+        import torch
+        torch.cuda.synchronize()
+        self.sh.barrier.wait()
 
     def all_reduce(self, t, op):
         import torch
-        if self.pending is None:
-            self.pending = t
-            return
-        a, b = self.pending, t
-        torch.cuda.synchronize()
-        r = torch.minimum(a, b) if op == "min" else a + b
-        a.copy_(r); b.copy_(r)
-        torch.cuda.synchronize()
-        self.pending = None
+        self.sh.slots[self.rank] = t
+        self._sync()
+        if self.rank == 0:
+            r = self.sh.slots[0].clone()
+            for o in self.sh.slots[1:]:
+                r = torch.minimum(r, o) if op == "min" else r + o
+            for o in self.sh.slots:
+                o.copy_(r)
+        self._sync()
+
+    def all_gather(self, out, t):
+        self.sh.slots[self.rank] = t.clone()
+        self._sync()
+        for k in range(self.sh.world):
+            out[k].copy_(self.sh.slots[k])
+        self._sync()
+
+    def batch_isend_irecv(self, ops):
+        for op, t, peer in ops:
+            if op == "isend":
+                self.sh.mail.setdefault((self.rank, peer), []).append(t.clone())
+        self._sync()
+        for op, t, peer in ops:
+            if op == "irecv":
+                t.copy_(self.sh.mail[(peer, self.rank)].pop(0))
+        self._sync()
+        return [self._Req() for _ in ops]
+
+
+def _run_ranks(fn, world):
+    """fn(rank, dist) on one thread per rank; re-raises the first failure."""
+    import threading
+    shared = _InProcessDist._Shared(world)
+    errors = []
+
+    def run(rank):
+        try:
+            fn(rank, _InProcessDist(shared, rank))
+        except Exception as e:          # pragma: no cover
+            errors.append(e)
+            shared.barrier.abort()
+
+    th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=300)
+    if errors:
+        raise errors[0]
+
+
+def _compare_with_whole(ctx, whole, kinds, rows=None):
+    """accumulators / resolved AOVs of `ctx` (restricted to `rows` of the frame) against the whole-frame context"""
+    p_y, p_x = whole.P.yres, whole.P.xres
+    sel = np.zeros(p_y, bool)
+    sel[slice(*rows) if rows else slice(None)] = True
+    sel = np.repeat(sel, p_x)
+    for a, kind in enumerate(kinds):
+        buf, w = ctx.download_accum(a)
+        ref, rw = whole.download_accum(a)
+        img, rimg = ctx.download_aov(a), whole.download_aov(a)
+        buf, ref, img, rimg, w, rw = buf[sel], ref[sel], img[sel], rimg[sel], w[sel], rw[sel]
+        if kind:                                            # closest: identical winners and values
+            assert np.array_equal(buf, ref) and np.array_equal(img, rimg)
+            assert np.count_nonzero(ref) > 0
+        else:                                               # gaussian: fp32 summation order differs
+            m = ref != 0
+            assert np.array_equal(buf != 0, m)
+            assert float(np.max(np.abs(buf[m] - ref[m]) / np.abs(ref[m]))) < TOL
+            assert float(np.max(np.abs(w[rw != 0] - rw[rw != 0]) / rw[rw != 0])) < TOL
+            mi = rimg != 0
+            assert float(np.max(np.abs(img[mi] - rimg[mi]) / np.abs(rimg[mi]))) < 2 * TOL
 
 
 def test_two_partitions_on_one_gpu_match_the_whole_frame(orc, gpu_ctx_factory):
     """Multi-GPU logic on one device: rows r mod 2 in two contexts, closest-AOV key
     exchange + owner gather, sum of the accumulators, local resolve -- against one context that
     processes the whole frame (which test_closest_filter_aovs pins to the oracle)."""
-    import threading
     from pota_amd import distributed, workload
     W, H, M = 64, 40, 9
     kinds = [0, 1, 0]
@@ -286,6 +374,7 @@ def test_two_partitions_on_one_gpu_match_the_whole_frame(orc, gpu_ctx_factory):
     visits, cols = common.make_stream(p, W, H, M, f_hi=0.03, n_extra=2)
     whole = gpu_ctx_factory()
     gpu_run(whole, p, table, visits, n_aovs=3, kinds=kinds)
+    whole.P = p
 
     engines, keepalive = [], []
     for rank in range(2):
@@ -298,66 +387,64 @@ def test_two_partitions_on_one_gpu_match_the_whole_frame(orc, gpu_ctx_factory):
         ctx.alloc_frame(3, kinds)
         ctx.upload_visits(v)
         keepalive.append((c, v, kv))
-        engines.append(distributed.HipEngine(ctx))
+        engines.append(distributed.HipEngine(ctx, rows=p.yres))
     assert engines[0].zkey is not None
 
-    # drive both "ranks" through frame_step in lock step (two threads, one collective object)
-    coll = _TwoEngineCollective()
-    barrier = threading.Barrier(2)
-    errors = []
+    def step(rank, dist):
+        distributed.frame_step(engines[rank], dist)
+        engines[rank].ctx.sync()
 
-    class _Dist:
-        ReduceOp = _TwoEngineCollective.ReduceOp
-
-        def __init__(self, rank):
-            self.rank = rank
-
-        def is_initialized(self):
-            return True
-
-        def get_world_size(self):
-            return 2
-
-        def all_reduce(self, t, op):
-            # rank 0 registers first, rank 1 completes the reduction; both return afterwards
-            if self.rank == 0:
-                coll.all_reduce(t, op)
-                barrier.wait()
-                barrier.wait()
-            else:
-                barrier.wait()
-                coll.all_reduce(t, op)
-                barrier.wait()
-
-    def run(rank):
-        try:
-            distributed.frame_step(engines[rank], _Dist(rank))
-            engines[rank].ctx.sync()
-        except Exception as e:          # pragma: no cover
-            errors.append(e)
-            barrier.abort()
-
-    th = [threading.Thread(target=run, args=(r,)) for r in range(2)]
-    for t in th:
-        t.start()
-    for t in th:
-        t.join(timeout=120)
-    assert not errors, errors
-
+    _run_ranks(step, 2)
     for rank in range(2):
-        ctx = engines[rank].ctx
-        buf, _ = ctx.download_accum(1)                       # closest: identical winners and values
-        ref, _ = whole.download_accum(1)
-        assert np.array_equal(buf, ref)
-        assert np.array_equal(ctx.download_aov(1), whole.download_aov(1))
-        assert np.count_nonzero(ref) > 0
-        for a in (0, 2):                                     # gaussian: fp32 summation order differs
-            buf, w = ctx.download_accum(a)
-            ref, rw = whole.download_accum(a)
-            m = ref != 0
-            assert np.array_equal(buf != 0, m)
-            assert float(np.max(np.abs(buf[m] - ref[m]) / np.abs(ref[m]))) < TOL
-            assert float(np.max(np.abs(w[rw != 0] - rw[rw != 0]) / rw[rw != 0])) < TOL
+        _compare_with_whole(engines[rank].ctx, whole, kinds)
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_tiled_output_on_one_gpu_matches_the_whole_frame(orc, gpu_ctx_factory, world):
+    """Tiled multi-GPU mode on one device: each "rank" processes a band of rows, tells the others which rows
+    it touched, sends the foreign ones to their owners (lentil_hip_merge_rows) and resolves its band
+    (lentil_hip_resolve_rows).  Every band must equal the same rows of a whole-frame context; a second pass
+    checks that the row-limited clear leaves nothing behind."""
+    from pota_amd import distributed, workload
+    W, H, M = 64, 45, 9
+    kinds = [0, 1, 0]
+    p, model, table, keep = common.po_setup(W, H, samples_override=48)
+    visits, cols = common.make_stream(p, W, H, M, f_hi=0.03, n_extra=2)
+    whole = gpu_ctx_factory()
+    gpu_run(whole, p, table, visits, n_aovs=3, kinds=kinds)
+    whole.P = p
+
+    engines, keepalive, bands = [], [], []
+    for rank in range(world):
+        b_lo, b_hi = distributed.band_of(rank, world, H, p.yres)
+        v_hi = min(b_hi, H)
+        c = workload.generate(np, b_lo * W * M, v_hi * W * M, W, H, M, f_hi=0.03, focus_dist=150.0,
+                              tan_half_fov=common.tan_half_fov(p), n_extra=2)
+        v, kv = capi.make_visits(c, visits_per_pixel=M, pixels_per_row=W, pixel_y0=b_lo)
+        ctx = gpu_ctx_factory()
+        ctx.set_params(p); ctx.set_lens(table); ctx.set_bokeh(None)
+        ctx.alloc_frame(3, kinds)
+        ctx.upload_visits(v)
+        keepalive.append((c, v, kv))
+        engines.append(distributed.HipEngine(ctx, rows=p.yres))
+        bands.append((b_lo, b_hi))
+    assert bands[0][0] == 0 and bands[-1][1] == p.yres
+
+    got = {}
+
+    def step(rank, dist):
+        for _ in range(2):                                   # second pass: clear_frame wipes only the touched rows
+            got[rank] = distributed.frame_step_bands(engines[rank], dist, H, p.yres)
+            engines[rank].ctx.sync()
+
+    _run_ranks(step, world)
+    reach = 0
+    for rank in range(world):
+        assert got[rank] == bands[rank]
+        lo, hi = engines[rank].ctx.touched_rows()
+        reach = max(reach, bands[rank][0] - lo, hi - bands[rank][1])
+        _compare_with_whole(engines[rank].ctx, whole, kinds, rows=bands[rank])
+    assert reach > 0            # draws did cross the band boundaries
 
 
 @pytest.mark.parametrize("chroma,lens_mode,override", [(0.5, 0, 48), (0.5, 1, 48), (1.0, 0, 0), (-0.5, 0, 48)])

@@ -15,8 +15,9 @@ import common
 
 
 class OracleEngine:
-    """CPU stand-in for HipEngine with the same interface (clear/redistribute/accum/resolve, and the
-    closest-AOV key exchange when the frame has closest-filtered AOVs)."""
+    """CPU stand-in for HipEngine with the same interface (clear/redistribute/accum/resolve, the
+    closest-AOV key exchange, and the row views / merge of the tiled mode).  Accumulators are kept as
+    pixel records [np][4 * n_aovs + 1] like the HIP library's, so that rows are contiguous."""
 
     def __init__(self, lib, p, table, visits, cols=None, kinds=None):
         import ctypes as C
@@ -28,13 +29,17 @@ class OracleEngine:
         self.frame = None
         self.oracle_lib = oracle_lib
         self.np = p.xres * p.yres
-        self.accum = torch.zeros(self.np * (4 * self.n_aovs + 1), dtype=torch.float32)
+        self.rows = p.yres
+        self.stride = 4 * self.n_aovs + 1
+        self.accum = torch.zeros(self.np * self.stride, dtype=torch.float32)
+        self.rec = self.accum.view(self.np, self.stride)
         self.zkey = torch.zeros(self.np, dtype=torch.int64) if any(self.kinds) else None
+        self.device = torch.device("cpu")
         self.deferred = False
         self.resolved = None
 
     def _aov(self, a):
-        return self.accum[a * self.np * 4:(a + 1) * self.np * 4]
+        return self.rec[:, 4 * a:4 * a + 4]
 
     def _gid(self, v):
         """frame-wide visit id, same rule as visit_gid() in pota_amd/csrc/lentil_kernels.h"""
@@ -53,8 +58,8 @@ class OracleEngine:
     def redistribute(self):
         self.frame.run(self.lens, None, self.visits)
         for a in range(self.n_aovs):
-            self._aov(a)[:] = torch.from_numpy(self.frame.buffer(a).reshape(-1))
-        self.accum[self.np * 4 * self.n_aovs:] = torch.from_numpy(self.frame.weight())
+            self._aov(a)[:] = torch.from_numpy(self.frame.buffer(a))
+        self.rec[:, 4 * self.n_aovs] = torch.from_numpy(self.frame.weight())
         if self.zkey is not None:
             zv = self.frame.zvisit().astype(np.int64)
             have = zv != 0xFFFFFFFF
@@ -86,17 +91,55 @@ class OracleEngine:
         mine &= v < V.n
         for a in range(1, self.n_aovs):
             if self.kinds[a]:
-                dst = self._aov(a).reshape(-1, 4)
-                dst[torch.from_numpy(mine)] = torch.from_numpy(self.cols["extra"][a - 1][v[mine]])
+                self._aov(a)[torch.from_numpy(mine)] = torch.from_numpy(self.cols["extra"][a - 1][v[mine]])
 
     def before_resolve(self):
         pass
 
+    # ---- tiled mode
+    def touched_rows(self):
+        w = self.rec.abs().sum(dim=1).view(self.p.yres, self.p.xres).sum(dim=1).numpy()
+        rows = np.nonzero(w)[0]
+        return (int(rows[0]), int(rows[-1]) + 1) if len(rows) else (0, 0)
+
+    def acc_rows(self, lo, hi):
+        per = self.p.xres * self.stride
+        return self.accum[lo * per:hi * per]
+
+    def key_rows(self, lo, hi):
+        return self.zkey[lo * self.p.xres:hi * self.p.xres]
+
+    def merge_rows(self, lo, acc, keys):
+        n = acc.numel() // (self.p.xres * self.stride)
+        p0, p1 = lo * self.p.xres, (lo + n) * self.p.xres
+        src = acc.view(-1, self.stride)
+        dst = self.rec[p0:p1]
+        closer = None
+        if keys is not None:
+            mine = self.zkey[p0:p1].numpy().view(np.uint64)
+            theirs = keys.numpy().view(np.uint64)
+            closer = torch.from_numpy(theirs < mine)
+        for a in range(self.n_aovs):
+            if self.kinds[a]:
+                dst[:, 4 * a:4 * a + 4][closer] = src[:, 4 * a:4 * a + 4][closer]
+            else:
+                dst[:, 4 * a:4 * a + 4] += src[:, 4 * a:4 * a + 4]
+        dst[:, 4 * self.n_aovs] += src[:, 4 * self.n_aovs]
+        if keys is not None:
+            self.zkey[p0:p1] = torch.from_numpy(np.minimum(mine, theirs).view(np.int64))
+
+    def resolve_rows(self, lo, hi):
+        self.resolve()
+        keep = np.zeros(self.np, bool)
+        keep[lo * self.p.xres:hi * self.p.xres] = True
+        for r in self.resolved:
+            r[~keep] = 0
+
     def resolve(self):
-        w = self.accum[self.np * 4 * self.n_aovs:].numpy()
+        w = self.rec[:, 4 * self.n_aovs].numpy()
         self.resolved = []
         for a in range(self.n_aovs):
-            acc = self._aov(a).reshape(-1, 4).numpy()
+            acc = self._aov(a).numpy()
             out = acc.copy()
             if not self.kinds[a]:
                 m = w != 0
@@ -104,7 +147,7 @@ class OracleEngine:
             self.resolved.append(out)
 
 
-def _worker(rank, world, port, W, H, M, f_hi, samples, kinds, q):
+def _worker(rank, world, port, W, H, M, f_hi, samples, kinds, q, bands=False):
     sys.path.insert(0, common.ROOT)
     sys.path.insert(0, os.path.join(common.ROOT, "tests"))
     import oracle_lib
@@ -114,16 +157,40 @@ def _worker(rank, world, port, W, H, M, f_hi, samples, kinds, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     lib = oracle_lib.load()
     p, model, table, keep = common.po_setup(W, H, samples_override=samples)
-    n_local = workload.frame_visit_count(W, H, M, world, rank)
-    assert list(distributed.partition_rows(H, world, rank)) == list(range(rank, H, world))
-    cols = workload.generate(np, 0, n_local, W, H, M, f_hi=f_hi, focus_dist=150.0,
-                             tan_half_fov=common.tan_half_fov(p), row_stride=world, row_offset=rank,
-                             n_extra=len(kinds) - 1)
-    visits, kv = capi.make_visits(cols, visits_per_pixel=M, pixels_per_row=W, pixel_y0=rank, pixel_row_stride=world)
-    eng = OracleEngine(lib, p, table, visits, cols, kinds)
-    distributed.frame_step(eng, dist)
-    if rank == 0:
-        q.put((eng.accum.numpy().copy(), [r.copy() for r in eng.resolved]))
+    if bands:
+        b_lo, b_hi = distributed.band_of(rank, world, H, p.yres)
+        v_hi = min(b_hi, H)
+        cols = workload.generate(np, b_lo * W * M, v_hi * W * M, W, H, M, f_hi=f_hi, focus_dist=150.0,
+                                 tan_half_fov=common.tan_half_fov(p), n_extra=len(kinds) - 1)
+        visits, kv = capi.make_visits(cols, visits_per_pixel=M, pixels_per_row=W, pixel_y0=b_lo)
+        eng = OracleEngine(lib, p, table, visits, cols, kinds)
+        band = distributed.frame_step_bands(eng, dist, H, p.yres)
+        assert band == (b_lo, b_hi)
+        # rank 0 assembles the tiled result for the comparison
+        per = p.xres * eng.stride
+        parts = [torch.zeros_like(eng.accum) for _ in range(world)] if rank == 0 else None
+        mask = torch.zeros_like(eng.accum); mask[b_lo * per:b_hi * per] = 1
+        dist.gather(eng.accum * mask, parts, dst=0)
+        imgs = []
+        for a in range(len(kinds)):
+            t = torch.from_numpy(eng.resolved[a]).contiguous()
+            g = [torch.zeros_like(t) for _ in range(world)] if rank == 0 else None
+            dist.gather(t, g, dst=0)
+            if rank == 0:
+                imgs.append(sum(g).numpy())
+        if rank == 0:
+            q.put((sum(parts).numpy().copy(), imgs))
+    else:
+        n_local = workload.frame_visit_count(W, H, M, world, rank)
+        assert list(distributed.partition_rows(H, world, rank)) == list(range(rank, H, world))
+        cols = workload.generate(np, 0, n_local, W, H, M, f_hi=f_hi, focus_dist=150.0,
+                                 tan_half_fov=common.tan_half_fov(p), row_stride=world, row_offset=rank,
+                                 n_extra=len(kinds) - 1)
+        visits, kv = capi.make_visits(cols, visits_per_pixel=M, pixels_per_row=W, pixel_y0=rank, pixel_row_stride=world)
+        eng = OracleEngine(lib, p, table, visits, cols, kinds)
+        distributed.frame_step(eng, dist)
+        if rank == 0:
+            q.put((eng.accum.numpy().copy(), [r.copy() for r in eng.resolved]))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -136,7 +203,7 @@ def _free_port():
     return port
 
 
-def _two_rank_vs_single(orc, kinds):
+def _two_rank_vs_single(orc, kinds, bands=False, world=2):
     W, H, M, f_hi, samples = 48, 32, 9, 0.03, 24
     # single rank reference
     from pota_amd import distributed
@@ -145,21 +212,21 @@ def _two_rank_vs_single(orc, kinds):
     eng = OracleEngine(orc, p, table, visits, cols, kinds)
     distributed.frame_step(eng, None)
     ref_acc, ref_img = eng.accum.numpy().copy(), [r.copy() for r in eng.resolved]
-    assert ref_acc[-eng.np:].sum() > 0
+    assert ref_acc.reshape(eng.np, -1)[:, -1].sum() > 0
 
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, W, H, M, f_hi, samples, kinds, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, W, H, M, f_hi, samples, kinds, q, bands)) for r in range(world)]
     for pr in procs:
         pr.start()
     acc, img = q.get(timeout=300)
     for pr in procs:
         pr.join(timeout=120)
         assert pr.exitcode == 0
-    n4 = eng.np * 4
+    ref_rec, rec = ref_acc.reshape(eng.np, -1), acc.reshape(eng.np, -1)
     for a, kind in enumerate(kinds):
-        ra, ga = ref_acc[a * n4:(a + 1) * n4], acc[a * n4:(a + 1) * n4]
+        ra, ga = ref_rec[:, 4 * a:4 * a + 4].reshape(-1), rec[:, 4 * a:4 * a + 4].reshape(-1)
         if kind:
             # closest-filtered: the same visit wins every pixel, values are copies
             assert np.array_equal(ga, ra)
@@ -181,6 +248,16 @@ def test_two_rank_gloo_equals_single_rank(orc):
 def test_two_rank_gloo_closest_aovs(orc):
     """closest-filtered AOVs: min-reduce of the winner keys + owner gather + sum"""
     _two_rank_vs_single(orc, [0, 1, 0, 1])
+
+
+def test_tiled_output_two_ranks(orc):
+    """row bands + exchange of the rows touched outside the own band (frame_step_bands)"""
+    _two_rank_vs_single(orc, [0], bands=True)
+
+
+def test_tiled_output_three_ranks_closest_aovs(orc):
+    """three bands (a middle band has two neighbours; 32 rows do not divide evenly), closest AOVs ride along"""
+    _two_rank_vs_single(orc, [0, 1, 0], bands=True, world=3)
 
 
 def test_row_partition_covers_frame():
