@@ -190,4 +190,6 @@ def frame_step_bands(engine, dist, visit_rows, frame_rows):
     for r_lo, acc, keys in incoming:
         engine.merge_rows(r_lo, acc, keys)
     engine.resolve_rows(band[0], band[1])
+    if incoming:
+        engine.finish_local()      # the merge kernels read torch-owned buffers: done before those are released
     return band
