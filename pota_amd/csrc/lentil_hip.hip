@@ -74,6 +74,7 @@ struct lentil_hip_ctx {
   // rows that may be non-zero since the last clear_frame (only trusted when dirty_known)
   int32_t dirty_lo = 0, dirty_hi = 0;
   bool dirty_known = false;
+  hipEvent_t scans_done = nullptr;   // after the last chunk's scan of a pass
   bool pass_pending = false;         // a redistribute ran whose rows have not been asked for yet
   bool closest_deferred = false;     // multi-GPU: the caller min-reduces the keys before the gather
   uint32_t visit_id_base = 0;
@@ -138,6 +139,7 @@ LENTIL_API int lentil_hip_create(int device, lentil_hip_ctx **out_ctx) {
     HIP_TRY(ctx, hipEventCreateWithFlags(&ch.scanned, hipEventDisableTiming));
     HIP_TRY(ctx, hipEventCreateWithFlags(&ch.done, hipEventDisableTiming));
   }
+  HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->scans_done, hipEventDisableTiming));
   if (const char *ft = getenv("LENTIL_FORCE_TABLES")) ctx->use_generated = !(ft[0] == '1');
   if (const char *fc = getenv("LENTIL_FIRST_CHUNK_FRAC")) {
     const double f = atof(fc);
@@ -185,6 +187,7 @@ LENTIL_API int lentil_hip_destroy(lentil_hip_ctx *ctx) {
     if (ch.done) (void)hipEventDestroy(ch.done);
     if (ch.stream) (void)hipStreamDestroy(ch.stream);
   }
+  if (ctx->scans_done) (void)hipEventDestroy(ctx->scans_done);
   (void)hipFree(ctx->d_ctr);
   (void)hipFree(ctx->d_log);
   for (auto &ev : ctx->ev) if (ev) (void)hipEventDestroy(ev);
@@ -661,6 +664,9 @@ static int enqueue_chunk_draws(lentil_hip_ctx *ctx, int ci, DrawArgs &da, int bl
     for (int round = 0; round < blind_rounds; ++round) {
       da.parity = round & 1;
       launch_solve(ctx, da, ch.stream, round == 0 ? solve_blocks : (solve_blocks > 256 ? 256 : solve_blocks));
+      // Splats go anywhere in the frame, also into rows a later chunk's scan is still read-modify-writing with
+      // plain stores: solves may overlap the remaining scans, the first accept may not.
+      if (round == 0) HIP_TRY(ctx, hipStreamWaitEvent(ch.stream, ctx->scans_done, 0));
       hipLaunchKernelGGL(accept_kernel, dim3(accept_blocks), dim3(256), 0, ch.stream, da);
       HIP_TRY(ctx, hipGetLastError());
     }
@@ -683,6 +689,7 @@ static int enqueue_chunk_draws(lentil_hip_ctx *ctx, int ci, DrawArgs &da, int bl
     da.parity = 0;
     hipLaunchKernelGGL(prep_items_kernel, dim3((unsigned)((ni + 255) / 256)), dim3(256), 0, ch.stream, da);
     launch_solve(ctx, da, ch.stream, (unsigned)max_blocks);
+    if (i0 == 0) HIP_TRY(ctx, hipStreamWaitEvent(ch.stream, ctx->scans_done, 0));   // see the blind rounds above
     hipLaunchKernelGGL(accept_kernel, dim3((unsigned)ctx->num_cu * 2), dim3(256), 0, ch.stream, da);
     HIP_TRY(ctx, hipGetLastError());
     int rounds = 0;
@@ -783,6 +790,7 @@ LENTIL_API int lentil_hip_redistribute(lentil_hip_ctx *ctx) {
     }
   }
   HIP_TRY(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
+  HIP_TRY(ctx, hipEventRecord(ctx->scans_done, ctx->stream));
   if (ctx->V.n) {
     // ---- draws: per chunk on its own stream
     DrawArgs da{};
