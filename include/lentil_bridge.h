@@ -132,6 +132,10 @@ typedef struct lentil_aov_plan {
 int lentil_operator_cook(const char *const *outputs, const char *const *filter_entry_names, int n,
                          lentil_aov_plan *plans, int cap, char *warnings, size_t warnings_cap);
 
+/* the `kind` byte lentil_hip_alloc_frame expects for a plan entry: its original filter, except that the AOV named
+ * lentil_debug gets LENTIL_FILTER_CLOSEST_DEBUG (own z-buffer and value, src/lentil.h:838-845) */
+int lentil_aov_frame_kind(const lentil_aov_plan *plan);
+
 /* sanitize_aov_list + index assignment of rebuild_arnold_outputs_from_list (src/aov_data.h:164-189):
  * drops duplicates and AOVs lentil does not filter, numbers the rest; returns the new count */
 int lentil_sanitize_aov_list(lentil_aov_plan *plans, int n);

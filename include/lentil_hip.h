@@ -52,6 +52,9 @@ extern "C" {
 #define LENTIL_FILTER_GAUSSIAN 0
 #define LENTIL_FILTER_CLOSEST 1
 #define LENTIL_FILTER_VARIANCE 2
+/* the lentil_debug AOV (src/lentil_operator.cpp:99-111): closest-filtered through its own z-buffer, fed by
+ * redistributed draws only, value = the visit's draw count; takes no visit column (extra[k-1] may be NULL) */
+#define LENTIL_FILTER_CLOSEST_DEBUG 3
 /* pupil geometry strings "cyl-y" / "cyl-x" / anything else, src/lentil.h:387-389 */
 #define LENTIL_GEOM_SPHERICAL 0
 #define LENTIL_GEOM_CYL_Y 1

@@ -813,6 +813,7 @@ struct OrcFrame {
   std::vector<float> buffer[LENTIL_MAX_AOVS];   /* AOVData::buffer, RGBA */
   std::vector<float> weight;                    /* filter_weight_buffer */
   std::vector<float> zbuffer;
+  std::vector<float> zbuffer_debug;             /* lentil_debug's own z-buffer, src/lentil.h:101 */
   std::vector<uint32_t> zvisit;                 /* visit that wrote zbuffer last (multi-rank merge tests) */
   uint32_t cur_visit = 0;
   std::vector<double> buffer64[LENTIL_MAX_AOVS];/* fp64 shadow accumulation (tolerance studies) */
@@ -838,6 +839,7 @@ ORC_API OrcFrame *orc_frame_create(uint32_t xres, uint32_t yres, uint32_t n_aovs
   F->weight.assign(np, 0.0f);
   if (F->shadow) F->weight64.assign(np, 0.0);
   F->zbuffer.assign(np, 0.0f);
+  F->zbuffer_debug.assign(np, 0.0f);
   F->zvisit.assign(np, 0xFFFFFFFFu);
   memset(&F->ctr, 0, sizeof(F->ctr));
   return F;
@@ -885,6 +887,16 @@ static inline void add_to_buffer(OrcFrame *F, uint32_t aov, uint32_t px, const f
       }
       F->zbuffer[px] = std::abs(depth);
       F->zvisit[px] = F->cur_visit;
+    }
+  } else if (F->kind[aov] == LENTIL_FILTER_CLOSEST_DEBUG) {       /* aov.name == lentil_debug, src/lentil.h:838-845 */
+    if ((std::abs(depth) <= F->zbuffer_debug[px]) || F->zbuffer_debug[px] == 0.0) {
+      if (value[0] != 0.0) {
+        for (int c = 0; c < 4; c++) {
+          F->buffer[aov][(size_t)px * 4 + c] = value[c];
+          if (F->shadow) F->buffer64[aov][(size_t)px * 4 + c] = value[c];
+        }
+        F->zbuffer_debug[px] = std::abs(depth);
+      }
     }
   }
 }
@@ -942,8 +954,14 @@ static void do_visit(const lentil_params *P, const OrcLens *L, const OrcBokeh *B
    * stored: the reference re-reads the RGBA AOV through AiAOVSampleIteratorGetAOVRGBA, :216) */
   float aov_values[LENTIL_MAX_AOVS][4];
   for (int c = 0; c < 4; c++) aov_values[0][c] = V->rgba[v * 4 + c];
-  for (uint32_t a = 1; a < F->n_aovs; a++)
+  for (uint32_t a = 1; a < F->n_aovs; a++) {
+    if (F->kind[a] == LENTIL_FILTER_CLOSEST_DEBUG) {      /* :209-211: an int assigned to an AtRGBA sets all four */
+      const float dbg = (float)(samples * (redistribute ? 1 : 0));
+      for (int c = 0; c < 4; c++) aov_values[a][c] = dbg;
+      continue;
+    }
     for (int c = 0; c < 4; c++) aov_values[a][c] = V->extra[a - 1][v * 4 + c];
+  }
 
   if (P->cameraType == LENTIL_POLYNOMIAL_OPTICS)
     if (std::abs(cs[2]) < (L->k.lens_length * 0.1)) redistribute = false;           /* :240 */

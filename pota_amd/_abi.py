@@ -4,7 +4,7 @@ import ctypes as C
 LENTIL_MAX_AOVS = 16
 THINLENS, POLYNOMIAL_OPTICS = 0, 1
 UNIT_MM, UNIT_CM, UNIT_DM, UNIT_M = 0, 1, 2, 3
-FILTER_GAUSSIAN, FILTER_CLOSEST, FILTER_VARIANCE = 0, 1, 2
+FILTER_GAUSSIAN, FILTER_CLOSEST, FILTER_VARIANCE, FILTER_CLOSEST_DEBUG = 0, 1, 2, 3
 GEOM_SPHERICAL, GEOM_CYL_Y, GEOM_CYL_X = 0, 1, 2
 OK, ERR_INVALID, ERR_HIP, ERR_UNSUPPORTED, ERR_NOMEM = 0, -1, -2, -3, -4
 

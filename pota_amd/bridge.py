@@ -52,7 +52,7 @@ EXPORTS = [
     "lentil_camera_node_parameters", "lentil_camera_node_defaults", "lentil_camera_params_from_node",
     "lentil_filter_required_aovs", "lentil_filter_width", "lentil_filter_output_type",
     "lentil_filter_inverse_sample_density", "lentil_tokenize_output", "lentil_rebuild_output",
-    "lentil_string_to_arnold_type", "lentil_operator_cook", "lentil_sanitize_aov_list",
+    "lentil_string_to_arnold_type", "lentil_operator_cook", "lentil_sanitize_aov_list", "lentil_aov_frame_kind",
     "lentil_stage_create", "lentil_stage_destroy", "lentil_stage_reset", "lentil_stage_append", "lentil_stage_size",
     "lentil_stage_visits", "lentil_imager_create", "lentil_imager_destroy", "lentil_imager_new_frame",
     "lentil_imager_process_bucket", "lentil_imager_last_error",
@@ -87,6 +87,7 @@ def load():
         "lentil_operator_cook": (i, [C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), i, C.POINTER(AovPlan), i, C.c_char_p,
                                      C.c_size_t]),
         "lentil_sanitize_aov_list": (i, [C.POINTER(AovPlan), i]),
+        "lentil_aov_frame_kind": (i, [C.POINTER(AovPlan)]),
         "lentil_stage_create": (i, [i, u32, C.POINTER(vp)]),
         "lentil_stage_destroy": (None, [vp]),
         "lentil_stage_reset": (None, [vp]),

@@ -119,7 +119,7 @@ def make_visits(cols, visits_per_pixel=0, pixels_per_row=0, pixel_x0=0, pixel_y0
     for name in ("rgba", "pos_z", "raydir_time", "volume_ignore", "transmission"):
         setattr(v, name, ptr(cols[name]) if n else None)
     for k, e in enumerate(extra):
-        v.extra[k] = ptr(e) if n else None
+        v.extra[k] = ptr(e) if (n and e is not None) else None      # None: an AOV without a column (lentil_debug)
     if cols.get("pixel") is not None:
         v.pixel = ptr(cols["pixel"])
     if cols.get("inv_density") is not None:

@@ -287,6 +287,12 @@ BRIDGE_API int lentil_operator_cook(const char *const *outputs, const char *cons
   return m;
 }
 
+BRIDGE_API int lentil_aov_frame_kind(const lentil_aov_plan *plan) {
+  if (!plan) return -1;
+  if (std::string(plan->name) == "lentil_debug") return LENTIL_FILTER_CLOSEST_DEBUG;
+  return plan->original_filter;
+}
+
 BRIDGE_API int lentil_sanitize_aov_list(lentil_aov_plan *plans, int n) {
   if (!plans) return -1;
   int m = 0;

@@ -177,6 +177,7 @@ LENTIL_API int lentil_hip_destroy(lentil_hip_ctx *ctx) {
   (void)hipFree(ctx->d_terms);
   (void)hipFree(ctx->F.acc);
   (void)hipFree(ctx->F.zkey);
+  (void)hipFree(ctx->F.zkey_dbg);
   (void)hipFree(ctx->d_resolved);
   (void)hipFree(ctx->d_work);
   for (auto &ch : ctx->chunks) {
@@ -356,7 +357,7 @@ LENTIL_API int lentil_hip_alloc_frame(lentil_hip_ctx *ctx, uint32_t n_aovs, cons
   if (n_aovs < 1 || n_aovs > LENTIL_MAX_AOVS) return fail(ctx, LENTIL_ERR_INVALID, "n_aovs out of range");
   for (uint32_t i = 0; i < n_aovs; ++i) {
     const uint8_t k = kind ? kind[i] : LENTIL_FILTER_GAUSSIAN;
-    if (k != LENTIL_FILTER_GAUSSIAN && k != LENTIL_FILTER_CLOSEST)
+    if (k != LENTIL_FILTER_GAUSSIAN && k != LENTIL_FILTER_CLOSEST && k != LENTIL_FILTER_CLOSEST_DEBUG)
       return fail(ctx, LENTIL_ERR_UNSUPPORTED, "variance-original AOVs are a no-op in the reference (src/lentil.h:848-850)");
     if (i == 0 && k != LENTIL_FILTER_GAUSSIAN)
       return fail(ctx, LENTIL_ERR_UNSUPPORTED, "AOV 0 (RGBA, the weight-buffer AOV) must be gaussian-filtered");
@@ -366,6 +367,7 @@ LENTIL_API int lentil_hip_alloc_frame(lentil_hip_ctx *ctx, uint32_t n_aovs, cons
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   (void)hipFree(ctx->F.acc);
   (void)hipFree(ctx->F.zkey);
+  (void)hipFree(ctx->F.zkey_dbg);
   (void)hipFree(ctx->d_resolved);
   ctx->F = FrameDev{};
   ctx->d_resolved = nullptr;
@@ -379,10 +381,17 @@ LENTIL_API int lentil_hip_alloc_frame(lentil_hip_ctx *ctx, uint32_t n_aovs, cons
   ctx->F.n_aovs = n_aovs;
   ctx->F.np = np;
   ctx->F.closest_mask = 0;
-  for (uint32_t i = 0; i < n_aovs; ++i) if (ctx->kind[i] == LENTIL_FILTER_CLOSEST) ctx->F.closest_mask |= 1u << i;
-  if (ctx->F.closest_mask) {
+  for (uint32_t i = 0; i < n_aovs; ++i) {
+    if (ctx->kind[i] == LENTIL_FILTER_CLOSEST) ctx->F.closest_mask |= 1u << i;
+    if (ctx->kind[i] == LENTIL_FILTER_CLOSEST_DEBUG) { ctx->F.closest_mask |= 1u << i; ctx->F.debug_mask |= 1u << i; }
+  }
+  if (ctx->F.closest_mask & ~ctx->F.debug_mask) {
     HIP_TRY(ctx, hipMalloc(&ctx->F.zkey, np * sizeof(unsigned long long)));
     HIP_TRY(ctx, hipMemsetAsync(ctx->F.zkey, 0xFF, np * sizeof(unsigned long long), ctx->stream));
+  }
+  if (ctx->F.debug_mask) {
+    HIP_TRY(ctx, hipMalloc(&ctx->F.zkey_dbg, np * sizeof(unsigned long long)));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->F.zkey_dbg, 0xFF, np * sizeof(unsigned long long), ctx->stream));
   }
   ctx->have_frame = true;
   HIP_TRY(ctx, hipMemsetAsync(ctx->F.acc, 0, nfl * sizeof(float), ctx->stream));
@@ -396,8 +405,6 @@ static int check_visits(lentil_hip_ctx *ctx, const lentil_visits *v) {
   if (v->n_extra > LENTIL_MAX_AOVS - 1) return fail(ctx, LENTIL_ERR_INVALID, "too many extra AOV columns");
   if (v->n && (!v->rgba || !v->pos_z || !v->raydir_time || !v->volume_ignore || !v->transmission))
     return fail(ctx, LENTIL_ERR_INVALID, "a visit column is null");
-  for (uint32_t k = 0; k < v->n_extra; ++k)
-    if (v->n && !v->extra[k]) return fail(ctx, LENTIL_ERR_INVALID, "an extra AOV column is null");
   if (v->visits_per_pixel == 0 && v->n && !v->pixel)
     return fail(ctx, LENTIL_ERR_INVALID, "visits_per_pixel == 0 needs the per-visit pixel array");
   if (v->visits_per_pixel && (v->pixels_per_row == 0 || v->pixel_row_stride == 0))
@@ -513,6 +520,7 @@ LENTIL_API int lentil_hip_clear_frame(lentil_hip_ctx *ctx) {
   if (p1 > p0) {
     HIP_TRY(ctx, hipMemsetAsync(ctx->F.acc + p0 * ctx->F.stride, 0, (p1 - p0) * ctx->F.stride * sizeof(float), ctx->stream));
     if (ctx->F.zkey) HIP_TRY(ctx, hipMemsetAsync(ctx->F.zkey + p0, 0xFF, (p1 - p0) * sizeof(unsigned long long), ctx->stream));
+    if (ctx->F.zkey_dbg) HIP_TRY(ctx, hipMemsetAsync(ctx->F.zkey_dbg + p0, 0xFF, (p1 - p0) * sizeof(unsigned long long), ctx->stream));
   }
   ctx->dirty_lo = ctx->dirty_hi = 0;
   ctx->dirty_known = true;      // clean frame: nothing is dirty
@@ -710,6 +718,11 @@ LENTIL_API int lentil_hip_redistribute(lentil_hip_ctx *ctx) {
   if (P.bokeh_enable_image && !ctx->have_bokeh) return fail(ctx, LENTIL_ERR_INVALID, "bokeh_enable_image needs set_bokeh");
   if (ctx->V.n_extra + 1 != ctx->F.n_aovs)
     return fail(ctx, LENTIL_ERR_INVALID, "visit stream carries a different number of AOVs than the frame");
+  for (uint32_t k = 1; k < ctx->F.n_aovs; ++k)
+    if (ctx->V.n && !ctx->V.extra[k - 1] && !(ctx->F.debug_mask & (1u << k)))
+      return fail(ctx, LENTIL_ERR_INVALID, "an extra AOV column is null");
+  if (ctx->F.debug_mask && ctx->closest_deferred)
+    return fail(ctx, LENTIL_ERR_UNSUPPORTED, "the lentil_debug AOV is not exchanged between GPUs");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   const int C = ctx->n_chunks;
   if (ctx->pass_pending) ctx->dirty_known = false;   // an earlier pass's rows were never asked for: unknown until a full clear
@@ -835,6 +848,11 @@ LENTIL_API int lentil_hip_redistribute(lentil_hip_ctx *ctx) {
     }
     ctx->last_rounds = max_rounds;
   }
+  if (ctx->F.zkey_dbg && ctx->V.n) {
+    hipLaunchKernelGGL(debug_gather_kernel, dim3((unsigned)ctx->num_cu * 8), dim3(256), 0, ctx->stream, ctx->F, ctx->V, P,
+                       ctx->have_lens ? ctx->hlens.length : 0.0);
+    HIP_TRY(ctx, hipGetLastError());
+  }
   if (ctx->F.zkey && ctx->V.n && !ctx->closest_deferred) {
     // closest-filter AOVs: the winners of this pass (one pass per frame: the keys index the bound stream)
     hipLaunchKernelGGL(closest_gather_kernel, dim3((unsigned)ctx->num_cu * 8), dim3(256), 0, ctx->stream, ctx->F, ctx->V);
@@ -914,6 +932,7 @@ LENTIL_API int lentil_hip_merge_rows(lentil_hip_ctx *ctx, uint32_t row_begin, ui
   if (!n_rows) return LENTIL_OK;
   if (!dev_acc_rows) return fail(ctx, LENTIL_ERR_INVALID, "dev_acc_rows is null");
   if (ctx->F.zkey && !dev_key_rows) return fail(ctx, LENTIL_ERR_INVALID, "the frame has closest-filtered AOVs: key rows are required");
+  if (ctx->F.debug_mask) return fail(ctx, LENTIL_ERR_UNSUPPORTED, "the lentil_debug AOV is not exchanged between GPUs");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   const uint64_t p_begin = (uint64_t)row_begin * ctx->P.xres, n_pix = (uint64_t)n_rows * ctx->P.xres;
   uint64_t blocks = (n_pix * ctx->F.stride + 255) / 256;

@@ -97,6 +97,8 @@ struct FrameDev {
   // (bits of |Z|) << 32 | (0xFFFFFFFF - visit), reduced with atomicMin: smallest depth wins, equal depths
   // go to the later visit -- exactly what the reference's sequential "depth <= zbuffer" test leaves.
   unsigned long long *zkey;   // [np], null when the frame has no closest AOV
+  unsigned long long *zkey_dbg;   // [np], lentil_debug's own z-buffer (src/lentil.h:838-845): redistributed draws only
+  uint32_t debug_mask;        // bit k: AOV k is lentil_debug (also set in closest_mask)
   uint32_t n_aovs;
   uint32_t closest_mask;      // bit k: AOV k is closest-filtered (never bit 0)
   uint64_t np;       // xres*yres
@@ -744,7 +746,7 @@ LD_DEV AcceptResult accept_item(const DrawArgs &a, AcceptShared &sh, uint32_t it
     const ItemVisit h = load_item_visit(a, item, lens_length);
     const uint32_t S = h.samples, max_total = S * 5u, m_limit = max_total + retries;
     const float ae = h.I.add_energy, w = h.w;
-    const unsigned long long zk = a.F.zkey ? closest_key(h.I.depth, visit_gid(a.V, h.visit)) : 0ull;
+    const unsigned long long zk = (a.F.zkey || a.F.zkey_dbg) ? closest_key(h.I.depth, visit_gid(a.V, h.visit)) : 0ull;
     // per-item add table: gaussian AOVs' (value + add_energy) * w, then the weight itself
     uint32_t U = 1;
     for (uint32_t k = 0; k < a.F.n_aovs; ++k) if (!(a.F.closest_mask & (1u << k))) U += 4;
@@ -809,6 +811,7 @@ LD_DEV AcceptResult accept_item(const DrawArgs &a, AcceptShared &sh, uint32_t it
         rmax_p1 = row + 1u > rmax_p1 ? row + 1u : rmax_p1;
         s_pix[wave][(uint32_t)__builtin_popcountll(tmask0 & lt_mask)] = pix;
         if (a.F.zkey) atomicMin(a.F.zkey + pix, zk);
+        if (a.F.zkey_dbg) atomicMin(a.F.zkey_dbg + pix, zk);      // value.r = samples != 0 for every draw
         if (a.log_cap) {
           const unsigned long long li = atomicAdd(a.log_count, 1ull);
           if (li < a.log_cap) { a.log[li].visit = h.visit; a.log[li].attempt = my_n; a.log[li].pixel = pix; }
@@ -880,7 +883,7 @@ LD_DEV AcceptResult accept_item_chroma(const DrawArgs &a, AcceptShared &sh, uint
   const ItemVisit h = load_item_visit(a, item, lens_length);
   const uint32_t S = h.samples, max_total = S * 5u, m_limit = max_total + retries;
   const float ae = h.I.add_energy, w = h.w;
-  const unsigned long long zk = a.F.zkey ? closest_key(h.I.depth, visit_gid(a.V, h.visit)) : 0ull;
+  const unsigned long long zk = (a.F.zkey || a.F.zkey_dbg) ? closest_key(h.I.depth, visit_gid(a.V, h.visit)) : 0ull;
   uint32_t U = 1;
   for (uint32_t k = 0; k < a.F.n_aovs; ++k) if (!(a.F.closest_mask & (1u << k))) U += 4;
   if (threadIdx.x < a.F.n_aovs * 4u) {
@@ -968,6 +971,7 @@ LD_DEV AcceptResult accept_item_chroma(const DrawArgs &a, AcceptShared &sh, uint
         rmax_p1 = row + 1u > rmax_p1 ? row + 1u : rmax_p1;
         s_pix[wave][(uint32_t)__builtin_popcountll(tmask & lt_mask)] = pix;
         if (a.F.zkey) atomicMin(a.F.zkey + pix, zk);
+        if (a.F.zkey_dbg) atomicMin(a.F.zkey_dbg + pix, zk);      // value.r = samples != 0 for every draw
         if (a.log_cap) {
           const unsigned long long li = atomicAdd(a.log_count, 1ull);
           if (li < a.log_cap) { a.log[li].visit = h.visit; a.log[li].attempt = my_n | (c << 30); a.log[li].pixel = pix; }
@@ -1080,8 +1084,27 @@ __global__ __launch_bounds__(256) void closest_gather_kernel(FrameDev F, VisitsD
     uint32_t visit;
     if (!visit_from_gid(V, 0xFFFFFFFFu - (uint32_t)(key & 0xFFFFFFFFull), visit)) continue;   // another GPU's visit won
     for (uint32_t k = 1; k < F.n_aovs; ++k)
-      if (F.closest_mask & (1u << k))
+      if ((F.closest_mask & (1u << k)) && !(F.debug_mask & (1u << k)))
         *F.aov(p, k) = V.extra[k - 1][visit];
+  }
+}
+
+// lentil_debug (src/lentil_filter.cpp:209-211, src/lentil.h:838-845): the value is the draw count of the visit
+// (samples * redistribute, an int assigned to an AtRGBA: all four components), written only by redistributed
+// draws, closest by its own z-buffer.  The count is recomputed from the winner's columns.
+__global__ __launch_bounds__(256) void debug_gather_kernel(FrameDev F, VisitsDev V, lentil_params P, double lens_length) {
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; p < F.np; p += stride) {
+    const unsigned long long key = F.zkey_dbg[p];
+    if (key == ~0ull) continue;
+    uint32_t v;
+    if (!visit_from_gid(V, 0xFFFFFFFFu - (uint32_t)(key & 0xFFFFFFFFull), v)) continue;
+    const float invd = V.inv_density ? V.inv_density[v] : P.inverse_sample_density;
+    const VisitInfo I = visit_prologue(P, lens_length, V.rgba[v], V.pos_z[v], V.raydir_time[v], V.volume_ignore[v],
+                                       V.transmission[v], invd);
+    const float s = (float)I.samples;
+    for (uint32_t k = 1; k < F.n_aovs; ++k)
+      if (F.debug_mask & (1u << k)) *F.aov(p, k) = make_float4(s, s, s, s);
   }
 }
 

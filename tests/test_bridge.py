@@ -153,6 +153,9 @@ def test_operator_cook_plans_the_aov_list():
     # setup_filter's list: duplicates and AOVs lentil does not filter are dropped, the rest numbered
     arr = (bridge.AovPlan * len(plans))(*plans)
     m = bridge.load().lentil_sanitize_aov_list(arr, len(plans))
+    kinds = [bridge.load().lentil_aov_frame_kind(C.byref(arr[k])) for k in range(m)]
+    assert kinds == [_abi.FILTER_GAUSSIAN, _abi.FILTER_CLOSEST, _abi.FILTER_GAUSSIAN, _abi.FILTER_VARIANCE,
+                     _abi.FILTER_CLOSEST_DEBUG, _abi.FILTER_GAUSSIAN, _abi.FILTER_GAUSSIAN]
     kept = [(arr[k].name.decode(), arr[k].index) for k in range(m)]
     assert kept == [("RGBA", 0), ("P", 1), ("albedo", 2), ("N", 3), ("lentil_debug", 4), ("lentil_time", 5), ("lentil_raydir", 6)]
 

@@ -495,6 +495,38 @@ def test_po_chromatic_aberration(orc, gpu_ctx_factory, chroma, lens_mode, overri
     ref.close()
 
 
+def test_lentil_debug_aov(orc, gpu_ctx_factory):
+    """The lentil_debug AOV (src/lentil_filter.cpp:209-211, src/lentil.h:838-845): value = draw count of the
+    visit, written by redistributed draws only, closest through its own z-buffer; no visit column."""
+    W, H, M = 64, 40, 9
+    kinds = [_abi.FILTER_GAUSSIAN, _abi.FILTER_CLOSEST_DEBUG, _abi.FILTER_CLOSEST]
+    p, model, table, keep = common.po_setup(W, H, samples_override=0)          # draw counts from the CoC formula
+    visits, cols = common.make_stream(p, W, H, M, f_hi=0.03, n_extra=2)
+    cols["extra"][0] = None
+    visits, keepv = capi.make_visits(cols, visits_per_pixel=M, pixels_per_row=W)
+    # the oracle reads every column: hand it a dummy one for the debug AOV (its values are ignored)
+    ocols = dict(cols); ocols["extra"] = [np.zeros_like(cols["rgba"]), cols["extra"][1]]
+    ovisits, okeep = capi.make_visits(ocols, visits_per_pixel=M, pixels_per_row=W)
+    lens = orc.orc_lens_create(C.byref(table))
+    ref = oracle_lib.Frame(orc, p, n_aovs=3, kinds=kinds, keep_log=True)
+    ref.run(lens, None, ovisits)
+    orc.orc_lens_destroy(lens)
+    ctx = gpu_ctx_factory()
+    gpu_run(ctx, p, table, visits, n_aovs=3, kinds=kinds)
+    check_logs(ctx, ref)
+    dbg, _ = ctx.download_accum(1)
+    rdbg = ref.buffer(1)
+    assert np.array_equal(dbg, rdbg)
+    counts = np.unique(rdbg[:, 0])
+    assert len(counts) > 3 and counts.max() > 4                    # several different draw counts landed
+    assert np.array_equal(ctx.download_aov(1), ref.resolve(1))     # (count, count, count, 1)
+    # pixels no draw reached stay empty although their own visits wrote the ordinary closest AOV
+    own, _ = ctx.download_accum(2)
+    assert np.array_equal(own, ref.buffer(2))
+    assert ((rdbg[:, 0] == 0) & own.any(axis=1)).sum() > 0
+    ref.close()
+
+
 def test_po_ragged_pixels_and_inv_density(orc, gpu_ctx_factory):
     """Explicit per-visit pixel + per-visit inverse density (ragged footprints / adaptive sampling)."""
     W, H, M = 48, 32, 9
