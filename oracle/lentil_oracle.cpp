@@ -24,8 +24,12 @@
  *    build's own (tools/fit_lens.py) and the solver body restates the published
  *    polynomial-optics generator output as evidenced by that trace.
  *  - PARITY UNPINNED for Arnold SDK inline helpers (AiV3Normalize, AiM4PointByMatrixMult,
- *    AiBias, AI_* constants): the SDK is absent; they are restated from its public headers
- *    as recalled.
+ *    AiBias, AI_* constants, AtRGBA * AtRGB = AtRGBA(rgb, 1) in the chromatic splat, an int assigned
+ *    to an AtRGBA setting all four components for lentil_debug): the SDK is absent; they are
+ *    restated from its public headers as recalled.
+ *  - PARITY UNPINNED for the three Eigen operations of the thin-lens coma rotation (AngleAxisd ->
+ *    Matrix3d, Matrix3d::inverse, Matrix3d * Vector3d): Eigen is included from a sibling checkout
+ *    (src/lens.h:5-6, no version pinned) and absent here; restated from Eigen 3.3/3.4's sources.
  *  The reference itself is unbuildable here (needs <ai.h>, Eigen, CryptomatteArnold and
  *  the generated lens code), so there is no oracle/_ref.
  *
