@@ -897,7 +897,8 @@ static int resolve_range(lentil_hip_ctx *ctx, uint64_t p_begin, uint64_t p_end) 
     uint64_t blocks = (total + 255) / 256;
     const uint64_t max_blocks = (uint64_t)ctx->num_cu * 8;
     if (blocks > max_blocks) blocks = max_blocks;
-    hipLaunchKernelGGL(resolve_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, ctx->F, ctx->d_resolved, p_begin, p_end);
+    const size_t lds = (size_t)4 * 64 * ctx->F.stride * sizeof(float);      // 4 waves x 64 records
+    hipLaunchKernelGGL(resolve_kernel, dim3((unsigned)blocks), dim3(256), lds, ctx->stream, ctx->F, ctx->d_resolved, p_begin, p_end);
     HIP_TRY(ctx, hipGetLastError());
   }
   HIP_TRY(ctx, hipEventRecord(ctx->ev[4], ctx->stream));

@@ -1142,19 +1142,41 @@ __global__ __launch_bounds__(256) void merge_keys_kernel(FrameDev F, uint64_t p_
 // K7 -- driver_process_bucket's normalisation, src/lentil_imager.cpp:169-186.  Reads the pixel records,
 // writes one planar RGBA image per AOV (what the imager copies into Arnold's buckets).
 __global__ __launch_bounds__(256) void resolve_kernel(FrameDev F, float *resolved, uint64_t p_begin, uint64_t p_end) {
-  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-  for (uint64_t p = p_begin + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; p < p_end; p += stride) {
-    const float wt = *F.wt(p);
-    const float inv = wt != 0.0f ? 1.0f / wt : 1.0f;        // AtRGBA /= float multiplies by 1.0f/f
-    for (uint32_t a = 0; a < F.n_aovs; ++a) {
-      float4 c = *F.aov(p, a);
-      if (F.closest_mask & (1u << a)) {
-        c.w = 1.0f;                                        // closest: (r, g, b, 1), src/lentil_imager.cpp:181-186
-      } else if (wt != 0.0f) {
-        c.x *= inv; c.y *= inv; c.z *= inv; c.w *= inv;
+  // A wave takes 64 consecutive pixels: their records are one contiguous block, read with fully coalesced
+  // float4 loads into LDS; lane p then normalises pixel p and every AOV plane receives 64 adjacent RGBA
+  // values (1 KiB per store instruction).
+  extern __shared__ float4 s_rec[];                       // [waves per block][64 * stride / 4]
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  const uint32_t q = F.stride >> 2;                       // float4 per record (stride is a multiple of 8 floats)
+  float4 *tile = s_rec + (size_t)wave * 64u * q;
+  const uint64_t n_tiles = (p_end - p_begin + 63ull) / 64ull;
+  const uint64_t wave_global = (uint64_t)blockIdx.x * (blockDim.x >> 6) + wave;
+  const uint64_t wave_stride = (uint64_t)gridDim.x * (blockDim.x >> 6);
+  const float4 *acc4 = reinterpret_cast<const float4 *>(F.acc);
+  for (uint64_t t = wave_global; t < n_tiles; t += wave_stride) {
+    const uint64_t p0 = p_begin + t * 64ull;
+    const uint32_t n_pix = (uint32_t)((p_end - p0) < 64ull ? (p_end - p0) : 64ull);
+    const uint32_t n4 = n_pix * q;
+    for (uint32_t i = lane; i < n4; i += 64u) tile[i] = acc4[p0 * q + i];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (lane < n_pix) {
+      const float *rec = reinterpret_cast<const float *>(tile + (size_t)lane * q);
+      const float wt = rec[4u * F.n_aovs];
+      const float inv = wt != 0.0f ? 1.0f / wt : 1.0f;      // AtRGBA /= float multiplies by 1.0f/f
+      for (uint32_t a = 0; a < F.n_aovs; ++a) {
+        float4 c = tile[(size_t)lane * q + a];
+        if (F.closest_mask & (1u << a)) {
+          c.w = 1.0f;                                      // closest: (r, g, b, 1), src/lentil_imager.cpp:181-186
+        } else if (wt != 0.0f) {
+          c.x *= inv; c.y *= inv; c.z *= inv; c.w *= inv;
+        }
+        reinterpret_cast<float4 *>(resolved)[(uint64_t)a * F.np + p0 + lane] = c;
       }
-      reinterpret_cast<float4 *>(resolved)[(uint64_t)a * F.np + p] = c;
     }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
   }
 }
 
