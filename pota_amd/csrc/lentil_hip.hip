@@ -741,6 +741,7 @@ LENTIL_API int lentil_hip_redistribute(lentil_hip_ctx *ctx) {
     const uint64_t max_blocks = (uint64_t)ctx->num_cu * 8;
     size_t lds = 0;
     uint64_t n_tiles = 0;
+    bool multi = false;
     const uint32_t M = ctx->V.visits_per_pixel;
     if (M) {
       // staging: 20 B per visit per wave, 4 waves per block, keep a block under ~48 KiB
@@ -754,6 +755,15 @@ LENTIL_API int lentil_hip_redistribute(lentil_hip_ctx *ctx) {
       sa.ppt = ppt;
       sa.tv_pad = ppt * M;
       lds = (size_t)sa.tv_pad * 20 * 4 + 4 * kWaveQueue * sizeof(uint2);
+      // frames with extra AOVs: all columns of a visit in flight at once, one step = 64 / M whole pixels
+      multi = ctx->V.n_extra > 0 && M <= 64 && !getenv("LENTIL_SCAN_SINGLE_COLUMN");
+      if (multi) {
+        ppt = 64 / M;
+        sa.ppt = ppt;
+        sa.tv_pad = ppt * M;
+        const size_t wave_f4 = (size_t)ctx->F.n_aovs * 64 + 16 + (size_t)ppt * (ctx->F.stride / 4);
+        lds = 4 * wave_f4 * 16 + 4 * kWaveQueue * sizeof(uint2);
+      }
       const uint64_t n_pixels = (ctx->V.n + M - 1) / M;
       n_tiles = (n_pixels + ppt - 1) / ppt;
     }
@@ -790,7 +800,8 @@ LENTIL_API int lentil_hip_redistribute(lentil_hip_ctx *ctx) {
         if (M) {
           uint64_t blocks = (ch.tile_end - ch.tile_begin + 3) / 4;
           if (blocks > max_blocks) blocks = max_blocks;
-          hipLaunchKernelGGL(scan_uniform_kernel, dim3((unsigned)blocks), dim3(256), lds, ctx->stream, sa);
+          if (multi) hipLaunchKernelGGL(scan_uniform_multi_kernel, dim3((unsigned)blocks), dim3(256), lds, ctx->stream, sa);
+          else hipLaunchKernelGGL(scan_uniform_kernel, dim3((unsigned)blocks), dim3(256), lds, ctx->stream, sa);
         } else {
           uint64_t blocks = (ch.v_end - ch.v_begin + 255) / 256;
           if (blocks > max_blocks) blocks = max_blocks;

@@ -336,6 +336,134 @@ __global__ __launch_bounds__(256) void scan_uniform_kernel(ScanArgs a) {
 
 // K1+K2+K6 for ragged footprints (explicit per-visit pixel): lane per visit, fp32 atomics for the
 // direct accumulation.
+// K1+K2+K6 for frames with extra AOVs (visits_per_pixel <= 64).  A wave takes ppt = 64 / M whole pixels =
+// at most 64 visits per step: every lane issues all 5 + K column loads of its visit at once (the only way a
+// wide record gets enough bytes in flight), weights them, and parks one float4 per gaussian AOV in LDS.
+// Lane (pixel, aov) then adds that pixel's M entries in iterator order -- the reference's summation order --
+// into a record tile, and the tile's records go to the accumulators with coalesced float4 accesses.
+__global__ __launch_bounds__(256) void scan_uniform_multi_kernel(ScanArgs a) {
+  extern __shared__ float4 smem[];
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  const uint32_t waves_per_block = blockDim.x >> 6;
+  const VisitsDev &V = a.V;
+  const uint32_t M = V.visits_per_pixel;
+  const uint32_t ppt = a.ppt;                 // pixels per step, ppt * M <= 64
+  const uint32_t TV = ppt * M;
+  const uint32_t n_aovs = a.F.n_aovs;
+  const uint32_t q = a.F.stride >> 2;         // float4 per record
+  // per wave: [n_aovs][64] float4 staged values, [64] float weights, [ppt][stride] record tile, then the queue
+  const size_t wave_f4 = (size_t)n_aovs * 64u + 16u + (size_t)ppt * q;
+  float4 *sval = smem + (size_t)wave * wave_f4;
+  float *sw = reinterpret_cast<float *>(sval + (size_t)n_aovs * 64u);
+  float4 *srec = sval + (size_t)n_aovs * 64u + 16u;
+  uint2 *qmem = reinterpret_cast<uint2 *>(smem + (size_t)waves_per_block * wave_f4);
+  WaveQueue wq;
+  wq.init(qmem + (size_t)wave * kWaveQueue);
+
+  const uint64_t n_pixels = (V.n + M - 1) / M;
+  const uint64_t n_tiles = a.tile_end;
+  const uint64_t wave_global = a.tile_begin + (uint64_t)blockIdx.x * waves_per_block + wave;
+  const uint64_t wave_stride = (uint64_t)gridDim.x * waves_per_block;
+  const uint32_t xres = a.P.xres;
+  float4 *acc4 = reinterpret_cast<float4 *>(a.F.acc);
+
+  for (uint64_t tile = wave_global; tile < n_tiles; tile += wave_stride) {
+    const uint64_t pix0 = tile * ppt;
+    const uint64_t v = pix0 * M + lane;
+    const bool valid = (lane < TV) && (v < V.n);
+    bool flagged = false;
+    int samples = 0;
+    float w = 0.f;
+    float depth = 0.f;
+    float4 val[LENTIL_MAX_AOVS];
+    if (valid) {
+      const float4 rgba = V.rgba[v];
+      const float4 pz = V.pos_z[v];
+      const float4 rt = V.raydir_time[v];
+      const float4 vi = V.volume_ignore[v];
+      const float4 tr = V.transmission[v];
+#pragma unroll
+      for (uint32_t k = 1; k < LENTIL_MAX_AOVS; ++k)
+        if (k < n_aovs && !(a.F.closest_mask & (1u << k))) val[k] = V.extra[k - 1][v];
+      const float invd = V.inv_density ? V.inv_density[v] : a.P.inverse_sample_density;
+      const VisitInfo I = visit_prologue(a.P, a.lens_length, rgba, pz, rt, vi, tr, invd);
+      depth = pz.w;
+      if (I.redistribute) {
+        flagged = true;
+        samples = I.samples;
+      } else {
+        w = 1.0f * invd;                                // filter_weight * inv_density, lentil.h:949-953
+        val[0] = rgba;
+      }
+    }
+    wq.push(flagged, (uint32_t)v, (uint32_t)samples, a.work, a.work_cap, a.ctr);
+    if (lane < TV) {
+      sw[lane] = w;
+#pragma unroll
+      for (uint32_t k = 0; k < LENTIL_MAX_AOVS; ++k) {
+        if (k < n_aovs && !(a.F.closest_mask & (1u << k))) {
+          float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (w != 0.0f) x = make_float4((val[k].x + 0.0f) * w, (val[k].y + 0.0f) * w, (val[k].z + 0.0f) * w, (val[k].w + 0.0f) * w);
+          sval[(size_t)k * 64u + lane] = x;
+        }
+      }
+    }
+    // closest AOVs: a pixel's own (non-redistributed) visits compete with their depth
+    if (a.F.zkey && valid && w != 0.0f) {
+      const uint64_t pp = pix0 + lane / M;
+      const int px = V.pixel_x0 + (int)(pp % V.pixels_per_row);
+      const int py = V.pixel_y0 + (int)(pp / V.pixels_per_row) * (int)V.pixel_row_stride;
+      atomicMin(a.F.zkey + ((uint64_t)px + (uint64_t)py * xres), closest_key(depth, visit_gid(V, (uint32_t)v)));
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+    // sums: one lane per (pixel, AOV), M entries in iterator order
+    const uint64_t left = n_pixels - pix0;
+    const uint32_t np_tile = (uint32_t)(left < ppt ? left : ppt);
+    for (uint32_t idx = lane; idx < np_tile * q; idx += 64u) srec[idx] = make_float4(0.f, 0.f, 0.f, 0.f);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    for (uint32_t idx = lane; idx < np_tile * n_aovs; idx += 64u) {
+      const uint32_t pi = idx / n_aovs, k = idx - pi * n_aovs;
+      if (a.F.closest_mask & (1u << k)) continue;
+      float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+      float ws = 0.f;
+      for (uint32_t j = 0; j < M; ++j) {
+        const float cw = sw[pi * M + j];
+        if (cw != 0.0f) {
+          const float4 c = sval[(size_t)k * 64u + pi * M + j];
+          sum.x += c.x; sum.y += c.y; sum.z += c.z; sum.w += c.w;
+          ws += cw;
+        }
+      }
+      srec[(size_t)pi * q + k] = sum;
+      if (k == 0) reinterpret_cast<float *>(srec + (size_t)pi * q)[4u * n_aovs] = ws;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+    // records -> accumulators (a row of the stream ends after pixels_per_row pixels, the frame row is wider)
+    for (uint32_t i = lane; i < np_tile * q; i += 64u) {
+      const uint32_t pi = i / q, j = i - pi * q;
+      const uint64_t pp = pix0 + pi;
+      const int px = V.pixel_x0 + (int)(pp % V.pixels_per_row);
+      const int py = V.pixel_y0 + (int)(pp / V.pixels_per_row) * (int)V.pixel_row_stride;
+      float4 *dst = acc4 + ((uint64_t)px + (uint64_t)py * xres) * q + j;
+      const float4 add = srec[i];
+      float4 cur = *dst;
+      cur.x += add.x; cur.y += add.y; cur.z += add.z; cur.w += add.w;
+      *dst = cur;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+  wq.finish(a.work, a.work_cap, a.ctr);
+}
+
 __global__ __launch_bounds__(256) void scan_ragged_kernel(ScanArgs a) {
   const VisitsDev &V = a.V;
   __shared__ uint2 s_queue[4 * kWaveQueue];
