@@ -6,14 +6,17 @@
 
 One "step" = one redistribution pass over one frame's worth of synthetic AOV-sample visits that are
 already resident in HBM: clear accumulators -> scan/compact/direct-accumulate -> draw/splat ->
-(N>1: RCCL sum all-reduce of the accumulators) -> resolve.  `value` = visits consumed by all ranks
+(N>1: exchange of the cross-tile splats over xGMI) -> resolve.  `value` = visits consumed by all ranks
 per second (Msamples/s; 1 sample = 1 visit record of 80+16K bytes).
 
 Workload at N=1: the configuration the metric is quoted on -- double-gauss 50 mm polynomial optics,
 3840x2160, 9 visits/pixel (AA 3), 1024 redistribution draws per redistributed visit, beauty only,
 highlight fraction f_hi (default 2^-16, the scan-dominated regime of SURVEY.md section 8d; the
 highlight-heavy regime 1.6e-3 is reported beside it in "regimes").  N>1 keeps the per-GPU work fixed
-(weak scaling): the frame grows to N x 2160 rows, rank r owns rows r mod N.
+(weak scaling): the same camera at N times the pixels (16:9, sqrt(N) finer both ways), rank r owns a band
+of consecutive rows -- its visits and its tile of the output -- and sends the rows its draws touched
+outside the band to their owners (pota_amd/distributed.py::frame_step_bands).
+LENTIL_PARTITION=interleaved selects rows r mod N with one sum all-reduce of the whole frame instead.
 
 The printed JSON line also carries
   roofline     -- the HBM-bound scan kernel: algorithmic bytes (visits x 80 B) / its mean duration,
@@ -23,6 +26,7 @@ The printed JSON line also carries
 """
 import argparse
 import json
+import math
 import os
 import sys
 import threading
@@ -136,8 +140,17 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     dev = torch.device("cuda", local_rank)
 
-    W, Hr, M = args.width, args.height, args.visits_per_pixel
-    H = Hr * world                                  # weak scaling: per-GPU rows stay fixed
+    M = args.visits_per_pixel
+    # Weak scaling: N GPUs render the same camera at N times the pixels (same 16:9 frame, sqrt(N) finer in both
+    # directions), so every rank's band has the per-GPU pixel count, highlight count and field-angle mix of the
+    # single-GPU frame.  (Stacking N frames on top of each other would push the outer bands far off axis, where the
+    # lens passes nothing and every visit burns its 5 x samples attempts.)
+    if world == 1:
+        W, Hr = args.width, args.height
+    else:
+        W = int(round(args.width * math.sqrt(world)))
+        Hr = int(round(args.height / math.sqrt(world)))
+    H = Hr * world
     p = camera.default_params()
     camera.setup_filter(p, W, H, filter_width=1.0, aa_samples=3)
     p, model = camera.setup_po(p, args.lens, focus_dist=150.0)
@@ -227,9 +240,10 @@ def main():
         "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
         "config": {
-            "workload": "polynomial-optics %s (self-fitted table), %dx%d per GPU, %d visits/pixel, %d redistribution "
-                        "draws per redistributed visit, %d AOV(s), highlight fraction f_hi=%.3g, frame rows split over %d GPU(s)"
-                        % (args.lens, W, Hr, M, args.samples, 1 + args.aovs, args.f_hi, world),
+            "workload": "polynomial-optics %s (self-fitted table), frame %dx%d (%d x the pixels of %dx%d, same camera), "
+                        "%d rows per GPU, %d visits/pixel, %d redistribution draws per redistributed visit, %d AOV(s), "
+                        "highlight fraction f_hi=%.3g"
+                        % (args.lens, W, H, world, args.width, args.height, Hr, M, args.samples, 1 + args.aovs, args.f_hi),
             "visits_per_gpu": n_local, "bytes_per_visit": bytes_per_visit,
             "redistributed_visits_rank0": int(ctr.redistributed_visits),
             "attempted_draws_rank0": int(ctr.attempted_draws), "accepted_draws_rank0": int(ctr.accepted_draws),
