@@ -212,6 +212,9 @@ typedef struct lentil_counters {
   uint64_t newton_iterations;    /* lane-iterations of the lt_sample_aperture solver (PO draw kernel) */
   uint64_t tries;                /* aperture draws = solves started (attempts x vignetting retries) */
   uint64_t lane_rounds;          /* 64 x scheduler rounds: iteration slots offered (utilisation = iterations / this) */
+  uint64_t slow_solves;          /* solves finished by the one-wave-per-solve straggler kernel (LENTIL_SLOW_AT) */
+  uint64_t blind_chunks;         /* chunks whose draw rounds were enqueued without waiting for their scan (sized from the previous pass) */
+  uint64_t fallback_chunks;      /* ... of which did not fit and were redone with exact sizes */
 } lentil_counters;
 
 /* one accepted draw, for index-parity tests: (visit, attempt n, linear pixel) */

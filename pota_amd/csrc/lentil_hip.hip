@@ -63,13 +63,27 @@ struct lentil_hip_ctx {
     uint64_t task_cap = 0;
     uint32_t *pool[2] = {nullptr, nullptr};
     uint64_t pool_cap = 0;
+    SlowRec *slow = nullptr;     // straggler queue (solve_slow_kernel)
+    uint64_t slow_cap = 0;
+    // what the last pass found in this chunk: sizes the buffers and grids of the next pass, whose draw rounds are
+    // then enqueued without waiting for the scan ("blind"; prep_items_kernel checks that everything fits)
+    bool have_est = false, was_blind = false;
+    uint64_t est_items = 0, est_sum = 0;
   };
   std::vector<Chunk> chunks;
   int n_chunks = 2;
   double first_chunk_frac = 0.5;             // LENTIL_FIRST_CHUNK_FRAC
   uint64_t early_cap_samples = 4ull << 20;   // LENTIL_EARLY_CAP_SAMPLES
   uint64_t max_pool_units = 1ull << 32;    // 16 GiB per pool at most (LENTIL_MAX_POOL_UNITS overrides)
+  int slow_at = 20;                          // LENTIL_SLOW_AT: iterations after which a solve is parked (0: never)
+ uint64_t slow_below = 8ull << 20;          // LENTIL_SLOW_BELOW: ... in chunks whose draw sum is below this
+  bool blind = true;                         // LENTIL_BLIND=0: always wait for a chunk's scan before sizing its draw rounds
+  uint32_t extra_num = 16, extra_const = 16; // LENTIL_EXTRA_256THS / LENTIL_EXTRA_CONST: first-batch over-provisioning
+  uint64_t extra_below = 8ull << 20;         // LENTIL_EXTRA_BELOW: ... while a chunk's draw sum is below this
+  int solve_cap_blocks = 1;                  // LENTIL_EARLY_CAP_BLOCKS: solve blocks per CU while later chunks are scanned
+  int solve_max_blocks = 4;                  // LENTIL_SOLVE_BLOCKS: solve blocks per CU at most
   int last_rounds = 0;
+  uint32_t last_blind = 0, last_fallback = 0;
   uint32_t last_scan_launches = 0;
   // rows that may be non-zero since the last clear_frame (only trusted when dirty_known)
   int32_t dirty_lo = 0, dirty_hi = 0;
@@ -147,6 +161,19 @@ LENTIL_API int lentil_hip_create(int device, lentil_hip_ctx **out_ctx) {
   }
   if (const char *ec = getenv("LENTIL_EARLY_CAP_SAMPLES")) ctx->early_cap_samples = strtoull(ec, nullptr, 10);
   if (const char *mp = getenv("LENTIL_MAX_POOL_UNITS")) ctx->max_pool_units = strtoull(mp, nullptr, 10);
+  if (const char *sa = getenv("LENTIL_SLOW_AT")) ctx->slow_at = atoi(sa);
+  if (ctx->slow_at < 0 || ctx->slow_at >= 100) ctx->slow_at = 0;
+  if (const char *e = getenv("LENTIL_SLOW_BELOW")) ctx->slow_below = strtoull(e, nullptr, 10);
+  if (const char *e = getenv("LENTIL_BLIND")) ctx->blind = !(e[0] == '0');
+  if (const char *e = getenv("LENTIL_EXTRA_256THS")) ctx->extra_num = (uint32_t)strtoul(e, nullptr, 10);
+  if (const char *e = getenv("LENTIL_EXTRA_CONST")) ctx->extra_const = (uint32_t)strtoul(e, nullptr, 10);
+  if (const char *e = getenv("LENTIL_EXTRA_BELOW")) ctx->extra_below = strtoull(e, nullptr, 10);
+  if (ctx->extra_num > 512) ctx->extra_num = 512;       // the result pool holds 4 x the draw sum
+  if (ctx->extra_const > 64) ctx->extra_const = 64;
+  if (const char *e = getenv("LENTIL_EARLY_CAP_BLOCKS")) ctx->solve_cap_blocks = atoi(e);
+  if (ctx->solve_cap_blocks < 1) ctx->solve_cap_blocks = 1;
+  if (const char *e = getenv("LENTIL_SOLVE_BLOCKS")) ctx->solve_max_blocks = atoi(e);
+  if (ctx->solve_max_blocks < 1) ctx->solve_max_blocks = 1;
   *out_ctx = ctx;
   return LENTIL_OK;
 }
@@ -184,6 +211,7 @@ LENTIL_API int lentil_hip_destroy(lentil_hip_ctx *ctx) {
     if (ch.stream) (void)hipStreamSynchronize(ch.stream);
     (void)hipFree(ch.hdr); (void)hipFree(ch.prog);
     for (int i = 0; i < 2; ++i) { (void)hipFree(ch.active[i]); (void)hipFree(ch.tasks[i]); (void)hipFree(ch.pool[i]); }
+    (void)hipFree(ch.slow);
     if (ch.scanned) (void)hipEventDestroy(ch.scanned);
     if (ch.done) (void)hipEventDestroy(ch.done);
     if (ch.stream) (void)hipStreamDestroy(ch.stream);
@@ -561,6 +589,9 @@ static void launch_solve(lentil_hip_ctx *ctx, const DrawArgs &da, hipStream_t st
   } else {
     hipLaunchKernelGGL(solve_thinlens_kernel, dim3(blocks), dim3(256), 0, st, da);
   }
+  // stragglers parked by the solve kernel: one wave each (blind launch; an empty queue costs a few microseconds)
+  if (da.P.cameraType == LENTIL_POLYNOMIAL_OPTICS && da.slow)
+    hipLaunchKernelGGL(solve_slow_kernel, dim3((unsigned)ctx->num_cu * 4), dim3(64), 0, st, da);
 }
 
 // Size one chunk's draw-pipeline buffers from its scan result and enqueue prep + `blind_rounds`
@@ -590,6 +621,13 @@ static int size_chunk_buffers(lentil_hip_ctx *ctx, lentil_hip_ctx::Chunk &ch, ui
     if ((rc = grow(ctx, &ch.pool[1], nc))) return rc;
     ch.pool_cap = nc;
   }
+  // stragglers are about 0.1 % of the solves; a full queue only means they stay in their lanes
+  const uint64_t slow_need = units / 128 + 4096;
+  if (ctx->slow_at > 0 && slow_need > ch.slow_cap) {
+    const uint64_t nc = slow_need + slow_need / 4;
+    if ((rc = grow(ctx, &ch.slow, nc))) return rc;
+    ch.slow_cap = nc;
+  }
   return LENTIL_OK;
 }
 
@@ -599,6 +637,8 @@ static void bind_chunk_buffers(const lentil_hip_ctx::Chunk &ch, DrawArgs &da) {
   for (int i = 0; i < 2; ++i) { da.tasks[i] = ch.tasks[i]; da.active[i] = ch.active[i]; da.pool[i] = ch.pool[i]; }
   da.task_cap = (uint32_t)(ch.task_cap > 0xFFFFFFF0ull ? 0xFFFFFFF0ull : ch.task_cap);
   da.pool_cap = ch.pool_cap < 0xFFFFFFFFull ? ch.pool_cap : 0xFFFFFFFFull;
+  da.slow = ch.slow;
+  da.slow_cap = (uint32_t)(ch.slow_cap < 0xFFFFFFF0ull ? ch.slow_cap : 0xFFFFFFF0ull);
 }
 
 // rounds with a host check after each (used when the blind rounds did not finish a chunk, and for
@@ -623,10 +663,82 @@ static int finish_rounds(lentil_hip_ctx *ctx, int ci, DrawArgs &da, int first_ro
   return LENTIL_OK;
 }
 
-// Size one chunk's draw-pipeline buffers from its scan result and enqueue prep + `blind_rounds`
-// solve/accept rounds on the chunk's stream (no host round trip between the rounds: every kernel
-// reads its queue lengths from device memory; a round with empty queues costs a few microseconds).
-// A chunk whose result pool would exceed max_pool_units is processed in sub-batches of items, each
+// prep + `blind_rounds` solve/accept rounds of one chunk on the chunk's stream, no host round trip in between:
+// every kernel reads its queue lengths from device memory (a round with empty queues costs a few microseconds).
+// n_items / sum_samples size the grids only (exact after a scan read-back, last pass's figures in blind mode).
+static int launch_chunk_rounds(lentil_hip_ctx *ctx, int ci, DrawArgs &da, uint64_t n_items, uint64_t sum_samples,
+                               uint64_t prep_threads, int blind_rounds) {
+  lentil_hip_ctx::Chunk &ch = ctx->chunks[ci];
+  const uint64_t nch = (uint64_t)da.n_channels;
+  const uint64_t max_blocks = (uint64_t)ctx->num_cu * (uint64_t)ctx->solve_max_blocks;
+  da.parity = 0;
+  hipLaunchKernelGGL(prep_items_kernel, dim3((unsigned)((prep_threads + 255) / 256)), dim3(256), 0, ch.stream, da);
+  HIP_TRY(ctx, hipGetLastError());
+  // enough persistent waves for the chunk's first batch, at most 4 blocks per CU
+  const uint64_t want = (nch * (sum_samples / 64 + n_items) + 3) / 4;
+  unsigned solve_blocks = (unsigned)(want < 1 ? 1 : (want > max_blocks ? max_blocks : want));
+  if (ci + 1 < ctx->n_chunks && sum_samples < ctx->early_cap_samples) {
+    // Later chunks are still being scanned and this chunk's solves are a fraction of a scan's worth of
+    // work: few blocks per CU leave the register file to the scan's waves, which otherwise wait for the
+    // persistent solve blocks to drain.
+    const unsigned cap = (unsigned)ctx->num_cu * (unsigned)ctx->solve_cap_blocks;
+    if (solve_blocks > cap) solve_blocks = cap;
+  }
+  const uint64_t acc_want = n_items < 1 ? 1 : n_items;
+  const unsigned accept_blocks = (unsigned)(acc_want > (uint64_t)ctx->num_cu * 2 ? (uint64_t)ctx->num_cu * 2 : acc_want);
+  for (int round = 0; round < blind_rounds; ++round) {
+    da.parity = round & 1;
+    launch_solve(ctx, da, ch.stream, round == 0 ? solve_blocks : (solve_blocks > 256 ? 256 : solve_blocks));
+    // Splats go anywhere in the frame, also into rows a later chunk's scan is still read-modify-writing with
+    // plain stores: solves may overlap the remaining scans, the first accept may not.
+    if (round == 0) HIP_TRY(ctx, hipStreamWaitEvent(ch.stream, ctx->scans_done, 0));
+    hipLaunchKernelGGL(accept_kernel, dim3(accept_blocks), dim3(256), 0, ch.stream, da);
+    HIP_TRY(ctx, hipGetLastError());
+  }
+  return LENTIL_OK;
+}
+
+static uint64_t chunk_units(const lentil_params &P, uint64_t nch, uint64_t sum_samples, uint64_t n_items) {
+  const bool po = P.cameraType == LENTIL_POLYNOMIAL_OPTICS;
+  const uint64_t retries = po ? (uint64_t)(P.vignetting_retries < 0 ? 0 : P.vignetting_retries) : 0u;
+  // round 0 needs sum(samples + retries) results per wavelength channel (plus the over-provisioned share); a later
+  // round at most the attempts an item has left (chromatic mode re-solves up to `retries` results of a stalled attempt)
+  return nch * (4 * sum_samples + (3 * retries + 32) * n_items);
+}
+
+// Blind mode: buffers and grids from what the previous pass found in this chunk (with headroom); the stream
+// waits for the chunk's scan on the device, the host does not.  prep_items_kernel reads the real item count and
+// raises DevCounters::fallback -- emitting nothing -- when it does not fit.
+static int enqueue_chunk_draws_blind(lentil_hip_ctx *ctx, int ci, DrawArgs &da, int blind_rounds, bool *done) {
+  lentil_hip_ctx::Chunk &ch = ctx->chunks[ci];
+  *done = false;
+  if (!ctx->blind || !ch.have_est) return LENTIL_OK;
+  const uint64_t cap = ch.v_end - ch.v_begin;
+  uint64_t items = ch.est_items + ch.est_items / 4 + 1024;
+  if (items > cap) items = cap;
+  const uint64_t sum = ch.est_sum + ch.est_sum / 4 + 65536;
+  const uint64_t nch = (uint64_t)da.n_channels;
+  const uint64_t units = chunk_units(ctx->P, nch, sum, items);
+  if (units > ctx->max_pool_units || items == 0) return LENTIL_OK;
+  int rc;
+  if ((rc = size_chunk_buffers(ctx, ch, items, units))) return rc;
+  bind_chunk_buffers(ch, da);
+  const bool po = ctx->P.cameraType == LENTIL_POLYNOMIAL_OPTICS;
+  da.ctr = ctx->d_ctr + ci;
+  da.retries = po ? (int32_t)(ctx->P.vignetting_retries < 0 ? 0 : ctx->P.vignetting_retries) : 0;
+  da.work = ctx->d_work + ch.v_begin;
+  da.work_cap = cap;
+  da.blind = 1u;
+  da.n_items = ch.item_cap < cap ? ch.item_cap : cap;      // capacity; the count comes from the scan's counter
+  if ((rc = launch_chunk_rounds(ctx, ci, da, ch.est_items, ch.est_sum, da.n_items, blind_rounds))) return rc;
+  ch.n_items = 1;          // unknown until the counters are read back: have the continuation loop look
+  ch.was_blind = true;
+  *done = true;
+  return LENTIL_OK;
+}
+
+// Sizes one chunk's draw-pipeline buffers from its scan result (host waits for the chunk's scan) and enqueues
+// its rounds.  A chunk whose result pool would exceed max_pool_units is processed in sub-batches of items, each
 // run to completion before the next reuses the buffers.
 static int enqueue_chunk_draws(lentil_hip_ctx *ctx, int ci, DrawArgs &da, int blind_rounds) {
   lentil_hip_ctx::Chunk &ch = ctx->chunks[ci];
@@ -640,15 +752,17 @@ static int enqueue_chunk_draws(lentil_hip_ctx *ctx, int ci, DrawArgs &da, int bl
   const uint64_t cap = ch.v_end - ch.v_begin;
   const uint64_t n_items = c.work_count < cap ? c.work_count : cap;
   ch.n_items = n_items;
+  ch.was_blind = false;
+  ch.have_est = true; ch.est_items = n_items; ch.est_sum = c.sum_samples;
   if (n_items == 0) return LENTIL_OK;
   const bool po = P.cameraType == LENTIL_POLYNOMIAL_OPTICS;
   const uint32_t retries = po ? (uint32_t)(P.vignetting_retries < 0 ? 0 : P.vignetting_retries) : 0u;
   da.ctr = dctr;
   da.retries = (int32_t)retries;
-  // round 0 needs sum(samples + retries) results per wavelength channel; a later round at most the attempts
-  // an item has left (chromatic mode re-solves up to `retries` results of a stalled attempt)
+  da.blind = 0u;
+  da.work_cap = cap;
   const uint64_t nch = (uint64_t)da.n_channels;
-  const uint64_t units = nch * (4 * c.sum_samples + (uint64_t)(3 * retries + 32) * n_items);
+  const uint64_t units = chunk_units(P, nch, c.sum_samples, n_items);
   const uint64_t max_blocks = (uint64_t)ctx->num_cu * 4;
   int rc;
   if (units <= ctx->max_pool_units) {
@@ -656,29 +770,7 @@ static int enqueue_chunk_draws(lentil_hip_ctx *ctx, int ci, DrawArgs &da, int bl
     bind_chunk_buffers(ch, da);
     da.work = ctx->d_work + ch.v_begin;
     da.n_items = n_items;
-    da.parity = 0;
-    hipLaunchKernelGGL(prep_items_kernel, dim3((unsigned)((n_items + 255) / 256)), dim3(256), 0, ch.stream, da);
-    HIP_TRY(ctx, hipGetLastError());
-    // enough persistent waves for the chunk's first batch, at most 4 blocks per CU
-    const uint64_t want = (nch * (c.sum_samples / 64 + n_items) + 3) / 4;
-    unsigned solve_blocks = (unsigned)(want < 1 ? 1 : (want > max_blocks ? max_blocks : want));
-    if (ci + 1 < ctx->n_chunks && c.sum_samples < ctx->early_cap_samples) {
-      // Later chunks are still being scanned and this chunk's solves are a fraction of a scan's worth of
-      // work: one block per CU (one wave per SIMD still issues fp64 back to back) leaves the register
-      // file to the scan's waves, which otherwise wait for the persistent solve blocks to drain.
-      if (solve_blocks > (unsigned)ctx->num_cu) solve_blocks = (unsigned)ctx->num_cu;
-    }
-    const unsigned accept_blocks = (unsigned)(n_items > (uint64_t)ctx->num_cu * 2 ? (uint64_t)ctx->num_cu * 2 : n_items);
-    for (int round = 0; round < blind_rounds; ++round) {
-      da.parity = round & 1;
-      launch_solve(ctx, da, ch.stream, round == 0 ? solve_blocks : (solve_blocks > 256 ? 256 : solve_blocks));
-      // Splats go anywhere in the frame, also into rows a later chunk's scan is still read-modify-writing with
-      // plain stores: solves may overlap the remaining scans, the first accept may not.
-      if (round == 0) HIP_TRY(ctx, hipStreamWaitEvent(ch.stream, ctx->scans_done, 0));
-      hipLaunchKernelGGL(accept_kernel, dim3(accept_blocks), dim3(256), 0, ch.stream, da);
-      HIP_TRY(ctx, hipGetLastError());
-    }
-    return LENTIL_OK;
+    return launch_chunk_rounds(ctx, ci, da, n_items, c.sum_samples, n_items, blind_rounds);
   }
   // ---- too many draws for one result pool: sub-batches of items, bounded by the per-item worst case
   const uint64_t max_samples = P.samples_override > 0 ? (uint64_t)P.samples_override : 2000ull;
@@ -691,13 +783,13 @@ static int enqueue_chunk_draws(lentil_hip_ctx *ctx, int ci, DrawArgs &da, int bl
     bind_chunk_buffers(ch, da);
     // fresh queues for this batch
     HIP_TRY(ctx, hipMemsetAsync((char *)dctr + offsetof(DevCounters, n_tasks), 0,
-                                sizeof(DevCounters) - offsetof(DevCounters, n_tasks), ch.stream));
+                                offsetof(DevCounters, inv_row_min) - offsetof(DevCounters, n_tasks), ch.stream));
     da.work = ctx->d_work + ch.v_begin + i0;
     da.n_items = ni;
     da.parity = 0;
     hipLaunchKernelGGL(prep_items_kernel, dim3((unsigned)((ni + 255) / 256)), dim3(256), 0, ch.stream, da);
     launch_solve(ctx, da, ch.stream, (unsigned)max_blocks);
-    if (i0 == 0) HIP_TRY(ctx, hipStreamWaitEvent(ch.stream, ctx->scans_done, 0));   // see the blind rounds above
+    if (i0 == 0) HIP_TRY(ctx, hipStreamWaitEvent(ch.stream, ctx->scans_done, 0));   // see launch_chunk_rounds
     hipLaunchKernelGGL(accept_kernel, dim3((unsigned)ctx->num_cu * 2), dim3(256), 0, ch.stream, da);
     HIP_TRY(ctx, hipGetLastError());
     int rounds = 0;
@@ -730,6 +822,7 @@ LENTIL_API int lentil_hip_redistribute(lentil_hip_ctx *ctx) {
   HIP_TRY(ctx, hipMemsetAsync(ctx->d_ctr, 0, sizeof(DevCounters) * (C + 1), ctx->stream));
   HIP_TRY(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
   ctx->last_rounds = 0;
+  ctx->last_blind = ctx->last_fallback = 0;
   ctx->last_scan_launches = 0;
   if (ctx->V.n) {
     // ---- scans: all chunks back to back on the main stream
@@ -836,15 +929,49 @@ LENTIL_API int lentil_hip_redistribute(lentil_hip_ctx *ctx) {
     da.bokeh = ctx->bokeh;
     da.V = ctx->V;
     da.F = ctx->F;
+    da.slow_at = ctx->slow_at;
+    da.slow_below = ctx->slow_below;
+    da.extra_num = ctx->extra_num; da.extra_const = ctx->extra_const; da.extra_below = ctx->extra_below;
     da.log = ctx->d_log;
     da.log_cap = ctx->log_cap;
     da.log_count = &ctx->d_ctr[C].log_count;
     const int blind_rounds = 3;
     std::vector<DrawArgs> das(C, da);
+    // chunks whose last pass left an estimate go first, without any host wait; the others wait for their scan
+    std::vector<char> enq(C, 0);
     for (int ci = 0; ci < C; ++ci) {
       HIP_TRY(ctx, hipStreamWaitEvent(ctx->chunks[ci].stream, ctx->chunks[ci].scanned, 0));
+      bool done = false;
+      const int rc = enqueue_chunk_draws_blind(ctx, ci, das[ci], blind_rounds, &done);
+      if (rc) return rc;
+      enq[ci] = done ? 1 : 0;
+      if (done) ++ctx->last_blind;
+    }
+    for (int ci = 0; ci < C; ++ci) {
+      if (enq[ci]) continue;
       const int rc = enqueue_chunk_draws(ctx, ci, das[ci], blind_rounds);
       if (rc) return rc;
+    }
+    // ---- blind chunks: what the scan really found (next pass's estimate); a chunk that did not fit is redone
+    for (int ci = 0; ci < C; ++ci) {
+      lentil_hip_ctx::Chunk &ch = ctx->chunks[ci];
+      if (!enq[ci]) continue;
+      HIP_TRY(ctx, hipStreamSynchronize(ch.stream));
+      DevCounters c;
+      HIP_TRY(ctx, hipMemcpy(&c, ctx->d_ctr + ci, offsetof(DevCounters, n_tasks), hipMemcpyDeviceToHost));
+      if (c.fallback) {
+        ++ctx->last_fallback;
+        // the empty rounds left their queue cursors behind: fresh queues, then the chunk again with exact sizes
+        HIP_TRY(ctx, hipMemsetAsync((char *)(ctx->d_ctr + ci) + offsetof(DevCounters, n_tasks), 0,
+                                    offsetof(DevCounters, inv_row_min) - offsetof(DevCounters, n_tasks), ch.stream));
+        const int rc = enqueue_chunk_draws(ctx, ci, das[ci], blind_rounds);
+        if (rc) return rc;
+      } else {
+        const uint64_t cap = ch.v_end - ch.v_begin;
+        ch.est_items = c.work_count < cap ? c.work_count : cap;
+        ch.est_sum = c.sum_samples;
+        if (ch.est_items == 0) ch.n_items = 0;
+      }
     }
     // ---- any chunk with items still missing draws after the blind rounds continues round by round
     int max_rounds = ctx->last_rounds > blind_rounds ? ctx->last_rounds : blind_rounds;
@@ -1071,7 +1198,10 @@ LENTIL_API int lentil_hip_get_counters(lentil_hip_ctx *ctx, lentil_counters *out
     out->newton_iterations += c[i].newton_iters;
     out->tries += c[i].tries;
     out->lane_rounds += c[i].lane_rounds;
+    out->slow_solves += c[i].slow_solves;
   }
+  out->blind_chunks = ctx->last_blind;
+  out->fallback_chunks = ctx->last_fallback;
   return LENTIL_OK;
 }
 

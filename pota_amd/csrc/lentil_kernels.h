@@ -29,12 +29,16 @@ struct DevCounters {
   unsigned long long newton_iters;   // lane-iterations of the Newton solver
   unsigned long long tries;          // solves started
   unsigned long long lane_rounds;    // 64 x scheduler rounds (iteration slots offered)
+  unsigned long long slow_solves;    // solves handed over to solve_slow_kernel (stragglers)
+  unsigned long long fallback;       // blind prep: the chunk did not fit the buffers sized from the last pass
   // per-round queues, double buffered by round parity
   unsigned int n_tasks[2];
   unsigned int task_head[2];
   unsigned int n_active[2];
   unsigned int active_head[2];
   unsigned long long pool_used[2];
+  unsigned int n_slow[2];            // stragglers parked by this round's solve kernel
+  unsigned int slow_head[2];
   // rows of the frame this pass has added to (zero-initialised: "none"): max over (INT_MAX - row), max over (row + 1)
   unsigned int inv_row_min, row_max_p1;
 };
@@ -562,6 +566,17 @@ struct Task {             // up to 64 consecutive m of one item (and one wavelen
   uint32_t item, m_base, res_off, count;   // count: bits 0-7 number of m, bits 8-9 channel
 };
 
+// A solve that is still running after `slow_at` Newton iterations (about one in a thousand) is parked here by
+// solve_po_kernel and finished by solve_slow_kernel, a whole wave per solve: the complete loop state, so that
+// the iteration sequence continues bit for bit.
+struct SlowRec {           // 128 B
+  double tx, ty, tz, ap_x, ap_y;
+  double x, y, dx, dy, sqr_err, sqr_ap_err;
+  int32_t k, error;
+  uint32_t res_idx, chan;
+  uint32_t pad[6];
+};
+
 struct DrawArgs {
   lentil_params P;
   const DevLens *lens;     // header, global memory (null for the thin lens)
@@ -579,6 +594,20 @@ struct DrawArgs {
   uint32_t *active[2];
   uint32_t *pool[2];
   uint64_t pool_cap;
+  // blind mode: the host enqueues the chunk's draw rounds without waiting for the scan; n_items is then the
+  // capacity of the item buffers, the real count is the scan's work_count, and prep_items_kernel checks that
+  // everything fits (DevCounters::fallback otherwise: nothing is emitted, the host redoes the chunk)
+  uint32_t blind;
+  uint64_t work_cap;       // visits in the chunk = capacity of its work list segment
+  // first batch: draws beyond samples + retries solved up front (in 1/256 of samples, plus a constant), applied
+  // while the chunk's draw sum is below extra_below -- saves the second round where latency matters
+  uint32_t extra_num, extra_const;
+  uint64_t extra_below;
+  SlowRec *slow;           // straggler queue of the current round (null: stragglers stay in their lanes)
+  uint32_t slow_cap;
+  int32_t slow_at;         // Newton iterations after which a solve counts as a straggler
+  uint64_t slow_below;     // ... in chunks whose draw sum is below this (where the end of a round is what costs;
+                           //     a long round absorbs its stragglers and a wave per solve would only cost throughput)
   lentil_draw_record *log;
   uint64_t log_cap;
   unsigned long long *log_count;   // shared by all chunks
@@ -644,8 +673,23 @@ LD_DEV bool emit_tasks(const DrawArgs &a, uint32_t par, uint32_t item, uint32_t 
 // one thread per item: header + first batch R(0 .. samples-1+retries)
 __global__ __launch_bounds__(256) void prep_items_kernel(DrawArgs a) {
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i == 0) a.ctr->n_active[0] = (unsigned int)a.n_items;
-  if (i >= a.n_items) return;
+  uint64_t n_items = a.n_items;
+  const unsigned long long sum_samples = a.ctr->sum_samples;
+  if (a.blind) {
+    const unsigned long long wc = a.ctr->work_count;
+    const uint64_t n = wc < a.work_cap ? wc : a.work_cap;
+    // same bounds as the host's sizing (enqueue_chunk_draws): any round's results, tasks
+    const uint64_t nch = (uint64_t)a.n_channels;
+    const uint64_t units = nch * (4ull * sum_samples + (uint64_t)(3 * a.retries + 32) * n);
+    const uint64_t tasks = units / 64 + 2 * n + 64;
+    if (n > a.n_items || units > a.pool_cap || tasks > a.task_cap) {
+      if (i == 0) { a.ctr->fallback = 1ull; a.ctr->n_active[0] = 0u; }
+      return;
+    }
+    n_items = n;
+  }
+  if (i == 0) a.ctr->n_active[0] = (unsigned int)n_items;
+  if (i >= n_items) return;
   const uint32_t item = (uint32_t)i;
   const ItemVisit h = load_item_visit(a, item, a.lens ? a.lens->length : 0.0);
   ItemHdr hd;
@@ -660,6 +704,7 @@ __global__ __launch_bounds__(256) void prep_items_kernel(DrawArgs a) {
   const uint32_t samples = h.samples, max_total = samples * 5u;
   const uint32_t m_limit = max_total + (uint32_t)a.retries;
   uint32_t m_hi = samples + (uint32_t)a.retries;
+  if (sum_samples < a.extra_below) m_hi += (uint32_t)(((unsigned long long)samples * a.extra_num) >> 8) + a.extra_const;
   if (m_hi > m_limit) m_hi = m_limit;
   ItemProg pg{};
   pg.m_lo = 0;
@@ -669,6 +714,24 @@ __global__ __launch_bounds__(256) void prep_items_kernel(DrawArgs a) {
   pg.res_off = off;
   a.prog[item] = pg;
   a.active[0][item] = item;
+}
+
+// What a finished backward trace leaves in the result pool: the tail of trace_ray_bw_po (transmittance and
+// inner-pupil tests, src/lentil.h:633-645, sensor shift :654-655) and the sensor -> pixel step of
+// filter_pixel (src/lentil_filter.cpp:276-290).
+template <class LensT>
+LD_DEV uint32_t solve_result(const lentil_params &P, const LensT &L, const NewtonState &s) {
+  const DevLens &k = L.consts();
+  double out4;
+  const float transmittance = (float)newton_finish(L, s, out4);
+  if (transmittance <= 0) return kCodeFail;
+  const double ipx = s.x + s.dx * k.back_focal_length;
+  const double ipy = s.y + s.dy * k.back_focal_length;
+  if (ipx * ipx + ipy * ipy > k.inner_pupil_radius * k.inner_pupil_radius) return kCodeFail;
+  const double sx = s.x + s.dx * -P.sensor_shift;
+  const double sy = s.y + s.dy * -P.sensor_shift;
+  uint32_t pix;
+  return po_sensor_to_pixel(P, sx, sy, pix) ? pix : kCodeOut;
 }
 
 // ---- solve, polynomial optics ------------------------------------------------------------------
@@ -707,6 +770,7 @@ __global__ __launch_bounds__(256) void solve_po_kernel(DrawArgs a) {
     const uint32_t nx = (uint32_t)a.parity ^ 1u;
     a.ctr->n_tasks[nx] = 0; a.ctr->task_head[nx] = 0; a.ctr->n_active[nx] = 0; a.ctr->active_head[nx] = 0;
     a.ctr->pool_used[nx] = 0;
+    a.ctr->n_slow[nx] = 0; a.ctr->slow_head[nx] = 0;
   }
   const uint32_t par = (uint32_t)a.parity;
   const Task *tasks = a.tasks[par];
@@ -721,12 +785,14 @@ __global__ __launch_bounds__(256) void solve_po_kernel(DrawArgs a) {
   bool no_more = false;
   // per-lane solve
   bool busy = false, need_init = false;
-  uint32_t m = 0, res_idx = 0, seed_a = 0;
+  uint32_t m = 0, res_idx = 0, seed_a = 0, cur_chan_lane = 0;
+  (void)cur_chan_lane;
   double target[3] = {0, 0, 1};
   double ap_x = 0.0, ap_y = 0.0;
   NewtonState s;
   newton_init(s);
   uint32_t st_iters = 0, st_tries = 0, st_rounds = 0;
+  const bool parking = a.slow != nullptr && a.ctr->sum_samples < a.slow_below;
 
   while (true) {
     const unsigned long long busy_mask = __ballot(busy);
@@ -759,7 +825,7 @@ __global__ __launch_bounds__(256) void solve_po_kernel(DrawArgs a) {
         seed_a = hd.seed_a;
         busy = true;
         need_init = true;
-        if constexpr (kChroma) L.k = &s_kc[cur_chan];
+        if constexpr (kChroma) { L.k = &s_kc[cur_chan]; cur_chan_lane = cur_chan; }
       }
       cur_m += take; cur_res += take; cur_left -= take; filled += take;
     }
@@ -776,23 +842,29 @@ __global__ __launch_bounds__(256) void solve_po_kernel(DrawArgs a) {
     ++st_rounds;
 
     if (busy && !newton_continue(s)) {
-      double out4;
-      const float transmittance = (float)newton_finish(L, s, out4);
-      uint32_t code = kCodeFail;
-      bool try_ok = !(transmittance <= 0);                                   // src/lentil.h:633-637
-      if (try_ok) {
-        const double ipx = s.x + s.dx * k.back_focal_length;                // :640-645
-        const double ipy = s.y + s.dy * k.back_focal_length;
-        if (ipx * ipx + ipy * ipy > k.inner_pupil_radius * k.inner_pupil_radius) try_ok = false;
-      }
-      if (try_ok) {
-        const double sx = s.x + s.dx * -P.sensor_shift;                     // :654-655
-        const double sy = s.y + s.dy * -P.sensor_shift;
-        uint32_t pix;
-        code = po_sensor_to_pixel(P, sx, sy, pix) ? pix : kCodeOut;         // src/lentil_filter.cpp:276-290
-      }
-      res[res_idx] = code;
+      res[res_idx] = solve_result(P, L, s);
       busy = false;
+    }
+    // Stragglers: about one solve in a thousand is still running after slow_at iterations and may need all 100.
+    // Park its loop state for solve_slow_kernel (a whole wave per solve, ~4x less time per iteration) instead of
+    // holding this wave -- and the end of the round -- for it.
+    if (parking) {
+      const bool park = busy && s.k == a.slow_at;
+      const unsigned long long pmask = __ballot(park);
+      if (pmask) {
+        uint32_t base = 0;
+        if (lane == (uint32_t)__builtin_ctzll(pmask)) base = atomicAdd(&a.ctr->n_slow[par], (uint32_t)__builtin_popcountll(pmask));
+        base = __shfl(base, __builtin_ctzll(pmask));
+        const uint32_t slot = base + (uint32_t)__builtin_popcountll(pmask & lt_mask);
+        if (park && slot < a.slow_cap) {       // a full queue leaves the solve where it is
+          double *d = reinterpret_cast<double *>(a.slow + slot);
+          d[0] = target[0]; d[1] = target[1]; d[2] = target[2]; d[3] = ap_x; d[4] = ap_y;
+          d[5] = s.x; d[6] = s.y; d[7] = s.dx; d[8] = s.dy; d[9] = s.sqr_err; d[10] = s.sqr_ap_err;
+          uint32_t *u = reinterpret_cast<uint32_t *>(d + 11);
+          u[0] = (uint32_t)s.k; u[1] = (uint32_t)s.error; u[2] = res_idx; u[3] = kChroma ? cur_chan_lane : 0u;
+          busy = false;
+        }
+      }
     }
   }
   unsigned long long it64 = st_iters, tr64 = st_tries, rd64 = st_rounds;
@@ -805,6 +877,166 @@ __global__ __launch_bounds__(256) void solve_po_kernel(DrawArgs a) {
     if (it64) atomicAdd(&a.ctr->newton_iters, it64);
     if (tr64) atomicAdd(&a.ctr->tries, tr64);
     if (rd64) atomicAdd(&a.ctr->lane_rounds, rd64);
+  }
+}
+
+// ---- stragglers: one wave per solve ----------------------------------------------------------------
+// CoopLens evaluates the 14 polynomials of an iteration with all 64 lanes: (1) lane (var, e) computes
+// lens_ipow(v[var], e) with the reference's recursion (src/lens.h:226-233) into a power table, (2) every lane
+// multiplies out its share of the terms, c * f(x) * f(y) * f(dx) * f(dy) * f(lambda) left to right -- a factor
+// with exponent 0 is 1.0 there, which changes no bit -- (3) lane p adds polynomial p's products in term order.
+// Same operations in the same order as LdsLens / the generated code, so the iteration sequence of a parked
+// solve continues unchanged; the sequential pupil transforms that follow are computed redundantly by all lanes.
+constexpr int kCoopPolys = 14;
+struct CoopShared {
+  DevTerm terms[kMaxTerms];
+  double prod[kMaxTerms];
+  uint16_t idx[kMaxTerms];      // term ids of the polynomials an iteration needs, in evaluation order
+  double pw[64];                // [var][e]
+  double sum[16];
+  double lambda_pow[3][kMaxExp + 1];
+  uint32_t first[16], count[16], n_needed;
+  DevLens k;
+};
+
+LD_DEV double ipow_lane(double x, uint32_t e) {     // lens_ipow for a per-lane exponent 0..15, branch free
+  double p = 1.0;
+#pragma unroll
+  for (int j = 3; j >= 0; --j) {
+    const uint32_t n = e >> j;
+    const double sq = p * p, xp = (x * p) * p;     // n = 1: (x * 1) * 1 = x;  n = 2: x * x
+    p = n == 0u ? p : ((n & 1u) ? xp : sq);
+  }
+  return p;
+}
+
+struct CoopLens {
+  CoopShared *sh;
+  const double *lp;      // lambda powers of this solve's wavelength channel (LDS)
+
+  LD_DEV void eval_bw(const double v[4], double pred_ap[2], double Jap[4], double out[4], double Jout[4]) const {
+    const uint32_t lane = threadIdx.x;
+    {
+      const uint32_t var = lane >> 4, e = lane & 15u;
+      const double x = var == 0u ? v[0] : (var == 1u ? v[1] : (var == 2u ? v[2] : v[3]));
+      sh->pw[lane] = ipow_lane(x, e);
+    }
+    __syncthreads();
+    const uint32_t nn = sh->n_needed;
+    for (uint32_t j = lane; j < nn; j += 64u) {
+      const DevTerm t = sh->terms[sh->idx[j]];
+      double term = t.c;
+      term = term * sh->pw[t.e & 15u];
+      term = term * sh->pw[16u + ((t.e >> 4) & 15u)];
+      term = term * sh->pw[32u + ((t.e >> 8) & 15u)];
+      term = term * sh->pw[48u + ((t.e >> 12) & 15u)];
+      term = term * lp[(t.e >> 16) & 15u];
+      sh->prod[j] = term;
+    }
+    __syncthreads();
+    if (lane < (uint32_t)kCoopPolys) {
+      const uint32_t f = sh->first[lane], c = sh->count[lane];
+      double sum = 0.0;
+      if (c) {
+        sum = sh->prod[f];
+        uint32_t i = 1;
+        for (; i + 4u <= c; i += 4u) {
+          const double p0 = sh->prod[f + i], p1 = sh->prod[f + i + 1], p2 = sh->prod[f + i + 2], p3 = sh->prod[f + i + 3];
+          sum = sum + p0; sum = sum + p1; sum = sum + p2; sum = sum + p3;
+        }
+        for (; i < c; ++i) sum = sum + sh->prod[f + i];
+      }
+      sh->sum[lane] = sum;
+    }
+    __syncthreads();
+    pred_ap[0] = sh->sum[0]; pred_ap[1] = sh->sum[1];
+    Jap[0] = sh->sum[2]; Jap[1] = sh->sum[3]; Jap[2] = sh->sum[4]; Jap[3] = sh->sum[5];
+    out[0] = sh->sum[6]; out[1] = sh->sum[7]; out[2] = sh->sum[8]; out[3] = sh->sum[9];
+    Jout[0] = sh->sum[10]; Jout[1] = sh->sum[11]; Jout[2] = sh->sum[12]; Jout[3] = sh->sum[13];
+  }
+  // once per solve: plain table walk (the state is wave-uniform)
+  LD_DEV double transmittance(const double v[4]) const {
+    const uint32_t first = sh->k.first[P_OUT_T], count = sh->k.count[P_OUT_T];
+    double sum = 0.0;
+    for (uint32_t i = 0; i < count; ++i) {
+      const DevTerm t = sh->terms[first + i];
+      const uint32_t e = __builtin_amdgcn_readfirstlane(t.e);
+      double term = t.c;
+#pragma unroll
+      for (int var = 0; var < 4; ++var) {
+        const uint32_t ev = (e >> (4 * var)) & 15u;
+        if (ev == 1) term = term * v[var];
+        else if (ev > 1) term = term * ipow_u(v[var], ev);
+      }
+      const uint32_t el = (e >> 16) & 15u;
+      if (el) term = term * lp[el];
+      sum = (i == 0) ? term : sum + term;
+    }
+    return sum;
+  }
+  LD_DEV const DevLens &consts() const { return sh->k; }
+};
+
+// One 64-thread block = one wave; blocks pull parked solves until the queue is empty.  Launched blind after every
+// solve_po_kernel: with an empty queue a block returns before it stages anything.
+__global__ __launch_bounds__(64) void solve_slow_kernel(DrawArgs a) {
+  __shared__ CoopShared sh;
+  __shared__ uint32_t s_q;
+  const uint32_t par = (uint32_t)a.parity;
+  uint32_t n_slow = a.ctr->n_slow[par];
+  if (n_slow > a.slow_cap) n_slow = a.slow_cap;
+  if (n_slow == 0u || blockIdx.x >= n_slow) return;
+  const uint32_t lane = threadIdx.x;
+  const uint32_t nt = a.lens->n_terms;
+  for (uint32_t i = lane; i < nt; i += 64u) sh.terms[i] = a.terms[i];
+  if (lane == 0) {
+    sh.k = *a.lens;
+    const int order[kCoopPolys] = {P_AP_X, P_AP_Y, P_DAP_00, P_DAP_01, P_DAP_10, P_DAP_11, P_OUT_X, P_OUT_Y,
+                                   P_OUT_DX, P_OUT_DY, P_DOUT_00, P_DOUT_01, P_DOUT_10, P_DOUT_11};
+    uint32_t n = 0;
+    for (int p = 0; p < kCoopPolys; ++p) {
+      const uint32_t f = a.lens->first[order[p]], c = a.lens->count[order[p]];
+      sh.first[p] = n; sh.count[p] = c;
+      for (uint32_t i = 0; i < c; ++i) sh.idx[n++] = (uint16_t)(f + i);
+    }
+    sh.n_needed = n;
+  }
+  if (lane < 3u) {
+    // lambda powers per wavelength channel, as solve_po_kernel prepares them
+    const double lam = a.n_channels == 3 ? a.lambda[lane] : 0.0;
+    for (uint32_t e = 0; e <= (uint32_t)kMaxExp; ++e)
+      sh.lambda_pow[lane][e] = a.n_channels == 3 ? (e == 0 ? 1.0 : (e == 1 ? lam : ipow_u(lam, e))) : a.lens->lambda_pow[e];
+  }
+  __syncthreads();
+  CoopLens L;
+  L.sh = &sh;
+  unsigned long long iters = 0, solves = 0;
+  while (true) {
+    __syncthreads();
+    if (lane == 0) s_q = atomicAdd(&a.ctr->slow_head[par], 1u);
+    __syncthreads();
+    const uint32_t q = s_q;
+    if (q >= n_slow) break;
+    const SlowRec r = a.slow[q];
+    L.lp = sh.lambda_pow[r.chan < 3u ? r.chan : 0u];
+    const double target[3] = {r.tx, r.ty, r.tz};
+    NewtonState s;
+    s.x = r.x; s.y = r.y; s.dx = r.dx; s.dy = r.dy;
+    s.sqr_err = r.sqr_err; s.sqr_ap_err = r.sqr_ap_err;
+    s.out[0] = s.out[1] = s.out[2] = s.out[3] = 0.0;     // a parked solve runs at least one more iteration
+    s.k = r.k; s.error = r.error;
+    // the loop condition is wave-uniform in value; make it uniform for the barriers inside eval_bw as well
+    while (__builtin_amdgcn_readfirstlane((int)newton_continue(s))) {
+      newton_iter(L, target, r.ap_x, r.ap_y, s);
+      ++iters;
+    }
+    const uint32_t code = solve_result(a.P, L, s);
+    if (lane == 0) a.pool[par][r.res_idx] = code;
+    ++solves;
+  }
+  if (lane == 0) {
+    if (iters) atomicAdd(&a.ctr->newton_iters, iters);
+    if (solves) atomicAdd(&a.ctr->slow_solves, solves);
   }
 }
 

@@ -621,6 +621,63 @@ def test_sub_batches_when_the_result_pool_is_small(orc, monkeypatch):
             ctx.close()
 
 
+@pytest.mark.parametrize("slow_at,lens,chroma,lens_mode", [("2", "double_gauss_50mm", 0.0, 0), ("5", "petzval_58mm", 0.0, 0),
+                                                           ("3", "double_gauss_50mm", 0.5, 0), ("12", "double_gauss_50mm", 0.0, 1),
+                                                           ("0", "double_gauss_50mm", 0.0, 0)])
+def test_stragglers_finish_in_the_cooperative_kernel(orc, monkeypatch, slow_at, lens, chroma, lens_mode):
+    """Solves still running after LENTIL_SLOW_AT iterations are parked with their loop state and finished by
+    solve_slow_kernel (one wave per solve, polynomial terms spread over the lanes).  With a threshold of a few
+    iterations nearly every solve takes that route; the accepted-draw lists must stay bit-identical to the
+    oracle's (same operations in the same order).  "0" switches the hand-over off."""
+    W, H, M = 64, 48, 9
+    p, model, table, keep = common.po_setup(W, H, lens=lens, samples_override=48, abb_chromatic=chroma)
+    visits, cols = common.make_stream(p, W, H, M, f_hi=0.02)
+    ref = common.run_oracle(orc, p, table, visits)
+    rc = ref.counters()
+    monkeypatch.setenv("LENTIL_SLOW_AT", slow_at)
+    ctx = capi.Context(0)
+    try:
+        c = gpu_run(ctx, p, table, visits, lens_mode=lens_mode)
+        assert (c.redistributed_visits, c.attempted_draws, c.accepted_draws) == (
+            rc.redistributed_visits, rc.attempted_draws, rc.accepted_draws)
+        if slow_at == "0":
+            assert c.slow_solves == 0
+        else:
+            assert c.slow_solves > (1000 if int(slow_at) <= 5 else 0)      # the queue is sized for ~1 % of the solves
+        check_logs(ctx, ref)
+        if chroma == 0.0:
+            check_frame(ctx, ref)
+    finally:
+        ctx.close()
+
+
+def test_blind_passes_and_fallback(orc, monkeypatch):
+    """From the second pass on a chunk's draw rounds are enqueued without waiting for its scan, sized from what the
+    previous pass found; prep_items_kernel checks the real counts on the device.  Same stream again -> blind, same
+    result; a stream with many more highlights -> does not fit, the chunk is redone with exact sizes."""
+    W, H, M = 96, 64, 9
+    p, model, table, keep = common.po_setup(W, H, samples_override=48)
+    light, keep_l = common.make_stream(p, W, H, M, f_hi=0.002)      # the column arrays must outlive the passes
+    heavy, keep_h = common.make_stream(p, W, H, M, f_hi=0.08, seed=0xBEEF)
+    ref_l = common.run_oracle(orc, p, table, light)
+    ref_h = common.run_oracle(orc, p, table, heavy)
+    monkeypatch.setenv("LENTIL_CHUNKS", "3")
+    ctx = capi.Context(0)
+    try:
+        for visits, ref, blind, fb in ((light, ref_l, 0, 0), (light, ref_l, 3, 0), (heavy, ref_h, 3, 3), (heavy, ref_h, 3, 0),
+                                       (light, ref_l, 3, 0)):
+            c = gpu_run(ctx, p, table, visits)
+            rc = ref.counters()
+            assert (c.redistributed_visits, c.attempted_draws, c.accepted_draws) == (
+                rc.redistributed_visits, rc.attempted_draws, rc.accepted_draws)
+            assert c.blind_chunks == blind
+            assert (c.fallback_chunks >= 2) if fb else (c.fallback_chunks == 0)    # a quarter-frame chunk may just fit
+            check_logs(ctx, ref)
+            check_frame(ctx, ref)
+    finally:
+        ctx.close()
+
+
 def test_empty_stream_and_error_paths(gpu_ctx_factory):
     p, model, table, keep = common.po_setup(32, 16)
     ctx = gpu_ctx_factory()
