@@ -560,6 +560,40 @@ struct VisitInfo {
   float depth;
 };
 
+// The redistribute decision alone, for the scan kernel (all but a few visits in 10^5 stay in their own pixel
+// and need nothing else): the same tests on the same fp32/fp64 values as visit_prologue below, minus
+// everything that only feeds the draw count.  `raydir` is only read for visits at infinite depth.
+template <class RaydirLoad>
+LD_DEV bool visit_redistributes(const lentil_params &P, double lens_length, float4 pos_z, float4 volume_ignore,
+                                float4 transmission, float inv_density, RaydirLoad load_raydir) {
+  bool redistribute = true;
+  if (P.adaptive_sampling) { if (inv_density > 0.2f) redistribute = false; }
+  float wx = pos_z.x, wy = pos_z.y, wz = pos_z.z;
+  const float depth = pos_z.w;
+  const bool small = fabsf(wx) < kAiEpsilon && fabsf(wy) < kAiEpsilon && fabsf(wz) < kAiEpsilon;
+  const bool far = ((double)depth == (double)kAiInfinite) || small;
+  if (far && P.enable_skydome) {
+    const float4 raydir_time = load_raydir();
+    if (raydir_time.x == 0.0f && raydir_time.y == 0.0f && raydir_time.z == 0.0f) redistribute = false;
+    else { wx = raydir_time.x * 100000000.0f; wy = raydir_time.y * 100000000.0f; wz = raydir_time.z * 100000000.0f; }
+  }
+  if (far && !P.enable_skydome) redistribute = false;
+  if (fmaxf(fmaxf(volume_ignore.x, volume_ignore.y), volume_ignore.z) > 0.0f) redistribute = false;
+  const float(*m)[4] = P.world_to_camera;
+  float cz = wx * m[0][2] + wy * m[1][2] + wz * m[2][2] + m[3][2];
+  float scale = 1.0f;
+  if (P.unitModel == LENTIL_UNIT_MM) scale = 0.1f;
+  else if (P.unitModel == LENTIL_UNIT_DM) scale = 10.0f;
+  else if (P.unitModel == LENTIL_UNIT_M) scale = 100.0f;
+  cz *= scale;
+  if (!P.enable_bidir_transmission && fmaxf(fmaxf(transmission.x, transmission.y), transmission.z) > 0.0f) redistribute = false;
+  if (volume_ignore.w > 0.0f) redistribute = false;
+  if (get_coc_thinlens(P, cz) < 0.4f) redistribute = false;
+  if (P.cameraType == LENTIL_POLYNOMIAL_OPTICS)
+    if ((double)fabsf(cz) < (lens_length * 0.1)) redistribute = false;
+  return redistribute;
+}
+
 LD_DEV VisitInfo visit_prologue(const lentil_params &P, double lens_length, float4 rgba, float4 pos_z,
                                 float4 raydir_time, float4 volume_ignore, float4 transmission,
                                 float inv_density) {

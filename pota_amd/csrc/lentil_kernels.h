@@ -230,50 +230,64 @@ __global__ __launch_bounds__(256) void scan_uniform_kernel(ScanArgs a) {
   for (uint64_t tile = wave_global; tile < n_tiles; tile += wave_stride) {
     const uint64_t pix0 = tile * ppt;
     const uint64_t v0 = pix0 * M;
-    for (uint32_t eb = 0; eb < TV; eb += 64) {
-      const uint32_t e = eb + lane;
-      const uint64_t v = v0 + e;
-      const bool valid = (e < TV) && (v < V.n);
-      float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
-      float w = 0.f;
-      bool flagged = false;
-      int samples = 0;
-      if (valid) {
-        const float4 rgba = V.rgba[v];
-        const float4 pz = V.pos_z[v];
-        const float4 rt = V.raydir_time[v];
-        const float4 vi = V.volume_ignore[v];
-        const float4 tr = V.transmission[v];
-        const float invd = V.inv_density ? V.inv_density[v] : a.P.inverse_sample_density;
-        const VisitInfo I = visit_prologue(a.P, a.lens_length, rgba, pz, rt, vi, tr, invd);
-        if (I.redistribute) {
-          flagged = true;
-          samples = I.samples;
-        } else {
-          w = 1.0f * invd;                              // filter_weight * inv_density, lentil.h:949-953
-          val = make_float4((rgba.x + 0.0f) * w, (rgba.y + 0.0f) * w, (rgba.z + 0.0f) * w, (rgba.w + 0.0f) * w);
-        }
+    // this lane's pixel record: requested now, used after the tile's visits have been staged
+    const uint64_t pix = pix0 + lane;
+    const bool own = (lane < ppt) && (pix < n_pixels);
+    uint64_t lin = 0;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    float ws = 0.f;
+    if (own) {
+      const int px = V.pixel_x0 + (int)(pix % V.pixels_per_row);
+      const int py = V.pixel_y0 + (int)(pix / V.pixels_per_row) * (int)V.pixel_row_stride;
+      lin = (uint64_t)px + (uint64_t)py * xres;
+      s = *a.F.aov(lin, 0);
+      ws = *a.F.wt(lin);
+    }
+    // two groups of 64 visits per step: eight 1 KiB column loads in flight per wave before the first use
+    for (uint32_t eb = 0; eb < TV; eb += 128) {
+      bool valid[2], flagged[2];
+      float4 rgba[2], pz[2], vi[2], tr[2];
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+        const uint32_t e = eb + 64u * g + lane;
+        const uint64_t v = v0 + e;
+        valid[g] = (e < TV) && (v < V.n);
+        const uint64_t vl = valid[g] ? v : v0;      // lanes past the end re-read the tile's first visit (unused)
+        rgba[g] = V.rgba[vl]; pz[g] = V.pos_z[vl]; vi[g] = V.volume_ignore[vl]; tr[g] = V.transmission[vl];
       }
-      wq.push(flagged, (uint32_t)v, (uint32_t)samples, a.work, a.work_cap, a.ctr);
-      if (e < TV) { sval[e] = val; sw[e] = w; }
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+        const uint32_t e = eb + 64u * g + lane;
+        const uint64_t v = v0 + e;
+        float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+        float w = 0.f;
+        int samples = 0;
+        flagged[g] = false;
+        if (valid[g]) {
+          const float invd = V.inv_density ? V.inv_density[v] : a.P.inverse_sample_density;
+          flagged[g] = visit_redistributes(a.P, a.lens_length, pz[g], vi[g], tr[g], invd, [&]() { return V.raydir_time[v]; });
+          if (flagged[g]) {
+            // a few visits in 10^5: the draw count (same function as the draw kernels use)
+            samples = visit_prologue(a.P, a.lens_length, rgba[g], pz[g], V.raydir_time[v], vi[g], tr[g], invd).samples;
+          } else {
+            w = 1.0f * invd;                              // filter_weight * inv_density, lentil.h:949-953
+            val = make_float4((rgba[g].x + 0.0f) * w, (rgba[g].y + 0.0f) * w, (rgba[g].z + 0.0f) * w, (rgba[g].w + 0.0f) * w);
+          }
+        }
+        wq.push(flagged[g], (uint32_t)v, (uint32_t)samples, a.work, a.work_cap, a.ctr);
+        if (e < TV) { sval[e] = val; sw[e] = w; }
+      }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
-    const uint64_t pix = pix0 + lane;
-    const bool own = (lane < ppt) && (pix < n_pixels);
-    uint64_t lin = 0;
     if (own) {
-      const int px = V.pixel_x0 + (int)(pix % V.pixels_per_row);
-      const int py = V.pixel_y0 + (int)(pix / V.pixels_per_row) * (int)V.pixel_row_stride;
-      lin = (uint64_t)px + (uint64_t)py * xres;
-      float4 s = *a.F.aov(lin, 0);
-      float ws = *a.F.wt(lin);
+      // a visit that was redistributed left zeros here; adding +0 changes nothing (an accumulator is never -0)
       for (uint32_t j = 0; j < M; ++j) {
         const float4 c = sval[lane * M + j];
         const float cw = sw[lane * M + j];
-        if (cw != 0.0f) { s.x += c.x; s.y += c.y; s.z += c.z; s.w += c.w; ws += cw; }
+        s.x += c.x; s.y += c.y; s.z += c.z; s.w += c.w; ws += cw;
       }
       *a.F.aov(lin, 0) = s;
       *a.F.wt(lin) = ws;
@@ -383,18 +397,16 @@ __global__ __launch_bounds__(256) void scan_uniform_multi_kernel(ScanArgs a) {
     if (valid) {
       const float4 rgba = V.rgba[v];
       const float4 pz = V.pos_z[v];
-      const float4 rt = V.raydir_time[v];
       const float4 vi = V.volume_ignore[v];
       const float4 tr = V.transmission[v];
 #pragma unroll
       for (uint32_t k = 1; k < LENTIL_MAX_AOVS; ++k)
         if (k < n_aovs && !(a.F.closest_mask & (1u << k))) val[k] = V.extra[k - 1][v];
       const float invd = V.inv_density ? V.inv_density[v] : a.P.inverse_sample_density;
-      const VisitInfo I = visit_prologue(a.P, a.lens_length, rgba, pz, rt, vi, tr, invd);
       depth = pz.w;
-      if (I.redistribute) {
+      if (visit_redistributes(a.P, a.lens_length, pz, vi, tr, invd, [&]() { return V.raydir_time[v]; })) {
         flagged = true;
-        samples = I.samples;
+        samples = visit_prologue(a.P, a.lens_length, rgba, pz, V.raydir_time[v], vi, tr, invd).samples;
       } else {
         w = 1.0f * invd;                                // filter_weight * inv_density, lentil.h:949-953
         val[0] = rgba;
@@ -482,11 +494,10 @@ __global__ __launch_bounds__(256) void scan_ragged_kernel(ScanArgs a) {
     if (v < a.v_end) {
       const float4 rgba = V.rgba[v];
       const float invd = V.inv_density ? V.inv_density[v] : a.P.inverse_sample_density;
-      const VisitInfo I = visit_prologue(a.P, a.lens_length, rgba, V.pos_z[v], V.raydir_time[v],
-                                         V.volume_ignore[v], V.transmission[v], invd);
-      if (I.redistribute) {
+      const float4 pz = V.pos_z[v], vi = V.volume_ignore[v], tr = V.transmission[v];
+      if (visit_redistributes(a.P, a.lens_length, pz, vi, tr, invd, [&]() { return V.raydir_time[v]; })) {
         flagged = true;
-        samples = I.samples;
+        samples = visit_prologue(a.P, a.lens_length, rgba, pz, V.raydir_time[v], vi, tr, invd).samples;
       } else {
         int px, py;
         visit_pixel(V, v, px, py);
