@@ -685,7 +685,8 @@ static int launch_chunk_rounds(lentil_hip_ctx *ctx, int ci, DrawArgs &da, uint64
     if (solve_blocks > cap) solve_blocks = cap;
   }
   const uint64_t acc_want = n_items < 1 ? 1 : n_items;
-  const unsigned accept_blocks = (unsigned)(acc_want > (uint64_t)ctx->num_cu * 2 ? (uint64_t)ctx->num_cu * 2 : acc_want);
+  // one block per item while the items fit the chip at once (85 VGPRs: five blocks per CU)
+  const unsigned accept_blocks = (unsigned)(acc_want > (uint64_t)ctx->num_cu * 4 ? (uint64_t)ctx->num_cu * 4 : acc_want);
   for (int round = 0; round < blind_rounds; ++round) {
     da.parity = round & 1;
     launch_solve(ctx, da, ch.stream, round == 0 ? solve_blocks : (solve_blocks > 256 ? 256 : solve_blocks));
@@ -958,7 +959,7 @@ LENTIL_API int lentil_hip_redistribute(lentil_hip_ctx *ctx) {
       if (!enq[ci]) continue;
       HIP_TRY(ctx, hipStreamSynchronize(ch.stream));
       DevCounters c;
-      HIP_TRY(ctx, hipMemcpy(&c, ctx->d_ctr + ci, offsetof(DevCounters, n_tasks), hipMemcpyDeviceToHost));
+      HIP_TRY(ctx, hipMemcpy(&c, ctx->d_ctr + ci, sizeof(c), hipMemcpyDeviceToHost));
       if (c.fallback) {
         ++ctx->last_fallback;
         // the empty rounds left their queue cursors behind: fresh queues, then the chunk again with exact sizes
@@ -970,7 +971,8 @@ LENTIL_API int lentil_hip_redistribute(lentil_hip_ctx *ctx) {
         const uint64_t cap = ch.v_end - ch.v_begin;
         ch.est_items = c.work_count < cap ? c.work_count : cap;
         ch.est_sum = c.sum_samples;
-        if (ch.est_items == 0) ch.n_items = 0;
+        // nothing left open after the blind rounds (the usual case): no round-by-round continuation, no second look
+        if (ch.est_items == 0 || c.n_active[blind_rounds & 1] == 0) ch.n_items = 0;
       }
     }
     // ---- any chunk with items still missing draws after the blind rounds continues round by round

@@ -394,6 +394,25 @@ __global__ __launch_bounds__(256) void scan_uniform_multi_kernel(ScanArgs a) {
     float w = 0.f;
     float depth = 0.f;
     float4 val[LENTIL_MAX_AOVS];
+    // the tile's pixel records (ppt * q float4; the first two per lane -- all of them at 9 visits per pixel and
+    // 9 AOVs): requested together with the visit columns, used at the end of the step
+    const uint64_t left = n_pixels - pix0;
+    const uint32_t np_tile = (uint32_t)(left < ppt ? left : ppt);
+    float4 *rdst[2] = {nullptr, nullptr};
+    float4 rcur[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const uint32_t i = lane + 64u * u;
+      rcur[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (i < np_tile * q) {
+        const uint32_t pi = i / q, j = i - pi * q;
+        const uint64_t pp = pix0 + pi;
+        const int px = V.pixel_x0 + (int)(pp % V.pixels_per_row);
+        const int py = V.pixel_y0 + (int)(pp / V.pixels_per_row) * (int)V.pixel_row_stride;
+        rdst[u] = acc4 + ((uint64_t)px + (uint64_t)py * xres) * q + j;
+        rcur[u] = *rdst[u];
+      }
+    }
     if (valid) {
       const float4 rgba = V.rgba[v];
       const float4 pz = V.pos_z[v];
@@ -436,8 +455,6 @@ __global__ __launch_bounds__(256) void scan_uniform_multi_kernel(ScanArgs a) {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
     // sums: one lane per (pixel, AOV), M entries in iterator order
-    const uint64_t left = n_pixels - pix0;
-    const uint32_t np_tile = (uint32_t)(left < ppt ? left : ppt);
     for (uint32_t idx = lane; idx < np_tile * q; idx += 64u) srec[idx] = make_float4(0.f, 0.f, 0.f, 0.f);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -463,7 +480,18 @@ __global__ __launch_bounds__(256) void scan_uniform_multi_kernel(ScanArgs a) {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
     // records -> accumulators (a row of the stream ends after pixels_per_row pixels, the frame row is wider)
-    for (uint32_t i = lane; i < np_tile * q; i += 64u) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const uint32_t i = lane + 64u * u;
+      if (i < np_tile * q) {
+        const float4 add = srec[i];
+        float4 cur = rcur[u];
+        cur.x += add.x; cur.y += add.y; cur.z += add.z; cur.w += add.w;
+        *rdst[u] = cur;
+      }
+    }
+    // tiles of more than two float4 per lane (few visits per pixel, many AOVs): the rest the plain way
+    for (uint32_t i = lane + 128u; i < np_tile * q; i += 64u) {
       const uint32_t pi = i / q, j = i - pi * q;
       const uint64_t pp = pix0 + pi;
       const int px = V.pixel_x0 + (int)(pp % V.pixels_per_row);
