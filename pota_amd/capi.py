@@ -11,7 +11,7 @@ import numpy as np
 from . import _abi
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "liblentil_hip.so")
+LIB_PATH = os.environ.get("LENTIL_HIP_LIB") or os.path.join(_PKG, "liblentil_hip.so")   # override: A/B runs of two builds
 
 EXPORTS = [
     "lentil_hip_abi_version", "lentil_hip_create", "lentil_hip_destroy", "lentil_hip_last_error",

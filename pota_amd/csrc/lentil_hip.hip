@@ -68,6 +68,7 @@ struct lentil_hip_ctx {
     // what the last pass found in this chunk: sizes the buffers and grids of the next pass, whose draw rounds are
     // then enqueued without waiting for the scan ("blind"; prep_items_kernel checks that everything fits)
     bool have_est = false, was_blind = false;
+    bool heavy_pending = false;    // this pass: the chunk's first solve round fills the chip; `done` marks its end
     uint64_t est_items = 0, est_sum = 0;
   };
   std::vector<Chunk> chunks;
@@ -77,10 +78,12 @@ struct lentil_hip_ctx {
   uint64_t max_pool_units = 1ull << 32;    // 16 GiB per pool at most (LENTIL_MAX_POOL_UNITS overrides)
   int slow_at = 20;                          // LENTIL_SLOW_AT: iterations after which a solve is parked (0: never)
  uint64_t slow_below = 8ull << 20;          // LENTIL_SLOW_BELOW: ... in chunks whose draw sum is below this
+ int slow_from_round = 1;                   // LENTIL_SLOW_FROM_ROUND
   bool blind = true;                         // LENTIL_BLIND=0: always wait for a chunk's scan before sizing its draw rounds
-  uint32_t extra_num = 16, extra_const = 16; // LENTIL_EXTRA_256THS / LENTIL_EXTRA_CONST: first-batch over-provisioning
+  uint32_t extra_num = 0, extra_const = 0;   // LENTIL_EXTRA_256THS / LENTIL_EXTRA_CONST: first-batch over-provisioning
   uint64_t extra_below = 8ull << 20;         // LENTIL_EXTRA_BELOW: ... while a chunk's draw sum is below this
   int solve_cap_blocks = 1;                  // LENTIL_EARLY_CAP_BLOCKS: solve blocks per CU while later chunks are scanned
+  int accept_max_blocks = 4;                 // LENTIL_ACCEPT_BLOCKS: accept blocks per CU at most
   int solve_max_blocks = 4;                  // LENTIL_SOLVE_BLOCKS: solve blocks per CU at most
   int last_rounds = 0;
   uint32_t last_blind = 0, last_fallback = 0;
@@ -164,6 +167,7 @@ LENTIL_API int lentil_hip_create(int device, lentil_hip_ctx **out_ctx) {
   if (const char *sa = getenv("LENTIL_SLOW_AT")) ctx->slow_at = atoi(sa);
   if (ctx->slow_at < 0 || ctx->slow_at >= 100) ctx->slow_at = 0;
   if (const char *e = getenv("LENTIL_SLOW_BELOW")) ctx->slow_below = strtoull(e, nullptr, 10);
+  if (const char *e = getenv("LENTIL_SLOW_FROM_ROUND")) ctx->slow_from_round = atoi(e);
   if (const char *e = getenv("LENTIL_BLIND")) ctx->blind = !(e[0] == '0');
   if (const char *e = getenv("LENTIL_EXTRA_256THS")) ctx->extra_num = (uint32_t)strtoul(e, nullptr, 10);
   if (const char *e = getenv("LENTIL_EXTRA_CONST")) ctx->extra_const = (uint32_t)strtoul(e, nullptr, 10);
@@ -172,6 +176,8 @@ LENTIL_API int lentil_hip_create(int device, lentil_hip_ctx **out_ctx) {
   if (ctx->extra_const > 64) ctx->extra_const = 64;
   if (const char *e = getenv("LENTIL_EARLY_CAP_BLOCKS")) ctx->solve_cap_blocks = atoi(e);
   if (ctx->solve_cap_blocks < 1) ctx->solve_cap_blocks = 1;
+  if (const char *e = getenv("LENTIL_ACCEPT_BLOCKS")) ctx->accept_max_blocks = atoi(e);
+  if (ctx->accept_max_blocks < 1) ctx->accept_max_blocks = 1;
   if (const char *e = getenv("LENTIL_SOLVE_BLOCKS")) ctx->solve_max_blocks = atoi(e);
   if (ctx->solve_max_blocks < 1) ctx->solve_max_blocks = 1;
   *out_ctx = ctx;
@@ -590,7 +596,9 @@ static void launch_solve(lentil_hip_ctx *ctx, const DrawArgs &da, hipStream_t st
     hipLaunchKernelGGL(solve_thinlens_kernel, dim3(blocks), dim3(256), 0, st, da);
   }
   // stragglers parked by the solve kernel: one wave each (blind launch; an empty queue costs a few microseconds)
-  if (da.P.cameraType == LENTIL_POLYNOMIAL_OPTICS && da.slow)
+  // (not in rounds that do not park: its 41 KB blocks would queue behind another chunk's chip-filling solve kernel
+  // just to find nothing to do, and hold up this chunk's accept meanwhile)
+  if (da.P.cameraType == LENTIL_POLYNOMIAL_OPTICS && da.slow && da.round >= da.slow_from_round)
     hipLaunchKernelGGL(solve_slow_kernel, dim3((unsigned)ctx->num_cu * 4), dim3(64), 0, st, da);
 }
 
@@ -653,7 +661,7 @@ static int finish_rounds(lentil_hip_ctx *ctx, int ci, DrawArgs &da, int first_ro
                                 sizeof(unsigned int), hipMemcpyDeviceToHost, ch.stream));
     HIP_TRY(ctx, hipStreamSynchronize(ch.stream));
     if (n_act == 0) break;
-    da.parity = round & 1;
+    da.parity = round & 1; da.round = round;
     launch_solve(ctx, da, ch.stream, 256);
     hipLaunchKernelGGL(accept_kernel, dim3(n_act < 512u ? n_act : 512u), dim3(256), 0, ch.stream, da);
     HIP_TRY(ctx, hipGetLastError());
@@ -672,6 +680,9 @@ static int launch_chunk_rounds(lentil_hip_ctx *ctx, int ci, DrawArgs &da, uint64
   const uint64_t nch = (uint64_t)da.n_channels;
   const uint64_t max_blocks = (uint64_t)ctx->num_cu * (uint64_t)ctx->solve_max_blocks;
   da.parity = 0;
+  // Parking is for chunks with few draws (see DrawArgs::slow_below).  Decided here, from the same figure that sizes
+  // the grids, and handed to the kernels as "no queue": a solve kernel never parks what no slow kernel will pick up.
+  if (sum_samples >= ctx->slow_below) da.slow = nullptr;
   hipLaunchKernelGGL(prep_items_kernel, dim3((unsigned)((prep_threads + 255) / 256)), dim3(256), 0, ch.stream, da);
   HIP_TRY(ctx, hipGetLastError());
   // enough persistent waves for the chunk's first batch, at most 4 blocks per CU
@@ -686,10 +697,24 @@ static int launch_chunk_rounds(lentil_hip_ctx *ctx, int ci, DrawArgs &da, uint64
   }
   const uint64_t acc_want = n_items < 1 ? 1 : n_items;
   // one block per item while the items fit the chip at once (85 VGPRs: five blocks per CU)
-  const unsigned accept_blocks = (unsigned)(acc_want > (uint64_t)ctx->num_cu * 4 ? (uint64_t)ctx->num_cu * 4 : acc_want);
+  const uint64_t acc_max = (uint64_t)ctx->num_cu * (uint64_t)ctx->accept_max_blocks;
+  const unsigned accept_blocks = (unsigned)(acc_want > acc_max ? acc_max : acc_want);
+  const bool heavy = sum_samples >= ctx->early_cap_samples;
   for (int round = 0; round < blind_rounds; ++round) {
-    da.parity = round & 1;
+    da.parity = round & 1; da.round = round;
+    // Two first-round solve kernels that each fill the chip only get in each other's way (measured: 109 ms side by
+    // side against 104 ms one after the other): a heavy chunk's first round waits for the previous heavy chunk's.
+    if (round == 0 && heavy && ci > 0 && ctx->chunks[ci - 1].heavy_pending)
+      HIP_TRY(ctx, hipStreamWaitEvent(ch.stream, ctx->chunks[ci - 1].done, 0));
+    // ... and for the scans: a chip-filling solve kernel whose blocks were placed while scan blocks were still
+    // resident ran ~10 % slower for its whole life (58 ms against 52 ms, same instruction counts); the overlap it
+    // gives up is a fraction of a millisecond
+    if (round == 0 && heavy) HIP_TRY(ctx, hipStreamWaitEvent(ch.stream, ctx->scans_done, 0));
     launch_solve(ctx, da, ch.stream, round == 0 ? solve_blocks : (solve_blocks > 256 ? 256 : solve_blocks));
+    if (round == 0) {
+      ch.heavy_pending = heavy;
+      if (heavy) HIP_TRY(ctx, hipEventRecord(ch.done, ch.stream));
+    }
     // Splats go anywhere in the frame, also into rows a later chunk's scan is still read-modify-writing with
     // plain stores: solves may overlap the remaining scans, the first accept may not.
     if (round == 0) HIP_TRY(ctx, hipStreamWaitEvent(ch.stream, ctx->scans_done, 0));
@@ -787,7 +812,7 @@ static int enqueue_chunk_draws(lentil_hip_ctx *ctx, int ci, DrawArgs &da, int bl
                                 offsetof(DevCounters, inv_row_min) - offsetof(DevCounters, n_tasks), ch.stream));
     da.work = ctx->d_work + ch.v_begin + i0;
     da.n_items = ni;
-    da.parity = 0;
+    da.parity = 0; da.round = 0;
     hipLaunchKernelGGL(prep_items_kernel, dim3((unsigned)((ni + 255) / 256)), dim3(256), 0, ch.stream, da);
     launch_solve(ctx, da, ch.stream, (unsigned)max_blocks);
     if (i0 == 0) HIP_TRY(ctx, hipStreamWaitEvent(ch.stream, ctx->scans_done, 0));   // see launch_chunk_rounds
@@ -824,6 +849,7 @@ LENTIL_API int lentil_hip_redistribute(lentil_hip_ctx *ctx) {
   HIP_TRY(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
   ctx->last_rounds = 0;
   ctx->last_blind = ctx->last_fallback = 0;
+  for (auto &ch : ctx->chunks) ch.heavy_pending = false;
   ctx->last_scan_launches = 0;
   if (ctx->V.n) {
     // ---- scans: all chunks back to back on the main stream
@@ -932,6 +958,7 @@ LENTIL_API int lentil_hip_redistribute(lentil_hip_ctx *ctx) {
     da.F = ctx->F;
     da.slow_at = ctx->slow_at;
     da.slow_below = ctx->slow_below;
+    da.slow_from_round = ctx->slow_from_round;
     da.extra_num = ctx->extra_num; da.extra_const = ctx->extra_const; da.extra_below = ctx->extra_below;
     da.log = ctx->d_log;
     da.log_cap = ctx->log_cap;

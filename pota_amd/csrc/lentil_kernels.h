@@ -645,6 +645,8 @@ struct DrawArgs {
   SlowRec *slow;           // straggler queue of the current round (null: stragglers stay in their lanes)
   uint32_t slow_cap;
   int32_t slow_at;         // Newton iterations after which a solve counts as a straggler
+  int32_t round;           // solve/accept round of the chunk (0 = first batch)
+  int32_t slow_from_round; // parking starts with this round: the first round's own ramp-down hides most of its stragglers
   uint64_t slow_below;     // ... in chunks whose draw sum is below this (where the end of a round is what costs;
                            //     a long round absorbs its stragglers and a wave per solve would only cost throughput)
   lentil_draw_record *log;
@@ -831,7 +833,7 @@ __global__ __launch_bounds__(256) void solve_po_kernel(DrawArgs a) {
   NewtonState s;
   newton_init(s);
   uint32_t st_iters = 0, st_tries = 0, st_rounds = 0;
-  const bool parking = a.slow != nullptr && a.ctr->sum_samples < a.slow_below;
+  const bool parking = a.slow != nullptr && a.round >= a.slow_from_round && a.ctr->sum_samples < a.slow_below;
 
   while (true) {
     const unsigned long long busy_mask = __ballot(busy);

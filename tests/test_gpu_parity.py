@@ -635,6 +635,7 @@ def test_stragglers_finish_in_the_cooperative_kernel(orc, monkeypatch, slow_at, 
     ref = common.run_oracle(orc, p, table, visits)
     rc = ref.counters()
     monkeypatch.setenv("LENTIL_SLOW_AT", slow_at)
+    monkeypatch.setenv("LENTIL_SLOW_FROM_ROUND", "0")       # by default the first round keeps its stragglers
     ctx = capi.Context(0)
     try:
         c = gpu_run(ctx, p, table, visits, lens_mode=lens_mode)
