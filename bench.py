@@ -54,6 +54,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-second-regime", action="store_true")
     ap.add_argument("--cpu-row-step", type=int, default=0, help="CPU baseline samples every n-th row (0 = auto)")
+    ap.add_argument("--bounds", default="", help="band boundaries (N+1 visit rows, comma separated) instead of the even split")
+    ap.add_argument("--emulate", default="", help="development aid: 'N,r' runs rank r's band of the N-GPU frame in one "
+                                                   "process (no exchange): per-band cost of the weak-scaling workload")
     return ap.parse_args()
 
 
@@ -127,6 +130,9 @@ def main():
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
+    emulate = None
+    if args.emulate:
+        emulate = tuple(int(x) for x in args.emulate.split(","))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
         if world == 1 and args.gpus > 1:
@@ -145,12 +151,13 @@ def main():
     # directions), so every rank's band has the per-GPU pixel count, highlight count and field-angle mix of the
     # single-GPU frame.  (Stacking N frames on top of each other would push the outer bands far off axis, where the
     # lens passes nothing and every visit burns its 5 x samples attempts.)
-    if world == 1:
+    frame_world = emulate[0] if emulate else world
+    if frame_world == 1:
         W, Hr = args.width, args.height
     else:
-        W = int(round(args.width * math.sqrt(world)))
-        Hr = int(round(args.height / math.sqrt(world)))
-    H = Hr * world
+        W = int(round(args.width * math.sqrt(frame_world)))
+        Hr = int(round(args.height / math.sqrt(frame_world)))
+    H = Hr * frame_world
     p = camera.default_params()
     camera.setup_filter(p, W, H, filter_width=1.0, aa_samples=3)
     p, model = camera.setup_po(p, args.lens, focus_dist=150.0)
@@ -167,20 +174,35 @@ def main():
     # rows its draws touched outside the band to their owners; LENTIL_PARTITION=interleaved selects rows
     # r mod N with one sum all-reduce over the whole frame instead
     tiled = (world > 1 or force_dist) and os.environ.get("LENTIL_PARTITION", "bands") != "interleaved"
-    if tiled:
-        band = distributed.band_of(rank, world, H, p.yres)
-        v_begin, v_end = band[0] * W * M, min(band[1], H) * W * M
-        n_local = v_end - v_begin
+    # band boundaries of the tiled mode: even split, --bounds, or (N > 1) re-cut after two calibration passes so that
+    # every rank's pass takes the same time (distributed.rebalance; LENTIL_REBALANCE=0 keeps the even split)
+    state = {"bounds": [int(x) for x in args.bounds.split(",")] if args.bounds else None, "band": None,
+             "v_begin": 0, "v_end": 0}
+
+    def set_band():
+        if emulate:
+            state["band"] = distributed.band_of(emulate[1], emulate[0], H, p.yres, state["bounds"])
+        else:
+            state["band"] = distributed.band_of(rank, world, H, p.yres, state["bounds"])
+        state["v_begin"] = state["band"][0] * W * M
+        state["v_end"] = min(state["band"][1], H) * W * M
+        return state["v_end"] - state["v_begin"]
+
+    if emulate:
+        tiled = False
+        n_local = set_band()
+    elif tiled:
+        n_local = set_band()
     else:
         n_local = workload.frame_visit_count(W, H, M, world, rank)
     bytes_per_visit = 80 + 16 * args.aovs
 
     def bind(f_hi):
-        if tiled:
-            cols = workload.generate(torch, v_begin, v_end, W, H, M, f_hi=f_hi, focus_dist=150.0,
+        if tiled or emulate:
+            cols = workload.generate(torch, state["v_begin"], state["v_end"], W, H, M, f_hi=f_hi, focus_dist=150.0,
                                      tan_half_fov=tan_half_fov, n_extra=args.aovs, device=dev)
             torch.cuda.synchronize()
-            v, kv = capi.make_visits(cols, visits_per_pixel=M, pixels_per_row=W, pixel_y0=band[0],
+            v, kv = capi.make_visits(cols, visits_per_pixel=M, pixels_per_row=W, pixel_y0=state["band"][0],
                                      ptr=lambda t: t.data_ptr())
         else:
             cols = workload.generate(torch, 0, n_local, W, H, M, f_hi=f_hi, focus_dist=150.0, tan_half_fov=tan_half_fov,
@@ -193,7 +215,7 @@ def main():
 
     def step():
         if tiled:
-            distributed.frame_step_bands(engine, dist, H, p.yres)
+            distributed.frame_step_bands(engine, dist, H, p.yres, state["bounds"])
         else:
             distributed.frame_step(engine, dist)
 
@@ -222,9 +244,27 @@ def main():
         return dt, scan_ms / steps, draw_ms / steps, res_ms / steps
 
     cols = bind(args.f_hi)
+    if tiled and (world > 1 or force_dist) and not args.bounds and os.environ.get("LENTIL_REBALANCE", "1") != "0":
+        # calibration (untimed set-up, before the warm-up steps): three passes, the first with even bands, each followed
+        # by an all-gather of the ranks' pass times (scan + draws, HIP events) and a re-cut of the bands
+        state["bounds"] = distributed.even_bounds(world, H)
+        for it in range(3):
+            step()
+            a, b, c = ctx.last_timing()
+            mine = torch.tensor([a + b], dtype=torch.float64, device=dev)
+            allt = [torch.zeros_like(mine) for _ in range(world)]
+            dist.all_gather(allt, mine)
+            times = torch.stack(allt).flatten().tolist()
+            new = distributed.rebalance(state["bounds"], times, damping=(1.0, 0.8, 0.6)[it])
+            if new != state["bounds"]:
+                state["bounds"] = new
+                n_local = set_band()
+                del cols
+                torch.cuda.empty_cache()
+                cols = bind(args.f_hi)
     dt, scan_ms, draw_ms, res_ms = run(args.steps, args.warmup)
     ctr = ctx.counters()
-    n_total = workload.frame_visit_count(W, H, M)         # all ranks
+    n_total = workload.frame_visit_count(W, H, M) if not emulate else n_local        # all ranks
     value = n_total * args.steps / dt / 1e6
     ms_per_step = dt / args.steps * 1e3
 
@@ -248,7 +288,8 @@ def main():
             "redistributed_visits_rank0": int(ctr.redistributed_visits),
             "attempted_draws_rank0": int(ctr.attempted_draws), "accepted_draws_rank0": int(ctr.accepted_draws),
             "parallelism": ("single GPU" if world == 1 else
-                            "%d row bands, rows touched outside a band sent to its owner (p2p), tiled output" % world if tiled else
+                            "%d row bands%s, rows touched outside a band sent to its owner (p2p), tiled output"
+                            % (world, (" at rows %s (balanced by pass time)" % state["bounds"]) if state["bounds"] else "") if tiled else
                             "rows%%%d + allreduce" % world),
         },
         "kernels_ms": {"scan": round(scan_ms, 4), "draw": round(draw_ms, 4), "resolve": round(res_ms, 4)},
@@ -282,6 +323,9 @@ def main():
         except Exception as e:      # the GPU number must still be reported
             out["cpu_baseline"] = {"value": None, "unit": "Msamples/s", "cores": 0, "kind": "port",
                                    "sample": "failed: %r" % (e,)}
+    if distributed.PHASE_SECONDS:
+        sys.stderr.write("[band timing, ms per step incl. warm-up steps] %s\n" % {k: round(v * 1e3 / (args.steps + args.warmup), 3)
+                                                                 for k, v in distributed.PHASE_SECONDS.items()})
     ctx.close()
     used_rccl = dist.is_initialized()
     if used_rccl:

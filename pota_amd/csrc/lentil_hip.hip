@@ -78,7 +78,7 @@ struct lentil_hip_ctx {
   uint64_t max_pool_units = 1ull << 32;    // 16 GiB per pool at most (LENTIL_MAX_POOL_UNITS overrides)
   int slow_at = 20;                          // LENTIL_SLOW_AT: iterations after which a solve is parked (0: never)
  uint64_t slow_below = 8ull << 20;          // LENTIL_SLOW_BELOW: ... in chunks whose draw sum is below this
- int slow_from_round = 1;                   // LENTIL_SLOW_FROM_ROUND
+ int slow_from_round = 0;                   // LENTIL_SLOW_FROM_ROUND
   bool blind = true;                         // LENTIL_BLIND=0: always wait for a chunk's scan before sizing its draw rounds
   uint32_t extra_num = 0, extra_const = 0;   // LENTIL_EXTRA_256THS / LENTIL_EXTRA_CONST: first-batch over-provisioning
   uint64_t extra_below = 8ull << 20;         // LENTIL_EXTRA_BELOW: ... while a chunk's draw sum is below this
@@ -630,7 +630,9 @@ static int size_chunk_buffers(lentil_hip_ctx *ctx, lentil_hip_ctx::Chunk &ch, ui
     ch.pool_cap = nc;
   }
   // stragglers are about 0.1 % of the solves; a full queue only means they stay in their lanes
-  const uint64_t slow_need = units / 128 + 4096;
+  // (only chunks below slow_below draws park at all, which bounds the queue at a few tens of MB)
+  const uint64_t park_units = units < 8 * ctx->slow_below ? units : 8 * ctx->slow_below;
+  const uint64_t slow_need = park_units / 128 + 4096;
   if (ctx->slow_at > 0 && slow_need > ch.slow_cap) {
     const uint64_t nc = slow_need + slow_need / 4;
     if ((rc = grow(ctx, &ch.slow, nc))) return rc;

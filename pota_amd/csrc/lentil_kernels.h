@@ -889,8 +889,10 @@ __global__ __launch_bounds__(256) void solve_po_kernel(DrawArgs a) {
     // Stragglers: about one solve in a thousand is still running after slow_at iterations and may need all 100.
     // Park its loop state for solve_slow_kernel (a whole wave per solve, ~4x less time per iteration) instead of
     // holding this wave -- and the end of the round -- for it.
-    if (parking) {
-      const bool park = busy && s.k == a.slow_at;
+    // Only while this wave is running dry (no task left to refill its lanes from): as long as there is work, a slow
+    // solve costs one lane; once there is none, it holds the wave and the end of the round.
+    if (parking && no_more) {
+      const bool park = busy && s.k >= a.slow_at;
       const unsigned long long pmask = __ballot(park);
       if (pmask) {
         uint32_t base = 0;

@@ -25,6 +25,24 @@ import os
 
 FORCE_COLLECTIVE = os.environ.get("LENTIL_FORCE_DIST") == "1"
 
+# LENTIL_BAND_TIMING=1: host wall time per phase of frame_step_bands, accumulated here (development aid; the
+# phases end with the synchronisations the step has anyway)
+PHASE_SECONDS = {}
+_TIMING = os.environ.get("LENTIL_BAND_TIMING") == "1"
+
+
+class _Phase:
+    def __init__(self):
+        import time
+        self._now = time.perf_counter
+        self.t = self._now()
+
+    def mark(self, name):
+        if _TIMING:
+            t = self._now()
+            PHASE_SECONDS[name] = PHASE_SECONDS.get(name, 0.0) + (t - self.t)
+            self.t = t
+
 
 class _CudaArrayView:
     """Zero-copy view of a device allocation for torch.as_tensor (CUDA array interface v2)."""
@@ -138,38 +156,82 @@ def frame_step(engine, dist=None):
     engine.resolve()
 
 
-def band_of(rank, world, visit_rows, frame_rows):
-    """Rows [lo, hi) of the frame owned by `rank`: consecutive visit rows split evenly; the last band also owns the
-    rows beyond the visits (the reference allocates yres = H + 1, src/lentil.h:1069-1080)."""
-    lo = visit_rows * rank // world
-    hi = visit_rows * (rank + 1) // world
+def even_bounds(world, visit_rows):
+    """Band boundaries (world + 1 visit rows) of the even split."""
+    return [visit_rows * r // world for r in range(world + 1)]
+
+
+def band_of(rank, world, visit_rows, frame_rows, bounds=None):
+    """Rows [lo, hi) of the frame owned by `rank`: consecutive visit rows, split evenly or at `bounds` (world + 1
+    ascending rows, bounds[0] = 0, bounds[world] = visit_rows); the last band also owns the rows beyond the visits
+    (the reference allocates yres = H + 1, src/lentil.h:1069-1080)."""
+    if bounds is None:
+        lo = visit_rows * rank // world
+        hi = visit_rows * (rank + 1) // world
+    else:
+        lo, hi = int(bounds[rank]), int(bounds[rank + 1])
     if rank == world - 1:
         hi = frame_rows
     return lo, hi
 
 
-def frame_step_bands(engine, dist, visit_rows, frame_rows):
+def rebalance(bounds, seconds, min_rows=8, damping=1.0):
+    """New band boundaries from the time every rank's pass took with the current ones: the cost of a row is taken as
+    constant within a band (seconds[r] / rows of band r), the cumulative cost is cut into equal parts.  The field
+    angle, and with it the cost of a backward trace, grows towards the frame edges, so even bands leave the outer
+    ranks with up to 40 % more work.  Pure function of its arguments: every rank computes the same result from the
+    all-gathered times.  `damping` < 1 moves only part of the way (the model is crude where the cost varies inside a
+    band)."""
+    world = len(bounds) - 1
+    rows = [max(1, int(bounds[r + 1]) - int(bounds[r])) for r in range(world)]
+    cost = [max(float(seconds[r]), 1e-9) for r in range(world)]
+    total = sum(cost)
+    new = [int(bounds[0])]
+    r, acc = 0, 0.0                      # acc: cost of the bands before band r
+    for k in range(1, world):
+        target = total * k / world
+        while r < world - 1 and acc + cost[r] < target:
+            acc += cost[r]
+            r += 1
+        frac = (target - acc) / cost[r]
+        row = bounds[r] + frac * rows[r]
+        row = bounds[k] + damping * (row - bounds[k])
+        new.append(int(round(row)))
+    new.append(int(bounds[world]))
+    for k in range(1, world):            # keep every band at least min_rows high, boundaries ascending
+        new[k] = max(new[k], new[k - 1] + min_rows)
+    for k in range(world - 1, 0, -1):
+        new[k] = min(new[k], new[k + 1] - min_rows)
+    return new
+
+
+def frame_step_bands(engine, dist, visit_rows, frame_rows, bounds=None):
     """One pass with tiled output: redistribute the rank's band, exchange the rows touched outside the own band with
-    their owners, merge what arrives, resolve the own band.  Returns the band."""
+    their owners, merge what arrives, resolve the own band.  Returns the band.  `bounds`: see band_of (the engine's
+    visits must be those of band_of(rank, ..., bounds))."""
     import torch
     world, rank = dist.get_world_size(), dist.get_rank()
     zkey = getattr(engine, "zkey", None)
     if zkey is not None:
         engine.set_deferred_closest(False)        # local winners are gathered by the pass; keys travel with the rows
+    ph = _Phase()
     engine.clear()
     engine.redistribute()
+    ph.mark("enqueue pass")
     engine.finish_local()
-    band = band_of(rank, world, visit_rows, frame_rows)
+    ph.mark("pass done")
+    band = band_of(rank, world, visit_rows, frame_rows, bounds)
     lo, hi = engine.touched_rows()
     mine = torch.tensor([lo, hi], dtype=torch.int64, device=engine.device)
     info = [torch.zeros_like(mine) for _ in range(world)]
     dist.all_gather(info, mine)
-    info = [(int(t[0]), int(t[1])) for t in info]
+    info = torch.stack(info).tolist()                              # one copy back for all ranks' row ranges
+    ph.mark("touched rows all-gather")
     ops, incoming, keep = [], [], []
     for q in range(world):
         if q == rank:
             continue
-        q_lo, q_hi = band_of(q, world, visit_rows, frame_rows)
+        q_lo, q_hi = band_of(q, world, visit_rows, frame_rows, bounds)
         s_lo, s_hi = max(lo, q_lo), min(hi, q_hi)                  # rows of q's band this rank added to
         if s_hi > s_lo:
             ops.append(dist.P2POp(dist.isend, engine.acc_rows(s_lo, s_hi), q))
@@ -187,9 +249,11 @@ def frame_step_bands(engine, dist, visit_rows, frame_rows):
         for req in dist.batch_isend_irecv(ops):
             req.wait()
     engine.before_resolve()                                        # received rows complete before the merge kernels
+    ph.mark("row exchange")
     for r_lo, acc, keys in incoming:
         engine.merge_rows(r_lo, acc, keys)
     engine.resolve_rows(band[0], band[1])
     if incoming:
         engine.finish_local()      # the merge kernels read torch-owned buffers: done before those are released
+    ph.mark("merge + resolve enqueue")
     return band

@@ -399,12 +399,13 @@ def test_two_partitions_on_one_gpu_match_the_whole_frame(orc, gpu_ctx_factory):
         _compare_with_whole(engines[rank].ctx, whole, kinds)
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_tiled_output_on_one_gpu_matches_the_whole_frame(orc, gpu_ctx_factory, world):
+@pytest.mark.parametrize("world,bounds", [(2, None), (3, None), (3, [0, 9, 31, 45])], ids=["2", "3", "3-unequal"])
+def test_tiled_output_on_one_gpu_matches_the_whole_frame(orc, gpu_ctx_factory, world, bounds):
     """Tiled multi-GPU mode on one device: each "rank" processes a band of rows, tells the others which rows
     it touched, sends the foreign ones to their owners (lentil_hip_merge_rows) and resolves its band
     (lentil_hip_resolve_rows).  Every band must equal the same rows of a whole-frame context; a second pass
-    checks that the row-limited clear leaves nothing behind."""
+    checks that the row-limited clear leaves nothing behind.  "unequal": bands cut the way
+    distributed.rebalance() cuts them when the ranks' pass times differ."""
     from pota_amd import distributed, workload
     W, H, M = 64, 45, 9
     kinds = [0, 1, 0]
@@ -416,7 +417,7 @@ def test_tiled_output_on_one_gpu_matches_the_whole_frame(orc, gpu_ctx_factory, w
 
     engines, keepalive, bands = [], [], []
     for rank in range(world):
-        b_lo, b_hi = distributed.band_of(rank, world, H, p.yres)
+        b_lo, b_hi = distributed.band_of(rank, world, H, p.yres, bounds)
         v_hi = min(b_hi, H)
         c = workload.generate(np, b_lo * W * M, v_hi * W * M, W, H, M, f_hi=0.03, focus_dist=150.0,
                               tan_half_fov=common.tan_half_fov(p), n_extra=2)
@@ -434,7 +435,7 @@ def test_tiled_output_on_one_gpu_matches_the_whole_frame(orc, gpu_ctx_factory, w
 
     def step(rank, dist):
         for _ in range(2):                                   # second pass: clear_frame wipes only the touched rows
-            got[rank] = distributed.frame_step_bands(engines[rank], dist, H, p.yres)
+            got[rank] = distributed.frame_step_bands(engines[rank], dist, H, p.yres, bounds)
             engines[rank].ctx.sync()
 
     _run_ranks(step, world)

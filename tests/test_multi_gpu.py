@@ -147,7 +147,7 @@ class OracleEngine:
             self.resolved.append(out)
 
 
-def _worker(rank, world, port, W, H, M, f_hi, samples, kinds, q, bands=False):
+def _worker(rank, world, port, W, H, M, f_hi, samples, kinds, q, bands=False, bounds=None):
     sys.path.insert(0, common.ROOT)
     sys.path.insert(0, os.path.join(common.ROOT, "tests"))
     import oracle_lib
@@ -158,13 +158,13 @@ def _worker(rank, world, port, W, H, M, f_hi, samples, kinds, q, bands=False):
     lib = oracle_lib.load()
     p, model, table, keep = common.po_setup(W, H, samples_override=samples)
     if bands:
-        b_lo, b_hi = distributed.band_of(rank, world, H, p.yres)
+        b_lo, b_hi = distributed.band_of(rank, world, H, p.yres, bounds)
         v_hi = min(b_hi, H)
         cols = workload.generate(np, b_lo * W * M, v_hi * W * M, W, H, M, f_hi=f_hi, focus_dist=150.0,
                                  tan_half_fov=common.tan_half_fov(p), n_extra=len(kinds) - 1)
         visits, kv = capi.make_visits(cols, visits_per_pixel=M, pixels_per_row=W, pixel_y0=b_lo)
         eng = OracleEngine(lib, p, table, visits, cols, kinds)
-        band = distributed.frame_step_bands(eng, dist, H, p.yres)
+        band = distributed.frame_step_bands(eng, dist, H, p.yres, bounds)
         assert band == (b_lo, b_hi)
         # rank 0 assembles the tiled result for the comparison
         per = p.xres * eng.stride
@@ -203,7 +203,7 @@ def _free_port():
     return port
 
 
-def _two_rank_vs_single(orc, kinds, bands=False, world=2):
+def _two_rank_vs_single(orc, kinds, bands=False, world=2, bounds=None):
     W, H, M, f_hi, samples = 48, 32, 9, 0.03, 24
     # single rank reference
     from pota_amd import distributed
@@ -217,7 +217,7 @@ def _two_rank_vs_single(orc, kinds, bands=False, world=2):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, W, H, M, f_hi, samples, kinds, q, bands)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, W, H, M, f_hi, samples, kinds, q, bands, bounds)) for r in range(world)]
     for pr in procs:
         pr.start()
     acc, img = q.get(timeout=300)
@@ -258,6 +258,37 @@ def test_tiled_output_two_ranks(orc):
 def test_tiled_output_three_ranks_closest_aovs(orc):
     """three bands (a middle band has two neighbours; 32 rows do not divide evenly), closest AOVs ride along"""
     _two_rank_vs_single(orc, [0, 1, 0], bands=True, world=3)
+
+
+def test_tiled_output_unequal_bands(orc):
+    """bands cut where distributed.rebalance() would put them: unequal heights, same frame"""
+    _two_rank_vs_single(orc, [0, 1], bands=True, world=3, bounds=[0, 7, 21, 32])
+
+
+def test_rebalance_equalises_the_modelled_cost():
+    from pota_amd import distributed
+    H, G = 6112, 8
+    even = distributed.even_bounds(G, H)
+    assert even[0] == 0 and even[-1] == H and len(even) == G + 1
+    assert distributed.band_of(3, G, H, H + 1) == distributed.band_of(3, G, H, H + 1, even)
+    assert distributed.band_of(G - 1, G, H, H + 1, even)[1] == H + 1       # the last band owns the extra frame row
+    times = [2.99, 2.45, 2.51, 2.48, 2.43, 2.50, 2.40, 3.50]                 # measured: outer bands cost more
+    new = distributed.rebalance(even, times)
+    assert new[0] == 0 and new[-1] == H and all(b > a for a, b in zip(new, new[1:]))
+    assert new[1] - new[0] < 764 and new[-1] - new[-2] < 764               # outer bands shrink
+    dens = [times[i] / (even[i + 1] - even[i]) for i in range(G)]
+
+    def cost(lo, hi):
+        return sum(dens[i] * max(0, min(hi, even[i + 1]) - max(lo, even[i])) for i in range(G))
+
+    c = [cost(new[i], new[i + 1]) for i in range(G)]
+    assert max(c) / min(c) < 1.01
+    assert distributed.rebalance(even, [1.0] * G) == even                   # balanced already: unchanged
+    half = distributed.rebalance(even, times, damping=0.5)
+    assert all(abs(h - e) <= abs(n - e) for h, n, e in zip(half, new, even))
+    # degenerate input keeps every band at least min_rows high
+    tiny = distributed.rebalance([0, 10, 20, 30], [100.0, 1e-9, 1e-9], min_rows=4)
+    assert tiny[0] == 0 and tiny[-1] == 30 and all(b - a >= 4 for a, b in zip(tiny, tiny[1:]))
 
 
 def test_row_partition_covers_frame():
