@@ -311,10 +311,17 @@ int lentil_hip_closest_gather(lentil_hip_ctx *ctx);
  *                closest-filtered slots follow the smaller winner key (dev_key_rows: the matching rows of
  *                the sender's lentil_hip_zkey_buffer, required iff the frame has closest AOVs; the sender
  *                must have gathered its local winners, i.e. not be in deferred mode).
+ * pack_rows / merge_packed_rows : the same exchange without the padding of the pixel records: pack_rows writes
+ *                n_rows * xres * (4 n_aovs + 1) floats (a record's RGBA values and weight, back to back) to
+ *                dev_dst; merge_packed_rows merges rows that arrived in that form.  5 instead of 8 floats per
+ *                pixel for a beauty-only frame.
  * resolve_rows : lentil_hip_resolve restricted to a band of rows. */
 int lentil_hip_touched_rows(lentil_hip_ctx *ctx, int32_t *row_lo, int32_t *row_hi);
 int lentil_hip_merge_rows(lentil_hip_ctx *ctx, uint32_t row_begin, uint32_t n_rows, const void *dev_acc_rows,
                           const void *dev_key_rows);
+int lentil_hip_pack_rows(lentil_hip_ctx *ctx, uint32_t row_begin, uint32_t n_rows, void *dev_dst);
+int lentil_hip_merge_packed_rows(lentil_hip_ctx *ctx, uint32_t row_begin, uint32_t n_rows, const void *dev_packed_rows,
+                                 const void *dev_key_rows);
 int lentil_hip_resolve_rows(lentil_hip_ctx *ctx, uint32_t row_begin, uint32_t n_rows);
 
 /* --- multi-GPU ---------------------------------------------------------------------

@@ -21,6 +21,7 @@ EXPORTS = [
     "lentil_hip_download_accum", "lentil_hip_accum_buffer", "lentil_hip_stream",
     "lentil_hip_set_closest_exchange", "lentil_hip_zkey_buffer", "lentil_hip_closest_gather",
     "lentil_hip_touched_rows", "lentil_hip_merge_rows", "lentil_hip_resolve_rows",
+    "lentil_hip_pack_rows", "lentil_hip_merge_packed_rows",
     "lentil_hip_get_counters", "lentil_hip_last_timing", "lentil_hip_last_launches", "lentil_hip_set_draw_log",
     "lentil_hip_download_draw_log", "lentil_hip_test_lt_sample_aperture",
     "lentil_hip_test_trace_bw_po", "lentil_hip_test_aperture_sample",
@@ -79,6 +80,8 @@ def load_library():
         "lentil_hip_closest_gather": (i, [vp]),
         "lentil_hip_touched_rows": (i, [vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
         "lentil_hip_merge_rows": (i, [vp, u32, u32, vp, vp]),
+        "lentil_hip_pack_rows": (i, [vp, u32, u32, vp]),
+        "lentil_hip_merge_packed_rows": (i, [vp, u32, u32, vp, vp]),
         "lentil_hip_resolve_rows": (i, [vp, u32, u32]),
         "lentil_hip_get_counters": (i, [vp, C.POINTER(_abi.Counters)]),
         "lentil_hip_last_timing": (i, [vp, C.POINTER(C.c_float)]),
@@ -249,6 +252,12 @@ class Context:
 
     def merge_rows(self, row_begin, n_rows, acc_ptr, key_ptr=None):
         self._chk(self.lib.lentil_hip_merge_rows(self.h, row_begin, n_rows, acc_ptr, key_ptr))
+
+    def pack_rows(self, row_begin, n_rows, dst_ptr):
+        self._chk(self.lib.lentil_hip_pack_rows(self.h, row_begin, n_rows, dst_ptr))
+
+    def merge_packed_rows(self, row_begin, n_rows, packed_ptr, key_ptr=None):
+        self._chk(self.lib.lentil_hip_merge_packed_rows(self.h, row_begin, n_rows, packed_ptr, key_ptr))
 
     def resolve_rows(self, row_begin, n_rows):
         self._chk(self.lib.lentil_hip_resolve_rows(self.h, row_begin, n_rows))

@@ -1094,8 +1094,37 @@ LENTIL_API int lentil_hip_resolve_rows(lentil_hip_ctx *ctx, uint32_t row_begin, 
   return resolve_range(ctx, (uint64_t)row_begin * ctx->P.xres, (uint64_t)(row_begin + n_rows) * ctx->P.xres);
 }
 
+LENTIL_API int lentil_hip_pack_rows(lentil_hip_ctx *ctx, uint32_t row_begin, uint32_t n_rows, void *dev_dst) {
+  CHECK_CTX(ctx);
+  int rc = check_rows(ctx, row_begin, n_rows);
+  if (rc) return rc;
+  if (!n_rows) return LENTIL_OK;
+  if (!dev_dst) return fail(ctx, LENTIL_ERR_INVALID, "dev_dst is null");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  const uint64_t p_begin = (uint64_t)row_begin * ctx->P.xres, n_pix = (uint64_t)n_rows * ctx->P.xres;
+  uint64_t blocks = (n_pix * (4ull * ctx->F.n_aovs + 1ull) + 255) / 256;
+  const uint64_t max_blocks = (uint64_t)ctx->num_cu * 8;
+  if (blocks > max_blocks) blocks = max_blocks;
+  hipLaunchKernelGGL(pack_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, ctx->F, p_begin, n_pix, (float *)dev_dst);
+  HIP_TRY(ctx, hipGetLastError());
+  return LENTIL_OK;
+}
+
+static int merge_rows_impl(lentil_hip_ctx *ctx, uint32_t row_begin, uint32_t n_rows, const void *dev_acc_rows,
+                           const void *dev_key_rows, bool packed);
+
+LENTIL_API int lentil_hip_merge_packed_rows(lentil_hip_ctx *ctx, uint32_t row_begin, uint32_t n_rows,
+                                            const void *dev_packed_rows, const void *dev_key_rows) {
+  return merge_rows_impl(ctx, row_begin, n_rows, dev_packed_rows, dev_key_rows, true);
+}
+
 LENTIL_API int lentil_hip_merge_rows(lentil_hip_ctx *ctx, uint32_t row_begin, uint32_t n_rows, const void *dev_acc_rows,
                                      const void *dev_key_rows) {
+  return merge_rows_impl(ctx, row_begin, n_rows, dev_acc_rows, dev_key_rows, false);
+}
+
+static int merge_rows_impl(lentil_hip_ctx *ctx, uint32_t row_begin, uint32_t n_rows, const void *dev_acc_rows,
+                           const void *dev_key_rows, bool packed) {
   CHECK_CTX(ctx);
   int rc = check_rows(ctx, row_begin, n_rows);
   if (rc) return rc;
@@ -1108,8 +1137,12 @@ LENTIL_API int lentil_hip_merge_rows(lentil_hip_ctx *ctx, uint32_t row_begin, ui
   uint64_t blocks = (n_pix * ctx->F.stride + 255) / 256;
   const uint64_t max_blocks = (uint64_t)ctx->num_cu * 8;
   if (blocks > max_blocks) blocks = max_blocks;
-  hipLaunchKernelGGL(merge_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, ctx->F, p_begin, n_pix,
-                     (const float *)dev_acc_rows, ctx->F.zkey ? (const unsigned long long *)dev_key_rows : nullptr);
+  if (packed)
+    hipLaunchKernelGGL(merge_packed_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, ctx->F, p_begin, n_pix,
+                       (const float *)dev_acc_rows, ctx->F.zkey ? (const unsigned long long *)dev_key_rows : nullptr);
+  else
+    hipLaunchKernelGGL(merge_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, ctx->F, p_begin, n_pix,
+                       (const float *)dev_acc_rows, ctx->F.zkey ? (const unsigned long long *)dev_key_rows : nullptr);
   HIP_TRY(ctx, hipGetLastError());
   if (ctx->F.zkey) {
     uint64_t kb = (n_pix + 255) / 256;

@@ -1533,6 +1533,38 @@ __global__ __launch_bounds__(256) void merge_rows_kernel(FrameDev F, uint64_t p_
   }
 }
 
+// Rows for another GPU without the padding of the pixel records: 4 n_aovs + 1 floats per pixel instead of `stride`
+// (5 instead of 8 for a beauty-only frame) -- the exchange over xGMI is what a tiled step adds to a pass.
+__global__ __launch_bounds__(256) void pack_rows_kernel(FrameDev F, uint64_t p_begin, uint64_t n_pix, float *dst) {
+  const uint32_t used = 4u * F.n_aovs + 1u;
+  const uint64_t total = n_pix * used;
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
+    const uint64_t i = t / used;
+    const uint32_t j = (uint32_t)(t - i * used);
+    dst[t] = F.acc[(p_begin + i) * F.stride + j];
+  }
+}
+
+// merge_rows_kernel for rows that arrived packed
+__global__ __launch_bounds__(256) void merge_packed_rows_kernel(FrameDev F, uint64_t p_begin, uint64_t n_pix,
+                                                                const float *src, const unsigned long long *src_keys) {
+  const uint32_t used = 4u * F.n_aovs + 1u;
+  const uint64_t total = n_pix * used;
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
+    const uint64_t i = t / used;
+    const uint32_t j = (uint32_t)(t - i * used);
+    float *dst = F.acc + (p_begin + i) * F.stride + j;
+    const uint32_t aov = j >> 2;
+    if (j < 4u * F.n_aovs && (F.closest_mask & (1u << aov))) {
+      if (src_keys && src_keys[i] < F.zkey[p_begin + i]) *dst = src[t];
+    } else {
+      *dst += src[t];
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void merge_keys_kernel(FrameDev F, uint64_t p_begin, uint64_t n_pix,
                                                          const unsigned long long *src_keys) {
   const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;

@@ -90,6 +90,19 @@ class HipEngine:
         per_row = self.accum.numel() // self.rows
         self.ctx.merge_rows(lo, acc.numel() // per_row, acc.data_ptr(), keys.data_ptr() if keys is not None else None)
 
+    # the same exchange without the padding of the pixel records (5 instead of 8 floats per pixel, beauty only)
+    def packed_row_floats(self):
+        return int(self.ctx.params.xres) * (4 * self.ctx.n_aovs + 1)
+
+    def pack_rows(self, lo, hi):
+        import torch
+        out = torch.empty((hi - lo) * self.packed_row_floats(), dtype=torch.float32, device=self.device)
+        self.ctx.pack_rows(lo, hi - lo, out.data_ptr())
+        return out
+
+    def merge_packed_rows(self, lo, n_rows, packed, keys):
+        self.ctx.merge_packed_rows(lo, n_rows, packed.data_ptr(), keys.data_ptr() if keys is not None else None)
+
     def resolve_rows(self, lo, hi):
         self.ctx.resolve_rows(lo, hi - lo)
 
@@ -228,30 +241,41 @@ def frame_step_bands(engine, dist, visit_rows, frame_rows, bounds=None):
     info = torch.stack(info).tolist()                              # one copy back for all ranks' row ranges
     ph.mark("touched rows all-gather")
     ops, incoming, keep = [], [], []
+    packed = hasattr(engine, "pack_rows")          # rows travel without the record padding where the engine can
     for q in range(world):
         if q == rank:
             continue
         q_lo, q_hi = band_of(q, world, visit_rows, frame_rows, bounds)
         s_lo, s_hi = max(lo, q_lo), min(hi, q_hi)                  # rows of q's band this rank added to
         if s_hi > s_lo:
-            ops.append(dist.P2POp(dist.isend, engine.acc_rows(s_lo, s_hi), q))
+            out = engine.pack_rows(s_lo, s_hi) if packed else engine.acc_rows(s_lo, s_hi)
+            keep.append(out)
+            ops.append(dist.P2POp(dist.isend, out, q))
             if zkey is not None:
                 ops.append(dist.P2POp(dist.isend, engine.key_rows(s_lo, s_hi), q))
         r_lo, r_hi = max(info[q][0], band[0]), min(info[q][1], band[1])   # rows of this band q added to
         if r_hi > r_lo:
-            acc = torch.empty_like(engine.acc_rows(r_lo, r_hi))
+            if packed:
+                acc = torch.empty((r_hi - r_lo) * engine.packed_row_floats(), dtype=torch.float32, device=engine.device)
+            else:
+                acc = torch.empty_like(engine.acc_rows(r_lo, r_hi))
             keys = torch.empty_like(engine.key_rows(r_lo, r_hi)) if zkey is not None else None
             ops.append(dist.P2POp(dist.irecv, acc, q))
             if keys is not None:
                 ops.append(dist.P2POp(dist.irecv, keys, q))
-            incoming.append((r_lo, acc, keys))
+            incoming.append((r_lo, r_hi, acc, keys))
+    if packed and keep:
+        engine.finish_local()                      # the pack kernels ran on the library's stream
     if ops:
         for req in dist.batch_isend_irecv(ops):
             req.wait()
     engine.before_resolve()                                        # received rows complete before the merge kernels
     ph.mark("row exchange")
-    for r_lo, acc, keys in incoming:
-        engine.merge_rows(r_lo, acc, keys)
+    for r_lo, r_hi, acc, keys in incoming:
+        if packed:
+            engine.merge_packed_rows(r_lo, r_hi - r_lo, acc, keys)
+        else:
+            engine.merge_rows(r_lo, acc, keys)
     engine.resolve_rows(band[0], band[1])
     if incoming:
         engine.finish_local()      # the merge kernels read torch-owned buffers: done before those are released
