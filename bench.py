@@ -54,6 +54,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-second-regime", action="store_true")
     ap.add_argument("--cpu-row-step", type=int, default=0, help="CPU baseline samples every n-th row (0 = auto)")
+    ap.add_argument("--bokeh-image", action="store_true", help="aperture draws from the reference's example bokeh image "
+                                                               "(tests/golden/example_bokeh_kernel_u8.npy; BASELINE config 3)")
     ap.add_argument("--bounds", default="", help="band boundaries (N+1 visit rows, comma separated) instead of the even split")
     ap.add_argument("--emulate", default="", help="development aid: 'N,r' runs rank r's band of the N-GPU frame in one "
                                                    "process (no exchange): per-band cost of the weak-scaling workload")
@@ -162,12 +164,18 @@ def main():
     camera.setup_filter(p, W, H, filter_width=1.0, aa_samples=3)
     p, model = camera.setup_po(p, args.lens, focus_dist=150.0)
     p.samples_override = args.samples
+    if args.bokeh_image:
+        p.bokeh_enable_image = 1
     table, keep = lens_io.make_lens_table(model.spec)
     tan_half_fov = float(p.sensor_width) * 0.5 / float(p.focal_length)
 
     ctx = capi.Context(local_rank)
     ctx.set_params(p)
     ctx.set_lens(table)
+    if args.bokeh_image:
+        from pota_amd import bokeh
+        tex = np.load(os.path.join(ROOT, "tests", "golden", "example_bokeh_kernel_u8.npy")).astype(np.float32) / np.float32(255)
+        ctx.set_bokeh(bokeh.build_tables(tex))
     ctx.alloc_frame(1 + args.aovs)
     engine = distributed.HipEngine(ctx, rows=p.yres)
     # N > 1: every rank owns a band of consecutive rows (its visits and its tile of the output) and sends the
