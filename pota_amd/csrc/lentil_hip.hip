@@ -869,6 +869,9 @@ LENTIL_API int lentil_hip_redistribute(lentil_hip_ctx *ctx) {
       // staging: 20 B per visit per wave, 4 waves per block, keep a block under ~48 KiB
       uint32_t ppt = 64;
       // extra AOV columns are streamed one at a time: more, smaller tiles keep enough loads in flight
+      // (beauty only: 64-pixel tiles, three blocks per CU.  32-pixel tiles / four blocks per CU are 3 % faster for a
+      // scan that has the chip to itself -- 0.946 against 0.972 ms -- and 20 % slower beside the first chunk's solve
+      // kernel, which then does not get its wave per SIMD until scan blocks retire)
       uint64_t lds_budget = (ctx->V.n_extra ? 24ull : 48ull) * 1024ull;
       if (const char *e = getenv("LENTIL_SCAN_LDS_KB")) lds_budget = strtoull(e, nullptr, 10) * 1024ull;
       while (ppt > 1 && (uint64_t)ppt * M * 20ull * 4ull > lds_budget) ppt >>= 1;

@@ -140,6 +140,12 @@ LD_DEV void visit_pixel(const VisitsDev &V, uint64_t v, int &px, int &py) {
   }
 }
 
+LD_DEV float4 nt_load(const float4 *p) {
+  typedef float v4f __attribute__((ext_vector_type(4)));
+  const v4f v = __builtin_nontemporal_load(reinterpret_cast<const v4f *>(p));
+  return make_float4(v.x, v.y, v.z, v.w);
+}
+
 LD_DEV uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 
 // K2: wave-ballot + prefix-sum compaction of flagged lanes into the work list.  Each wave collects
@@ -253,7 +259,9 @@ __global__ __launch_bounds__(256) void scan_uniform_kernel(ScanArgs a) {
         const uint64_t v = v0 + e;
         valid[g] = (e < TV) && (v < V.n);
         const uint64_t vl = valid[g] ? v : v0;      // lanes past the end re-read the tile's first visit (unused)
-        rgba[g] = V.rgba[vl]; pz[g] = V.pos_z[vl]; vi[g] = V.volume_ignore[vl]; tr[g] = V.transmission[vl];
+        // read once: nontemporal, so that the stream does not push the pixel records and work lists out of L2
+        rgba[g] = nt_load(V.rgba + vl); pz[g] = nt_load(V.pos_z + vl); vi[g] = nt_load(V.volume_ignore + vl);
+        tr[g] = nt_load(V.transmission + vl);
       }
 #pragma unroll
       for (int g = 0; g < 2; ++g) {
