@@ -315,6 +315,13 @@ int lentil_hip_closest_gather(lentil_hip_ctx *ctx);
  *                n_rows * xres * (4 n_aovs + 1) floats (a record's RGBA values and weight, back to back) to
  *                dev_dst; merge_packed_rows merges rows that arrived in that form.  5 instead of 8 floats per
  *                pixel for a beauty-only frame.
+ * compact_rows / merge_sparse : the same exchange for rows that are mostly empty (a band's draws reach ~100 rows into
+ *                its neighbours but touch ~2 % of their pixels when highlights are rare): compact_rows turns every
+ *                pixel of the rows that holds anything (weight != 0, or a winner key) into one entry -- frame-wide
+ *                pixel index (uint32), its 4 n_aovs + 1 floats, its key (uint64, only with closest AOVs) -- in three
+ *                device arrays of `capacity` entries and returns the number of entries found (synchronises; if it
+ *                exceeds capacity nothing beyond capacity was written: send the rows whole instead).  merge_sparse
+ *                merges n such entries of one sender, all inside rows [row_begin, row_begin + n_rows).
  * resolve_rows : lentil_hip_resolve restricted to a band of rows. */
 int lentil_hip_touched_rows(lentil_hip_ctx *ctx, int32_t *row_lo, int32_t *row_hi);
 int lentil_hip_merge_rows(lentil_hip_ctx *ctx, uint32_t row_begin, uint32_t n_rows, const void *dev_acc_rows,
@@ -322,6 +329,10 @@ int lentil_hip_merge_rows(lentil_hip_ctx *ctx, uint32_t row_begin, uint32_t n_ro
 int lentil_hip_pack_rows(lentil_hip_ctx *ctx, uint32_t row_begin, uint32_t n_rows, void *dev_dst);
 int lentil_hip_merge_packed_rows(lentil_hip_ctx *ctx, uint32_t row_begin, uint32_t n_rows, const void *dev_packed_rows,
                                  const void *dev_key_rows);
+int lentil_hip_compact_rows(lentil_hip_ctx *ctx, uint32_t row_begin, uint32_t n_rows, void *dev_idx, void *dev_vals,
+                            void *dev_keys, uint32_t capacity, uint32_t *count);
+int lentil_hip_merge_sparse(lentil_hip_ctx *ctx, uint32_t row_begin, uint32_t n_rows, uint32_t n, const void *dev_idx,
+                            const void *dev_vals, const void *dev_keys);
 int lentil_hip_resolve_rows(lentil_hip_ctx *ctx, uint32_t row_begin, uint32_t n_rows);
 
 /* --- multi-GPU ---------------------------------------------------------------------

@@ -21,7 +21,7 @@ EXPORTS = [
     "lentil_hip_download_accum", "lentil_hip_accum_buffer", "lentil_hip_stream",
     "lentil_hip_set_closest_exchange", "lentil_hip_zkey_buffer", "lentil_hip_closest_gather",
     "lentil_hip_touched_rows", "lentil_hip_merge_rows", "lentil_hip_resolve_rows",
-    "lentil_hip_pack_rows", "lentil_hip_merge_packed_rows",
+    "lentil_hip_pack_rows", "lentil_hip_merge_packed_rows", "lentil_hip_compact_rows", "lentil_hip_merge_sparse",
     "lentil_hip_get_counters", "lentil_hip_last_timing", "lentil_hip_last_launches", "lentil_hip_set_draw_log",
     "lentil_hip_download_draw_log", "lentil_hip_test_lt_sample_aperture",
     "lentil_hip_test_trace_bw_po", "lentil_hip_test_aperture_sample",
@@ -82,6 +82,8 @@ def load_library():
         "lentil_hip_merge_rows": (i, [vp, u32, u32, vp, vp]),
         "lentil_hip_pack_rows": (i, [vp, u32, u32, vp]),
         "lentil_hip_merge_packed_rows": (i, [vp, u32, u32, vp, vp]),
+        "lentil_hip_compact_rows": (i, [vp, u32, u32, vp, vp, vp, u32, C.POINTER(u32)]),
+        "lentil_hip_merge_sparse": (i, [vp, u32, u32, u32, vp, vp, vp]),
         "lentil_hip_resolve_rows": (i, [vp, u32, u32]),
         "lentil_hip_get_counters": (i, [vp, C.POINTER(_abi.Counters)]),
         "lentil_hip_last_timing": (i, [vp, C.POINTER(C.c_float)]),
@@ -258,6 +260,14 @@ class Context:
 
     def merge_packed_rows(self, row_begin, n_rows, packed_ptr, key_ptr=None):
         self._chk(self.lib.lentil_hip_merge_packed_rows(self.h, row_begin, n_rows, packed_ptr, key_ptr))
+
+    def compact_rows(self, row_begin, n_rows, idx_ptr, vals_ptr, keys_ptr, capacity):
+        n = C.c_uint32()
+        self._chk(self.lib.lentil_hip_compact_rows(self.h, row_begin, n_rows, idx_ptr, vals_ptr, keys_ptr, capacity, C.byref(n)))
+        return n.value
+
+    def merge_sparse(self, row_begin, n_rows, n, idx_ptr, vals_ptr, keys_ptr=None):
+        self._chk(self.lib.lentil_hip_merge_sparse(self.h, row_begin, n_rows, n, idx_ptr, vals_ptr, keys_ptr))
 
     def resolve_rows(self, row_begin, n_rows):
         self._chk(self.lib.lentil_hip_resolve_rows(self.h, row_begin, n_rows))

@@ -1116,6 +1116,66 @@ LENTIL_API int lentil_hip_pack_rows(lentil_hip_ctx *ctx, uint32_t row_begin, uin
 static int merge_rows_impl(lentil_hip_ctx *ctx, uint32_t row_begin, uint32_t n_rows, const void *dev_acc_rows,
                            const void *dev_key_rows, bool packed);
 
+LENTIL_API int lentil_hip_compact_rows(lentil_hip_ctx *ctx, uint32_t row_begin, uint32_t n_rows, void *dev_idx,
+                                       void *dev_vals, void *dev_keys, uint32_t capacity, uint32_t *count) {
+  CHECK_CTX(ctx);
+  int rc = check_rows(ctx, row_begin, n_rows);
+  if (rc) return rc;
+  if (!count) return fail(ctx, LENTIL_ERR_INVALID, "count is null");
+  *count = 0;
+  if (!n_rows) return LENTIL_OK;
+  if (!dev_idx || !dev_vals) return fail(ctx, LENTIL_ERR_INVALID, "dev_idx / dev_vals is null");
+  if (ctx->F.zkey && !dev_keys) return fail(ctx, LENTIL_ERR_INVALID, "the frame has closest-filtered AOVs: dev_keys is required");
+  if (ctx->F.debug_mask) return fail(ctx, LENTIL_ERR_UNSUPPORTED, "the lentil_debug AOV is not exchanged between GPUs");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  const uint64_t p_begin = (uint64_t)row_begin * ctx->P.xres, n_pix = (uint64_t)n_rows * ctx->P.xres;
+  // the shared slot of the counter block (draw-log cursor) is free between passes
+  unsigned int *d_count = reinterpret_cast<unsigned int *>(&ctx->d_ctr[ctx->n_chunks].overflow);
+  HIP_TRY(ctx, hipMemsetAsync(d_count, 0, sizeof(unsigned int), ctx->stream));
+  uint64_t blocks = (n_pix + 255) / 256;
+  const uint64_t max_blocks = (uint64_t)ctx->num_cu * 8;
+  if (blocks > max_blocks) blocks = max_blocks;
+  hipLaunchKernelGGL(compact_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, ctx->F, p_begin, n_pix,
+                     (uint32_t *)dev_idx, (float *)dev_vals, ctx->F.zkey ? (unsigned long long *)dev_keys : nullptr, capacity,
+                     d_count);
+  HIP_TRY(ctx, hipGetLastError());
+  unsigned int n = 0;
+  HIP_TRY(ctx, hipMemcpyAsync(&n, d_count, sizeof(n), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  *count = n;
+  return LENTIL_OK;
+}
+
+LENTIL_API int lentil_hip_merge_sparse(lentil_hip_ctx *ctx, uint32_t row_begin, uint32_t n_rows, uint32_t n,
+                                       const void *dev_idx, const void *dev_vals, const void *dev_keys) {
+  CHECK_CTX(ctx);
+  int rc = check_rows(ctx, row_begin, n_rows);
+  if (rc) return rc;
+  if (!n) return LENTIL_OK;
+  if (!dev_idx || !dev_vals) return fail(ctx, LENTIL_ERR_INVALID, "dev_idx / dev_vals is null");
+  if (ctx->F.zkey && !dev_keys) return fail(ctx, LENTIL_ERR_INVALID, "the frame has closest-filtered AOVs: dev_keys is required");
+  if (ctx->F.debug_mask) return fail(ctx, LENTIL_ERR_UNSUPPORTED, "the lentil_debug AOV is not exchanged between GPUs");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  const uint64_t max_blocks = (uint64_t)ctx->num_cu * 8;
+  uint64_t blocks = ((uint64_t)n * (4ull * ctx->F.n_aovs + 1ull) + 255) / 256;
+  if (blocks > max_blocks) blocks = max_blocks;
+  hipLaunchKernelGGL(merge_sparse_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, ctx->F, n, (const uint32_t *)dev_idx,
+                     (const float *)dev_vals, ctx->F.zkey ? (const unsigned long long *)dev_keys : nullptr);
+  HIP_TRY(ctx, hipGetLastError());
+  if (ctx->F.zkey) {
+    uint64_t kb = ((uint64_t)n + 255) / 256;
+    if (kb > max_blocks) kb = max_blocks;
+    hipLaunchKernelGGL(merge_sparse_keys_kernel, dim3((unsigned)kb), dim3(256), 0, ctx->stream, ctx->F, n,
+                       (const uint32_t *)dev_idx, (const unsigned long long *)dev_keys);
+    HIP_TRY(ctx, hipGetLastError());
+  }
+  if (ctx->dirty_known) {       // the entries lie in rows [row_begin, row_begin + n_rows), the sender's compact_rows range
+    if ((int32_t)row_begin < ctx->dirty_lo || ctx->dirty_hi <= ctx->dirty_lo) ctx->dirty_lo = (int32_t)row_begin;
+    if ((int32_t)(row_begin + n_rows) > ctx->dirty_hi) ctx->dirty_hi = (int32_t)(row_begin + n_rows);
+  }
+  return LENTIL_OK;
+}
+
 LENTIL_API int lentil_hip_merge_packed_rows(lentil_hip_ctx *ctx, uint32_t row_begin, uint32_t n_rows,
                                             const void *dev_packed_rows, const void *dev_key_rows) {
   return merge_rows_impl(ctx, row_begin, n_rows, dev_packed_rows, dev_key_rows, true);

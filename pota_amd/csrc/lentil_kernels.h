@@ -1554,6 +1554,65 @@ __global__ __launch_bounds__(256) void pack_rows_kernel(FrameDev F, uint64_t p_b
   }
 }
 
+// ... and without the pixels nothing was added to: in the scan-dominated regime a band's draws reach ~100 rows into
+// its neighbours but fill only ~2 % of them.  Every pixel of the rows with a non-zero weight (or, in frames with
+// closest-filtered AOVs, a winner key) becomes one entry: its frame-wide index, its 4 n_aovs + 1 floats, its key.
+// Entries beyond `cap` are counted but not written (the caller then sends the rows whole).
+__global__ __launch_bounds__(256) void compact_rows_kernel(FrameDev F, uint64_t p_begin, uint64_t n_pix, uint32_t *idx,
+                                                           float *vals, unsigned long long *keys, uint32_t cap,
+                                                           unsigned int *count) {
+  const uint32_t used = 4u * F.n_aovs + 1u;
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  const uint64_t n_round = (n_pix + 63ull) & ~63ull;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_round; i += stride) {
+    const uint64_t p = p_begin + i;
+    bool live = false;
+    if (i < n_pix) live = F.acc[p * F.stride + 4u * F.n_aovs] != 0.0f || (F.zkey && F.zkey[p] != ~0ull);
+    const unsigned long long m = __ballot(live);
+    if (m == 0ull) continue;
+    uint32_t base = 0;
+    if (lane == 0) base = atomicAdd(count, (unsigned int)__builtin_popcountll(m));
+    base = __shfl(base, 0);
+    const uint32_t slot = base + (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1ull));
+    if (live && slot < cap) {
+      idx[slot] = (uint32_t)p;
+      for (uint32_t j = 0; j < used; ++j) vals[(uint64_t)slot * used + j] = F.acc[p * F.stride + j];
+      if (keys) keys[slot] = F.zkey[p];
+    }
+  }
+}
+
+// the receiving side: entries of ONE sender (every pixel at most once), launches of different senders are ordered
+__global__ __launch_bounds__(256) void merge_sparse_kernel(FrameDev F, uint32_t n, const uint32_t *idx, const float *vals,
+                                                           const unsigned long long *keys) {
+  const uint32_t used = 4u * F.n_aovs + 1u;
+  const uint64_t total = (uint64_t)n * used;
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
+    const uint64_t e = t / used;
+    const uint32_t j = (uint32_t)(t - e * used);
+    const uint64_t p = idx[e];
+    if (p >= F.np) continue;
+    float *dst = F.acc + p * F.stride + j;
+    const uint32_t aov = j >> 2;
+    if (j < 4u * F.n_aovs && (F.closest_mask & (1u << aov))) {
+      if (keys && keys[e] < F.zkey[p]) *dst = vals[t];
+    } else {
+      *dst += vals[t];
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void merge_sparse_keys_kernel(FrameDev F, uint32_t n, const uint32_t *idx,
+                                                                const unsigned long long *keys) {
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += stride) {
+    const uint64_t p = idx[e];
+    if (p < F.np && keys[e] < F.zkey[p]) F.zkey[p] = keys[e];
+  }
+}
+
 // merge_rows_kernel for rows that arrived packed
 __global__ __launch_bounds__(256) void merge_packed_rows_kernel(FrameDev F, uint64_t p_begin, uint64_t n_pix,
                                                                 const float *src, const unsigned long long *src_keys) {

@@ -28,6 +28,8 @@ FORCE_COLLECTIVE = os.environ.get("LENTIL_FORCE_DIST") == "1"
 # LENTIL_BAND_TIMING=1: host wall time per phase of frame_step_bands, accumulated here (development aid; the
 # phases end with the synchronisations the step has anyway)
 PHASE_SECONDS = {}
+SPARSE_EXCHANGE = os.environ.get("LENTIL_EXCHANGE", "") != "rows"      # LENTIL_EXCHANGE=rows: always whole rows
+LAST_FORMS = {}        # rank -> what frame_step_bands last sent to every rank (n > 0 entries, -1 whole rows, 0 nothing); for tests
 _TIMING = os.environ.get("LENTIL_BAND_TIMING") == "1"
 
 
@@ -102,6 +104,31 @@ class HipEngine:
 
     def merge_packed_rows(self, lo, n_rows, packed, keys):
         self.ctx.merge_packed_rows(lo, n_rows, packed.data_ptr(), keys.data_ptr() if keys is not None else None)
+
+    # ... and for rows that are mostly empty: one entry per pixel that holds anything
+    def entry_floats(self):
+        return 4 * self.ctx.n_aovs + 1
+
+    def compact_rows(self, lo, hi):
+        """-> (count, idx, vals, keys); count > capacity means "too dense, send the rows whole" (nothing usable written)."""
+        import torch
+        n_pix = (hi - lo) * int(self.ctx.params.xres)
+        cap = max(1024, n_pix // 4)
+        idx = torch.empty(cap, dtype=torch.int32, device=self.device)
+        vals = torch.empty(cap * self.entry_floats(), dtype=torch.float32, device=self.device)
+        keys = torch.empty(cap, dtype=torch.int64, device=self.device) if self.zkey is not None else None
+        n = self.ctx.compact_rows(lo, hi - lo, idx.data_ptr(), vals.data_ptr(), keys.data_ptr() if keys is not None else None, cap)
+        return n, cap, idx, vals, keys
+
+    def sparse_buffers(self, n):
+        import torch
+        idx = torch.empty(n, dtype=torch.int32, device=self.device)
+        vals = torch.empty(n * self.entry_floats(), dtype=torch.float32, device=self.device)
+        keys = torch.empty(n, dtype=torch.int64, device=self.device) if self.zkey is not None else None
+        return idx, vals, keys
+
+    def merge_sparse(self, lo, hi, n, idx, vals, keys):
+        self.ctx.merge_sparse(lo, hi - lo, n, idx.data_ptr(), vals.data_ptr(), keys.data_ptr() if keys is not None else None)
 
     def resolve_rows(self, lo, hi):
         self.ctx.resolve_rows(lo, hi - lo)
@@ -235,26 +262,62 @@ def frame_step_bands(engine, dist, visit_rows, frame_rows, bounds=None):
     ph.mark("pass done")
     band = band_of(rank, world, visit_rows, frame_rows, bounds)
     lo, hi = engine.touched_rows()
-    mine = torch.tensor([lo, hi], dtype=torch.int64, device=engine.device)
-    info = [torch.zeros_like(mine) for _ in range(world)]
-    dist.all_gather(info, mine)
-    info = torch.stack(info).tolist()                              # one copy back for all ranks' row ranges
-    ph.mark("touched rows all-gather")
-    ops, incoming, keep = [], [], []
     packed = hasattr(engine, "pack_rows")          # rows travel without the record padding where the engine can
+    sparse = SPARSE_EXCHANGE and hasattr(engine, "compact_rows")       # ... and as lists of the pixels that hold anything when few do
+    # what this rank added to every other band: decided before the all-gather, which then also carries the form it
+    # will arrive in (entries per destination: n > 0 a list of n pixels, -1 whole rows, 0 nothing)
+    outgoing, forms = {}, [0] * world
     for q in range(world):
         if q == rank:
             continue
         q_lo, q_hi = band_of(q, world, visit_rows, frame_rows, bounds)
         s_lo, s_hi = max(lo, q_lo), min(hi, q_hi)                  # rows of q's band this rank added to
-        if s_hi > s_lo:
-            out = engine.pack_rows(s_lo, s_hi) if packed else engine.acc_rows(s_lo, s_hi)
-            keep.append(out)
-            ops.append(dist.P2POp(dist.isend, out, q))
+        if s_hi <= s_lo:
+            continue
+        forms[q] = -1
+        if sparse:
+            n, cap, idx, vals, keys = engine.compact_rows(s_lo, s_hi)
+            if n <= cap:
+                forms[q] = n
+                if n:
+                    outgoing[q] = ("sparse", n, idx, vals, keys)
+                continue
+        outgoing[q] = ("rows", s_lo, s_hi)
+    LAST_FORMS[rank] = list(forms)
+    ph.mark("compact foreign rows")
+    mine = torch.tensor([lo, hi] + forms, dtype=torch.int64, device=engine.device)
+    info = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(info, mine)
+    info = torch.stack(info).tolist()                              # one copy back for all ranks' row ranges
+    ph.mark("touched rows all-gather")
+    ops, incoming, keep = [], [], []
+    for q in range(world):
+        if q == rank:
+            continue
+        out = outgoing.get(q)
+        if out and out[0] == "sparse":
+            _, n, idx, vals, keys = out
+            ops.append(dist.P2POp(dist.isend, idx[:n], q))
+            ops.append(dist.P2POp(dist.isend, vals[:n * engine.entry_floats()], q))
+            if keys is not None:
+                ops.append(dist.P2POp(dist.isend, keys[:n], q))
+        elif out:
+            _, s_lo, s_hi = out
+            buf = engine.pack_rows(s_lo, s_hi) if packed else engine.acc_rows(s_lo, s_hi)
+            keep.append(buf)
+            ops.append(dist.P2POp(dist.isend, buf, q))
             if zkey is not None:
                 ops.append(dist.P2POp(dist.isend, engine.key_rows(s_lo, s_hi), q))
         r_lo, r_hi = max(info[q][0], band[0]), min(info[q][1], band[1])   # rows of this band q added to
-        if r_hi > r_lo:
+        form = info[q][2 + rank]
+        if r_hi > r_lo and form > 0:
+            idx, vals, keys = engine.sparse_buffers(form)
+            ops.append(dist.P2POp(dist.irecv, idx, q))
+            ops.append(dist.P2POp(dist.irecv, vals, q))
+            if keys is not None:
+                ops.append(dist.P2POp(dist.irecv, keys, q))
+            incoming.append(("sparse", r_lo, r_hi, form, idx, vals, keys))
+        elif r_hi > r_lo and form < 0:
             if packed:
                 acc = torch.empty((r_hi - r_lo) * engine.packed_row_floats(), dtype=torch.float32, device=engine.device)
             else:
@@ -263,7 +326,7 @@ def frame_step_bands(engine, dist, visit_rows, frame_rows, bounds=None):
             ops.append(dist.P2POp(dist.irecv, acc, q))
             if keys is not None:
                 ops.append(dist.P2POp(dist.irecv, keys, q))
-            incoming.append((r_lo, r_hi, acc, keys))
+            incoming.append(("rows", r_lo, r_hi, acc, keys))
     if packed and keep:
         engine.finish_local()                      # the pack kernels ran on the library's stream
     if ops:
@@ -271,11 +334,16 @@ def frame_step_bands(engine, dist, visit_rows, frame_rows, bounds=None):
             req.wait()
     engine.before_resolve()                                        # received rows complete before the merge kernels
     ph.mark("row exchange")
-    for r_lo, r_hi, acc, keys in incoming:
-        if packed:
-            engine.merge_packed_rows(r_lo, r_hi - r_lo, acc, keys)
+    for item in incoming:
+        if item[0] == "sparse":
+            _, r_lo, r_hi, n, idx, vals, keys = item
+            engine.merge_sparse(r_lo, r_hi, n, idx, vals, keys)
         else:
-            engine.merge_rows(r_lo, acc, keys)
+            _, r_lo, r_hi, acc, keys = item
+            if packed:
+                engine.merge_packed_rows(r_lo, r_hi - r_lo, acc, keys)
+            else:
+                engine.merge_rows(r_lo, acc, keys)
     engine.resolve_rows(band[0], band[1])
     if incoming:
         engine.finish_local()      # the merge kernels read torch-owned buffers: done before those are released

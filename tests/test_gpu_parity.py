@@ -399,18 +399,23 @@ def test_two_partitions_on_one_gpu_match_the_whole_frame(orc, gpu_ctx_factory):
         _compare_with_whole(engines[rank].ctx, whole, kinds)
 
 
-@pytest.mark.parametrize("world,bounds", [(2, None), (3, None), (3, [0, 9, 31, 45])], ids=["2", "3", "3-unequal"])
-def test_tiled_output_on_one_gpu_matches_the_whole_frame(orc, gpu_ctx_factory, world, bounds):
+@pytest.mark.parametrize("world,bounds,f_hi", [(2, None, 0.03), (3, None, 0.03), (3, [0, 9, 31, 45], 0.03), (3, None, 0.0015)],
+                         ids=["2", "3", "3-unequal", "3-sparse"])
+def test_tiled_output_on_one_gpu_matches_the_whole_frame(orc, gpu_ctx_factory, monkeypatch, world, bounds, f_hi):
     """Tiled multi-GPU mode on one device: each "rank" processes a band of rows, tells the others which rows
     it touched, sends the foreign ones to their owners (lentil_hip_merge_rows) and resolves its band
     (lentil_hip_resolve_rows).  Every band must equal the same rows of a whole-frame context; a second pass
     checks that the row-limited clear leaves nothing behind.  "unequal": bands cut the way
-    distributed.rebalance() cuts them when the ranks' pass times differ."""
+    distributed.rebalance() cuts them when the ranks' pass times differ.  "sparse": few highlights, so the rows a
+    band touches in its neighbours are mostly empty and travel as lists of pixels (lentil_hip_compact_rows /
+    _merge_sparse) instead of whole rows."""
     from pota_amd import distributed, workload
+    if bounds is not None:
+        monkeypatch.setattr(distributed, "SPARSE_EXCHANGE", False)      # this case: whole (packed) rows
     W, H, M = 64, 45, 9
     kinds = [0, 1, 0]
     p, model, table, keep = common.po_setup(W, H, samples_override=48)
-    visits, cols = common.make_stream(p, W, H, M, f_hi=0.03, n_extra=2)
+    visits, cols = common.make_stream(p, W, H, M, f_hi=f_hi, n_extra=2)
     whole = gpu_ctx_factory()
     gpu_run(whole, p, table, visits, n_aovs=3, kinds=kinds)
     whole.P = p
@@ -419,7 +424,7 @@ def test_tiled_output_on_one_gpu_matches_the_whole_frame(orc, gpu_ctx_factory, w
     for rank in range(world):
         b_lo, b_hi = distributed.band_of(rank, world, H, p.yres, bounds)
         v_hi = min(b_hi, H)
-        c = workload.generate(np, b_lo * W * M, v_hi * W * M, W, H, M, f_hi=0.03, focus_dist=150.0,
+        c = workload.generate(np, b_lo * W * M, v_hi * W * M, W, H, M, f_hi=f_hi, focus_dist=150.0,
                               tan_half_fov=common.tan_half_fov(p), n_extra=2)
         v, kv = capi.make_visits(c, visits_per_pixel=M, pixels_per_row=W, pixel_y0=b_lo)
         ctx = gpu_ctx_factory()
@@ -446,6 +451,11 @@ def test_tiled_output_on_one_gpu_matches_the_whole_frame(orc, gpu_ctx_factory, w
         reach = max(reach, bands[rank][0] - lo, hi - bands[rank][1])
         _compare_with_whole(engines[rank].ctx, whole, kinds, rows=bands[rank])
     assert reach > 0            # draws did cross the band boundaries
+    forms = [f for r in range(world) for f in distributed.LAST_FORMS[r]]
+    if bounds is not None:
+        assert any(f < 0 for f in forms) and not any(f > 0 for f in forms)     # whole (packed) rows only
+    else:
+        assert any(f > 0 for f in forms) and not any(f < 0 for f in forms)     # pixel lists only
 
 
 @pytest.mark.parametrize("chroma,lens_mode,override", [(0.5, 0, 48), (0.5, 1, 48), (1.0, 0, 0), (-0.5, 0, 48)])
