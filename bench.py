@@ -347,7 +347,7 @@ def main():
     # (rocprofv3 writes its output files from an exit handler).
     sys.stdout.flush()
     sys.stderr.flush()
-    if used_rccl:
+    if used_rccl and world > 1:
         os._exit(0)
 
 

@@ -96,6 +96,8 @@ struct lentil_hip_ctx {
   bool closest_deferred = false;     // multi-GPU: the caller min-reduces the keys before the gather
   uint32_t visit_id_base = 0;
   DevCounters *d_ctr = nullptr;
+  std::vector<DevCounters> h_ctr;    // the chunks' counters as read back at the end of the last (blind) pass
+  bool h_ctr_valid = false;
   lentil_draw_record *d_log = nullptr;
   uint64_t log_cap = 0;
   bool timed_draw = false, timed_resolve = false;
@@ -850,6 +852,7 @@ LENTIL_API int lentil_hip_redistribute(lentil_hip_ctx *ctx) {
   HIP_TRY(ctx, hipMemsetAsync(ctx->d_ctr, 0, sizeof(DevCounters) * (C + 1), ctx->stream));
   HIP_TRY(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
   ctx->last_rounds = 0;
+  ctx->h_ctr_valid = false;
   ctx->last_blind = ctx->last_fallback = 0;
   for (auto &ch : ctx->chunks) ch.heavy_pending = false;
   ctx->last_scan_launches = 0;
@@ -985,14 +988,22 @@ LENTIL_API int lentil_hip_redistribute(lentil_hip_ctx *ctx) {
       const int rc = enqueue_chunk_draws(ctx, ci, das[ci], blind_rounds);
       if (rc) return rc;
     }
-    // ---- blind chunks: what the scan really found (next pass's estimate); a chunk that did not fit is redone
+    // ---- blind chunks: what the scan really found (next pass's estimate); a chunk that did not fit is redone.
+    // One read-back of all chunks' counters once every chunk stream has drained; it also serves touched_rows.
+    bool any_blind = false;
+    for (int ci = 0; ci < C; ++ci) any_blind = any_blind || enq[ci];
+    if (any_blind) {
+      for (int ci = 0; ci < C; ++ci) HIP_TRY(ctx, hipStreamSynchronize(ctx->chunks[ci].stream));
+      ctx->h_ctr.resize((size_t)C);
+      HIP_TRY(ctx, hipMemcpy(ctx->h_ctr.data(), ctx->d_ctr, sizeof(DevCounters) * (size_t)C, hipMemcpyDeviceToHost));
+      ctx->h_ctr_valid = true;
+    }
     for (int ci = 0; ci < C; ++ci) {
       lentil_hip_ctx::Chunk &ch = ctx->chunks[ci];
       if (!enq[ci]) continue;
-      HIP_TRY(ctx, hipStreamSynchronize(ch.stream));
-      DevCounters c;
-      HIP_TRY(ctx, hipMemcpy(&c, ctx->d_ctr + ci, sizeof(c), hipMemcpyDeviceToHost));
+      const DevCounters c = ctx->h_ctr[(size_t)ci];
       if (c.fallback) {
+        ctx->h_ctr_valid = false;
         ++ctx->last_fallback;
         // the empty rounds left their queue cursors behind: fresh queues, then the chunk again with exact sizes
         HIP_TRY(ctx, hipMemsetAsync((char *)(ctx->d_ctr + ci) + offsetof(DevCounters, n_tasks), 0,
@@ -1013,6 +1024,7 @@ LENTIL_API int lentil_hip_redistribute(lentil_hip_ctx *ctx) {
       lentil_hip_ctx::Chunk &ch = ctx->chunks[ci];
       HIP_TRY(ctx, hipStreamSynchronize(ch.stream));
       if (ch.n_items == 0) continue;
+      ctx->h_ctr_valid = false;       // more rounds: the counters move on
       int rounds = blind_rounds;
       const int rc = finish_rounds(ctx, ci, das[ci], blind_rounds, &rounds);
       if (rc) return rc;
@@ -1225,9 +1237,13 @@ LENTIL_API int lentil_hip_touched_rows(lentil_hip_ctx *ctx, int32_t *row_lo, int
   CHECK_CTX(ctx);
   if (!ctx->have_frame) return fail(ctx, LENTIL_ERR_INVALID, "no frame allocated");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
-  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   std::vector<DevCounters> c((size_t)ctx->n_chunks);
-  HIP_TRY(ctx, hipMemcpy(c.data(), ctx->d_ctr, sizeof(DevCounters) * (size_t)ctx->n_chunks, hipMemcpyDeviceToHost));
+  if (ctx->h_ctr_valid && ctx->h_ctr.size() == c.size()) {
+    c = ctx->h_ctr;                 // a blind pass has read them back already, after its last kernel
+  } else {
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipMemcpy(c.data(), ctx->d_ctr, sizeof(DevCounters) * (size_t)ctx->n_chunks, hipMemcpyDeviceToHost));
+  }
   int64_t lo = INT32_MAX, hi = 0;
   for (const DevCounters &k : c) {
     if (!k.row_max_p1) continue;

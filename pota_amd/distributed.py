@@ -285,10 +285,13 @@ def frame_step_bands(engine, dist, visit_rows, frame_rows, bounds=None):
         outgoing[q] = ("rows", s_lo, s_hi)
     LAST_FORMS[rank] = list(forms)
     ph.mark("compact foreign rows")
-    mine = torch.tensor([lo, hi] + forms, dtype=torch.int64, device=engine.device)
-    info = [torch.zeros_like(mine) for _ in range(world)]
-    dist.all_gather(info, mine)
-    info = torch.stack(info).tolist()                              # one copy back for all ranks' row ranges
+    # one small all-gather: staged through pinned memory, gathered into one tensor, read back with one copy
+    cuda = torch.device(engine.device).type == "cuda"
+    stage = torch.tensor([lo, hi] + forms, dtype=torch.int64, pin_memory=cuda)
+    mine = stage.to(engine.device, non_blocking=True)
+    gathered = torch.empty((world, 2 + world), dtype=torch.int64, device=engine.device)
+    dist.all_gather(list(gathered.unbind(0)), mine)
+    info = gathered.tolist()
     ph.mark("touched rows all-gather")
     ops, incoming, keep = [], [], []
     for q in range(world):
