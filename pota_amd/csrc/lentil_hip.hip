@@ -796,7 +796,12 @@ static int enqueue_chunk_draws(lentil_hip_ctx *ctx, int ci, DrawArgs &da, int bl
   const uint64_t max_blocks = (uint64_t)ctx->num_cu * 4;
   int rc;
   if (units <= ctx->max_pool_units) {
-    if ((rc = size_chunk_buffers(ctx, ch, n_items, units))) return rc;
+    // with the headroom the next (blind) pass will ask for, so that it does not have to grow the buffers again
+    uint64_t items_h = n_items + n_items / 4 + 1024;
+    if (items_h > cap) items_h = cap;
+    uint64_t units_h = chunk_units(P, nch, c.sum_samples + c.sum_samples / 4 + 65536, items_h);
+    if (units_h > ctx->max_pool_units) { units_h = units; items_h = n_items; }
+    if ((rc = size_chunk_buffers(ctx, ch, items_h, units_h))) return rc;
     bind_chunk_buffers(ch, da);
     da.work = ctx->d_work + ch.v_begin;
     da.n_items = n_items;

@@ -670,7 +670,7 @@ def test_blind_passes_and_fallback(orc, monkeypatch):
     W, H, M = 96, 64, 9
     p, model, table, keep = common.po_setup(W, H, samples_override=48)
     light, keep_l = common.make_stream(p, W, H, M, f_hi=0.002)      # the column arrays must outlive the passes
-    heavy, keep_h = common.make_stream(p, W, H, M, f_hi=0.08, seed=0xBEEF)
+    heavy, keep_h = common.make_stream(p, W, H, M, f_hi=0.12, seed=0xBEEF)
     ref_l = common.run_oracle(orc, p, table, light)
     ref_h = common.run_oracle(orc, p, table, heavy)
     monkeypatch.setenv("LENTIL_CHUNKS", "3")
@@ -683,7 +683,7 @@ def test_blind_passes_and_fallback(orc, monkeypatch):
             assert (c.redistributed_visits, c.attempted_draws, c.accepted_draws) == (
                 rc.redistributed_visits, rc.attempted_draws, rc.accepted_draws)
             assert c.blind_chunks == blind
-            assert (c.fallback_chunks >= 2) if fb else (c.fallback_chunks == 0)    # a quarter-frame chunk may just fit
+            assert (c.fallback_chunks >= 1) if fb else (c.fallback_chunks == 0)    # the quarter-frame chunks may just fit
             check_logs(ctx, ref)
             check_frame(ctx, ref)
     finally:
