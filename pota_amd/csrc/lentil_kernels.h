@@ -1040,17 +1040,30 @@ __global__ __launch_bounds__(64) void solve_slow_kernel(DrawArgs a) {
   const uint32_t lane = threadIdx.x;
   const uint32_t nt = a.lens->n_terms;
   for (uint32_t i = lane; i < nt; i += 64u) sh.terms[i] = a.terms[i];
-  if (lane == 0) {
-    sh.k = *a.lens;
+  if (lane == 0) sh.k = *a.lens;
+  {
+    // the polynomials an iteration needs, in the order eval_bw hands them out: lane p looks after polynomial p
+    // (one parallel read of the header, a prefix sum over the 14 counts, then every lane lists its own terms)
     const int order[kCoopPolys] = {P_AP_X, P_AP_Y, P_DAP_00, P_DAP_01, P_DAP_10, P_DAP_11, P_OUT_X, P_OUT_Y,
                                    P_OUT_DX, P_OUT_DY, P_DOUT_00, P_DOUT_01, P_DOUT_10, P_DOUT_11};
-    uint32_t n = 0;
-    for (int p = 0; p < kCoopPolys; ++p) {
-      const uint32_t f = a.lens->first[order[p]], c = a.lens->count[order[p]];
-      sh.first[p] = n; sh.count[p] = c;
-      for (uint32_t i = 0; i < c; ++i) sh.idx[n++] = (uint16_t)(f + i);
+    uint32_t f = 0, c = 0;
+    if (lane < (uint32_t)kCoopPolys) {
+      int pid = order[0];
+#pragma unroll
+      for (int p = 1; p < kCoopPolys; ++p) pid = lane == (uint32_t)p ? order[p] : pid;
+      f = a.lens->first[pid]; c = a.lens->count[pid];
     }
-    sh.n_needed = n;
+    uint32_t incl = c;
+    for (int off = 1; off < 16; off <<= 1) {
+      const uint32_t up = __shfl_up(incl, off);
+      if ((int)lane >= off) incl += up;
+    }
+    if (lane < (uint32_t)kCoopPolys) {
+      const uint32_t start = incl - c;
+      sh.first[lane] = start; sh.count[lane] = c;
+      for (uint32_t i = 0; i < c; ++i) sh.idx[start + i] = (uint16_t)(f + i);
+      if (lane == (uint32_t)kCoopPolys - 1u) sh.n_needed = incl;
+    }
   }
   if (lane < 3u) {
     // lambda powers per wavelength channel, as solve_po_kernel prepares them
