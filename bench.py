@@ -35,6 +35,12 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+# A pass uses three HIP streams (scans, one per chunk of draws); torch and RCCL bring theirs.  With the runtime's
+# default of 4 hardware queues per process two of them end up sharing one in the multi-GPU runs, and the first
+# chunk's solves then queue behind the second scan instead of running beside it (3.34 -> 3.05 ms per step).
+# Read when the HIP runtime initialises, so: before torch is imported.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 FP64_VECTOR_PEAK_TFLOPS = 78.6
 
@@ -347,7 +353,7 @@ def main():
     # (rocprofv3 writes its output files from an exit handler).
     sys.stdout.flush()
     sys.stderr.flush()
-    if used_rccl and world > 1:
+    if used_rccl and os.environ.get("LENTIL_BENCH_NO_EXIT") != "1":     # (set it under rocprofv3 with LENTIL_FORCE_DIST)
         os._exit(0)
 
 
