@@ -578,6 +578,68 @@ def test_po_bokeh_image(orc, gpu_ctx_factory):
     orc.orc_bokeh_destroy(ob)
 
 
+def _poison_stream(cols, n, lens_length_cm, seed):
+    """Every branch of the redistribute decision (src/lentil_filter.cpp:105-165,240): on a third of the visits one of
+    the special cases, highlights included (their radiance is kept, so the draw path sees them too)."""
+    rng = np.random.default_rng(seed)
+    kind = rng.integers(0, 24, n)
+    pz, vi, tr, rd = cols["pos_z"], cols["volume_ignore"], cols["transmission"], cols["raydir_time"]
+    m = kind == 0; vi[m, 0] = 0.5                                   # volume in r
+    m = kind == 1; vi[m, 2] = 1e-6                                  # volume in b, tiny but > 0
+    m = kind == 2; vi[m, 3] = 1.0                                   # lentil_ignore
+    m = kind == 3; tr[m, 1] = 0.25; tr[m, 0] = 0.1                  # transmission
+    m = kind == 4; pz[m, 3] = np.float32(1.0e30)                    # Z == AI_INFINITE, raydir from the generator
+    m = kind == 5; pz[m, 3] = np.float32(1.0e30); rd[m, :3] = 0.0   # ... and no ray direction
+    m = kind == 6; pz[m, :3] = np.float32(5e-5)                     # P ~ 0
+    m = kind == 7; pz[m, 2] = -np.float32(lens_length_cm * 0.05)    # inside the lens (PO: |z| < lens_length * 0.1)
+    m = (kind == 8) & (rng.integers(0, 16, n) == 0); pz[m, 2] = np.abs(pz[m, 2])   # behind the camera (few: every one
+    #                                                                                  of them burns its 5 x samples attempts)
+    m = kind == 9; vi[m, 0] = -1.0; vi[m, 3] = -2.0                 # negative flags do not count
+    m = kind == 10; tr[m, 3] = 0.9                                  # transmission alpha alone does not count
+    return cols
+
+
+@pytest.mark.parametrize("mode", ["uniform", "extra_aovs", "ragged", "skydome", "bidir_transmission", "add_energy", "metres"])
+def test_redistribute_decision_branches(orc, gpu_ctx_factory, mode):
+    """The scan kernels decide with visit_redistributes() -- the tests of visit_prologue() without the draw-count
+    arithmetic -- and only flagged visits run the full prologue.  Streams that hit every branch of the decision
+    (volume, ignore flag, transmission with and without enable_bidir_transmission, infinite depth with and without
+    the skydome, P ~ 0, inside the lens, behind the camera), through all three scan kernels: counters, accepted-draw
+    lists and accumulators against the oracle."""
+    W, H, M = 64, 40, 9
+    kw = {}
+    if mode == "skydome":
+        kw["enable_skydome"] = 1
+    if mode == "bidir_transmission":
+        kw["enable_bidir_transmission"] = 1
+    if mode == "add_energy":
+        kw.update(bidir_add_energy=0.7, bidir_add_energy_minimum_luminance=1.5, bidir_add_energy_transition=60.0)
+    if mode == "metres":
+        kw["unitModel"] = _abi.UNIT_M
+    p, model, table, keep = common.po_setup(W, H, samples_override=24, **kw)
+    n_extra = 2 if mode == "extra_aovs" else 0
+    visits, cols = common.make_stream(p, W, H, M, f_hi=0.05, n_extra=n_extra)
+    n = cols["rgba"].shape[0]
+    _poison_stream(cols, n, float(table.lens_length) * 0.1, seed=11)
+    if mode == "metres":
+        cols["pos_z"][:, :3] *= np.float32(0.01)     # the same scene in metres (world_to_camera is the identity)
+    if mode == "ragged":
+        rng = np.random.default_rng(5)
+        cols["pixel"] = (rng.integers(0, W, n).astype(np.uint32) | (rng.integers(0, H, n).astype(np.uint32) << 16)).astype(np.uint32)
+        visits, keepv = capi.make_visits(cols, visits_per_pixel=0)
+    else:
+        visits, keepv = capi.make_visits(cols, visits_per_pixel=M, pixels_per_row=W)
+    ref = common.run_oracle(orc, p, table, visits, n_aovs=1 + n_extra)
+    rc = ref.counters()
+    assert 0 < rc.redistributed_visits < 0.2 * n
+    ctx = gpu_ctx_factory()
+    c = gpu_run(ctx, p, table, visits, n_aovs=1 + n_extra)
+    assert (c.redistributed_visits, c.attempted_draws, c.accepted_draws) == (
+        rc.redistributed_visits, rc.attempted_draws, rc.accepted_draws)
+    check_logs(ctx, ref)
+    check_frame(ctx, ref, n_aovs=1 + n_extra)
+
+
 @pytest.mark.parametrize("override", [0, 64])
 def test_thinlens_redistribute_parity(orc, gpu_ctx_factory, override):
     """BASELINE config 1 shape (thin lens, 64 draws, beauty only) at test size."""
