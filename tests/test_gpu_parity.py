@@ -596,10 +596,14 @@ def _poison_stream(cols, n, lens_length_cm, seed):
     #                                                                                  of them burns its 5 x samples attempts)
     m = kind == 9; vi[m, 0] = -1.0; vi[m, 3] = -2.0                 # negative flags do not count
     m = kind == 10; tr[m, 3] = 0.9                                  # transmission alpha alone does not count
+    rare = rng.integers(0, 8, n) == 0
+    m = (kind == 11) & rare; pz[m, 0] = np.float32(np.inf)          # non-finite positions: decided, drawn and rejected
+    m = (kind == 12) & rare; pz[m, 2] = np.float32(np.nan)          # the same way on both sides
     return cols
 
 
-@pytest.mark.parametrize("mode", ["uniform", "extra_aovs", "ragged", "skydome", "bidir_transmission", "add_energy", "metres"])
+@pytest.mark.parametrize("mode", ["uniform", "extra_aovs", "ragged", "skydome", "bidir_transmission", "add_energy", "metres",
+                                  "thinlens"])
 def test_redistribute_decision_branches(orc, gpu_ctx_factory, mode):
     """The scan kernels decide with visit_redistributes() -- the tests of visit_prologue() without the draw-count
     arithmetic -- and only flagged visits run the full prologue.  Streams that hit every branch of the decision
@@ -616,11 +620,14 @@ def test_redistribute_decision_branches(orc, gpu_ctx_factory, mode):
         kw.update(bidir_add_energy=0.7, bidir_add_energy_minimum_luminance=1.5, bidir_add_energy_transition=60.0)
     if mode == "metres":
         kw["unitModel"] = _abi.UNIT_M
-    p, model, table, keep = common.po_setup(W, H, samples_override=24, **kw)
+    if mode == "thinlens":
+        p, table = common.tl_setup(W, H, samples_override=24), None
+    else:
+        p, model, table, keep = common.po_setup(W, H, samples_override=24, **kw)
     n_extra = 2 if mode == "extra_aovs" else 0
     visits, cols = common.make_stream(p, W, H, M, f_hi=0.05, n_extra=n_extra)
     n = cols["rgba"].shape[0]
-    _poison_stream(cols, n, float(table.lens_length) * 0.1, seed=11)
+    _poison_stream(cols, n, float(table.lens_length) * 0.1 if table is not None else 1.0, seed=11)
     if mode == "metres":
         cols["pos_z"][:, :3] *= np.float32(0.01)     # the same scene in metres (world_to_camera is the identity)
     if mode == "ragged":
