@@ -644,7 +644,10 @@ def test_redistribute_decision_branches(orc, gpu_ctx_factory, mode):
     assert (c.redistributed_visits, c.attempted_draws, c.accepted_draws) == (
         rc.redistributed_visits, rc.attempted_draws, rc.accepted_draws)
     check_logs(ctx, ref)
-    check_frame(ctx, ref, n_aovs=1 + n_extra)
+    # thin lens: the draws of the visits at x = inf all land on pixel (0, 0) -- several thousand fp32 additions, after
+    # which GPU and oracle agree with each other to the bit in alpha and weight and both sit 1.25e-5 off the exact
+    # (fp64) sum the checker compares with
+    check_frame(ctx, ref, n_aovs=1 + n_extra, tol=3e-5 if mode == "thinlens" else TOL)
 
 
 @pytest.mark.parametrize("override", [0, 64])
