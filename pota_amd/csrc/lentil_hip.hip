@@ -70,6 +70,7 @@ struct lentil_hip_ctx {
     bool have_est = false, was_blind = false;
     bool heavy_pending = false;    // this pass: the chunk's first solve round fills the chip; `done` marks its end
     uint64_t est_items = 0, est_sum = 0;
+    int est_rounds = 3;            // rounds the chunk's items needed (DevCounters::rounds_used)
   };
   std::vector<Chunk> chunks;
   int n_chunks = 2;
@@ -985,14 +986,23 @@ LENTIL_API int lentil_hip_redistribute(lentil_hip_ctx *ctx) {
     da.log = ctx->d_log;
     da.log_cap = ctx->log_cap;
     da.log_count = &ctx->d_ctr[C].log_count;
-    const int blind_rounds = 3;
+    // solve/accept rounds enqueued without looking (an unused one costs ~30 us, a missing one a host round trip):
+    // per chunk what it needed in the previous pass, at least 2 (3 when nothing is known); LENTIL_BLIND_ROUNDS fixes it
+    int forced_rounds = 0;
+    if (const char *e = getenv("LENTIL_BLIND_ROUNDS")) { forced_rounds = atoi(e); if (forced_rounds < 1) forced_rounds = 1; if (forced_rounds > 8) forced_rounds = 8; }
+    const int blind_rounds = forced_rounds ? forced_rounds : 3;
+    std::vector<int> rounds_of(C, blind_rounds);
     std::vector<DrawArgs> das(C, da);
     // chunks whose last pass left an estimate go first, without any host wait; the others wait for their scan
     std::vector<char> enq(C, 0);
     for (int ci = 0; ci < C; ++ci) {
       HIP_TRY(ctx, hipStreamWaitEvent(ctx->chunks[ci].stream, ctx->chunks[ci].scanned, 0));
       bool done = false;
-      const int rc = enqueue_chunk_draws_blind(ctx, ci, das[ci], blind_rounds, &done);
+      if (!forced_rounds && ctx->chunks[ci].have_est) {
+        const int r = ctx->chunks[ci].est_rounds;
+        rounds_of[ci] = r < 2 ? 2 : (r > 6 ? 6 : r);
+      }
+      const int rc = enqueue_chunk_draws_blind(ctx, ci, das[ci], rounds_of[ci], &done);
       if (rc) return rc;
       enq[ci] = done ? 1 : 0;
       if (done) ++ctx->last_blind;
@@ -1024,23 +1034,27 @@ LENTIL_API int lentil_hip_redistribute(lentil_hip_ctx *ctx) {
                                     offsetof(DevCounters, inv_row_min) - offsetof(DevCounters, n_tasks), ch.stream));
         const int rc = enqueue_chunk_draws(ctx, ci, das[ci], blind_rounds);
         if (rc) return rc;
+        rounds_of[ci] = blind_rounds;
       } else {
         const uint64_t cap = ch.v_end - ch.v_begin;
         ch.est_items = c.work_count < cap ? c.work_count : cap;
         ch.est_sum = c.sum_samples;
+        ch.est_rounds = (int)c.rounds_used;
         // nothing left open after the blind rounds (the usual case): no round-by-round continuation, no second look
-        if (ch.est_items == 0 || c.n_active[blind_rounds & 1] == 0) ch.n_items = 0;
+        if (ch.est_items == 0 || c.n_active[rounds_of[ci] & 1] == 0) ch.n_items = 0;
       }
     }
     // ---- any chunk with items still missing draws after the blind rounds continues round by round
-    int max_rounds = ctx->last_rounds > blind_rounds ? ctx->last_rounds : blind_rounds;
+    int max_rounds = ctx->last_rounds;
+    for (int ci = 0; ci < C; ++ci) if (rounds_of[ci] > max_rounds) max_rounds = rounds_of[ci];
     for (int ci = 0; ci < C; ++ci) {
       lentil_hip_ctx::Chunk &ch = ctx->chunks[ci];
       HIP_TRY(ctx, hipStreamSynchronize(ch.stream));
       if (ch.n_items == 0) continue;
       ctx->h_ctr_valid = false;       // more rounds: the counters move on
-      int rounds = blind_rounds;
-      const int rc = finish_rounds(ctx, ci, das[ci], blind_rounds, &rounds);
+      int rounds = rounds_of[ci];
+      const int rc = finish_rounds(ctx, ci, das[ci], rounds_of[ci], &rounds);
+      if (rounds > ch.est_rounds) ch.est_rounds = rounds;
       if (rc) return rc;
       if (rounds > max_rounds) max_rounds = rounds;
     }

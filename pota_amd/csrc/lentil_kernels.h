@@ -31,6 +31,7 @@ struct DevCounters {
   unsigned long long lane_rounds;    // 64 x scheduler rounds (iteration slots offered)
   unsigned long long slow_solves;    // solves handed over to solve_slow_kernel (stragglers)
   unsigned long long fallback;       // blind prep: the chunk did not fit the buffers sized from the last pass
+  unsigned long long rounds_used;    // 1 + the last round whose accept kernel found items to process
   // per-round queues, double buffered by round parity
   unsigned int n_tasks[2];
   unsigned int task_head[2];
@@ -1459,6 +1460,7 @@ __global__ __launch_bounds__(256) void accept_kernel(DrawArgs a) {
   __shared__ AcceptShared sh;
   const uint32_t par = (uint32_t)a.parity, nxt = par ^ 1u;
   const uint32_t n_active = a.ctr->n_active[par];
+  if (blockIdx.x == 0 && threadIdx.x == 0 && n_active) atomicMax(&a.ctr->rounds_used, (unsigned long long)(a.round + 1));
   const uint32_t *res = a.pool[par];
   unsigned long long tot_attempted = 0, tot_accepted = 0;
   uint32_t rmin = 0x7FFFFFFFu, rmax_p1 = 0u;       // rows this thread's accepted draws went to
