@@ -80,6 +80,7 @@ struct lentil_hip_ctx {
   int slow_at = 20;                          // LENTIL_SLOW_AT: iterations after which a solve is parked (0: never)
  uint64_t slow_below = 8ull << 20;          // LENTIL_SLOW_BELOW: ... in chunks whose draw sum is below this
  int slow_from_round = 0;                   // LENTIL_SLOW_FROM_ROUND
+  int slow_max_lanes = 4;                    // LENTIL_SLOW_MAX_LANES
   bool blind = true;                         // LENTIL_BLIND=0: always wait for a chunk's scan before sizing its draw rounds
   uint32_t extra_num = 0, extra_const = 0;   // LENTIL_EXTRA_256THS / LENTIL_EXTRA_CONST: first-batch over-provisioning
   uint64_t extra_below = 8ull << 20;         // LENTIL_EXTRA_BELOW: ... while a chunk's draw sum is below this
@@ -171,6 +172,7 @@ LENTIL_API int lentil_hip_create(int device, lentil_hip_ctx **out_ctx) {
   if (ctx->slow_at < 0 || ctx->slow_at >= 100) ctx->slow_at = 0;
   if (const char *e = getenv("LENTIL_SLOW_BELOW")) ctx->slow_below = strtoull(e, nullptr, 10);
   if (const char *e = getenv("LENTIL_SLOW_FROM_ROUND")) ctx->slow_from_round = atoi(e);
+  if (const char *e = getenv("LENTIL_SLOW_MAX_LANES")) ctx->slow_max_lanes = atoi(e);
   if (const char *e = getenv("LENTIL_BLIND")) ctx->blind = !(e[0] == '0');
   if (const char *e = getenv("LENTIL_EXTRA_256THS")) ctx->extra_num = (uint32_t)strtoul(e, nullptr, 10);
   if (const char *e = getenv("LENTIL_EXTRA_CONST")) ctx->extra_const = (uint32_t)strtoul(e, nullptr, 10);
@@ -982,6 +984,7 @@ LENTIL_API int lentil_hip_redistribute(lentil_hip_ctx *ctx) {
     da.slow_at = ctx->slow_at;
     da.slow_below = ctx->slow_below;
     da.slow_from_round = ctx->slow_from_round;
+    da.slow_max_lanes = ctx->slow_max_lanes;
     da.extra_num = ctx->extra_num; da.extra_const = ctx->extra_const; da.extra_below = ctx->extra_below;
     da.log = ctx->d_log;
     da.log_cap = ctx->log_cap;

@@ -654,6 +654,7 @@ struct DrawArgs {
   SlowRec *slow;           // straggler queue of the current round (null: stragglers stay in their lanes)
   uint32_t slow_cap;
   int32_t slow_at;         // Newton iterations after which a solve counts as a straggler
+  int32_t slow_max_lanes;  // a dry wave parks only when at most this many of its lanes are still busy
   int32_t round;           // solve/accept round of the chunk (0 = first batch)
   int32_t slow_from_round; // parking starts with this round: the first round's own ramp-down hides most of its stragglers
   uint64_t slow_below;     // ... in chunks whose draw sum is below this (where the end of a round is what costs;
@@ -900,7 +901,10 @@ __global__ __launch_bounds__(256) void solve_po_kernel(DrawArgs a) {
     // holding this wave -- and the end of the round -- for it.
     // Only while this wave is running dry (no task left to refill its lanes from): as long as there is work, a slow
     // solve costs one lane; once there is none, it holds the wave and the end of the round.
-    if (parking && no_more) {
+    // ... and only its last few lanes: a lens whose solves routinely take more than slow_at iterations (the petzval
+    // table: heavy vignetting, thousands of such solves per round) would otherwise send them all to a kernel that
+    // spends a wave on each (config 4: 17.5 ms per frame with that, 3 ms of it per solve_slow_kernel launch).
+    if (parking && no_more && __builtin_popcountll(__ballot(busy)) <= a.slow_max_lanes) {
       const bool park = busy && s.k >= a.slow_at;
       const unsigned long long pmask = __ballot(park);
       if (pmask) {

@@ -718,7 +718,8 @@ def test_stragglers_finish_in_the_cooperative_kernel(orc, monkeypatch, slow_at, 
     ref = common.run_oracle(orc, p, table, visits)
     rc = ref.counters()
     monkeypatch.setenv("LENTIL_SLOW_AT", slow_at)
-    monkeypatch.setenv("LENTIL_SLOW_FROM_ROUND", "0")       # by default the first round keeps its stragglers
+    monkeypatch.setenv("LENTIL_SLOW_FROM_ROUND", "0")
+    monkeypatch.setenv("LENTIL_SLOW_MAX_LANES", "64")       # by default a dry wave parks only its last four lanes
     ctx = capi.Context(0)
     try:
         c = gpu_run(ctx, p, table, visits, lens_mode=lens_mode)
