@@ -14,14 +14,14 @@ def main():
     f = glob.glob(os.path.join(sys.argv[1], "**", "*kernel_trace.csv"), recursive=True)[0]
     rows = list(csv.DictReader(open(f)))
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-    # a pass starts at a scan kernel that follows a resolve kernel (or the beginning)
-    starts = [i for i, r in enumerate(rows) if "scan_" in r["Kernel_Name"] and
-              (i == 0 or "scan_" not in rows[i - 1]["Kernel_Name"]) and
-              not any("scan_" in rows[j]["Kernel_Name"] or "solve" in rows[j]["Kernel_Name"] or "accept" in rows[j]["Kernel_Name"]
-                      for j in range(max(0, i - 3), i))]
+    # a pass ends with its resolve kernel: pass `which` (default: the last one) = everything after the previous resolve,
+    # starting at its first scan launch
+    ends = [i for i, r in enumerate(rows) if "resolve_kernel" in r["Kernel_Name"]]
     which = int(sys.argv[2]) if len(sys.argv) > 2 else -1
-    s = starts[which]
-    e = len(rows) if which == -1 or which + 1 >= len(starts) else starts[which + 1]
+    e = ends[which] + 1
+    k = ends.index(ends[which])
+    lo = ends[k - 1] + 1 if k > 0 else 0
+    s = next(i for i in range(lo, e) if "scan_" in rows[i]["Kernel_Name"])
     t0 = int(rows[s]["Start_Timestamp"])
     for r in rows[s:e]:
         a = (int(r["Start_Timestamp"]) - t0) / 1e3
