@@ -458,6 +458,91 @@ def test_tiled_output_on_one_gpu_matches_the_whole_frame(orc, gpu_ctx_factory, m
         assert any(f > 0 for f in forms) and not any(f < 0 for f in forms)     # pixel lists only
 
 
+def _tiled_rank_process(rank, world, port, W, H, M, f_hi, kinds, bounds, sparse, q):
+    """One rank of test_tiled_output_two_processes: a process of its own, torch.distributed (gloo) between the ranks,
+    all of them on GPU 0."""
+    import os
+    import sys
+    sys.path.insert(0, common.ROOT)
+    sys.path.insert(0, os.path.join(common.ROOT, "tests"))
+    import torch
+    import torch.distributed as dist
+    from pota_amd import distributed, workload
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    distributed.SPARSE_EXCHANGE = sparse
+    p, model, table, keep = common.po_setup(W, H, samples_override=48)
+    b_lo, b_hi = distributed.band_of(rank, world, H, p.yres, bounds)
+    c = workload.generate(np, b_lo * W * M, min(b_hi, H) * W * M, W, H, M, f_hi=f_hi, focus_dist=150.0,
+                          tan_half_fov=common.tan_half_fov(p), n_extra=len(kinds) - 1)
+    v, kv = capi.make_visits(c, visits_per_pixel=M, pixels_per_row=W, pixel_y0=b_lo)
+    ctx = capi.Context(0)
+    ctx.set_params(p); ctx.set_lens(table); ctx.set_bokeh(None)
+    ctx.alloc_frame(len(kinds), kinds)
+    ctx.upload_visits(v)
+    eng = distributed.HipEngine(ctx, rows=p.yres)
+    for _ in range(2):                                       # second pass: blind, row-limited clear
+        band = distributed.frame_step_bands(eng, dist, H, p.yres, bounds)
+        ctx.sync()
+    out = {"band": band, "forms": distributed.LAST_FORMS[rank]}
+    for a in range(len(kinds)):
+        buf, w = ctx.download_accum(a)
+        out[a] = (buf, w, ctx.download_aov(a))
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+    ctx.close()
+
+
+@pytest.mark.parametrize("sparse", [True, False], ids=["pixel-lists", "rows"])
+def test_tiled_output_two_processes(orc, gpu_ctx_factory, sparse):
+    """The tiled step as bench.py --gpus N runs it -- one process per rank, torch.distributed collectives and
+    batch_isend_irecv between them (gloo here, both ranks on the one GPU of the test box; RCCL in the real thing) --
+    against a context that has the whole frame.  Unequal bands, closest-filtered AOV included."""
+    import socket
+    import torch.multiprocessing as mp
+    W, H, M = 64, 45, 9
+    kinds = [0, 1, 0]
+    bounds = [0, 19, 45]
+    f_hi = 0.0015 if sparse else 0.03
+    p, model, table, keep = common.po_setup(W, H, samples_override=48)
+    visits, cols = common.make_stream(p, W, H, M, f_hi=f_hi, n_extra=2)
+    whole = gpu_ctx_factory()
+    gpu_run(whole, p, table, visits, n_aovs=3, kinds=kinds)
+    ref = {a: (whole.download_accum(a), whole.download_aov(a)) for a in range(3)}
+    sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
+    mpc = mp.get_context("spawn")
+    q = mpc.Queue()
+    procs = [mpc.Process(target=_tiled_rank_process, args=(r, 2, port, W, H, M, f_hi, kinds, bounds, sparse, q)) for r in range(2)]
+    for pr in procs:
+        pr.start()
+    got = dict(q.get(timeout=300) for _ in range(2))
+    for pr in procs:
+        pr.join(timeout=120)
+        assert pr.exitcode == 0
+    forms = got[0]["forms"] + got[1]["forms"]
+    assert any(f > 0 for f in forms) if sparse else any(f < 0 for f in forms)
+    for rank in range(2):
+        lo, hi = got[rank]["band"]
+        sel = np.zeros(p.yres, bool); sel[lo:hi] = True
+        sel = np.repeat(sel, p.xres)
+        for a, kind in enumerate(kinds):
+            buf, w, img = got[rank][a]
+            (rbuf, rw), rimg = ref[a]
+            buf, w, img, rbuf, rw, rimg = buf[sel], w[sel], img[sel], rbuf[sel], rw[sel], rimg[sel]
+            if kind:
+                assert np.array_equal(buf, rbuf) and np.array_equal(img, rimg)
+            else:
+                m = rbuf != 0
+                assert np.array_equal(buf != 0, m)
+                assert float(np.max(np.abs(buf[m] - rbuf[m]) / np.abs(rbuf[m]))) < TOL
+                assert float(np.max(np.abs(w[rw != 0] - rw[rw != 0]) / rw[rw != 0])) < TOL
+                mi = rimg != 0
+                assert float(np.max(np.abs(img[mi] - rimg[mi]) / np.abs(rimg[mi]))) < 2 * TOL
+
+
 @pytest.mark.parametrize("chroma,lens_mode,override", [(0.5, 0, 48), (0.5, 1, 48), (1.0, 0, 0), (-0.5, 0, 48)])
 def test_po_chromatic_aberration(orc, gpu_ctx_factory, chroma, lens_mode, override):
     """abb_chromatic != 0 in polynomial-optics mode (src/lentil_filter.cpp:248-299): three wavelength
