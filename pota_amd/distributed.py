@@ -238,10 +238,14 @@ def rebalance(bounds, seconds, min_rows=8, damping=1.0):
         row = bounds[k] + damping * (row - bounds[k])
         new.append(int(round(row)))
     new.append(int(bounds[world]))
-    for k in range(1, world):            # keep every band at least min_rows high, boundaries ascending
-        new[k] = max(new[k], new[k - 1] + min_rows)
-    for k in range(world - 1, 0, -1):
-        new[k] = min(new[k], new[k + 1] - min_rows)
+    # a band never shrinks below half or grows beyond twice the even height, whatever the timings say (the physical
+    # imbalance is a few tens of percent; a rank that was merely disturbed while it was timed must not wreck the cut)
+    even = (int(bounds[world]) - int(bounds[0])) / world
+    lo_h, hi_h = max(min_rows, int(even * 0.5)), max(min_rows, int(even * 2.0))
+    for k in range(1, world):            # boundaries ascending, heights within [lo_h, hi_h] ...
+        new[k] = min(max(new[k], new[k - 1] + lo_h), new[k - 1] + hi_h)
+    for k in range(world - 1, 0, -1):    # ... also seen from the other end (the last boundary is fixed)
+        new[k] = max(min(new[k], new[k + 1] - lo_h), new[k + 1] - hi_h)
     return new
 
 
