@@ -77,6 +77,7 @@ struct lentil_hip_ctx {
   double first_chunk_frac = 0.5;             // LENTIL_FIRST_CHUNK_FRAC
   uint64_t early_cap_samples = 4ull << 20;   // LENTIL_EARLY_CAP_SAMPLES
   uint64_t max_pool_units = 1ull << 32;    // 16 GiB per pool at most (LENTIL_MAX_POOL_UNITS overrides)
+  double mean_iters = 0.0;                   // Newton iterations per solve in the last pass (0: unknown)
   int slow_at = 20;                          // LENTIL_SLOW_AT: iterations after which a solve is parked (0: never)
  uint64_t slow_below = 8ull << 20;          // LENTIL_SLOW_BELOW: ... in chunks whose draw sum is below this
  int slow_from_round = 0;                   // LENTIL_SLOW_FROM_ROUND
@@ -981,7 +982,13 @@ LENTIL_API int lentil_hip_redistribute(lentil_hip_ctx *ctx) {
     da.bokeh = ctx->bokeh;
     da.V = ctx->V;
     da.F = ctx->F;
+    // a straggler is a solve well beyond what this lens usually takes: 1.3 x the mean iteration count of the previous
+    // pass where that is above LENTIL_SLOW_AT (petzval table: ~25 iterations on average, 20 would park thousands)
     da.slow_at = ctx->slow_at;
+    if (ctx->slow_at > 0 && ctx->mean_iters > 0.0) {
+      const int adaptive = (int)(1.3 * ctx->mean_iters + 0.5);
+      if (adaptive > da.slow_at) da.slow_at = adaptive < 90 ? adaptive : 90;
+    }
     da.slow_below = ctx->slow_below;
     da.slow_from_round = ctx->slow_from_round;
     da.slow_max_lanes = ctx->slow_max_lanes;
@@ -1024,6 +1031,9 @@ LENTIL_API int lentil_hip_redistribute(lentil_hip_ctx *ctx) {
       ctx->h_ctr.resize((size_t)C);
       HIP_TRY(ctx, hipMemcpy(ctx->h_ctr.data(), ctx->d_ctr, sizeof(DevCounters) * (size_t)C, hipMemcpyDeviceToHost));
       ctx->h_ctr_valid = true;
+      unsigned long long it = 0, tr = 0;
+      for (const DevCounters &k : ctx->h_ctr) { it += k.newton_iters; tr += k.tries; }
+      if (tr) ctx->mean_iters = (double)it / (double)tr;
     }
     for (int ci = 0; ci < C; ++ci) {
       lentil_hip_ctx::Chunk &ch = ctx->chunks[ci];
