@@ -2,17 +2,17 @@
 upload + pass, against the pass alone.  usage: pcie_rate.py [W H]"""
 import os, sys, time
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
 import numpy as np
 import torch  # noqa: F401  (one HIP runtime per process)
-import common
-from pota_amd import capi, workload
+from pota_amd import camera, capi, lens_io, workload
 
 W, H = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (1920, 1080)
 M = 9
-p, model, table, keep = common.po_setup(W, H, samples_override=1024)
+p = camera.default_params(); camera.setup_filter(p, W, H, filter_width=1.0, aa_samples=3)
+p, model = camera.setup_po(p, "double_gauss_50mm", focus_dist=150.0); p.samples_override = 1024
+table, keep = lens_io.make_lens_table(model.spec)
 n = W * H * M
-cols = workload.generate(np, 0, n, W, H, M, f_hi=2.0 ** -16, focus_dist=150.0, tan_half_fov=common.tan_half_fov(p))
+cols = workload.generate(np, 0, n, W, H, M, f_hi=2.0 ** -16, focus_dist=150.0, tan_half_fov=float(p.sensor_width) * 0.5 / float(p.focal_length))
 visits, kv = capi.make_visits(cols, visits_per_pixel=M, pixels_per_row=W)
 ctx = capi.Context(0); ctx.set_params(p); ctx.set_lens(table); ctx.alloc_frame(1)
 nbytes = n * 80

@@ -1,17 +1,17 @@
 """Ad-hoc timing of the kernels (development aid; the contract benchmark is bench.py)."""
 import sys, os, time
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
-sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "tests"))
 import numpy as np, torch
-import common
-from pota_amd import capi, workload
+from pota_amd import camera, capi, lens_io, workload
 
 W, H, M = int(sys.argv[1]), int(sys.argv[2]), 9
 override = int(sys.argv[3]); f_hi = float(sys.argv[4]); K = int(sys.argv[5]) if len(sys.argv) > 5 else 0
-p, model, table, keep = common.po_setup(W, H, samples_override=override)
+p = camera.default_params(); camera.setup_filter(p, W, H, filter_width=1.0, aa_samples=3)
+p, model = camera.setup_po(p, "double_gauss_50mm", focus_dist=150.0); p.samples_override = override
+table, keep = lens_io.make_lens_table(model.spec)
 dev = torch.device("cuda:0")
 n = W * H * M
-cols = workload.generate(torch, 0, n, W, H, M, f_hi=f_hi, focus_dist=150.0, tan_half_fov=common.tan_half_fov(p), n_extra=K, device=dev)
+cols = workload.generate(torch, 0, n, W, H, M, f_hi=f_hi, focus_dist=150.0, tan_half_fov=float(p.sensor_width) * 0.5 / float(p.focal_length), n_extra=K, device=dev)
 torch.cuda.synchronize()
 ctx = capi.Context(0)
 ctx.set_params(p); ctx.set_lens(table); ctx.alloc_frame(1 + K)
