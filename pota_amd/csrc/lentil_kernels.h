@@ -168,14 +168,14 @@ struct WaveQueue {
     unsigned long long base = 0;
     if (lane == 0) base = atomicAdd(&ctr->work_count, (unsigned long long)n);
     base = __shfl(base, 0);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
     __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
     for (uint32_t i = lane; i < n; i += 64u) {
       if (base + i < cap) work[base + i] = q[i];
       else atomicAdd(&ctr->overflow, 1ull);
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
     __builtin_amdgcn_wave_barrier();
     n = 0;
   }
@@ -287,9 +287,9 @@ __global__ __launch_bounds__(256) void scan_uniform_kernel(ScanArgs a) {
         if (e < TV) { sval[e] = val; sw[e] = w; }
       }
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
     __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
 
     if (own) {
       // a visit that was redistributed left zeros here; adding +0 changes nothing (an accumulator is never -0)
@@ -316,7 +316,7 @@ __global__ __launch_bounds__(256) void scan_uniform_kernel(ScanArgs a) {
     // extra AOVs: same weights, one column at a time through the same staging area
     for (uint32_t k = 0; k < V.n_extra; ++k) {
       if (a.F.closest_mask & (2u << k)) continue;       // closest AOVs are gathered from the winners later
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
       __builtin_amdgcn_wave_barrier();
       // four independent 16 B loads in flight per lane (one column has no other source of memory parallelism)
       const float4 *col = V.extra[k];
@@ -340,9 +340,9 @@ __global__ __launch_bounds__(256) void scan_uniform_kernel(ScanArgs a) {
                                      : make_float4(0.f, 0.f, 0.f, 0.f);
         }
       }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
       __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
       if (own) {
         float4 *dst = a.F.aov(lin, k + 1);
         float4 s = *dst;
@@ -355,7 +355,7 @@ __global__ __launch_bounds__(256) void scan_uniform_kernel(ScanArgs a) {
         *dst = s;
       }
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
     __builtin_amdgcn_wave_barrier();
   }
   wq.finish(a.work, a.work_cap, a.ctr);
@@ -459,15 +459,15 @@ __global__ __launch_bounds__(256) void scan_uniform_multi_kernel(ScanArgs a) {
       const int py = V.pixel_y0 + (int)(pp / V.pixels_per_row) * (int)V.pixel_row_stride;
       atomicMin(a.F.zkey + ((uint64_t)px + (uint64_t)py * xres), closest_key(depth, visit_gid(V, (uint32_t)v)));
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
     __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
 
     // sums: one lane per (pixel, AOV), M entries in iterator order
     for (uint32_t idx = lane; idx < np_tile * q; idx += 64u) srec[idx] = make_float4(0.f, 0.f, 0.f, 0.f);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
     __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
     for (uint32_t idx = lane; idx < np_tile * n_aovs; idx += 64u) {
       const uint32_t pi = idx / n_aovs, k = idx - pi * n_aovs;
       if (a.F.closest_mask & (1u << k)) continue;
@@ -484,9 +484,9 @@ __global__ __launch_bounds__(256) void scan_uniform_multi_kernel(ScanArgs a) {
       srec[(size_t)pi * q + k] = sum;
       if (k == 0) reinterpret_cast<float *>(srec + (size_t)pi * q)[4u * n_aovs] = ws;
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
     __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
 
     // records -> accumulators (a row of the stream ends after pixels_per_row pixels, the frame row is wider)
 #pragma unroll
@@ -511,7 +511,7 @@ __global__ __launch_bounds__(256) void scan_uniform_multi_kernel(ScanArgs a) {
       cur.x += add.x; cur.y += add.y; cur.z += add.z; cur.w += add.w;
       *dst = cur;
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
     __builtin_amdgcn_wave_barrier();
   }
   wq.finish(a.work, a.work_cap, a.ctr);
@@ -1246,14 +1246,14 @@ LD_DEV AcceptResult accept_item(const DrawArgs &a, AcceptShared &sh, uint32_t it
           if (li < a.log_cap) { a.log[li].visit = h.visit; a.log[li].attempt = my_n; a.log[li].pixel = pix; }
         }
       }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
       __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
       for (uint32_t q = lane; q < T * U; q += 64u) {
         const uint32_t d = q / U, ch = q - d * U;
         atomicAdd(a.F.acc + (size_t)s_pix[wave][d] * a.F.stride + s_off[ch], s_val[ch]);
       }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
       __builtin_amdgcn_wave_barrier();
       // highest accepted attempt of the step
       const unsigned long long tmask = tmask0;
@@ -1406,9 +1406,9 @@ LD_DEV AcceptResult accept_item_chroma(const DrawArgs &a, AcceptShared &sh, uint
           if (li < a.log_cap) { a.log[li].visit = h.visit; a.log[li].attempt = my_n | (c << 30); a.log[li].pixel = pix; }
         }
       }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
       __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
       for (uint32_t q = lane; q < T * U; q += 64u) {
         const uint32_t d = q / U, ch = q - d * U;
         float val = s_val[ch];
@@ -1421,7 +1421,7 @@ LD_DEV AcceptResult accept_item_chroma(const DrawArgs &a, AcceptShared &sh, uint
         }
         atomicAdd(a.F.acc + (size_t)s_pix[wave][d] * a.F.stride + s_off[ch], val);
       }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
       __builtin_amdgcn_wave_barrier();
     }
     // block totals: splats, and the count after the last executed attempt
@@ -1679,9 +1679,9 @@ __global__ __launch_bounds__(256) void resolve_kernel(FrameDev F, float *resolve
     const uint32_t n_pix = (uint32_t)((p_end - p0) < 64ull ? (p_end - p0) : 64ull);
     const uint32_t n4 = n_pix * q;
     for (uint32_t i = lane; i < n4; i += 64u) tile[i] = acc4[p0 * q + i];
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
     __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
     if (lane < n_pix) {
       const float *rec = reinterpret_cast<const float *>(tile + (size_t)lane * q);
       const float wt = rec[4u * F.n_aovs];
@@ -1696,7 +1696,7 @@ __global__ __launch_bounds__(256) void resolve_kernel(FrameDev F, float *resolve
         reinterpret_cast<float4 *>(resolved)[(uint64_t)a * F.np + p0 + lane] = c;
       }
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
     __builtin_amdgcn_wave_barrier();
   }
 }
