@@ -18,6 +18,10 @@ of consecutive rows -- its visits and its tile of the output -- and sends the ro
 outside the band to their owners (pota_amd/distributed.py::frame_step_bands).
 LENTIL_PARTITION=interleaved selects rows r mod N with one sum all-reduce of the whole frame instead.
 
+Set-up before the W warm-up steps (untimed, like generating the visits): two passes that let the context size its
+draw buffers (the first pass of a context waits for each chunk's scan and allocates); for N > 1 three calibration
+passes that re-cut the row bands from the ranks' pass times.
+
 The printed JSON line also carries
   roofline     -- the HBM-bound scan kernel: algorithmic bytes (visits x 80 B) / its mean duration,
                   measured with HIP events on the library's stream, against 8 TB/s
@@ -282,6 +286,12 @@ def main():
                 del cols
                 torch.cuda.empty_cache()
                 cols = bind(args.f_hi)
+    else:
+        # set-up: the first pass of a context sizes its draw buffers from the scan's counters (host round trips,
+        # allocations); two passes settle that, whatever --warmup says
+        for _ in range(2):
+            step()
+        torch.cuda.synchronize()
     dt, scan_ms, draw_ms, res_ms = run(args.steps, args.warmup)
     ctr = ctx.counters()
     n_total = workload.frame_visit_count(W, H, M) if not emulate else n_local        # all ranks
