@@ -100,6 +100,7 @@ struct lentil_hip_ctx {
   uint32_t visit_id_base = 0;
   DevCounters *d_ctr = nullptr;
   std::vector<DevCounters> h_ctr;    // the chunks' counters as read back at the end of the last (blind) pass
+  DevCounters *h_ctr_pinned = nullptr;   // staging for that read-back (pinned: an asynchronous copy on the last chunk's stream)
   bool h_ctr_valid = false;
   lentil_draw_record *d_log = nullptr;
   uint64_t log_cap = 0;
@@ -154,6 +155,7 @@ LENTIL_API int lentil_hip_create(int device, lentil_hip_ctx **out_ctx) {
   if (ctx->n_chunks > 16) ctx->n_chunks = 16;
   // one DevCounters per chunk + one shared (draw-log cursor)
   HIP_TRY(ctx, hipMalloc(&ctx->d_ctr, sizeof(DevCounters) * (ctx->n_chunks + 1)));
+  HIP_TRY(ctx, hipHostMalloc((void **)&ctx->h_ctr_pinned, sizeof(DevCounters) * ctx->n_chunks, hipHostMallocDefault));
   HIP_TRY(ctx, hipMemsetAsync(ctx->d_ctr, 0, sizeof(DevCounters) * (ctx->n_chunks + 1), ctx->stream));
   ctx->chunks.resize(ctx->n_chunks);
   for (auto &ch : ctx->chunks) {
@@ -230,6 +232,7 @@ LENTIL_API int lentil_hip_destroy(lentil_hip_ctx *ctx) {
   }
   if (ctx->scans_done) (void)hipEventDestroy(ctx->scans_done);
   (void)hipFree(ctx->d_ctr);
+  if (ctx->h_ctr_pinned) (void)hipHostFree(ctx->h_ctr_pinned);
   (void)hipFree(ctx->d_log);
   for (auto &ev : ctx->ev) if (ev) (void)hipEventDestroy(ev);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -1028,8 +1031,10 @@ LENTIL_API int lentil_hip_redistribute(lentil_hip_ctx *ctx) {
     for (int ci = 0; ci < C; ++ci) any_blind = any_blind || enq[ci];
     if (any_blind) {
       for (int ci = 0; ci < C; ++ci) HIP_TRY(ctx, hipStreamSynchronize(ctx->chunks[ci].stream));
-      ctx->h_ctr.resize((size_t)C);
-      HIP_TRY(ctx, hipMemcpy(ctx->h_ctr.data(), ctx->d_ctr, sizeof(DevCounters) * (size_t)C, hipMemcpyDeviceToHost));
+      hipStream_t cs = ctx->chunks[C - 1].stream;
+      HIP_TRY(ctx, hipMemcpyAsync(ctx->h_ctr_pinned, ctx->d_ctr, sizeof(DevCounters) * (size_t)C, hipMemcpyDeviceToHost, cs));
+      HIP_TRY(ctx, hipStreamSynchronize(cs));
+      ctx->h_ctr.assign(ctx->h_ctr_pinned, ctx->h_ctr_pinned + C);
       ctx->h_ctr_valid = true;
       unsigned long long it = 0, tr = 0;
       for (const DevCounters &k : ctx->h_ctr) { it += k.newton_iters; tr += k.tries; }
