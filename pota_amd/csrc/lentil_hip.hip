@@ -100,7 +100,7 @@ struct lentil_hip_ctx {
   uint32_t visit_id_base = 0;
   DevCounters *d_ctr = nullptr;
   std::vector<DevCounters> h_ctr;    // the chunks' counters as read back at the end of the last (blind) pass
-  DevCounters *h_ctr_pinned = nullptr;   // staging for that read-back (pinned: an asynchronous copy on the last chunk's stream)
+  DevCounters *h_ctr_pinned = nullptr;   // staging for that read-back (pinned: an asynchronous copy at the end of each chunk's stream)
   bool h_ctr_valid = false;
   lentil_draw_record *d_log = nullptr;
   uint64_t log_cap = 0;
@@ -1025,15 +1025,16 @@ LENTIL_API int lentil_hip_redistribute(lentil_hip_ctx *ctx) {
       const int rc = enqueue_chunk_draws(ctx, ci, das[ci], blind_rounds);
       if (rc) return rc;
     }
-    // ---- blind chunks: what the scan really found (next pass's estimate); a chunk that did not fit is redone.
-    // One read-back of all chunks' counters once every chunk stream has drained; it also serves touched_rows.
+    // every chunk's counters follow its last kernel on its own stream (pinned, asynchronous): one host wait below
     bool any_blind = false;
     for (int ci = 0; ci < C; ++ci) any_blind = any_blind || enq[ci];
+    if (any_blind)
+      for (int ci = 0; ci < C; ++ci)
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->h_ctr_pinned + ci, ctx->d_ctr + ci, sizeof(DevCounters), hipMemcpyDeviceToHost, ctx->chunks[ci].stream));
+    // ---- blind chunks: what the scan really found (next pass's estimate); a chunk that did not fit is redone.
+    // The counters read back above are there once every chunk stream has drained; they also serve touched_rows.
     if (any_blind) {
       for (int ci = 0; ci < C; ++ci) HIP_TRY(ctx, hipStreamSynchronize(ctx->chunks[ci].stream));
-      hipStream_t cs = ctx->chunks[C - 1].stream;
-      HIP_TRY(ctx, hipMemcpyAsync(ctx->h_ctr_pinned, ctx->d_ctr, sizeof(DevCounters) * (size_t)C, hipMemcpyDeviceToHost, cs));
-      HIP_TRY(ctx, hipStreamSynchronize(cs));
       ctx->h_ctr.assign(ctx->h_ctr_pinned, ctx->h_ctr_pinned + C);
       ctx->h_ctr_valid = true;
       unsigned long long it = 0, tr = 0;
