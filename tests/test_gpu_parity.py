@@ -848,6 +848,43 @@ def test_blind_passes_and_fallback(orc, monkeypatch):
         ctx.close()
 
 
+def test_randomized_configurations_two_passes_each(orc):
+    """Seeded soak over the knobs the fixed cases above hold still: frame sizes that are not multiples of the
+    tile, visits per pixel, lens, compiled / table kernels, draw counts, extra AOVs, highlight fraction, focus
+    distance.  One context per configuration, two passes (the second one is enqueued blind) — counters, accepted-draw
+    lists and frames against the oracle both times."""
+    rng = np.random.default_rng(0x10E7)
+    for case in range(8):
+        W, H = int(rng.integers(17, 120)), int(rng.integers(9, 70))
+        aa, fw = [(2, 1.0), (3, 1.0), (4, 1.5)][int(rng.integers(0, 3))]
+        M = {2: 4, 3: 9, 4: 36}[aa]
+        lens = ["double_gauss_50mm", "petzval_58mm"][int(rng.integers(0, 2))]
+        override = int(rng.choice([0, 8, 17, 33]))
+        n_extra = int(rng.integers(0, 4))
+        f_hi = float(rng.choice([0.0005, 0.004, 0.02]))
+        focus = float(rng.choice([60.0, 150.0, 400.0]))
+        lens_mode = int(rng.integers(0, 2))
+        tag = "case %d: %dx%d M=%d %s override=%d extra=%d f_hi=%g focus=%g mode=%d" % (
+            case, W, H, M, lens, override, n_extra, f_hi, focus, lens_mode)
+        p, model, table, keep = common.po_setup(W, H, lens=lens, aa=aa, filter_width=fw, samples_override=override,
+                                                focus_dist=focus)
+        visits, cols = common.make_stream(p, W, H, M, f_hi=f_hi, n_extra=n_extra, seed=0xA000 + case)
+        ref = common.run_oracle(orc, p, table, visits, n_aovs=1 + n_extra)
+        rc = ref.counters()
+        ctx = capi.Context(0)
+        try:
+            for again in range(2):
+                c = gpu_run(ctx, p, table, visits, n_aovs=1 + n_extra, lens_mode=lens_mode)
+                assert (c.redistributed_visits, c.attempted_draws, c.accepted_draws) == (
+                    rc.redistributed_visits, rc.attempted_draws, rc.accepted_draws), tag
+                if again and rc.redistributed_visits:
+                    assert c.blind_chunks > 0, tag
+                check_logs(ctx, ref)
+                check_frame(ctx, ref, n_aovs=1 + n_extra)
+        finally:
+            ctx.close()
+
+
 def test_empty_stream_and_error_paths(gpu_ctx_factory):
     p, model, table, keep = common.po_setup(32, 16)
     ctx = gpu_ctx_factory()
