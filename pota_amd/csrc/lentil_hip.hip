@@ -910,7 +910,7 @@ LENTIL_API int lentil_hip_redistribute(lentil_hip_ctx *ctx) {
         ppt = 64 / M;
         sa.ppt = ppt;
         sa.tv_pad = ppt * M;
-        const size_t wave_f4 = (size_t)ctx->F.n_aovs * 64 + 16 + (size_t)ppt * (ctx->F.stride / 4);
+        const size_t wave_f4 = (size_t)ctx->F.n_aovs * kMultiPlane + 16 + (size_t)ppt * (ctx->F.stride / 4);
         lds = 4 * wave_f4 * 16 + 4 * kWaveQueue * sizeof(uint2);
       }
       const uint64_t n_pixels = (ctx->V.n + M - 1) / M;

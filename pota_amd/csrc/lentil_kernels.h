@@ -154,6 +154,9 @@ LD_DEV uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdg
 // reserves space in the global list with ONE returning atomic per flush (queue more than half full,
 // or end of the wave) -- a single hot counter only sustains ~90 returning atomics per microsecond.
 constexpr uint32_t kWaveQueue = 128;
+// scan_uniform_multi_kernel: float4 slots per AOV plane of a wave's staging area.  65, not 64: the summing lanes
+// (pixel, aov) read plane aov at the same offset -- a stride of 64 float4 put all planes on the same LDS banks
+constexpr uint32_t kMultiPlane = 65;
 
 struct WaveQueue {
   uint2 *q;                 // wave-private LDS, kWaveQueue entries
@@ -378,11 +381,11 @@ __global__ __launch_bounds__(256) void scan_uniform_multi_kernel(ScanArgs a) {
   const uint32_t TV = ppt * M;
   const uint32_t n_aovs = a.F.n_aovs;
   const uint32_t q = a.F.stride >> 2;         // float4 per record
-  // per wave: [n_aovs][64] float4 staged values, [64] float weights, [ppt][stride] record tile, then the queue
-  const size_t wave_f4 = (size_t)n_aovs * 64u + 16u + (size_t)ppt * q;
+  // per wave: [n_aovs][kMultiPlane] float4 staged values, [64] float weights, [ppt][stride] record tile, then the queue
+  const size_t wave_f4 = (size_t)n_aovs * kMultiPlane + 16u + (size_t)ppt * q;
   float4 *sval = smem + (size_t)wave * wave_f4;
-  float *sw = reinterpret_cast<float *>(sval + (size_t)n_aovs * 64u);
-  float4 *srec = sval + (size_t)n_aovs * 64u + 16u;
+  float *sw = reinterpret_cast<float *>(sval + (size_t)n_aovs * kMultiPlane);
+  float4 *srec = sval + (size_t)n_aovs * kMultiPlane + 16u;
   uint2 *qmem = reinterpret_cast<uint2 *>(smem + (size_t)waves_per_block * wave_f4);
   WaveQueue wq;
   wq.init(qmem + (size_t)wave * kWaveQueue);
@@ -448,7 +451,7 @@ __global__ __launch_bounds__(256) void scan_uniform_multi_kernel(ScanArgs a) {
         if (k < n_aovs && !(a.F.closest_mask & (1u << k))) {
           float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
           if (w != 0.0f) x = make_float4((val[k].x + 0.0f) * w, (val[k].y + 0.0f) * w, (val[k].z + 0.0f) * w, (val[k].w + 0.0f) * w);
-          sval[(size_t)k * 64u + lane] = x;
+          sval[(size_t)k * kMultiPlane + lane] = x;
         }
       }
     }
@@ -473,13 +476,11 @@ __global__ __launch_bounds__(256) void scan_uniform_multi_kernel(ScanArgs a) {
       if (a.F.closest_mask & (1u << k)) continue;
       float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
       float ws = 0.f;
+      // entries of visits that do not add to their own pixel are +0 (weight and values): adding them changes nothing
       for (uint32_t j = 0; j < M; ++j) {
-        const float cw = sw[pi * M + j];
-        if (cw != 0.0f) {
-          const float4 c = sval[(size_t)k * 64u + pi * M + j];
-          sum.x += c.x; sum.y += c.y; sum.z += c.z; sum.w += c.w;
-          ws += cw;
-        }
+        const float4 c = sval[(size_t)k * kMultiPlane + pi * M + j];
+        sum.x += c.x; sum.y += c.y; sum.z += c.z; sum.w += c.w;
+        ws += sw[pi * M + j];
       }
       srec[(size_t)pi * q + k] = sum;
       if (k == 0) reinterpret_cast<float *>(srec + (size_t)pi * q)[4u * n_aovs] = ws;
