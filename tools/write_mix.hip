@@ -6,6 +6,8 @@
 //   mode 2  read-modify-write them every step      mode 3  collect B steps in LDS, store B*REC contiguous bytes
 //   mode 4  as 3 with read-modify-write (records requested at the start of the B steps)
 //   mode 5  as 1, the record address wrapped into 1 MiB (stays in L2: is it the memory or the store path?)
+//   mode 6  as 3, with a grid-wide barrier before and after the stores: chip-wide read and write phases
+//           (spins are bounded: a grid that is not co-resident gives wrong timing, not a hang)
 // Waves walk B consecutive tiles, then jump by the grid, so that mode 3/4 bursts are contiguous.
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -17,12 +19,23 @@
 constexpr int kCols = 8;
 typedef float v4f __attribute__((ext_vector_type(4)));
 
+__device__ void grid_barrier(unsigned int *ctr, unsigned int target) {
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __atomic_fetch_add(ctr, 1u, __ATOMIC_RELEASE);
+    for (int spin = 0; spin < 200000 && __atomic_load_n(ctr, __ATOMIC_ACQUIRE) < target; ++spin) __builtin_amdgcn_s_sleep(2);
+  }
+  __syncthreads();
+}
+
 template <int MODE, int B, int REC4>   // REC4: v4f of records per step (<= 64)
-__global__ __launch_bounds__(256) void mix(const v4f *__restrict__ cols, v4f *rec, uint64_t n_tiles, uint64_t col_stride) {
+__global__ __launch_bounds__(256) void mix(const v4f *__restrict__ cols, v4f *rec, uint64_t n_tiles, uint64_t col_stride, unsigned int *bar) {
   __shared__ v4f stage[4][B * REC4 > 0 ? B * REC4 : 1];
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
   const uint64_t wave_global = (uint64_t)blockIdx.x * 4 + wave, wave_stride = (uint64_t)gridDim.x * 4;
-  for (uint64_t t0 = wave_global * B; t0 < n_tiles; t0 += wave_stride * B) {
+  unsigned int phase = 0;
+  const uint64_t t_end = MODE == 6 ? ((n_tiles + wave_stride * B - 1) / (wave_stride * B)) * (wave_stride * B) : n_tiles;
+  for (uint64_t t0 = wave_global * B; t0 < t_end; t0 += wave_stride * B) {
     v4f old[(B * REC4 + 63) / 64];
     if (MODE == 4) {
 #pragma unroll
@@ -47,9 +60,10 @@ __global__ __launch_bounds__(256) void mix(const v4f *__restrict__ cols, v4f *re
       if (MODE == 0) { if (s.x == 1.2345e-30f) rec[lane] = s; }
       if ((MODE == 1 || MODE == 2) && lane < REC4) rec[t * REC4 + lane] = s;
       if (MODE == 5 && lane < REC4) rec[(t * REC4 + lane) & 0xFFFFu] = s;
-      if ((MODE == 3 || MODE == 4) && lane < REC4) stage[wave][b * REC4 + lane] = s;
+      if ((MODE == 3 || MODE == 4 || MODE == 6) && lane < REC4) stage[wave][b * REC4 + lane] = s;
     }
-    if (MODE == 3 || MODE == 4) {
+    if (MODE == 6) grid_barrier(bar, ++phase * gridDim.x);
+    if (MODE == 3 || MODE == 4 || MODE == 6) {
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
@@ -65,18 +79,28 @@ __global__ __launch_bounds__(256) void mix(const v4f *__restrict__ cols, v4f *re
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
       __builtin_amdgcn_wave_barrier();
     }
+    if (MODE == 6) grid_barrier(bar, ++phase * gridDim.x);
   }
 }
 
 template <int MODE, int B, int REC4>
 static int run(const char *name, const v4f *cols, v4f *rec, uint64_t n_tiles, uint64_t col_stride, int blocks, bool clear = true) {
+  static unsigned int *bar = nullptr;
+  if (!bar) CK(hipMalloc(&bar, 4));
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  if (MODE == 6) {                      // the barrier needs every block resident at once
+    int occ = 0;
+    CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, mix<MODE, B, REC4>, 256, 0));
+    if (occ < 1) { printf("%s: does not fit\n", name); return 0; }
+    if (occ < 4) blocks = blocks / 4 * occ;
+  }
   float best = 1e30f;
   for (int it = 0; it < 6; ++it) {
     if (clear || it == 0) CK(hipMemsetAsync(rec, 0, n_tiles * REC4 * 16, 0));
+    CK(hipMemsetAsync(bar, 0, 4, 0));
     CK(hipEventRecord(e0, 0));
-    hipLaunchKernelGGL((mix<MODE, B, REC4>), dim3(blocks), dim3(256), 0, 0, cols, rec, n_tiles, col_stride);
+    hipLaunchKernelGGL((mix<MODE, B, REC4>), dim3(blocks), dim3(256), 0, 0, cols, rec, n_tiles, col_stride, bar);
     CK(hipEventRecord(e1, 0));
     CK(hipEventSynchronize(e1));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
@@ -112,5 +136,8 @@ int main() {
   if (run<2, 1, 64>("1 KiB r-m-w per step, records not cleared", cols, rec, n_tiles, col_stride, blocks, false)) return 1;
   if (run<5, 1, 64>("1 KiB stored per step into 1 MiB", cols, rec, n_tiles, col_stride, blocks)) return 1;
   if (run<1, 1, 16>("256 B stored per step", cols, rec, n_tiles, col_stride, blocks)) return 1;
+  if (run<6, 16, 32>("8 KiB every 16 steps, chip-wide phases", cols, rec, n_tiles, col_stride, blocks)) return 1;
+  if (run<6, 8, 64>("8 KiB every 8 steps, chip-wide phases", cols, rec, n_tiles, col_stride, blocks)) return 1;
+  if (run<6, 16, 64>("16 KiB every 16 steps, chip-wide phases", cols, rec, n_tiles, col_stride, blocks)) return 1;
   return 0;
 }
