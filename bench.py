@@ -44,6 +44,8 @@ sys.path.insert(0, ROOT)
 # chunk's solves then queue behind the second scan instead of running beside it (3.34 -> 3.05 ms per step).
 # Read when the HIP runtime initialises, so: before torch is imported.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# dmabuf IPC for RCCL between the ranks of one node (the host driver here supports nothing else); also read early
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 FP64_VECTOR_PEAK_TFLOPS = 78.6
@@ -155,7 +157,6 @@ def main():
     torch.cuda.set_device(local_rank)
     force_dist = os.environ.get("LENTIL_FORCE_DIST") == "1"     # exercise the RCCL plumbing on one GPU
     if world > 1 or force_dist:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         if backend == "nccl":
