@@ -851,10 +851,19 @@ def test_blind_passes_and_fallback(orc, monkeypatch):
 def test_randomized_configurations_two_passes_each(orc):
     """Seeded soak over the knobs the fixed cases above hold still: frame sizes that are not multiples of the
     tile, visits per pixel, lens, compiled / table kernels, draw counts, extra AOVs, highlight fraction, focus
-    distance.  One context per configuration, two passes (the second one is enqueued blind) — counters, accepted-draw
-    lists and frames against the oracle both times."""
-    rng = np.random.default_rng(0x10E7)
-    for case in range(8):
+    distance, bokeh image, chromatic aberration.  One context per configuration, two passes (the second one is
+    enqueued blind) -- counters, accepted-draw lists and frames against the oracle both times.
+    LENTIL_SOAK_CASES / LENTIL_SOAK_SEED run a longer or a different sequence."""
+    import os
+    n_cases = int(os.environ.get("LENTIL_SOAK_CASES", "8"))
+    rng = np.random.default_rng(int(os.environ.get("LENTIL_SOAK_SEED", "0x10E7"), 0))
+    tex = np.load(os.path.join(common.ROOT, "tests", "golden", "example_bokeh_kernel_u8.npy")).astype(np.float32) / np.float32(255)
+    tables = bokeh.build_tables(tex)
+    bt = _abi.BokehTable()
+    bt.x, bt.y = tables["x"], tables["y"]
+    for k in ("cdfRow", "rowIndices", "cdfColumn", "columnIndices"):
+        setattr(bt, k, tables[k].ctypes.data)
+    for case in range(n_cases):
         W, H = int(rng.integers(17, 120)), int(rng.integers(9, 70))
         aa, fw = [(2, 1.0), (3, 1.0), (4, 1.5)][int(rng.integers(0, 3))]
         M = {2: 4, 3: 9, 4: 36}[aa]
@@ -864,25 +873,32 @@ def test_randomized_configurations_two_passes_each(orc):
         f_hi = float(rng.choice([0.0005, 0.004, 0.02]))
         focus = float(rng.choice([60.0, 150.0, 400.0]))
         lens_mode = int(rng.integers(0, 2))
-        tag = "case %d: %dx%d M=%d %s override=%d extra=%d f_hi=%g focus=%g mode=%d" % (
-            case, W, H, M, lens, override, n_extra, f_hi, focus, lens_mode)
+        image = case >= 8 and int(rng.integers(0, 4)) == 0           # the first eight cases: as first committed
+        chroma = float(rng.choice([0.0, 0.0, 0.5])) if case >= 8 else 0.0
+        tag = "case %d: %dx%d M=%d %s override=%d extra=%d f_hi=%g focus=%g mode=%d image=%d chroma=%g" % (
+            case, W, H, M, lens, override, n_extra, f_hi, focus, lens_mode, image, chroma)
         p, model, table, keep = common.po_setup(W, H, lens=lens, aa=aa, filter_width=fw, samples_override=override,
-                                                focus_dist=focus)
+                                                focus_dist=focus, bokeh_enable_image=int(image), abb_chromatic=chroma)
         visits, cols = common.make_stream(p, W, H, M, f_hi=f_hi, n_extra=n_extra, seed=0xA000 + case)
-        ref = common.run_oracle(orc, p, table, visits, n_aovs=1 + n_extra)
+        ob = orc.orc_bokeh_from_tables(C.byref(bt)) if image else None
+        ref = common.run_oracle(orc, p, table, visits, n_aovs=1 + n_extra, bokeh=ob)
         rc = ref.counters()
         ctx = capi.Context(0)
         try:
             for again in range(2):
-                c = gpu_run(ctx, p, table, visits, n_aovs=1 + n_extra, lens_mode=lens_mode)
+                c = gpu_run(ctx, p, table, visits, n_aovs=1 + n_extra, lens_mode=lens_mode,
+                            bokeh_tables=tables if image else None)
                 assert (c.redistributed_visits, c.attempted_draws, c.accepted_draws) == (
                     rc.redistributed_visits, rc.attempted_draws, rc.accepted_draws), tag
                 if again and rc.redistributed_visits:
                     assert c.blind_chunks > 0, tag
                 check_logs(ctx, ref)
-                check_frame(ctx, ref, n_aovs=1 + n_extra)
+                # chromatic draws: three splats per attempt, see test_po_chromatic_aberration for the wider bound
+                check_frame(ctx, ref, n_aovs=1 + n_extra, tol=TOL if chroma == 0.0 else 4 * TOL)
         finally:
             ctx.close()
+            if ob:
+                orc.orc_bokeh_destroy(ob)
 
 
 def test_empty_stream_and_error_paths(gpu_ctx_factory):
