@@ -901,6 +901,60 @@ def test_randomized_configurations_two_passes_each(orc):
                 orc.orc_bokeh_destroy(ob)
 
 
+def test_randomized_thinlens_configurations(orc):
+    """The thin-lens draw under the same kind of seeded soak: frame size, visits per pixel, draw count, extra AOVs,
+    aperture blades, coma, optical vignetting, distortion, bokeh image; two passes per context."""
+    import os
+    n_cases = int(os.environ.get("LENTIL_SOAK_CASES", "8"))
+    rng = np.random.default_rng(int(os.environ.get("LENTIL_SOAK_SEED", "0x71E5"), 0))
+    tex = np.load(os.path.join(common.ROOT, "tests", "golden", "example_bokeh_kernel_u8.npy")).astype(np.float32) / np.float32(255)
+    tables = bokeh.build_tables(tex)
+    bt = _abi.BokehTable()
+    bt.x, bt.y = tables["x"], tables["y"]
+    for k in ("cdfRow", "rowIndices", "cdfColumn", "columnIndices"):
+        setattr(bt, k, tables[k].ctypes.data)
+    for case in range(n_cases):
+        W, H = int(rng.integers(17, 120)), int(rng.integers(9, 70))
+        aa, fw = [(2, 1.0), (3, 1.0), (4, 1.5)][int(rng.integers(0, 3))]
+        M = {2: 4, 3: 9, 4: 36}[aa]
+        override = int(rng.choice([0, 8, 17, 64]))
+        n_extra = int(rng.integers(0, 3))
+        f_hi = float(rng.choice([0.0005, 0.004, 0.02]))
+        kw = {}
+        if rng.integers(0, 2):
+            kw["bokeh_aperture_blades"] = int(rng.choice([5, 6, 8]))
+        if rng.integers(0, 2):
+            kw["abb_coma"] = float(rng.choice([0.35, 1.0]))
+        if rng.integers(0, 2):
+            kw["optical_vignetting_distance"] = 2.0
+            kw["optical_vignetting_radius"] = float(rng.choice([1.0, 1.5]))
+        if rng.integers(0, 2):
+            kw["abb_distortion"] = float(rng.choice([0.05, 0.15]))
+        image = int(rng.integers(0, 4)) == 0
+        if image:
+            kw["bokeh_enable_image"] = 1
+        tag = "case %d: %dx%d M=%d override=%d extra=%d f_hi=%g %r" % (case, W, H, M, override, n_extra, f_hi, kw)
+        p = common.tl_setup(W, H, aa=aa, filter_width=fw, samples_override=override, **kw)
+        visits, cols = common.make_stream(p, W, H, M, f_hi=f_hi, n_extra=n_extra, seed=0xB000 + case)
+        ob = orc.orc_bokeh_from_tables(C.byref(bt)) if image else None
+        ref = common.run_oracle(orc, p, None, visits, n_aovs=1 + n_extra, bokeh=ob)
+        rc = ref.counters()
+        ctx = capi.Context(0)
+        try:
+            for again in range(2):
+                c = gpu_run(ctx, p, None, visits, n_aovs=1 + n_extra, bokeh_tables=tables if image else None)
+                assert (c.redistributed_visits, c.attempted_draws, c.accepted_draws) == (
+                    rc.redistributed_visits, rc.attempted_draws, rc.accepted_draws), tag
+                check_logs(ctx, ref)
+                # draws of neighbouring highlights pile up on few pixels here (no lens to spread them): 3e-5, as in
+                # test_redistribute_decision_branches' thin-lens mode
+                check_frame(ctx, ref, n_aovs=1 + n_extra, tol=3 * TOL)
+        finally:
+            ctx.close()
+            if ob:
+                orc.orc_bokeh_destroy(ob)
+
+
 def test_empty_stream_and_error_paths(gpu_ctx_factory):
     p, model, table, keep = common.po_setup(32, 16)
     ctx = gpu_ctx_factory()
