@@ -203,8 +203,8 @@ def _free_port():
     return port
 
 
-def _two_rank_vs_single(orc, kinds, bands=False, world=2, bounds=None):
-    W, H, M, f_hi, samples = 48, 32, 9, 0.03, 24
+def _two_rank_vs_single(orc, kinds, bands=False, world=2, bounds=None, f_hi=0.03):
+    W, H, M, samples = 48, 32, 9, 24
     # single rank reference
     from pota_amd import distributed
     p, model, table, keep = common.po_setup(W, H, samples_override=samples)
@@ -263,6 +263,18 @@ def test_tiled_output_three_ranks_closest_aovs(orc):
 def test_tiled_output_unequal_bands(orc):
     """bands cut where distributed.rebalance() would put them: unequal heights, same frame"""
     _two_rank_vs_single(orc, [0, 1], bands=True, world=3, bounds=[0, 7, 21, 32])
+
+
+def test_tiled_output_four_ranks_thin_bands_few_highlights(orc):
+    """Two-row bands in the middle and a handful of highlights: draws cross several bands, some ranks touch only some
+    of the others and some pairs exchange nothing at all -- every rank still posts exactly the sends and receives its
+    peers expect (the forms travel in the all-gather), with a real backend underneath."""
+    _two_rank_vs_single(orc, [0, 1], bands=True, world=4, bounds=[0, 2, 4, 20, 32], f_hi=0.004)
+
+
+def test_tiled_output_without_highlights_exchanges_nothing(orc):
+    """no redistributed visit anywhere: every rank's exchange list is empty and the step must not wait for anybody"""
+    _two_rank_vs_single(orc, [0], bands=True, world=3, f_hi=0.0)
 
 
 def test_rebalance_equalises_the_modelled_cost():
