@@ -277,6 +277,182 @@ def test_tiled_output_without_highlights_exchanges_nothing(orc):
     _two_rank_vs_single(orc, [0], bands=True, world=3, f_hi=0.0)
 
 
+class SparseOracleEngine(OracleEngine):
+    """... with the pixel-list form of the exchange (HipEngine.compact_rows / sparse_buffers / merge_sparse): an entry
+    per pixel of the rows that holds anything, its index within those rows, its record and (closest AOVs) its key."""
+
+    def entry_floats(self):
+        return self.stride
+
+    def compact_rows(self, lo, hi):
+        p0, p1 = lo * self.p.xres, hi * self.p.xres
+        cap = max(16, (p1 - p0) // 4)
+        rec = self.rec[p0:p1]
+        hold = rec.abs().sum(dim=1) != 0
+        if self.zkey is not None:
+            hold |= self.zkey[p0:p1] != -1
+        sel = torch.nonzero(hold).flatten()
+        n = int(sel.numel())
+        idx = torch.zeros(cap, dtype=torch.int32)
+        vals = torch.zeros(cap * self.stride, dtype=torch.float32)
+        keys = torch.zeros(cap, dtype=torch.int64) if self.zkey is not None else None
+        if n <= cap:
+            idx[:n] = sel.to(torch.int32)
+            vals[:n * self.stride] = rec[sel].flatten()
+            if keys is not None:
+                keys[:n] = self.zkey[p0:p1][sel]
+        return n, cap, idx, vals, keys
+
+    def sparse_buffers(self, n):
+        return (torch.empty(n, dtype=torch.int32), torch.empty(n * self.stride, dtype=torch.float32),
+                torch.empty(n, dtype=torch.int64) if self.zkey is not None else None)
+
+    def merge_sparse(self, lo, hi, n, idx, vals, keys):
+        pix = lo * self.p.xres + idx[:n].to(torch.int64)
+        assert int(pix.max()) < hi * self.p.xres and pix.unique().numel() == n
+        src = vals[:n * self.stride].view(n, self.stride)
+        closer = None
+        if keys is not None:
+            mine = self.zkey[pix].numpy().view(np.uint64)
+            theirs = keys[:n].numpy().view(np.uint64)
+            closer = torch.from_numpy(theirs < mine)
+        for a in range(self.n_aovs):
+            cols_a = slice(4 * a, 4 * a + 4)
+            if self.kinds[a]:
+                upd = self.rec[pix, cols_a]
+                upd[closer] = src[:, cols_a][closer]
+                self.rec[pix, cols_a] = upd
+            else:
+                self.rec[pix, cols_a] += src[:, cols_a]
+        self.rec[pix, 4 * self.n_aovs] += src[:, 4 * self.n_aovs]
+        if keys is not None:
+            self.zkey[pix] = torch.from_numpy(np.minimum(mine, theirs).view(np.int64))
+
+
+class _ThreadDist:
+    """torch.distributed stand-in between engines that live in one process, one thread per rank: the calls
+    frame_step_bands makes, with the semantics of a real backend -- the all-gather is collective, sends and receives
+    pair up per (source, destination) in posting order and involve nobody else."""
+
+    class _Req:
+        def wait(self):
+            return None
+
+    class Shared:
+        def __init__(self, world):
+            import queue
+            import threading
+            self.world = world
+            self.barrier = threading.Barrier(world)
+            self.slots = [None] * world
+            self.mail = {(a, b): queue.Queue() for a in range(world) for b in range(world)}
+
+    isend, irecv = "isend", "irecv"
+
+    @staticmethod
+    def P2POp(op, tensor, peer):
+        return (op, tensor, peer)
+
+    def __init__(self, shared, rank):
+        self.sh, self.rank = shared, rank
+
+    def get_world_size(self):
+        return self.sh.world
+
+    def get_rank(self):
+        return self.rank
+
+    def all_gather(self, out, t):
+        self.sh.slots[self.rank] = t.clone()
+        self.sh.barrier.wait(timeout=60)
+        for k in range(self.sh.world):
+            out[k].copy_(self.sh.slots[k])
+        self.sh.barrier.wait(timeout=60)
+
+    def batch_isend_irecv(self, ops):
+        for op, t, peer in ops:
+            if op == "isend":
+                self.sh.mail[(self.rank, peer)].put(t.clone())
+        for op, t, peer in ops:
+            if op == "irecv":
+                t.copy_(self.sh.mail[(peer, self.rank)].get(timeout=60))
+        return [self._Req() for _ in ops]
+
+
+def test_tiled_step_seeded_soak(orc):
+    """Seeded soak of frame_step_bands: 2-5 ranks, even or random band boundaries down to two-row bands (draws cross
+    several bands; some ranks exchange with some of the others only, or with nobody), frame size, highlight
+    fraction, AOV kinds.  Every band against the same rows of a single-rank pass over the whole frame."""
+    import threading
+    from pota_amd import capi, distributed, workload
+    n_cases = int(os.environ.get("LENTIL_SOAK_CASES", "10"))
+    rng = np.random.default_rng(int(os.environ.get("LENTIL_SOAK_SEED", "0x7D1E"), 0))
+    M = 9
+    seen = {"lists": 0, "rows": 0, "nothing": 0}
+    for case in range(n_cases):
+        world = int(rng.integers(2, 6))
+        W, H = int(rng.integers(24, 64)), int(rng.integers(4 * world, 44))
+        cuts = sorted(rng.choice(np.arange(2, H - 1, 2), size=world - 1, replace=False).tolist())
+        bounds = [0] + [int(c) for c in cuts] + [H] if rng.integers(0, 2) else None
+        f_hi = float(rng.choice([0.0, 0.0015, 0.01, 0.03]))
+        kinds = [[0], [0, 0], [0, 1, 0]][int(rng.integers(0, 3))]
+        Engine = SparseOracleEngine if rng.integers(0, 3) else OracleEngine          # pixel lists where they fit / rows only
+        tag = "case %d: world %d %dx%d bounds %r f_hi %g kinds %r %s" % (case, world, W, H, bounds, f_hi, kinds, Engine.__name__)
+        p, model, table, keep = common.po_setup(W, H, samples_override=16)
+        visits, cols = common.make_stream(p, W, H, M, f_hi, n_extra=len(kinds) - 1)
+        whole = OracleEngine(orc, p, table, visits, cols, kinds)
+        distributed.frame_step(whole, None)
+        engines, keepalive, bands = [], [], []
+        for rank in range(world):
+            b_lo, b_hi = distributed.band_of(rank, world, H, p.yres, bounds)
+            c = workload.generate(np, b_lo * W * M, min(b_hi, H) * W * M, W, H, M, f_hi=f_hi, focus_dist=150.0,
+                                  tan_half_fov=common.tan_half_fov(p), n_extra=len(kinds) - 1)
+            v, kv = capi.make_visits(c, visits_per_pixel=M, pixels_per_row=W, pixel_y0=b_lo)
+            keepalive.append((c, v, kv))
+            engines.append(Engine(orc, p, table, v, c, kinds))
+            bands.append((b_lo, b_hi))
+        shared, errors = _ThreadDist.Shared(world), []
+
+        def run(rank):
+            try:
+                assert distributed.frame_step_bands(engines[rank], _ThreadDist(shared, rank), H, p.yres, bounds) == bands[rank]
+            except Exception as e:
+                errors.append((rank, e))
+                shared.barrier.abort()
+
+        th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join(timeout=120)
+        assert not errors, "%s: rank %d: %r" % (tag, errors[0][0], errors[0][1])
+        assert not any(t.is_alive() for t in th), tag
+        for rank in range(world):
+            for f in distributed.LAST_FORMS[rank]:
+                seen["lists" if f > 0 else ("rows" if f < 0 else "nothing")] += 1
+        for rank in range(world):
+            lo, hi = bands[rank][0] * p.xres, bands[rank][1] * p.xres
+            got, ref = engines[rank].rec[lo:hi].numpy(), whole.rec[lo:hi].numpy()
+            for a, kind in enumerate(kinds):
+                g, r = got[:, 4 * a:4 * a + 4], ref[:, 4 * a:4 * a + 4]
+                gi, ri = engines[rank].resolved[a][lo:hi], whole.resolved[a][lo:hi]
+                if kind:
+                    assert np.array_equal(g, r) and np.array_equal(gi, ri), "%s rank %d aov %d" % (tag, rank, a)
+                else:
+                    m = r != 0
+                    assert np.array_equal(g != 0, m), "%s rank %d aov %d" % (tag, rank, a)
+                    if m.any():
+                        assert float(np.max(np.abs(g[m] - r[m]) / np.abs(r[m]))) < 1e-5, "%s rank %d aov %d" % (tag, rank, a)
+                    mi = ri != 0
+                    if mi.any():
+                        assert float(np.max(np.abs(gi[mi] - ri[mi]) / np.abs(ri[mi]))) < 2e-5, "%s rank %d aov %d" % (tag, rank, a)
+            gw, rw = got[:, -1], ref[:, -1]
+            assert np.array_equal(gw != 0, rw != 0), tag
+            assert float(np.max(np.abs(gw - rw) / np.maximum(np.abs(rw), 1e-30))) < 1e-5, tag
+    if n_cases >= 10:
+        assert all(seen.values()), seen            # every form of the exchange came up
+
+
 def test_rebalance_equalises_the_modelled_cost():
     from pota_amd import distributed
     H, G = 6112, 8
