@@ -458,6 +458,84 @@ def test_tiled_output_on_one_gpu_matches_the_whole_frame(orc, gpu_ctx_factory, m
         assert any(f > 0 for f in forms) and not any(f < 0 for f in forms)     # pixel lists only
 
 
+@pytest.mark.skipif(__import__("os").environ.get("LENTIL_TILED_SOAK") != "1",
+                    reason="opt-in (LENTIL_TILED_SOAK=1): written at the end of round 1 after the GPU budget was spent, "
+                           "not yet run on a GPU; its CPU twin is test_multi_gpu.py::test_tiled_step_seeded_soak")
+def test_randomized_tiled_bands(orc, monkeypatch):
+    """Seeded soak of the tiled multi-GPU step on one device: number of ranks, band boundaries (down to bands of two
+    rows, so that draws cross several bands), frame size, highlight fraction, AOV kinds, pixel lists or packed rows.
+    Every band against the same rows of a whole-frame context, two passes.  Ranks are threads; the stand-in for
+    torch.distributed is the per-pair-queue one of the CPU suite (steps in which only some ranks exchange anything
+    stall _InProcessDist's barrier)."""
+    import os
+    import threading
+    from pota_amd import distributed, workload
+    from test_multi_gpu import _ThreadDist
+    n_cases = int(os.environ.get("LENTIL_SOAK_CASES", "5"))
+    rng = np.random.default_rng(int(os.environ.get("LENTIL_SOAK_SEED", "0x7D1E"), 0))
+    for case in range(n_cases):
+        world = int(rng.integers(2, 6))
+        W, H, M = int(rng.integers(24, 90)), int(rng.integers(4 * world, 60)), 9
+        cuts = sorted(rng.choice(np.arange(2, H - 1, 2), size=world - 1, replace=False).tolist())
+        bounds = [0] + [int(c) for c in cuts] + [H] if rng.integers(0, 2) else None
+        f_hi = float(rng.choice([0.0015, 0.01, 0.03]))
+        kinds = [[0], [0, 0], [0, 1, 0]][int(rng.integers(0, 3))]
+        sparse = bool(rng.integers(0, 2))
+        tag = "case %d: world %d %dx%d bounds %r f_hi %g kinds %r sparse %d" % (case, world, W, H, bounds, f_hi, kinds, sparse)
+        monkeypatch.setattr(distributed, "SPARSE_EXCHANGE", sparse)
+        n_aovs = len(kinds)
+        p, model, table, keep = common.po_setup(W, H, samples_override=int(rng.choice([16, 48])))
+        visits, cols = common.make_stream(p, W, H, M, f_hi=f_hi, n_extra=n_aovs - 1)
+        ctxs = []
+        try:
+            whole = capi.Context(0)
+            ctxs.append(whole)
+            gpu_run(whole, p, table, visits, n_aovs=n_aovs, kinds=kinds)
+            whole.P = p
+            engines, keepalive, bands = [], [], []
+            for rank in range(world):
+                b_lo, b_hi = distributed.band_of(rank, world, H, p.yres, bounds)
+                c = workload.generate(np, b_lo * W * M, min(b_hi, H) * W * M, W, H, M, f_hi=f_hi, focus_dist=150.0,
+                                      tan_half_fov=common.tan_half_fov(p), n_extra=n_aovs - 1)
+                v, kv = capi.make_visits(c, visits_per_pixel=M, pixels_per_row=W, pixel_y0=b_lo)
+                ctx = capi.Context(0)
+                ctxs.append(ctx)
+                ctx.set_params(p); ctx.set_lens(table); ctx.set_bokeh(None)
+                ctx.alloc_frame(n_aovs, kinds)
+                ctx.upload_visits(v)
+                keepalive.append((c, v, kv))
+                engines.append(distributed.HipEngine(ctx, rows=p.yres))
+                bands.append((b_lo, b_hi))
+            shared, errors = _ThreadDist.Shared(world), []
+
+            def run(rank):
+                try:
+                    import torch
+                    for _ in range(2):
+                        distributed.frame_step_bands(engines[rank], _ThreadDist(shared, rank), H, p.yres, bounds)
+                        engines[rank].ctx.sync()
+                        torch.cuda.synchronize()
+                except Exception as e:
+                    errors.append((rank, e))
+                    shared.barrier.abort()
+
+            th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+            for t in th:
+                t.start()
+            for t in th:
+                t.join(timeout=120)
+            assert not errors, "%s: rank %d: %r" % (tag, errors[0][0], errors[0][1])
+            assert not any(t.is_alive() for t in th), tag
+            for rank in range(world):
+                try:
+                    _compare_with_whole(engines[rank].ctx, whole, kinds, rows=bands[rank])
+                except AssertionError as e:
+                    raise AssertionError("%s, rank %d: %s" % (tag, rank, e))
+        finally:
+            for c in ctxs:
+                c.close()
+
+
 def _tiled_rank_process(rank, world, port, W, H, M, f_hi, kinds, bounds, sparse, q):
     """One rank of test_tiled_output_two_processes: a process of its own, torch.distributed (gloo) between the ranks,
     all of them on GPU 0."""
