@@ -215,6 +215,7 @@ typedef struct lentil_counters {
   uint64_t slow_solves;          /* solves finished by the one-wave-per-solve straggler kernel (LENTIL_SLOW_AT) */
   uint64_t blind_chunks;         /* chunks whose draw rounds were enqueued without waiting for their scan (sized from the previous pass) */
   uint64_t fallback_chunks;      /* ... of which did not fit and were redone with exact sizes */
+  uint64_t streamed;             /* 1: the pass ran streamed (one scan launch feeding persistent solve waves; counts as one blind chunk) */
 } lentil_counters;
 
 /* one accepted draw, for index-parity tests: (visit, attempt n, linear pixel) */

@@ -83,7 +83,7 @@ class Counters(C.Structure):
                 ("attempted_draws", C.c_uint64), ("accepted_draws", C.c_uint64),
                 ("worklist_overflow", C.c_uint64), ("newton_iterations", C.c_uint64),
                 ("tries", C.c_uint64), ("lane_rounds", C.c_uint64), ("slow_solves", C.c_uint64),
-                ("blind_chunks", C.c_uint64), ("fallback_chunks", C.c_uint64)]
+                ("blind_chunks", C.c_uint64), ("fallback_chunks", C.c_uint64), ("streamed", C.c_uint64)]
 
 
 class DrawRecord(C.Structure):

@@ -594,6 +594,30 @@ LD_DEV bool visit_redistributes(const lentil_params &P, double lens_length, floa
   return redistribute;
 }
 
+// camera-space position of a visit (the part of visit_prologue below that the item header needs; same arithmetic)
+template <class RaydirLoad>
+LD_DEV void visit_camera_space(const lentil_params &P, float4 pos_z, RaydirLoad load_raydir, float cs[3]) {
+  float wx = pos_z.x, wy = pos_z.y, wz = pos_z.z;
+  const float depth = pos_z.w;
+  const bool small = fabsf(wx) < kAiEpsilon && fabsf(wy) < kAiEpsilon && fabsf(wz) < kAiEpsilon;
+  const bool far = ((double)depth == (double)kAiInfinite) || small;
+  if (far && P.enable_skydome) {
+    const float4 raydir_time = load_raydir();
+    if (!(raydir_time.x == 0.0f && raydir_time.y == 0.0f && raydir_time.z == 0.0f)) {
+      wx = raydir_time.x * 100000000.0f; wy = raydir_time.y * 100000000.0f; wz = raydir_time.z * 100000000.0f;
+    }
+  }
+  const float(*m)[4] = P.world_to_camera;
+  float cx = wx * m[0][0] + wy * m[1][0] + wz * m[2][0] + m[3][0];
+  float cy = wx * m[0][1] + wy * m[1][1] + wz * m[2][1] + m[3][1];
+  float cz = wx * m[0][2] + wy * m[1][2] + wz * m[2][2] + m[3][2];
+  float scale = 1.0f;
+  if (P.unitModel == LENTIL_UNIT_MM) scale = 0.1f;
+  else if (P.unitModel == LENTIL_UNIT_DM) scale = 10.0f;
+  else if (P.unitModel == LENTIL_UNIT_M) scale = 100.0f;
+  cs[0] = cx * scale; cs[1] = cy * scale; cs[2] = cz * scale;
+}
+
 LD_DEV VisitInfo visit_prologue(const lentil_params &P, double lens_length, float4 rgba, float4 pos_z,
                                 float4 raydir_time, float4 volume_ignore, float4 transmission,
                                 float inv_density) {

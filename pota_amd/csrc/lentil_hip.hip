@@ -88,6 +88,18 @@ struct lentil_hip_ctx {
   int solve_cap_blocks = 1;                  // LENTIL_EARLY_CAP_BLOCKS: solve blocks per CU while later chunks are scanned
   int accept_max_blocks = 4;                 // LENTIL_ACCEPT_BLOCKS: accept blocks per CU at most
   int solve_max_blocks = 4;                  // LENTIL_SOLVE_BLOCKS: solve blocks per CU at most
+  // Streamed pass (polynomial optics, from the second pass of a context on): one scan launch that publishes its items
+  // and their first-batch tasks itself, persistent solve waves that follow the task queue while the scan runs.
+  bool stream_mode = true;                   // LENTIL_STREAM=0: chunked passes only
+  int stream_blocks = 1;                     // LENTIL_STREAM_BLOCKS: solve blocks per CU beside the scan
+  uint32_t epoch = 0;                        // tag of the current pass's task slots
+  uint64_t *d_ranges = nullptr;              // range queue scan -> publish_kernel
+  uint64_t range_cap = 0;
+  int publish_waves = 64;                    // LENTIL_PUBLISH_WAVES
+  bool have_total_est = false;               // what the last pass found in the whole stream
+  uint64_t est_items_total = 0, est_sum_total = 0;
+  int est_rounds_total = 3;
+  uint32_t last_streamed = 0;
   int last_rounds = 0;
   uint32_t last_blind = 0, last_fallback = 0;
   uint32_t last_scan_launches = 0;
@@ -95,6 +107,8 @@ struct lentil_hip_ctx {
   int32_t dirty_lo = 0, dirty_hi = 0;
   bool dirty_known = false;
   hipEvent_t scans_done = nullptr;   // after the last chunk's scan of a pass
+  hipStream_t pub_stream = nullptr;  // streamed pass: publish_kernel
+  hipEvent_t pub_done = nullptr;
   bool pass_pending = false;         // a redistribute ran whose rows have not been asked for yet
   bool closest_deferred = false;     // multi-GPU: the caller min-reduces the keys before the gather
   uint32_t visit_id_base = 0;
@@ -164,6 +178,8 @@ LENTIL_API int lentil_hip_create(int device, lentil_hip_ctx **out_ctx) {
     HIP_TRY(ctx, hipEventCreateWithFlags(&ch.done, hipEventDisableTiming));
   }
   HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->scans_done, hipEventDisableTiming));
+  HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->pub_stream, hipStreamNonBlocking));
+  HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->pub_done, hipEventDisableTiming));
   if (const char *ft = getenv("LENTIL_FORCE_TABLES")) ctx->use_generated = !(ft[0] == '1');
   if (const char *fc = getenv("LENTIL_FIRST_CHUNK_FRAC")) {
     const double f = atof(fc);
@@ -188,6 +204,11 @@ LENTIL_API int lentil_hip_create(int device, lentil_hip_ctx **out_ctx) {
   if (ctx->accept_max_blocks < 1) ctx->accept_max_blocks = 1;
   if (const char *e = getenv("LENTIL_SOLVE_BLOCKS")) ctx->solve_max_blocks = atoi(e);
   if (ctx->solve_max_blocks < 1) ctx->solve_max_blocks = 1;
+  if (const char *e = getenv("LENTIL_STREAM")) ctx->stream_mode = !(e[0] == '0');
+  if (const char *e = getenv("LENTIL_STREAM_BLOCKS")) ctx->stream_blocks = atoi(e);
+  if (ctx->stream_blocks < 1) ctx->stream_blocks = 1;
+  if (const char *e = getenv("LENTIL_PUBLISH_WAVES")) ctx->publish_waves = atoi(e);
+  if (ctx->publish_waves < 1) ctx->publish_waves = 1;
   *out_ctx = ctx;
   return LENTIL_OK;
 }
@@ -231,8 +252,11 @@ LENTIL_API int lentil_hip_destroy(lentil_hip_ctx *ctx) {
     if (ch.stream) (void)hipStreamDestroy(ch.stream);
   }
   if (ctx->scans_done) (void)hipEventDestroy(ctx->scans_done);
+  if (ctx->pub_stream) { (void)hipStreamSynchronize(ctx->pub_stream); (void)hipStreamDestroy(ctx->pub_stream); }
+  if (ctx->pub_done) (void)hipEventDestroy(ctx->pub_done);
   (void)hipFree(ctx->d_ctr);
   if (ctx->h_ctr_pinned) (void)hipHostFree(ctx->h_ctr_pinned);
+  (void)hipFree(ctx->d_ranges);
   (void)hipFree(ctx->d_log);
   for (auto &ev : ctx->ev) if (ev) (void)hipEventDestroy(ev);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -579,36 +603,36 @@ static int grow(lentil_hip_ctx *ctx, T **p, uint64_t need) {
   return LENTIL_OK;
 }
 
-static void launch_solve(lentil_hip_ctx *ctx, const DrawArgs &da, hipStream_t st, unsigned blocks) {
-  if (da.P.cameraType == LENTIL_POLYNOMIAL_OPTICS && da.n_channels == 3) {
-    // chromatic aberration: three wavelength channels per attempt
-    bool launched = false;
+template <bool kStream>
+static void launch_solve_po(lentil_hip_ctx *ctx, const DrawArgs &da, hipStream_t st, unsigned blocks) {
+  const bool chroma = da.n_channels == 3;       // chromatic aberration: three wavelength channels per attempt
+  bool launched = false;
 #define LENTIL_LAUNCH_GEN(NAME)                                                                          \
-    if (!launched && ctx->use_generated && ctx->lens_hash == gen::Lens_##NAME::kTableHash) {              \
-      hipLaunchKernelGGL((solve_po_kernel<GenLens<gen::Lens_##NAME>, false, true>), dim3(blocks), dim3(256), 0, st, da); \
-      launched = true;                                                                                   \
-    }
-    LENTIL_GENERATED_LENSES(LENTIL_LAUNCH_GEN)
-#undef LENTIL_LAUNCH_GEN
-    if (!launched) hipLaunchKernelGGL((solve_po_kernel<LdsLens, true, true>), dim3(blocks), dim3(256), 0, st, da);
-  } else if (da.P.cameraType == LENTIL_POLYNOMIAL_OPTICS) {
-    bool launched = false;
-#define LENTIL_LAUNCH_GEN(NAME)                                                                          \
-    if (!launched && ctx->use_generated && ctx->lens_hash == gen::Lens_##NAME::kTableHash) {              \
-      hipLaunchKernelGGL((solve_po_kernel<GenLens<gen::Lens_##NAME>, false>), dim3(blocks), dim3(256), 0, st, da); \
-      launched = true;                                                                                   \
-    }
-    LENTIL_GENERATED_LENSES(LENTIL_LAUNCH_GEN)
-#undef LENTIL_LAUNCH_GEN
-    if (!launched) hipLaunchKernelGGL((solve_po_kernel<LdsLens, true>), dim3(blocks), dim3(256), 0, st, da);
-  } else {
-    hipLaunchKernelGGL(solve_thinlens_kernel, dim3(blocks), dim3(256), 0, st, da);
+  if (!launched && ctx->use_generated && ctx->lens_hash == gen::Lens_##NAME::kTableHash) {                \
+    if (chroma) hipLaunchKernelGGL((solve_po_kernel<GenLens<gen::Lens_##NAME>, false, true, kStream>), dim3(blocks), dim3(256), 0, st, da); \
+    else hipLaunchKernelGGL((solve_po_kernel<GenLens<gen::Lens_##NAME>, false, false, kStream>), dim3(blocks), dim3(256), 0, st, da); \
+    launched = true;                                                                                     \
   }
-  // stragglers parked by the solve kernel: one wave each (blind launch; an empty queue costs a few microseconds)
-  // (not in rounds that do not park: its 41 KB blocks would queue behind another chunk's chip-filling solve kernel
-  // just to find nothing to do, and hold up this chunk's accept meanwhile)
+  LENTIL_GENERATED_LENSES(LENTIL_LAUNCH_GEN)
+#undef LENTIL_LAUNCH_GEN
+  if (!launched) {
+    if (chroma) hipLaunchKernelGGL((solve_po_kernel<LdsLens, true, true, kStream>), dim3(blocks), dim3(256), 0, st, da);
+    else hipLaunchKernelGGL((solve_po_kernel<LdsLens, true, false, kStream>), dim3(blocks), dim3(256), 0, st, da);
+  }
+}
+
+// stragglers parked by the solve kernel: one wave each (blind launch; an empty queue costs a few microseconds)
+// (not in rounds that do not park: its 41 KB blocks would queue behind another chunk's chip-filling solve kernel
+// just to find nothing to do, and hold up this chunk's accept meanwhile)
+static void launch_slow(lentil_hip_ctx *ctx, const DrawArgs &da, hipStream_t st) {
   if (da.P.cameraType == LENTIL_POLYNOMIAL_OPTICS && da.slow && da.round >= da.slow_from_round)
     hipLaunchKernelGGL(solve_slow_kernel, dim3((unsigned)ctx->num_cu * 4), dim3(64), 0, st, da);
+}
+
+static void launch_solve(lentil_hip_ctx *ctx, const DrawArgs &da, hipStream_t st, unsigned blocks) {
+  if (da.P.cameraType == LENTIL_POLYNOMIAL_OPTICS) launch_solve_po<false>(ctx, da, st, blocks);
+  else hipLaunchKernelGGL(solve_thinlens_kernel, dim3(blocks), dim3(256), 0, st, da);
+  launch_slow(ctx, da, st);
 }
 
 // Size one chunk's draw-pipeline buffers from its scan result and enqueue prep + `blind_rounds`
@@ -631,6 +655,8 @@ static int size_chunk_buffers(lentil_hip_ctx *ctx, lentil_hip_ctx::Chunk &ch, ui
     if ((rc = grow(ctx, &ch.tasks[0], nc))) return rc;
     if ((rc = grow(ctx, &ch.tasks[1], nc))) return rc;
     ch.task_cap = nc;
+    // a streamed pass tells a filled slot by its tag: no stale bits
+    HIP_TRY(ctx, hipMemsetAsync(ch.tasks[0], 0, nc * sizeof(Task), ctx->stream));
   }
   if (units > ch.pool_cap) {
     const uint64_t nc = units + units / 4;
@@ -728,7 +754,7 @@ static int launch_chunk_rounds(lentil_hip_ctx *ctx, int ci, DrawArgs &da, uint64
     }
     // Splats go anywhere in the frame, also into rows a later chunk's scan is still read-modify-writing with
     // plain stores: solves may overlap the remaining scans, the first accept may not.
-    if (round == 0) HIP_TRY(ctx, hipStreamWaitEvent(ch.stream, ctx->scans_done, 0));
+    if (round == 0 && !getenv("LENTIL_XP_EARLY_ACCEPT")) HIP_TRY(ctx, hipStreamWaitEvent(ch.stream, ctx->scans_done, 0));
     // A heavy chunk's first accept is released by the same event as the next heavy chunk's first solve.  With its
     // full grid it reaches the CUs first and the solve kernel's blocks are placed around it -- the slow start that
     // costs that kernel 10 % for its whole life (see above).  A quarter block per CU trickles along beside the solve
@@ -851,6 +877,311 @@ static int enqueue_chunk_draws(lentil_hip_ctx *ctx, int ci, DrawArgs &da, int bl
   return LENTIL_OK;
 }
 
+static void init_draw_args(lentil_hip_ctx *ctx, DrawArgs &da) {
+  const lentil_params &P = ctx->P;
+  const int C = ctx->n_chunks;
+  da.P = P;
+  // wavelength channels of the polynomial-optics draw loop, src/lentil_filter.cpp:254-268 (float arithmetic of
+  // linear_interpolate, src/global.h:3-5); abb_chromatic < 0 runs three white channels at 0.55, like upstream
+  da.n_channels = (P.cameraType == LENTIL_POLYNOMIAL_OPTICS && P.abb_chromatic != 0.0f) ? 3 : 1;
+  da.chroma_weights = P.abb_chromatic > 0.0f ? 1 : 0;
+  da.lambda[0] = da.lambda[1] = da.lambda[2] = (double)P.lambda_bw;
+  if (da.n_channels == 3 && da.chroma_weights) {
+    const float c = P.abb_chromatic;
+    const float p0 = (float)(1.0 - (double)c);
+    da.lambda[0] = (double)(0.35f + p0 * (0.55f - 0.35f));
+    da.lambda[1] = (double)0.55f;
+    da.lambda[2] = (double)(0.55f + c * (0.85f - 0.55f));
+  }
+  da.lens = P.cameraType == LENTIL_POLYNOMIAL_OPTICS ? ctx->d_lens : nullptr;
+  da.terms = ctx->d_terms;
+  da.bokeh = ctx->bokeh;
+  da.V = ctx->V;
+  da.F = ctx->F;
+  // a straggler is a solve well beyond what this lens usually takes: 1.3 x the mean iteration count of the previous
+  // pass where that is above LENTIL_SLOW_AT (petzval table: ~25 iterations on average, 20 would park thousands)
+  da.slow_at = ctx->slow_at;
+  if (ctx->slow_at > 0 && ctx->mean_iters > 0.0) {
+    const int adaptive = (int)(1.3 * ctx->mean_iters + 0.5);
+    if (adaptive > da.slow_at) da.slow_at = adaptive < 90 ? adaptive : 90;
+  }
+  da.slow_below = ctx->slow_below;
+  da.slow_from_round = ctx->slow_from_round;
+  da.slow_max_lanes = ctx->slow_max_lanes;
+  da.extra_num = ctx->extra_num; da.extra_const = ctx->extra_const; da.extra_below = ctx->extra_below;
+  da.log = ctx->d_log;
+  da.log_cap = ctx->log_cap;
+  da.log_count = &ctx->d_ctr[C].log_count;
+}
+
+// How the bound visit stream is scanned: kernel, tile size, LDS.
+struct ScanPlan {
+  ScanArgs sa{};
+  size_t lds = 0;
+  uint64_t n_tiles = 0;
+  bool multi = false;
+  uint32_t M = 0;
+};
+
+static int plan_scan(lentil_hip_ctx *ctx, ScanPlan &pl) {
+  ScanArgs &sa = pl.sa;
+  sa.P = ctx->P;
+  sa.lens_length = ctx->have_lens ? ctx->hlens.length : 0.0;
+  sa.V = ctx->V;
+  sa.F = ctx->F;
+  const uint32_t M = ctx->V.visits_per_pixel;
+  pl.M = M;
+  if (M) {
+    // staging: 20 B per visit per wave, 4 waves per block, keep a block under ~48 KiB
+    uint32_t ppt = 64;
+    // extra AOV columns are streamed one at a time: more, smaller tiles keep enough loads in flight
+    // (beauty only: 64-pixel tiles, three blocks per CU.  32-pixel tiles / four blocks per CU are 3 % faster for a
+    // scan that has the chip to itself -- 0.946 against 0.972 ms -- and 20 % slower beside the first chunk's solve
+    // kernel, which then does not get its wave per SIMD until scan blocks retire)
+    uint64_t lds_budget = (ctx->V.n_extra ? 24ull : 48ull) * 1024ull;
+    if (const char *e = getenv("LENTIL_SCAN_LDS_KB")) lds_budget = strtoull(e, nullptr, 10) * 1024ull;
+    while (ppt > 1 && (uint64_t)ppt * M * 20ull * 4ull > lds_budget) ppt >>= 1;
+    if ((uint64_t)ppt * M * 20ull * 4ull > 150ull * 1024ull)
+      return fail(ctx, LENTIL_ERR_UNSUPPORTED, "visits_per_pixel too large for the LDS staging area");
+    sa.ppt = ppt;
+    sa.tv_pad = ppt * M;
+    pl.lds = (size_t)sa.tv_pad * 20 * 4 + 4 * kWaveQueueLds * sizeof(uint2);
+    // frames with extra AOVs: all columns of a visit in flight at once, one step = 64 / M whole pixels
+    pl.multi = ctx->V.n_extra > 0 && M <= 64 && !getenv("LENTIL_SCAN_SINGLE_COLUMN");
+    if (pl.multi) {
+      ppt = 64 / M;
+      sa.ppt = ppt;
+      sa.tv_pad = ppt * M;
+      const size_t wave_f4 = (size_t)ctx->F.n_aovs * kMultiPlane + 16 + (size_t)ppt * (ctx->F.stride / 4);
+      pl.lds = 4 * wave_f4 * 16 + 4 * kWaveQueueLds * sizeof(uint2);
+    }
+    const uint64_t n_pixels = (ctx->V.n + M - 1) / M;
+    pl.n_tiles = (n_pixels + ppt - 1) / ppt;
+  }
+  return LENTIL_OK;
+}
+
+// one scan launch over a chunk's range of the stream (ch.tile_begin/_end, ch.v_begin/_end) on the main stream
+static int launch_scan(lentil_hip_ctx *ctx, const ScanPlan &pl, const lentil_hip_ctx::Chunk &ch, DevCounters *ctr,
+                       unsigned *blocks_out) {
+  ScanArgs sa = pl.sa;
+  sa.work = ctx->d_work + ch.v_begin;
+  sa.work_cap = ch.v_end - ch.v_begin;
+  sa.ctr = ctr;
+  sa.tile_begin = ch.tile_begin; sa.tile_end = ch.tile_end;
+  sa.v_begin = ch.v_begin; sa.v_end = ch.v_end;
+  const uint64_t max_blocks = (uint64_t)ctx->num_cu * 8;
+  uint64_t blocks;
+  if (pl.M) {
+    blocks = (ch.tile_end - ch.tile_begin + 3) / 4;
+    if (blocks > max_blocks) blocks = max_blocks;
+    if (pl.multi) hipLaunchKernelGGL(scan_uniform_multi_kernel, dim3((unsigned)blocks), dim3(256), pl.lds, ctx->stream, sa);
+    else hipLaunchKernelGGL(scan_uniform_kernel, dim3((unsigned)blocks), dim3(256), pl.lds, ctx->stream, sa);
+  } else {
+    blocks = (ch.v_end - ch.v_begin + 255) / 256;
+    if (blocks > max_blocks) blocks = max_blocks;
+    hipLaunchKernelGGL(scan_ragged_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, sa);
+  }
+  HIP_TRY(ctx, hipGetLastError());
+  if (blocks_out) *blocks_out = (unsigned)blocks;
+  return LENTIL_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// Streamed pass.  The chunked pass above cannot start a chunk's solves before the chunk's scan has ended, and
+// every chunk's first solve kernel brings its own ramp-down; solve kernels of several chunks resident at once take
+// the register file from the scan.  Here the whole stream is ONE scan launch that publishes items and first-batch
+// tasks as it finds them (publish_item), and the first round is one task queue followed by persistent solve waves:
+//   stream A (chunk 0's): solve_po_kernel<.., kStream>, `stream_blocks` blocks per CU, resident beside the scan
+//                         from the start of the pass
+//   main stream:          scan, then a second launch of the same kernel on the CUs' remaining room, then -- once
+//                         both have run dry -- the parked stragglers, the first accept and the later rounds
+//                         (ordinary queues written by the accept kernel).
+// Nothing on the device waits for a kernel that has not been submitted before it: under a profiler that runs
+// kernels one at a time, A starts after the scan and finds the queue complete.
+// Buffers are sized from the previous pass (twice what it found); an item that does not fit raises
+// DevCounters::fallback, the accept kernel then does nothing and the host redoes the draws with exact sizes.
+// ---------------------------------------------------------------------------------------
+static int redistribute_streamed(lentil_hip_ctx *ctx, bool *streamed) {
+  *streamed = false;
+  const lentil_params &P = ctx->P;
+  if (!ctx->stream_mode || P.cameraType != LENTIL_POLYNOMIAL_OPTICS || !ctx->have_total_est || ctx->V.n == 0)
+    return LENTIL_OK;
+  if (ctx->V.n > 0xFFFFFFF0ull) return LENTIL_OK;
+  lentil_hip_ctx::Chunk &ch = ctx->chunks[0];
+  DrawArgs da{};
+  init_draw_args(ctx, da);
+  const uint64_t nch = (uint64_t)da.n_channels;
+  uint64_t items = 2 * ctx->est_items_total + 4096;
+  if (items > ctx->V.n) items = ctx->V.n;
+  const uint64_t sum = 2 * ctx->est_sum_total + (1ull << 20);
+  const uint64_t units = chunk_units(P, nch, sum, items);
+  if (units > ctx->max_pool_units) return LENTIL_OK;       // sub-batches: the chunked pass knows how
+  int rc;
+  if ((rc = size_chunk_buffers(ctx, ch, items, units))) return rc;
+  bind_chunk_buffers(ch, da);
+  ScanPlan plan;
+  if ((rc = plan_scan(ctx, plan))) return rc;
+  ch.tile_begin = 0; ch.tile_end = plan.n_tiles;
+  ch.v_begin = 0; ch.v_end = ctx->V.n;
+  for (int ci = 1; ci < ctx->n_chunks; ++ci) {
+    lentil_hip_ctx::Chunk &o = ctx->chunks[ci];
+    o.tile_begin = o.tile_end = plan.n_tiles; o.v_begin = o.v_end = ctx->V.n; o.n_items = 0;
+  }
+  ctx->epoch = (ctx->epoch + 1u) & 0x3FFFFFu;
+  if (ctx->epoch == 0u) {
+    // the 22-bit tag has come round: wipe what older passes left in the queues
+    ctx->epoch = 1u;
+    HIP_TRY(ctx, hipMemsetAsync(ch.tasks[0], 0, ch.task_cap * sizeof(Task), ctx->stream));
+    if (ctx->d_ranges) HIP_TRY(ctx, hipMemsetAsync(ctx->d_ranges, 0, ctx->range_cap * sizeof(uint64_t), ctx->stream));
+  }
+  const uint32_t retries = (uint32_t)(P.vignetting_retries < 0 ? 0 : P.vignetting_retries);
+  const bool few = ctx->est_sum_total < ctx->slow_below;
+
+  PublishArgs pa{};
+  pa.P = P;
+  pa.V = ctx->V;
+  StreamPub &pub = pa.S;
+  pub.epoch = ctx->epoch;
+  pub.n_channels = (uint32_t)nch;
+  pub.retries = (int32_t)retries;
+  pub.extra_num = ctx->est_sum_total < ctx->extra_below ? ctx->extra_num : 0u;
+  pub.extra_const = ctx->est_sum_total < ctx->extra_below ? ctx->extra_const : 0u;
+  pub.item_cap = (uint32_t)(ch.item_cap < 0xFFFFFFF0ull ? ch.item_cap : 0xFFFFFFF0ull);
+  pub.task_cap = da.task_cap;
+  pub.pool_cap = da.pool_cap;
+  pub.hdr = ch.hdr; pub.prog = ch.prog; pub.active0 = ch.active[0]; pub.tasks0 = ch.tasks[0];
+  // range queue: one record per flush of a wave queue (at most one per 64 visits, plus one per wave and tile)
+  {
+    const uint64_t need = ctx->V.n / 64 + 2 * plan.n_tiles + 65536;
+    if (need > ctx->range_cap) {
+      if ((rc = grow(ctx, &ctx->d_ranges, need))) return rc;
+      ctx->range_cap = need;
+      HIP_TRY(ctx, hipMemsetAsync(ctx->d_ranges, 0, need * sizeof(uint64_t), ctx->stream));
+    }
+  }
+  plan.sa.ranges = ctx->d_ranges;
+  plan.sa.range_cap = (uint32_t)(ctx->range_cap < 0xFFFFFFF0ull ? ctx->range_cap : 0xFFFFFFF0ull);
+  plan.sa.epoch = ctx->epoch;
+  plan.sa.flush_each_tile = ctx->est_items_total < (1u << 16) ? 1u : 0u;
+  pa.ctr = ctx->d_ctr;
+  pa.work = ctx->d_work;
+  pa.work_cap = ctx->V.n;
+  pa.ranges = ctx->d_ranges;
+  pa.range_cap = plan.sa.range_cap;
+
+  da.ctr = ctx->d_ctr;
+  da.retries = (int32_t)retries;
+  da.work = ctx->d_work;
+  da.work_cap = ctx->V.n;
+  da.blind = 0u;
+  da.n_items = pub.item_cap;
+  da.parity = 0; da.round = 0;
+  da.epoch = ctx->epoch;
+  if (!few) da.slow = nullptr;              // parking is for passes with few draws (DrawArgs::slow_below)
+
+  // scan grid first: the solve waves need to know how many blocks will sign off
+  unsigned scan_blocks;
+  {
+    const uint64_t max_blocks = (uint64_t)ctx->num_cu * 8;
+    uint64_t b = plan.M ? (plan.n_tiles + 3) / 4 : (ctx->V.n + 255) / 256;
+    if (b > max_blocks) b = max_blocks;
+    scan_blocks = (unsigned)b;
+  }
+  pa.scan_blocks_total = scan_blocks;
+  da.publishers_total = (uint32_t)ctx->publish_waves;
+
+  unsigned launched_blocks = 0;
+  if ((rc = launch_scan(ctx, plan, ch, ctx->d_ctr, &launched_blocks))) return rc;
+  if (launched_blocks != scan_blocks) return fail(ctx, LENTIL_ERR_HIP, "streamed pass: scan grid mismatch");
+  ctx->last_scan_launches = 1;
+  HIP_TRY(ctx, hipEventRecord(ch.scanned, ctx->stream));
+  HIP_TRY(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
+  HIP_TRY(ctx, hipEventRecord(ctx->scans_done, ctx->stream));
+
+  // The publishers and A, resident beside the scan (the counters they poll were cleared by the memset ahead of
+  // ev[0]).  Submitted AFTER what they wait for -- the scan, then the publishers: should the streams share a
+  // hardware queue, each finds its producer ahead of it there.
+  const unsigned a_blocks = (unsigned)ctx->num_cu * (unsigned)ctx->stream_blocks;
+  HIP_TRY(ctx, hipStreamWaitEvent(ctx->pub_stream, ctx->ev[0], 0));
+  hipLaunchKernelGGL(publish_kernel, dim3((unsigned)ctx->publish_waves), dim3(64), 0, ctx->pub_stream, pa);
+  HIP_TRY(ctx, hipGetLastError());
+  HIP_TRY(ctx, hipEventRecord(ctx->pub_done, ctx->pub_stream));
+  HIP_TRY(ctx, hipStreamWaitEvent(ch.stream, ctx->ev[0], 0));
+  launch_solve_po<true>(ctx, da, ch.stream, a_blocks);
+  HIP_TRY(ctx, hipGetLastError());
+  HIP_TRY(ctx, hipEventRecord(ch.done, ch.stream));
+
+  // B: the rest of the CUs' room, once the scan's waves have left
+  int b_per_cu = ctx->solve_max_blocks - ctx->stream_blocks;
+  if (b_per_cu < 1) b_per_cu = 1;
+  {
+    const uint64_t want = (nch * (ctx->est_sum_total / 64 + ctx->est_items_total) + 3) / 4;
+    uint64_t b = (uint64_t)ctx->num_cu * (uint64_t)b_per_cu;
+    if (want < b) b = want < 1 ? 1 : want;
+    launch_solve_po<true>(ctx, da, ctx->stream, (unsigned)b);
+    HIP_TRY(ctx, hipGetLastError());
+  }
+  HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ch.done, 0));
+  HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->pub_done, 0));
+  launch_slow(ctx, da, ctx->stream);
+  const uint64_t acc_max = (uint64_t)ctx->num_cu * (uint64_t)ctx->accept_max_blocks;
+  const uint64_t acc_want = ctx->est_items_total + ctx->est_items_total / 4 + 1;
+  const unsigned accept_blocks = (unsigned)(acc_want > acc_max ? acc_max : acc_want);
+  hipLaunchKernelGGL(accept_kernel, dim3(accept_blocks), dim3(256), 0, ctx->stream, da);
+  HIP_TRY(ctx, hipGetLastError());
+  int blind_rounds = ctx->est_rounds_total < 2 ? 2 : (ctx->est_rounds_total > 6 ? 6 : ctx->est_rounds_total);
+  if (const char *e = getenv("LENTIL_BLIND_ROUNDS")) { blind_rounds = atoi(e); if (blind_rounds < 1) blind_rounds = 1; if (blind_rounds > 8) blind_rounds = 8; }
+  for (int round = 1; round < blind_rounds; ++round) {
+    da.parity = round & 1; da.round = round;
+    launch_solve(ctx, da, ctx->stream, (unsigned)ctx->num_cu);
+    hipLaunchKernelGGL(accept_kernel, dim3(accept_blocks), dim3(256), 0, ctx->stream, da);
+    HIP_TRY(ctx, hipGetLastError());
+  }
+  const int C = ctx->n_chunks;
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->h_ctr_pinned, ctx->d_ctr, sizeof(DevCounters) * C, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->h_ctr.assign(ctx->h_ctr_pinned, ctx->h_ctr_pinned + C);
+  ctx->h_ctr_valid = true;
+  ctx->last_streamed = 1;
+  const DevCounters c = ctx->h_ctr[0];
+  ch.was_blind = true;
+  if (c.stuck) return fail(ctx, LENTIL_ERR_HIP, "streamed pass: a wave gave up waiting for its queue slot (LENTIL_STREAM=0 selects the chunked pass)");
+  if (c.fallback) {
+    // did not fit: nothing was accepted.  Fresh queues, then the draws again the plain way, sized from the counters
+    ctx->h_ctr_valid = false;
+    ++ctx->last_fallback;
+    HIP_TRY(ctx, hipMemsetAsync((char *)ctx->d_ctr + offsetof(DevCounters, n_tasks), 0,
+                                offsetof(DevCounters, inv_row_min) - offsetof(DevCounters, n_tasks), ch.stream));
+    HIP_TRY(ctx, hipMemsetAsync((char *)ctx->d_ctr + offsetof(DevCounters, fallback), 0, sizeof(unsigned long long), ch.stream));
+    DrawArgs db{};
+    init_draw_args(ctx, db);
+    if ((rc = enqueue_chunk_draws(ctx, 0, db, 3))) return rc;
+    HIP_TRY(ctx, hipStreamSynchronize(ch.stream));
+    int rounds = 3;
+    if (ch.n_items) { if ((rc = finish_rounds(ctx, 0, db, 3, &rounds))) return rc; }
+    ch.est_rounds = rounds;
+    ctx->last_rounds = rounds;
+  } else {
+    ++ctx->last_blind;
+    const uint64_t n_items = c.work_count < ctx->V.n ? c.work_count : ctx->V.n;
+    ch.have_est = true; ch.est_items = n_items; ch.est_sum = c.sum_samples; ch.est_rounds = (int)c.rounds_used;
+    if (c.tries) ctx->mean_iters = (double)c.newton_iters / (double)c.tries;
+    int rounds = blind_rounds;
+    if (n_items && c.n_active[blind_rounds & 1] != 0) {
+      ctx->h_ctr_valid = false;
+      if ((rc = finish_rounds(ctx, 0, da, blind_rounds, &rounds))) return rc;
+      if (rounds > ch.est_rounds) ch.est_rounds = rounds;
+    }
+    ctx->last_rounds = rounds;
+  }
+  ctx->have_total_est = true;
+  ctx->est_items_total = ch.est_items; ctx->est_sum_total = ch.est_sum; ctx->est_rounds_total = ch.est_rounds;
+  for (int ci = 1; ci < C; ++ci) { ctx->chunks[ci].have_est = true; ctx->chunks[ci].est_items = 0; ctx->chunks[ci].est_sum = 0; }
+  *streamed = true;
+  return LENTIL_OK;
+}
+
 LENTIL_API int lentil_hip_redistribute(lentil_hip_ctx *ctx) {
   CHECK_CTX(ctx);
   if (!ctx->have_params || !ctx->have_frame || !ctx->have_visits)
@@ -875,63 +1206,38 @@ LENTIL_API int lentil_hip_redistribute(lentil_hip_ctx *ctx) {
   ctx->last_rounds = 0;
   ctx->h_ctr_valid = false;
   ctx->last_blind = ctx->last_fallback = 0;
+  ctx->last_streamed = 0;
   for (auto &ch : ctx->chunks) ch.heavy_pending = false;
   ctx->last_scan_launches = 0;
-  if (ctx->V.n) {
+  bool streamed = false;
+  {
+    const int rc = redistribute_streamed(ctx, &streamed);
+    if (rc) return rc;
+  }
+  if (!streamed && ctx->V.n) {
     // ---- scans: all chunks back to back on the main stream
-    ScanArgs sa{};
-    sa.P = P;
-    sa.lens_length = ctx->have_lens ? ctx->hlens.length : 0.0;
-    sa.V = ctx->V;
-    sa.F = ctx->F;
-    const uint64_t max_blocks = (uint64_t)ctx->num_cu * 8;
-    size_t lds = 0;
-    uint64_t n_tiles = 0;
-    bool multi = false;
-    const uint32_t M = ctx->V.visits_per_pixel;
-    if (M) {
-      // staging: 20 B per visit per wave, 4 waves per block, keep a block under ~48 KiB
-      uint32_t ppt = 64;
-      // extra AOV columns are streamed one at a time: more, smaller tiles keep enough loads in flight
-      // (beauty only: 64-pixel tiles, three blocks per CU.  32-pixel tiles / four blocks per CU are 3 % faster for a
-      // scan that has the chip to itself -- 0.946 against 0.972 ms -- and 20 % slower beside the first chunk's solve
-      // kernel, which then does not get its wave per SIMD until scan blocks retire)
-      uint64_t lds_budget = (ctx->V.n_extra ? 24ull : 48ull) * 1024ull;
-      if (const char *e = getenv("LENTIL_SCAN_LDS_KB")) lds_budget = strtoull(e, nullptr, 10) * 1024ull;
-      while (ppt > 1 && (uint64_t)ppt * M * 20ull * 4ull > lds_budget) ppt >>= 1;
-      if ((uint64_t)ppt * M * 20ull * 4ull > 150ull * 1024ull)
-        return fail(ctx, LENTIL_ERR_UNSUPPORTED, "visits_per_pixel too large for the LDS staging area");
-      sa.ppt = ppt;
-      sa.tv_pad = ppt * M;
-      lds = (size_t)sa.tv_pad * 20 * 4 + 4 * kWaveQueue * sizeof(uint2);
-      // frames with extra AOVs: all columns of a visit in flight at once, one step = 64 / M whole pixels
-      multi = ctx->V.n_extra > 0 && M <= 64 && !getenv("LENTIL_SCAN_SINGLE_COLUMN");
-      if (multi) {
-        ppt = 64 / M;
-        sa.ppt = ppt;
-        sa.tv_pad = ppt * M;
-        const size_t wave_f4 = (size_t)ctx->F.n_aovs * kMultiPlane + 16 + (size_t)ppt * (ctx->F.stride / 4);
-        lds = 4 * wave_f4 * 16 + 4 * kWaveQueue * sizeof(uint2);
-      }
-      const uint64_t n_pixels = (ctx->V.n + M - 1) / M;
-      n_tiles = (n_pixels + ppt - 1) / ppt;
+    ScanPlan plan;
+    {
+      const int rc = plan_scan(ctx, plan);
+      if (rc) return rc;
     }
+    const uint32_t M = plan.M;
     for (int ci = 0; ci < C; ++ci) {
       lentil_hip_ctx::Chunk &ch = ctx->chunks[ci];
       if (M) {
         // chunk boundaries: the first chunk takes first_chunk_frac of the tiles, the others share the rest
         auto bound = [&](int i) -> uint64_t {
           if (i <= 0) return 0;
-          if (i >= C) return n_tiles;
+          if (i >= C) return plan.n_tiles;
           const double f0 = C > 1 ? ctx->first_chunk_frac : 1.0;
           const double x = f0 + (1.0 - f0) * (double)(i - 1) / (double)(C - 1);
-          const uint64_t b = (uint64_t)((double)n_tiles * x);
-          return b > n_tiles ? n_tiles : b;
+          const uint64_t b = (uint64_t)((double)plan.n_tiles * x);
+          return b > plan.n_tiles ? plan.n_tiles : b;
         };
         ch.tile_begin = bound(ci);
         ch.tile_end = bound(ci + 1);
-        ch.v_begin = ch.tile_begin * sa.ppt * M;
-        ch.v_end = ch.tile_end * sa.ppt * M;
+        ch.v_begin = ch.tile_begin * plan.sa.ppt * M;
+        ch.v_end = ch.tile_end * plan.sa.ppt * M;
         if (ch.v_begin > ctx->V.n) ch.v_begin = ctx->V.n;
         if (ch.v_end > ctx->V.n) ch.v_end = ctx->V.n;
       } else {
@@ -940,65 +1246,22 @@ LENTIL_API int lentil_hip_redistribute(lentil_hip_ctx *ctx) {
         if (ch.v_begin > ctx->V.n) ch.v_begin = ctx->V.n;
         if (ch.v_end > ctx->V.n) ch.v_end = ctx->V.n;
       }
-      sa.work = ctx->d_work + ch.v_begin;
-      sa.work_cap = ch.v_end - ch.v_begin;
-      sa.ctr = ctx->d_ctr + ci;
-      sa.tile_begin = ch.tile_begin; sa.tile_end = ch.tile_end;
-      sa.v_begin = ch.v_begin; sa.v_end = ch.v_end;
       if (ch.v_end > ch.v_begin) {
-        if (M) {
-          uint64_t blocks = (ch.tile_end - ch.tile_begin + 3) / 4;
-          if (blocks > max_blocks) blocks = max_blocks;
-          if (multi) hipLaunchKernelGGL(scan_uniform_multi_kernel, dim3((unsigned)blocks), dim3(256), lds, ctx->stream, sa);
-          else hipLaunchKernelGGL(scan_uniform_kernel, dim3((unsigned)blocks), dim3(256), lds, ctx->stream, sa);
-        } else {
-          uint64_t blocks = (ch.v_end - ch.v_begin + 255) / 256;
-          if (blocks > max_blocks) blocks = max_blocks;
-          hipLaunchKernelGGL(scan_ragged_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, sa);
-        }
-        HIP_TRY(ctx, hipGetLastError());
+        const int rc = launch_scan(ctx, plan, ch, ctx->d_ctr + ci, nullptr);
+        if (rc) return rc;
         ++ctx->last_scan_launches;
       }
       HIP_TRY(ctx, hipEventRecord(ch.scanned, ctx->stream));
     }
   }
-  HIP_TRY(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
-  HIP_TRY(ctx, hipEventRecord(ctx->scans_done, ctx->stream));
-  if (ctx->V.n) {
+  if (!streamed) {
+    HIP_TRY(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
+    HIP_TRY(ctx, hipEventRecord(ctx->scans_done, ctx->stream));
+  }
+  if (!streamed && ctx->V.n) {
     // ---- draws: per chunk on its own stream
     DrawArgs da{};
-    da.P = P;
-    // wavelength channels of the polynomial-optics draw loop, src/lentil_filter.cpp:254-268 (float arithmetic of
-    // linear_interpolate, src/global.h:3-5); abb_chromatic < 0 runs three white channels at 0.55, like upstream
-    da.n_channels = (P.cameraType == LENTIL_POLYNOMIAL_OPTICS && P.abb_chromatic != 0.0f) ? 3 : 1;
-    da.chroma_weights = P.abb_chromatic > 0.0f ? 1 : 0;
-    da.lambda[0] = da.lambda[1] = da.lambda[2] = (double)P.lambda_bw;
-    if (da.n_channels == 3 && da.chroma_weights) {
-      const float c = P.abb_chromatic;
-      const float p0 = (float)(1.0 - (double)c);
-      da.lambda[0] = (double)(0.35f + p0 * (0.55f - 0.35f));
-      da.lambda[1] = (double)0.55f;
-      da.lambda[2] = (double)(0.55f + c * (0.85f - 0.55f));
-    }
-    da.lens = P.cameraType == LENTIL_POLYNOMIAL_OPTICS ? ctx->d_lens : nullptr;
-    da.terms = ctx->d_terms;
-    da.bokeh = ctx->bokeh;
-    da.V = ctx->V;
-    da.F = ctx->F;
-    // a straggler is a solve well beyond what this lens usually takes: 1.3 x the mean iteration count of the previous
-    // pass where that is above LENTIL_SLOW_AT (petzval table: ~25 iterations on average, 20 would park thousands)
-    da.slow_at = ctx->slow_at;
-    if (ctx->slow_at > 0 && ctx->mean_iters > 0.0) {
-      const int adaptive = (int)(1.3 * ctx->mean_iters + 0.5);
-      if (adaptive > da.slow_at) da.slow_at = adaptive < 90 ? adaptive : 90;
-    }
-    da.slow_below = ctx->slow_below;
-    da.slow_from_round = ctx->slow_from_round;
-    da.slow_max_lanes = ctx->slow_max_lanes;
-    da.extra_num = ctx->extra_num; da.extra_const = ctx->extra_const; da.extra_below = ctx->extra_below;
-    da.log = ctx->d_log;
-    da.log_cap = ctx->log_cap;
-    da.log_count = &ctx->d_ctr[C].log_count;
+    init_draw_args(ctx, da);
     // solve/accept rounds enqueued without looking (an unused one costs ~30 us, a missing one a host round trip):
     // per chunk what it needed in the previous pass, at least 2 (3 when nothing is known); LENTIL_BLIND_ROUNDS fixes it
     int forced_rounds = 0;
@@ -1078,6 +1341,18 @@ LENTIL_API int lentil_hip_redistribute(lentil_hip_ctx *ctx) {
       if (rounds > max_rounds) max_rounds = rounds;
     }
     ctx->last_rounds = max_rounds;
+    // what the whole stream held: sizes the next pass if it runs streamed
+    {
+      uint64_t items = 0, sum = 0;
+      int rounds = 0;
+      bool all = true;
+      for (const auto &ch : ctx->chunks) {
+        all = all && ch.have_est;
+        items += ch.est_items; sum += ch.est_sum;
+        if (ch.est_rounds > rounds) rounds = ch.est_rounds;
+      }
+      if (all) { ctx->have_total_est = true; ctx->est_items_total = items; ctx->est_sum_total = sum; ctx->est_rounds_total = rounds; }
+    }
   }
   if (ctx->F.zkey_dbg && ctx->V.n) {
     hipLaunchKernelGGL(debug_gather_kernel, dim3((unsigned)ctx->num_cu * 8), dim3(256), 0, ctx->stream, ctx->F, ctx->V, P,
@@ -1392,6 +1667,7 @@ LENTIL_API int lentil_hip_get_counters(lentil_hip_ctx *ctx, lentil_counters *out
   }
   out->blind_chunks = ctx->last_blind;
   out->fallback_chunks = ctx->last_fallback;
+  out->streamed = ctx->last_streamed;
   return LENTIL_OK;
 }
 

@@ -42,6 +42,10 @@ struct DevCounters {
   unsigned int slow_head[2];
   // rows of the frame this pass has added to (zero-initialised: "none"): max over (INT_MAX - row), max over (row + 1)
   unsigned int inv_row_min, row_max_p1;
+  // streamed pass: scan blocks that have published everything they found (solve_po_kernel<.., kStream> polls it)
+  unsigned int scan_blocks_done, publishers_done;
+  unsigned int n_ranges, range_head;   // work-list ranges the scan has handed to publish_kernel / tickets drawn on them
+  unsigned int stuck, stream_pad;      // a wave gave up waiting for its queue slot (kStuckTicks): the pass is void
 };
 
 // per-thread running row range -> one pair of atomics per wave
@@ -115,6 +119,62 @@ LD_DEV unsigned long long closest_key(float depth, uint32_t visit) {
   return ((unsigned long long)__float_as_uint(fabsf(depth)) << 32) | (unsigned long long)(0xFFFFFFFFu - visit);
 }
 
+struct ItemHdr {          // 32 B, written by prep_items_kernel
+  double tx, ty, tz;      // PO: -P_cs * 10 (src/lentil_filter.cpp:271); thin lens: P_cs (floats, exactly)
+  uint32_t seed_a;        // (unsigned)(px*py+px)
+  int32_t px_py;          // px | py << 16
+};
+
+struct ItemProg {         // 32 B, progress of an item across rounds
+  uint32_t n_done;        // attempts resolved so far (all earlier attempts are final)
+  uint32_t accepted;
+  uint32_t m_lo, m_hi;    // R(m) of the current round covers [m_lo, m_hi); any R(m < m_lo) still needed is FAIL
+  uint32_t res_off;       // offset of R(m_lo) in the current round's result pool
+  uint32_t last_ok;       // highest accepted attempt index
+  uint32_t splats;        // chromatic mode: accepted (attempt, channel) pairs so far
+  uint32_t pad1;
+};
+
+struct Task {             // up to 64 consecutive m of one item (and one wavelength channel)
+  uint32_t item, m_base, res_off, count;   // count: bits 0-7 number of m, bits 8-9 channel
+};
+
+
+// ---------------------------------------------------------------------------------------
+// Streamed pass: the scan kernels publish every item they find -- header, progress record and the solve
+// tasks of its first batch -- themselves, while they run; persistent waves of solve_po_kernel<.., kStream>
+// draw tickets on the task queue and poll their slot.  Hand-off between CUs without fences
+// (MI355X_MICROARCH.md, "Valid forms"): every handed-off byte is stored write-through (agent-scope relaxed
+// store = global_store sc1) and waited for (vmcnt(0)) before the word that publishes it, and read with agent-scope
+// loads (sc1, past the reader's L1).  A task slot is valid when its tag equals this pass's epoch, so the queue is
+// never cleared.
+// ---------------------------------------------------------------------------------------
+struct StreamPub {
+  uint32_t epoch;              // 22 bits, never 0
+  uint32_t n_channels;
+  int32_t retries;
+  uint32_t extra_num, extra_const;
+  uint32_t item_cap, task_cap;
+  uint64_t pool_cap;
+  ItemHdr *hdr;
+  ItemProg *prog;
+  uint32_t *active0;
+  Task *tasks0;
+};
+
+LD_DEV void st_agent64(void *p, uint64_t v) {
+  __hip_atomic_store(reinterpret_cast<uint64_t *>(p), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+LD_DEV uint64_t ld_agent64(const void *p) {
+  return __hip_atomic_load(reinterpret_cast<const uint64_t *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+LD_DEV uint32_t ld_agent32(const void *p) {
+  return __hip_atomic_load(reinterpret_cast<const uint32_t *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// every wait on a queue slot is bounded: 3 s of the 100 MHz real-time counter, then DevCounters::stuck
+constexpr uint64_t kStuckTicks = 300000000ull;
+constexpr uint32_t kTaskTagShift = 10;    // Task::count bits 10..31: epoch of the pass that published the slot
+
 struct ScanArgs {
   lentil_params P;
   double lens_length;
@@ -127,6 +187,10 @@ struct ScanArgs {
   uint32_t tv_pad;   // staging entries per wave (>= ppt * visits_per_pixel)
   uint64_t tile_begin, tile_end;   // uniform mode: this launch's range of pixel tiles
   uint64_t v_begin, v_end;         // ragged mode: this launch's range of visits
+  // streamed pass: every flush of a wave queue is announced to publish_kernel as a (first item, count) range
+  uint64_t *ranges;                // null: not a streamed pass
+  uint32_t range_cap, epoch;
+  uint32_t flush_each_tile;        // announce at the end of every tile (few items per pass: latency matters, atomics do not)
 };
 
 LD_DEV void visit_pixel(const VisitsDev &V, uint64_t v, int &px, int &py) {
@@ -149,6 +213,99 @@ LD_DEV float4 nt_load(const float4 *p) {
 
 LD_DEV uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 
+struct ItemVisit {
+  uint32_t visit, samples;
+  int px, py;
+  VisitInfo I;
+  float4 rgba;
+  float w;
+};
+
+// everything the draw kernels need to know about a work-list entry (visit, samples)
+LD_DEV ItemVisit load_work_visit(const lentil_params &P, const VisitsDev &V, uint2 wi, double lens_length) {
+  ItemVisit h;
+  h.visit = wi.x;
+  h.samples = wi.y;
+  const uint32_t v = h.visit;
+  h.rgba = V.rgba[v];
+  const float invd = V.inv_density ? V.inv_density[v] : P.inverse_sample_density;
+  h.I = visit_prologue(P, lens_length, h.rgba, V.pos_z[v], V.raydir_time[v], V.volume_ignore[v], V.transmission[v], invd);
+  visit_pixel(V, v, h.px, h.py);
+  const float inv_samples = (float)(1.0 / (double)(float)(int)h.samples);
+  h.w = 1.0f * invd * inv_samples;              // src/lentil_filter.cpp:297
+  return h;
+}
+
+LD_DEV ItemHdr make_item_hdr(const lentil_params &P, const float cs[3], int px, int py) {
+  ItemHdr hd;
+  if (P.cameraType == LENTIL_POLYNOMIAL_OPTICS) {
+    hd.tx = -(double)cs[0] * 10.0; hd.ty = -(double)cs[1] * 10.0; hd.tz = -(double)cs[2] * 10.0;
+  } else {
+    hd.tx = (double)cs[0]; hd.ty = (double)cs[1]; hd.tz = (double)cs[2];
+  }
+  hd.seed_a = (uint32_t)(px * py + px);
+  hd.px_py = (px & 0xFFFF) | (py << 16);
+  return hd;
+}
+
+// first batch of an item: R(0 .. samples - 1 + retries), plus the over-provisioned share
+LD_DEV uint32_t first_batch_hi(uint32_t samples, uint32_t retries, uint32_t extra_num, uint32_t extra_const) {
+  const uint32_t m_limit = samples * 5u + retries;
+  uint32_t m_hi = samples + retries + (uint32_t)(((unsigned long long)samples * extra_num) >> 8) + extra_const;
+  return m_hi > m_limit ? m_limit : m_hi;
+}
+
+// Streamed pass: one lane publishes one item (work-list entry `item`): header, progress record, result space and
+// the tasks of its first batch.  An item that does not fit (item buffers, result pool, task queue: sized from the
+// previous pass) raises DevCounters::fallback -- the host then redoes the draws of the pass with exact sizes -- and
+// still fills the task slots it reserved (with empty tasks), so that no ticket waits for a slot that never comes.
+LD_DEV void publish_item(const lentil_params &P, const VisitsDev &V, const StreamPub &S, DevCounters *ctr, uint32_t item, uint2 wi) {
+  const uint32_t retries = (uint32_t)S.retries, nch = S.n_channels;
+  const uint32_t count = first_batch_hi(wi.y, retries, S.extra_num, S.extra_const);
+  const uint32_t nt = (count + 63u) / 64u;
+  const unsigned long long off = atomicAdd(&ctr->pool_used[0], (unsigned long long)count * nch);
+  const uint32_t tb = atomicAdd(&ctr->n_tasks[0], nt * nch);
+  const bool ok = item < S.item_cap && off + (unsigned long long)count * nch <= S.pool_cap &&
+                  (unsigned long long)tb + nt * nch <= S.task_cap;
+  if (!ok) ctr->fallback = 1ull;
+  if (item < S.item_cap) {
+    float cs[3];
+    const uint32_t v = wi.x;
+    visit_camera_space(P, V.pos_z[v], [&]() { return V.raydir_time[v]; }, cs);
+    int px, py;
+    visit_pixel(V, v, px, py);
+    const ItemHdr hd = make_item_hdr(P, cs, px, py);
+    uint64_t *d = reinterpret_cast<uint64_t *>(S.hdr + item);
+    st_agent64(d + 0, (uint64_t)__double_as_longlong(hd.tx));
+    st_agent64(d + 1, (uint64_t)__double_as_longlong(hd.ty));
+    st_agent64(d + 2, (uint64_t)__double_as_longlong(hd.tz));
+    st_agent64(d + 3, (uint64_t)hd.seed_a | ((uint64_t)(uint32_t)hd.px_py << 32));
+    ItemProg pg{};
+    pg.m_lo = 0;
+    pg.m_hi = ok ? count : 0u;
+    pg.res_off = (uint32_t)off;
+    S.prog[item] = pg;
+    S.active0[item] = item;
+  }
+  // the header must have arrived before a task that names the item can be seen
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  for (uint32_t i = 0; i < nt * nch; ++i) {
+    const uint32_t slot = tb + i, t = i % nt;
+    if (slot < S.task_cap) st_agent64(S.tasks0 + slot, (uint64_t)item | ((uint64_t)(t * 64u) << 32));
+  }
+  // ... and a slot's first half before the half that carries its tag
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  for (uint32_t i = 0; i < nt * nch; ++i) {
+    const uint32_t slot = tb + i, c = i / nt, t = i - c * nt;
+    if (slot >= S.task_cap) continue;
+    const uint32_t n = ok ? ((count - t * 64u) < 64u ? (count - t * 64u) : 64u) : 0u;
+    st_agent64(reinterpret_cast<uint64_t *>(S.tasks0 + slot) + 1,
+               (uint64_t)((uint32_t)off + c * count + t * 64u) |
+                   ((uint64_t)(n | (c << 8) | (S.epoch << kTaskTagShift)) << 32));
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
 // K2: wave-ballot + prefix-sum compaction of flagged lanes into the work list.  Each wave collects
 // its items in a private 128-entry LDS queue (slot = popcount of the ballot below the lane) and
 // reserves space in the global list with ONE returning atomic per flush (queue more than half full,
@@ -158,32 +315,51 @@ constexpr uint32_t kWaveQueue = 128;
 // (pixel, aov) read plane aov at the same offset -- a stride of 64 float4 put all planes on the same LDS banks
 constexpr uint32_t kMultiPlane = 65;
 
+// (streamed pass: what a flush added to the work list is published at the end of the tile, where nothing of the
+// tile is live any more -- up to kWavePending flushes are remembered behind the queue, in the same LDS block)
+constexpr uint32_t kWavePending = 16;
+constexpr uint32_t kWaveQueueLds = kWaveQueue + kWavePending;     // uint2 entries per wave
+
 struct WaveQueue {
-  uint2 *q;                 // wave-private LDS, kWaveQueue entries
+  uint2 *q;                 // wave-private LDS, kWaveQueueLds entries
   uint32_t n;               // wave-uniform fill
+  uint32_t n_pend;          // wave-uniform: flushed (base, count) ranges not published yet
   unsigned long long sum_samples, n_items;   // per-lane partial sums, reduced in finish()
 
-  LD_DEV void init(uint2 *lds) { q = lds; n = 0; sum_samples = 0; n_items = 0; }
+  LD_DEV void init(uint2 *lds) { q = lds; n = 0; n_pend = 0; sum_samples = 0; n_items = 0; }
 
-  LD_DEV void flush(uint2 *work, uint64_t cap, DevCounters *ctr) {
+  LD_DEV void flush(const ScanArgs &a) {
     if (n == 0) return;
     const uint32_t lane = lane_id();
     unsigned long long base = 0;
-    if (lane == 0) base = atomicAdd(&ctr->work_count, (unsigned long long)n);
+    if (lane == 0) {
+      base = atomicAdd(&a.ctr->work_count, (unsigned long long)n);
+      if (a.ranges) {
+        atomicAdd(&a.ctr->n_active[0], n);
+        if (n_pend < kWavePending) q[kWaveQueue + n_pend] = make_uint2((uint32_t)base, n);
+        else a.ctr->fallback = 1ull;       // (a flush holds more than 64 entries, a tile fewer than 16 x 64 visits)
+      }
+    }
+    if (a.ranges && n_pend < kWavePending) ++n_pend;
     base = __shfl(base, 0);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
     for (uint32_t i = lane; i < n; i += 64u) {
-      if (base + i < cap) work[base + i] = q[i];
-      else atomicAdd(&ctr->overflow, 1ull);
+      if (base + i < a.work_cap) {
+        // streamed pass: read by publish_kernel on another CU while this kernel runs -- written through
+        if (a.ranges) st_agent64(a.work + base + i, (uint64_t)q[i].x | ((uint64_t)q[i].y << 32));
+        else a.work[base + i] = q[i];
+      } else {
+        atomicAdd(&a.ctr->overflow, 1ull);
+      }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
     __builtin_amdgcn_wave_barrier();
     n = 0;
   }
 
-  LD_DEV void push(bool flagged, uint32_t visit, uint32_t samples, uint2 *work, uint64_t cap, DevCounters *ctr) {
+  LD_DEV void push(bool flagged, uint32_t visit, uint32_t samples, const ScanArgs &a) {
     const unsigned long long mask = __ballot(flagged);
     if (mask == 0ull) return;
     const uint32_t lane = lane_id();
@@ -193,21 +369,58 @@ struct WaveQueue {
       n_items += 1;
     }
     n += (uint32_t)__builtin_popcountll(mask);
-    if (n > kWaveQueue - 64u) flush(work, cap, ctr);
+    if (n > kWaveQueue - 64u) flush(a);
   }
 
-  LD_DEV void finish(uint2 *work, uint64_t cap, DevCounters *ctr) {
-    flush(work, cap, ctr);
+  // announce the flushed ranges: one 8-byte record each, (first item | count << 32 | epoch tag << 42)
+  LD_DEV void publish_pending(const ScanArgs &a) {
+    if (n_pend == 0) return;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's work-list stores have arrived
+    const uint32_t lane = lane_id();
+    uint32_t k = 0;
+    if (lane == 0) k = atomicAdd(&a.ctr->n_ranges, n_pend);
+    k = __shfl(k, 0);
+    if (lane < n_pend) {
+      const uint2 pr = q[kWaveQueue + lane];
+      if (k + lane < a.range_cap)
+        st_agent64(a.ranges + k + lane, (uint64_t)pr.x | ((uint64_t)(pr.y | (a.epoch << kTaskTagShift)) << 32));
+      else
+        a.ctr->fallback = 1ull;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+    __builtin_amdgcn_wave_barrier();
+    n_pend = 0;
+  }
+
+  // streamed pass: what a tile found goes out when the tile is done, not when the wave is (few items per pass:
+  // latency matters, the extra atomics do not)
+  LD_DEV void end_tile(const ScanArgs &a) {
+    if (!a.ranges) return;
+    if (a.flush_each_tile) flush(a);
+    publish_pending(a);
+  }
+
+  LD_DEV void finish(const ScanArgs &a) {
+    flush(a);
+    if (a.ranges) publish_pending(a);
     for (int off = 32; off > 0; off >>= 1) {
       sum_samples += __shfl_down(sum_samples, off);
       n_items += __shfl_down(n_items, off);
     }
     if (lane_id() == 0 && n_items) {
-      atomicAdd(&ctr->sum_samples, sum_samples);
-      atomicAdd(&ctr->redistributed, n_items);
+      atomicAdd(&a.ctr->sum_samples, sum_samples);
+      atomicAdd(&a.ctr->redistributed, n_items);
     }
   }
 };
+
+// streamed pass: the last thing a scan block does -- after every wave's items and tasks have arrived
+LD_DEV void scan_block_done(const ScanArgs &a) {
+  if (!a.ranges) return;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(&a.ctr->scan_blocks_done, 1u);
+}
 
 // ---------------------------------------------------------------------------------------
 // K1+K2+K6, uniform footprints.  One wave owns a tile of `ppt` consecutive source pixels
@@ -225,7 +438,7 @@ __global__ __launch_bounds__(256) void scan_uniform_kernel(ScanArgs a) {
   uint2 *qmem = reinterpret_cast<uint2 *>(reinterpret_cast<float *>(smem + (size_t)waves_per_block * a.tv_pad) +
                                           (size_t)waves_per_block * a.tv_pad);
   WaveQueue wq;
-  wq.init(qmem + (size_t)wave * kWaveQueue);
+  wq.init(qmem + (size_t)wave * kWaveQueueLds);
 
   const VisitsDev &V = a.V;
   const uint32_t M = V.visits_per_pixel;
@@ -286,7 +499,7 @@ __global__ __launch_bounds__(256) void scan_uniform_kernel(ScanArgs a) {
             val = make_float4((rgba[g].x + 0.0f) * w, (rgba[g].y + 0.0f) * w, (rgba[g].z + 0.0f) * w, (rgba[g].w + 0.0f) * w);
           }
         }
-        wq.push(flagged[g], (uint32_t)v, (uint32_t)samples, a.work, a.work_cap, a.ctr);
+        wq.push(flagged[g], (uint32_t)v, (uint32_t)samples, a);
         if (e < TV) { sval[e] = val; sw[e] = w; }
       }
     }
@@ -360,8 +573,10 @@ __global__ __launch_bounds__(256) void scan_uniform_kernel(ScanArgs a) {
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
     __builtin_amdgcn_wave_barrier();
+    wq.end_tile(a);
   }
-  wq.finish(a.work, a.work_cap, a.ctr);
+  wq.finish(a);
+  scan_block_done(a);
 }
 
 // K1+K2+K6 for ragged footprints (explicit per-visit pixel): lane per visit, fp32 atomics for the
@@ -388,7 +603,7 @@ __global__ __launch_bounds__(256) void scan_uniform_multi_kernel(ScanArgs a) {
   float4 *srec = sval + (size_t)n_aovs * kMultiPlane + 16u;
   uint2 *qmem = reinterpret_cast<uint2 *>(smem + (size_t)waves_per_block * wave_f4);
   WaveQueue wq;
-  wq.init(qmem + (size_t)wave * kWaveQueue);
+  wq.init(qmem + (size_t)wave * kWaveQueueLds);
 
   const uint64_t n_pixels = (V.n + M - 1) / M;
   const uint64_t n_tiles = a.tile_end;
@@ -443,7 +658,7 @@ __global__ __launch_bounds__(256) void scan_uniform_multi_kernel(ScanArgs a) {
         val[0] = rgba;
       }
     }
-    wq.push(flagged, (uint32_t)v, (uint32_t)samples, a.work, a.work_cap, a.ctr);
+    wq.push(flagged, (uint32_t)v, (uint32_t)samples, a);
     if (lane < TV) {
       sw[lane] = w;
 #pragma unroll
@@ -514,15 +729,17 @@ __global__ __launch_bounds__(256) void scan_uniform_multi_kernel(ScanArgs a) {
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
     __builtin_amdgcn_wave_barrier();
+    wq.end_tile(a);
   }
-  wq.finish(a.work, a.work_cap, a.ctr);
+  wq.finish(a);
+  scan_block_done(a);
 }
 
 __global__ __launch_bounds__(256) void scan_ragged_kernel(ScanArgs a) {
   const VisitsDev &V = a.V;
-  __shared__ uint2 s_queue[4 * kWaveQueue];
+  __shared__ uint2 s_queue[4 * kWaveQueueLds];
   WaveQueue wq;
-  wq.init(s_queue + (threadIdx.x >> 6) * kWaveQueue);
+  wq.init(s_queue + (threadIdx.x >> 6) * kWaveQueueLds);
   const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
   const uint64_t n_round = a.v_begin + ((a.v_end - a.v_begin + 63ull) & ~63ull);
   uint32_t rmin = 0x7FFFFFFFu, rmax_p1 = 0u;
@@ -561,11 +778,77 @@ __global__ __launch_bounds__(256) void scan_ragged_kernel(ScanArgs a) {
         }
       }
     }
-    wq.push(flagged, (uint32_t)v, (uint32_t)samples, a.work, a.work_cap, a.ctr);
+    wq.push(flagged, (uint32_t)v, (uint32_t)samples, a);
+    wq.end_tile(a);
   }
-  wq.finish(a.work, a.work_cap, a.ctr);
+  wq.finish(a);
   flush_row_range(a.ctr, rmin, rmax_p1);
+  scan_block_done(a);
 }
+// ---------------------------------------------------------------------------------------
+// Streamed pass, stage two: publish_kernel.  A handful of one-wave blocks that follow the scan's range queue and
+// turn every announced work-list entry into an item (publish_item): header, progress record, result space, the
+// first batch's solve tasks.  In a kernel of its own so that the scan's hot loop carries none of it (the scan
+// kernels sit at the SGPR limit; six more VGPRs would cost them a wave per SIMD beside the solve kernel).
+// A wave draws a ticket on the range queue and polls its slot; the queue is complete once every scan block has
+// signed off.  The solve waves, in turn, know the task queue is complete once every publisher has signed off.
+// ---------------------------------------------------------------------------------------
+struct PublishArgs {
+  lentil_params P;
+  VisitsDev V;
+  StreamPub S;
+  DevCounters *ctr;
+  const uint2 *work;
+  uint64_t work_cap;
+  const uint64_t *ranges;
+  uint32_t range_cap;
+  uint32_t scan_blocks_total;
+};
+
+__global__ __launch_bounds__(64) void publish_kernel(PublishArgs a) {
+  const uint32_t lane = threadIdx.x;
+  uint32_t polls = 0;
+  while (true) {
+    uint32_t t = 0;
+    if (lane == 0) t = atomicAdd(&a.ctr->range_head, 1u);
+    const uint32_t ticket = __builtin_amdgcn_readfirstlane(t);
+    if (ticket >= a.range_cap) break;
+    uint64_t rec = 0;
+    bool over = false;
+    const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
+    while (true) {
+      if (lane == 0) rec = ld_agent64(a.ranges + ticket);
+      rec = ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(rec >> 32)) << 32) |
+            (uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)rec);
+      if (((uint32_t)(rec >> 32) >> kTaskTagShift) == a.S.epoch) break;
+      // nothing there (yet).  Every few polls: has the scan ended, and does its queue end before this ticket?
+      if ((polls++ & 3u) == 0u) {
+        uint32_t o = 0;
+        if (lane == 0 && ld_agent32(&a.ctr->scan_blocks_done) >= a.scan_blocks_total)
+          o = ld_agent32(&a.ctr->n_ranges) <= ticket ? 1u : 0u;
+        if (__builtin_amdgcn_readfirstlane(o)) { over = true; break; }
+        if (__builtin_amdgcn_s_memrealtime() - t0 > kStuckTicks) {
+          if (lane == 0) a.ctr->stuck = 1u;
+          over = true;
+          break;
+        }
+      }
+      __builtin_amdgcn_s_sleep(32);
+    }
+    if (over) break;
+    const uint32_t base = (uint32_t)rec, n = (uint32_t)(rec >> 32) & ((1u << kTaskTagShift) - 1u);
+    for (uint32_t i = lane; i < n; i += 64u) {
+      const uint32_t item = base + i;
+      if ((uint64_t)item >= a.work_cap) continue;
+      const uint64_t wi = ld_agent64(a.work + item);          // written through by the scan before the range record
+      publish_item(a.P, a.V, a.S, a.ctr, item, make_uint2((uint32_t)wi, (uint32_t)(wi >> 32)));
+    }
+  }
+  // everything this wave published has arrived (publish_item waits for its stores); sign off
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (lane == 0) atomicAdd(&a.ctr->publishers_done, 1u);
+}
+
 // ---------------------------------------------------------------------------------------
 // K3/K4/K5: draws -- "solve once".
 //
@@ -594,26 +877,6 @@ __global__ __launch_bounds__(256) void scan_ragged_kernel(ScanArgs a) {
 constexpr int kMaxBokehRows = 2048;
 constexpr uint32_t kCodeFail = 0xFFFFFFFFu;
 constexpr uint32_t kCodeOut = 0xFFFFFFFEu;
-
-struct ItemHdr {          // 32 B, written by prep_items_kernel
-  double tx, ty, tz;      // PO: -P_cs * 10 (src/lentil_filter.cpp:271); thin lens: P_cs (floats, exactly)
-  uint32_t seed_a;        // (unsigned)(px*py+px)
-  int32_t px_py;          // px | py << 16
-};
-
-struct ItemProg {         // 32 B, progress of an item across rounds
-  uint32_t n_done;        // attempts resolved so far (all earlier attempts are final)
-  uint32_t accepted;
-  uint32_t m_lo, m_hi;    // R(m) of the current round covers [m_lo, m_hi); any R(m < m_lo) still needed is FAIL
-  uint32_t res_off;       // offset of R(m_lo) in the current round's result pool
-  uint32_t last_ok;       // highest accepted attempt index
-  uint32_t splats;        // chromatic mode: accepted (attempt, channel) pairs so far
-  uint32_t pad1;
-};
-
-struct Task {             // up to 64 consecutive m of one item (and one wavelength channel)
-  uint32_t item, m_base, res_off, count;   // count: bits 0-7 number of m, bits 8-9 channel
-};
 
 // A solve that is still running after `slow_at` Newton iterations (about one in a thousand) is parked here by
 // solve_po_kernel and finished by solve_slow_kernel, a whole wave per solve: the complete loop state, so that
@@ -665,6 +928,8 @@ struct DrawArgs {
   unsigned long long *log_count;   // shared by all chunks
   int32_t retries;         // vignetting_retries for PO, 0 for the thin lens
   int32_t parity;
+  // streamed pass (solve_po_kernel<.., kStream>): tag of this pass's task slots, publish_kernel waves that will sign off
+  uint32_t epoch, publishers_total;
   // chromatic aberration of the polynomial-optics path (src/lentil_filter.cpp:255-268): three traces per
   // attempt, one wavelength each; n_channels is 1 when abb_chromatic == 0
   int32_t n_channels;
@@ -672,28 +937,8 @@ struct DrawArgs {
   double lambda[3];
 };
 
-struct ItemVisit {
-  uint32_t visit, samples;
-  int px, py;
-  VisitInfo I;
-  float4 rgba;
-  float w;
-};
-
 LD_DEV ItemVisit load_item_visit(const DrawArgs &a, uint32_t item, double lens_length) {
-  ItemVisit h;
-  const uint2 wi = a.work[item];
-  h.visit = wi.x;
-  h.samples = wi.y;
-  const uint32_t v = h.visit;
-  h.rgba = a.V.rgba[v];
-  const float invd = a.V.inv_density ? a.V.inv_density[v] : a.P.inverse_sample_density;
-  h.I = visit_prologue(a.P, lens_length, h.rgba, a.V.pos_z[v], a.V.raydir_time[v], a.V.volume_ignore[v],
-                       a.V.transmission[v], invd);
-  visit_pixel(a.V, v, h.px, h.py);
-  const float inv_samples = (float)(1.0 / (double)(float)(int)h.samples);
-  h.w = 1.0f * invd * inv_samples;              // src/lentil_filter.cpp:297
-  return h;
+  return load_work_visit(a.P, a.V, a.work[item], lens_length);
 }
 
 // emit the solve tasks for m in [m_lo, m_hi) of `item` into the queues of round parity `par`
@@ -744,14 +989,7 @@ __global__ __launch_bounds__(256) void prep_items_kernel(DrawArgs a) {
   if (i >= n_items) return;
   const uint32_t item = (uint32_t)i;
   const ItemVisit h = load_item_visit(a, item, a.lens ? a.lens->length : 0.0);
-  ItemHdr hd;
-  if (a.P.cameraType == LENTIL_POLYNOMIAL_OPTICS) {
-    hd.tx = -(double)h.I.cs[0] * 10.0; hd.ty = -(double)h.I.cs[1] * 10.0; hd.tz = -(double)h.I.cs[2] * 10.0;
-  } else {
-    hd.tx = (double)h.I.cs[0]; hd.ty = (double)h.I.cs[1]; hd.tz = (double)h.I.cs[2];
-  }
-  hd.seed_a = (uint32_t)(h.px * h.py + h.px);
-  hd.px_py = (h.px & 0xFFFF) | (h.py << 16);
+  const ItemHdr hd = make_item_hdr(a.P, h.I.cs, h.px, h.py);
   a.hdr[item] = hd;
   const uint32_t samples = h.samples, max_total = samples * 5u;
   const uint32_t m_limit = max_total + (uint32_t)a.retries;
@@ -789,7 +1027,10 @@ LD_DEV uint32_t solve_result(const lentil_params &P, const LensT &L, const Newto
 // ---- solve, polynomial optics ------------------------------------------------------------------
 // kChroma: tasks carry a wavelength channel (src/lentil_filter.cpp:255-268); every lane then reads the lens
 // header through its own pointer into three LDS copies that differ in the lambda powers only.
-template <class LensT, bool kTables, bool kChroma = false>
+// kStream (first round of a streamed pass): the task queue is still being filled by the scan kernels while this
+// kernel runs.  A wave that needs work draws a ticket and polls its slot between Newton iterations; the queue is
+// complete once every wave of publish_kernel has signed off (DevCounters::publishers_done).
+template <class LensT, bool kTables, bool kChroma = false, bool kStream = false>
 __global__ __launch_bounds__(256) void solve_po_kernel(DrawArgs a) {
   __shared__ DevTerm s_terms[kTables ? kMaxTerms : 1];
   __shared__ DevLens s_k;
@@ -827,7 +1068,8 @@ __global__ __launch_bounds__(256) void solve_po_kernel(DrawArgs a) {
   const uint32_t par = (uint32_t)a.parity;
   const Task *tasks = a.tasks[par];
   uint32_t *res = a.pool[par];
-  const uint32_t n_tasks = a.ctr->n_tasks[par] < a.task_cap ? a.ctr->n_tasks[par] : a.task_cap;
+  uint32_t n_tasks = 0;
+  if constexpr (!kStream) n_tasks = a.ctr->n_tasks[par] < a.task_cap ? a.ctr->n_tasks[par] : a.task_cap;
   const uint32_t lane = lane_id();
   const unsigned long long lt_mask = (1ull << lane) - 1ull;
 
@@ -835,6 +1077,10 @@ __global__ __launch_bounds__(256) void solve_po_kernel(DrawArgs a) {
   uint32_t cur_item = 0, cur_m = 0, cur_res = 0, cur_left = 0, cur_chan = 0;
   (void)cur_chan;
   bool no_more = false;
+  constexpr uint32_t kNoTicket = 0xFFFFFFFFu;
+  uint32_t ticket = kNoTicket, polls = 0;     // kStream: the queue slot this wave is waiting for
+  uint64_t ticket_t0 = 0;
+  (void)ticket; (void)polls; (void)ticket_t0;
   // per-lane solve
   bool busy = false, need_init = false;
   uint32_t m = 0, res_idx = 0, seed_a = 0, cur_chan_lane = 0;
@@ -844,7 +1090,8 @@ __global__ __launch_bounds__(256) void solve_po_kernel(DrawArgs a) {
   NewtonState s;
   newton_init(s);
   uint32_t st_iters = 0, st_tries = 0, st_rounds = 0;
-  const bool parking = a.slow != nullptr && a.round >= a.slow_from_round && a.ctr->sum_samples < a.slow_below;
+  // (streamed pass: the draw sum is not known yet; the host decides from the previous pass and passes no queue otherwise)
+  const bool parking = a.slow != nullptr && a.round >= a.slow_from_round && (kStream || a.ctr->sum_samples < a.slow_below);
 
   while (true) {
     const unsigned long long busy_mask = __ballot(busy);
@@ -855,16 +1102,53 @@ __global__ __launch_bounds__(256) void solve_po_kernel(DrawArgs a) {
     while (filled < n_idle) {
       if (cur_left == 0) {
         if (no_more) break;
-        uint32_t q = 0;
-        if (lane == 0) q = atomicAdd(&a.ctr->task_head[par], 1u);
-        q = __builtin_amdgcn_readfirstlane(q);
-        if (q >= n_tasks) { no_more = true; break; }
-        const Task t = tasks[q];
-        cur_item = __builtin_amdgcn_readfirstlane(t.item);
-        cur_m = __builtin_amdgcn_readfirstlane(t.m_base);
-        cur_res = __builtin_amdgcn_readfirstlane(t.res_off);
-        cur_left = __builtin_amdgcn_readfirstlane(t.count) & 0xFFu;
-        if (kChroma) cur_chan = (__builtin_amdgcn_readfirstlane(t.count) >> 8) & 3u;
+        if constexpr (kStream) {
+          if (ticket == kNoTicket) {
+            uint32_t q = 0;
+            if (lane == 0) q = atomicAdd(&a.ctr->task_head[par], 1u);
+            ticket = __builtin_amdgcn_readfirstlane(q);
+            polls = 0;
+            ticket_t0 = __builtin_amdgcn_s_memrealtime();
+          }
+          if (ticket >= a.task_cap) { no_more = true; break; }
+          uint64_t w1 = 0;
+          if (lane == 0) w1 = ld_agent64(reinterpret_cast<const uint64_t *>(tasks + ticket) + 1);
+          const uint32_t w1_hi = __builtin_amdgcn_readfirstlane((uint32_t)(w1 >> 32));
+          if ((w1_hi >> kTaskTagShift) != a.epoch) {
+            // nothing there (yet).  Every few polls: is the queue complete, and does it end before this ticket?
+            if ((polls++ & 3u) == 0u) {
+              uint32_t over = 0;
+              if (lane == 0 && ld_agent32(&a.ctr->publishers_done) >= a.publishers_total)
+                over = ld_agent32(&a.ctr->n_tasks[par]) <= ticket ? 1u : 0u;
+              if (__builtin_amdgcn_readfirstlane(over)) no_more = true;
+              if (__builtin_amdgcn_s_memrealtime() - ticket_t0 > kStuckTicks) {
+                if (lane == 0) a.ctr->stuck = 1u;
+                no_more = true;
+              }
+            }
+            break;
+          }
+          uint64_t w0 = 0;
+          if (lane == 0) w0 = ld_agent64(reinterpret_cast<const uint64_t *>(tasks + ticket));
+          cur_item = __builtin_amdgcn_readfirstlane((uint32_t)w0);
+          cur_m = __builtin_amdgcn_readfirstlane((uint32_t)(w0 >> 32));
+          cur_res = __builtin_amdgcn_readfirstlane((uint32_t)w1);
+          cur_left = w1_hi & 0xFFu;
+          if (kChroma) cur_chan = (w1_hi >> 8) & 3u;
+          ticket = kNoTicket;
+          if (cur_left == 0) continue;        // an item that did not fit left empty tasks
+        } else {
+          uint32_t q = 0;
+          if (lane == 0) q = atomicAdd(&a.ctr->task_head[par], 1u);
+          q = __builtin_amdgcn_readfirstlane(q);
+          if (q >= n_tasks) { no_more = true; break; }
+          const Task t = tasks[q];
+          cur_item = __builtin_amdgcn_readfirstlane(t.item);
+          cur_m = __builtin_amdgcn_readfirstlane(t.m_base);
+          cur_res = __builtin_amdgcn_readfirstlane(t.res_off);
+          cur_left = __builtin_amdgcn_readfirstlane(t.count) & 0xFFu;
+          if (kChroma) cur_chan = (__builtin_amdgcn_readfirstlane(t.count) >> 8) & 3u;
+        }
       }
       uint32_t take = n_idle - filled;
       if (take > cur_left) take = cur_left;
@@ -872,16 +1156,29 @@ __global__ __launch_bounds__(256) void solve_po_kernel(DrawArgs a) {
         const uint32_t j = my_rank - filled;
         m = cur_m + j;
         res_idx = cur_res + j;
-        const ItemHdr hd = a.hdr[cur_item];
-        target[0] = hd.tx; target[1] = hd.ty; target[2] = hd.tz;
-        seed_a = hd.seed_a;
+        if constexpr (kStream) {
+          // written by a scan block on another CU during this launch: past this CU's L1
+          const uint64_t *hp = reinterpret_cast<const uint64_t *>(a.hdr + cur_item);
+          target[0] = __longlong_as_double((long long)ld_agent64(hp + 0));
+          target[1] = __longlong_as_double((long long)ld_agent64(hp + 1));
+          target[2] = __longlong_as_double((long long)ld_agent64(hp + 2));
+          seed_a = (uint32_t)ld_agent64(hp + 3);
+        } else {
+          const ItemHdr hd = a.hdr[cur_item];
+          target[0] = hd.tx; target[1] = hd.ty; target[2] = hd.tz;
+          seed_a = hd.seed_a;
+        }
         busy = true;
         need_init = true;
         if constexpr (kChroma) { L.k = &s_kc[cur_chan]; cur_chan_lane = cur_chan; }
       }
       cur_m += take; cur_res += take; cur_left -= take; filled += take;
     }
-    if (inflight + filled == 0u) break;
+    if (inflight + filled == 0u) {
+      if (!kStream || no_more) break;
+      __builtin_amdgcn_s_sleep(64);          // ~1.5 us: an idle wave polls its slot, nothing else
+      continue;
+    }
 
     // aperture draw of the reference's try with seed (seed_a, m), src/lentil.h:596-609
     if (busy && need_init) {
@@ -1464,7 +1761,8 @@ __global__ __launch_bounds__(256) void accept_kernel(DrawArgs a) {
   __shared__ uint32_t s_item;
   __shared__ AcceptShared sh;
   const uint32_t par = (uint32_t)a.parity, nxt = par ^ 1u;
-  const uint32_t n_active = a.ctr->n_active[par];
+  // (a streamed or blind pass whose buffers were too small: nothing is accepted, the host redoes the draws)
+  const uint32_t n_active = a.ctr->fallback ? 0u : a.ctr->n_active[par];
   if (blockIdx.x == 0 && threadIdx.x == 0 && n_active) atomicMax(&a.ctr->rounds_used, (unsigned long long)(a.round + 1));
   const uint32_t *res = a.pool[par];
   unsigned long long tot_attempted = 0, tot_accepted = 0;

@@ -899,10 +899,12 @@ def test_stragglers_finish_in_the_cooperative_kernel(orc, monkeypatch, slow_at, 
         ctx.close()
 
 
-def test_blind_passes_and_fallback(orc, monkeypatch):
-    """From the second pass on a chunk's draw rounds are enqueued without waiting for its scan, sized from what the
-    previous pass found; prep_items_kernel checks the real counts on the device.  Same stream again -> blind, same
-    result; a stream with many more highlights -> does not fit, the chunk is redone with exact sizes."""
+@pytest.mark.parametrize("stream", ["1", "0"])
+def test_blind_passes_and_fallback(orc, monkeypatch, stream):
+    """From the second pass on nothing waits for the scan on the host: buffers are sized from what the previous pass
+    found and the device checks the real counts.  Streamed (default): one scan launch publishes items and tasks to
+    persistent solve waves.  LENTIL_STREAM=0: per chunk, prep_items_kernel after the chunk's scan.  Same stream
+    again -> same result; a stream with many more highlights -> does not fit, the draws are redone with exact sizes."""
     W, H, M = 96, 64, 9
     p, model, table, keep = common.po_setup(W, H, samples_override=48)
     light, keep_l = common.make_stream(p, W, H, M, f_hi=0.002)      # the column arrays must outlive the passes
@@ -910,15 +912,18 @@ def test_blind_passes_and_fallback(orc, monkeypatch):
     ref_l = common.run_oracle(orc, p, table, light)
     ref_h = common.run_oracle(orc, p, table, heavy)
     monkeypatch.setenv("LENTIL_CHUNKS", "3")
+    monkeypatch.setenv("LENTIL_STREAM", stream)
+    per_pass = 1 if stream == "1" else 3        # a streamed pass is one "chunk"
     ctx = capi.Context(0)
     try:
-        for visits, ref, blind, fb in ((light, ref_l, 0, 0), (light, ref_l, 3, 0), (heavy, ref_h, 3, 3), (heavy, ref_h, 3, 0),
-                                       (light, ref_l, 3, 0)):
+        for visits, ref, blind, fb in ((light, ref_l, 0, 0), (light, ref_l, per_pass, 0), (heavy, ref_h, per_pass, 3),
+                                       (heavy, ref_h, per_pass, 0), (light, ref_l, per_pass, 0)):
             c = gpu_run(ctx, p, table, visits)
             rc = ref.counters()
             assert (c.redistributed_visits, c.attempted_draws, c.accepted_draws) == (
                 rc.redistributed_visits, rc.attempted_draws, rc.accepted_draws)
             assert c.blind_chunks == blind
+            assert c.streamed == (1 if stream == "1" and blind else 0)
             assert (c.fallback_chunks >= 1) if fb else (c.fallback_chunks == 0)    # the quarter-frame chunks may just fit
             check_logs(ctx, ref)
             check_frame(ctx, ref)
