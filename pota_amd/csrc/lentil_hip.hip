@@ -39,6 +39,15 @@ struct lentil_hip_ctx {
   uint8_t kind[LENTIL_MAX_AOVS] = {0};
   float *d_resolved = nullptr;
   bool have_frame = false;
+  // FrameDev::dir (see there): the allocation, whether its content counts (F.dir is set exactly then), whether
+  // it may hold non-zeros at all, and the pixels of the stream that wrote them
+  float *d_dir = nullptr;
+  bool dir_dirty = false;
+  struct DirRegion {
+    int32_t x0 = 0, y0 = 0; uint32_t row_stride = 0, ppr = 0; uint64_t npix = 0;
+    bool operator==(const DirRegion &o) const { return x0 == o.x0 && y0 == o.y0 && row_stride == o.row_stride && ppr == o.ppr && npix == o.npix; }
+  } dir_region;
+  bool scan_dma = true;               // LENTIL_SCAN_DMA=0: register-staged scan kernels only
 
   VisitsDev V{};
   bool have_visits = false;
@@ -205,6 +214,7 @@ LENTIL_API int lentil_hip_create(int device, lentil_hip_ctx **out_ctx) {
   if (const char *e = getenv("LENTIL_SOLVE_BLOCKS")) ctx->solve_max_blocks = atoi(e);
   if (ctx->solve_max_blocks < 1) ctx->solve_max_blocks = 1;
   if (const char *e = getenv("LENTIL_STREAM")) ctx->stream_mode = !(e[0] == '0');
+  if (const char *e = getenv("LENTIL_SCAN_DMA")) ctx->scan_dma = !(e[0] == '0');
   if (const char *e = getenv("LENTIL_STREAM_BLOCKS")) ctx->stream_blocks = atoi(e);
   if (ctx->stream_blocks < 1) ctx->stream_blocks = 1;
   if (const char *e = getenv("LENTIL_PUBLISH_WAVES")) ctx->publish_waves = atoi(e);
@@ -433,6 +443,9 @@ LENTIL_API int lentil_hip_alloc_frame(lentil_hip_ctx *ctx, uint32_t n_aovs, cons
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   (void)hipFree(ctx->F.acc);
+  (void)hipFree(ctx->d_dir);
+  ctx->d_dir = nullptr;
+  ctx->dir_dirty = false;
   (void)hipFree(ctx->F.zkey);
   (void)hipFree(ctx->F.zkey_dbg);
   (void)hipFree(ctx->d_resolved);
@@ -589,6 +602,7 @@ LENTIL_API int lentil_hip_clear_frame(lentil_hip_ctx *ctx) {
     if (ctx->F.zkey) HIP_TRY(ctx, hipMemsetAsync(ctx->F.zkey + p0, 0xFF, (p1 - p0) * sizeof(unsigned long long), ctx->stream));
     if (ctx->F.zkey_dbg) HIP_TRY(ctx, hipMemsetAsync(ctx->F.zkey_dbg + p0, 0xFF, (p1 - p0) * sizeof(unsigned long long), ctx->stream));
   }
+  ctx->F.dir = nullptr;         // what the scan stored there no longer counts (wiped or overwritten before it does again)
   ctx->dirty_lo = ctx->dirty_hi = 0;
   ctx->dirty_known = true;      // clean frame: nothing is dirty
   ctx->pass_pending = false;
@@ -639,7 +653,8 @@ static void launch_solve(lentil_hip_ctx *ctx, const DrawArgs &da, hipStream_t st
 // solve/accept rounds on the chunk's stream (no host round trip between the rounds: every kernel
 // reads its queue lengths from device memory; a round with empty queues costs a few microseconds).
 static int size_chunk_buffers(lentil_hip_ctx *ctx, lentil_hip_ctx::Chunk &ch, uint64_t n_items, uint64_t units) {
-  const uint64_t tasks = units / 64 + 2 * n_items + 64;
+  // (+ room for a streamed pass's end markers: one per first-round solve wave)
+  const uint64_t tasks = units / 64 + 2 * n_items + 64 + (uint64_t)ctx->num_cu * 64;
   if (tasks > 0xFFFFFFF0ull) return fail(ctx, LENTIL_ERR_NOMEM, "too many solve tasks in one batch");
   int rc;
   if (n_items > ch.item_cap) {
@@ -655,8 +670,9 @@ static int size_chunk_buffers(lentil_hip_ctx *ctx, lentil_hip_ctx::Chunk &ch, ui
     if ((rc = grow(ctx, &ch.tasks[0], nc))) return rc;
     if ((rc = grow(ctx, &ch.tasks[1], nc))) return rc;
     ch.task_cap = nc;
-    // a streamed pass tells a filled slot by its tag: no stale bits
+    // a streamed pass tells a filled slot by its tag: no stale bits (now: the chunk's own stream may fill it next)
     HIP_TRY(ctx, hipMemsetAsync(ch.tasks[0], 0, nc * sizeof(Task), ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   }
   if (units > ch.pool_cap) {
     const uint64_t nc = units + units / 4;
@@ -914,12 +930,57 @@ static void init_draw_args(lentil_hip_ctx *ctx, DrawArgs &da) {
   da.log_count = &ctx->d_ctr[C].log_count;
 }
 
+// ---- FrameDev::dir bookkeeping ---------------------------------------------------------------------------
+static int fold_direct(lentil_hip_ctx *ctx, uint64_t p_begin, uint64_t p_end, bool all) {
+  if (!ctx->F.dir) return LENTIL_OK;
+  if (p_end > p_begin) {
+    uint64_t blocks = ((p_end - p_begin) * (ctx->F.stride / 4) + 255) / 256;
+    const uint64_t max_blocks = (uint64_t)ctx->num_cu * 8;
+    if (blocks > max_blocks) blocks = max_blocks;
+    hipLaunchKernelGGL(fold_direct_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, ctx->F, ctx->d_dir, p_begin, p_end);
+    HIP_TRY(ctx, hipGetLastError());
+  }
+  if (all) { ctx->F.dir = nullptr; ctx->dir_dirty = false; }
+  return LENTIL_OK;
+}
+
+// before the scans of a pass: `region` is what scan_dma_kernel is about to store (null: another scan kernel runs)
+static int prepare_direct(lentil_hip_ctx *ctx, const lentil_hip_ctx::DirRegion *region) {
+  int rc;
+  // a second pass into the same frame: what the first one stored becomes part of `acc`
+  if (ctx->F.dir && (rc = fold_direct(ctx, 0, ctx->F.np, true))) return rc;
+  if (ctx->dir_dirty && !(region && *region == ctx->dir_region)) {
+    // left over from a cleared frame and not about to be overwritten pixel for pixel: wipe its rows
+    const lentil_hip_ctx::DirRegion &r = ctx->dir_region;
+    const uint64_t rows = r.ppr ? (r.npix + r.ppr - 1) / r.ppr : 0;
+    uint64_t row_lo = (uint64_t)(r.y0 < 0 ? 0 : r.y0);
+    uint64_t row_hi = rows ? row_lo + (rows - 1) * (r.row_stride ? r.row_stride : 1) + 1 : row_lo;
+    if (row_hi > ctx->P.yres) row_hi = ctx->P.yres;
+    if (row_hi > row_lo)
+      HIP_TRY(ctx, hipMemsetAsync(ctx->d_dir + row_lo * ctx->P.xres * ctx->F.stride, 0,
+                                  (row_hi - row_lo) * ctx->P.xres * ctx->F.stride * sizeof(float), ctx->stream));
+    ctx->dir_dirty = false;
+  }
+  if (region) {
+    if (!ctx->d_dir) {
+      const uint64_t nfl = ctx->F.np * ctx->F.stride;
+      HIP_TRY(ctx, hipMalloc(&ctx->d_dir, nfl * sizeof(float)));
+      HIP_TRY(ctx, hipMemsetAsync(ctx->d_dir, 0, nfl * sizeof(float), ctx->stream));
+    }
+    ctx->F.dir = ctx->d_dir;
+    ctx->dir_dirty = true;
+    ctx->dir_region = *region;
+  }
+  return LENTIL_OK;
+}
+
 // How the bound visit stream is scanned: kernel, tile size, LDS.
 struct ScanPlan {
   ScanArgs sa{};
   size_t lds = 0;
   uint64_t n_tiles = 0;
   bool multi = false;
+  bool dma = false;       // scan_dma_kernel (beauty only, uniform weights)
   uint32_t M = 0;
 };
 
@@ -955,9 +1016,27 @@ static int plan_scan(lentil_hip_ctx *ctx, ScanPlan &pl) {
       const size_t wave_f4 = (size_t)ctx->F.n_aovs * kMultiPlane + 16 + (size_t)ppt * (ctx->F.stride / 4);
       pl.lds = 4 * wave_f4 * 16 + 4 * kWaveQueueLds * sizeof(uint2);
     }
+    const size_t dma_lds = (size_t)4 * dma_wave_f4(M) * 16 + 4 * kWaveQueueLds * sizeof(uint2);
+    pl.dma = ctx->scan_dma && ctx->V.n_extra == 0 && !ctx->V.inv_density && !ctx->F.zkey && !ctx->F.zkey_dbg &&
+             ctx->V.n % M == 0 && dma_lds <= 80u * 1024u;
+    if (pl.dma) {
+      ppt = 64;
+      sa.ppt = ppt;
+      sa.tv_pad = ppt * M;
+      pl.lds = dma_lds;
+      pl.multi = false;
+    }
     const uint64_t n_pixels = (ctx->V.n + M - 1) / M;
     pl.n_tiles = (n_pixels + ppt - 1) / ppt;
   }
+  lentil_hip_ctx::DirRegion reg;
+  if (pl.dma) {
+    reg.x0 = ctx->V.pixel_x0; reg.y0 = ctx->V.pixel_y0; reg.row_stride = ctx->V.pixel_row_stride; reg.ppr = ctx->V.pixels_per_row;
+    reg.npix = ctx->V.n / M;
+  }
+  const int rc = prepare_direct(ctx, pl.dma ? &reg : nullptr);
+  if (rc) return rc;
+  sa.F = ctx->F;
   return LENTIL_OK;
 }
 
@@ -972,7 +1051,15 @@ static int launch_scan(lentil_hip_ctx *ctx, const ScanPlan &pl, const lentil_hip
   sa.v_begin = ch.v_begin; sa.v_end = ch.v_end;
   const uint64_t max_blocks = (uint64_t)ctx->num_cu * 8;
   uint64_t blocks;
-  if (pl.M) {
+  if (pl.dma) {
+    // persistent: two blocks per CU (LDS), every wave draws four tiles at a time
+    blocks = (ch.tile_end - ch.tile_begin + 15) / 16;
+    uint64_t per_cu = 2;
+    if (const char *e = getenv("LENTIL_DMA_BLOCKS")) per_cu = strtoull(e, nullptr, 10);
+    if (blocks > (uint64_t)ctx->num_cu * per_cu) blocks = (uint64_t)ctx->num_cu * per_cu;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(scan_dma_kernel, dim3((unsigned)blocks), dim3(256), pl.lds, ctx->stream, sa);
+  } else if (pl.M) {
     blocks = (ch.tile_end - ch.tile_begin + 3) / 4;
     if (blocks > max_blocks) blocks = max_blocks;
     if (pl.multi) hipLaunchKernelGGL(scan_uniform_multi_kernel, dim3((unsigned)blocks), dim3(256), pl.lds, ctx->stream, sa);
@@ -1063,6 +1150,7 @@ static int redistribute_streamed(lentil_hip_ctx *ctx, bool *streamed) {
   plan.sa.ranges = ctx->d_ranges;
   plan.sa.range_cap = (uint32_t)(ctx->range_cap < 0xFFFFFFF0ull ? ctx->range_cap : 0xFFFFFFF0ull);
   plan.sa.epoch = ctx->epoch;
+  plan.sa.end_ranges = (uint32_t)ctx->publish_waves;
   plan.sa.flush_each_tile = ctx->est_items_total < (1u << 16) ? 1u : 0u;
   pa.ctr = ctx->d_ctr;
   pa.work = ctx->d_work;
@@ -1080,20 +1168,9 @@ static int redistribute_streamed(lentil_hip_ctx *ctx, bool *streamed) {
   da.epoch = ctx->epoch;
   if (!few) da.slow = nullptr;              // parking is for passes with few draws (DrawArgs::slow_below)
 
-  // scan grid first: the solve waves need to know how many blocks will sign off
-  unsigned scan_blocks;
-  {
-    const uint64_t max_blocks = (uint64_t)ctx->num_cu * 8;
-    uint64_t b = plan.M ? (plan.n_tiles + 3) / 4 : (ctx->V.n + 255) / 256;
-    if (b > max_blocks) b = max_blocks;
-    scan_blocks = (unsigned)b;
-  }
-  pa.scan_blocks_total = scan_blocks;
-  da.publishers_total = (uint32_t)ctx->publish_waves;
-
-  unsigned launched_blocks = 0;
-  if ((rc = launch_scan(ctx, plan, ch, ctx->d_ctr, &launched_blocks))) return rc;
-  if (launched_blocks != scan_blocks) return fail(ctx, LENTIL_ERR_HIP, "streamed pass: scan grid mismatch");
+  unsigned scan_blocks = 0;
+  if ((rc = launch_scan(ctx, plan, ch, ctx->d_ctr, &scan_blocks))) return rc;
+  (void)scan_blocks;
   ctx->last_scan_launches = 1;
   HIP_TRY(ctx, hipEventRecord(ch.scanned, ctx->stream));
   HIP_TRY(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
@@ -1103,25 +1180,30 @@ static int redistribute_streamed(lentil_hip_ctx *ctx, bool *streamed) {
   // ev[0]).  Submitted AFTER what they wait for -- the scan, then the publishers: should the streams share a
   // hardware queue, each finds its producer ahead of it there.
   const unsigned a_blocks = (unsigned)ctx->num_cu * (unsigned)ctx->stream_blocks;
+  unsigned b_blocks;
+  {
+    int b_per_cu = ctx->solve_max_blocks - ctx->stream_blocks;
+    if (b_per_cu < 1) b_per_cu = 1;
+    const uint64_t want = (nch * (ctx->est_sum_total / 64 + ctx->est_items_total) + 3) / 4;
+    uint64_t b = (uint64_t)ctx->num_cu * (uint64_t)b_per_cu;
+    if (want < b) b = want < 1 ? 1 : want;
+    b_blocks = (unsigned)b;
+  }
+  pa.end_tasks = (a_blocks + b_blocks) * 4u;       // every first-round solve wave may hold one ticket past the last task
   HIP_TRY(ctx, hipStreamWaitEvent(ctx->pub_stream, ctx->ev[0], 0));
   hipLaunchKernelGGL(publish_kernel, dim3((unsigned)ctx->publish_waves), dim3(64), 0, ctx->pub_stream, pa);
   HIP_TRY(ctx, hipGetLastError());
   HIP_TRY(ctx, hipEventRecord(ctx->pub_done, ctx->pub_stream));
   HIP_TRY(ctx, hipStreamWaitEvent(ch.stream, ctx->ev[0], 0));
+  da.instance = 0;
   launch_solve_po<true>(ctx, da, ch.stream, a_blocks);
   HIP_TRY(ctx, hipGetLastError());
   HIP_TRY(ctx, hipEventRecord(ch.done, ch.stream));
 
   // B: the rest of the CUs' room, once the scan's waves have left
-  int b_per_cu = ctx->solve_max_blocks - ctx->stream_blocks;
-  if (b_per_cu < 1) b_per_cu = 1;
-  {
-    const uint64_t want = (nch * (ctx->est_sum_total / 64 + ctx->est_items_total) + 3) / 4;
-    uint64_t b = (uint64_t)ctx->num_cu * (uint64_t)b_per_cu;
-    if (want < b) b = want < 1 ? 1 : want;
-    launch_solve_po<true>(ctx, da, ctx->stream, (unsigned)b);
-    HIP_TRY(ctx, hipGetLastError());
-  }
+  da.instance = 1;
+  launch_solve_po<true>(ctx, da, ctx->stream, b_blocks);
+  HIP_TRY(ctx, hipGetLastError());
   HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ch.done, 0));
   HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->pub_done, 0));
   launch_slow(ctx, da, ctx->stream);
@@ -1144,8 +1226,21 @@ static int redistribute_streamed(lentil_hip_ctx *ctx, bool *streamed) {
   ctx->h_ctr.assign(ctx->h_ctr_pinned, ctx->h_ctr_pinned + C);
   ctx->h_ctr_valid = true;
   ctx->last_streamed = 1;
+  ++ctx->last_blind;
   const DevCounters c = ctx->h_ctr[0];
   ch.was_blind = true;
+  if (getenv("LENTIL_STREAM_DEBUG"))
+    fprintf(stderr, "[stream] A: solves %llu start %.1f first-task %.1f | B: solves %llu start %.1f first-task %.1f | last wave end %.1f (us after A's first wave)\n",
+            c.dbg[1], 0.0, ((double)c.dbg[3] - (double)c.dbg[2]) / 100.0, c.dbg[4], ((double)c.dbg[5] - (double)c.dbg[2]) / 100.0,
+            ((double)c.dbg[6] - (double)c.dbg[2]) / 100.0, ((double)c.dbg[0] - (double)c.dbg[2]) / 100.0);
+  if (getenv("LENTIL_STREAM_DEBUG")) {
+    fprintf(stderr, "[stream] A: mean clock %.0f MHz, %.2f us per wave-iteration (wave lifetime / rounds)\n",
+            c.dbg[45] ? (double)c.dbg[44] / (double)c.dbg[45] * 100.0 : 0.0, c.dbg[46] ? (double)c.dbg[45] / 100.0 / (double)c.dbg[46] : 0.0);
+    fprintf(stderr, "[stream] wave exits per 100 us:");
+    for (int i = 0; i < 32; ++i) fprintf(stderr, " %llu", c.dbg[8 + i]);
+    fprintf(stderr, " | max k (lane 0 sample) %llu parked %llu slow %llu | last publisher off %.1f last scan block off %.1f pubs %u scanblocks %u ranges %u/%u tasks %u/%u\n", c.dbg[40], c.dbg[41], c.slow_solves,
+            ((double)c.dbg[42] - (double)c.dbg[2]) / 100.0, ((double)c.dbg[43] - (double)c.dbg[2]) / 100.0, c.publishers_done, c.scan_blocks_done, c.range_head, c.n_ranges, c.task_head[0], c.n_tasks[0]);
+  }
   if (c.stuck) return fail(ctx, LENTIL_ERR_HIP, "streamed pass: a wave gave up waiting for its queue slot (LENTIL_STREAM=0 selects the chunked pass)");
   if (c.fallback) {
     // did not fit: nothing was accepted.  Fresh queues, then the draws again the plain way, sized from the counters
@@ -1163,7 +1258,6 @@ static int redistribute_streamed(lentil_hip_ctx *ctx, bool *streamed) {
     ch.est_rounds = rounds;
     ctx->last_rounds = rounds;
   } else {
-    ++ctx->last_blind;
     const uint64_t n_items = c.work_count < ctx->V.n ? c.work_count : ctx->V.n;
     ch.have_est = true; ch.est_items = n_items; ch.est_sum = c.sum_samples; ch.est_rounds = (int)c.rounds_used;
     if (c.tries) ctx->mean_iters = (double)c.newton_iters / (double)c.tries;
@@ -1202,6 +1296,8 @@ LENTIL_API int lentil_hip_redistribute(lentil_hip_ctx *ctx) {
   if (ctx->pass_pending) ctx->dirty_known = false;   // an earlier pass's rows were never asked for: unknown until a full clear
   ctx->pass_pending = true;
   HIP_TRY(ctx, hipMemsetAsync(ctx->d_ctr, 0, sizeof(DevCounters) * (C + 1), ctx->stream));
+  HIP_TRY(ctx, hipMemsetAsync((char *)ctx->d_ctr + offsetof(DevCounters, dbg) + 16, 0xFF, 16, ctx->stream));
+  HIP_TRY(ctx, hipMemsetAsync((char *)ctx->d_ctr + offsetof(DevCounters, dbg) + 40, 0xFF, 16, ctx->stream));
   HIP_TRY(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
   ctx->last_rounds = 0;
   ctx->h_ctr_valid = false;
@@ -1314,6 +1410,7 @@ LENTIL_API int lentil_hip_redistribute(lentil_hip_ctx *ctx) {
         // the empty rounds left their queue cursors behind: fresh queues, then the chunk again with exact sizes
         HIP_TRY(ctx, hipMemsetAsync((char *)(ctx->d_ctr + ci) + offsetof(DevCounters, n_tasks), 0,
                                     offsetof(DevCounters, inv_row_min) - offsetof(DevCounters, n_tasks), ch.stream));
+        HIP_TRY(ctx, hipMemsetAsync((char *)(ctx->d_ctr + ci) + offsetof(DevCounters, fallback), 0, sizeof(unsigned long long), ch.stream));
         const int rc = enqueue_chunk_draws(ctx, ci, das[ci], blind_rounds);
         if (rc) return rc;
         rounds_of[ci] = blind_rounds;
@@ -1439,6 +1536,7 @@ LENTIL_API int lentil_hip_pack_rows(lentil_hip_ctx *ctx, uint32_t row_begin, uin
   if (!dev_dst) return fail(ctx, LENTIL_ERR_INVALID, "dev_dst is null");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   const uint64_t p_begin = (uint64_t)row_begin * ctx->P.xres, n_pix = (uint64_t)n_rows * ctx->P.xres;
+  if ((rc = fold_direct(ctx, p_begin, p_begin + n_pix, false))) return rc;
   uint64_t blocks = (n_pix * (4ull * ctx->F.n_aovs + 1ull) + 255) / 256;
   const uint64_t max_blocks = (uint64_t)ctx->num_cu * 8;
   if (blocks > max_blocks) blocks = max_blocks;
@@ -1463,6 +1561,7 @@ LENTIL_API int lentil_hip_compact_rows(lentil_hip_ctx *ctx, uint32_t row_begin, 
   if (ctx->F.debug_mask) return fail(ctx, LENTIL_ERR_UNSUPPORTED, "the lentil_debug AOV is not exchanged between GPUs");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   const uint64_t p_begin = (uint64_t)row_begin * ctx->P.xres, n_pix = (uint64_t)n_rows * ctx->P.xres;
+  if ((rc = fold_direct(ctx, p_begin, p_begin + n_pix, false))) return rc;
   // the shared slot of the counter block (draw-log cursor) is free between passes
   unsigned int *d_count = reinterpret_cast<unsigned int *>(&ctx->d_ctr[ctx->n_chunks].overflow);
   HIP_TRY(ctx, hipMemsetAsync(d_count, 0, sizeof(unsigned int), ctx->stream));
@@ -1619,6 +1718,10 @@ LENTIL_API int lentil_hip_download_accum(lentil_hip_ctx *ctx, uint32_t aov, floa
   if (!ctx->have_frame || aov >= ctx->F.n_aovs) return fail(ctx, LENTIL_ERR_INVALID, "bad download_accum arguments");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   // debugging / test path: fetch the interleaved pixel records and pick the requested columns on the host
+  {
+    const int rc = fold_direct(ctx, 0, ctx->F.np, true);
+    if (rc) return rc;
+  }
   const uint64_t np = ctx->F.np;
   const uint32_t rec = ctx->F.stride;
   std::vector<float> tmp(np * rec);
@@ -1634,6 +1737,10 @@ LENTIL_API int lentil_hip_download_accum(lentil_hip_ctx *ctx, uint32_t aov, floa
 LENTIL_API int lentil_hip_accum_buffer(lentil_hip_ctx *ctx, void **device_ptr, uint64_t *n_floats) {
   CHECK_CTX(ctx);
   if (!ctx->have_frame || !device_ptr || !n_floats) return fail(ctx, LENTIL_ERR_INVALID, "bad accum_buffer arguments");
+  {
+    const int rc = fold_direct(ctx, 0, ctx->F.np, true);      // the caller reduces `acc` across GPUs
+    if (rc) return rc;
+  }
   *device_ptr = ctx->F.acc;
   *n_floats = ctx->F.np * ctx->F.stride;
   return LENTIL_OK;

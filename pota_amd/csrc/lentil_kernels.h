@@ -45,7 +45,8 @@ struct DevCounters {
   // streamed pass: scan blocks that have published everything they found (solve_po_kernel<.., kStream> polls it)
   unsigned int scan_blocks_done, publishers_done;
   unsigned int n_ranges, range_head;   // work-list ranges the scan has handed to publish_kernel / tickets drawn on them
-  unsigned int stuck, stream_pad;      // a wave gave up waiting for its queue slot (kStuckTicks): the pass is void
+  unsigned long long dbg[48];           // LENTIL_STREAM_DEBUG: per solve-kernel instance: solves started, first wave start, first task (100 MHz ticks)
+  unsigned int stuck, tile_next;       // a wave gave up waiting for its queue slot (kStuckTicks): the pass is void; scan_dma_kernel's tile cursor
 };
 
 // per-thread running row range -> one pair of atomics per wave
@@ -101,6 +102,11 @@ struct FrameDev {
   // issue its fp32 atomics "transposed" (consecutive lanes = consecutive floats of one record): the
   // memory side executes atomics per 64-B request, and a draw then costs 1-3 requests instead of 5-37.
   float *acc;        // [np][stride]
+  // What scan_dma_kernel adds up for a pixel out of its own visits (same record layout): stored whole, never read
+  // by the scan and never touched by a splat, so that the accept kernel's atomics on `acc` may run while the scan
+  // still does.  The resolve adds the two; anything else that looks at the accumulators folds `dir` into `acc`
+  // first (fold_direct_kernel).  Null while it holds nothing.
+  float *dir;
   uint32_t stride;   // floats per record
   // closest-filter AOVs (src/lentil.h:832-837): per pixel the winning candidate as one 64-bit key,
   // (bits of |Z|) << 32 | (0xFFFFFFFF - visit), reduced with atomicMin: smallest depth wins, equal depths
@@ -119,10 +125,12 @@ LD_DEV unsigned long long closest_key(float depth, uint32_t visit) {
   return ((unsigned long long)__float_as_uint(fabsf(depth)) << 32) | (unsigned long long)(0xFFFFFFFFu - visit);
 }
 
-struct ItemHdr {          // 32 B, written by prep_items_kernel
+struct ItemHdr {          // written by prep_items_kernel / publish_item; a 128-byte line of its own (streamed pass: never
+                          // in an L2 before it is written)
   double tx, ty, tz;      // PO: -P_cs * 10 (src/lentil_filter.cpp:271); thin lens: P_cs (floats, exactly)
   uint32_t seed_a;        // (unsigned)(px*py+px)
   int32_t px_py;          // px | py << 16
+  uint32_t pad[24];
 };
 
 struct ItemProg {         // 32 B, progress of an item across rounds
@@ -144,10 +152,11 @@ struct Task {             // up to 64 consecutive m of one item (and one wavelen
 // Streamed pass: the scan kernels publish every item they find -- header, progress record and the solve
 // tasks of its first batch -- themselves, while they run; persistent waves of solve_po_kernel<.., kStream>
 // draw tickets on the task queue and poll their slot.  Hand-off between CUs without fences
-// (MI355X_MICROARCH.md, "Valid forms"): every handed-off byte is stored write-through (agent-scope relaxed
-// store = global_store sc1) and waited for (vmcnt(0)) before the word that publishes it, and read with agent-scope
-// loads (sc1, past the reader's L1).  A task slot is valid when its tag equals this pass's epoch, so the queue is
-// never cleared.
+// (MI355X_MICROARCH.md, "Valid forms", 8-byte granules): every handed-off byte is stored write-through (agent-scope
+// relaxed store = global_store sc1) and waited for (vmcnt(0)) before the word that publishes it, and read with a
+// returning atomic (ld_coherent64).  A slot is valid when its tag equals this pass's epoch, so the queues are never
+// cleared; the end of a queue is a run of end markers behind its last entry, one for every wave that may hold a
+// ticket: nobody polls a shared word.
 // ---------------------------------------------------------------------------------------
 struct StreamPub {
   uint32_t epoch;              // 22 bits, never 0
@@ -165,12 +174,25 @@ struct StreamPub {
 LD_DEV void st_agent64(void *p, uint64_t v) {
   __hip_atomic_store(reinterpret_cast<uint64_t *>(p), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-LD_DEV uint64_t ld_agent64(const void *p) {
-  return __hip_atomic_load(reinterpret_cast<const uint64_t *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+// Reads of words another CU writes while this kernel runs are returning atomics (x | 0), not loads: an agent-scope
+// load (sc1) goes past this CU's L1 but is served by this XCD's L2, which may hold the line from before the other
+// XCD wrote it through -- measured: end-of-queue words polled with sc1 loads were seen 0.4-0.9 ms late once the
+// scan's traffic no longer swept the L2s.  Atomics execute at the memory side (MI355X_MICROARCH.md).
+// (in assembly: the optimiser turns a relaxed `x | 0` into an atomic load, volatile or not)
+LD_DEV uint64_t ld_coherent64(const void *p) {
+  uint64_t old;
+  const uint64_t zero = 0ull;
+  asm volatile("global_atomic_or_x2 %0, %1, %2, off sc0\n\ts_waitcnt vmcnt(0)" : "=&v"(old) : "v"(p), "v"(zero) : "memory");
+  return old;
 }
-LD_DEV uint32_t ld_agent32(const void *p) {
-  return __hip_atomic_load(reinterpret_cast<const uint32_t *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+LD_DEV uint32_t ld_coherent32(const void *p) {
+  uint32_t old;
+  const uint32_t zero = 0u;
+  asm volatile("global_atomic_or %0, %1, %2, off sc0\n\ts_waitcnt vmcnt(0)" : "=&v"(old) : "v"(p), "v"(zero) : "memory");
+  return old;
 }
+constexpr uint32_t kEndCount = 0xFFu;       // Task::count of the end-of-queue markers behind the last task
+constexpr uint32_t kEndRange = 0x3FFu;      // ... and the count field of the end markers of the range queue
 // every wait on a queue slot is bounded: 3 s of the 100 MHz real-time counter, then DevCounters::stuck
 constexpr uint64_t kStuckTicks = 300000000ull;
 constexpr uint32_t kTaskTagShift = 10;    // Task::count bits 10..31: epoch of the pass that published the slot
@@ -190,6 +212,7 @@ struct ScanArgs {
   // streamed pass: every flush of a wave queue is announced to publish_kernel as a (first item, count) range
   uint64_t *ranges;                // null: not a streamed pass
   uint32_t range_cap, epoch;
+  uint32_t end_ranges;             // waves of publish_kernel: end markers behind the last range
   uint32_t flush_each_tile;        // announce at the end of every tile (few items per pass: latency matters, atomics do not)
 };
 
@@ -237,7 +260,7 @@ LD_DEV ItemVisit load_work_visit(const lentil_params &P, const VisitsDev &V, uin
 }
 
 LD_DEV ItemHdr make_item_hdr(const lentil_params &P, const float cs[3], int px, int py) {
-  ItemHdr hd;
+  ItemHdr hd{};
   if (P.cameraType == LENTIL_POLYNOMIAL_OPTICS) {
     hd.tx = -(double)cs[0] * 10.0; hd.ty = -(double)cs[1] * 10.0; hd.tz = -(double)cs[2] * 10.0;
   } else {
@@ -417,9 +440,17 @@ struct WaveQueue {
 // streamed pass: the last thing a scan block does -- after every wave's items and tasks have arrived
 LD_DEV void scan_block_done(const ScanArgs &a) {
   if (!a.ranges) return;
+  __shared__ uint32_t s_last;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  if (threadIdx.x == 0) atomicAdd(&a.ctr->scan_blocks_done, 1u);
+  if (threadIdx.x == 0) s_last = atomicAdd(&a.ctr->scan_blocks_done, 1u) == gridDim.x - 1u ? 1u : 0u;
+  __syncthreads();
+  if (!s_last) return;
+  // the last block to sign off: the range queue is complete.  One end marker for every publisher wave.
+  const uint32_t n = ld_coherent32(&a.ctr->n_ranges);
+  for (uint32_t i = threadIdx.x; i < a.end_ranges; i += blockDim.x)
+    if ((uint64_t)n + i < a.range_cap)
+      st_agent64(a.ranges + n + i, (uint64_t)(kEndRange | (a.epoch << kTaskTagShift)) << 32);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -574,6 +605,161 @@ __global__ __launch_bounds__(256) void scan_uniform_kernel(ScanArgs a) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
     __builtin_amdgcn_wave_barrier();
     wq.end_tile(a);
+  }
+  wq.finish(a);
+  scan_block_done(a);
+}
+
+// ---------------------------------------------------------------------------------------
+// K1+K2+K6 for beauty-only frames with a uniform footprint -- the LDS-DMA form.  The register-staged kernel
+// above keeps its bytes in flight in VGPRs (104 of them, three waves per SIMD): beside it a SIMD holds ONE wave of
+// the solve kernel (168), which alone runs at 60 % of what two or three reach.  Here the columns go from HBM
+// straight into LDS (global_load_lds_dwordx4, 1 KiB per instruction, no destination registers): two waves per SIMD
+// with up to 18 KiB in flight each, in under 88 VGPRs -- which leaves room for two solve waves.
+//   tile    64 pixels = M groups of 64 visits (M = visits per pixel)
+//   LDS     per wave: the tile's rgba column (M KiB, read again by the ordered sums), a ring of kDmaRing slots for
+//           the three columns the decision reads (3 KiB per group), 64 per-pixel counts of visits that do not add
+//           to their own pixel, the work queue
+//   order   rgba DMAs first, then the ring: vmcnt retires in issue order, so when a ring slot has landed the whole
+//           rgba tile has.  Group g is awaited with s_waitcnt vmcnt(3 x groups issued after it).
+//   sums    lane p adds pixel p's M entries in iterator order (src/lentil.h:938-955) and STORES the record to
+//           FrameDev::dir: nothing is read back, nothing is shared with the splats.
+//   tiles   handed out four at a time from DevCounters::tile_next (blocks are placed as the solve kernels leave
+//           room: a static split would wait for the slowest CU).
+// ---------------------------------------------------------------------------------------
+constexpr uint32_t kDmaRing = 2;      // (3 slots: 79 KB per block at M = 9, two blocks then leave the solve kernel no LDS)
+
+LD_DEV void lds_dma16(const float4 *g, float4 *lds_wave_base) {
+  // 64 lanes x 16 B -> lds_wave_base[lane]; aux 2 = nontemporal (read once)
+  typedef const __attribute__((address_space(1))) void *gptr_t;
+  typedef __attribute__((address_space(3))) void *lptr_t;
+  __builtin_amdgcn_global_load_lds((gptr_t)(const void *)g, (lptr_t)(void *)lds_wave_base, 16, 0, 2);
+}
+
+__host__ __device__ constexpr uint32_t dma_wave_f4(uint32_t M) { return M * 64u + kDmaRing * 192u + 16u; }
+
+// The three columns of one ring slot, lane's visit.  In assembly because hipcc puts s_waitcnt vmcnt(0) in front of
+// every LDS read it can see while an LDS-DMA may be in flight -- which would wait for the groups behind this one too
+// (the caller has waited for exactly this group's DMAs).  The reads are waited for here: the compiler does not
+// track them.
+LD_DEV void lds_read_slot(const float4 *slot_lane, float4 &c0, float4 &c1, float4 &c2) {
+  typedef float v4f __attribute__((ext_vector_type(4)));
+  typedef const __attribute__((address_space(3))) void *lptr_t;
+  const uint32_t addr = (uint32_t)(size_t)(lptr_t)(const void *)slot_lane;
+  v4f x, y, z;
+  asm volatile("ds_read_b128 %0, %3\n\tds_read_b128 %1, %3 offset:1024\n\tds_read_b128 %2, %3 offset:2048\n\ts_waitcnt lgkmcnt(0)"
+               : "=&v"(x), "=&v"(y), "=&v"(z)
+               : "v"(addr)
+               : "memory");
+  c0 = make_float4(x.x, x.y, x.z, x.w);
+  c1 = make_float4(y.x, y.y, y.z, y.w);
+  c2 = make_float4(z.x, z.y, z.z, z.w);
+}
+
+__global__ __launch_bounds__(256) void scan_dma_kernel(ScanArgs a) {
+  extern __shared__ float4 smem[];
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  const VisitsDev &V = a.V;
+  const uint32_t M = V.visits_per_pixel;
+  const uint32_t wave_f4 = dma_wave_f4(M);
+  float4 *srgba = smem + (size_t)wave * wave_f4;                   // [M][64]
+  float4 *ring = srgba + (size_t)M * 64u;                          // [kDmaRing][3][64]
+  uint32_t *nskip = reinterpret_cast<uint32_t *>(ring + kDmaRing * 192u);   // [64]
+  uint2 *qmem = reinterpret_cast<uint2 *>(smem + (size_t)4u * wave_f4);
+  WaveQueue wq;
+  wq.init(qmem + (size_t)wave * kWaveQueueLds);
+
+  // beside solve waves that would issue fp64 arithmetic in every cycle: the scan's few instructions go first
+  __builtin_amdgcn_s_setprio(3);
+  const uint64_t n_pixels = V.n / M;                               // (the host checks that the stream holds whole pixels)
+  const uint64_t n_tiles = a.tile_end;
+  const uint32_t xres = a.P.xres;
+  const float w = 1.0f * a.P.inverse_sample_density;               // filter_weight * inv_density, lentil.h:949-953
+  float4 *dir4 = reinterpret_cast<float4 *>(a.F.dir);
+  const uint64_t v_last = V.n - 1;
+
+  nskip[lane] = 0u;
+  auto issue_ring = [&](uint64_t v0, uint32_t g) {
+    const uint64_t v = v0 + (uint64_t)g * 64u + lane;
+    const uint64_t vl = v < V.n ? v : v_last;                      // lanes past the end re-read the last visit (unused)
+    float4 *slot = ring + (size_t)(g % kDmaRing) * 192u;
+    lds_dma16(V.pos_z + vl, slot);
+    lds_dma16(V.volume_ignore + vl, slot + 64);
+    lds_dma16(V.transmission + vl, slot + 128);
+  };
+
+  while (true) {
+    uint32_t t4 = 0;
+    if (lane == 0) t4 = atomicAdd(&a.ctr->tile_next, 4u);
+    const uint64_t tile4 = a.tile_begin + (uint64_t)__builtin_amdgcn_readfirstlane(t4);
+    if (tile4 >= n_tiles) break;
+    const uint64_t tile4_end = tile4 + 4u < n_tiles ? tile4 + 4u : n_tiles;
+    for (uint64_t tile = tile4; tile < tile4_end; ++tile) {
+      const uint64_t pix0 = tile * 64u;
+      const uint64_t v0 = pix0 * M;
+      for (uint32_t g = 0; g < M; ++g) {
+        const uint64_t v = v0 + (uint64_t)g * 64u + lane;
+        lds_dma16(V.rgba + (v < V.n ? v : v_last), srgba + (size_t)g * 64u);
+      }
+      for (uint32_t g = 0; g < kDmaRing && g < M; ++g) issue_ring(v0, g);
+      for (uint32_t g = 0; g < M; ++g) {
+        // ring groups issued after g's: g+1 .. min(g + kDmaRing - 1, M - 1)
+        const uint32_t behind = (M - 1u - g) < (kDmaRing - 1u) ? (M - 1u - g) : (kDmaRing - 1u);
+        static_assert(kDmaRing <= 3, "one wait form per number of groups in flight behind the awaited one");
+        if (behind >= 2u) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else if (behind == 1u) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        float4 pz, vi, tr;
+        lds_read_slot(ring + (size_t)(g % kDmaRing) * 192u + lane, pz, vi, tr);
+        const uint32_t e = g * 64u + lane;
+        const uint64_t v = v0 + e;
+        const bool valid = v < V.n;
+        bool flagged = false;
+        int samples = 0;
+        if (valid) {
+          flagged = visit_redistributes(a.P, a.lens_length, pz, vi, tr, a.P.inverse_sample_density,
+                                        [&]() { return V.raydir_time[v]; });
+          // a few visits in 10^5: the draw count (same function as the draw kernels use)
+          if (flagged)
+            samples = visit_prologue(a.P, a.lens_length, srgba[e], pz, V.raydir_time[v], vi, tr, a.P.inverse_sample_density).samples;
+        }
+        if (flagged || !valid) {
+          // adds nothing to its own pixel: +0 values (x + (+0) changes no bit, an accumulator is never -0), one weight fewer
+          srgba[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+          atomicAdd(&nskip[e / M], 1u);
+        }
+        wq.push(flagged, (uint32_t)v, (uint32_t)samples, a);
+        if (g + kDmaRing < M) {
+          // the slot's values are in registers (the decision above has used them): refill it
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+          issue_ring(v0, g + kDmaRing);
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
+      const uint64_t pix = pix0 + lane;
+      const uint32_t skipped = nskip[lane];
+      nskip[lane] = 0u;        // for the next tile, here: an LDS access at the top of a tile would wait for this tile's stores
+      if (pix < n_pixels) {
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (uint32_t j = 0; j < M; ++j) {
+          const float4 c = srgba[lane * M + j];
+          s.x += (c.x + 0.0f) * w; s.y += (c.y + 0.0f) * w; s.z += (c.z + 0.0f) * w; s.w += (c.w + 0.0f) * w;
+        }
+        float ws = 0.f;
+        const uint32_t cnt = M - skipped;
+        for (uint32_t j = 0; j < cnt; ++j) ws += w;
+        const int px = V.pixel_x0 + (int)(pix % V.pixels_per_row);
+        const int py = V.pixel_y0 + (int)(pix / V.pixels_per_row) * (int)V.pixel_row_stride;
+        const uint64_t lin = (uint64_t)px + (uint64_t)py * xres;
+        dir4[lin * 2u] = s;
+        dir4[lin * 2u + 1u] = make_float4(ws, 0.f, 0.f, 0.f);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+      __builtin_amdgcn_wave_barrier();
+      wq.end_tile(a);
+    }
   }
   wq.finish(a);
   scan_block_done(a);
@@ -790,8 +976,8 @@ __global__ __launch_bounds__(256) void scan_ragged_kernel(ScanArgs a) {
 // turn every announced work-list entry into an item (publish_item): header, progress record, result space, the
 // first batch's solve tasks.  In a kernel of its own so that the scan's hot loop carries none of it (the scan
 // kernels sit at the SGPR limit; six more VGPRs would cost them a wave per SIMD beside the solve kernel).
-// A wave draws a ticket on the range queue and polls its slot; the queue is complete once every scan block has
-// signed off.  The solve waves, in turn, know the task queue is complete once every publisher has signed off.
+// A wave draws a ticket on the range queue and polls its slot; the last scan block to sign off puts an end marker
+// behind the last range for every publisher, the last publisher one behind the last task for every solve wave.
 // ---------------------------------------------------------------------------------------
 struct PublishArgs {
   lentil_params P;
@@ -802,12 +988,11 @@ struct PublishArgs {
   uint64_t work_cap;
   const uint64_t *ranges;
   uint32_t range_cap;
-  uint32_t scan_blocks_total;
+  uint32_t end_tasks;      // solve waves of the first round (both launches)
 };
 
 __global__ __launch_bounds__(64) void publish_kernel(PublishArgs a) {
   const uint32_t lane = threadIdx.x;
-  uint32_t polls = 0;
   while (true) {
     uint32_t t = 0;
     if (lane == 0) t = atomicAdd(&a.ctr->range_head, 1u);
@@ -815,38 +1000,42 @@ __global__ __launch_bounds__(64) void publish_kernel(PublishArgs a) {
     if (ticket >= a.range_cap) break;
     uint64_t rec = 0;
     bool over = false;
+    uint32_t naps = 1u;
     const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
     while (true) {
-      if (lane == 0) rec = ld_agent64(a.ranges + ticket);
+      if (lane == 0) rec = ld_coherent64(a.ranges + ticket);
       rec = ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(rec >> 32)) << 32) |
             (uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)rec);
       if (((uint32_t)(rec >> 32) >> kTaskTagShift) == a.S.epoch) break;
-      // nothing there (yet).  Every few polls: has the scan ended, and does its queue end before this ticket?
-      if ((polls++ & 3u) == 0u) {
-        uint32_t o = 0;
-        if (lane == 0 && ld_agent32(&a.ctr->scan_blocks_done) >= a.scan_blocks_total)
-          o = ld_agent32(&a.ctr->n_ranges) <= ticket ? 1u : 0u;
-        if (__builtin_amdgcn_readfirstlane(o)) { over = true; break; }
-        if (__builtin_amdgcn_s_memrealtime() - t0 > kStuckTicks) {
-          if (lane == 0) a.ctr->stuck = 1u;
-          over = true;
-          break;
-        }
+      if (__builtin_amdgcn_s_memrealtime() - t0 > kStuckTicks) {
+        if (lane == 0) a.ctr->stuck = 1u;
+        over = true;
+        break;
       }
-      __builtin_amdgcn_s_sleep(32);
+      for (uint32_t i = 0; i < naps; ++i) __builtin_amdgcn_s_sleep(64);      // 2 us, doubling to 15 us
+      if (naps < 8u) naps <<= 1;
     }
     if (over) break;
     const uint32_t base = (uint32_t)rec, n = (uint32_t)(rec >> 32) & ((1u << kTaskTagShift) - 1u);
+    if (n == kEndRange) break;                                  // behind the last range
     for (uint32_t i = lane; i < n; i += 64u) {
       const uint32_t item = base + i;
       if ((uint64_t)item >= a.work_cap) continue;
-      const uint64_t wi = ld_agent64(a.work + item);          // written through by the scan before the range record
+      const uint64_t wi = ld_coherent64(a.work + item);         // written through by the scan before the range record
       publish_item(a.P, a.V, a.S, a.ctr, item, make_uint2((uint32_t)wi, (uint32_t)(wi >> 32)));
     }
   }
   // everything this wave published has arrived (publish_item waits for its stores); sign off
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  if (lane == 0) atomicAdd(&a.ctr->publishers_done, 1u);
+  uint32_t last = 0;
+  if (lane == 0) last = atomicAdd(&a.ctr->publishers_done, 1u) == gridDim.x - 1u ? 1u : 0u;
+  if (!__builtin_amdgcn_readfirstlane(last)) return;
+  // the last publisher: the task queue is complete.  One end marker for every solve wave that may hold a ticket.
+  const uint32_t n = ld_coherent32(&a.ctr->n_tasks[0]);
+  for (uint32_t i = lane; i < a.end_tasks; i += 64u)
+    if ((uint64_t)n + i < a.S.task_cap)
+      st_agent64(reinterpret_cast<uint64_t *>(a.S.tasks0 + n + i) + 1,
+                 (uint64_t)(kEndCount | (a.S.epoch << kTaskTagShift)) << 32);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -929,7 +1118,8 @@ struct DrawArgs {
   int32_t retries;         // vignetting_retries for PO, 0 for the thin lens
   int32_t parity;
   // streamed pass (solve_po_kernel<.., kStream>): tag of this pass's task slots, publish_kernel waves that will sign off
-  uint32_t epoch, publishers_total;
+  uint32_t epoch;
+  uint32_t instance;       // 0: beside the scan, 1: after it (debug statistics)
   // chromatic aberration of the polynomial-optics path (src/lentil_filter.cpp:255-268): three traces per
   // attempt, one wavelength each; n_channels is 1 when abb_chromatic == 0
   int32_t n_channels;
@@ -1036,6 +1226,8 @@ __global__ __launch_bounds__(256) void solve_po_kernel(DrawArgs a) {
   __shared__ DevLens s_k;
   __shared__ DevLens s_kc[kChroma ? 3 : 1];
   __shared__ float s_cdfRow[kMaxBokehRows];
+  __shared__ uint64_t s_hdr[kStream ? 4 : 1][4];      // kStream: per wave, the header of the task being handed out
+  (void)s_hdr;
   if (kTables) {
     const uint32_t nt = a.lens->n_terms;
     for (uint32_t i = threadIdx.x; i < nt; i += blockDim.x) s_terms[i] = a.terms[i];
@@ -1080,7 +1272,18 @@ __global__ __launch_bounds__(256) void solve_po_kernel(DrawArgs a) {
   constexpr uint32_t kNoTicket = 0xFFFFFFFFu;
   uint32_t ticket = kNoTicket, polls = 0;     // kStream: the queue slot this wave is waiting for
   uint64_t ticket_t0 = 0;
-  (void)ticket; (void)polls; (void)ticket_t0;
+  uint32_t idle_naps = 1u;
+  bool dbg_first = true;
+  uint32_t dbg_maxk = 0, dbg_parked = 0;
+  (void)dbg_maxk; (void)dbg_parked;
+  uint64_t dbg_c0 = 0, dbg_r0 = 0;
+  if constexpr (kStream) {
+    if (lane == 0) atomicMin(&a.ctr->dbg[2 + a.instance * 3], (unsigned long long)__builtin_amdgcn_s_memrealtime());
+    dbg_c0 = __builtin_amdgcn_s_memtime(); dbg_r0 = __builtin_amdgcn_s_memrealtime();
+  }
+  (void)dbg_c0; (void)dbg_r0;
+  (void)dbg_first;
+  (void)ticket; (void)polls; (void)ticket_t0; (void)idle_naps;
   // per-lane solve
   bool busy = false, need_init = false;
   uint32_t m = 0, res_idx = 0, seed_a = 0, cur_chan_lane = 0;
@@ -1112,30 +1315,41 @@ __global__ __launch_bounds__(256) void solve_po_kernel(DrawArgs a) {
           }
           if (ticket >= a.task_cap) { no_more = true; break; }
           uint64_t w1 = 0;
-          if (lane == 0) w1 = ld_agent64(reinterpret_cast<const uint64_t *>(tasks + ticket) + 1);
+          if (lane == 0) w1 = ld_coherent64(reinterpret_cast<const uint64_t *>(tasks + ticket) + 1);
           const uint32_t w1_hi = __builtin_amdgcn_readfirstlane((uint32_t)(w1 >> 32));
           if ((w1_hi >> kTaskTagShift) != a.epoch) {
-            // nothing there (yet).  Every few polls: is the queue complete, and does it end before this ticket?
-            if ((polls++ & 3u) == 0u) {
-              uint32_t over = 0;
-              if (lane == 0 && ld_agent32(&a.ctr->publishers_done) >= a.publishers_total)
-                over = ld_agent32(&a.ctr->n_tasks[par]) <= ticket ? 1u : 0u;
-              if (__builtin_amdgcn_readfirstlane(over)) no_more = true;
-              if (__builtin_amdgcn_s_memrealtime() - ticket_t0 > kStuckTicks) {
-                if (lane == 0) a.ctr->stuck = 1u;
-                no_more = true;
-              }
+            // nothing there (yet): back to the solves in flight (an idle wave naps, below)
+            if (__builtin_amdgcn_s_memrealtime() - ticket_t0 > kStuckTicks) {
+              if (lane == 0) a.ctr->stuck = 1u;
+              no_more = true;
             }
             break;
           }
+          if ((w1_hi & 0xFFu) == kEndCount) { no_more = true; break; }      // behind the last task
           uint64_t w0 = 0;
-          if (lane == 0) w0 = ld_agent64(reinterpret_cast<const uint64_t *>(tasks + ticket));
+          if (lane == 0) w0 = ld_coherent64(reinterpret_cast<const uint64_t *>(tasks + ticket));
           cur_item = __builtin_amdgcn_readfirstlane((uint32_t)w0);
           cur_m = __builtin_amdgcn_readfirstlane((uint32_t)(w0 >> 32));
           cur_res = __builtin_amdgcn_readfirstlane((uint32_t)w1);
           cur_left = w1_hi & 0xFFu;
           if (kChroma) cur_chan = (w1_hi >> 8) & 3u;
           ticket = kNoTicket;
+          if (cur_left) {
+            // the item's header, written by a publisher on another CU while this kernel runs: lane 0 fetches it with
+            // atomics and parks it in the wave's LDS slot, where the lanes that take solves of this task pick it up
+            if (lane == 0) {
+              const uint64_t *hp = reinterpret_cast<const uint64_t *>(a.hdr + cur_item);
+              uint64_t *dst = s_hdr[threadIdx.x >> 6];
+              dst[0] = ld_coherent64(hp + 0); dst[1] = ld_coherent64(hp + 1); dst[2] = ld_coherent64(hp + 2); dst[3] = ld_coherent64(hp + 3);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
+          }
+          if (dbg_first) {
+            dbg_first = false;
+            if (lane == 0) atomicMin(&a.ctr->dbg[3 + a.instance * 3], (unsigned long long)__builtin_amdgcn_s_memrealtime());
+          }
           if (cur_left == 0) continue;        // an item that did not fit left empty tasks
         } else {
           uint32_t q = 0;
@@ -1157,12 +1371,12 @@ __global__ __launch_bounds__(256) void solve_po_kernel(DrawArgs a) {
         m = cur_m + j;
         res_idx = cur_res + j;
         if constexpr (kStream) {
-          // written by a scan block on another CU during this launch: past this CU's L1
-          const uint64_t *hp = reinterpret_cast<const uint64_t *>(a.hdr + cur_item);
-          target[0] = __longlong_as_double((long long)ld_agent64(hp + 0));
-          target[1] = __longlong_as_double((long long)ld_agent64(hp + 1));
-          target[2] = __longlong_as_double((long long)ld_agent64(hp + 2));
-          seed_a = (uint32_t)ld_agent64(hp + 3);
+          // written by a publisher on another CU during this launch (wave-uniform: hdr_* were fetched with the task)
+          const uint64_t *hs = s_hdr[threadIdx.x >> 6];
+          target[0] = __longlong_as_double((long long)hs[0]);
+          target[1] = __longlong_as_double((long long)hs[1]);
+          target[2] = __longlong_as_double((long long)hs[2]);
+          seed_a = (uint32_t)hs[3];
         } else {
           const ItemHdr hd = a.hdr[cur_item];
           target[0] = hd.tx; target[1] = hd.ty; target[2] = hd.tz;
@@ -1176,9 +1390,14 @@ __global__ __launch_bounds__(256) void solve_po_kernel(DrawArgs a) {
     }
     if (inflight + filled == 0u) {
       if (!kStream || no_more) break;
-      __builtin_amdgcn_s_sleep(64);          // ~1.5 us: an idle wave polls its slot, nothing else
+      // An idle wave polls its slot, nothing else -- and rarely: a thousand waves asking every microsecond keep the
+      // L2 channel that holds the queue busy enough to hold up every DMA group of the scan that touches it
+      // (measured: scan 0.95 -> 2.6 ms beside 1024 idle waves polling every ~2 us).  4 us, doubling to 30 us.
+      for (uint32_t i = 0; i < idle_naps; ++i) __builtin_amdgcn_s_sleep(127);
+      if (idle_naps < 8u) idle_naps <<= 1;
       continue;
     }
+    idle_naps = 1u;
 
     // aperture draw of the reference's try with seed (seed_a, m), src/lentil.h:596-609
     if (busy && need_init) {
@@ -1193,6 +1412,7 @@ __global__ __launch_bounds__(256) void solve_po_kernel(DrawArgs a) {
     if (busy && !newton_continue(s)) {
       res[res_idx] = solve_result(P, L, s);
       busy = false;
+      if (kStream) { const uint32_t kk = (uint32_t)__builtin_amdgcn_readfirstlane(s.k); dbg_maxk = kk > dbg_maxk ? kk : dbg_maxk; }
     }
     // Stragglers: about one solve in a thousand is still running after slow_at iterations and may need all 100.
     // Park its loop state for solve_slow_kernel (a whole wave per solve, ~4x less time per iteration) instead of
@@ -1217,6 +1437,7 @@ __global__ __launch_bounds__(256) void solve_po_kernel(DrawArgs a) {
           uint32_t *u = reinterpret_cast<uint32_t *>(d + 11);
           u[0] = (uint32_t)s.k; u[1] = (uint32_t)s.error; u[2] = res_idx; u[3] = kChroma ? cur_chan_lane : 0u;
           busy = false;
+          ++dbg_parked;
         }
       }
     }
@@ -1230,6 +1451,22 @@ __global__ __launch_bounds__(256) void solve_po_kernel(DrawArgs a) {
   if (lane == 0) {
     if (it64) atomicAdd(&a.ctr->newton_iters, it64);
     if (tr64) atomicAdd(&a.ctr->tries, tr64);
+    if (kStream && tr64) atomicAdd(&a.ctr->dbg[1 + a.instance * 3], tr64);
+    if (kStream) {
+      const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+      atomicMax(&a.ctr->dbg[0], now);
+      const unsigned long long t0 = a.ctr->dbg[2];
+      unsigned long long b = now > t0 ? (now - t0) / 10000ull : 0ull;      // 100 us buckets
+      if (b > 31ull) b = 31ull;
+      atomicAdd(&a.ctr->dbg[8 + b], 1ull);
+      atomicMax(&a.ctr->dbg[40], (unsigned long long)dbg_maxk);
+      if (a.instance == 0) {
+        atomicAdd(&a.ctr->dbg[44], (unsigned long long)(__builtin_amdgcn_s_memtime() - dbg_c0));
+        atomicAdd(&a.ctr->dbg[45], (unsigned long long)(now - dbg_r0));
+        atomicAdd(&a.ctr->dbg[46], (unsigned long long)st_rounds);
+      }
+      atomicAdd(&a.ctr->dbg[41], (unsigned long long)dbg_parked);
+    }
     if (rd64) atomicAdd(&a.ctr->lane_rounds, rd64);
   }
 }
@@ -1959,6 +2196,25 @@ __global__ __launch_bounds__(256) void merge_keys_kernel(FrameDev F, uint64_t p_
   }
 }
 
+// FrameDev::dir -> FrameDev::acc for a range of pixels (and zero there): for everything but the resolve that looks at
+// the accumulators (downloads, the exchange between GPUs, a second pass into the same frame)
+__global__ __launch_bounds__(256) void fold_direct_kernel(FrameDev F, float *dir, uint64_t p_begin, uint64_t p_end) {
+  const uint32_t q = F.stride >> 2;
+  float4 *acc4 = reinterpret_cast<float4 *>(F.acc);
+  float4 *dir4 = reinterpret_cast<float4 *>(dir);
+  const uint64_t i0 = p_begin * q, i1 = p_end * q;
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (uint64_t i = i0 + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < i1; i += stride) {
+    const float4 d = dir4[i];
+    if (d.x != 0.0f || d.y != 0.0f || d.z != 0.0f || d.w != 0.0f) {
+      float4 a = acc4[i];
+      a.x += d.x; a.y += d.y; a.z += d.z; a.w += d.w;
+      acc4[i] = a;
+      dir4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+}
+
 // K7 -- driver_process_bucket's normalisation, src/lentil_imager.cpp:169-186.  Reads the pixel records,
 // writes one planar RGBA image per AOV (what the imager copies into Arnold's buckets).
 __global__ __launch_bounds__(256) void resolve_kernel(FrameDev F, float *resolved, uint64_t p_begin, uint64_t p_end) {
@@ -1973,11 +2229,21 @@ __global__ __launch_bounds__(256) void resolve_kernel(FrameDev F, float *resolve
   const uint64_t wave_global = (uint64_t)blockIdx.x * (blockDim.x >> 6) + wave;
   const uint64_t wave_stride = (uint64_t)gridDim.x * (blockDim.x >> 6);
   const float4 *acc4 = reinterpret_cast<const float4 *>(F.acc);
+  const float4 *dir4 = reinterpret_cast<const float4 *>(F.dir);
   for (uint64_t t = wave_global; t < n_tiles; t += wave_stride) {
     const uint64_t p0 = p_begin + t * 64ull;
     const uint32_t n_pix = (uint32_t)((p_end - p0) < 64ull ? (p_end - p0) : 64ull);
     const uint32_t n4 = n_pix * q;
-    for (uint32_t i = lane; i < n4; i += 64u) tile[i] = acc4[p0 * q + i];
+    if (dir4) {
+      // what the pixels' own visits added (scan_dma_kernel) + what was splatted: a pixel that received no draw has a
+      // zero record in `acc`, and 0 + x is x bit for bit (the scan's sums are never -0)
+      for (uint32_t i = lane; i < n4; i += 64u) {
+        const float4 a = acc4[p0 * q + i], d = dir4[p0 * q + i];
+        tile[i] = make_float4(a.x + d.x, a.y + d.y, a.z + d.z, a.w + d.w);
+      }
+    } else {
+      for (uint32_t i = lane; i < n4; i += 64u) tile[i] = acc4[p0 * q + i];
+    }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
