@@ -4,6 +4,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -43,6 +44,9 @@ struct lentil_hip_ctx {
   // it may hold non-zeros at all, and the pixels of the stream that wrote them
   float *d_dir = nullptr;
   bool dir_dirty = false;
+  // FrameDev::touched (see there): the allocation; F.touched is set while it is trusted
+  uint8_t *d_touched = nullptr;
+  bool cleared_since_pass = false;     // clear_frame / alloc_frame, and no redistribute since
   struct DirRegion {
     int32_t x0 = 0, y0 = 0; uint32_t row_stride = 0, ppr = 0; uint64_t npix = 0;
     bool operator==(const DirRegion &o) const { return x0 == o.x0 && y0 == o.y0 && row_stride == o.row_stride && ppr == o.ppr && npix == o.npix; }
@@ -100,7 +104,7 @@ struct lentil_hip_ctx {
   // Streamed pass (polynomial optics, from the second pass of a context on): one scan launch that publishes its items
   // and their first-batch tasks itself, persistent solve waves that follow the task queue while the scan runs.
   bool stream_mode = true;                   // LENTIL_STREAM=0: chunked passes only
-  int stream_blocks = 1;                     // LENTIL_STREAM_BLOCKS: solve blocks per CU beside the scan
+  int stream_blocks = 2;                     // LENTIL_STREAM_BLOCKS: solve blocks per CU beside the scan (1 or 2)
   uint32_t epoch = 0;                        // tag of the current pass's task slots
   uint64_t *d_ranges = nullptr;              // range queue scan -> publish_kernel
   uint64_t range_cap = 0;
@@ -109,6 +113,7 @@ struct lentil_hip_ctx {
   uint64_t est_items_total = 0, est_sum_total = 0;
   int est_rounds_total = 3;
   uint32_t last_streamed = 0;
+  uint64_t n_stuck = 0;                      // streamed passes whose waves gave up waiting (redone the chunked way)
   int last_rounds = 0;
   uint32_t last_blind = 0, last_fallback = 0;
   uint32_t last_scan_launches = 0;
@@ -131,6 +136,11 @@ struct lentil_hip_ctx {
 };
 
 static thread_local std::string g_err;
+
+// One streamed pass at a time per device and process: its solve waves are resident while they wait for the scan's
+// output, and the waves of two such passes can fill the CUs' register files between them before either scan is
+// placed (contexts driven from several threads; across processes the bounded wait and the chunked redo catch it).
+static std::mutex g_stream_mutex[64];
 
 static int fail(lentil_hip_ctx *ctx, int code, const std::string &msg) {
   if (ctx) ctx->err = msg; else g_err = msg;
@@ -217,6 +227,11 @@ LENTIL_API int lentil_hip_create(int device, lentil_hip_ctx **out_ctx) {
   if (const char *e = getenv("LENTIL_SCAN_DMA")) ctx->scan_dma = !(e[0] == '0');
   if (const char *e = getenv("LENTIL_STREAM_BLOCKS")) ctx->stream_blocks = atoi(e);
   if (ctx->stream_blocks < 1) ctx->stream_blocks = 1;
+  // Never three: three solve blocks per CU fill the register file (3 x 168 of 512 VGPRs per lane), and should they be
+  // placed before the scan's blocks -- the two kernels sit in different hardware queues -- the scan they wait for
+  // never starts (seen on the first streamed pass of a context, when the scan's launch trails a memset: 250 ms until
+  // the waves give up, then the chunked redo).  Two leave room for a scan block (72) and a publisher (40) everywhere.
+  if (ctx->stream_blocks > 2) ctx->stream_blocks = 2;
   if (const char *e = getenv("LENTIL_PUBLISH_WAVES")) ctx->publish_waves = atoi(e);
   if (ctx->publish_waves < 1) ctx->publish_waves = 1;
   *out_ctx = ctx;
@@ -446,6 +461,8 @@ LENTIL_API int lentil_hip_alloc_frame(lentil_hip_ctx *ctx, uint32_t n_aovs, cons
   (void)hipFree(ctx->d_dir);
   ctx->d_dir = nullptr;
   ctx->dir_dirty = false;
+  (void)hipFree(ctx->d_touched);
+  ctx->d_touched = nullptr;
   (void)hipFree(ctx->F.zkey);
   (void)hipFree(ctx->F.zkey_dbg);
   (void)hipFree(ctx->d_resolved);
@@ -476,6 +493,7 @@ LENTIL_API int lentil_hip_alloc_frame(lentil_hip_ctx *ctx, uint32_t n_aovs, cons
   ctx->have_frame = true;
   HIP_TRY(ctx, hipMemsetAsync(ctx->F.acc, 0, nfl * sizeof(float), ctx->stream));
   ctx->dirty_lo = ctx->dirty_hi = 0; ctx->dirty_known = true; ctx->pass_pending = false;
+  ctx->cleared_since_pass = true;
   return LENTIL_OK;
 }
 
@@ -590,6 +608,16 @@ LENTIL_API int lentil_hip_clear_frame(lentil_hip_ctx *ctx) {
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   // rows known to hold everything added since the last clear (lentil_hip_touched_rows was asked after the
   // pass): wipe only those; otherwise the whole frame
+  if (ctx->F.touched) {
+    // only splats have been added since the last clear, and their records are flagged: wipe those
+    const uint64_t n_groups = (ctx->F.np + 63) / 64;
+    uint64_t blocks = (n_groups + 255) / 256;
+    const uint64_t max_blocks = (uint64_t)ctx->num_cu * 4;
+    if (blocks > max_blocks) blocks = max_blocks;
+    hipLaunchKernelGGL(clear_touched_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, ctx->F, n_groups);
+    HIP_TRY(ctx, hipGetLastError());
+    ctx->F.touched = nullptr;
+  } else {
   uint64_t p0 = 0, p1 = ctx->F.np;
   if (ctx->dirty_known && !ctx->pass_pending) {
     p0 = (uint64_t)(ctx->dirty_lo < 0 ? 0 : ctx->dirty_lo) * ctx->P.xres;
@@ -602,7 +630,9 @@ LENTIL_API int lentil_hip_clear_frame(lentil_hip_ctx *ctx) {
     if (ctx->F.zkey) HIP_TRY(ctx, hipMemsetAsync(ctx->F.zkey + p0, 0xFF, (p1 - p0) * sizeof(unsigned long long), ctx->stream));
     if (ctx->F.zkey_dbg) HIP_TRY(ctx, hipMemsetAsync(ctx->F.zkey_dbg + p0, 0xFF, (p1 - p0) * sizeof(unsigned long long), ctx->stream));
   }
+  }
   ctx->F.dir = nullptr;         // what the scan stored there no longer counts (wiped or overwritten before it does again)
+  ctx->cleared_since_pass = true;
   ctx->dirty_lo = ctx->dirty_hi = 0;
   ctx->dirty_known = true;      // clean frame: nothing is dirty
   ctx->pass_pending = false;
@@ -930,9 +960,18 @@ static void init_draw_args(lentil_hip_ctx *ctx, DrawArgs &da) {
   da.log_count = &ctx->d_ctr[C].log_count;
 }
 
+// FrameDev::touched stops being the whole truth about `acc` (something other than a splat is written there): the
+// flags are reset, the next clear wipes the rows it knows to be dirty -- or everything
+static void untrust_touched(lentil_hip_ctx *ctx) {
+  if (!ctx->F.touched) return;
+  (void)hipMemsetAsync(ctx->d_touched, 0, (ctx->F.np + 63) / 64, ctx->stream);
+  ctx->F.touched = nullptr;
+}
+
 // ---- FrameDev::dir bookkeeping ---------------------------------------------------------------------------
 static int fold_direct(lentil_hip_ctx *ctx, uint64_t p_begin, uint64_t p_end, bool all) {
   if (!ctx->F.dir) return LENTIL_OK;
+  untrust_touched(ctx);        // `acc` is about to hold more than splats
   if (p_end > p_begin) {
     uint64_t blocks = ((p_end - p_begin) * (ctx->F.stride / 4) + 255) / 256;
     const uint64_t max_blocks = (uint64_t)ctx->num_cu * 8;
@@ -970,7 +1009,19 @@ static int prepare_direct(lentil_hip_ctx *ctx, const lentil_hip_ctx::DirRegion *
     ctx->F.dir = ctx->d_dir;
     ctx->dir_dirty = true;
     ctx->dir_region = *region;
+    if (ctx->cleared_since_pass) {
+      // `acc` is all zeros and this pass only splats into it
+      if (!ctx->d_touched) {
+        const uint64_t n = (ctx->F.np + 63) / 64;
+        HIP_TRY(ctx, hipMalloc(&ctx->d_touched, n));
+        HIP_TRY(ctx, hipMemsetAsync(ctx->d_touched, 0, n, ctx->stream));
+      }
+      ctx->F.touched = ctx->d_touched;
+    }
+  } else {
+    untrust_touched(ctx);
   }
+  ctx->cleared_since_pass = false;
   return LENTIL_OK;
 }
 
@@ -1052,9 +1103,11 @@ static int launch_scan(lentil_hip_ctx *ctx, const ScanPlan &pl, const lentil_hip
   const uint64_t max_blocks = (uint64_t)ctx->num_cu * 8;
   uint64_t blocks;
   if (pl.dma) {
-    // persistent: two blocks per CU (LDS), every wave draws four tiles at a time
+    // persistent, every wave draws four tiles at a time
     blocks = (ch.tile_end - ch.tile_begin + 15) / 16;
-    uint64_t per_cu = 2;
+    // one block per CU: 1.07 ms alone against 0.98 with two, but a CU then has room (registers, LDS) for three solve
+    // blocks beside it, and a streamed pass ends when its solves do
+    uint64_t per_cu = ctx->stream_mode ? 1 : 2;
     if (const char *e = getenv("LENTIL_DMA_BLOCKS")) per_cu = strtoull(e, nullptr, 10);
     if (blocks > (uint64_t)ctx->num_cu * per_cu) blocks = (uint64_t)ctx->num_cu * per_cu;
     if (blocks < 1) blocks = 1;
@@ -1096,6 +1149,7 @@ static int redistribute_streamed(lentil_hip_ctx *ctx, bool *streamed) {
     return LENTIL_OK;
   if (ctx->V.n > 0xFFFFFFF0ull) return LENTIL_OK;
   lentil_hip_ctx::Chunk &ch = ctx->chunks[0];
+  std::lock_guard<std::mutex> one_at_a_time(g_stream_mutex[ctx->device & 63]);
   DrawArgs da{};
   init_draw_args(ctx, da);
   const uint64_t nch = (uint64_t)da.n_channels;
@@ -1109,6 +1163,7 @@ static int redistribute_streamed(lentil_hip_ctx *ctx, bool *streamed) {
   bind_chunk_buffers(ch, da);
   ScanPlan plan;
   if ((rc = plan_scan(ctx, plan))) return rc;
+  da.F = ctx->F;                // (plan_scan decides where the direct sums go and whether splats are flagged)
   ch.tile_begin = 0; ch.tile_end = plan.n_tiles;
   ch.v_begin = 0; ch.v_end = ctx->V.n;
   for (int ci = 1; ci < ctx->n_chunks; ++ci) {
@@ -1145,6 +1200,7 @@ static int redistribute_streamed(lentil_hip_ctx *ctx, bool *streamed) {
       if ((rc = grow(ctx, &ctx->d_ranges, need))) return rc;
       ctx->range_cap = need;
       HIP_TRY(ctx, hipMemsetAsync(ctx->d_ranges, 0, need * sizeof(uint64_t), ctx->stream));
+      HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     }
   }
   plan.sa.ranges = ctx->d_ranges;
@@ -1241,8 +1297,18 @@ static int redistribute_streamed(lentil_hip_ctx *ctx, bool *streamed) {
     fprintf(stderr, " | max k (lane 0 sample) %llu parked %llu slow %llu | last publisher off %.1f last scan block off %.1f pubs %u scanblocks %u ranges %u/%u tasks %u/%u\n", c.dbg[40], c.dbg[41], c.slow_solves,
             ((double)c.dbg[42] - (double)c.dbg[2]) / 100.0, ((double)c.dbg[43] - (double)c.dbg[2]) / 100.0, c.publishers_done, c.scan_blocks_done, c.range_head, c.n_ranges, c.task_head[0], c.n_tasks[0]);
   }
-  if (c.stuck) return fail(ctx, LENTIL_ERR_HIP, "streamed pass: a wave gave up waiting for its queue slot (LENTIL_STREAM=0 selects the chunked pass)");
-  if (c.fallback) {
+  if (c.fallback || c.stuck) {
+    if (getenv("LENTIL_STREAM_DEBUG"))
+      fprintf(stderr, "[stream] stuck detail: tail %llu head %llu instance %llu block %llu slot-now %016llx | END writer: n %llu count %llu cap %llu\n",
+              c.dbg[32], c.dbg[33], c.dbg[34], c.dbg[35], c.dbg[36], c.dbg[37], c.dbg[38], c.dbg[39]);
+    if (getenv("LENTIL_STREAM_DEBUG"))
+      fprintf(stderr, "[stream] redo: who %u ticket %u saw %016llx epoch %u range_head %u pubs_done %u scan_done %u | fallback %llu stuck %u | items %llu (cap %u) tasks %u (cap %u) pool %llu (cap %llu) ranges %u (cap %u)\n",
+              c.stuck & 3u, c.stuck >> 2, c.dbg[47], ctx->epoch, c.range_head, c.publishers_done, c.scan_blocks_done, c.fallback, c.stuck, c.work_count, pub.item_cap, c.n_tasks[0], pub.task_cap, c.pool_used[0], (unsigned long long)pub.pool_cap,
+              c.n_ranges, plan.sa.range_cap);
+    if (c.stuck) {
+      ++ctx->n_stuck;
+      HIP_TRY(ctx, hipMemsetAsync((char *)ctx->d_ctr + offsetof(DevCounters, stuck), 0, sizeof(unsigned int), ch.stream));
+    }
     // did not fit: nothing was accepted.  Fresh queues, then the draws again the plain way, sized from the counters
     ctx->h_ctr_valid = false;
     ++ctx->last_fallback;
@@ -1589,6 +1655,7 @@ LENTIL_API int lentil_hip_merge_sparse(lentil_hip_ctx *ctx, uint32_t row_begin, 
   if (ctx->F.zkey && !dev_keys) return fail(ctx, LENTIL_ERR_INVALID, "the frame has closest-filtered AOVs: dev_keys is required");
   if (ctx->F.debug_mask) return fail(ctx, LENTIL_ERR_UNSUPPORTED, "the lentil_debug AOV is not exchanged between GPUs");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
+  untrust_touched(ctx);
   const uint64_t max_blocks = (uint64_t)ctx->num_cu * 8;
   uint64_t blocks = ((uint64_t)n * (4ull * ctx->F.n_aovs + 1ull) + 255) / 256;
   if (blocks > max_blocks) blocks = max_blocks;
@@ -1629,6 +1696,7 @@ static int merge_rows_impl(lentil_hip_ctx *ctx, uint32_t row_begin, uint32_t n_r
   if (ctx->F.zkey && !dev_key_rows) return fail(ctx, LENTIL_ERR_INVALID, "the frame has closest-filtered AOVs: key rows are required");
   if (ctx->F.debug_mask) return fail(ctx, LENTIL_ERR_UNSUPPORTED, "the lentil_debug AOV is not exchanged between GPUs");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
+  untrust_touched(ctx);
   const uint64_t p_begin = (uint64_t)row_begin * ctx->P.xres, n_pix = (uint64_t)n_rows * ctx->P.xres;
   uint64_t blocks = (n_pix * ctx->F.stride + 255) / 256;
   const uint64_t max_blocks = (uint64_t)ctx->num_cu * 8;

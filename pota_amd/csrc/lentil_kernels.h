@@ -107,6 +107,11 @@ struct FrameDev {
   // still does.  The resolve adds the two; anything else that looks at the accumulators folds `dir` into `acc`
   // first (fold_direct_kernel).  Null while it holds nothing.
   float *dir;
+  // One byte per 64 pixel records of `acc`, set by the accept kernel for every record a draw is added to.  Non-null
+  // only while nothing but splats has been added since the last clear (a pass whose scan stores to `dir`): the
+  // resolve then reads `acc` only where something was splatted -- 2 % of the frame in the scan-dominated regime --
+  // and the next clear wipes only that.
+  uint8_t *touched;
   uint32_t stride;   // floats per record
   // closest-filter AOVs (src/lentil.h:832-837): per pixel the winning candidate as one 64-bit key,
   // (bits of |Z|) << 32 | (0xFFFFFFFF - visit), reduced with atomicMin: smallest depth wins, equal depths
@@ -171,30 +176,38 @@ struct StreamPub {
   Task *tasks0;
 };
 
+// Hand-off words are written with atomics as well (exchange, nothing returned): "8-byte agent-scope atomics on both
+// sides" is a form MI355X_MICROARCH.md lists as valid; a write-through store on one side and an atomic on the
+// other is not, and was seen to lose a word once in a few hundred passes (an end marker that its reader, polling
+// with atomics, never saw).
 LD_DEV void st_agent64(void *p, uint64_t v) {
-  __hip_atomic_store(reinterpret_cast<uint64_t *>(p), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  (void)__hip_atomic_exchange(reinterpret_cast<uint64_t *>(p), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 // Reads of words another CU writes while this kernel runs are returning atomics (x | 0), not loads: an agent-scope
 // load (sc1) goes past this CU's L1 but is served by this XCD's L2, which may hold the line from before the other
 // XCD wrote it through -- measured: end-of-queue words polled with sc1 loads were seen 0.4-0.9 ms late once the
 // scan's traffic no longer swept the L2s.  Atomics execute at the memory side (MI355X_MICROARCH.md).
-// (in assembly: the optimiser turns a relaxed `x | 0` into an atomic load, volatile or not)
+// A compare-and-swap whose comparand never occurs (all ones: no record, header word or counter is that): it
+// returns the word and never writes.  (Not `x | 0`: the optimiser turns that into an atomic load, volatile or not --
+// and as an instruction it writes the old value back.)
 LD_DEV uint64_t ld_coherent64(const void *p) {
+  typedef uint64_t u64x2 __attribute__((ext_vector_type(2)));
   uint64_t old;
-  const uint64_t zero = 0ull;
-  asm volatile("global_atomic_or_x2 %0, %1, %2, off sc0\n\ts_waitcnt vmcnt(0)" : "=&v"(old) : "v"(p), "v"(zero) : "memory");
+  const u64x2 swap_cmp = {~0ull, ~0ull};
+  asm volatile("global_atomic_cmpswap_x2 %0, %1, %2, off sc0\n\ts_waitcnt vmcnt(0)" : "=&v"(old) : "v"(p), "v"(swap_cmp) : "memory");
   return old;
 }
 LD_DEV uint32_t ld_coherent32(const void *p) {
   uint32_t old;
-  const uint32_t zero = 0u;
-  asm volatile("global_atomic_or %0, %1, %2, off sc0\n\ts_waitcnt vmcnt(0)" : "=&v"(old) : "v"(p), "v"(zero) : "memory");
+  const uint64_t swap_cmp = ~0ull;
+  asm volatile("global_atomic_cmpswap %0, %1, %2, off sc0\n\ts_waitcnt vmcnt(0)" : "=&v"(old) : "v"(p), "v"(swap_cmp) : "memory");
   return old;
 }
 constexpr uint32_t kEndCount = 0xFFu;       // Task::count of the end-of-queue markers behind the last task
 constexpr uint32_t kEndRange = 0x3FFu;      // ... and the count field of the end markers of the range queue
-// every wait on a queue slot is bounded: 3 s of the 100 MHz real-time counter, then DevCounters::stuck
-constexpr uint64_t kStuckTicks = 300000000ull;
+// every wait on a queue slot is bounded: 250 ms of the 100 MHz real-time counter, then DevCounters::stuck (the
+// host redoes the draws of the pass the chunked way)
+constexpr uint64_t kStuckTicks = 25000000ull;
 constexpr uint32_t kTaskTagShift = 10;    // Task::count bits 10..31: epoch of the pass that published the slot
 
 struct ScanArgs {
@@ -1008,7 +1021,7 @@ __global__ __launch_bounds__(64) void publish_kernel(PublishArgs a) {
             (uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)rec);
       if (((uint32_t)(rec >> 32) >> kTaskTagShift) == a.S.epoch) break;
       if (__builtin_amdgcn_s_memrealtime() - t0 > kStuckTicks) {
-        if (lane == 0) a.ctr->stuck = 1u;
+        if (lane == 0) { a.ctr->stuck = 1u | (ticket << 2); a.ctr->dbg[47] = rec; }
         over = true;
         break;
       }
@@ -1032,6 +1045,7 @@ __global__ __launch_bounds__(64) void publish_kernel(PublishArgs a) {
   if (!__builtin_amdgcn_readfirstlane(last)) return;
   // the last publisher: the task queue is complete.  One end marker for every solve wave that may hold a ticket.
   const uint32_t n = ld_coherent32(&a.ctr->n_tasks[0]);
+  if (lane == 0) { a.ctr->dbg[37] = n; a.ctr->dbg[38] = a.end_tasks; a.ctr->dbg[39] = a.S.task_cap; }
   for (uint32_t i = lane; i < a.end_tasks; i += 64u)
     if ((uint64_t)n + i < a.S.task_cap)
       st_agent64(reinterpret_cast<uint64_t *>(a.S.tasks0 + n + i) + 1,
@@ -1320,7 +1334,12 @@ __global__ __launch_bounds__(256) void solve_po_kernel(DrawArgs a) {
           if ((w1_hi >> kTaskTagShift) != a.epoch) {
             // nothing there (yet): back to the solves in flight (an idle wave naps, below)
             if (__builtin_amdgcn_s_memrealtime() - ticket_t0 > kStuckTicks) {
-              if (lane == 0) a.ctr->stuck = 1u;
+              if (lane == 0) {
+                a.ctr->stuck = 2u | (ticket << 2); a.ctr->dbg[47] = w1;
+                a.ctr->dbg[32] = ld_coherent32(&a.ctr->n_tasks[par]); a.ctr->dbg[33] = ld_coherent32(&a.ctr->task_head[par]);
+                a.ctr->dbg[34] = a.instance; a.ctr->dbg[35] = blockIdx.x;
+                a.ctr->dbg[36] = ld_coherent64(reinterpret_cast<const uint64_t *>(tasks + ticket) + 1);
+              }
               no_more = true;
             }
             break;
@@ -1774,6 +1793,7 @@ LD_DEV AcceptResult accept_item(const DrawArgs &a, AcceptShared &sh, uint32_t it
         rmin = row < rmin ? row : rmin;
         rmax_p1 = row + 1u > rmax_p1 ? row + 1u : rmax_p1;
         s_pix[wave][(uint32_t)__builtin_popcountll(tmask0 & lt_mask)] = pix;
+        if (a.F.touched) a.F.touched[pix >> 6] = 1;
         if (a.F.zkey) atomicMin(a.F.zkey + pix, zk);
         if (a.F.zkey_dbg) atomicMin(a.F.zkey_dbg + pix, zk);      // value.r = samples != 0 for every draw
         if (a.log_cap) {
@@ -1934,6 +1954,7 @@ LD_DEV AcceptResult accept_item_chroma(const DrawArgs &a, AcceptShared &sh, uint
         rmin = row < rmin ? row : rmin;
         rmax_p1 = row + 1u > rmax_p1 ? row + 1u : rmax_p1;
         s_pix[wave][(uint32_t)__builtin_popcountll(tmask & lt_mask)] = pix;
+        if (a.F.touched) a.F.touched[pix >> 6] = 1;
         if (a.F.zkey) atomicMin(a.F.zkey + pix, zk);
         if (a.F.zkey_dbg) atomicMin(a.F.zkey_dbg + pix, zk);      // value.r = samples != 0 for every draw
         if (a.log_cap) {
@@ -1999,7 +2020,7 @@ __global__ __launch_bounds__(256) void accept_kernel(DrawArgs a) {
   __shared__ AcceptShared sh;
   const uint32_t par = (uint32_t)a.parity, nxt = par ^ 1u;
   // (a streamed or blind pass whose buffers were too small: nothing is accepted, the host redoes the draws)
-  const uint32_t n_active = a.ctr->fallback ? 0u : a.ctr->n_active[par];
+  const uint32_t n_active = (a.ctr->fallback || a.ctr->stuck) ? 0u : a.ctr->n_active[par];
   if (blockIdx.x == 0 && threadIdx.x == 0 && n_active) atomicMax(&a.ctr->rounds_used, (unsigned long long)(a.round + 1));
   const uint32_t *res = a.pool[par];
   unsigned long long tot_attempted = 0, tot_accepted = 0;
@@ -2196,6 +2217,29 @@ __global__ __launch_bounds__(256) void merge_keys_kernel(FrameDev F, uint64_t p_
   }
 }
 
+// clear_frame while FrameDev::touched is trusted: wipe the groups of 64 records that received splats, nothing else
+__global__ __launch_bounds__(256) void clear_touched_kernel(FrameDev F, uint64_t n_groups) {
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t q = F.stride >> 2;
+  float4 *acc4 = reinterpret_cast<float4 *>(F.acc);
+  const uint64_t wave_global = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const uint64_t wave_stride = (uint64_t)gridDim.x * (blockDim.x >> 6);
+  for (uint64_t g0 = wave_global * 64u; g0 < n_groups; g0 += wave_stride * 64u) {
+    // 64 flags per wave step; then every flagged group by the whole wave
+    const uint64_t g = g0 + lane;
+    const bool set = g < n_groups && F.touched[g] != 0;
+    unsigned long long m = __ballot(set);
+    if (set) F.touched[g] = 0;
+    while (m) {
+      const uint32_t b = (uint32_t)__builtin_ctzll(m);
+      m &= m - 1ull;
+      const uint64_t p0 = (g0 + b) * 64u;
+      const uint64_t n_pix = (F.np - p0) < 64ull ? (F.np - p0) : 64ull;
+      for (uint32_t i = lane; i < n_pix * q; i += 64u) acc4[p0 * q + i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+}
+
 // FrameDev::dir -> FrameDev::acc for a range of pixels (and zero there): for everything but the resolve that looks at
 // the accumulators (downloads, the exchange between GPUs, a second pass into the same frame)
 __global__ __launch_bounds__(256) void fold_direct_kernel(FrameDev F, float *dir, uint64_t p_begin, uint64_t p_end) {
@@ -2234,7 +2278,10 @@ __global__ __launch_bounds__(256) void resolve_kernel(FrameDev F, float *resolve
     const uint64_t p0 = p_begin + t * 64ull;
     const uint32_t n_pix = (uint32_t)((p_end - p0) < 64ull ? (p_end - p0) : 64ull);
     const uint32_t n4 = n_pix * q;
-    if (dir4) {
+    if (dir4 && F.touched && !(F.touched[p0 >> 6] | F.touched[(p0 + n_pix - 1u) >> 6])) {
+      // nothing was splatted into these records: they are all zero, the direct sums are the whole story
+      for (uint32_t i = lane; i < n4; i += 64u) tile[i] = dir4[p0 * q + i];
+    } else if (dir4) {
       // what the pixels' own visits added (scan_dma_kernel) + what was splatted: a pixel that received no draw has a
       // zero record in `acc`, and 0 + x is x bit for bit (the scan's sums are never -0)
       for (uint32_t i = lane; i < n4; i += 64u) {

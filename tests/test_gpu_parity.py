@@ -924,7 +924,7 @@ def test_blind_passes_and_fallback(orc, monkeypatch, stream):
                 rc.redistributed_visits, rc.attempted_draws, rc.accepted_draws)
             assert c.blind_chunks == blind
             assert c.streamed == (1 if stream == "1" and blind else 0)
-            assert (c.fallback_chunks >= 1) if fb else (c.fallback_chunks == 0)    # the quarter-frame chunks may just fit
+            assert (c.fallback_chunks >= 1) if fb else (c.fallback_chunks == 0), (blind, fb, c.fallback_chunks)    # the quarter-frame chunks may just fit
             check_logs(ctx, ref)
             check_frame(ctx, ref)
     finally:
