@@ -18,15 +18,25 @@ of consecutive rows -- its visits and its tile of the output -- and sends the ro
 outside the band to their owners (pota_amd/distributed.py::frame_step_bands).
 LENTIL_PARTITION=interleaved selects rows r mod N with one sum all-reduce of the whole frame instead.
 
+The timed steps ALTERNATE between two resident visit streams generated from different seeds (different
+highlights in different places): a pass sizes its buffers from what the previous pass found, and a renderer
+never sees the same frame twice.  `passes` in the JSON line says how the timed passes ran (streamed / chunks
+enqueued blind / redone because the estimate was too small).
+
 Set-up before the W warm-up steps (untimed, like generating the visits): two passes that let the context size its
 draw buffers (the first pass of a context waits for each chunk's scan and allocates); for N > 1 three calibration
 passes that re-cut the row bands from the ranks' pass times.
 
 The printed JSON line also carries
   roofline     -- the HBM-bound scan kernel: algorithmic bytes (visits x 80 B) / its mean duration,
-                  measured with HIP events on the library's stream, against 8 TB/s
+                  measured with HIP events on the library's stream, against 8 TB/s; `bytes_moved_per_visit` is
+                  what the kernel actually requests (it does not read raydir_time unless a visit is at infinite
+                  depth, and stores a record per pixel); `whole_step_frac` relates the frame's bytes to the whole step
+  solve_fp64   -- the fp64-VALU-bound draw kernels: Newton lane-iterations x operations per iteration
+                  (counted from the lens table) against the fp64 vector peak, per regime
   cpu_baseline -- the oracle (a port of the reference CPU path) timed on this box's host cores on a
-                  bounded row sample of the same workload (rank 0, N=1 only).
+                  bounded row sample of the same workload (rank 0, N=1 only): all threads and one thread
+  configs      -- BASELINE.json's configs 2, 3 and 4 measured the same way (N=1 only; --no-configs skips them).
 """
 import argparse
 import json
@@ -39,22 +49,22 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-# A pass uses three HIP streams (scans, one per chunk of draws); torch and RCCL bring theirs.  With the runtime's
-# default of 4 hardware queues per process two of them end up sharing one in the multi-GPU runs, and the first
-# chunk's solves then queue behind the second scan instead of running beside it (3.34 -> 3.05 ms per step).
+# A pass uses several HIP streams (scan, publishers, solve waves beside the scan); torch and RCCL bring theirs.
+# With the runtime's default of 4 hardware queues per process two of them end up sharing one.
 # Read when the HIP runtime initialises, so: before torch is imported.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 # dmabuf IPC for RCCL between the ranks of one node (the host driver here supports nothing else); also read early
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-FP64_VECTOR_PEAK_TFLOPS = 78.6
+FP64_VECTOR_PEAK_TFLOPS = 78.6  # counts a fused multiply-add as two; the reference's arithmetic has none
+SEEDS = (0x5EED, 0xBEEF)
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=6)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--width", type=int, default=3840)
     ap.add_argument("--height", type=int, default=2160)
@@ -65,6 +75,8 @@ def parse():
     ap.add_argument("--lens", default="double_gauss_50mm")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-second-regime", action="store_true")
+    ap.add_argument("--no-configs", action="store_true", help="skip BASELINE.json's configs 2-4")
+    ap.add_argument("--same-frame", action="store_true", help="replay ONE visit stream (development aid; the default alternates two)")
     ap.add_argument("--cpu-row-step", type=int, default=0, help="CPU baseline samples every n-th row (0 = auto)")
     ap.add_argument("--bokeh-image", action="store_true", help="aperture draws from the reference's example bokeh image "
                                                                "(tests/golden/example_bokeh_kernel_u8.npy; BASELINE config 3)")
@@ -74,9 +86,29 @@ def parse():
     return ap.parse_args()
 
 
+def physical_cores():
+    try:
+        seen = set()
+        phys = core = None
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("physical id"):
+                    phys = line.split(":")[1].strip()
+                elif line.startswith("core id"):
+                    core = line.split(":")[1].strip()
+                elif not line.strip():
+                    if phys is not None and core is not None:
+                        seen.add((phys, core))
+                    phys = core = None
+        return len(seen) or None
+    except OSError:
+        return None
+
+
 def cpu_baseline(args, p, table, M, tan_half_fov):
     """Oracle ("port" of the reference CPU path) on a bounded sample: every row_step-th image row of
-    the same frame, threaded over rows with per-thread private accumulators merged at the end."""
+    the same frame, threaded over rows with per-thread private accumulators merged at the end; then the
+    same on one thread over a tenth of those rows."""
     import ctypes as C
     import numpy as np
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -85,45 +117,53 @@ def cpu_baseline(args, p, table, M, tan_half_fov):
 
     lib = oracle_lib.load()
     W, H = args.width, args.height
-    threads = max(1, min(os.cpu_count() or 1, 32))
-    # bound the CPU work to roughly 10-30 s: ~0.1 us per scanned visit, ~35 us per draw attempt per core
-    est_full = W * H * M * (0.1e-6 + args.f_hi * args.samples * 35e-6 * 1.1)
-    row_step = args.cpu_row_step or max(1, int(round(est_full / (20.0 * threads))))
-    rows = list(range(0, H, row_step))
-    n = len(rows) * W * M
-    cols = workload.generate(np, 0, n, W, H, M, f_hi=args.f_hi, focus_dist=150.0, tan_half_fov=tan_half_fov,
-                             n_extra=args.aovs, row_stride=row_step, row_offset=0)
-    visits, keep = capi.make_visits(cols, visits_per_pixel=M, pixels_per_row=W, pixel_row_stride=row_step)
-    lens = lib.orc_lens_create(C.byref(table))
-    frames = [oracle_lib.Frame(lib, p, n_aovs=1 + args.aovs, shadow=False) for _ in range(threads)]
-    # contiguous row blocks per thread
-    bounds = [int(round(i * len(rows) / threads)) * W * M for i in range(threads + 1)]
+    logical = os.cpu_count() or 1
+    threads = max(1, min(logical, 32))
 
-    def work(i):
-        frames[i].run(lens, None, visits, bounds[i], bounds[i + 1])
+    def timed(n_threads, budget_s):
+        # bound the CPU work: ~0.1 us per scanned visit, ~35 us per draw attempt per core
+        est_full = W * H * M * (0.1e-6 + args.f_hi * args.samples * 35e-6 * 1.1)
+        row_step = args.cpu_row_step or max(1, int(round(est_full / (budget_s * n_threads))))
+        rows = list(range(0, H, row_step))
+        n = len(rows) * W * M
+        cols = workload.generate(np, 0, n, W, H, M, f_hi=args.f_hi, focus_dist=150.0, tan_half_fov=tan_half_fov,
+                                 n_extra=args.aovs, row_stride=row_step, row_offset=0)
+        visits, keep = capi.make_visits(cols, visits_per_pixel=M, pixels_per_row=W, pixel_row_stride=row_step)
+        lens = lib.orc_lens_create(C.byref(table))
+        frames = [oracle_lib.Frame(lib, p, n_aovs=1 + args.aovs, shadow=False) for _ in range(n_threads)]
+        bounds = [int(round(i * len(rows) / n_threads)) * W * M for i in range(n_threads + 1)]
 
-    t0 = time.perf_counter()
-    ts = [threading.Thread(target=work, args=(i,)) for i in range(threads)]
-    for t in ts:
-        t.start()
-    for t in ts:
-        t.join()
-    for f in frames[1:]:
-        lib.orc_frame_merge(frames[0].h, f.h)
-    dt = time.perf_counter() - t0
-    c = frames[0].counters()
-    lib.orc_lens_destroy(lens)
-    for f in frames:
-        f.close()
+        def work(i):
+            frames[i].run(lens, None, visits, bounds[i], bounds[i + 1])
+
+        t0 = time.perf_counter()
+        ts = [threading.Thread(target=work, args=(i,)) for i in range(n_threads)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+        for f in frames[1:]:
+            lib.orc_frame_merge(frames[0].h, f.h)
+        dt = time.perf_counter() - t0
+        c = frames[0].counters()
+        lib.orc_lens_destroy(lens)
+        for f in frames:
+            f.close()
+        return n / dt / 1e6, "every %d-th row of the same %dx%d frame: %d visits, %d redistributed, %d draw attempts, %.1f s" % (
+            row_step, W, H, n, c.redistributed_visits, c.attempted_draws, dt)
+
+    v_all, s_all = timed(threads, 20.0)
+    v_one, s_one = timed(1, 6.0)
     return {
-        "value": round(n / dt / 1e6, 4), "unit": "Msamples/s", "cores": threads, "kind": "port",
-        "sample": "every %d-th row of the same %dx%d frame: %d visits, %d redistributed, %d draw attempts, %.1f s"
-                  % (row_step, W, H, n, c.redistributed_visits, c.attempted_draws, dt),
+        "value": round(v_all, 4), "unit": "Msamples/s", "cores": threads, "kind": "port", "sample": s_all,
+        "threads": threads, "logical_cpus": logical, "physical_cores": physical_cores(),
+        "one_thread": {"value": round(v_one, 4), "unit": "Msamples/s", "sample": s_one},
     }
 
 
 def load_traffic(workload_tag):
-    """HBM bytes per scan launch from a separate rocprofv3 --pmc pass (profiles/pmc_scan_latest.json)."""
+    """HBM bytes per scan launch from a separate rocprofv3 --pmc pass (profiles/pmc_scan_latest.json); None unless
+    that file was taken on this very workload and kernel."""
     path = os.path.join(ROOT, "profiles", "pmc_scan_latest.json")
     try:
         with open(path) as f:
@@ -135,22 +175,168 @@ def load_traffic(workload_tag):
     return None
 
 
+class Bench:
+    """One context + two resident visit streams of one frame geometry; run() times alternating passes."""
+
+    def __init__(self, torch, dist, dev, local_rank, world, rank, W, H, Hr, M, lens, samples, aovs, f_hi, bokeh_image,
+                 emulate=None, bounds=None, tiled=False, same_frame=False):
+        import numpy as np
+        from pota_amd import camera, capi, distributed, lens_io
+        self.torch, self.dist, self.dev = torch, dist, dev
+        self.world, self.rank = world, rank
+        self.W, self.H, self.Hr, self.M = W, H, Hr, M
+        self.aovs, self.f_hi, self.emulate, self.tiled = aovs, f_hi, emulate, tiled
+        self.n_streams = 1 if same_frame else 2
+        p = camera.default_params()
+        camera.setup_filter(p, W, H, filter_width=1.0, aa_samples=3)
+        p, model = camera.setup_po(p, lens, focus_dist=150.0)
+        p.samples_override = samples
+        if bokeh_image:
+            p.bokeh_enable_image = 1
+        self.p, self.model = p, model
+        self.table, self.keep = lens_io.make_lens_table(model.spec)
+        self.flops = lens_io.newton_iteration_flops(model.spec)
+        self.tan_half_fov = float(p.sensor_width) * 0.5 / float(p.focal_length)
+        ctx = capi.Context(local_rank)
+        ctx.set_params(p)
+        ctx.set_lens(self.table)
+        if bokeh_image:
+            from pota_amd import bokeh
+            tex = np.load(os.path.join(ROOT, "tests", "golden", "example_bokeh_kernel_u8.npy")).astype(np.float32) / np.float32(255)
+            ctx.set_bokeh(bokeh.build_tables(tex))
+        ctx.alloc_frame(1 + aovs)
+        self.ctx = ctx
+        self.engine = distributed.HipEngine(ctx, rows=p.yres)
+        self.distributed = distributed
+        self.bounds = bounds
+        self.band = None
+        self.streams = []
+        self.set_band()
+
+    def set_band(self):
+        from pota_amd import workload
+        d = self.distributed
+        if self.emulate:
+            self.band = d.band_of(self.emulate[1], self.emulate[0], self.H, self.p.yres, self.bounds)
+        elif self.tiled:
+            self.band = d.band_of(self.rank, self.world, self.H, self.p.yres, self.bounds)
+        if self.band is not None:
+            self.v_begin = self.band[0] * self.W * self.M
+            self.v_end = min(self.band[1], self.H) * self.W * self.M
+            self.n_local = self.v_end - self.v_begin
+        else:
+            self.n_local = workload.frame_visit_count(self.W, self.H, self.M, self.world, self.rank)
+
+    def generate(self, f_hi):
+        """(re)creates the resident streams: same geometry, different seeds"""
+        from pota_amd import capi, workload
+        torch = self.torch
+        self.streams = []
+        torch.cuda.empty_cache()
+        for seed in SEEDS[:self.n_streams]:
+            if self.band is not None:
+                cols = workload.generate(torch, self.v_begin, self.v_end, self.W, self.H, self.M, seed=seed, f_hi=f_hi,
+                                         focus_dist=150.0, tan_half_fov=self.tan_half_fov, n_extra=self.aovs, device=self.dev)
+                v, kv = capi.make_visits(cols, visits_per_pixel=self.M, pixels_per_row=self.W, pixel_y0=self.band[0],
+                                         ptr=lambda t: t.data_ptr())
+            else:
+                cols = workload.generate(torch, 0, self.n_local, self.W, self.H, self.M, seed=seed, f_hi=f_hi, focus_dist=150.0,
+                                         tan_half_fov=self.tan_half_fov, n_extra=self.aovs, device=self.dev,
+                                         row_stride=self.world, row_offset=self.rank)
+                v, kv = capi.make_visits(cols, visits_per_pixel=self.M, pixels_per_row=self.W, pixel_y0=self.rank,
+                                         pixel_row_stride=self.world, ptr=lambda t: t.data_ptr())
+            self.streams.append((cols, v, kv))
+        torch.cuda.synchronize()
+        self.i_stream = 0
+
+    def step(self):
+        cols, v, kv = self.streams[self.i_stream % len(self.streams)]
+        self.i_stream += 1
+        self.ctx.bind_visits(v, kv)
+        if self.tiled:
+            self.distributed.frame_step_bands(self.engine, self.dist, self.H, self.p.yres, self.bounds)
+        else:
+            self.distributed.frame_step(self.engine, self.dist)
+
+    def run(self, steps, warmup):
+        torch, dist = self.torch, self.dist
+        for _ in range(warmup):
+            self.step()
+        if self.world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        acc = {"scan": 0.0, "draw": 0.0, "resolve": 0.0, "streamed": 0, "blind_chunks": 0, "redone": 0, "iters": 0,
+               "attempted": 0, "accepted": 0, "redistributed": 0, "scan_launches": 0}
+        for _ in range(steps):
+            self.step()
+            # HIP-event times of this step's kernels (the call waits for the step's stream work, which
+            # the step would have to finish anyway before the next clear)
+            a, b, c = self.ctx.last_timing()
+            acc["scan"] += a; acc["draw"] += b; acc["resolve"] += c
+            k = self.ctx.counters()
+            if k.worklist_overflow:
+                raise SystemExit("bench.py: the device dropped work (worklist_overflow = %d): results incomplete" % k.worklist_overflow)
+            acc["streamed"] += int(k.streamed); acc["blind_chunks"] += int(k.blind_chunks); acc["redone"] += int(k.fallback_chunks)
+            acc["iters"] += int(k.newton_iterations); acc["attempted"] += int(k.attempted_draws)
+            acc["accepted"] += int(k.accepted_draws); acc["redistributed"] += int(k.redistributed_visits)
+            acc["scan_launches"] += max(1, self.ctx.last_launches()[0])
+        if self.world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if self.world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=self.dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        acc["dt"] = dt
+        acc["steps"] = steps
+        return acc
+
+    def solve_block(self, r):
+        """the draw kernels against the fp64 vector peak; the time is everything but the resolve (in a streamed pass
+        the solves run beside the scan)"""
+        mul, add, other = self.flops
+        per_iter = mul + add + other
+        secs = (r["scan"] + r["draw"]) * 1e-3
+        tf = r["iters"] * per_iter / secs / 1e12 if secs > 0 else 0.0
+        return {
+            "kernel": "solve_po_kernel + solve_slow_kernel", "bound": "fp64 valu",
+            "lane_iterations_per_step": r["iters"] // max(1, r["steps"]),
+            "flops_per_lane_iteration": {"mul": mul, "add": add, "transforms_and_inverses": other},
+            "ms_per_step_scan_plus_draw": round(secs * 1e3 / max(1, r["steps"]), 4),
+            "achieved": round(tf, 3), "unit": "TFLOP/s", "peak_fma": FP64_VECTOR_PEAK_TFLOPS,
+            "frac_of_fma_peak": round(tf / FP64_VECTOR_PEAK_TFLOPS, 4),
+            "frac_of_non_fma_ceiling": round(tf / (FP64_VECTOR_PEAK_TFLOPS / 2), 4),
+        }
+
+    def close(self):
+        self.streams = []
+        self.ctx.close()
+        self.torch.cuda.empty_cache()
+
+
+def summarize(b, r, n_total, bytes_per_visit):
+    ms = r["dt"] / r["steps"] * 1e3
+    launches = max(1, r["scan_launches"] // r["steps"])
+    launch_ms = r["scan"] / r["steps"] / launches
+    launch_bytes = b.n_local * bytes_per_visit / launches
+    achieved = launch_bytes / (launch_ms * 1e-3) / 1e9 if launch_ms > 0 else 0.0
+    return ms, launches, launch_ms, launch_bytes, achieved
+
+
 def main():
     args = parse()
-    import numpy as np
     import torch
     import torch.distributed as dist
-    from pota_amd import camera, capi, distributed, lens_io, workload
+    from pota_amd import workload
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    emulate = None
-    if args.emulate:
-        emulate = tuple(int(x) for x in args.emulate.split(","))
+    emulate = tuple(int(x) for x in args.emulate.split(",")) if args.emulate else None
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs torch.distributed.run with %d ranks" % (args.gpus, args.gpus))
+    if args.gpus != world and world == 1 and args.gpus > 1:
+        raise SystemExit("--gpus %d needs torch.distributed.run with %d ranks" % (args.gpus, args.gpus))
     backend = os.environ.get("LENTIL_DIST_BACKEND", "nccl")     # "gloo": several ranks on one GPU (development aid)
     if backend != "nccl":
         local_rank = local_rank % max(1, torch.cuda.device_count())
@@ -164,6 +350,12 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
     dev = torch.device("cuda", local_rank)
+    if world > 1:
+        # self-check of the launch: every rank the driver asked for has joined
+        t = torch.ones(1, dtype=torch.int64, device=dev)
+        dist.all_reduce(t)
+        if int(t.item()) != world or world != args.gpus:
+            raise SystemExit("bench.py: %d ranks joined, --gpus %d, WORLD_SIZE %d" % (int(t.item()), args.gpus, world))
 
     M = args.visits_per_pixel
     # Weak scaling: N GPUs render the same camera at N times the pixels (same 16:9 frame, sqrt(N) finer in both
@@ -177,134 +369,47 @@ def main():
         W = int(round(args.width * math.sqrt(frame_world)))
         Hr = int(round(args.height / math.sqrt(frame_world)))
     H = Hr * frame_world
-    p = camera.default_params()
-    camera.setup_filter(p, W, H, filter_width=1.0, aa_samples=3)
-    p, model = camera.setup_po(p, args.lens, focus_dist=150.0)
-    p.samples_override = args.samples
-    if args.bokeh_image:
-        p.bokeh_enable_image = 1
-    table, keep = lens_io.make_lens_table(model.spec)
-    tan_half_fov = float(p.sensor_width) * 0.5 / float(p.focal_length)
+    tiled = (world > 1 or force_dist) and os.environ.get("LENTIL_PARTITION", "bands") != "interleaved" and not emulate
+    bounds = [int(x) for x in args.bounds.split(",")] if args.bounds else None
 
-    ctx = capi.Context(local_rank)
-    ctx.set_params(p)
-    ctx.set_lens(table)
-    if args.bokeh_image:
-        from pota_amd import bokeh
-        tex = np.load(os.path.join(ROOT, "tests", "golden", "example_bokeh_kernel_u8.npy")).astype(np.float32) / np.float32(255)
-        ctx.set_bokeh(bokeh.build_tables(tex))
-    ctx.alloc_frame(1 + args.aovs)
-    engine = distributed.HipEngine(ctx, rows=p.yres)
-    # N > 1: every rank owns a band of consecutive rows (its visits and its tile of the output) and sends the
-    # rows its draws touched outside the band to their owners; LENTIL_PARTITION=interleaved selects rows
-    # r mod N with one sum all-reduce over the whole frame instead
-    tiled = (world > 1 or force_dist) and os.environ.get("LENTIL_PARTITION", "bands") != "interleaved"
-    # band boundaries of the tiled mode: even split, --bounds, or (N > 1) re-cut after two calibration passes so that
-    # every rank's pass takes the same time (distributed.rebalance; LENTIL_REBALANCE=0 keeps the even split)
-    state = {"bounds": [int(x) for x in args.bounds.split(",")] if args.bounds else None, "band": None,
-             "v_begin": 0, "v_end": 0}
-
-    def set_band():
-        if emulate:
-            state["band"] = distributed.band_of(emulate[1], emulate[0], H, p.yres, state["bounds"])
-        else:
-            state["band"] = distributed.band_of(rank, world, H, p.yres, state["bounds"])
-        state["v_begin"] = state["band"][0] * W * M
-        state["v_end"] = min(state["band"][1], H) * W * M
-        return state["v_end"] - state["v_begin"]
-
-    if emulate:
-        tiled = False
-        n_local = set_band()
-    elif tiled:
-        n_local = set_band()
-    else:
-        n_local = workload.frame_visit_count(W, H, M, world, rank)
+    b = Bench(torch, dist, dev, local_rank, world, rank, W, H, Hr, M, args.lens, args.samples, args.aovs, args.f_hi,
+              args.bokeh_image, emulate=emulate, bounds=bounds, tiled=tiled, same_frame=args.same_frame)
     bytes_per_visit = 80 + 16 * args.aovs
-
-    def bind(f_hi):
-        if tiled or emulate:
-            cols = workload.generate(torch, state["v_begin"], state["v_end"], W, H, M, f_hi=f_hi, focus_dist=150.0,
-                                     tan_half_fov=tan_half_fov, n_extra=args.aovs, device=dev)
-            torch.cuda.synchronize()
-            v, kv = capi.make_visits(cols, visits_per_pixel=M, pixels_per_row=W, pixel_y0=state["band"][0],
-                                     ptr=lambda t: t.data_ptr())
-        else:
-            cols = workload.generate(torch, 0, n_local, W, H, M, f_hi=f_hi, focus_dist=150.0, tan_half_fov=tan_half_fov,
-                                     n_extra=args.aovs, device=dev, row_stride=world, row_offset=rank)
-            torch.cuda.synchronize()
-            v, kv = capi.make_visits(cols, visits_per_pixel=M, pixels_per_row=W, pixel_y0=rank, pixel_row_stride=world,
-                                     ptr=lambda t: t.data_ptr())
-        ctx.bind_visits(v, kv)
-        return cols
-
-    def step():
-        if tiled:
-            distributed.frame_step_bands(engine, dist, H, p.yres, state["bounds"])
-        else:
-            distributed.frame_step(engine, dist)
-
-    def run(steps, warmup):
-        for _ in range(warmup):
-            step()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        scan_ms = draw_ms = res_ms = 0.0
-        for _ in range(steps):
-            step()
-            # HIP-event times of this step's kernels (the call waits for the step's stream work, which
-            # the step would have to finish anyway before the next clear)
-            a, b, c = ctx.last_timing()
-            scan_ms += a; draw_ms += b; res_ms += c
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
-        if world > 1:
-            t = torch.tensor([dt], dtype=torch.float64, device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = float(t.item())
-        return dt, scan_ms / steps, draw_ms / steps, res_ms / steps
-
-    cols = bind(args.f_hi)
+    b.generate(args.f_hi)
     if tiled and (world > 1 or force_dist) and not args.bounds and os.environ.get("LENTIL_REBALANCE", "1") != "0":
         # calibration (untimed set-up, before the warm-up steps): three passes, the first with even bands, each followed
         # by an all-gather of the ranks' pass times (scan + draws, HIP events) and a re-cut of the bands
-        state["bounds"] = distributed.even_bounds(world, H)
+        b.bounds = b.distributed.even_bounds(world, H)
         for it in range(3):
-            step()
-            a, b, c = ctx.last_timing()
-            mine = torch.tensor([a + b], dtype=torch.float64, device=dev)
+            b.step()
+            a_, b_, c_ = b.ctx.last_timing()
+            mine = torch.tensor([a_ + b_], dtype=torch.float64, device=dev)
             allt = [torch.zeros_like(mine) for _ in range(world)]
             dist.all_gather(allt, mine)
             times = torch.stack(allt).flatten().tolist()
-            new = distributed.rebalance(state["bounds"], times, damping=(1.0, 0.8, 0.6)[it])
-            if new != state["bounds"]:
-                state["bounds"] = new
-                n_local = set_band()
-                del cols
-                torch.cuda.empty_cache()
-                cols = bind(args.f_hi)
+            new = b.distributed.rebalance(b.bounds, times, damping=(1.0, 0.8, 0.6)[it])
+            if new != b.bounds:
+                b.bounds = new
+                b.set_band()
+                b.generate(args.f_hi)
     else:
         # set-up: the first pass of a context sizes its draw buffers from the scan's counters (host round trips,
         # allocations); two passes settle that, whatever --warmup says
         for _ in range(2):
-            step()
+            b.step()
         torch.cuda.synchronize()
-    dt, scan_ms, draw_ms, res_ms = run(args.steps, args.warmup)
-    ctr = ctx.counters()
-    n_total = workload.frame_visit_count(W, H, M) if not emulate else n_local        # all ranks
-    value = n_total * args.steps / dt / 1e6
-    ms_per_step = dt / args.steps * 1e3
-
-    workload_tag = "%s %dx%d M=%d samples=%d aovs=%d f_hi=%.3g" % (args.lens, W, Hr, M, args.samples, 1 + args.aovs, args.f_hi)
-    # the scan runs as one launch per chunk of the visit stream; bytes and duration below are per launch
-    scan_launches = max(1, ctx.last_launches()[0])
-    launch_bytes = n_local * bytes_per_visit / scan_launches
-    launch_ms = scan_ms / scan_launches
-    achieved = launch_bytes / (launch_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
+    r = b.run(args.steps, args.warmup)
+    n_total = workload.frame_visit_count(W, H, M) if not emulate else b.n_local        # all ranks
+    value = n_total * r["steps"] / r["dt"] / 1e6
+    ms_per_step, launches, launch_ms, launch_bytes, achieved = summarize(b, r, n_total, bytes_per_visit)
+    scan_kernel = "scan_dma_kernel" if (args.aovs == 0 and os.environ.get("LENTIL_SCAN_DMA", "1") != "0") else (
+        "scan_uniform_multi_kernel" if args.aovs else "scan_uniform_kernel")
+    workload_tag = "%s %s %dx%d M=%d samples=%d aovs=%d f_hi=%.3g" % (scan_kernel, args.lens, W, Hr, M, args.samples, 1 + args.aovs, args.f_hi)
+    # bytes the scan requests per visit: four of the five base columns (raydir_time only for visits at infinite
+    # depth) + the extra AOV columns, and per pixel one record stored (and, in the register-staged kernels, read first)
+    rec_bytes = 4 * (((4 * (1 + args.aovs) + 1) + 7) // 8 * 8)
+    moved = 64 + 16 * args.aovs + (rec_bytes if scan_kernel == "scan_dma_kernel" else 2 * rec_bytes) / M
+    steps = r["steps"]
     out = {
         "metric": "bidir redistribution Msamples/s at 4K, double-gauss 50mm",
         "value": round(value, 3), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -313,51 +418,86 @@ def main():
         "config": {
             "workload": "polynomial-optics %s (self-fitted table), frame %dx%d (%d x the pixels of %dx%d, same camera), "
                         "%d rows per GPU, %d visits/pixel, %d redistribution draws per redistributed visit, %d AOV(s), "
-                        "highlight fraction f_hi=%.3g"
-                        % (args.lens, W, H, world, args.width, args.height, Hr, M, args.samples, 1 + args.aovs, args.f_hi),
-            "visits_per_gpu": n_local, "bytes_per_visit": bytes_per_visit,
-            "redistributed_visits_rank0": int(ctr.redistributed_visits),
-            "attempted_draws_rank0": int(ctr.attempted_draws), "accepted_draws_rank0": int(ctr.accepted_draws),
+                        "highlight fraction f_hi=%.3g; %s"
+                        % (args.lens, W, H, world, args.width, args.height, Hr, M, args.samples, 1 + args.aovs, args.f_hi,
+                           "ONE visit stream replayed" if args.same_frame else
+                           "timed steps alternate between two visit streams (seeds %#x / %#x)" % SEEDS),
+            "visits_per_gpu": b.n_local, "bytes_per_visit": bytes_per_visit,
+            "redistributed_visits_per_step_rank0": r["redistributed"] // steps,
+            "attempted_draws_per_step_rank0": r["attempted"] // steps, "accepted_draws_per_step_rank0": r["accepted"] // steps,
             "parallelism": ("single GPU" if world == 1 else
                             "%d row bands%s, rows touched outside a band sent to its owner (p2p), tiled output"
-                            % (world, (" at rows %s (balanced by pass time)" % state["bounds"]) if state["bounds"] else "") if tiled else
+                            % (world, (" at rows %s (balanced by pass time)" % b.bounds) if b.bounds else "") if tiled else
                             "rows%%%d + allreduce" % world),
         },
-        "kernels_ms": {"scan": round(scan_ms, 4), "draw": round(draw_ms, 4), "resolve": round(res_ms, 4)},
+        "passes": {"timed": steps, "streamed": r["streamed"], "chunks_enqueued_blind": r["blind_chunks"],
+                   "chunks_redone_after_a_short_estimate": r["redone"]},
+        "kernels_ms": {"scan": round(r["scan"] / steps, 4), "draw": round(r["draw"] / steps, 4), "resolve": round(r["resolve"] / steps, 4)},
         "roofline": {
-            "kernel": "scan_uniform_kernel", "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+            "kernel": scan_kernel, "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": load_traffic(workload_tag),
-            "launches_per_step": scan_launches, "algorithmic_bytes_per_launch": round(launch_bytes),
+            "traffic_source": "profiles/pmc_scan_latest.json (separate rocprofv3 --pmc passes; null unless taken on this workload)",
+            "launches_per_step": launches, "algorithmic_bytes_per_launch": round(launch_bytes),
             "avg_launch_ms": round(launch_ms, 4),
-            "whole_step_frac": round(n_local * bytes_per_visit / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+            "algorithmic_bytes_per_visit": bytes_per_visit, "bytes_moved_per_visit": round(moved, 2),
+            "whole_step_frac": round(b.n_local * bytes_per_visit / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
         },
-        "draw_kernel": {"Mdraws_per_s_attempted": round(ctr.attempted_draws / (draw_ms * 1e-3) / 1e6, 3) if draw_ms > 0 else None},
+        "solve_fp64": {"scan_dominated": b.solve_block(r)},
     }
 
     if not args.no_second_regime and world == 1:
-        del cols
-        torch.cuda.empty_cache()
         f2 = 1.6e-3
-        cols = bind(f2)
-        st = max(1, min(args.steps, 2))
-        dt2, s2, d2, r2 = run(st, 1)
-        c2 = ctx.counters()
+        b.generate(f2)
+        st = max(2, min(args.steps, 2))
+        r2 = b.run(st, 2)
         out["regimes"] = {"highlight_heavy": {
-            "f_hi": f2, "value": round(n_total * st / dt2 / 1e6, 3), "unit": "Msamples/s", "steps": st,
-            "kernels_ms": {"scan": round(s2, 4), "draw": round(d2, 4), "resolve": round(r2, 4)},
-            "attempted_draws": int(c2.attempted_draws),
-            "Mdraws_per_s_attempted": round(c2.attempted_draws / (d2 * 1e-3) / 1e6, 3) if d2 > 0 else None}}
+            "f_hi": f2, "value": round(n_total * st / r2["dt"] / 1e6, 3), "unit": "Msamples/s", "steps": st,
+            "ms_per_step": round(r2["dt"] / st * 1e3, 3),
+            "kernels_ms": {"scan": round(r2["scan"] / st, 4), "draw": round(r2["draw"] / st, 4), "resolve": round(r2["resolve"] / st, 4)},
+            "attempted_draws_per_step": r2["attempted"] // st,
+            "passes": {"streamed": r2["streamed"], "chunks_redone_after_a_short_estimate": r2["redone"]}}}
+        out["solve_fp64"]["highlight_heavy"] = b.solve_block(r2)
+
+    cpu_args = (args, b.p, b.table, M, b.tan_half_fov)
+    b.close()
+
+    if not args.no_configs and world == 1 and not emulate:
+        # BASELINE.json's other single-GPU configurations, measured the same way (alternating streams)
+        cfgs = {}
+        for name, kw in (
+                ("config2_double_gauss_1920x1080_256_draws", dict(W=1920, H=1080, lens="double_gauss_50mm", samples=256, aovs=0, bokeh=False)),
+                ("config3_double_gauss_bokeh_image_3840x2160_512_draws", dict(W=3840, H=2160, lens="double_gauss_50mm", samples=512, aovs=0, bokeh=True)),
+                ("config4_petzval_3840x2160_1024_draws_9_aovs", dict(W=3840, H=2160, lens="petzval_58mm", samples=1024, aovs=8, bokeh=False))):
+            try:
+                c = Bench(torch, dist, dev, local_rank, 1, 0, kw["W"], kw["H"], kw["H"], M, kw["lens"], kw["samples"], kw["aovs"],
+                          args.f_hi, kw["bokeh"])
+                c.generate(args.f_hi)
+                for _ in range(2):
+                    c.step()
+                rc = c.run(4, 2)
+                bpv = 80 + 16 * kw["aovs"]
+                n_c = workload.frame_visit_count(kw["W"], kw["H"], M)
+                ms_c, l_c, lms_c, lb_c, ach_c = summarize(c, rc, n_c, bpv)
+                cfgs[name] = {"value": round(n_c * rc["steps"] / rc["dt"] / 1e6, 3), "unit": "Msamples/s", "ms_per_step": round(ms_c, 4),
+                              "kernels_ms": {"scan": round(rc["scan"] / 4, 4), "draw": round(rc["draw"] / 4, 4), "resolve": round(rc["resolve"] / 4, 4)},
+                              "bytes_per_visit": bpv, "scan_frac_of_hbm_peak": round(ach_c / HBM_PEAK_GBS, 4),
+                              "whole_step_frac_of_hbm_peak": round(n_c * bpv / (ms_c * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                              "attempted_draws_per_step": rc["attempted"] // 4, "passes_streamed": rc["streamed"], "steps": 4}
+                c.close()
+            except Exception as e:      # the headline number must still be reported
+                cfgs[name] = {"value": None, "error": repr(e)}
+        out["configs"] = cfgs
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
-            out["cpu_baseline"] = cpu_baseline(args, p, table, M, tan_half_fov)
+            out["cpu_baseline"] = cpu_baseline(*cpu_args)
         except Exception as e:      # the GPU number must still be reported
             out["cpu_baseline"] = {"value": None, "unit": "Msamples/s", "cores": 0, "kind": "port",
                                    "sample": "failed: %r" % (e,)}
+    from pota_amd import distributed
     if distributed.PHASE_SECONDS:
         sys.stderr.write("[band timing, ms per step incl. warm-up steps] %s\n" % {k: round(v * 1e3 / (args.steps + args.warmup), 3)
                                                                  for k, v in distributed.PHASE_SECONDS.items()})
-    ctx.close()
     used_rccl = dist.is_initialized()
     if used_rccl:
         dist.destroy_process_group()

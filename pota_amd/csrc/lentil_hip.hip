@@ -104,6 +104,7 @@ struct lentil_hip_ctx {
   // Streamed pass (polynomial optics, from the second pass of a context on): one scan launch that publishes its items
   // and their first-batch tasks itself, persistent solve waves that follow the task queue while the scan runs.
   bool stream_mode = true;                   // LENTIL_STREAM=0: chunked passes only
+  uint64_t stream_below = 4ull << 20;        // LENTIL_STREAM_BELOW: ... and for passes with at least this many draws (previous pass's count)
   int stream_blocks = 2;                     // LENTIL_STREAM_BLOCKS: solve blocks per CU beside the scan (1 or 2)
   uint32_t epoch = 0;                        // tag of the current pass's task slots
   uint64_t *d_ranges = nullptr;              // range queue scan -> publish_kernel
@@ -225,6 +226,7 @@ LENTIL_API int lentil_hip_create(int device, lentil_hip_ctx **out_ctx) {
   if (ctx->solve_max_blocks < 1) ctx->solve_max_blocks = 1;
   if (const char *e = getenv("LENTIL_STREAM")) ctx->stream_mode = !(e[0] == '0');
   if (const char *e = getenv("LENTIL_SCAN_DMA")) ctx->scan_dma = !(e[0] == '0');
+  if (const char *e = getenv("LENTIL_STREAM_BELOW")) ctx->stream_below = strtoull(e, nullptr, 10);
   if (const char *e = getenv("LENTIL_STREAM_BLOCKS")) ctx->stream_blocks = atoi(e);
   if (ctx->stream_blocks < 1) ctx->stream_blocks = 1;
   // Never three: three solve blocks per CU fill the register file (3 x 168 of 512 VGPRs per lane), and should they be
@@ -1148,6 +1150,11 @@ static int redistribute_streamed(lentil_hip_ctx *ctx, bool *streamed) {
   if (!ctx->stream_mode || P.cameraType != LENTIL_POLYNOMIAL_OPTICS || !ctx->have_total_est || ctx->V.n == 0)
     return LENTIL_OK;
   if (ctx->V.n > 0xFFFFFFF0ull) return LENTIL_OK;
+  // Streaming pays where the scan is most of the pass.  With many draws the chunked pass is ahead (highlight-heavy
+  // frame: 114 ms against 135 ms; 15 M draws: 16.6 against 18.4 ms -- solve waves placed while the scan's are
+  // resident keep running slower long after those have left, see launch_chunk_rounds), and so it is with extra
+  // AOVs, whose scan kernel leaves the solve waves less room (config 4: 10.8 against 11.5 ms).
+  if (ctx->est_sum_total >= ctx->stream_below || ctx->V.n_extra) return LENTIL_OK;
   lentil_hip_ctx::Chunk &ch = ctx->chunks[0];
   std::lock_guard<std::mutex> one_at_a_time(g_stream_mutex[ctx->device & 63]);
   DrawArgs da{};
@@ -1337,7 +1344,8 @@ static int redistribute_streamed(lentil_hip_ctx *ctx, bool *streamed) {
   }
   ctx->have_total_est = true;
   ctx->est_items_total = ch.est_items; ctx->est_sum_total = ch.est_sum; ctx->est_rounds_total = ch.est_rounds;
-  for (int ci = 1; ci < C; ++ci) { ctx->chunks[ci].have_est = true; ctx->chunks[ci].est_items = 0; ctx->chunks[ci].est_sum = 0; }
+  // (should the next pass run chunked, its chunks look at their scans first: this pass knows nothing about them)
+  for (int ci = 0; ci < C; ++ci) ctx->chunks[ci].have_est = false;
   *streamed = true;
   return LENTIL_OK;
 }
@@ -1529,6 +1537,21 @@ LENTIL_API int lentil_hip_redistribute(lentil_hip_ctx *ctx) {
   }
   HIP_TRY(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
   ctx->timed_draw = true;
+  // A work list, task queue or result pool that was too small drops work on the device (DevCounters::overflow):
+  // that is an incomplete frame, not a result
+  if (ctx->V.n) {
+    if (!ctx->h_ctr_valid) {
+      HIP_TRY(ctx, hipMemcpyAsync(ctx->h_ctr_pinned, ctx->d_ctr, sizeof(DevCounters) * C, hipMemcpyDeviceToHost, ctx->stream));
+      HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+      ctx->h_ctr.assign(ctx->h_ctr_pinned, ctx->h_ctr_pinned + C);
+      ctx->h_ctr_valid = true;
+    }
+    unsigned long long dropped = 0;
+    for (const DevCounters &k : ctx->h_ctr) dropped += k.overflow;
+    if (dropped)
+      return fail(ctx, LENTIL_ERR_NOMEM, "the device dropped " + std::to_string(dropped) +
+                                             " work items (work list, task queue or result pool too small): the frame is incomplete");
+  }
   return LENTIL_OK;
 }
 

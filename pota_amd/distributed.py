@@ -149,6 +149,9 @@ class HipEngine:
     def redistribute(self):
         self.ctx.redistribute()
 
+    def fold_direct(self):
+        self.ctx.accum_buffer()      # what the scan keeps apart for the resolve goes into the block the collective sums
+
     def finish_local(self):
         self.ctx.sync()              # accumulators complete before the collective reads them
 
@@ -185,6 +188,8 @@ def frame_step(engine, dist=None):
     engine.clear()
     engine.redistribute()
     if collective:
+        if hasattr(engine, "fold_direct"):
+            engine.fold_direct()
         engine.finish_local()
         if zkey is not None:
             exchange_closest(zkey, dist)
