@@ -57,6 +57,12 @@ struct DevBokeh {
   const int32_t *rowIndices;
   const float *cdfColumn;
   const int32_t *columnIndices;
+  // Polygonal apertures (bokeh_aperture_blades): sin and cos of the blades' corner angles, [2 k] = sin, [2 k + 1] = cos of
+  // (double)(2.0f * AI_PI / blades * k), k = 0 .. blades, computed by the HOST's libm -- the reference calls std::sin /
+  // std::cos on exactly these few arguments (src/lentil.h:964-982), and the device's own sin / cos differ from glibc's
+  // in the last bit now and then.  Null: more blades than the table holds, device functions.
+  const double *blade_sc;
+  int32_t blade_count;
 };
 
 // ---------------------------------------------------------------------------------------
@@ -142,15 +148,22 @@ LD_DEV void concentricDiskSample_tl(float ox, float oy, double &lx, double &ly, 
 }
 
 // a10 -- Camera::lens_sample_triangular_aperture, src/lentil.h:964-982
-LD_DEV void triangular_aperture(double &x, double &y, double r1, double r2, double radius, int blades) {
+LD_DEV void triangular_aperture(double &x, double &y, double r1, double r2, double radius, int blades,
+                                const double *blade_sc = nullptr, int blade_count = 0) {
   const int tri = (int)(r1 * blades);
   r1 = r1 * blades - tri;
   const double a = sqrt(r1);
   const double b = (1.0 - r2) * a;
   const double c = r2 * a;
-  const double ph1 = (double)(2.0f * kAiPi / (float)blades * (float)(tri + 1));
-  const double ph2 = (double)(2.0f * kAiPi / (float)blades * (float)tri);
-  const double s1 = sin(ph1), c1 = cos(ph1), s2 = sin(ph2), c2 = cos(ph2);
+  double s1, c1, s2, c2;
+  if (blade_sc && blade_count == blades && tri >= 0 && tri < blades) {
+    s1 = blade_sc[2 * (tri + 1)]; c1 = blade_sc[2 * (tri + 1) + 1];
+    s2 = blade_sc[2 * tri]; c2 = blade_sc[2 * tri + 1];
+  } else {
+    const double ph1 = (double)(2.0f * kAiPi / (float)blades * (float)(tri + 1));
+    const double ph2 = (double)(2.0f * kAiPi / (float)blades * (float)tri);
+    s1 = sin(ph1); c1 = cos(ph1); s2 = sin(ph2); c2 = cos(ph2);
+  }
   x = radius * (b * c1 + c * c2);
   y = radius * (b * s1 + c * s2);
 }
@@ -451,7 +464,7 @@ LD_DEV void po_aperture_sample(const lentil_params &P, const DevBokeh &B, const 
     ay = uy * P.aperture_radius;
   } else {
     const float d1 = lcg(seed), d2 = lcg(seed);
-    triangular_aperture(ax, ay, (double)d2, (double)d1, P.aperture_radius, P.bokeh_aperture_blades);
+    triangular_aperture(ax, ay, (double)d2, (double)d1, P.aperture_radius, P.bokeh_aperture_blades, B.blade_sc, B.blade_count);
   }
 }
 
@@ -744,7 +757,7 @@ LD_DEV bool thinlens_draw(const lentil_params &P, const DevBokeh &B, const float
     concentricDiskSample_tl(d2, d1, ux, uy, P.abb_spherical, P.circle_to_square);
   } else {
     const float d1 = lcg(seed), d2 = lcg(seed);
-    triangular_aperture(ux, uy, (double)d2, (double)d1, 1.0, P.bokeh_aperture_blades);
+    triangular_aperture(ux, uy, (double)d2, (double)d1, 1.0, P.bokeh_aperture_blades, B.blade_sc, B.blade_count);
   }
   ux *= (double)P.bokeh_anamorphic;
   const float lx = (float)(ux * P.aperture_radius), ly = (float)(uy * P.aperture_radius), lz = 0.0f;

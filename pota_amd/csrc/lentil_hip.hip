@@ -1,6 +1,7 @@
 // lentil_hip.hip -- C-ABI of liblentil_hip.so (gfx950 only): host side.  Kernels: lentil_kernels.h.
 #include <hip/hip_runtime.h>
 
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -35,6 +36,8 @@ struct lentil_hip_ctx {
 
   DevBokeh bokeh{};
   bool have_bokeh = false;
+  double *d_blade_sc = nullptr;       // DevBokeh::blade_sc (see there)
+  int blade_count = 0;
 
   FrameDev F{};
   uint8_t kind[LENTIL_MAX_AOVS] = {0};
@@ -253,6 +256,8 @@ static void free_bokeh(lentil_hip_ctx *ctx) {
     (void)hipFree((void *)ctx->bokeh.columnIndices);
   }
   ctx->bokeh = DevBokeh{};
+  ctx->bokeh.blade_sc = ctx->blade_count ? ctx->d_blade_sc : nullptr;
+  ctx->bokeh.blade_count = ctx->blade_count;
   ctx->have_bokeh = false;
 }
 
@@ -264,6 +269,7 @@ LENTIL_API int lentil_hip_destroy(lentil_hip_ctx *ctx) {
   free_bokeh(ctx);
   (void)hipFree(ctx->d_lens);
   (void)hipFree(ctx->d_terms);
+  (void)hipFree(ctx->d_blade_sc);
   (void)hipFree(ctx->F.acc);
   (void)hipFree(ctx->F.zkey);
   (void)hipFree(ctx->F.zkey_dbg);
@@ -310,6 +316,30 @@ LENTIL_API int lentil_hip_set_params(lentil_hip_ctx *ctx, const lentil_params *p
     return fail(ctx, LENTIL_ERR_INVALID, "xres/yres changed after alloc_frame");
   ctx->P = *p;
   ctx->have_params = true;
+  // polygonal apertures: the corner angles' sin / cos from this host's libm (DevBokeh::blade_sc)
+  {
+    constexpr int kMaxBlades = 255;
+    const int blades = p->bokeh_aperture_blades;
+    if (blades >= 2 && blades <= kMaxBlades) {
+      if (blades != ctx->blade_count) {
+        HIP_TRY(ctx, hipSetDevice(ctx->device));
+        if (!ctx->d_blade_sc) HIP_TRY(ctx, hipMalloc(&ctx->d_blade_sc, sizeof(double) * 2 * (kMaxBlades + 1)));
+        std::vector<double> sc(2 * (size_t)(blades + 1));
+        for (int k = 0; k <= blades; ++k) {
+          const double ph = (double)(2.0f * 3.14159265358979f / (float)blades * (float)k);     // AI_PI is a float constant
+          sc[2 * (size_t)k] = std::sin(ph);
+          sc[2 * (size_t)k + 1] = std::cos(ph);
+        }
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));       // (no pass is reading the old table)
+        HIP_TRY(ctx, hipMemcpy(ctx->d_blade_sc, sc.data(), sc.size() * sizeof(double), hipMemcpyHostToDevice));
+        ctx->blade_count = blades;
+      }
+    } else {
+      ctx->blade_count = 0;
+    }
+    ctx->bokeh.blade_sc = ctx->blade_count ? ctx->d_blade_sc : nullptr;
+    ctx->bokeh.blade_count = ctx->blade_count;
+  }
   // lambda powers depend on the params' wavelength
   if (ctx->have_lens) {
     const double lam = (double)p->lambda_bw;

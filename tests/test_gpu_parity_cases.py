@@ -1,0 +1,210 @@
+"""More GPU-vs-oracle parity cases (round 2): branches of the device code that the first round's suite never ran --
+the polygonal aperture of the polynomial-optics path, enable_dof = 0, cylindrical pupils -- full-size geometry for
+BASELINE configs 1 and 2, and the two captured input files the reference's own tests hold
+(tests/golden/sampledata_2k.npy, po_bidir_positions.npy; tools/make_sample_fixtures.py).
+
+Bar as everywhere: accepted-draw lists (visit, attempt, pixel) bit-identical, counters equal, frames within 1e-5.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import common
+import oracle_lib
+from pota_amd import capi, workload
+from test_gpu_parity import _band_parity_at_full_geometry, check_frame, check_logs, gpu_run
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(common.ROOT, "tests", "golden")
+
+
+def _same_counters(c, ref):
+    rc = ref.counters()
+    assert (c.redistributed_visits, c.attempted_draws, c.accepted_draws) == (
+        rc.redistributed_visits, rc.attempted_draws, rc.accepted_draws)
+    return rc
+
+
+@pytest.mark.parametrize("blades", [3, 5, 6, 8])
+def test_po_polygonal_aperture(orc, gpu_ctx_factory, blades):
+    """bokeh_aperture_blades > 2 in polynomial-optics mode: Camera::lens_sample_triangular_aperture with
+    radius = aperture_radius, no image option (src/lentil.h:597-609, 964-982; the threshold differs from the thin
+    lens's)."""
+    W, H, M = 64, 48, 9
+    p, model, table, keep = common.po_setup(W, H, samples_override=48, bokeh_aperture_blades=blades)
+    visits, cols = common.make_stream(p, W, H, M, f_hi=0.02)
+    ref = common.run_oracle(orc, p, table, visits)
+    assert ref.counters().redistributed_visits > 100
+    ctx = gpu_ctx_factory()
+    for lens_mode in (0, 1):                      # compiled kernel, table interpreter
+        c = gpu_run(ctx, p, table, visits, lens_mode=lens_mode)
+        _same_counters(c, ref)
+        check_logs(ctx, ref)
+        check_frame(ctx, ref)
+    # the aperture draws themselves, bit for bit
+    rng = np.random.default_rng(blades)
+    a = rng.integers(0, 2 ** 32, 4096, dtype=np.uint64).astype(np.uint32)
+    b = rng.integers(0, 6000, 4096, dtype=np.uint64).astype(np.uint32)
+    got = ctx.test_aperture_sample(a, b)
+    want = np.empty_like(got)
+    xy = (C.c_double * 2)()
+    for i in range(a.shape[0]):
+        orc.orc_po_aperture_sample(C.byref(p), None, int(a[i]), int(b[i]), xy)
+        want[i] = xy[0], xy[1]
+    assert np.array_equal(got, want)
+
+
+def test_po_enable_dof_off(orc, gpu_ctx_factory):
+    """enable_dof = 0: every backward trace goes through the aperture's centre (src/lentil.h:592-595)."""
+    W, H, M = 64, 48, 9
+    p, model, table, keep = common.po_setup(W, H, samples_override=32, enable_dof=0)
+    visits, cols = common.make_stream(p, W, H, M, f_hi=0.02)
+    ref = common.run_oracle(orc, p, table, visits)
+    assert ref.counters().redistributed_visits > 100
+    ctx = gpu_ctx_factory()
+    c = gpu_run(ctx, p, table, visits)
+    _same_counters(c, ref)
+    check_logs(ctx, ref)
+    check_frame(ctx, ref)
+
+
+def test_po_cylindrical_outer_pupil(orc, gpu_ctx_factory):
+    """A lens whose outer pupil is a cylinder (axis along y: "cyl-y", the anamorphic front attachment of
+    pota_amd/lenses/anamorphic_petzval_58mm.json): cylinderToCs / csToCylinder in every Newton iteration
+    (src/lens.h:156-221, src/lentil.h:387-389).  Table interpreter (no compiled kernel is shipped for this table)."""
+    W, H, M = 64, 48, 9
+    p, model, table, keep = common.po_setup(W, H, lens="anamorphic_petzval_58mm", samples_override=32)
+    assert table.lens_outer_pupil_geometry != 0
+    visits, cols = common.make_stream(p, W, H, M, f_hi=0.03)
+    ref = common.run_oracle(orc, p, table, visits)
+    rc = ref.counters()
+    assert rc.redistributed_visits > 100 and rc.accepted_draws > 1000      # the solver does converge on this table
+    ctx = gpu_ctx_factory()
+    c = gpu_run(ctx, p, table, visits, compiled=False)
+    _same_counters(c, ref)
+    check_logs(ctx, ref)
+    check_frame(ctx, ref)
+    # lt_sample_aperture alone, fp64 bit for bit
+    rng = np.random.default_rng(11)
+    n = 2048
+    scene = np.stack([rng.uniform(-400, 400, n), rng.uniform(-300, 300, n), rng.uniform(600, 4000, n)], 1)
+    ap = rng.uniform(-0.7, 0.7, (n, 2)) * float(p.aperture_radius)
+    lam = float(np.float32(0.55))
+    sensor, out, T = ctx.test_lt_sample_aperture(scene, ap, lam)
+    lens = orc.orc_lens_create(C.byref(table))
+    es, eo, eT = np.empty_like(sensor), np.empty_like(out), np.empty_like(T)
+    s5, o5 = (C.c_double * 5)(), (C.c_double * 5)()
+    for i in range(n):
+        for k in range(5):
+            o5[k] = 0.0
+        o5[4] = lam
+        eT[i] = orc.orc_lt_sample_aperture(lens, oracle_lib.darr(*scene[i]), oracle_lib.darr(*ap[i]), s5, o5, lam, None)
+        es[i] = list(s5)
+        eo[i] = list(o5)
+    orc.orc_lens_destroy(lens)
+    assert (eT > 0).mean() > 0.2
+    assert np.array_equal(T, eT, equal_nan=True)
+    assert np.array_equal(sensor, es, equal_nan=True)
+    assert np.array_equal(out, eo, equal_nan=True)
+
+
+def test_config1_thinlens_512_full_frame(orc, gpu_ctx_factory):
+    """BASELINE config 1 at its full size: thin lens, 512 x 512, 64 draws, beauty only -- the whole frame against the
+    oracle (2.4 M visits; the thin-lens draw has no solver, the oracle takes a few seconds)."""
+    W = H = 512
+    M = 9
+    p = common.tl_setup(W, H, samples_override=64)
+    visits, cols = common.make_stream(p, W, H, M, f_hi=2.0 ** -9)
+    ref = common.run_oracle(orc, p, None, visits)
+    assert ref.counters().redistributed_visits > 3000
+    ctx = gpu_ctx_factory()
+    c = gpu_run(ctx, p, None, visits)
+    _same_counters(c, ref)
+    check_logs(ctx, ref)
+    check_frame(ctx, ref)
+
+
+def test_config2_1080p_bands(orc, gpu_ctx_factory):
+    """BASELINE config 2 (double-gauss, 1920 x 1080, 256 draws, beauty): three bands of rows at full-frame geometry --
+    top edge, centre, bottom edge -- against the oracle."""
+    W, H, M = 1920, 1080, 9
+    p, model, table, keep = common.po_setup(W, H, samples_override=256)
+    ctx = gpu_ctx_factory()
+    for y0 in (0, 538, 1076):
+        _band_parity_at_full_geometry(orc, ctx, p, table, W, M, y0, 4, 2.0 ** -9)
+
+
+def _captured_stream(p, W, H, pos_cs, rgba, depth):
+    """Visits from captured camera-space positions: identity world_to_camera, pixel = pinhole projection of the
+    position (ragged stream with explicit pixels), uniform inverse density."""
+    n = pos_cs.shape[0]
+    t = common.tan_half_fov(p)
+    fx = pos_cs[:, 0] / (-pos_cs[:, 2]) / t
+    fy = pos_cs[:, 1] / (-pos_cs[:, 2]) / (t * H / W)
+    px = np.clip(((fx + 1.0) * 0.5 * W).astype(np.int64), 0, W - 1).astype(np.uint32)
+    py = np.clip(((1.0 - fy) * 0.5 * H).astype(np.int64), 0, H - 1).astype(np.uint32)
+    z = np.zeros((n, 4), np.float32)
+    nrm = np.linalg.norm(pos_cs, axis=1, keepdims=True)
+    cols = {
+        "rgba": np.ascontiguousarray(rgba, np.float32),
+        "pos_z": np.ascontiguousarray(np.concatenate([pos_cs, depth[:, None]], 1), np.float32),
+        "raydir_time": np.ascontiguousarray(np.concatenate([pos_cs / nrm, np.zeros((n, 1))], 1), np.float32),
+        "volume_ignore": z.copy(), "transmission": z.copy(), "extra": [],
+        "pixel": (px | (py << 16)).astype(np.uint32),
+    }
+    visits, keep = capi.make_visits(cols, visits_per_pixel=0)
+    return visits, (cols, keep)
+
+
+@pytest.mark.parametrize("mode", ["thinlens", "po"])
+def test_captured_light_grid_samples(orc, gpu_ctx_factory, mode):
+    """The reference's captured AOV samples (tests/cuda/sampledata.txt, every 26th line: RGBA 84.1589, depth, camera-
+    space position of the light-grid scene) as the input of a pass, thin lens and polynomial optics."""
+    d = np.load(os.path.join(GOLDEN, "sampledata_2k.npy"))
+    W, H = 96, 64
+    if mode == "thinlens":
+        p, table = common.tl_setup(W, H, samples_override=24), None
+    else:
+        p, model, table, keep = common.po_setup(W, H, samples_override=24, focus_dist=110.0)
+    visits, keepv = _captured_stream(p, W, H, d[:, 5:8].astype(np.float64), d[:, 0:4], d[:, 4])
+    ref = common.run_oracle(orc, p, table, visits)
+    assert ref.counters().redistributed_visits > 500
+    ctx = gpu_ctx_factory()
+    c = gpu_run(ctx, p, table, visits)
+    _same_counters(c, ref)
+    check_logs(ctx, ref)
+    check_frame(ctx, ref)
+
+
+@pytest.mark.parametrize("mode", ["thinlens", "po"])
+def test_captured_sphere_positions(orc, gpu_ctx_factory, mode):
+    """The 3 699 camera-space positions of tests/po_bidir_debug/po_bidir_spheres_debug_position.txt (the debug dump of
+    the reference's bidirectional spheres scene) as highlights."""
+    pos = np.load(os.path.join(GOLDEN, "po_bidir_positions.npy")).astype(np.float64)
+    n = pos.shape[0]
+    W, H = 96, 64
+    if mode == "thinlens":
+        p, table = common.tl_setup(W, H, samples_override=16), None
+    else:
+        p, model, table, keep = common.po_setup(W, H, samples_override=16, focus_dist=90.0)
+    rgba = np.tile(np.array([workload.HIGHLIGHT_RADIANCE] * 3 + [1.0], np.float32), (n, 1))
+    visits, keepv = _captured_stream(p, W, H, pos, rgba, np.linalg.norm(pos, axis=1).astype(np.float32))
+    ref = common.run_oracle(orc, p, table, visits)
+    assert ref.counters().redistributed_visits > 1000
+    ctx = gpu_ctx_factory()
+    c = gpu_run(ctx, p, table, visits)
+    _same_counters(c, ref)
+    check_logs(ctx, ref)
+    check_frame(ctx, ref)
+
+
+def test_config5_8k_bands(orc, gpu_ctx_factory):
+    """BASELINE config 5's geometry (double-gauss, 7680 x 4320, 2048 draws -- above the reference's clamp of 2000,
+    hence an override): single rows at the top edge and in the centre of the frame against the oracle."""
+    W, H, M = 7680, 4320, 9
+    p, model, table, keep = common.po_setup(W, H, samples_override=2048)
+    ctx = gpu_ctx_factory()
+    for y0 in (0, 2160):
+        _band_parity_at_full_geometry(orc, ctx, p, table, W, M, y0, 1, 2.0 ** -11)

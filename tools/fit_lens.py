@@ -69,10 +69,19 @@ _PZ = [
     (-157.8, 40.7, AIR, 18.0),
 ]
 
+# The same Petzval behind a weak cylindrical front attachment (curved in x only: a 1.33x-style anamorphic squeeze):
+# the outer pupil is then a cylinder with its axis along y -- lens_outer_pupil_geometry "cyl-y", the
+# cylinderToCs / csToCylinder parametrisation of src/lens.h:156-221.  A sixth entry "cyl-y" marks such a surface.
+_PZ_ANA = [
+    (120.0, 3.5, BK7, 23.0, "cyl-y"),
+    (0.0, 6.0, AIR, 23.0),
+] + _PZ
+
 LENSES = {
     # name: (prescription, scale, max_degree, n_terms, sensor half-extent used for the fit [mm])
     "double_gauss_50mm": dict(rx=_DG, scale=0.5, degree=7, terms=36, field=18.0),
     "petzval_58mm": dict(rx=_PZ, scale=0.4745, degree=9, terms=48, field=16.0, refocus=True),
+    "anamorphic_petzval_58mm": dict(rx=_PZ_ANA, scale=0.4745, degree=7, terms=32, field=14.0, refocus=True, outer="cyl-y"),
 }
 
 
@@ -103,14 +112,15 @@ class Lens:
     def __init__(self, rx, scale, refocus=False):
         if refocus:     # put the sensor at the paraxial focus for infinity
             rx = list(rx)
-            rx[-1] = (rx[-1][0], paraxial_bfl(rx), rx[-1][2], rx[-1][3])
+            rx[-1] = (rx[-1][0], paraxial_bfl([e[:4] for e in rx if not (len(e) > 4)]), rx[-1][2], rx[-1][3])
         self.rx = rx
         self.surf = []
         z = 0.0
-        for (R, t, glass, sd) in rx:
+        for ent in rx:
+            R, t, glass, sd = ent[:4]
             stop = R == "stop"
             self.surf.append(dict(R=0.0 if stop else R * scale, z=z, glass=glass,
-                                  sd=sd * scale, stop=stop))
+                                  sd=sd * scale, stop=stop, cyl=(len(ent) > 4 and ent[4] == "cyl-y")))
             z += t * scale
         self.z_sensor = z            # standard frame: surface 1 vertex at z=0, sensor at +z
         self.bfl = self.rx[-1][1] * scale
@@ -133,6 +143,22 @@ class Lens:
                 t = (s["z"] - o[:, 2]) / d[:, 2]
                 p = o + t[:, None] * d
                 nrm = np.tile(np.array([0.0, 0.0, 1.0]), (n, 1))
+            elif s.get("cyl"):
+                # cylinder with its axis along y through (0, *, z + R): x^2 + (z - c)^2 = R^2
+                c = np.array([0.0, 0.0, s["z"] + R])
+                oc = o - c
+                a2 = d[:, 0] ** 2 + d[:, 2] ** 2
+                b = (oc[:, 0] * d[:, 0] + oc[:, 2] * d[:, 2]) / a2
+                cc = (oc[:, 0] ** 2 + oc[:, 2] ** 2 - R * R) / a2
+                disc = b * b - cc
+                ok &= disc > 0
+                sq = np.sqrt(np.maximum(disc, 0.0))
+                t1, t2 = -b - sq, -b + sq
+                p1 = o + t1[:, None] * d
+                use1 = np.sign(p1[:, 2] - c[2]) == -np.sign(R)
+                t = np.where(use1, t1, t2)
+                p = o + t[:, None] * d
+                nrm = -np.stack([p[:, 0] - c[0], np.zeros(n), p[:, 2] - c[2]], 1) / R
             else:
                 c = np.array([0.0, 0.0, s["z"] + R])
                 oc = o - c
@@ -174,7 +200,10 @@ class Lens:
         pos = np.stack([o[:, 0], o[:, 1], -o[:, 2]], 1)
         dr = np.stack([d[:, 0], d[:, 1], -d[:, 2]], 1)
         nz = np.abs((pos[:, 2] + R1) / R1)
-        nrm = np.stack([pos[:, 0] / R1, pos[:, 1] / R1, nz], 1)
+        if self.surf[0].get("cyl"):     # csToCylinder, cyl-y (src/lens.h:190-221): the normal has no y component
+            nrm = np.stack([pos[:, 0] / R1, np.zeros(n), nz], 1)
+        else:
+            nrm = np.stack([pos[:, 0] / R1, pos[:, 1] / R1, nz], 1)
         ex = np.stack([nrm[:, 2], np.zeros(n), -nrm[:, 0]], 1)
         ex /= np.linalg.norm(ex, axis=1, keepdims=True)
         ey = np.cross(nrm, ex)
@@ -304,7 +333,7 @@ def build(name, spec, seed=1234, n_rays=400000, n_fit=40000):
         lens_fstop=fstop,
         lens_aperture_radius_at_fstop=stop["sd"],
         lens_inner_pupil_geometry="spherical",
-        lens_outer_pupil_geometry="spherical",
+        lens_outer_pupil_geometry=spec.get("outer", "spherical"),
     )
     table = dict(name=name, constants=consts, polys=polys,
                  note="self-fitted by tools/fit_lens.py; NOT a polynomial-optics database lens")
