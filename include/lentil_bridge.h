@@ -98,6 +98,21 @@ int lentil_filter_output_type(int input_type);             /* RGBA/RGB/VECTOR/FL
 float lentil_filter_inverse_sample_density(int samples_in_footprint, float filter_width, int aa_samples_set_by_user,
                                            int *disable_redistribution);
 
+/* Camera::setup_filter, the resolution / region part (src/lentil.h:1060-1080): region_* as options hold them
+ * (INT32_MIN / INT32_MAX = unset -> the whole frame, with region_max = res: the W + 1 quirk); fills xres, yres,
+ * xres_without_region, yres_without_region, region_min_x/y and filter_width of `p`. */
+void lentil_setup_filter_region(lentil_params *p, int xres, int yres, int region_min_x, int region_min_y, int region_max_x,
+                                int region_max_y, float filter_width);
+
+/* The display pass-through of filter_pixel (src/lentil_filter.cpp:453-479): what Arnold shows until the imager
+ * overwrites it.  Camera::filter_gaussian_complete (src/lentil.h:738-775): samples within the filter radius weighted
+ * by exp(-2 r) * inverse density (the SDK's AiFastExp is an approximation of exp; display only) -- offsets_xy 2 n,
+ * values_rgba 4 n, inv_density n or NULL for a uniform value.  Camera::filter_closest_complete (src/lentil.h:696-735):
+ * the value of the sample with the smallest |depth| (later samples win ties; depth 0 re-opens), alpha 1. */
+void lentil_filter_gaussian_complete(int n, const float *offsets_xy, const float *values_rgba, const float *inv_density,
+                                     float uniform_inv_density, float filter_width, float out_rgba[4]);
+void lentil_filter_closest_complete(int n, const float *depth, const float *values_rgba, float out_rgba[4]);
+
 /* ------------------------------------------------------------------------------------
  * lentil_operator (src/lentil_operator.cpp:25-127) and the output-string tokens it edits
  * (TokenizedOutputLentil, src/aov_data.h:12-115)

@@ -56,6 +56,7 @@ EXPORTS = [
     "lentil_stage_create", "lentil_stage_destroy", "lentil_stage_reset", "lentil_stage_append", "lentil_stage_size",
     "lentil_stage_visits", "lentil_imager_create", "lentil_imager_destroy", "lentil_imager_new_frame",
     "lentil_imager_process_bucket", "lentil_imager_last_error",
+    "lentil_setup_filter_region", "lentil_filter_gaussian_complete", "lentil_filter_closest_complete",
 ]
 
 _lib = None
@@ -99,6 +100,9 @@ def load():
         "lentil_imager_new_frame": (None, [vp]),
         "lentil_imager_process_bucket": (i, [vp, u32, i, i, i, i, vp]),
         "lentil_imager_last_error": (C.c_char_p, [vp]),
+        "lentil_setup_filter_region": (None, [C.POINTER(_abi.Params), i, i, i, i, i, i, f]),
+        "lentil_filter_gaussian_complete": (None, [i, vp, vp, vp, f, f, vp]),
+        "lentil_filter_closest_complete": (None, [i, vp, vp, vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)
@@ -106,6 +110,25 @@ def load():
         fn.argtypes = args
     _lib = lib
     return lib
+
+
+def camera_node_parameters():
+    """The camera node's parameter table (src/lentil_camera.cpp:19-52) as a list of dicts."""
+    lib = load()
+    n = C.c_int()
+    arr = lib.lentil_camera_node_parameters(C.byref(n))
+    out = []
+    for k in range(n.value):
+        p = arr[k]
+        enum = []
+        if p.enum_values:
+            j = 0
+            while p.enum_values[j]:
+                enum.append(p.enum_values[j].decode())
+                j += 1
+        out.append({"name": p.name.decode(), "type": int(p.type), "default": float(p.default_value),
+                    "default_string": p.default_string.decode() if p.default_string else None, "enum_values": enum})
+    return out
 
 
 def operator_cook(outputs, filter_entry_names):

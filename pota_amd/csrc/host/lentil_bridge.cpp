@@ -3,6 +3,7 @@
 #include "lentil_bridge.h"
 
 #include <cmath>
+#include <cstdint>
 #include <cstdio>
 #include <cstring>
 #include <mutex>
@@ -20,7 +21,7 @@ static const char *const kCameraTypes[] = {"ThinLens", "PolynomialOptics", nullp
 static const char *const kChromaticTypes[] = {"green_magenta", "red_cyan", nullptr};
 // the reference splices its lens list in from a generated header that is not in its tree
 // (include/auto_generated_lens_includes/pota_cpp_lenses.h); the lenses shipped here take its place
-static const char *const kLensModels[] = {"double_gauss_50mm", "petzval_58mm", nullptr};
+static const char *const kLensModels[] = {"double_gauss_50mm", "petzval_58mm", "anamorphic_petzval_58mm", nullptr};
 
 #define P_ENUM(n, d, v) {n, LENTIL_AI_TYPE_ENUM, (double)(d), nullptr, v}
 #define P_INT(n, d) {n, LENTIL_AI_TYPE_INT, (double)(d), nullptr, nullptr}
@@ -303,6 +304,54 @@ BRIDGE_API int lentil_sanitize_aov_list(lentil_aov_plan *plans, int n) {
     ++m;
   }
   return m;
+}
+
+// ---------------------------------------------------------------------------------------
+// setup_filter (resolution / region) and the display pass-through filters
+// ---------------------------------------------------------------------------------------
+BRIDGE_API void lentil_setup_filter_region(lentil_params *p, int xres, int yres, int region_min_x, int region_min_y,
+                                           int region_max_x, int region_max_y, float filter_width) {
+  if (!p) return;
+  auto unset = [](int v) { return v == INT32_MIN || v == INT32_MAX; };
+  if (unset(region_min_x) || unset(region_max_x) || unset(region_min_y) || unset(region_max_y)) {     // src/lentil.h:1068-1077
+    region_min_x = 0; region_min_y = 0; region_max_x = xres; region_max_y = yres;
+  }
+  p->xres_without_region = (uint32_t)xres;
+  p->yres_without_region = (uint32_t)yres;
+  p->region_min_x = region_min_x;
+  p->region_min_y = region_min_y;
+  p->xres = (uint32_t)(region_max_x - region_min_x + 1);
+  p->yres = (uint32_t)(region_max_y - region_min_y + 1);
+  p->filter_width = filter_width;
+}
+
+BRIDGE_API void lentil_filter_gaussian_complete(int n, const float *offsets_xy, const float *values_rgba, const float *inv_density,
+                                                float uniform_inv_density, float filter_width, float out_rgba[4]) {
+  float aweight = 0.0f, av[4] = {0, 0, 0, 0};
+  for (int i = 0; i < n; ++i) {
+    const float invd = inv_density ? inv_density[i] : uniform_inv_density;
+    if (invd <= 0.f) continue;
+    const float k = 2.0f / filter_width;
+    const float r = (k * k) * (offsets_xy[2 * i] * offsets_xy[2 * i] + offsets_xy[2 * i + 1] * offsets_xy[2 * i + 1]);
+    if (r > 1.0f) continue;
+    const float w = std::exp(2 * -r) * invd;
+    for (int c = 0; c < 4; ++c) av[c] += w * values_rgba[4 * i + c];
+    aweight += w;
+  }
+  if (aweight != 0.0f) for (int c = 0; c < 4; ++c) av[c] *= 1.0f / aweight;
+  for (int c = 0; c < 4; ++c) out_rgba[c] = av[c];
+}
+
+BRIDGE_API void lentil_filter_closest_complete(int n, const float *depth, const float *values_rgba, float out_rgba[4]) {
+  float z = 0.0f;
+  out_rgba[0] = out_rgba[1] = out_rgba[2] = out_rgba[3] = 0.0f;
+  for (int i = 0; i < n; ++i) {
+    if (std::fabs(depth[i]) <= z || z == 0.0f) {
+      z = std::fabs(depth[i]);
+      out_rgba[0] = values_rgba[4 * i]; out_rgba[1] = values_rgba[4 * i + 1]; out_rgba[2] = values_rgba[4 * i + 2];
+      out_rgba[3] = 1.0f;
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------------------

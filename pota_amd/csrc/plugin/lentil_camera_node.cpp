@@ -1,0 +1,273 @@
+// lentil_camera_node.cpp -- the lentil_camera node (src/lentil_camera.cpp): parameters from the bridge's table,
+// Camera state as local data, forward rays from the host library, and LentilCamera::setup -- the counterpart of
+// Camera::setup_camera (src/lentil.h:211-280) that ends with the GPU context ready for the frame.
+#include "lentil_plugin.h"
+
+#include <climits>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+#include "../generated/lens_tables_host.h"
+
+AI_CAMERA_NODE_EXPORT_METHODS(LentilCameraMtd)
+
+const LentilStrings &lentil_strings() {
+  static const LentilStrings s;
+  return s;
+}
+
+node_parameters {
+  // same names, types, defaults and order as src/lentil_camera.cpp:19-52 (lentil_camera_node_parameters());
+  // the lens_model enum lists the tables this build ships
+  int n = 0;
+  const lentil_node_param *p = lentil_camera_node_parameters(&n);
+  for (int i = 0; i < n; ++i) {
+    switch (p[i].type) {
+      case LENTIL_AI_TYPE_INT: AiParameterInt(p[i].name, (int)p[i].default_value) break;
+      case LENTIL_AI_TYPE_FLOAT: AiParameterFlt(p[i].name, (float)p[i].default_value) break;
+      case LENTIL_AI_TYPE_BOOLEAN: AiParameterBool(p[i].name, p[i].default_value != 0.0) break;
+      case LENTIL_AI_TYPE_STRING: AiParameterStr(p[i].name, p[i].default_string ? p[i].default_string : "") break;
+      case LENTIL_AI_TYPE_ENUM: AiParameterEnum(p[i].name, (int)p[i].default_value, const_cast<const char **>(p[i].enum_values)) break;
+      default: break;
+    }
+  }
+  AiMetaDataSetBool(nentry, nullptr, "force_update", true);
+}
+
+node_plugin_initialize { (void)plugin_data; return true; }
+node_plugin_cleanup { (void)plugin_data; }
+
+node_initialize {
+  AiCameraInitialize(node);
+  AiNodeSetLocalData(node, new LentilCamera());
+}
+
+node_update {
+  LentilCamera *cam = (LentilCamera *)AiNodeGetLocalData(node);
+  cam->setup(AiNodeGetUniverse(node));
+  AiCameraUpdate(node, false);
+}
+
+node_finish {
+  delete (LentilCamera *)AiNodeGetLocalData(node);
+  AiNodeSetLocalData(node, nullptr);
+}
+
+camera_create_ray {
+  LentilCamera *cam = (LentilCamera *)AiNodeGetLocalData(node);
+  // xor128 state for the vignetting retries: per thread (the reference's generator is a function static shared by
+  // all threads, src/global.h:22-27)
+  thread_local uint32_t rng[4];
+  thread_local bool seeded = false;
+  if (!seeded) { lentil_host_xor128_init(rng); seeded = true; }
+  (void)tid;
+  const float in[6] = {input.sx, input.sy, input.dsx, input.dsy, input.lensx, input.lensy};
+  lentil_host_camera_ray r;
+  lentil_host_camera_create_ray(&cam->P, cam->host_lens, cam->have_bokeh ? &cam->bokeh : nullptr, rng, cam->lambda_um,
+                                cam->exposure, in, &r);
+  output.origin = AtVector(r.origin[0], r.origin[1], r.origin[2]);
+  output.dir = AtVector(r.dir[0], r.dir[1], r.dir[2]);
+  output.weight = AtRGB(r.weight[0], r.weight[1], r.weight[2]);
+  output.dOdx = AtVector(r.dOdx[0], r.dOdx[1], r.dOdx[2]);
+  output.dOdy = AtVector(r.dOdy[0], r.dOdy[1], r.dOdy[2]);
+  output.dDdx = AtVector(r.dDdx[0], r.dDdx[1], r.dDdx[2]);
+  output.dDdy = AtVector(r.dDdy[0], r.dDdy[1], r.dDdy[2]);
+}
+
+camera_reverse_ray {
+  LentilCamera *cam = (LentilCamera *)AiNodeGetLocalData(node);
+  (void)relative_time;
+  const float po[3] = {Po.x, Po.y, Po.z};
+  float ps[2];
+  lentil_host_camera_reverse_ray(cam->tan_fov, po, ps);
+  Ps.x = ps[0];
+  Ps.y = ps[1];
+  return true;
+}
+
+void registerLentilCamera(AtNodeLib *node) {
+  node->methods = (const void *)LentilCameraMtd;
+  node->output_type = AI_TYPE_UNDEFINED;
+  node->name = "lentil_camera";
+  node->node_type = AI_NODE_CAMERA;
+  strncpy(node->version, AI_VERSION, AI_MAXSIZE_VERSION - 1);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+LentilCamera::~LentilCamera() {
+  release_gpu();
+  if (host_lens) lentil_host_lens_destroy(host_lens);
+}
+
+void LentilCamera::release_gpu() {
+  if (imager) { lentil_imager_destroy(imager); imager = nullptr; }
+  if (stage) { lentil_stage_destroy(stage); stage = nullptr; }
+  if (gpu) { lentil_hip_destroy(gpu); gpu = nullptr; }
+}
+
+int LentilCamera::aov_index(const char *name) const {
+  for (size_t i = 0; i < aovs.size(); ++i)
+    if (strcmp(aovs[i].name, name) == 0) return (int)i;
+  return -1;
+}
+
+int LentilCamera::thread_slot() {
+  thread_local int slot = -1;
+  thread_local const LentilCamera *owner = nullptr;
+  if (slot < 0 || owner != this) { slot = next_slot++; owner = this; }
+  return slot;
+}
+
+void LentilCamera::setup(AtUniverse *universe) {
+  std::lock_guard<std::mutex> guard(setup_mutex);
+  const LentilStrings &S = lentil_strings();
+  options_node = AiUniverseGetOptions(universe);
+  camera_node = AiUniverseGetCamera(universe);
+  redistribution = false;
+
+  // ---- get_lentil_camera_params (src/lentil.h:1189-1243): one getter per parameter of the table
+  lentil_camera_node_values v;
+  lentil_camera_node_defaults(&v);
+  auto I = [&](const char *n) { return AiNodeGetInt(camera_node, AtString(n)); };
+  auto F = [&](const char *n) { return AiNodeGetFlt(camera_node, AtString(n)); };
+  auto B = [&](const char *n) { return AiNodeGetBool(camera_node, AtString(n)) ? 1 : 0; };
+  v.camera_type = I("camera_type"); v.bidir_sample_mult = I("bidir_sample_mult"); v.units = I("units");
+  v.sensor_width = F("sensor_width"); v.enable_dof = B("enable_dof"); v.fstop = F("fstop"); v.focus_dist = F("focus_dist");
+  v.aperture_blades_lentil = I("aperture_blades_lentil"); v.exp = F("exp"); v.lens_model = I("lens_model");
+  v.wavelength = F("wavelength"); v.extra_sensor_shift = F("extra_sensor_shift"); v.focal_length_lentil = F("focal_length_lentil");
+  v.optical_vignetting = F("optical_vignetting"); v.abb_spherical = F("abb_spherical"); v.abb_distortion = F("abb_distortion");
+  v.abb_coma = F("abb_coma"); v.abb_chromatic = F("abb_chromatic"); v.abb_chromatic_type = I("abb_chromatic_type");
+  v.bokeh_circle_to_square = F("bokeh_circle_to_square"); v.bokeh_anamorphic = F("bokeh_anamorphic");
+  v.bokeh_enable_image = B("bokeh_enable_image");
+  const AtString image_path = AiNodeGetStr(camera_node, AtString("bokeh_image_path"));
+  v.bokeh_image_path = image_path.c_str();
+  v.vignetting_retries = I("vignetting_retries"); v.bidir_add_energy = F("bidir_add_energy");
+  v.bidir_add_energy_minimum_luminance = F("bidir_add_energy_minimum_luminance");
+  v.bidir_add_energy_transition = F("bidir_add_energy_transition");
+  v.enable_bidir_transmission = B("enable_bidir_transmission"); v.enable_skydome = B("enable_skydome");
+  lentil_camera_params_from_node(&v, AiNodeGetFlt(options_node, AtString("meters_per_unit")),
+                                 AiNodeGetBool(options_node, AtString("ignore_dof")) ? 1 : 0, &P, &input_fstop, &lambda_um,
+                                 &extra_sensor_shift, &exposure);
+  P.adaptive_sampling = AiNodeGetBool(options_node, AtString("enable_adaptive_sampling")) ? 1 : 0;
+  if (const char *e = getenv("LENTIL_SAMPLES_OVERRIDE")) P.samples_override = atoi(e);     // bench / test knob, 0 upstream
+
+  // ---- the lens of the enum (the reference switches over its compiled-in lens bodies, src/lentil.h:1576)
+  if (host_lens) { lentil_host_lens_destroy(host_lens); host_lens = nullptr; }
+  lens_table = nullptr;
+  if (P.cameraType == LENTIL_POLYNOMIAL_OPTICS) {
+    int n = 0;
+    const lentil_node_param *params = lentil_camera_node_parameters(&n);
+    const char *want = nullptr;
+    for (int i = 0; i < n; ++i)
+      if (strcmp(params[i].name, "lens_model") == 0 && params[i].enum_values) {
+        int count = 0;
+        while (params[i].enum_values[count]) ++count;
+        if (v.lens_model >= 0 && v.lens_model < count) want = params[i].enum_values[v.lens_model];
+      }
+    for (int i = 0; want && i < kShippedLensCount; ++i)
+      if (strcmp(kShippedLenses[i].name, want) == 0) lens_table = kShippedLenses[i].table;
+    if (!lens_table) { AiMsgError("[LENTIL] lens_model %d has no table in this build", v.lens_model); AiRenderAbort(); return; }
+    host_lens = lentil_host_lens_create(lens_table);
+  }
+  // ---- camera_model_specific_setup (src/lentil.h:1568-1670)
+  if (lentil_host_camera_model_specific_setup(&P, host_lens, input_fstop, lambda_um * 1000.0, extra_sensor_shift, &tan_fov) != 0) {
+    AiMsgError("[LENTIL] camera setup failed");
+    AiRenderAbort();
+    return;
+  }
+  P.lambda_bw = (float)lambda_um;
+  AtMatrix w2c;
+  AiWorldToCameraMatrix(camera_node, 0.0f, w2c);          // static camera: one matrix (declared gap)
+  memcpy(P.world_to_camera, w2c.data, sizeof P.world_to_camera);
+
+  have_bokeh = false;
+  if (P.bokeh_enable_image) {
+    // the reference reads the image through AiTextureLoad (src/imagebokeh.h:16-18): not part of this path's scope
+    AiMsgError("[LENTIL CAMERA PO] Couldn't open bokeh image!");
+    AiRenderAbort();
+    return;
+  }
+
+  // ---- get_bidirectional_status + setup_lentil_aovs + setup_filter (src/lentil.h:1008-1122): the operator's AOV
+  // list, sanitised; resolution and region; filter width
+  // get_bidirectional_status (src/lentil.h:1151-1174)
+  if (!P.enable_dof) {
+    AiMsgWarning("[LENTIL BIDIRECTIONAL] Depth of field is disabled, therefore disabling bidirectional sampling.");
+    release_gpu();
+    return;
+  }
+  if (P.bidir_sample_mult == 0) {
+    AiMsgWarning("[LENTIL BIDIRECTIONAL] Bidirectional samples are set to 0, filter will not execute.");
+    release_gpu();
+    return;
+  }
+  if (AiNodeGetBool(options_node, AtString("enable_progressive_render"))) {
+    AiMsgError("[LENTIL BIDIRECTIONAL] Progressive rendering is not supported.");
+    AiRenderAbort();
+    return;
+  }
+  // setup_lentil_aovs (src/lentil.h:988-1012): the lentil_operator node, by its node entry
+  AtNode *op = nullptr;
+  AtNodeIterator *iter = AiUniverseGetNodeIterator(universe, AI_NODE_ALL);
+  while (!AiNodeIteratorFinished(iter)) {
+    AtNode *c = AiNodeIteratorGetNext(iter);
+    if (AiNodeEntryGetNameAtString(AiNodeGetNodeEntry(c)) == AtString("lentil_operator")) { op = c; break; }
+  }
+  AiNodeIteratorDestroy(iter);
+  LentilOperatorData *od = op ? (LentilOperatorData *)AiNodeGetLocalData(op) : nullptr;
+  if (!od || !od->cooked) {
+    AiMsgError("[LENTIL] Since Lentil 2.5, lentil requires an operator (lentil_operator) to function. Please insert this operator.");
+    release_gpu();
+    return;
+  }
+  aovs = od->aovs;
+  const int n_aovs = lentil_sanitize_aov_list(aovs.data(), (int)aovs.size());
+  aovs.resize((size_t)(n_aovs < 0 ? 0 : n_aovs));
+  if (aovs.empty() || strcmp(aovs[0].name, "RGBA") != 0) {
+    AiMsgWarning("[LENTIL] the first lentil-filtered output must be RGBA; redistribution is off");
+    release_gpu();
+    return;
+  }
+  // the bookkeeping AOV lentil_time adds nothing to the images (the imager skips it, src/lentil_imager.cpp:109)
+  for (size_t i = 0; i < aovs.size();)
+    if (strcmp(aovs[i].name, "lentil_time") == 0) aovs.erase(aovs.begin() + (long)i); else ++i;
+  if (aovs.size() > LENTIL_MAX_AOVS) { AiMsgError("[LENTIL] more than %d redistributed AOVs", LENTIL_MAX_AOVS); AiRenderAbort(); return; }
+
+  const AtNodeEntry *oidn = AiNodeEntryLookUp(AtString("imager_denoiser_oidn"));
+  lentil_setup_filter_region(&P, AiNodeGetInt(options_node, AtString("xres")), AiNodeGetInt(options_node, AtString("yres")),
+                             AiNodeGetInt(options_node, AtString("region_min_x")), AiNodeGetInt(options_node, AtString("region_min_y")),
+                             AiNodeGetInt(options_node, AtString("region_max_x")), AiNodeGetInt(options_node, AtString("region_max_y")),
+                             lentil_filter_width(AiNodeEntryGetCount(oidn) != 0));
+  const int aa = AiNodeGetInt(options_node, AtString("AA_samples"));
+  P.inverse_sample_density = 1.0f / ((float)aa * (float)aa);
+
+  // ---- the GPU side: context, lens, frame, staging, imager
+  auto check = [&](int rc, const char *what) {
+    if (rc == LENTIL_OK) return true;
+    AiMsgError("[LENTIL] %s: %s", what, lentil_hip_last_error(gpu));
+    AiRenderAbort();
+    return false;
+  };
+  if (!gpu && !check(lentil_hip_create(0, &gpu), "lentil_hip_create")) return;
+  if (!check(lentil_hip_set_params(gpu, &P), "set_params")) return;
+  if (P.cameraType == LENTIL_POLYNOMIAL_OPTICS && !check(lentil_hip_set_lens(gpu, lens_table), "set_lens")) return;
+  if (!check(lentil_hip_set_bokeh(gpu, nullptr), "set_bokeh")) return;
+  std::vector<uint8_t> kinds;
+  for (const lentil_aov_plan &a : aovs) kinds.push_back((uint8_t)lentil_aov_frame_kind(&a));
+  if (!check(lentil_hip_alloc_frame(gpu, (uint32_t)aovs.size(), kinds.data()), "alloc_frame")) return;
+  if (imager) { lentil_imager_destroy(imager); imager = nullptr; }
+  if (stage) { lentil_stage_destroy(stage); stage = nullptr; }
+  stage_slots = 256;
+  next_slot = 0;
+  if (lentil_stage_create(stage_slots, (uint32_t)aovs.size() - 1, &stage) != LENTIL_OK ||
+      lentil_imager_create(gpu, stage, &P, (uint32_t)aovs.size(), &imager) != LENTIL_OK) {
+    AiMsgError("[LENTIL] could not set up the visit staging");
+    AiRenderAbort();
+    return;
+  }
+  for (const lentil_aov_plan &a : aovs)
+    AiMsgInfo("[LENTIL BIDIRECTIONAL] Driver '%s' -- Adding aov %s of type %s", a.to.driver, a.to.aov_name, a.to.aov_type);
+  imager_print_once_only = false;
+  redistribution = true;
+}

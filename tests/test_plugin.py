@@ -1,0 +1,219 @@
+"""lentil.so -- the Arnold plugin DSO -- driven by a stand-in renderer (tests/fake_arnold, test infrastructure: a fake
+<ai.h> plus libai_fake.so, which also plays Arnold: node registration through NodeLoader, operator cook, node update,
+filter_pixel from several threads, driver_process_bucket per bucket).
+
+CPU tests: the registration surface (four nodes in the reference's order, src/lentil_loader.cpp:11-28), the camera
+node's parameters against the reference's list (src/lentil_camera.cpp:19-52 as lentil_camera_node_parameters() states
+it), node metadata, what lentil_operator leaves in options.outputs / aov_shaders (src/lentil_operator.cpp:25-171).
+GPU test: a whole frame through the plugin -- operator_cook -> node_update -> filter_pixel on 6 threads ->
+driver_process_bucket on 6 threads -- against the ORACLE (not against the direct HIP path).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import common
+import oracle_lib
+from pota_amd import _abi, bridge, capi, workload
+
+FAKE = os.path.join(common.ROOT, "tests", "fake_arnold", "libai_fake.so")
+PLUGIN = os.path.join(common.ROOT, "pota_amd", "lentil.so")
+AI_NODE_CAMERA, AI_NODE_DRIVER, AI_NODE_FILTER, AI_NODE_OPERATOR = 0x0002, 0x0040, 0x0080, 0x1000
+AI_TYPE = {"INT": 1, "BOOLEAN": 3, "FLOAT": 4, "RGB": 5, "RGBA": 6, "VECTOR": 7, "STRING": 10, "ENUM": 15}
+
+
+@pytest.fixture(scope="module")
+def fa():
+    lib = C.CDLL(FAKE, mode=C.RTLD_GLOBAL)
+    lib.fa_entry_name.restype = C.c_char_p
+    lib.fa_entry_meta.restype = C.c_char_p
+    lib.fa_output.restype = C.c_char_p
+    lib.fa_universe_create.restype = C.c_void_p
+    lib.fa_node.restype = C.c_void_p
+    lib.fa_options.restype = C.c_void_p
+    for f in ("fa_node", "fa_set_camera", "fa_node_set_int", "fa_node_set_flt", "fa_node_set_bool", "fa_node_set_str",
+              "fa_add_output", "fa_output_count", "fa_output", "fa_set_samples", "fa_set_aov", "fa_render", "fa_get_image",
+              "fa_cook_operators", "fa_universe_destroy", "fa_node_exists", "fa_aov_shader_count", "fa_render_hint",
+              "fa_filter_width_x1000", "fa_options"):
+        getattr(lib, f).argtypes = None
+    assert lib.fa_load_plugin(PLUGIN.encode()) == 4
+    return lib
+
+
+def _messages(fa):
+    buf = C.create_string_buffer(1 << 16)
+    fa.fa_messages(buf, len(buf))
+    return buf.value.decode()
+
+
+def test_node_loader_registers_the_four_nodes(fa):
+    names = [fa.fa_entry_name(i).decode() for i in range(fa.fa_entry_count())]
+    assert names == ["lentil_camera", "lentil_filter", "imager_lentil", "lentil_operator"]
+    assert [fa.fa_entry_node_type(i) for i in range(4)] == [AI_NODE_CAMERA, AI_NODE_FILTER, AI_NODE_DRIVER, AI_NODE_OPERATOR]
+    for n in names:
+        assert fa.fa_entry_meta(n.encode(), None, b"ai_version").decode().startswith("7.")
+
+
+def test_camera_parameters_match_the_reference_list(fa):
+    want = bridge.camera_node_parameters()
+    assert fa.fa_entry_param_count(b"lentil_camera") == len(want) == 29
+    name = C.create_string_buffer(128)
+    s = C.create_string_buffer(1024)
+    typ, num = C.c_int(), C.c_double()
+    for i, w in enumerate(want):
+        assert fa.fa_entry_param(b"lentil_camera", i, name, 128, C.byref(typ), C.byref(num), s, 1024) == 0
+        assert name.value.decode() == w["name"]
+        assert typ.value == w["type"]
+        if w["type"] == AI_TYPE["STRING"]:
+            assert s.value.decode() == (w["default_string"] or "")
+        elif w["type"] == AI_TYPE["ENUM"]:
+            assert s.value.decode().split("|") == w["enum_values"] and int(num.value) == int(w["default"])
+        else:
+            assert num.value == pytest.approx(w["default"])
+    assert fa.fa_entry_meta(b"lentil_camera", None, b"force_update") == b"true"
+
+
+def test_node_metadata_and_imager_parameters(fa):
+    assert fa.fa_entry_meta(b"imager_lentil", None, b"subtype") == b"imager"
+    assert fa.fa_entry_meta(b"lentil_filter", None, b"force_update") == b"true"
+    assert fa.fa_entry_meta(b"lentil_operator", None, b"force_update") == b"true"
+    assert fa.fa_entry_param_count(b"imager_lentil") == 1
+    name, s = C.create_string_buffer(64), C.create_string_buffer(64)
+    typ, num = C.c_int(), C.c_double()
+    fa.fa_entry_param(b"imager_lentil", 0, name, 64, C.byref(typ), C.byref(num), s, 64)
+    assert (name.value, typ.value, num.value) == (b"enable", AI_TYPE["BOOLEAN"], 1.0)
+    assert fa.fa_entry_param_count(b"lentil_filter") == 0 and fa.fa_entry_param_count(b"lentil_operator") == 0
+
+
+def _scene(fa, W, H, outputs, aa=3, oidn=True):
+    u = fa.fa_universe_create(W, H, aa)
+    cam = fa.fa_node(C.c_void_p(u), b"lentil_camera", b"camera")
+    fa.fa_set_camera(C.c_void_p(u), C.c_void_p(cam))
+    for f in ("gaussian_filter", "closest_filter", "box_filter"):
+        fa.fa_node(C.c_void_p(u), f.encode(), f.encode())
+    fa.fa_node(C.c_void_p(u), b"driver_exr", b"driver_exr")
+    if oidn:
+        fa.fa_node(C.c_void_p(u), b"imager_denoiser_oidn", b"oidn")       # filter width 1.0: a pixel's own samples
+    fa.fa_node(C.c_void_p(u), b"imager_lentil", b"imager_lentil")
+    fa.fa_node(C.c_void_p(u), b"lentil_operator", b"lentil_operator")
+    for o in outputs:
+        fa.fa_add_output(C.c_void_p(u), o.encode())
+    return u, cam
+
+
+def test_operator_cook_rewires_the_outputs(fa):
+    fa.fa_messages_clear()
+    u, cam = _scene(fa, 32, 24, ["RGBA RGBA gaussian_filter driver_exr", "diffuse RGB gaussian_filter driver_exr",
+                                 "N VECTOR closest_filter driver_exr", "Z FLOAT box_filter driver_exr",
+                                 "ID UINT closest_filter driver_exr"])
+    assert fa.fa_cook_operators(C.c_void_p(u)) == 1
+    outs = [fa.fa_output(C.c_void_p(u), i).decode() for i in range(fa.fa_output_count(C.c_void_p(u)))]
+    assert outs == ["RGBA RGBA lentil_replaced_filter driver_exr", "diffuse RGB lentil_replaced_filter driver_exr",
+                    "N VECTOR lentil_replaced_filter driver_exr", "Z FLOAT lentil_replaced_filter driver_exr",
+                    "ID UINT closest_filter driver_exr",
+                    "lentil_debug FLOAT lentil_replaced_filter driver_exr", "lentil_time FLOAT lentil_replaced_filter driver_exr",
+                    "lentil_raydir RGB lentil_replaced_filter driver_exr"]
+    for n in (b"lentil_replaced_filter", b"lentil_time_write", b"lentil_time_read", b"lentil_raydir_write", b"lentil_raydir_read"):
+        assert fa.fa_node_exists(C.c_void_p(u), n) == 1
+    assert fa.fa_aov_shader_count(C.c_void_p(u)) == 2
+    assert "Specified AOV filter (box_filter) is incompatible with Lentil" in _messages(fa)
+    # a second cook (Arnold re-cooks on scene edits) adds nothing twice
+    assert fa.fa_cook_operators(C.c_void_p(u)) == 1
+    assert fa.fa_aov_shader_count(C.c_void_p(u)) == 2
+    fa.fa_universe_destroy(C.c_void_p(u))
+
+
+def test_shipped_mtd_lists_the_camera_parameters():
+    """pota_amd/plugin/lentil.mtd (tools/gen_mtd.py) against the parameter table and against the reference's own
+    lentil.mtd (tests/golden/lentil.mtd: generated here from src/lentil_camera.ui by the reference's uigen.py and
+    concatenated with its hardcoded part like src/CMakeLists.txt:47-67 does; tools/make_mtd_fixture.py)."""
+    import re
+
+    def parse(path):
+        nodes, cur, attrs = {}, None, None
+        for line in open(path):
+            m = re.match(r"\s*\[node (\w+)\]", line)
+            if m and not line.lstrip().startswith("#"):
+                cur = m.group(1); attrs = nodes.setdefault(cur, [])
+                continue
+            m = re.match(r"\s*\[attr (\w+)\]", line)
+            if m and cur and not line.lstrip().startswith("#"):
+                attrs.append(m.group(1))
+        return nodes
+    ours = parse(os.path.join(common.ROOT, "pota_amd", "plugin", "lentil.mtd"))
+    ref = parse(os.path.join(common.ROOT, "tests", "golden", "lentil.mtd"))
+    want = [w["name"] for w in bridge.camera_node_parameters()]
+    assert ours["lentil_camera"] == want
+    assert sorted(ref["lentil_camera"]) == sorted(want)         # (the .ui lists them by UI group, not by declaration)
+    assert set(ref) <= set(ours) and {"lentil_camera", "imager_lentil", "lentil_filter"} <= set(ours)
+
+
+@pytest.mark.gpu
+def test_frame_through_the_plugin_matches_the_oracle(fa, orc, monkeypatch):
+    W, H, M, S = 64, 48, 9, 48
+    monkeypatch.setenv("LENTIL_SAMPLES_OVERRIDE", str(S))
+    fa.fa_messages_clear()
+    u, cam = _scene(fa, W, H, ["RGBA RGBA gaussian_filter driver_exr", "diffuse RGB gaussian_filter driver_exr"])
+    fa.fa_node_set_int(C.c_void_p(cam), b"camera_type", 1)                 # PolynomialOptics
+    fa.fa_node_set_int(C.c_void_p(cam), b"lens_model", 0)                  # double_gauss_50mm
+    # the same frame for the oracle: parameters as the plugin derives them
+    # (focal_length: the node's focal_length_lentil default, which the reference's CoC formula uses in PO mode too,
+    # src/lentil.h:674-692,1217)
+    p, model, table, keep = common.po_setup(W, H, samples_override=S, focal_length=np.float32(35.0))
+    visits, cols = common.make_stream(p, W, H, M, f_hi=0.02, n_extra=1)
+    n = W * H * M
+    pix = np.arange(n) // M
+    px = (pix % W).astype(np.int32); py = (pix // W).astype(np.int32)
+    rng = np.random.default_rng(5)
+    ox = rng.uniform(-0.5, 0.5, n).astype(np.float32); oy = rng.uniform(-0.5, 0.5, n).astype(np.float32)
+    invd = np.full(n, 1.0 / 9.0, np.float32)
+    fa.fa_set_samples(C.c_void_p(u), n, px.ctypes.data_as(C.c_void_p), py.ctypes.data_as(C.c_void_p), ox.ctypes.data_as(C.c_void_p),
+                      oy.ctypes.data_as(C.c_void_p), invd.ctypes.data_as(C.c_void_p))
+    zeros = np.zeros((n, 4), np.float32)
+    z4 = np.repeat(cols["pos_z"][:, 3:4], 4, axis=1).copy()
+    aov = {"RGBA": (AI_TYPE["RGBA"], cols["rgba"]), "P": (AI_TYPE["VECTOR"], cols["pos_z"]), "Z": (AI_TYPE["FLOAT"], z4),
+           "lentil_raydir": (AI_TYPE["RGB"], cols["raydir_time"]), "lentil_time": (AI_TYPE["FLOAT"], zeros),
+           "volume": (AI_TYPE["RGB"], zeros), "transmission": (AI_TYPE["RGBA"], zeros), "lentil_ignore": (AI_TYPE["FLOAT"], zeros),
+           "diffuse": (AI_TYPE["RGB"], cols["extra"][0])}
+    keep_arrays = []
+    for name, (t, a) in aov.items():
+        a = np.ascontiguousarray(a, np.float32); keep_arrays.append(a)
+        fa.fa_set_aov(C.c_void_p(u), name.encode(), t, a.ctypes.data_as(C.c_void_p))
+    rc = fa.fa_render(C.c_void_p(u), 6, 16)
+    msgs = _messages(fa)
+    assert rc == 0 and fa.fa_error_count() == 0, msgs
+    assert fa.fa_filter_width_x1000(C.c_void_p(u), b"lentil_replaced_filter") == 1000
+    assert fa.fa_render_hint(C.c_void_p(u), b"imager_schedule") == 2 and fa.fa_render_hint(C.c_void_p(u), b"imager_padding") == 0
+    assert "Adding aov RGBA" in msgs and "Adding aov diffuse" in msgs
+    img = {}
+    for name in ("RGBA", "diffuse", "lentil_debug", "lentil_raydir"):
+        a = np.zeros((H, W, 4), np.float32)
+        assert fa.fa_get_image(C.c_void_p(u), name.encode(), a.ctypes.data_as(C.c_void_p)) == 0
+        img[name] = a
+
+    # ---- oracle: AOVs in the plugin's order -- RGBA, diffuse (RGB widened with alpha 1), lentil_debug (own z-buffer,
+    # no column), lentil_raydir (RGB widened)
+    kinds = [_abi.FILTER_GAUSSIAN, _abi.FILTER_GAUSSIAN, _abi.FILTER_CLOSEST_DEBUG, _abi.FILTER_GAUSSIAN]
+    ocols = dict(cols)
+    widen = lambda a: np.ascontiguousarray(np.concatenate([a[:, :3], np.ones((n, 1), np.float32)], 1), np.float32)
+    ocols["extra"] = [widen(cols["extra"][0]), np.zeros_like(cols["rgba"]), widen(cols["raydir_time"])]
+    ovisits, okeep = capi.make_visits(ocols, visits_per_pixel=M, pixels_per_row=W)
+    lens = orc.orc_lens_create(C.byref(table))
+    ref = oracle_lib.Frame(orc, p, n_aovs=4, kinds=kinds)
+    ref.run(lens, None, ovisits)
+    orc.orc_lens_destroy(lens)
+    assert ref.counters().redistributed_visits > 300
+    for k, name in enumerate(("RGBA", "diffuse", "lentil_debug", "lentil_raydir")):
+        want = ref.resolve(k).reshape(p.yres, p.xres, 4)[:H, :W]
+        got = img[name]
+        if kinds[k] == _abi.FILTER_CLOSEST_DEBUG:
+            assert np.array_equal(got, want), name
+            continue
+        m = want != 0
+        assert np.array_equal(got != 0, m), name
+        err = float(np.max(np.abs(got[m].astype(np.float64) - want[m]) / np.abs(want[m])))
+        assert err < 2e-5, (name, err)      # two fp32 sums in different orders (ragged capture order vs iterator order)
+    ref.close()
+    fa.fa_universe_destroy(C.c_void_p(u))
