@@ -208,6 +208,7 @@ class Bench:
         self.ctx = ctx
         self.engine = distributed.HipEngine(ctx, rows=p.yres)
         self.distributed = distributed
+        self.native = False          # the exchange inside liblentil_hip.so (main() switches it on after its self-check)
         self.bounds = bounds
         self.band = None
         self.streams = []
@@ -253,10 +254,53 @@ class Bench:
         cols, v, kv = self.streams[self.i_stream % len(self.streams)]
         self.i_stream += 1
         self.ctx.bind_visits(v, kv)
-        if self.tiled:
+        if self.native and self.tiled:
+            self.distributed.frame_step_bands_native(self.ctx, self.H, self.bounds)
+        elif self.native:
+            self.distributed.frame_step_native(self.ctx)
+        elif self.tiled:
             self.distributed.frame_step_bands(self.engine, self.dist, self.H, self.p.yres, self.bounds)
         else:
             self.distributed.frame_step(self.engine, self.dist)
+
+    def band_accumulators(self):
+        """copy of the accumulator rows this rank owns after a step (the whole frame when not tiled)"""
+        self.ctx.sync()
+        self.ctx.accum_buffer()                      # folds what the scan keeps apart into the block
+        self.ctx.sync()
+        acc = self.engine.accum
+        if self.band is not None and self.tiled:
+            per_row = acc.numel() // self.p.yres
+            acc = acc[self.band[0] * per_row:self.band[1] * per_row]
+        return acc.clone()
+
+    def check_native_exchange(self):
+        """One step through the library's own RCCL exchange and one through torch.distributed (the Python form of the
+        same step, which the gloo tests cover), same visit stream: the rank's part of the accumulators must agree to
+        fp32 summation order.  Collective; every rank gets the same verdict."""
+        torch, dist = self.torch, self.dist
+        ok, rel = 1, float("nan")
+        try:
+            i0 = self.i_stream
+            self.native = False
+            self.step()
+            ref = self.band_accumulators()
+            self.i_stream = i0
+            self.native = True
+            self.step()
+            got = self.band_accumulators()
+            self.i_stream = i0
+            scale = float(ref.abs().max().item())
+            rel = float((got - ref).abs().max().item()) / max(scale, 1e-30)
+            same_pixels = bool(((got != 0) == (ref != 0)).all().item())
+            ok = 1 if (scale > 0 and rel < 1e-4 and same_pixels) else 0
+        except Exception as e:
+            sys.stderr.write("bench.py rank %d: native exchange self-check raised %r\n" % (self.rank, e))
+            ok = 0
+        t = torch.tensor([ok], dtype=torch.int64, device=self.dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        self.native = bool(int(t.item()))
+        return {"ok": self.native, "max_abs_diff_over_max_rank0": rel}
 
     def run(self, steps, warmup):
         torch, dist = self.torch, self.dist
@@ -376,6 +420,23 @@ def main():
               args.bokeh_image, emulate=emulate, bounds=bounds, tiled=tiled, same_frame=args.same_frame)
     bytes_per_visit = 80 + 16 * args.aovs
     b.generate(args.f_hi)
+    exchange = None
+    if (world > 1 or force_dist) and not emulate:
+        exchange = {"impl": "torch.distributed (pota_amd/distributed.py)", "self_check": None}
+        if backend == "nccl" and os.environ.get("LENTIL_EXCHANGE_IMPL", "native") == "native":
+            try:
+                b.distributed.native_comm_init(b.ctx, dist)
+                have = 1
+            except Exception as e:
+                sys.stderr.write("bench.py rank %d: no native communicator: %r\n" % (rank, e))
+                have = 0
+            t = torch.tensor([have], dtype=torch.int64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            if int(t.item()):
+                exchange["self_check"] = b.check_native_exchange()
+                if b.native:
+                    exchange["impl"] = ("liblentil_hip.so: %s (RCCL bound by the library)"
+                                        % ("lentil_hip_exchange_bands" if tiled else "lentil_hip_allreduce"))
     if tiled and (world > 1 or force_dist) and not args.bounds and os.environ.get("LENTIL_REBALANCE", "1") != "0":
         # calibration (untimed set-up, before the warm-up steps): three passes, the first with even bands, each followed
         # by an all-gather of the ranks' pass times (scan + draws, HIP events) and a re-cut of the bands
@@ -430,6 +491,7 @@ def main():
                             % (world, (" at rows %s (balanced by pass time)" % b.bounds) if b.bounds else "") if tiled else
                             "rows%%%d + allreduce" % world),
         },
+        "exchange": exchange,
         "passes": {"timed": steps, "streamed": r["streamed"], "chunks_enqueued_blind": r["blind_chunks"],
                    "chunks_redone_after_a_short_estimate": r["redone"]},
         "kernels_ms": {"scan": round(r["scan"] / steps, 4), "draw": round(r["draw"] / steps, 4), "resolve": round(r["resolve"] / steps, 4)},

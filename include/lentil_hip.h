@@ -344,6 +344,31 @@ int lentil_hip_resolve_rows(lentil_hip_ctx *ctx, uint32_t row_begin, uint32_t n_
 int lentil_hip_accum_buffer(lentil_hip_ctx *ctx, void **device_ptr, uint64_t *n_floats);
 int lentil_hip_stream(lentil_hip_ctx *ctx, void **hip_stream);
 
+/* --- multi-GPU, the exchange itself (RCCL over xGMI; one process per GPU, one context per process) ------
+ * The library owns its communicator: librccl.so is loaded on the first of these calls (dlopen; a process
+ * that already holds an RCCL gets that same instance), so a renderer linking liblentil_hip.so for one GPU
+ * needs no RCCL.  No reference counterpart (src/lentil.h:823-851 adds into buffers all threads share).
+ * comm_unique_id : rank 0 fills the 128-byte id (ncclGetUniqueId) and hands it to the other processes by
+ *                  whatever channel the host has (the renderer's own job description, a file, MPI ...).
+ * comm_init      : collective over `world` processes, rank in [0, world); replaces an earlier communicator.
+ * allreduce      : row-interleaved partition, every GPU holds the whole frame.  After lentil_hip_redistribute
+ *                  on every rank: closest-AOV winner keys are min-reduced and the winners gathered (requires
+ *                  set_closest_exchange(deferred = 1) when the frame has closest AOVs), then one sum all-reduce
+ *                  of accum_buffer.  lentil_hip_resolve afterwards gives every rank the whole image.
+ * exchange_bands : tiled output.  Rank r's visits are rows [bounds[r], bounds[r+1]) (bounds == NULL: an even split
+ *                  of visit_rows); its band of the frame is the same rows, the last band reaching to yres.
+ *                  After lentil_hip_redistribute on every rank: the touched rows are all-gathered, what a
+ *                  rank added to another's band travels point to point (sparse != 0: as pixel entries when
+ *                  at most a quarter of the pixels hold anything, else as packed rows), the owner merges
+ *                  the arrivals in rank order and resolves its band; band_lo / band_hi (may be NULL) return it.
+ *                  Collective: every rank calls it with the same bounds / visit_rows / sparse. */
+int lentil_hip_comm_unique_id(uint8_t id[128]);
+int lentil_hip_comm_init(lentil_hip_ctx *ctx, const uint8_t id[128], int rank, int world);
+int lentil_hip_comm_destroy(lentil_hip_ctx *ctx);
+int lentil_hip_allreduce(lentil_hip_ctx *ctx);
+int lentil_hip_exchange_bands(lentil_hip_ctx *ctx, const int32_t *bounds, int32_t visit_rows, int32_t sparse,
+                              int32_t *band_lo, int32_t *band_hi);
+
 /* --- instrumentation ----------------------------------------------------------------
  * timings are HIP-event times on the context's stream for the last redistribute/resolve:
  * ms[0] scan+compaction+direct accumulate, ms[1] draw/splat kernel, ms[2] resolve. */

@@ -26,6 +26,8 @@ EXPORTS = [
     "lentil_hip_download_draw_log", "lentil_hip_test_lt_sample_aperture",
     "lentil_hip_test_trace_bw_po", "lentil_hip_test_aperture_sample",
     "lentil_hip_lens_is_compiled", "lentil_hip_set_lens_mode",
+    "lentil_hip_comm_unique_id", "lentil_hip_comm_init", "lentil_hip_comm_destroy", "lentil_hip_allreduce",
+    "lentil_hip_exchange_bands",
 ]
 
 _lib = None
@@ -95,6 +97,11 @@ def load_library():
         "lentil_hip_test_aperture_sample": (i, [vp, u64, vp, vp, vp]),
         "lentil_hip_lens_is_compiled": (i, [vp]),
         "lentil_hip_set_lens_mode": (i, [vp, i]),
+        "lentil_hip_comm_unique_id": (i, [vp]),
+        "lentil_hip_comm_init": (i, [vp, vp, i, i]),
+        "lentil_hip_comm_destroy": (i, [vp]),
+        "lentil_hip_allreduce": (i, [vp]),
+        "lentil_hip_exchange_bands": (i, [vp, vp, C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)
@@ -246,6 +253,35 @@ class Context:
 
     def closest_gather(self):
         self._chk(self.lib.lentil_hip_closest_gather(self.h))
+
+    # --- the native exchange (RCCL inside the library; include/lentil_hip.h "multi-GPU, the exchange itself")
+    @staticmethod
+    def comm_unique_id():
+        buf = (C.c_uint8 * 128)()
+        lib = load_library()
+        rc = lib.lentil_hip_comm_unique_id(buf)
+        if rc != 0:
+            raise RuntimeError("lentil_hip_comm_unique_id: %s" % (lib.lentil_hip_last_error(None) or b"").decode())
+        return bytes(buf)
+
+    def comm_init(self, uid, rank, world):
+        buf = (C.c_uint8 * 128).from_buffer_copy(uid)
+        self._chk(self.lib.lentil_hip_comm_init(self.h, buf, rank, world))
+
+    def comm_destroy(self):
+        self._chk(self.lib.lentil_hip_comm_destroy(self.h))
+
+    def allreduce(self):
+        self._chk(self.lib.lentil_hip_allreduce(self.h))
+
+    def exchange_bands(self, visit_rows, bounds=None, sparse=True):
+        lo, hi = C.c_int32(), C.c_int32()
+        b = None
+        if bounds is not None:
+            b = (C.c_int32 * len(bounds))(*[int(x) for x in bounds])
+        self._chk(self.lib.lentil_hip_exchange_bands(self.h, b, int(visit_rows), 1 if sparse else 0,
+                                                     C.byref(lo), C.byref(hi)))
+        return lo.value, hi.value
 
     def touched_rows(self):
         lo, hi = C.c_int32(), C.c_int32()

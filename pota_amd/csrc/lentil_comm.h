@@ -1,0 +1,292 @@
+// lentil_comm.h -- the exchange between the GPUs of one node, native: RCCL over xGMI, called through the C-ABI
+// (lentil_hip_comm_* / _allreduce / _exchange_bands in include/lentil_hip.h).  Included by lentil_hip.hip.
+//
+// The reference has nothing like it (one process, threads sharing one set of buffers, src/lentil.h:823-851);
+// SURVEY.md section 8(e) defines the step.  Two partitions, as in pota_amd/distributed.py, whose Python form of the
+// same steps the world_size-2/3 gloo tests keep exercising:
+//   interleaved rows + all-reduce   every rank holds the whole frame: closest-AOV winner keys are min-reduced
+//                                   (ncclUint64 / ncclMin), winners gathered, then one sum all-reduce of the
+//                                   accumulator block
+//   row bands (tiled output)        touched rows all-gathered (one small ncclAllGather), what a rank added to
+//                                   another's band goes there point to point -- a list of pixel entries when the rows
+//                                   are mostly empty, packed rows otherwise -- the owner merges and resolves its band
+// RCCL is loaded at run time (dlopen): liblentil_hip.so does not depend on it unless a communicator is asked for, and
+// a process that already has an RCCL loaded (torch's) gets that same instance by soname.
+#pragma once
+#include <dlfcn.h>
+
+typedef struct ncclComm *lentil_ncclComm_t;
+struct LentilNcclId { char b[128]; };     // ncclUniqueId (rccl.h: NCCL_UNIQUE_ID_BYTES 128), passed by value
+struct LentilRccl {
+  void *lib = nullptr;
+  int (*GetUniqueId)(void *id) = nullptr;
+  int (*CommInitRank)(lentil_ncclComm_t *comm, int nranks, LentilNcclId id, int rank) = nullptr;
+  int (*CommDestroy)(lentil_ncclComm_t comm) = nullptr;
+  int (*AllReduce)(const void *s, void *r, size_t count, int dtype, int op, lentil_ncclComm_t comm, hipStream_t st) = nullptr;
+  int (*AllGather)(const void *s, void *r, size_t sendcount, int dtype, lentil_ncclComm_t comm, hipStream_t st) = nullptr;
+  int (*Send)(const void *s, size_t count, int dtype, int peer, lentil_ncclComm_t comm, hipStream_t st) = nullptr;
+  int (*Recv)(void *r, size_t count, int dtype, int peer, lentil_ncclComm_t comm, hipStream_t st) = nullptr;
+  int (*GroupStart)() = nullptr;
+  int (*GroupEnd)() = nullptr;
+  const char *(*GetErrorString)(int) = nullptr;
+};
+// rccl.h: ncclSum 0, ncclMin 3; ncclInt8 0, ncclUint8 1, ncclInt64 4, ncclUint64 5, ncclFloat32 7
+enum { kNcclSum = 0, kNcclMin = 3, kNcclUint8 = 1, kNcclInt64 = 4, kNcclUint64 = 5, kNcclFloat32 = 7 };
+
+static LentilRccl g_rccl;
+static std::mutex g_rccl_mutex;
+
+static const char *load_rccl() {
+  std::lock_guard<std::mutex> g(g_rccl_mutex);
+  if (g_rccl.lib) return nullptr;
+  const char *names[] = {getenv("LENTIL_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+  void *h = nullptr;
+  for (const char *n : names) {
+    if (!n || !n[0]) continue;
+    h = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+    if (h) break;
+  }
+  if (!h) return "librccl.so not found (LENTIL_RCCL_LIB names it)";
+  LentilRccl r;
+  r.lib = h;
+#define LENTIL_RCCL_SYM(field, name)                                \
+  *(void **)(&r.field) = dlsym(h, name);                            \
+  if (!r.field) return "librccl.so lacks " name;
+  LENTIL_RCCL_SYM(GetUniqueId, "ncclGetUniqueId")
+  LENTIL_RCCL_SYM(CommInitRank, "ncclCommInitRank")
+  LENTIL_RCCL_SYM(CommDestroy, "ncclCommDestroy")
+  LENTIL_RCCL_SYM(AllReduce, "ncclAllReduce")
+  LENTIL_RCCL_SYM(AllGather, "ncclAllGather")
+  LENTIL_RCCL_SYM(Send, "ncclSend")
+  LENTIL_RCCL_SYM(Recv, "ncclRecv")
+  LENTIL_RCCL_SYM(GroupStart, "ncclGroupStart")
+  LENTIL_RCCL_SYM(GroupEnd, "ncclGroupEnd")
+  LENTIL_RCCL_SYM(GetErrorString, "ncclGetErrorString")
+#undef LENTIL_RCCL_SYM
+  g_rccl = r;
+  return nullptr;
+}
+
+struct LentilComm {
+  lentil_ncclComm_t comm = nullptr;
+  int rank = 0, world = 1;
+  int64_t *d_meta_mine = nullptr, *d_meta_all = nullptr, *h_meta_all = nullptr;   // [2 + world] / [world][2 + world]
+  std::vector<void *> scratch;          // grow-only device buffers, one per use slot
+  std::vector<size_t> scratch_bytes;
+};
+
+#define RCCL_TRY(ctx, call)                                                                           \
+  do {                                                                                                \
+    const int r_ = (call);                                                                            \
+    if (r_ != 0) return fail(ctx, LENTIL_ERR_HIP, std::string(#call) + ": " + g_rccl.GetErrorString(r_)); \
+  } while (0)
+
+static int comm_scratch(lentil_hip_ctx *ctx, LentilComm *cm, size_t slot, size_t bytes, void **out) {
+  if (cm->scratch.size() <= slot) { cm->scratch.resize(slot + 1, nullptr); cm->scratch_bytes.resize(slot + 1, 0); }
+  if (cm->scratch_bytes[slot] < bytes) {
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));      // nobody is still using the old buffer
+    (void)hipFree(cm->scratch[slot]);
+    cm->scratch[slot] = nullptr;
+    const size_t want = bytes + bytes / 4 + 4096;
+    HIP_TRY(ctx, hipMalloc(&cm->scratch[slot], want));
+    cm->scratch_bytes[slot] = want;
+  }
+  *out = cm->scratch[slot];
+  return LENTIL_OK;
+}
+
+LENTIL_API int lentil_hip_comm_unique_id(uint8_t id[128]) {
+  if (!id) return fail(nullptr, LENTIL_ERR_INVALID, "id is null");
+  if (const char *e = load_rccl()) return fail(nullptr, LENTIL_ERR_UNSUPPORTED, e);
+  const int r = g_rccl.GetUniqueId(id);
+  if (r != 0) return fail(nullptr, LENTIL_ERR_HIP, std::string("ncclGetUniqueId: ") + g_rccl.GetErrorString(r));
+  return LENTIL_OK;
+}
+
+LENTIL_API int lentil_hip_comm_destroy(lentil_hip_ctx *ctx) {
+  CHECK_CTX(ctx);
+  LentilComm *cm = ctx->comm;
+  if (!cm) return LENTIL_OK;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  if (cm->comm) (void)g_rccl.CommDestroy(cm->comm);
+  (void)hipFree(cm->d_meta_mine); (void)hipFree(cm->d_meta_all);
+  if (cm->h_meta_all) (void)hipHostFree(cm->h_meta_all);
+  for (void *p : cm->scratch) (void)hipFree(p);
+  delete cm;
+  ctx->comm = nullptr;
+  return LENTIL_OK;
+}
+
+LENTIL_API int lentil_hip_comm_init(lentil_hip_ctx *ctx, const uint8_t id[128], int rank, int world) {
+  CHECK_CTX(ctx);
+  if (!id || world < 1 || rank < 0 || rank >= world) return fail(ctx, LENTIL_ERR_INVALID, "bad communicator arguments");
+  if (const char *e = load_rccl()) return fail(ctx, LENTIL_ERR_UNSUPPORTED, e);
+  int rc = lentil_hip_comm_destroy(ctx);
+  if (rc) return rc;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  LentilComm *cm = new (std::nothrow) LentilComm();
+  if (!cm) return fail(ctx, LENTIL_ERR_NOMEM, "out of host memory");
+  cm->rank = rank; cm->world = world;
+  LentilNcclId uid;
+  memcpy(uid.b, id, 128);
+  ctx->comm = cm;
+  RCCL_TRY(ctx, g_rccl.CommInitRank(&cm->comm, world, uid, rank));
+  const size_t m = (size_t)(2 + world);
+  HIP_TRY(ctx, hipMalloc(&cm->d_meta_mine, m * sizeof(int64_t)));
+  HIP_TRY(ctx, hipMalloc(&cm->d_meta_all, m * (size_t)world * sizeof(int64_t)));
+  HIP_TRY(ctx, hipHostMalloc((void **)&cm->h_meta_all, m * (size_t)world * sizeof(int64_t), hipHostMallocDefault));
+  return LENTIL_OK;
+}
+
+// interleaved partition: every rank ends up with the whole frame's accumulators (distributed.frame_step)
+LENTIL_API int lentil_hip_allreduce(lentil_hip_ctx *ctx) {
+  CHECK_CTX(ctx);
+  LentilComm *cm = ctx->comm;
+  if (!cm) return fail(ctx, LENTIL_ERR_INVALID, "no communicator (lentil_hip_comm_init)");
+  if (!ctx->have_frame) return fail(ctx, LENTIL_ERR_INVALID, "no frame allocated");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  int rc;
+  if ((rc = fold_direct(ctx, 0, ctx->F.np, true))) return rc;        // what the scan kept apart joins the sum
+  untrust_touched(ctx);
+  if (ctx->F.zkey) {
+    if (!ctx->closest_deferred)
+      return fail(ctx, LENTIL_ERR_INVALID, "closest-filtered AOVs: lentil_hip_set_closest_exchange(ctx, 1, ...) before the pass");
+    RCCL_TRY(ctx, g_rccl.AllReduce(ctx->F.zkey, ctx->F.zkey, ctx->F.np, kNcclUint64, kNcclMin, cm->comm, ctx->stream));
+    if ((rc = lentil_hip_closest_gather(ctx))) return rc;
+  }
+  RCCL_TRY(ctx, g_rccl.AllReduce(ctx->F.acc, ctx->F.acc, ctx->F.np * ctx->F.stride, kNcclFloat32, kNcclSum, cm->comm, ctx->stream));
+  return LENTIL_OK;
+}
+
+// row bands (distributed.frame_step_bands): call after lentil_hip_redistribute; ends with the band resolved
+LENTIL_API int lentil_hip_exchange_bands(lentil_hip_ctx *ctx, const int32_t *bounds, int32_t visit_rows, int32_t sparse,
+                                         int32_t *band_lo, int32_t *band_hi) {
+  CHECK_CTX(ctx);
+  LentilComm *cm = ctx->comm;
+  if (!cm) return fail(ctx, LENTIL_ERR_INVALID, "no communicator (lentil_hip_comm_init)");
+  if (!ctx->have_frame || visit_rows <= 0) return fail(ctx, LENTIL_ERR_INVALID, "bad exchange_bands arguments");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  const int world = cm->world, rank = cm->rank;
+  const int32_t yres = (int32_t)ctx->P.yres;
+  const uint32_t xres = ctx->P.xres;
+  auto band_of = [&](int r, int32_t &lo, int32_t &hi) {
+    if (bounds) { lo = bounds[r]; hi = bounds[r + 1]; }
+    else { lo = (int32_t)((int64_t)visit_rows * r / world); hi = (int32_t)((int64_t)visit_rows * (r + 1) / world); }
+    if (r == world - 1) hi = yres;      // the last band also owns the rows beyond the visits (yres = H + 1)
+  };
+  int32_t b_lo, b_hi;
+  band_of(rank, b_lo, b_hi);
+  if (band_lo) *band_lo = b_lo;
+  if (band_hi) *band_hi = b_hi;
+  int rc;
+  int32_t lo = 0, hi = 0;
+  if ((rc = lentil_hip_touched_rows(ctx, &lo, &hi))) return rc;
+  const uint32_t used = 4u * ctx->F.n_aovs + 1u;
+  const bool keys = ctx->F.zkey != nullptr;
+  if (keys && ctx->closest_deferred)
+    return fail(ctx, LENTIL_ERR_INVALID, "tiled exchange: the pass must gather its own winners (set_closest_exchange(ctx, 0, ...))");
+
+  // ---- what this rank added to every other band, and the form it will travel in
+  struct Out { int form = 0; int32_t s_lo = 0, s_hi = 0; uint32_t *idx = nullptr; float *vals = nullptr; unsigned long long *k = nullptr; float *packed = nullptr; };
+  std::vector<Out> out((size_t)world);
+  std::vector<int64_t> mine((size_t)(2 + world), 0);
+  mine[0] = lo; mine[1] = hi;
+  for (int q = 0; q < world; ++q) {
+    if (q == rank) continue;
+    int32_t q_lo, q_hi;
+    band_of(q, q_lo, q_hi);
+    Out &o = out[(size_t)q];
+    o.s_lo = lo > q_lo ? lo : q_lo;
+    o.s_hi = hi < q_hi ? hi : q_hi;
+    if (o.s_hi <= o.s_lo) continue;
+    o.form = -1;
+    const uint64_t n_pix = (uint64_t)(o.s_hi - o.s_lo) * xres;
+    if (sparse) {
+      const uint32_t cap = (uint32_t)(n_pix / 4 > 1024 ? n_pix / 4 : 1024);
+      void *p;
+      if ((rc = comm_scratch(ctx, cm, (size_t)q * 8 + 0, (size_t)cap * 4, &p))) return rc;
+      o.idx = (uint32_t *)p;
+      if ((rc = comm_scratch(ctx, cm, (size_t)q * 8 + 1, (size_t)cap * used * 4, &p))) return rc;
+      o.vals = (float *)p;
+      if (keys) { if ((rc = comm_scratch(ctx, cm, (size_t)q * 8 + 2, (size_t)cap * 8, &p))) return rc; o.k = (unsigned long long *)p; }
+      uint32_t n = 0;
+      if ((rc = lentil_hip_compact_rows(ctx, (uint32_t)o.s_lo, (uint32_t)(o.s_hi - o.s_lo), o.idx, o.vals, o.k, cap, &n))) return rc;
+      if (n <= cap) o.form = (int)n;
+    }
+    if (o.form < 0) {
+      void *p;
+      if ((rc = comm_scratch(ctx, cm, (size_t)q * 8 + 3, (size_t)n_pix * used * 4, &p))) return rc;
+      o.packed = (float *)p;
+      if ((rc = lentil_hip_pack_rows(ctx, (uint32_t)o.s_lo, (uint32_t)(o.s_hi - o.s_lo), o.packed))) return rc;
+    }
+    mine[(size_t)(2 + q)] = o.form;
+  }
+  // ---- one small all-gather: [touched lo, hi, form per destination] of every rank
+  const size_t m = (size_t)(2 + world);
+  HIP_TRY(ctx, hipMemcpyAsync(cm->d_meta_mine, mine.data(), m * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream));
+  RCCL_TRY(ctx, g_rccl.AllGather(cm->d_meta_mine, cm->d_meta_all, m, kNcclInt64, cm->comm, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(cm->h_meta_all, cm->d_meta_all, m * (size_t)world * sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  // ---- receive buffers from what the others announced
+  struct In { int form = 0; int32_t r_lo = 0, r_hi = 0; uint32_t *idx = nullptr; float *vals = nullptr; unsigned long long *k = nullptr; float *packed = nullptr; unsigned long long *key_rows = nullptr; };
+  std::vector<In> in((size_t)world);
+  for (int q = 0; q < world; ++q) {
+    if (q == rank) continue;
+    const int64_t *info = cm->h_meta_all + (size_t)q * m;
+    In &i = in[(size_t)q];
+    i.r_lo = (int32_t)(info[0] > b_lo ? info[0] : b_lo);
+    i.r_hi = (int32_t)(info[1] < b_hi ? info[1] : b_hi);
+    i.form = (int)info[2 + rank];
+    if (i.r_hi <= i.r_lo || i.form == 0) { i.form = 0; continue; }
+    void *p;
+    if (i.form > 0) {
+      if ((rc = comm_scratch(ctx, cm, (size_t)q * 8 + 4, (size_t)i.form * 4, &p))) return rc;
+      i.idx = (uint32_t *)p;
+      if ((rc = comm_scratch(ctx, cm, (size_t)q * 8 + 5, (size_t)i.form * used * 4, &p))) return rc;
+      i.vals = (float *)p;
+      if (keys) { if ((rc = comm_scratch(ctx, cm, (size_t)q * 8 + 6, (size_t)i.form * 8, &p))) return rc; i.k = (unsigned long long *)p; }
+    } else {
+      const uint64_t n_pix = (uint64_t)(i.r_hi - i.r_lo) * xres;
+      if ((rc = comm_scratch(ctx, cm, (size_t)q * 8 + 5, (size_t)n_pix * used * 4, &p))) return rc;
+      i.packed = (float *)p;
+      if (keys) { if ((rc = comm_scratch(ctx, cm, (size_t)q * 8 + 6, (size_t)n_pix * 8, &p))) return rc; i.key_rows = (unsigned long long *)p; }
+    }
+  }
+  // ---- the exchange itself: every send has its receive on the other side, in the same order per pair
+  RCCL_TRY(ctx, g_rccl.GroupStart());
+  for (int q = 0; q < world; ++q) {
+    if (q == rank) continue;
+    const Out &o = out[(size_t)q];
+    if (o.form > 0) {
+      RCCL_TRY(ctx, g_rccl.Send(o.idx, (size_t)o.form * 4, kNcclUint8, q, cm->comm, ctx->stream));
+      RCCL_TRY(ctx, g_rccl.Send(o.vals, (size_t)o.form * used, kNcclFloat32, q, cm->comm, ctx->stream));
+      if (keys) RCCL_TRY(ctx, g_rccl.Send(o.k, (size_t)o.form, kNcclUint64, q, cm->comm, ctx->stream));
+    } else if (o.form < 0) {
+      const uint64_t n_pix = (uint64_t)(o.s_hi - o.s_lo) * xres;
+      RCCL_TRY(ctx, g_rccl.Send(o.packed, (size_t)n_pix * used, kNcclFloat32, q, cm->comm, ctx->stream));
+      if (keys) RCCL_TRY(ctx, g_rccl.Send(ctx->F.zkey + (uint64_t)o.s_lo * xres, (size_t)n_pix, kNcclUint64, q, cm->comm, ctx->stream));
+    }
+    const In &i = in[(size_t)q];
+    if (i.form > 0) {
+      RCCL_TRY(ctx, g_rccl.Recv(i.idx, (size_t)i.form * 4, kNcclUint8, q, cm->comm, ctx->stream));
+      RCCL_TRY(ctx, g_rccl.Recv(i.vals, (size_t)i.form * used, kNcclFloat32, q, cm->comm, ctx->stream));
+      if (keys) RCCL_TRY(ctx, g_rccl.Recv(i.k, (size_t)i.form, kNcclUint64, q, cm->comm, ctx->stream));
+    } else if (i.form < 0) {
+      const uint64_t n_pix = (uint64_t)(i.r_hi - i.r_lo) * xres;
+      RCCL_TRY(ctx, g_rccl.Recv(i.packed, (size_t)n_pix * used, kNcclFloat32, q, cm->comm, ctx->stream));
+      if (keys) RCCL_TRY(ctx, g_rccl.Recv(i.key_rows, (size_t)n_pix, kNcclUint64, q, cm->comm, ctx->stream));
+    }
+  }
+  RCCL_TRY(ctx, g_rccl.GroupEnd());
+  // ---- merge what arrived (senders in rank order: the merge of one sender's entries is not atomic against another's)
+  for (int q = 0; q < world; ++q) {
+    const In &i = in[(size_t)q];
+    if (i.form > 0) {
+      if ((rc = lentil_hip_merge_sparse(ctx, (uint32_t)i.r_lo, (uint32_t)(i.r_hi - i.r_lo), (uint32_t)i.form, i.idx, i.vals, i.k))) return rc;
+    } else if (i.form < 0) {
+      if ((rc = lentil_hip_merge_packed_rows(ctx, (uint32_t)i.r_lo, (uint32_t)(i.r_hi - i.r_lo), i.packed, i.key_rows))) return rc;
+    }
+  }
+  return lentil_hip_resolve_rows(ctx, (uint32_t)b_lo, (uint32_t)(b_hi - b_lo));
+}

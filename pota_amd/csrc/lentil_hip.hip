@@ -137,6 +137,7 @@ struct lentil_hip_ctx {
   lentil_draw_record *d_log = nullptr;
   uint64_t log_cap = 0;
   bool timed_draw = false, timed_resolve = false;
+  struct LentilComm *comm = nullptr; // lentil_comm.h: this context's RCCL communicator, if one was asked for
 };
 
 static thread_local std::string g_err;
@@ -261,8 +262,11 @@ static void free_bokeh(lentil_hip_ctx *ctx) {
   ctx->have_bokeh = false;
 }
 
+LENTIL_API int lentil_hip_comm_destroy(lentil_hip_ctx *ctx);
+
 LENTIL_API int lentil_hip_destroy(lentil_hip_ctx *ctx) {
   if (!ctx) return LENTIL_OK;
+  (void)lentil_hip_comm_destroy(ctx);
   (void)hipSetDevice(ctx->device);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   free_visits(ctx);
@@ -2050,3 +2054,5 @@ LENTIL_API int lentil_hip_test_aperture_sample(lentil_hip_ctx *ctx, uint64_t n, 
   HIP_TRY(ctx, hipMemcpy(xy, o0, n * 2 * 8, hipMemcpyDeviceToHost));
   return LENTIL_OK;
 }
+
+#include "lentil_comm.h"

@@ -201,6 +201,37 @@ def frame_step(engine, dist=None):
     engine.resolve()
 
 
+def native_comm_init(ctx, dist):
+    """Give `ctx` (capi.Context) the library's own RCCL communicator over the ranks of `dist`'s default group: rank 0
+    draws the id, the group (any backend) carries its 128 bytes.  Collective."""
+    from . import capi
+    world, rank = dist.get_world_size(), dist.get_rank()
+    box = [capi.Context.comm_unique_id() if rank == 0 else None]
+    dist.broadcast_object_list(box, src=0)
+    ctx.comm_init(box[0], rank, world)
+
+
+def frame_step_native(ctx):
+    """frame_step with the exchange inside liblentil_hip.so (lentil_hip_allreduce): clear, pass, min-reduce of the
+    winner keys + gather (frames with closest AOVs), sum all-reduce, resolve -- all enqueued on the library's stream,
+    no torch.distributed call on the data path."""
+    if ctx.zkey_buffer()[1]:
+        ctx.set_closest_exchange(True)
+    ctx.clear_frame()
+    ctx.redistribute()
+    ctx.allreduce()
+    ctx.resolve()
+
+
+def frame_step_bands_native(ctx, visit_rows, bounds=None):
+    """frame_step_bands with the exchange inside liblentil_hip.so (lentil_hip_exchange_bands).  Returns the band."""
+    if ctx.zkey_buffer()[1]:
+        ctx.set_closest_exchange(False)       # local winners are gathered by the pass; keys travel with the rows
+    ctx.clear_frame()
+    ctx.redistribute()
+    return ctx.exchange_bands(visit_rows, bounds, sparse=SPARSE_EXCHANGE)
+
+
 def even_bounds(world, visit_rows):
     """Band boundaries (world + 1 visit rows) of the even split."""
     return [visit_rows * r // world for r in range(world + 1)]
@@ -246,12 +277,14 @@ def rebalance(bounds, seconds, min_rows=8, damping=1.0):
     # a band never shrinks below half or grows beyond twice the even height, whatever the timings say (the physical
     # imbalance is a few tens of percent; a rank that was merely disturbed while it was timed must not wreck the cut)
     even = (int(bounds[world]) - int(bounds[0])) / world
-    lo_h, hi_h = max(min_rows, int(even * 0.5)), max(min_rows, int(even * 2.0))
+    lo_h = min(max(min_rows, int(even * 0.5)), int(even))      # never more than the even height: the bands must fit
+    hi_h = max(min_rows, int(even * 2.0), lo_h)
     for k in range(1, world):            # boundaries ascending, heights within [lo_h, hi_h] ...
         new[k] = min(max(new[k], new[k - 1] + lo_h), new[k - 1] + hi_h)
     for k in range(world - 1, 0, -1):    # ... also seen from the other end (the last boundary is fixed)
         new[k] = max(min(new[k], new[k + 1] - lo_h), new[k + 1] - hi_h)
-    return new
+    ok = all(new[k] < new[k + 1] for k in range(world)) and new[0] == bounds[0] and new[world] == bounds[world]
+    return new if ok else [int(b) for b in bounds]      # frames too small to cut any other way keep their bounds
 
 
 def frame_step_bands(engine, dist, visit_rows, frame_rows, bounds=None):

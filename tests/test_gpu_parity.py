@@ -279,7 +279,8 @@ class _InProcessDist:
             self.world = world
             self.barrier = threading.Barrier(world)
             self.slots = [None] * world
-            self.mail = {}
+            import queue
+            self.mail = {(a, b): queue.Queue() for a in range(world) for b in range(world)}
 
     isend, irecv = "isend", "irecv"
 
@@ -324,14 +325,18 @@ class _InProcessDist:
         self._sync()
 
     def batch_isend_irecv(self, ops):
+        # sends and receives pair up per (source, destination) in posting order and involve nobody else, as with a
+        # real backend: a rank with nothing to exchange does not take part (a barrier here would stall on it)
+        import torch
         for op, t, peer in ops:
             if op == "isend":
-                self.sh.mail.setdefault((self.rank, peer), []).append(t.clone())
-        self._sync()
+                c = t.clone()
+                torch.cuda.synchronize()
+                self.sh.mail[(self.rank, peer)].put(c)
         for op, t, peer in ops:
             if op == "irecv":
-                t.copy_(self.sh.mail[(peer, self.rank)].pop(0))
-        self._sync()
+                t.copy_(self.sh.mail[(peer, self.rank)].get(timeout=60))
+        torch.cuda.synchronize()
         return [self._Req() for _ in ops]
 
 
@@ -475,9 +480,6 @@ def test_tiled_output_on_one_gpu_matches_the_whole_frame(orc, gpu_ctx_factory, m
         assert any(f > 0 for f in forms) and not any(f < 0 for f in forms)     # pixel lists only
 
 
-@pytest.mark.skipif(__import__("os").environ.get("LENTIL_TILED_SOAK") != "1",
-                    reason="opt-in (LENTIL_TILED_SOAK=1): written at the end of round 1 after the GPU budget was spent, "
-                           "not yet run on a GPU; its CPU twin is test_multi_gpu.py::test_tiled_step_seeded_soak")
 def test_randomized_tiled_bands(orc, monkeypatch):
     """Seeded soak of the tiled multi-GPU step on one device: number of ranks, band boundaries (down to bands of two
     rows, so that draws cross several bands), frame size, highlight fraction, AOV kinds, pixel lists or packed rows.
@@ -488,7 +490,7 @@ def test_randomized_tiled_bands(orc, monkeypatch):
     import threading
     from pota_amd import distributed, workload
     from test_multi_gpu import _ThreadDist
-    n_cases = int(os.environ.get("LENTIL_SOAK_CASES", "5"))
+    n_cases = int(os.environ.get("LENTIL_SOAK_CASES", "4"))
     rng = np.random.default_rng(int(os.environ.get("LENTIL_SOAK_SEED", "0x7D1E"), 0))
     for case in range(n_cases):
         world = int(rng.integers(2, 6))

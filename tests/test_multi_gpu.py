@@ -453,6 +453,23 @@ def test_tiled_step_seeded_soak(orc):
         assert all(seen.values()), seen            # every form of the exchange came up
 
 
+def test_rebalance_keeps_tiny_frames_cuttable():
+    """Frames with fewer rows per rank than min_rows: the boundaries stay strictly ascending inside the frame (the
+    clamp used to push them past the end and back below zero), whatever the timings say."""
+    from pota_amd import distributed
+    rng = np.random.default_rng(5)
+    for world, rows in [(4, 20), (8, 9), (2, 3), (5, 37), (8, 64), (3, 3)]:
+        even = distributed.even_bounds(world, rows)
+        for _ in range(20):
+            sec = rng.uniform(1e-4, 1.0, world).tolist()
+            new = distributed.rebalance(even, sec)
+            assert new[0] == 0 and new[-1] == rows and len(new) == world + 1
+            assert all(new[k] < new[k + 1] for k in range(world)), (world, rows, sec, new)
+            again = distributed.rebalance(new, sec, damping=0.6)
+            assert all(again[k] < again[k + 1] for k in range(world)) and again[0] == 0 and again[-1] == rows
+    assert distributed.rebalance([0, 5, 10, 15, 20], [1.0, 1.0, 1.0, 1.0]) == [0, 5, 10, 15, 20]
+
+
 def test_rebalance_equalises_the_modelled_cost():
     from pota_amd import distributed
     H, G = 6112, 8

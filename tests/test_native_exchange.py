@@ -1,0 +1,242 @@
+"""The native multi-GPU exchange of liblentil_hip.so (lentil_hip_comm_* / _allreduce / _exchange_bands,
+pota_amd/csrc/lentil_comm.h) on the one GPU a test box has.
+
+Real RCCL refuses two ranks on one device, so the world_size > 1 cases run every rank as a thread with a context of
+its own and tests/fake_rccl/libfake_rccl.so (test infrastructure: an in-process stand-in for the eight RCCL entry
+points the library binds, strict about the matching of sends and receives) in RCCL's place -- what is under test is
+the library's side: which rows go where in which form, the metadata all-gather, the merge order, the band resolve.
+The real librccl.so is exercised at world_size 1 in a process of its own (the RCCL binding is process-wide).
+Every band / frame is compared with a context that processed the whole frame, which the parity suite pins to the oracle.
+"""
+import os
+import threading
+
+import numpy as np
+import pytest
+
+import common
+from pota_amd import capi, distributed, workload
+from test_gpu_parity import TOL, _compare_with_whole, gpu_run
+
+pytestmark = pytest.mark.gpu
+FAKE = os.path.join(common.ROOT, "tests", "fake_rccl", "libfake_rccl.so")
+
+
+@pytest.fixture()
+def fake_rccl(monkeypatch):
+    if not os.path.exists(FAKE):
+        pytest.fail("tests/fake_rccl/libfake_rccl.so missing: run __graft_entry__.build()")
+    monkeypatch.setenv("LENTIL_RCCL_LIB", FAKE)      # read once, at the first comm call of the process
+
+
+def _threads(fn, world, timeout=240):
+    errors = []
+
+    def run(rank):
+        try:
+            fn(rank)
+        except Exception as e:          # pragma: no cover
+            errors.append((rank, e))
+
+    th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=timeout)
+    assert not errors, "rank %d: %r" % errors[0]
+    assert not any(t.is_alive() for t in th)
+
+
+def _band_contexts(factory, p, table, W, H, M, world, bounds, f_hi, kinds):
+    ctxs, keep, bands = [], [], []
+    for rank in range(world):
+        b_lo, b_hi = distributed.band_of(rank, world, H, p.yres, bounds)
+        c = workload.generate(np, b_lo * W * M, min(b_hi, H) * W * M, W, H, M, f_hi=f_hi, focus_dist=150.0,
+                              tan_half_fov=common.tan_half_fov(p), n_extra=len(kinds) - 1)
+        v, kv = capi.make_visits(c, visits_per_pixel=M, pixels_per_row=W, pixel_y0=b_lo)
+        ctx = factory()
+        ctx.set_params(p); ctx.set_lens(table); ctx.set_bokeh(None)
+        ctx.alloc_frame(len(kinds), kinds)
+        ctx.upload_visits(v)
+        keep.append((c, v, kv))
+        ctxs.append(ctx)
+        bands.append((b_lo, b_hi))
+    return ctxs, keep, bands
+
+
+@pytest.mark.parametrize("world,bounds,f_hi,sparse", [(2, None, 0.03, True), (3, None, 0.03, True), (3, [0, 9, 31, 45], 0.03, False),
+                                                     (3, None, 0.0015, True), (4, [0, 2, 4, 30, 45], 0.03, True)],
+                         ids=["2", "3", "3-unequal-rows", "3-sparse", "4-thin-bands"])
+def test_exchange_bands_matches_the_whole_frame(orc, gpu_ctx_factory, fake_rccl, monkeypatch, world, bounds, f_hi, sparse):
+    """lentil_hip_exchange_bands: every band equals the same rows of a whole-frame context, two passes (the second
+    blind, with the row-limited clear).  "4-thin-bands": two-row bands, draws cross several bands and a rank exchanges
+    with ranks that are not its neighbours."""
+    monkeypatch.setattr(distributed, "SPARSE_EXCHANGE", sparse)
+    W, H, M = 64, 45, 9
+    kinds = [0, 1, 0]
+    p, model, table, keep = common.po_setup(W, H, samples_override=48)
+    visits, cols = common.make_stream(p, W, H, M, f_hi=f_hi, n_extra=2)
+    whole = gpu_ctx_factory()
+    gpu_run(whole, p, table, visits, n_aovs=3, kinds=kinds)
+    whole.P = p
+    ctxs, keepalive, bands = _band_contexts(gpu_ctx_factory, p, table, W, H, M, world, bounds, f_hi, kinds)
+    uid = capi.Context.comm_unique_id()
+    got = {}
+
+    def rank_fn(rank):
+        ctx = ctxs[rank]
+        ctx.comm_init(uid, rank, world)
+        for _ in range(2):
+            got[rank] = distributed.frame_step_bands_native(ctx, H, bounds)
+            ctx.sync()
+        ctx.comm_destroy()
+
+    _threads(rank_fn, world)
+    reach = 0
+    for rank in range(world):
+        assert got[rank] == bands[rank]
+        lo, hi = ctxs[rank].touched_rows()
+        reach = max(reach, bands[rank][0] - lo, hi - bands[rank][1])
+        _compare_with_whole(ctxs[rank], whole, kinds, rows=bands[rank])
+    assert reach > 0
+
+
+def test_allreduce_matches_the_whole_frame(orc, gpu_ctx_factory, fake_rccl):
+    """lentil_hip_allreduce: rows r mod 3 in three contexts, winner keys min-reduced + gathered, accumulators summed:
+    every rank ends with the whole frame."""
+    W, H, M, world = 64, 40, 9, 3
+    kinds = [0, 1, 0]
+    p, model, table, keep = common.po_setup(W, H, samples_override=48)
+    visits, cols = common.make_stream(p, W, H, M, f_hi=0.03, n_extra=2)
+    whole = gpu_ctx_factory()
+    gpu_run(whole, p, table, visits, n_aovs=3, kinds=kinds)
+    whole.P = p
+    ctxs, keepalive = [], []
+    for rank in range(world):
+        n_local = workload.frame_visit_count(W, H, M, world, rank)
+        c = workload.generate(np, 0, n_local, W, H, M, f_hi=0.03, focus_dist=150.0, tan_half_fov=common.tan_half_fov(p),
+                              row_stride=world, row_offset=rank, n_extra=2)
+        v, kv = capi.make_visits(c, visits_per_pixel=M, pixels_per_row=W, pixel_y0=rank, pixel_row_stride=world)
+        ctx = gpu_ctx_factory()
+        ctx.set_params(p); ctx.set_lens(table); ctx.set_bokeh(None)
+        ctx.alloc_frame(3, kinds)
+        ctx.upload_visits(v)
+        keepalive.append((c, v, kv))
+        ctxs.append(ctx)
+    uid = capi.Context.comm_unique_id()
+
+    def rank_fn(rank):
+        ctxs[rank].comm_init(uid, rank, world)
+        for _ in range(2):
+            distributed.frame_step_native(ctxs[rank])
+            ctxs[rank].sync()
+
+    _threads(rank_fn, world)
+    for rank in range(world):
+        _compare_with_whole(ctxs[rank], whole, kinds)
+
+
+def test_exchange_bands_seeded_soak(orc, fake_rccl, monkeypatch):
+    """Seeded soak of the native tiled step: 2-5 ranks, even or random boundaries down to two-row bands, frame size,
+    highlight fraction, AOV kinds, pixel lists or packed rows; every band against the whole frame, two passes."""
+    n_cases = int(os.environ.get("LENTIL_SOAK_CASES", "6"))
+    rng = np.random.default_rng(int(os.environ.get("LENTIL_SOAK_SEED", "0x7D1E"), 0))
+    for case in range(n_cases):
+        world = int(rng.integers(2, 6))
+        W, H, M = int(rng.integers(24, 90)), int(rng.integers(4 * world, 60)), 9
+        cuts = sorted(rng.choice(np.arange(2, H - 1, 2), size=world - 1, replace=False).tolist())
+        bounds = [0] + [int(c) for c in cuts] + [H] if rng.integers(0, 2) else None
+        f_hi = float(rng.choice([0.0, 0.0015, 0.01, 0.03]))
+        kinds = [[0], [0, 0], [0, 1, 0]][int(rng.integers(0, 3))]
+        sparse = bool(rng.integers(0, 2))
+        tag = "case %d: world %d %dx%d bounds %r f_hi %g kinds %r sparse %d" % (case, world, W, H, bounds, f_hi, kinds, sparse)
+        monkeypatch.setattr(distributed, "SPARSE_EXCHANGE", sparse)
+        p, model, table, keep = common.po_setup(W, H, samples_override=int(rng.choice([16, 48])))
+        visits, cols = common.make_stream(p, W, H, M, f_hi=f_hi, n_extra=len(kinds) - 1)
+        made = []
+
+        def factory():
+            made.append(capi.Context(0))
+            return made[-1]
+
+        try:
+            whole = factory()
+            gpu_run(whole, p, table, visits, n_aovs=len(kinds), kinds=kinds)
+            whole.P = p
+            ctxs, keepalive, bands = _band_contexts(factory, p, table, W, H, M, world, bounds, f_hi, kinds)
+            uid = capi.Context.comm_unique_id()
+
+            def rank_fn(rank):
+                ctxs[rank].comm_init(uid, rank, world)
+                for _ in range(2):
+                    assert distributed.frame_step_bands_native(ctxs[rank], H, bounds) == bands[rank]
+                    ctxs[rank].sync()
+
+            _threads(rank_fn, world)
+            for rank in range(world):
+                try:
+                    if f_hi > 0:
+                        _compare_with_whole(ctxs[rank], whole, kinds, rows=bands[rank])
+                    else:                   # nothing redistributed: direct sums only, bit for bit
+                        for a in range(len(kinds)):
+                            lo, hi = bands[rank][0] * p.xres, bands[rank][1] * p.xres
+                            assert np.array_equal(ctxs[rank].download_aov(a)[lo:hi], whole.download_aov(a)[lo:hi])
+                except AssertionError as e:
+                    raise AssertionError("%s, rank %d: %s" % (tag, rank, e))
+        finally:
+            for c in made:
+                c.close()
+
+
+def _real_rccl_world1(q):
+    """world_size 1 through the real librccl.so: communicator, both exchanges (which then move nothing), the results"""
+    import sys
+    sys.path.insert(0, common.ROOT)
+    sys.path.insert(0, os.path.join(common.ROOT, "tests"))
+    os.environ.pop("LENTIL_RCCL_LIB", None)
+    W, H, M = 64, 40, 9
+    kinds = [0, 1, 0]
+    p, model, table, keep = common.po_setup(W, H, samples_override=48)
+    c = workload.generate(np, 0, W * H * M, W, H, M, f_hi=0.03, focus_dist=150.0, tan_half_fov=common.tan_half_fov(p), n_extra=2)
+    v, kv = capi.make_visits(c, visits_per_pixel=M, pixels_per_row=W)
+    out = {}
+    ctx = capi.Context(0)
+    ctx.set_params(p); ctx.set_lens(table); ctx.set_bokeh(None)
+    ctx.alloc_frame(3, kinds)
+    ctx.upload_visits(v)
+    ctx.redistribute(); ctx.resolve(); ctx.sync()
+    out["plain"] = [ctx.download_aov(a) for a in range(3)]
+    ctx.comm_init(capi.Context.comm_unique_id(), 0, 1)
+    distributed.frame_step_native(ctx)
+    ctx.sync()
+    out["allreduce"] = [ctx.download_aov(a) for a in range(3)]
+    out["band"] = distributed.frame_step_bands_native(ctx, H)
+    ctx.sync()
+    out["bands"] = [ctx.download_aov(a) for a in range(3)]
+    out["yres"] = int(p.yres)
+    ctx.comm_destroy()
+    ctx.close()
+    q.put(out)
+
+
+def test_real_rccl_world_size_one():
+    import torch.multiprocessing as mp
+    mpc = mp.get_context("spawn")
+    q = mpc.Queue()
+    pr = mpc.Process(target=_real_rccl_world1, args=(q,))
+    pr.start()
+    out = q.get(timeout=300)
+    pr.join(timeout=120)
+    assert pr.exitcode == 0
+    assert out["band"] == (0, out["yres"])
+    for a, kind in enumerate([0, 1, 0]):
+        ref = out["plain"][a]
+        assert np.count_nonzero(ref) > 0
+        for name in ("allreduce", "bands"):
+            got = out[name][a]
+            if kind:
+                assert np.array_equal(got, ref)
+            else:
+                m = ref != 0
+                assert np.array_equal(got != 0, m)
+                assert float(np.max(np.abs(got[m] - ref[m]) / np.abs(ref[m]))) < 2 * TOL
