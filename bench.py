@@ -272,7 +272,9 @@ class Bench:
         if self.band is not None and self.tiled:
             per_row = acc.numel() // self.p.yres
             acc = acc[self.band[0] * per_row:self.band[1] * per_row]
-        return acc.clone()
+        out = acc.clone()
+        self.torch.cuda.synchronize()                # the copy ran on torch's stream; the next step's clear is on the library's
+        return out
 
     def check_native_exchange(self):
         """One step through the library's own RCCL exchange and one through torch.distributed (the Python form of the
