@@ -184,6 +184,16 @@ uint64_t lentil_stage_size(const lentil_stage *s);
 /* concatenates the slots (slot order, append order inside a slot) into contiguous columns owned by the
  * stage and describes them as a ragged visit stream (explicit pixel + inv_density columns) */
 int lentil_stage_visits(lentil_stage *s, lentil_visits *out);
+/* Streaming mode: instead of keeping the frame's visits on the host until the imager asks, every slot fills
+ * page-locked blocks of block_visits visits (0: 16384; allocated when a slot is first used) and sends each full block to `gpu` at once
+ * (lentil_hip_visits_append; two blocks per slot, used in turn), so that the PCIe transfer runs while the
+ * buckets render.  Call between frames (empty stage); gpu == NULL returns to plain staging.  capacity_hint:
+ * expected visits per frame (0: unknown).  lentil_stage_reset starts the next frame's stream;
+ * lentil_stage_finish_stream sends the partly filled blocks and makes the stream the context's visits
+ * (lentil_imager_process_bucket does that itself); lentil_stage_visits is not available in this mode. */
+int lentil_stage_stream_to(lentil_stage *s, lentil_hip_ctx *gpu, uint32_t block_visits, uint64_t capacity_hint);
+int lentil_stage_finish_stream(lentil_stage *s, uint64_t *n_visits);
+int lentil_stage_is_streaming(const lentil_stage *s);
 
 /* ------------------------------------------------------------------------------------
  * imager_lentil: driver_process_bucket (src/lentil_imager.cpp:66-193).  The first call from any

@@ -265,6 +265,29 @@ int lentil_hip_alloc_frame(lentil_hip_ctx *ctx, uint32_t n_aovs, const uint8_t *
 int lentil_hip_upload_visits(lentil_hip_ctx *ctx, const lentil_visits *host_visits);
 int lentil_hip_bind_visits(lentil_hip_ctx *ctx, const lentil_visits *device_visits);
 
+/* The same hand-over piece by piece, while the renderer is still rendering: a capturing filter_pixel
+ * (src/lentil_filter.cpp:66-436 runs per pixel on many bucket threads) fills blocks of visits and sends each
+ * block as it fills, so that the PCIe transfer (80 B per visit: 0.11 s for a 4K frame in one piece) hides
+ * behind the render and the frame end waits for the last block only.
+ * host_alloc / host_free : page-locked host memory for those blocks (copies from it are asynchronous DMA;
+ *                ordinary memory works too, the copy then returns when the runtime has staged it).
+ * visits_begin : starts a frame's stream.  `layout` gives its geometry (visits_per_pixel, pixels_per_row,
+ *                pixel_x0/y0, pixel_row_stride, n_extra; n and the column pointers are ignored, except that
+ *                inv_density != NULL announces per-visit densities for a ragged stream).  capacity_hint:
+ *                expected number of visits (0: unknown; the columns grow by doubling).  Waits for the
+ *                previous pass; the previous frame's device columns are reused when they fit.
+ * visits_append: part->n visits (host columns) go to the end of the stream, in call order; thread-safe.
+ *                Returns at once; *ticket (may be NULL) identifies the copies.
+ * visits_wait  : returns when the copies of that ticket are complete -- the block may be refilled.
+ * visits_end   : waits for all copies and makes the assembled stream the context's visits (as upload_visits
+ *                would have); *n_visits (may be NULL) returns their number. */
+int lentil_hip_host_alloc(void **host_ptr, uint64_t bytes);
+int lentil_hip_host_free(void *host_ptr);
+int lentil_hip_visits_begin(lentil_hip_ctx *ctx, const lentil_visits *layout, uint64_t capacity_hint);
+int lentil_hip_visits_append(lentil_hip_ctx *ctx, const lentil_visits *part, uint64_t *ticket);
+int lentil_hip_visits_wait(lentil_hip_ctx *ctx, uint64_t ticket);
+int lentil_hip_visits_end(lentil_hip_ctx *ctx, uint64_t *n_visits);
+
 /* --- the hot path ------------------------------------------------------------------
  * clear_frame : zero-initialisation done by std::vector::resize (src/lentil.h:1096-1098)
  * redistribute: the filter_pixel visit loop (src/lentil_filter.cpp:91-451) for every bound

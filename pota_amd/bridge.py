@@ -54,7 +54,7 @@ EXPORTS = [
     "lentil_filter_inverse_sample_density", "lentil_tokenize_output", "lentil_rebuild_output",
     "lentil_string_to_arnold_type", "lentil_operator_cook", "lentil_sanitize_aov_list", "lentil_aov_frame_kind",
     "lentil_stage_create", "lentil_stage_destroy", "lentil_stage_reset", "lentil_stage_append", "lentil_stage_size",
-    "lentil_stage_visits", "lentil_imager_create", "lentil_imager_destroy", "lentil_imager_new_frame",
+    "lentil_stage_visits", "lentil_stage_stream_to", "lentil_stage_finish_stream", "lentil_stage_is_streaming", "lentil_imager_create", "lentil_imager_destroy", "lentil_imager_new_frame",
     "lentil_imager_process_bucket", "lentil_imager_last_error",
     "lentil_setup_filter_region", "lentil_filter_gaussian_complete", "lentil_filter_closest_complete",
 ]
@@ -95,6 +95,9 @@ def load():
         "lentil_stage_append": (i, [vp, i, C.POINTER(SampleCapture)]),
         "lentil_stage_size": (u64, [vp]),
         "lentil_stage_visits": (i, [vp, C.POINTER(_abi.Visits)]),
+        "lentil_stage_stream_to": (i, [vp, vp, u32, u64]),
+        "lentil_stage_finish_stream": (i, [vp, C.POINTER(u64)]),
+        "lentil_stage_is_streaming": (i, [vp]),
         "lentil_imager_create": (i, [vp, vp, C.POINTER(_abi.Params), u32, C.POINTER(vp)]),
         "lentil_imager_destroy": (None, [vp]),
         "lentil_imager_new_frame": (None, [vp]),

@@ -26,6 +26,8 @@ EXPORTS = [
     "lentil_hip_download_draw_log", "lentil_hip_test_lt_sample_aperture",
     "lentil_hip_test_trace_bw_po", "lentil_hip_test_aperture_sample",
     "lentil_hip_lens_is_compiled", "lentil_hip_set_lens_mode",
+    "lentil_hip_host_alloc", "lentil_hip_host_free", "lentil_hip_visits_begin", "lentil_hip_visits_append",
+    "lentil_hip_visits_wait", "lentil_hip_visits_end",
     "lentil_hip_comm_unique_id", "lentil_hip_comm_init", "lentil_hip_comm_destroy", "lentil_hip_allreduce",
     "lentil_hip_exchange_bands",
 ]
@@ -97,6 +99,12 @@ def load_library():
         "lentil_hip_test_aperture_sample": (i, [vp, u64, vp, vp, vp]),
         "lentil_hip_lens_is_compiled": (i, [vp]),
         "lentil_hip_set_lens_mode": (i, [vp, i]),
+        "lentil_hip_host_alloc": (i, [C.POINTER(vp), u64]),
+        "lentil_hip_host_free": (i, [vp]),
+        "lentil_hip_visits_begin": (i, [vp, C.POINTER(_abi.Visits), u64]),
+        "lentil_hip_visits_append": (i, [vp, C.POINTER(_abi.Visits), C.POINTER(u64)]),
+        "lentil_hip_visits_wait": (i, [vp, u64]),
+        "lentil_hip_visits_end": (i, [vp, C.POINTER(u64)]),
         "lentil_hip_comm_unique_id": (i, [vp]),
         "lentil_hip_comm_init": (i, [vp, vp, i, i]),
         "lentil_hip_comm_destroy": (i, [vp]),
@@ -111,6 +119,19 @@ def load_library():
         raise RuntimeError("liblentil_hip.so ABI version mismatch")
     _lib = lib
     return lib
+
+
+def host_alloc(nbytes):
+    """Page-locked host memory from the library (lentil_hip_host_alloc) as a ctypes char array; free with host_free."""
+    p = C.c_void_p()
+    rc = load_library().lentil_hip_host_alloc(C.byref(p), nbytes)
+    if rc:
+        raise LentilError(rc, "lentil_hip_host_alloc(%d)" % nbytes)
+    return p.value
+
+
+def host_free(ptr):
+    load_library().lentil_hip_host_free(C.c_void_p(ptr))
 
 
 def make_visits(cols, visits_per_pixel=0, pixels_per_row=0, pixel_x0=0, pixel_y0=0, pixel_row_stride=1,
@@ -253,6 +274,23 @@ class Context:
 
     def closest_gather(self):
         self._chk(self.lib.lentil_hip_closest_gather(self.h))
+
+    # --- the visit stream handed over piece by piece (include/lentil_hip.h "piece by piece")
+    def visits_begin(self, layout, capacity_hint=0):
+        self._chk(self.lib.lentil_hip_visits_begin(self.h, C.byref(layout), capacity_hint))
+
+    def visits_append(self, part):
+        t = C.c_uint64()
+        self._chk(self.lib.lentil_hip_visits_append(self.h, C.byref(part), C.byref(t)))
+        return t.value
+
+    def visits_wait(self, ticket):
+        self._chk(self.lib.lentil_hip_visits_wait(self.h, ticket))
+
+    def visits_end(self):
+        n = C.c_uint64()
+        self._chk(self.lib.lentil_hip_visits_end(self.h, C.byref(n)))
+        return n.value
 
     # --- the native exchange (RCCL inside the library; include/lentil_hip.h "multi-GPU, the exchange itself")
     @staticmethod

@@ -357,17 +357,75 @@ BRIDGE_API void lentil_filter_closest_complete(int n, const float *depth, const 
 // ---------------------------------------------------------------------------------------
 // visit capture
 // ---------------------------------------------------------------------------------------
+// streaming mode (lentil_stage_stream_to): a page-locked block of `cap` visits, columns one after the other
+struct PinnedBlock {
+  char *base = nullptr;
+  uint32_t n = 0;
+  uint64_t ticket = 0;           // of the copies last started from this block
+};
+
 struct StageSlot {
   std::vector<float> rgba, pos_z, raydir_time, volume_ignore, transmission, inv_density;
   std::vector<std::vector<float>> extra;
   std::vector<uint32_t> pixel;
+  PinnedBlock blk[2];
+  int cur = 0;
+  uint64_t sent = 0;             // visits of this slot already on their way to the GPU
 };
 
 struct lentil_stage {
   uint32_t n_extra = 0;
   std::vector<StageSlot> slots;
   StageSlot all;               // concatenation, built by lentil_stage_visits
+  // streaming mode
+  lentil_hip_ctx *gpu = nullptr;
+  uint32_t block_visits = 0;
+  uint64_t capacity_hint = 0;
+  bool stream_open = false;
+  std::string error;
 };
+
+static float *block_col(const lentil_stage *s, const PinnedBlock &b, uint32_t c) {        // column c of a block: cap x 4 floats
+  return reinterpret_cast<float *>(b.base + (size_t)c * s->block_visits * 16);
+}
+static uint32_t *block_pixel(const lentil_stage *s, const PinnedBlock &b) {
+  return reinterpret_cast<uint32_t *>(b.base + (size_t)(5 + s->n_extra) * s->block_visits * 16);
+}
+static float *block_inv(const lentil_stage *s, const PinnedBlock &b) {
+  return reinterpret_cast<float *>(b.base + (size_t)(5 + s->n_extra) * s->block_visits * 16 + (size_t)s->block_visits * 4);
+}
+
+static int stage_begin_stream(lentil_stage *s) {
+  lentil_visits lay;
+  memset(&lay, 0, sizeof(lay));
+  lay.pixel_row_stride = 1;
+  lay.n_extra = s->n_extra;
+  static const float announce = 0.0f;
+  lay.inv_density = &announce;                   // per-visit densities follow
+  const int rc = lentil_hip_visits_begin(s->gpu, &lay, s->capacity_hint);
+  s->stream_open = rc == LENTIL_OK;
+  if (rc != LENTIL_OK) s->error = lentil_hip_last_error(s->gpu);
+  return rc;
+}
+
+// sends what block `b` of a slot holds
+static int stage_send_block(lentil_stage *s, StageSlot &sl, PinnedBlock &b) {
+  if (b.n == 0) return LENTIL_OK;
+  lentil_visits part;
+  memset(&part, 0, sizeof(part));
+  part.n = b.n;
+  part.n_extra = s->n_extra;
+  part.rgba = block_col(s, b, 0); part.pos_z = block_col(s, b, 1); part.raydir_time = block_col(s, b, 2);
+  part.volume_ignore = block_col(s, b, 3); part.transmission = block_col(s, b, 4);
+  for (uint32_t k = 0; k < s->n_extra; ++k) part.extra[k] = block_col(s, b, 5 + k);
+  part.pixel = block_pixel(s, b);
+  part.inv_density = block_inv(s, b);
+  const int rc = lentil_hip_visits_append(s->gpu, &part, &b.ticket);
+  if (rc != LENTIL_OK) return rc;
+  sl.sent += b.n;
+  b.n = 0;
+  return LENTIL_OK;
+}
 
 BRIDGE_API int lentil_stage_create(int n_thread_slots, uint32_t n_extra, lentil_stage **out) {
   if (!out || n_thread_slots <= 0 || n_extra > LENTIL_MAX_AOVS - 1) return LENTIL_ERR_INVALID;
@@ -381,7 +439,33 @@ BRIDGE_API int lentil_stage_create(int n_thread_slots, uint32_t n_extra, lentil_
   return LENTIL_OK;
 }
 
-BRIDGE_API void lentil_stage_destroy(lentil_stage *s) { delete s; }
+BRIDGE_API uint64_t lentil_stage_size(const lentil_stage *s);
+
+static void stage_free_blocks(lentil_stage *s) {
+  for (StageSlot &sl : s->slots)
+    for (PinnedBlock &b : sl.blk) {
+      if (b.base) (void)lentil_hip_host_free(b.base);
+      b = PinnedBlock();
+    }
+}
+
+BRIDGE_API void lentil_stage_destroy(lentil_stage *s) {
+  if (!s) return;
+  stage_free_blocks(s);
+  delete s;
+}
+
+BRIDGE_API int lentil_stage_stream_to(lentil_stage *s, lentil_hip_ctx *gpu, uint32_t block_visits, uint64_t capacity_hint) {
+  if (!s) return LENTIL_ERR_INVALID;
+  if (lentil_stage_size(s) != 0) return LENTIL_ERR_INVALID;      // between frames only
+  stage_free_blocks(s);
+  s->gpu = gpu;
+  s->stream_open = false;
+  if (!gpu) return LENTIL_OK;                                    // back to plain staging
+  s->block_visits = block_visits ? block_visits : (1u << 14);
+  s->capacity_hint = capacity_hint;
+  return stage_begin_stream(s);          // a slot's blocks are allocated when a thread first uses the slot
+}
 
 static void clear_slot(StageSlot &sl) {
   sl.rgba.clear(); sl.pos_z.clear(); sl.raydir_time.clear(); sl.volume_ignore.clear(); sl.transmission.clear();
@@ -391,8 +475,13 @@ static void clear_slot(StageSlot &sl) {
 
 BRIDGE_API void lentil_stage_reset(lentil_stage *s) {
   if (!s) return;
-  for (StageSlot &sl : s->slots) clear_slot(sl);
+  for (StageSlot &sl : s->slots) {
+    clear_slot(sl);
+    sl.sent = 0; sl.cur = 0;
+    for (PinnedBlock &b : sl.blk) { b.n = 0; b.ticket = 0; }      // tickets belong to the previous frame's stream
+  }
   clear_slot(s->all);
+  if (s->gpu) (void)stage_begin_stream(s);       // a failure shows at the next append
 }
 
 static inline void push4(std::vector<float> &v, float a, float b, float c, float d) {
@@ -404,6 +493,40 @@ BRIDGE_API int lentil_stage_append(lentil_stage *s, int thread_slot, const lenti
   if (c->px < 0 || c->py < 0 || c->px > 0xFFFF || c->py > 0xFFFF) return LENTIL_ERR_INVALID;
   if (s->n_extra && !c->extra_rgba) return LENTIL_ERR_INVALID;
   StageSlot &sl = s->slots[(size_t)thread_slot];
+  if (s->gpu) {
+    // streaming mode: into the slot's current page-locked block; a full block goes to the GPU and the slot
+    // continues in its other block once that one's previous copies are done
+    if (!s->stream_open) return LENTIL_ERR_INVALID;
+    PinnedBlock *b = &sl.blk[sl.cur];
+    if (b->n == s->block_visits) {
+      int rc = stage_send_block(s, sl, *b);
+      if (rc != LENTIL_OK) return rc;
+      sl.cur ^= 1;
+      b = &sl.blk[sl.cur];
+      if (b->ticket && (rc = lentil_hip_visits_wait(s->gpu, b->ticket)) != LENTIL_OK) return rc;
+    }
+    if (!b->base) {
+      void *p = nullptr;
+      const int rc = lentil_hip_host_alloc(&p, (size_t)s->block_visits * (16 * (5 + s->n_extra) + 8));
+      if (rc != LENTIL_OK) return rc;
+      b->base = static_cast<char *>(p);
+    }
+    const uint32_t i = b->n++;
+    auto put4 = [&](uint32_t col, float x, float y, float z, float w) {
+      float *d = block_col(s, *b, col) + (size_t)i * 4;
+      d[0] = x; d[1] = y; d[2] = z; d[3] = w;
+    };
+    put4(0, c->rgba[0], c->rgba[1], c->rgba[2], c->rgba[3]);
+    put4(1, c->P[0], c->P[1], c->P[2], c->Z);
+    put4(2, c->raydir[0], c->raydir[1], c->raydir[2], c->time);
+    put4(3, c->volume[0], c->volume[1], c->volume[2], c->bidir_ignore);
+    put4(4, c->transmission[0], c->transmission[1], c->transmission[2], c->transmission[3]);
+    for (uint32_t k = 0; k < s->n_extra; ++k)
+      put4(5 + k, c->extra_rgba[k * 4], c->extra_rgba[k * 4 + 1], c->extra_rgba[k * 4 + 2], c->extra_rgba[k * 4 + 3]);
+    block_pixel(s, *b)[i] = (uint32_t)c->px | ((uint32_t)c->py << 16);
+    block_inv(s, *b)[i] = c->inverse_sample_density;
+    return LENTIL_OK;
+  }
   try {
     push4(sl.rgba, c->rgba[0], c->rgba[1], c->rgba[2], c->rgba[3]);
     push4(sl.pos_z, c->P[0], c->P[1], c->P[2], c->Z);
@@ -422,12 +545,26 @@ BRIDGE_API int lentil_stage_append(lentil_stage *s, int thread_slot, const lenti
 
 BRIDGE_API uint64_t lentil_stage_size(const lentil_stage *s) {
   uint64_t n = 0;
-  if (s) for (const StageSlot &sl : s->slots) n += sl.pixel.size();
+  if (s) for (const StageSlot &sl : s->slots) n += sl.pixel.size() + sl.sent + sl.blk[0].n + sl.blk[1].n;
   return n;
 }
 
+// streaming mode: the partly filled blocks follow, the stream becomes the context's visits
+BRIDGE_API int lentil_stage_finish_stream(lentil_stage *s, uint64_t *n_visits) {
+  if (!s || !s->gpu || !s->stream_open) return LENTIL_ERR_INVALID;
+  for (StageSlot &sl : s->slots)
+    for (PinnedBlock &b : sl.blk) {
+      const int rc = stage_send_block(s, sl, b);
+      if (rc != LENTIL_OK) return rc;
+    }
+  s->stream_open = false;
+  return lentil_hip_visits_end(s->gpu, n_visits);
+}
+
+BRIDGE_API int lentil_stage_is_streaming(const lentil_stage *s) { return s && s->gpu ? 1 : 0; }
+
 BRIDGE_API int lentil_stage_visits(lentil_stage *s, lentil_visits *out) {
-  if (!s || !out) return LENTIL_ERR_INVALID;
+  if (!s || !out || s->gpu) return LENTIL_ERR_INVALID;
   StageSlot &a = s->all;
   clear_slot(a);
   try {
@@ -507,9 +644,14 @@ static void run_gpu_pass(lentil_imager *im) {
     }
     return rc == LENTIL_OK;
   };
-  lentil_visits v;
-  if (!check(lentil_stage_visits(im->stage, &v), "stage")) return;
-  if (!check(lentil_hip_upload_visits(im->gpu, &v), "upload_visits")) return;
+  if (lentil_stage_is_streaming(im->stage)) {
+    // the visits went to the GPU while the buckets rendered; only the partly filled blocks are left
+    if (!check(lentil_stage_finish_stream(im->stage, nullptr), "finish_stream")) return;
+  } else {
+    lentil_visits v;
+    if (!check(lentil_stage_visits(im->stage, &v), "stage")) return;
+    if (!check(lentil_hip_upload_visits(im->gpu, &v), "upload_visits")) return;
+  }
   if (!check(lentil_hip_clear_frame(im->gpu), "clear_frame")) return;
   if (!check(lentil_hip_redistribute(im->gpu), "redistribute")) return;
   if (!check(lentil_hip_resolve(im->gpu), "resolve")) return;

@@ -137,6 +137,7 @@ struct lentil_hip_ctx {
   lentil_draw_record *d_log = nullptr;
   uint64_t log_cap = 0;
   bool timed_draw = false, timed_resolve = false;
+  struct LentilUpload *upload = nullptr;   // lentil_upload.h: the visit stream handed over piece by piece
   struct LentilComm *comm = nullptr; // lentil_comm.h: this context's RCCL communicator, if one was asked for
 };
 
@@ -263,10 +264,14 @@ static void free_bokeh(lentil_hip_ctx *ctx) {
 }
 
 LENTIL_API int lentil_hip_comm_destroy(lentil_hip_ctx *ctx);
+static void upload_destroy(lentil_hip_ctx *ctx);
+static void upload_release(lentil_hip_ctx *ctx, bool free_columns);
 
 LENTIL_API int lentil_hip_destroy(lentil_hip_ctx *ctx) {
   if (!ctx) return LENTIL_OK;
   (void)lentil_hip_comm_destroy(ctx);
+  (void)hipSetDevice(ctx->device);
+  upload_destroy(ctx);
   (void)hipSetDevice(ctx->device);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   free_visits(ctx);
@@ -594,6 +599,7 @@ LENTIL_API int lentil_hip_bind_visits(lentil_hip_ctx *ctx, const lentil_visits *
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   free_visits(ctx);
+  upload_release(ctx, true);
   to_dev(ctx->V, v);
   ctx->V.id_base = ctx->visit_id_base;
   rc = ensure_worklist(ctx, v->n);
@@ -609,6 +615,7 @@ LENTIL_API int lentil_hip_upload_visits(lentil_hip_ctx *ctx, const lentil_visits
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   free_visits(ctx);
+  upload_release(ctx, true);
   lentil_visits d = *v;
   auto up = [&](const void *src, size_t bytes, const void **dst) -> int {
     *dst = nullptr;
@@ -2055,4 +2062,5 @@ LENTIL_API int lentil_hip_test_aperture_sample(lentil_hip_ctx *ctx, uint64_t n, 
   return LENTIL_OK;
 }
 
+#include "lentil_upload.h"
 #include "lentil_comm.h"

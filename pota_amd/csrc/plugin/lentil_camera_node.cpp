@@ -266,6 +266,14 @@ void LentilCamera::setup(AtUniverse *universe) {
     AiRenderAbort();
     return;
   }
+  // the visits travel to the GPU while the buckets render (LENTIL_STREAM_UPLOAD=0: one upload at the frame end)
+  const char *su = getenv("LENTIL_STREAM_UPLOAD");
+  if (!(su && su[0] == '0')) {
+    const double per_pixel = P.inverse_sample_density > 0.0f ? 1.0 / P.inverse_sample_density : 1.0;      // AA^2
+    const uint64_t expect = (uint64_t)((double)P.xres * P.yres * per_pixel);
+    if (lentil_stage_stream_to(stage, gpu, 0, expect) != LENTIL_OK)
+      AiMsgWarning("[LENTIL] streaming upload unavailable (%s); the visits are uploaded at the end of the frame", lentil_hip_last_error(gpu));
+  }
   for (const lentil_aov_plan &a : aovs)
     AiMsgInfo("[LENTIL BIDIRECTIONAL] Driver '%s' -- Adding aov %s of type %s", a.to.driver, a.to.aov_name, a.to.aov_type);
   imager_print_once_only = false;

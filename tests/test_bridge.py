@@ -208,9 +208,13 @@ def test_visit_capture_from_concurrent_threads():
 
 
 @pytest.mark.gpu
-def test_imager_buckets_match_the_direct_pipeline(gpu_ctx_factory):
+@pytest.mark.parametrize("streaming", [False, True], ids=["staged", "streamed-upload"])
+def test_imager_buckets_match_the_direct_pipeline(gpu_ctx_factory, streaming):
     """driver_process_bucket (src/lentil_imager.cpp:66-193): buckets requested from several threads; the
-    GPU pass runs once; the assembled frame equals the one the C-ABI pipeline delivers directly."""
+    GPU pass runs once; the assembled frame equals the one the C-ABI pipeline delivers directly.
+    "streamed-upload": the stage sends its visits to the GPU in page-locked blocks while they are appended
+    (lentil_stage_stream_to; blocks of 1000 visits so that every slot sends several and reuses its two blocks),
+    then a second frame through the same stage."""
     lib = bridge.load()
     W, H, M = 80, 48, 9
     kinds = [0, 1, 0]
@@ -232,10 +236,28 @@ def test_imager_buckets_match_the_direct_pipeline(gpu_ctx_factory):
     assert lib.lentil_stage_create(3, 2, C.byref(stage)) == 0
     order = np.arange(n).reshape(-1, M)            # whole pixels per thread, like buckets
     parts = np.array_split(order, 3)
-    for k in range(3):
-        bridge.stage_append_arrays(stage, k, cols, parts[k].reshape(-1))
     im = C.c_void_p()
     assert lib.lentil_imager_create(ctx.h, stage, C.byref(p), 3, C.byref(im)) == 0
+    if streaming:
+        assert lib.lentil_stage_stream_to(stage, ctx.h, 1000, 0) == 0
+        assert lib.lentil_stage_is_streaming(stage) == 1
+        # a first frame with other content through the same stage: its blocks and device columns are reused
+        for k in range(3):
+            bridge.stage_append_arrays(stage, k, cols, parts[(k + 1) % 3].reshape(-1)[: 5000 + 700 * k])
+        assert lib.lentil_stage_size(stage) == 3 * 5000 + 700 * 3
+        buf = np.empty((4, 4, 4), np.float32)
+        assert lib.lentil_imager_process_bucket(im, 0, 0, 0, 4, 4, buf.ctypes.data) == 0
+        lib.lentil_stage_reset(stage)
+        lib.lentil_imager_new_frame(im)
+        th = [threading.Thread(target=bridge.stage_append_arrays, args=(stage, k, cols, parts[k].reshape(-1))) for k in range(3)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        assert lib.lentil_stage_size(stage) == n
+    else:
+        for k in range(3):
+            bridge.stage_append_arrays(stage, k, cols, parts[k].reshape(-1))
 
     B = 16
     got = [np.full((p.yres, p.xres, 4), np.nan, np.float32) for _ in range(3)]

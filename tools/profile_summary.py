@@ -15,7 +15,8 @@ import os
 import sys
 
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
-MINE = ("scan_", "solve_", "accept_", "prep_items", "resolve_kernel")
+MINE = ("scan_", "solve_", "accept_", "prep_items", "resolve_kernel", "publish_kernel", "fold_direct", "clear_touched",
+        "pack_rows", "merge_", "compact_rows", "closest_gather", "debug_gather")
 
 
 def find(d, pat):
@@ -52,7 +53,7 @@ def main():
         fetch_kb, nf = per_launch(args[2], "FETCH_SIZE")
         write_kb, nw = per_launch(args[3], "WRITE_SIZE")
         res = {
-            "kernel": "scan_uniform_kernel", "workload": workload, "launches": [nf, nw],
+            "kernel": (workload or "scan_").split()[0], "workload": workload, "launches": [nf, nw],
             "FETCH_SIZE_KB_raw": fetch_kb, "WRITE_SIZE_KB_raw": write_kb,
             "fetch_bytes_corrected": fetch_kb * 1024 * 2, "write_bytes": write_kb * 1024,
             "hbm_bytes_per_launch": fetch_kb * 1024 * 2 + write_kb * 1024,
