@@ -1333,25 +1333,10 @@ static int redistribute_streamed(lentil_hip_ctx *ctx, bool *streamed) {
   ++ctx->last_blind;
   const DevCounters c = ctx->h_ctr[0];
   ch.was_blind = true;
-  if (getenv("LENTIL_STREAM_DEBUG"))
-    fprintf(stderr, "[stream] A: solves %llu start %.1f first-task %.1f | B: solves %llu start %.1f first-task %.1f | last wave end %.1f (us after A's first wave)\n",
-            c.dbg[1], 0.0, ((double)c.dbg[3] - (double)c.dbg[2]) / 100.0, c.dbg[4], ((double)c.dbg[5] - (double)c.dbg[2]) / 100.0,
-            ((double)c.dbg[6] - (double)c.dbg[2]) / 100.0, ((double)c.dbg[0] - (double)c.dbg[2]) / 100.0);
-  if (getenv("LENTIL_STREAM_DEBUG")) {
-    fprintf(stderr, "[stream] A: mean clock %.0f MHz, %.2f us per wave-iteration (wave lifetime / rounds)\n",
-            c.dbg[45] ? (double)c.dbg[44] / (double)c.dbg[45] * 100.0 : 0.0, c.dbg[46] ? (double)c.dbg[45] / 100.0 / (double)c.dbg[46] : 0.0);
-    fprintf(stderr, "[stream] wave exits per 100 us:");
-    for (int i = 0; i < 32; ++i) fprintf(stderr, " %llu", c.dbg[8 + i]);
-    fprintf(stderr, " | max k (lane 0 sample) %llu parked %llu slow %llu | last publisher off %.1f last scan block off %.1f pubs %u scanblocks %u ranges %u/%u tasks %u/%u\n", c.dbg[40], c.dbg[41], c.slow_solves,
-            ((double)c.dbg[42] - (double)c.dbg[2]) / 100.0, ((double)c.dbg[43] - (double)c.dbg[2]) / 100.0, c.publishers_done, c.scan_blocks_done, c.range_head, c.n_ranges, c.task_head[0], c.n_tasks[0]);
-  }
   if (c.fallback || c.stuck) {
     if (getenv("LENTIL_STREAM_DEBUG"))
-      fprintf(stderr, "[stream] stuck detail: tail %llu head %llu instance %llu block %llu slot-now %016llx | END writer: n %llu count %llu cap %llu\n",
-              c.dbg[32], c.dbg[33], c.dbg[34], c.dbg[35], c.dbg[36], c.dbg[37], c.dbg[38], c.dbg[39]);
-    if (getenv("LENTIL_STREAM_DEBUG"))
-      fprintf(stderr, "[stream] redo: who %u ticket %u saw %016llx epoch %u range_head %u pubs_done %u scan_done %u | fallback %llu stuck %u | items %llu (cap %u) tasks %u (cap %u) pool %llu (cap %llu) ranges %u (cap %u)\n",
-              c.stuck & 3u, c.stuck >> 2, c.dbg[47], ctx->epoch, c.range_head, c.publishers_done, c.scan_blocks_done, c.fallback, c.stuck, c.work_count, pub.item_cap, c.n_tasks[0], pub.task_cap, c.pool_used[0], (unsigned long long)pub.pool_cap,
+      fprintf(stderr, "[stream] redo: who %u ticket %u epoch %u range_head %u pubs_done %u scan_done %u | fallback %llu stuck %u | items %llu (cap %u) tasks %u (cap %u) pool %llu (cap %llu) ranges %u (cap %u)\n",
+              c.stuck & 3u, c.stuck >> 2, ctx->epoch, c.range_head, c.publishers_done, c.scan_blocks_done, c.fallback, c.stuck, c.work_count, pub.item_cap, c.n_tasks[0], pub.task_cap, c.pool_used[0], (unsigned long long)pub.pool_cap,
               c.n_ranges, plan.sa.range_cap);
     if (c.stuck) {
       ++ctx->n_stuck;
@@ -1411,8 +1396,6 @@ LENTIL_API int lentil_hip_redistribute(lentil_hip_ctx *ctx) {
   if (ctx->pass_pending) ctx->dirty_known = false;   // an earlier pass's rows were never asked for: unknown until a full clear
   ctx->pass_pending = true;
   HIP_TRY(ctx, hipMemsetAsync(ctx->d_ctr, 0, sizeof(DevCounters) * (C + 1), ctx->stream));
-  HIP_TRY(ctx, hipMemsetAsync((char *)ctx->d_ctr + offsetof(DevCounters, dbg) + 16, 0xFF, 16, ctx->stream));
-  HIP_TRY(ctx, hipMemsetAsync((char *)ctx->d_ctr + offsetof(DevCounters, dbg) + 40, 0xFF, 16, ctx->stream));
   HIP_TRY(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
   ctx->last_rounds = 0;
   ctx->h_ctr_valid = false;

@@ -45,7 +45,6 @@ struct DevCounters {
   // streamed pass: scan blocks that have published everything they found (solve_po_kernel<.., kStream> polls it)
   unsigned int scan_blocks_done, publishers_done;
   unsigned int n_ranges, range_head;   // work-list ranges the scan has handed to publish_kernel / tickets drawn on them
-  unsigned long long dbg[48];           // LENTIL_STREAM_DEBUG: per solve-kernel instance: solves started, first wave start, first task (100 MHz ticks)
   unsigned int stuck, tile_next;       // a wave gave up waiting for its queue slot (kStuckTicks): the pass is void; scan_dma_kernel's tile cursor
 };
 
@@ -1021,7 +1020,7 @@ __global__ __launch_bounds__(64) void publish_kernel(PublishArgs a) {
             (uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)rec);
       if (((uint32_t)(rec >> 32) >> kTaskTagShift) == a.S.epoch) break;
       if (__builtin_amdgcn_s_memrealtime() - t0 > kStuckTicks) {
-        if (lane == 0) { a.ctr->stuck = 1u | (ticket << 2); a.ctr->dbg[47] = rec; }
+        if (lane == 0) a.ctr->stuck = 1u | (ticket << 2);
         over = true;
         break;
       }
@@ -1045,7 +1044,6 @@ __global__ __launch_bounds__(64) void publish_kernel(PublishArgs a) {
   if (!__builtin_amdgcn_readfirstlane(last)) return;
   // the last publisher: the task queue is complete.  One end marker for every solve wave that may hold a ticket.
   const uint32_t n = ld_coherent32(&a.ctr->n_tasks[0]);
-  if (lane == 0) { a.ctr->dbg[37] = n; a.ctr->dbg[38] = a.end_tasks; a.ctr->dbg[39] = a.S.task_cap; }
   for (uint32_t i = lane; i < a.end_tasks; i += 64u)
     if ((uint64_t)n + i < a.S.task_cap)
       st_agent64(reinterpret_cast<uint64_t *>(a.S.tasks0 + n + i) + 1,
@@ -1287,16 +1285,6 @@ __global__ __launch_bounds__(256) void solve_po_kernel(DrawArgs a) {
   uint32_t ticket = kNoTicket, polls = 0;     // kStream: the queue slot this wave is waiting for
   uint64_t ticket_t0 = 0;
   uint32_t idle_naps = 1u;
-  bool dbg_first = true;
-  uint32_t dbg_maxk = 0, dbg_parked = 0;
-  (void)dbg_maxk; (void)dbg_parked;
-  uint64_t dbg_c0 = 0, dbg_r0 = 0;
-  if constexpr (kStream) {
-    if (lane == 0) atomicMin(&a.ctr->dbg[2 + a.instance * 3], (unsigned long long)__builtin_amdgcn_s_memrealtime());
-    dbg_c0 = __builtin_amdgcn_s_memtime(); dbg_r0 = __builtin_amdgcn_s_memrealtime();
-  }
-  (void)dbg_c0; (void)dbg_r0;
-  (void)dbg_first;
   (void)ticket; (void)polls; (void)ticket_t0; (void)idle_naps;
   // per-lane solve
   bool busy = false, need_init = false;
@@ -1334,12 +1322,7 @@ __global__ __launch_bounds__(256) void solve_po_kernel(DrawArgs a) {
           if ((w1_hi >> kTaskTagShift) != a.epoch) {
             // nothing there (yet): back to the solves in flight (an idle wave naps, below)
             if (__builtin_amdgcn_s_memrealtime() - ticket_t0 > kStuckTicks) {
-              if (lane == 0) {
-                a.ctr->stuck = 2u | (ticket << 2); a.ctr->dbg[47] = w1;
-                a.ctr->dbg[32] = ld_coherent32(&a.ctr->n_tasks[par]); a.ctr->dbg[33] = ld_coherent32(&a.ctr->task_head[par]);
-                a.ctr->dbg[34] = a.instance; a.ctr->dbg[35] = blockIdx.x;
-                a.ctr->dbg[36] = ld_coherent64(reinterpret_cast<const uint64_t *>(tasks + ticket) + 1);
-              }
+              if (lane == 0) a.ctr->stuck = 2u | (ticket << 2);      // the host redoes the pass chunk by chunk
               no_more = true;
             }
             break;
@@ -1364,10 +1347,6 @@ __global__ __launch_bounds__(256) void solve_po_kernel(DrawArgs a) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
-          }
-          if (dbg_first) {
-            dbg_first = false;
-            if (lane == 0) atomicMin(&a.ctr->dbg[3 + a.instance * 3], (unsigned long long)__builtin_amdgcn_s_memrealtime());
           }
           if (cur_left == 0) continue;        // an item that did not fit left empty tasks
         } else {
@@ -1431,7 +1410,6 @@ __global__ __launch_bounds__(256) void solve_po_kernel(DrawArgs a) {
     if (busy && !newton_continue(s)) {
       res[res_idx] = solve_result(P, L, s);
       busy = false;
-      if (kStream) { const uint32_t kk = (uint32_t)__builtin_amdgcn_readfirstlane(s.k); dbg_maxk = kk > dbg_maxk ? kk : dbg_maxk; }
     }
     // Stragglers: about one solve in a thousand is still running after slow_at iterations and may need all 100.
     // Park its loop state for solve_slow_kernel (a whole wave per solve, ~4x less time per iteration) instead of
@@ -1456,7 +1434,6 @@ __global__ __launch_bounds__(256) void solve_po_kernel(DrawArgs a) {
           uint32_t *u = reinterpret_cast<uint32_t *>(d + 11);
           u[0] = (uint32_t)s.k; u[1] = (uint32_t)s.error; u[2] = res_idx; u[3] = kChroma ? cur_chan_lane : 0u;
           busy = false;
-          ++dbg_parked;
         }
       }
     }
@@ -1470,22 +1447,6 @@ __global__ __launch_bounds__(256) void solve_po_kernel(DrawArgs a) {
   if (lane == 0) {
     if (it64) atomicAdd(&a.ctr->newton_iters, it64);
     if (tr64) atomicAdd(&a.ctr->tries, tr64);
-    if (kStream && tr64) atomicAdd(&a.ctr->dbg[1 + a.instance * 3], tr64);
-    if (kStream) {
-      const unsigned long long now = __builtin_amdgcn_s_memrealtime();
-      atomicMax(&a.ctr->dbg[0], now);
-      const unsigned long long t0 = a.ctr->dbg[2];
-      unsigned long long b = now > t0 ? (now - t0) / 10000ull : 0ull;      // 100 us buckets
-      if (b > 31ull) b = 31ull;
-      atomicAdd(&a.ctr->dbg[8 + b], 1ull);
-      atomicMax(&a.ctr->dbg[40], (unsigned long long)dbg_maxk);
-      if (a.instance == 0) {
-        atomicAdd(&a.ctr->dbg[44], (unsigned long long)(__builtin_amdgcn_s_memtime() - dbg_c0));
-        atomicAdd(&a.ctr->dbg[45], (unsigned long long)(now - dbg_r0));
-        atomicAdd(&a.ctr->dbg[46], (unsigned long long)st_rounds);
-      }
-      atomicAdd(&a.ctr->dbg[41], (unsigned long long)dbg_parked);
-    }
     if (rd64) atomicAdd(&a.ctr->lane_rounds, rd64);
   }
 }
