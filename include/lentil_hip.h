@@ -258,6 +258,13 @@ int lentil_hip_lens_is_compiled(lentil_hip_ctx *ctx);
 int lentil_hip_set_lens_mode(lentil_hip_ctx *ctx, int mode);
 int lentil_hip_alloc_frame(lentil_hip_ctx *ctx, uint32_t n_aovs, const uint8_t *aov_filter_kind);
 
+/* Camera::logarithmic_focus_search (src/lentil.h:1445-1460; called per camera update at :1632): the sensor
+ * shift, among the 20 001 candidates of logarithmic_values() (src/lens.h:395-407), whose axial ray crosses
+ * the optical axis closest in front of focal_distance (mm).  One GPU lane per candidate instead of the
+ * reference's sequential loop; the winner is the one that loop keeps (first smallest positive miss).
+ * Uses the table of set_lens; lambda in micrometres. */
+int lentil_hip_focus_search(lentil_hip_ctx *ctx, double focal_distance, double lambda, double *best_sensor_shift);
+
 /* --- visit stream ------------------------------------------------------------------
  * upload_visits: host columns -> library-owned device memory (what the capturing
  *                filter_pixel hands over once per frame).
@@ -411,7 +418,13 @@ int lentil_hip_download_draw_log(lentil_hip_ctx *ctx, lentil_draw_record *out, u
  * trace_bw_po: Camera::trace_ray_bw_po (src/lentil.h:573-661) for target[n][3]
  *    (already -P_cs*10), px[n], py[n], attempt[n] -> sensor_xy[n][2], ok[n]
  * aperture_sample: the aperture draw of trace_ray_bw_po (src/lentil.h:596-609) for
- *    seed pairs (a[n] = px*py+px, b[n] = total_samples_taken+tries) -> xy[n][2] */
+ *    seed pairs (a[n] = px*py+px, b[n] = total_samples_taken+tries) -> xy[n][2]
+ * y0_intersection: Camera::camera_get_y0_intersection_distance (src/lentil.h:1361-1386) for
+ *    sensor_shift[n] -> distance[n], and what lens_pt_sample_aperture / lens_evaluate (:1257-1291)
+ *    left on the way: sensor[n][5] (x, y, dx, dy, lambda), out[n][5] (x, y, dx, dy, transmittance);
+ *    sensor / out may be NULL */
+int lentil_hip_test_y0_intersection(lentil_hip_ctx *ctx, uint64_t n, const double *sensor_shift, double lambda,
+                                    double *distance, double *sensor, double *out);
 int lentil_hip_test_lt_sample_aperture(lentil_hip_ctx *ctx, uint64_t n, const double *scene,
                                        const double *ap, double lambda, double *sensor,
                                        double *out, double *transmittance);

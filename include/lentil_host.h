@@ -55,6 +55,14 @@ int lentil_host_trace_ray_focus_check(const lentil_host_lens *lens, double senso
  * tan_fov; lens may be NULL for the thin lens.  Returns 0, or -1 on invalid arguments. */
 int lentil_host_camera_model_specific_setup(lentil_params *params, const lentil_host_lens *lens, double input_fstop,
                                             double wavelength_nm, double extra_sensor_shift, double *tan_fov);
+/* The same with the focus search (src/lentil.h:1632: 20 001 candidate sensor shifts, two polynomial solves each)
+ * delegated: focus_search(user, focal_distance_mm, lambda_um, &shift) returns 0 and the shift of
+ * Camera::logarithmic_focus_search -- lentil_hip_focus_search does, one GPU lane per candidate; NULL or a
+ * non-zero return runs the sequential loop of lentil_host_logarithmic_focus_search. */
+typedef int (*lentil_focus_search_fn)(void *user, double focal_distance, double lambda, double *best_sensor_shift);
+int lentil_host_camera_model_specific_setup_with(lentil_params *params, const lentil_host_lens *lens, double input_fstop,
+                                                 double wavelength_nm, double extra_sensor_shift, double *tan_fov,
+                                                 lentil_focus_search_fn focus_search, void *user);
 
 /* Forward camera rays: Camera::trace_ray_fw_po / trace_ray_fw_thinlens (src/lentil.h:283-569).
  * rng: the xor128 state (src/global.h:22-27; the reference keeps it in function statics -- pass

@@ -26,6 +26,7 @@ EXPORTS = [
     "lentil_hip_download_draw_log", "lentil_hip_test_lt_sample_aperture",
     "lentil_hip_test_trace_bw_po", "lentil_hip_test_aperture_sample",
     "lentil_hip_lens_is_compiled", "lentil_hip_set_lens_mode",
+    "lentil_hip_focus_search", "lentil_hip_test_y0_intersection",
     "lentil_hip_host_alloc", "lentil_hip_host_free", "lentil_hip_visits_begin", "lentil_hip_visits_append",
     "lentil_hip_visits_wait", "lentil_hip_visits_end",
     "lentil_hip_comm_unique_id", "lentil_hip_comm_init", "lentil_hip_comm_destroy", "lentil_hip_allreduce",
@@ -99,6 +100,8 @@ def load_library():
         "lentil_hip_test_aperture_sample": (i, [vp, u64, vp, vp, vp]),
         "lentil_hip_lens_is_compiled": (i, [vp]),
         "lentil_hip_set_lens_mode": (i, [vp, i]),
+        "lentil_hip_focus_search": (i, [vp, C.c_double, C.c_double, C.POINTER(C.c_double)]),
+        "lentil_hip_test_y0_intersection": (i, [vp, u64, vp, C.c_double, vp, vp, vp]),
         "lentil_hip_host_alloc": (i, [C.POINTER(vp), u64]),
         "lentil_hip_host_free": (i, [vp]),
         "lentil_hip_visits_begin": (i, [vp, C.POINTER(_abi.Visits), u64]),
@@ -274,6 +277,20 @@ class Context:
 
     def closest_gather(self):
         self._chk(self.lib.lentil_hip_closest_gather(self.h))
+
+    def focus_search(self, focal_distance, lam):
+        best = C.c_double()
+        self._chk(self.lib.lentil_hip_focus_search(self.h, focal_distance, lam, C.byref(best)))
+        return best.value
+
+    def test_y0_intersection(self, sensor_shift, lam):
+        import numpy as np
+        sh = np.ascontiguousarray(sensor_shift, np.float64)
+        n = sh.shape[0]
+        dist, sensor, out = np.empty(n), np.empty((n, 5)), np.empty((n, 5))
+        self._chk(self.lib.lentil_hip_test_y0_intersection(self.h, n, sh.ctypes.data, lam, dist.ctypes.data,
+                                                           sensor.ctypes.data, out.ctypes.data))
+        return dist, sensor, out
 
     # --- the visit stream handed over piece by piece (include/lentil_hip.h "piece by piece")
     def visits_begin(self, layout, capacity_hint=0):

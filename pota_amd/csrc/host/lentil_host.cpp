@@ -338,6 +338,12 @@ HOST_API int lentil_host_trace_ray_focus_check(const lentil_host_lens *L, double
 
 HOST_API int lentil_host_camera_model_specific_setup(lentil_params *p, const lentil_host_lens *L, double input_fstop,
                                                      double wavelength_nm, double extra_sensor_shift, double *tan_fov) {
+  return lentil_host_camera_model_specific_setup_with(p, L, input_fstop, wavelength_nm, extra_sensor_shift, tan_fov, nullptr, nullptr);
+}
+
+HOST_API int lentil_host_camera_model_specific_setup_with(lentil_params *p, const lentil_host_lens *L, double input_fstop,
+                                                          double wavelength_nm, double extra_sensor_shift, double *tan_fov,
+                                                          lentil_focus_search_fn focus_search, void *user) {
   if (!p) return -1;
   if (p->cameraType == LENTIL_POLYNOMIAL_OPTICS) {
     if (!L) return -1;
@@ -351,7 +357,11 @@ HOST_API int lentil_host_camera_model_specific_setup(lentil_params *p, const len
       lentil_host_trace_backwards_for_fstop(L, input_fstop, lambda, &f, &r);
       p->aperture_radius = std::min(k.lens_aperture_radius_at_fstop, r); // :1614
     }
-    p->sensor_shift = lentil_host_logarithmic_focus_search(L, p->focus_distance, lambda) + (double)(float)extra_sensor_shift;
+    double best_shift = 0.0;
+    // the 20 001-candidate search: the caller's accelerated version (lentil_hip_focus_search), or the loop here
+    if (!focus_search || focus_search(user, p->focus_distance, lambda, &best_shift) != 0)
+      best_shift = lentil_host_logarithmic_focus_search(L, p->focus_distance, lambda);
+    p->sensor_shift = best_shift + (double)(float)extra_sensor_shift;
     if (tan_fov) *tan_fov = std::tan(k.lens_field_of_view / 2.0);        // :1658
   } else {
     const float fov = 2.0 * std::atan(p->sensor_width / (2.0 * p->focal_length));   // :1665

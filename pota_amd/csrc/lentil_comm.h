@@ -149,10 +149,13 @@ LENTIL_API int lentil_hip_allreduce(lentil_hip_ctx *ctx) {
   int rc;
   if ((rc = fold_direct(ctx, 0, ctx->F.np, true))) return rc;        // what the scan kept apart joins the sum
   untrust_touched(ctx);
-  if (ctx->F.zkey) {
+  if (ctx->F.zkey || ctx->F.zkey_dbg) {
     if (!ctx->closest_deferred)
       return fail(ctx, LENTIL_ERR_INVALID, "closest-filtered AOVs: lentil_hip_set_closest_exchange(ctx, 1, ...) before the pass");
-    RCCL_TRY(ctx, g_rccl.AllReduce(ctx->F.zkey, ctx->F.zkey, ctx->F.np, kNcclUint64, kNcclMin, cm->comm, ctx->stream));
+    if (ctx->F.zkey)
+      RCCL_TRY(ctx, g_rccl.AllReduce(ctx->F.zkey, ctx->F.zkey, ctx->F.np, kNcclUint64, kNcclMin, cm->comm, ctx->stream));
+    if (ctx->F.zkey_dbg)       // lentil_debug: a key plane of its own (src/lentil.h:838-845)
+      RCCL_TRY(ctx, g_rccl.AllReduce(ctx->F.zkey_dbg, ctx->F.zkey_dbg, ctx->F.np, kNcclUint64, kNcclMin, cm->comm, ctx->stream));
     if ((rc = lentil_hip_closest_gather(ctx))) return rc;
   }
   RCCL_TRY(ctx, g_rccl.AllReduce(ctx->F.acc, ctx->F.acc, ctx->F.np * ctx->F.stride, kNcclFloat32, kNcclSum, cm->comm, ctx->stream));
@@ -183,12 +186,12 @@ LENTIL_API int lentil_hip_exchange_bands(lentil_hip_ctx *ctx, const int32_t *bou
   int32_t lo = 0, hi = 0;
   if ((rc = lentil_hip_touched_rows(ctx, &lo, &hi))) return rc;
   const uint32_t used = 4u * ctx->F.n_aovs + 1u;
-  const bool keys = ctx->F.zkey != nullptr;
-  if (keys && ctx->closest_deferred)
+  const bool keys = ctx->F.zkey != nullptr, dkeys = ctx->F.zkey_dbg != nullptr;
+  if ((keys || dkeys) && ctx->closest_deferred)
     return fail(ctx, LENTIL_ERR_INVALID, "tiled exchange: the pass must gather its own winners (set_closest_exchange(ctx, 0, ...))");
 
   // ---- what this rank added to every other band, and the form it will travel in
-  struct Out { int form = 0; int32_t s_lo = 0, s_hi = 0; uint32_t *idx = nullptr; float *vals = nullptr; unsigned long long *k = nullptr; float *packed = nullptr; };
+  struct Out { int form = 0; int32_t s_lo = 0, s_hi = 0; uint32_t *idx = nullptr; float *vals = nullptr; unsigned long long *k = nullptr, *kd = nullptr; float *packed = nullptr; };
   std::vector<Out> out((size_t)world);
   std::vector<int64_t> mine((size_t)(2 + world), 0);
   mine[0] = lo; mine[1] = hi;
@@ -205,18 +208,19 @@ LENTIL_API int lentil_hip_exchange_bands(lentil_hip_ctx *ctx, const int32_t *bou
     if (sparse) {
       const uint32_t cap = (uint32_t)(n_pix / 4 > 1024 ? n_pix / 4 : 1024);
       void *p;
-      if ((rc = comm_scratch(ctx, cm, (size_t)q * 8 + 0, (size_t)cap * 4, &p))) return rc;
+      if ((rc = comm_scratch(ctx, cm, (size_t)q * 12 + 0, (size_t)cap * 4, &p))) return rc;
       o.idx = (uint32_t *)p;
-      if ((rc = comm_scratch(ctx, cm, (size_t)q * 8 + 1, (size_t)cap * used * 4, &p))) return rc;
+      if ((rc = comm_scratch(ctx, cm, (size_t)q * 12 + 1, (size_t)cap * used * 4, &p))) return rc;
       o.vals = (float *)p;
-      if (keys) { if ((rc = comm_scratch(ctx, cm, (size_t)q * 8 + 2, (size_t)cap * 8, &p))) return rc; o.k = (unsigned long long *)p; }
+      if (keys) { if ((rc = comm_scratch(ctx, cm, (size_t)q * 12 + 2, (size_t)cap * 8, &p))) return rc; o.k = (unsigned long long *)p; }
+      if (dkeys) { if ((rc = comm_scratch(ctx, cm, (size_t)q * 12 + 8, (size_t)cap * 8, &p))) return rc; o.kd = (unsigned long long *)p; }
       uint32_t n = 0;
-      if ((rc = lentil_hip_compact_rows(ctx, (uint32_t)o.s_lo, (uint32_t)(o.s_hi - o.s_lo), o.idx, o.vals, o.k, cap, &n))) return rc;
+      if ((rc = compact_rows_impl(ctx, (uint32_t)o.s_lo, (uint32_t)(o.s_hi - o.s_lo), o.idx, o.vals, o.k, o.kd, cap, &n))) return rc;
       if (n <= cap) o.form = (int)n;
     }
     if (o.form < 0) {
       void *p;
-      if ((rc = comm_scratch(ctx, cm, (size_t)q * 8 + 3, (size_t)n_pix * used * 4, &p))) return rc;
+      if ((rc = comm_scratch(ctx, cm, (size_t)q * 12 + 3, (size_t)n_pix * used * 4, &p))) return rc;
       o.packed = (float *)p;
       if ((rc = lentil_hip_pack_rows(ctx, (uint32_t)o.s_lo, (uint32_t)(o.s_hi - o.s_lo), o.packed))) return rc;
     }
@@ -229,7 +233,7 @@ LENTIL_API int lentil_hip_exchange_bands(lentil_hip_ctx *ctx, const int32_t *bou
   HIP_TRY(ctx, hipMemcpyAsync(cm->h_meta_all, cm->d_meta_all, m * (size_t)world * sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   // ---- receive buffers from what the others announced
-  struct In { int form = 0; int32_t r_lo = 0, r_hi = 0; uint32_t *idx = nullptr; float *vals = nullptr; unsigned long long *k = nullptr; float *packed = nullptr; unsigned long long *key_rows = nullptr; };
+  struct In { int form = 0; int32_t r_lo = 0, r_hi = 0; uint32_t *idx = nullptr; float *vals = nullptr; unsigned long long *k = nullptr, *kd = nullptr; float *packed = nullptr; unsigned long long *key_rows = nullptr, *dkey_rows = nullptr; };
   std::vector<In> in((size_t)world);
   for (int q = 0; q < world; ++q) {
     if (q == rank) continue;
@@ -241,16 +245,18 @@ LENTIL_API int lentil_hip_exchange_bands(lentil_hip_ctx *ctx, const int32_t *bou
     if (i.r_hi <= i.r_lo || i.form == 0) { i.form = 0; continue; }
     void *p;
     if (i.form > 0) {
-      if ((rc = comm_scratch(ctx, cm, (size_t)q * 8 + 4, (size_t)i.form * 4, &p))) return rc;
+      if ((rc = comm_scratch(ctx, cm, (size_t)q * 12 + 4, (size_t)i.form * 4, &p))) return rc;
       i.idx = (uint32_t *)p;
-      if ((rc = comm_scratch(ctx, cm, (size_t)q * 8 + 5, (size_t)i.form * used * 4, &p))) return rc;
+      if ((rc = comm_scratch(ctx, cm, (size_t)q * 12 + 5, (size_t)i.form * used * 4, &p))) return rc;
       i.vals = (float *)p;
-      if (keys) { if ((rc = comm_scratch(ctx, cm, (size_t)q * 8 + 6, (size_t)i.form * 8, &p))) return rc; i.k = (unsigned long long *)p; }
+      if (keys) { if ((rc = comm_scratch(ctx, cm, (size_t)q * 12 + 6, (size_t)i.form * 8, &p))) return rc; i.k = (unsigned long long *)p; }
+      if (dkeys) { if ((rc = comm_scratch(ctx, cm, (size_t)q * 12 + 9, (size_t)i.form * 8, &p))) return rc; i.kd = (unsigned long long *)p; }
     } else {
       const uint64_t n_pix = (uint64_t)(i.r_hi - i.r_lo) * xres;
-      if ((rc = comm_scratch(ctx, cm, (size_t)q * 8 + 5, (size_t)n_pix * used * 4, &p))) return rc;
+      if ((rc = comm_scratch(ctx, cm, (size_t)q * 12 + 5, (size_t)n_pix * used * 4, &p))) return rc;
       i.packed = (float *)p;
-      if (keys) { if ((rc = comm_scratch(ctx, cm, (size_t)q * 8 + 6, (size_t)n_pix * 8, &p))) return rc; i.key_rows = (unsigned long long *)p; }
+      if (keys) { if ((rc = comm_scratch(ctx, cm, (size_t)q * 12 + 6, (size_t)n_pix * 8, &p))) return rc; i.key_rows = (unsigned long long *)p; }
+      if (dkeys) { if ((rc = comm_scratch(ctx, cm, (size_t)q * 12 + 9, (size_t)n_pix * 8, &p))) return rc; i.dkey_rows = (unsigned long long *)p; }
     }
   }
   // ---- the exchange itself: every send has its receive on the other side, in the same order per pair
@@ -262,20 +268,24 @@ LENTIL_API int lentil_hip_exchange_bands(lentil_hip_ctx *ctx, const int32_t *bou
       RCCL_TRY(ctx, g_rccl.Send(o.idx, (size_t)o.form * 4, kNcclUint8, q, cm->comm, ctx->stream));
       RCCL_TRY(ctx, g_rccl.Send(o.vals, (size_t)o.form * used, kNcclFloat32, q, cm->comm, ctx->stream));
       if (keys) RCCL_TRY(ctx, g_rccl.Send(o.k, (size_t)o.form, kNcclUint64, q, cm->comm, ctx->stream));
+      if (dkeys) RCCL_TRY(ctx, g_rccl.Send(o.kd, (size_t)o.form, kNcclUint64, q, cm->comm, ctx->stream));
     } else if (o.form < 0) {
       const uint64_t n_pix = (uint64_t)(o.s_hi - o.s_lo) * xres;
       RCCL_TRY(ctx, g_rccl.Send(o.packed, (size_t)n_pix * used, kNcclFloat32, q, cm->comm, ctx->stream));
       if (keys) RCCL_TRY(ctx, g_rccl.Send(ctx->F.zkey + (uint64_t)o.s_lo * xres, (size_t)n_pix, kNcclUint64, q, cm->comm, ctx->stream));
+      if (dkeys) RCCL_TRY(ctx, g_rccl.Send(ctx->F.zkey_dbg + (uint64_t)o.s_lo * xres, (size_t)n_pix, kNcclUint64, q, cm->comm, ctx->stream));
     }
     const In &i = in[(size_t)q];
     if (i.form > 0) {
       RCCL_TRY(ctx, g_rccl.Recv(i.idx, (size_t)i.form * 4, kNcclUint8, q, cm->comm, ctx->stream));
       RCCL_TRY(ctx, g_rccl.Recv(i.vals, (size_t)i.form * used, kNcclFloat32, q, cm->comm, ctx->stream));
       if (keys) RCCL_TRY(ctx, g_rccl.Recv(i.k, (size_t)i.form, kNcclUint64, q, cm->comm, ctx->stream));
+      if (dkeys) RCCL_TRY(ctx, g_rccl.Recv(i.kd, (size_t)i.form, kNcclUint64, q, cm->comm, ctx->stream));
     } else if (i.form < 0) {
       const uint64_t n_pix = (uint64_t)(i.r_hi - i.r_lo) * xres;
       RCCL_TRY(ctx, g_rccl.Recv(i.packed, (size_t)n_pix * used, kNcclFloat32, q, cm->comm, ctx->stream));
       if (keys) RCCL_TRY(ctx, g_rccl.Recv(i.key_rows, (size_t)n_pix, kNcclUint64, q, cm->comm, ctx->stream));
+      if (dkeys) RCCL_TRY(ctx, g_rccl.Recv(i.dkey_rows, (size_t)n_pix, kNcclUint64, q, cm->comm, ctx->stream));
     }
   }
   RCCL_TRY(ctx, g_rccl.GroupEnd());
@@ -283,9 +293,9 @@ LENTIL_API int lentil_hip_exchange_bands(lentil_hip_ctx *ctx, const int32_t *bou
   for (int q = 0; q < world; ++q) {
     const In &i = in[(size_t)q];
     if (i.form > 0) {
-      if ((rc = lentil_hip_merge_sparse(ctx, (uint32_t)i.r_lo, (uint32_t)(i.r_hi - i.r_lo), (uint32_t)i.form, i.idx, i.vals, i.k))) return rc;
+      if ((rc = merge_sparse_impl(ctx, (uint32_t)i.r_lo, (uint32_t)(i.r_hi - i.r_lo), (uint32_t)i.form, i.idx, i.vals, i.k, i.kd))) return rc;
     } else if (i.form < 0) {
-      if ((rc = lentil_hip_merge_packed_rows(ctx, (uint32_t)i.r_lo, (uint32_t)(i.r_hi - i.r_lo), i.packed, i.key_rows))) return rc;
+      if ((rc = merge_rows_impl(ctx, (uint32_t)i.r_lo, (uint32_t)(i.r_hi - i.r_lo), i.packed, i.key_rows, i.dkey_rows, true))) return rc;
     }
   }
   return lentil_hip_resolve_rows(ctx, (uint32_t)b_lo, (uint32_t)(b_hi - b_lo));

@@ -21,7 +21,7 @@ constexpr float kAiInfinite = 1.0e30f;
 constexpr double kPi = 3.14159265358979323846;
 
 // ---------------------------------------------------------------------------------------
-// Device-side lens table.  17 polynomials: out[5], ap[4], d ap_{x,y}/d{dx,dy}, d out_{dx,dy}/d{x,y}.
+// Device-side lens table.  21 polynomials: out[5], ap[4], d ap_{x,y}/d{dx,dy}, d out_{dx,dy}/d{x,y}, d ap_{x,y}/d{x,y}.
 // A term packs its five exponents in 4 bits each (x | y<<4 | dx<<8 | dy<<12 | lambda<<16).
 // ---------------------------------------------------------------------------------------
 enum PolyId {
@@ -29,6 +29,7 @@ enum PolyId {
   P_AP_X, P_AP_Y, P_AP_DX, P_AP_DY,
   P_DAP_00, P_DAP_01, P_DAP_10, P_DAP_11,      // d ap_x/d dx, d ap_x/d dy, d ap_y/d dx, d ap_y/d dy
   P_DOUT_00, P_DOUT_01, P_DOUT_10, P_DOUT_11,  // d out_dx/d x, d out_dx/d y, d out_dy/d x, d out_dy/d y
+  P_DAPPOS_00, P_DAPPOS_01, P_DAPPOS_10, P_DAPPOS_11,   // d ap_x/d x, d ap_x/d y, d ap_y/d x, d ap_y/d y (lens_pt_sample_aperture only)
   P_COUNT
 };
 
@@ -401,6 +402,71 @@ LD_DEV void newton_iter(const Lens &L, const double scene[3], double ap_x, doubl
   if (s.k < 10) error = 0;
   s.error = error;
   s.k += 1;
+}
+
+// ---------------------------------------------------------------------------------------
+// a13 -- Camera::lens_evaluate (src/lentil.h:1257-1266) and Camera::lens_pt_sample_aperture (:1272-1291; body as the
+// polynomial-optics generator emits it: at most 5 Newton steps on the direction at the sensor, tolerance 1e-4, the
+// Jacobian with the dist * d/dpos chain term of the shifted start point), and on top of them
+// Camera::camera_get_y0_intersection_distance (:1361-1386) -- what the focus search evaluates per candidate.
+// Table interpreter only (a camera update runs them 20 001 times, not per draw).
+// ---------------------------------------------------------------------------------------
+LD_DEV double lens_evaluate(const LdsLens &L, const double in[4], double out[4]) {
+  out[0] = L.eval(P_OUT_X, in); out[1] = L.eval(P_OUT_Y, in);
+  out[2] = L.eval(P_OUT_DX, in); out[3] = L.eval(P_OUT_DY, in);
+  return fmax(0.0, L.eval(P_OUT_T, in));
+}
+
+// in: x, y, dx, dy at the sensor (dx, dy solved for); ap_x, ap_y: the aperture point to hit; out_dx/out_dy: the
+// direction predicted at the aperture
+LD_DEV void lens_pt_sample_aperture(const LdsLens &L, double in[4], double ap_x, double ap_y, double dist,
+                                    double &out_dx, double &out_dy) {
+  double dx = in[2], dy = in[3];
+  double pred_dx = 0.0, pred_dy = 0.0;
+  double sqr_err = 3.4028234663852886e38;
+  for (int k = 0; k < 5 && sqr_err > 1e-4; ++k) {
+    const double begin[4] = {in[0] + dist * dx, in[1] + dist * dy, dx, dy};
+    const double pred_x = L.eval(P_AP_X, begin), pred_y = L.eval(P_AP_Y, begin);
+    pred_dx = L.eval(P_AP_DX, begin);
+    pred_dy = L.eval(P_AP_DY, begin);
+    const double j00 = L.eval(P_DAP_00, begin) + dist * L.eval(P_DAPPOS_00, begin);
+    const double j01 = L.eval(P_DAP_01, begin) + dist * L.eval(P_DAPPOS_01, begin);
+    const double j10 = L.eval(P_DAP_10, begin) + dist * L.eval(P_DAPPOS_10, begin);
+    const double j11 = L.eval(P_DAP_11, begin) + dist * L.eval(P_DAPPOS_11, begin);
+    const double invdet = 1.0 / (j00 * j11 - j01 * j10);
+    const double i00 = j11 * invdet, i11 = j00 * invdet, i01 = -j01 * invdet, i10 = -j10 * invdet;
+    const double r0 = ap_x - pred_x, r1 = ap_y - pred_y;
+    dx += i00 * r0; dy += i10 * r0;
+    dx += i01 * r1; dy += i11 * r1;
+    sqr_err = r0 * r0 + r1 * r1;
+  }
+  out_dx = pred_dx; out_dy = pred_dy;
+  in[2] = dx; in[3] = dy;
+}
+
+// line_plane_intersection with the y = 0 plane (src/lens.h:412-419), z component: the direction is normalised
+// (Eigen: v / norm), scaled by (0 - origin.y), then divided by its y component
+LD_DEV double y0_plane_z(const double pos[3], const double dir[3]) {
+  const double n = sqrt(dir[0] * dir[0] + dir[1] * dir[1] + dir[2] * dir[2]);
+  const double dy = dir[1] / n, dz = dir[2] / n;
+  return pos[2] + (dz * (0.0 - pos[1])) / dy;
+}
+
+LD_DEV double camera_get_y0_intersection_distance(const LdsLens &L, double sensor_shift, double aperture_housing_radius,
+                                                  double sensor_out[4], double out[4], double &transmittance) {
+  const DevLens &k = L.consts();
+  double sensor[4] = {0.0, 0.0, 0.0, 0.0};
+  double adx, ady;
+  lens_pt_sample_aperture(L, sensor, 0.0, aperture_housing_radius * 0.25, sensor_shift, adx, ady);
+  sensor[0] += sensor[2] * sensor_shift;
+  sensor[1] += sensor[3] * sensor_shift;
+  transmittance = lens_evaluate(L, sensor, out);
+  for (int c = 0; c < 4; ++c) sensor_out[c] = sensor[c];
+  const double R = k.outer_pupil_curvature_radius;
+  double pos[3], dir[3];
+  if (k.outer_pupil_geometry == LENTIL_GEOM_SPHERICAL) sphereToCs(out[0], out[1], out[2], out[3], pos, dir, -R, R);
+  else cylinderToCs(out[0], out[1], out[2], out[3], pos, dir, -R, R, k.outer_pupil_geometry == LENTIL_GEOM_CYL_Y);
+  return y0_plane_z(pos, dir);
 }
 
 // after the loop: outer-pupil radius test + transmittance (0 on error); returns max(0, T)

@@ -137,6 +137,7 @@ struct lentil_hip_ctx {
   lentil_draw_record *d_log = nullptr;
   uint64_t log_cap = 0;
   bool timed_draw = false, timed_resolve = false;
+  double lens_housing_radius = 0.0;  // lens_aperture_housing_radius of the current table (focus search)
   struct LentilUpload *upload = nullptr;   // lentil_upload.h: the visit stream handed over piece by piece
   struct LentilComm *comm = nullptr; // lentil_comm.h: this context's RCCL communicator, if one was asked for
 };
@@ -402,6 +403,9 @@ LENTIL_API int lentil_hip_set_lens(lentil_hip_ctx *ctx, const lentil_lens_table 
       ok &= pack_terms(t, t->ap[i], 2 + j, terms, h.first[P_DAP_00 + i * 2 + j], h.count[P_DAP_00 + i * 2 + j]);
       ok &= pack_terms(t, t->out[2 + i], j, terms, h.first[P_DOUT_00 + i * 2 + j], h.count[P_DOUT_00 + i * 2 + j]);
     }
+  for (int i = 0; i < 2; ++i)       // behind everything the draw kernels use
+    for (int j = 0; j < 2; ++j)
+      ok &= pack_terms(t, t->ap[i], j, terms, h.first[P_DAPPOS_00 + i * 2 + j], h.count[P_DAPPOS_00 + i * 2 + j]);
   if (!ok) return fail(ctx, LENTIL_ERR_UNSUPPORTED, "lens table exponent > 15");
   if (terms.size() > (size_t)kMaxTerms)
     return fail(ctx, LENTIL_ERR_UNSUPPORTED, "lens table has too many terms for the LDS staging area");
@@ -411,6 +415,7 @@ LENTIL_API int lentil_hip_set_lens(lentil_hip_ctx *ctx, const lentil_lens_table 
   h.back_focal_length = t->lens_back_focal_length;
   h.outer_pupil_curvature_radius = t->lens_outer_pupil_curvature_radius;
   h.outer_pupil_geometry = t->lens_outer_pupil_geometry;
+  ctx->lens_housing_radius = t->lens_aperture_housing_radius;
   h.n_terms = (uint32_t)terms.size();
   {  // FNV-1a over the base table (tools/gen_lens_code.py: table_hash) -> compiled-in specialisation
     unsigned long long hs = 0xCBF29CE484222325ull;
@@ -1389,8 +1394,8 @@ LENTIL_API int lentil_hip_redistribute(lentil_hip_ctx *ctx) {
   for (uint32_t k = 1; k < ctx->F.n_aovs; ++k)
     if (ctx->V.n && !ctx->V.extra[k - 1] && !(ctx->F.debug_mask & (1u << k)))
       return fail(ctx, LENTIL_ERR_INVALID, "an extra AOV column is null");
-  if (ctx->F.debug_mask && ctx->closest_deferred)
-    return fail(ctx, LENTIL_ERR_UNSUPPORTED, "the lentil_debug AOV is not exchanged between GPUs");
+  if (ctx->F.debug_mask && ctx->closest_deferred && !ctx->comm)
+    return fail(ctx, LENTIL_ERR_UNSUPPORTED, "the lentil_debug AOV is exchanged between GPUs by lentil_hip_allreduce / _exchange_bands only");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   const int C = ctx->n_chunks;
   if (ctx->pass_pending) ctx->dirty_known = false;   // an earlier pass's rows were never asked for: unknown until a full clear
@@ -1549,7 +1554,7 @@ LENTIL_API int lentil_hip_redistribute(lentil_hip_ctx *ctx) {
       if (all) { ctx->have_total_est = true; ctx->est_items_total = items; ctx->est_sum_total = sum; ctx->est_rounds_total = rounds; }
     }
   }
-  if (ctx->F.zkey_dbg && ctx->V.n) {
+  if (ctx->F.zkey_dbg && ctx->V.n && !ctx->closest_deferred) {
     hipLaunchKernelGGL(debug_gather_kernel, dim3((unsigned)ctx->num_cu * 8), dim3(256), 0, ctx->stream, ctx->F, ctx->V, P,
                        ctx->have_lens ? ctx->hlens.length : 0.0);
     HIP_TRY(ctx, hipGetLastError());
@@ -1598,10 +1603,17 @@ LENTIL_API int lentil_hip_zkey_buffer(lentil_hip_ctx *ctx, void **device_ptr, ui
 LENTIL_API int lentil_hip_closest_gather(lentil_hip_ctx *ctx) {
   CHECK_CTX(ctx);
   if (!ctx->have_frame) return fail(ctx, LENTIL_ERR_INVALID, "no frame allocated");
-  if (!ctx->F.zkey || !ctx->V.n) return LENTIL_OK;
+  if (!ctx->V.n) return LENTIL_OK;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
-  hipLaunchKernelGGL(closest_gather_kernel, dim3((unsigned)ctx->num_cu * 8), dim3(256), 0, ctx->stream, ctx->F, ctx->V);
-  HIP_TRY(ctx, hipGetLastError());
+  if (ctx->F.zkey) {
+    hipLaunchKernelGGL(closest_gather_kernel, dim3((unsigned)ctx->num_cu * 8), dim3(256), 0, ctx->stream, ctx->F, ctx->V);
+    HIP_TRY(ctx, hipGetLastError());
+  }
+  if (ctx->F.zkey_dbg) {      // lentil_debug: its own key plane (min-reduced by lentil_hip_allreduce), value from the winner's columns
+    hipLaunchKernelGGL(debug_gather_kernel, dim3((unsigned)ctx->num_cu * 8), dim3(256), 0, ctx->stream, ctx->F, ctx->V, ctx->P,
+                       ctx->have_lens ? ctx->hlens.length : 0.0);
+    HIP_TRY(ctx, hipGetLastError());
+  }
   return LENTIL_OK;
 }
 
@@ -1659,10 +1671,26 @@ LENTIL_API int lentil_hip_pack_rows(lentil_hip_ctx *ctx, uint32_t row_begin, uin
 }
 
 static int merge_rows_impl(lentil_hip_ctx *ctx, uint32_t row_begin, uint32_t n_rows, const void *dev_acc_rows,
-                           const void *dev_key_rows, bool packed);
+                           const void *dev_key_rows, const void *dev_key_rows_dbg, bool packed);
+
+// The public entry points of the tiled exchange carry one key plane; frames with a lentil_debug AOV have two, and only
+// the library's own exchange (lentil_comm.h) passes the second
+#define LENTIL_NO_DEBUG_AOV(ctx)                                                                                          \
+  if ((ctx)->F.debug_mask)                                                                                                \
+  return fail(ctx, LENTIL_ERR_UNSUPPORTED, "frames with a lentil_debug AOV are exchanged by lentil_hip_exchange_bands / _allreduce only")
+
+static int compact_rows_impl(lentil_hip_ctx *ctx, uint32_t row_begin, uint32_t n_rows, void *dev_idx, void *dev_vals,
+                             void *dev_keys, void *dev_keys_dbg, uint32_t capacity, uint32_t *count);
 
 LENTIL_API int lentil_hip_compact_rows(lentil_hip_ctx *ctx, uint32_t row_begin, uint32_t n_rows, void *dev_idx,
                                        void *dev_vals, void *dev_keys, uint32_t capacity, uint32_t *count) {
+  CHECK_CTX(ctx);
+  LENTIL_NO_DEBUG_AOV(ctx);
+  return compact_rows_impl(ctx, row_begin, n_rows, dev_idx, dev_vals, dev_keys, nullptr, capacity, count);
+}
+
+static int compact_rows_impl(lentil_hip_ctx *ctx, uint32_t row_begin, uint32_t n_rows, void *dev_idx, void *dev_vals,
+                             void *dev_keys, void *dev_keys_dbg, uint32_t capacity, uint32_t *count) {
   CHECK_CTX(ctx);
   int rc = check_rows(ctx, row_begin, n_rows);
   if (rc) return rc;
@@ -1671,7 +1699,7 @@ LENTIL_API int lentil_hip_compact_rows(lentil_hip_ctx *ctx, uint32_t row_begin, 
   if (!n_rows) return LENTIL_OK;
   if (!dev_idx || !dev_vals) return fail(ctx, LENTIL_ERR_INVALID, "dev_idx / dev_vals is null");
   if (ctx->F.zkey && !dev_keys) return fail(ctx, LENTIL_ERR_INVALID, "the frame has closest-filtered AOVs: dev_keys is required");
-  if (ctx->F.debug_mask) return fail(ctx, LENTIL_ERR_UNSUPPORTED, "the lentil_debug AOV is not exchanged between GPUs");
+  if (ctx->F.zkey_dbg && !dev_keys_dbg) return fail(ctx, LENTIL_ERR_INVALID, "the frame has a lentil_debug AOV: its keys are required");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   const uint64_t p_begin = (uint64_t)row_begin * ctx->P.xres, n_pix = (uint64_t)n_rows * ctx->P.xres;
   if ((rc = fold_direct(ctx, p_begin, p_begin + n_pix, false))) return rc;
@@ -1682,8 +1710,8 @@ LENTIL_API int lentil_hip_compact_rows(lentil_hip_ctx *ctx, uint32_t row_begin, 
   const uint64_t max_blocks = (uint64_t)ctx->num_cu * 8;
   if (blocks > max_blocks) blocks = max_blocks;
   hipLaunchKernelGGL(compact_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, ctx->F, p_begin, n_pix,
-                     (uint32_t *)dev_idx, (float *)dev_vals, ctx->F.zkey ? (unsigned long long *)dev_keys : nullptr, capacity,
-                     d_count);
+                     (uint32_t *)dev_idx, (float *)dev_vals, ctx->F.zkey ? (unsigned long long *)dev_keys : nullptr,
+                     ctx->F.zkey_dbg ? (unsigned long long *)dev_keys_dbg : nullptr, capacity, d_count);
   HIP_TRY(ctx, hipGetLastError());
   unsigned int n = 0;
   HIP_TRY(ctx, hipMemcpyAsync(&n, d_count, sizeof(n), hipMemcpyDeviceToHost, ctx->stream));
@@ -1692,28 +1720,44 @@ LENTIL_API int lentil_hip_compact_rows(lentil_hip_ctx *ctx, uint32_t row_begin, 
   return LENTIL_OK;
 }
 
+static int merge_sparse_impl(lentil_hip_ctx *ctx, uint32_t row_begin, uint32_t n_rows, uint32_t n, const void *dev_idx,
+                             const void *dev_vals, const void *dev_keys, const void *dev_keys_dbg);
+
 LENTIL_API int lentil_hip_merge_sparse(lentil_hip_ctx *ctx, uint32_t row_begin, uint32_t n_rows, uint32_t n,
                                        const void *dev_idx, const void *dev_vals, const void *dev_keys) {
+  CHECK_CTX(ctx);
+  LENTIL_NO_DEBUG_AOV(ctx);
+  return merge_sparse_impl(ctx, row_begin, n_rows, n, dev_idx, dev_vals, dev_keys, nullptr);
+}
+
+static int merge_sparse_impl(lentil_hip_ctx *ctx, uint32_t row_begin, uint32_t n_rows, uint32_t n, const void *dev_idx,
+                             const void *dev_vals, const void *dev_keys, const void *dev_keys_dbg) {
   CHECK_CTX(ctx);
   int rc = check_rows(ctx, row_begin, n_rows);
   if (rc) return rc;
   if (!n) return LENTIL_OK;
   if (!dev_idx || !dev_vals) return fail(ctx, LENTIL_ERR_INVALID, "dev_idx / dev_vals is null");
   if (ctx->F.zkey && !dev_keys) return fail(ctx, LENTIL_ERR_INVALID, "the frame has closest-filtered AOVs: dev_keys is required");
-  if (ctx->F.debug_mask) return fail(ctx, LENTIL_ERR_UNSUPPORTED, "the lentil_debug AOV is not exchanged between GPUs");
+  if (ctx->F.zkey_dbg && !dev_keys_dbg) return fail(ctx, LENTIL_ERR_INVALID, "the frame has a lentil_debug AOV: its keys are required");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   untrust_touched(ctx);
   const uint64_t max_blocks = (uint64_t)ctx->num_cu * 8;
   uint64_t blocks = ((uint64_t)n * (4ull * ctx->F.n_aovs + 1ull) + 255) / 256;
   if (blocks > max_blocks) blocks = max_blocks;
   hipLaunchKernelGGL(merge_sparse_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, ctx->F, n, (const uint32_t *)dev_idx,
-                     (const float *)dev_vals, ctx->F.zkey ? (const unsigned long long *)dev_keys : nullptr);
+                     (const float *)dev_vals, ctx->F.zkey ? (const unsigned long long *)dev_keys : nullptr,
+                     ctx->F.zkey_dbg ? (const unsigned long long *)dev_keys_dbg : nullptr);
   HIP_TRY(ctx, hipGetLastError());
+  uint64_t kb = ((uint64_t)n + 255) / 256;
+  if (kb > max_blocks) kb = max_blocks;
   if (ctx->F.zkey) {
-    uint64_t kb = ((uint64_t)n + 255) / 256;
-    if (kb > max_blocks) kb = max_blocks;
-    hipLaunchKernelGGL(merge_sparse_keys_kernel, dim3((unsigned)kb), dim3(256), 0, ctx->stream, ctx->F, n,
+    hipLaunchKernelGGL(merge_sparse_keys_kernel, dim3((unsigned)kb), dim3(256), 0, ctx->stream, ctx->F.zkey, ctx->F.np, n,
                        (const uint32_t *)dev_idx, (const unsigned long long *)dev_keys);
+    HIP_TRY(ctx, hipGetLastError());
+  }
+  if (ctx->F.zkey_dbg) {
+    hipLaunchKernelGGL(merge_sparse_keys_kernel, dim3((unsigned)kb), dim3(256), 0, ctx->stream, ctx->F.zkey_dbg, ctx->F.np, n,
+                       (const uint32_t *)dev_idx, (const unsigned long long *)dev_keys_dbg);
     HIP_TRY(ctx, hipGetLastError());
   }
   if (ctx->dirty_known) {       // the entries lie in rows [row_begin, row_begin + n_rows), the sender's compact_rows range
@@ -1725,23 +1769,27 @@ LENTIL_API int lentil_hip_merge_sparse(lentil_hip_ctx *ctx, uint32_t row_begin, 
 
 LENTIL_API int lentil_hip_merge_packed_rows(lentil_hip_ctx *ctx, uint32_t row_begin, uint32_t n_rows,
                                             const void *dev_packed_rows, const void *dev_key_rows) {
-  return merge_rows_impl(ctx, row_begin, n_rows, dev_packed_rows, dev_key_rows, true);
+  CHECK_CTX(ctx);
+  LENTIL_NO_DEBUG_AOV(ctx);
+  return merge_rows_impl(ctx, row_begin, n_rows, dev_packed_rows, dev_key_rows, nullptr, true);
 }
 
 LENTIL_API int lentil_hip_merge_rows(lentil_hip_ctx *ctx, uint32_t row_begin, uint32_t n_rows, const void *dev_acc_rows,
                                      const void *dev_key_rows) {
-  return merge_rows_impl(ctx, row_begin, n_rows, dev_acc_rows, dev_key_rows, false);
+  CHECK_CTX(ctx);
+  LENTIL_NO_DEBUG_AOV(ctx);
+  return merge_rows_impl(ctx, row_begin, n_rows, dev_acc_rows, dev_key_rows, nullptr, false);
 }
 
 static int merge_rows_impl(lentil_hip_ctx *ctx, uint32_t row_begin, uint32_t n_rows, const void *dev_acc_rows,
-                           const void *dev_key_rows, bool packed) {
+                           const void *dev_key_rows, const void *dev_key_rows_dbg, bool packed) {
   CHECK_CTX(ctx);
   int rc = check_rows(ctx, row_begin, n_rows);
   if (rc) return rc;
   if (!n_rows) return LENTIL_OK;
   if (!dev_acc_rows) return fail(ctx, LENTIL_ERR_INVALID, "dev_acc_rows is null");
   if (ctx->F.zkey && !dev_key_rows) return fail(ctx, LENTIL_ERR_INVALID, "the frame has closest-filtered AOVs: key rows are required");
-  if (ctx->F.debug_mask) return fail(ctx, LENTIL_ERR_UNSUPPORTED, "the lentil_debug AOV is not exchanged between GPUs");
+  if (ctx->F.zkey_dbg && !dev_key_rows_dbg) return fail(ctx, LENTIL_ERR_INVALID, "the frame has a lentil_debug AOV: its key rows are required");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   untrust_touched(ctx);
   const uint64_t p_begin = (uint64_t)row_begin * ctx->P.xres, n_pix = (uint64_t)n_rows * ctx->P.xres;
@@ -1750,16 +1798,23 @@ static int merge_rows_impl(lentil_hip_ctx *ctx, uint32_t row_begin, uint32_t n_r
   if (blocks > max_blocks) blocks = max_blocks;
   if (packed)
     hipLaunchKernelGGL(merge_packed_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, ctx->F, p_begin, n_pix,
-                       (const float *)dev_acc_rows, ctx->F.zkey ? (const unsigned long long *)dev_key_rows : nullptr);
+                       (const float *)dev_acc_rows, ctx->F.zkey ? (const unsigned long long *)dev_key_rows : nullptr,
+                       ctx->F.zkey_dbg ? (const unsigned long long *)dev_key_rows_dbg : nullptr);
   else
     hipLaunchKernelGGL(merge_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, ctx->F, p_begin, n_pix,
-                       (const float *)dev_acc_rows, ctx->F.zkey ? (const unsigned long long *)dev_key_rows : nullptr);
+                       (const float *)dev_acc_rows, ctx->F.zkey ? (const unsigned long long *)dev_key_rows : nullptr,
+                       ctx->F.zkey_dbg ? (const unsigned long long *)dev_key_rows_dbg : nullptr);
   HIP_TRY(ctx, hipGetLastError());
+  uint64_t kb = (n_pix + 255) / 256;
+  if (kb > max_blocks) kb = max_blocks;
   if (ctx->F.zkey) {
-    uint64_t kb = (n_pix + 255) / 256;
-    if (kb > max_blocks) kb = max_blocks;
-    hipLaunchKernelGGL(merge_keys_kernel, dim3((unsigned)kb), dim3(256), 0, ctx->stream, ctx->F, p_begin, n_pix,
+    hipLaunchKernelGGL(merge_keys_kernel, dim3((unsigned)kb), dim3(256), 0, ctx->stream, ctx->F.zkey, p_begin, n_pix,
                        (const unsigned long long *)dev_key_rows);
+    HIP_TRY(ctx, hipGetLastError());
+  }
+  if (ctx->F.zkey_dbg) {
+    hipLaunchKernelGGL(merge_keys_kernel, dim3((unsigned)kb), dim3(256), 0, ctx->stream, ctx->F.zkey_dbg, p_begin, n_pix,
+                       (const unsigned long long *)dev_key_rows_dbg);
     HIP_TRY(ctx, hipGetLastError());
   }
   if (ctx->dirty_known) {
@@ -1989,6 +2044,67 @@ LENTIL_API int lentil_hip_test_lt_sample_aperture(lentil_hip_ctx *ctx, uint64_t 
   HIP_TRY(ctx, hipMemcpy(sensor, o0, n * 5 * 8, hipMemcpyDeviceToHost));
   HIP_TRY(ctx, hipMemcpy(out, o1, n * 5 * 8, hipMemcpyDeviceToHost));
   HIP_TRY(ctx, hipMemcpy(transmittance, o2, n * 8, hipMemcpyDeviceToHost));
+  return LENTIL_OK;
+}
+
+// Camera::logarithmic_focus_search on the GPU: the candidates on the host exactly as the reference produces them
+// (the running fp64 sum of logarithmic_values and libm's pow, src/lens.h:395-407), one lane per candidate, one block
+// for the ordered minimum.
+static void focus_candidates(std::vector<double> &shift) {
+  shift.clear();
+  for (double i = -1.0; i <= 1.0; i += 0.0001) shift.push_back((i < 0 ? -1 : 1) * std::pow(i, 2.0) * (45.0 - 0.0) + 0.0);
+}
+
+static int run_focus(lentil_hip_ctx *ctx, const double *shift, uint32_t n, double focal_distance, double lambda,
+                     double *miss, double *sensor, double *out, double *best) {
+  TmpFree tf;
+  FocusArgs f{};
+  f.lens = ctx->d_lens; f.terms = ctx->d_terms; f.lambda = lambda; f.housing_radius = ctx->lens_housing_radius;
+  f.focal_distance = focal_distance; f.n = n;
+  double *d_shift, *d_miss, *d_sensor = nullptr, *d_out = nullptr, *d_best;
+  int rc;
+  if ((rc = dev_copy_in(ctx, shift, n, &d_shift, tf.v))) return rc;
+  if ((rc = dev_alloc(ctx, n, &d_miss, tf.v))) return rc;
+  if (sensor && (rc = dev_alloc(ctx, (uint64_t)n * 5, &d_sensor, tf.v))) return rc;
+  if (out && (rc = dev_alloc(ctx, (uint64_t)n * 5, &d_out, tf.v))) return rc;
+  if ((rc = dev_alloc(ctx, 2, &d_best, tf.v))) return rc;
+  f.shift = d_shift; f.miss = d_miss; f.sensor = d_sensor; f.out = d_out; f.best = d_best;
+  hipLaunchKernelGGL(focus_miss_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, f);
+  HIP_TRY(ctx, hipGetLastError());
+  hipLaunchKernelGGL(focus_argmin_kernel, dim3(1), dim3(1024), 0, ctx->stream, f);
+  HIP_TRY(ctx, hipGetLastError());
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  if (miss) HIP_TRY(ctx, hipMemcpy(miss, d_miss, (size_t)n * 8, hipMemcpyDeviceToHost));
+  if (sensor) HIP_TRY(ctx, hipMemcpy(sensor, d_sensor, (size_t)n * 40, hipMemcpyDeviceToHost));
+  if (out) HIP_TRY(ctx, hipMemcpy(out, d_out, (size_t)n * 40, hipMemcpyDeviceToHost));
+  if (best) HIP_TRY(ctx, hipMemcpy(best, d_best, 16, hipMemcpyDeviceToHost));
+  return LENTIL_OK;
+}
+
+LENTIL_API int lentil_hip_focus_search(lentil_hip_ctx *ctx, double focal_distance, double lambda, double *best_sensor_shift) {
+  CHECK_CTX(ctx);
+  if (!ctx->have_lens) return fail(ctx, LENTIL_ERR_INVALID, "set_lens first");
+  if (!best_sensor_shift) return fail(ctx, LENTIL_ERR_INVALID, "best_sensor_shift is null");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  std::vector<double> shift;
+  focus_candidates(shift);
+  double best[2] = {0.0, 0.0};
+  const int rc = run_focus(ctx, shift.data(), (uint32_t)shift.size(), focal_distance, lambda, nullptr, nullptr, nullptr, best);
+  if (rc) return rc;
+  *best_sensor_shift = best[0];
+  return LENTIL_OK;
+}
+
+LENTIL_API int lentil_hip_test_y0_intersection(lentil_hip_ctx *ctx, uint64_t n, const double *sensor_shift, double lambda,
+                                               double *distance, double *sensor, double *out) {
+  CHECK_CTX(ctx);
+  if (!ctx->have_lens) return fail(ctx, LENTIL_ERR_INVALID, "set_lens first");
+  if (!n) return LENTIL_OK;
+  if (n > 0x7FFFFFFFull || !sensor_shift || !distance) return fail(ctx, LENTIL_ERR_INVALID, "bad test_y0_intersection arguments");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  const int rc = run_focus(ctx, sensor_shift, (uint32_t)n, 0.0, lambda, distance, sensor, out, nullptr);
+  if (rc) return rc;
+  for (uint64_t i = 0; i < n; ++i) distance[i] = 0.0 - distance[i];      // miss = 0 - distance, exactly
   return LENTIL_OK;
 }
 

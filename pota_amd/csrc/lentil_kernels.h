@@ -2090,8 +2090,10 @@ __global__ __launch_bounds__(256) void debug_gather_kernel(FrameDev F, VisitsDev
 // Multi-GPU tiles: rows of another GPU's accumulators (same record layout) are merged into
 // this GPU's: gaussian slots and the weight add up; closest-filtered slots follow the smaller winner key.
 // The keys themselves are merged by a second launch (every float of a pixel reads both keys first).
+// (lentil_debug slots follow their own key plane, zkey_dbg / src_keys_dbg.)
 __global__ __launch_bounds__(256) void merge_rows_kernel(FrameDev F, uint64_t p_begin, uint64_t n_pix,
-                                                         const float *src, const unsigned long long *src_keys) {
+                                                         const float *src, const unsigned long long *src_keys,
+                                                         const unsigned long long *src_keys_dbg) {
   const uint64_t total = n_pix * F.stride;
   const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
   const uint32_t used = 4u * F.n_aovs + 1u;
@@ -2102,7 +2104,10 @@ __global__ __launch_bounds__(256) void merge_rows_kernel(FrameDev F, uint64_t p_
     float *dst = F.acc + (p_begin + i) * F.stride + j;
     const uint32_t aov = j >> 2;
     if (j < 4u * F.n_aovs && (F.closest_mask & (1u << aov))) {
-      if (src_keys && src_keys[i] < F.zkey[p_begin + i]) *dst = src[t];
+      const bool dbg = (F.debug_mask >> aov) & 1u;
+      const unsigned long long *sk = dbg ? src_keys_dbg : src_keys;
+      const unsigned long long *mine = dbg ? F.zkey_dbg : F.zkey;
+      if (sk && sk[i] < mine[p_begin + i]) *dst = src[t];
     } else {
       *dst += src[t];
     }
@@ -2127,8 +2132,8 @@ __global__ __launch_bounds__(256) void pack_rows_kernel(FrameDev F, uint64_t p_b
 // closest-filtered AOVs, a winner key) becomes one entry: its frame-wide index, its 4 n_aovs + 1 floats, its key.
 // Entries beyond `cap` are counted but not written (the caller then sends the rows whole).
 __global__ __launch_bounds__(256) void compact_rows_kernel(FrameDev F, uint64_t p_begin, uint64_t n_pix, uint32_t *idx,
-                                                           float *vals, unsigned long long *keys, uint32_t cap,
-                                                           unsigned int *count) {
+                                                           float *vals, unsigned long long *keys, unsigned long long *keys_dbg,
+                                                           uint32_t cap, unsigned int *count) {
   const uint32_t used = 4u * F.n_aovs + 1u;
   const uint32_t lane = threadIdx.x & 63u;
   const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
@@ -2136,7 +2141,8 @@ __global__ __launch_bounds__(256) void compact_rows_kernel(FrameDev F, uint64_t 
   for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_round; i += stride) {
     const uint64_t p = p_begin + i;
     bool live = false;
-    if (i < n_pix) live = F.acc[p * F.stride + 4u * F.n_aovs] != 0.0f || (F.zkey && F.zkey[p] != ~0ull);
+    if (i < n_pix) live = F.acc[p * F.stride + 4u * F.n_aovs] != 0.0f || (F.zkey && F.zkey[p] != ~0ull) ||
+                          (F.zkey_dbg && F.zkey_dbg[p] != ~0ull);
     const unsigned long long m = __ballot(live);
     if (m == 0ull) continue;
     uint32_t base = 0;
@@ -2147,13 +2153,14 @@ __global__ __launch_bounds__(256) void compact_rows_kernel(FrameDev F, uint64_t 
       idx[slot] = (uint32_t)p;
       for (uint32_t j = 0; j < used; ++j) vals[(uint64_t)slot * used + j] = F.acc[p * F.stride + j];
       if (keys) keys[slot] = F.zkey[p];
+      if (keys_dbg) keys_dbg[slot] = F.zkey_dbg[p];
     }
   }
 }
 
 // the receiving side: entries of ONE sender (every pixel at most once), launches of different senders are ordered
 __global__ __launch_bounds__(256) void merge_sparse_kernel(FrameDev F, uint32_t n, const uint32_t *idx, const float *vals,
-                                                           const unsigned long long *keys) {
+                                                           const unsigned long long *keys, const unsigned long long *keys_dbg) {
   const uint32_t used = 4u * F.n_aovs + 1u;
   const uint64_t total = (uint64_t)n * used;
   const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
@@ -2165,25 +2172,29 @@ __global__ __launch_bounds__(256) void merge_sparse_kernel(FrameDev F, uint32_t 
     float *dst = F.acc + p * F.stride + j;
     const uint32_t aov = j >> 2;
     if (j < 4u * F.n_aovs && (F.closest_mask & (1u << aov))) {
-      if (keys && keys[e] < F.zkey[p]) *dst = vals[t];
+      const bool dbg = (F.debug_mask >> aov) & 1u;
+      const unsigned long long *sk = dbg ? keys_dbg : keys;
+      const unsigned long long *mine = dbg ? F.zkey_dbg : F.zkey;
+      if (sk && sk[e] < mine[p]) *dst = vals[t];
     } else {
       *dst += vals[t];
     }
   }
 }
 
-__global__ __launch_bounds__(256) void merge_sparse_keys_kernel(FrameDev F, uint32_t n, const uint32_t *idx,
-                                                                const unsigned long long *keys) {
+__global__ __launch_bounds__(256) void merge_sparse_keys_kernel(unsigned long long *mine, uint64_t np, uint32_t n,
+                                                                const uint32_t *idx, const unsigned long long *keys) {
   const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
   for (uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += stride) {
     const uint64_t p = idx[e];
-    if (p < F.np && keys[e] < F.zkey[p]) F.zkey[p] = keys[e];
+    if (p < np && keys[e] < mine[p]) mine[p] = keys[e];
   }
 }
 
 // merge_rows_kernel for rows that arrived packed
 __global__ __launch_bounds__(256) void merge_packed_rows_kernel(FrameDev F, uint64_t p_begin, uint64_t n_pix,
-                                                                const float *src, const unsigned long long *src_keys) {
+                                                                const float *src, const unsigned long long *src_keys,
+                                                                const unsigned long long *src_keys_dbg) {
   const uint32_t used = 4u * F.n_aovs + 1u;
   const uint64_t total = n_pix * used;
   const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
@@ -2193,19 +2204,22 @@ __global__ __launch_bounds__(256) void merge_packed_rows_kernel(FrameDev F, uint
     float *dst = F.acc + (p_begin + i) * F.stride + j;
     const uint32_t aov = j >> 2;
     if (j < 4u * F.n_aovs && (F.closest_mask & (1u << aov))) {
-      if (src_keys && src_keys[i] < F.zkey[p_begin + i]) *dst = src[t];
+      const bool dbg = (F.debug_mask >> aov) & 1u;
+      const unsigned long long *sk = dbg ? src_keys_dbg : src_keys;
+      const unsigned long long *mine = dbg ? F.zkey_dbg : F.zkey;
+      if (sk && sk[i] < mine[p_begin + i]) *dst = src[t];
     } else {
       *dst += src[t];
     }
   }
 }
 
-__global__ __launch_bounds__(256) void merge_keys_kernel(FrameDev F, uint64_t p_begin, uint64_t n_pix,
+__global__ __launch_bounds__(256) void merge_keys_kernel(unsigned long long *mine, uint64_t p_begin, uint64_t n_pix,
                                                          const unsigned long long *src_keys) {
   const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
   for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_pix; i += stride) {
     const unsigned long long k = src_keys[i];
-    if (k < F.zkey[p_begin + i]) F.zkey[p_begin + i] = k;
+    if (k < mine[p_begin + i]) mine[p_begin + i] = k;
   }
 }
 
@@ -2302,6 +2316,77 @@ __global__ __launch_bounds__(256) void resolve_kernel(FrameDev F, float *resolve
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
     __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// Focus search, Camera::logarithmic_focus_search (src/lentil.h:1445-1460) over logarithmic_values()
+// (src/lens.h:395-407): 20 001 candidate sensor shifts, for each the distance at which the ray through a quarter of
+// the aperture housing radius crosses the optical axis (camera_get_y0_intersection_distance), the winner the
+// candidate whose miss = focal_distance - distance is the smallest positive one -- the first such in candidate order,
+// as the reference's sequential `new_distance < closest_distance` keeps it.  One candidate per lane; the candidates
+// (an fp64 running sum and std::pow on the host side of the reference) come from the host.
+// ---------------------------------------------------------------------------------------
+struct FocusArgs {
+  const DevLens *lens;
+  const DevTerm *terms;
+  double lambda, housing_radius, focal_distance;
+  uint32_t n;
+  const double *shift;     // [n] candidates
+  double *miss;            // [n] focal_distance - intersection distance
+  double *sensor, *out;    // optional [n][5] each: what lens_pt_sample_aperture / lens_evaluate left (parity tests)
+  double *best;            // [2]: winning shift, its miss (focus_argmin_kernel)
+};
+
+__global__ __launch_bounds__(256) void focus_miss_kernel(FocusArgs f) {
+  __shared__ DevTerm s_terms[kMaxTerms];
+  __shared__ DevLens s_k;
+  const uint32_t nt = f.lens->n_terms;
+  for (uint32_t i = threadIdx.x; i < nt; i += blockDim.x) s_terms[i] = f.terms[i];
+  if (threadIdx.x == 0) {
+    s_k = *f.lens;
+    s_k.lambda_pow[0] = 1.0; s_k.lambda_pow[1] = f.lambda;
+    for (uint32_t e = 2; e <= kMaxExp; ++e) s_k.lambda_pow[e] = ipow_u(f.lambda, e);     // lens_ipow, like the host
+  }
+  __syncthreads();
+  const LdsLens L{s_terms, &s_k};
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t ii = i < f.n ? i : f.n - 1u;      // whole waves stay converged: table reads go through readfirstlane
+  double sensor[4], out[4], T;
+  const double dist = camera_get_y0_intersection_distance(L, f.shift[ii], f.housing_radius, sensor, out, T);
+  if (i < f.n) {
+    f.miss[i] = f.focal_distance - dist;
+    if (f.sensor) { for (int c = 0; c < 4; ++c) f.sensor[(size_t)i * 5 + c] = sensor[c]; f.sensor[(size_t)i * 5 + 4] = f.lambda; }
+    if (f.out) { for (int c = 0; c < 4; ++c) f.out[(size_t)i * 5 + c] = out[c]; f.out[(size_t)i * 5 + 4] = T; }
+  }
+}
+
+// one block: smallest positive miss, ties to the earlier candidate; no positive miss: shift 0 (the reference's initial value)
+__global__ __launch_bounds__(1024) void focus_argmin_kernel(FocusArgs f) {
+  __shared__ double s_val[1024];
+  __shared__ uint32_t s_idx[1024];
+  double bv = 999999999.0;           // closest_distance starts here: a miss must be below it to count
+  uint32_t bi = 0xFFFFFFFFu;
+  for (uint32_t i = threadIdx.x; i < f.n; i += blockDim.x) {
+    const double m = f.miss[i];
+    if (m > 0.0 && m < bv) { bv = m; bi = i; }      // ascending i per thread: strict < keeps the earlier one
+  }
+  s_val[threadIdx.x] = bv; s_idx[threadIdx.x] = bi;
+  __syncthreads();
+  for (uint32_t off = 512; off > 0; off >>= 1) {
+    if (threadIdx.x < off) {
+      const double ov = s_val[threadIdx.x + off];
+      const uint32_t oi = s_idx[threadIdx.x + off];
+      if (oi != 0xFFFFFFFFu && (ov < s_val[threadIdx.x] || (ov == s_val[threadIdx.x] && oi < s_idx[threadIdx.x]))) {
+        s_val[threadIdx.x] = ov; s_idx[threadIdx.x] = oi;
+      }
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const uint32_t w = s_idx[0];
+    f.best[0] = w != 0xFFFFFFFFu ? f.shift[w] : 0.0;
+    f.best[1] = w != 0xFFFFFFFFu ? s_val[0] : 999999999.0;
   }
 }
 

@@ -170,8 +170,19 @@ void LentilCamera::setup(AtUniverse *universe) {
     if (!lens_table) { AiMsgError("[LENTIL] lens_model %d has no table in this build", v.lens_model); AiRenderAbort(); return; }
     host_lens = lentil_host_lens_create(lens_table);
   }
-  // ---- camera_model_specific_setup (src/lentil.h:1568-1670)
-  if (lentil_host_camera_model_specific_setup(&P, host_lens, input_fstop, lambda_um * 1000.0, extra_sensor_shift, &tan_fov) != 0) {
+  // ---- camera_model_specific_setup (src/lentil.h:1568-1670); its focus search runs on the GPU when there is one
+  // (LENTIL_GPU_FOCUS_SEARCH=0: the sequential loop on the host; both give the same shift bit for bit)
+  lentil_focus_search_fn focus_fn = nullptr;
+  const char *gf = getenv("LENTIL_GPU_FOCUS_SEARCH");
+  if (P.cameraType == LENTIL_POLYNOMIAL_OPTICS && !(gf && gf[0] == '0')) {
+    if (!gpu && lentil_hip_create(0, &gpu) != LENTIL_OK) gpu = nullptr;
+    if (gpu && lentil_hip_set_lens(gpu, lens_table) == LENTIL_OK)
+      focus_fn = [](void *user, double focal_distance, double lambda, double *shift) -> int {
+        return lentil_hip_focus_search(static_cast<lentil_hip_ctx *>(user), focal_distance, lambda, shift);
+      };
+  }
+  if (lentil_host_camera_model_specific_setup_with(&P, host_lens, input_fstop, lambda_um * 1000.0, extra_sensor_shift, &tan_fov,
+                                                   focus_fn, gpu) != 0) {
     AiMsgError("[LENTIL] camera setup failed");
     AiRenderAbort();
     return;

@@ -215,8 +215,7 @@ def frame_step_native(ctx):
     """frame_step with the exchange inside liblentil_hip.so (lentil_hip_allreduce): clear, pass, min-reduce of the
     winner keys + gather (frames with closest AOVs), sum all-reduce, resolve -- all enqueued on the library's stream,
     no torch.distributed call on the data path."""
-    if ctx.zkey_buffer()[1]:
-        ctx.set_closest_exchange(True)
+    ctx.set_closest_exchange(True)            # (means nothing for frames without closest-filtered AOVs)
     ctx.clear_frame()
     ctx.redistribute()
     ctx.allreduce()
@@ -225,8 +224,7 @@ def frame_step_native(ctx):
 
 def frame_step_bands_native(ctx, visit_rows, bounds=None):
     """frame_step_bands with the exchange inside liblentil_hip.so (lentil_hip_exchange_bands).  Returns the band."""
-    if ctx.zkey_buffer()[1]:
-        ctx.set_closest_exchange(False)       # local winners are gathered by the pass; keys travel with the rows
+    ctx.set_closest_exchange(False)           # local winners are gathered by the pass; keys travel with the rows
     ctx.clear_frame()
     ctx.redistribute()
     return ctx.exchange_bands(visit_rows, bounds, sparse=SPARSE_EXCHANGE)

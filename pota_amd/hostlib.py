@@ -34,6 +34,7 @@ def load():
         "lentil_host_trace_backwards_for_fstop": (None, [vp, d, d, pd, pd]),
         "lentil_host_trace_ray_focus_check": (i, [vp, d, d, pd]),
         "lentil_host_camera_model_specific_setup": (i, [C.POINTER(_abi.Params), vp, d, d, d, pd]),
+        "lentil_host_camera_model_specific_setup_with": (i, [C.POINTER(_abi.Params), vp, d, d, d, pd, vp, vp]),
         "lentil_host_xor128_init": (None, [pu]),
         "lentil_host_trace_ray_fw_po": (None, [C.POINTER(_abi.Params), vp, C.POINTER(_abi.BokehTable), pu, d, d, d, pd, pd, i,
                                                pf, pf, pf, C.POINTER(i)]),

@@ -188,6 +188,70 @@ def test_exchange_bands_seeded_soak(orc, fake_rccl, monkeypatch):
                 c.close()
 
 
+@pytest.mark.parametrize("partition", ["bands", "interleaved"])
+def test_lentil_debug_aov_across_ranks(orc, gpu_ctx_factory, fake_rccl, partition):
+    """The lentil_debug AOV (own z-buffer fed by redistributed draws only, value = the winner's draw count,
+    src/lentil.h:838-845) through both exchanges: its key plane travels / is min-reduced beside the ordinary one.
+    Every rank's part equals the single-context frame, which test_lentil_debug_aov pins to the oracle."""
+    from pota_amd import _abi
+    W, H, M, world = 64, 42, 9, 3
+    kinds = [_abi.FILTER_GAUSSIAN, _abi.FILTER_CLOSEST_DEBUG, _abi.FILTER_CLOSEST]
+    p, model, table, keep = common.po_setup(W, H, samples_override=0)
+
+    def stream(v_lo, v_hi, **kw):
+        c = workload.generate(np, v_lo, v_hi, W, H, M, f_hi=0.03, focus_dist=150.0, tan_half_fov=common.tan_half_fov(p),
+                              n_extra=2, **kw)
+        c["extra"][0] = None                   # lentil_debug has no visit column
+        return c
+
+    cw = stream(0, W * H * M)
+    vw, kw_ = capi.make_visits(cw, visits_per_pixel=M, pixels_per_row=W)
+    whole = gpu_ctx_factory()
+    gpu_run(whole, p, table, vw, n_aovs=3, kinds=kinds)
+    whole.P = p
+    assert np.unique(whole.download_accum(1)[0][:, 0]).size > 3
+    ctxs, keepalive, bands = [], [], []
+    for rank in range(world):
+        if partition == "bands":
+            b_lo, b_hi = distributed.band_of(rank, world, H, p.yres)
+            c = stream(b_lo * W * M, min(b_hi, H) * W * M)
+            v, kv = capi.make_visits(c, visits_per_pixel=M, pixels_per_row=W, pixel_y0=b_lo)
+            bands.append((b_lo, b_hi))
+        else:
+            c = stream(0, workload.frame_visit_count(W, H, M, world, rank), row_stride=world, row_offset=rank)
+            v, kv = capi.make_visits(c, visits_per_pixel=M, pixels_per_row=W, pixel_y0=rank, pixel_row_stride=world)
+            bands.append(None)
+        ctx = gpu_ctx_factory()
+        ctx.set_params(p); ctx.set_lens(table); ctx.set_bokeh(None)
+        ctx.alloc_frame(3, kinds)
+        ctx.upload_visits(v)
+        keepalive.append((c, v, kv))
+        ctxs.append(ctx)
+    uid = capi.Context.comm_unique_id()
+
+    def rank_fn(rank):
+        ctxs[rank].comm_init(uid, rank, world)
+        for _ in range(2):
+            if partition == "bands":
+                assert distributed.frame_step_bands_native(ctxs[rank], H) == bands[rank]
+            else:
+                distributed.frame_step_native(ctxs[rank])
+            ctxs[rank].sync()
+
+    _threads(rank_fn, world)
+    for rank in range(world):
+        _compare_with_whole(ctxs[rank], whole, [0, 1, 1], rows=bands[rank])
+    # without the library's communicator the debug AOV cannot be exchanged, and says so
+    lone = gpu_ctx_factory()
+    lone.set_params(p); lone.set_lens(table); lone.set_bokeh(None); lone.alloc_frame(3, kinds)
+    lone.upload_visits(vw)
+    lone.set_closest_exchange(True)
+    with pytest.raises(capi.LentilError):
+        lone.redistribute()
+    with pytest.raises(capi.LentilError):
+        lone.compact_rows(0, 4, 0, 0, 0, 16)
+
+
 def _real_rccl_world1(q):
     """world_size 1 through the real librccl.so: communicator, both exchanges (which then move nothing), the results"""
     import sys
