@@ -74,6 +74,7 @@ def parse():
     ap.add_argument("--aovs", type=int, default=0, help="extra (non-beauty) AOVs")
     ap.add_argument("--lens", default="double_gauss_50mm")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pcie", action="store_true", help="skip the PCIe-inclusive measurement (upload from host memory + pass)")
     ap.add_argument("--no-second-regime", action="store_true")
     ap.add_argument("--no-configs", action="store_true", help="skip BASELINE.json's configs 2-4")
     ap.add_argument("--same-frame", action="store_true", help="replay ONE visit stream (development aid; the default alternates two)")
@@ -103,6 +104,53 @@ def physical_cores():
         return len(seen) or None
     except OSError:
         return None
+
+
+def pcie_inclusive(b):
+    """The same frame when its visit columns start in (page-locked) host memory: lentil_hip_upload_visits + the pass,
+    best of two.  Never `value`: the metric is quoted with the inputs resident in HBM.  (A renderer hands the visits
+    over while it renders -- lentil_hip_visits_append, tools/pcie_rate.py, profiles/r02_pcie_rate.json -- and then
+    the frame end waits for the pass only.)"""
+    import ctypes as C
+    import numpy as np
+    from pota_amd import capi
+    torch = b.torch
+    cols, v, kv = b.streams[0]
+    names = ("rgba", "pos_z", "raydir_time", "volume_ignore", "transmission")
+    n = int(v.n)
+    nbytes = n * 16 * (5 + b.aovs)
+    ptr = capi.host_alloc(nbytes)
+    try:
+        host = np.frombuffer((C.c_char * nbytes).from_address(ptr), np.float32).reshape(5 + b.aovs, n, 4)
+        ht = torch.from_numpy(host)
+        for c, name in enumerate(names):
+            ht[c].copy_(cols[name])
+        for k in range(b.aovs):
+            ht[5 + k].copy_(cols["extra"][k])
+        torch.cuda.synchronize()
+        hcols = {name: host[c] for c, name in enumerate(names)}
+        hcols["extra"] = [host[5 + k] for k in range(b.aovs)]
+        hv, hkv = capi.make_visits(hcols, visits_per_pixel=b.M, pixels_per_row=b.W, pixel_y0=int(v.pixel_y0),
+                                   pixel_row_stride=int(v.pixel_row_stride))
+        best = None
+        for _ in range(2):
+            t0 = time.perf_counter()
+            b.ctx.upload_visits(hv)
+            b.ctx.sync()
+            t1 = time.perf_counter()
+            b.ctx.clear_frame(); b.ctx.redistribute(); b.ctx.resolve(); b.ctx.sync()
+            t2 = time.perf_counter()
+            if best is None or t2 - t0 < best[0]:
+                best = (t2 - t0, t1 - t0, t2 - t1)
+        del ht, host, hcols, hv, hkv
+    finally:
+        capi.host_free(ptr)
+    b.ctx.bind_visits(v, kv)
+    return {"value": round(n / best[0] / 1e6, 1), "unit": "Msamples/s", "upload_ms": round(best[1] * 1e3, 2),
+            "upload_GBps": round(nbytes / best[1] / 1e9, 1), "pass_ms": round(best[2] * 1e3, 3),
+            "what": "one lentil_hip_upload_visits of the whole frame from page-locked host memory + the pass; "
+                    "handed over in blocks during the render instead, the frame end waits for the pass only "
+                    "(profiles/r02_pcie_rate.json)"}
 
 
 def cpu_baseline(args, p, table, M, tan_half_fov):
@@ -522,6 +570,12 @@ def main():
             "passes": {"streamed": r2["streamed"], "chunks_redone_after_a_short_estimate": r2["redone"]}}}
         out["solve_fp64"]["highlight_heavy"] = b.solve_block(r2)
 
+    if rank == 0 and world == 1 and not args.no_pcie and not emulate:
+        try:
+            b.generate(args.f_hi)
+            out["pcie_inclusive"] = pcie_inclusive(b)
+        except Exception as e:      # the GPU number must still be reported
+            out["pcie_inclusive"] = {"value": None, "error": repr(e)}
     cpu_args = (args, b.p, b.table, M, b.tan_half_fov)
     b.close()
 

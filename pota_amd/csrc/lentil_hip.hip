@@ -848,7 +848,7 @@ static int launch_chunk_rounds(lentil_hip_ctx *ctx, int ci, DrawArgs &da, uint64
     }
     // Splats go anywhere in the frame, also into rows a later chunk's scan is still read-modify-writing with
     // plain stores: solves may overlap the remaining scans, the first accept may not.
-    if (round == 0 && !getenv("LENTIL_XP_EARLY_ACCEPT")) HIP_TRY(ctx, hipStreamWaitEvent(ch.stream, ctx->scans_done, 0));
+    if (round == 0) HIP_TRY(ctx, hipStreamWaitEvent(ch.stream, ctx->scans_done, 0));
     // A heavy chunk's first accept is released by the same event as the next heavy chunk's first solve.  With its
     // full grid it reaches the CUs first and the solve kernel's blocks are placed around it -- the slow start that
     // costs that kernel 10 % for its whole life (see above).  A quarter block per CU trickles along beside the solve
