@@ -1668,7 +1668,29 @@ struct AcceptShared {
   uint32_t cnt[4][64];                      // draws of this wave step on the same pixel, at the first of them (0 at the others)
   float val[4 * LENTIL_MAX_AOVS + 1];      // what one accepted draw of the item adds, float by float
   uint32_t off[4 * LENTIL_MAX_AOVS + 1];   // ... and where inside the pixel record
+  uint32_t rwin[3][256 + 64];              // R(n .. n + 255 + retries) of the step, per wavelength channel (stage_results)
 };
+
+// The results a 256-attempt step looks at, R(n .. n + 255 + retries), fetched by the block with one round of
+// coalesced loads into LDS.  Every attempt then walks its tries there.  (Walking them in global memory is a chain of
+// dependent loads per attempt -- up to retries + 1 of them where the lens vignettes -- and the block waits for its
+// slowest lane: 25 us per step for the items near the frame's edge, 130 of the accept kernel's 175 us.)
+constexpr uint32_t kAcceptWinRetries = 64;        // more retries than this: the attempts read global memory
+constexpr uint32_t kCodeBeyond = 0xFFFFFFFDu;     // R(m) with m >= m_hi: not part of this batch
+LD_DEV uint32_t result_at(const uint32_t *res, const ItemProg &pg, uint32_t res_base, uint32_t m) {
+  return m < pg.m_lo ? kCodeFail : (m >= pg.m_hi ? kCodeBeyond : res[res_base + (m - pg.m_lo)]);
+}
+LD_DEV void stage_results(uint32_t *win, const uint32_t *res, const ItemProg &pg, uint32_t res_base, uint32_t n, uint32_t count) {
+  for (uint32_t i = threadIdx.x; i < count; i += blockDim.x) win[i] = result_at(res, pg, res_base, n + i);
+}
+// A block barrier that orders LDS only.  __syncthreads() also waits for the thread's outstanding global memory
+// operations (s_waitcnt vmcnt(0)) -- here the splat atomics of the step before, 5-7 us each time, for nothing: no
+// thread of the block reads what they wrote.
+LD_DEV void block_sync_lds() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
 
 struct AcceptResult {
   bool more;                // draws are still missing and more attempts exist: [new_lo, new_hi) must be solved
@@ -1729,13 +1751,33 @@ LD_DEV AcceptResult accept_item(const DrawArgs &a, AcceptShared &sh, uint32_t it
     __syncthreads();
     uint32_t n = pg.n_done, acc = pg.accepted, last_ok = pg.last_ok;
     bool stalled = false;
+    // the window of a step is requested a step ahead (entries threadIdx.x and 256 + threadIdx.x), before the splat
+    // atomics of the step in between: loads return in order with them, so a load issued behind 1 280 atomics waits
+    // for all of them
+    const bool win = retries <= kAcceptWinRetries;
+    uint32_t pre0 = kCodeBeyond, pre1 = kCodeBeyond;
+    if (win) {
+      pre0 = result_at(res, pg, pg.res_off, n + threadIdx.x);
+      if (threadIdx.x < retries) pre1 = result_at(res, pg, pg.res_off, n + 256u + threadIdx.x);
+    }
     while (!stalled && acc < S && n < max_total) {
       const uint32_t my_i = wave * 64u + lane;              // position inside this 256-attempt step
       const uint32_t my_n = n + my_i;
       const bool valid = my_n < max_total;
       uint32_t code = kCodeFail;
       bool unresolved = false;
-      if (valid) {
+      if (win) {
+        sh.rwin[0][threadIdx.x] = pre0;
+        if (threadIdx.x < retries) sh.rwin[0][256u + threadIdx.x] = pre1;
+        block_sync_lds();
+        if (valid) {
+          for (uint32_t t = 0; t <= retries; ++t) {
+            const uint32_t c = sh.rwin[0][my_i + t];
+            if (c == kCodeBeyond) { unresolved = (pg.m_hi < m_limit); break; }
+            if (c != kCodeFail) { code = c; break; }
+          }
+        }
+      } else if (valid) {
         for (uint32_t t = 0; t <= retries; ++t) {
           const uint32_t m = my_n + t;
           if (m >= pg.m_hi) { unresolved = (pg.m_hi < m_limit); break; }
@@ -1746,7 +1788,7 @@ LD_DEV AcceptResult accept_item(const DrawArgs &a, AcceptShared &sh, uint32_t it
       // first unresolved attempt of the step (all later ones are unresolved too)
       const unsigned long long umask = __ballot(valid && unresolved);
       if (lane == 0) s_first_u[wave] = umask ? wave * 64u + (uint32_t)__builtin_ctzll(umask) : 256u;
-      __syncthreads();
+      block_sync_lds();
       uint32_t limit = max_total - n < 256u ? max_total - n : 256u;
       {
         uint32_t fu = s_first_u[0];
@@ -1755,10 +1797,14 @@ LD_DEV AcceptResult accept_item(const DrawArgs &a, AcceptShared &sh, uint32_t it
         if (s_first_u[3] < fu) fu = s_first_u[3];
         if (fu < limit) { limit = fu; stalled = true; }
       }
+      if (win && !stalled) {
+        pre0 = result_at(res, pg, pg.res_off, n + limit + threadIdx.x);
+        if (threadIdx.x < retries) pre1 = result_at(res, pg, pg.res_off, n + limit + 256u + threadIdx.x);
+      }
       const bool succ = my_i < limit && code < kCodeOut;
       const unsigned long long smask = __ballot(succ);
       if (lane == 0) s_nsucc[wave] = (uint32_t)__builtin_popcountll(smask);
-      __syncthreads();
+      block_sync_lds();
       uint32_t before = 0, total = 0;
       for (uint32_t k = 0; k < 4; ++k) { if (k < wave) before += s_nsucc[k]; total += s_nsucc[k]; }
       const uint32_t rank = acc + before + (uint32_t)__builtin_popcountll(smask & lt_mask);
@@ -1799,7 +1845,7 @@ LD_DEV AcceptResult accept_item(const DrawArgs &a, AcceptShared &sh, uint32_t it
       // highest accepted attempt of the step
       const unsigned long long tmask = tmask0;
       if (lane == 0) s_top[wave] = tmask ? n + wave * 64u + (63u - (uint32_t)__builtin_clzll(tmask)) : 0u;
-      __syncthreads();
+      block_sync_lds();
       uint32_t taken = total < S - acc ? total : S - acc;
       if (taken) {
         uint32_t top = s_top[0];
@@ -1879,7 +1925,20 @@ LD_DEV AcceptResult accept_item_chroma(const DrawArgs &a, AcceptShared &sh, uint
     const bool valid = my_n < max_total;
     uint32_t code[3] = {kCodeFail, kCodeFail, kCodeFail};
     bool unresolved = false;
-    if (valid) {
+    if (retries <= kAcceptWinRetries) {
+      for (uint32_t c = 0; c < 3; ++c) stage_results(sh.rwin[c], res, pg, pg.res_off + c * cnt, n, 256u + retries);
+      __syncthreads();
+      if (valid) {
+#pragma unroll
+        for (uint32_t c = 0; c < 3; ++c) {
+          for (uint32_t t = 0; t <= retries; ++t) {
+            const uint32_t r = sh.rwin[c][my_i + t];
+            if (r == kCodeBeyond) { unresolved = unresolved || (pg.m_hi < m_limit); break; }
+            if (r != kCodeFail) { code[c] = r; break; }
+          }
+        }
+      }
+    } else if (valid) {
 #pragma unroll
       for (uint32_t c = 0; c < 3; ++c) {
         for (uint32_t t = 0; t <= retries; ++t) {
