@@ -317,6 +317,16 @@ int lentil_hip_sync(lentil_hip_ctx *ctx);
 int lentil_hip_download_aov(lentil_hip_ctx *ctx, uint32_t aov, float *host_rgba);
 int lentil_hip_download_accum(lentil_hip_ctx *ctx, uint32_t aov, float *host_rgba, float *host_weight);
 
+/* Thin lens with abb_chromatic > 0 (src/lentil_filter.cpp:393-406): every attempt that passes the optical
+ * vignetting test draws its colour channel from xor128 (src/global.h:22-27), whose state the reference
+ * keeps in function statics -- one per process, advanced by whichever thread gets there first.  Here the
+ * order is the single-threaded one (visits in stream order, attempts in order) and the state is explicit:
+ * it starts at the generator's initial constants, every lentil_hip_redistribute continues from where the
+ * previous one stopped, and a host that wants another starting point (or to mirror draws it made itself)
+ * reads / writes the four words x, y, z, w.  One GPU only. */
+int lentil_hip_set_xor128_state(lentil_hip_ctx *ctx, const uint32_t state[4]);
+int lentil_hip_get_xor128_state(lentil_hip_ctx *ctx, uint32_t state[4]);
+
 /* Closest-filtered AOVs across GPUs (the reference's single z-buffer, src/lentil.h:832-837).
  * deferred != 0: lentil_hip_redistribute leaves the per-pixel winner keys -- (bits of |Z|) << 32 |
  * (0xFFFFFFFF - frame-wide visit id), empty = all ones -- in lentil_hip_zkey_buffer instead of gathering

@@ -826,6 +826,10 @@ struct OrcFrame {
   std::vector<lentil_draw_record> log;
   bool keep_log = false;
   bool shadow = true;             /* keep the fp64 shadow accumulators */
+  /* xor128's state (src/global.h:22-27 keeps it in function statics, one per process): thin-lens abb_chromatic > 0
+   * draws every attempt's colour channel from it (src/lentil_filter.cpp:397).  Explicit here, one per frame object,
+   * advanced in the order this oracle walks the visits -- the single-threaded order. */
+  uint32_t xor_state[4] = {123456789u, 362436069u, 521288629u, 88675123u};
 };
 
 ORC_API OrcFrame *orc_frame_create(uint32_t xres, uint32_t yres, uint32_t n_aovs, const uint8_t *kind,
@@ -856,6 +860,8 @@ ORC_API const uint32_t *orc_frame_zvisit(const OrcFrame *F) { return F->zvisit.d
 ORC_API const double *orc_frame_buffer64(const OrcFrame *F, uint32_t aov) { return F->buffer64[aov].data(); }
 ORC_API const double *orc_frame_weight64(const OrcFrame *F) { return F->weight64.data(); }
 ORC_API void orc_frame_counters(const OrcFrame *F, lentil_counters *c) { *c = F->ctr; }
+ORC_API void orc_frame_set_xor128(OrcFrame *F, const uint32_t st[4]) { memcpy(F->xor_state, st, sizeof F->xor_state); }
+ORC_API void orc_frame_get_xor128(const OrcFrame *F, uint32_t st[4]) { memcpy(st, F->xor_state, sizeof F->xor_state); }
 ORC_API uint64_t orc_frame_log(const OrcFrame *F, lentil_draw_record *out, uint64_t cap) {
   uint64_t n = std::min<uint64_t>(cap, F->log.size());
   if (out && n) memcpy(out, F->log.data(), n * sizeof(lentil_draw_record));
@@ -1021,8 +1027,8 @@ static void do_visit(const lentil_params *P, const OrcLens *L, const OrcBokeh *B
     return;
   }
 
-  /* ---- ThinLens, src/lentil_filter.cpp:303-447 (abb_chromatic == 0 only: the chromatic branch draws
-   * its channel from the process-wide xor128 state, :397) ---- */
+  /* ---- ThinLens, src/lentil_filter.cpp:303-447.  abb_chromatic > 0 draws every attempt's channel from xor128
+   * (:397): OrcFrame::xor_state, advanced in this function's visit order ---- */
   for (int count = 0; count < samples && total_samples_taken < max_total_samples; ++count, ++total_samples_taken) {
     F->ctr.attempted_draws++;
     unsigned int seed = orc_tea8((uint32_t)(px * py + px), total_samples_taken);
@@ -1079,6 +1085,28 @@ static void do_visit(const lentil_params *P, const OrcLens *L, const OrcBokeh *B
     }
     const float image_dist_focusdist = (-focal_length * -P->focus_distance) / (-focal_length + -P->focus_distance); /* lentil.h:665-667 */
     float focusdist_intersection = std::abs(image_dist_focusdist / dir_from_lens_to_image_sample[2]);     /* :389 */
+    float rgb_weight[3] = {1.0f, 1.0f, 1.0f};                                                             /* :392 */
+    int channel = 0;
+    if (P->abb_chromatic > 0.0) {                                                                         /* :393-406 */
+      /* sensor point of the unaberrated ray, for scaling the aberration (less in the centre), :348-353 */
+      const float fi_u = std::abs(image_dist_focusdist / dir_from_lens_to_image_sample[2]);
+      const float fip_u[3] = {lens[0] + dir_from_lens_to_image_sample[0] * fi_u,
+                              lens[1] + dir_from_lens_to_image_sample[1] * fi_u,
+                              lens[2] + dir_from_lens_to_image_sample[2] * fi_u};
+      const float spu[2] = {fip_u[0] / fip_u[2], fip_u[1] / fip_u[2]};
+      const float ddx = 0.0f - spu[0], ddy = 0.0f - spu[1];
+      const float distance_to_center_unperturbed = sqrtf(ddx * ddx + ddy * ddy);      /* AiV2Dist (SDK, recalled) */
+      const float abb_chromatic_lateral = 5.0;
+      channel = static_cast<int>(std::floor((orc_xor128(F->xor_state) / 4294967296.0) * 3.0)) - 1;
+      if (channel == -1) { rgb_weight[0] = 3; rgb_weight[1] = 0; rgb_weight[2] = 0; }
+      else if (channel == 0) { rgb_weight[0] = 0; rgb_weight[1] = 3; rgb_weight[2] = 0; }
+      else if (channel == 1) { rgb_weight[0] = 0; rgb_weight[1] = 0; rgb_weight[2] = 3; }
+      float direction_shift = P->abb_chromatic_type == 0 /* green_magenta, src/lentil.h:82 */ ? std::abs(channel) : channel;
+      const float shift = direction_shift * P->abb_chromatic * abb_chromatic_lateral * distance_to_center_unperturbed;
+      /* Camera::get_image_dist_focusdist_thinlens_abberated, src/lentil.h:669-671 */
+      const float aberrated = (-focal_length * -(P->focus_distance + shift)) / (-focal_length + -(P->focus_distance + shift));
+      focusdist_intersection = std::abs(aberrated / dir_from_lens_to_image_sample[2]);
+    }
     float fip[3] = {lens[0] + dir_from_lens_to_image_sample[0] * focusdist_intersection,
                     lens[1] + dir_from_lens_to_image_sample[1] * focusdist_intersection,
                     lens[2] + dir_from_lens_to_image_sample[2] * focusdist_intersection};               /* :409 */
@@ -1101,9 +1129,11 @@ static void do_visit(const lentil_params *P, const OrcLens *L, const OrcBokeh *B
     const unsigned pixelnumber = ix + (iy * P->xres);                                                     /* :434 */
     for (uint32_t a = 0; a < F->n_aovs; a++)                                                              /* :442-445 */
       add_to_buffer(F, a, pixelnumber, aov_values[a], fitted_bidir_add_energy, depth,
-                    1.0f * inverse_sample_density * inv_samples);
+                    1.0f * inverse_sample_density * inv_samples, rgb_weight);
     F->ctr.accepted_draws++;
-    if (F->keep_log) F->log.push_back({(uint32_t)v, total_samples_taken, pixelnumber});
+    /* chromatic mode: the channel (0..2) rides in the attempt's top two bits, as on the polynomial-optics path */
+    if (F->keep_log) F->log.push_back({(uint32_t)v, total_samples_taken | ((uint32_t)(P->abb_chromatic > 0.0 ? channel + 1 : 0) << 30),
+                                       pixelnumber});
   }
 }
 
@@ -1122,7 +1152,6 @@ static inline void visit_pixel(const lentil_visits *V, uint64_t v, int *px, int 
 /* Runs visits [v_begin, v_end) in order.  Returns 0, or LENTIL_ERR_UNSUPPORTED. */
 ORC_API int orc_redistribute(const lentil_params *P, const OrcLens *L, const OrcBokeh *B, OrcFrame *F,
                              const lentil_visits *V, uint64_t v_begin, uint64_t v_end) {
-  if (P->cameraType == LENTIL_THINLENS && P->abb_chromatic > 0.0f) return LENTIL_ERR_UNSUPPORTED;
   if (P->cameraType == LENTIL_POLYNOMIAL_OPTICS && !L) return LENTIL_ERR_UNSUPPORTED;
   if (P->bokeh_enable_image && !B) return LENTIL_ERR_INVALID;
   for (uint64_t v = v_begin; v < v_end; v++) {

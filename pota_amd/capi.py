@@ -27,6 +27,7 @@ EXPORTS = [
     "lentil_hip_test_trace_bw_po", "lentil_hip_test_aperture_sample",
     "lentil_hip_lens_is_compiled", "lentil_hip_set_lens_mode",
     "lentil_hip_focus_search", "lentil_hip_test_y0_intersection",
+    "lentil_hip_set_xor128_state", "lentil_hip_get_xor128_state",
     "lentil_hip_host_alloc", "lentil_hip_host_free", "lentil_hip_visits_begin", "lentil_hip_visits_append",
     "lentil_hip_visits_wait", "lentil_hip_visits_end",
     "lentil_hip_comm_unique_id", "lentil_hip_comm_init", "lentil_hip_comm_destroy", "lentil_hip_allreduce",
@@ -101,6 +102,8 @@ def load_library():
         "lentil_hip_lens_is_compiled": (i, [vp]),
         "lentil_hip_set_lens_mode": (i, [vp, i]),
         "lentil_hip_focus_search": (i, [vp, C.c_double, C.c_double, C.POINTER(C.c_double)]),
+        "lentil_hip_set_xor128_state": (i, [vp, C.POINTER(C.c_uint32)]),
+        "lentil_hip_get_xor128_state": (i, [vp, C.POINTER(C.c_uint32)]),
         "lentil_hip_test_y0_intersection": (i, [vp, u64, vp, C.c_double, vp, vp, vp]),
         "lentil_hip_host_alloc": (i, [C.POINTER(vp), u64]),
         "lentil_hip_host_free": (i, [vp]),
@@ -277,6 +280,14 @@ class Context:
 
     def closest_gather(self):
         self._chk(self.lib.lentil_hip_closest_gather(self.h))
+
+    def set_xor128_state(self, state):
+        self._chk(self.lib.lentil_hip_set_xor128_state(self.h, (C.c_uint32 * 4)(*[int(x) for x in state])))
+
+    def get_xor128_state(self):
+        st = (C.c_uint32 * 4)()
+        self._chk(self.lib.lentil_hip_get_xor128_state(self.h, st))
+        return list(st)
 
     def focus_search(self, focal_distance, lam):
         best = C.c_double()

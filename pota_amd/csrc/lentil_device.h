@@ -808,8 +808,13 @@ LD_DEV void abb_coma_perturb(float lx, float ly, float lz, float rx, float ry, f
 }
 
 // a16 -- one thin-lens draw, src/lentil_filter.cpp:311-434 (abb_chromatic == 0)
-LD_DEV bool thinlens_draw(const lentil_params &P, const DevBokeh &B, const float *cdfRow, const float cs[3],
-                          int px, int py, uint32_t total_samples_taken, uint32_t &pixelnumber) {
+// The draw in two parts: the ray from the lens point towards the sample's image (everything up to the optical
+// vignetting test, src/lentil_filter.cpp:304-386), and its projection onto the sensor for a given image distance of
+// the focus plane (:389-434) -- chromatic aberration (:393-406) moves only that distance, per colour channel.
+struct TlRay { float lx, ly, dlx, dly, dlz; };
+
+LD_DEV bool thinlens_ray(const lentil_params &P, const DevBokeh &B, const float *cdfRow, const float cs[3],
+                         int px, int py, uint32_t total_samples_taken, TlRay &ray) {
   uint32_t seed = tea8((uint32_t)(px * py + px), total_samples_taken);
   const float f = P.focal_length;
   const float image_dist_samplepos = (-f * cs[2]) / (-f + cs[2]);
@@ -857,8 +862,19 @@ LD_DEV bool thinlens_draw(const lentil_params &P, const DevBokeh &B, const float
     const float dist = powf(fabsf(ovx), power) + powf(fabsf(ovy), power);
     if (dist > powf(radius, power)) return false;
   }
-  const float image_dist_focusdist =
-      (float)(((double)-f * -P.focus_distance) / ((double)-f + -P.focus_distance));
+  ray.lx = lx; ray.ly = ly; ray.dlx = dlx; ray.dly = dly; ray.dlz = dlz;
+  return true;
+}
+
+// Camera::get_image_dist_focusdist_thinlens / _abberated (src/lentil.h:665-671): double arithmetic narrowed to float
+LD_DEV float thinlens_image_dist_focus(const lentil_params &P, float shift) {
+  const float f = P.focal_length;
+  return (float)(((double)-f * -(P.focus_distance + (double)shift)) / ((double)-f + -(P.focus_distance + (double)shift)));
+}
+
+LD_DEV bool thinlens_project(const lentil_params &P, const TlRay &ray, float image_dist_focusdist, uint32_t &pixelnumber) {
+  const float f = P.focal_length;
+  const float lx = ray.lx, ly = ray.ly, lz = 0.0f, dlx = ray.dlx, dly = ray.dly, dlz = ray.dlz;
   const float fi = fabsf(image_dist_focusdist / dlz);
   const float fx = lx + dlx * fi, fy = ly + dly * fi, fz = lz + dlz * fi;
   float spx = fx / fz, spy = fy / fz;
@@ -881,6 +897,30 @@ LD_DEV bool thinlens_draw(const lentil_params &P, const DevBokeh &B, const float
   const int ix = (int)floorf(pixel_x), iy = (int)floorf(pixel_y);
   pixelnumber = (uint32_t)(ix + (iy * (int)P.xres));
   return true;
+}
+
+LD_DEV bool thinlens_draw(const lentil_params &P, const DevBokeh &B, const float *cdfRow, const float cs[3],
+                          int px, int py, uint32_t total_samples_taken, uint32_t &pixelnumber) {
+  TlRay ray;
+  if (!thinlens_ray(P, B, cdfRow, cs, px, py, total_samples_taken, ray)) return false;
+  const float image_dist_focusdist =
+      (float)(((double)-P.focal_length * -P.focus_distance) / ((double)-P.focal_length + -P.focus_distance));
+  return thinlens_project(P, ray, image_dist_focusdist, pixelnumber);
+}
+
+// abb_chromatic > 0 (src/lentil_filter.cpp:348-353, 393-406): the focus plane's image distance of colour channel
+// `channel` (-1 red, 0 green, 1 blue) -- shifted by channel (or |channel|: green/magenta) * abb_chromatic * 5 * the
+// distance of the unaberrated sensor point from the centre.  All factors float, multiplied left to right.
+LD_DEV float thinlens_chroma_image_dist(const lentil_params &P, const TlRay &ray, int channel) {
+  const float idf = thinlens_image_dist_focus(P, 0.0f);       // shift 0: x + 0.0 changes no bit of the double sum
+  const float fi = fabsf(idf / ray.dlz);
+  const float ux = ray.lx + ray.dlx * fi, uy = ray.ly + ray.dly * fi, uz = 0.0f + ray.dlz * fi;
+  const float sx = ux / uz, sy = uy / uz;
+  const float ddx = 0.0f - sx, ddy = 0.0f - sy;
+  const float dist = sqrtf(ddx * ddx + ddy * ddy);            // AiV2Dist((0, 0), sensor_position_unperturbed)
+  const float abb_chromatic_lateral = 5.0f;
+  const float direction_shift = P.abb_chromatic_type == 0 ? (float)(channel < 0 ? -channel : channel) : (float)channel;
+  return thinlens_image_dist_focus(P, direction_shift * P.abb_chromatic * abb_chromatic_lateral * dist);
 }
 
 }  // namespace lentil

@@ -1,6 +1,7 @@
 // lentil_hip.hip -- C-ABI of liblentil_hip.so (gfx950 only): host side.  Kernels: lentil_kernels.h.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -137,6 +138,13 @@ struct lentil_hip_ctx {
   lentil_draw_record *d_log = nullptr;
   uint64_t log_cap = 0;
   bool timed_draw = false, timed_resolve = false;
+  // thin lens with abb_chromatic > 0: the xor128 state the colour channels are drawn from (src/global.h:22-27), handed
+  // from pass to pass, and the pass's buffers
+  uint32_t xor_state[4] = {123456789u, 362436069u, 521288629u, 88675123u};
+  uint32_t *d_xor = nullptr, *d_tlc_res = nullptr;
+  uint64_t *d_tlc_off = nullptr;
+  uint2 *d_tlc_tasks = nullptr;
+  uint64_t tlc_res_cap = 0, tlc_off_cap = 0, tlc_tasks_cap = 0;
   double lens_housing_radius = 0.0;  // lens_aperture_housing_radius of the current table (focus search)
   struct LentilUpload *upload = nullptr;   // lentil_upload.h: the visit stream handed over piece by piece
   struct LentilComm *comm = nullptr; // lentil_comm.h: this context's RCCL communicator, if one was asked for
@@ -300,6 +308,7 @@ LENTIL_API int lentil_hip_destroy(lentil_hip_ctx *ctx) {
   (void)hipFree(ctx->d_ctr);
   if (ctx->h_ctr_pinned) (void)hipHostFree(ctx->h_ctr_pinned);
   (void)hipFree(ctx->d_ranges);
+  (void)hipFree(ctx->d_xor); (void)hipFree(ctx->d_tlc_res); (void)hipFree(ctx->d_tlc_off); (void)hipFree(ctx->d_tlc_tasks);
   (void)hipFree(ctx->d_log);
   for (auto &ev : ctx->ev) if (ev) (void)hipEventDestroy(ev);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -317,9 +326,6 @@ LENTIL_API int lentil_hip_set_params(lentil_hip_ctx *ctx, const lentil_params *p
   if (p->cameraType != LENTIL_THINLENS && p->cameraType != LENTIL_POLYNOMIAL_OPTICS)
     return fail(ctx, LENTIL_ERR_INVALID, "cameraType must be ThinLens or PolynomialOptics");
   if (p->xres == 0 || p->yres == 0) return fail(ctx, LENTIL_ERR_INVALID, "xres/yres must be non-zero");
-  if (p->cameraType == LENTIL_THINLENS && p->abb_chromatic > 0.0f)
-    return fail(ctx, LENTIL_ERR_UNSUPPORTED,
-                "thin-lens abb_chromatic > 0 is not implemented on the GPU (the channel comes from the process-wide xor128 state)");
   if (p->samples_override < 0 || p->samples_override > (1 << 24))
     return fail(ctx, LENTIL_ERR_INVALID, "samples_override out of range");
   if (ctx->have_frame && (p->xres != ctx->P.xres || p->yres != ctx->P.yres))
@@ -1381,6 +1387,93 @@ static int redistribute_streamed(lentil_hip_ctx *ctx, bool *streamed) {
   return LENTIL_OK;
 }
 
+// Thin lens with abb_chromatic > 0 (kernels: tl_chroma_*): scan, the work list put into visit order on the host, every
+// possible attempt's channel-independent part solved in parallel, then one block walks the items in order.
+static int redistribute_tl_chroma(lentil_hip_ctx *ctx) {
+  if (ctx->comm || ctx->closest_deferred)
+    return fail(ctx, LENTIL_ERR_UNSUPPORTED, "thin-lens abb_chromatic > 0: the order of the xor128 draws is defined for one GPU only");
+  ScanPlan plan;
+  int rc = plan_scan(ctx, plan);
+  if (rc) return rc;
+  lentil_hip_ctx::Chunk &ch = ctx->chunks[0];
+  ch.tile_begin = 0; ch.tile_end = plan.n_tiles;
+  ch.v_begin = 0; ch.v_end = ctx->V.n;
+  if ((rc = launch_scan(ctx, plan, ch, ctx->d_ctr, nullptr))) return rc;
+  ++ctx->last_scan_launches;
+  HIP_TRY(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
+  HIP_TRY(ctx, hipEventRecord(ctx->scans_done, ctx->stream));
+  DevCounters c0;
+  HIP_TRY(ctx, hipMemcpyAsync(&c0, ctx->d_ctr, sizeof(c0), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  if (c0.work_count > ctx->V.n) return fail(ctx, LENTIL_ERR_NOMEM, "work list overflow");
+  const uint32_t n_items = (uint32_t)c0.work_count;
+  if (!n_items) return LENTIL_OK;
+  std::vector<uint2> work(n_items);
+  HIP_TRY(ctx, hipMemcpy(work.data(), ctx->d_work, (size_t)n_items * sizeof(uint2), hipMemcpyDeviceToHost));
+  std::sort(work.begin(), work.end(), [](const uint2 &a, const uint2 &b) { return a.x < b.x; });      // iterator order
+  std::vector<uint64_t> off((size_t)n_items + 1);
+  std::vector<uint2> tasks;
+  uint64_t slots = 0;
+  for (uint32_t i = 0; i < n_items; ++i) {
+    off[i] = slots;
+    const uint64_t att = (uint64_t)work[i].y * 5ull;
+    for (uint64_t n0 = 0; n0 < att; n0 += 256) tasks.push_back(make_uint2(i, (uint32_t)n0));
+    slots += att;
+  }
+  off[n_items] = slots;
+  if (slots * 12ull > (64ull << 30)) return fail(ctx, LENTIL_ERR_NOMEM, "thin-lens abb_chromatic > 0: more than 64 GiB of attempt results");
+  auto grow_to = [&](auto **p, uint64_t &cap, uint64_t need) -> int {
+    if (cap >= need) return LENTIL_OK;
+    (void)hipFree(*p);
+    *p = nullptr;
+    cap = 0;
+    HIP_TRY(ctx, hipMalloc((void **)p, need * sizeof(**p)));
+    cap = need;
+    return LENTIL_OK;
+  };
+  if ((rc = grow_to(&ctx->d_tlc_res, ctx->tlc_res_cap, slots * 3ull + 4ull))) return rc;
+  if ((rc = grow_to(&ctx->d_tlc_off, ctx->tlc_off_cap, (uint64_t)n_items + 1))) return rc;
+  if ((rc = grow_to(&ctx->d_tlc_tasks, ctx->tlc_tasks_cap, (uint64_t)tasks.size() + 1))) return rc;
+  if (!ctx->d_xor) HIP_TRY(ctx, hipMalloc(&ctx->d_xor, 4 * sizeof(uint32_t)));
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->d_work, work.data(), (size_t)n_items * sizeof(uint2), hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->d_tlc_off, off.data(), off.size() * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->d_tlc_tasks, tasks.data(), tasks.size() * sizeof(uint2), hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->d_xor, ctx->xor_state, sizeof ctx->xor_state, hipMemcpyHostToDevice, ctx->stream));
+  TlChromaArgs ta{};
+  ta.P = ctx->P; ta.bokeh = ctx->bokeh; ta.V = ctx->V; ta.F = ctx->F;
+  ta.work = ctx->d_work; ta.n_items = n_items;
+  ta.att_off = ctx->d_tlc_off; ta.res = ctx->d_tlc_res;
+  ta.tasks = ctx->d_tlc_tasks; ta.n_tasks = (uint32_t)tasks.size();
+  ta.xor_state = ctx->d_xor;
+  ta.ctr = ctx->d_ctr;
+  ta.log = ctx->d_log; ta.log_cap = ctx->log_cap; ta.log_count = &ctx->d_ctr[ctx->n_chunks].log_count;
+  uint64_t blocks = tasks.size();
+  const uint64_t max_blocks = (uint64_t)ctx->num_cu * 8;
+  if (blocks > max_blocks) blocks = max_blocks;
+  hipLaunchKernelGGL(tl_chroma_solve_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, ta);
+  HIP_TRY(ctx, hipGetLastError());
+  hipLaunchKernelGGL(tl_chroma_walk_kernel, dim3(1), dim3(256), 0, ctx->stream, ta);
+  HIP_TRY(ctx, hipGetLastError());
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->xor_state, ctx->d_xor, sizeof ctx->xor_state, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));      // (the host vectors above are the copies' sources)
+  ctx->last_rounds = 1;
+  return LENTIL_OK;
+}
+
+LENTIL_API int lentil_hip_set_xor128_state(lentil_hip_ctx *ctx, const uint32_t state[4]) {
+  CHECK_CTX(ctx);
+  if (!state) return fail(ctx, LENTIL_ERR_INVALID, "state is null");
+  memcpy(ctx->xor_state, state, sizeof ctx->xor_state);
+  return LENTIL_OK;
+}
+
+LENTIL_API int lentil_hip_get_xor128_state(lentil_hip_ctx *ctx, uint32_t state[4]) {
+  CHECK_CTX(ctx);
+  if (!state) return fail(ctx, LENTIL_ERR_INVALID, "state is null");
+  memcpy(state, ctx->xor_state, sizeof ctx->xor_state);
+  return LENTIL_OK;
+}
+
 LENTIL_API int lentil_hip_redistribute(lentil_hip_ctx *ctx) {
   CHECK_CTX(ctx);
   if (!ctx->have_params || !ctx->have_frame || !ctx->have_visits)
@@ -1409,7 +1502,12 @@ LENTIL_API int lentil_hip_redistribute(lentil_hip_ctx *ctx) {
   for (auto &ch : ctx->chunks) ch.heavy_pending = false;
   ctx->last_scan_launches = 0;
   bool streamed = false;
-  {
+  const bool tl_chroma = P.cameraType == LENTIL_THINLENS && P.abb_chromatic > 0.0f;
+  if (tl_chroma) {
+    if (ctx->V.n) { const int rc = redistribute_tl_chroma(ctx); if (rc) return rc; }
+    else { HIP_TRY(ctx, hipEventRecord(ctx->ev[1], ctx->stream)); HIP_TRY(ctx, hipEventRecord(ctx->scans_done, ctx->stream)); }
+    streamed = true;          // (nothing of the chunked form below runs)
+  } else {
     const int rc = redistribute_streamed(ctx, &streamed);
     if (rc) return rc;
   }

@@ -2113,6 +2113,219 @@ __global__ __launch_bounds__(256) void accept_kernel(DrawArgs a) {
   flush_row_range(a.ctr, rmin, rmax_p1);
 }
 
+// ---------------------------------------------------------------------------------------
+// Thin lens with abb_chromatic > 0 (src/lentil_filter.cpp:393-406): every attempt that survives the optical
+// vignetting test draws its colour channel from xor128 (src/global.h:22-27) -- ONE generator state for the whole
+// process upstream, so the channel of an attempt depends on how many such attempts every earlier visit made, and
+// those numbers depend on the channels drawn (a channel moves the focus plane, hence whether the draw lands inside the
+// frame and counts).  The order is defined here as the single-threaded one: visits in iterator order, the generator
+// state handed in and out (lentil_hip_set_xor128_state / _get_xor128_state).
+//   tl_chroma_solve_kernel : everything that does not depend on the channel drawn, for every attempt an item could
+//                            make (n < 5 * samples): vignetted?, and the outcome for each of the three channels.
+//   tl_chroma_walk_kernel  : ONE block walks the items in visit order, 256 attempts per step: prefix count of the
+//                            survivors = each attempt's index into the generator's output, channel, outcome, ordered
+//                            acceptance, splat.  Sequential in the items by construction (~15 us per item).
+// ---------------------------------------------------------------------------------------
+struct TlChromaArgs {
+  lentil_params P;
+  DevBokeh bokeh;
+  VisitsDev V;
+  FrameDev F;
+  const uint2 *work;             // items (visit, samples), sorted by visit
+  uint32_t n_items;
+  const uint64_t *att_off;       // [n_items + 1]: first attempt slot of every item (an item has 5 * samples slots)
+  uint32_t *res;                 // [slots][3]: outcome per channel; all three kCodeFail = vignetted
+  const uint2 *tasks;            // (item, first attempt) per block of tl_chroma_solve_kernel
+  uint32_t n_tasks;
+  uint32_t *xor_state;           // [4] x, y, z, w: in and out
+  DevCounters *ctr;
+  lentil_draw_record *log;
+  uint64_t log_cap;
+  unsigned long long *log_count;
+};
+
+__global__ __launch_bounds__(256) void tl_chroma_solve_kernel(TlChromaArgs a) {
+  __shared__ float s_cdfRow[kMaxBokehRows];
+  const bool row_in_lds = a.P.bokeh_enable_image && a.bokeh.y <= kMaxBokehRows;
+  if (row_in_lds)
+    for (int i = threadIdx.x; i < a.bokeh.y; i += blockDim.x) s_cdfRow[i] = a.bokeh.cdfRow[i];
+  __syncthreads();
+  const float *cdfRow = row_in_lds ? s_cdfRow : a.bokeh.cdfRow;
+  for (uint32_t q = blockIdx.x; q < a.n_tasks; q += gridDim.x) {
+    const uint2 t = a.tasks[q];
+    const ItemVisit h = load_work_visit(a.P, a.V, a.work[t.x], 0.0);
+    const uint32_t n = t.y + threadIdx.x;
+    if (n >= h.samples * 5u) continue;
+    uint32_t code[3] = {kCodeFail, kCodeFail, kCodeFail};
+    TlRay ray;
+    if (thinlens_ray(a.P, a.bokeh, cdfRow, h.I.cs, h.px, h.py, n, ray)) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        uint32_t pix;
+        code[c] = thinlens_project(a.P, ray, thinlens_chroma_image_dist(a.P, ray, c - 1), pix) ? pix : kCodeOut;
+      }
+    }
+    uint32_t *dst = a.res + (a.att_off[t.x] + n) * 3ull;
+    dst[0] = code[0]; dst[1] = code[1]; dst[2] = code[2];
+  }
+}
+
+LD_DEV uint32_t xor128_next(uint32_t &x, uint32_t &y, uint32_t &z, uint32_t &w) {      // src/global.h:22-27
+  const uint32_t t = x ^ (x << 11);
+  x = y; y = z; z = w;
+  return w = (w ^ (w >> 19) ^ t ^ (t >> 8));
+}
+
+__global__ __launch_bounds__(256) void tl_chroma_walk_kernel(TlChromaArgs a) {
+  __shared__ uint32_t s_x[256];            // the step's generator outputs, in order
+  __shared__ uint32_t s_state[256][4];     // generator state after each of them
+  __shared__ uint32_t s_cnt[4], s_cnt2[4], s_pix[4][64], s_same[4][64], s_ch[4][64], s_key[4][64];
+  __shared__ uint32_t s_cur[4];            // current generator state
+  __shared__ float s_val[4 * LENTIL_MAX_AOVS + 1];
+  __shared__ uint32_t s_off[4 * LENTIL_MAX_AOVS + 1];
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  const unsigned long long lt_mask = (1ull << lane) - 1ull;
+  if (threadIdx.x < 4) s_cur[threadIdx.x] = a.xor_state[threadIdx.x];
+  unsigned long long tot_attempted = 0, tot_accepted = 0;
+  uint32_t rmin = 0x7FFFFFFFu, rmax_p1 = 0u;
+  __syncthreads();
+  for (uint32_t item = 0; item < a.n_items; ++item) {
+    const ItemVisit h = load_work_visit(a.P, a.V, a.work[item], 0.0);
+    const uint32_t S = h.samples, max_total = S * 5u;
+    const float ae = h.I.add_energy, w = h.w;
+    const unsigned long long zk = (a.F.zkey || a.F.zkey_dbg) ? closest_key(h.I.depth, visit_gid(a.V, h.visit)) : 0ull;
+    const uint32_t *res = a.res + a.att_off[item] * 3ull;
+    // what an accepted draw adds (gaussian AOVs: (value + add_energy) * w per component, then the weight itself)
+    uint32_t U = 1;
+    for (uint32_t k = 0; k < a.F.n_aovs; ++k) if (!(a.F.closest_mask & (1u << k))) U += 4;
+    __syncthreads();
+    if (threadIdx.x < a.F.n_aovs * 4u) {
+      const uint32_t k = threadIdx.x >> 2, c = threadIdx.x & 3u;
+      if (!(a.F.closest_mask & (1u << k))) {
+        uint32_t slot = 0;
+        for (uint32_t j = 0; j < k; ++j) if (!(a.F.closest_mask & (1u << j))) slot += 4;
+        const float4 v = k == 0 ? h.rgba : a.V.extra[k - 1][h.visit];
+        const float vc = c == 0 ? v.x : (c == 1 ? v.y : (c == 2 ? v.z : v.w));
+        s_val[slot + c] = (vc + ae) * w;
+        s_off[slot + c] = 4u * k + c;
+      }
+    }
+    if (threadIdx.x == 0) { s_val[U - 1] = w; s_off[U - 1] = 4u * a.F.n_aovs; }
+    __syncthreads();
+    uint32_t n = 0, acc = 0, last_n = 0;
+    bool done = false;
+    while (!done && acc < S && n < max_total) {
+      const uint32_t my_n = n + threadIdx.x;
+      const bool valid = my_n < max_total;
+      uint32_t code[3] = {kCodeFail, kCodeFail, kCodeFail};
+      if (valid) { code[0] = res[my_n * 3ull]; code[1] = res[my_n * 3ull + 1]; code[2] = res[my_n * 3ull + 2]; }
+      const bool survives = valid && !(code[0] == kCodeFail && code[1] == kCodeFail && code[2] == kCodeFail);
+      // index of this attempt's generator output within the step: survivors before it
+      const unsigned long long vm = __ballot(survives);
+      if (lane == 0) s_cnt[wave] = (uint32_t)__builtin_popcountll(vm);
+      __syncthreads();
+      uint32_t vbefore = 0, vtotal = 0;
+      for (uint32_t k = 0; k < 4; ++k) { if (k < wave) vbefore += s_cnt[k]; vtotal += s_cnt[k]; }
+      const uint32_t xi = vbefore + (uint32_t)__builtin_popcountll(vm & lt_mask);
+      if (threadIdx.x == 0) {
+        uint32_t x = s_cur[0], y = s_cur[1], z = s_cur[2], ww = s_cur[3];
+        for (uint32_t i = 0; i < vtotal; ++i) {
+          s_x[i] = xor128_next(x, y, z, ww);
+          s_state[i][0] = x; s_state[i][1] = y; s_state[i][2] = z; s_state[i][3] = ww;
+        }
+      }
+      __syncthreads();
+      int channel = 0;
+      uint32_t my_code = kCodeFail;
+      if (survives) {
+        channel = (int)floor(((double)s_x[xi] / 4294967296.0) * 3.0) - 1;      // :397
+        my_code = code[channel + 1];
+      }
+      const bool succ = survives && my_code < kCodeOut;
+      // the attempt at which the count reaches `samples` ends the loop: later attempts are not made (and draw nothing)
+      const unsigned long long sm = __ballot(succ);
+      if (lane == 0) s_cnt2[wave] = (uint32_t)__builtin_popcountll(sm);
+      __syncthreads();
+      uint32_t sbefore = 0, stotal = 0;
+      for (uint32_t k = 0; k < 4; ++k) { if (k < wave) sbefore += s_cnt2[k]; stotal += s_cnt2[k]; }
+      const uint32_t rank = acc + sbefore + (uint32_t)__builtin_popcountll(sm & lt_mask);      // successes before this attempt
+      const bool take = succ && rank < S;
+      const bool is_last = take && rank + 1u == S;        // the S-th success: the last attempt the reference makes
+      const unsigned long long lm = __ballot(is_last);
+      __syncthreads();
+      if (lane == 0) s_cnt[wave] = lm ? wave * 64u + (uint32_t)__builtin_ctzll(lm) : 0xFFFFFFFFu;
+      __syncthreads();
+      uint32_t end_i = 0xFFFFFFFFu;                        // position of that attempt within the step, if it is here
+      for (uint32_t k = 0; k < 4; ++k) if (s_cnt[k] != 0xFFFFFFFFu) end_i = s_cnt[k];
+      const uint32_t step_n = (max_total - n) < 256u ? (max_total - n) : 256u;
+      const uint32_t executed = end_i != 0xFFFFFFFFu ? end_i + 1u : step_n;      // attempts of this step that are made
+      // generator outputs consumed: survivors among the executed attempts
+      const unsigned long long cm = __ballot(survives && threadIdx.x < executed);
+      __syncthreads();
+      if (lane == 0) s_cnt2[wave] = (uint32_t)__builtin_popcountll(cm);
+      __syncthreads();
+      const uint32_t consumed = s_cnt2[0] + s_cnt2[1] + s_cnt2[2] + s_cnt2[3];
+      // splat the accepted draws: channel c feeds colour component c only, three-fold; alpha and weight as they are
+      const unsigned long long tm = __ballot(take);
+      const uint32_t T = (uint32_t)__builtin_popcountll(tm);
+      if (take) {
+        const uint32_t pix = my_code;
+        const uint32_t row = pix / a.P.xres;
+        rmin = row < rmin ? row : rmin;
+        rmax_p1 = row + 1u > rmax_p1 ? row + 1u : rmax_p1;
+        const uint32_t slot = (uint32_t)__builtin_popcountll(tm & lt_mask);
+        s_pix[wave][slot] = pix;
+        s_ch[wave][slot] = (uint32_t)(channel + 1);
+        s_key[wave][slot] = (pix << 2) | (uint32_t)(channel + 1);       // (frames of up to 2^30 pixels)
+        if (a.F.touched) a.F.touched[pix >> 6] = 1;
+        if (a.F.zkey) atomicMin(a.F.zkey + pix, zk);
+        if (a.F.zkey_dbg) atomicMin(a.F.zkey_dbg + pix, zk);
+        if (a.log_cap) {
+          const unsigned long long li = atomicAdd(a.log_count, 1ull);
+          if (li < a.log_cap) { a.log[li].visit = h.visit; a.log[li].attempt = my_n | ((uint32_t)(channel + 1) << 30); a.log[li].pixel = pix; }
+        }
+      }
+      __syncthreads();
+      // draws of the step with the same pixel and channel: one atomic of count x value (accept_item does the same)
+      count_same_pixel(s_key[wave], s_same[wave], T, lane);
+      __syncthreads();
+      for (uint32_t q = lane; q < T * U; q += 64u) {
+        const uint32_t d = q / U, ch = q - d * U;
+        const uint32_t same = s_same[wave][d];
+        if (!same) continue;
+        float val = s_val[ch];
+        if (ch != U - 1u) {
+          const uint32_t comp = s_off[ch] & 3u;
+          if (comp < 3u) {
+            if (comp != s_ch[wave][d]) continue;          // rgb_weight is 0 there
+            val = val * 3.0f;
+          }
+        }
+        atomicAdd(a.F.acc + (size_t)s_pix[wave][d] * a.F.stride + s_off[ch], (float)same * val);
+      }
+      uint32_t taken = stotal < S - acc ? stotal : S - acc;
+      acc += taken;
+      n += executed;
+      if (end_i != 0xFFFFFFFFu) { done = true; last_n = n; }
+      __syncthreads();
+      if (threadIdx.x == 0 && consumed) {
+        s_cur[0] = s_state[consumed - 1][0]; s_cur[1] = s_state[consumed - 1][1];
+        s_cur[2] = s_state[consumed - 1][2]; s_cur[3] = s_state[consumed - 1][3];
+      }
+      __syncthreads();
+    }
+    (void)last_n;
+    tot_attempted += n;            // total_samples_taken when the loop ends
+    tot_accepted += acc;
+  }
+  if (threadIdx.x == 0) {
+    for (int i = 0; i < 4; ++i) a.xor_state[i] = s_cur[i];
+    if (tot_attempted) atomicAdd(&a.ctr->attempted, tot_attempted);
+    if (tot_accepted) atomicAdd(&a.ctr->accepted, tot_accepted);
+  }
+  flush_row_range(a.ctr, rmin, rmax_p1);
+}
+
 // closest-filter AOVs: copy the winning visit's value into AOVData::buffer (src/lentil.h:835)
 __global__ __launch_bounds__(256) void closest_gather_kernel(FrameDev F, VisitsDev V) {
   const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;

@@ -65,6 +65,8 @@ def load():
         "orc_frame_buffer64": (pd, [vp, u32]),
         "orc_frame_weight64": (pd, [vp]),
         "orc_frame_counters": (None, [vp, C.POINTER(_abi.Counters)]),
+        "orc_frame_set_xor128": (None, [vp, C.POINTER(C.c_uint32)]),
+        "orc_frame_get_xor128": (None, [vp, C.POINTER(C.c_uint32)]),
         "orc_frame_log": (u64, [vp, vp, u64]),
         "orc_frame_merge": (None, [vp, vp]),
         "orc_redistribute": (i, [C.POINTER(_abi.Params), vp, vp, vp, C.POINTER(_abi.Visits), u64, u64]),

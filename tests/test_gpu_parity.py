@@ -865,6 +865,50 @@ def test_thinlens_coma_vignetting_distortion(orc, gpu_ctx_factory, coma):
     check_frame(ctx, ref)
 
 
+@pytest.mark.parametrize("ctype,coma,vignetting", [(0, 0.0, 0.0), (1, 0.35, 2.0)], ids=["green-magenta", "red-cyan+coma+vignetting"])
+def test_thinlens_chromatic_aberration(orc, gpu_ctx_factory, ctype, coma, vignetting):
+    """Thin lens with abb_chromatic > 0 (src/lentil_filter.cpp:393-406): every attempt that survives the optical
+    vignetting test draws its colour channel from xor128; the channel shifts the focus plane with the distance from
+    the frame centre and feeds one colour component three-fold.  The order of the generator's draws is the
+    single-threaded one on both sides: accepted (attempt, channel, pixel) lists bit-identical, the generator state
+    after the pass identical -- also over a second pass that continues the stream, and from a chosen starting state.
+    A gaussian and a closest extra AOV ride along."""
+    W, H, M = 96, 64, 9
+    kinds = [0, 0, 1]
+    p = common.tl_setup(W, H, samples_override=48, abb_chromatic=0.6, abb_chromatic_type=ctype, abb_coma=coma,
+                        optical_vignetting_distance=vignetting, optical_vignetting_radius=1.5)
+    visits, cols = common.make_stream(p, W, H, M, f_hi=0.02, n_extra=2)
+    ctx = gpu_ctx_factory()
+    start = None
+    for frame in range(3):
+        ref = oracle_lib.Frame(orc, p, n_aovs=3, kinds=kinds, keep_log=True)
+        if frame == 2:                                   # a starting state of the host's choosing
+            start = [0x12345678, 0x9ABCDEF0, 0x0F1E2D3C, 0x4B5A6978]
+            ctx.set_xor128_state(start)
+        if start is not None:
+            orc.orc_frame_set_xor128(ref.h, (C.c_uint32 * 4)(*start))
+        ref.run(None, None, visits)
+        rc = ref.counters()
+        assert rc.redistributed_visits > 100 and rc.accepted_draws > 5000
+        c = gpu_run(ctx, p, None, visits, n_aovs=3, kinds=kinds)
+        assert (c.redistributed_visits, c.attempted_draws, c.accepted_draws) == \
+            (rc.redistributed_visits, rc.attempted_draws, rc.accepted_draws)
+        check_logs(ctx, ref)
+        chan = ctx.draw_log()[:, 1] >> 30
+        assert set(np.unique(chan)) == {0, 1, 2}
+        st = (C.c_uint32 * 4)()
+        orc.orc_frame_get_xor128(ref.h, st)
+        assert ctx.get_xor128_state() == list(st)
+        start = list(st)                                 # the next pass continues the stream
+        if vignetting:
+            assert rc.attempted_draws > rc.accepted_draws        # some attempts were vignetted / left the frame
+        check_frame(ctx, ref, n_aovs=3, kinds=kinds)
+        ref.close()
+    # the three colour components of a highlight's disc differ: the channels are focused at different distances
+    img = ctx.download_aov(0).reshape(p.yres, p.xres, 4)
+    assert float(np.abs(img[..., 0] - img[..., 2]).max()) > 0.0
+
+
 def test_sub_batches_when_the_result_pool_is_small(orc, monkeypatch):
     """A chunk whose draws do not fit the result pool is processed in sub-batches of items (and single
     chunk / many chunks give the same answer)."""
@@ -1071,10 +1115,16 @@ def test_empty_stream_and_error_paths(gpu_ctx_factory):
     ctx.resolve()
     buf, w = ctx.download_accum(0)
     assert not buf.any() and not w.any()
-    bad = common.tl_setup(32, 16)
-    bad.abb_chromatic = 0.5            # thin lens: the channel comes from the process-wide xor128 state
+    # thin-lens abb_chromatic > 0 draws its channels from one xor128 stream: defined for one GPU, refused across GPUs
+    chroma = common.tl_setup(32, 16)
+    chroma.abb_chromatic = 0.5
+    ctx.set_params(chroma)
+    ctx.set_closest_exchange(True)
+    visits, cols = common.make_stream(chroma, 32, 16, 9, f_hi=0.05)
+    ctx.upload_visits(visits)
+    ctx.clear_frame()
     with pytest.raises(capi.LentilError) as ei:
-        ctx.set_params(bad)
+        ctx.redistribute()
     assert ei.value.code == _abi.ERR_UNSUPPORTED
 
 

@@ -361,3 +361,34 @@ def test_seed_depends_on_attempt_plus_try_only(orc):
         orc.orc_po_aperture_sample(C.byref(p), None, 1234, n + t, a)
         orc.orc_po_aperture_sample(C.byref(p), None, 1234, (n + t) + 0, b)
         assert list(a) == list(b)
+
+
+def test_thinlens_chromatic_draws_one_xor128_value_per_surviving_attempt(orc):
+    """Thin lens, abb_chromatic > 0 (src/lentil_filter.cpp:393-406): without optical vignetting every attempt draws
+    exactly one channel from xor128 (src/global.h:22-27), so the generator has advanced by the number of attempts; the
+    channels come out in thirds; channel c feeds colour component c only."""
+    import ctypes as C
+    import common
+    import oracle_lib
+    W, H, M = 48, 32, 9
+    p = common.tl_setup(W, H, samples_override=32, abb_chromatic=0.7)
+    visits, cols = common.make_stream(p, W, H, M, f_hi=0.03)
+    ref = oracle_lib.Frame(orc, p, n_aovs=1, keep_log=True)
+    ref.run(None, None, visits)
+    rc = ref.counters()
+    assert rc.attempted_draws > 1000
+    st = (C.c_uint32 * 4)()
+    orc.orc_frame_get_xor128(ref.h, st)
+    replay = (C.c_uint32 * 4)()
+    orc.orc_xor128_init(replay)
+    for _ in range(int(rc.attempted_draws)):
+        orc.orc_xor128(replay)
+    assert list(replay) == list(st)
+    chan = ref.log()[:, 1] >> 30
+    counts = np.bincount(chan, minlength=3)
+    assert counts.min() > 0.25 * counts.sum()
+    # a highlight's energy arrives in one component per draw: the three components of the sum differ pixel by pixel
+    buf = ref.buffer(0)
+    lit = buf[:, :3].max(axis=1) > 10.0
+    assert lit.any() and (buf[lit, 0] != buf[lit, 1]).any()
+    ref.close()
