@@ -608,7 +608,11 @@ LENTIL_API int lentil_hip_bind_visits(lentil_hip_ctx *ctx, const lentil_visits *
   int rc = check_visits(ctx, v);
   if (rc) return rc;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
-  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  // nothing of the previous stream is freed and the work list is large enough: the next pass simply follows the last
+  // one on the stream (the caller keeps the columns it bound alive until the pass that reads them is done, as ever)
+  const bool frees = !ctx->owned_visit_mem.empty() || ctx->upload != nullptr ||
+                     !(v->n <= ctx->work_cap && ctx->d_work);
+  if (frees) HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   free_visits(ctx);
   upload_release(ctx, true);
   to_dev(ctx->V, v);
