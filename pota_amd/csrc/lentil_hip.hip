@@ -126,7 +126,9 @@ struct lentil_hip_ctx {
   int32_t dirty_lo = 0, dirty_hi = 0;
   bool dirty_known = false;
   hipEvent_t scans_done = nullptr;   // after the last chunk's scan of a pass
-  hipStream_t pub_stream = nullptr;  // streamed pass: publish_kernel
+  bool slow_live = true;             // LENTIL_SLOW_LIVE=0: stragglers of a streamed pass wait for their round's solve kernel to end
+  hipEvent_t ev_slow = nullptr, ev_round = nullptr;
+  hipStream_t pub_stream = nullptr;  // streamed pass: publish_kernel, then the live straggler kernel
   hipEvent_t pub_done = nullptr;
   bool pass_pending = false;         // a redistribute ran whose rows have not been asked for yet
   bool closest_deferred = false;     // multi-GPU: the caller min-reduces the keys before the gather
@@ -213,6 +215,8 @@ LENTIL_API int lentil_hip_create(int device, lentil_hip_ctx **out_ctx) {
   }
   HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->scans_done, hipEventDisableTiming));
   HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->pub_stream, hipStreamNonBlocking));
+  HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_slow, hipEventDisableTiming));
+  HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_round, hipEventDisableTiming));
   HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->pub_done, hipEventDisableTiming));
   if (const char *ft = getenv("LENTIL_FORCE_TABLES")) ctx->use_generated = !(ft[0] == '1');
   if (const char *fc = getenv("LENTIL_FIRST_CHUNK_FRAC")) {
@@ -240,6 +244,7 @@ LENTIL_API int lentil_hip_create(int device, lentil_hip_ctx **out_ctx) {
   if (ctx->solve_max_blocks < 1) ctx->solve_max_blocks = 1;
   if (const char *e = getenv("LENTIL_STREAM")) ctx->stream_mode = !(e[0] == '0');
   if (const char *e = getenv("LENTIL_SCAN_DMA")) ctx->scan_dma = !(e[0] == '0');
+  if (const char *e = getenv("LENTIL_SLOW_LIVE")) ctx->slow_live = !(e[0] == '0');
   if (const char *e = getenv("LENTIL_STREAM_BELOW")) ctx->stream_below = strtoull(e, nullptr, 10);
   if (const char *e = getenv("LENTIL_STREAM_BLOCKS")) ctx->stream_blocks = atoi(e);
   if (ctx->stream_blocks < 1) ctx->stream_blocks = 1;
@@ -305,6 +310,8 @@ LENTIL_API int lentil_hip_destroy(lentil_hip_ctx *ctx) {
   if (ctx->scans_done) (void)hipEventDestroy(ctx->scans_done);
   if (ctx->pub_stream) { (void)hipStreamSynchronize(ctx->pub_stream); (void)hipStreamDestroy(ctx->pub_stream); }
   if (ctx->pub_done) (void)hipEventDestroy(ctx->pub_done);
+  if (ctx->ev_slow) (void)hipEventDestroy(ctx->ev_slow);
+  if (ctx->ev_round) (void)hipEventDestroy(ctx->ev_round);
   (void)hipFree(ctx->d_ctr);
   if (ctx->h_ctr_pinned) (void)hipHostFree(ctx->h_ctr_pinned);
   (void)hipFree(ctx->d_ranges);
@@ -706,20 +713,20 @@ static int grow(lentil_hip_ctx *ctx, T **p, uint64_t need) {
 }
 
 template <bool kStream>
-static void launch_solve_po(lentil_hip_ctx *ctx, const DrawArgs &da, hipStream_t st, unsigned blocks) {
+static void launch_solve_po(lentil_hip_ctx *ctx, const DrawArgs &da, hipStream_t st, unsigned blocks, unsigned threads = 256) {
   const bool chroma = da.n_channels == 3;       // chromatic aberration: three wavelength channels per attempt
   bool launched = false;
 #define LENTIL_LAUNCH_GEN(NAME)                                                                          \
   if (!launched && ctx->use_generated && ctx->lens_hash == gen::Lens_##NAME::kTableHash) {                \
-    if (chroma) hipLaunchKernelGGL((solve_po_kernel<GenLens<gen::Lens_##NAME>, false, true, kStream>), dim3(blocks), dim3(256), 0, st, da); \
-    else hipLaunchKernelGGL((solve_po_kernel<GenLens<gen::Lens_##NAME>, false, false, kStream>), dim3(blocks), dim3(256), 0, st, da); \
+    if (chroma) hipLaunchKernelGGL((solve_po_kernel<GenLens<gen::Lens_##NAME>, false, true, kStream>), dim3(blocks), dim3(threads), 0, st, da); \
+    else hipLaunchKernelGGL((solve_po_kernel<GenLens<gen::Lens_##NAME>, false, false, kStream>), dim3(blocks), dim3(threads), 0, st, da); \
     launched = true;                                                                                     \
   }
   LENTIL_GENERATED_LENSES(LENTIL_LAUNCH_GEN)
 #undef LENTIL_LAUNCH_GEN
   if (!launched) {
-    if (chroma) hipLaunchKernelGGL((solve_po_kernel<LdsLens, true, true, kStream>), dim3(blocks), dim3(256), 0, st, da);
-    else hipLaunchKernelGGL((solve_po_kernel<LdsLens, true, false, kStream>), dim3(blocks), dim3(256), 0, st, da);
+    if (chroma) hipLaunchKernelGGL((solve_po_kernel<LdsLens, true, true, kStream>), dim3(blocks), dim3(threads), 0, st, da);
+    else hipLaunchKernelGGL((solve_po_kernel<LdsLens, true, false, kStream>), dim3(blocks), dim3(threads), 0, st, da);
   }
 }
 
@@ -771,11 +778,14 @@ static int size_chunk_buffers(lentil_hip_ctx *ctx, lentil_hip_ctx::Chunk &ch, ui
   // stragglers are about 0.1 % of the solves; a full queue only means they stay in their lanes
   // (only chunks below slow_below draws park at all, which bounds the queue at a few tens of MB)
   const uint64_t park_units = units < 8 * ctx->slow_below ? units : 8 * ctx->slow_below;
-  const uint64_t slow_need = park_units / 128 + 4096;
+  const uint64_t slow_need = park_units / 128 + 4096 + (uint64_t)ctx->num_cu * 4;     // (+ a live queue's end markers)
   if (ctx->slow_at > 0 && slow_need > ch.slow_cap) {
     const uint64_t nc = slow_need + slow_need / 4;
     if ((rc = grow(ctx, &ch.slow, nc))) return rc;
     ch.slow_cap = nc;
+    // a live queue tells a filled slot by its tag: no stale ones from whoever had this memory before
+    HIP_TRY(ctx, hipMemsetAsync(ch.slow, 0, nc * sizeof(SlowRec), ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   }
   return LENTIL_OK;
 }
@@ -787,7 +797,10 @@ static void bind_chunk_buffers(const lentil_hip_ctx::Chunk &ch, DrawArgs &da) {
   da.task_cap = (uint32_t)(ch.task_cap > 0xFFFFFFF0ull ? 0xFFFFFFF0ull : ch.task_cap);
   da.pool_cap = ch.pool_cap < 0xFFFFFFFFull ? ch.pool_cap : 0xFFFFFFFFull;
   da.slow = ch.slow;
-  da.slow_cap = (uint32_t)(ch.slow_cap < 0xFFFFFFF0ull ? ch.slow_cap : 0xFFFFFFF0ull);
+  // (the last num_cu * 4 records are kept for a live queue's end markers)
+  const uint64_t usable = ch.slow_cap > (uint64_t)4096 ? ch.slow_cap - 1024 : 0;
+  da.slow_cap = (uint32_t)(usable < 0xFFFFFFF0ull ? usable : 0xFFFFFFF0ull);
+  if (!usable) da.slow = nullptr;
 }
 
 // rounds with a host check after each (used when the blind rounds did not finish a chunk, and for
@@ -1239,6 +1252,7 @@ static int redistribute_streamed(lentil_hip_ctx *ctx, bool *streamed) {
     ctx->epoch = 1u;
     HIP_TRY(ctx, hipMemsetAsync(ch.tasks[0], 0, ch.task_cap * sizeof(Task), ctx->stream));
     if (ctx->d_ranges) HIP_TRY(ctx, hipMemsetAsync(ctx->d_ranges, 0, ctx->range_cap * sizeof(uint64_t), ctx->stream));
+    if (ch.slow) HIP_TRY(ctx, hipMemsetAsync(ch.slow, 0, ch.slow_cap * sizeof(SlowRec), ctx->stream));
   }
   const uint32_t retries = (uint32_t)(P.vignetting_retries < 0 ? 0 : P.vignetting_retries);
   const bool few = ctx->est_sum_total < ctx->slow_below;
@@ -1299,20 +1313,34 @@ static int redistribute_streamed(lentil_hip_ctx *ctx, bool *streamed) {
   // ev[0]).  Submitted AFTER what they wait for -- the scan, then the publishers: should the streams share a
   // hardware queue, each finds its producer ahead of it there.
   const unsigned a_blocks = (unsigned)ctx->num_cu * (unsigned)ctx->stream_blocks;
+  // Live straggler queue: solve_slow_kernel runs beside the solve kernels from the end of the scan on and takes the
+  // parked solves as they come (one wave per CU, on the publishers' stream behind them).  B then brings three waves
+  // per block instead of four: with A's two per SIMD that leaves one SIMD per CU room for a straggler wave (152 VGPRs).
+  const bool live = ctx->slow_live && da.slow != nullptr && P.cameraType == LENTIL_POLYNOMIAL_OPTICS;
+  const unsigned b_threads = live ? 192u : 256u;
   unsigned b_blocks;
   {
-    int b_per_cu = ctx->solve_max_blocks - ctx->stream_blocks;
+    int b_per_cu = live ? 1 : ctx->solve_max_blocks - ctx->stream_blocks;
     if (b_per_cu < 1) b_per_cu = 1;
     const uint64_t want = (nch * (ctx->est_sum_total / 64 + ctx->est_items_total) + 3) / 4;
     uint64_t b = (uint64_t)ctx->num_cu * (uint64_t)b_per_cu;
     if (want < b) b = want < 1 ? 1 : want;
     b_blocks = (unsigned)b;
   }
-  pa.end_tasks = (a_blocks + b_blocks) * 4u;       // every first-round solve wave may hold one ticket past the last task
+  da.slow_live = live ? 1 : 0;
+  da.slow_waves = live ? (uint32_t)ctx->num_cu : 0u;
+  da.pub_total = (uint32_t)ctx->publish_waves;
+  pa.end_tasks = a_blocks * 4u + b_blocks * (b_threads / 64u);       // every first-round solve wave may hold one ticket past the last task
   HIP_TRY(ctx, hipStreamWaitEvent(ctx->pub_stream, ctx->ev[0], 0));
   hipLaunchKernelGGL(publish_kernel, dim3((unsigned)ctx->publish_waves), dim3(64), 0, ctx->pub_stream, pa);
   HIP_TRY(ctx, hipGetLastError());
   HIP_TRY(ctx, hipEventRecord(ctx->pub_done, ctx->pub_stream));
+  if (live) {
+    // (behind the publishers on their stream: they end with the scan, whose registers this kernel's waves need)
+    hipLaunchKernelGGL(solve_slow_kernel, dim3(da.slow_waves), dim3(64), 0, ctx->pub_stream, da);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_slow, ctx->pub_stream));
+  }
   HIP_TRY(ctx, hipStreamWaitEvent(ch.stream, ctx->ev[0], 0));
   da.instance = 0;
   launch_solve_po<true>(ctx, da, ch.stream, a_blocks);
@@ -1321,11 +1349,12 @@ static int redistribute_streamed(lentil_hip_ctx *ctx, bool *streamed) {
 
   // B: the rest of the CUs' room, once the scan's waves have left
   da.instance = 1;
-  launch_solve_po<true>(ctx, da, ctx->stream, b_blocks);
+  launch_solve_po<true>(ctx, da, ctx->stream, b_blocks, b_threads);
   HIP_TRY(ctx, hipGetLastError());
   HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ch.done, 0));
   HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->pub_done, 0));
-  launch_slow(ctx, da, ctx->stream);
+  if (live) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_slow, 0));
+  else launch_slow(ctx, da, ctx->stream);
   const uint64_t acc_max = (uint64_t)ctx->num_cu * (uint64_t)ctx->accept_max_blocks;
   const uint64_t acc_want = ctx->est_items_total + ctx->est_items_total / 4 + 1;
   const unsigned accept_blocks = (unsigned)(acc_want > acc_max ? acc_max : acc_want);
@@ -1335,10 +1364,22 @@ static int redistribute_streamed(lentil_hip_ctx *ctx, bool *streamed) {
   if (const char *e = getenv("LENTIL_BLIND_ROUNDS")) { blind_rounds = atoi(e); if (blind_rounds < 1) blind_rounds = 1; if (blind_rounds > 8) blind_rounds = 8; }
   for (int round = 1; round < blind_rounds; ++round) {
     da.parity = round & 1; da.round = round;
-    launch_solve(ctx, da, ctx->stream, (unsigned)ctx->num_cu);
+    if (live) {
+      // the round's stragglers beside its solves: the straggler kernel on the other stream, released by the accept
+      // before it; this round's accept waits for both
+      HIP_TRY(ctx, hipEventRecord(ctx->ev_round, ctx->stream));
+      launch_solve_po<false>(ctx, da, ctx->stream, (unsigned)ctx->num_cu);
+      HIP_TRY(ctx, hipStreamWaitEvent(ctx->pub_stream, ctx->ev_round, 0));
+      hipLaunchKernelGGL(solve_slow_kernel, dim3(da.slow_waves), dim3(64), 0, ctx->pub_stream, da);
+      HIP_TRY(ctx, hipEventRecord(ctx->ev_slow, ctx->pub_stream));
+      HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_slow, 0));
+    } else {
+      launch_solve(ctx, da, ctx->stream, (unsigned)ctx->num_cu);
+    }
     hipLaunchKernelGGL(accept_kernel, dim3(accept_blocks), dim3(256), 0, ctx->stream, da);
     HIP_TRY(ctx, hipGetLastError());
   }
+  da.slow_live = 0;       // (rounds the host adds one by one, below, park and finish their stragglers the plain way)
   const int C = ctx->n_chunks;
   HIP_TRY(ctx, hipMemcpyAsync(ctx->h_ctr_pinned, ctx->d_ctr, sizeof(DevCounters) * C, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -1353,6 +1394,18 @@ static int redistribute_streamed(lentil_hip_ctx *ctx, bool *streamed) {
       fprintf(stderr, "[stream] redo: who %u ticket %u epoch %u range_head %u pubs_done %u scan_done %u | fallback %llu stuck %u | items %llu (cap %u) tasks %u (cap %u) pool %llu (cap %llu) ranges %u (cap %u)\n",
               c.stuck & 3u, c.stuck >> 2, ctx->epoch, c.range_head, c.publishers_done, c.scan_blocks_done, c.fallback, c.stuck, c.work_count, pub.item_cap, c.n_tasks[0], pub.task_cap, c.pool_used[0], (unsigned long long)pub.pool_cap,
               c.n_ranges, plan.sa.range_cap);
+    if (getenv("LENTIL_STREAM_DEBUG")) {
+      HIP_TRY(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
+      HIP_TRY(ctx, hipEventSynchronize(ctx->ev[2]));
+      float ms_scan = 0.f, ms_all = 0.f;
+      (void)hipEventElapsedTime(&ms_scan, ctx->ev[0], ctx->ev[1]);
+      (void)hipEventElapsedTime(&ms_all, ctx->ev[0], ctx->ev[2]);
+      fprintf(stderr, "[stream] scan %.3f ms, pass until the read-back %.3f ms\n", ms_scan, ms_all);
+    }
+    if (getenv("LENTIL_STREAM_DEBUG"))
+      fprintf(stderr, "[stream] stragglers: live %d waves_done %u/%u (round 1: %u) parked %u/%u heads %u/%u cap %u waves %u rounds_used %llu\n", (int)live,
+              c.waves_done[0], c.waves_started[0], c.waves_done[1], c.n_slow[0], c.n_slow[1], c.slow_head[0], c.slow_head[1],
+              da.slow_cap, da.slow_waves, c.rounds_used);
     if (c.stuck) {
       ++ctx->n_stuck;
       HIP_TRY(ctx, hipMemsetAsync((char *)ctx->d_ctr + offsetof(DevCounters, stuck), 0, sizeof(unsigned int), ch.stream));

@@ -40,6 +40,7 @@ struct DevCounters {
   unsigned long long pool_used[2];
   unsigned int n_slow[2];            // stragglers parked by this round's solve kernel
   unsigned int slow_head[2];
+  unsigned int waves_started[2], waves_done[2];   // live straggler queue: solve waves of the round that have begun / exited
   // rows of the frame this pass has added to (zero-initialised: "none"): max over (INT_MAX - row), max over (row + 1)
   unsigned int inv_row_min, row_max_p1;
   // streamed pass: scan blocks that have published everything they found (solve_po_kernel<.., kStream> polls it)
@@ -1020,7 +1021,7 @@ __global__ __launch_bounds__(64) void publish_kernel(PublishArgs a) {
             (uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)rec);
       if (((uint32_t)(rec >> 32) >> kTaskTagShift) == a.S.epoch) break;
       if (__builtin_amdgcn_s_memrealtime() - t0 > kStuckTicks) {
-        if (lane == 0) a.ctr->stuck = 1u | (ticket << 2);
+        if (lane == 0) atomicCAS(&a.ctr->stuck, 0u, 1u | (ticket << 2));      // (the first to give up is the one worth knowing)
         over = true;
         break;
       }
@@ -1087,8 +1088,11 @@ struct SlowRec {           // 128 B
   double x, y, dx, dy, sqr_err, sqr_ap_err;
   int32_t k, error;
   uint32_t res_idx, chan;
-  uint32_t pad[6];
+  uint32_t pad[4];
+  uint64_t tag;            // live queue (DrawArgs::slow_live): (pass epoch << 8 | round) << 32 | 1 record, 2 end marker
 };
+static_assert(sizeof(SlowRec) == 128, "SlowRec is 128 bytes");
+constexpr uint64_t kSlowRecord = 1, kSlowEnd = 2;
 
 struct DrawArgs {
   lentil_params P;
@@ -1137,7 +1141,14 @@ struct DrawArgs {
   int32_t n_channels;
   int32_t chroma_weights;  // abb_chromatic > 0: channel c only feeds colour component c, three-fold
   double lambda[3];
+  // live straggler queue: solve_slow_kernel runs BESIDE the solve kernel and takes parked solves as they come (every
+  // solve that reaches slow_at iterations is parked, not only those of waves running dry); the last solve wave to
+  // exit -- solver_waves_total of them, over all launches of the round -- writes one end marker per straggler wave
+  int32_t slow_live;
+  uint32_t slow_waves;     // waves of the straggler kernel (one end marker each)
+  uint32_t pub_total;      // streamed pass: publish_kernel waves (the task queue is complete when all have signed off)
 };
+LD_DEV uint64_t slow_tag(const DrawArgs &a, uint64_t what) { return ((uint64_t)((a.epoch << 8) | ((uint32_t)a.round & 0xFFu)) << 32) | what; }
 
 LD_DEV ItemVisit load_item_visit(const DrawArgs &a, uint32_t item, double lens_length) {
   return load_work_visit(a.P, a.V, a.work[item], lens_length);
@@ -1267,7 +1278,7 @@ __global__ __launch_bounds__(256) void solve_po_kernel(DrawArgs a) {
     const uint32_t nx = (uint32_t)a.parity ^ 1u;
     a.ctr->n_tasks[nx] = 0; a.ctr->task_head[nx] = 0; a.ctr->n_active[nx] = 0; a.ctr->active_head[nx] = 0;
     a.ctr->pool_used[nx] = 0;
-    a.ctr->n_slow[nx] = 0; a.ctr->slow_head[nx] = 0;
+    a.ctr->n_slow[nx] = 0; a.ctr->slow_head[nx] = 0; a.ctr->waves_done[nx] = 0; a.ctr->waves_started[nx] = 0;
   }
   const uint32_t par = (uint32_t)a.parity;
   const Task *tasks = a.tasks[par];
@@ -1276,6 +1287,7 @@ __global__ __launch_bounds__(256) void solve_po_kernel(DrawArgs a) {
   if constexpr (!kStream) n_tasks = a.ctr->n_tasks[par] < a.task_cap ? a.ctr->n_tasks[par] : a.task_cap;
   const uint32_t lane = lane_id();
   const unsigned long long lt_mask = (1ull << lane) - 1ull;
+  if (a.slow_live && a.slow && lane == 0) atomicAdd(&a.ctr->waves_started[par], 1u);
 
   // wave-uniform cursor into the current task
   uint32_t cur_item = 0, cur_m = 0, cur_res = 0, cur_left = 0, cur_chan = 0;
@@ -1322,7 +1334,7 @@ __global__ __launch_bounds__(256) void solve_po_kernel(DrawArgs a) {
           if ((w1_hi >> kTaskTagShift) != a.epoch) {
             // nothing there (yet): back to the solves in flight (an idle wave naps, below)
             if (__builtin_amdgcn_s_memrealtime() - ticket_t0 > kStuckTicks) {
-              if (lane == 0) a.ctr->stuck = 2u | (ticket << 2);      // the host redoes the pass chunk by chunk
+              if (lane == 0) atomicCAS(&a.ctr->stuck, 0u, 2u | (ticket << 2));      // the host redoes the pass chunk by chunk
               no_more = true;
             }
             break;
@@ -1419,7 +1431,7 @@ __global__ __launch_bounds__(256) void solve_po_kernel(DrawArgs a) {
     // ... and only its last few lanes: a lens whose solves routinely take more than slow_at iterations (the petzval
     // table: heavy vignetting, thousands of such solves per round) would otherwise send them all to a kernel that
     // spends a wave on each (config 4: 17.5 ms per frame with that, 3 ms of it per solve_slow_kernel launch).
-    if (parking && no_more && __builtin_popcountll(__ballot(busy)) <= a.slow_max_lanes) {
+    if (parking && (a.slow_live || (no_more && __builtin_popcountll(__ballot(busy)) <= a.slow_max_lanes))) {
       const bool park = busy && s.k >= a.slow_at;
       const unsigned long long pmask = __ballot(park);
       if (pmask) {
@@ -1429,13 +1441,48 @@ __global__ __launch_bounds__(256) void solve_po_kernel(DrawArgs a) {
         const uint32_t slot = base + (uint32_t)__builtin_popcountll(pmask & lt_mask);
         if (park && slot < a.slow_cap) {       // a full queue leaves the solve where it is
           double *d = reinterpret_cast<double *>(a.slow + slot);
-          d[0] = target[0]; d[1] = target[1]; d[2] = target[2]; d[3] = ap_x; d[4] = ap_y;
-          d[5] = s.x; d[6] = s.y; d[7] = s.dx; d[8] = s.dy; d[9] = s.sqr_err; d[10] = s.sqr_ap_err;
-          uint32_t *u = reinterpret_cast<uint32_t *>(d + 11);
-          u[0] = (uint32_t)s.k; u[1] = (uint32_t)s.error; u[2] = res_idx; u[3] = kChroma ? cur_chan_lane : 0u;
+          if (a.slow_live) {
+            // read by a wave of solve_slow_kernel on another CU while both kernels run: atomics on both sides, the
+            // payload waited for before the word that publishes it
+            const double pay[11] = {target[0], target[1], target[2], ap_x, ap_y, s.x, s.y, s.dx, s.dy, s.sqr_err, s.sqr_ap_err};
+#pragma unroll
+            for (int i = 0; i < 11; ++i) st_agent64(d + i, (uint64_t)__double_as_longlong(pay[i]));
+            st_agent64(d + 11, (uint64_t)(uint32_t)s.k | ((uint64_t)(uint32_t)s.error << 32));
+            st_agent64(d + 12, (uint64_t)res_idx | ((uint64_t)(kChroma ? cur_chan_lane : 0u) << 32));
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            st_agent64(d + 15, slow_tag(a, kSlowRecord));
+          } else {
+            d[0] = target[0]; d[1] = target[1]; d[2] = target[2]; d[3] = ap_x; d[4] = ap_y;
+            d[5] = s.x; d[6] = s.y; d[7] = s.dx; d[8] = s.dy; d[9] = s.sqr_err; d[10] = s.sqr_ap_err;
+            uint32_t *u = reinterpret_cast<uint32_t *>(d + 11);
+            u[0] = (uint32_t)s.k; u[1] = (uint32_t)s.error; u[2] = res_idx; u[3] = kChroma ? cur_chan_lane : 0u;
+          }
           busy = false;
         }
       }
+    }
+  }
+  if (a.slow_live && a.slow) {
+    // Everything this wave parked has arrived.  The straggler queue is closed by whichever wave finds, on leaving, that
+    // every wave that has begun has left and every task has been taken (and, streamed, published): no solve can be
+    // parked any more.  Waves of a launch that begin later -- blocks that had to wait for room, perhaps for the very
+    // room the straggler kernel's waves take up -- find the task queue at its end, park nothing, and come to the same
+    // conclusion: the end markers are simply written again.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    uint32_t close = 0;
+    if (lane == 0) {
+      const uint32_t done = atomicAdd(&a.ctr->waves_done[par], 1u) + 1u;
+      const uint32_t begun = ld_coherent32(&a.ctr->waves_started[par]);
+      const uint32_t taken = ld_coherent32(&a.ctr->task_head[par]);
+      const uint32_t published = kStream ? ld_coherent32(&a.ctr->n_tasks[par]) : n_tasks;
+      const bool complete = !kStream || ld_coherent32(&a.ctr->publishers_done) >= a.pub_total;
+      close = (done == begun && complete && taken >= published) ? 1u : 0u;
+    }
+    if (__builtin_amdgcn_readfirstlane(close)) {
+      uint32_t n = ld_coherent32(&a.ctr->n_slow[par]);
+      if (n > a.slow_cap) n = a.slow_cap;
+      for (uint32_t i = lane; i < a.slow_waves; i += 64u)
+        st_agent64(reinterpret_cast<double *>(a.slow + n + i) + 15, slow_tag(a, kSlowEnd));      // (the queue holds slow_cap + slow_waves records)
     }
   }
   unsigned long long it64 = st_iters, tr64 = st_tries, rd64 = st_rounds;
@@ -1554,9 +1601,11 @@ __global__ __launch_bounds__(64) void solve_slow_kernel(DrawArgs a) {
   __shared__ CoopShared sh;
   __shared__ uint32_t s_q;
   const uint32_t par = (uint32_t)a.parity;
-  uint32_t n_slow = a.ctr->n_slow[par];
-  if (n_slow > a.slow_cap) n_slow = a.slow_cap;
-  if (n_slow == 0u || blockIdx.x >= n_slow) return;
+  uint32_t n_slow = a.slow_live ? 0xFFFFFFFFu : a.ctr->n_slow[par];
+  if (!a.slow_live) {
+    if (n_slow > a.slow_cap) n_slow = a.slow_cap;
+    if (n_slow == 0u || blockIdx.x >= n_slow) return;
+  }
   const uint32_t lane = threadIdx.x;
   const uint32_t nt = a.lens->n_terms;
   for (uint32_t i = lane; i < nt; i += 64u) sh.terms[i] = a.terms[i];
@@ -1601,7 +1650,38 @@ __global__ __launch_bounds__(64) void solve_slow_kernel(DrawArgs a) {
     __syncthreads();
     const uint32_t q = s_q;
     if (q >= n_slow) break;
-    const SlowRec r = a.slow[q];
+    SlowRec r;
+    if (a.slow_live) {
+      // the solve kernel is still running: wait for this slot's record, or for the end marker the last solve wave leaves
+      if (q >= a.slow_cap + a.slow_waves) break;
+      const uint64_t *src = reinterpret_cast<const uint64_t *>(a.slow + q);
+      uint64_t tag = 0;
+      uint32_t naps = 1u;
+      const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
+      bool over = false;
+      while (true) {
+        if (lane == 0) tag = ld_coherent64(src + 15);
+        tag = ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(tag >> 32)) << 32) | (uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)tag);
+        if ((tag >> 32) == (slow_tag(a, 0) >> 32) && (uint32_t)tag != 0u) break;
+        if (__builtin_amdgcn_s_memrealtime() - t0 > kStuckTicks) { if (lane == 0) atomicCAS(&a.ctr->stuck, 0u, 3u | ((q & 0xFFFFFu) << 2) | ((uint32_t)a.round << 24)); over = true; break; }
+        for (uint32_t i = 0; i < naps; ++i) __builtin_amdgcn_s_sleep(64);
+        if (naps < 8u) naps <<= 1;
+      }
+      if (over || (uint32_t)tag == (uint32_t)kSlowEnd) break;
+      uint64_t wv = 0;
+      if (lane < 13u) wv = ld_coherent64(src + lane);
+      auto word = [&](int i) { return ((uint64_t)(uint32_t)__shfl((int)(wv >> 32), i) << 32) | (uint64_t)(uint32_t)__shfl((int)(uint32_t)wv, i); };
+      r.tx = __longlong_as_double((long long)word(0)); r.ty = __longlong_as_double((long long)word(1)); r.tz = __longlong_as_double((long long)word(2));
+      r.ap_x = __longlong_as_double((long long)word(3)); r.ap_y = __longlong_as_double((long long)word(4));
+      r.x = __longlong_as_double((long long)word(5)); r.y = __longlong_as_double((long long)word(6));
+      r.dx = __longlong_as_double((long long)word(7)); r.dy = __longlong_as_double((long long)word(8));
+      r.sqr_err = __longlong_as_double((long long)word(9)); r.sqr_ap_err = __longlong_as_double((long long)word(10));
+      const uint64_t w11 = word(11), w12 = word(12);
+      r.k = (int32_t)(uint32_t)w11; r.error = (int32_t)(uint32_t)(w11 >> 32);
+      r.res_idx = (uint32_t)w12; r.chan = (uint32_t)(w12 >> 32);
+    } else {
+      r = a.slow[q];
+    }
     L.lp = sh.lambda_pow[r.chan < 3u ? r.chan : 0u];
     const double target[3] = {r.tx, r.ty, r.tz};
     NewtonState s;
