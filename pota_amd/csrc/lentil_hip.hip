@@ -126,6 +126,7 @@ struct lentil_hip_ctx {
   int32_t dirty_lo = 0, dirty_hi = 0;
   bool dirty_known = false;
   hipEvent_t scans_done = nullptr;   // after the last chunk's scan of a pass
+  bool overlap_rounds = true;        // LENTIL_OVERLAP_ROUNDS=0: a streamed pass's second round starts after its first accept has ended
   bool slow_live = true;             // LENTIL_SLOW_LIVE=0: stragglers of a streamed pass wait for their round's solve kernel to end
   hipEvent_t ev_slow = nullptr, ev_round = nullptr;
   // a streamed pass resolves the direct sums beside its solves (LENTIL_EARLY_RESOLVE=0: not)
@@ -252,6 +253,7 @@ LENTIL_API int lentil_hip_create(int device, lentil_hip_ctx **out_ctx) {
   if (const char *e = getenv("LENTIL_STREAM")) ctx->stream_mode = !(e[0] == '0');
   if (const char *e = getenv("LENTIL_SCAN_DMA")) ctx->scan_dma = !(e[0] == '0');
   if (const char *e = getenv("LENTIL_SLOW_LIVE")) ctx->slow_live = !(e[0] == '0');
+  if (const char *e = getenv("LENTIL_OVERLAP_ROUNDS")) ctx->overlap_rounds = !(e[0] == '0');
   if (const char *e = getenv("LENTIL_STREAM_BELOW")) ctx->stream_below = strtoull(e, nullptr, 10);
   if (const char *e = getenv("LENTIL_STREAM_BLOCKS")) ctx->stream_blocks = atoi(e);
   if (ctx->stream_blocks < 1) ctx->stream_blocks = 1;
@@ -778,6 +780,7 @@ static int size_chunk_buffers(lentil_hip_ctx *ctx, lentil_hip_ctx::Chunk &ch, ui
     ch.task_cap = nc;
     // a streamed pass tells a filled slot by its tag: no stale bits (now: the chunk's own stream may fill it next)
     HIP_TRY(ctx, hipMemsetAsync(ch.tasks[0], 0, nc * sizeof(Task), ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(ch.tasks[1], 0, nc * sizeof(Task), ctx->stream));      // (second round beside the first accept)
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   }
   if (units > ch.pool_cap) {
@@ -1264,6 +1267,7 @@ static int redistribute_streamed(lentil_hip_ctx *ctx, bool *streamed) {
     // the 22-bit tag has come round: wipe what older passes left in the queues
     ctx->epoch = 1u;
     HIP_TRY(ctx, hipMemsetAsync(ch.tasks[0], 0, ch.task_cap * sizeof(Task), ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(ch.tasks[1], 0, ch.task_cap * sizeof(Task), ctx->stream));
     if (ctx->d_ranges) HIP_TRY(ctx, hipMemsetAsync(ctx->d_ranges, 0, ctx->range_cap * sizeof(uint64_t), ctx->stream));
     if (ch.slow) HIP_TRY(ctx, hipMemsetAsync(ch.slow, 0, ch.slow_cap * sizeof(SlowRec), ctx->stream));
   }
@@ -1351,7 +1355,8 @@ static int redistribute_streamed(lentil_hip_ctx *ctx, bool *streamed) {
   }
   da.slow_live = live ? 1 : 0;
   da.slow_waves = live ? (uint32_t)ctx->num_cu : 0u;
-  da.pub_total = (uint32_t)ctx->publish_waves;
+  da.producers_done = &ctx->d_ctr->publishers_done;
+  da.producers_total = (uint32_t)ctx->publish_waves;
   pa.end_tasks = a_blocks * 4u + b_blocks * (b_threads / 64u);       // every first-round solve wave may hold one ticket past the last task
   HIP_TRY(ctx, hipStreamWaitEvent(ctx->pub_stream, ctx->ev[0], 0));
   hipLaunchKernelGGL(publish_kernel, dim3((unsigned)ctx->publish_waves), dim3(64), 0, ctx->pub_stream, pa);
@@ -1380,21 +1385,53 @@ static int redistribute_streamed(lentil_hip_ctx *ctx, bool *streamed) {
   const uint64_t acc_max = (uint64_t)ctx->num_cu * (uint64_t)ctx->accept_max_blocks;
   const uint64_t acc_want = ctx->est_items_total + ctx->est_items_total / 4 + 1;
   const unsigned accept_blocks = (unsigned)(acc_want > acc_max ? acc_max : acc_want);
-  hipLaunchKernelGGL(accept_kernel, dim3(accept_blocks), dim3(256), 0, ctx->stream, da);
-  HIP_TRY(ctx, hipGetLastError());
   int blind_rounds = ctx->est_rounds_total < 2 ? 2 : (ctx->est_rounds_total > 6 ? 6 : ctx->est_rounds_total);
   if (const char *e = getenv("LENTIL_BLIND_ROUNDS")) { blind_rounds = atoi(e); if (blind_rounds < 1) blind_rounds = 1; if (blind_rounds > 8) blind_rounds = 8; }
+  // Second round beside the first accept: the accept kernel hands out the next round's tasks as it goes (tagged slots,
+  // end markers from its last block), a kStream solve kernel -- one block per CU, which fits beside four accept blocks
+  // -- takes them as they come, the straggler kernel beside both.  Launched AFTER the accept, so that a profiler that
+  // serialises kernels runs them in an order that completes.
+  const bool overlap = live && ctx->overlap_rounds && blind_rounds >= 2;
+  {
+    DrawArgs d0 = da;
+    d0.emit_live = overlap ? 1 : 0;
+    d0.end_tasks = (uint32_t)ctx->num_cu * 4u;
+    if (overlap) HIP_TRY(ctx, hipEventRecord(ctx->ev_round, ctx->stream));      // everything the first accept waits for
+    hipLaunchKernelGGL(accept_kernel, dim3(accept_blocks), dim3(256), 0, ctx->stream, d0);
+    HIP_TRY(ctx, hipGetLastError());
+  }
   for (int round = 1; round < blind_rounds; ++round) {
     da.parity = round & 1; da.round = round;
     if (live) {
       // the round's stragglers beside its solves: the straggler kernel on the other stream, released by the accept
-      // before it; this round's accept waits for both
-      HIP_TRY(ctx, hipEventRecord(ctx->ev_round, ctx->stream));
-      launch_solve_po<false>(ctx, da, ctx->stream, (unsigned)ctx->num_cu);
-      HIP_TRY(ctx, hipStreamWaitEvent(ctx->pub_stream, ctx->ev_round, 0));
-      hipLaunchKernelGGL(solve_slow_kernel, dim3(da.slow_waves), dim3(64), 0, ctx->pub_stream, da);
-      HIP_TRY(ctx, hipEventRecord(ctx->ev_slow, ctx->pub_stream));
-      HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_slow, 0));
+      // before it (round 1 with `overlap`: by what that accept itself waited for); this round's accept waits for both
+      const bool beside = overlap && round == 1;
+      if (beside) {
+        DrawArgs d1 = da;
+        d1.no_reset = 1;
+        d1.producers_done = &ctx->d_ctr->accept_done[0];
+        d1.producers_total = accept_blocks;
+        HIP_TRY(ctx, hipStreamWaitEvent(ch.stream, ctx->ev_round, 0));
+        launch_solve_po<true>(ctx, d1, ch.stream, (unsigned)ctx->num_cu);
+        HIP_TRY(ctx, hipGetLastError());
+        HIP_TRY(ctx, hipEventRecord(ch.done, ch.stream));
+        HIP_TRY(ctx, hipStreamWaitEvent(ctx->pub_stream, ctx->ev_round, 0));
+        hipLaunchKernelGGL(solve_slow_kernel, dim3(d1.slow_waves), dim3(64), 0, ctx->pub_stream, d1);
+        HIP_TRY(ctx, hipEventRecord(ctx->ev_slow, ctx->pub_stream));
+        HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ch.done, 0));
+        HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_slow, 0));
+        // (the first accept and this round's solves are done: the first round's queues can go back to empty for what
+        // the accept below schedules)
+        hipLaunchKernelGGL(reset_round_kernel, dim3(1), dim3(1), 0, ctx->stream, ctx->d_ctr, 0u);
+      } else {
+        da.producers_done = nullptr; da.producers_total = 0;
+        HIP_TRY(ctx, hipEventRecord(ctx->ev_round, ctx->stream));
+        launch_solve_po<false>(ctx, da, ctx->stream, (unsigned)ctx->num_cu);
+        HIP_TRY(ctx, hipStreamWaitEvent(ctx->pub_stream, ctx->ev_round, 0));
+        hipLaunchKernelGGL(solve_slow_kernel, dim3(da.slow_waves), dim3(64), 0, ctx->pub_stream, da);
+        HIP_TRY(ctx, hipEventRecord(ctx->ev_slow, ctx->pub_stream));
+        HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_slow, 0));
+      }
     } else {
       launch_solve(ctx, da, ctx->stream, (unsigned)ctx->num_cu);
     }
@@ -1428,6 +1465,8 @@ static int redistribute_streamed(lentil_hip_ctx *ctx, bool *streamed) {
       fprintf(stderr, "[stream] stragglers: live %d waves_done %u/%u (round 1: %u) parked %u/%u heads %u/%u cap %u waves %u rounds_used %llu\n", (int)live,
               c.waves_done[0], c.waves_started[0], c.waves_done[1], c.n_slow[0], c.n_slow[1], c.slow_head[0], c.slow_head[1],
               da.slow_cap, da.slow_waves, c.rounds_used);
+    if (c.stuck && c.rounds_used)
+      return fail(ctx, LENTIL_ERR_HIP, "streamed pass stalled after its first accept: the frame holds a part of the pass (clear it and run the pass again)");
     if (c.stuck) {
       ++ctx->n_stuck;
       HIP_TRY(ctx, hipMemsetAsync((char *)ctx->d_ctr + offsetof(DevCounters, stuck), 0, sizeof(unsigned int), ch.stream));

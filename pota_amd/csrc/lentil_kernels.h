@@ -41,6 +41,7 @@ struct DevCounters {
   unsigned int n_slow[2];            // stragglers parked by this round's solve kernel
   unsigned int slow_head[2];
   unsigned int waves_started[2], waves_done[2];   // live straggler queue: solve waves of the round that have begun / exited
+  unsigned int accept_done[2];       // accept blocks of the round that have emitted everything they will (DrawArgs::emit_live)
   // rows of the frame this pass has added to (zero-initialised: "none"): max over (INT_MAX - row), max over (row + 1)
   unsigned int inv_row_min, row_max_p1;
   // streamed pass: scan blocks that have published everything they found (solve_po_kernel<.., kStream> polls it)
@@ -1146,7 +1147,15 @@ struct DrawArgs {
   // exit -- solver_waves_total of them, over all launches of the round -- writes one end marker per straggler wave
   int32_t slow_live;
   uint32_t slow_waves;     // waves of the straggler kernel (one end marker each)
-  uint32_t pub_total;      // streamed pass: publish_kernel waves (the task queue is complete when all have signed off)
+  // whoever fills the task queue a kStream solve kernel reads: publish_kernel's waves in the first round, the accept
+  // kernel's blocks when a round's solves run beside the accept that schedules them.  Complete when all have signed off.
+  const unsigned int *producers_done;
+  uint32_t producers_total;
+  // accept kernel: the next round's tasks go out tagged and through atomics (its solve kernel is already running and
+  // takes them as they come), end_tasks end markers behind them from the last block
+  int32_t emit_live;
+  uint32_t end_tasks;
+  int32_t no_reset;        // solve kernel: leave the other parity's queues alone (the accept beside it is using them)
 };
 LD_DEV uint64_t slow_tag(const DrawArgs &a, uint64_t what) { return ((uint64_t)((a.epoch << 8) | ((uint32_t)a.round & 0xFFu)) << 32) | what; }
 
@@ -1167,6 +1176,18 @@ LD_DEV bool emit_tasks(const DrawArgs &a, uint32_t par, uint32_t item, uint32_t 
     return false;
   }
   res_off = (uint32_t)off;
+  if (a.emit_live) {
+    // the round's solve kernel is running: slot halves through atomics, the half with the tag last (publish_item)
+    for (uint32_t i = 0; i < nt * nch; ++i) st_agent64(a.tasks[par] + tb + i, (uint64_t)item | ((uint64_t)(m_lo + (i % nt) * 64u) << 32));
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    for (uint32_t i = 0; i < nt * nch; ++i) {
+      const uint32_t c = i / nt, t = i - c * nt;
+      const uint32_t n = (count - t * 64u) < 64u ? (count - t * 64u) : 64u;
+      st_agent64(reinterpret_cast<uint64_t *>(a.tasks[par] + tb + i) + 1,
+                 (uint64_t)((uint32_t)off + c * count + t * 64u) | ((uint64_t)(n | (c << 8) | (a.epoch << kTaskTagShift)) << 32));
+    }
+    return true;
+  }
   for (uint32_t c = 0; c < nch; ++c) {
     for (uint32_t t = 0; t < nt; ++t) {
       Task k;
@@ -1179,6 +1200,14 @@ LD_DEV bool emit_tasks(const DrawArgs &a, uint32_t par, uint32_t item, uint32_t 
   }
   return true;
 }
+
+// the queues of one round parity back to empty
+LD_DEV void reset_round(DevCounters *c, uint32_t par) {
+  c->n_tasks[par] = 0; c->task_head[par] = 0; c->n_active[par] = 0; c->active_head[par] = 0;
+  c->pool_used[par] = 0;
+  c->n_slow[par] = 0; c->slow_head[par] = 0; c->waves_done[par] = 0; c->waves_started[par] = 0; c->accept_done[par] = 0;
+}
+__global__ void reset_round_kernel(DevCounters *c, uint32_t par) { reset_round(c, par); }
 
 // one thread per item: header + first batch R(0 .. samples-1+retries)
 __global__ __launch_bounds__(256) void prep_items_kernel(DrawArgs a) {
@@ -1274,12 +1303,7 @@ __global__ __launch_bounds__(256) void solve_po_kernel(DrawArgs a) {
   const lentil_params &P = a.P;
 
   // round r+1's queues are filled by this round's accept kernel: reset them here (nothing else touches them now)
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
-    const uint32_t nx = (uint32_t)a.parity ^ 1u;
-    a.ctr->n_tasks[nx] = 0; a.ctr->task_head[nx] = 0; a.ctr->n_active[nx] = 0; a.ctr->active_head[nx] = 0;
-    a.ctr->pool_used[nx] = 0;
-    a.ctr->n_slow[nx] = 0; a.ctr->slow_head[nx] = 0; a.ctr->waves_done[nx] = 0; a.ctr->waves_started[nx] = 0;
-  }
+  if (blockIdx.x == 0 && threadIdx.x == 0 && !a.no_reset) reset_round(a.ctr, (uint32_t)a.parity ^ 1u);
   const uint32_t par = (uint32_t)a.parity;
   const Task *tasks = a.tasks[par];
   uint32_t *res = a.pool[par];
@@ -1475,7 +1499,7 @@ __global__ __launch_bounds__(256) void solve_po_kernel(DrawArgs a) {
       const uint32_t begun = ld_coherent32(&a.ctr->waves_started[par]);
       const uint32_t taken = ld_coherent32(&a.ctr->task_head[par]);
       const uint32_t published = kStream ? ld_coherent32(&a.ctr->n_tasks[par]) : n_tasks;
-      const bool complete = !kStream || ld_coherent32(&a.ctr->publishers_done) >= a.pub_total;
+      const bool complete = !kStream || ld_coherent32(a.producers_done) >= a.producers_total;
       close = (done == begun && complete && taken >= published) ? 1u : 0u;
     }
     if (__builtin_amdgcn_readfirstlane(close)) {
@@ -2146,7 +2170,9 @@ LD_DEV AcceptResult accept_item_chroma(const DrawArgs &a, AcceptShared &sh, uint
   return r;
 }
 
-__global__ __launch_bounds__(256) void accept_kernel(DrawArgs a) {
+// (six waves per SIMD: beside four accept blocks per CU a SIMD then has room for a solve wave -- the next round's solves
+// run beside the accept that schedules them, DrawArgs::emit_live)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) void accept_kernel(DrawArgs a) {
   __shared__ uint32_t s_item;
   __shared__ AcceptShared sh;
   const uint32_t par = (uint32_t)a.parity, nxt = par ^ 1u;
@@ -2191,6 +2217,18 @@ __global__ __launch_bounds__(256) void accept_kernel(DrawArgs a) {
     if (tot_accepted) atomicAdd(&a.ctr->accepted, tot_accepted);
   }
   flush_row_range(a.ctr, rmin, rmax_p1);
+  if (a.emit_live && threadIdx.x < 64u) {
+    // everything this block emitted has arrived; the last block puts the end markers behind the queue
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    uint32_t last = 0;
+    if (threadIdx.x == 0) last = atomicAdd(&a.ctr->accept_done[par], 1u) == gridDim.x - 1u ? 1u : 0u;
+    if (__builtin_amdgcn_readfirstlane(last)) {
+      const uint32_t n = ld_coherent32(&a.ctr->n_tasks[nxt]);
+      for (uint32_t i = threadIdx.x; i < a.end_tasks; i += 64u)
+        if ((uint64_t)n + i < a.task_cap)
+          st_agent64(reinterpret_cast<uint64_t *>(a.tasks[nxt] + n + i) + 1, (uint64_t)(kEndCount | (a.epoch << kTaskTagShift)) << 32);
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------------------
