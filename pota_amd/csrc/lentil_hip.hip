@@ -129,10 +129,6 @@ struct lentil_hip_ctx {
   bool overlap_rounds = true;        // LENTIL_OVERLAP_ROUNDS=0: a streamed pass's second round starts after its first accept has ended
   bool slow_live = true;             // LENTIL_SLOW_LIVE=0: stragglers of a streamed pass wait for their round's solve kernel to end
   hipEvent_t ev_slow = nullptr, ev_round = nullptr;
-  // a streamed pass resolves the direct sums beside its solves (LENTIL_EARLY_RESOLVE=0: not)
-  bool early_resolve = true, early_resolved = false;
-  hipStream_t aux_stream = nullptr;
-  hipEvent_t ev_early = nullptr;
   hipStream_t pub_stream = nullptr;  // streamed pass: publish_kernel, then the live straggler kernel
   hipEvent_t pub_done = nullptr;
   bool pass_pending = false;         // a redistribute ran whose rows have not been asked for yet
@@ -221,9 +217,6 @@ LENTIL_API int lentil_hip_create(int device, lentil_hip_ctx **out_ctx) {
   HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->scans_done, hipEventDisableTiming));
   HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->pub_stream, hipStreamNonBlocking));
   HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_slow, hipEventDisableTiming));
-  HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_early, hipEventDisableTiming));
-  HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking));
-  if (const char *e = getenv("LENTIL_EARLY_RESOLVE")) ctx->early_resolve = !(e[0] == '0');
   HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_round, hipEventDisableTiming));
   HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->pub_done, hipEventDisableTiming));
   if (const char *ft = getenv("LENTIL_FORCE_TABLES")) ctx->use_generated = !(ft[0] == '1');
@@ -320,8 +313,6 @@ LENTIL_API int lentil_hip_destroy(lentil_hip_ctx *ctx) {
   if (ctx->pub_stream) { (void)hipStreamSynchronize(ctx->pub_stream); (void)hipStreamDestroy(ctx->pub_stream); }
   if (ctx->pub_done) (void)hipEventDestroy(ctx->pub_done);
   if (ctx->ev_slow) (void)hipEventDestroy(ctx->ev_slow);
-  if (ctx->ev_early) (void)hipEventDestroy(ctx->ev_early);
-  if (ctx->aux_stream) { (void)hipStreamSynchronize(ctx->aux_stream); (void)hipStreamDestroy(ctx->aux_stream); }
   if (ctx->ev_round) (void)hipEventDestroy(ctx->ev_round);
   (void)hipFree(ctx->d_ctr);
   if (ctx->h_ctr_pinned) (void)hipHostFree(ctx->h_ctr_pinned);
@@ -563,7 +554,6 @@ LENTIL_API int lentil_hip_alloc_frame(lentil_hip_ctx *ctx, uint32_t n_aovs, cons
   ctx->have_frame = true;
   HIP_TRY(ctx, hipMemsetAsync(ctx->F.acc, 0, nfl * sizeof(float), ctx->stream));
   ctx->dirty_lo = ctx->dirty_hi = 0; ctx->dirty_known = true; ctx->pass_pending = false;
-  ctx->early_resolved = false;
   ctx->cleared_since_pass = true;
   return LENTIL_OK;
 }
@@ -709,7 +699,6 @@ LENTIL_API int lentil_hip_clear_frame(lentil_hip_ctx *ctx) {
   }
   }
   ctx->F.dir = nullptr;         // what the scan stored there no longer counts (wiped or overwritten before it does again)
-  ctx->early_resolved = false;
   ctx->cleared_since_pass = true;
   ctx->dirty_lo = ctx->dirty_hi = 0;
   ctx->dirty_known = true;      // clean frame: nothing is dirty
@@ -1227,8 +1216,6 @@ static int launch_scan(lentil_hip_ctx *ctx, const ScanPlan &pl, const lentil_hip
 // Buffers are sized from the previous pass (twice what it found); an item that does not fit raises
 // DevCounters::fallback, the accept kernel then does nothing and the host redoes the draws with exact sizes.
 // ---------------------------------------------------------------------------------------
-static int launch_resolve(lentil_hip_ctx *ctx, hipStream_t st, uint64_t p_begin, uint64_t p_end, int mode);
-
 static int redistribute_streamed(lentil_hip_ctx *ctx, bool *streamed) {
   *streamed = false;
   const lentil_params &P = ctx->P;
@@ -1325,15 +1312,6 @@ static int redistribute_streamed(lentil_hip_ctx *ctx, bool *streamed) {
   HIP_TRY(ctx, hipEventRecord(ch.scanned, ctx->stream));
   HIP_TRY(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
   HIP_TRY(ctx, hipEventRecord(ctx->scans_done, ctx->stream));
-  if (ctx->early_resolve && ctx->F.dir && ctx->F.touched && ctx->d_resolved) {
-    // every pixel no draw will reach is final once the scan has stored its direct sums: resolve the whole frame from
-    // them now, beside the solves (a memory-bound kernel among fp64 ones); lentil_hip_resolve then only redoes the
-    // records that did receive splats
-    HIP_TRY(ctx, hipStreamWaitEvent(ctx->aux_stream, ctx->scans_done, 0));
-    if ((rc = launch_resolve(ctx, ctx->aux_stream, 0, ctx->F.np, 1))) return rc;
-    HIP_TRY(ctx, hipEventRecord(ctx->ev_early, ctx->aux_stream));
-    ctx->early_resolved = true;
-  }
 
   // The publishers and A, resident beside the scan (the counters they poll were cleared by the memset ahead of
   // ev[0]).  Submitted AFTER what they wait for -- the scan, then the publishers: should the streams share a
@@ -1617,7 +1595,6 @@ LENTIL_API int lentil_hip_redistribute(lentil_hip_ctx *ctx) {
   ctx->h_ctr_valid = false;
   ctx->last_blind = ctx->last_fallback = 0;
   ctx->last_streamed = 0;
-  ctx->early_resolved = false;
   for (auto &ch : ctx->chunks) ch.heavy_pending = false;
   ctx->last_scan_launches = 0;
   bool streamed = false;
@@ -1834,37 +1811,17 @@ LENTIL_API int lentil_hip_closest_gather(lentil_hip_ctx *ctx) {
   return LENTIL_OK;
 }
 
-static int launch_resolve(lentil_hip_ctx *ctx, hipStream_t st, uint64_t p_begin, uint64_t p_end, int mode) {
-  const uint64_t total = p_end - p_begin;
-  if (!total) return LENTIL_OK;
-  uint64_t blocks = (total + 255) / 256;
-  const uint64_t max_blocks = (uint64_t)ctx->num_cu * 8;
-  if (blocks > max_blocks) blocks = max_blocks;
-  const size_t lds = (size_t)4 * 64 * ctx->F.stride * sizeof(float);      // 4 waves x 64 records
-  if (mode == 2) {
-    // only the records that received splats (whole frame; p_begin / p_end unused)
-    const uint64_t n_groups = (ctx->F.np + 63) / 64;
-    uint64_t tb = (n_groups + 255) / 256;
-    if (tb > (uint64_t)ctx->num_cu * 4) tb = (uint64_t)ctx->num_cu * 4;
-    hipLaunchKernelGGL(resolve_touched_kernel, dim3((unsigned)tb), dim3(256), lds, st, ctx->F, ctx->d_resolved, n_groups);
-  } else {
-    hipLaunchKernelGGL(resolve_kernel, dim3((unsigned)blocks), dim3(256), lds, st, ctx->F, ctx->d_resolved, p_begin, p_end, mode);
-  }
-  HIP_TRY(ctx, hipGetLastError());
-  return LENTIL_OK;
-}
-
 static int resolve_range(lentil_hip_ctx *ctx, uint64_t p_begin, uint64_t p_end) {
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   HIP_TRY(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
-  // The pass resolved the direct sums of the whole frame itself, beside its solves (early_resolved): what is left are
-  // the records that received splats -- as long as nothing else has touched the frame since (FrameDev::touched still
-  // trusted, FrameDev::dir still apart).
-  const bool rest_only = ctx->early_resolved && ctx->F.touched && ctx->F.dir && p_begin == 0 && p_end == ctx->F.np;
-  if (rest_only) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_early, 0));
-  {
-    const int rc = launch_resolve(ctx, ctx->stream, p_begin, p_end, rest_only ? 2 : 0);
-    if (rc) return rc;
+  const uint64_t total = p_end - p_begin;
+  if (total) {
+    uint64_t blocks = (total + 255) / 256;
+    const uint64_t max_blocks = (uint64_t)ctx->num_cu * 8;
+    if (blocks > max_blocks) blocks = max_blocks;
+    const size_t lds = (size_t)4 * 64 * ctx->F.stride * sizeof(float);      // 4 waves x 64 records
+    hipLaunchKernelGGL(resolve_kernel, dim3((unsigned)blocks), dim3(256), lds, ctx->stream, ctx->F, ctx->d_resolved, p_begin, p_end);
+    HIP_TRY(ctx, hipGetLastError());
   }
   HIP_TRY(ctx, hipEventRecord(ctx->ev[4], ctx->stream));
   ctx->timed_resolve = true;

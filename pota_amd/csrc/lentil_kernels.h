@@ -2655,89 +2655,57 @@ __global__ __launch_bounds__(256) void fold_direct_kernel(FrameDev F, float *dir
   }
 }
 
-// One tile of the resolve: 64 consecutive pixels (fewer at the end), their records through the wave's LDS slice.
-// use_acc / use_dir: which of the two accumulator blocks hold anything for these pixels.
-LD_DEV void resolve_tile(const FrameDev &F, float *resolved, float4 *tile, uint64_t p0, uint32_t n_pix, uint32_t lane,
-                         bool use_acc, bool use_dir) {
-  const uint32_t q = F.stride >> 2;
-  const uint32_t n4 = n_pix * q;
-  const float4 *acc4 = reinterpret_cast<const float4 *>(F.acc);
-  const float4 *dir4 = reinterpret_cast<const float4 *>(F.dir);
-  if (use_dir && !use_acc) {
-    // nothing was splatted into these records: they are all zero, the direct sums are the whole story
-    for (uint32_t i = lane; i < n4; i += 64u) tile[i] = dir4[p0 * q + i];
-  } else if (use_dir) {
-    // what the pixels' own visits added (scan_dma_kernel) + what was splatted: a pixel that received no draw has a
-    // zero record in `acc`, and 0 + x is x bit for bit (the scan's sums are never -0)
-    for (uint32_t i = lane; i < n4; i += 64u) {
-      const float4 a = acc4[p0 * q + i], d = dir4[p0 * q + i];
-      tile[i] = make_float4(a.x + d.x, a.y + d.y, a.z + d.z, a.w + d.w);
-    }
-  } else {
-    for (uint32_t i = lane; i < n4; i += 64u) tile[i] = acc4[p0 * q + i];
-  }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
-  if (lane < n_pix) {
-    const float *rec = reinterpret_cast<const float *>(tile + (size_t)lane * q);
-    const float wt = rec[4u * F.n_aovs];
-    const float inv = wt != 0.0f ? 1.0f / wt : 1.0f;      // AtRGBA /= float multiplies by 1.0f/f
-    for (uint32_t a = 0; a < F.n_aovs; ++a) {
-      float4 c = tile[(size_t)lane * q + a];
-      if (F.closest_mask & (1u << a)) {
-        c.w = 1.0f;                                      // closest: (r, g, b, 1), src/lentil_imager.cpp:181-186
-      } else if (wt != 0.0f) {
-        c.x *= inv; c.y *= inv; c.z *= inv; c.w *= inv;
-      }
-      reinterpret_cast<float4 *>(resolved)[(uint64_t)a * F.np + p0 + lane] = c;
-    }
-  }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
-  __builtin_amdgcn_wave_barrier();
-}
-
 // K7 -- driver_process_bucket's normalisation, src/lentil_imager.cpp:169-186.  Reads the pixel records,
 // writes one planar RGBA image per AOV (what the imager copies into Arnold's buckets).
-// A wave takes 64 consecutive pixels: their records are one contiguous block, read with fully coalesced float4 loads
-// into LDS; lane p then normalises pixel p and every AOV plane receives 64 adjacent RGBA values (1 KiB per store).
-// dir_only: the direct sums alone (FrameDev::dir) -- what a streamed pass launches right behind its scan, beside the
-// solves: every pixel no draw reaches is final then, and resolve_touched_kernel finishes the others.
-__global__ __launch_bounds__(256) void resolve_kernel(FrameDev F, float *resolved, uint64_t p_begin, uint64_t p_end, int dir_only) {
+__global__ __launch_bounds__(256) void resolve_kernel(FrameDev F, float *resolved, uint64_t p_begin, uint64_t p_end) {
+  // A wave takes 64 consecutive pixels: their records are one contiguous block, read with fully coalesced
+  // float4 loads into LDS; lane p then normalises pixel p and every AOV plane receives 64 adjacent RGBA
+  // values (1 KiB per store instruction).
   extern __shared__ float4 s_rec[];                       // [waves per block][64 * stride / 4]
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-  float4 *tile = s_rec + (size_t)wave * 64u * (F.stride >> 2);
+  const uint32_t q = F.stride >> 2;                       // float4 per record (stride is a multiple of 8 floats)
+  float4 *tile = s_rec + (size_t)wave * 64u * q;
   const uint64_t n_tiles = (p_end - p_begin + 63ull) / 64ull;
   const uint64_t wave_global = (uint64_t)blockIdx.x * (blockDim.x >> 6) + wave;
   const uint64_t wave_stride = (uint64_t)gridDim.x * (blockDim.x >> 6);
+  const float4 *acc4 = reinterpret_cast<const float4 *>(F.acc);
+  const float4 *dir4 = reinterpret_cast<const float4 *>(F.dir);
   for (uint64_t t = wave_global; t < n_tiles; t += wave_stride) {
     const uint64_t p0 = p_begin + t * 64ull;
     const uint32_t n_pix = (uint32_t)((p_end - p0) < 64ull ? (p_end - p0) : 64ull);
-    const bool splatted = !(F.dir && F.touched) || (F.touched[p0 >> 6] | F.touched[(p0 + n_pix - 1u) >> 6]);
-    resolve_tile(F, resolved, tile, p0, n_pix, lane, !dir_only && splatted, F.dir != nullptr);
-  }
-}
-
-// The rest of a resolve that resolve_kernel(dir_only) started: only the groups of 64 records that received splats
-// (FrameDev::touched; 2 % of the headline frame).  Splats cluster -- a bokeh disc is a run of flagged groups in every
-// row it crosses -- so a wave takes groups a whole grid apart (lane k looks at the flag of group wave + k * waves):
-// neighbouring groups go to different waves, and the flags are in flight together.
-__global__ __launch_bounds__(256) void resolve_touched_kernel(FrameDev F, float *resolved, uint64_t n_groups) {
-  extern __shared__ float4 s_rec[];
-  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-  float4 *tile = s_rec + (size_t)wave * 64u * (F.stride >> 2);
-  const uint64_t wave_global = (uint64_t)blockIdx.x * (blockDim.x >> 6) + wave;
-  const uint64_t wave_stride = (uint64_t)gridDim.x * (blockDim.x >> 6);
-  for (uint64_t base = wave_global; base < n_groups; base += wave_stride * 64u) {
-    const uint64_t g = base + (uint64_t)lane * wave_stride;
-    unsigned long long m = __ballot(g < n_groups && F.touched[g] != 0);
-    while (m) {
-      const uint32_t b = (uint32_t)__builtin_ctzll(m);
-      m &= m - 1ull;
-      const uint64_t p0 = (base + (uint64_t)b * wave_stride) * 64ull;
-      const uint32_t n_pix = (uint32_t)((F.np - p0) < 64ull ? (F.np - p0) : 64ull);
-      resolve_tile(F, resolved, tile, p0, n_pix, lane, true, true);
+    const uint32_t n4 = n_pix * q;
+    if (dir4 && F.touched && !(F.touched[p0 >> 6] | F.touched[(p0 + n_pix - 1u) >> 6])) {
+      // nothing was splatted into these records: they are all zero, the direct sums are the whole story
+      for (uint32_t i = lane; i < n4; i += 64u) tile[i] = dir4[p0 * q + i];
+    } else if (dir4) {
+      // what the pixels' own visits added (scan_dma_kernel) + what was splatted: a pixel that received no draw has a
+      // zero record in `acc`, and 0 + x is x bit for bit (the scan's sums are never -0)
+      for (uint32_t i = lane; i < n4; i += 64u) {
+        const float4 a = acc4[p0 * q + i], d = dir4[p0 * q + i];
+        tile[i] = make_float4(a.x + d.x, a.y + d.y, a.z + d.z, a.w + d.w);
+      }
+    } else {
+      for (uint32_t i = lane; i < n4; i += 64u) tile[i] = acc4[p0 * q + i];
     }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
+    if (lane < n_pix) {
+      const float *rec = reinterpret_cast<const float *>(tile + (size_t)lane * q);
+      const float wt = rec[4u * F.n_aovs];
+      const float inv = wt != 0.0f ? 1.0f / wt : 1.0f;      // AtRGBA /= float multiplies by 1.0f/f
+      for (uint32_t a = 0; a < F.n_aovs; ++a) {
+        float4 c = tile[(size_t)lane * q + a];
+        if (F.closest_mask & (1u << a)) {
+          c.w = 1.0f;                                      // closest: (r, g, b, 1), src/lentil_imager.cpp:181-186
+        } else if (wt != 0.0f) {
+          c.x *= inv; c.y *= inv; c.z *= inv; c.w *= inv;
+        }
+        reinterpret_cast<float4 *>(resolved)[(uint64_t)a * F.np + p0 + lane] = c;
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+    __builtin_amdgcn_wave_barrier();
   }
 }
 

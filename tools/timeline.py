@@ -16,9 +16,7 @@ def main():
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
     # a pass ends with its resolve kernel: pass `which` (default: the last one) = everything after the previous resolve,
     # starting at its first scan launch
-    # (a streamed pass also launches resolve_kernel early, beside its solves: the pass ends with resolve_touched_kernel then)
-    late = [i for i, r in enumerate(rows) if "resolve_touched_kernel" in r["Kernel_Name"]]
-    ends = late if late else [i for i, r in enumerate(rows) if "resolve_kernel" in r["Kernel_Name"]]
+    ends = [i for i, r in enumerate(rows) if "resolve_kernel" in r["Kernel_Name"]]
     which = int(sys.argv[2]) if len(sys.argv) > 2 else -1
     e = ends[which] + 1
     k = ends.index(ends[which])
@@ -30,7 +28,7 @@ def main():
         b = (int(r["End_Timestamp"]) - t0) / 1e3
         name = r["Kernel_Name"].split("(")[0][:60]
         print("%9.1f %9.1f %8.1f  q%-3s grid %-8s %s" % (a, b, b - a, r.get("Queue_Id", "?"), r.get("Grid_Size", "?"), name))
-        if ("resolve_touched" in name) if late else ("resolve" in name):
+        if "resolve" in name:
             break
 
 
