@@ -1306,6 +1306,8 @@ static int redistribute_streamed(lentil_hip_ctx *ctx, bool *streamed) {
   if (!few) da.slow = nullptr;              // parking is for passes with few draws (DrawArgs::slow_below)
 
   unsigned scan_blocks = 0;
+  // (the scan's start for lentil_hip_last_timing: the host work since the pass began -- sizing, the plan -- is not the kernel's)
+  HIP_TRY(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
   if ((rc = launch_scan(ctx, plan, ch, ctx->d_ctr, &scan_blocks))) return rc;
   (void)scan_blocks;
   ctx->last_scan_launches = 1;
