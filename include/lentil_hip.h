@@ -301,7 +301,12 @@ int lentil_hip_visits_end(lentil_hip_ctx *ctx, uint64_t *n_visits);
  *               visit: predicate + draw count, trace_ray_bw_po / thin-lens draws,
  *               add_to_buffer / filter_and_add_to_buffer_new (src/lentil.h:823-851,938-955).
  *               Accumulates on top of whatever the frame holds (call clear_frame first).
- *               Asynchronous on the context's stream.
+ *               Returns when the pass is complete on the device: it ends with a read-back of the
+ *               pass's counters (did everything fit the buffers sized from the previous pass? is any
+ *               visit still short of draws?), after which it redoes or continues what is needed.
+ *               LENTIL_ERR_NOMEM if the device had to drop work (a frame that is incomplete).
+ *               clear_frame, resolve and the row / exchange calls are asynchronous on the context's
+ *               stream (lentil_hip_stream); downloads and lentil_hip_sync wait for it.
  * resolve     : driver_process_bucket's normalisation (src/lentil_imager.cpp:112-118,169-186)
  *               into a separate resolved image (the accumulators stay intact). */
 int lentil_hip_clear_frame(lentil_hip_ctx *ctx);
