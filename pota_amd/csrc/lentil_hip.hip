@@ -108,7 +108,7 @@ struct lentil_hip_ctx {
   // Streamed pass (polynomial optics, from the second pass of a context on): one scan launch that publishes its items
   // and their first-batch tasks itself, persistent solve waves that follow the task queue while the scan runs.
   bool stream_mode = true;                   // LENTIL_STREAM=0: chunked passes only
-  uint64_t stream_below = 4ull << 20;        // LENTIL_STREAM_BELOW: ... and for passes with at least this many draws (previous pass's count)
+  uint64_t stream_below = 5ull << 19;        // LENTIL_STREAM_BELOW: ... and for passes with at least this many draws (previous pass's count; 2.5 Mi: measured crossover between 1.2 M draws, streamed 2.6 vs 2.9 ms, and 3.1 M, 5.1 vs 4.9 ms)
   int stream_blocks = 2;                     // LENTIL_STREAM_BLOCKS: solve blocks per CU beside the scan (1 or 2)
   uint32_t epoch = 0;                        // tag of the current pass's task slots
   uint64_t *d_ranges = nullptr;              // range queue scan -> publish_kernel
