@@ -1100,6 +1100,68 @@ def test_randomized_thinlens_configurations(orc):
                 orc.orc_bokeh_destroy(ob)
 
 
+def test_randomized_thinlens_chromatic(orc):
+    """Thin lens with abb_chromatic > 0 (the xor128 channel stream, src/lentil_filter.cpp:393-406) under a seeded soak of
+    the draw's other options: aperture blades / image, coma, optical vignetting, distortion, visits per pixel, draw
+    count, extra AOVs.  Two passes per context: the second continues the generator where the first stopped."""
+    import os
+    n_cases = int(os.environ.get("LENTIL_SOAK_CASES", "6"))
+    rng = np.random.default_rng(int(os.environ.get("LENTIL_SOAK_SEED", "0xC4A0"), 0))
+    tex = np.load(os.path.join(common.ROOT, "tests", "golden", "example_bokeh_kernel_u8.npy")).astype(np.float32) / np.float32(255)
+    tables = bokeh.build_tables(tex)
+    bt = _abi.BokehTable()
+    bt.x, bt.y = tables["x"], tables["y"]
+    for k in ("cdfRow", "rowIndices", "cdfColumn", "columnIndices"):
+        setattr(bt, k, tables[k].ctypes.data)
+    for case in range(n_cases):
+        W, H = int(rng.integers(24, 110)), int(rng.integers(16, 70))
+        aa, fw = [(2, 1.0), (3, 1.0)][int(rng.integers(0, 2))]
+        M = {2: 4, 3: 9}[aa]
+        override = int(rng.choice([0, 8, 33]))
+        n_extra = int(rng.integers(0, 2))
+        f_hi = float(rng.choice([0.002, 0.02]))
+        kw = {"abb_chromatic": float(rng.choice([0.3, 1.0])), "abb_chromatic_type": int(rng.integers(0, 2))}
+        if rng.integers(0, 2):
+            kw["bokeh_aperture_blades"] = int(rng.choice([5, 8]))
+        if rng.integers(0, 2):
+            kw["abb_coma"] = 0.35
+        if rng.integers(0, 2):
+            kw["optical_vignetting_distance"] = 2.0
+            kw["optical_vignetting_radius"] = float(rng.choice([1.0, 1.5]))
+        if rng.integers(0, 2):
+            kw["abb_distortion"] = 0.1
+        image = int(rng.integers(0, 3)) == 0
+        if image:
+            kw["bokeh_enable_image"] = 1
+        tag = "case %d: %dx%d M=%d override=%d extra=%d f_hi=%g %r" % (case, W, H, M, override, n_extra, f_hi, kw)
+        p = common.tl_setup(W, H, aa=aa, filter_width=fw, samples_override=override, **kw)
+        visits, cols = common.make_stream(p, W, H, M, f_hi=f_hi, n_extra=n_extra, seed=0xC000 + case)
+        ob = orc.orc_bokeh_from_tables(C.byref(bt)) if image else None
+        ctx = capi.Context(0)
+        state = None
+        try:
+            for again in range(2):
+                ref = oracle_lib.Frame(orc, p, n_aovs=1 + n_extra, keep_log=True)
+                if state is not None:
+                    orc.orc_frame_set_xor128(ref.h, (C.c_uint32 * 4)(*state))
+                ref.run(None, ob, visits)
+                rc = ref.counters()
+                c = gpu_run(ctx, p, None, visits, n_aovs=1 + n_extra, bokeh_tables=tables if image else None)
+                assert (c.redistributed_visits, c.attempted_draws, c.accepted_draws) == (
+                    rc.redistributed_visits, rc.attempted_draws, rc.accepted_draws), tag
+                check_logs(ctx, ref)
+                st = (C.c_uint32 * 4)()
+                orc.orc_frame_get_xor128(ref.h, st)
+                state = list(st)
+                assert ctx.get_xor128_state() == state, tag
+                check_frame(ctx, ref, n_aovs=1 + n_extra)
+                ref.close()
+        finally:
+            ctx.close()
+            if ob:
+                orc.orc_bokeh_destroy(ob)
+
+
 def test_empty_stream_and_error_paths(gpu_ctx_factory):
     p, model, table, keep = common.po_setup(32, 16)
     ctx = gpu_ctx_factory()
