@@ -1823,8 +1823,10 @@ LD_DEV void count_same_pixel(const uint32_t *pix, uint32_t *cnt, uint32_t T, uin
 }
 
 // Processes the current result batch of `item` (block-cooperative; must be called by all 256 threads).
+// dry: the walk without its effects -- nothing is splatted, logged or flagged; the result (how far the batch got, whether
+// and how many more attempts are needed) is what the real walk will find.
 LD_DEV AcceptResult accept_item(const DrawArgs &a, AcceptShared &sh, uint32_t item, const ItemProg pg, const uint32_t *res,
-                                uint32_t &rmin, uint32_t &rmax_p1) {
+                                uint32_t &rmin, uint32_t &rmax_p1, bool dry = false) {
   uint32_t *s_first_u = sh.first_u, *s_nsucc = sh.nsucc, *s_top = sh.top;
   uint32_t(*s_pix)[64] = sh.pix;
   float *s_val = sh.val;
@@ -1918,7 +1920,7 @@ LD_DEV AcceptResult accept_item(const DrawArgs &a, AcceptShared &sh, uint32_t it
       // floats of one pixel record.
       const unsigned long long tmask0 = __ballot(take);
       const uint32_t T = (uint32_t)__builtin_popcountll(tmask0);
-      if (take) {
+      if (take && !dry) {
         const uint32_t pix = code;
         const uint32_t row = pix / a.P.xres;
         rmin = row < rmin ? row : rmin;
@@ -1935,11 +1937,11 @@ LD_DEV AcceptResult accept_item(const DrawArgs &a, AcceptShared &sh, uint32_t it
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
-      count_same_pixel(s_pix[wave], sh.cnt[wave], T, lane);
+      if (!dry) count_same_pixel(s_pix[wave], sh.cnt[wave], T, lane);
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
-      for (uint32_t q = lane; q < T * U; q += 64u) {
+      for (uint32_t q = lane; !dry && q < T * U; q += 64u) {
         const uint32_t d = q / U, ch = q - d * U;
         const uint32_t c = sh.cnt[wave][d];
         if (c) atomicAdd(a.F.acc + (size_t)s_pix[wave][d] * a.F.stride + s_off[ch], (float)c * s_val[ch]);
@@ -2191,14 +2193,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
     const uint32_t item = a.active[par][ai];
     const ItemProg pg = a.prog[item];
     const bool chroma = a.n_channels == 3;
+    // The next round's solve kernel is waiting for tasks (emit_live): find out what the item still needs with a dry
+    // walk (a third of the real one's time: no splats) and hand its tasks out before splatting anything.
+    bool emitted = false;
+    uint32_t off = 0;
+    if (a.emit_live && !chroma) {
+      const AcceptResult rd = accept_item(a, sh, item, pg, res, rmin, rmax_p1, true);
+      if (threadIdx.x == 0 && rd.more) emitted = emit_tasks(a, nxt, item, rd.new_lo, rd.new_hi, off);
+      __syncthreads();
+    }
     const AcceptResult r = chroma ? accept_item_chroma(a, sh, item, pg, res, rmin, rmax_p1)
                                   : accept_item(a, sh, item, pg, res, rmin, rmax_p1);
     if (threadIdx.x == 0) {
       if (r.more) {
-        uint32_t off = 0;
         ItemProg np_ = r.prog;
         np_.m_lo = r.new_lo; np_.m_hi = r.new_hi;
-        if (emit_tasks(a, nxt, item, r.new_lo, r.new_hi, off)) {
+        if (emitted || emit_tasks(a, nxt, item, r.new_lo, r.new_hi, off)) {
           np_.res_off = off;
           a.prog[item] = np_;
           const uint32_t slot = atomicAdd(&a.ctr->n_active[nxt], 1u);
