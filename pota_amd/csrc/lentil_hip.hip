@@ -2123,9 +2123,14 @@ LENTIL_API int lentil_hip_get_counters(lentil_hip_ctx *ctx, lentil_counters *out
   CHECK_CTX(ctx);
   if (!out) return fail(ctx, LENTIL_ERR_INVALID, "out is null");
   std::vector<DevCounters> c(ctx->n_chunks + 1);
-  HIP_TRY(ctx, hipSetDevice(ctx->device));
-  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-  HIP_TRY(ctx, hipMemcpy(c.data(), ctx->d_ctr, sizeof(DevCounters) * c.size(), hipMemcpyDeviceToHost));
+  if (ctx->h_ctr_valid && ctx->h_ctr.size() == (size_t)ctx->n_chunks) {
+    // the pass read them back itself, behind its last kernel
+    for (int i = 0; i < ctx->n_chunks; ++i) c[i] = ctx->h_ctr[i];
+  } else {
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipMemcpy(c.data(), ctx->d_ctr, sizeof(DevCounters) * c.size(), hipMemcpyDeviceToHost));
+  }
   memset(out, 0, sizeof(*out));
   out->visits = ctx->have_visits ? ctx->V.n : 0;
   for (int i = 0; i < ctx->n_chunks; ++i) {
