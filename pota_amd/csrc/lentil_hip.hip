@@ -1326,7 +1326,7 @@ static int redistribute_streamed(lentil_hip_ctx *ctx, bool *streamed) {
   const unsigned b_threads = live ? 192u : 256u;
   unsigned b_blocks;
   {
-    int b_per_cu = live ? 1 : ctx->solve_max_blocks - ctx->stream_blocks;
+    int b_per_cu = live ? 3 - ctx->stream_blocks : ctx->solve_max_blocks - ctx->stream_blocks;
     if (b_per_cu < 1) b_per_cu = 1;
     const uint64_t want = (nch * (ctx->est_sum_total / 64 + ctx->est_items_total) + 3) / 4;
     uint64_t b = (uint64_t)ctx->num_cu * (uint64_t)b_per_cu;
