@@ -61,6 +61,7 @@ extern "C" {
 #define LENTIL_GEOM_CYL_X 2
 
 #define LENTIL_MAX_AOVS 16 /* RGBA + up to 15 more redistributed AOVs */
+#define LENTIL_MAX_CRYPTO 9 /* cryptomatte AOVs: crypto_{material,object,asset}{00,01,02} */
 
 /* ------------------------------------------------------------------------------------
  * Camera state the kernels need: the fields of `struct Camera` (src/lentil.h:92-196,
@@ -413,6 +414,44 @@ int lentil_hip_comm_destroy(lentil_hip_ctx *ctx);
 int lentil_hip_allreduce(lentil_hip_ctx *ctx);
 int lentil_hip_exchange_bands(lentil_hip_ctx *ctx, const int32_t *bounds, int32_t visit_rows, int32_t sparse,
                               int32_t *band_lo, int32_t *band_hi);
+
+/* --- cryptomatte AOVs ------------------------------------------------------------------
+ * The reference keeps a std::map<float, float> id -> weight and a total weight per pixel for every ranked
+ * cryptomatte AOV (AOVData::crypto_hash_map / crypto_total_weight, src/aov_data.h:127-128,145-150).  Each add of a
+ * visit to a pixel -- its own pixel (src/lentil.h:952) or the pixel of an accepted draw
+ * (src/lentil_filter.cpp:296,443) -- adds the visit's cache {id -> weight} times the sample weight
+ * (Camera::add_to_buffer_cryptomatte, src/lentil.h:814-819); the imager writes the pairs at positions rank, rank + 1
+ * of a pixel's map sorted by weight (src/lentil_imager.cpp:121-161).
+ *
+ * lentil_crypto_visits carries, per cryptomatte AOV, the cache of every visit of the bound stream as `entries`
+ * (id, weight) pairs (what Camera::cryptomatte_construct_cache, src/lentil.h:781-811, leaves: ids distinct; a pair
+ * whose weight has the bits 0xFFFFFFFF is unused; -0 counts as +0, which is one key to the reference's map too).
+ * Host arrays with lentil_hip_upload_crypto, device arrays with lentil_hip_bind_crypto; after the visits, before
+ * lentil_hip_redistribute.  lentil_hip_alloc_crypto follows lentil_hip_alloc_frame (which drops the tables);
+ * slots_per_pixel is the number of distinct ids a pixel can hold (0: 16, at most 64) -- a pass that meets more
+ * returns LENTIL_ERR_NOMEM, as does one whose accepted draws exceed the draw log the adds are replayed from (sized
+ * by the library from the previous pass unless lentil_hip_set_draw_log was called; clear the frame and redistribute
+ * again).  lentil_hip_clear_frame empties the tables.  One GPU (a context with a communicator refuses).
+ *
+ * lentil_hip_download_crypto: np RGBA = (id, weight / total) of positions rank and rank + 1 -- rank 0 / 2 / 4 for
+ * the AOVs named ...00 / ...01 / ...02 (:124-126); equal weights stay in id order (what std::sort does to the up
+ * to 16 pairs it sorts by insertion).  host_has_rank (np bytes, may be NULL): 0 where the pixel's map has no more
+ * than `rank` entries -- the reference stops copying the bucket row at such a pixel (:132-134).
+ * lentil_hip_download_crypto_table: the raw tables (np * slots ids as bits, 0xFFFFFFFF = free, and weights; np
+ * totals); any pointer may be NULL. */
+typedef struct lentil_crypto_visits {
+  uint64_t n;                               /* visits (the bound stream's n) */
+  uint32_t n_crypto;                        /* cryptomatte AOVs */
+  uint32_t entries;                         /* pairs per visit and AOV, 1..64 */
+  const float *hash[LENTIL_MAX_CRYPTO];     /* n * entries ids */
+  const float *weight[LENTIL_MAX_CRYPTO];   /* n * entries weights */
+} lentil_crypto_visits;
+int lentil_hip_alloc_crypto(lentil_hip_ctx *ctx, uint32_t n_crypto, uint32_t slots_per_pixel);
+int lentil_hip_upload_crypto(lentil_hip_ctx *ctx, const lentil_crypto_visits *c);
+int lentil_hip_bind_crypto(lentil_hip_ctx *ctx, const lentil_crypto_visits *c);
+int lentil_hip_download_crypto(lentil_hip_ctx *ctx, uint32_t crypto, uint32_t rank, float *host_rgba, uint8_t *host_has_rank);
+int lentil_hip_download_crypto_table(lentil_hip_ctx *ctx, uint32_t crypto, uint32_t *slots_per_pixel, uint32_t *host_id_bits,
+                                     float *host_weight, float *host_total);
 
 /* --- instrumentation ----------------------------------------------------------------
  * timings are HIP-event times on the context's stream for the last redistribute/resolve:

@@ -42,6 +42,7 @@
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <vector>
 
 #include "../include/lentil_hip.h"
@@ -830,6 +831,15 @@ struct OrcFrame {
    * draws every attempt's colour channel from it (src/lentil_filter.cpp:397).  Explicit here, one per frame object,
    * advanced in the order this oracle walks the visits -- the single-threaded order. */
   uint32_t xor_state[4] = {123456789u, 362436069u, 521288629u, 88675123u};
+  /* cryptomatte AOVs: AOVData::crypto_hash_map / crypto_total_weight, src/aov_data.h:127-128, and the visits' caches
+   * (what cryptomatte_construct_cache leaves per visit) as `entries` (id, weight) pairs per visit */
+  struct Crypto {
+    std::vector<std::map<float, float>> hash_map;
+    std::vector<float> total_weight;
+    const float *hash = nullptr, *weight = nullptr;
+  };
+  std::vector<Crypto> crypto;
+  uint32_t crypto_entries = 0;
 };
 
 ORC_API OrcFrame *orc_frame_create(uint32_t xres, uint32_t yres, uint32_t n_aovs, const uint8_t *kind,
@@ -875,6 +885,99 @@ ORC_API void orc_frame_merge(OrcFrame *dst, const OrcFrame *src) {   /* per-thre
   dst->ctr.redistributed_visits += src->ctr.redistributed_visits;
   dst->ctr.attempted_draws += src->ctr.attempted_draws;
   dst->ctr.accepted_draws += src->ctr.accepted_draws;
+}
+
+/* ---- cryptomatte ---------------------------------------------------------------------- */
+ORC_API void orc_frame_set_crypto(OrcFrame *F, uint32_t n_crypto, uint32_t entries, const float *const *hash,
+                                  const float *const *weight) {
+  F->crypto.assign(n_crypto, OrcFrame::Crypto());
+  F->crypto_entries = entries;
+  const size_t np = (size_t)F->xres * F->yres;
+  for (uint32_t c = 0; c < n_crypto; c++) {
+    F->crypto[c].hash_map.assign(np, std::map<float, float>());      /* allocate_cryptomatte_buffers, aov_data.h:145-150 */
+    F->crypto[c].total_weight.assign(np, 0.0f);
+    F->crypto[c].hash = hash[c];
+    F->crypto[c].weight = weight[c];
+  }
+}
+
+/* Camera::cryptomatte_construct_cache, src/lentil.h:781-811, for one cryptomatte AOV: the depth samples of one AOV
+ * sample (opacity RGB and the AOV's float per depth) folded into id -> weight.  AiColorToGrey is the SDK's
+ * (r + g + b) / 3 (recalled).  Returns the number of pairs (ids ascending, the map's order); -1 when cap is short. */
+ORC_API int orc_crypto_construct_cache(int n_depth, const float *opacity_rgb, const float *value, float *ids,
+                                       float *weights, int cap) {
+  std::map<float, float> cache;
+  float iterative_transparency_weight = 1.0f;
+  float quota = 1.0;
+  float sample_value = 0.0f;
+  for (int d = 0; d < n_depth; d++) {                                 /* while (AiAOVSampleIteratorGetNextDepth) */
+    const float sub_sample_opacity = (opacity_rgb[d * 3] + opacity_rgb[d * 3 + 1] + opacity_rgb[d * 3 + 2]) / 3;
+    sample_value = value[d];
+    const float sub_sample_weight = sub_sample_opacity * iterative_transparency_weight;
+    iterative_transparency_weight *= (1.0f - sub_sample_opacity);
+    quota -= sub_sample_weight;
+    cache[sample_value] += sub_sample_weight;
+  }
+  if (quota > 0.0) cache[sample_value] += quota;                      /* :804 */
+  if ((int)cache.size() > cap) return -1;
+  int n = 0;
+  for (auto const &e : cache) { ids[n] = e.first; weights[n] = e.second; n++; }
+  return n;
+}
+
+/* the cache of visit v as the filter holds it while it adds the visit (src/lentil_filter.cpp:168-169) */
+static inline void crypto_cache_of(const OrcFrame *F, uint32_t c, uint64_t v, std::map<float, float> &cache) {
+  const OrcFrame::Crypto &K = F->crypto[c];
+  for (uint32_t e = 0; e < F->crypto_entries; e++) {
+    const float w = K.weight[v * F->crypto_entries + e];
+    uint32_t bits; memcpy(&bits, &w, 4);
+    if (bits == 0xFFFFFFFFu) continue;
+    cache[K.hash[v * F->crypto_entries + e]] += w;
+  }
+}
+
+/* Camera::add_to_buffer_cryptomatte, src/lentil.h:814-819 */
+static inline void add_to_buffer_cryptomatte(OrcFrame::Crypto &aov, uint32_t px, const std::map<float, float> &cryptomatte_cache,
+                                             const float sample_weight) {
+  aov.total_weight[px] += sample_weight;
+  for (auto const &sample : cryptomatte_cache) aov.hash_map[px][sample.first] += sample.second * sample_weight;
+}
+
+struct compareTail {                                                   /* src/lentil_imager.cpp:11-16 */
+  bool operator()(const std::pair<float, float> x, const std::pair<float, float> y) { return x.second > y.second; }
+};
+
+/* the cryptomatte branch of driver_process_bucket, src/lentil_imager.cpp:121-161, for every pixel: out np*4,
+ * has np (0 where the reference leaves the bucket row, :132-134; out is not written there) */
+ORC_API void orc_crypto_rank(const OrcFrame *F, uint32_t c, int rank, float *out, uint8_t *has) {
+  const size_t np = (size_t)F->xres * F->yres;
+  const OrcFrame::Crypto &K = F->crypto[c];
+  for (size_t p = 0; p < np; p++) {
+    has[p] = 0;
+    if ((int)K.hash_map[p].size() <= rank) continue;
+    has[p] = 1;
+    std::vector<std::pair<float, float>> all_vals;
+    all_vals.reserve(K.hash_map[p].size());
+    for (auto it = K.hash_map[p].begin(); it != K.hash_map[p].end(); ++it) all_vals.push_back(*it);
+    std::sort(all_vals.begin(), all_vals.end(), compareTail());
+    float o[4] = {0, 0, 0, 0};
+    int iter = 0;
+    for (auto it = all_vals.begin(); it != all_vals.end(); ++it) {
+      if (iter == rank) { o[0] = it->first; o[1] = (it->second / K.total_weight[p]); }
+      else if (iter == rank + 1) { o[2] = it->first; o[3] = (it->second / K.total_weight[p]); }
+      iter++;
+    }
+    memcpy(out + p * 4, o, sizeof o);
+  }
+}
+
+/* one pixel's map (ids ascending) and total weight; returns the number of entries */
+ORC_API int orc_crypto_pixel(const OrcFrame *F, uint32_t c, uint64_t p, float *ids, float *weights, int cap, float *total) {
+  const OrcFrame::Crypto &K = F->crypto[c];
+  int n = 0;
+  for (auto const &e : K.hash_map[p]) { if (n < cap) { ids[n] = e.first; weights[n] = e.second; } n++; }
+  if (total) *total = K.total_weight[p];
+  return n;
 }
 
 /* Camera::add_to_buffer, src/lentil.h:823-851 (rgb_weight is white on this path) */
@@ -950,6 +1053,9 @@ static void do_visit(const lentil_params *P, const OrcLens *L, const OrcBokeh *B
   const float sample_luminance = (sample[0] + sample[1] + sample[2]) / 3.0;         /* :161 */
   if (V->volume_ignore[v * 4 + 3] > 0.0) redistribute = false;                      /* :162-164 */
 
+  std::vector<std::map<float, float>> crypto_cache(F->crypto.size());               /* :167-169 */
+  for (uint32_t c = 0; c < F->crypto.size(); c++) crypto_cache_of(F, c, v, crypto_cache[c]);
+
   float fitted_bidir_add_energy = 0.0;                                              /* :173-174 */
   if (P->bidir_add_energy > 0.0) fitted_bidir_add_energy = orc_additional_luminance_soft_trans(P, sample_luminance);
 
@@ -981,6 +1087,8 @@ static void do_visit(const lentil_params *P, const OrcLens *L, const OrcBokeh *B
     const uint32_t pixelnumber = P->xres * py + px;                                 /* lentil.h:945 */
     for (uint32_t a = 0; a < F->n_aovs; a++)
       add_to_buffer(F, a, pixelnumber, aov_values[a], 0.0, depth, 1.0f * inverse_sample_density);
+    for (uint32_t c = 0; c < F->crypto.size(); c++)                                 /* lentil.h:952 */
+      add_to_buffer_cryptomatte(F->crypto[c], pixelnumber, crypto_cache[c], inverse_sample_density);
     return;
   }
   F->ctr.redistributed_visits++;
@@ -1018,6 +1126,8 @@ static void do_visit(const lentil_params *P, const OrcLens *L, const OrcBokeh *B
         for (uint32_t a = 0; a < F->n_aovs; a++)                                                        /* :295-298 */
           add_to_buffer(F, a, pixelnumber, aov_values[a], fitted_bidir_add_energy, depth,
                         1.0f * inverse_sample_density * inv_samples, rgb_weight);
+        for (uint32_t c = 0; c < F->crypto.size(); c++)                                                 /* :296 */
+          add_to_buffer_cryptomatte(F->crypto[c], pixelnumber, crypto_cache[c], inverse_sample_density * inv_samples);
         F->ctr.accepted_draws++;
         /* chromatic mode: the channel (0..2) rides in the attempt's top two bits */
         if (F->keep_log) F->log.push_back({(uint32_t)v, total_samples_taken | ((uint32_t)(P->abb_chromatic != 0.0 ? channel + 1 : 0) << 30),
@@ -1130,6 +1240,8 @@ static void do_visit(const lentil_params *P, const OrcLens *L, const OrcBokeh *B
     for (uint32_t a = 0; a < F->n_aovs; a++)                                                              /* :442-445 */
       add_to_buffer(F, a, pixelnumber, aov_values[a], fitted_bidir_add_energy, depth,
                     1.0f * inverse_sample_density * inv_samples, rgb_weight);
+    for (uint32_t c = 0; c < F->crypto.size(); c++)                                                       /* :443 */
+      add_to_buffer_cryptomatte(F->crypto[c], pixelnumber, crypto_cache[c], inverse_sample_density * inv_samples);
     F->ctr.accepted_draws++;
     /* chromatic mode: the channel (0..2) rides in the attempt's top two bits, as on the polynomial-optics path */
     if (F->keep_log) F->log.push_back({(uint32_t)v, total_samples_taken | ((uint32_t)(P->abb_chromatic > 0.0 ? channel + 1 : 0) << 30),

@@ -2,6 +2,7 @@
 import ctypes as C
 
 LENTIL_MAX_AOVS = 16
+LENTIL_MAX_CRYPTO = 9
 THINLENS, POLYNOMIAL_OPTICS = 0, 1
 UNIT_MM, UNIT_CM, UNIT_DM, UNIT_M = 0, 1, 2, 3
 FILTER_GAUSSIAN, FILTER_CLOSEST, FILTER_VARIANCE, FILTER_CLOSEST_DEBUG = 0, 1, 2, 3
@@ -76,6 +77,11 @@ class Visits(C.Structure):
         ("extra", C.c_void_p * (LENTIL_MAX_AOVS - 1)),
         ("pixel", C.c_void_p), ("inv_density", C.c_void_p),
     ]
+
+
+class CryptoVisits(C.Structure):
+    _fields_ = [("n", C.c_uint64), ("n_crypto", C.c_uint32), ("entries", C.c_uint32),
+                ("hash", C.c_void_p * LENTIL_MAX_CRYPTO), ("weight", C.c_void_p * LENTIL_MAX_CRYPTO)]
 
 
 class Counters(C.Structure):

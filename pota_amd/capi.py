@@ -32,6 +32,8 @@ EXPORTS = [
     "lentil_hip_visits_wait", "lentil_hip_visits_end",
     "lentil_hip_comm_unique_id", "lentil_hip_comm_init", "lentil_hip_comm_destroy", "lentil_hip_allreduce",
     "lentil_hip_exchange_bands",
+    "lentil_hip_alloc_crypto", "lentil_hip_upload_crypto", "lentil_hip_bind_crypto", "lentil_hip_download_crypto",
+    "lentil_hip_download_crypto_table",
 ]
 
 _lib = None
@@ -94,6 +96,11 @@ def load_library():
         "lentil_hip_get_counters": (i, [vp, C.POINTER(_abi.Counters)]),
         "lentil_hip_last_timing": (i, [vp, C.POINTER(C.c_float)]),
         "lentil_hip_last_launches": (i, [vp, C.POINTER(C.c_uint32)]),
+        "lentil_hip_alloc_crypto": (i, [vp, u32, u32]),
+        "lentil_hip_upload_crypto": (i, [vp, C.POINTER(_abi.CryptoVisits)]),
+        "lentil_hip_bind_crypto": (i, [vp, C.POINTER(_abi.CryptoVisits)]),
+        "lentil_hip_download_crypto": (i, [vp, u32, u32, vp, vp]),
+        "lentil_hip_download_crypto_table": (i, [vp, u32, C.POINTER(u32), vp, vp, vp]),
         "lentil_hip_set_draw_log": (i, [vp, u64]),
         "lentil_hip_download_draw_log": (i, [vp, vp, u64, C.POINTER(u64)]),
         "lentil_hip_test_lt_sample_aperture": (i, [vp, u64, vp, vp, C.c_double, vp, vp, vp]),
@@ -138,6 +145,20 @@ def host_alloc(nbytes):
 
 def host_free(ptr):
     load_library().lentil_hip_host_free(C.c_void_p(ptr))
+
+
+def make_crypto_visits(hashes, weights, ptr=lambda a: a.ctypes.data):
+    """lentil_crypto_visits from per-AOV lists of [n, entries] fp32 arrays.  Returns (CryptoVisits, keepalive)."""
+    c = _abi.CryptoVisits()
+    c.n_crypto = len(hashes)
+    c.n, c.entries = hashes[0].shape
+    keep = []
+    for a, (h, w) in enumerate(zip(hashes, weights)):
+        assert h.shape == w.shape == (c.n, c.entries)
+        c.hash[a] = ptr(h)
+        c.weight[a] = ptr(w)
+        keep += [h, w]
+    return c, keep
 
 
 def make_visits(cols, visits_per_pixel=0, pixels_per_row=0, pixel_x0=0, pixel_y0=0, pixel_row_stride=1,
@@ -393,6 +414,35 @@ class Context:
         n = (C.c_uint32 * 2)()
         self._chk(self.lib.lentil_hip_last_launches(self.h, n))
         return int(n[0]), int(n[1])
+
+    # --- cryptomatte AOVs
+    def alloc_crypto(self, n_crypto, slots_per_pixel=0):
+        self._chk(self.lib.lentil_hip_alloc_crypto(self.h, n_crypto, slots_per_pixel))
+
+    def upload_crypto(self, crypto_visits):
+        self._chk(self.lib.lentil_hip_upload_crypto(self.h, C.byref(crypto_visits)))
+
+    def bind_crypto(self, crypto_visits, keepalive=None):
+        self._chk(self.lib.lentil_hip_bind_crypto(self.h, C.byref(crypto_visits)))
+        self._keep["crypto"] = keepalive
+
+    def download_crypto(self, crypto, rank):
+        """(np x 4 RGBA, np bool: the pixel's map has more than `rank` entries)"""
+        out = np.empty((self.n_pixels, 4), np.float32)
+        has = np.empty(self.n_pixels, np.uint8)
+        self._chk(self.lib.lentil_hip_download_crypto(self.h, crypto, rank, out.ctypes.data, has.ctypes.data))
+        return out, has.astype(bool)
+
+    def download_crypto_table(self, crypto):
+        """(id bits [np, slots] uint32 with 0xFFFFFFFF = free, weights [np, slots], totals [np])"""
+        slots = C.c_uint32()
+        self._chk(self.lib.lentil_hip_download_crypto_table(self.h, crypto, C.byref(slots), None, None, None))
+        ids = np.empty((self.n_pixels, slots.value), np.uint32)
+        wts = np.empty((self.n_pixels, slots.value), np.float32)
+        tot = np.empty(self.n_pixels, np.float32)
+        self._chk(self.lib.lentil_hip_download_crypto_table(self.h, crypto, C.byref(slots), ids.ctypes.data, wts.ctypes.data,
+                                                            tot.ctypes.data))
+        return ids, wts, tot
 
     def set_draw_log(self, capacity):
         self._chk(self.lib.lentil_hip_set_draw_log(self.h, capacity))

@@ -1,0 +1,333 @@
+// lentil_crypto.h -- cryptomatte AOVs through the bidirectional pass (lentil_hip_alloc_crypto / _upload_crypto /
+// _bind_crypto / _download_crypto / _download_crypto_table; include/lentil_hip.h).  Included by lentil_hip.hip.
+//
+// The reference keeps, per cryptomatte AOV and pixel, a std::map<float, float> id -> weight and a total weight
+// (AOVData::crypto_hash_map / crypto_total_weight, src/aov_data.h:127-128).  Every add of a visit to a pixel -- its
+// own pixel when it is not redistributed (src/lentil.h:952), the pixel of each accepted draw otherwise
+// (src/lentil_filter.cpp:296,443) -- adds `sample_weight` to the total and `cache weight * sample_weight` to the map
+// entry of every id in the visit's cache (add_to_buffer_cryptomatte, src/lentil.h:814-819); the cache is the visit's
+// depth samples folded by opacity (cryptomatte_construct_cache, :781-811: host work on the renderer's iterator,
+// lentil_crypto_construct_cache in liblentil_bridge.so).  The imager sorts a pixel's map by weight and writes the
+// pairs at positions rank, rank + 1 (src/lentil_imager.cpp:121-161).
+//
+// Here: the maps are open-addressed tables of `slots` (id bits, fp32 weight) pairs per pixel in HBM -- a pixel's
+// table is one or two 64-byte lines -- filled with atomicCAS on the id and atomicAdd on the weight.  The adds do not
+// ride in the draw kernels (whose register budgets are what the pass's speed hangs on): they are replayed after the
+// pass from what it leaves behind -- the redistribute decision, recomputed per visit (visit_redistributes, the very
+// function the scan uses), for the visits that stay in their pixel, and the pass's draw log (visit, pixel per accepted
+// draw; the log the parity tests compare with the oracle's in every mode of the pass) for the others.  The weight of
+// a draw is the visit's inverse density times 1 / draw count, recomputed like load_work_visit does.
+#pragma once
+
+constexpr uint32_t kCryptoEmpty = 0xFFFFFFFFu;     // id bits of a free slot (a NaN pattern; cryptomatte ids never are)
+constexpr uint32_t kCryptoMaxSlots = 64;
+
+struct CryptoDev {
+  uint32_t n_crypto, entries, slots;
+  uint64_t np;
+  const float *hash[LENTIL_MAX_CRYPTO];     // per visit: `entries` ids ...
+  const float *weight[LENTIL_MAX_CRYPTO];   // ... and weights (bits 0xFFFFFFFF: pair unused)
+  uint32_t *keys;                           // [n_crypto][np][slots]
+  float *wts;                               // [n_crypto][np][slots]
+  float *total;                             // [n_crypto][np]
+  unsigned long long *overflow;             // adds that found their pixel's table full
+};
+
+struct LentilCrypto {
+  CryptoDev D{};
+  bool have_columns = false;
+  uint64_t n_visits = 0;
+  std::vector<void *> owned;                // device columns of lentil_hip_upload_crypto
+  float *d_rank = nullptr;                  // download staging: np RGBA + np flags
+  uint8_t *d_has = nullptr;
+  uint64_t auto_log = 0;                    // draw-log capacity this module asked for (0: the caller's)
+};
+
+// std::map<float, float> compares ids as floats: +0 and -0 are one key.  The table compares bits.
+LD_DEV uint32_t crypto_key_bits(float id) {
+  const uint32_t b = __float_as_uint(id);
+  return b == 0x80000000u ? 0u : b;
+}
+
+// add_to_buffer_cryptomatte, src/lentil.h:814-819, for visit v and every cryptomatte AOV
+LD_DEV void crypto_add_visit(const CryptoDev &C, uint64_t pix, uint64_t v, float sample_weight) {
+  for (uint32_t c = 0; c < C.n_crypto; ++c) {
+    atomicAdd(C.total + (uint64_t)c * C.np + pix, sample_weight);                       // :815
+    uint32_t *K = C.keys + ((uint64_t)c * C.np + pix) * C.slots;
+    float *Wt = C.wts + ((uint64_t)c * C.np + pix) * C.slots;
+    const float *h = C.hash[c] + v * C.entries, *w = C.weight[c] + v * C.entries;
+    for (uint32_t e = 0; e < C.entries; ++e) {
+      const float cw = w[e];
+      if (__float_as_uint(cw) == kCryptoEmpty) continue;
+      const uint32_t key = crypto_key_bits(h[e]);
+      const float val = cw * sample_weight;                                             // :817
+      uint32_t s = (key * 2654435761u >> 16) % C.slots;
+      bool placed = false;
+      for (uint32_t i = 0; i < C.slots && !placed; ++i) {
+        uint32_t cur = __hip_atomic_load(K + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (cur == kCryptoEmpty) cur = atomicCAS(K + s, kCryptoEmpty, key);
+        if (cur == kCryptoEmpty || cur == key) { atomicAdd(Wt + s, val); placed = true; }
+        else s = s + 1u == C.slots ? 0u : s + 1u;
+      }
+      if (!placed) atomicAdd(C.overflow, 1ull);
+    }
+  }
+}
+
+// visits that stay in their own pixel: filter_and_add_to_buffer_new, src/lentil.h:938-955 (:952), called at
+// src/lentil_filter.cpp:243-246 / :306-309 -- sample weight = inverse sample density
+__global__ __launch_bounds__(256) void crypto_direct_kernel(CryptoDev C, VisitsDev V, lentil_params P, double lens_length) {
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; v < V.n; v += stride) {
+    const float invd = V.inv_density ? V.inv_density[v] : P.inverse_sample_density;
+    if (visit_redistributes(P, lens_length, V.pos_z[v], V.volume_ignore[v], V.transmission[v], invd,
+                            [&]() { return V.raydir_time[v]; }))
+      continue;
+    int px, py;
+    visit_pixel(V, v, px, py);
+    crypto_add_visit(C, (uint64_t)P.xres * (uint32_t)py + (uint32_t)px, v, invd);
+  }
+}
+
+// accepted draws (src/lentil_filter.cpp:296 polynomial optics, :443 thin lens; with abb_chromatic every channel's
+// draw is a log record of its own, like it is an add of its own there) -- sample weight = inverse density / draws
+__global__ __launch_bounds__(256) void crypto_draws_kernel(CryptoDev C, VisitsDev V, lentil_params P, double lens_length,
+                                                           const lentil_draw_record *log, uint64_t n_log) {
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_log; i += stride) {
+    const uint32_t v = log[i].visit;
+    const float invd = V.inv_density ? V.inv_density[v] : P.inverse_sample_density;
+    const VisitInfo I = visit_prologue(P, lens_length, V.rgba[v], V.pos_z[v], V.raydir_time[v], V.volume_ignore[v],
+                                       V.transmission[v], invd);
+    const float inv_samples = (float)(1.0 / (double)(float)(int)I.samples);            // src/lentil_filter.cpp:199
+    crypto_add_visit(C, log[i].pixel, v, invd * inv_samples);
+  }
+}
+
+// src/lentil_imager.cpp:121-161 for one AOV: the map's pairs ordered by weight, largest first (std::sort with
+// compareTail on the map's id-ordered pairs: for the up to 16 pairs libstdc++ sorts by insertion, equal weights stay
+// in id order -- the order used here for any count), positions rank and rank + 1 written as (id, weight / total).
+// has[p] = 0 where the map has no more than `rank` entries (the reference stops copying the bucket row there, :132-134).
+__global__ __launch_bounds__(256) void crypto_rank_kernel(CryptoDev C, uint32_t c, uint32_t rank, float4 *out, uint8_t *has) {
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; p < C.np; p += stride) {
+    const uint32_t *K = C.keys + ((uint64_t)c * C.np + p) * C.slots;
+    const float *Wt = C.wts + ((uint64_t)c * C.np + p) * C.slots;
+    uint32_t count = 0;
+    for (uint32_t i = 0; i < C.slots; ++i) count += K[i] != kCryptoEmpty;
+    float4 o = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (count > rank) {
+      const float total = C.total[(uint64_t)c * C.np + p];
+      for (uint32_t i = 0; i < C.slots; ++i) {
+        if (K[i] == kCryptoEmpty) continue;
+        const float wi = Wt[i], ki = __uint_as_float(K[i]);
+        uint32_t pos = 0;                    // pairs sorted before pair i
+        for (uint32_t j = 0; j < C.slots; ++j) {
+          if (j == i || K[j] == kCryptoEmpty) continue;
+          const float wj = Wt[j], kj = __uint_as_float(K[j]);
+          pos += (wj > wi) || (!(wi > wj) && kj < ki);
+        }
+        if (pos == rank) { o.x = ki; o.y = wi / total; }
+        else if (pos == rank + 1u) { o.z = ki; o.w = wi / total; }
+      }
+    }
+    out[p] = o;
+    has[p] = count > rank;
+  }
+}
+
+static void crypto_free_columns(LentilCrypto *k) {
+  for (void *p : k->owned) (void)hipFree(p);
+  k->owned.clear();
+  for (uint32_t c = 0; c < LENTIL_MAX_CRYPTO; ++c) k->D.hash[c] = k->D.weight[c] = nullptr;
+  k->have_columns = false;
+  k->n_visits = 0;
+}
+
+static void crypto_destroy(lentil_hip_ctx *ctx) {
+  LentilCrypto *k = ctx->crypto;
+  if (!k) return;
+  if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+  crypto_free_columns(k);
+  (void)hipFree(k->D.keys); (void)hipFree(k->D.wts); (void)hipFree(k->D.total); (void)hipFree(k->D.overflow);
+  (void)hipFree(k->d_rank); (void)hipFree(k->d_has);
+  delete k;
+  ctx->crypto = nullptr;
+}
+
+LENTIL_API int lentil_hip_alloc_crypto(lentil_hip_ctx *ctx, uint32_t n_crypto, uint32_t slots_per_pixel) {
+  CHECK_CTX(ctx);
+  if (!ctx->have_frame) return fail(ctx, LENTIL_ERR_INVALID, "alloc_crypto needs alloc_frame first");
+  if (n_crypto > LENTIL_MAX_CRYPTO) return fail(ctx, LENTIL_ERR_INVALID, "too many cryptomatte AOVs");
+  if (slots_per_pixel == 0) slots_per_pixel = 16;
+  if (slots_per_pixel > kCryptoMaxSlots) return fail(ctx, LENTIL_ERR_INVALID, "at most 64 table slots per pixel");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  crypto_destroy(ctx);
+  if (n_crypto == 0) return LENTIL_OK;
+  LentilCrypto *k = new LentilCrypto();
+  ctx->crypto = k;
+  k->D.n_crypto = n_crypto;
+  k->D.slots = slots_per_pixel;
+  k->D.np = ctx->F.np;
+  const uint64_t cells = (uint64_t)n_crypto * k->D.np * slots_per_pixel;
+  HIP_TRY(ctx, hipMalloc(&k->D.keys, cells * sizeof(uint32_t)));
+  HIP_TRY(ctx, hipMalloc(&k->D.wts, cells * sizeof(float)));
+  HIP_TRY(ctx, hipMalloc(&k->D.total, (uint64_t)n_crypto * k->D.np * sizeof(float)));
+  HIP_TRY(ctx, hipMalloc(&k->D.overflow, sizeof(unsigned long long)));
+  HIP_TRY(ctx, hipMalloc(&k->d_rank, k->D.np * sizeof(float4)));
+  HIP_TRY(ctx, hipMalloc(&k->d_has, k->D.np));
+  HIP_TRY(ctx, hipMemsetAsync(k->D.keys, 0xFF, cells * sizeof(uint32_t), ctx->stream));
+  HIP_TRY(ctx, hipMemsetAsync(k->D.wts, 0, cells * sizeof(float), ctx->stream));
+  HIP_TRY(ctx, hipMemsetAsync(k->D.total, 0, (uint64_t)n_crypto * k->D.np * sizeof(float), ctx->stream));
+  HIP_TRY(ctx, hipMemsetAsync(k->D.overflow, 0, sizeof(unsigned long long), ctx->stream));
+  return LENTIL_OK;
+}
+
+// lentil_hip_clear_frame: AOVData::allocate_cryptomatte_buffers, src/aov_data.h:145-150
+static int crypto_clear(lentil_hip_ctx *ctx) {
+  LentilCrypto *k = ctx->crypto;
+  if (!k) return LENTIL_OK;
+  const uint64_t cells = (uint64_t)k->D.n_crypto * k->D.np * k->D.slots;
+  HIP_TRY(ctx, hipMemsetAsync(k->D.keys, 0xFF, cells * sizeof(uint32_t), ctx->stream));
+  HIP_TRY(ctx, hipMemsetAsync(k->D.wts, 0, cells * sizeof(float), ctx->stream));
+  HIP_TRY(ctx, hipMemsetAsync(k->D.total, 0, (uint64_t)k->D.n_crypto * k->D.np * sizeof(float), ctx->stream));
+  HIP_TRY(ctx, hipMemsetAsync(k->D.overflow, 0, sizeof(unsigned long long), ctx->stream));
+  return LENTIL_OK;
+}
+
+static int crypto_check_columns(lentil_hip_ctx *ctx, const lentil_crypto_visits *c) {
+  if (!ctx->crypto) return fail(ctx, LENTIL_ERR_INVALID, "no cryptomatte AOVs allocated (lentil_hip_alloc_crypto)");
+  if (!c) return fail(ctx, LENTIL_ERR_INVALID, "crypto columns are null");
+  if (c->n_crypto != ctx->crypto->D.n_crypto) return fail(ctx, LENTIL_ERR_INVALID, "crypto columns for a different number of AOVs");
+  if (c->entries == 0 || c->entries > 64) return fail(ctx, LENTIL_ERR_INVALID, "crypto entries per visit must be 1..64");
+  for (uint32_t a = 0; a < c->n_crypto; ++a)
+    if (c->n && (!c->hash[a] || !c->weight[a])) return fail(ctx, LENTIL_ERR_INVALID, "a crypto column is null");
+  return LENTIL_OK;
+}
+
+LENTIL_API int lentil_hip_bind_crypto(lentil_hip_ctx *ctx, const lentil_crypto_visits *c) {
+  CHECK_CTX(ctx);
+  { const int rc = crypto_check_columns(ctx, c); if (rc) return rc; }
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  LentilCrypto *k = ctx->crypto;
+  crypto_free_columns(k);
+  for (uint32_t a = 0; a < c->n_crypto; ++a) { k->D.hash[a] = c->hash[a]; k->D.weight[a] = c->weight[a]; }
+  k->D.entries = c->entries;
+  k->n_visits = c->n;
+  k->have_columns = true;
+  return LENTIL_OK;
+}
+
+LENTIL_API int lentil_hip_upload_crypto(lentil_hip_ctx *ctx, const lentil_crypto_visits *c) {
+  CHECK_CTX(ctx);
+  { const int rc = crypto_check_columns(ctx, c); if (rc) return rc; }
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  LentilCrypto *k = ctx->crypto;
+  crypto_free_columns(k);
+  const size_t bytes = (size_t)c->n * c->entries * sizeof(float);
+  for (uint32_t a = 0; a < c->n_crypto && bytes; ++a) {
+    for (int which = 0; which < 2; ++which) {
+      void *d = nullptr;
+      HIP_TRY(ctx, hipMalloc(&d, bytes));
+      k->owned.push_back(d);
+      HIP_TRY(ctx, hipMemcpyAsync(d, which ? (const void *)c->weight[a] : (const void *)c->hash[a], bytes, hipMemcpyHostToDevice, ctx->stream));
+      (which ? k->D.weight[a] : k->D.hash[a]) = (const float *)d;
+    }
+  }
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  k->D.entries = c->entries;
+  k->n_visits = c->n;
+  k->have_columns = true;
+  return LENTIL_OK;
+}
+
+// lentil_hip_redistribute, before the pass: the replay needs the pass's draw log
+static int crypto_before_pass(lentil_hip_ctx *ctx) {
+  LentilCrypto *k = ctx->crypto;
+  if (!k) return LENTIL_OK;
+  if (!k->have_columns || k->n_visits != ctx->V.n)
+    return fail(ctx, LENTIL_ERR_INVALID, "the cryptomatte columns do not belong to the bound visit stream (lentil_hip_upload_crypto / _bind_crypto after the visits)");
+  if (ctx->comm || ctx->closest_deferred)
+    return fail(ctx, LENTIL_ERR_UNSUPPORTED, "cryptomatte AOVs are not exchanged between GPUs");
+  if (ctx->log_cap == 0) {
+    // no log asked for by the caller: one sized from the last pass (or 4 Mi records, 48 MB)
+    uint64_t want = 4ull << 20;
+    if (k->auto_log > want) want = k->auto_log;
+    const int rc = lentil_hip_set_draw_log(ctx, want);
+    if (rc) return rc;
+    k->auto_log = want;
+  }
+  return LENTIL_OK;
+}
+
+// ... and after it (on the main stream, behind everything the pass enqueued)
+static int crypto_after_pass(lentil_hip_ctx *ctx) {
+  LentilCrypto *k = ctx->crypto;
+  if (!k || !ctx->V.n) return LENTIL_OK;
+  unsigned long long n_log = 0;
+  HIP_TRY(ctx, hipMemcpyAsync(&n_log, (char *)(ctx->d_ctr + ctx->n_chunks) + offsetof(DevCounters, log_count), sizeof(n_log),
+                              hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  if (n_log > ctx->log_cap) {
+    if (k->auto_log) {       // this module's own log: the next pass gets one that fits
+      k->auto_log = n_log + n_log / 4;
+      (void)lentil_hip_set_draw_log(ctx, 0);
+    }
+    return fail(ctx, LENTIL_ERR_NOMEM, "the draw log (" + std::to_string(ctx->log_cap) + " records) is too small for the cryptomatte AOVs of this pass (" +
+                                           std::to_string(n_log) + " accepted draws): clear the frame and redistribute again");
+  }
+  const double lens_length = ctx->have_lens ? ctx->hlens.length : 0.0;
+  const unsigned blocks = (unsigned)ctx->num_cu * 8;
+  hipLaunchKernelGGL(crypto_direct_kernel, dim3(blocks), dim3(256), 0, ctx->stream, k->D, ctx->V, ctx->P, lens_length);
+  HIP_TRY(ctx, hipGetLastError());
+  if (n_log) {
+    hipLaunchKernelGGL(crypto_draws_kernel, dim3(blocks), dim3(256), 0, ctx->stream, k->D, ctx->V, ctx->P, lens_length,
+                       ctx->d_log, (uint64_t)n_log);
+    HIP_TRY(ctx, hipGetLastError());
+  }
+  unsigned long long full = 0;
+  HIP_TRY(ctx, hipMemcpyAsync(&full, k->D.overflow, sizeof(full), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  if (full)
+    return fail(ctx, LENTIL_ERR_NOMEM, std::to_string(full) + " cryptomatte adds found their pixel's table full (" + std::to_string(k->D.slots) +
+                                           " ids per pixel): allocate more slots (lentil_hip_alloc_crypto)");
+  return LENTIL_OK;
+}
+
+static int crypto_check_index(lentil_hip_ctx *ctx, uint32_t crypto) {
+  if (!ctx->crypto) return fail(ctx, LENTIL_ERR_INVALID, "no cryptomatte AOVs allocated");
+  if (crypto >= ctx->crypto->D.n_crypto) return fail(ctx, LENTIL_ERR_INVALID, "cryptomatte AOV index out of range");
+  return LENTIL_OK;
+}
+
+LENTIL_API int lentil_hip_download_crypto(lentil_hip_ctx *ctx, uint32_t crypto, uint32_t rank, float *host_rgba, uint8_t *host_has_rank) {
+  CHECK_CTX(ctx);
+  { const int rc = crypto_check_index(ctx, crypto); if (rc) return rc; }
+  if (!host_rgba) return fail(ctx, LENTIL_ERR_INVALID, "host_rgba is null");
+  LentilCrypto *k = ctx->crypto;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  hipLaunchKernelGGL(crypto_rank_kernel, dim3((unsigned)ctx->num_cu * 8), dim3(256), 0, ctx->stream, k->D, crypto, rank,
+                     reinterpret_cast<float4 *>(k->d_rank), k->d_has);
+  HIP_TRY(ctx, hipGetLastError());
+  HIP_TRY(ctx, hipMemcpyAsync(host_rgba, k->d_rank, k->D.np * sizeof(float4), hipMemcpyDeviceToHost, ctx->stream));
+  if (host_has_rank) HIP_TRY(ctx, hipMemcpyAsync(host_has_rank, k->d_has, k->D.np, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return LENTIL_OK;
+}
+
+LENTIL_API int lentil_hip_download_crypto_table(lentil_hip_ctx *ctx, uint32_t crypto, uint32_t *slots_per_pixel, uint32_t *host_id_bits,
+                                                float *host_weight, float *host_total) {
+  CHECK_CTX(ctx);
+  { const int rc = crypto_check_index(ctx, crypto); if (rc) return rc; }
+  LentilCrypto *k = ctx->crypto;
+  if (slots_per_pixel) *slots_per_pixel = k->D.slots;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  const uint64_t cells = k->D.np * k->D.slots;
+  if (host_id_bits) HIP_TRY(ctx, hipMemcpyAsync(host_id_bits, k->D.keys + crypto * cells, cells * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+  if (host_weight) HIP_TRY(ctx, hipMemcpyAsync(host_weight, k->D.wts + crypto * cells, cells * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+  if (host_total) HIP_TRY(ctx, hipMemcpyAsync(host_total, k->D.total + crypto * k->D.np, k->D.np * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return LENTIL_OK;
+}

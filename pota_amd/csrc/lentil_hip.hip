@@ -151,6 +151,7 @@ struct lentil_hip_ctx {
   double lens_housing_radius = 0.0;  // lens_aperture_housing_radius of the current table (focus search)
   struct LentilUpload *upload = nullptr;   // lentil_upload.h: the visit stream handed over piece by piece
   struct LentilComm *comm = nullptr; // lentil_comm.h: this context's RCCL communicator, if one was asked for
+  struct LentilCrypto *crypto = nullptr;   // lentil_crypto.h: cryptomatte AOVs, if any were allocated
 };
 
 static thread_local std::string g_err;
@@ -282,6 +283,10 @@ static void free_bokeh(lentil_hip_ctx *ctx) {
 LENTIL_API int lentil_hip_comm_destroy(lentil_hip_ctx *ctx);
 static void upload_destroy(lentil_hip_ctx *ctx);
 static void upload_release(lentil_hip_ctx *ctx, bool free_columns);
+static void crypto_destroy(lentil_hip_ctx *ctx);
+static int crypto_clear(lentil_hip_ctx *ctx);
+static int crypto_before_pass(lentil_hip_ctx *ctx);
+static int crypto_after_pass(lentil_hip_ctx *ctx);
 
 LENTIL_API int lentil_hip_destroy(lentil_hip_ctx *ctx) {
   if (!ctx) return LENTIL_OK;
@@ -289,6 +294,7 @@ LENTIL_API int lentil_hip_destroy(lentil_hip_ctx *ctx) {
   (void)hipSetDevice(ctx->device);
   upload_destroy(ctx);
   (void)hipSetDevice(ctx->device);
+  crypto_destroy(ctx);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   free_visits(ctx);
   free_bokeh(ctx);
@@ -518,6 +524,7 @@ LENTIL_API int lentil_hip_alloc_frame(lentil_hip_ctx *ctx, uint32_t n_aovs, cons
   }
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  crypto_destroy(ctx);          // tables are per pixel of the frame: lentil_hip_alloc_crypto follows alloc_frame
   (void)hipFree(ctx->F.acc);
   (void)hipFree(ctx->d_dir);
   ctx->d_dir = nullptr;
@@ -698,6 +705,7 @@ LENTIL_API int lentil_hip_clear_frame(lentil_hip_ctx *ctx) {
     if (ctx->F.zkey_dbg) HIP_TRY(ctx, hipMemsetAsync(ctx->F.zkey_dbg + p0, 0xFF, (p1 - p0) * sizeof(unsigned long long), ctx->stream));
   }
   }
+  { const int rc = crypto_clear(ctx); if (rc) return rc; }
   ctx->F.dir = nullptr;         // what the scan stored there no longer counts (wiped or overwritten before it does again)
   ctx->cleared_since_pass = true;
   ctx->dirty_lo = ctx->dirty_hi = 0;
@@ -1588,6 +1596,7 @@ LENTIL_API int lentil_hip_redistribute(lentil_hip_ctx *ctx) {
   if (ctx->F.debug_mask && ctx->closest_deferred && !ctx->comm)
     return fail(ctx, LENTIL_ERR_UNSUPPORTED, "the lentil_debug AOV is exchanged between GPUs by lentil_hip_allreduce / _exchange_bands only");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
+  { const int rc = crypto_before_pass(ctx); if (rc) return rc; }
   const int C = ctx->n_chunks;
   if (ctx->pass_pending) ctx->dirty_known = false;   // an earlier pass's rows were never asked for: unknown until a full clear
   ctx->pass_pending = true;
@@ -1777,7 +1786,7 @@ LENTIL_API int lentil_hip_redistribute(lentil_hip_ctx *ctx) {
       return fail(ctx, LENTIL_ERR_NOMEM, "the device dropped " + std::to_string(dropped) +
                                              " work items (work list, task queue or result pool too small): the frame is incomplete");
   }
-  return LENTIL_OK;
+  return crypto_after_pass(ctx);
 }
 
 LENTIL_API int lentil_hip_set_closest_exchange(lentil_hip_ctx *ctx, int deferred, uint32_t visit_id_base) {
@@ -2364,3 +2373,4 @@ LENTIL_API int lentil_hip_test_aperture_sample(lentil_hip_ctx *ctx, uint64_t n, 
 
 #include "lentil_upload.h"
 #include "lentil_comm.h"
+#include "lentil_crypto.h"

@@ -68,6 +68,10 @@ def load():
         "orc_frame_set_xor128": (None, [vp, C.POINTER(C.c_uint32)]),
         "orc_frame_get_xor128": (None, [vp, C.POINTER(C.c_uint32)]),
         "orc_frame_log": (u64, [vp, vp, u64]),
+        "orc_frame_set_crypto": (None, [vp, u32, u32, vp, vp]),
+        "orc_crypto_construct_cache": (i, [i, vp, vp, vp, vp, i]),
+        "orc_crypto_rank": (None, [vp, u32, i, vp, vp]),
+        "orc_crypto_pixel": (i, [vp, u32, u64, vp, vp, i, C.POINTER(f)]),
         "orc_frame_merge": (None, [vp, vp]),
         "orc_redistribute": (i, [C.POINTER(_abi.Params), vp, vp, vp, C.POINTER(_abi.Visits), u64, u64]),
         "orc_resolve": (None, [vp, u32, vp]),
@@ -140,6 +144,28 @@ class Frame:
         rec = np.empty((n, 3), np.uint32)
         self.lib.orc_frame_log(self.h, rec.ctypes.data, n)
         return rec
+
+    def set_crypto(self, hashes, weights):
+        """per-AOV lists of [n, entries] fp32 arrays (kept alive by the wrapper)"""
+        n = len(hashes)
+        self._crypto_keep = ([np.ascontiguousarray(h, np.float32) for h in hashes],
+                             [np.ascontiguousarray(w, np.float32) for w in weights])
+        hp = (C.c_void_p * n)(*[h.ctypes.data for h in self._crypto_keep[0]])
+        wp = (C.c_void_p * n)(*[w.ctypes.data for w in self._crypto_keep[1]])
+        self.lib.orc_frame_set_crypto(self.h, n, self._crypto_keep[0][0].shape[1], C.cast(hp, C.c_void_p), C.cast(wp, C.c_void_p))
+
+    def crypto_rank(self, crypto, rank):
+        out = np.zeros((self.np, 4), np.float32)
+        has = np.zeros(self.np, np.uint8)
+        self.lib.orc_crypto_rank(self.h, crypto, rank, out.ctypes.data, has.ctypes.data)
+        return out, has.astype(bool)
+
+    def crypto_pixel(self, crypto, p, cap=256):
+        ids = np.empty(cap, np.float32); wts = np.empty(cap, np.float32)
+        tot = C.c_float()
+        n = self.lib.orc_crypto_pixel(self.h, crypto, p, ids.ctypes.data, wts.ctypes.data, cap, C.byref(tot))
+        assert n <= cap
+        return ids[:n].copy(), wts[:n].copy(), tot.value
 
     def close(self):
         if self.h:

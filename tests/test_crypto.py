@@ -1,0 +1,251 @@
+"""Cryptomatte AOVs through the bidirectional pass: Camera::cryptomatte_construct_cache,
+add_to_buffer_cryptomatte (src/lentil.h:781-819) and the imager's ranking (src/lentil_imager.cpp:121-161).
+
+The oracle keeps the reference's std::map per pixel; the GPU keeps open-addressed tables filled with atomics.  Ids and
+the set of ids per pixel are compared exactly; weights and totals are fp32 sums in a different order (1e-5, like the
+gaussian AOVs); the ranked RGBA images exactly in the ids wherever the oracle's weights are further apart than that."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import common
+import oracle_lib
+from pota_amd import capi
+
+TOL = 1e-5
+UNUSED = np.array([0xFFFFFFFF], np.uint32).view(np.float32)[0]
+
+
+def make_crypto_columns(n, W, M, n_crypto, entries, seed=7, palette=11):
+    """Per cryptomatte AOV: [n, entries] ids and weights.  Ids follow the pixel column (objects are coherent in the
+    image), one entry in four is unused, some weights are exactly 0 (the reference still creates the map entry),
+    one id is -0.0 beside +0.0."""
+    rng = np.random.default_rng(seed)
+    pal = rng.standard_normal(palette).astype(np.float32) * 1e3
+    pal[0], pal[1] = 0.0, -0.0
+    pix_x = (np.arange(n) // M) % W
+    hashes, weights = [], []
+    for a in range(n_crypto):
+        base = (pix_x // 6 + a) % palette
+        ids = np.empty((n, entries), np.float32)
+        for e in range(entries):                                   # distinct ids inside a visit's cache
+            ids[:, e] = pal[(base + e * (1 + (rng.integers(0, 2, n)))) % palette] if e else pal[base]
+        for e in range(1, entries):                                # make them distinct like a map's keys are
+            clash = np.zeros(n, bool)
+            for e2 in range(e):
+                clash |= ids[:, e] == ids[:, e2]
+            ids[clash, e] = (1e6 + 17.0 * e + a + np.arange(n)[clash] % 5).astype(np.float32)
+        w = rng.random((n, entries)).astype(np.float32)
+        w[rng.random((n, entries)) < 0.1] = 0.0
+        unused = rng.random((n, entries)) < 0.25
+        unused[:, 0] = False
+        w[unused] = UNUSED
+        hashes.append(np.ascontiguousarray(ids))
+        weights.append(np.ascontiguousarray(w))
+    return hashes, weights
+
+
+def test_construct_cache_known_answers(orc):
+    """cryptomatte_construct_cache, src/lentil.h:781-811, on hand-worked depth lists."""
+    def cache(opacity, values):
+        op = np.repeat(np.asarray(opacity, np.float32), 3)
+        va = np.asarray(values, np.float32)
+        ids = np.empty(16, np.float32); wts = np.empty(16, np.float32)
+        n = orc.orc_crypto_construct_cache(len(values), op.ctypes.data, va.ctypes.data, ids.ctypes.data, wts.ctypes.data, 16)
+        return dict(zip(ids[:n].tolist(), wts[:n].tolist())), ids[:n]
+    # half-transparent A in front of opaque B: A 0.5, B 0.5, nothing left over
+    d, _ = cache([0.5, 1.0], [3.0, 5.0])
+    assert d == {3.0: 0.5, 5.0: 0.5}
+    # only a quarter-opaque A: the remaining 0.75 goes to the last sample's id
+    d, _ = cache([0.25], [3.0])
+    assert d == {3.0: 1.0}
+    # no depth samples at all: id 0 with the whole quota
+    d, _ = cache([], [])
+    assert d == {0.0: 1.0}
+    # the same id at two depths is one entry; ids come out in the map's (ascending) order
+    d, ids = cache([0.5, 0.5, 0.5], [7.0, -2.0, 7.0])
+    assert list(ids) == [-2.0, 7.0]
+    assert d[-2.0] == np.float32(0.25)
+    assert d[7.0] == np.float32(np.float32(0.5) + np.float32(0.125)) + np.float32(0.125)     # 0.5 + 0.125, then the 0.125 left
+    # a fully transparent sample still makes its (zero-weight) entry
+    d, _ = cache([0.0, 1.0], [9.0, 4.0])
+    assert d == {9.0: 0.0, 4.0: 1.0}
+
+
+def test_oracle_crypto_conserves_weight(orc):
+    """Every add spreads sample_weight over the cache's ids: with caches that sum to 1 a pixel's map sums to its total
+    weight, and the total equals the RGBA AOV's filter weight (same adds, src/lentil.h:826 / :815)."""
+    W, H, M = 48, 32, 9
+    p, model, table, keep = common.po_setup(W, H, samples_override=32)
+    visits, cols = common.make_stream(p, W, H, M, f_hi=0.02)
+    n = visits.n
+    rng = np.random.default_rng(3)
+    w = rng.random((n, 3)).astype(np.float32)
+    w /= w.sum(1, keepdims=True)
+    ids = np.stack([np.full(n, 1.0, np.float32), np.full(n, 2.0, np.float32), ((np.arange(n) // M) % 5 + 10).astype(np.float32)], 1)
+    lens = orc.orc_lens_create(C.byref(table))
+    fr = oracle_lib.Frame(orc, p, n_aovs=1)
+    fr.set_crypto([ids], [w])
+    fr.run(lens, None, visits)
+    fw = fr.weight()
+    out0, has0 = fr.crypto_rank(0, 0)
+    out2, has2 = fr.crypto_rank(0, 2)
+    assert np.array_equal(has0, fw != 0) and has2.any()       # (xres is W + 1: the region quirk leaves an empty column)
+    for pix in np.nonzero(has0)[0][::7]:
+        k, wt, tot = fr.crypto_pixel(0, pix)
+        assert abs(wt.sum() - tot) <= 2e-5 * max(tot, 1.0)
+        assert abs(tot - fw[pix]) <= 1e-5 * max(tot, 1.0)
+        order = np.argsort(-wt, kind="stable")
+        assert out0[pix, 0] == k[order[0]] and out0[pix, 2] == k[order[1]]
+        assert np.isclose(out0[pix, 1] + out0[pix, 3] + (out2[pix, 1] + out2[pix, 3] if has2[pix] else 0.0), 1.0, atol=1e-4) or len(k) > 4
+    fr.close()
+    orc.orc_lens_destroy(lens)
+
+
+def compare_tables(ctx, ref, n_crypto, np_, tol=TOL):
+    worst = 0.0
+    for a in range(n_crypto):
+        ids, wts, tot = ctx.download_crypto_table(a)
+        for pix in range(np_):
+            rk, rw, rtot = ref.crypto_pixel(a, pix)
+            used = ids[pix] != 0xFFFFFFFF
+            gk = ids[pix][used].view(np.float32)
+            gw = wts[pix][used]
+            order = np.argsort(gk, kind="stable")
+            gk, gw = gk[order], gw[order]
+            assert gk.shape == rk.shape and np.array_equal(gk, rk), "pixel %d of crypto %d holds other ids" % (pix, a)
+            scale = max(float(rtot), 1e-30)
+            if len(rw):
+                worst = max(worst, float(np.max(np.abs(gw.astype(np.float64) - rw)) / scale))
+            worst = max(worst, abs(float(tot[pix]) - rtot) / scale)
+    assert worst < tol, worst
+    return worst
+
+
+def compare_ranks(ctx, ref, n_crypto, tol=TOL):
+    checked = 0
+    for a in range(n_crypto):
+        for rank in (0, 2, 4):
+            out, has = ctx.download_crypto(a, rank)
+            rout, rhas = ref.crypto_rank(a, rank)
+            assert np.array_equal(has, rhas)
+            # ids: exact where the oracle's neighbouring weights are further apart than the summation tolerance
+            for pix in np.nonzero(rhas)[0]:
+                k, w, tot = ref.crypto_pixel(a, pix)
+                ws = np.sort(w)[::-1] / max(tot, 1e-30)
+                lo, hi = max(rank - 1, 0), min(rank + 2, len(ws) - 1)
+                gaps = np.abs(np.diff(ws[lo:hi + 1]))
+                if len(gaps) and gaps.min() < 4 * tol:
+                    continue
+                assert out[pix, 0] == rout[pix, 0] and out[pix, 2] == rout[pix, 2], (a, rank, pix)
+                assert abs(out[pix, 1] - rout[pix, 1]) < 4 * tol and abs(out[pix, 3] - rout[pix, 3]) < 4 * tol
+                checked += 1
+    assert checked > 100
+    return checked
+
+
+CASES = {
+    "po": dict(po=True),
+    "po_chromatic": dict(po=True, abb_chromatic=0.5),
+    "thinlens": dict(po=False),
+    "thinlens_chromatic": dict(po=False, abb_chromatic=0.6, abb_chromatic_type=0),
+}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", list(CASES))
+def test_crypto_tables_and_ranks_match_oracle(orc, gpu_ctx_factory, case):
+    """Two cryptomatte AOVs beside the beauty and a gaussian extra AOV, three passes of one context (the second and
+    third are enqueued blind / streamed): per-pixel id sets exact, weights and totals to 1e-5, ranked images exact in
+    the ids wherever the ranking is decided by more than the tolerance."""
+    kw = dict(CASES[case])
+    W, H, M = 64, 48, 9
+    if kw.pop("po"):
+        p, model, table, keep = common.po_setup(W, H, samples_override=48, **kw)
+    else:
+        p, table = common.tl_setup(W, H, samples_override=48, **kw), None
+    visits, cols = common.make_stream(p, W, H, M, f_hi=0.02, n_extra=1)
+    n = visits.n
+    n_crypto, entries = 2, 3
+    hashes, weights = make_crypto_columns(n, W, M, n_crypto, entries)
+    cv, keepc = capi.make_crypto_visits(hashes, weights)
+    lens = orc.orc_lens_create(C.byref(table)) if table is not None else None
+    ctx = gpu_ctx_factory()
+    ctx.set_params(p)
+    if table is not None:
+        ctx.set_lens(table)
+    ctx.alloc_frame(2)
+    ctx.alloc_crypto(n_crypto, 32)
+    ctx.upload_visits(visits)
+    ctx.upload_crypto(cv)
+    for frame in range(3):
+        ref = oracle_lib.Frame(orc, p, n_aovs=2, keep_log=False)
+        ref.set_crypto(hashes, weights)
+        if case == "thinlens_chromatic":
+            st = ctx.get_xor128_state()
+            orc.orc_frame_set_xor128(ref.h, (C.c_uint32 * 4)(*st))
+        ref.run(lens, None, visits)
+        rc = ref.counters()
+        assert rc.redistributed_visits > 100 and rc.accepted_draws > 3000
+        ctx.clear_frame()
+        ctx.redistribute()
+        ctx.resolve()
+        c = ctx.counters()
+        assert (c.redistributed_visits, c.accepted_draws) == (rc.redistributed_visits, rc.accepted_draws)
+        compare_tables(ctx, ref, n_crypto, p.xres * p.yres)
+        compare_ranks(ctx, ref, n_crypto)
+        # the beauty is what it is without cryptomatte
+        buf, w = ctx.download_accum(0)
+        assert common.rel_err(w[ref.weight() != 0], ref.weight()[ref.weight() != 0]) < TOL
+        ref.close()
+    if lens:
+        orc.orc_lens_destroy(lens)
+
+
+@pytest.mark.gpu
+def test_crypto_error_paths(orc, gpu_ctx_factory):
+    """A table or draw log that is too small is an error of the pass, never a silently short map; the library sizes its
+    own log for the next attempt; columns of another stream are refused."""
+    W, H, M = 48, 32, 9
+    p, model, table, keep = common.po_setup(W, H, samples_override=32)
+    visits, cols = common.make_stream(p, W, H, M, f_hi=0.03)
+    n = visits.n
+    hashes, weights = make_crypto_columns(n, W, M, 1, 4)
+    cv, keepc = capi.make_crypto_visits(hashes, weights)
+    ctx = gpu_ctx_factory()
+    ctx.set_params(p); ctx.set_lens(table); ctx.alloc_frame(1)
+    with pytest.raises(capi.LentilError):                    # nothing allocated
+        ctx.upload_crypto(cv)
+    ctx.alloc_crypto(1, 2)
+    ctx.upload_visits(visits)
+    ctx.clear_frame()
+    with pytest.raises(capi.LentilError, match="columns"):   # no columns for this stream
+        ctx.redistribute()
+    ctx.upload_crypto(cv)
+    ctx.clear_frame()
+    with pytest.raises(capi.LentilError, match="table full") as e:
+        ctx.redistribute()
+    assert e.value.code == -4 or "full" in str(e.value)
+    ctx.alloc_crypto(1, 0)                                   # default: 16 ids per pixel
+    ctx.upload_crypto(cv)
+    ctx.set_draw_log(64)
+    ctx.clear_frame()
+    with pytest.raises(capi.LentilError, match="draw log"):
+        ctx.redistribute()
+    ctx.set_draw_log(0)                                      # the library's own log from here on
+    ctx.clear_frame()
+    ctx.redistribute()
+    lens = orc.orc_lens_create(C.byref(table))
+    ref = oracle_lib.Frame(orc, p, n_aovs=1)
+    ref.set_crypto(hashes, weights)
+    ref.run(lens, None, visits)
+    compare_tables(ctx, ref, 1, p.xres * p.yres)
+    # a shorter stream with the old columns still bound
+    visits2, cols2 = common.make_stream(p, W, H, M, f_hi=0.03, v_end=n - M * W)
+    ctx.upload_visits(visits2)
+    ctx.clear_frame()
+    with pytest.raises(capi.LentilError, match="columns"):
+        ctx.redistribute()
+    ref.close()
+    orc.orc_lens_destroy(lens)
