@@ -156,6 +156,26 @@ int lentil_aov_frame_kind(const lentil_aov_plan *plan);
 int lentil_sanitize_aov_list(lentil_aov_plan *plans, int n);
 
 /* ------------------------------------------------------------------------------------
+ * Cryptomatte (Camera::setup_crypto_aovs, cryptomatte_construct_cache, src/lentil.h:781-811,1015-1055; the
+ * imager's ranking names, src/lentil_imager.cpp:84-92,124-126)
+ * ---------------------------------------------------------------------------------- */
+/* The AOV list additions of Camera::setup_crypto_aovs (src/lentil.h:1015-1055), which runs once cryptomatte has added
+ * its ranked outputs to options.outputs: every output whose AOV name contains "crypto_" is appended -- the ranked
+ * ones (crypto_material00 ...) with is_crypto set and the filter token replaced by "lentil_replaced_filter", the
+ * three display AOVs (crypto_material / crypto_asset / crypto_object) as they are.  Returns the number of entries
+ * written to plans (to be appended to the camera's list before lentil_sanitize_aov_list), -1 when cap is short. */
+int lentil_setup_crypto_aovs(const char *const *outputs, int n, lentil_aov_plan *plans, int cap);
+/* Camera::cryptomatte_construct_cache (src/lentil.h:781-811) for one cryptomatte AOV of one AOV sample: its depth
+ * samples (opacity RGB 3 n, the AOV's float n; front to back as AiAOVSampleIteratorGetNextDepth yields them) folded
+ * into id -> weight.  Writes the pairs in id order, pads ids / weights up to cap with unused pairs (weight bits
+ * 0xFFFFFFFF) and returns the number of pairs, or -1 when there are more than cap. */
+int lentil_crypto_construct_cache(int n_depth, const float *opacity_rgb, const float *value, float *ids, float *weights,
+                                  int cap);
+/* position in the weight-sorted map that an AOV of this name shows (and the next): 2 for crypto_material01 /
+ * crypto_asset01 / crypto_object01, 4 for ...02, 0 for every other name (src/lentil_imager.cpp:124-126) */
+int lentil_crypto_rank_of_name(const char *aov_name);
+
+/* ------------------------------------------------------------------------------------
  * Visit capture: what filter_pixel gathers per AOV sample (src/lentil_filter.cpp:105-165,
  * 206-234) appended to per-thread staging columns instead of being traced on the spot.
  * One slot per render thread; appends to different slots may run concurrently.
@@ -174,9 +194,18 @@ typedef struct lentil_sample_capture {
   float bidir_ignore;             /* AOV "lentil_bidir_ignore" */
   float transmission[4];          /* AOV "transmission" */
   const float *extra_rgba;        /* n_extra x 4: the other lentil-filtered AOVs widened to RGBA (:214-232) */
+  /* stages with cryptomatte AOVs (lentil_stage_set_crypto): the sample's cache per AOV, n_crypto x entries ids and
+   * weights as lentil_crypto_construct_cache leaves them (:167-169); NULL otherwise */
+  const float *crypto_ids;
+  const float *crypto_weights;
 } lentil_sample_capture;
 
 int lentil_stage_create(int n_thread_slots, uint32_t n_extra, lentil_stage **out);
+/* cryptomatte AOVs ride along as n_crypto x entries (id, weight) pairs per visit; call on an empty stage, before the
+ * first append (plain staging only: lentil_stage_stream_to refuses such a stage).  lentil_stage_crypto: the columns
+ * that belong to what lentil_stage_visits returned last (lentil_hip_upload_crypto takes them as they are). */
+int lentil_stage_set_crypto(lentil_stage *s, uint32_t n_crypto, uint32_t entries);
+int lentil_stage_crypto(lentil_stage *s, lentil_crypto_visits *out);
 void lentil_stage_destroy(lentil_stage *s);
 void lentil_stage_reset(lentil_stage *s);                         /* new frame */
 int lentil_stage_append(lentil_stage *s, int thread_slot, const lentil_sample_capture *c);
@@ -211,6 +240,15 @@ void lentil_imager_new_frame(lentil_imager *im);                   /* re-arms th
  * LENTIL_OK or the error of the GPU pass (lentil_imager_last_error). */
 int lentil_imager_process_bucket(lentil_imager *im, uint32_t aov, int bucket_xo, int bucket_yo, int bucket_size_x,
                                  int bucket_size_y, float *bucket_rgba);
+/* Cryptomatte AOVs of the frame (after lentil_hip_alloc_crypto on the context and lentil_stage_set_crypto on the
+ * stage): `ranks[c]` = lentil_crypto_rank_of_name of AOV c.  The once-only pass then also uploads the stage's
+ * cryptomatte columns; a pass that reports a short draw log is repeated once (the library has sized its log by
+ * then).  lentil_imager_process_crypto_bucket is the cryptomatte branch of driver_process_bucket
+ * (src/lentil_imager.cpp:121-161): (id, weight / total) pairs of the AOV's rank; at the first pixel of a bucket
+ * row whose map has no more than `rank` entries the rest of that row is left as it is (:132-134). */
+int lentil_imager_set_crypto(lentil_imager *im, uint32_t n_crypto, const int *ranks);
+int lentil_imager_process_crypto_bucket(lentil_imager *im, uint32_t crypto, int bucket_xo, int bucket_yo, int bucket_size_x,
+                                        int bucket_size_y, float *bucket_rgba);
 const char *lentil_imager_last_error(const lentil_imager *im);
 
 #ifdef __cplusplus

@@ -45,7 +45,8 @@ class SampleCapture(C.Structure):
     _fields_ = [("px", C.c_int), ("py", C.c_int), ("inverse_sample_density", C.c_float), ("rgba", C.c_float * 4),
                 ("P", C.c_float * 3), ("Z", C.c_float), ("raydir", C.c_float * 3), ("time", C.c_float),
                 ("volume", C.c_float * 3), ("bidir_ignore", C.c_float), ("transmission", C.c_float * 4),
-                ("extra_rgba", C.POINTER(C.c_float))]
+                ("extra_rgba", C.POINTER(C.c_float)), ("crypto_ids", C.POINTER(C.c_float)),
+                ("crypto_weights", C.POINTER(C.c_float))]
 
 
 EXPORTS = [
@@ -56,6 +57,8 @@ EXPORTS = [
     "lentil_stage_create", "lentil_stage_destroy", "lentil_stage_reset", "lentil_stage_append", "lentil_stage_size",
     "lentil_stage_visits", "lentil_stage_stream_to", "lentil_stage_finish_stream", "lentil_stage_is_streaming", "lentil_imager_create", "lentil_imager_destroy", "lentil_imager_new_frame",
     "lentil_imager_process_bucket", "lentil_imager_last_error",
+    "lentil_setup_crypto_aovs", "lentil_crypto_construct_cache", "lentil_crypto_rank_of_name", "lentil_stage_set_crypto",
+    "lentil_stage_crypto", "lentil_imager_set_crypto", "lentil_imager_process_crypto_bucket",
     "lentil_setup_filter_region", "lentil_filter_gaussian_complete", "lentil_filter_closest_complete",
 ]
 
@@ -102,6 +105,13 @@ def load():
         "lentil_imager_destroy": (None, [vp]),
         "lentil_imager_new_frame": (None, [vp]),
         "lentil_imager_process_bucket": (i, [vp, u32, i, i, i, i, vp]),
+        "lentil_setup_crypto_aovs": (i, [C.POINTER(C.c_char_p), i, C.POINTER(AovPlan), i]),
+        "lentil_crypto_construct_cache": (i, [i, vp, vp, vp, vp, i]),
+        "lentil_crypto_rank_of_name": (i, [C.c_char_p]),
+        "lentil_stage_set_crypto": (i, [vp, u32, u32]),
+        "lentil_stage_crypto": (i, [vp, C.POINTER(_abi.CryptoVisits)]),
+        "lentil_imager_set_crypto": (i, [vp, u32, C.POINTER(i)]),
+        "lentil_imager_process_crypto_bucket": (i, [vp, u32, i, i, i, i, vp]),
         "lentil_imager_last_error": (C.c_char_p, [vp]),
         "lentil_setup_filter_region": (None, [C.POINTER(_abi.Params), i, i, i, i, i, i, f]),
         "lentil_filter_gaussian_complete": (None, [i, vp, vp, vp, f, f, vp]),
@@ -162,6 +172,7 @@ def stage_append_arrays(stage, slot, cols, idx):
     the way filter_pixel would."""
     lib = load()
     n_extra = len(cols.get("extra", []))
+    n_crypto = len(cols.get("crypto_ids", []))
     for v in idx:
         c = SampleCapture()
         px = int(cols["pixel"][v])
@@ -175,6 +186,11 @@ def stage_append_arrays(stage, slot, cols, idx):
         if n_extra:
             ex = np.ascontiguousarray(np.stack([cols["extra"][k][v] for k in range(n_extra)]).astype(np.float32))
             c.extra_rgba = ex.ctypes.data_as(C.POINTER(C.c_float))
+        if n_crypto:       # per cryptomatte AOV the sample's cache, entries (id, weight) pairs
+            ci = np.ascontiguousarray(np.stack([cols["crypto_ids"][k][v] for k in range(n_crypto)]).astype(np.float32))
+            cw = np.ascontiguousarray(np.stack([cols["crypto_weights"][k][v] for k in range(n_crypto)]).astype(np.float32))
+            c.crypto_ids = ci.ctypes.data_as(C.POINTER(C.c_float))
+            c.crypto_weights = cw.ctypes.data_as(C.POINTER(C.c_float))
         rc = lib.lentil_stage_append(stage, slot, C.byref(c))
         if rc:
             raise RuntimeError("lentil_stage_append rc=%d" % rc)

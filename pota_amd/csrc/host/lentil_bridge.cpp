@@ -6,6 +6,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <map>
 #include <mutex>
 #include <new>
 #include <string>
@@ -307,6 +308,64 @@ BRIDGE_API int lentil_sanitize_aov_list(lentil_aov_plan *plans, int n) {
 }
 
 // ---------------------------------------------------------------------------------------
+// cryptomatte
+// ---------------------------------------------------------------------------------------
+BRIDGE_API int lentil_setup_crypto_aovs(const char *const *outputs, int n, lentil_aov_plan *plans, int cap) {
+  if (!outputs || !plans || n < 0) return -1;
+  int m = 0;
+  for (int i = 0; i < n; ++i) {                                            // src/lentil.h:1021-1049
+    lentil_aov_plan aov;
+    plan_from_output(outputs[i] ? outputs[i] : "", &aov);
+    bool replace_filter = true, cryptomatte_aov = false;
+    const std::string nm = aov.to.aov_name;
+    if (nm == "crypto_material" || nm == "crypto_asset" || nm == "crypto_object") {       // :1032-1036: display only
+      replace_filter = false;
+      cryptomatte_aov = true;
+    } else if (nm.find("crypto_") != std::string::npos) {                                  // :1037-1040
+      aov.is_crypto = 1;
+      cryptomatte_aov = true;
+    }
+    if (!cryptomatte_aov) continue;
+    if (replace_filter && nm != "lentil_replaced_filter") put(aov.to.filter, sizeof(aov.to.filter), "lentil_replaced_filter");
+    if (m >= cap) return -1;
+    plans[m++] = aov;
+  }
+  return m;
+}
+
+BRIDGE_API int lentil_crypto_construct_cache(int n_depth, const float *opacity_rgb, const float *value, float *ids,
+                                             float *weights, int cap) {
+  if (n_depth < 0 || (n_depth && (!opacity_rgb || !value)) || !ids || !weights || cap <= 0) return -1;
+  std::map<float, float> cache;                                            // crypto_hashmap_cache[aov.index]
+  float iterative_transparency_weight = 1.0f;
+  float quota = 1.0;
+  float sample_value = 0.0f;
+  for (int d = 0; d < n_depth; ++d) {                                      // src/lentil.h:789-801
+    // AiColorToGrey: (r + g + b) / 3
+    const float sub_sample_opacity = (opacity_rgb[3 * d] + opacity_rgb[3 * d + 1] + opacity_rgb[3 * d + 2]) / 3;
+    sample_value = value[d];
+    const float sub_sample_weight = sub_sample_opacity * iterative_transparency_weight;
+    iterative_transparency_weight *= (1.0f - sub_sample_opacity);
+    quota -= sub_sample_weight;
+    cache[sample_value] += sub_sample_weight;
+  }
+  if (quota > 0.0) cache[sample_value] += quota;                           // :804: what is left goes to the last sample
+  if ((int)cache.size() > cap) return -1;
+  int k = 0;
+  for (const auto &e : cache) { ids[k] = e.first; weights[k] = e.second; ++k; }
+  const uint32_t unused = 0xFFFFFFFFu;
+  for (int j = k; j < cap; ++j) { ids[j] = 0.0f; memcpy(&weights[j], &unused, 4); }
+  return k;
+}
+
+BRIDGE_API int lentil_crypto_rank_of_name(const char *aov_name) {
+  const std::string nm = aov_name ? aov_name : "";
+  if (nm == "crypto_material01" || nm == "crypto_asset01" || nm == "crypto_object01") return 2;
+  if (nm == "crypto_material02" || nm == "crypto_asset02" || nm == "crypto_object02") return 4;
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------
 // setup_filter (resolution / region) and the display pass-through filters
 // ---------------------------------------------------------------------------------------
 BRIDGE_API void lentil_setup_filter_region(lentil_params *p, int xres, int yres, int region_min_x, int region_min_y,
@@ -368,6 +427,7 @@ struct StageSlot {
   std::vector<float> rgba, pos_z, raydir_time, volume_ignore, transmission, inv_density;
   std::vector<std::vector<float>> extra;
   std::vector<uint32_t> pixel;
+  std::vector<std::vector<float>> crypto_ids, crypto_weights;   // per cryptomatte AOV: entries floats per visit
   PinnedBlock blk[2];
   int cur = 0;
   uint64_t sent = 0;             // visits of this slot already on their way to the GPU
@@ -375,6 +435,7 @@ struct StageSlot {
 
 struct lentil_stage {
   uint32_t n_extra = 0;
+  uint32_t n_crypto = 0, crypto_entries = 0;
   std::vector<StageSlot> slots;
   StageSlot all;               // concatenation, built by lentil_stage_visits
   // streaming mode
@@ -458,6 +519,7 @@ BRIDGE_API void lentil_stage_destroy(lentil_stage *s) {
 BRIDGE_API int lentil_stage_stream_to(lentil_stage *s, lentil_hip_ctx *gpu, uint32_t block_visits, uint64_t capacity_hint) {
   if (!s) return LENTIL_ERR_INVALID;
   if (lentil_stage_size(s) != 0) return LENTIL_ERR_INVALID;      // between frames only
+  if (gpu && s->n_crypto) return LENTIL_ERR_UNSUPPORTED;         // cryptomatte columns are uploaded with the frame
   stage_free_blocks(s);
   s->gpu = gpu;
   s->stream_open = false;
@@ -471,6 +533,8 @@ static void clear_slot(StageSlot &sl) {
   sl.rgba.clear(); sl.pos_z.clear(); sl.raydir_time.clear(); sl.volume_ignore.clear(); sl.transmission.clear();
   sl.inv_density.clear(); sl.pixel.clear();
   for (auto &e : sl.extra) e.clear();
+  for (auto &e : sl.crypto_ids) e.clear();
+  for (auto &e : sl.crypto_weights) e.clear();
 }
 
 BRIDGE_API void lentil_stage_reset(lentil_stage *s) {
@@ -492,6 +556,7 @@ BRIDGE_API int lentil_stage_append(lentil_stage *s, int thread_slot, const lenti
   if (!s || !c || thread_slot < 0 || (size_t)thread_slot >= s->slots.size()) return LENTIL_ERR_INVALID;
   if (c->px < 0 || c->py < 0 || c->px > 0xFFFF || c->py > 0xFFFF) return LENTIL_ERR_INVALID;
   if (s->n_extra && !c->extra_rgba) return LENTIL_ERR_INVALID;
+  if (s->n_crypto && (!c->crypto_ids || !c->crypto_weights)) return LENTIL_ERR_INVALID;
   StageSlot &sl = s->slots[(size_t)thread_slot];
   if (s->gpu) {
     // streaming mode: into the slot's current page-locked block; a full block goes to the GPU and the slot
@@ -537,6 +602,11 @@ BRIDGE_API int lentil_stage_append(lentil_stage *s, int thread_slot, const lenti
       push4(sl.extra[k], c->extra_rgba[k * 4], c->extra_rgba[k * 4 + 1], c->extra_rgba[k * 4 + 2], c->extra_rgba[k * 4 + 3]);
     sl.pixel.push_back((uint32_t)c->px | ((uint32_t)c->py << 16));
     sl.inv_density.push_back(c->inverse_sample_density);
+    for (uint32_t k = 0; k < s->n_crypto; ++k) {
+      const float *ids = c->crypto_ids + (size_t)k * s->crypto_entries, *w = c->crypto_weights + (size_t)k * s->crypto_entries;
+      sl.crypto_ids[k].insert(sl.crypto_ids[k].end(), ids, ids + s->crypto_entries);
+      sl.crypto_weights[k].insert(sl.crypto_weights[k].end(), w, w + s->crypto_entries);
+    }
   } catch (const std::bad_alloc &) {
     return LENTIL_ERR_NOMEM;
   }
@@ -577,6 +647,10 @@ BRIDGE_API int lentil_stage_visits(lentil_stage *s, lentil_visits *out) {
       a.inv_density.insert(a.inv_density.end(), sl.inv_density.begin(), sl.inv_density.end());
       a.pixel.insert(a.pixel.end(), sl.pixel.begin(), sl.pixel.end());
       for (uint32_t k = 0; k < s->n_extra; ++k) a.extra[k].insert(a.extra[k].end(), sl.extra[k].begin(), sl.extra[k].end());
+      for (uint32_t k = 0; k < s->n_crypto; ++k) {
+        a.crypto_ids[k].insert(a.crypto_ids[k].end(), sl.crypto_ids[k].begin(), sl.crypto_ids[k].end());
+        a.crypto_weights[k].insert(a.crypto_weights[k].end(), sl.crypto_weights[k].begin(), sl.crypto_weights[k].end());
+      }
     }
   } catch (const std::bad_alloc &) {
     return LENTIL_ERR_NOMEM;
@@ -597,6 +671,32 @@ BRIDGE_API int lentil_stage_visits(lentil_stage *s, lentil_visits *out) {
   return LENTIL_OK;
 }
 
+BRIDGE_API int lentil_stage_set_crypto(lentil_stage *s, uint32_t n_crypto, uint32_t entries) {
+  if (!s || n_crypto > LENTIL_MAX_CRYPTO || (n_crypto && (entries == 0 || entries > 64))) return LENTIL_ERR_INVALID;
+  if (lentil_stage_size(s) != 0) return LENTIL_ERR_INVALID;
+  if (n_crypto && s->gpu) return LENTIL_ERR_UNSUPPORTED;       // the piecewise upload carries the visit columns only
+  s->n_crypto = n_crypto;
+  s->crypto_entries = n_crypto ? entries : 0;
+  for (StageSlot &sl : s->slots) { sl.crypto_ids.assign(n_crypto, {}); sl.crypto_weights.assign(n_crypto, {}); }
+  s->all.crypto_ids.assign(n_crypto, {});
+  s->all.crypto_weights.assign(n_crypto, {});
+  return LENTIL_OK;
+}
+
+BRIDGE_API int lentil_stage_crypto(lentil_stage *s, lentil_crypto_visits *out) {
+  if (!s || !out || s->gpu || !s->n_crypto) return LENTIL_ERR_INVALID;
+  memset(out, 0, sizeof(*out));
+  out->n = s->all.pixel.size();
+  out->n_crypto = s->n_crypto;
+  out->entries = s->crypto_entries;
+  for (uint32_t k = 0; k < s->n_crypto; ++k) {
+    if (s->all.crypto_ids[k].size() != out->n * s->crypto_entries) return LENTIL_ERR_INVALID;   // lentil_stage_visits first
+    out->hash[k] = s->all.crypto_ids[k].data();
+    out->weight[k] = s->all.crypto_weights[k].data();
+  }
+  return LENTIL_OK;
+}
+
 // ---------------------------------------------------------------------------------------
 // imager
 // ---------------------------------------------------------------------------------------
@@ -609,6 +709,9 @@ struct lentil_imager {
   int rc = LENTIL_OK;
   std::string error;
   std::vector<std::vector<float>> resolved;   // per AOV: xres * yres * 4
+  std::vector<int> crypto_ranks;              // per cryptomatte AOV
+  std::vector<std::vector<float>> crypto_rgba;      // per cryptomatte AOV: xres * yres * 4
+  std::vector<std::vector<uint8_t>> crypto_has;     // ... and whether the pixel's map reaches the AOV's rank
 };
 
 BRIDGE_API int lentil_imager_create(lentil_hip_ctx *gpu, lentil_stage *stage, const lentil_params *params, uint32_t n_aovs,
@@ -651,15 +754,36 @@ static void run_gpu_pass(lentil_imager *im) {
     lentil_visits v;
     if (!check(lentil_stage_visits(im->stage, &v), "stage")) return;
     if (!check(lentil_hip_upload_visits(im->gpu, &v), "upload_visits")) return;
+    if (!im->crypto_ranks.empty()) {
+      lentil_crypto_visits cv;
+      if (!check(lentil_stage_crypto(im->stage, &cv), "stage crypto")) return;
+      if (!check(lentil_hip_upload_crypto(im->gpu, &cv), "upload_crypto")) return;
+    }
   }
   if (!check(lentil_hip_clear_frame(im->gpu), "clear_frame")) return;
-  if (!check(lentil_hip_redistribute(im->gpu), "redistribute")) return;
+  int rc = lentil_hip_redistribute(im->gpu);
+  if (rc == LENTIL_ERR_NOMEM && !im->crypto_ranks.empty() && strstr(lentil_hip_last_error(im->gpu), "draw log")) {
+    // the cryptomatte adds are replayed from the pass's draw log, which the library sizes from the pass before:
+    // it now knows this frame's count
+    if (!check(lentil_hip_clear_frame(im->gpu), "clear_frame")) return;
+    rc = lentil_hip_redistribute(im->gpu);
+  }
+  if (!check(rc, "redistribute")) return;
   if (!check(lentil_hip_resolve(im->gpu), "resolve")) return;
   const size_t np = (size_t)im->P.xres * im->P.yres;
   im->resolved.assign(im->n_aovs, std::vector<float>());
   for (uint32_t a = 0; a < im->n_aovs; ++a) {
     im->resolved[a].resize(np * 4);
     if (!check(lentil_hip_download_aov(im->gpu, a, im->resolved[a].data()), "download_aov")) return;
+  }
+  const size_t nc = im->crypto_ranks.size();
+  im->crypto_rgba.assign(nc, std::vector<float>());
+  im->crypto_has.assign(nc, std::vector<uint8_t>());
+  for (size_t c = 0; c < nc; ++c) {
+    im->crypto_rgba[c].resize(np * 4);
+    im->crypto_has[c].resize(np);
+    if (!check(lentil_hip_download_crypto(im->gpu, (uint32_t)c, (uint32_t)im->crypto_ranks[c], im->crypto_rgba[c].data(),
+                                          im->crypto_has[c].data()), "download_crypto")) return;
   }
 }
 
@@ -674,6 +798,32 @@ BRIDGE_API int lentil_imager_process_bucket(lentil_imager *im, uint32_t aov, int
       const int x = i + bucket_xo - im->P.region_min_x, y = j + bucket_yo - im->P.region_min_y;   // :116-118
       if (x < 0 || y < 0 || x >= im->P.xres || y >= im->P.yres) continue;
       const size_t lin = (size_t)x + (size_t)y * (size_t)im->P.xres;                               // coords_to_linear_pixel
+      memcpy(bucket_rgba + ((size_t)j * bucket_size_x + i) * 4, img.data() + lin * 4, 4 * sizeof(float));
+    }
+  }
+  return LENTIL_OK;
+}
+
+BRIDGE_API int lentil_imager_set_crypto(lentil_imager *im, uint32_t n_crypto, const int *ranks) {
+  if (!im || n_crypto > LENTIL_MAX_CRYPTO || (n_crypto && !ranks)) return LENTIL_ERR_INVALID;
+  im->crypto_ranks.assign(ranks, ranks + n_crypto);
+  for (int r : im->crypto_ranks) if (r < 0) return LENTIL_ERR_INVALID;
+  return LENTIL_OK;
+}
+
+BRIDGE_API int lentil_imager_process_crypto_bucket(lentil_imager *im, uint32_t crypto, int bucket_xo, int bucket_yo,
+                                                   int bucket_size_x, int bucket_size_y, float *bucket_rgba) {
+  if (!im || !bucket_rgba || crypto >= im->crypto_ranks.size() || bucket_size_x < 0 || bucket_size_y < 0) return LENTIL_ERR_INVALID;
+  std::call_once(*im->once, run_gpu_pass, im);
+  if (im->rc != LENTIL_OK) return im->rc;
+  const std::vector<float> &img = im->crypto_rgba[crypto];
+  const std::vector<uint8_t> &has = im->crypto_has[crypto];
+  for (int j = 0; j < bucket_size_y; ++j) {
+    for (int i = 0; i < bucket_size_x; ++i) {
+      const int x = i + bucket_xo - im->P.region_min_x, y = j + bucket_yo - im->P.region_min_y;   // :116-118
+      if (x < 0 || y < 0 || x >= im->P.xres || y >= im->P.yres) continue;
+      const size_t lin = (size_t)x + (size_t)y * (size_t)im->P.xres;
+      if (!has[lin]) break;                                         // :132-134: leaves the inner (row) loop
       memcpy(bucket_rgba + ((size_t)j * bucket_size_x + i) * 4, img.data() + lin * 4, 4 * sizeof(float));
     }
   }

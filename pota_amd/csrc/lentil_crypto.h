@@ -252,8 +252,9 @@ static int crypto_before_pass(lentil_hip_ctx *ctx) {
   if (ctx->comm || ctx->closest_deferred)
     return fail(ctx, LENTIL_ERR_UNSUPPORTED, "cryptomatte AOVs are not exchanged between GPUs");
   if (ctx->log_cap == 0) {
-    // no log asked for by the caller: one sized from the last pass (or 4 Mi records, 48 MB)
+    // no log asked for by the caller: one sized from the last pass, or 4 Mi records (48 MB; LENTIL_CRYPTO_LOG overrides)
     uint64_t want = 4ull << 20;
+    if (const char *e = getenv("LENTIL_CRYPTO_LOG")) { const long long v = atoll(e); if (v > 0) want = (uint64_t)v; }
     if (k->auto_log > want) want = k->auto_log;
     const int rc = lentil_hip_set_draw_log(ctx, want);
     if (rc) return rc;

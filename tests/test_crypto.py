@@ -11,7 +11,7 @@ import pytest
 
 import common
 import oracle_lib
-from pota_amd import capi
+from pota_amd import bridge, capi, workload
 
 TOL = 1e-5
 UNUSED = np.array([0xFFFFFFFF], np.uint32).view(np.float32)[0]
@@ -247,5 +247,163 @@ def test_crypto_error_paths(orc, gpu_ctx_factory):
     ctx.clear_frame()
     with pytest.raises(capi.LentilError, match="columns"):
         ctx.redistribute()
+    ref.close()
+    orc.orc_lens_destroy(lens)
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# the plugin side: liblentil_bridge.so
+# ----------------------------------------------------------------------------------------------------------------
+def depth_lists(rng, n, max_depth=4, palette=9):
+    """n AOV samples' depth lists: (opacity rgb [d, 3], id [d]) with 0..max_depth depths, ids from a small palette"""
+    pal = (rng.standard_normal(palette) * 100).astype(np.float32)
+    out = []
+    for _ in range(n):
+        d = int(rng.integers(0, max_depth + 1))
+        op = rng.random((d, 3)).astype(np.float32)
+        op[rng.random(d) < 0.3] = 1.0
+        out.append((op, pal[rng.integers(0, palette, d)].astype(np.float32)))
+    return out
+
+
+def test_bridge_construct_cache_equals_oracle(orc):
+    """lentil_crypto_construct_cache (what lentil_filter's filter_pixel calls per cryptomatte AOV) against the oracle's
+    restatement of src/lentil.h:781-811: the same pairs, bit for bit, padded with unused pairs."""
+    lib = bridge.load()
+    rng = np.random.default_rng(11)
+    cap = 6
+    for op, ids in depth_lists(rng, 300):
+        a_i = np.empty(cap, np.float32); a_w = np.empty(cap, np.float32)
+        b_i = np.empty(cap, np.float32); b_w = np.empty(cap, np.float32)
+        na = lib.lentil_crypto_construct_cache(len(ids), op.ctypes.data, ids.ctypes.data, a_i.ctypes.data, a_w.ctypes.data, cap)
+        nb = orc.orc_crypto_construct_cache(len(ids), op.ctypes.data, ids.ctypes.data, b_i.ctypes.data, b_w.ctypes.data, cap)
+        assert na == nb and na >= 1
+        assert np.array_equal(a_i[:na].view(np.uint32), b_i[:nb].view(np.uint32))
+        assert np.array_equal(a_w[:na].view(np.uint32), b_w[:nb].view(np.uint32))
+        assert (a_w[na:].view(np.uint32) == 0xFFFFFFFF).all()
+    one = np.ones(3, np.float32); v = np.arange(3, dtype=np.float32)
+    small = np.empty(2, np.float32)
+    assert lib.lentil_crypto_construct_cache(3, np.tile(one * 0.5, 3).ctypes.data, v.ctypes.data, small.ctypes.data,
+                                             small.copy().ctypes.data, 2) == -1          # three ids do not fit two pairs
+
+
+def test_crypto_aov_list_and_rank_names():
+    """Camera::setup_crypto_aovs (src/lentil.h:1015-1055) and the imager's rank names (src/lentil_imager.cpp:124-126)."""
+    lib = bridge.load()
+    outputs = ["RGBA RGBA lentil_replaced_filter driver",
+               "crypto_material RGBA crypto_filter driver",
+               "crypto_material00 FLOAT crypto_filter00 driver",
+               "crypto_material01 FLOAT crypto_filter01 driver",
+               "cam crypto_object02 FLOAT crypto_filter02 driver HALF",
+               "Z FLOAT closest driver"]
+    arr = (C.c_char_p * len(outputs))(*[o.encode() for o in outputs])
+    plans = (bridge.AovPlan * 8)()
+    m = lib.lentil_setup_crypto_aovs(arr, len(outputs), plans, 8)
+    assert m == 4
+    got = [(plans[k].to.aov_name.decode(), plans[k].is_crypto, plans[k].to.filter.decode()) for k in range(m)]
+    assert got == [("crypto_material", 0, "crypto_filter"), ("crypto_material00", 1, "lentil_replaced_filter"),
+                   ("crypto_material01", 1, "lentil_replaced_filter"), ("crypto_object02", 1, "lentil_replaced_filter")]
+    assert bridge.rebuild_output(plans[3].to) == "cam crypto_object02 FLOAT lentil_replaced_filter driver HALF"
+    # sanitize keeps what lentil filters: the display AOV goes
+    k = lib.lentil_sanitize_aov_list(plans, m)
+    assert [plans[j].to.aov_name.decode() for j in range(k)] == ["crypto_material00", "crypto_material01", "crypto_object02"]
+    assert lib.lentil_setup_crypto_aovs(arr, len(outputs), plans, 2) == -1
+    ranks = {n: lib.lentil_crypto_rank_of_name(n.encode()) for n in
+             ("crypto_material00", "crypto_material01", "crypto_material02", "crypto_asset01", "crypto_object02", "crypto_object03",
+              "crypto_custom01")}
+    assert ranks == {"crypto_material00": 0, "crypto_material01": 2, "crypto_material02": 4, "crypto_asset01": 2,
+                     "crypto_object02": 4, "crypto_object03": 0, "crypto_custom01": 0}
+
+
+@pytest.mark.gpu
+def test_imager_crypto_buckets_match_oracle(orc, gpu_ctx_factory, monkeypatch):
+    """filter_pixel's capture with cryptomatte caches (built from depth lists by lentil_crypto_construct_cache) through
+    the stage and the once-only imager pass; cryptomatte buckets against the oracle's ranking, including the bucket
+    rows the reference abandons at the first pixel whose map is too short.  The library sizes its draw log itself (the
+    first pass of the context reports it short; the imager repeats it)."""
+    lib = bridge.load()
+    W, H, M = 64, 40, 9
+    p, model, table, keep = common.po_setup(W, H, samples_override=48)
+    n = W * H * M
+    cols = workload.generate(np, 0, n, W, H, M, f_hi=0.03, focus_dist=150.0, tan_half_fov=common.tan_half_fov(p))
+    pix = np.arange(n, dtype=np.uint32) // M
+    cols["pixel"] = ((pix % W) | ((pix // W) << 16)).astype(np.uint32)
+    cols["inv_density"] = np.full(n, p.inverse_sample_density, np.float32)
+    rng = np.random.default_rng(5)
+    names = ["crypto_object00", "crypto_object01", "crypto_material02"]
+    entries = 4
+    ids = [np.empty((n, entries), np.float32) for _ in names]
+    wts = [np.empty((n, entries), np.float32) for _ in names]
+    for a in range(len(names)):
+        # objects coherent over 8-pixel columns: the palette of a sample follows its pixel
+        lists = depth_lists(rng, n, max_depth=entries, palette=3 if a == 1 else 7)
+        for v, (op, val) in enumerate(lists):
+            val = val + np.float32((v // M % W) // 8 * 1000.0) if a != 1 else val
+            val = np.ascontiguousarray(val, np.float32)
+            got = lib.lentil_crypto_construct_cache(len(val), op.ctypes.data, val.ctypes.data, ids[a][v].ctypes.data,
+                                                    wts[a][v].ctypes.data, entries)
+            assert got >= 1
+    cols["crypto_ids"], cols["crypto_weights"] = ids, wts
+    visits, kv = capi.make_visits(cols, visits_per_pixel=0)
+
+    lens = orc.orc_lens_create(C.byref(table))
+    ref = oracle_lib.Frame(orc, p, n_aovs=1)
+    ref.set_crypto(ids, wts)
+    ref.run(lens, None, visits)
+
+    ctx = gpu_ctx_factory()
+    ctx.set_params(p); ctx.set_lens(table); ctx.set_bokeh(None); ctx.alloc_frame(1)
+    ctx.alloc_crypto(len(names), 32)
+    ctx.set_draw_log(0)
+    monkeypatch.setenv("LENTIL_CRYPTO_LOG", "1000")     # the library's first guess at the draw log: too short for this frame
+    stage = C.c_void_p()
+    assert lib.lentil_stage_create(2, 0, C.byref(stage)) == 0
+    assert lib.lentil_stage_set_crypto(stage, len(names), entries) == 0
+    assert lib.lentil_stage_stream_to(stage, ctx.h, 0, 0) != 0          # cryptomatte columns go with the frame
+    im = C.c_void_p()
+    assert lib.lentil_imager_create(ctx.h, stage, C.byref(p), 1, C.byref(im)) == 0
+    ranks = (C.c_int * len(names))(*[lib.lentil_crypto_rank_of_name(nm.encode()) for nm in names])
+    assert list(ranks) == [0, 2, 4]
+    assert lib.lentil_imager_set_crypto(im, len(names), ranks) == 0
+    half = n // 2 // M * M
+    bridge.stage_append_arrays(stage, 0, cols, np.arange(0, half))
+    bridge.stage_append_arrays(stage, 1, cols, np.arange(half, n))
+    B = 16
+    for a in range(len(names)):
+        rout, rhas = ref.crypto_rank(a, ranks[a])
+        rout = rout.reshape(p.yres, p.xres, 4); rhas = rhas.reshape(p.yres, p.xres)
+        checked = abandoned = 0
+        for y in range(0, p.yres, B):
+            for x in range(0, p.xres, B):
+                sx, sy = min(B, p.xres - x), min(B, p.yres - y)
+                buf = np.full((sy, sx, 4), -7.0, np.float32)
+                rc = lib.lentil_imager_process_crypto_bucket(im, a, x, y, sx, sy, buf.ctypes.data)
+                assert rc == 0, lib.lentil_imager_last_error(im)
+                for j in range(sy):
+                    stop = sx
+                    miss = np.nonzero(~rhas[y + j, x:x + sx])[0]
+                    if len(miss):
+                        stop = int(miss[0]); abandoned += 1
+                    assert (buf[j, stop:] == -7.0).all()              # left as it was (src/lentil_imager.cpp:132-134)
+                    for i in range(stop):
+                        k, w, tot = ref.crypto_pixel(a, (y + j) * p.xres + x + i)
+                        ws = np.sort(w)[::-1] / max(tot, 1e-30)
+                        lo, hi = max(ranks[a] - 1, 0), min(ranks[a] + 2, len(ws) - 1)
+                        gaps = np.abs(np.diff(ws[lo:hi + 1]))
+                        if len(gaps) and gaps.min() < 4 * TOL:
+                            continue
+                        assert buf[j, i, 0] == rout[y + j, x + i, 0] and buf[j, i, 2] == rout[y + j, x + i, 2]
+                        assert abs(buf[j, i, 1] - rout[y + j, x + i, 1]) < 4 * TOL
+                        checked += 1
+        assert checked > 200
+        if ranks[a]:
+            assert abandoned > 0
+    # the beauty went through the same pass
+    buf = np.empty((p.yres, p.xres, 4), np.float32)
+    assert lib.lentil_imager_process_bucket(im, 0, 0, 0, p.xres, p.yres, buf.ctypes.data) == 0
+    want = ref.resolve(0).reshape(p.yres, p.xres, 4)
+    assert common.rel_err(buf[want != 0], want[want != 0]) < 1e-4
+    lib.lentil_imager_destroy(im)
+    lib.lentil_stage_destroy(stage)
     ref.close()
     orc.orc_lens_destroy(lens)
