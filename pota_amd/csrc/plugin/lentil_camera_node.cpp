@@ -112,6 +112,12 @@ int LentilCamera::aov_index(const char *name) const {
   return -1;
 }
 
+int LentilCamera::crypto_index(const char *name) const {
+  for (size_t i = 0; i < crypto_aovs.size(); ++i)
+    if (strcmp(crypto_aovs[i].name, name) == 0) return (int)i;
+  return -1;
+}
+
 int LentilCamera::thread_slot() {
   thread_local int slot = -1;
   thread_local const LentilCamera *owner = nullptr;
@@ -233,8 +239,58 @@ void LentilCamera::setup(AtUniverse *universe) {
     return;
   }
   aovs = od->aovs;
+  // cryptomatte (src/lentil.h:241-278): its node sits in options.aov_shaders; once it has added its ranked outputs
+  // (crypto_material00 ...) to options.outputs, setup_crypto_aovs puts lentil's filter on them.  The reference polls
+  // CryptomatteData::is_setup_completed of that node's local data for up to 25 s; that struct is CryptomatteArnold's
+  // (not part of this build), so the outputs are taken as they are when the camera updates.
+  crypto_aovs.clear();
+  cryptomatte_lentil = false;
+  {
+    AtArray *aov_shaders = AiNodeGetArray(options_node, AtString("aov_shaders"));
+    const uint32_t ns = aov_shaders ? AiArrayGetNumElements(aov_shaders) : 0;
+    for (uint32_t i = 0; i < ns; ++i) {
+      AtNode *sh = static_cast<AtNode *>(AiArrayGetPtr(aov_shaders, i));
+      if (sh && AiNodeEntryGetNameAtString(AiNodeGetNodeEntry(sh)) == AtString("cryptomatte")) cryptomatte_lentil = true;
+    }
+  }
+  {
+    // setup_crypto_aovs (src/lentil.h:1015-1055): every crypto_* output joins the list, options.outputs is rebuilt
+    AtArray *outputs = AiNodeGetArray(options_node, S.outputs);
+    const uint32_t n_out = outputs ? AiArrayGetNumElements(outputs) : 0;
+    std::vector<std::string> strings(n_out);
+    std::vector<const char *> ptrs(n_out);
+    for (uint32_t i = 0; i < n_out; ++i) { strings[i] = AiArrayGetStr(outputs, i).c_str(); ptrs[i] = strings[i].c_str(); }
+    std::vector<lentil_aov_plan> extra(n_out + 1);
+    const int m = lentil_setup_crypto_aovs(ptrs.data(), (int)n_out, extra.data(), (int)extra.size());
+    if (m > 0) {
+      // the outputs the operator left, with the cryptomatte ones now carrying lentil's filter (a list that already
+      // holds them -- a second update of the same scene -- is left alone)
+      AtArray *rebuilt = AiArrayAllocate(n_out, 1, AI_TYPE_STRING);
+      for (uint32_t i = 0; i < n_out; ++i) {
+        lentil_output_tokens tok;
+        lentil_tokenize_output(strings[i].c_str(), &tok);
+        std::string out = strings[i];
+        for (int k = 0; k < m; ++k)
+          if (strcmp(extra[(size_t)k].to.aov_name, tok.aov_name) == 0 && strcmp(extra[(size_t)k].to.driver, tok.driver) == 0) {
+            char buf[1024];
+            if (lentil_rebuild_output(&extra[(size_t)k].to, buf, sizeof buf) >= 0) out = buf;
+          }
+        AiArraySetStr(rebuilt, i, AtString(out.c_str()));
+      }
+      AiNodeSetArray(options_node, S.outputs, rebuilt);
+      for (int k = 0; k < m; ++k) {
+        bool dup = false;
+        for (const lentil_aov_plan &a : aovs) dup = dup || strcmp(a.to.aov_name, extra[(size_t)k].to.aov_name) == 0;
+        if (!dup) aovs.push_back(extra[(size_t)k]);
+      }
+    }
+  }
   const int n_aovs = lentil_sanitize_aov_list(aovs.data(), (int)aovs.size());
   aovs.resize((size_t)(n_aovs < 0 ? 0 : n_aovs));
+  for (size_t i = 0; i < aovs.size();)
+    if (aovs[i].is_crypto) { crypto_aovs.push_back(aovs[i]); aovs.erase(aovs.begin() + (long)i); } else ++i;
+  if (!cryptomatte_lentil) crypto_aovs.clear();        // (no cache is built without the node, src/lentil_filter.cpp:169)
+  if (crypto_aovs.size() > LENTIL_MAX_CRYPTO) { AiMsgError("[LENTIL] more than %d cryptomatte AOVs", LENTIL_MAX_CRYPTO); AiRenderAbort(); return; }
   if (aovs.empty() || strcmp(aovs[0].name, "RGBA") != 0) {
     AiMsgWarning("[LENTIL] the first lentil-filtered output must be RGBA; redistribution is off");
     release_gpu();
@@ -277,15 +333,32 @@ void LentilCamera::setup(AtUniverse *universe) {
     AiRenderAbort();
     return;
   }
-  // the visits travel to the GPU while the buckets render (LENTIL_STREAM_UPLOAD=0: one upload at the frame end)
+  if (!crypto_aovs.empty()) {
+    // per-pixel id tables on the GPU, the samples' caches as extra columns of the stage, the ranks by AOV name
+    if (const char *e = getenv("LENTIL_CRYPTO_ENTRIES")) crypto_entries = atoi(e) > 0 ? atoi(e) : crypto_entries;
+    const char *sl = getenv("LENTIL_CRYPTO_SLOTS");
+    std::vector<int> ranks;
+    for (const lentil_aov_plan &a : crypto_aovs) ranks.push_back(lentil_crypto_rank_of_name(a.name));
+    if (!check(lentil_hip_alloc_crypto(gpu, (uint32_t)crypto_aovs.size(), sl ? (uint32_t)atoi(sl) : 0), "alloc_crypto")) return;
+    if (lentil_stage_set_crypto(stage, (uint32_t)crypto_aovs.size(), (uint32_t)crypto_entries) != LENTIL_OK ||
+        lentil_imager_set_crypto(imager, (uint32_t)crypto_aovs.size(), ranks.data()) != LENTIL_OK) {
+      AiMsgError("[LENTIL] could not set up the cryptomatte staging");
+      AiRenderAbort();
+      return;
+    }
+  }
+  // the visits travel to the GPU while the buckets render (LENTIL_STREAM_UPLOAD=0: one upload at the frame end;
+  // frames with cryptomatte AOVs upload their columns with the frame)
   const char *su = getenv("LENTIL_STREAM_UPLOAD");
-  if (!(su && su[0] == '0')) {
+  if (!(su && su[0] == '0') && crypto_aovs.empty()) {
     const double per_pixel = P.inverse_sample_density > 0.0f ? 1.0 / P.inverse_sample_density : 1.0;      // AA^2
     const uint64_t expect = (uint64_t)((double)P.xres * P.yres * per_pixel);
     if (lentil_stage_stream_to(stage, gpu, 0, expect) != LENTIL_OK)
       AiMsgWarning("[LENTIL] streaming upload unavailable (%s); the visits are uploaded at the end of the frame", lentil_hip_last_error(gpu));
   }
   for (const lentil_aov_plan &a : aovs)
+    AiMsgInfo("[LENTIL BIDIRECTIONAL] Driver '%s' -- Adding aov %s of type %s", a.to.driver, a.to.aov_name, a.to.aov_type);
+  for (const lentil_aov_plan &a : crypto_aovs)
     AiMsgInfo("[LENTIL BIDIRECTIONAL] Driver '%s' -- Adding aov %s of type %s", a.to.driver, a.to.aov_name, a.to.aov_type);
   imager_print_once_only = false;
   redistribution = true;

@@ -7,6 +7,7 @@
 
 #include <cmath>
 #include <cstring>
+#include <vector>
 
 AI_FILTER_NODE_EXPORT_METHODS(LentilFilterDataMtd);
 
@@ -61,7 +62,10 @@ filter_pixel {
     const int slot = cam->thread_slot();
     const size_t n_extra = cam->aovs.size() - 1;
     float extra[4 * LENTIL_MAX_AOVS];
-    while (AiAOVSampleIteratorGetNext(iterator)) {
+    const size_t n_crypto = cam->crypto_aovs.size();
+    const int entries = cam->crypto_entries;
+    std::vector<float> crypto_ids(n_crypto * (size_t)entries), crypto_w(n_crypto * (size_t)entries);
+    for (int sampleid = 0; AiAOVSampleIteratorGetNext(iterator); ++sampleid) {
       lentil_sample_capture c;
       memset(&c, 0, sizeof c);
       c.px = px; c.py = py;
@@ -96,6 +100,34 @@ filter_pixel {
         }
       }
       c.extra_rgba = n_extra ? extra : nullptr;
+      // cryptomatte_construct_cache (src/lentil.h:781-811): per cryptomatte AOV the sample's depth entries -- opacity
+      // and the AOV's id -- folded into id -> weight; the iterator has left the sample after its last depth entry
+      // and is put back (reset_iterator_to_id, :1178-1186)
+      bool crypto_ok = true;
+      for (size_t k = 0; k < n_crypto; ++k) {
+        float opacity[3 * 64], value[64];
+        int nd = 0;
+        const AtString name(cam->crypto_aovs[k].name);
+        while (AiAOVSampleIteratorGetNextDepth(iterator)) {
+          if (nd < 64) {
+            const AtRGB o = AiAOVSampleIteratorGetAOVRGB(iterator, S.opacity);
+            opacity[3 * nd] = o.r; opacity[3 * nd + 1] = o.g; opacity[3 * nd + 2] = o.b;
+            value[nd] = AiAOVSampleIteratorGetAOVFlt(iterator, name);
+            ++nd;
+          } else crypto_ok = false;
+        }
+        AiAOVSampleIteratorReset(iterator);
+        for (int i = 0; AiAOVSampleIteratorGetNext(iterator); ++i) if (i == sampleid) break;
+        if (lentil_crypto_construct_cache(nd, opacity, value, crypto_ids.data() + k * (size_t)entries,
+                                          crypto_w.data() + k * (size_t)entries, entries) < 0) crypto_ok = false;
+      }
+      if (!crypto_ok) {
+        AiMsgError("[LENTIL] an AOV sample holds more cryptomatte ids than LENTIL_CRYPTO_ENTRIES (%d)", entries);
+        cam->redistribution = false;
+        break;
+      }
+      c.crypto_ids = n_crypto ? crypto_ids.data() : nullptr;
+      c.crypto_weights = n_crypto ? crypto_w.data() : nullptr;
       if (slot >= cam->stage_slots || lentil_stage_append(cam->stage, slot, &c) != LENTIL_OK) {
         AiMsgError("[LENTIL] could not stage an AOV sample (thread slot %d)", slot);
         cam->redistribution = false;

@@ -60,7 +60,22 @@ driver_process_bucket {
   const void *bucket_data = nullptr;
   while (AiOutputIteratorGetNext(iterator, &aov_name, &aov_type, &bucket_data)) {
     const int idx = cam->aov_index(aov_name.c_str());
-    if (idx < 0) continue;                    // not one of lentil's AOVs (lentil_time was dropped from the list)
+    if (idx < 0) {
+      // a ranked cryptomatte AOV (src/lentil_imager.cpp:121-161)?
+      const int cidx = cam->crypto_index(aov_name.c_str());
+      if (cidx < 0) continue;                 // not one of lentil's AOVs (lentil_time was dropped from the list)
+      const int rc = lentil_imager_process_crypto_bucket(cam->imager, (uint32_t)cidx, bucket_xo, bucket_yo, bucket_size_x,
+                                                         bucket_size_y, (float *)const_cast<void *>(bucket_data));
+      if (rc != LENTIL_OK) {
+        if (!cam->imager_print_once_only) {
+          AiMsgError("%s", lentil_imager_last_error(cam->imager));
+          AiRenderAbort();
+        }
+        cam->imager_print_once_only = true;
+        return;
+      }
+      continue;
+    }
     // the filter turned every type into RGBA (filter_output_type), so bucket_data is AtRGBA[sx * sy] (:100,160,178)
     const int rc = lentil_imager_process_bucket(cam->imager, (uint32_t)idx, bucket_xo, bucket_yo, bucket_size_x, bucket_size_y,
                                                 (float *)const_cast<void *>(bucket_data));

@@ -38,6 +38,11 @@ struct LentilCamera {
   bool have_bokeh = false;
 
   std::vector<lentil_aov_plan> aovs;      // sanitised: the AOVs lentil filters, RGBA first
+  // the ranked cryptomatte AOVs (AOVData::is_crypto, src/lentil.h:1037-1040) in their own list: they take no column of
+  // the frame but a per-pixel id table each; crypto_entries = ids one AOV sample's depth entries may hold
+  std::vector<lentil_aov_plan> crypto_aovs;
+  bool cryptomatte_lentil = false;
+  int crypto_entries = 8;
   std::atomic<bool> redistribution{false};
   bool imager_print_once_only = false;
 
@@ -53,11 +58,12 @@ struct LentilCamera {
   void setup(AtUniverse *universe);
   int thread_slot();                      // one staging slot per render thread
   int aov_index(const char *name) const;
+  int crypto_index(const char *name) const;
 };
 
 // AtString constants, interned once
 struct LentilStrings {
   AtString rgba{"RGBA"}, p{"P"}, z{"Z"}, time{"lentil_time"}, raydir{"lentil_raydir"}, debug{"lentil_debug"},
-      volume{"volume"}, transmission{"transmission"}, ignore{"lentil_ignore"}, outputs{"outputs"};
+      volume{"volume"}, transmission{"transmission"}, ignore{"lentil_ignore"}, outputs{"outputs"}, opacity{"opacity"};
 };
 const LentilStrings &lentil_strings();

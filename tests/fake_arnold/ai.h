@@ -287,6 +287,7 @@ AI_API void AiCameraToWorldMatrix(const AtNode *node, float time, AtMatrix &out)
 
 // ---- iterators -------------------------------------------------------------------------------------------------
 AI_API bool AiAOVSampleIteratorGetNext(AtAOVSampleIterator *iter);
+AI_API bool AiAOVSampleIteratorGetNextDepth(AtAOVSampleIterator *iter);
 AI_API void AiAOVSampleIteratorReset(AtAOVSampleIterator *iter);
 AI_API void AiAOVSampleIteratorGetPixel(AtAOVSampleIterator *iter, int &x, int &y);
 AI_API AtVector2 AiAOVSampleIteratorGetOffset(AtAOVSampleIterator *iter);

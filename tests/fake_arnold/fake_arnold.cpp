@@ -78,6 +78,10 @@ struct SampleStore {
   std::vector<float> ox, oy, inv_density;
   std::map<std::string, std::pair<uint8_t, std::vector<float>>> aov;    // name -> (type, 4 floats per sample)
   std::vector<std::vector<int>> per_pixel;
+  // deep samples: sample i holds depth_count[i] depth entries starting at depth_start[i]; AOVs that have per-depth
+  // values (opacity, the cryptomatte ids) are read from depth_aov while an iterator walks a sample's depths
+  std::vector<int> depth_count, depth_start;
+  std::map<std::string, std::vector<float>> depth_aov;                   // name -> 4 floats per depth entry
 };
 
 struct AtUniverse {
@@ -88,6 +92,7 @@ struct AtUniverse {
   int xres = 0, yres = 0;
   std::map<std::string, std::vector<float>> images;     // output AOV name -> xres * yres * 4
   std::vector<AtArray *> arrays;
+  std::vector<std::string> late_outputs;                // appended to options.outputs after the operators cooked
 };
 
 struct AtAOVSampleIterator {
@@ -96,6 +101,7 @@ struct AtAOVSampleIterator {
   const std::vector<int> *ids;
   int cur;                 // -1 before the first GetNext
   const char *aov_name;    // interned
+  int depth = -1;          // -1: not inside a sample's depth entries
 };
 
 struct OutputSlot { const char *name; int type; float *bucket; };
@@ -133,6 +139,8 @@ static void builtin_entries() {
   entry("driver_exr", AI_NODE_DRIVER);
   entry("imager_denoiser_oidn", AI_NODE_DRIVER);
   for (const char *s : {"aov_write_float", "aov_write_rgb", "state_float", "state_vector"}) entry(s, AI_NODE_SHADER);
+  entry("cryptomatte", AI_NODE_SHADER);            // another plugin's nodes, present by name only
+  entry("cryptomatte_filter", AI_NODE_FILTER);
 }
 
 static void msg(const char *level, const char *format, va_list ap) {
@@ -266,8 +274,19 @@ void AiCameraToWorldMatrix(const AtNode *, float, AtMatrix &out) { identity(out)
 // ---------------------------------------------------------------------------------------------------------------
 // iterators
 // ---------------------------------------------------------------------------------------------------------------
-bool AiAOVSampleIteratorGetNext(AtAOVSampleIterator *it) { if (it->cur + 1 >= (int)it->ids->size()) return false; ++it->cur; return true; }
-void AiAOVSampleIteratorReset(AtAOVSampleIterator *it) { it->cur = -1; }
+bool AiAOVSampleIteratorGetNext(AtAOVSampleIterator *it) { it->depth = -1; if (it->cur + 1 >= (int)it->ids->size()) return false; ++it->cur; return true; }
+void AiAOVSampleIteratorReset(AtAOVSampleIterator *it) { it->cur = -1; it->depth = -1; }
+// walks the depth entries of the current sample; after the last one the iterator has moved on to the next sample
+// (what the reference's comment at src/lentil.h:806-807 reports of the SDK), so callers reset to their sample
+bool AiAOVSampleIteratorGetNextDepth(AtAOVSampleIterator *it) {
+  const SampleStore &s = it->u->samples;
+  if (it->cur < 0 || it->ids->empty() || s.depth_count.empty()) return false;
+  const int id = (*it->ids)[(size_t)it->cur];
+  if (it->depth + 1 < s.depth_count[(size_t)id]) { ++it->depth; return true; }
+  it->depth = -1;
+  if (it->cur + 1 < (int)it->ids->size()) ++it->cur;
+  return false;
+}
 void AiAOVSampleIteratorGetPixel(AtAOVSampleIterator *it, int &x, int &y) { x = it->x; y = it->y; }
 static int sid(const AtAOVSampleIterator *it) { return (*it->ids)[(size_t)(it->cur < 0 ? 0 : it->cur)]; }
 AtVector2 AiAOVSampleIteratorGetOffset(AtAOVSampleIterator *it) { const int s = sid(it); return AtVector2{it->u->samples.ox[s], it->u->samples.oy[s]}; }
@@ -275,6 +294,11 @@ float AiAOVSampleIteratorGetInvDensity(AtAOVSampleIterator *it) { return it->u->
 AtString AiAOVSampleIteratorGetAOVName(AtAOVSampleIterator *it) { return AtString(it->aov_name); }
 static const float *aov4(AtAOVSampleIterator *it, const char *name) {
   static const float zero[4] = {0, 0, 0, 0};
+  if (it->depth >= 0 && !it->ids->empty()) {
+    auto d = it->u->samples.depth_aov.find(name);
+    if (d != it->u->samples.depth_aov.end())
+      return d->second.data() + ((size_t)it->u->samples.depth_start[(size_t)(*it->ids)[(size_t)it->cur]] + (size_t)it->depth) * 4;
+  }
   auto f = it->u->samples.aov.find(name);
   if (f == it->u->samples.aov.end() || it->ids->empty()) return zero;
   return f->second.second.data() + (size_t)sid(it) * 4;
@@ -392,6 +416,20 @@ FA_API void fa_set_samples(AtUniverse *u, int n, const int *px, const int *py, c
   for (int i = 0; i < n; ++i)
     if (px[i] >= 0 && py[i] >= 0 && px[i] < u->xres && py[i] < u->yres) s.per_pixel[(size_t)py[i] * u->xres + px[i]].push_back(i);
 }
+FA_API void fa_set_depths(AtUniverse *u, const int *counts) {
+  SampleStore &s = u->samples;
+  s.depth_count.assign(counts, counts + s.n);
+  s.depth_start.resize((size_t)s.n);
+  int at = 0;
+  for (int i = 0; i < s.n; ++i) { s.depth_start[(size_t)i] = at; at += counts[i]; }
+}
+FA_API void fa_set_depth_aov(AtUniverse *u, const char *name, const float *data4) {
+  const SampleStore &s = u->samples;
+  const size_t total = s.n ? (size_t)s.depth_start.back() + (size_t)s.depth_count.back() : 0;
+  u->samples.depth_aov[name].assign(data4, data4 + total * 4);
+}
+FA_API void fa_add_late_output(AtUniverse *u, const char *output) { u->late_outputs.push_back(output); }
+FA_API void fa_add_aov_shader(AtUniverse *u, AtNode *n) { u->options->p["aov_shaders"].arr->ptrs.push_back(n); }
 FA_API void fa_set_aov(AtUniverse *u, const char *name, int type, const float *data4) {
   auto &slot = u->samples.aov[name];
   slot.first = (uint8_t)type;
@@ -442,6 +480,9 @@ FA_API int fa_render(AtUniverse *u, int n_threads, int bucket_size) {
   fa_node_set_int(u->options, "threads", n_threads);
   // 1. operators
   fa_cook_operators(u);
+  // (outputs other plugins add in their own update, after the operators: cryptomatte's ranked AOVs)
+  for (const std::string &o : u->late_outputs) u->options->p["outputs"].arr->strs.push_back(o);
+  u->late_outputs.clear();
   // 2. node initialise / update: camera first
   std::vector<AtNode *> order;
   if (u->camera) order.push_back(u->camera);

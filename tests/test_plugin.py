@@ -36,7 +36,8 @@ def fa():
     for f in ("fa_node", "fa_set_camera", "fa_node_set_int", "fa_node_set_flt", "fa_node_set_bool", "fa_node_set_str",
               "fa_add_output", "fa_output_count", "fa_output", "fa_set_samples", "fa_set_aov", "fa_render", "fa_get_image",
               "fa_cook_operators", "fa_universe_destroy", "fa_node_exists", "fa_aov_shader_count", "fa_render_hint",
-              "fa_filter_width_x1000", "fa_options"):
+              "fa_filter_width_x1000", "fa_options", "fa_set_depths", "fa_set_depth_aov", "fa_add_late_output",
+              "fa_add_aov_shader"):
         getattr(lib, f).argtypes = None
     assert lib.fa_load_plugin(PLUGIN.encode()) == 4
     return lib
@@ -215,5 +216,124 @@ def test_frame_through_the_plugin_matches_the_oracle(fa, orc, monkeypatch):
         assert np.array_equal(got != 0, m), name
         err = float(np.max(np.abs(got[m].astype(np.float64) - want[m]) / np.abs(want[m])))
         assert err < 2e-5, (name, err)      # two fp32 sums in different orders (ragged capture order vs iterator order)
+    ref.close()
+    fa.fa_universe_destroy(C.c_void_p(u))
+
+
+@pytest.mark.gpu
+def test_cryptomatte_frame_through_the_plugin_matches_the_oracle(fa, orc, monkeypatch):
+    """A scene with a cryptomatte node: its ranked outputs (added after the operator cooked, like cryptomatte's own
+    update does) get lentil's filter (Camera::setup_crypto_aovs, src/lentil.h:1015-1055); filter_pixel folds every AOV
+    sample's depth entries into an id -> weight cache (cryptomatte_construct_cache, :781-811); the imager writes the
+    ranked pairs (src/lentil_imager.cpp:121-161).  Against the oracle run on the same samples with caches built by the
+    oracle's own restatement of the cache construction."""
+    W, H, M, S = 48, 32, 9, 48
+    monkeypatch.setenv("LENTIL_SAMPLES_OVERRIDE", str(S))
+    monkeypatch.setenv("LENTIL_CRYPTO_ENTRIES", "4")
+    fa.fa_messages_clear()
+    u, cam = _scene(fa, W, H, ["RGBA RGBA gaussian_filter driver_exr", "crypto_object RGB gaussian_filter driver_exr"])
+    cm = fa.fa_node(C.c_void_p(u), b"cryptomatte", b"cryptomatte1")
+    fa.fa_add_aov_shader(C.c_void_p(u), C.c_void_p(cm))
+    fa.fa_node(C.c_void_p(u), b"cryptomatte_filter", b"crypto_object_filter00")
+    names = ["crypto_object00", "crypto_object01"]
+    for nm in names:
+        fa.fa_add_late_output(C.c_void_p(u), (nm + " FLOAT crypto_object_filter00 driver_exr").encode())
+    fa.fa_node_set_int(C.c_void_p(cam), b"camera_type", 1)
+    fa.fa_node_set_int(C.c_void_p(cam), b"lens_model", 0)
+    p, model, table, keep = common.po_setup(W, H, samples_override=S, focal_length=np.float32(35.0))
+    visits, cols = common.make_stream(p, W, H, M, f_hi=0.03)
+    n = W * H * M
+    pix = np.arange(n) // M
+    px = (pix % W).astype(np.int32); py = (pix // W).astype(np.int32)
+    rng = np.random.default_rng(9)
+    ox = rng.uniform(-0.5, 0.5, n).astype(np.float32); oy = rng.uniform(-0.5, 0.5, n).astype(np.float32)
+    invd = np.full(n, 1.0 / 9.0, np.float32)
+    fa.fa_set_samples(C.c_void_p(u), n, px.ctypes.data_as(C.c_void_p), py.ctypes.data_as(C.c_void_p), ox.ctypes.data_as(C.c_void_p),
+                      oy.ctypes.data_as(C.c_void_p), invd.ctypes.data_as(C.c_void_p))
+    zeros = np.zeros((n, 4), np.float32)
+    z4 = np.repeat(cols["pos_z"][:, 3:4], 4, axis=1).copy()
+    aov = {"RGBA": (AI_TYPE["RGBA"], cols["rgba"]), "P": (AI_TYPE["VECTOR"], cols["pos_z"]), "Z": (AI_TYPE["FLOAT"], z4),
+           "lentil_raydir": (AI_TYPE["RGB"], cols["raydir_time"]), "lentil_time": (AI_TYPE["FLOAT"], zeros),
+           "volume": (AI_TYPE["RGB"], zeros), "transmission": (AI_TYPE["RGBA"], zeros), "lentil_ignore": (AI_TYPE["FLOAT"], zeros)}
+    keep_arrays = []
+    for name, (t, a) in aov.items():
+        a = np.ascontiguousarray(a, np.float32); keep_arrays.append(a)
+        fa.fa_set_aov(C.c_void_p(u), name.encode(), t, a.ctypes.data_as(C.c_void_p))
+    # depth entries: 0..3 per sample; ids follow 6-pixel columns so that neighbouring pixels share objects
+    counts = rng.integers(0, 4, n).astype(np.int32)
+    total = int(counts.sum())
+    start = np.concatenate([[0], np.cumsum(counts)[:-1]])
+    owner = np.repeat(np.arange(n), counts)
+    opacity = rng.random((total, 1)).astype(np.float32).repeat(4, 1)
+    opacity[rng.random(total) < 0.35] = 1.0
+    pal = (rng.standard_normal(64) * 50).astype(np.float32)
+    idv = pal[((px[owner] // 6) * 3 + rng.integers(0, 3, total)) % 64]
+    id4 = np.ascontiguousarray(np.repeat(idv[:, None], 4, 1), np.float32)
+    fa.fa_set_depths(C.c_void_p(u), counts.ctypes.data_as(C.c_void_p))
+    fa.fa_set_depth_aov(C.c_void_p(u), b"opacity", np.ascontiguousarray(opacity).ctypes.data_as(C.c_void_p))
+    for nm in names:
+        fa.fa_set_depth_aov(C.c_void_p(u), nm.encode(), id4.ctypes.data_as(C.c_void_p))
+
+    rc = fa.fa_render(C.c_void_p(u), 4, 16)
+    msgs = _messages(fa)
+    assert rc == 0 and fa.fa_error_count() == 0, msgs
+    outs = [fa.fa_output(C.c_void_p(u), i).decode() for i in range(fa.fa_output_count(C.c_void_p(u)))]
+    assert "crypto_object00 FLOAT lentil_replaced_filter driver_exr" in outs
+    assert "crypto_object01 FLOAT lentil_replaced_filter driver_exr" in outs
+    assert "crypto_object RGB gaussian_filter driver_exr" in outs           # the display AOV keeps its filter
+    assert "Adding aov crypto_object00" in msgs and "Adding aov crypto_object01" in msgs
+
+    # ---- oracle: caches from the oracle's own cache construction
+    entries = 4
+    ids = np.zeros((n, entries), np.float32)
+    wts = np.full((n, entries), np.array([0xFFFFFFFF], np.uint32).view(np.float32)[0], np.float32)
+    op3 = np.ascontiguousarray(opacity[:, :3])
+    for v in range(n):
+        a, b = int(start[v]), int(start[v]) + int(counts[v])
+        o = np.ascontiguousarray(op3[a:b]); val = np.ascontiguousarray(idv[a:b])
+        ti = np.empty(entries, np.float32); tw = np.empty(entries, np.float32)
+        k = orc.orc_crypto_construct_cache(b - a, o.ctypes.data, val.ctypes.data, ti.ctypes.data, tw.ctypes.data, entries)
+        assert 1 <= k <= entries
+        ids[v, :k] = ti[:k]; wts[v, :k] = tw[:k]
+    lens = orc.orc_lens_create(C.byref(table))
+    ref = oracle_lib.Frame(orc, p, n_aovs=1)
+    ref.set_crypto([ids, ids], [wts, wts])
+    ref.run(lens, None, visits)
+    orc.orc_lens_destroy(lens)
+    assert ref.counters().redistributed_visits > 200
+    B = 16
+    for a, nm in enumerate(names):
+        rank = 2 * a
+        got = np.zeros((H, W, 4), np.float32)
+        assert fa.fa_get_image(C.c_void_p(u), nm.encode(), got.ctypes.data_as(C.c_void_p)) == 0
+        rout, rhas = ref.crypto_rank(a, rank)
+        rout = rout.reshape(p.yres, p.xres, 4)[:H, :W]; rhas = rhas.reshape(p.yres, p.xres)[:H, :W]
+        checked = left = 0
+        for y in range(H):
+            for x0 in range(0, W, B):
+                stop = B
+                miss = np.nonzero(~rhas[y, x0:x0 + B])[0]
+                if len(miss):
+                    stop = int(miss[0])
+                # the rest of the bucket row keeps the display value: these AOVs have no sample-level data -> 0
+                assert (got[y, x0 + stop:x0 + B] == 0).all()
+                left += B - stop
+                for x in range(x0, x0 + stop):
+                    k, w, tot = ref.crypto_pixel(a, y * p.xres + x)
+                    ws = np.sort(w)[::-1] / max(tot, 1e-30)
+                    lo, hi = max(rank - 1, 0), min(rank + 2, len(ws) - 1)
+                    gaps = np.abs(np.diff(ws[lo:hi + 1]))
+                    if len(gaps) and gaps.min() < 1e-4:
+                        continue
+                    assert got[y, x, 0] == rout[y, x, 0] and got[y, x, 2] == rout[y, x, 2], (nm, x, y)
+                    assert abs(got[y, x, 1] - rout[y, x, 1]) < 1e-4 and abs(got[y, x, 3] - rout[y, x, 3]) < 1e-4
+                    checked += 1
+        assert checked > 300, (nm, checked, left)
+    # the beauty of the same pass
+    got = np.zeros((H, W, 4), np.float32)
+    fa.fa_get_image(C.c_void_p(u), b"RGBA", got.ctypes.data_as(C.c_void_p))
+    want = ref.resolve(0).reshape(p.yres, p.xres, 4)[:H, :W]
+    m = want != 0
+    assert float(np.max(np.abs(got[m].astype(np.float64) - want[m]) / np.abs(want[m]))) < 2e-5
     ref.close()
     fa.fa_universe_destroy(C.c_void_p(u))
