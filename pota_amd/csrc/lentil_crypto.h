@@ -89,6 +89,175 @@ __global__ __launch_bounds__(256) void crypto_direct_kernel(CryptoDev C, VisitsD
   }
 }
 
+// The same for pixel-major streams (visits_per_pixel > 0): one lane owns a pixel and walks its visits in stream order,
+// which is the order the reference adds them in.  Nothing else touches the tables while this kernel runs (the draws
+// are replayed behind it), so the owner reads and writes its pixel's table without atomics, and a pixel no draw lands
+// on ends up with the reference's sums bit for bit.
+__global__ __launch_bounds__(256) void crypto_direct_owner_kernel(CryptoDev C, VisitsDev V, lentil_params P, double lens_length) {
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  const uint64_t n_pix = V.n / V.visits_per_pixel;
+  for (uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; q < n_pix; q += stride) {
+    int px, py;
+    visit_pixel(V, q * V.visits_per_pixel, px, py);
+    const uint64_t pix = (uint64_t)P.xres * (uint32_t)py + (uint32_t)px;
+    for (uint32_t c = 0; c < C.n_crypto; ++c) {
+      uint32_t *K = C.keys + ((uint64_t)c * C.np + pix) * C.slots;
+      float *Wt = C.wts + ((uint64_t)c * C.np + pix) * C.slots;
+      float total = C.total[(uint64_t)c * C.np + pix];
+      for (uint32_t m = 0; m < V.visits_per_pixel; ++m) {
+        const uint64_t v = q * V.visits_per_pixel + m;
+        const float invd = V.inv_density ? V.inv_density[v] : P.inverse_sample_density;
+        if (visit_redistributes(P, lens_length, V.pos_z[v], V.volume_ignore[v], V.transmission[v], invd,
+                                [&]() { return V.raydir_time[v]; }))
+          continue;
+        total += invd;                                                                    // :815
+        const float *h = C.hash[c] + v * C.entries, *w = C.weight[c] + v * C.entries;
+        for (uint32_t e = 0; e < C.entries; ++e) {
+          const float cw = w[e];
+          if (__float_as_uint(cw) == kCryptoEmpty) continue;
+          const uint32_t key = crypto_key_bits(h[e]);
+          uint32_t s = (key * 2654435761u >> 16) % C.slots;
+          bool placed = false;
+          for (uint32_t i = 0; i < C.slots && !placed; ++i) {
+            const uint32_t cur = K[s];
+            if (cur == kCryptoEmpty) K[s] = key;
+            if (cur == kCryptoEmpty || cur == key) { Wt[s] += cw * invd; placed = true; }     // :817
+            else s = s + 1u == C.slots ? 0u : s + 1u;
+          }
+          if (!placed) atomicAdd(C.overflow, 1ull);
+        }
+      }
+      C.total[(uint64_t)c * C.np + pix] = total;
+    }
+  }
+}
+
+// The tiled form of the owner kernel, the one pixel-major streams normally get: a block of 128 lanes takes 128
+// consecutive pixels of the stream.  All lanes first read the tile's visits the way they lie in memory (lane = visit:
+// the three columns the decision needs, then per cryptomatte AOV the visits' pairs as one flat range) into LDS, and
+// the tile's table lines likewise; then lane = pixel walks its visits out of LDS, in stream order, into its LDS copy
+// of the table; the tables go back as whole lines.  HBM-bound: 48 B per visit once, entries * 8 B per visit and AOV,
+// the table lines read and written once per AOV.
+struct CryptoTile {
+  uint32_t tp;            // pixels per tile (= block size)
+  uint32_t off_w, off_h, off_cw, off_k, off_wt, off_tot, off_pix;     // LDS offsets in 4-byte words
+};
+__global__ __launch_bounds__(128) void crypto_direct_tile_kernel(CryptoDev C, VisitsDev V, lentil_params P, double lens_length,
+                                                                 CryptoTile T) {
+  extern __shared__ uint32_t crypto_lds[];
+  float *s_w = reinterpret_cast<float *>(crypto_lds + T.off_w);        // [tp * M] inverse density, or the unused pattern
+  float *s_h = reinterpret_cast<float *>(crypto_lds + T.off_h);        // [tp * M * entries]
+  float *s_cw = reinterpret_cast<float *>(crypto_lds + T.off_cw);
+  uint32_t *s_k = crypto_lds + T.off_k;                                // [tp][slots + 1]
+  float *s_wt = reinterpret_cast<float *>(crypto_lds + T.off_wt);      // [tp][slots + 1]
+  float *s_tot = reinterpret_cast<float *>(crypto_lds + T.off_tot);    // [tp]
+  uint32_t *s_pix = crypto_lds + T.off_pix;                            // [tp] frame pixel of the tile's entries
+  const uint32_t M = V.visits_per_pixel, E = C.entries, SL = C.slots, SP = SL + 1u;
+  const uint64_t n_pix = V.n / M;
+  const uint64_t n_tiles = (n_pix + T.tp - 1) / T.tp;
+  for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const uint64_t q0 = tile * T.tp;
+    const uint32_t np_tile = (uint32_t)(n_pix - q0 < T.tp ? n_pix - q0 : T.tp);
+    const uint64_t v0 = q0 * M;
+    const uint32_t nv = np_tile * M;
+    __syncthreads();                       // the previous tile's LDS is done with
+    for (uint32_t i = threadIdx.x; i < nv; i += blockDim.x) {
+      const uint64_t v = v0 + i;
+      const float invd = V.inv_density ? V.inv_density[v] : P.inverse_sample_density;
+      const bool redistributed = visit_redistributes(P, lens_length, nt_load(V.pos_z + v), nt_load(V.volume_ignore + v),
+                                                     nt_load(V.transmission + v), invd, [&]() { return V.raydir_time[v]; });
+      s_w[i] = redistributed ? __uint_as_float(kCryptoEmpty) : invd;
+    }
+    int px = 0, py = 0;
+    uint64_t pix = 0;
+    const bool own = threadIdx.x < np_tile;
+    if (own) {
+      visit_pixel(V, (q0 + threadIdx.x) * M, px, py);
+      pix = (uint64_t)P.xres * (uint32_t)py + (uint32_t)px;
+      s_pix[threadIdx.x] = (uint32_t)pix;
+    }
+    for (uint32_t c = 0; c < C.n_crypto; ++c) {
+      __syncthreads();
+      const float *gh = C.hash[c] + v0 * E, *gw = C.weight[c] + v0 * E;
+      if (((nv * E) & 3u) == 0 && ((v0 * E) & 3u) == 0) {          // 16 bytes per lane (full tiles always are)
+        for (uint32_t i = threadIdx.x; i < nv * E / 4; i += blockDim.x) {
+          const float4 a = nt_load(reinterpret_cast<const float4 *>(gh) + i), b = nt_load(reinterpret_cast<const float4 *>(gw) + i);
+          *reinterpret_cast<float4 *>(s_h + 4 * i) = a;
+          *reinterpret_cast<float4 *>(s_cw + 4 * i) = b;
+        }
+      } else {
+        for (uint32_t i = threadIdx.x; i < nv * E; i += blockDim.x) { s_h[i] = __builtin_nontemporal_load(gh + i); s_cw[i] = __builtin_nontemporal_load(gw + i); }
+      }
+      // the tile's table lines: element (pixel j, slot s); the pixel of tile entry j from its stream position
+      if ((SL & 3u) == 0) {
+        const uint32_t QL = SL / 4;
+        for (uint32_t i = threadIdx.x; i < np_tile * QL; i += blockDim.x) {
+          const uint32_t j = i / QL, sl = (i - j * QL) * 4;
+          const uint64_t at = ((uint64_t)c * C.np + s_pix[j]) * SL + sl;
+          const uint4 k4 = *reinterpret_cast<const uint4 *>(C.keys + at);
+          const float4 w4 = *reinterpret_cast<const float4 *>(C.wts + at);
+          uint32_t *dk = s_k + j * SP + sl; float *dw = s_wt + j * SP + sl;
+          dk[0] = k4.x; dk[1] = k4.y; dk[2] = k4.z; dk[3] = k4.w;
+          dw[0] = w4.x; dw[1] = w4.y; dw[2] = w4.z; dw[3] = w4.w;
+        }
+      } else {
+        for (uint32_t i = threadIdx.x; i < np_tile * SL; i += blockDim.x) {
+          const uint32_t j = i / SL, sl = i - j * SL;
+          const uint64_t at = ((uint64_t)c * C.np + s_pix[j]) * SL + sl;
+          s_k[j * SP + sl] = C.keys[at];
+          s_wt[j * SP + sl] = C.wts[at];
+        }
+      }
+      if (own) s_tot[threadIdx.x] = C.total[(uint64_t)c * C.np + pix];
+      __syncthreads();
+      if (own) {
+        uint32_t *K = s_k + threadIdx.x * SP;
+        float *Wt = s_wt + threadIdx.x * SP;
+        float total = s_tot[threadIdx.x];
+        for (uint32_t m = 0; m < M; ++m) {
+          const float w = s_w[threadIdx.x * M + m];
+          if (__float_as_uint(w) == kCryptoEmpty) continue;
+          total += w;                                                                       // :815
+          for (uint32_t e = 0; e < E; ++e) {
+            const float cw = s_cw[(threadIdx.x * M + m) * E + e];
+            if (__float_as_uint(cw) == kCryptoEmpty) continue;
+            const uint32_t key = crypto_key_bits(s_h[(threadIdx.x * M + m) * E + e]);
+            uint32_t sl = (key * 2654435761u >> 16) % SL;
+            bool placed = false;
+            for (uint32_t i = 0; i < SL && !placed; ++i) {
+              const uint32_t cur = K[sl];
+              if (cur == kCryptoEmpty) K[sl] = key;
+              if (cur == kCryptoEmpty || cur == key) { Wt[sl] += cw * w; placed = true; }    // :817
+              else sl = sl + 1u == SL ? 0u : sl + 1u;
+            }
+            if (!placed) atomicAdd(C.overflow, 1ull);
+          }
+        }
+        s_tot[threadIdx.x] = total;
+      }
+      __syncthreads();
+      if ((SL & 3u) == 0) {
+        const uint32_t QL = SL / 4;
+        for (uint32_t i = threadIdx.x; i < np_tile * QL; i += blockDim.x) {
+          const uint32_t j = i / QL, sl = (i - j * QL) * 4;
+          const uint64_t at = ((uint64_t)c * C.np + s_pix[j]) * SL + sl;
+          const uint32_t *sk = s_k + j * SP + sl; const float *sw = s_wt + j * SP + sl;
+          *reinterpret_cast<uint4 *>(C.keys + at) = make_uint4(sk[0], sk[1], sk[2], sk[3]);
+          *reinterpret_cast<float4 *>(C.wts + at) = make_float4(sw[0], sw[1], sw[2], sw[3]);
+        }
+      } else {
+        for (uint32_t i = threadIdx.x; i < np_tile * SL; i += blockDim.x) {
+          const uint32_t j = i / SL, sl = i - j * SL;
+          const uint64_t at = ((uint64_t)c * C.np + s_pix[j]) * SL + sl;
+          C.keys[at] = s_k[j * SP + sl];
+          C.wts[at] = s_wt[j * SP + sl];
+        }
+      }
+      if (own) C.total[(uint64_t)c * C.np + pix] = s_tot[threadIdx.x];
+    }
+  }
+}
+
 // accepted draws (src/lentil_filter.cpp:296 polynomial optics, :443 thin lens; with abb_chromatic every channel's
 // draw is a log record of its own, like it is an add of its own there) -- sample weight = inverse density / draws
 __global__ __launch_bounds__(256) void crypto_draws_kernel(CryptoDev C, VisitsDev V, lentil_params P, double lens_length,
@@ -281,7 +450,32 @@ static int crypto_after_pass(lentil_hip_ctx *ctx) {
   }
   const double lens_length = ctx->have_lens ? ctx->hlens.length : 0.0;
   const unsigned blocks = (unsigned)ctx->num_cu * 8;
-  hipLaunchKernelGGL(crypto_direct_kernel, dim3(blocks), dim3(256), 0, ctx->stream, k->D, ctx->V, ctx->P, lens_length);
+  // pixel-major streams whose pixels are all distinct (one pass per clear: the tables hold nothing yet that another
+  // lane could be adding to): owner lanes, no atomics
+  if (ctx->V.visits_per_pixel && ctx->V.n % ctx->V.visits_per_pixel == 0) {
+    CryptoTile T{};
+    T.tp = 128;
+    const uint32_t M = ctx->V.visits_per_pixel, E = k->D.entries, SP = k->D.slots + 1;
+    uint32_t at = 0;
+    T.off_w = at; at += (T.tp * M + 3u) & ~3u;
+    T.off_h = at; at += (T.tp * M * E + 3u) & ~3u;          // (16-byte aligned: filled with float4 stores)
+    T.off_cw = at; at += (T.tp * M * E + 3u) & ~3u;
+    T.off_k = at; at += T.tp * SP;
+    T.off_wt = at; at += T.tp * SP;
+    T.off_tot = at; at += T.tp;
+    T.off_pix = at; at += T.tp;
+    const size_t lds = (size_t)at * 4;
+    const char *force = getenv("LENTIL_CRYPTO_TILE");
+    if (lds <= 64 * 1024 && !(force && force[0] == '0')) {
+      const uint64_t n_tiles = (ctx->V.n / M + T.tp - 1) / T.tp;
+      const uint64_t max_blocks = (uint64_t)ctx->num_cu * 16;
+      hipLaunchKernelGGL(crypto_direct_tile_kernel, dim3((unsigned)(n_tiles < max_blocks ? n_tiles : max_blocks)), dim3(128), lds,
+                         ctx->stream, k->D, ctx->V, ctx->P, lens_length, T);
+    } else {
+      hipLaunchKernelGGL(crypto_direct_owner_kernel, dim3(blocks), dim3(256), 0, ctx->stream, k->D, ctx->V, ctx->P, lens_length);
+    }
+  } else
+    hipLaunchKernelGGL(crypto_direct_kernel, dim3(blocks), dim3(256), 0, ctx->stream, k->D, ctx->V, ctx->P, lens_length);
   HIP_TRY(ctx, hipGetLastError());
   if (n_log) {
     hipLaunchKernelGGL(crypto_draws_kernel, dim3(blocks), dim3(256), 0, ctx->stream, k->D, ctx->V, ctx->P, lens_length,

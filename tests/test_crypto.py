@@ -103,7 +103,9 @@ def test_oracle_crypto_conserves_weight(orc):
     orc.orc_lens_destroy(lens)
 
 
-def compare_tables(ctx, ref, n_crypto, np_, tol=TOL):
+def compare_tables(ctx, ref, n_crypto, np_, tol=TOL, exact_pixels=None):
+    """exact_pixels: pixels no draw landed on -- their sums are the pixel's own visits in stream order, added by one
+    lane: bit-identical to the sequential reference"""
     worst = 0.0
     for a in range(n_crypto):
         ids, wts, tot = ctx.download_crypto_table(a)
@@ -115,6 +117,8 @@ def compare_tables(ctx, ref, n_crypto, np_, tol=TOL):
             order = np.argsort(gk, kind="stable")
             gk, gw = gk[order], gw[order]
             assert gk.shape == rk.shape and np.array_equal(gk, rk), "pixel %d of crypto %d holds other ids" % (pix, a)
+            if exact_pixels is not None and exact_pixels[pix]:
+                assert np.array_equal(gw.view(np.uint32), rw.view(np.uint32)) and np.float32(tot[pix]) == np.float32(rtot), pix
             scale = max(float(rtot), 1e-30)
             if len(rw):
                 worst = max(worst, float(np.max(np.abs(gw.astype(np.float64) - rw)) / scale))
@@ -147,6 +151,7 @@ def compare_ranks(ctx, ref, n_crypto, tol=TOL):
 
 CASES = {
     "po": dict(po=True),
+    "po_owner_lanes": dict(po=True, tile="0"),
     "po_chromatic": dict(po=True, abb_chromatic=0.5),
     "thinlens": dict(po=False),
     "thinlens_chromatic": dict(po=False, abb_chromatic=0.6, abb_chromatic_type=0),
@@ -155,11 +160,13 @@ CASES = {
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("case", list(CASES))
-def test_crypto_tables_and_ranks_match_oracle(orc, gpu_ctx_factory, case):
+def test_crypto_tables_and_ranks_match_oracle(orc, gpu_ctx_factory, case, monkeypatch):
     """Two cryptomatte AOVs beside the beauty and a gaussian extra AOV, three passes of one context (the second and
     third are enqueued blind / streamed): per-pixel id sets exact, weights and totals to 1e-5, ranked images exact in
     the ids wherever the ranking is decided by more than the tolerance."""
     kw = dict(CASES[case])
+    if "tile" in kw:
+        monkeypatch.setenv("LENTIL_CRYPTO_TILE", kw.pop("tile"))      # the untiled owner-lane kernel
     W, H, M = 64, 48, 9
     if kw.pop("po"):
         p, model, table, keep = common.po_setup(W, H, samples_override=48, **kw)
@@ -193,7 +200,10 @@ def test_crypto_tables_and_ranks_match_oracle(orc, gpu_ctx_factory, case):
         ctx.resolve()
         c = ctx.counters()
         assert (c.redistributed_visits, c.accepted_draws) == (rc.redistributed_visits, rc.accepted_draws)
-        compare_tables(ctx, ref, n_crypto, p.xres * p.yres)
+        untouched = np.ones(p.xres * p.yres, bool)
+        untouched[ctx.draw_log()[:, 2]] = False
+        assert untouched.sum() > 500
+        compare_tables(ctx, ref, n_crypto, p.xres * p.yres, exact_pixels=untouched)
         compare_ranks(ctx, ref, n_crypto)
         # the beauty is what it is without cryptomatte
         buf, w = ctx.download_accum(0)
