@@ -251,6 +251,12 @@ def test_crypto_error_paths(orc, gpu_ctx_factory):
     ref.set_crypto(hashes, weights)
     ref.run(lens, None, visits)
     compare_tables(ctx, ref, 1, p.xres * p.yres)
+    # between GPUs the tables are not exchanged: a context set up for the deferred (multi-GPU) closest merge refuses
+    ctx.set_closest_exchange(1, 0)
+    ctx.clear_frame()
+    with pytest.raises(capi.LentilError, match="not exchanged"):
+        ctx.redistribute()
+    ctx.set_closest_exchange(0, 0)
     # a shorter stream with the old columns still bound
     visits2, cols2 = common.make_stream(p, W, H, M, f_hi=0.03, v_end=n - M * W)
     ctx.upload_visits(visits2)
