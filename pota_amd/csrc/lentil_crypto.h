@@ -161,12 +161,24 @@ __global__ __launch_bounds__(128) void crypto_direct_tile_kernel(CryptoDev C, Vi
     const uint64_t v0 = q0 * M;
     const uint32_t nv = np_tile * M;
     __syncthreads();                       // the previous tile's LDS is done with
-    for (uint32_t i = threadIdx.x; i < nv; i += blockDim.x) {
-      const uint64_t v = v0 + i;
-      const float invd = V.inv_density ? V.inv_density[v] : P.inverse_sample_density;
-      const bool redistributed = visit_redistributes(P, lens_length, nt_load(V.pos_z + v), nt_load(V.volume_ignore + v),
-                                                     nt_load(V.transmission + v), invd, [&]() { return V.raydir_time[v]; });
-      s_w[i] = redistributed ? __uint_as_float(kCryptoEmpty) : invd;
+    // (three visits' columns in flight per lane before the first decision: at 6 waves per CU the loads of one
+    // iteration alone do not cover the HBM latency)
+    for (uint32_t i0 = threadIdx.x; i0 < nv; i0 += 3u * blockDim.x) {
+      float4 pz[3], vi[3], tr[3];
+#pragma unroll
+      for (uint32_t u = 0; u < 3; ++u) {
+        const uint32_t i = i0 + u * blockDim.x;
+        if (i < nv) { pz[u] = nt_load(V.pos_z + v0 + i); vi[u] = nt_load(V.volume_ignore + v0 + i); tr[u] = nt_load(V.transmission + v0 + i); }
+      }
+#pragma unroll
+      for (uint32_t u = 0; u < 3; ++u) {
+        const uint32_t i = i0 + u * blockDim.x;
+        if (i >= nv) continue;
+        const uint64_t v = v0 + i;
+        const float invd = V.inv_density ? V.inv_density[v] : P.inverse_sample_density;
+        const bool redistributed = visit_redistributes(P, lens_length, pz[u], vi[u], tr[u], invd, [&]() { return V.raydir_time[v]; });
+        s_w[i] = redistributed ? __uint_as_float(kCryptoEmpty) : invd;
+      }
     }
     int px = 0, py = 0;
     uint64_t pix = 0;
@@ -180,6 +192,7 @@ __global__ __launch_bounds__(128) void crypto_direct_tile_kernel(CryptoDev C, Vi
       __syncthreads();
       const float *gh = C.hash[c] + v0 * E, *gw = C.weight[c] + v0 * E;
       if (((nv * E) & 3u) == 0 && ((v0 * E) & 3u) == 0) {          // 16 bytes per lane (full tiles always are)
+#pragma unroll 4
         for (uint32_t i = threadIdx.x; i < nv * E / 4; i += blockDim.x) {
           const float4 a = nt_load(reinterpret_cast<const float4 *>(gh) + i), b = nt_load(reinterpret_cast<const float4 *>(gw) + i);
           *reinterpret_cast<float4 *>(s_h + 4 * i) = a;
@@ -191,6 +204,7 @@ __global__ __launch_bounds__(128) void crypto_direct_tile_kernel(CryptoDev C, Vi
       // the tile's table lines: element (pixel j, slot s); the pixel of tile entry j from its stream position
       if ((SL & 3u) == 0) {
         const uint32_t QL = SL / 4;
+#pragma unroll 4
         for (uint32_t i = threadIdx.x; i < np_tile * QL; i += blockDim.x) {
           const uint32_t j = i / QL, sl = (i - j * QL) * 4;
           const uint64_t at = ((uint64_t)c * C.np + s_pix[j]) * SL + sl;
