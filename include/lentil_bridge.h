@@ -202,8 +202,9 @@ typedef struct lentil_sample_capture {
 
 int lentil_stage_create(int n_thread_slots, uint32_t n_extra, lentil_stage **out);
 /* cryptomatte AOVs ride along as n_crypto x entries (id, weight) pairs per visit; call on an empty stage, before the
- * first append (plain staging only: lentil_stage_stream_to refuses such a stage).  lentil_stage_crypto: the columns
- * that belong to what lentil_stage_visits returned last (lentil_hip_upload_crypto takes them as they are). */
+ * first append (a streaming stage sends them with its blocks: lentil_hip_visits_begin_crypto / _append_crypto; the
+ * context needs its lentil_hip_alloc_crypto first).  lentil_stage_crypto (plain staging): the columns that belong to
+ * what lentil_stage_visits returned last (lentil_hip_upload_crypto takes them as they are). */
 int lentil_stage_set_crypto(lentil_stage *s, uint32_t n_crypto, uint32_t entries);
 int lentil_stage_crypto(lentil_stage *s, lentil_crypto_visits *out);
 void lentil_stage_destroy(lentil_stage *s);

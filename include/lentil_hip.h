@@ -449,6 +449,13 @@ typedef struct lentil_crypto_visits {
 int lentil_hip_alloc_crypto(lentil_hip_ctx *ctx, uint32_t n_crypto, uint32_t slots_per_pixel);
 int lentil_hip_upload_crypto(lentil_hip_ctx *ctx, const lentil_crypto_visits *c);
 int lentil_hip_bind_crypto(lentil_hip_ctx *ctx, const lentil_crypto_visits *c);
+/* the caches with a piecewise upload (lentil_hip_visits_begin ... _end above): lentil_hip_visits_begin_crypto right
+ * after _visits_begin announces `entries` pairs per visit and cryptomatte AOV; every part then goes through
+ * lentil_hip_visits_append_crypto with its caches (caches->n == part->n; page-locked like the part); _visits_end
+ * makes them the context's cryptomatte columns */
+int lentil_hip_visits_begin_crypto(lentil_hip_ctx *ctx, uint32_t entries);
+int lentil_hip_visits_append_crypto(lentil_hip_ctx *ctx, const lentil_visits *part, const lentil_crypto_visits *caches,
+                                    uint64_t *ticket);
 int lentil_hip_download_crypto(lentil_hip_ctx *ctx, uint32_t crypto, uint32_t rank, float *host_rgba, uint8_t *host_has_rank);
 int lentil_hip_download_crypto_table(lentil_hip_ctx *ctx, uint32_t crypto, uint32_t *slots_per_pixel, uint32_t *host_id_bits,
                                      float *host_weight, float *host_total);

@@ -33,7 +33,7 @@ EXPORTS = [
     "lentil_hip_comm_unique_id", "lentil_hip_comm_init", "lentil_hip_comm_destroy", "lentil_hip_allreduce",
     "lentil_hip_exchange_bands",
     "lentil_hip_alloc_crypto", "lentil_hip_upload_crypto", "lentil_hip_bind_crypto", "lentil_hip_download_crypto",
-    "lentil_hip_download_crypto_table",
+    "lentil_hip_download_crypto_table", "lentil_hip_visits_begin_crypto", "lentil_hip_visits_append_crypto",
 ]
 
 _lib = None
@@ -100,6 +100,8 @@ def load_library():
         "lentil_hip_upload_crypto": (i, [vp, C.POINTER(_abi.CryptoVisits)]),
         "lentil_hip_bind_crypto": (i, [vp, C.POINTER(_abi.CryptoVisits)]),
         "lentil_hip_download_crypto": (i, [vp, u32, u32, vp, vp]),
+        "lentil_hip_visits_begin_crypto": (i, [vp, u32]),
+        "lentil_hip_visits_append_crypto": (i, [vp, C.POINTER(_abi.Visits), C.POINTER(_abi.CryptoVisits), C.POINTER(u64)]),
         "lentil_hip_download_crypto_table": (i, [vp, u32, C.POINTER(u32), vp, vp, vp]),
         "lentil_hip_set_draw_log": (i, [vp, u64]),
         "lentil_hip_download_draw_log": (i, [vp, vp, u64, C.POINTER(u64)]),
@@ -331,6 +333,14 @@ class Context:
     def visits_append(self, part):
         t = C.c_uint64()
         self._chk(self.lib.lentil_hip_visits_append(self.h, C.byref(part), C.byref(t)))
+        return t.value
+
+    def visits_begin_crypto(self, entries):
+        self._chk(self.lib.lentil_hip_visits_begin_crypto(self.h, entries))
+
+    def visits_append_crypto(self, part, caches):
+        t = C.c_uint64()
+        self._chk(self.lib.lentil_hip_visits_append_crypto(self.h, C.byref(part), C.byref(caches), C.byref(t)))
         return t.value
 
     def visits_wait(self, ticket):

@@ -456,6 +456,16 @@ static float *block_inv(const lentil_stage *s, const PinnedBlock &b) {
   return reinterpret_cast<float *>(b.base + (size_t)(5 + s->n_extra) * s->block_visits * 16 + (size_t)s->block_visits * 4);
 }
 
+// bytes of one visit in a page-locked block: the columns, pixel + density, the cryptomatte caches
+static size_t block_visit_bytes(const lentil_stage *s) {
+  return 16 * (size_t)(5 + s->n_extra) + 8 + (size_t)s->n_crypto * s->crypto_entries * 8;
+}
+// cryptomatte AOV a's ids (which = 0) / weights (1) of a block: block_visits x entries floats
+static float *block_crypto(const lentil_stage *s, const PinnedBlock &b, uint32_t a, int which) {
+  const size_t head = ((size_t)(5 + s->n_extra) * 16 + 8) * s->block_visits;
+  return reinterpret_cast<float *>(b.base + head + ((size_t)a * 2 + (size_t)which) * s->block_visits * s->crypto_entries * 4);
+}
+
 static int stage_begin_stream(lentil_stage *s) {
   lentil_visits lay;
   memset(&lay, 0, sizeof(lay));
@@ -463,7 +473,8 @@ static int stage_begin_stream(lentil_stage *s) {
   lay.n_extra = s->n_extra;
   static const float announce = 0.0f;
   lay.inv_density = &announce;                   // per-visit densities follow
-  const int rc = lentil_hip_visits_begin(s->gpu, &lay, s->capacity_hint);
+  int rc = lentil_hip_visits_begin(s->gpu, &lay, s->capacity_hint);
+  if (rc == LENTIL_OK && s->n_crypto) rc = lentil_hip_visits_begin_crypto(s->gpu, s->crypto_entries);
   s->stream_open = rc == LENTIL_OK;
   if (rc != LENTIL_OK) s->error = lentil_hip_last_error(s->gpu);
   return rc;
@@ -481,7 +492,16 @@ static int stage_send_block(lentil_stage *s, StageSlot &sl, PinnedBlock &b) {
   for (uint32_t k = 0; k < s->n_extra; ++k) part.extra[k] = block_col(s, b, 5 + k);
   part.pixel = block_pixel(s, b);
   part.inv_density = block_inv(s, b);
-  const int rc = lentil_hip_visits_append(s->gpu, &part, &b.ticket);
+  int rc;
+  if (s->n_crypto) {
+    lentil_crypto_visits cv;
+    memset(&cv, 0, sizeof(cv));
+    cv.n = b.n; cv.n_crypto = s->n_crypto; cv.entries = s->crypto_entries;
+    for (uint32_t a = 0; a < s->n_crypto; ++a) { cv.hash[a] = block_crypto(s, b, a, 0); cv.weight[a] = block_crypto(s, b, a, 1); }
+    rc = lentil_hip_visits_append_crypto(s->gpu, &part, &cv, &b.ticket);
+  } else {
+    rc = lentil_hip_visits_append(s->gpu, &part, &b.ticket);
+  }
   if (rc != LENTIL_OK) return rc;
   sl.sent += b.n;
   b.n = 0;
@@ -519,7 +539,6 @@ BRIDGE_API void lentil_stage_destroy(lentil_stage *s) {
 BRIDGE_API int lentil_stage_stream_to(lentil_stage *s, lentil_hip_ctx *gpu, uint32_t block_visits, uint64_t capacity_hint) {
   if (!s) return LENTIL_ERR_INVALID;
   if (lentil_stage_size(s) != 0) return LENTIL_ERR_INVALID;      // between frames only
-  if (gpu && s->n_crypto) return LENTIL_ERR_UNSUPPORTED;         // cryptomatte columns are uploaded with the frame
   stage_free_blocks(s);
   s->gpu = gpu;
   s->stream_open = false;
@@ -572,7 +591,7 @@ BRIDGE_API int lentil_stage_append(lentil_stage *s, int thread_slot, const lenti
     }
     if (!b->base) {
       void *p = nullptr;
-      const int rc = lentil_hip_host_alloc(&p, (size_t)s->block_visits * (16 * (5 + s->n_extra) + 8));
+      const int rc = lentil_hip_host_alloc(&p, (size_t)s->block_visits * block_visit_bytes(s));
       if (rc != LENTIL_OK) return rc;
       b->base = static_cast<char *>(p);
     }
@@ -590,6 +609,10 @@ BRIDGE_API int lentil_stage_append(lentil_stage *s, int thread_slot, const lenti
       put4(5 + k, c->extra_rgba[k * 4], c->extra_rgba[k * 4 + 1], c->extra_rgba[k * 4 + 2], c->extra_rgba[k * 4 + 3]);
     block_pixel(s, *b)[i] = (uint32_t)c->px | ((uint32_t)c->py << 16);
     block_inv(s, *b)[i] = c->inverse_sample_density;
+    for (uint32_t k = 0; k < s->n_crypto; ++k) {
+      memcpy(block_crypto(s, *b, k, 0) + (size_t)i * s->crypto_entries, c->crypto_ids + (size_t)k * s->crypto_entries, (size_t)s->crypto_entries * 4);
+      memcpy(block_crypto(s, *b, k, 1) + (size_t)i * s->crypto_entries, c->crypto_weights + (size_t)k * s->crypto_entries, (size_t)s->crypto_entries * 4);
+    }
     return LENTIL_OK;
   }
   try {
@@ -674,9 +697,13 @@ BRIDGE_API int lentil_stage_visits(lentil_stage *s, lentil_visits *out) {
 BRIDGE_API int lentil_stage_set_crypto(lentil_stage *s, uint32_t n_crypto, uint32_t entries) {
   if (!s || n_crypto > LENTIL_MAX_CRYPTO || (n_crypto && (entries == 0 || entries > 64))) return LENTIL_ERR_INVALID;
   if (lentil_stage_size(s) != 0) return LENTIL_ERR_INVALID;
-  if (n_crypto && s->gpu) return LENTIL_ERR_UNSUPPORTED;       // the piecewise upload carries the visit columns only
   s->n_crypto = n_crypto;
   s->crypto_entries = n_crypto ? entries : 0;
+  if (s->gpu) {                        // streaming: the blocks change size, the stream is announced anew
+    stage_free_blocks(s);
+    const int rc = stage_begin_stream(s);
+    if (rc != LENTIL_OK) return rc;
+  }
   for (StageSlot &sl : s->slots) { sl.crypto_ids.assign(n_crypto, {}); sl.crypto_weights.assign(n_crypto, {}); }
   s->all.crypto_ids.assign(n_crypto, {});
   s->all.crypto_weights.assign(n_crypto, {});
@@ -684,7 +711,7 @@ BRIDGE_API int lentil_stage_set_crypto(lentil_stage *s, uint32_t n_crypto, uint3
 }
 
 BRIDGE_API int lentil_stage_crypto(lentil_stage *s, lentil_crypto_visits *out) {
-  if (!s || !out || s->gpu || !s->n_crypto) return LENTIL_ERR_INVALID;
+  if (!s || !out || s->gpu || !s->n_crypto) return LENTIL_ERR_INVALID;       // (a streaming stage has sent them already)
   memset(out, 0, sizeof(*out));
   out->n = s->all.pixel.size();
   out->n_crypto = s->n_crypto;

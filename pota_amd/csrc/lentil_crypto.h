@@ -36,11 +36,13 @@ struct CryptoDev {
 struct LentilCrypto {
   CryptoDev D{};
   bool have_columns = false;
+  bool from_upload = false;                 // the columns belong to the context's piecewise upload (lentil_hip_visits_*_crypto)
   uint64_t n_visits = 0;
   std::vector<void *> owned;                // device columns of lentil_hip_upload_crypto
   float *d_rank = nullptr;                  // download staging: np RGBA + np flags
   uint8_t *d_has = nullptr;
-  uint64_t auto_log = 0;                    // draw-log capacity this module asked for (0: the caller's)
+  uint64_t auto_log = 0;                    // capacity of the draw log this module allocated (0: the log is the caller's, or none)
+  uint64_t auto_log_hint = 0;               // what the last pass needed, for the next log this module allocates
 };
 
 // std::map<float, float> compares ids as floats: +0 and -0 are one key.  The table compares bits.
@@ -319,12 +321,43 @@ __global__ __launch_bounds__(256) void crypto_rank_kernel(CryptoDev C, uint32_t 
   }
 }
 
+// lentil_hip_set_draw_log: a log of the caller's is the caller's to size (an overflow is reported, the log stays)
+static void crypto_log_set_by_caller(lentil_hip_ctx *ctx) {
+  LentilCrypto *k = ctx->crypto;
+  if (!k) return;
+  if (k->auto_log > k->auto_log_hint) k->auto_log_hint = k->auto_log;
+  k->auto_log = 0;
+}
+
+static uint32_t crypto_count(const lentil_hip_ctx *ctx) { return ctx->crypto ? ctx->crypto->D.n_crypto : 0; }
+
 static void crypto_free_columns(LentilCrypto *k) {
   for (void *p : k->owned) (void)hipFree(p);
   k->owned.clear();
   for (uint32_t c = 0; c < LENTIL_MAX_CRYPTO; ++c) k->D.hash[c] = k->D.weight[c] = nullptr;
   k->have_columns = false;
+  k->from_upload = false;
   k->n_visits = 0;
+}
+
+// the piecewise upload (lentil_upload.h) frees or reallocates the columns it lent to this module
+static void crypto_columns_gone(lentil_hip_ctx *ctx) {
+  LentilCrypto *k = ctx->crypto;
+  if (!k || !k->from_upload) return;
+  if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+  crypto_free_columns(k);
+}
+
+// lentil_hip_visits_end of a stream that carried cryptomatte caches
+static void crypto_bind_uploaded(lentil_hip_ctx *ctx, uint32_t n_crypto, uint32_t entries, uint64_t n, float *const *hash, float *const *weight) {
+  LentilCrypto *k = ctx->crypto;
+  if (!k || k->D.n_crypto != n_crypto) return;       // (alloc_crypto changed under the stream: redistribute reports the mismatch)
+  crypto_free_columns(k);
+  for (uint32_t a = 0; a < n_crypto; ++a) { k->D.hash[a] = hash[a]; k->D.weight[a] = weight[a]; }
+  k->D.entries = entries;
+  k->n_visits = n;
+  k->have_columns = true;
+  k->from_upload = true;
 }
 
 static void crypto_destroy(lentil_hip_ctx *ctx) {
@@ -438,7 +471,7 @@ static int crypto_before_pass(lentil_hip_ctx *ctx) {
     // no log asked for by the caller: one sized from the last pass, or 4 Mi records (48 MB; LENTIL_CRYPTO_LOG overrides)
     uint64_t want = 4ull << 20;
     if (const char *e = getenv("LENTIL_CRYPTO_LOG")) { const long long v = atoll(e); if (v > 0) want = (uint64_t)v; }
-    if (k->auto_log > want) want = k->auto_log;
+    if (k->auto_log_hint > want) want = k->auto_log_hint;
     const int rc = lentil_hip_set_draw_log(ctx, want);
     if (rc) return rc;
     k->auto_log = want;
@@ -455,11 +488,12 @@ static int crypto_after_pass(lentil_hip_ctx *ctx) {
                               hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   if (n_log > ctx->log_cap) {
+    const uint64_t had = ctx->log_cap;
     if (k->auto_log) {       // this module's own log: the next pass gets one that fits
-      k->auto_log = n_log + n_log / 4;
       (void)lentil_hip_set_draw_log(ctx, 0);
+      k->auto_log_hint = n_log + n_log / 4;
     }
-    return fail(ctx, LENTIL_ERR_NOMEM, "the draw log (" + std::to_string(ctx->log_cap) + " records) is too small for the cryptomatte AOVs of this pass (" +
+    return fail(ctx, LENTIL_ERR_NOMEM, "the draw log (" + std::to_string(had) + " records) is too small for the cryptomatte AOVs of this pass (" +
                                            std::to_string(n_log) + " accepted draws): clear the frame and redistribute again");
   }
   const double lens_length = ctx->have_lens ? ctx->hlens.length : 0.0;

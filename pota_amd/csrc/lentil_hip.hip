@@ -284,6 +284,9 @@ LENTIL_API int lentil_hip_comm_destroy(lentil_hip_ctx *ctx);
 static void upload_destroy(lentil_hip_ctx *ctx);
 static void upload_release(lentil_hip_ctx *ctx, bool free_columns);
 static void crypto_destroy(lentil_hip_ctx *ctx);
+static void crypto_columns_gone(lentil_hip_ctx *ctx);
+static uint32_t crypto_count(const lentil_hip_ctx *ctx);
+static void crypto_bind_uploaded(lentil_hip_ctx *ctx, uint32_t n_crypto, uint32_t entries, uint64_t n, float *const *hash, float *const *weight);
 static int crypto_clear(lentil_hip_ctx *ctx);
 static int crypto_before_pass(lentil_hip_ctx *ctx);
 static int crypto_after_pass(lentil_hip_ctx *ctx);
@@ -2180,8 +2183,10 @@ LENTIL_API int lentil_hip_last_launches(lentil_hip_ctx *ctx, uint32_t n[2]) {
   return LENTIL_OK;
 }
 
+static void crypto_log_set_by_caller(lentil_hip_ctx *ctx);
 LENTIL_API int lentil_hip_set_draw_log(lentil_hip_ctx *ctx, uint64_t capacity) {
   CHECK_CTX(ctx);
+  crypto_log_set_by_caller(ctx);      // (the cryptomatte replay re-marks a log it allocates itself)
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   (void)hipFree(ctx->d_log);

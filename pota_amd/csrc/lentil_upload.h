@@ -16,6 +16,12 @@ struct LentilUpload {
   void *col[5 + LENTIL_MAX_AOVS - 1] = {};   // device columns: rgba, pos_z, raydir_time, volume_ignore, transmission, extras
   uint32_t *pixel = nullptr;
   float *inv_density = nullptr;
+  // cryptomatte caches riding with the stream (lentil_hip_visits_begin_crypto): per AOV `crypto_entries` ids and
+  // weights per visit; the columns are kept from frame to frame like the others
+  uint32_t crypto_n = 0, crypto_entries = 0;           // this frame's stream (0: none)
+  uint32_t crypto_alloc_n = 0, crypto_alloc_entries = 0;   // what the columns below were allocated for
+  uint64_t crypto_capacity = 0;
+  float *chash[LENTIL_MAX_CRYPTO] = {}, *cweight[LENTIL_MAX_CRYPTO] = {};
   hipStream_t stream = nullptr;
   std::mutex m;                      // appends come from many render threads
   // tickets: one event per append, in a ring (a ticket older than the ring is known to be complete when the oldest
@@ -37,6 +43,16 @@ LENTIL_API int lentil_hip_host_free(void *host_ptr) {
   return LENTIL_OK;
 }
 
+static void upload_free_crypto(lentil_hip_ctx *ctx, LentilUpload *u) {
+  crypto_columns_gone(ctx);          // the context's cryptomatte module may be looking at them
+  for (uint32_t a = 0; a < LENTIL_MAX_CRYPTO; ++a) {
+    (void)hipFree(u->chash[a]); u->chash[a] = nullptr;
+    (void)hipFree(u->cweight[a]); u->cweight[a] = nullptr;
+  }
+  u->crypto_alloc_n = u->crypto_alloc_entries = 0;
+  u->crypto_capacity = 0;
+}
+
 static void upload_release(lentil_hip_ctx *ctx, bool free_columns) {
   LentilUpload *u = ctx->upload;
   if (!u) return;
@@ -45,6 +61,7 @@ static void upload_release(lentil_hip_ctx *ctx, bool free_columns) {
     for (void *&p : u->col) { (void)hipFree(p); p = nullptr; }
     (void)hipFree(u->pixel); u->pixel = nullptr;
     (void)hipFree(u->inv_density); u->inv_density = nullptr;
+    upload_free_crypto(ctx, u);
   }
   u->open = false;
   u->capacity = u->n = 0;
@@ -79,6 +96,14 @@ static int upload_reserve(lentil_hip_ctx *ctx, LentilUpload *u, uint64_t capacit
     if ((rc = regrow((void **)&u->inv_density, 4))) return rc;
   }
   u->capacity = capacity;
+  if (u->crypto_n) {
+    crypto_columns_gone(ctx);
+    for (uint32_t a = 0; a < u->crypto_n; ++a) {
+      if ((rc = regrow((void **)&u->chash[a], (size_t)u->crypto_entries * 4))) return rc;
+      if ((rc = regrow((void **)&u->cweight[a], (size_t)u->crypto_entries * 4))) return rc;
+    }
+    u->crypto_capacity = capacity;
+  }
   return LENTIL_OK;
 }
 
@@ -109,16 +134,60 @@ LENTIL_API int lentil_hip_visits_begin(lentil_hip_ctx *ctx, const lentil_visits 
   }
   u->layout = *layout;
   u->n = 0;
+  u->crypto_n = u->crypto_entries = 0;      // a plain stream unless lentil_hip_visits_begin_crypto follows
   u->open = true;
   return LENTIL_OK;
 }
 
+LENTIL_API int lentil_hip_visits_begin_crypto(lentil_hip_ctx *ctx, uint32_t entries) {
+  CHECK_CTX(ctx);
+  LentilUpload *u = ctx->upload;
+  if (!u || !u->open) return fail(ctx, LENTIL_ERR_INVALID, "visits_begin_crypto without visits_begin");
+  const uint32_t n_crypto = crypto_count(ctx);
+  if (!n_crypto) return fail(ctx, LENTIL_ERR_INVALID, "no cryptomatte AOVs allocated (lentil_hip_alloc_crypto)");
+  if (entries == 0 || entries > 64) return fail(ctx, LENTIL_ERR_INVALID, "crypto entries per visit must be 1..64");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  std::lock_guard<std::mutex> g(u->m);
+  if (u->n) return fail(ctx, LENTIL_ERR_INVALID, "visits_begin_crypto after the first append");
+  if (u->crypto_alloc_n != n_crypto || u->crypto_alloc_entries != entries || u->crypto_capacity < u->capacity) {
+    upload_free_crypto(ctx, u);
+    for (uint32_t a = 0; a < n_crypto; ++a) {
+      HIP_TRY(ctx, hipMalloc(&u->chash[a], (size_t)u->capacity * entries * 4));
+      HIP_TRY(ctx, hipMalloc(&u->cweight[a], (size_t)u->capacity * entries * 4));
+    }
+    u->crypto_alloc_n = n_crypto; u->crypto_alloc_entries = entries; u->crypto_capacity = u->capacity;
+  }
+  u->crypto_n = n_crypto;
+  u->crypto_entries = entries;
+  return LENTIL_OK;
+}
+
+static int visits_append_impl(lentil_hip_ctx *ctx, const lentil_visits *part, const lentil_crypto_visits *caches, uint64_t *ticket);
 LENTIL_API int lentil_hip_visits_append(lentil_hip_ctx *ctx, const lentil_visits *part, uint64_t *ticket) {
+  return visits_append_impl(ctx, part, nullptr, ticket);
+}
+LENTIL_API int lentil_hip_visits_append_crypto(lentil_hip_ctx *ctx, const lentil_visits *part, const lentil_crypto_visits *caches,
+                                               uint64_t *ticket) {
+  CHECK_CTX(ctx);
+  if (!caches) return fail(ctx, LENTIL_ERR_INVALID, "caches is null");
+  return visits_append_impl(ctx, part, caches, ticket);
+}
+
+static int visits_append_impl(lentil_hip_ctx *ctx, const lentil_visits *part, const lentil_crypto_visits *caches, uint64_t *ticket) {
   CHECK_CTX(ctx);
   LentilUpload *u = ctx->upload;
   if (!u || !u->open) return fail(ctx, LENTIL_ERR_INVALID, "visits_append without visits_begin");
   if (!part) return fail(ctx, LENTIL_ERR_INVALID, "part is null");
   if (ticket) *ticket = 0;
+  if ((u->crypto_n != 0) != (caches != nullptr))
+    return fail(ctx, LENTIL_ERR_INVALID, caches ? "visits_append_crypto on a stream without cryptomatte caches (lentil_hip_visits_begin_crypto)"
+                                                : "this stream carries cryptomatte caches: lentil_hip_visits_append_crypto");
+  if (caches) {
+    if (caches->n != part->n || caches->n_crypto != u->crypto_n || caches->entries != u->crypto_entries)
+      return fail(ctx, LENTIL_ERR_INVALID, "the caches do not match the part / the stream");
+    for (uint32_t a = 0; a < caches->n_crypto; ++a)
+      if (part->n && (!caches->hash[a] || !caches->weight[a])) return fail(ctx, LENTIL_ERR_INVALID, "a crypto column of the part is null");
+  }
   if (part->n == 0) return LENTIL_OK;
   if (part->n_extra != u->layout.n_extra) return fail(ctx, LENTIL_ERR_INVALID, "part has another number of AOV columns");
   const bool ragged = u->layout.visits_per_pixel == 0;
@@ -146,6 +215,13 @@ LENTIL_API int lentil_hip_visits_append(lentil_hip_ctx *ctx, const lentil_visits
       HIP_TRY(ctx, hipMemcpyAsync(u->inv_density + u->n, part->inv_density, (size_t)part->n * 4, hipMemcpyHostToDevice, u->stream));
     else if (u->layout.inv_density)      // layout.inv_density != NULL announces per-visit densities: every part must bring them
       return fail(ctx, LENTIL_ERR_INVALID, "part without inv_density in a stream that has it");
+  }
+  if (caches) {
+    const size_t row = (size_t)u->crypto_entries * 4;
+    for (uint32_t a = 0; a < u->crypto_n; ++a) {
+      HIP_TRY(ctx, hipMemcpyAsync((char *)u->chash[a] + (size_t)u->n * row, caches->hash[a], (size_t)part->n * row, hipMemcpyHostToDevice, u->stream));
+      HIP_TRY(ctx, hipMemcpyAsync((char *)u->cweight[a] + (size_t)u->n * row, caches->weight[a], (size_t)part->n * row, hipMemcpyHostToDevice, u->stream));
+    }
   }
   u->n += part->n;
   const uint64_t t = u->next_ticket++;
@@ -197,5 +273,6 @@ LENTIL_API int lentil_hip_visits_end(lentil_hip_ctx *ctx, uint64_t *n_visits) {
   rc = ensure_worklist(ctx, d.n);
   if (rc) return rc;
   ctx->have_visits = true;          // the columns stay with the upload object (reused by the next frame's begin)
+  if (u->crypto_n) crypto_bind_uploaded(ctx, u->crypto_n, u->crypto_entries, u->n, u->chash, u->cweight);
   return LENTIL_OK;
 }

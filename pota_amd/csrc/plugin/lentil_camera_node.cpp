@@ -347,10 +347,10 @@ void LentilCamera::setup(AtUniverse *universe) {
       return;
     }
   }
-  // the visits travel to the GPU while the buckets render (LENTIL_STREAM_UPLOAD=0: one upload at the frame end;
-  // frames with cryptomatte AOVs upload their columns with the frame)
+  // the visits (and their cryptomatte caches) travel to the GPU while the buckets render (LENTIL_STREAM_UPLOAD=0: one
+  // upload at the frame end)
   const char *su = getenv("LENTIL_STREAM_UPLOAD");
-  if (!(su && su[0] == '0') && crypto_aovs.empty()) {
+  if (!(su && su[0] == '0')) {
     const double per_pixel = P.inverse_sample_density > 0.0f ? 1.0 / P.inverse_sample_density : 1.0;      // AA^2
     const uint64_t expect = (uint64_t)((double)P.xres * P.yres * per_pixel);
     if (lentil_stage_stream_to(stage, gpu, 0, expect) != LENTIL_OK)

@@ -332,7 +332,8 @@ def test_crypto_aov_list_and_rank_names():
 
 
 @pytest.mark.gpu
-def test_imager_crypto_buckets_match_oracle(orc, gpu_ctx_factory, monkeypatch):
+@pytest.mark.parametrize("streaming", [False, True], ids=["staged", "streamed-upload"])
+def test_imager_crypto_buckets_match_oracle(orc, gpu_ctx_factory, monkeypatch, streaming):
     """filter_pixel's capture with cryptomatte caches (built from depth lists by lentil_crypto_construct_cache) through
     the stage and the once-only imager pass; cryptomatte buckets against the oracle's ranking, including the bucket
     rows the reference abandons at the first pixel whose map is too short.  The library sizes its draw log itself (the
@@ -375,7 +376,8 @@ def test_imager_crypto_buckets_match_oracle(orc, gpu_ctx_factory, monkeypatch):
     stage = C.c_void_p()
     assert lib.lentil_stage_create(2, 0, C.byref(stage)) == 0
     assert lib.lentil_stage_set_crypto(stage, len(names), entries) == 0
-    assert lib.lentil_stage_stream_to(stage, ctx.h, 0, 0) != 0          # cryptomatte columns go with the frame
+    if streaming:      # blocks of 700 visits (and their caches) leave for the GPU while the appends go on
+        assert lib.lentil_stage_stream_to(stage, ctx.h, 700, 0) == 0
     im = C.c_void_p()
     assert lib.lentil_imager_create(ctx.h, stage, C.byref(p), 1, C.byref(im)) == 0
     ranks = (C.c_int * len(names))(*[lib.lentil_crypto_rank_of_name(nm.encode()) for nm in names])
@@ -423,3 +425,67 @@ def test_imager_crypto_buckets_match_oracle(orc, gpu_ctx_factory, monkeypatch):
     lib.lentil_stage_destroy(stage)
     ref.close()
     orc.orc_lens_destroy(lens)
+
+
+@pytest.mark.gpu
+def test_piecewise_upload_carries_the_caches(orc, gpu_ctx_factory):
+    """lentil_hip_visits_begin_crypto / _append_crypto: the stream handed over in parts of uneven size, caches with every
+    part (the columns grow on the way: capacity hint far too small); a second frame through the same columns; the
+    tables equal the ones of a whole upload.  Misuse is refused."""
+    W, H, M = 48, 32, 9
+    p, model, table, keep = common.po_setup(W, H, samples_override=32)
+    visits, cols = common.make_stream(p, W, H, M, f_hi=0.03)
+    n = visits.n
+    hashes, weights = make_crypto_columns(n, W, M, 2, 3)
+    lens = orc.orc_lens_create(C.byref(table))
+    ref = oracle_lib.Frame(orc, p, n_aovs=1)
+    ref.set_crypto(hashes, weights)
+    ref.run(lens, None, visits)
+    ctx = gpu_ctx_factory()
+    ctx.set_params(p); ctx.set_lens(table); ctx.alloc_frame(1)
+    layout = _abi_visits_layout(M, W)
+    ctx.visits_begin(layout, 1000)
+    with pytest.raises(capi.LentilError):                 # no cryptomatte AOVs allocated yet
+        ctx.visits_begin_crypto(3)
+    ctx.alloc_crypto(2, 32)
+    NAMES = ("rgba", "pos_z", "raydir_time", "volume_ignore", "transmission")
+    for frame in range(2):
+        ctx.visits_begin(layout, 1000)
+        ctx.visits_begin_crypto(3)
+        cuts = [0, 5 * M, 500 * M, n // 2 // M * M, n - 7 * M, n] if frame == 0 else [0, n // 2 // M * M, n]
+        for lo, hi in zip(cuts[:-1], cuts[1:]):
+            part = type(layout)()
+            part.n = hi - lo
+            for name in NAMES:
+                setattr(part, name, cols[name][lo:hi].ctypes.data)
+            cv, keepc = capi.make_crypto_visits([h[lo:hi] for h in hashes], [w[lo:hi] for w in weights])
+            if frame == 0 and lo == 0:
+                with pytest.raises(capi.LentilError, match="carries cryptomatte"):
+                    ctx.visits_append(part)
+            t = ctx.visits_append_crypto(part, cv)
+            ctx.visits_wait(t)                             # (the slices are pageable temporaries)
+        assert ctx.visits_end() == n
+        ctx.clear_frame(); ctx.redistribute()
+        compare_tables(ctx, ref, 2, p.xres * p.yres)
+    # a plain stream after it: its appends take no caches, and the pass then misses them
+    ctx.visits_begin(layout, n)
+    part = type(layout)(); part.n = n
+    for name in NAMES:
+        setattr(part, name, cols[name].ctypes.data)
+    cv, keepc = capi.make_crypto_visits(hashes, weights)
+    with pytest.raises(capi.LentilError, match="without cryptomatte"):
+        ctx.visits_append_crypto(part, cv)
+    ctx.visits_append(part)
+    ctx.visits_end()
+    ctx.upload_crypto(cv)                                  # ... unless they are uploaded whole
+    ctx.clear_frame(); ctx.redistribute()
+    compare_tables(ctx, ref, 2, p.xres * p.yres)
+    ref.close()
+    orc.orc_lens_destroy(lens)
+
+
+def _abi_visits_layout(M, W):
+    from pota_amd import _abi
+    lay = _abi.Visits()
+    lay.visits_per_pixel, lay.pixels_per_row, lay.pixel_row_stride = M, W, 1
+    return lay
