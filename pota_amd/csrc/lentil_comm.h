@@ -142,6 +142,7 @@ LENTIL_API int lentil_hip_comm_init(lentil_hip_ctx *ctx, const uint8_t id[128], 
 // interleaved partition: every rank ends up with the whole frame's accumulators (distributed.frame_step)
 LENTIL_API int lentil_hip_allreduce(lentil_hip_ctx *ctx) {
   CHECK_CTX(ctx);
+  ctx->resolved_valid = false;
   LentilComm *cm = ctx->comm;
   if (!cm) return fail(ctx, LENTIL_ERR_INVALID, "no communicator (lentil_hip_comm_init)");
   if (!ctx->have_frame) return fail(ctx, LENTIL_ERR_INVALID, "no frame allocated");
@@ -166,6 +167,7 @@ LENTIL_API int lentil_hip_allreduce(lentil_hip_ctx *ctx) {
 LENTIL_API int lentil_hip_exchange_bands(lentil_hip_ctx *ctx, const int32_t *bounds, int32_t visit_rows, int32_t sparse,
                                          int32_t *band_lo, int32_t *band_hi) {
   CHECK_CTX(ctx);
+  ctx->resolved_valid = false;
   LentilComm *cm = ctx->comm;
   if (!cm) return fail(ctx, LENTIL_ERR_INVALID, "no communicator (lentil_hip_comm_init)");
   if (!ctx->have_frame || visit_rows <= 0) return fail(ctx, LENTIL_ERR_INVALID, "bad exchange_bands arguments");

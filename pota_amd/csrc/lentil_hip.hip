@@ -129,6 +129,13 @@ struct lentil_hip_ctx {
   bool overlap_rounds = true;        // LENTIL_OVERLAP_ROUNDS=0: a streamed pass's second round starts after its first accept has ended
   bool slow_live = true;             // LENTIL_SLOW_LIVE=0: stragglers of a streamed pass wait for their round's solve kernel to end
   hipEvent_t ev_slow = nullptr, ev_round = nullptr;
+  // A streamed pass resolves the frame while its second round is still solving (the chip's HBM is idle then) and, at the
+  // end, once more the 64-pixel groups that received draws: lentil_hip_resolve then finds its work done.
+  bool early_resolve = true;         // LENTIL_EARLY_RESOLVE=0: lentil_hip_resolve does all of it
+  bool early_resolve_pending = false;    // the early half of this pass is enqueued (ev_res marks its end)
+  bool late_resolve_done = false;    // ... and so is the second half, behind the last accept
+  bool resolved_valid = false;       // d_resolved holds the frame as it is
+  hipEvent_t ev_acc1 = nullptr, ev_res = nullptr;
   hipStream_t pub_stream = nullptr;  // streamed pass: publish_kernel, then the live straggler kernel
   hipEvent_t pub_done = nullptr;
   bool pass_pending = false;         // a redistribute ran whose rows have not been asked for yet
@@ -220,6 +227,9 @@ LENTIL_API int lentil_hip_create(int device, lentil_hip_ctx **out_ctx) {
   HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_slow, hipEventDisableTiming));
   HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_round, hipEventDisableTiming));
   HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->pub_done, hipEventDisableTiming));
+  HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_acc1, hipEventDisableTiming));
+  HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_res, hipEventDisableTiming));
+  if (const char *e = getenv("LENTIL_EARLY_RESOLVE")) ctx->early_resolve = atoi(e) != 0;
   if (const char *ft = getenv("LENTIL_FORCE_TABLES")) ctx->use_generated = !(ft[0] == '1');
   if (const char *fc = getenv("LENTIL_FIRST_CHUNK_FRAC")) {
     const double f = atof(fc);
@@ -283,6 +293,7 @@ static void free_bokeh(lentil_hip_ctx *ctx) {
 LENTIL_API int lentil_hip_comm_destroy(lentil_hip_ctx *ctx);
 static void upload_destroy(lentil_hip_ctx *ctx);
 static void upload_release(lentil_hip_ctx *ctx, bool free_columns);
+static int launch_resolve_half(lentil_hip_ctx *ctx, hipStream_t st, uint32_t only_touched);
 static void crypto_destroy(lentil_hip_ctx *ctx);
 static void crypto_columns_gone(lentil_hip_ctx *ctx);
 static uint32_t crypto_count(const lentil_hip_ctx *ctx);
@@ -323,6 +334,8 @@ LENTIL_API int lentil_hip_destroy(lentil_hip_ctx *ctx) {
   if (ctx->pub_done) (void)hipEventDestroy(ctx->pub_done);
   if (ctx->ev_slow) (void)hipEventDestroy(ctx->ev_slow);
   if (ctx->ev_round) (void)hipEventDestroy(ctx->ev_round);
+  if (ctx->ev_acc1) (void)hipEventDestroy(ctx->ev_acc1);
+  if (ctx->ev_res) (void)hipEventDestroy(ctx->ev_res);
   (void)hipFree(ctx->d_ctr);
   if (ctx->h_ctr_pinned) (void)hipHostFree(ctx->h_ctr_pinned);
   (void)hipFree(ctx->d_ranges);
@@ -515,6 +528,7 @@ LENTIL_API int lentil_hip_set_bokeh(lentil_hip_ctx *ctx, const lentil_bokeh_tabl
 
 LENTIL_API int lentil_hip_alloc_frame(lentil_hip_ctx *ctx, uint32_t n_aovs, const uint8_t *kind) {
   CHECK_CTX(ctx);
+  ctx->resolved_valid = false;         // (what an early resolve left in d_resolved no longer describes the frame)
   if (!ctx->have_params) return fail(ctx, LENTIL_ERR_INVALID, "set_params must precede alloc_frame");
   if (n_aovs < 1 || n_aovs > LENTIL_MAX_AOVS) return fail(ctx, LENTIL_ERR_INVALID, "n_aovs out of range");
   for (uint32_t i = 0; i < n_aovs; ++i) {
@@ -681,6 +695,7 @@ LENTIL_API int lentil_hip_upload_visits(lentil_hip_ctx *ctx, const lentil_visits
 
 LENTIL_API int lentil_hip_clear_frame(lentil_hip_ctx *ctx) {
   CHECK_CTX(ctx);
+  ctx->resolved_valid = false;         // (what an early resolve left in d_resolved no longer describes the frame)
   if (!ctx->have_frame) return fail(ctx, LENTIL_ERR_INVALID, "no frame allocated");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   // rows known to hold everything added since the last clear (lentil_hip_touched_rows was asked after the
@@ -1391,6 +1406,17 @@ static int redistribute_streamed(lentil_hip_ctx *ctx, bool *streamed) {
     hipLaunchKernelGGL(accept_kernel, dim3(accept_blocks), dim3(256), 0, ctx->stream, d0);
     HIP_TRY(ctx, hipGetLastError());
   }
+  // The frame's resolve, first half: behind the first accept, beside the second round's solves (one block per CU, no
+  // HBM traffic to speak of) on the otherwise idle second chunk stream.  What later accepts add lands in groups of
+  // pixels whose `touched` flag is set by then: lentil_hip_redistribute resolves those once more at its end.
+  if (ctx->early_resolve && ctx->F.dir && ctx->F.touched && ctx->n_chunks >= 2 && !ctx->comm && !ctx->closest_deferred) {
+    hipStream_t rs = ctx->chunks[1].stream;
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_acc1, ctx->stream));
+    HIP_TRY(ctx, hipStreamWaitEvent(rs, ctx->ev_acc1, 0));
+    if ((rc = launch_resolve_half(ctx, rs, 0u))) return rc;
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_res, rs));
+    ctx->early_resolve_pending = true;
+  }
   for (int round = 1; round < blind_rounds; ++round) {
     da.parity = round & 1; da.round = round;
     if (live) {
@@ -1430,6 +1456,13 @@ static int redistribute_streamed(lentil_hip_ctx *ctx, bool *streamed) {
     HIP_TRY(ctx, hipGetLastError());
   }
   da.slow_live = 0;       // (rounds the host adds one by one, below, park and finish their stragglers the plain way)
+  if (ctx->early_resolve_pending) {
+    // the resolve's second half behind the last accept enqueued blind (should the host have to add rounds, or redo
+    // the draws, lentil_hip_redistribute runs it once more)
+    HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_res, 0));
+    if ((rc = launch_resolve_half(ctx, ctx->stream, 1u))) return rc;
+    ctx->late_resolve_done = true;
+  }
   const int C = ctx->n_chunks;
   HIP_TRY(ctx, hipMemcpyAsync(ctx->h_ctr_pinned, ctx->d_ctr, sizeof(DevCounters) * C, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -1464,6 +1497,7 @@ static int redistribute_streamed(lentil_hip_ctx *ctx, bool *streamed) {
     }
     // did not fit: nothing was accepted.  Fresh queues, then the draws again the plain way, sized from the counters
     ctx->h_ctr_valid = false;
+    ctx->late_resolve_done = false;
     ++ctx->last_fallback;
     HIP_TRY(ctx, hipMemsetAsync((char *)ctx->d_ctr + offsetof(DevCounters, n_tasks), 0,
                                 offsetof(DevCounters, inv_row_min) - offsetof(DevCounters, n_tasks), ch.stream));
@@ -1483,6 +1517,7 @@ static int redistribute_streamed(lentil_hip_ctx *ctx, bool *streamed) {
     int rounds = blind_rounds;
     if (n_items && c.n_active[blind_rounds & 1] != 0) {
       ctx->h_ctr_valid = false;
+      ctx->late_resolve_done = false;
       if ((rc = finish_rounds(ctx, 0, da, blind_rounds, &rounds))) return rc;
       if (rounds > ch.est_rounds) ch.est_rounds = rounds;
     }
@@ -1600,6 +1635,9 @@ LENTIL_API int lentil_hip_redistribute(lentil_hip_ctx *ctx) {
     return fail(ctx, LENTIL_ERR_UNSUPPORTED, "the lentil_debug AOV is exchanged between GPUs by lentil_hip_allreduce / _exchange_bands only");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   { const int rc = crypto_before_pass(ctx); if (rc) return rc; }
+  ctx->resolved_valid = false;
+  ctx->early_resolve_pending = false;
+  ctx->late_resolve_done = false;
   const int C = ctx->n_chunks;
   if (ctx->pass_pending) ctx->dirty_known = false;   // an earlier pass's rows were never asked for: unknown until a full clear
   ctx->pass_pending = true;
@@ -1772,6 +1810,22 @@ LENTIL_API int lentil_hip_redistribute(lentil_hip_ctx *ctx) {
     hipLaunchKernelGGL(closest_gather_kernel, dim3((unsigned)ctx->num_cu * 8), dim3(256), 0, ctx->stream, ctx->F, ctx->V);
     HIP_TRY(ctx, hipGetLastError());
   }
+  if (ctx->early_resolve_pending) {
+    // second half of the resolve that ran beside the pass's second round: the groups of pixels that received draws
+    ctx->early_resolve_pending = false;
+    // (a pass whose draws were redone the chunked way added first-round draws after the early half: lentil_hip_resolve
+    // then does the whole frame)
+    if (ctx->F.dir && ctx->F.touched && !ctx->last_fallback) {
+      if (!ctx->late_resolve_done) {
+        HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_res, 0));
+        const int rc = launch_resolve_half(ctx, ctx->stream, 1u);
+        if (rc) return rc;
+      }
+      ctx->resolved_valid = true;
+    } else {
+      HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_res, 0));     // (the early half must not overwrite a later resolve)
+    }
+  }
   HIP_TRY(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
   ctx->timed_draw = true;
   // A work list, task queue or result pool that was too small drops work on the device (DevCounters::overflow):
@@ -1810,6 +1864,7 @@ LENTIL_API int lentil_hip_zkey_buffer(lentil_hip_ctx *ctx, void **device_ptr, ui
 
 LENTIL_API int lentil_hip_closest_gather(lentil_hip_ctx *ctx) {
   CHECK_CTX(ctx);
+  ctx->resolved_valid = false;         // (what an early resolve left in d_resolved no longer describes the frame)
   if (!ctx->have_frame) return fail(ctx, LENTIL_ERR_INVALID, "no frame allocated");
   if (!ctx->V.n) return LENTIL_OK;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -1842,9 +1897,39 @@ static int resolve_range(lentil_hip_ctx *ctx, uint64_t p_begin, uint64_t p_end) 
   return LENTIL_OK;
 }
 
+// one half of a whole-frame resolve on `st`: everything (only_touched = 0) or the groups that received draws
+static int launch_resolve_half(lentil_hip_ctx *ctx, hipStream_t st, uint32_t only_touched) {
+  const size_t lds = (size_t)4 * 64 * ctx->F.stride * sizeof(float);
+  if (only_touched) {
+    const uint64_t chunks = ((ctx->F.np + 63) / 64 + 63) / 64;         // 64 groups of 64 pixels per wave
+    uint64_t blocks = (chunks + 3) / 4;
+    const uint64_t max_blocks = (uint64_t)ctx->num_cu * 8;
+    if (blocks > max_blocks) blocks = max_blocks;
+    hipLaunchKernelGGL(resolve_touched_kernel, dim3((unsigned)blocks), dim3(256), lds, st, ctx->F, ctx->d_resolved);
+  } else {
+    // (few waves per CU: the second round's solves and parked solves are a chain of latencies on the same SIMDs, and
+    // this kernel has that whole round to finish in)
+    int per_cu = 4;
+    if (const char *e = getenv("LENTIL_EARLY_RESOLVE_BLOCKS")) { per_cu = atoi(e); if (per_cu < 1) per_cu = 1; if (per_cu > 8) per_cu = 8; }
+    uint64_t blocks = (ctx->F.np + 255) / 256;
+    const uint64_t max_blocks = (uint64_t)ctx->num_cu * (uint64_t)per_cu;
+    if (blocks > max_blocks) blocks = max_blocks;
+    hipLaunchKernelGGL(resolve_kernel, dim3((unsigned)blocks), dim3(256), lds, st, ctx->F, ctx->d_resolved, (uint64_t)0, ctx->F.np);
+  }
+  HIP_TRY(ctx, hipGetLastError());
+  return LENTIL_OK;
+}
+
 LENTIL_API int lentil_hip_resolve(lentil_hip_ctx *ctx) {
   CHECK_CTX(ctx);
   if (!ctx->have_frame) return fail(ctx, LENTIL_ERR_INVALID, "no frame allocated");
+  if (ctx->resolved_valid) {          // the pass resolved the frame on its way (nothing has touched it since)
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
+    HIP_TRY(ctx, hipEventRecord(ctx->ev[4], ctx->stream));
+    ctx->timed_resolve = true;
+    return LENTIL_OK;
+  }
   return resolve_range(ctx, 0, ctx->F.np);
 }
 
@@ -1940,6 +2025,7 @@ LENTIL_API int lentil_hip_merge_sparse(lentil_hip_ctx *ctx, uint32_t row_begin, 
 
 static int merge_sparse_impl(lentil_hip_ctx *ctx, uint32_t row_begin, uint32_t n_rows, uint32_t n, const void *dev_idx,
                              const void *dev_vals, const void *dev_keys, const void *dev_keys_dbg) {
+  ctx->resolved_valid = false;         // (what an early resolve left in d_resolved no longer describes the frame)
   CHECK_CTX(ctx);
   int rc = check_rows(ctx, row_begin, n_rows);
   if (rc) return rc;
@@ -1991,6 +2077,7 @@ LENTIL_API int lentil_hip_merge_rows(lentil_hip_ctx *ctx, uint32_t row_begin, ui
 
 static int merge_rows_impl(lentil_hip_ctx *ctx, uint32_t row_begin, uint32_t n_rows, const void *dev_acc_rows,
                            const void *dev_key_rows, const void *dev_key_rows_dbg, bool packed) {
+  ctx->resolved_valid = false;         // (what an early resolve left in d_resolved no longer describes the frame)
   CHECK_CTX(ctx);
   int rc = check_rows(ctx, row_begin, n_rows);
   if (rc) return rc;
@@ -2114,6 +2201,7 @@ LENTIL_API int lentil_hip_download_accum(lentil_hip_ctx *ctx, uint32_t aov, floa
 
 LENTIL_API int lentil_hip_accum_buffer(lentil_hip_ctx *ctx, void **device_ptr, uint64_t *n_floats) {
   CHECK_CTX(ctx);
+  ctx->resolved_valid = false;         // (what an early resolve left in d_resolved no longer describes the frame)
   if (!ctx->have_frame || !device_ptr || !n_floats) return fail(ctx, LENTIL_ERR_INVALID, "bad accum_buffer arguments");
   {
     const int rc = fold_direct(ctx, 0, ctx->F.np, true);      // the caller reduces `acc` across GPUs

@@ -1926,7 +1926,7 @@ LD_DEV AcceptResult accept_item(const DrawArgs &a, AcceptShared &sh, uint32_t it
         rmin = row < rmin ? row : rmin;
         rmax_p1 = row + 1u > rmax_p1 ? row + 1u : rmax_p1;
         s_pix[wave][(uint32_t)__builtin_popcountll(tmask0 & lt_mask)] = pix;
-        if (a.F.touched) a.F.touched[pix >> 6] = 1;
+        if (a.F.touched) a.F.touched[pix >> 6] = a.round ? 2 : 1;      // (2: by a round after the first, see resolve_touched_kernel)
         if (a.F.zkey) atomicMin(a.F.zkey + pix, zk);
         if (a.F.zkey_dbg) atomicMin(a.F.zkey_dbg + pix, zk);      // value.r = samples != 0 for every draw
         if (a.log_cap) {
@@ -2667,55 +2667,84 @@ __global__ __launch_bounds__(256) void fold_direct_kernel(FrameDev F, float *dir
 
 // K7 -- driver_process_bucket's normalisation, src/lentil_imager.cpp:169-186.  Reads the pixel records,
 // writes one planar RGBA image per AOV (what the imager copies into Arnold's buckets).
+// One 64-pixel group: the records, read with fully coalesced float4 loads into the wave's LDS tile; lane p then
+// normalises pixel p and every AOV plane receives 64 adjacent RGBA values (1 KiB per store instruction).
+LD_DEV void resolve_group(const FrameDev &F, float *resolved, float4 *tile, uint64_t p0, uint32_t n_pix, uint32_t lane) {
+  const uint32_t q = F.stride >> 2;                       // float4 per record (stride is a multiple of 8 floats)
+  const float4 *acc4 = reinterpret_cast<const float4 *>(F.acc);
+  const float4 *dir4 = reinterpret_cast<const float4 *>(F.dir);
+  const uint32_t n4 = n_pix * q;
+  if (dir4 && F.touched && !(F.touched[p0 >> 6] | F.touched[(p0 + n_pix - 1u) >> 6])) {
+    // nothing was splatted into these records: they are all zero, the direct sums are the whole story
+    for (uint32_t i = lane; i < n4; i += 64u) tile[i] = dir4[p0 * q + i];
+  } else if (dir4) {
+    // what the pixels' own visits added (scan_dma_kernel) + what was splatted: a pixel that received no draw has a
+    // zero record in `acc`, and 0 + x is x bit for bit (the scan's sums are never -0)
+    for (uint32_t i = lane; i < n4; i += 64u) {
+      const float4 a = acc4[p0 * q + i], d = dir4[p0 * q + i];
+      tile[i] = make_float4(a.x + d.x, a.y + d.y, a.z + d.z, a.w + d.w);
+    }
+  } else {
+    for (uint32_t i = lane; i < n4; i += 64u) tile[i] = acc4[p0 * q + i];
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
+  if (lane < n_pix) {
+    const float *rec = reinterpret_cast<const float *>(tile + (size_t)lane * q);
+    const float wt = rec[4u * F.n_aovs];
+    const float inv = wt != 0.0f ? 1.0f / wt : 1.0f;      // AtRGBA /= float multiplies by 1.0f/f
+    for (uint32_t a = 0; a < F.n_aovs; ++a) {
+      float4 c = tile[(size_t)lane * q + a];
+      if (F.closest_mask & (1u << a)) {
+        c.w = 1.0f;                                      // closest: (r, g, b, 1), src/lentil_imager.cpp:181-186
+      } else if (wt != 0.0f) {
+        c.x *= inv; c.y *= inv; c.z *= inv; c.w *= inv;
+      }
+      reinterpret_cast<float4 *>(resolved)[(uint64_t)a * F.np + p0 + lane] = c;
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+  __builtin_amdgcn_wave_barrier();
+}
+
+// K7 -- driver_process_bucket's normalisation, src/lentil_imager.cpp:169-186.  Reads the pixel records,
+// writes one planar RGBA image per AOV (what the imager copies into Arnold's buckets).  A wave takes 64 consecutive
+// pixels at a time.
 __global__ __launch_bounds__(256) void resolve_kernel(FrameDev F, float *resolved, uint64_t p_begin, uint64_t p_end) {
-  // A wave takes 64 consecutive pixels: their records are one contiguous block, read with fully coalesced
-  // float4 loads into LDS; lane p then normalises pixel p and every AOV plane receives 64 adjacent RGBA
-  // values (1 KiB per store instruction).
   extern __shared__ float4 s_rec[];                       // [waves per block][64 * stride / 4]
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-  const uint32_t q = F.stride >> 2;                       // float4 per record (stride is a multiple of 8 floats)
-  float4 *tile = s_rec + (size_t)wave * 64u * q;
+  float4 *tile = s_rec + (size_t)wave * 64u * (F.stride >> 2);
   const uint64_t n_tiles = (p_end - p_begin + 63ull) / 64ull;
   const uint64_t wave_global = (uint64_t)blockIdx.x * (blockDim.x >> 6) + wave;
   const uint64_t wave_stride = (uint64_t)gridDim.x * (blockDim.x >> 6);
-  const float4 *acc4 = reinterpret_cast<const float4 *>(F.acc);
-  const float4 *dir4 = reinterpret_cast<const float4 *>(F.dir);
   for (uint64_t t = wave_global; t < n_tiles; t += wave_stride) {
     const uint64_t p0 = p_begin + t * 64ull;
-    const uint32_t n_pix = (uint32_t)((p_end - p0) < 64ull ? (p_end - p0) : 64ull);
-    const uint32_t n4 = n_pix * q;
-    if (dir4 && F.touched && !(F.touched[p0 >> 6] | F.touched[(p0 + n_pix - 1u) >> 6])) {
-      // nothing was splatted into these records: they are all zero, the direct sums are the whole story
-      for (uint32_t i = lane; i < n4; i += 64u) tile[i] = dir4[p0 * q + i];
-    } else if (dir4) {
-      // what the pixels' own visits added (scan_dma_kernel) + what was splatted: a pixel that received no draw has a
-      // zero record in `acc`, and 0 + x is x bit for bit (the scan's sums are never -0)
-      for (uint32_t i = lane; i < n4; i += 64u) {
-        const float4 a = acc4[p0 * q + i], d = dir4[p0 * q + i];
-        tile[i] = make_float4(a.x + d.x, a.y + d.y, a.z + d.z, a.w + d.w);
-      }
-    } else {
-      for (uint32_t i = lane; i < n4; i += 64u) tile[i] = acc4[p0 * q + i];
+    resolve_group(F, resolved, tile, p0, (uint32_t)((p_end - p0) < 64ull ? (p_end - p0) : 64ull), lane);
+  }
+}
+
+// The second half of a resolve that ran early -- behind the pass's first accept, while its later rounds were still
+// adding draws (see lentil_hip_redistribute): just the 64-pixel groups a later round's draw was splatted into (flag 2;
+// the headline frame's first round touches most groups, its second a few hundred).  A wave looks at 64 groups'
+// flags with one load and walks the set bits.
+__global__ __launch_bounds__(256) void resolve_touched_kernel(FrameDev F, float *resolved) {
+  extern __shared__ float4 s_rec[];
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  float4 *tile = s_rec + (size_t)wave * 64u * (F.stride >> 2);
+  const uint64_t n_groups = (F.np + 63ull) / 64ull;
+  const uint64_t n_chunks = (n_groups + 63ull) / 64ull;
+  const uint64_t wave_global = (uint64_t)blockIdx.x * (blockDim.x >> 6) + wave;
+  const uint64_t wave_stride = (uint64_t)gridDim.x * (blockDim.x >> 6);
+  for (uint64_t ch = wave_global; ch < n_chunks; ch += wave_stride) {
+    const uint64_t g = ch * 64ull + lane;
+    unsigned long long mask = __ballot(g < n_groups && F.touched[g] >= 2);
+    while (mask) {
+      const uint32_t b = (uint32_t)__builtin_ctzll(mask);
+      mask &= mask - 1ull;
+      const uint64_t p0 = (ch * 64ull + b) * 64ull;
+      resolve_group(F, resolved, tile, p0, (uint32_t)((F.np - p0) < 64ull ? (F.np - p0) : 64ull), lane);
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
-    if (lane < n_pix) {
-      const float *rec = reinterpret_cast<const float *>(tile + (size_t)lane * q);
-      const float wt = rec[4u * F.n_aovs];
-      const float inv = wt != 0.0f ? 1.0f / wt : 1.0f;      // AtRGBA /= float multiplies by 1.0f/f
-      for (uint32_t a = 0; a < F.n_aovs; ++a) {
-        float4 c = tile[(size_t)lane * q + a];
-        if (F.closest_mask & (1u << a)) {
-          c.w = 1.0f;                                      // closest: (r, g, b, 1), src/lentil_imager.cpp:181-186
-        } else if (wt != 0.0f) {
-          c.x *= inv; c.y *= inv; c.z *= inv; c.w *= inv;
-        }
-        reinterpret_cast<float4 *>(resolved)[(uint64_t)a * F.np + p0 + lane] = c;
-      }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
-    __builtin_amdgcn_wave_barrier();
   }
 }
 

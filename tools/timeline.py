@@ -1,9 +1,5 @@
-#!/usr/bin/env python3
-"""Print the kernel timeline of the last redistribution pass from a rocprofv3 --kernel-trace csv.
-
-usage: timeline.py <dir with *_kernel_trace.csv>
-Times are microseconds relative to the first scan launch of the pass.
-"""
+"""Start/end of every kernel of the LAST pass in a rocprofv3 --kernel-trace CSV, relative to the pass's first scan
+launch (microseconds), with the HIP queue each ran on.  usage: timeline.py <rocprof output dir>"""
 import csv
 import glob
 import os
@@ -11,25 +7,26 @@ import sys
 
 
 def main():
-    f = glob.glob(os.path.join(sys.argv[1], "**", "*kernel_trace.csv"), recursive=True)[0]
+    files = glob.glob(os.path.join(sys.argv[1], "**", "*kernel_trace.csv"), recursive=True)
+    f = max(files, key=os.path.getmtime)          # (a directory reused by several runs holds several traces)
     rows = list(csv.DictReader(open(f)))
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-    # a pass ends with its resolve kernel: pass `which` (default: the last one) = everything after the previous resolve,
-    # starting at its first scan launch
-    ends = [i for i, r in enumerate(rows) if "resolve_kernel" in r["Kernel_Name"]]
-    which = int(sys.argv[2]) if len(sys.argv) > 2 else -1
-    e = ends[which] + 1
-    k = ends.index(ends[which])
-    lo = ends[k - 1] + 1 if k > 0 else 0
-    s = next(i for i in range(lo, e) if "scan_" in rows[i]["Kernel_Name"])
+    mine = ("scan_", "solve_", "accept_", "resolve_", "prep_", "publish_", "clear_", "reset_round", "closest_", "fold_", "crypto_")
+    # the last pass: from its first scan launch (the scan after the last resolve / clear before it) to the end
+    scans = [i for i, r in enumerate(rows) if "scan_" in r["Kernel_Name"]]
+    if not scans:
+        raise SystemExit("no scan kernel in " + f)
+    s = scans[-1]
+    while s > 0 and "scan_" in rows[s - 1]["Kernel_Name"]:      # (chunked form: several scan launches back to back)
+        s -= 1
     t0 = int(rows[s]["Start_Timestamp"])
-    for r in rows[s:e]:
+    for r in rows[s:]:
+        name = r["Kernel_Name"]
+        if not any(k in name for k in mine) and "rocclr" not in name:
+            continue
         a = (int(r["Start_Timestamp"]) - t0) / 1e3
         b = (int(r["End_Timestamp"]) - t0) / 1e3
-        name = r["Kernel_Name"].split("(")[0][:60]
-        print("%9.1f %9.1f %8.1f  q%-3s grid %-8s %s" % (a, b, b - a, r.get("Queue_Id", "?"), r.get("Grid_Size", "?"), name))
-        if "resolve" in name:
-            break
+        print("%9.1f %9.1f %8.1f  q%-2s grid %-8s %s" % (a, b, b - a, r.get("Queue_Id", "?"), r.get("Grid_Size", "?"), name[:60]))
 
 
 if __name__ == "__main__":
