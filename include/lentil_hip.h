@@ -309,7 +309,8 @@ int lentil_hip_visits_end(lentil_hip_ctx *ctx, uint64_t *n_visits);
  *               clear_frame, resolve and the row / exchange calls are asynchronous on the context's
  *               stream (lentil_hip_stream); downloads and lentil_hip_sync wait for it.
  * resolve     : driver_process_bucket's normalisation (src/lentil_imager.cpp:112-118,169-186)
- *               into a separate resolved image (the accumulators stay intact). */
+ *               into a separate resolved image (the accumulators stay intact).  A streamed pass has
+ *               usually done it on its way (beside its second round); the call then costs nothing. */
 int lentil_hip_clear_frame(lentil_hip_ctx *ctx);
 int lentil_hip_redistribute(lentil_hip_ctx *ctx);
 int lentil_hip_resolve(lentil_hip_ctx *ctx);

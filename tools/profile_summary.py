@@ -15,7 +15,7 @@ import os
 import sys
 
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
-MINE = ("scan_", "solve_", "accept_", "prep_items", "resolve_kernel", "publish_kernel", "fold_direct", "clear_touched",
+MINE = ("scan_", "solve_", "accept_", "prep_items", "resolve_kernel", "resolve_touched", "reset_round", "crypto_", "publish_kernel", "fold_direct", "clear_touched",
         "pack_rows", "merge_", "compact_rows", "closest_gather", "debug_gather")
 
 
