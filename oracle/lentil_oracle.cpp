@@ -30,6 +30,10 @@
  *  - PARITY UNPINNED for the three Eigen operations of the thin-lens coma rotation (AngleAxisd ->
  *    Matrix3d, Matrix3d::inverse, Matrix3d * Vector3d): Eigen is included from a sibling checkout
  *    (src/lens.h:5-6, no version pinned) and absent here; restated from Eigen 3.3/3.4's sources.
+ *  - PARITY UNPINNED for the cryptomatte path (cache construction, per-pixel maps, ranking): the reference
+ *    holds scenes with cryptomatte AOVs (tests/tl_redistribution_bug) but no captured samples or images for
+ *    them; AiColorToGrey is restated as recalled ((r + g + b) / 3).  Pinned only by hand-worked depth lists
+ *    (tests/test_crypto.py) and by std::map / std::sort being libstdc++'s own here as there.
  *  The reference itself is unbuildable here (needs <ai.h>, Eigen, CryptomatteArnold and
  *  the generated lens code), so there is no oracle/_ref.
  *
