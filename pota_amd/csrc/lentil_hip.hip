@@ -104,6 +104,7 @@ struct lentil_hip_ctx {
   uint64_t extra_below = 8ull << 20;         // LENTIL_EXTRA_BELOW: ... while a chunk's draw sum is below this
   int solve_cap_blocks = 1;                  // LENTIL_EARLY_CAP_BLOCKS: solve blocks per CU while later chunks are scanned
   int accept_max_blocks = 4;                 // LENTIL_ACCEPT_BLOCKS: accept blocks per CU at most
+  int accept_stream_blocks = 2;              // ... in a streamed pass, whose accepts share the CUs with the next round's solves
   int solve_max_blocks = 4;                  // LENTIL_SOLVE_BLOCKS: solve blocks per CU at most
   // Streamed pass (polynomial optics, from the second pass of a context on): one scan launch that publishes its items
   // and their first-batch tasks itself, persistent solve waves that follow the task queue while the scan runs.
@@ -250,7 +251,7 @@ LENTIL_API int lentil_hip_create(int device, lentil_hip_ctx **out_ctx) {
   if (ctx->extra_const > 64) ctx->extra_const = 64;
   if (const char *e = getenv("LENTIL_EARLY_CAP_BLOCKS")) ctx->solve_cap_blocks = atoi(e);
   if (ctx->solve_cap_blocks < 1) ctx->solve_cap_blocks = 1;
-  if (const char *e = getenv("LENTIL_ACCEPT_BLOCKS")) ctx->accept_max_blocks = atoi(e);
+  if (const char *e = getenv("LENTIL_ACCEPT_BLOCKS")) ctx->accept_max_blocks = ctx->accept_stream_blocks = atoi(e);
   if (ctx->accept_max_blocks < 1) ctx->accept_max_blocks = 1;
   if (const char *e = getenv("LENTIL_SOLVE_BLOCKS")) ctx->solve_max_blocks = atoi(e);
   if (ctx->solve_max_blocks < 1) ctx->solve_max_blocks = 1;
@@ -1388,7 +1389,7 @@ static int redistribute_streamed(lentil_hip_ctx *ctx, bool *streamed) {
   HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->pub_done, 0));
   if (live) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_slow, 0));
   else launch_slow(ctx, da, ctx->stream);
-  const uint64_t acc_max = (uint64_t)ctx->num_cu * (uint64_t)ctx->accept_max_blocks;
+  const uint64_t acc_max = (uint64_t)ctx->num_cu * (uint64_t)(ctx->accept_stream_blocks < 1 ? 1 : ctx->accept_stream_blocks);
   const uint64_t acc_want = ctx->est_items_total + ctx->est_items_total / 4 + 1;
   const unsigned accept_blocks = (unsigned)(acc_want > acc_max ? acc_max : acc_want);
   int blind_rounds = ctx->est_rounds_total < 2 ? 2 : (ctx->est_rounds_total > 6 ? 6 : ctx->est_rounds_total);
