@@ -331,6 +331,54 @@ def test_crypto_aov_list_and_rank_names():
                      "crypto_object02": 4, "crypto_object03": 0, "crypto_custom01": 0}
 
 
+def test_stage_keeps_the_caches_beside_their_visits():
+    """lentil_stage_set_crypto / lentil_stage_crypto (host logic): appended from two thread slots, the concatenated
+    cryptomatte columns line up with the concatenated visits; misuse is refused."""
+    lib = bridge.load()
+    W, H, M = 12, 8, 3
+    p, model, table, keep = common.po_setup(W, H)
+    n = W * H * M
+    cols = workload.generate(np, 0, n, W, H, M, f_hi=0.05, focus_dist=150.0, tan_half_fov=common.tan_half_fov(p))
+    pix = np.arange(n, dtype=np.uint32) // M
+    cols["pixel"] = ((pix % W) | ((pix // W) << 16)).astype(np.uint32)
+    cols["inv_density"] = np.full(n, p.inverse_sample_density, np.float32)
+    rng = np.random.default_rng(1)
+    ids = [rng.standard_normal((n, 2)).astype(np.float32) for _ in range(2)]
+    wts = [rng.random((n, 2)).astype(np.float32) for _ in range(2)]
+    cols["crypto_ids"], cols["crypto_weights"] = ids, wts
+    stage = C.c_void_p()
+    assert lib.lentil_stage_create(2, 0, C.byref(stage)) == 0
+    cv = _abi_crypto()
+    assert lib.lentil_stage_crypto(stage, C.byref(cv)) != 0                  # no cryptomatte AOVs announced
+    assert lib.lentil_stage_set_crypto(stage, 2, 65) != 0                    # entries out of range
+    assert lib.lentil_stage_set_crypto(stage, 2, 2) == 0
+    order = [np.arange(100, n), np.arange(0, 100)]                           # slot 0 holds the later visits
+    for k in range(2):
+        bridge.stage_append_arrays(stage, k, cols, order[k])
+    assert lib.lentil_stage_set_crypto(stage, 1, 2) != 0                     # not on a stage that holds visits
+    from pota_amd import _abi
+    v = _abi.Visits()
+    assert lib.lentil_stage_visits(stage, C.byref(v)) == 0 and v.n == n
+    assert lib.lentil_stage_crypto(stage, C.byref(cv)) == 0
+    assert (cv.n, cv.n_crypto, cv.entries) == (n, 2, 2)
+    perm = np.concatenate(order)
+    got_rgba = np.ctypeslib.as_array(C.cast(v.rgba, C.POINTER(C.c_float)), (n, 4))
+    assert np.array_equal(got_rgba, cols["rgba"][perm])
+    for a in range(2):
+        h = np.ctypeslib.as_array(C.cast(cv.hash[a], C.POINTER(C.c_float)), (n, 2))
+        w = np.ctypeslib.as_array(C.cast(cv.weight[a], C.POINTER(C.c_float)), (n, 2))
+        assert np.array_equal(h, ids[a][perm]) and np.array_equal(w, wts[a][perm])
+    # a capture without caches on such a stage is refused
+    c = bridge.SampleCapture()
+    assert lib.lentil_stage_append(stage, 0, C.byref(c)) != 0
+    lib.lentil_stage_destroy(stage)
+
+
+def _abi_crypto():
+    from pota_amd import _abi
+    return _abi.CryptoVisits()
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("streaming", [False, True], ids=["staged", "streamed-upload"])
 def test_imager_crypto_buckets_match_oracle(orc, gpu_ctx_factory, monkeypatch, streaming):
