@@ -427,8 +427,8 @@ int lentil_hip_exchange_bands(lentil_hip_ctx *ctx, const int32_t *bounds, int32_
  * lentil_crypto_visits carries, per cryptomatte AOV, the cache of every visit of the bound stream as `entries`
  * (id, weight) pairs (what Camera::cryptomatte_construct_cache, src/lentil.h:781-811, leaves: ids distinct; a pair
  * whose weight has the bits 0xFFFFFFFF is unused; -0 counts as +0, which is one key to the reference's map too).
- * Host arrays with lentil_hip_upload_crypto, device arrays with lentil_hip_bind_crypto; after the visits, before
- * lentil_hip_redistribute.  lentil_hip_alloc_crypto follows lentil_hip_alloc_frame (which drops the tables);
+ * Host arrays with lentil_hip_upload_crypto, device arrays with lentil_hip_bind_crypto; after the visits they belong
+ * to (binding other visits makes them stale: the pass then refuses), before lentil_hip_redistribute.  lentil_hip_alloc_crypto follows lentil_hip_alloc_frame (which drops the tables);
  * slots_per_pixel is the number of distinct ids a pixel can hold (0: 16, at most 64) -- a pass that meets more
  * returns LENTIL_ERR_NOMEM, as does one whose accepted draws exceed the draw log the adds are replayed from (sized
  * by the library from the previous pass unless lentil_hip_set_draw_log was called; clear the frame and redistribute

@@ -38,6 +38,7 @@ struct LentilCrypto {
   bool have_columns = false;
   bool from_upload = false;                 // the columns belong to the context's piecewise upload (lentil_hip_visits_*_crypto)
   uint64_t n_visits = 0;
+  uint64_t visits_gen = 0;                  // lentil_hip_ctx::visits_gen when the columns were handed over
   std::vector<void *> owned;                // device columns of lentil_hip_upload_crypto
   float *d_rank = nullptr;                  // download staging: np RGBA + np flags
   uint8_t *d_has = nullptr;
@@ -356,6 +357,7 @@ static void crypto_bind_uploaded(lentil_hip_ctx *ctx, uint32_t n_crypto, uint32_
   for (uint32_t a = 0; a < n_crypto; ++a) { k->D.hash[a] = hash[a]; k->D.weight[a] = weight[a]; }
   k->D.entries = entries;
   k->n_visits = n;
+  k->visits_gen = ctx->visits_gen;
   k->have_columns = true;
   k->from_upload = true;
 }
@@ -431,6 +433,7 @@ LENTIL_API int lentil_hip_bind_crypto(lentil_hip_ctx *ctx, const lentil_crypto_v
   for (uint32_t a = 0; a < c->n_crypto; ++a) { k->D.hash[a] = c->hash[a]; k->D.weight[a] = c->weight[a]; }
   k->D.entries = c->entries;
   k->n_visits = c->n;
+  k->visits_gen = ctx->visits_gen;
   k->have_columns = true;
   return LENTIL_OK;
 }
@@ -455,6 +458,7 @@ LENTIL_API int lentil_hip_upload_crypto(lentil_hip_ctx *ctx, const lentil_crypto
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   k->D.entries = c->entries;
   k->n_visits = c->n;
+  k->visits_gen = ctx->visits_gen;
   k->have_columns = true;
   return LENTIL_OK;
 }
@@ -463,7 +467,7 @@ LENTIL_API int lentil_hip_upload_crypto(lentil_hip_ctx *ctx, const lentil_crypto
 static int crypto_before_pass(lentil_hip_ctx *ctx) {
   LentilCrypto *k = ctx->crypto;
   if (!k) return LENTIL_OK;
-  if (!k->have_columns || k->n_visits != ctx->V.n)
+  if (!k->have_columns || k->n_visits != ctx->V.n || k->visits_gen != ctx->visits_gen)
     return fail(ctx, LENTIL_ERR_INVALID, "the cryptomatte columns do not belong to the bound visit stream (lentil_hip_upload_crypto / _bind_crypto after the visits)");
   if (ctx->comm || ctx->closest_deferred)
     return fail(ctx, LENTIL_ERR_UNSUPPORTED, "cryptomatte AOVs are not exchanged between GPUs");

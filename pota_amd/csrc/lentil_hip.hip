@@ -59,6 +59,7 @@ struct lentil_hip_ctx {
 
   VisitsDev V{};
   bool have_visits = false;
+  uint64_t visits_gen = 0;            // counts the visit streams bound so far (cryptomatte columns belong to one of them)
   std::vector<void *> owned_visit_mem;
 
   uint2 *d_work = nullptr;
@@ -654,6 +655,7 @@ LENTIL_API int lentil_hip_bind_visits(lentil_hip_ctx *ctx, const lentil_visits *
   rc = ensure_worklist(ctx, v->n);
   if (rc) return rc;
   ctx->have_visits = true;
+  ++ctx->visits_gen;
   return LENTIL_OK;
 }
 
@@ -691,6 +693,7 @@ LENTIL_API int lentil_hip_upload_visits(lentil_hip_ctx *ctx, const lentil_visits
   rc = ensure_worklist(ctx, v->n);
   if (rc) return rc;
   ctx->have_visits = true;
+  ++ctx->visits_gen;
   return LENTIL_OK;
 }
 

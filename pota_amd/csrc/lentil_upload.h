@@ -273,6 +273,7 @@ LENTIL_API int lentil_hip_visits_end(lentil_hip_ctx *ctx, uint64_t *n_visits) {
   rc = ensure_worklist(ctx, d.n);
   if (rc) return rc;
   ctx->have_visits = true;          // the columns stay with the upload object (reused by the next frame's begin)
+  ++ctx->visits_gen;
   if (u->crypto_n) crypto_bind_uploaded(ctx, u->crypto_n, u->crypto_entries, u->n, u->chash, u->cweight);
   return LENTIL_OK;
 }

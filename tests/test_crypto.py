@@ -257,6 +257,14 @@ def test_crypto_error_paths(orc, gpu_ctx_factory):
     with pytest.raises(capi.LentilError, match="not exchanged"):
         ctx.redistribute()
     ctx.set_closest_exchange(0, 0)
+    # the same visits bound anew: caches handed over for an earlier stream do not count, whatever its length
+    ctx.upload_visits(visits)
+    ctx.clear_frame()
+    with pytest.raises(capi.LentilError, match="columns"):
+        ctx.redistribute()
+    ctx.upload_crypto(cv)
+    ctx.clear_frame()
+    ctx.redistribute()
     # a shorter stream with the old columns still bound
     visits2, cols2 = common.make_stream(p, W, H, M, f_hi=0.03, v_end=n - M * W)
     ctx.upload_visits(visits2)
