@@ -361,7 +361,7 @@ class Bench:
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         acc = {"scan": 0.0, "draw": 0.0, "resolve": 0.0, "streamed": 0, "blind_chunks": 0, "redone": 0, "iters": 0,
-               "attempted": 0, "accepted": 0, "redistributed": 0, "scan_launches": 0}
+               "attempted": 0, "accepted": 0, "redistributed": 0, "scan_launches": 0, "lane_rounds": 0, "tries": 0, "slow": 0}
         for _ in range(steps):
             self.step()
             # HIP-event times of this step's kernels (the call waits for the step's stream work, which
@@ -373,6 +373,7 @@ class Bench:
                 raise SystemExit("bench.py: the device dropped work (worklist_overflow = %d): results incomplete" % k.worklist_overflow)
             acc["streamed"] += int(k.streamed); acc["blind_chunks"] += int(k.blind_chunks); acc["redone"] += int(k.fallback_chunks)
             acc["iters"] += int(k.newton_iterations); acc["attempted"] += int(k.attempted_draws)
+            acc["lane_rounds"] += int(k.lane_rounds); acc["tries"] += int(k.tries); acc["slow"] += int(k.slow_solves)
             acc["accepted"] += int(k.accepted_draws); acc["redistributed"] += int(k.redistributed_visits)
             acc["scan_launches"] += max(1, self.ctx.last_launches()[0])
         if self.world > 1:
@@ -397,6 +398,8 @@ class Bench:
         return {
             "kernel": "solve_po_kernel + solve_slow_kernel", "bound": "fp64 valu",
             "lane_iterations_per_step": r["iters"] // max(1, r["steps"]),
+            "solves_per_step": r["tries"] // max(1, r["steps"]), "parked_solves_per_step": r["slow"] // max(1, r["steps"]),
+            "lane_utilisation": round(r["iters"] / r["lane_rounds"], 4) if r["lane_rounds"] else None,
             "flops_per_lane_iteration": {"mul": mul, "add": add, "transforms_and_inverses": other},
             "ms_per_step_scan_plus_draw": round(secs * 1e3 / max(1, r["steps"]), 4),
             "achieved": round(tf, 3), "unit": "TFLOP/s", "peak_fma": FP64_VECTOR_PEAK_TFLOPS,

@@ -885,6 +885,11 @@ ORC_API void orc_frame_merge(OrcFrame *dst, const OrcFrame *src) {   /* per-thre
   for (uint32_t a = 0; a < dst->n_aovs; a++)
     for (size_t i = 0; i < dst->buffer[a].size(); i++) dst->buffer[a][i] += src->buffer[a][i];
   for (size_t i = 0; i < dst->weight.size(); i++) dst->weight[i] += src->weight[i];
+  if (dst->shadow && src->shadow) {   /* the exact sums add up exactly where the partial sums do (gaussian AOVs) */
+    for (uint32_t a = 0; a < dst->n_aovs; a++)
+      for (size_t i = 0; i < dst->buffer64[a].size(); i++) dst->buffer64[a][i] += src->buffer64[a][i];
+    for (size_t i = 0; i < dst->weight64.size(); i++) dst->weight64[i] += src->weight64[i];
+  }
   dst->ctr.visits += src->ctr.visits;
   dst->ctr.redistributed_visits += src->ctr.redistributed_visits;
   dst->ctr.attempted_draws += src->ctr.attempted_draws;

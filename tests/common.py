@@ -71,3 +71,67 @@ def rel_err(a, b, floor=1e-30):
     a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
     scale = np.maximum(np.abs(b), floor)
     return float(np.max(np.abs(a - b) / scale)) if a.size else 0.0
+
+
+class ThreadedOracle:
+    """The oracle over a whole (large) stream, threaded over contiguous visit ranges that end on pixel-row
+    boundaries, every thread with private accumulators (the reference's own threads share theirs and race,
+    SURVEY 3.4) merged at the end.  A pixel that only receives its own visits is summed by one thread in
+    iterator order -- bit for bit what a single thread leaves there; where draws land, the per-thread
+    partial sums add up in thread order (inside the 1e-5 bar, and the fp64 shadows add up exactly)."""
+
+    def __init__(self, lib, p, table, visits, n_threads, n_aovs=1, kinds=None, bokeh=None, row_visits=None):
+        import threading
+        self.lib = lib
+        lens = lib.orc_lens_create(C.byref(table)) if table is not None else None
+        n = int(visits.n)
+        rv = int(row_visits or (visits.pixels_per_row * visits.visits_per_pixel))
+        rows = (n + rv - 1) // rv
+        n_threads = max(1, min(n_threads, rows))
+        bounds = [min(n, int(round(i * rows / n_threads)) * rv) for i in range(n_threads + 1)]
+        self.frames = [oracle_lib.Frame(lib, p, n_aovs=n_aovs, kinds=kinds, keep_log=True) for _ in range(n_threads)]
+        errs = []
+
+        def work(i):
+            try:
+                self.frames[i].run(lens, bokeh, visits, bounds[i], bounds[i + 1])
+            except Exception as e:      # noqa: BLE001
+                errs.append(e)
+
+        ts = [threading.Thread(target=work, args=(i,)) for i in range(n_threads)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+        if lens:
+            lib.orc_lens_destroy(lens)
+        if errs:
+            raise errs[0]
+        self._log = np.concatenate([f.log() for f in self.frames], axis=0)
+        for f in self.frames[1:]:
+            lib.orc_frame_merge(self.frames[0].h, f.h)
+            f.close()
+        self.frames = self.frames[:1]
+
+    def __getattr__(self, name):         # buffer / weight / buffer64 / weight64 / resolve / counters of the merged frame
+        if name == "frames":
+            raise AttributeError(name)
+        return getattr(self.frames[0], name)
+
+    def log(self):
+        return self._log
+
+    def close(self):
+        for f in self.frames:
+            f.close()
+
+
+def host_memory_gb():
+    try:
+        with open("/proc/meminfo") as f:
+            for line in f:
+                if line.startswith("MemAvailable:"):
+                    return int(line.split()[1]) / (1 << 20)
+    except OSError:
+        pass
+    return 16.0

@@ -1,0 +1,116 @@
+"""The pass bench.py times, at the size it is timed at, against the oracle.
+
+bench.py's headline step is the *streamed* pass -- scan_dma_kernel publishing to persistent solve waves, live
+stragglers, the second round beside the first accept, the early resolve -- on 3840x2160 / 9 visits per pixel /
+1024 draws / f_hi 2^-16, alternating between two seeded streams.  Here that very workload (same generator on the
+device, same seeds, same order of passes) is compared with the oracle run over the whole frame, threaded over
+rows: accepted-draw lists bit-identical, counters equal, direct sums bit-exact where no draw lands, everything
+within 1e-5 where draws land, including the image the pass resolves on its way.
+Reference loop being replaced: src/lentil_filter.cpp:248-299; direct adds src/lentil.h:938-955.
+"""
+import numpy as np
+import pytest
+
+import common
+from pota_amd import capi, workload
+from test_gpu_parity import check_frame, check_logs
+
+pytestmark = pytest.mark.gpu
+
+
+def _device_stream(torch, p, W, H, M, seed, f_hi, v_begin, v_end, y0=0):
+    """The bench's generator on the device + the same arrays on the host (the oracle reads exactly what the GPU reads)."""
+    dev = torch.device("cuda:0")
+    cols = workload.generate(torch, v_begin, v_end, W, H, M, seed=seed, f_hi=f_hi, focus_dist=150.0,
+                             tan_half_fov=common.tan_half_fov(p), device=dev)
+    dv, dkeep = capi.make_visits(cols, visits_per_pixel=M, pixels_per_row=W, pixel_y0=y0, ptr=lambda t: t.data_ptr())
+    torch.cuda.synchronize()
+    host = {k: (v.cpu().numpy() if k != "extra" else []) for k, v in cols.items()}
+    hv, hkeep = capi.make_visits(host, visits_per_pixel=M, pixels_per_row=W, pixel_y0=y0)
+    return (dv, (cols, dkeep)), (hv, (host, hkeep))
+
+
+def _oracle_threads(p, per_frame_gb):
+    import os
+    return int(max(2, min(32, os.cpu_count() or 2, (common.host_memory_gb() * 0.5) // per_frame_gb)))
+
+
+def _compare(ctx, ref, c, samples, n_visits, p):
+    rc = ref.counters()
+    assert (c.visits, c.redistributed_visits, c.attempted_draws, c.accepted_draws) == (
+        n_visits, rc.redistributed_visits, rc.attempted_draws, rc.accepted_draws)
+    assert c.worklist_overflow == 0
+    check_logs(ctx, ref)                      # (visit, attempt, pixel) of every accepted draw, bit for bit
+    worst = check_frame(ctx, ref)             # accumulators, weights, resolved image (the early-resolved one): 1e-5
+    # pixels no draw lands on only hold their own visits, added in iterator order: bit-exact
+    touched = np.zeros(p.xres * p.yres, bool)
+    touched[ref.log()[:, 2]] = True
+    buf, w = ctx.download_accum(0)
+    assert np.array_equal(buf[~touched], ref.buffer(0)[~touched])
+    assert np.array_equal(w[~touched], ref.weight()[~touched])
+    assert np.array_equal(ctx.download_aov(0)[~touched], ref.resolve(0)[~touched])
+    return worst, int(touched.sum())
+
+
+def test_headline_4k_streamed_vs_oracle(orc):
+    import torch
+    W, H, M, S, f_hi = 3840, 2160, 9, 1024, 2.0 ** -16
+    n = W * H * M
+    p, model, table, keep = common.po_setup(W, H, samples_override=S)
+    ctx = capi.Context(0)
+    try:
+        ctx.set_params(p); ctx.set_lens(table); ctx.set_bokeh(None)
+        assert ctx.lens_is_compiled()
+        ctx.alloc_frame(1)
+        ctx.set_draw_log(1 << 21)
+        streams, refs = [], []
+        threads = _oracle_threads(p, 0.7)
+        for seed in (0x5EED, 0xBEEF):               # bench.py's SEEDS
+            d, h = _device_stream(torch, p, W, H, M, seed, f_hi, 0, n)
+            streams.append(d)
+            ref = common.ThreadedOracle(orc, p, table, h[0], threads)
+            assert 900 < ref.counters().redistributed_visits < 1400
+            refs.append(ref)
+            del h
+        # bench.py's order: set-up passes, then alternating streams.  The first pass of a context looks at its scans
+        # (chunked); every later one is streamed.
+        for i, want_streamed in ((0, 0), (1, 1), (0, 1), (1, 1)):
+            dv, dkeep = streams[i]
+            ctx.bind_visits(dv, dkeep)
+            ctx.clear_frame(); ctx.redistribute(); ctx.resolve(); ctx.sync()
+            c = ctx.counters()
+            assert c.streamed == want_streamed and c.fallback_chunks == 0, (i, c.streamed, c.fallback_chunks)
+            worst, n_touched = _compare(ctx, refs[i], c, S, n, p)
+            print("stream %d %s: %d items, %d accepted draws on %d pixels, max rel err %.2e"
+                  % (i, "streamed" if want_streamed else "chunked", c.redistributed_visits, c.accepted_draws, n_touched, worst))
+    finally:
+        ctx.close()
+
+
+def test_config5_quarter_frame_chunked_vs_oracle(orc, monkeypatch):
+    """BASELINE config 5 (7680x4320, 2048 draws) as one GPU runs it -- the chunked form, blind from the second pass on --
+    on a quarter of the frame: the 1080 rows around the optical axis, at the full frame's geometry."""
+    import torch
+    W, H, M, S, f_hi = 7680, 4320, 9, 2048, 2.0 ** -16
+    y0, rows = 1620, 1080
+    p, model, table, keep = common.po_setup(W, H, samples_override=S)
+    monkeypatch.setenv("LENTIL_STREAM", "0")
+    ctx = capi.Context(0)
+    try:
+        ctx.set_params(p); ctx.set_lens(table); ctx.set_bokeh(None)
+        ctx.alloc_frame(1)
+        ctx.set_draw_log(1 << 22)
+        d, h = _device_stream(torch, p, W, H, M, 0x5EED, f_hi, y0 * W * M, (y0 + rows) * W * M, y0=y0)
+        ref = common.ThreadedOracle(orc, p, table, h[0], _oracle_threads(p, 2.6))
+        del h
+        n = rows * W * M
+        for blind in (0, 2):
+            ctx.bind_visits(*d)
+            ctx.clear_frame(); ctx.redistribute(); ctx.resolve(); ctx.sync()
+            c = ctx.counters()
+            assert c.streamed == 0 and c.blind_chunks == blind and c.fallback_chunks == 0
+            worst, n_touched = _compare(ctx, ref, c, S, n, p)
+            print("config 5 quarter frame, %s: %d items, %d accepted draws on %d pixels, max rel err %.2e"
+                  % ("blind" if blind else "first pass", c.redistributed_visits, c.accepted_draws, n_touched, worst))
+    finally:
+        ctx.close()

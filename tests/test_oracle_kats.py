@@ -392,3 +392,29 @@ def test_thinlens_chromatic_draws_one_xor128_value_per_surviving_attempt(orc):
     lit = buf[:, :3].max(axis=1) > 10.0
     assert lit.any() and (buf[lit, 0] != buf[lit, 1]).any()
     ref.close()
+
+
+def test_threaded_oracle_equals_the_single_thread_one(orc):
+    """tests/common.py::ThreadedOracle (the checker of the full-size GPU tests): same accepted draws and counters as one
+    thread walking the stream; pixels no draw lands on bit-equal; the rest equal to fp32 summation order; fp64 shadows
+    equal to rounding of the merge."""
+    import common
+    W, H, M = 48, 40, 9
+    p, model, table, keep = common.po_setup(W, H, samples_override=32)
+    visits, cols = common.make_stream(p, W, H, M, f_hi=0.01)
+    one = common.run_oracle(orc, p, table, visits)
+    thr = common.ThreadedOracle(orc, p, table, visits, 5)
+    a, b = one.counters(), thr.counters()
+    assert (a.visits, a.redistributed_visits, a.attempted_draws, a.accepted_draws) == (
+        b.visits, b.redistributed_visits, b.attempted_draws, b.accepted_draws)
+    assert a.redistributed_visits > 50
+    assert np.array_equal(common.sort_log(one.log()), common.sort_log(thr.log()))
+    touched = np.zeros(p.xres * p.yres, bool)
+    touched[one.log()[:, 2]] = True
+    assert touched.any() and not touched.all()
+    assert np.array_equal(one.buffer(0)[~touched], thr.buffer(0)[~touched])
+    assert np.array_equal(one.weight()[~touched], thr.weight()[~touched])
+    assert np.allclose(one.buffer(0), thr.buffer(0), rtol=2e-6, atol=0)
+    assert np.allclose(one.buffer64(0), thr.buffer64(0), rtol=1e-13, atol=0)
+    assert np.allclose(one.weight64(), thr.weight64(), rtol=1e-13, atol=0)
+    thr.close()
