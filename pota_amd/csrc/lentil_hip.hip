@@ -101,7 +101,7 @@ struct lentil_hip_ctx {
  int slow_from_round = 0;                   // LENTIL_SLOW_FROM_ROUND
   int slow_max_lanes = 4;                    // LENTIL_SLOW_MAX_LANES
   bool blind = true;                         // LENTIL_BLIND=0: always wait for a chunk's scan before sizing its draw rounds
-  uint32_t extra_num = 0, extra_const = 0;   // LENTIL_EXTRA_256THS / LENTIL_EXTRA_CONST: first-batch over-provisioning
+  uint32_t extra_num = 0, extra_const = 16;  // LENTIL_EXTRA_256THS / LENTIL_EXTRA_CONST: first-batch over-provisioning (16 spare attempts: what a decoupled first accept's guess about its unknown attempts may be off by, accept_item<1>)
   uint64_t extra_below = 8ull << 20;         // LENTIL_EXTRA_BELOW: ... while a chunk's draw sum is below this
   int solve_cap_blocks = 1;                  // LENTIL_EARLY_CAP_BLOCKS: solve blocks per CU while later chunks are scanned
   int accept_max_blocks = 4;                 // LENTIL_ACCEPT_BLOCKS: accept blocks per CU at most
@@ -130,6 +130,9 @@ struct lentil_hip_ctx {
   hipEvent_t scans_done = nullptr;   // after the last chunk's scan of a pass
   bool overlap_rounds = true;        // LENTIL_OVERLAP_ROUNDS=0: a streamed pass's second round starts after its first accept has ended
   bool slow_live = true;             // LENTIL_SLOW_LIVE=0: stragglers of a streamed pass wait for their round's solve kernel to end
+  int crowd_stays_first = 0, crowd_stays_later = 1;    // LENTIL_CROWD_STAYS=ab (two digits): DrawArgs::slow_crowd_stays of a streamed pass's first / later rounds
+  bool solve_b = false;              // LENTIL_SOLVE_B=1: the second solve launch behind the scan (its blocks only find room when the first launch's leave: measured idle)
+  bool decouple = true;              // LENTIL_DECOUPLE=0: a streamed pass's first accept waits for the first round's stragglers
   hipEvent_t ev_slow = nullptr, ev_round = nullptr;
   // A streamed pass resolves the frame while its second round is still solving (the chip's HBM is idle then) and, at the
   // end, once more the 64-pixel groups that received draws: lentil_hip_resolve then finds its work done.
@@ -260,6 +263,9 @@ LENTIL_API int lentil_hip_create(int device, lentil_hip_ctx **out_ctx) {
   if (const char *e = getenv("LENTIL_SCAN_DMA")) ctx->scan_dma = !(e[0] == '0');
   if (const char *e = getenv("LENTIL_SLOW_LIVE")) ctx->slow_live = !(e[0] == '0');
   if (const char *e = getenv("LENTIL_OVERLAP_ROUNDS")) ctx->overlap_rounds = !(e[0] == '0');
+  if (const char *e = getenv("LENTIL_DECOUPLE")) ctx->decouple = !(e[0] == '0');
+  if (const char *e = getenv("LENTIL_CROWD_STAYS")) { ctx->crowd_stays_first = e[0] == '1'; ctx->crowd_stays_later = e[0] && e[1] == '1'; }
+  if (const char *e = getenv("LENTIL_SOLVE_B")) ctx->solve_b = e[0] == '1';
   if (const char *e = getenv("LENTIL_STREAM_BELOW")) ctx->stream_below = strtoull(e, nullptr, 10);
   if (const char *e = getenv("LENTIL_STREAM_BLOCKS")) ctx->stream_blocks = atoi(e);
   if (ctx->stream_blocks < 1) ctx->stream_blocks = 1;
@@ -270,6 +276,21 @@ LENTIL_API int lentil_hip_create(int device, lentil_hip_ctx **out_ctx) {
   if (ctx->stream_blocks > 2) ctx->stream_blocks = 2;
   if (const char *e = getenv("LENTIL_PUBLISH_WAVES")) ctx->publish_waves = atoi(e);
   if (ctx->publish_waves < 1) ctx->publish_waves = 1;
+  {
+    // The accept kernels spill a few registers: the first launch of one on a stream makes the runtime size that
+    // queue's scratch memory, and it does so behind everything already in flight -- in a streamed pass that is the
+    // resident solve waves which are waiting for this very accept's tasks (seen as a 250 ms stall of the first
+    // streamed pass of a context, then the chunked redo).  One empty launch of each form here, on the stream the
+    // streamed pass launches them on, settles that before anything waits for anything.
+    DrawArgs w{};
+    w.ctr = ctx->d_ctr;        // zeroed above: no active items, the kernels return at once
+    const unsigned wg = (unsigned)ctx->num_cu * 8u;       // (the runtime sizes the scratch by the grid: the largest any pass launches)
+    hipLaunchKernelGGL(accept_kernel<0>, dim3(wg), dim3(256), 0, ctx->stream, w);
+    hipLaunchKernelGGL(accept_kernel<1>, dim3(wg), dim3(256), 0, ctx->stream, w);
+    hipLaunchKernelGGL(accept_kernel<2>, dim3(wg), dim3(256), 0, ctx->stream, w);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  }
   *out_ctx = ctx;
   return LENTIL_OK;
 }
@@ -557,6 +578,7 @@ LENTIL_API int lentil_hip_alloc_frame(lentil_hip_ctx *ctx, uint32_t n_aovs, cons
   ctx->d_resolved = nullptr;
   ctx->have_frame = false;
   const uint64_t np = (uint64_t)ctx->P.xres * ctx->P.yres;
+  if (np >= (uint64_t)kCodePendingBase) return fail(ctx, LENTIL_ERR_UNSUPPORTED, "frames of 0xFE000000 pixels or more");
   const uint32_t rec = ((4u * n_aovs + 1u) + 7u) & ~7u;      // floats per pixel record
   const uint64_t nfl = np * rec;
   HIP_TRY(ctx, hipMalloc(&ctx->F.acc, nfl * sizeof(float)));
@@ -832,7 +854,7 @@ static void bind_chunk_buffers(const lentil_hip_ctx::Chunk &ch, DrawArgs &da) {
   da.slow = ch.slow;
   // (the last num_cu * 4 records are kept for a live queue's end markers)
   const uint64_t usable = ch.slow_cap > (uint64_t)4096 ? ch.slow_cap - 1024 : 0;
-  da.slow_cap = (uint32_t)(usable < 0xFFFFFFF0ull ? usable : 0xFFFFFFF0ull);
+  da.slow_cap = (uint32_t)(usable < 0x00FFFFF0ull ? usable : 0x00FFFFF0ull);      // (a pending mark names its slot in 24 bits)
   if (!usable) da.slow = nullptr;
 }
 
@@ -850,7 +872,7 @@ static int finish_rounds(lentil_hip_ctx *ctx, int ci, DrawArgs &da, int first_ro
     if (n_act == 0) break;
     da.parity = round & 1; da.round = round;
     launch_solve(ctx, da, ch.stream, 256);
-    hipLaunchKernelGGL(accept_kernel, dim3(n_act < 512u ? n_act : 512u), dim3(256), 0, ch.stream, da);
+    hipLaunchKernelGGL(accept_kernel<0>, dim3(n_act < 512u ? n_act : 512u), dim3(256), 0, ch.stream, da);
     HIP_TRY(ctx, hipGetLastError());
   }
   HIP_TRY(ctx, hipStreamSynchronize(ch.stream));
@@ -914,7 +936,7 @@ static int launch_chunk_rounds(lentil_hip_ctx *ctx, int ci, DrawArgs &da, uint64
       const unsigned lim = (unsigned)ctx->num_cu / 4u > 0u ? (unsigned)ctx->num_cu / 4u : 1u;
       if (ab > lim) ab = lim;
     }
-    hipLaunchKernelGGL(accept_kernel, dim3(ab), dim3(256), 0, ch.stream, da);
+    hipLaunchKernelGGL(accept_kernel<0>, dim3(ab), dim3(256), 0, ch.stream, da);
     HIP_TRY(ctx, hipGetLastError());
   }
   return LENTIL_OK;
@@ -1017,7 +1039,7 @@ static int enqueue_chunk_draws(lentil_hip_ctx *ctx, int ci, DrawArgs &da, int bl
     hipLaunchKernelGGL(prep_items_kernel, dim3((unsigned)((ni + 255) / 256)), dim3(256), 0, ch.stream, da);
     launch_solve(ctx, da, ch.stream, (unsigned)max_blocks);
     if (i0 == 0) HIP_TRY(ctx, hipStreamWaitEvent(ch.stream, ctx->scans_done, 0));   // see launch_chunk_rounds
-    hipLaunchKernelGGL(accept_kernel, dim3((unsigned)ctx->num_cu * 2), dim3(256), 0, ch.stream, da);
+    hipLaunchKernelGGL(accept_kernel<0>, dim3((unsigned)ctx->num_cu * 2), dim3(256), 0, ch.stream, da);
     HIP_TRY(ctx, hipGetLastError());
     int rounds = 0;
     if ((rc = finish_rounds(ctx, ci, da, 1, &rounds))) return rc;
@@ -1062,6 +1084,7 @@ static void init_draw_args(lentil_hip_ctx *ctx, DrawArgs &da) {
   da.log = ctx->d_log;
   da.log_cap = ctx->log_cap;
   da.log_count = &ctx->d_ctr[C].log_count;
+  da.slow_q = -1; da.slow_round = -1; da.slow_close = 1; da.slow_indirect = 0;      // a straggler queue per round
 }
 
 // FrameDev::touched stops being the whole truth about `acc` (something other than a splat is written there): the
@@ -1353,6 +1376,24 @@ static int redistribute_streamed(lentil_hip_ctx *ctx, bool *streamed) {
   // parked solves as they come (one wave per CU, on the publishers' stream behind them).  B then brings three waves
   // per block instead of four: with A's two per SIMD that leaves one SIMD per CU room for a straggler wave (152 VGPRs).
   const bool live = ctx->slow_live && da.slow != nullptr && P.cameraType == LENTIL_POLYNOMIAL_OPTICS;
+  int blind_rounds = ctx->est_rounds_total < 2 ? 2 : (ctx->est_rounds_total > 6 ? 6 : ctx->est_rounds_total);
+  if (const char *e = getenv("LENTIL_BLIND_ROUNDS")) { blind_rounds = atoi(e); if (blind_rounds < 1) blind_rounds = 1; if (blind_rounds > 8) blind_rounds = 8; }
+  // Second round beside the first accept: the accept kernel hands out the next round's tasks as it goes (tagged slots,
+  // end markers from its last block), a kStream solve kernel -- one block per CU, which fits beside four accept blocks
+  // -- takes them as they come, the straggler kernel beside both.  Launched AFTER the accept, so that a profiler that
+  // serialises kernels runs them in an order that completes.
+  const bool overlap = live && ctx->overlap_rounds && blind_rounds >= 2;
+  // ... and the first accept does not wait for the first round's stragglers either (accept_item<1> / <2>): one
+  // straggler queue and one solve_slow_kernel launch for both rounds, closed by the second round's solve kernel.
+  const bool decoupled = overlap && ctx->decouple && nch == 1;
+  // (A queue and a solve_slow_kernel launch per round, as ever: ONE kernel for both rounds would wait for end markers from
+  // kernels submitted after it -- the first accept, the second round's solves -- and where two of the pass's streams share
+  // a hardware queue, the default with the runtime's 4, those sit behind it in that queue: 250 ms, then the chunked redo.
+  // The second round parks into the upper half of the record buffer, its kernel follows the first round's on their stream.)
+  SlowRec *const slow_base = da.slow;
+  const uint32_t slow_cap_all = da.slow_cap;
+  da.slow_crowd_stays = ctx->crowd_stays_first;
+  if (decoupled) { da.slow_indirect = 1; da.slow_cap = slow_cap_all / 2u > (uint32_t)ctx->num_cu ? slow_cap_all / 2u - (uint32_t)ctx->num_cu : 0u; }      // (its end markers stay below the upper half)
   const unsigned b_threads = live ? 192u : 256u;
   unsigned b_blocks;
   {
@@ -1362,6 +1403,10 @@ static int redistribute_streamed(lentil_hip_ctx *ctx, bool *streamed) {
     uint64_t b = (uint64_t)ctx->num_cu * (uint64_t)b_per_cu;
     if (want < b) b = want < 1 ? 1 : want;
     b_blocks = (unsigned)b;
+    // (Measured, round 3: with the straggler kernel's wave on one of a CU's SIMDs the three-wave blocks of this launch are
+    // not placed before the first launch's blocks leave -- zero iterations in every pass looked at; the launch then only
+    // stands between the first launch's end and the accept.)
+    if (live && !ctx->solve_b) b_blocks = 0;
   }
   da.slow_live = live ? 1 : 0;
   da.slow_waves = live ? (uint32_t)ctx->num_cu : 0u;
@@ -1386,28 +1431,22 @@ static int redistribute_streamed(lentil_hip_ctx *ctx, bool *streamed) {
 
   // B: the rest of the CUs' room, once the scan's waves have left
   da.instance = 1;
-  launch_solve_po<true>(ctx, da, ctx->stream, b_blocks, b_threads);
+  if (b_blocks) launch_solve_po<true>(ctx, da, ctx->stream, b_blocks, b_threads);
   HIP_TRY(ctx, hipGetLastError());
   HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ch.done, 0));
   HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->pub_done, 0));
-  if (live) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_slow, 0));
-  else launch_slow(ctx, da, ctx->stream);
+  if (live && !decoupled) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_slow, 0));
+  else if (!live) launch_slow(ctx, da, ctx->stream);
   const uint64_t acc_max = (uint64_t)ctx->num_cu * (uint64_t)(ctx->accept_stream_blocks < 1 ? 1 : ctx->accept_stream_blocks);
   const uint64_t acc_want = ctx->est_items_total + ctx->est_items_total / 4 + 1;
   const unsigned accept_blocks = (unsigned)(acc_want > acc_max ? acc_max : acc_want);
-  int blind_rounds = ctx->est_rounds_total < 2 ? 2 : (ctx->est_rounds_total > 6 ? 6 : ctx->est_rounds_total);
-  if (const char *e = getenv("LENTIL_BLIND_ROUNDS")) { blind_rounds = atoi(e); if (blind_rounds < 1) blind_rounds = 1; if (blind_rounds > 8) blind_rounds = 8; }
-  // Second round beside the first accept: the accept kernel hands out the next round's tasks as it goes (tagged slots,
-  // end markers from its last block), a kStream solve kernel -- one block per CU, which fits beside four accept blocks
-  // -- takes them as they come, the straggler kernel beside both.  Launched AFTER the accept, so that a profiler that
-  // serialises kernels runs them in an order that completes.
-  const bool overlap = live && ctx->overlap_rounds && blind_rounds >= 2;
   {
     DrawArgs d0 = da;
     d0.emit_live = overlap ? 1 : 0;
     d0.end_tasks = (uint32_t)ctx->num_cu * 4u;
     if (overlap) HIP_TRY(ctx, hipEventRecord(ctx->ev_round, ctx->stream));      // everything the first accept waits for
-    hipLaunchKernelGGL(accept_kernel, dim3(accept_blocks), dim3(256), 0, ctx->stream, d0);
+    if (decoupled) hipLaunchKernelGGL(accept_kernel<1>, dim3(accept_blocks), dim3(256), 0, ctx->stream, d0);
+    else hipLaunchKernelGGL(accept_kernel<0>, dim3(accept_blocks), dim3(256), 0, ctx->stream, d0);
     HIP_TRY(ctx, hipGetLastError());
   }
   // The frame's resolve, first half: behind the first accept, beside the second round's solves (one block per CU, no
@@ -1432,6 +1471,8 @@ static int redistribute_streamed(lentil_hip_ctx *ctx, bool *streamed) {
         d1.no_reset = 1;
         d1.producers_done = &ctx->d_ctr->accept_done[0];
         d1.producers_total = accept_blocks;
+        d1.slow_crowd_stays = ctx->crowd_stays_later;
+        if (decoupled) { d1.slow_indirect = 0; d1.slow = slow_base + slow_cap_all / 2u; d1.slow_cap = slow_cap_all - slow_cap_all / 2u - d1.slow_waves; }
         HIP_TRY(ctx, hipStreamWaitEvent(ch.stream, ctx->ev_round, 0));
         launch_solve_po<true>(ctx, d1, ch.stream, (unsigned)ctx->num_cu);
         HIP_TRY(ctx, hipGetLastError());
@@ -1440,10 +1481,10 @@ static int redistribute_streamed(lentil_hip_ctx *ctx, bool *streamed) {
         hipLaunchKernelGGL(solve_slow_kernel, dim3(d1.slow_waves), dim3(64), 0, ctx->pub_stream, d1);
         HIP_TRY(ctx, hipEventRecord(ctx->ev_slow, ctx->pub_stream));
         HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ch.done, 0));
-        HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_slow, 0));
+        HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_slow, 0));      // (decoupled: behind the first round's straggler kernel too)
         // (the first accept and this round's solves are done: the first round's queues can go back to empty for what
         // the accept below schedules)
-        hipLaunchKernelGGL(reset_round_kernel, dim3(1), dim3(1), 0, ctx->stream, ctx->d_ctr, 0u);
+        hipLaunchKernelGGL(reset_round_kernel, dim3(1), dim3(1), 0, ctx->stream, ctx->d_ctr, 0u, decoupled ? 1u : 0u);
       } else {
         da.producers_done = nullptr; da.producers_total = 0;
         HIP_TRY(ctx, hipEventRecord(ctx->ev_round, ctx->stream));
@@ -1456,9 +1497,12 @@ static int redistribute_streamed(lentil_hip_ctx *ctx, bool *streamed) {
     } else {
       launch_solve(ctx, da, ctx->stream, (unsigned)ctx->num_cu);
     }
-    hipLaunchKernelGGL(accept_kernel, dim3(accept_blocks), dim3(256), 0, ctx->stream, da);
+    if (decoupled && round == 1) hipLaunchKernelGGL(accept_kernel<2>, dim3(accept_blocks), dim3(256), 0, ctx->stream, da);
+    else hipLaunchKernelGGL(accept_kernel<0>, dim3(accept_blocks), dim3(256), 0, ctx->stream, da);
     HIP_TRY(ctx, hipGetLastError());
+    if (decoupled && round == 1) { da.slow_indirect = 0; da.slow_cap = slow_cap_all; }
   }
+  da.slow_indirect = 0; da.slow_cap = slow_cap_all;
   da.slow_live = 0;       // (rounds the host adds one by one, below, park and finish their stragglers the plain way)
   if (ctx->early_resolve_pending) {
     // the resolve's second half behind the last accept enqueued blind (should the host have to add rounds, or redo
@@ -1489,6 +1533,10 @@ static int redistribute_streamed(lentil_hip_ctx *ctx, bool *streamed) {
       (void)hipEventElapsedTime(&ms_all, ctx->ev[0], ctx->ev[2]);
       fprintf(stderr, "[stream] scan %.3f ms, pass until the read-back %.3f ms\n", ms_scan, ms_all);
     }
+    if (getenv("LENTIL_STREAM_DEBUG"))
+      fprintf(stderr, "[stream] queues: n_tasks %u/%u task_head %u/%u n_active %u/%u active_head %u/%u accept_done %u/%u pool_used %llu/%llu\n",
+              c.n_tasks[0], c.n_tasks[1], c.task_head[0], c.task_head[1], c.n_active[0], c.n_active[1], c.active_head[0], c.active_head[1],
+              c.accept_done[0], c.accept_done[1], c.pool_used[0], c.pool_used[1]);
     if (getenv("LENTIL_STREAM_DEBUG"))
       fprintf(stderr, "[stream] stragglers: live %d waves_done %u/%u (round 1: %u) parked %u/%u heads %u/%u cap %u waves %u rounds_used %llu\n", (int)live,
               c.waves_done[0], c.waves_started[0], c.waves_done[1], c.n_slow[0], c.n_slow[1], c.slow_head[0], c.slow_head[1],
@@ -2471,3 +2519,19 @@ LENTIL_API int lentil_hip_test_aperture_sample(lentil_hip_ctx *ctx, uint64_t n, 
 #include "lentil_upload.h"
 #include "lentil_comm.h"
 #include "lentil_crypto.h"
+
+#ifdef LENTIL_TIMELINE
+// development aid (tools/timeline.py): copies the event histogram out and clears it
+LENTIL_API int lentil_hip_debug_timeline(unsigned int *out, int reset) {
+  if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_timeline), sizeof(unsigned int) * kTlSub * kTlChannels * kTlBuckets) != hipSuccess) return LENTIL_ERR_HIP;
+  if (out && hipMemcpyFromSymbol(out + kTlSub * kTlChannels * kTlBuckets, HIP_SYMBOL(g_dbg), sizeof(unsigned long long) * 32) != hipSuccess) return LENTIL_ERR_HIP;
+  if (reset) {
+    void *q = nullptr;
+    if (hipGetSymbolAddress(&q, HIP_SYMBOL(g_dbg)) != hipSuccess || hipMemset(q, 0, sizeof(unsigned long long) * 32) != hipSuccess) return LENTIL_ERR_HIP;
+    void *p = nullptr;
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_timeline)) != hipSuccess) return LENTIL_ERR_HIP;
+    if (hipMemset(p, 0, sizeof(unsigned int) * kTlSub * kTlChannels * kTlBuckets) != hipSuccess) return LENTIL_ERR_HIP;
+  }
+  return LENTIL_OK;
+}
+#endif

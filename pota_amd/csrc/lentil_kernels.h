@@ -139,14 +139,20 @@ struct ItemHdr {          // written by prep_items_kernel / publish_item; a 128-
   uint32_t pad[24];
 };
 
-struct ItemProg {         // 32 B, progress of an item across rounds
+struct ItemProg {         // 48 B, progress of an item across rounds
   uint32_t n_done;        // attempts resolved so far (all earlier attempts are final)
   uint32_t accepted;
-  uint32_t m_lo, m_hi;    // R(m) of the current round covers [m_lo, m_hi); any R(m < m_lo) still needed is FAIL
+  uint32_t m_lo, m_hi;    // R(m) of the current round covers [m_lo, m_hi); any R(m < m_lo) still needed is FAIL ...
   uint32_t res_off;       // offset of R(m_lo) in the current round's result pool
   uint32_t last_ok;       // highest accepted attempt index
   uint32_t splats;        // chromatic mode: accepted (attempt, channel) pairs so far
-  uint32_t pad1;
+  // ... unless it lies in [p_lo, p_hi): the batch before, at p_off in the OTHER parity's pool.  Only an item whose first
+  // accept ran while some of its solves were still parked (uacc > 0 of them were met; accept_item<1>) carries one: the
+  // accept behind it (accept_item<2>) walks the item again from attempt 0, knows from n_end1 and the pending marks
+  // which draws the first one has added already, and adds the rest.
+  uint32_t uacc;
+  uint32_t p_lo, p_hi, p_off;
+  uint32_t n_end1;        // attempts the first accept looked at
 };
 
 struct Task {             // up to 64 consecutive m of one item (and one wavelength channel)
@@ -250,6 +256,25 @@ LD_DEV float4 nt_load(const float4 *p) {
 
 LD_DEV uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 
+// Development aid (-DLENTIL_TIMELINE, tools/timeline.py; never in the shipped build): what the kernels of a pass do
+// when -- events counted into 20 us buckets of the chip-wide 100 MHz counter.  One lane of a wave calls tl_add.
+#ifdef LENTIL_TIMELINE
+constexpr int kTlChannels = 10, kTlBuckets = 1024, kTlSub = 64;
+// (every bucket exists kTlSub times, 40 KB apart, chosen by block: thousands of atomics per microsecond on ONE word
+// throttle the kernels that issue them -- the first version of this slowed the scan from 1.1 to 4 ms)
+__device__ unsigned int g_timeline[kTlSub][kTlChannels][kTlBuckets];
+LD_DEV void tl_add(int ch, uint32_t n) {
+  if (n) atomicAdd(&g_timeline[(blockIdx.x * 4u + (threadIdx.x >> 6)) & (kTlSub - 1)][ch][(uint32_t)(__builtin_amdgcn_s_memrealtime() >> 11) & (kTlBuckets - 1)], n);
+}
+__device__ unsigned long long g_dbg[32];       // plain event counts (tools/timeline.py prints them)
+LD_DEV void dbg_add(int i, unsigned long long n) { atomicAdd(&g_dbg[i], n); }
+#else
+LD_DEV void tl_add(int, uint32_t) {}
+LD_DEV void dbg_add(int, unsigned long long) {}
+#endif
+enum { TL_SCAN_TILES = 0, TL_TASKS_PUBLISHED, TL_ITERS_A, TL_ITERS_B, TL_ITERS_LATER, TL_ITERS_SLOW, TL_ITEMS_ACCEPTED,
+       TL_POLLS_EMPTY, TL_TASKS_TAKEN, TL_PARKED };
+
 struct ItemVisit {
   uint32_t visit, samples;
   int px, py;
@@ -341,6 +366,7 @@ LD_DEV void publish_item(const lentil_params &P, const VisitsDev &V, const Strea
                    ((uint64_t)(n | (c << 8) | (S.epoch << kTaskTagShift)) << 32));
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  tl_add(TL_TASKS_PUBLISHED, nt * nch);
 }
 
 // K2: wave-ballot + prefix-sum compaction of flagged lanes into the work list.  Each wave collects
@@ -774,6 +800,7 @@ __global__ __launch_bounds__(256) void scan_dma_kernel(ScanArgs a) {
       __builtin_amdgcn_wave_barrier();
       wq.end_tile(a);
     }
+    if (lane == 0) tl_add(TL_SCAN_TILES, (uint32_t)(tile4_end - tile4));
   }
   wq.finish(a);
   scan_block_done(a);
@@ -1080,6 +1107,11 @@ __global__ __launch_bounds__(64) void publish_kernel(PublishArgs a) {
 constexpr int kMaxBokehRows = 2048;
 constexpr uint32_t kCodeFail = 0xFFFFFFFFu;
 constexpr uint32_t kCodeOut = 0xFFFFFFFEu;
+// R(m) of a solve that was parked for solve_slow_kernel while the first accept of the pass may already run
+// (DrawArgs::slow_indirect): 0xFE000000 | slot in the straggler queue; the straggler's result goes to the queue
+// record (SlowRec::result), the mark stays.  Pixel indices are below 0xFE000000 (lentil_hip_alloc_frame checks).
+constexpr uint32_t kCodePendingBase = 0xFE000000u;
+LD_DEV bool code_is_pending(uint32_t c) { return (c & 0xFF000000u) == kCodePendingBase; }
 
 // A solve that is still running after `slow_at` Newton iterations (about one in a thousand) is parked here by
 // solve_po_kernel and finished by solve_slow_kernel, a whole wave per solve: the complete loop state, so that
@@ -1088,10 +1120,12 @@ struct SlowRec {           // 128 B
   double tx, ty, tz, ap_x, ap_y;
   double x, y, dx, dy, sqr_err, sqr_ap_err;
   int32_t k, error;
-  uint32_t res_idx, chan;
-  uint32_t pad[4];
+  uint32_t res_idx, chan;  // chan: bits 0-1 wavelength channel, bit 8 parity of the result pool, bit 9 result goes to `result` (pending mark in the pool)
+  uint32_t result;         // slow_indirect: R(m) once the straggler is through
+  uint32_t pad[3];
   uint64_t tag;            // live queue (DrawArgs::slow_live): (pass epoch << 8 | round) << 32 | 1 record, 2 end marker
 };
+constexpr uint32_t kSlowParBit = 1u << 8, kSlowIndirectBit = 1u << 9;
 static_assert(sizeof(SlowRec) == 128, "SlowRec is 128 bytes");
 constexpr uint64_t kSlowRecord = 1, kSlowEnd = 2;
 
@@ -1156,8 +1190,21 @@ struct DrawArgs {
   int32_t emit_live;
   uint32_t end_tasks;
   int32_t no_reset;        // solve kernel: leave the other parity's queues alone (the accept beside it is using them)
+  // Decoupled streamed pass: ONE straggler queue and one solve_slow_kernel launch serve the first round and the second
+  // (which runs beside the first accept): both rounds' solve kernels park into counter set `slow_q` under round tag
+  // `slow_round`, only the launch with slow_close set closes the queue, and the first round parks `slow_indirect`:
+  // the first accept does not wait for the stragglers (accept_item<1>).  Defaults (-1, -1, 1, 0): a queue per round.
+  int32_t slow_q, slow_round, slow_close, slow_indirect;
+  int32_t slow_crowd_stays;   // live queue: where more than slow_max_lanes lanes of a wave are past slow_at at once, none is parked
 };
-LD_DEV uint64_t slow_tag(const DrawArgs &a, uint64_t what) { return ((uint64_t)((a.epoch << 8) | ((uint32_t)a.round & 0xFFu)) << 32) | what; }
+LD_DEV uint32_t slow_queue(const DrawArgs &a) { return a.slow_q >= 0 ? (uint32_t)a.slow_q : (uint32_t)a.parity; }
+LD_DEV uint64_t slow_tag(const DrawArgs &a, uint64_t what) {
+  const uint32_t r = a.slow_round >= 0 ? (uint32_t)a.slow_round : (uint32_t)a.round;
+  return ((uint64_t)((a.epoch << 8) | (r & 0xFFu)) << 32) | what;
+}
+LD_DEV void st_agent32(void *p, uint32_t v) {
+  (void)__hip_atomic_exchange(reinterpret_cast<uint32_t *>(p), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 
 LD_DEV ItemVisit load_item_visit(const DrawArgs &a, uint32_t item, double lens_length) {
   return load_work_visit(a.P, a.V, a.work[item], lens_length);
@@ -1207,7 +1254,13 @@ LD_DEV void reset_round(DevCounters *c, uint32_t par) {
   c->pool_used[par] = 0;
   c->n_slow[par] = 0; c->slow_head[par] = 0; c->waves_done[par] = 0; c->waves_started[par] = 0; c->accept_done[par] = 0;
 }
-__global__ void reset_round_kernel(DevCounters *c, uint32_t par) { reset_round(c, par); }
+// keep_pool: items of the accept that follows still read results out of this parity's pool (ItemProg::p_lo) while that
+// accept allocates the next batch's results in it: go on behind them
+__global__ void reset_round_kernel(DevCounters *c, uint32_t par, uint32_t keep_pool) {
+  const unsigned long long used = c->pool_used[par];
+  reset_round(c, par);
+  if (keep_pool) c->pool_used[par] = used;
+}
 
 // one thread per item: header + first batch R(0 .. samples-1+retries)
 __global__ __launch_bounds__(256) void prep_items_kernel(DrawArgs a) {
@@ -1356,6 +1409,7 @@ __global__ __launch_bounds__(256) void solve_po_kernel(DrawArgs a) {
           if (lane == 0) w1 = ld_coherent64(reinterpret_cast<const uint64_t *>(tasks + ticket) + 1);
           const uint32_t w1_hi = __builtin_amdgcn_readfirstlane((uint32_t)(w1 >> 32));
           if ((w1_hi >> kTaskTagShift) != a.epoch) {
+            if (lane == 0) tl_add(TL_POLLS_EMPTY, 1u);
             // nothing there (yet): back to the solves in flight (an idle wave naps, below)
             if (__builtin_amdgcn_s_memrealtime() - ticket_t0 > kStuckTicks) {
               if (lane == 0) atomicCAS(&a.ctr->stuck, 0u, 2u | (ticket << 2));      // the host redoes the pass chunk by chunk
@@ -1372,6 +1426,7 @@ __global__ __launch_bounds__(256) void solve_po_kernel(DrawArgs a) {
           cur_left = w1_hi & 0xFFu;
           if (kChroma) cur_chan = (w1_hi >> 8) & 3u;
           ticket = kNoTicket;
+          if (lane == 0) tl_add(TL_TASKS_TAKEN, 1u);
           if (cur_left) {
             // the item's header, written by a publisher on another CU while this kernel runs: lane 0 fetches it with
             // atomics and parks it in the wave's LDS slot, where the lanes that take solves of this task pick it up
@@ -1442,6 +1497,9 @@ __global__ __launch_bounds__(256) void solve_po_kernel(DrawArgs a) {
     }
     if (busy) { newton_iter(L, target, ap_x, ap_y, s); ++st_iters; }
     ++st_rounds;
+#ifdef LENTIL_TIMELINE
+    { const uint32_t nb_ = (uint32_t)__builtin_popcountll(__ballot(busy)); if (lane == 0) tl_add(!kStream || a.round ? TL_ITERS_LATER : (a.instance ? TL_ITERS_B : TL_ITERS_A), nb_); }
+#endif
 
     if (busy && !newton_continue(s)) {
       res[res_idx] = solve_result(P, L, s);
@@ -1457,14 +1515,24 @@ __global__ __launch_bounds__(256) void solve_po_kernel(DrawArgs a) {
     // spends a wave on each (config 4: 17.5 ms per frame with that, 3 ms of it per solve_slow_kernel launch).
     if (parking && (a.slow_live || (no_more && __builtin_popcountll(__ballot(busy)) <= a.slow_max_lanes))) {
       const bool park = busy && s.k >= a.slow_at;
-      const unsigned long long pmask = __ballot(park);
+      unsigned long long pmask = __ballot(park);
+      // Live queue: outliers only.  Where many lanes of a wave are past slow_at at once it is not a straggler but the item:
+      // near the frame's edge, where the lens vignettes, a third of an item's solves run 20-40 iterations before they
+      // raise an error bit (2 700 of a headline frame's solves -- in ten of its 1 100 items; 83 % of them fail).  Parked,
+      // they swamp the 256 straggler waves and leave half of such an item's attempts unknown to the first accept; in
+      // their lanes they cost the wave a few iterations more.  The crowd thins out by itself, what stays is parked.
+      if (a.slow_live && a.slow_crowd_stays && __builtin_popcountll(pmask) > a.slow_max_lanes) pmask = 0ull;
       if (pmask) {
+        const uint32_t sq = slow_queue(a);
         uint32_t base = 0;
-        if (lane == (uint32_t)__builtin_ctzll(pmask)) base = atomicAdd(&a.ctr->n_slow[par], (uint32_t)__builtin_popcountll(pmask));
+        if (lane == (uint32_t)__builtin_ctzll(pmask)) base = atomicAdd(&a.ctr->n_slow[sq], (uint32_t)__builtin_popcountll(pmask));
         base = __shfl(base, __builtin_ctzll(pmask));
         const uint32_t slot = base + (uint32_t)__builtin_popcountll(pmask & lt_mask);
-        if (park && slot < a.slow_cap) {       // a full queue leaves the solve where it is
+        if (park && pmask && slot < a.slow_cap) {       // a full queue leaves the solve where it is
+          tl_add(TL_PARKED, 1u);
           double *d = reinterpret_cast<double *>(a.slow + slot);
+          const uint32_t chan_word = (kChroma ? cur_chan_lane : 0u) | (par ? kSlowParBit : 0u) |
+                                     ((a.slow_live && a.slow_indirect) ? kSlowIndirectBit : 0u);
           if (a.slow_live) {
             // read by a wave of solve_slow_kernel on another CU while both kernels run: atomics on both sides, the
             // payload waited for before the word that publishes it
@@ -1472,21 +1540,24 @@ __global__ __launch_bounds__(256) void solve_po_kernel(DrawArgs a) {
 #pragma unroll
             for (int i = 0; i < 11; ++i) st_agent64(d + i, (uint64_t)__double_as_longlong(pay[i]));
             st_agent64(d + 11, (uint64_t)(uint32_t)s.k | ((uint64_t)(uint32_t)s.error << 32));
-            st_agent64(d + 12, (uint64_t)res_idx | ((uint64_t)(kChroma ? cur_chan_lane : 0u) << 32));
+            st_agent64(d + 12, (uint64_t)res_idx | ((uint64_t)chan_word << 32));
+            // the first accept may look at this result before the straggler is through: it finds the mark (and, behind
+            // it, where the result will be); the straggler's result never overwrites it
+            if (a.slow_indirect) st_agent32(res + res_idx, kCodePendingBase | slot);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             st_agent64(d + 15, slow_tag(a, kSlowRecord));
           } else {
             d[0] = target[0]; d[1] = target[1]; d[2] = target[2]; d[3] = ap_x; d[4] = ap_y;
             d[5] = s.x; d[6] = s.y; d[7] = s.dx; d[8] = s.dy; d[9] = s.sqr_err; d[10] = s.sqr_ap_err;
             uint32_t *u = reinterpret_cast<uint32_t *>(d + 11);
-            u[0] = (uint32_t)s.k; u[1] = (uint32_t)s.error; u[2] = res_idx; u[3] = kChroma ? cur_chan_lane : 0u;
+            u[0] = (uint32_t)s.k; u[1] = (uint32_t)s.error; u[2] = res_idx; u[3] = chan_word;
           }
           busy = false;
         }
       }
     }
   }
-  if (a.slow_live && a.slow) {
+  if (a.slow_live && a.slow && a.slow_close) {
     // Everything this wave parked has arrived.  The straggler queue is closed by whichever wave finds, on leaving, that
     // every wave that has begun has left and every task has been taken (and, streamed, published): no solve can be
     // parked any more.  Waves of a launch that begin later -- blocks that had to wait for room, perhaps for the very
@@ -1503,7 +1574,7 @@ __global__ __launch_bounds__(256) void solve_po_kernel(DrawArgs a) {
       close = (done == begun && complete && taken >= published) ? 1u : 0u;
     }
     if (__builtin_amdgcn_readfirstlane(close)) {
-      uint32_t n = ld_coherent32(&a.ctr->n_slow[par]);
+      uint32_t n = ld_coherent32(&a.ctr->n_slow[slow_queue(a)]);
       if (n > a.slow_cap) n = a.slow_cap;
       for (uint32_t i = lane; i < a.slow_waves; i += 64u)
         st_agent64(reinterpret_cast<double *>(a.slow + n + i) + 15, slow_tag(a, kSlowEnd));      // (the queue holds slow_cap + slow_waves records)
@@ -1624,8 +1695,8 @@ struct CoopLens {
 __global__ __launch_bounds__(64) void solve_slow_kernel(DrawArgs a) {
   __shared__ CoopShared sh;
   __shared__ uint32_t s_q;
-  const uint32_t par = (uint32_t)a.parity;
-  uint32_t n_slow = a.slow_live ? 0xFFFFFFFFu : a.ctr->n_slow[par];
+  const uint32_t par = (uint32_t)a.parity, sq = slow_queue(a);
+  uint32_t n_slow = a.slow_live ? 0xFFFFFFFFu : a.ctr->n_slow[sq];
   if (!a.slow_live) {
     if (n_slow > a.slow_cap) n_slow = a.slow_cap;
     if (n_slow == 0u || blockIdx.x >= n_slow) return;
@@ -1670,7 +1741,7 @@ __global__ __launch_bounds__(64) void solve_slow_kernel(DrawArgs a) {
   unsigned long long iters = 0, solves = 0;
   while (true) {
     __syncthreads();
-    if (lane == 0) s_q = atomicAdd(&a.ctr->slow_head[par], 1u);
+    if (lane == 0) s_q = atomicAdd(&a.ctr->slow_head[sq], 1u);
     __syncthreads();
     const uint32_t q = s_q;
     if (q >= n_slow) break;
@@ -1706,7 +1777,7 @@ __global__ __launch_bounds__(64) void solve_slow_kernel(DrawArgs a) {
     } else {
       r = a.slow[q];
     }
-    L.lp = sh.lambda_pow[r.chan < 3u ? r.chan : 0u];
+    L.lp = sh.lambda_pow[(r.chan & 3u) < 3u ? (r.chan & 3u) : 0u];
     const double target[3] = {r.tx, r.ty, r.tz};
     NewtonState s;
     s.x = r.x; s.y = r.y; s.dx = r.dx; s.dy = r.dy;
@@ -1717,9 +1788,16 @@ __global__ __launch_bounds__(64) void solve_slow_kernel(DrawArgs a) {
     while (__builtin_amdgcn_readfirstlane((int)newton_continue(s))) {
       newton_iter(L, target, r.ap_x, r.ap_y, s);
       ++iters;
+      if (lane == 0) tl_add(TL_ITERS_SLOW, 1u);
     }
     const uint32_t code = solve_result(a.P, L, s);
-    if (lane == 0) a.pool[par][r.res_idx] = code;
+    if (lane == 0) dbg_add(code < kCodePendingBase ? 0 : (code == kCodeOut ? 1 : 2), 1);        // stragglers: pixel / out / fail
+    if (lane == 0) dbg_add(3 + (s.k >= 100 ? 1 : 0), 1);                                          // ... ended before / at 100 iterations
+    if (lane == 0) {
+      // (the record says which pool: one queue may serve two rounds, DrawArgs::slow_q)
+      if (r.chan & kSlowIndirectBit) st_agent32(&a.slow[q].result, code);
+      else a.pool[a.slow_live ? ((r.chan & kSlowParBit) ? 1u : 0u) : par][r.res_idx] = code;
+    }
     ++solves;
   }
   if (lane == 0) {
@@ -1773,7 +1851,10 @@ struct AcceptShared {
   float val[4 * LENTIL_MAX_AOVS + 1];      // what one accepted draw of the item adds, float by float
   uint32_t off[4 * LENTIL_MAX_AOVS + 1];   // ... and where inside the pixel record
   uint32_t rwin[3][256 + 64];              // R(n .. n + 255 + retries) of the step, per wavelength channel (stage_results)
+  uint32_t nunk[4], nsucc1[4];             // accept_item<1, 2>: unknown attempts / mode 1's known successes per wave
 };
+// accept_item<1>: an attempt that met a pending mark is no success (yet); modes 0 and 2 have resolved it
+template <int kMode> LD_DEV bool unk_blocks(bool unk) { return kMode == 1 && unk; }
 
 // The results a 256-attempt step looks at, R(n .. n + 255 + retries), fetched by the block with one round of
 // coalesced loads into LDS.  Every attempt then walks its tries there.  (Walking them in global memory is a chain of
@@ -1822,11 +1903,34 @@ LD_DEV void count_same_pixel(const uint32_t *pix, uint32_t *cnt, uint32_t T, uin
   }
 }
 
+// R(m) as the accept of an item finds it: the current batch in `res`, the batch before -- if the item carries one
+// (ItemProg::p_lo) -- in the other parity's pool, FAIL below that, "beyond" above.
+LD_DEV uint32_t result_at2(const uint32_t *res, const uint32_t *res_prev, const ItemProg &pg, uint32_t m) {
+  if (m >= pg.m_hi) return kCodeBeyond;
+  if (m >= pg.m_lo) return res[pg.res_off + (m - pg.m_lo)];
+  if (m >= pg.p_lo && m < pg.p_hi) return res_prev[pg.p_off + (m - pg.p_lo)];
+  return kCodeFail;
+}
+
 // Processes the current result batch of `item` (block-cooperative; must be called by all 256 threads).
 // dry: the walk without its effects -- nothing is splatted, logged or flagged; the result (how far the batch got, whether
 // and how many more attempts are needed) is what the real walk will find.
+//
+// kMode 0: every R(m) the walk meets is final.
+// kMode 1: the first accept of a streamed pass that does not wait for the parked solves of its round (the slowest of them
+//   takes another 0.3 ms, and nearly every item has one).  A parked solve's R(m) is a *pending mark*; an attempt whose
+//   tries reach one before a result that ends them is UNKNOWN.  With s known successes and u unknown attempts before it,
+//   a known success is among the first S successes whatever the unknowns turn out to be iff s + u < S (S = samples):
+//   those are splatted now -- all but a handful per item.  Draws still missing are counted as if every unknown attempt
+//   failed, and the next batch is scheduled from that (a surplus is never accepted).  An item that met an unknown is
+//   handed to the next accept whole.
+// kMode 2: that next accept (the stragglers are through; their results sit in the queue records behind the marks).  It
+//   walks such an item again from attempt 0 with the final results, replays beside it what mode 1 saw (the marks are
+//   still there, ItemProg::n_end1 says how far it looked), and splats the accepted draws mode 1 did not.  What mode 1
+//   splatted is a subset of the final set: a known success with s + u < S has final rank <= s + u.
+template <int kMode>
 LD_DEV AcceptResult accept_item(const DrawArgs &a, AcceptShared &sh, uint32_t item, const ItemProg pg, const uint32_t *res,
-                                uint32_t &rmin, uint32_t &rmax_p1, bool dry = false) {
+                                const uint32_t *res_prev, uint32_t &rmin, uint32_t &rmax_p1, bool dry = false) {
   uint32_t *s_first_u = sh.first_u, *s_nsucc = sh.nsucc, *s_top = sh.top;
   uint32_t(*s_pix)[64] = sh.pix;
   float *s_val = sh.val;
@@ -1855,7 +1959,11 @@ LD_DEV AcceptResult accept_item(const DrawArgs &a, AcceptShared &sh, uint32_t it
     }
     if (threadIdx.x == 0) { s_val[U - 1] = w; s_off[U - 1] = 4u * a.F.n_aovs; }
     __syncthreads();
+    // mode 2 starts an item that carries unknowns over: its walk is the whole walk
+    const bool replay = kMode == 2 && pg.uacc != 0u;
     uint32_t n = pg.n_done, acc = pg.accepted, last_ok = pg.last_ok;
+    uint32_t uacc = 0;               // mode 1: unknown attempts so far; mode 2: the same, replayed
+    uint32_t acc1 = 0;               // mode 2: known successes mode 1 counted so far
     bool stalled = false;
     // the window of a step is requested a step ahead (entries threadIdx.x and 256 + threadIdx.x), before the splat
     // atomics of the step in between: loads return in order with them, so a load issued behind 1 280 atomics waits
@@ -1863,31 +1971,38 @@ LD_DEV AcceptResult accept_item(const DrawArgs &a, AcceptShared &sh, uint32_t it
     const bool win = retries <= kAcceptWinRetries;
     uint32_t pre0 = kCodeBeyond, pre1 = kCodeBeyond;
     if (win) {
-      pre0 = result_at(res, pg, pg.res_off, n + threadIdx.x);
-      if (threadIdx.x < retries) pre1 = result_at(res, pg, pg.res_off, n + 256u + threadIdx.x);
+      pre0 = result_at2(res, res_prev, pg, n + threadIdx.x);
+      if (threadIdx.x < retries) pre1 = result_at2(res, res_prev, pg, n + 256u + threadIdx.x);
     }
     while (!stalled && acc < S && n < max_total) {
       const uint32_t my_i = wave * 64u + lane;              // position inside this 256-attempt step
       const uint32_t my_n = n + my_i;
       const bool valid = my_n < max_total;
-      uint32_t code = kCodeFail;
-      bool unresolved = false;
+      uint32_t code = kCodeFail;       // what ends the attempt (mode 1: as far as known)
+      uint32_t code1 = kCodeFail;      // mode 2: what mode 1 knew
+      bool unresolved = false, unk = false, seen1 = false;
+      (void)code1; (void)seen1;
       if (win) {
         sh.rwin[0][threadIdx.x] = pre0;
         if (threadIdx.x < retries) sh.rwin[0][256u + threadIdx.x] = pre1;
         block_sync_lds();
-        if (valid) {
-          for (uint32_t t = 0; t <= retries; ++t) {
-            const uint32_t c = sh.rwin[0][my_i + t];
-            if (c == kCodeBeyond) { unresolved = (pg.m_hi < m_limit); break; }
-            if (c != kCodeFail) { code = c; break; }
-          }
-        }
-      } else if (valid) {
+      }
+      if (valid) {
         for (uint32_t t = 0; t <= retries; ++t) {
-          const uint32_t m = my_n + t;
-          if (m >= pg.m_hi) { unresolved = (pg.m_hi < m_limit); break; }
-          const uint32_t c = (m < pg.m_lo) ? kCodeFail : res[pg.res_off + (m - pg.m_lo)];
+          uint32_t c = win ? sh.rwin[0][my_i + t] : result_at2(res, res_prev, pg, my_n + t);
+          if (c == kCodeBeyond) { unresolved = (pg.m_hi < m_limit); break; }
+          if (code_is_pending(c)) {
+            if (kMode == 1) { unk = true; break; }
+            if (kMode == 2) {
+              if (!seen1) { unk = true; seen1 = true; }
+              c = a.slow[c & 0x00FFFFFFu].result;            // the straggler is through
+            } else {
+              atomicAdd(&a.ctr->overflow, 1ull);               // a mark nobody is going to resolve: the pass is void
+              c = kCodeFail;
+            }
+          } else if (kMode == 2 && !seen1 && c != kCodeFail) {
+            code1 = c; seen1 = true;
+          }
           if (c != kCodeFail) { code = c; break; }
         }
       }
@@ -1904,28 +2019,54 @@ LD_DEV AcceptResult accept_item(const DrawArgs &a, AcceptShared &sh, uint32_t it
         if (fu < limit) { limit = fu; stalled = true; }
       }
       if (win && !stalled) {
-        pre0 = result_at(res, pg, pg.res_off, n + limit + threadIdx.x);
-        if (threadIdx.x < retries) pre1 = result_at(res, pg, pg.res_off, n + limit + 256u + threadIdx.x);
+        pre0 = result_at2(res, res_prev, pg, n + limit + threadIdx.x);
+        if (threadIdx.x < retries) pre1 = result_at2(res, res_prev, pg, n + limit + 256u + threadIdx.x);
       }
-      const bool succ = my_i < limit && code < kCodeOut;
+      const bool succ = my_i < limit && !unk_blocks<kMode>(unk) && code < kCodePendingBase;
       const unsigned long long smask = __ballot(succ);
-      if (lane == 0) s_nsucc[wave] = (uint32_t)__builtin_popcountll(smask);
+      // mode 1: the unknown attempts; mode 2: the same and mode 1's known successes, as far as mode 1 looked
+      const bool was1 = kMode == 2 && replay && my_n < pg.n_end1 && my_i < limit;
+      const bool unk1 = kMode == 1 ? (my_i < limit && unk) : (was1 && unk);
+      const bool succ1 = was1 && !unk && code1 < kCodePendingBase;
+      const unsigned long long u1mask = kMode != 0 ? __ballot(unk1) : 0ull;
+      const unsigned long long s1mask = kMode == 2 ? __ballot(succ1) : 0ull;
+      if (lane == 0) {
+        s_nsucc[wave] = (uint32_t)__builtin_popcountll(smask);
+        if (kMode != 0) sh.nunk[wave] = (uint32_t)__builtin_popcountll(u1mask);
+        if (kMode == 2) sh.nsucc1[wave] = (uint32_t)__builtin_popcountll(s1mask);
+      }
       block_sync_lds();
-      uint32_t before = 0, total = 0;
-      for (uint32_t k = 0; k < 4; ++k) { if (k < wave) before += s_nsucc[k]; total += s_nsucc[k]; }
+      uint32_t before = 0, total = 0, ubefore = 0, utotal = 0, before1 = 0, total1 = 0;
+      for (uint32_t k = 0; k < 4; ++k) {
+        if (k < wave) before += s_nsucc[k];
+        total += s_nsucc[k];
+        if (kMode != 0) { if (k < wave) ubefore += sh.nunk[k]; utotal += sh.nunk[k]; }
+        if (kMode == 2) { if (k < wave) before1 += sh.nsucc1[k]; total1 += sh.nsucc1[k]; }
+      }
       const uint32_t rank = acc + before + (uint32_t)__builtin_popcountll(smask & lt_mask);
-      const bool take = succ && rank < S;
+      const bool take = succ && rank < S;              // mode 1: among the first S *known* successes
+      // what is splatted now
+      bool splat = take;
+      if (kMode == 1) {
+        const uint32_t ub = uacc + ubefore + (uint32_t)__builtin_popcountll(u1mask & lt_mask);
+        splat = take && rank + ub < S;
+      } else if (kMode == 2) {
+        const uint32_t ub = uacc + ubefore + (uint32_t)__builtin_popcountll(u1mask & lt_mask);
+        const uint32_t rank1 = acc1 + before1 + (uint32_t)__builtin_popcountll(s1mask & lt_mask);
+        splat = take && !(succ1 && rank1 + ub < S);    // mode 1 has added that one
+      }
       // Camera::add_to_buffer, src/lentil.h:827-830 -- transposed: the wave's accepted pixels go through
       // LDS, then lane q adds float (q % U) of accepted draw (q / U): consecutive lanes hit consecutive
       // floats of one pixel record.
       const unsigned long long tmask0 = __ballot(take);
-      const uint32_t T = (uint32_t)__builtin_popcountll(tmask0);
-      if (take && !dry) {
+      const unsigned long long pmask0 = __ballot(splat);
+      const uint32_t T = (uint32_t)__builtin_popcountll(pmask0);
+      if (splat && !dry) {
         const uint32_t pix = code;
         const uint32_t row = pix / a.P.xres;
         rmin = row < rmin ? row : rmin;
         rmax_p1 = row + 1u > rmax_p1 ? row + 1u : rmax_p1;
-        s_pix[wave][(uint32_t)__builtin_popcountll(tmask0 & lt_mask)] = pix;
+        s_pix[wave][(uint32_t)__builtin_popcountll(pmask0 & lt_mask)] = pix;
         if (a.F.touched) a.F.touched[pix >> 6] = a.round ? 2 : 1;      // (2: by a round after the first, see resolve_touched_kernel)
         if (a.F.zkey) atomicMin(a.F.zkey + pix, zk);
         if (a.F.zkey_dbg) atomicMin(a.F.zkey_dbg + pix, zk);      // value.r = samples != 0 for every draw
@@ -1961,12 +2102,15 @@ LD_DEV AcceptResult accept_item(const DrawArgs &a, AcceptShared &sh, uint32_t it
         last_ok = top;
         acc += taken;
       }
+      uacc += utotal;
+      if (kMode == 2) acc1 += total1;       // (mode 1 capped its count at S; beyond that rank1 >= S either way)
       n += limit;
     }
     AcceptResult r;
     r.samples = S;
     r.prog = pg;
     r.prog.n_done = n; r.prog.accepted = acc; r.prog.last_ok = last_ok;
+    r.prog.uacc = kMode == 1 ? uacc : 0u;
     r.more = acc < S && n < max_total && pg.m_hi < m_limit && pg.m_hi > 0;
     r.new_lo = pg.m_hi;
     r.new_hi = pg.m_hi;
@@ -2174,6 +2318,8 @@ LD_DEV AcceptResult accept_item_chroma(const DrawArgs &a, AcceptShared &sh, uint
 
 // (six waves per SIMD: beside four accept blocks per CU a SIMD then has room for a solve wave -- the next round's solves
 // run beside the accept that schedules them, DrawArgs::emit_live)
+// kMode: accept_item's -- 1 for the first accept of a decoupled streamed pass, 2 for the one behind it, 0 otherwise.
+template <int kMode>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) void accept_kernel(DrawArgs a) {
   __shared__ uint32_t s_item;
   __shared__ AcceptShared sh;
@@ -2181,33 +2327,71 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
   // (a streamed or blind pass whose buffers were too small: nothing is accepted, the host redoes the draws)
   const uint32_t n_active = (a.ctr->fallback || a.ctr->stuck) ? 0u : a.ctr->n_active[par];
   if (blockIdx.x == 0 && threadIdx.x == 0 && n_active) atomicMax(&a.ctr->rounds_used, (unsigned long long)(a.round + 1));
-  const uint32_t *res = a.pool[par];
+  const uint32_t *res = a.pool[par], *res_prev = a.pool[nxt];
   unsigned long long tot_attempted = 0, tot_accepted = 0;
   uint32_t rmin = 0x7FFFFFFFu, rmax_p1 = 0u;       // rows this thread's accepted draws went to
+  // The next round's solve kernel is waiting for tasks (emit_live): a block takes its share of the items at once, finds
+  // out what each of them still needs with a dry walk (a third of the real one's time: no splats) and hands those tasks
+  // out before it splats anything -- the last tasks leave ~0.06 ms into the kernel instead of ~0.15 ms.
+  constexpr uint32_t kGroup = 8;
+  __shared__ uint32_t s_emit_off[kGroup], s_emit_hi[kGroup], s_emitted[kGroup];
+  const bool chroma = a.n_channels == 3;
+  const bool dry_first = a.emit_live && !chroma;
+  uint32_t per = 1;
+  if (dry_first) { per = (n_active + gridDim.x - 1u) / gridDim.x; per = per < 1u ? 1u : (per > kGroup ? kGroup : per); }
   while (true) {
     __syncthreads();
-    if (threadIdx.x == 0) s_item = atomicAdd(&a.ctr->active_head[par], 1u);
+    if (threadIdx.x == 0) s_item = atomicAdd(&a.ctr->active_head[par], per);
     __syncthreads();
-    const uint32_t ai = s_item;
-    if (ai >= n_active) break;
-    const uint32_t item = a.active[par][ai];
-    const ItemProg pg = a.prog[item];
-    const bool chroma = a.n_channels == 3;
-    // The next round's solve kernel is waiting for tasks (emit_live): find out what the item still needs with a dry
-    // walk (a third of the real one's time: no splats) and hand its tasks out before splatting anything.
-    bool emitted = false;
-    uint32_t off = 0;
-    if (a.emit_live && !chroma) {
-      const AcceptResult rd = accept_item(a, sh, item, pg, res, rmin, rmax_p1, true);
-      if (threadIdx.x == 0 && rd.more) emitted = emit_tasks(a, nxt, item, rd.new_lo, rd.new_hi, off);
-      __syncthreads();
+    const uint32_t ai0 = s_item;
+    if (ai0 >= n_active) break;
+    const uint32_t cnt = n_active - ai0 < per ? n_active - ai0 : per;
+    if (dry_first) {
+      for (uint32_t j = 0; j < cnt; ++j) {
+        const uint32_t item = a.active[par][ai0 + j];
+        const ItemProg pg = a.prog[item];
+        const AcceptResult rd = accept_item<kMode>(a, sh, item, pg, res, res_prev, rmin, rmax_p1, true);
+        if (threadIdx.x == 0) {
+          uint32_t off = 0;
+          s_emitted[j] = (rd.more && emit_tasks(a, nxt, item, rd.new_lo, rd.new_hi, off)) ? 1u : 0u;
+          s_emit_off[j] = off; s_emit_hi[j] = rd.new_hi;
+        }
+        __syncthreads();
+      }
     }
+    for (uint32_t j = 0; j < cnt; ++j) {
+    const uint32_t item = a.active[par][ai0 + j];
+    const ItemProg pg = a.prog[item];
     const AcceptResult r = chroma ? accept_item_chroma(a, sh, item, pg, res, rmin, rmax_p1)
-                                  : accept_item(a, sh, item, pg, res, rmin, rmax_p1);
+                                  : accept_item<kMode>(a, sh, item, pg, res, res_prev, rmin, rmax_p1);
+    if (threadIdx.x == 0) tl_add(TL_ITEMS_ACCEPTED, 1u);
     if (threadIdx.x == 0) {
-      if (r.more) {
+      bool emitted = dry_first && s_emitted[j] != 0u;
+      uint32_t off = dry_first ? s_emit_off[j] : 0u, emitted_hi = dry_first ? s_emit_hi[j] : 0u;
+      if (kMode == 1) {
+        const uint32_t u = r.prog.uacc;
+        dbg_add(8 + (u == 0 ? 0 : (u <= 4 ? 1 : (u <= 16 ? 2 : (u <= 64 ? 3 : (u <= 256 ? 4 : 5))))), 1);
+        dbg_add(14, u);
+        if (u) dbg_add(15, r.more ? 1 : 0);
+      }
+      if (kMode == 2 && pg.uacc) { dbg_add(16, 1); dbg_add(17, r.more ? 1 : 0); dbg_add(18, r.prog.accepted); dbg_add(19, r.samples); }
+      if (kMode == 1 && r.prog.uacc != 0u) {
+        // met attempts whose solves are still parked: the next accept walks the item again, this batch beside the next
+        ItemProg np_ = pg;
+        np_.uacc = r.prog.uacc;
+        np_.n_end1 = r.prog.n_done;
+        np_.p_lo = pg.m_lo; np_.p_hi = pg.m_hi; np_.p_off = pg.res_off;
+        np_.m_lo = np_.m_hi = pg.m_hi; np_.res_off = 0;
+        if (!emitted && r.more) { emitted = emit_tasks(a, nxt, item, r.new_lo, r.new_hi, off); emitted_hi = r.new_hi; }
+        if (emitted) { np_.m_hi = emitted_hi; np_.res_off = off; }
+        a.prog[item] = np_;
+        const uint32_t slot = atomicAdd(&a.ctr->n_active[nxt], 1u);
+        a.active[nxt][slot] = item;
+      } else if (r.more) {
         ItemProg np_ = r.prog;
         np_.m_lo = r.new_lo; np_.m_hi = r.new_hi;
+        np_.uacc = 0; np_.p_lo = np_.p_hi = np_.p_off = 0; np_.n_end1 = 0;
+        if (emitted) np_.m_hi = emitted_hi;         // (the dry walk's word: the same, its view of the results being the same)
         if (emitted || emit_tasks(a, nxt, item, r.new_lo, r.new_hi, off)) {
           np_.res_off = off;
           a.prog[item] = np_;
@@ -2220,6 +2404,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
                                                                    : (unsigned long long)r.samples * 5ull;
         tot_accepted += chroma ? r.prog.splats : r.prog.accepted;
       }
+    }
+    __syncthreads();       // (s_emit_*[j] and the add table in `sh` are the block's)
     }
   }
   if (threadIdx.x == 0) {
