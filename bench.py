@@ -12,11 +12,17 @@ per second (Msamples/s; 1 sample = 1 visit record of 80+16K bytes, SURVEY.md sec
 Workload at N=1: the configuration the metric is quoted on -- double-gauss 50 mm polynomial optics,
 3840x2160, 9 visits/pixel (AA 3), 1024 redistribution draws per redistributed visit, beauty only,
 highlight fraction f_hi (default 2^-16, the scan-dominated regime of SURVEY.md section 8d; the
-highlight-heavy regime 1.6e-3 is reported beside it in "regimes").  N>1 keeps the per-GPU work fixed
-(weak scaling): the same camera at N times the pixels (16:9, sqrt(N) finer both ways), rank r owns a band
-of consecutive rows -- its visits and its tile of the output -- and sends the rows its draws touched
-outside the band to their owners (pota_amd/distributed.py::frame_step_bands).
+highlight-heavy regime 1.6e-3 is reported beside it in "regimes").  N>1 is the metric's wording -- the SAME 4K
+frame at 1/2/4/8 GPUs (strong scaling, the default): rank r owns a band of consecutive rows -- its visits and its
+tile of the output -- and sends what its draws touched outside the band to the owners over xGMI
+(lentil_hip_exchange_bands; pota_amd/distributed.py::frame_step_bands is the torch.distributed form of the same
+step).  At N>1 BASELINE config 5 (7680x4320, 2048 draws, tiled across the N GPUs) is timed the same way and
+reported under "configs"; --scaling weak keeps the per-GPU work fixed instead (the same camera at N times the pixels).
 LENTIL_PARTITION=interleaved selects rows r mod N with one sum all-reduce of the whole frame instead.
+
+Launch: `python bench.py --gpus N` starts its own N ranks (a child `python -m torch.distributed.run ... bench.py`,
+spawned before this process touches the GPU; its JSON line and exit code are passed on); under a launcher
+(WORLD_SIZE set) it is one of the ranks.
 
 The timed steps ALTERNATE between two resident visit streams generated from different seeds (different
 highlights in different places): a pass sizes its buffers from what the previous pass found, and a renderer
@@ -81,6 +87,9 @@ def parse():
     ap.add_argument("--cpu-row-step", type=int, default=0, help="CPU baseline samples every n-th row (0 = auto)")
     ap.add_argument("--bokeh-image", action="store_true", help="aperture draws from the reference's example bokeh image "
                                                                "(tests/golden/example_bokeh_kernel_u8.npy; BASELINE config 3)")
+    ap.add_argument("--scaling", default="strong", choices=("strong", "weak"),
+                    help="N > 1: strong = the same frame tiled over the GPUs (the metric's wording); weak = N times the pixels")
+    ap.add_argument("--no-config5", action="store_true", help="N > 1: skip BASELINE config 5 (7680x4320, 2048 draws, tiled)")
     ap.add_argument("--bounds", default="", help="band boundaries (N+1 visit rows, comma separated) instead of the even split")
     ap.add_argument("--emulate", default="", help="development aid: 'N,r' runs rank r's band of the N-GPU frame in one "
                                                    "process (no exchange): per-band cost of the weak-scaling workload")
@@ -422,8 +431,60 @@ def summarize(b, r, n_total, bytes_per_visit):
     return ms, launches, launch_ms, launch_bytes, achieved
 
 
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as a child (the launcher the driver itself uses),
+    BEFORE this process has imported torch or touched the GPU, pass its output on and leave with its exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stderr.write("bench.py: starting %d ranks: %s\n" % (args.gpus, " ".join(cmd)))
+    p = subprocess.run(cmd, stdout=subprocess.PIPE, text=True)
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    js = [l for l in lines if l.lstrip().startswith("{") and '"metric"' in l]
+    for l in lines:
+        if not js or l is not js[-1]:
+            sys.stderr.write(l + "\n")          # (launcher / RCCL chatter)
+    if js:
+        print(js[-1], flush=True)
+    elif p.returncode == 0:
+        sys.stderr.write("bench.py: the ranks printed no result line\n")
+        sys.exit(1)
+    sys.exit(p.returncode)
+
+
+def rank_details(b, dist, torch, dev, steps=3):
+    """Per-rank pass / exchange times (host clock around the two halves of the step, a stream sync after each; untimed
+    extra steps) and what the rank sent and received in its last exchange; gathered to every rank."""
+    mine = {"rank": b.rank, "pass_ms": None, "exchange_ms": None, "sent_bytes": None, "received_bytes": None, "band_rows": list(b.band) if b.band else None}
+    if b.native and b.tiled:
+        tp = te = 0.0
+        for _ in range(steps):
+            cols, v, kv = b.streams[b.i_stream % len(b.streams)]
+            b.i_stream += 1
+            b.ctx.bind_visits(v, kv)
+            b.ctx.set_closest_exchange(False)
+            dist.barrier()
+            t0 = time.perf_counter()
+            b.ctx.clear_frame(); b.ctx.redistribute(); b.ctx.sync()
+            t1 = time.perf_counter()
+            b.ctx.exchange_bands(b.H, b.bounds, sparse=b.distributed.SPARSE_EXCHANGE); b.ctx.sync()
+            t2 = time.perf_counter()
+            tp += t1 - t0; te += t2 - t1
+        sent, recv = b.ctx.exchange_stats()
+        mine.update(pass_ms=round(tp / steps * 1e3, 3), exchange_ms=round(te / steps * 1e3, 3), sent_bytes=sent, received_bytes=recv)
+    allr = [None] * b.world
+    dist.all_gather_object(allr, mine)
+    return allr
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not args.emulate:
+        spawn_ranks(args)
     import torch
     import torch.distributed as dist
     from pota_amd import workload
@@ -432,8 +493,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     emulate = tuple(int(x) for x in args.emulate.split(",")) if args.emulate else None
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world and world == 1 and args.gpus > 1:
-        raise SystemExit("--gpus %d needs torch.distributed.run with %d ranks" % (args.gpus, args.gpus))
+    if args.gpus != world and not emulate:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE is %d" % (args.gpus, world))
     backend = os.environ.get("LENTIL_DIST_BACKEND", "nccl")     # "gloo": several ranks on one GPU (development aid)
     if backend != "nccl":
         local_rank = local_rank % max(1, torch.cuda.device_count())
@@ -447,12 +508,14 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
     dev = torch.device("cuda", local_rank)
+    ranks_joined = 1
     if world > 1:
         # self-check of the launch: every rank the driver asked for has joined
         t = torch.ones(1, dtype=torch.int64, device=dev)
         dist.all_reduce(t)
-        if int(t.item()) != world or world != args.gpus:
-            raise SystemExit("bench.py: %d ranks joined, --gpus %d, WORLD_SIZE %d" % (int(t.item()), args.gpus, world))
+        ranks_joined = int(t.item())
+        if ranks_joined != world or world != args.gpus:
+            raise SystemExit("bench.py: %d ranks joined, --gpus %d, WORLD_SIZE %d" % (ranks_joined, args.gpus, world))
 
     M = args.visits_per_pixel
     # Weak scaling: N GPUs render the same camera at N times the pixels (same 16:9 frame, sqrt(N) finer in both
@@ -460,12 +523,18 @@ def main():
     # single-GPU frame.  (Stacking N frames on top of each other would push the outer bands far off axis, where the
     # lens passes nothing and every visit burns its 5 x samples attempts.)
     frame_world = emulate[0] if emulate else world
+    strong = args.scaling == "strong" and not emulate
     if frame_world == 1:
         W, Hr = args.width, args.height
+        H = Hr
+    elif strong:
+        # the metric's wording: the 4K frame at N GPUs -- the same frame, tiled
+        W, H = args.width, args.height
+        Hr = (H + frame_world - 1) // frame_world
     else:
         W = int(round(args.width * math.sqrt(frame_world)))
         Hr = int(round(args.height / math.sqrt(frame_world)))
-    H = Hr * frame_world
+        H = Hr * frame_world
     tiled = (world > 1 or force_dist) and os.environ.get("LENTIL_PARTITION", "bands") != "interleaved" and not emulate
     bounds = [int(x) for x in args.bounds.split(",")] if args.bounds else None
 
@@ -527,13 +596,17 @@ def main():
     out = {
         "metric": "bidir redistribution Msamples/s at 4K, double-gauss 50mm",
         "value": round(value, 3), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+        "scaling": "weak" if (args.scaling == "weak" and not emulate) else "strong", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
         "config": {
-            "workload": "polynomial-optics %s (self-fitted table), frame %dx%d (%d x the pixels of %dx%d, same camera), "
-                        "%d rows per GPU, %d visits/pixel, %d redistribution draws per redistributed visit, %d AOV(s), "
+            "workload": "polynomial-optics %s (self-fitted table), frame %dx%d (%s), "
+                        "~%d rows per GPU, %d visits/pixel, %d redistribution draws per redistributed visit, %d AOV(s), "
                         "highlight fraction f_hi=%.3g; %s"
-                        % (args.lens, W, H, world, args.width, args.height, Hr, M, args.samples, 1 + args.aovs, args.f_hi,
+                        % (args.lens, W, H,
+                           ("the %dx%d frame tiled over %d GPU(s)" % (args.width, args.height, world)) if (strong or world == 1)
+                           else ("%d x the pixels of %dx%d, same camera" % (frame_world, args.width, args.height)),
+                           Hr, M, args.samples, 1 + args.aovs, args.f_hi,
                            "ONE visit stream replayed" if args.same_frame else
                            "timed steps alternate between two visit streams (seeds %#x / %#x)" % SEEDS),
             "visits_per_gpu": b.n_local, "bytes_per_visit": bytes_per_visit,
@@ -544,7 +617,7 @@ def main():
                             % (world, (" at rows %s (balanced by pass time)" % b.bounds) if b.bounds else "") if tiled else
                             "rows%%%d + allreduce" % world),
         },
-        "exchange": exchange,
+        "exchange": exchange, "ranks_joined": ranks_joined,
         "passes": {"timed": steps, "streamed": r["streamed"], "chunks_enqueued_blind": r["blind_chunks"],
                    "chunks_redone_after_a_short_estimate": r["redone"]},
         "kernels_ms": {"scan": round(r["scan"] / steps, 4), "draw": round(r["draw"] / steps, 4), "resolve": round(r["resolve"] / steps, 4)},
@@ -559,6 +632,38 @@ def main():
         },
         "solve_fp64": {"scan_dominated": b.solve_block(r)},
     }
+
+    if world > 1 and not emulate:
+        try:
+            out["ranks"] = rank_details(b, dist, torch, dev)
+        except Exception as e:      # the headline number must still be reported
+            out["ranks"] = {"error": repr(e)}
+        if not args.no_config5:
+            # BASELINE config 5: 7680x4320, 2048 draws (above the reference's clamp of 2000: samples_override), the frame
+            # tiled across the N GPUs, cross-tile splats exchanged over xGMI
+            name = "config5_double_gauss_7680x4320_2048_draws_tiled_%d_gpus" % world
+            try:
+                W5, H5 = 7680, 4320
+                c5 = Bench(torch, dist, dev, local_rank, world, rank, W5, H5, (H5 + world - 1) // world, M, args.lens, 2048, 0,
+                           args.f_hi, False, tiled=tiled)
+                c5.generate(args.f_hi)
+                c5.native = False
+                if b.native:
+                    c5.distributed.native_comm_init(c5.ctx, dist)
+                    c5.native = True
+                for _ in range(2):
+                    c5.step()
+                r5 = c5.run(4, 2)
+                n5 = workload.frame_visit_count(W5, H5, M)
+                out.setdefault("configs", {})[name] = {
+                    "value": round(n5 * r5["steps"] / r5["dt"] / 1e6, 3), "unit": "Msamples/s", "ms_per_step": round(r5["dt"] / r5["steps"] * 1e3, 4),
+                    "kernels_ms_rank0": {"scan": round(r5["scan"] / 4, 4), "draw": round(r5["draw"] / 4, 4), "resolve": round(r5["resolve"] / 4, 4)},
+                    "attempted_draws_per_step_rank0": r5["attempted"] // 4, "steps": 4,
+                    "whole_step_frac_of_hbm_peak_per_gpu": round(n5 * 80 / world / (r5["dt"] / r5["steps"]) / 1e9 / HBM_PEAK_GBS, 4),
+                    "exchange": "native" if c5.native else "torch.distributed", "ranks": rank_details(c5, dist, torch, dev, steps=2)}
+                c5.close()
+            except Exception as e:
+                out.setdefault("configs", {})[name] = {"value": None, "error": repr(e)}
 
     if not args.no_second_regime and world == 1:
         f2 = 1.6e-3

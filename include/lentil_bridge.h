@@ -106,11 +106,18 @@ void lentil_setup_filter_region(lentil_params *p, int xres, int yres, int region
 
 /* The display pass-through of filter_pixel (src/lentil_filter.cpp:453-479): what Arnold shows until the imager
  * overwrites it.  Camera::filter_gaussian_complete (src/lentil.h:738-775): samples within the filter radius weighted
- * by exp(-2 r) * inverse density (the SDK's AiFastExp is an approximation of exp; display only) -- offsets_xy 2 n,
+ * by AiFastExp(-2 r) * inverse density (the caller hands the SDK's function in; without one, expf -- display only) -- offsets_xy 2 n,
  * values_rgba 4 n, inv_density n or NULL for a uniform value.  Camera::filter_closest_complete (src/lentil.h:696-735):
  * the value of the sample with the smallest |depth| (later samples win ties; depth 0 re-opens), alpha 1. */
+/* lens_model (src/lentil_camera.cpp:13-16,29, src/lentil.h:62-65,1212): the reference's 44 lens ids in its order, then
+ * this build's own tables.  _name: the id's string (NULL when out of range); _table: the name of the shipped table that
+ * stands in for it, NULL when this build ships none for that id (the camera update then refuses the id by name). */
+const char *lentil_lens_model_name(int lens_model);
+const char *lentil_lens_model_table(int lens_model);
+
+typedef float (*lentil_exp_fn)(float);   /* the SDK's AiFastExp where there is one (lentil.so passes it); NULL: expf */
 void lentil_filter_gaussian_complete(int n, const float *offsets_xy, const float *values_rgba, const float *inv_density,
-                                     float uniform_inv_density, float filter_width, float out_rgba[4]);
+                                     float uniform_inv_density, float filter_width, lentil_exp_fn fast_exp, float out_rgba[4]);
 void lentil_filter_closest_complete(int n, const float *depth, const float *values_rgba, float out_rgba[4]);
 
 /* ------------------------------------------------------------------------------------

@@ -415,6 +415,10 @@ int lentil_hip_comm_destroy(lentil_hip_ctx *ctx);
 int lentil_hip_allreduce(lentil_hip_ctx *ctx);
 int lentil_hip_exchange_bands(lentil_hip_ctx *ctx, const int32_t *bounds, int32_t visit_rows, int32_t sparse,
                               int32_t *band_lo, int32_t *band_hi);
+/* payload bytes this rank sent / received over xGMI in its last lentil_hip_exchange_bands (pixel entries or packed rows,
+ * winner keys included) or lentil_hip_allreduce (ring traffic of the reduced buffers); either pointer may be NULL.
+ * Instrumentation for the scaling bench; no reference counterpart. */
+int lentil_hip_exchange_stats(lentil_hip_ctx *ctx, uint64_t *bytes_sent, uint64_t *bytes_received);
 
 /* --- cryptomatte AOVs ------------------------------------------------------------------
  * The reference keeps a std::map<float, float> id -> weight and a total weight per pixel for every ranked

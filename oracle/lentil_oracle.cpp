@@ -896,6 +896,65 @@ ORC_API void orc_frame_merge(OrcFrame *dst, const OrcFrame *src) {   /* per-thre
   dst->ctr.accepted_draws += src->ctr.accepted_draws;
 }
 
+/* ---- a21: the display pass-through of filter_pixel ----------------------------------------
+ * Camera::filter_closest_complete, src/lentil.h:696-735, and Camera::filter_gaussian_complete, :738-775, over one
+ * pixel's AOV samples handed in as arrays (what the iterator yields, in its order).  aov_type: the SDK's AI_TYPE_*
+ * codes (FLOAT 4, RGB 5, RGBA 6, VECTOR 7); value: 4 floats per sample as the typed getter would return them.
+ * fast_exp: AiFastExp -- an exported SDK function whose bits are not in the reference tree; the caller supplies the one
+ * of the SDK at hand (NULL: expf).  AtRGBA arithmetic as everywhere in this file: `float * AtRGBA` on all four
+ * channels, `AtRGBA /= float` as a multiplication by 1.0f / f (SDK semantics recalled; parity unpinned). */
+ORC_API void orc_filter_closest_complete(int n, const float *depth, const float *value, int aov_type, float out[4]) {
+  float pixel_energy[4] = {0.0f, 0.0f, 0.0f, 0.0f};       /* AI_RGBA_ZERO */
+  float z = 0.0;
+  for (int i = 0; i < n; i++) {                          /* while (AiAOVSampleIteratorGetNext(iterator)) */
+    const float d = depth[i];
+    if ((std::abs(d) <= z) || z == 0.0) {
+      z = std::abs(d);
+      switch (aov_type) {
+        case 7: {                                        /* AI_TYPE_VECTOR */
+          pixel_energy[0] = value[4 * i]; pixel_energy[1] = value[4 * i + 1]; pixel_energy[2] = value[4 * i + 2]; pixel_energy[3] = 1.0f;
+          break;
+        }
+        case 4: {                                        /* AI_TYPE_FLOAT */
+          const float sample_energy = value[4 * i];
+          pixel_energy[0] = sample_energy; pixel_energy[1] = sample_energy; pixel_energy[2] = sample_energy; pixel_energy[3] = 1.0f;
+          break;
+        }
+        /* (no other case: an RGB / RGBA AOV leaves pixel_energy alone, :706-728) */
+      }
+    }
+  }
+  for (int c = 0; c < 4; c++) out[c] = pixel_energy[c];
+}
+
+ORC_API void orc_filter_gaussian_complete(int n, const float *offset_xy, const float *value, const float *sample_inv_density,
+                                          int aov_type, float inverse_sample_density, int adaptive_sampling, float filter_width,
+                                          float (*fast_exp)(float), float out[4]) {
+  float aweight = 0.0f;
+  float avalue[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+  float inv_density = inverse_sample_density;
+  for (int i = 0; i < n; i++) {
+    if (adaptive_sampling) inv_density = sample_inv_density[i];
+    if (inv_density <= 0.f) continue;
+    const float ox = offset_xy[2 * i], oy = offset_xy[2 * i + 1];
+    const float q = 2 / filter_width;                    /* AiSqr(2 / filter_width): int / float */
+    const float r = (q * q) * ((ox * ox) + (oy * oy));
+    if (r > 1.0f) continue;
+    const float e = fast_exp ? fast_exp(2 * -r) : std::exp(2 * -r);
+    const float weight = e * inv_density;
+    float sample_energy[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    switch (aov_type) {
+      case 6: { for (int c = 0; c < 4; c++) sample_energy[c] = value[4 * i + c]; } break;          /* AI_TYPE_RGBA */
+      case 5: { sample_energy[0] = value[4 * i]; sample_energy[1] = value[4 * i + 1]; sample_energy[2] = value[4 * i + 2];
+                sample_energy[3] = 1.0f; } break;        /* AI_TYPE_RGB: AtRGB -> AtRGBA, alpha 1 */
+    }
+    for (int c = 0; c < 4; c++) avalue[c] += weight * sample_energy[c];
+    aweight += weight;
+  }
+  if (aweight != 0.0f) { const float inv = 1.0f / aweight; for (int c = 0; c < 4; c++) avalue[c] *= inv; }
+  for (int c = 0; c < 4; c++) out[c] = avalue[c];
+}
+
 /* ---- cryptomatte ---------------------------------------------------------------------- */
 ORC_API void orc_frame_set_crypto(OrcFrame *F, uint32_t n_crypto, uint32_t entries, const float *const *hash,
                                   const float *const *weight) {

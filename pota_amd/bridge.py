@@ -59,7 +59,7 @@ EXPORTS = [
     "lentil_imager_process_bucket", "lentil_imager_last_error",
     "lentil_setup_crypto_aovs", "lentil_crypto_construct_cache", "lentil_crypto_rank_of_name", "lentil_stage_set_crypto",
     "lentil_stage_crypto", "lentil_imager_set_crypto", "lentil_imager_process_crypto_bucket",
-    "lentil_setup_filter_region", "lentil_filter_gaussian_complete", "lentil_filter_closest_complete",
+    "lentil_setup_filter_region", "lentil_filter_gaussian_complete", "lentil_filter_closest_complete", "lentil_lens_model_name", "lentil_lens_model_table",
 ]
 
 _lib = None
@@ -114,8 +114,10 @@ def load():
         "lentil_imager_process_crypto_bucket": (i, [vp, u32, i, i, i, i, vp]),
         "lentil_imager_last_error": (C.c_char_p, [vp]),
         "lentil_setup_filter_region": (None, [C.POINTER(_abi.Params), i, i, i, i, i, i, f]),
-        "lentil_filter_gaussian_complete": (None, [i, vp, vp, vp, f, f, vp]),
+        "lentil_filter_gaussian_complete": (None, [i, vp, vp, vp, f, f, vp, vp]),
         "lentil_filter_closest_complete": (None, [i, vp, vp, vp]),
+        "lentil_lens_model_name": (C.c_char_p, [i]),
+        "lentil_lens_model_table": (C.c_char_p, [i]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)

@@ -22,7 +22,36 @@ static const char *const kCameraTypes[] = {"ThinLens", "PolynomialOptics", nullp
 static const char *const kChromaticTypes[] = {"green_magenta", "red_cyan", nullptr};
 // the reference splices its lens list in from a generated header that is not in its tree
 // (include/auto_generated_lens_includes/pota_cpp_lenses.h); the lenses shipped here take its place
-static const char *const kLensModels[] = {"double_gauss_50mm", "petzval_58mm", "anamorphic_petzval_58mm", nullptr};
+// The reference's lens ids, in its order (include/auto_generated_lens_includes/pota_h_lenses.h:4-47 = the LensModel enum,
+// pota_cpp_lenses.h the strings): a scene file written for the reference parses, and an id keeps its number.  Their
+// polynomial tables live in zpelgrims/polynomial-optics, which the reference tree does not hold; this build ships
+// tables of its own (kLensTableOf below maps the ids they stand in for, every other id is refused by name at camera
+// update).  Behind the 44: this build's tables under their own names.
+static const char *const kLensModels[] = {
+    "angenieux__double_gauss__1953__49mm", "angenieux__double_gauss__1953__85mm", "angenieux__double_gauss__1953__105mm",
+    "angenieux__double_gauss__1953__55mm", "asahi__takumar__1969__45mm", "asahi__takumar__1969__50mm",
+    "asahi__takumar__1969__65mm", "asahi__takumar__1969__75mm", "asahi__takumar__1969__58mm",
+    "asahi__takumar__1969__85mm", "asahi__takumar__1970__28mm", "asahi__takumar__1970__50mm",
+    "asahi__takumar__1970__35mm", "canon__retrofocus_wideangle__1982__22mm", "canon__unknown__1956__35mm",
+    "canon__unknown__1956__52mm", "cooke__speed_panchro__1920__40mm", "cooke__speed_panchro__1920__75mm",
+    "cooke__speed_panchro__1920__100mm", "cooke__speed_panchro__1920__50mm", "kodak__petzval__1948__150mm",
+    "kodak__petzval__1948__105mm", "kodak__petzval__1948__85mm", "kodak__petzval__1948__65mm",
+    "kodak__petzval__1948__75mm", "kodak__petzval__1948__58mm", "meyer_optik_goerlitz__primoplan__1936__58mm",
+    "meyer_optik_goerlitz__primoplan__1936__75mm", "minolta__fisheye__1978__16mm", "minolta__fisheye__1978__22mm",
+    "minolta__fisheye__1978__28mm", "nikon__retrofocus_wideangle__1971__28mm", "nikon__retrofocus_wideangle__1971__35mm",
+    "nikon__unknown__2014__65mm", "nikon__unknown__2014__40mm", "nikon__unknown__2014__50mm",
+    "unknown__petzval__1900__85mm", "unknown__petzval__1900__100mm", "unknown__petzval__1900__75mm",
+    "unknown__petzval__1900__65mm", "zeiss__biotar__1927__65mm", "zeiss__biotar__1927__58mm",
+    "zeiss__biotar__1927__85mm", "zeiss__biotar__1927__45mm",
+    "double_gauss_50mm", "petzval_58mm", "anamorphic_petzval_58mm", nullptr};
+static const int kLensModelDefault = 16;      // cooke__speed_panchro__1920__40mm, src/lentil_camera.cpp:29
+struct LensStandIn { const char *id, *table; };
+static const LensStandIn kLensTableOf[] = {
+    {"angenieux__double_gauss__1953__49mm", "double_gauss_50mm"},     // (BASELINE's "double-gauss 50 mm" class)
+    {"kodak__petzval__1948__58mm", "petzval_58mm"},
+    {"double_gauss_50mm", "double_gauss_50mm"}, {"petzval_58mm", "petzval_58mm"},
+    {"anamorphic_petzval_58mm", "anamorphic_petzval_58mm"},
+};
 
 #define P_ENUM(n, d, v) {n, LENTIL_AI_TYPE_ENUM, (double)(d), nullptr, v}
 #define P_INT(n, d) {n, LENTIL_AI_TYPE_INT, (double)(d), nullptr, nullptr}
@@ -40,7 +69,7 @@ static const lentil_node_param kCameraParams[] = {     // src/lentil_camera.cpp:
     P_FLT("focus_dist", 150.0),
     P_INT("aperture_blades_lentil", 0),
     P_FLT("exp", 1.0),
-    P_ENUM("lens_model", 0, kLensModels),
+    P_ENUM("lens_model", kLensModelDefault, kLensModels),
     P_FLT("wavelength", 550.0),
     P_FLT("extra_sensor_shift", 0.0),
     P_FLT("focal_length_lentil", 35.0),
@@ -71,7 +100,7 @@ BRIDGE_API void lentil_camera_node_defaults(lentil_camera_node_values *v) {
   if (!v) return;
   memset(v, 0, sizeof(*v));
   v->camera_type = 0; v->bidir_sample_mult = 5; v->units = 1; v->sensor_width = 36.0f; v->enable_dof = 1;
-  v->fstop = 0.0f; v->focus_dist = 150.0f; v->aperture_blades_lentil = 0; v->exp = 1.0f; v->lens_model = 0;
+  v->fstop = 0.0f; v->focus_dist = 150.0f; v->aperture_blades_lentil = 0; v->exp = 1.0f; v->lens_model = kLensModelDefault;
   v->wavelength = 550.0f; v->extra_sensor_shift = 0.0f; v->focal_length_lentil = 35.0f;
   v->optical_vignetting = 0.0f; v->abb_spherical = 0.5f; v->abb_distortion = 0.0f; v->abb_coma = 0.0f;
   v->abb_chromatic = 0.0f; v->abb_chromatic_type = 0; v->bokeh_circle_to_square = 0.0f; v->bokeh_anamorphic = 0.0f;
@@ -384,8 +413,23 @@ BRIDGE_API void lentil_setup_filter_region(lentil_params *p, int xres, int yres,
   p->filter_width = filter_width;
 }
 
+// lens_model -> the id's name and the name of the shipped table that stands in for it (NULL: none shipped)
+BRIDGE_API const char *lentil_lens_model_name(int lens_model) {
+  int count = 0;
+  while (kLensModels[count]) ++count;
+  return (lens_model >= 0 && lens_model < count) ? kLensModels[lens_model] : nullptr;
+}
+BRIDGE_API const char *lentil_lens_model_table(int lens_model) {
+  const char *id = lentil_lens_model_name(lens_model);
+  if (!id) return nullptr;
+  for (const LensStandIn &m : kLensTableOf)
+    if (strcmp(m.id, id) == 0) return m.table;
+  return nullptr;
+}
+
 BRIDGE_API void lentil_filter_gaussian_complete(int n, const float *offsets_xy, const float *values_rgba, const float *inv_density,
-                                                float uniform_inv_density, float filter_width, float out_rgba[4]) {
+                                                float uniform_inv_density, float filter_width, lentil_exp_fn fast_exp,
+                                                float out_rgba[4]) {
   float aweight = 0.0f, av[4] = {0, 0, 0, 0};
   for (int i = 0; i < n; ++i) {
     const float invd = inv_density ? inv_density[i] : uniform_inv_density;
@@ -393,7 +437,7 @@ BRIDGE_API void lentil_filter_gaussian_complete(int n, const float *offsets_xy, 
     const float k = 2.0f / filter_width;
     const float r = (k * k) * (offsets_xy[2 * i] * offsets_xy[2 * i] + offsets_xy[2 * i + 1] * offsets_xy[2 * i + 1]);
     if (r > 1.0f) continue;
-    const float w = std::exp(2 * -r) * invd;
+    const float w = (fast_exp ? fast_exp(2 * -r) : std::exp(2 * -r)) * invd;
     for (int c = 0; c < 4; ++c) av[c] += w * values_rgba[4 * i + c];
     aweight += w;
   }
@@ -545,7 +589,15 @@ BRIDGE_API int lentil_stage_stream_to(lentil_stage *s, lentil_hip_ctx *gpu, uint
   if (!gpu) return LENTIL_OK;                                    // back to plain staging
   s->block_visits = block_visits ? block_visits : (1u << 14);
   s->capacity_hint = capacity_hint;
-  return stage_begin_stream(s);          // a slot's blocks are allocated when a thread first uses the slot
+  const int rc = stage_begin_stream(s);  // a slot's blocks are allocated when a thread first uses the slot
+  if (rc != LENTIL_OK) {
+    // plain staging again: with `gpu` left set every lentil_stage_append would fail (no open stream) and the frame would
+    // lose its redistribution, where the caller was told "the visits are uploaded at the end of the frame"
+    stage_free_blocks(s);
+    s->gpu = nullptr;
+    s->stream_open = false;
+  }
+  return rc;
 }
 
 static void clear_slot(StageSlot &sl) {

@@ -73,6 +73,7 @@ struct LentilComm {
   int64_t *d_meta_mine = nullptr, *d_meta_all = nullptr, *h_meta_all = nullptr;   // [2 + world] / [world][2 + world]
   std::vector<void *> scratch;          // grow-only device buffers, one per use slot
   std::vector<size_t> scratch_bytes;
+  uint64_t last_sent = 0, last_received = 0;     // payload bytes of the last exchange_bands / allreduce (lentil_hip_exchange_stats)
 };
 
 #define RCCL_TRY(ctx, call)                                                                           \
@@ -130,12 +131,34 @@ LENTIL_API int lentil_hip_comm_init(lentil_hip_ctx *ctx, const uint8_t id[128], 
   cm->rank = rank; cm->world = world;
   LentilNcclId uid;
   memcpy(uid.b, id, 128);
-  ctx->comm = cm;
-  RCCL_TRY(ctx, g_rccl.CommInitRank(&cm->comm, world, uid, rank));
+  // (the context only gets a communicator that is complete: a half-built one would be handed to RCCL by the next
+  // exchange, and would make the cryptomatte pass refuse the context for being "multi-GPU")
+  auto undo = [&]() {
+    if (cm->comm) (void)g_rccl.CommDestroy(cm->comm);
+    (void)hipFree(cm->d_meta_mine); (void)hipFree(cm->d_meta_all);
+    if (cm->h_meta_all) (void)hipHostFree(cm->h_meta_all);
+    delete cm;
+  };
+  {
+    const int r = g_rccl.CommInitRank(&cm->comm, world, uid, rank);
+    if (r != 0) { cm->comm = nullptr; undo(); return fail(ctx, LENTIL_ERR_HIP, std::string("ncclCommInitRank: ") + g_rccl.GetErrorString(r)); }
+  }
   const size_t m = (size_t)(2 + world);
-  HIP_TRY(ctx, hipMalloc(&cm->d_meta_mine, m * sizeof(int64_t)));
-  HIP_TRY(ctx, hipMalloc(&cm->d_meta_all, m * (size_t)world * sizeof(int64_t)));
-  HIP_TRY(ctx, hipHostMalloc((void **)&cm->h_meta_all, m * (size_t)world * sizeof(int64_t), hipHostMallocDefault));
+  hipError_t e = hipMalloc(&cm->d_meta_mine, m * sizeof(int64_t));
+  if (e == hipSuccess) e = hipMalloc(&cm->d_meta_all, m * (size_t)world * sizeof(int64_t));
+  if (e == hipSuccess) e = hipHostMalloc((void **)&cm->h_meta_all, m * (size_t)world * sizeof(int64_t), hipHostMallocDefault);
+  if (e != hipSuccess) { undo(); return fail(ctx, LENTIL_ERR_HIP, std::string("communicator buffers: ") + hipGetErrorString(e)); }
+  ctx->comm = cm;
+  return LENTIL_OK;
+}
+
+// payload bytes this rank sent / received in its last lentil_hip_exchange_bands (entries or packed rows, keys included) or
+// lentil_hip_allreduce (ring traffic 2 (G - 1) / G of the reduced buffers, both ways)
+LENTIL_API int lentil_hip_exchange_stats(lentil_hip_ctx *ctx, uint64_t *bytes_sent, uint64_t *bytes_received) {
+  CHECK_CTX(ctx);
+  if (!ctx->comm) return fail(ctx, LENTIL_ERR_INVALID, "no communicator (lentil_hip_comm_init)");
+  if (bytes_sent) *bytes_sent = ctx->comm->last_sent;
+  if (bytes_received) *bytes_received = ctx->comm->last_received;
   return LENTIL_OK;
 }
 
@@ -160,6 +183,12 @@ LENTIL_API int lentil_hip_allreduce(lentil_hip_ctx *ctx) {
     if ((rc = lentil_hip_closest_gather(ctx))) return rc;
   }
   RCCL_TRY(ctx, g_rccl.AllReduce(ctx->F.acc, ctx->F.acc, ctx->F.np * ctx->F.stride, kNcclFloat32, kNcclSum, cm->comm, ctx->stream));
+  {
+    uint64_t bytes = ctx->F.np * ctx->F.stride * 4ull;
+    if (ctx->F.zkey) bytes += ctx->F.np * 8ull;
+    if (ctx->F.zkey_dbg) bytes += ctx->F.np * 8ull;
+    cm->last_sent = cm->last_received = cm->world > 1 ? bytes * 2ull * (uint64_t)(cm->world - 1) / (uint64_t)cm->world : 0ull;
+  }
   return LENTIL_OK;
 }
 
@@ -262,35 +291,51 @@ LENTIL_API int lentil_hip_exchange_bands(lentil_hip_ctx *ctx, const int32_t *bou
     }
   }
   // ---- the exchange itself: every send has its receive on the other side, in the same order per pair
+  // (an error inside the group is remembered and returned after GroupEnd: an early return would leave the group open)
   RCCL_TRY(ctx, g_rccl.GroupStart());
+  int g_err = 0;
+  uint64_t sent = 0, received = 0;
+  auto snd = [&](const void *p, size_t n, int type, size_t elem, int q) {
+    if (!g_err) g_err = g_rccl.Send(p, n, type, q, cm->comm, ctx->stream);
+    sent += (uint64_t)n * elem;
+  };
+  auto rcv = [&](void *p, size_t n, int type, size_t elem, int q) {
+    if (!g_err) g_err = g_rccl.Recv(p, n, type, q, cm->comm, ctx->stream);
+    received += (uint64_t)n * elem;
+  };
   for (int q = 0; q < world; ++q) {
     if (q == rank) continue;
     const Out &o = out[(size_t)q];
     if (o.form > 0) {
-      RCCL_TRY(ctx, g_rccl.Send(o.idx, (size_t)o.form * 4, kNcclUint8, q, cm->comm, ctx->stream));
-      RCCL_TRY(ctx, g_rccl.Send(o.vals, (size_t)o.form * used, kNcclFloat32, q, cm->comm, ctx->stream));
-      if (keys) RCCL_TRY(ctx, g_rccl.Send(o.k, (size_t)o.form, kNcclUint64, q, cm->comm, ctx->stream));
-      if (dkeys) RCCL_TRY(ctx, g_rccl.Send(o.kd, (size_t)o.form, kNcclUint64, q, cm->comm, ctx->stream));
+      snd(o.idx, (size_t)o.form * 4, kNcclUint8, 1, q);
+      snd(o.vals, (size_t)o.form * used, kNcclFloat32, 4, q);
+      if (keys) snd(o.k, (size_t)o.form, kNcclUint64, 8, q);
+      if (dkeys) snd(o.kd, (size_t)o.form, kNcclUint64, 8, q);
     } else if (o.form < 0) {
       const uint64_t n_pix = (uint64_t)(o.s_hi - o.s_lo) * xres;
-      RCCL_TRY(ctx, g_rccl.Send(o.packed, (size_t)n_pix * used, kNcclFloat32, q, cm->comm, ctx->stream));
-      if (keys) RCCL_TRY(ctx, g_rccl.Send(ctx->F.zkey + (uint64_t)o.s_lo * xres, (size_t)n_pix, kNcclUint64, q, cm->comm, ctx->stream));
-      if (dkeys) RCCL_TRY(ctx, g_rccl.Send(ctx->F.zkey_dbg + (uint64_t)o.s_lo * xres, (size_t)n_pix, kNcclUint64, q, cm->comm, ctx->stream));
+      snd(o.packed, (size_t)n_pix * used, kNcclFloat32, 4, q);
+      if (keys) snd(ctx->F.zkey + (uint64_t)o.s_lo * xres, (size_t)n_pix, kNcclUint64, 8, q);
+      if (dkeys) snd(ctx->F.zkey_dbg + (uint64_t)o.s_lo * xres, (size_t)n_pix, kNcclUint64, 8, q);
     }
     const In &i = in[(size_t)q];
     if (i.form > 0) {
-      RCCL_TRY(ctx, g_rccl.Recv(i.idx, (size_t)i.form * 4, kNcclUint8, q, cm->comm, ctx->stream));
-      RCCL_TRY(ctx, g_rccl.Recv(i.vals, (size_t)i.form * used, kNcclFloat32, q, cm->comm, ctx->stream));
-      if (keys) RCCL_TRY(ctx, g_rccl.Recv(i.k, (size_t)i.form, kNcclUint64, q, cm->comm, ctx->stream));
-      if (dkeys) RCCL_TRY(ctx, g_rccl.Recv(i.kd, (size_t)i.form, kNcclUint64, q, cm->comm, ctx->stream));
+      rcv(i.idx, (size_t)i.form * 4, kNcclUint8, 1, q);
+      rcv(i.vals, (size_t)i.form * used, kNcclFloat32, 4, q);
+      if (keys) rcv(i.k, (size_t)i.form, kNcclUint64, 8, q);
+      if (dkeys) rcv(i.kd, (size_t)i.form, kNcclUint64, 8, q);
     } else if (i.form < 0) {
       const uint64_t n_pix = (uint64_t)(i.r_hi - i.r_lo) * xres;
-      RCCL_TRY(ctx, g_rccl.Recv(i.packed, (size_t)n_pix * used, kNcclFloat32, q, cm->comm, ctx->stream));
-      if (keys) RCCL_TRY(ctx, g_rccl.Recv(i.key_rows, (size_t)n_pix, kNcclUint64, q, cm->comm, ctx->stream));
-      if (dkeys) RCCL_TRY(ctx, g_rccl.Recv(i.dkey_rows, (size_t)n_pix, kNcclUint64, q, cm->comm, ctx->stream));
+      rcv(i.packed, (size_t)n_pix * used, kNcclFloat32, 4, q);
+      if (keys) rcv(i.key_rows, (size_t)n_pix, kNcclUint64, 8, q);
+      if (dkeys) rcv(i.dkey_rows, (size_t)n_pix, kNcclUint64, 8, q);
     }
   }
-  RCCL_TRY(ctx, g_rccl.GroupEnd());
+  {
+    const int r_end = g_rccl.GroupEnd();
+    if (g_err) return fail(ctx, LENTIL_ERR_HIP, std::string("ncclSend / ncclRecv: ") + g_rccl.GetErrorString(g_err));
+    if (r_end) return fail(ctx, LENTIL_ERR_HIP, std::string("ncclGroupEnd: ") + g_rccl.GetErrorString(r_end));
+  }
+  cm->last_sent = sent; cm->last_received = received;
   // ---- merge what arrived (senders in rank order: the merge of one sender's entries is not atomic against another's)
   for (int q = 0; q < world; ++q) {
     const In &i = in[(size_t)q];

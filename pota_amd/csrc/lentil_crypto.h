@@ -42,8 +42,8 @@ struct LentilCrypto {
   std::vector<void *> owned;                // device columns of lentil_hip_upload_crypto
   float *d_rank = nullptr;                  // download staging: np RGBA + np flags
   uint8_t *d_has = nullptr;
-  uint64_t auto_log = 0;                    // capacity of the draw log this module allocated (0: the log is the caller's, or none)
-  uint64_t auto_log_hint = 0;               // what the last pass needed, for the next log this module allocates
+  // (whether the draw log is this module's own, and what the last pass needed, live in the context --
+  // lentil_hip_ctx::crypto_auto_log / _hint --: alloc_frame drops this object on every camera update, the log stays)
 };
 
 // std::map<float, float> compares ids as floats: +0 and -0 are one key.  The table compares bits.
@@ -324,10 +324,8 @@ __global__ __launch_bounds__(256) void crypto_rank_kernel(CryptoDev C, uint32_t 
 
 // lentil_hip_set_draw_log: a log of the caller's is the caller's to size (an overflow is reported, the log stays)
 static void crypto_log_set_by_caller(lentil_hip_ctx *ctx) {
-  LentilCrypto *k = ctx->crypto;
-  if (!k) return;
-  if (k->auto_log > k->auto_log_hint) k->auto_log_hint = k->auto_log;
-  k->auto_log = 0;
+  if (ctx->crypto_auto_log > ctx->crypto_auto_log_hint) ctx->crypto_auto_log_hint = ctx->crypto_auto_log;
+  ctx->crypto_auto_log = 0;
 }
 
 static uint32_t crypto_count(const lentil_hip_ctx *ctx) { return ctx->crypto ? ctx->crypto->D.n_crypto : 0; }
@@ -475,10 +473,10 @@ static int crypto_before_pass(lentil_hip_ctx *ctx) {
     // no log asked for by the caller: one sized from the last pass, or 4 Mi records (48 MB; LENTIL_CRYPTO_LOG overrides)
     uint64_t want = 4ull << 20;
     if (const char *e = getenv("LENTIL_CRYPTO_LOG")) { const long long v = atoll(e); if (v > 0) want = (uint64_t)v; }
-    if (k->auto_log_hint > want) want = k->auto_log_hint;
+    if (ctx->crypto_auto_log_hint > want) want = ctx->crypto_auto_log_hint;
     const int rc = lentil_hip_set_draw_log(ctx, want);
     if (rc) return rc;
-    k->auto_log = want;
+    ctx->crypto_auto_log = want;
   }
   return LENTIL_OK;
 }
@@ -493,9 +491,9 @@ static int crypto_after_pass(lentil_hip_ctx *ctx) {
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   if (n_log > ctx->log_cap) {
     const uint64_t had = ctx->log_cap;
-    if (k->auto_log) {       // this module's own log: the next pass gets one that fits
+    if (ctx->crypto_auto_log) {       // this module's own log: the next pass gets one that fits
       (void)lentil_hip_set_draw_log(ctx, 0);
-      k->auto_log_hint = n_log + n_log / 4;
+      ctx->crypto_auto_log_hint = n_log + n_log / 4;
     }
     return fail(ctx, LENTIL_ERR_NOMEM, "the draw log (" + std::to_string(had) + " records) is too small for the cryptomatte AOVs of this pass (" +
                                            std::to_string(n_log) + " accepted draws): clear the frame and redistribute again");

@@ -164,6 +164,8 @@ struct lentil_hip_ctx {
   struct LentilUpload *upload = nullptr;   // lentil_upload.h: the visit stream handed over piece by piece
   struct LentilComm *comm = nullptr; // lentil_comm.h: this context's RCCL communicator, if one was asked for
   struct LentilCrypto *crypto = nullptr;   // lentil_crypto.h: cryptomatte AOVs, if any were allocated
+  uint64_t crypto_auto_log = 0;            // capacity of the draw log the cryptomatte replay allocated itself (0: the log is the caller's, or none)
+  uint64_t crypto_auto_log_hint = 0;       // what the last pass needed, for the next log it allocates
 };
 
 static thread_local std::string g_err;

@@ -119,7 +119,12 @@ LENTIL_API int lentil_hip_visits_begin(lentil_hip_ctx *ctx, const lentil_visits 
   if (!ctx->upload) {
     ctx->upload = new (std::nothrow) LentilUpload();
     if (!ctx->upload) return fail(ctx, LENTIL_ERR_NOMEM, "out of host memory");
-    HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->upload->stream, hipStreamNonBlocking));
+    const hipError_t e = hipStreamCreateWithFlags(&ctx->upload->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {         // (no half-made state: later begins would copy on the legacy null stream)
+      delete ctx->upload;
+      ctx->upload = nullptr;
+      return fail(ctx, LENTIL_ERR_HIP, std::string("hipStreamCreateWithFlags: ") + hipGetErrorString(e));
+    }
   }
   LentilUpload *u = ctx->upload;
   std::lock_guard<std::mutex> g(u->m);
@@ -129,6 +134,7 @@ LENTIL_API int lentil_hip_visits_begin(lentil_hip_ctx *ctx, const lentil_visits 
   if (!reuse) {                      // the previous frame's columns serve again when they fit
     upload_release(ctx, true);
     u->layout = *layout;
+    u->crypto_n = 0; u->crypto_entries = 0;       // (the previous frame's: lentil_hip_visits_begin_crypto announces this frame's, and allocates them)
     int rc = upload_reserve(ctx, u, want, 0);
     if (rc) return rc;
   }

@@ -19,7 +19,7 @@ const LentilStrings &lentil_strings() {
 
 node_parameters {
   // same names, types, defaults and order as src/lentil_camera.cpp:19-52 (lentil_camera_node_parameters());
-  // the lens_model enum lists the tables this build ships
+  // lens_model: the reference's 44 ids in its order, then this build's own tables (lentil_lens_model_table)
   int n = 0;
   const lentil_node_param *p = lentil_camera_node_parameters(&n);
   for (int i = 0; i < n; ++i) {
@@ -118,10 +118,17 @@ int LentilCamera::crypto_index(const char *name) const {
   return -1;
 }
 
+// Every camera object numbers its setups process-wide (a new object at a recycled address never repeats a number), and a
+// thread's cached slot belongs to one of them: setup() hands the slots out afresh, so a render thread that outlives a
+// camera update -- or meets another camera at the same address -- must not keep a slot a new thread may be given too
+// (two threads appending to one staging slot, unlocked).
+static std::atomic<uint64_t> g_slot_generations{0};
+
 int LentilCamera::thread_slot() {
   thread_local int slot = -1;
-  thread_local const LentilCamera *owner = nullptr;
-  if (slot < 0 || owner != this) { slot = next_slot++; owner = this; }
+  thread_local uint64_t generation = 0;
+  const uint64_t now = slot_generation.load(std::memory_order_acquire);
+  if (slot < 0 || generation != now) { slot = next_slot++; generation = now; }
   return slot;
 }
 
@@ -162,18 +169,16 @@ void LentilCamera::setup(AtUniverse *universe) {
   if (host_lens) { lentil_host_lens_destroy(host_lens); host_lens = nullptr; }
   lens_table = nullptr;
   if (P.cameraType == LENTIL_POLYNOMIAL_OPTICS) {
-    int n = 0;
-    const lentil_node_param *params = lentil_camera_node_parameters(&n);
-    const char *want = nullptr;
-    for (int i = 0; i < n; ++i)
-      if (strcmp(params[i].name, "lens_model") == 0 && params[i].enum_values) {
-        int count = 0;
-        while (params[i].enum_values[count]) ++count;
-        if (v.lens_model >= 0 && v.lens_model < count) want = params[i].enum_values[v.lens_model];
-      }
+    const char *id = lentil_lens_model_name(v.lens_model);
+    const char *want = lentil_lens_model_table(v.lens_model);
     for (int i = 0; want && i < kShippedLensCount; ++i)
       if (strcmp(kShippedLenses[i].name, want) == 0) lens_table = kShippedLenses[i].table;
-    if (!lens_table) { AiMsgError("[LENTIL] lens_model %d has no table in this build", v.lens_model); AiRenderAbort(); return; }
+    if (!lens_table) {
+      AiMsgError("[LENTIL] no polynomial table shipped for lens_model %s (%d): this build carries tables for "
+                 "angenieux__double_gauss__1953__49mm and kodak__petzval__1948__58mm (self-fitted stand-ins)", id ? id : "?", v.lens_model);
+      AiRenderAbort();
+      return;
+    }
     host_lens = lentil_host_lens_create(lens_table);
   }
   // ---- camera_model_specific_setup (src/lentil.h:1568-1670); its focus search runs on the GPU when there is one
@@ -327,6 +332,7 @@ void LentilCamera::setup(AtUniverse *universe) {
   if (stage) { lentil_stage_destroy(stage); stage = nullptr; }
   stage_slots = 256;
   next_slot = 0;
+  slot_generation.store(++g_slot_generations, std::memory_order_release);      // (cached slots of the threads are void)
   if (lentil_stage_create(stage_slots, (uint32_t)aovs.size() - 1, &stage) != LENTIL_OK ||
       lentil_imager_create(gpu, stage, &P, (uint32_t)aovs.size(), &imager) != LENTIL_OK) {
     AiMsgError("[LENTIL] could not set up the visit staging");

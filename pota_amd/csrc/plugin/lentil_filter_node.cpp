@@ -159,11 +159,11 @@ filter_pixel {
   float out[4] = {0, 0, 0, 0};
   switch (data_type) {
     case AI_TYPE_RGBA:
-      lentil_filter_gaussian_complete(n, offs, vals, dens, 0.f, cam->P.filter_width, out);
+      lentil_filter_gaussian_complete(n, offs, vals, dens, 0.f, cam->P.filter_width, AiFastExp, out);
       *((AtRGBA *)data_out) = AtRGBA(out[0], out[1], out[2], out[3]);
       break;
     case AI_TYPE_RGB:
-      lentil_filter_gaussian_complete(n, offs, vals, dens, 0.f, cam->P.filter_width, out);
+      lentil_filter_gaussian_complete(n, offs, vals, dens, 0.f, cam->P.filter_width, AiFastExp, out);
       *((AtRGB *)data_out) = AtRGB(out[0], out[1], out[2]);
       break;
     case AI_TYPE_VECTOR:

@@ -51,6 +51,7 @@ struct LentilCamera {
   lentil_imager *imager = nullptr;
   int stage_slots = 0;
   std::atomic<int> next_slot{0};
+  std::atomic<uint64_t> slot_generation{0};   // advanced by every setup(): render threads that outlive a camera update take a new slot
 
   ~LentilCamera();
   void release_gpu();

@@ -48,6 +48,9 @@
 #define AI_NODE_ALL 0xFFFF
 
 #define AI_PI 3.14159265358979323846f
+// The SDK's fast exp is an exported approximation whose bits only the SDK has.  The stand-in is deliberately NOT expf
+// (2^(x log2 e) through exp2f), so that a test can tell whether the plugin went through this function or through libm's.
+AI_API float AiFastExp(float x);
 #define AI_EPSILON 1.0e-4f
 #define AI_BIG 1.0e12f
 #define AI_INFINITE 1.0e30f

@@ -12,6 +12,7 @@
 #include <dlfcn.h>
 
 #include <atomic>
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <map>
@@ -91,6 +92,7 @@ struct AtUniverse {
   SampleStore samples;
   int xres = 0, yres = 0;
   std::map<std::string, std::vector<float>> images;     // output AOV name -> xres * yres * 4
+  std::map<std::string, std::vector<float>> display;    // the same right after filter_pixel, before the imagers edit the buckets
   std::vector<AtArray *> arrays;
   std::vector<std::string> late_outputs;                // appended to options.outputs after the operators cooked
 };
@@ -287,6 +289,7 @@ bool AiAOVSampleIteratorGetNextDepth(AtAOVSampleIterator *it) {
   if (it->cur + 1 < (int)it->ids->size()) ++it->cur;
   return false;
 }
+float AiFastExp(float x) { return exp2f(x * 1.44269504088896340736f); }       // (see ai.h: recognisably not expf)
 void AiAOVSampleIteratorGetPixel(AtAOVSampleIterator *it, int &x, int &y) { x = it->x; y = it->y; }
 static int sid(const AtAOVSampleIterator *it) { return (*it->ids)[(size_t)(it->cur < 0 ? 0 : it->cur)]; }
 AtVector2 AiAOVSampleIteratorGetOffset(AtAOVSampleIterator *it) { const int s = sid(it); return AtVector2{it->u->samples.ox[s], it->u->samples.oy[s]}; }
@@ -528,6 +531,7 @@ FA_API int fa_render(AtUniverse *u, int n_threads, int bucket_size) {
     }
     for (auto &t : ts) t.join();
   }
+  u->display = u->images;
   // 5. imagers: driver_process_bucket per bucket, in place
   for (AtNode *n : u->nodes) {
     if (!n->e->m || n->e->node_type != AI_NODE_DRIVER) continue;
@@ -578,6 +582,34 @@ FA_API int fa_get_image(AtUniverse *u, const char *aov, float *dst) {
   if (it == u->images.end()) return -1;
   memcpy(dst, it->second.data(), it->second.size() * sizeof(float));
   return 0;
+}
+// what filter_pixel returned (the display pass-through), before the imagers ran
+FA_API int fa_get_display_image(AtUniverse *u, const char *aov, float *dst) {
+  auto it = u->display.find(aov);
+  if (it == u->display.end()) return -1;
+  memcpy(dst, it->second.data(), it->second.size() * sizeof(float));
+  return 0;
+}
+// the camera node's own entry points, through its method table (what Arnold calls per camera sample):
+// in = sx, sy, dsx, dsy, lensx, lensy, relative_time; out = origin, dir, dOdx, dOdy, dDdx, dDdy, weight (21 floats)
+FA_API int fa_camera_create_ray(AtUniverse *u, const float in[7], float out[21], int tid) {
+  if (!u->camera || !u->camera->e->m || u->camera->e->node_type != AI_NODE_CAMERA) return -1;
+  const AtCameraNodeMethods *cm = (const AtCameraNodeMethods *)u->camera->e->m->dmethods;
+  AtCameraInput ci{in[0], in[1], in[2], in[3], in[4], in[5], in[6]};
+  AtCameraOutput co{};
+  cm->CreateRay(u->camera, ci, co, (uint16_t)tid);
+  const AtVector *v[6] = {&co.origin, &co.dir, &co.dOdx, &co.dOdy, &co.dDdx, &co.dDdy};
+  for (int k = 0; k < 6; ++k) { out[3 * k] = v[k]->x; out[3 * k + 1] = v[k]->y; out[3 * k + 2] = v[k]->z; }
+  out[18] = co.weight.r; out[19] = co.weight.g; out[20] = co.weight.b;
+  return 0;
+}
+FA_API int fa_camera_reverse_ray(AtUniverse *u, const float po[3], float relative_time, float ps[2]) {
+  if (!u->camera || !u->camera->e->m || u->camera->e->node_type != AI_NODE_CAMERA) return -1;
+  const AtCameraNodeMethods *cm = (const AtCameraNodeMethods *)u->camera->e->m->dmethods;
+  AtVector2 r{0.f, 0.f};
+  const bool ok = cm->ReverseRay(u->camera, AtVector(po[0], po[1], po[2]), relative_time, r);
+  ps[0] = r.x; ps[1] = r.y;
+  return ok ? 1 : 0;
 }
 FA_API int fa_filter_width_x1000(AtUniverse *u, const char *node_name) {
   AtNode *n = AiNodeLookUpByName(u, AtString(node_name));

@@ -76,6 +76,8 @@ def load():
         "orc_redistribute": (i, [C.POINTER(_abi.Params), vp, vp, vp, C.POINTER(_abi.Visits), u64, u64]),
         "orc_resolve": (None, [vp, u32, vp]),
         "orc_inverse_sample_density": (f, [i, f, i, C.POINTER(i)]),
+        "orc_filter_closest_complete": (None, [i, vp, vp, i, vp]),
+        "orc_filter_gaussian_complete": (None, [i, vp, vp, vp, i, f, i, f, vp, vp]),
         "orc_camera_get_y0_intersection_distance": (d, [vp, d, d]),
         "orc_logarithmic_focus_search": (d, [vp, d, d]),
         "orc_trace_backwards_for_fstop": (None, [vp, d, d, pd, pd]),

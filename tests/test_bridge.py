@@ -292,3 +292,70 @@ def test_imager_buckets_match_the_direct_pipeline(gpu_ctx_factory, streaming):
     assert np.all(buf[4:, :] == -7.0) and np.all(buf[:, 4:] == -7.0) and np.array_equal(buf[:4, :4], got[0][-4:, -4:])
     lib.lentil_imager_destroy(im)
     lib.lentil_stage_destroy(stage)
+
+
+def test_display_pass_through_equals_the_oracle(orc):
+    """a21: lentil_filter_gaussian_complete / _closest_complete (what lentil.so's filter_pixel returns for display)
+    against the oracle's restatement of Camera::filter_gaussian_complete / filter_closest_complete
+    (src/lentil.h:696-775), bit for bit: samples outside the filter radius, non-positive densities, adaptive and uniform
+    densities, equal and zero depths, libm's exp and an SDK-style fast exp handed in by the caller."""
+    lib = bridge.load()
+    fake = C.CDLL(os.path.join(common.ROOT, "tests", "fake_arnold", "libai_fake.so"))
+    fast_exp = C.cast(getattr(fake, "_Z9AiFastExpf"), C.c_void_p)          # (C++ linkage, like the rest of the stand-in SDK)
+    rng = np.random.default_rng(21)
+    RGBA, RGB, FLOAT, VECTOR = 6, 5, 4, 7
+    differs = 0
+    for case in range(200):
+        n = int(rng.integers(0, 40))
+        off = rng.uniform(-0.9, 0.9, (n, 2)).astype(np.float32)
+        val = rng.uniform(-2, 5, (n, 4)).astype(np.float32)
+        dens = rng.choice(np.array([1 / 9, 1 / 16, 0.0, -1.0, 0.3], np.float32), n).astype(np.float32)
+        fw = np.float32(rng.choice([1.0, 1.5, 2.0]))
+        adaptive = int(rng.integers(0, 2))
+        uniform = np.float32(1 / 9)
+        for typ in (RGBA, RGB):
+            v = val.copy()
+            if typ == RGB:
+                v[:, 3] = 1.0                   # what the plugin hands over for an RGB AOV (AtRGB -> AtRGBA)
+            for fe in (None, fast_exp):
+                got = np.zeros(4, np.float32); want = np.zeros(4, np.float32)
+                d_arr = dens if adaptive else np.full(n, uniform, np.float32)
+                lib.lentil_filter_gaussian_complete(n, off.ctypes.data, v.ctypes.data, d_arr.ctypes.data, C.c_float(0.0),
+                                                    C.c_float(fw), fe, got.ctypes.data)
+                orc.orc_filter_gaussian_complete(n, off.ctypes.data, val.ctypes.data, dens.ctypes.data, typ, C.c_float(uniform),
+                                                 adaptive, C.c_float(fw), fe, want.ctypes.data)
+                assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (case, typ, fe is not None)
+            a = np.zeros(4, np.float32); b = np.zeros(4, np.float32)
+            d_arr = dens if adaptive else np.full(n, uniform, np.float32)
+            lib.lentil_filter_gaussian_complete(n, off.ctypes.data, v.ctypes.data, d_arr.ctypes.data, C.c_float(0.0), C.c_float(fw), None, a.ctypes.data)
+            lib.lentil_filter_gaussian_complete(n, off.ctypes.data, v.ctypes.data, d_arr.ctypes.data, C.c_float(0.0), C.c_float(fw), fast_exp, b.ctypes.data)
+            differs += int(not np.array_equal(a, b))
+        depth = rng.choice(np.array([0.0, 1.0, -1.0, 2.5, 7.0, -7.0], np.float32), n).astype(np.float32)
+        for typ in (VECTOR, FLOAT):
+            v = val.copy()
+            if typ == FLOAT:
+                v[:, 1] = v[:, 0]; v[:, 2] = v[:, 0]
+            v[:, 3] = 1.0
+            got = np.zeros(4, np.float32); want = np.zeros(4, np.float32)
+            lib.lentil_filter_closest_complete(n, depth.ctypes.data, v.ctypes.data, got.ctypes.data)
+            orc.orc_filter_closest_complete(n, depth.ctypes.data, val.ctypes.data, typ, want.ctypes.data)
+            assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (case, typ)
+    assert differs > 50            # the caller's exp function is the one that is used
+
+
+def test_lens_model_enum_is_the_references():
+    """lens_model keeps the reference's ids and numbers (include/auto_generated_lens_includes/pota_h_lenses.h:4-47; default
+    cooke__speed_panchro__1920__40mm, src/lentil_camera.cpp:29): a scene written for the reference parses.  Tables ship for
+    two of the ids (stand-ins), the rest are refused by name at camera update."""
+    lib = bridge.load()
+    d = {w["name"]: w for w in bridge.camera_node_parameters()}["lens_model"]
+    ids = d["enum_values"]
+    assert len(ids) == 47 and ids[0] == "angenieux__double_gauss__1953__49mm" and ids[43] == "zeiss__biotar__1927__45mm"
+    assert ids[int(d["default"])] == "cooke__speed_panchro__1920__40mm" and int(d["default"]) == 16
+    assert ids[25] == "kodak__petzval__1948__58mm" and ids[20] == "kodak__petzval__1948__150mm"
+    assert [i for i in ids[:44] if i.count("__") != 3] == []            # maker__design__year__focal-length
+    assert ids[44:] == ["double_gauss_50mm", "petzval_58mm", "anamorphic_petzval_58mm"]
+    assert lib.lentil_lens_model_name(0) == b"angenieux__double_gauss__1953__49mm"
+    assert lib.lentil_lens_model_table(0) == b"double_gauss_50mm" and lib.lentil_lens_model_table(25) == b"petzval_58mm"
+    assert lib.lentil_lens_model_table(16) is None and lib.lentil_lens_model_table(46) == b"anamorphic_petzval_58mm"
+    assert lib.lentil_lens_model_name(47) is None and lib.lentil_lens_model_name(-1) is None

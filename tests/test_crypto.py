@@ -275,6 +275,44 @@ def test_crypto_error_paths(orc, gpu_ctx_factory):
     orc.orc_lens_destroy(lens)
 
 
+@pytest.mark.gpu
+def test_crypto_log_bookkeeping_survives_a_camera_update(orc, gpu_ctx_factory, monkeypatch):
+    """lentil.so calls lentil_hip_alloc_frame on every camera update, which drops the cryptomatte state; the draw log the
+    replay allocated itself stays.  A later frame with more accepted draws than that log holds must still find the log
+    marked as the library's own: the pass reports NOMEM once, sizes the log, and the retry (what the bridge does) fits."""
+    monkeypatch.setenv("LENTIL_CRYPTO_LOG", "2000")
+    W, H, M = 48, 32, 9
+    p, model, table, keep = common.po_setup(W, H, samples_override=32)
+    ctx = gpu_ctx_factory()
+    ctx.set_params(p); ctx.set_lens(table)
+    lens = orc.orc_lens_create(C.byref(table))
+    for frame, f_hi in enumerate((0.004, 0.03)):              # frame 2 accepts ~8x the draws of frame 1
+        visits, cols = common.make_stream(p, W, H, M, f_hi=f_hi, seed=0x5EED + frame)
+        hashes, weights = make_crypto_columns(visits.n, W, M, 1, 4)
+        cv, keepc = capi.make_crypto_visits(hashes, weights)
+        ctx.alloc_frame(1)                                    # the camera update: drops the tables and their state
+        ctx.alloc_crypto(1, 0)
+        ctx.upload_visits(visits)
+        ctx.upload_crypto(cv)
+        ctx.clear_frame()
+        try:
+            ctx.redistribute()
+            retried = False
+        except capi.LentilError as e:
+            assert "draw log" in str(e)
+            ctx.clear_frame()
+            ctx.redistribute()                                # the library's log now fits
+            retried = True
+        assert retried == (frame == 1)
+        ref = oracle_lib.Frame(orc, p, n_aovs=1)
+        ref.set_crypto(hashes, weights)
+        ref.run(lens, None, visits)
+        assert ref.counters().accepted_draws > (2000 if frame else 100)
+        compare_tables(ctx, ref, 1, p.xres * p.yres)
+        ref.close()
+    orc.orc_lens_destroy(lens)
+
+
 # ----------------------------------------------------------------------------------------------------------------
 # the plugin side: liblentil_bridge.so
 # ----------------------------------------------------------------------------------------------------------------

@@ -37,7 +37,7 @@ def fa():
               "fa_add_output", "fa_output_count", "fa_output", "fa_set_samples", "fa_set_aov", "fa_render", "fa_get_image",
               "fa_cook_operators", "fa_universe_destroy", "fa_node_exists", "fa_aov_shader_count", "fa_render_hint",
               "fa_filter_width_x1000", "fa_options", "fa_set_depths", "fa_set_depth_aov", "fa_add_late_output",
-              "fa_add_aov_shader"):
+              "fa_add_aov_shader", "fa_get_display_image", "fa_camera_create_ray", "fa_camera_reverse_ray"):
         getattr(lib, f).argtypes = None
     assert lib.fa_load_plugin(PLUGIN.encode()) == 4
     return lib
@@ -61,10 +61,10 @@ def test_camera_parameters_match_the_reference_list(fa):
     want = bridge.camera_node_parameters()
     assert fa.fa_entry_param_count(b"lentil_camera") == len(want) == 29
     name = C.create_string_buffer(128)
-    s = C.create_string_buffer(1024)
+    s = C.create_string_buffer(4096)
     typ, num = C.c_int(), C.c_double()
     for i, w in enumerate(want):
-        assert fa.fa_entry_param(b"lentil_camera", i, name, 128, C.byref(typ), C.byref(num), s, 1024) == 0
+        assert fa.fa_entry_param(b"lentil_camera", i, name, 128, C.byref(typ), C.byref(num), s, 4096) == 0
         assert name.value.decode() == w["name"]
         assert typ.value == w["type"]
         if w["type"] == AI_TYPE["STRING"]:
@@ -126,29 +126,67 @@ def test_operator_cook_rewires_the_outputs(fa):
     fa.fa_universe_destroy(C.c_void_p(u))
 
 
-def test_shipped_mtd_lists_the_camera_parameters():
-    """pota_amd/plugin/lentil.mtd (tools/gen_mtd.py) against the parameter table and against the reference's own
-    lentil.mtd (tests/golden/lentil.mtd: generated here from src/lentil_camera.ui by the reference's uigen.py and
-    concatenated with its hardcoded part like src/CMakeLists.txt:47-67 does; tools/make_mtd_fixture.py)."""
+def test_a_reference_lens_id_without_a_table_is_refused_by_name(fa):
+    """A scene written for the reference: lens_model is one of its 44 ids (here the node's default,
+    cooke__speed_panchro__1920__40mm, src/lentil_camera.cpp:29).  The id parses; in polynomial-optics mode the camera
+    update says which table is missing and aborts the render (AiMsgError + AiRenderAbort, like src/lentil.h:225-228)."""
+    fa.fa_messages_clear()
+    u, cam = _scene(fa, 32, 24, ["RGBA RGBA gaussian_filter driver_exr"])
+    fa.fa_node_set_int(C.c_void_p(cam), b"camera_type", 1)                 # PolynomialOptics, lens_model left at its default
+    assert fa.fa_render(C.c_void_p(u), 2, 16) == -1
+    assert "no polynomial table shipped for lens_model cooke__speed_panchro__1920__40mm (16)" in _messages(fa)
+    fa.fa_universe_destroy(C.c_void_p(u))
+    fa.fa_messages_clear()
+
+
+def test_shipped_mtd_equals_the_references_in_everything_a_translator_acts_on():
+    """pota_amd/plugin/lentil.mtd (tools/gen_mtd.py) against the reference's own lentil.mtd (tests/golden/lentil.mtd:
+    generated here from src/lentil_camera.ui by the reference's uigen.py and concatenated with src/lentil_hardcode.mtd
+    like src/CMakeLists.txt:47-67 does; tools/make_mtd_fixture.py): the same nodes, node-level keys, attributes, and per
+    attribute the same keys with the same types and VALUES -- labels, ranges, linkability, disable rules, Maya node ids,
+    hidden imager attributes, the operator's block commented out.  Only the free-text descriptions are this repo's own."""
     import re
+    FREE_TEXT = ("desc", "houdini.help")
 
     def parse(path):
-        nodes, cur, attrs = {}, None, None
+        nodes, node, attr, pending = {}, None, None, None
         for line in open(path):
-            m = re.match(r"\s*\[node (\w+)\]", line)
-            if m and not line.lstrip().startswith("#"):
-                cur = m.group(1); attrs = nodes.setdefault(cur, [])
+            t = line.strip()
+            if not t or t.startswith("#"):
                 continue
-            m = re.match(r"\s*\[attr (\w+)\]", line)
-            if m and cur and not line.lstrip().startswith("#"):
-                attrs.append(m.group(1))
+            m = re.match(r"\[node (\w+)\]", t)
+            if m:
+                node = nodes.setdefault(m.group(1), {"keys": {}, "attrs": {}}); attr = None; pending = None
+                continue
+            m = re.match(r"\[attr (\w+)\]", t)
+            if m:
+                attr = node["attrs"].setdefault(m.group(1), {}); pending = None
+                continue
+            m = re.match(r"([\w\.]+)\s+(\w+)\s+(.*)$", t)
+            if m:
+                tgt = attr if attr is not None else node["keys"]
+                tgt[m.group(1)] = [m.group(2), m.group(3).strip()]
+                pending = tgt[m.group(1)]
+            elif t.startswith('"') and pending is not None:       # a string continued on the next line (houdini.order)
+                pending[1] += " " + t
         return nodes
     ours = parse(os.path.join(common.ROOT, "pota_amd", "plugin", "lentil.mtd"))
     ref = parse(os.path.join(common.ROOT, "tests", "golden", "lentil.mtd"))
     want = [w["name"] for w in bridge.camera_node_parameters()]
-    assert ours["lentil_camera"] == want
-    assert sorted(ref["lentil_camera"]) == sorted(want)         # (the .ui lists them by UI group, not by declaration)
-    assert set(ref) <= set(ours) and {"lentil_camera", "imager_lentil", "lentil_filter"} <= set(ours)
+    assert list(ours["lentil_camera"]["attrs"]) == want          # declaration order
+    assert sorted(ref["lentil_camera"]["attrs"]) == sorted(want)  # (the .ui lists them by UI group)
+    assert sorted(ours) == sorted(ref) == ["imager_lentil", "lentil_camera", "lentil_filter"]
+    n_values = 0
+    for node in ref:
+        strip = lambda d: {k: v for k, v in d.items() if k not in FREE_TEXT}
+        assert strip(ours[node]["keys"]) == strip(ref[node]["keys"]), node
+        assert sorted(ours[node]["attrs"]) == sorted(ref[node]["attrs"]), node
+        for a, kv in ref[node]["attrs"].items():
+            assert strip(ours[node]["attrs"][a]) == strip(kv), (node, a)
+            assert set(ours[node]["attrs"][a]) == set(kv), (node, a)           # (the free-text keys exist on both sides)
+            n_values += len(strip(kv))
+    assert n_values > 150
+    assert ours["imager_lentil"]["attrs"] == {"layer_selection": {"maya.hide": ["BOOL", "false"]}, "input": {"maya.hide": ["BOOL", "TRUE"]}}
 
 
 @pytest.mark.gpu
@@ -217,6 +255,79 @@ def test_frame_through_the_plugin_matches_the_oracle(fa, orc, monkeypatch):
         err = float(np.max(np.abs(got[m].astype(np.float64) - want[m]) / np.abs(want[m])))
         assert err < 2e-5, (name, err)      # two fp32 sums in different orders (ragged capture order vs iterator order)
     ref.close()
+
+    # ---- a21: what filter_pixel itself returned (the display pass-through, before the imager overwrote the buckets):
+    # Camera::filter_gaussian_complete for the RGBA / RGB outputs, filter_closest_complete for the FLOAT one
+    # (src/lentil_filter.cpp:453-479, src/lentil.h:696-775), with the stand-in SDK's AiFastExp -- bit for bit
+    fast_exp = C.cast(getattr(fa, "_Z9AiFastExpf"), C.c_void_p)
+    off = np.ascontiguousarray(np.stack([ox, oy], 1))
+    zf = np.ascontiguousarray(z4[:, 0])
+    shown = {"RGBA": (AI_TYPE["RGBA"], np.ascontiguousarray(cols["rgba"])),
+             "diffuse": (AI_TYPE["RGB"], np.ascontiguousarray(cols["extra"][0])),
+             "lentil_raydir": (AI_TYPE["RGB"], np.ascontiguousarray(cols["raydir_time"])),
+             "lentil_debug": (AI_TYPE["FLOAT"], np.zeros((n, 4), np.float32))}
+    for name, (typ, vals) in shown.items():
+        got = np.zeros((H, W, 4), np.float32)
+        assert fa.fa_get_display_image(C.c_void_p(u), name.encode(), got.ctypes.data_as(C.c_void_p)) == 0
+        want = np.zeros((H, W, 4), np.float32)
+        out = np.zeros(4, np.float32)
+        for q in range(W * H):
+            a, b = q * M, (q + 1) * M
+            if typ == AI_TYPE["FLOAT"]:
+                orc.orc_filter_closest_complete(M, zf[a:b].ctypes.data, vals[a:b].ctypes.data, typ, out.ctypes.data)
+            else:
+                orc.orc_filter_gaussian_complete(M, off[a:b].ctypes.data, vals[a:b].ctypes.data, invd[a:b].ctypes.data, typ,
+                                                 C.c_float(1.0 / 9.0), 0, C.c_float(1.0), fast_exp, out.ctypes.data)
+            nc = 4 if typ == AI_TYPE["RGBA"] else (1 if typ == AI_TYPE["FLOAT"] else 3)
+            want[q // W, q % W, :nc] = out[:nc]
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), name
+        if name == "RGBA":
+            assert float(np.abs(got).max()) > 0.1
+
+    # ---- f2: camera_create_ray / camera_reverse_ray through lentil.so's method table (src/lentil_camera.cpp:78-172)
+    # against the oracle's forward trace (Camera::trace_ray_fw_po, src/lentil.h:283-427) and the finite differences of
+    # :95-118.  Lens points near the axis: no vignetting retry, so the thread's xor128 stream is not consulted.
+    import math
+    lens2 = orc.orc_lens_create(C.byref(table))
+    lam = float(np.float32(550.0)) * 0.001
+    step = np.float32(0.001)
+    inv_step = np.float32(1.0) / step                        # AtVector / float: a multiplication by 1 / f (SDK, recalled)
+    rg = np.random.default_rng(3)
+    n_checked = 0
+    for _ in range(200):
+        sx, sy = np.float32(rg.uniform(-0.8, 0.8)), np.float32(rg.uniform(-0.4, 0.4))
+        dsx, dsy = np.float32(rg.uniform(0.5, 2.0)), np.float32(rg.uniform(0.5, 2.0))
+        lx, ly = np.float32(rg.uniform(0.3, 0.7)), np.float32(rg.uniform(0.3, 0.7))
+        inp = (C.c_float * 7)(sx, sy, dsx, dsy, lx, ly, 0.0)
+        outp = (C.c_float * 21)()
+        assert fa.fa_camera_create_ray(C.c_void_p(u), inp, outp, 0) == 0
+        got = np.array(list(outp), np.float32)
+
+        def trace(tsx, tsy, deriv, r):
+            st = (C.c_uint32 * 4)(); orc.orc_xor128_init(st)
+            o, d, w = (C.c_float * 3)(), (C.c_float * 3)(), (C.c_float * 3)(1, 1, 1)
+            tr = C.c_int()
+            orc.orc_trace_ray_fw_po(C.byref(p), lens2, None, st, lam, float(tsx), float(tsy), C.byref(r[0]), C.byref(r[1]), deriv, o, d, w, C.byref(tr))
+            return np.array(list(o), np.float32), np.array(list(d), np.float32), np.array(list(w), np.float32), tr.value
+        r = (C.c_double(float(lx)), C.c_double(float(ly)))
+        o0, d0, w0, t0 = trace(sx, sy, 0, r)
+        if t0:                      # a retry would draw from the thread's generator: not this check's subject
+            continue
+        sxd, syd = np.float32(sx + dsx * step), np.float32(sy + dsy * step)
+        o1, d1, _, _ = trace(sxd, sy, 1, r)
+        o2, d2, _, _ = trace(sx, syd, 1, r)
+        want = np.concatenate([o0, d0, (o1 - o0) * inv_step, (o2 - o0) * inv_step, (d1 - d0) * inv_step, (d2 - d0) * inv_step,
+                               w0 * np.float32(1.0)]).astype(np.float32)
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (sx, sy, got, want)
+        n_checked += 1
+    assert n_checked > 150
+    orc.orc_lens_destroy(lens2)
+    tan_fov = math.tan(model.spec["constants"]["lens_field_of_view"] / 2.0)
+    for po in ((10.0, 5.0, -100.0), (-3.0, 0.5, -0.001), (0.25, -0.75, 40.0)):
+        ps = (C.c_float * 2)()
+        assert fa.fa_camera_reverse_ray(C.c_void_p(u), (C.c_float * 3)(*po), C.c_float(0.0), ps) == 1
+        coeff = 1.0 / max(abs(float(np.float32(po[2])) * tan_fov), 1e-3)
+        assert ps[0] == np.float32(float(np.float32(po[0])) * coeff) and ps[1] == np.float32(float(np.float32(po[1])) * coeff)
     fa.fa_universe_destroy(C.c_void_p(u))
 
 
