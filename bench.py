@@ -384,7 +384,9 @@ class Bench:
             acc["iters"] += int(k.newton_iterations); acc["attempted"] += int(k.attempted_draws)
             acc["lane_rounds"] += int(k.lane_rounds); acc["tries"] += int(k.tries); acc["slow"] += int(k.slow_solves)
             acc["accepted"] += int(k.accepted_draws); acc["redistributed"] += int(k.redistributed_visits)
-            acc["scan_launches"] += max(1, self.ctx.last_launches()[0])
+            ll = self.ctx.last_launches()
+            acc["scan_launches"] += max(1, ll[0])
+            acc["rounds_max"] = max(acc.get("rounds_max", 0), int(ll[1]))
         if self.world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -619,7 +621,7 @@ def main():
         },
         "exchange": exchange, "ranks_joined": ranks_joined,
         "passes": {"timed": steps, "streamed": r["streamed"], "chunks_enqueued_blind": r["blind_chunks"],
-                   "chunks_redone_after_a_short_estimate": r["redone"]},
+                   "chunks_redone_after_a_short_estimate": r["redone"], "solve_accept_rounds_max": r.get("rounds_max")},
         "kernels_ms": {"scan": round(r["scan"] / steps, 4), "draw": round(r["draw"] / steps, 4), "resolve": round(r["resolve"] / steps, 4)},
         "roofline": {
             "kernel": scan_kernel, "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,

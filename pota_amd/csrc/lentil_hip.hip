@@ -130,8 +130,12 @@ struct lentil_hip_ctx {
   hipEvent_t scans_done = nullptr;   // after the last chunk's scan of a pass
   bool overlap_rounds = true;        // LENTIL_OVERLAP_ROUNDS=0: a streamed pass's second round starts after its first accept has ended
   bool slow_live = true;             // LENTIL_SLOW_LIVE=0: stragglers of a streamed pass wait for their round's solve kernel to end
-  int crowd_stays_first = 0, crowd_stays_later = 1;    // LENTIL_CROWD_STAYS=ab (two digits): DrawArgs::slow_crowd_stays of a streamed pass's first / later rounds
+  int crowd_stays_first = 0, crowd_stays_later = 0;    // LENTIL_CROWD_STAYS=ab (two digits): DrawArgs::slow_crowd_stays of a streamed pass's first / later rounds
   bool solve_b = false;              // LENTIL_SOLVE_B=1: the second solve launch behind the scan (its blocks only find room when the first launch's leave: measured idle)
+  uint32_t unknown_credit = 7;        // LENTIL_UNKNOWN_CREDIT (0..8): DrawArgs::unknown_credit
+  bool chain_streams = true;          // LENTIL_CHAIN_STREAMS=0: a decoupled pass keeps its accepts on the main stream
+  hipEvent_t ev_solve = nullptr, ev_slow1 = nullptr;
+  hipStream_t slow1_stream = nullptr;   // a decoupled pass's second-round straggler kernel (beside the first round's, which is still at work)
   bool decouple = true;              // LENTIL_DECOUPLE=0: a streamed pass's first accept waits for the first round's stragglers
   hipEvent_t ev_slow = nullptr, ev_round = nullptr;
   // A streamed pass resolves the frame while its second round is still solving (the chip's HBM is idle then) and, at the
@@ -236,6 +240,9 @@ LENTIL_API int lentil_hip_create(int device, lentil_hip_ctx **out_ctx) {
   HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->pub_done, hipEventDisableTiming));
   HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_acc1, hipEventDisableTiming));
   HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_res, hipEventDisableTiming));
+  HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_solve, hipEventDisableTiming));
+  HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_slow1, hipEventDisableTiming));
+  HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->slow1_stream, hipStreamNonBlocking));
   if (const char *e = getenv("LENTIL_EARLY_RESOLVE")) ctx->early_resolve = atoi(e) != 0;
   if (const char *ft = getenv("LENTIL_FORCE_TABLES")) ctx->use_generated = !(ft[0] == '1');
   if (const char *fc = getenv("LENTIL_FIRST_CHUNK_FRAC")) {
@@ -266,6 +273,8 @@ LENTIL_API int lentil_hip_create(int device, lentil_hip_ctx **out_ctx) {
   if (const char *e = getenv("LENTIL_SLOW_LIVE")) ctx->slow_live = !(e[0] == '0');
   if (const char *e = getenv("LENTIL_OVERLAP_ROUNDS")) ctx->overlap_rounds = !(e[0] == '0');
   if (const char *e = getenv("LENTIL_DECOUPLE")) ctx->decouple = !(e[0] == '0');
+  if (const char *e = getenv("LENTIL_CHAIN_STREAMS")) ctx->chain_streams = !(e[0] == '0');
+  if (const char *e = getenv("LENTIL_UNKNOWN_CREDIT")) { const int v = atoi(e); ctx->unknown_credit = (uint32_t)(v < 0 ? 0 : (v > 8 ? 8 : v)); }
   if (const char *e = getenv("LENTIL_CROWD_STAYS")) { ctx->crowd_stays_first = e[0] == '1'; ctx->crowd_stays_later = e[0] && e[1] == '1'; }
   if (const char *e = getenv("LENTIL_SOLVE_B")) ctx->solve_b = e[0] == '1';
   if (const char *e = getenv("LENTIL_STREAM_BELOW")) ctx->stream_below = strtoull(e, nullptr, 10);
@@ -287,11 +296,14 @@ LENTIL_API int lentil_hip_create(int device, lentil_hip_ctx **out_ctx) {
     DrawArgs w{};
     w.ctr = ctx->d_ctr;        // zeroed above: no active items, the kernels return at once
     const unsigned wg = (unsigned)ctx->num_cu * 8u;       // (the runtime sizes the scratch by the grid: the largest any pass launches)
-    hipLaunchKernelGGL(accept_kernel<0>, dim3(wg), dim3(256), 0, ctx->stream, w);
-    hipLaunchKernelGGL(accept_kernel<1>, dim3(wg), dim3(256), 0, ctx->stream, w);
-    hipLaunchKernelGGL(accept_kernel<2>, dim3(wg), dim3(256), 0, ctx->stream, w);
-    HIP_TRY(ctx, hipGetLastError());
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    hipStream_t on[3] = {ctx->stream, ctx->chunks[0].stream, ctx->pub_stream};      // (where a streamed pass launches them)
+    for (hipStream_t st : on) {
+      hipLaunchKernelGGL(accept_kernel<0>, dim3(wg), dim3(256), 0, st, w);
+      hipLaunchKernelGGL(accept_kernel<1>, dim3(wg), dim3(256), 0, st, w);
+      hipLaunchKernelGGL(accept_kernel<2>, dim3(wg), dim3(256), 0, st, w);
+      HIP_TRY(ctx, hipGetLastError());
+      HIP_TRY(ctx, hipStreamSynchronize(st));
+    }
   }
   *out_ctx = ctx;
   return LENTIL_OK;
@@ -361,6 +373,9 @@ LENTIL_API int lentil_hip_destroy(lentil_hip_ctx *ctx) {
   if (ctx->ev_round) (void)hipEventDestroy(ctx->ev_round);
   if (ctx->ev_acc1) (void)hipEventDestroy(ctx->ev_acc1);
   if (ctx->ev_res) (void)hipEventDestroy(ctx->ev_res);
+  if (ctx->ev_solve) (void)hipEventDestroy(ctx->ev_solve);
+  if (ctx->ev_slow1) (void)hipEventDestroy(ctx->ev_slow1);
+  if (ctx->slow1_stream) { (void)hipStreamSynchronize(ctx->slow1_stream); (void)hipStreamDestroy(ctx->slow1_stream); }
   (void)hipFree(ctx->d_ctr);
   if (ctx->h_ctr_pinned) (void)hipHostFree(ctx->h_ctr_pinned);
   (void)hipFree(ctx->d_ranges);
@@ -1249,7 +1264,10 @@ static int launch_scan(lentil_hip_ctx *ctx, const ScanPlan &pl, const lentil_hip
   } else {
     blocks = (ch.v_end - ch.v_begin + 255) / 256;
     if (blocks > max_blocks) blocks = max_blocks;
-    hipLaunchKernelGGL(scan_ragged_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, sa);
+    // runs of a pixel's visits are summed in their order (LENTIL_SCAN_RUNS=0: an atomic per visit and float, any order)
+    static const bool runs = !(getenv("LENTIL_SCAN_RUNS") && getenv("LENTIL_SCAN_RUNS")[0] == '0');
+    if (runs) hipLaunchKernelGGL(scan_runs_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, sa);
+    else hipLaunchKernelGGL(scan_ragged_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, sa);
   }
   HIP_TRY(ctx, hipGetLastError());
   if (blocks_out) *blocks_out = (unsigned)blocks;
@@ -1395,6 +1413,7 @@ static int redistribute_streamed(lentil_hip_ctx *ctx, bool *streamed) {
   SlowRec *const slow_base = da.slow;
   const uint32_t slow_cap_all = da.slow_cap;
   da.slow_crowd_stays = ctx->crowd_stays_first;
+  da.unknown_credit = ctx->unknown_credit;
   if (decoupled) { da.slow_indirect = 1; da.slow_cap = slow_cap_all / 2u > (uint32_t)ctx->num_cu ? slow_cap_all / 2u - (uint32_t)ctx->num_cu : 0u; }      // (its end markers stay below the upper half)
   const unsigned b_threads = live ? 192u : 256u;
   unsigned b_blocks;
@@ -1431,6 +1450,90 @@ static int redistribute_streamed(lentil_hip_ctx *ctx, bool *streamed) {
   HIP_TRY(ctx, hipGetLastError());
   HIP_TRY(ctx, hipEventRecord(ch.done, ch.stream));
 
+  const uint64_t acc_max = (uint64_t)ctx->num_cu * (uint64_t)(ctx->accept_stream_blocks < 1 ? 1 : ctx->accept_stream_blocks);
+  const uint64_t acc_want = ctx->est_items_total + ctx->est_items_total / 4 + 1;
+  const unsigned accept_blocks = (unsigned)(acc_want > acc_max ? acc_max : acc_want);
+  hipStream_t tail = ctx->stream;       // the stream the pass's last kernels and its counter read-back are on
+  if (decoupled && ctx->chain_streams) {
+    // ---- the decoupled pass with its chain of kernels laid along streams: a dependency that crosses streams costs
+    // 40-90 us (event, barrier packet, a queue waking up) where a kernel behind its predecessor on ONE stream costs ~2:
+    //   chunk stream : A -> first accept                      (the accept starts as the last first-round solve ends)
+    //   main stream  : scan -> second round's solves          (released by what the first accept waited for)
+    //   straggler st.: publishers -> stragglers of round one -> of round two -> second accept -> later rounds' accepts
+    //                  -> the resolve's second half -> counter read-back       (each behind the kernel it ends last)
+    // The only cross-stream waits left on the critical path release kernels that then sit waiting for tasks anyway.
+    hipStream_t ps = ctx->pub_stream;
+    HIP_TRY(ctx, hipStreamWaitEvent(ch.stream, ctx->pub_done, 0));       // (both long past when A ends)
+    HIP_TRY(ctx, hipStreamWaitEvent(ch.stream, ctx->scans_done, 0));
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_round, ch.stream));
+    {
+      DrawArgs d0 = da;
+      d0.emit_live = 1;
+      d0.end_tasks = (uint32_t)ctx->num_cu * 4u;
+      hipLaunchKernelGGL(accept_kernel<1>, dim3(accept_blocks), dim3(256), 0, ch.stream, d0);
+      HIP_TRY(ctx, hipGetLastError());
+    }
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_acc1, ch.stream));
+    if (ctx->early_resolve && ctx->F.dir && ctx->F.touched && ctx->n_chunks >= 2 && !ctx->comm && !ctx->closest_deferred) {
+      hipStream_t rs = ctx->chunks[1].stream;
+      HIP_TRY(ctx, hipStreamWaitEvent(rs, ctx->ev_acc1, 0));
+      if ((rc = launch_resolve_half(ctx, rs, 0u))) return rc;
+      HIP_TRY(ctx, hipEventRecord(ctx->ev_res, rs));
+      ctx->early_resolve_pending = true;
+    }
+    for (int round = 1; round < blind_rounds; ++round) {
+      da.parity = round & 1; da.round = round;
+      DrawArgs d1 = da;
+      d1.slow_crowd_stays = ctx->crowd_stays_later;
+      d1.slow_indirect = 0;
+      if (round == 1) {
+        d1.no_reset = 1;
+        d1.producers_done = &ctx->d_ctr->accept_done[0];
+        d1.producers_total = accept_blocks;
+        d1.slow = slow_base + slow_cap_all / 2u;
+        d1.slow_cap = slow_cap_all - slow_cap_all / 2u - d1.slow_waves;
+        HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_round, 0));
+        launch_solve_po<true>(ctx, d1, ctx->stream, (unsigned)ctx->num_cu);
+      } else {
+        d1.producers_done = nullptr; d1.producers_total = 0;
+        d1.slow_cap = slow_cap_all;
+        HIP_TRY(ctx, hipEventRecord(ctx->ev_round, ps));                   // behind the accept that filled this round's queues
+        HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_round, 0));
+        launch_solve_po<false>(ctx, d1, ctx->stream, (unsigned)ctx->num_cu);
+      }
+      HIP_TRY(ctx, hipGetLastError());
+      HIP_TRY(ctx, hipEventRecord(ctx->ev_solve, ctx->stream));
+      if (round == 1) {
+        // (on a stream of its own: the first round's straggler kernel, ahead of everything on `ps`, is at work for another
+        // ~0.25 ms -- its last records come when A ends -- and this round's parked solves need not wait for it)
+        HIP_TRY(ctx, hipStreamWaitEvent(ctx->slow1_stream, ctx->ev_round, 0));
+        hipLaunchKernelGGL(solve_slow_kernel, dim3(d1.slow_waves), dim3(64), 0, ctx->slow1_stream, d1);
+        HIP_TRY(ctx, hipEventRecord(ctx->ev_slow1, ctx->slow1_stream));
+        HIP_TRY(ctx, hipStreamWaitEvent(ps, ctx->ev_slow1, 0));
+      } else {
+        hipLaunchKernelGGL(solve_slow_kernel, dim3(d1.slow_waves), dim3(64), 0, ps, d1);      // beside the round's solves
+      }
+      HIP_TRY(ctx, hipStreamWaitEvent(ps, ctx->ev_solve, 0));
+      if (round == 1) {
+        HIP_TRY(ctx, hipStreamWaitEvent(ps, ctx->ev_acc1, 0));
+        // (the first round's queues can go back to empty for what the accept below schedules; its result pool is still read)
+        hipLaunchKernelGGL(reset_round_kernel, dim3(1), dim3(1), 0, ps, ctx->d_ctr, 0u, 1u);
+        hipLaunchKernelGGL(accept_kernel<2>, dim3(accept_blocks), dim3(256), 0, ps, da);
+        da.slow_cap = slow_cap_all;
+      } else {
+        hipLaunchKernelGGL(accept_kernel<0>, dim3(accept_blocks), dim3(256), 0, ps, da);
+      }
+      HIP_TRY(ctx, hipGetLastError());
+    }
+    da.slow_indirect = 0; da.slow_cap = slow_cap_all;
+    da.slow_live = 0;
+    if (ctx->early_resolve_pending) {
+      HIP_TRY(ctx, hipStreamWaitEvent(ps, ctx->ev_res, 0));
+      if ((rc = launch_resolve_half(ctx, ps, 1u))) return rc;
+      ctx->late_resolve_done = true;
+    }
+    tail = ps;
+  } else {
   // B: the rest of the CUs' room, once the scan's waves have left
   da.instance = 1;
   if (b_blocks) launch_solve_po<true>(ctx, da, ctx->stream, b_blocks, b_threads);
@@ -1439,9 +1542,6 @@ static int redistribute_streamed(lentil_hip_ctx *ctx, bool *streamed) {
   HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->pub_done, 0));
   if (live && !decoupled) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_slow, 0));
   else if (!live) launch_slow(ctx, da, ctx->stream);
-  const uint64_t acc_max = (uint64_t)ctx->num_cu * (uint64_t)(ctx->accept_stream_blocks < 1 ? 1 : ctx->accept_stream_blocks);
-  const uint64_t acc_want = ctx->est_items_total + ctx->est_items_total / 4 + 1;
-  const unsigned accept_blocks = (unsigned)(acc_want > acc_max ? acc_max : acc_want);
   {
     DrawArgs d0 = da;
     d0.emit_live = overlap ? 1 : 0;
@@ -1513,9 +1613,15 @@ static int redistribute_streamed(lentil_hip_ctx *ctx, bool *streamed) {
     if ((rc = launch_resolve_half(ctx, ctx->stream, 1u))) return rc;
     ctx->late_resolve_done = true;
   }
+  }
   const int C = ctx->n_chunks;
-  HIP_TRY(ctx, hipMemcpyAsync(ctx->h_ctr_pinned, ctx->d_ctr, sizeof(DevCounters) * C, hipMemcpyDeviceToHost, ctx->stream));
-  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->h_ctr_pinned, ctx->d_ctr, sizeof(DevCounters) * C, hipMemcpyDeviceToHost, tail));
+  HIP_TRY(ctx, hipStreamSynchronize(tail));
+  if (tail != ctx->stream) {
+    // everything the pass enqueued anywhere is behind the read-back that has just arrived; what the caller enqueues on
+    // the context's stream next (resolve, downloads, the next pass) follows the main stream's own last kernel
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  }
   ctx->h_ctr.assign(ctx->h_ctr_pinned, ctx->h_ctr_pinned + C);
   ctx->h_ctr_valid = true;
   ctx->last_streamed = 1;

@@ -1012,6 +1012,126 @@ __global__ __launch_bounds__(256) void scan_ragged_kernel(ScanArgs a) {
   flush_row_range(a.ctr, rmin, rmax_p1);
   scan_block_done(a);
 }
+// K1+K2+K6 for ragged streams, ordered.  A capturing filter_pixel appends the samples of ONE pixel, in iterator order, as a
+// run of consecutive visits (src/lentil_filter.cpp:105 walks them; include/lentil_bridge.h, lentil_stage_append); the
+// runs of different pixels arrive in whatever order the render threads got to them.  scan_ragged_kernel above adds
+// every visit with atomics of its own: the own-pixel sums then take their roundings in arbitrary order (2e-5 of the
+// reference's sequential sum).  Here a run is added up in its order -- the reference's (src/lentil.h:938-955) -- by the
+// lane of its first visit, from values the wave staged in LDS with coalesced loads, and lands in the pixel record as one
+// atomic add per float: on a cleared record that is the sequential sum, bit for bit (a pixel is filtered once per
+// frame, so its record meets one run).  A run that leaves the wave's 64 visits is followed into the next ones (their
+// own lanes see that they continue a run and add nothing).  A stream without runs degenerates to a visit per run:
+// what scan_ragged_kernel does.
+__global__ __launch_bounds__(256) void scan_runs_kernel(ScanArgs a) {
+  const VisitsDev &V = a.V;
+  __shared__ uint2 s_queue[4 * kWaveQueueLds];
+  __shared__ float4 s_val[4][64];
+  __shared__ float s_w[4][64];
+  __shared__ uint32_t s_pix[4][64];
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  WaveQueue wq;
+  wq.init(s_queue + wave * kWaveQueueLds);
+  const uint64_t n_groups = (a.v_end - a.v_begin + 63ull) / 64ull;
+  const uint64_t wave_global = (uint64_t)blockIdx.x * 4u + wave, wave_stride = (uint64_t)gridDim.x * 4u;
+  uint32_t rmin = 0x7FFFFFFFu, rmax_p1 = 0u;
+  constexpr uint32_t kNoPixel = 0xFFFFFFFFu;
+  // what visit u adds to its own pixel: weight (0: redistributed) and weighted value of column `col`
+  auto own = [&](uint64_t u, const float4 *col, float &w) -> float4 {
+    const float invd = V.inv_density ? V.inv_density[u] : a.P.inverse_sample_density;
+    const bool red = visit_redistributes(a.P, a.lens_length, V.pos_z[u], V.volume_ignore[u], V.transmission[u], invd,
+                                         [&]() { return V.raydir_time[u]; });
+    w = red ? 0.0f : 1.0f * invd;
+    if (red) return make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 c = col[u];
+    return make_float4((c.x + 0.0f) * w, (c.y + 0.0f) * w, (c.z + 0.0f) * w, (c.w + 0.0f) * w);
+  };
+  for (uint64_t g = wave_global; g < n_groups; g += wave_stride) {
+    const uint64_t v = a.v_begin + g * 64ull + lane;
+    const bool valid = v < a.v_end;
+    const uint32_t pix = valid ? V.pixel[v] : kNoPixel;
+    uint32_t prev = __shfl_up(pix, 1);
+    if (lane == 0) prev = v > 0 ? V.pixel[v - 1] : kNoPixel;      // (a run may have begun in the chunk before)
+    if (v == 0) prev = kNoPixel;
+    const bool start = valid && pix != prev;
+    bool flagged = false;
+    int samples = 0;
+    float w = 0.f;
+    float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (valid) {
+      const float4 rgba = V.rgba[v];
+      const float invd = V.inv_density ? V.inv_density[v] : a.P.inverse_sample_density;
+      const float4 pz = V.pos_z[v], vi = V.volume_ignore[v], tr = V.transmission[v];
+      if (visit_redistributes(a.P, a.lens_length, pz, vi, tr, invd, [&]() { return V.raydir_time[v]; })) {
+        flagged = true;
+        samples = visit_prologue(a.P, a.lens_length, rgba, pz, V.raydir_time[v], vi, tr, invd).samples;
+      } else {
+        w = 1.0f * invd;
+        val = make_float4((rgba.x + 0.0f) * w, (rgba.y + 0.0f) * w, (rgba.z + 0.0f) * w, (rgba.w + 0.0f) * w);
+        if (a.F.zkey) {
+          const uint32_t px = pix & 0xFFFFu, py = pix >> 16;
+          atomicMin(a.F.zkey + ((uint64_t)px + (uint64_t)py * a.P.xres), closest_key(pz.w, visit_gid(V, (uint32_t)v)));
+        }
+      }
+    }
+    wq.push(flagged, (uint32_t)v, (uint32_t)samples, a);
+    wq.end_tile(a);
+    s_pix[wave][lane] = pix;
+    s_w[wave][lane] = w;
+    const uint32_t px = pix & 0xFFFFu, py = pix >> 16;
+    const uint64_t lin = (uint64_t)px + (uint64_t)py * a.P.xres;
+    if (start) {
+      rmin = py < rmin ? py : rmin;
+      rmax_p1 = py + 1u > rmax_p1 ? py + 1u : rmax_p1;
+    }
+    // the beauty, then every gaussian AOV column: staged by all lanes, summed per run in order by the run's first lane
+    for (uint32_t k = 0; k <= V.n_extra; ++k) {
+      if (k && (a.F.closest_mask & (1u << k))) continue;          // closest AOVs are gathered from the winners later
+      if (k) {
+        val = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (valid && w != 0.0f) {
+          const float4 c = V.extra[k - 1][v];
+          val = make_float4((c.x + 0.0f) * w, (c.y + 0.0f) * w, (c.z + 0.0f) * w, (c.w + 0.0f) * w);
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+      __builtin_amdgcn_wave_barrier();
+      s_val[wave][lane] = val;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
+      if (start) {
+        float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+        float ws = 0.f;
+        uint32_t j = lane;
+        for (; j < 64u && s_pix[wave][j] == pix; ++j) {
+          const float4 c = s_val[wave][j];
+          sum.x += c.x; sum.y += c.y; sum.z += c.z; sum.w += c.w;
+          ws += s_w[wave][j];
+        }
+        if (j == 64u) {
+          // the run goes on beyond this wave's visits
+          const float4 *col = k ? V.extra[k - 1] : V.rgba;
+          for (uint64_t u = a.v_begin + g * 64ull + 64ull; u < V.n && V.pixel[u] == pix; ++u) {
+            float wu;
+            const float4 c = own(u, col, wu);
+            sum.x += c.x; sum.y += c.y; sum.z += c.z; sum.w += c.w;
+            ws += wu;
+          }
+        }
+        float *d = reinterpret_cast<float *>(a.F.aov(lin, k));
+        // (a visit that adds nothing left +0; an accumulator is never -0: adding the sum to a cleared record stores it)
+        atomicAdd(d + 0, sum.x); atomicAdd(d + 1, sum.y); atomicAdd(d + 2, sum.z); atomicAdd(d + 3, sum.w);
+        if (k == 0) atomicAdd(a.F.wt(lin), ws);
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+    __builtin_amdgcn_wave_barrier();
+  }
+  wq.finish(a);
+  flush_row_range(a.ctr, rmin, rmax_p1);
+  scan_block_done(a);
+}
+
 // ---------------------------------------------------------------------------------------
 // Streamed pass, stage two: publish_kernel.  A handful of one-wave blocks that follow the scan's range queue and
 // turn every announced work-list entry into an item (publish_item): header, progress record, result space, the
@@ -1195,6 +1315,7 @@ struct DrawArgs {
   // `slow_round`, only the launch with slow_close set closes the queue, and the first round parks `slow_indirect`:
   // the first accept does not wait for the stragglers (accept_item<1>).  Defaults (-1, -1, 1, 0): a queue per round.
   int32_t slow_q, slow_round, slow_close, slow_indirect;
+  uint32_t unknown_credit;    // accept_item<1>: eighths of the known attempts' success rate credited to the unknown ones (0: none)
   int32_t slow_crowd_stays;   // live queue: where more than slow_max_lanes lanes of a wave are past slow_at at once, none is parked
 };
 LD_DEV uint32_t slow_queue(const DrawArgs &a) { return a.slow_q >= 0 ? (uint32_t)a.slow_q : (uint32_t)a.parity; }
@@ -2111,6 +2232,18 @@ LD_DEV AcceptResult accept_item(const DrawArgs &a, AcceptShared &sh, uint32_t it
     r.prog = pg;
     r.prog.n_done = n; r.prog.accepted = acc; r.prog.last_ok = last_ok;
     r.prog.uacc = kMode == 1 ? uacc : 0u;
+    if (kMode == 1 && uacc && a.unknown_credit) {
+      // What the next batch is sized from.  Counting every unknown attempt as a failure is safe and costly: unknowns come
+      // in clusters -- in a headline frame ten items near the frame's edge, where the lens vignettes, hold all of them,
+      // ~500 each (their solves run 20-40 iterations, are parked, and 83 % of them fail -- after which the attempt simply
+      // moves on to its next try and mostly succeeds) -- and the batches that pessimism sends those items are as slow as
+      // their first ones: thousands of parked solves for 256 straggler waves.  So the unknown attempts are credited with
+      // unknown_credit / 8 of the success rate of the item's known ones.  Where that is too generous by a few attempts
+      // the first batch's spare ones (DrawArgs::extra_const) make up for it; beyond that the item costs a third round.
+      const uint32_t known = n > uacc ? n - uacc : 1u;
+      const unsigned long long est = (unsigned long long)acc + ((unsigned long long)uacc * acc * a.unknown_credit) / (8ull * known);
+      acc = est < S ? (uint32_t)est : S;
+    }
     r.more = acc < S && n < max_total && pg.m_hi < m_limit && pg.m_hi > 0;
     r.new_lo = pg.m_hi;
     r.new_hi = pg.m_hi;
