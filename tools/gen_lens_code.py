@@ -110,13 +110,107 @@ class Emitter:
         self.lines.append("  %s = %s;" % (target, tmp))
 
 
+class PrefetchEmitter:
+    """eval_bw with its coefficient loads written out: `s_load_dwordx16` of the next 8 coefficients into the other of
+    two SGPR blocks is issued BEFORE the current 8 terms are computed, and waited for (lgkmcnt(0): scalar loads return out
+    of order, so that is the only count that means anything) only when its terms come up.  The compiler's own placement
+    (load, wait at once, compute) exposes the scalar cache's latency 60 times per Newton iteration -- what one wave
+    alone on a SIMD spends half its time on.  The lambda powers are read from LDS once, ahead of the first load, so that
+    no LDS wait of the compiler's falls between a prefetch and its use."""
+    CHUNK = 8
+
+    def __init__(self, coef):
+        self.coef = coef
+        self.base = len(coef)
+        self.terms = []          # (poly index, expression with C? placeholder)
+        self.targets = []
+        self.pows = {}
+        self.pow_lines = []
+        self.lp_used = set()
+
+    def power(self, var, e):
+        key = (var, e)
+        if key in self.pows:
+            return self.pows[key]
+        v = VARS[var]
+        name = "%s_%d" % (v, e)
+        if e == 2:
+            self.pow_lines.append("  const double %s = %s * %s;" % (name, v, v))
+        else:
+            h = e // 2
+            p2 = v if h == 1 else self.power(var, h)
+            if e & 1:
+                self.pow_lines.append("  const double %s = %s * %s * %s;" % (name, v, p2, p2))
+            else:
+                self.pow_lines.append("  const double %s = %s * %s;" % (name, p2, p2))
+        self.pows[key] = name
+        return name
+
+    def poly(self, target, terms):
+        pi = len(self.targets)
+        self.targets.append((target, len(terms)))
+        for c, e in terms:
+            for var in range(4):
+                if e[var] >= 2:
+                    self.power(var, e[var])
+            self.coef.append(float(c))
+            f = []
+            for var in range(4):
+                if e[var] == 1:
+                    f.append(VARS[var])
+                elif e[var] >= 2:
+                    f.append(self.pows[(var, e[var])])
+            if e[4] >= 1:
+                self.lp_used.add(e[4])
+                f.append("lp%d" % e[4])
+            self.terms.append((pi, f))
+
+    def lines(self):
+        # pad the coefficient array: whole blocks, plus one the last prefetch may touch
+        while (len(self.coef) - self.base) % self.CHUNK:
+            self.coef.append(0.0)
+        for _ in range(self.CHUNK):
+            self.coef.append(0.0)
+        L = []
+        for e in sorted(self.lp_used):
+            L.append("  const double lp%d = lp[%d];" % (e, e))
+        L.extend(self.pow_lines)
+        L.append("  lentil_v8d ca, cb;")
+        L.append("  LENTIL_SLOAD8(ca, C, %d);" % (self.base * 8))
+        started = set()
+        n_chunks = (len(self.terms) + self.CHUNK - 1) // self.CHUNK
+        touched = []
+        for j in range(n_chunks):
+            cur, nxt = ("ca", "cb") if j % 2 == 0 else ("cb", "ca")
+            # (the wait also consumes what the chunk before it computed: the compiler may not push those terms behind
+            # this point -- it would keep block after block of coefficients alive and spill them through VGPR lanes)
+            if touched:
+                L.append("  LENTIL_SWAIT_AFTER%d(%s, %s);" % (len(touched), cur, ", ".join("acc%d" % t for t in touched)))
+            else:
+                L.append("  LENTIL_SWAIT(%s);" % cur)
+            touched = sorted(set(pi for pi, f in self.terms[j * self.CHUNK:(j + 1) * self.CHUNK]))
+            if j + 1 < n_chunks:
+                L.append("  LENTIL_SLOAD8(%s, C, %d);" % (nxt, (self.base + (j + 1) * self.CHUNK) * 8))
+            for i, (pi, f) in enumerate(self.terms[j * self.CHUNK:(j + 1) * self.CHUNK]):
+                expr = " * ".join(["%s[%d]" % (cur, i)] + f)
+                if pi in started:
+                    L.append("  acc%d = acc%d + %s;" % (pi, pi, expr))
+                else:
+                    L.append("  double acc%d = %s;" % (pi, expr))
+                    started.add(pi)
+        for pi, (target, n) in enumerate(self.targets):
+            L.append("  %s = %s;" % (target, ("acc%d" % pi) if n else "0.0"))
+        return L
+
+
 def gen_lens(name, spec):
     polys = spec["polys"]
     dap = [[derive(polys["ap_" + a], 2 + j) for j in range(2)] for a in ("x", "y")]
     dout = [[derive(polys["out_" + a], j) for j in range(2)] for a in ("dx", "dy")]
     coef = []
     cname = "kCoef_%s" % name
-    em = Emitter(coef, "C")
+    prefetch = os.environ.get("LENTIL_GEN_PREFETCH", "1") != "0"
+    em = PrefetchEmitter(coef) if prefetch else Emitter(coef, "C")
     em.poly("pred_ap[0]", polys["ap_x"])
     em.poly("pred_ap[1]", polys["ap_y"])
     for i in range(2):
@@ -127,6 +221,7 @@ def gen_lens(name, spec):
     for i in range(2):
         for j in range(2):
             em.poly("Jout[%d]" % (i * 2 + j), dout[i][j])
+    em_lines = em.lines() if prefetch else em.lines
     et = Emitter(coef, "C")
     et.poly("const double t", polys["out_t"])
     n_terms = sum(len(polys[n]) for n in OUT_NAMES + AP_NAMES)
@@ -143,6 +238,16 @@ def gen_lens(name, spec):
     src.append("  const __attribute__((address_space(4))) double *NAME = (const __attribute__((address_space(4))) double *)(ARR); \\")
     src.append("  asm volatile(\"\" : \"+s\"(NAME))")
     src.append("#endif")
+    src.append("#ifndef LENTIL_SLOAD8")
+    src.append("// eight coefficients = 16 SGPRs, loaded by hand (PrefetchEmitter in tools/gen_lens_code.py says why); the wait takes the")
+    src.append("// block as an in/out operand, so that no use of it can be scheduled ahead of the wait")
+    src.append("typedef double lentil_v8d __attribute__((ext_vector_type(8)));")
+    src.append("#define LENTIL_SLOAD8(DST, PTR, BYTES) asm volatile(\"s_load_dwordx16 %0, %1, \" #BYTES : \"=s\"(DST) : \"s\"(PTR))")
+    src.append("#define LENTIL_SWAIT(BLK) asm volatile(\"s_waitcnt lgkmcnt(0)\" : \"+s\"(BLK))")
+    src.append("#define LENTIL_SWAIT_AFTER1(BLK, A) asm volatile(\"s_waitcnt lgkmcnt(0)\" : \"+s\"(BLK) : \"v\"(A))")
+    src.append("#define LENTIL_SWAIT_AFTER2(BLK, A, B) asm volatile(\"s_waitcnt lgkmcnt(0)\" : \"+s\"(BLK) : \"v\"(A), \"v\"(B))")
+    src.append("#define LENTIL_SWAIT_AFTER3(BLK, A, B, D) asm volatile(\"s_waitcnt lgkmcnt(0)\" : \"+s\"(BLK) : \"v\"(A), \"v\"(B), \"v\"(D))")
+    src.append("#endif")
     src.append("namespace lentil { namespace gen {")
     src.append("// coefficients in order of use (base terms and c*e derivative terms); constant address space,")
     src.append("// uniform indices -> the compiler fetches them with wide scalar loads (s_load_dwordx8/x16)")
@@ -157,7 +262,7 @@ def gen_lens(name, spec):
     src.append("                                                 double Jap[4], double out[4], double Jout[4]) {")
     src.append("  const double x = v[0], y = v[1], dx = v[2], dy = v[3];")
     src.append("  LENTIL_COEF_PTR(C, %s);" % cname)
-    src.extend(em.lines)
+    src.extend(em_lines)
     src.append("  }")
     src.append("  static __device__ __forceinline__ double transmittance(const double v[4], const double *lp) {")
     src.append("  const double x = v[0], y = v[1], dx = v[2], dy = v[3];")
@@ -175,6 +280,8 @@ def gen_lens(name, spec):
 def main():
     os.makedirs(OUT_DIR, exist_ok=True)
     names = sorted(f[:-5] for f in os.listdir(LENS_DIR) if f.endswith(".json"))
+    only = os.environ.get("LENTIL_GEN_LENSES", "double_gauss_50mm,petzval_58mm")     # (every compiled lens is four more solve kernels to build)
+    names = [n for n in names if n in only.split(",")]
     reg = ["// GENERATED by tools/gen_lens_code.py -- the lenses compiled into liblentil_hip.so.",
            "#pragma once"]
     for n in names:
