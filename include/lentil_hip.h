@@ -259,6 +259,16 @@ int lentil_hip_lens_is_compiled(lentil_hip_ctx *ctx);
 int lentil_hip_set_lens_mode(lentil_hip_ctx *ctx, int mode);
 int lentil_hip_alloc_frame(lentil_hip_ctx *ctx, uint32_t n_aovs, const uint8_t *aov_filter_kind);
 
+/* A moving camera.  The reference asks Arnold for the matrix at every AOV sample's own time:
+ * AiWorldToCameraMatrix(camera_node, lentil_time) (src/lentil_filter.cpp:141-144).  Here the caller hands over n_keys
+ * world-to-camera matrices (row-vector convention like lentil_params::world_to_camera) at equidistant shutter-relative
+ * times 0 ... 1 -- the camera's matrix keys, or samples of AiWorldToCameraMatrix at those times -- and every visit uses
+ * the component-wise interpolation ((b - a) * f) + a of the two keys around its lentil_time (raydir_time column, .w;
+ * clamped to [0, 1]).  n_keys <= 1 or NULL: the static matrix of lentil_params again.  With keys the scan reads the
+ * raydir_time column for every visit (80 instead of 64 bytes moved per visit) and runs register-staged. */
+#define LENTIL_MAX_MOTION_KEYS 16
+int lentil_hip_set_camera_motion(lentil_hip_ctx *ctx, uint32_t n_keys, const float *world_to_camera);
+
 /* Camera::logarithmic_focus_search (src/lentil.h:1445-1460; called per camera update at :1632): the sensor
  * shift, among the 20 001 candidates of logarithmic_values() (src/lens.h:395-407), whose axial ray crosses
  * the optical axis closest in front of focal_distance (mm).  One GPU lane per candidate instead of the

@@ -844,6 +844,12 @@ struct OrcFrame {
   };
   std::vector<Crypto> crypto;
   uint32_t crypto_entries = 0;
+  /* A moving camera: AiWorldToCameraMatrix(camera, time) (src/lentil_filter.cpp:141-144) as the linear interpolation of
+   * n_cam_keys matrices at equidistant shutter-relative times 0 ... 1 (orc_frame_set_camera_motion).  How Arnold itself
+   * interpolates a camera's matrix keys is the SDK's business and not in the reference tree: parity unpinned; the
+   * component-wise AiLerp form ((b - a) * t) + a is what this oracle and the HIP path share. */
+  std::vector<float> cam_keys;
+  uint32_t n_cam_keys = 0;
 };
 
 ORC_API OrcFrame *orc_frame_create(uint32_t xres, uint32_t yres, uint32_t n_aovs, const uint8_t *kind,
@@ -881,6 +887,11 @@ ORC_API uint64_t orc_frame_log(const OrcFrame *F, lentil_draw_record *out, uint6
   if (out && n) memcpy(out, F->log.data(), n * sizeof(lentil_draw_record));
   return F->log.size();
 }
+ORC_API void orc_frame_set_camera_motion(OrcFrame *F, uint32_t n_keys, const float *world_to_camera) {
+  F->n_cam_keys = n_keys >= 2 ? n_keys : 0;
+  F->cam_keys.assign(world_to_camera, world_to_camera + (size_t)F->n_cam_keys * 16);
+}
+
 ORC_API void orc_frame_merge(OrcFrame *dst, const OrcFrame *src) {   /* per-thread private buffers summed */
   for (uint32_t a = 0; a < dst->n_aovs; a++)
     for (size_t i = 0; i < dst->buffer[a].size(); i++) dst->buffer[a][i] += src->buffer[a][i];
@@ -1107,7 +1118,20 @@ static void do_visit(const lentil_params *P, const OrcLens *L, const OrcBokeh *B
   if (maxrgb(&V->volume_ignore[v * 4]) > 0.0) redistribute = false;                 /* :135-137 */
 
   float cs[3];
-  m4_point(P->world_to_camera, sample_pos_ws, cs);                                  /* :144 */
+  if (F->n_cam_keys >= 2) {                                                         /* :141-143, per-sample camera time */
+    float t = V->raydir_time[v * 4 + 3];
+    t = t < 0.0f ? 0.0f : (t > 1.0f ? 1.0f : t);
+    const float sc = t * (float)(F->n_cam_keys - 1);
+    uint32_t i0 = (uint32_t)sc;
+    if (i0 > F->n_cam_keys - 2) i0 = F->n_cam_keys - 2;
+    const float f = sc - (float)i0;
+    const float *ka = &F->cam_keys[(size_t)i0 * 16], *kb = ka + 16;
+    float m[4][4];
+    for (int r = 0; r < 4; r++) for (int c = 0; c < 4; c++) m[r][c] = ((kb[r * 4 + c] - ka[r * 4 + c]) * f) + ka[r * 4 + c];
+    m4_point(m, sample_pos_ws, cs);
+  } else {
+    m4_point(P->world_to_camera, sample_pos_ws, cs);                                /* :144 */
+  }
   switch (P->unitModel) {                                                           /* :145-150 */
     /* AtVector::operator*=(float): the double literals narrow to float at the call */
     case LENTIL_UNIT_MM: for (int i = 0; i < 3; i++) cs[i] *= 0.1f; break;

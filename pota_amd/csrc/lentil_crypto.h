@@ -84,7 +84,7 @@ __global__ __launch_bounds__(256) void crypto_direct_kernel(CryptoDev C, VisitsD
   for (uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; v < V.n; v += stride) {
     const float invd = V.inv_density ? V.inv_density[v] : P.inverse_sample_density;
     if (visit_redistributes(P, lens_length, V.pos_z[v], V.volume_ignore[v], V.transmission[v], invd,
-                            [&]() { return V.raydir_time[v]; }))
+                            [&]() { return V.raydir_time[v]; }, V.cam))
       continue;
     int px, py;
     visit_pixel(V, v, px, py);
@@ -111,7 +111,7 @@ __global__ __launch_bounds__(256) void crypto_direct_owner_kernel(CryptoDev C, V
         const uint64_t v = q * V.visits_per_pixel + m;
         const float invd = V.inv_density ? V.inv_density[v] : P.inverse_sample_density;
         if (visit_redistributes(P, lens_length, V.pos_z[v], V.volume_ignore[v], V.transmission[v], invd,
-                                [&]() { return V.raydir_time[v]; }))
+                                [&]() { return V.raydir_time[v]; }, V.cam))
           continue;
         total += invd;                                                                    // :815
         const float *h = C.hash[c] + v * C.entries, *w = C.weight[c] + v * C.entries;
@@ -179,7 +179,7 @@ __global__ __launch_bounds__(128) void crypto_direct_tile_kernel(CryptoDev C, Vi
         if (i >= nv) continue;
         const uint64_t v = v0 + i;
         const float invd = V.inv_density ? V.inv_density[v] : P.inverse_sample_density;
-        const bool redistributed = visit_redistributes(P, lens_length, pz[u], vi[u], tr[u], invd, [&]() { return V.raydir_time[v]; });
+        const bool redistributed = visit_redistributes(P, lens_length, pz[u], vi[u], tr[u], invd, [&]() { return V.raydir_time[v]; }, V.cam);
         s_w[i] = redistributed ? __uint_as_float(kCryptoEmpty) : invd;
       }
     }
@@ -284,7 +284,7 @@ __global__ __launch_bounds__(256) void crypto_draws_kernel(CryptoDev C, VisitsDe
     const uint32_t v = log[i].visit;
     const float invd = V.inv_density ? V.inv_density[v] : P.inverse_sample_density;
     const VisitInfo I = visit_prologue(P, lens_length, V.rgba[v], V.pos_z[v], V.raydir_time[v], V.volume_ignore[v],
-                                       V.transmission[v], invd);
+                                       V.transmission[v], invd, V.cam);
     const float inv_samples = (float)(1.0 / (double)(float)(int)I.samples);            // src/lentil_filter.cpp:199
     crypto_add_visit(C, log[i].pixel, v, invd * inv_samples);
   }

@@ -631,6 +631,26 @@ LD_DEV void v3norm(float &x, float &y, float &z) {    // AiV3Normalize
 // Visit prologue shared by the scan kernel and the draw kernels:
 // src/lentil_filter.cpp:105-165,173-202,240.
 // ---------------------------------------------------------------------------------------
+// A moving camera (lentil_hip_set_camera_motion): n >= 2 world-to-camera matrices, row-vector convention like
+// lentil_params::world_to_camera, at equidistant shutter-relative times 0 ... 1; a visit's matrix is the component-wise
+// interpolation ((b - a) * f) + a of the two keys around its lentil_time (src/lentil_filter.cpp:141-144).  n < 2: the
+// static matrix of the parameters.
+struct CamMotion {
+  const float *keys;
+  uint32_t n;
+};
+// column `c` of the visit's matrix (what one camera-space coordinate needs), rows 0..3
+LD_DEV void cam_column(const lentil_params &P, const CamMotion &cm, float time, int c, float col[4]) {
+  if (cm.n < 2u) { for (int r = 0; r < 4; ++r) col[r] = P.world_to_camera[r][c]; return; }
+  float t = time < 0.0f ? 0.0f : (time > 1.0f ? 1.0f : time);
+  const float sc = t * (float)(cm.n - 1u);
+  uint32_t i0 = (uint32_t)sc;
+  if (i0 > cm.n - 2u) i0 = cm.n - 2u;
+  const float f = sc - (float)i0;
+  const float *ka = cm.keys + (size_t)i0 * 16u, *kb = ka + 16;
+  for (int r = 0; r < 4; ++r) col[r] = ((kb[r * 4 + c] - ka[r * 4 + c]) * f) + ka[r * 4 + c];
+}
+
 struct VisitInfo {
   bool redistribute;
   int samples;
@@ -644,7 +664,7 @@ struct VisitInfo {
 // everything that only feeds the draw count.  `raydir` is only read for visits at infinite depth.
 template <class RaydirLoad>
 LD_DEV bool visit_redistributes(const lentil_params &P, double lens_length, float4 pos_z, float4 volume_ignore,
-                                float4 transmission, float inv_density, RaydirLoad load_raydir) {
+                                float4 transmission, float inv_density, RaydirLoad load_raydir, const CamMotion &cm = CamMotion{nullptr, 0u}) {
   bool redistribute = true;
   if (P.adaptive_sampling) { if (inv_density > 0.2f) redistribute = false; }
   float wx = pos_z.x, wy = pos_z.y, wz = pos_z.z;
@@ -658,8 +678,9 @@ LD_DEV bool visit_redistributes(const lentil_params &P, double lens_length, floa
   }
   if (far && !P.enable_skydome) redistribute = false;
   if (fmaxf(fmaxf(volume_ignore.x, volume_ignore.y), volume_ignore.z) > 0.0f) redistribute = false;
-  const float(*m)[4] = P.world_to_camera;
-  float cz = wx * m[0][2] + wy * m[1][2] + wz * m[2][2] + m[3][2];
+  float mz[4];
+  cam_column(P, cm, cm.n >= 2u ? load_raydir().w : 0.0f, 2, mz);      // (a moving camera reads the visit's lentil_time)
+  float cz = wx * mz[0] + wy * mz[1] + wz * mz[2] + mz[3];
   float scale = 1.0f;
   if (P.unitModel == LENTIL_UNIT_MM) scale = 0.1f;
   else if (P.unitModel == LENTIL_UNIT_DM) scale = 10.0f;
@@ -675,7 +696,8 @@ LD_DEV bool visit_redistributes(const lentil_params &P, double lens_length, floa
 
 // camera-space position of a visit (the part of visit_prologue below that the item header needs; same arithmetic)
 template <class RaydirLoad>
-LD_DEV void visit_camera_space(const lentil_params &P, float4 pos_z, RaydirLoad load_raydir, float cs[3]) {
+LD_DEV void visit_camera_space(const lentil_params &P, float4 pos_z, RaydirLoad load_raydir, float cs[3],
+                               const CamMotion &cm = CamMotion{nullptr, 0u}) {
   float wx = pos_z.x, wy = pos_z.y, wz = pos_z.z;
   const float depth = pos_z.w;
   const bool small = fabsf(wx) < kAiEpsilon && fabsf(wy) < kAiEpsilon && fabsf(wz) < kAiEpsilon;
@@ -686,10 +708,12 @@ LD_DEV void visit_camera_space(const lentil_params &P, float4 pos_z, RaydirLoad 
       wx = raydir_time.x * 100000000.0f; wy = raydir_time.y * 100000000.0f; wz = raydir_time.z * 100000000.0f;
     }
   }
-  const float(*m)[4] = P.world_to_camera;
-  float cx = wx * m[0][0] + wy * m[1][0] + wz * m[2][0] + m[3][0];
-  float cy = wx * m[0][1] + wy * m[1][1] + wz * m[2][1] + m[3][1];
-  float cz = wx * m[0][2] + wy * m[1][2] + wz * m[2][2] + m[3][2];
+  float m0[4], m1[4], m2[4];
+  const float time = cm.n >= 2u ? load_raydir().w : 0.0f;
+  cam_column(P, cm, time, 0, m0); cam_column(P, cm, time, 1, m1); cam_column(P, cm, time, 2, m2);
+  float cx = wx * m0[0] + wy * m0[1] + wz * m0[2] + m0[3];
+  float cy = wx * m1[0] + wy * m1[1] + wz * m1[2] + m1[3];
+  float cz = wx * m2[0] + wy * m2[1] + wz * m2[2] + m2[3];
   float scale = 1.0f;
   if (P.unitModel == LENTIL_UNIT_MM) scale = 0.1f;
   else if (P.unitModel == LENTIL_UNIT_DM) scale = 10.0f;
@@ -699,7 +723,7 @@ LD_DEV void visit_camera_space(const lentil_params &P, float4 pos_z, RaydirLoad 
 
 LD_DEV VisitInfo visit_prologue(const lentil_params &P, double lens_length, float4 rgba, float4 pos_z,
                                 float4 raydir_time, float4 volume_ignore, float4 transmission,
-                                float inv_density) {
+                                float inv_density, const CamMotion &cm = CamMotion{nullptr, 0u}) {
   VisitInfo I;
   bool redistribute = true;
   if (P.adaptive_sampling) { if (inv_density > 0.2f) redistribute = false; }
@@ -714,10 +738,11 @@ LD_DEV VisitInfo visit_prologue(const lentil_params &P, double lens_length, floa
   if (far && !P.enable_skydome) redistribute = false;
   if (fmaxf(fmaxf(volume_ignore.x, volume_ignore.y), volume_ignore.z) > 0.0f) redistribute = false;
 
-  const float(*m)[4] = P.world_to_camera;
-  float cx = wx * m[0][0] + wy * m[1][0] + wz * m[2][0] + m[3][0];
-  float cy = wx * m[0][1] + wy * m[1][1] + wz * m[2][1] + m[3][1];
-  float cz = wx * m[0][2] + wy * m[1][2] + wz * m[2][2] + m[3][2];
+  float m0[4], m1[4], m2[4];
+  cam_column(P, cm, raydir_time.w, 0, m0); cam_column(P, cm, raydir_time.w, 1, m1); cam_column(P, cm, raydir_time.w, 2, m2);
+  float cx = wx * m0[0] + wy * m0[1] + wz * m0[2] + m0[3];
+  float cy = wx * m1[0] + wy * m1[1] + wz * m1[2] + m1[3];
+  float cz = wx * m2[0] + wy * m2[1] + wz * m2[2] + m2[3];
   float scale = 1.0f;
   if (P.unitModel == LENTIL_UNIT_MM) scale = 0.1f;
   else if (P.unitModel == LENTIL_UNIT_DM) scale = 10.0f;

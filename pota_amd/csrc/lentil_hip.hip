@@ -165,6 +165,8 @@ struct lentil_hip_ctx {
   uint2 *d_tlc_tasks = nullptr;
   uint64_t tlc_res_cap = 0, tlc_off_cap = 0, tlc_tasks_cap = 0;
   double lens_housing_radius = 0.0;  // lens_aperture_housing_radius of the current table (focus search)
+  float *d_cam_keys = nullptr;        // lentil_hip_set_camera_motion
+  uint32_t n_cam_keys = 0;
   struct LentilUpload *upload = nullptr;   // lentil_upload.h: the visit stream handed over piece by piece
   struct LentilComm *comm = nullptr; // lentil_comm.h: this context's RCCL communicator, if one was asked for
   struct LentilCrypto *crypto = nullptr;   // lentil_crypto.h: cryptomatte AOVs, if any were allocated
@@ -173,6 +175,7 @@ struct lentil_hip_ctx {
 };
 
 static thread_local std::string g_err;
+static void apply_camera_motion(lentil_hip_ctx *ctx);
 
 // One streamed pass at a time per device and process: its solve waves are resident while they wait for the scan's
 // output, and the waves of two such passes can fill the CUs' register files between them before either scan is
@@ -352,6 +355,7 @@ LENTIL_API int lentil_hip_destroy(lentil_hip_ctx *ctx) {
   (void)hipFree(ctx->d_lens);
   (void)hipFree(ctx->d_terms);
   (void)hipFree(ctx->d_blade_sc);
+  (void)hipFree(ctx->d_cam_keys);
   (void)hipFree(ctx->F.acc);
   (void)hipFree(ctx->F.zkey);
   (void)hipFree(ctx->F.zkey_dbg);
@@ -566,6 +570,22 @@ LENTIL_API int lentil_hip_set_bokeh(lentil_hip_ctx *ctx, const lentil_bokeh_tabl
   return LENTIL_OK;
 }
 
+LENTIL_API int lentil_hip_set_camera_motion(lentil_hip_ctx *ctx, uint32_t n_keys, const float *w2c) {
+  CHECK_CTX(ctx);
+  if (n_keys > LENTIL_MAX_MOTION_KEYS) return fail(ctx, LENTIL_ERR_INVALID, "more than LENTIL_MAX_MOTION_KEYS camera matrices");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));        // (no pass is reading the old keys)
+  if (n_keys < 2 || !w2c) {
+    ctx->n_cam_keys = 0;
+  } else {
+    if (!ctx->d_cam_keys) HIP_TRY(ctx, hipMalloc(&ctx->d_cam_keys, sizeof(float) * 16 * LENTIL_MAX_MOTION_KEYS));
+    HIP_TRY(ctx, hipMemcpy(ctx->d_cam_keys, w2c, sizeof(float) * 16 * n_keys, hipMemcpyHostToDevice));
+    ctx->n_cam_keys = n_keys;
+  }
+  apply_camera_motion(ctx);
+  return LENTIL_OK;
+}
+
 LENTIL_API int lentil_hip_alloc_frame(lentil_hip_ctx *ctx, uint32_t n_aovs, const uint8_t *kind) {
   CHECK_CTX(ctx);
   ctx->resolved_valid = false;         // (what an early resolve left in d_resolved no longer describes the frame)
@@ -647,6 +667,11 @@ static int check_visits(lentil_hip_ctx *ctx, const lentil_visits *v) {
   return LENTIL_OK;
 }
 
+static void apply_camera_motion(lentil_hip_ctx *ctx) {
+  ctx->V.cam.keys = ctx->n_cam_keys >= 2 ? ctx->d_cam_keys : nullptr;
+  ctx->V.cam.n = ctx->n_cam_keys >= 2 ? ctx->n_cam_keys : 0u;
+}
+
 static void to_dev(VisitsDev &d, const lentil_visits *v) {
   d.n = v->n;
   d.visits_per_pixel = v->visits_per_pixel;
@@ -664,6 +689,7 @@ static void to_dev(VisitsDev &d, const lentil_visits *v) {
   d.pixel = v->pixel;
   d.inv_density = v->inv_density;
   d.id_base = 0;
+  d.cam = CamMotion{nullptr, 0u};
 }
 
 static int ensure_worklist(lentil_hip_ctx *ctx, uint64_t n) {
@@ -690,6 +716,7 @@ LENTIL_API int lentil_hip_bind_visits(lentil_hip_ctx *ctx, const lentil_visits *
   free_visits(ctx);
   upload_release(ctx, true);
   to_dev(ctx->V, v);
+  apply_camera_motion(ctx);
   ctx->V.id_base = ctx->visit_id_base;
   rc = ensure_worklist(ctx, v->n);
   if (rc) return rc;
@@ -728,6 +755,7 @@ LENTIL_API int lentil_hip_upload_visits(lentil_hip_ctx *ctx, const lentil_visits
   if ((rc = up(v->pixel, (size_t)v->n * 4, (const void **)&d.pixel))) return rc;
   if ((rc = up(v->inv_density, (size_t)v->n * 4, (const void **)&d.inv_density))) return rc;
   to_dev(ctx->V, &d);
+  apply_camera_motion(ctx);
   ctx->V.id_base = ctx->visit_id_base;
   rc = ensure_worklist(ctx, v->n);
   if (rc) return rc;
@@ -1212,7 +1240,7 @@ static int plan_scan(lentil_hip_ctx *ctx, ScanPlan &pl) {
       pl.lds = 4 * wave_f4 * 16 + 4 * kWaveQueueLds * sizeof(uint2);
     }
     const size_t dma_lds = (size_t)4 * dma_wave_f4(M) * 16 + 4 * kWaveQueueLds * sizeof(uint2);
-    pl.dma = ctx->scan_dma && ctx->V.n_extra == 0 && !ctx->V.inv_density && !ctx->F.zkey && !ctx->F.zkey_dbg &&
+    pl.dma = ctx->scan_dma && ctx->V.n_extra == 0 && !ctx->V.inv_density && !ctx->F.zkey && !ctx->F.zkey_dbg && ctx->V.cam.n < 2 &&
              ctx->V.n % M == 0 && dma_lds <= 80u * 1024u;
     if (pl.dma) {
       ppt = 64;

@@ -73,6 +73,7 @@ struct VisitsDev {
   const uint32_t *pixel;
   const float *inv_density;
   uint32_t id_base;       // ragged streams: frame-wide id of visit 0 (multi-GPU partitions)
+  CamMotion cam;          // a moving camera's matrix keys (lentil_hip_set_camera_motion); n < 2: lentil_params::world_to_camera
 };
 
 // Frame-wide visit id: the position of a visit in the order a single process would walk the whole frame
@@ -291,7 +292,7 @@ LD_DEV ItemVisit load_work_visit(const lentil_params &P, const VisitsDev &V, uin
   const uint32_t v = h.visit;
   h.rgba = V.rgba[v];
   const float invd = V.inv_density ? V.inv_density[v] : P.inverse_sample_density;
-  h.I = visit_prologue(P, lens_length, h.rgba, V.pos_z[v], V.raydir_time[v], V.volume_ignore[v], V.transmission[v], invd);
+  h.I = visit_prologue(P, lens_length, h.rgba, V.pos_z[v], V.raydir_time[v], V.volume_ignore[v], V.transmission[v], invd, V.cam);
   visit_pixel(V, v, h.px, h.py);
   const float inv_samples = (float)(1.0 / (double)(float)(int)h.samples);
   h.w = 1.0f * invd * inv_samples;              // src/lentil_filter.cpp:297
@@ -333,7 +334,7 @@ LD_DEV void publish_item(const lentil_params &P, const VisitsDev &V, const Strea
   if (item < S.item_cap) {
     float cs[3];
     const uint32_t v = wi.x;
-    visit_camera_space(P, V.pos_z[v], [&]() { return V.raydir_time[v]; }, cs);
+    visit_camera_space(P, V.pos_z[v], [&]() { return V.raydir_time[v]; }, cs, V.cam);
     int px, py;
     visit_pixel(V, v, px, py);
     const ItemHdr hd = make_item_hdr(P, cs, px, py);
@@ -561,10 +562,10 @@ __global__ __launch_bounds__(256) void scan_uniform_kernel(ScanArgs a) {
         flagged[g] = false;
         if (valid[g]) {
           const float invd = V.inv_density ? V.inv_density[v] : a.P.inverse_sample_density;
-          flagged[g] = visit_redistributes(a.P, a.lens_length, pz[g], vi[g], tr[g], invd, [&]() { return V.raydir_time[v]; });
+          flagged[g] = visit_redistributes(a.P, a.lens_length, pz[g], vi[g], tr[g], invd, [&]() { return V.raydir_time[v]; }, V.cam);
           if (flagged[g]) {
             // a few visits in 10^5: the draw count (same function as the draw kernels use)
-            samples = visit_prologue(a.P, a.lens_length, rgba[g], pz[g], V.raydir_time[v], vi[g], tr[g], invd).samples;
+            samples = visit_prologue(a.P, a.lens_length, rgba[g], pz[g], V.raydir_time[v], vi[g], tr[g], invd, V.cam).samples;
           } else {
             w = 1.0f * invd;                              // filter_weight * inv_density, lentil.h:949-953
             val = make_float4((rgba[g].x + 0.0f) * w, (rgba[g].y + 0.0f) * w, (rgba[g].z + 0.0f) * w, (rgba[g].w + 0.0f) * w);
@@ -758,10 +759,10 @@ __global__ __launch_bounds__(256) void scan_dma_kernel(ScanArgs a) {
         int samples = 0;
         if (valid) {
           flagged = visit_redistributes(a.P, a.lens_length, pz, vi, tr, a.P.inverse_sample_density,
-                                        [&]() { return V.raydir_time[v]; });
+                                        [&]() { return V.raydir_time[v]; }, V.cam);
           // a few visits in 10^5: the draw count (same function as the draw kernels use)
           if (flagged)
-            samples = visit_prologue(a.P, a.lens_length, srgba[e], pz, V.raydir_time[v], vi, tr, a.P.inverse_sample_density).samples;
+            samples = visit_prologue(a.P, a.lens_length, srgba[e], pz, V.raydir_time[v], vi, tr, a.P.inverse_sample_density, V.cam).samples;
         }
         if (flagged || !valid) {
           // adds nothing to its own pixel: +0 values (x + (+0) changes no bit, an accumulator is never -0), one weight fewer
@@ -877,9 +878,9 @@ __global__ __launch_bounds__(256) void scan_uniform_multi_kernel(ScanArgs a) {
         if (k < n_aovs && !(a.F.closest_mask & (1u << k))) val[k] = V.extra[k - 1][v];
       const float invd = V.inv_density ? V.inv_density[v] : a.P.inverse_sample_density;
       depth = pz.w;
-      if (visit_redistributes(a.P, a.lens_length, pz, vi, tr, invd, [&]() { return V.raydir_time[v]; })) {
+      if (visit_redistributes(a.P, a.lens_length, pz, vi, tr, invd, [&]() { return V.raydir_time[v]; }, V.cam)) {
         flagged = true;
-        samples = visit_prologue(a.P, a.lens_length, rgba, pz, V.raydir_time[v], vi, tr, invd).samples;
+        samples = visit_prologue(a.P, a.lens_length, rgba, pz, V.raydir_time[v], vi, tr, invd, V.cam).samples;
       } else {
         w = 1.0f * invd;                                // filter_weight * inv_density, lentil.h:949-953
         val[0] = rgba;
@@ -977,9 +978,9 @@ __global__ __launch_bounds__(256) void scan_ragged_kernel(ScanArgs a) {
       const float4 rgba = V.rgba[v];
       const float invd = V.inv_density ? V.inv_density[v] : a.P.inverse_sample_density;
       const float4 pz = V.pos_z[v], vi = V.volume_ignore[v], tr = V.transmission[v];
-      if (visit_redistributes(a.P, a.lens_length, pz, vi, tr, invd, [&]() { return V.raydir_time[v]; })) {
+      if (visit_redistributes(a.P, a.lens_length, pz, vi, tr, invd, [&]() { return V.raydir_time[v]; }, V.cam)) {
         flagged = true;
-        samples = visit_prologue(a.P, a.lens_length, rgba, pz, V.raydir_time[v], vi, tr, invd).samples;
+        samples = visit_prologue(a.P, a.lens_length, rgba, pz, V.raydir_time[v], vi, tr, invd, V.cam).samples;
       } else {
         int px, py;
         visit_pixel(V, v, px, py);
@@ -1039,7 +1040,7 @@ __global__ __launch_bounds__(256) void scan_runs_kernel(ScanArgs a) {
   auto own = [&](uint64_t u, const float4 *col, float &w) -> float4 {
     const float invd = V.inv_density ? V.inv_density[u] : a.P.inverse_sample_density;
     const bool red = visit_redistributes(a.P, a.lens_length, V.pos_z[u], V.volume_ignore[u], V.transmission[u], invd,
-                                         [&]() { return V.raydir_time[u]; });
+                                         [&]() { return V.raydir_time[u]; }, V.cam);
     w = red ? 0.0f : 1.0f * invd;
     if (red) return make_float4(0.f, 0.f, 0.f, 0.f);
     const float4 c = col[u];
@@ -1061,9 +1062,9 @@ __global__ __launch_bounds__(256) void scan_runs_kernel(ScanArgs a) {
       const float4 rgba = V.rgba[v];
       const float invd = V.inv_density ? V.inv_density[v] : a.P.inverse_sample_density;
       const float4 pz = V.pos_z[v], vi = V.volume_ignore[v], tr = V.transmission[v];
-      if (visit_redistributes(a.P, a.lens_length, pz, vi, tr, invd, [&]() { return V.raydir_time[v]; })) {
+      if (visit_redistributes(a.P, a.lens_length, pz, vi, tr, invd, [&]() { return V.raydir_time[v]; }, V.cam)) {
         flagged = true;
-        samples = visit_prologue(a.P, a.lens_length, rgba, pz, V.raydir_time[v], vi, tr, invd).samples;
+        samples = visit_prologue(a.P, a.lens_length, rgba, pz, V.raydir_time[v], vi, tr, invd, V.cam).samples;
       } else {
         w = 1.0f * invd;
         val = make_float4((rgba.x + 0.0f) * w, (rgba.y + 0.0f) * w, (rgba.z + 0.0f) * w, (rgba.w + 0.0f) * w);
@@ -2799,7 +2800,7 @@ __global__ __launch_bounds__(256) void debug_gather_kernel(FrameDev F, VisitsDev
     if (!visit_from_gid(V, 0xFFFFFFFFu - (uint32_t)(key & 0xFFFFFFFFull), v)) continue;
     const float invd = V.inv_density ? V.inv_density[v] : P.inverse_sample_density;
     const VisitInfo I = visit_prologue(P, lens_length, V.rgba[v], V.pos_z[v], V.raydir_time[v], V.volume_ignore[v],
-                                       V.transmission[v], invd);
+                                       V.transmission[v], invd, V.cam);
     const float s = (float)I.samples;
     for (uint32_t k = 1; k < F.n_aovs; ++k)
       if (F.debug_mask & (1u << k)) *F.aov(p, k) = make_float4(s, s, s, s);

@@ -275,6 +275,7 @@ LENTIL_API int lentil_hip_visits_end(lentil_hip_ctx *ctx, uint64_t *n_visits) {
   int rc = check_visits(ctx, &d);
   if (rc) return rc;
   to_dev(ctx->V, &d);
+  apply_camera_motion(ctx);
   ctx->V.id_base = ctx->visit_id_base;
   rc = ensure_worklist(ctx, d.n);
   if (rc) return rc;

@@ -200,8 +200,24 @@ void LentilCamera::setup(AtUniverse *universe) {
   }
   P.lambda_bw = (float)lambda_um;
   AtMatrix w2c;
-  AiWorldToCameraMatrix(camera_node, 0.0f, w2c);          // static camera: one matrix (declared gap)
+  AiWorldToCameraMatrix(camera_node, 0.0f, w2c);
   memcpy(P.world_to_camera, w2c.data, sizeof P.world_to_camera);
+  // A moving camera: the reference asks for the matrix at every sample's own time (src/lentil_filter.cpp:141-144); the
+  // GPU path gets the camera's matrix at its key times and interpolates per visit (lentil_hip_set_camera_motion)
+  motion_keys.clear();
+  {
+    int nkeys = 1;
+    if (AtArray *ma = AiNodeGetArray(camera_node, AtString("matrix"))) nkeys = (int)AiArrayGetNumKeys(ma);
+    if (nkeys > LENTIL_MAX_MOTION_KEYS) {
+      AiMsgWarning("[LENTIL] the camera has %d matrix keys, the redistribution samples %d over the shutter", nkeys, LENTIL_MAX_MOTION_KEYS);
+      nkeys = LENTIL_MAX_MOTION_KEYS;
+    }
+    for (int k = 0; nkeys >= 2 && k < nkeys; ++k) {
+      AtMatrix mk;
+      AiWorldToCameraMatrix(camera_node, (float)k / (float)(nkeys - 1), mk);
+      motion_keys.insert(motion_keys.end(), &mk.data[0][0], &mk.data[0][0] + 16);
+    }
+  }
 
   have_bokeh = false;
   if (P.bokeh_enable_image) {
@@ -322,6 +338,8 @@ void LentilCamera::setup(AtUniverse *universe) {
     return false;
   };
   if (!gpu && !check(lentil_hip_create(0, &gpu), "lentil_hip_create")) return;
+  if (!check(lentil_hip_set_camera_motion(gpu, (uint32_t)(motion_keys.size() / 16), motion_keys.empty() ? nullptr : motion_keys.data()),
+             "lentil_hip_set_camera_motion")) return;
   if (!check(lentil_hip_set_params(gpu, &P), "set_params")) return;
   if (P.cameraType == LENTIL_POLYNOMIAL_OPTICS && !check(lentil_hip_set_lens(gpu, lens_table), "set_lens")) return;
   if (!check(lentil_hip_set_bokeh(gpu, nullptr), "set_bokeh")) return;

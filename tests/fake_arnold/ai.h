@@ -270,6 +270,7 @@ AI_API void AiNodeSetStr(AtNode *node, AtString param, AtString value);
 AI_API bool AiNodeSetArray(AtNode *node, AtString param, AtArray *array);
 AI_API bool AiNodeLink(AtNode *src, AtString input, AtNode *target);
 AI_API uint32_t AiArrayGetNumElements(const AtArray *array);
+AI_API uint8_t AiArrayGetNumKeys(const AtArray *array);
 AI_API AtString AiArrayGetStr(const AtArray *array, uint32_t i);
 AI_API void *AiArrayGetPtr(const AtArray *array, uint32_t i);
 AI_API AtArray *AiArrayAllocate(uint32_t nelements, uint8_t nkeys, uint8_t type);

@@ -54,6 +54,8 @@ struct AtNodeEntry {
 
 struct AtArray {
   uint8_t type = AI_TYPE_NONE;
+  uint8_t nkeys = 1;
+  std::vector<float> mats;                 // AI_TYPE_MATRIX: nkeys x 16 floats
   std::vector<std::string> strs;
   std::vector<void *> ptrs;
 };
@@ -246,6 +248,7 @@ AtArray *AiNodeGetArray(const AtNode *node, AtString param) { Param *p = find(no
 void AiNodeSetStr(AtNode *node, AtString param, AtString value) { if (node) { Param &p = node->p[param.c_str()]; p.type = AI_TYPE_STRING; p.s = value.c_str(); } }
 bool AiNodeSetArray(AtNode *node, AtString param, AtArray *array) { if (!node) return false; Param &p = node->p[param.c_str()]; p.type = AI_TYPE_ARRAY; p.arr = array; return true; }
 bool AiNodeLink(AtNode *src, AtString input, AtNode *target) { if (!src || !target) return false; target->links[input.c_str()] = src; return true; }
+uint8_t AiArrayGetNumKeys(const AtArray *a) { return a ? a->nkeys : 0; }
 uint32_t AiArrayGetNumElements(const AtArray *a) { return a ? (uint32_t)(a->type == AI_TYPE_STRING ? a->strs.size() : a->ptrs.size()) : 0; }
 AtString AiArrayGetStr(const AtArray *a, uint32_t i) { return AtString(a && i < a->strs.size() ? a->strs[i].c_str() : ""); }
 void *AiArrayGetPtr(const AtArray *a, uint32_t i) { return a && i < a->ptrs.size() ? a->ptrs[i] : nullptr; }
@@ -270,7 +273,23 @@ void AiFilterInitialize(AtNode *node, bool, const char **required_aovs) {
 void AiFilterUpdate(AtNode *node, float width) { node->filter_width = width; }
 void AiDriverInitialize(AtNode *, bool) {}
 static void identity(AtMatrix &m) { memset(&m, 0, sizeof m); for (int i = 0; i < 4; ++i) m.data[i][i] = 1.f; }
-void AiWorldToCameraMatrix(const AtNode *, float, AtMatrix &out) { identity(out); }
+// The stand-in's camera carries WORLD-TO-CAMERA keys in its "matrix" array (fa_camera_set_matrix_keys); between keys the
+// matrix is interpolated component-wise, ((b - a) * f) + a -- what this repo defines a moving camera's matrix to be
+// (include/lentil_hip.h, lentil_hip_set_camera_motion; how Arnold itself interpolates is not in the reference tree).
+void AiWorldToCameraMatrix(const AtNode *node, float time, AtMatrix &out) {
+  identity(out);
+  const AtArray *a = node ? AiNodeGetArray(node, AtString("matrix")) : nullptr;
+  if (!a || a->mats.size() < 16) return;
+  const int n = a->nkeys;
+  if (n < 2) { memcpy(out.data, a->mats.data(), 64); return; }
+  float t = time < 0.f ? 0.f : (time > 1.f ? 1.f : time);
+  const float sc = t * (float)(n - 1);
+  int i0 = (int)sc;
+  if (i0 > n - 2) i0 = n - 2;
+  const float f = sc - (float)i0;
+  const float *ka = a->mats.data() + (size_t)i0 * 16, *kb = ka + 16;
+  for (int i = 0; i < 16; ++i) (&out.data[0][0])[i] = ((kb[i] - ka[i]) * f) + ka[i];
+}
 void AiCameraToWorldMatrix(const AtNode *, float, AtMatrix &out) { identity(out); }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -610,6 +629,17 @@ FA_API int fa_camera_reverse_ray(AtUniverse *u, const float po[3], float relativ
   const bool ok = cm->ReverseRay(u->camera, AtVector(po[0], po[1], po[2]), relative_time, r);
   ps[0] = r.x; ps[1] = r.y;
   return ok ? 1 : 0;
+}
+// a moving camera: n world-to-camera matrices (row-vector convention) over the shutter
+FA_API int fa_camera_set_matrix_keys(AtUniverse *u, int n, const float *mats) {
+  if (!u->camera || n < 1 || n > 255) return -1;
+  AtArray *a = new AtArray();
+  a->type = AI_TYPE_MATRIX;
+  a->nkeys = (uint8_t)n;
+  a->mats.assign(mats, mats + (size_t)n * 16);
+  u->arrays.push_back(a);
+  AiNodeSetArray(u->camera, AtString("matrix"), a);
+  return 0;
 }
 FA_API int fa_filter_width_x1000(AtUniverse *u, const char *node_name) {
   AtNode *n = AiNodeLookUpByName(u, AtString(node_name));

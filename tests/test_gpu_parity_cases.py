@@ -208,3 +208,61 @@ def test_config5_8k_bands(orc, gpu_ctx_factory):
     ctx = gpu_ctx_factory()
     for y0 in (0, 2160):
         _band_parity_at_full_geometry(orc, ctx, p, table, W, M, y0, 1, 2.0 ** -11)
+
+
+def _moving_camera_keys(n_keys):
+    """world-to-camera matrices (row-vector convention, translation in row 3) of a camera that trucks sideways and pans a
+    little over the shutter: enough to move a highlight's camera-space position by a good fraction of its depth."""
+    keys = []
+    for k in range(n_keys):
+        t = k / max(1, n_keys - 1)
+        a = 0.06 * t
+        m = np.eye(4, dtype=np.float32)
+        m[0, 0], m[0, 2], m[2, 0], m[2, 2] = np.cos(a), -np.sin(a), np.sin(a), np.cos(a)
+        m[3, 0], m[3, 1], m[3, 2] = 12.0 * t, -3.0 * t * t, 4.0 * t
+        keys.append(m)
+    return np.stack(keys)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_keys,ragged", [(2, False), (5, False), (3, True)])
+def test_moving_camera_per_sample_time(orc, gpu_ctx_factory, n_keys, ragged):
+    """Every AOV sample is taken to camera space with the matrix of its own time -- AiWorldToCameraMatrix(camera,
+    lentil_time), src/lentil_filter.cpp:141-144: matrix keys over the shutter (lentil_hip_set_camera_motion), the
+    lentil_time column deciding between them per visit.  Oracle and HIP path on the same keys and times: accepted-draw
+    lists bit-identical, frames within 1e-5; and the keys do matter (the static camera gives another frame)."""
+    import test_gpu_parity as tp
+    W, H, M = 64, 48, 9
+    p, model, table, keep = common.po_setup(W, H, samples_override=48)
+    visits, cols = common.make_stream(p, W, H, M, f_hi=0.02)
+    cols["raydir_time"] = cols["raydir_time"].copy()
+    rng = np.random.default_rng(11)
+    cols["raydir_time"][:, 3] = rng.uniform(-0.1, 1.1, visits.n).astype(np.float32)        # incl. times outside the shutter (clamped)
+    if ragged:
+        pix = np.arange(visits.n) // M
+        cols["pixel"] = ((pix % W) | ((pix // W) << 16)).astype(np.uint32)
+        visits, keepv = capi.make_visits(cols, visits_per_pixel=0)
+    else:
+        visits, keepv = capi.make_visits(cols, visits_per_pixel=M, pixels_per_row=W)
+    keys = _moving_camera_keys(n_keys)
+    lens = orc.orc_lens_create(C.byref(table))
+    ref = oracle_lib.Frame(orc, p, n_aovs=1, keep_log=True)
+    ref.set_camera_motion(keys)
+    ref.run(lens, None, visits)
+    still = oracle_lib.Frame(orc, p, n_aovs=1, keep_log=True)
+    still.run(lens, None, visits)
+    orc.orc_lens_destroy(lens)
+    assert ref.counters().redistributed_visits > 100
+    assert not np.array_equal(common.sort_log(ref.log()), common.sort_log(still.log()))
+    ctx = gpu_ctx_factory()
+    ctx.set_camera_motion(keys)
+    for _ in range(2):                     # second pass: blind / streamed
+        c = tp.gpu_run(ctx, p, table, visits)
+        rc = ref.counters()
+        assert (c.redistributed_visits, c.attempted_draws, c.accepted_draws) == (rc.redistributed_visits, rc.attempted_draws, rc.accepted_draws)
+        tp.check_logs(ctx, ref)
+        tp.check_frame(ctx, ref)
+    ctx.set_camera_motion(None)            # back to the parameters' static matrix
+    tp.gpu_run(ctx, p, table, visits)
+    tp.check_logs(ctx, still)
+    ref.close(); still.close()

@@ -418,3 +418,38 @@ def test_threaded_oracle_equals_the_single_thread_one(orc):
     assert np.allclose(one.buffer64(0), thr.buffer64(0), rtol=1e-13, atol=0)
     assert np.allclose(one.weight64(), thr.weight64(), rtol=1e-13, atol=0)
     thr.close()
+
+
+def test_oracle_camera_motion_interpolates_the_keys(orc):
+    """orc_frame_set_camera_motion: a visit at lentil_time t sees ((b - a) * f) + a of the two keys around t; two equal
+    keys are the static camera; times outside the shutter clamp."""
+    import common
+    import oracle_lib
+    W, H, M = 32, 24, 9
+    p, model, table, keep = common.po_setup(W, H, samples_override=16)
+    visits, cols = common.make_stream(p, W, H, M, f_hi=0.03)
+    lens = orc.orc_lens_create(C.byref(table))
+
+    def run(keys, times):
+        cols["raydir_time"][:, 3] = times
+        f = oracle_lib.Frame(orc, p, n_aovs=1, keep_log=True)
+        if keys is not None:
+            f.set_camera_motion(keys)
+        f.run(lens, None, visits)
+        log = common.sort_log(f.log())
+        f.close()
+        return log
+    ident = np.eye(4, dtype=np.float32)
+    moved = ident.copy(); moved[3, 0] = 20.0
+    n = visits.n
+    still = run(None, np.zeros(n, np.float32))
+    assert still.shape[0] > 100
+    assert np.array_equal(run(np.stack([ident, ident]), np.full(n, 0.37, np.float32)), still)
+    at_end = run(np.stack([ident, moved]), np.ones(n, np.float32))
+    assert not np.array_equal(at_end, still)
+    assert np.array_equal(run(np.stack([ident, moved]), np.full(n, 7.0, np.float32)), at_end)        # clamped to 1
+    assert np.array_equal(run(np.stack([ident, moved]), np.full(n, -3.0, np.float32)), still)        # clamped to 0
+    half = moved.copy(); half[3, 0] = 10.0
+    assert np.array_equal(run(np.stack([ident, moved]), np.full(n, 0.5, np.float32)), run(np.stack([half, half]), np.zeros(n, np.float32)))
+    assert np.array_equal(run(np.stack([ident, half, moved]), np.full(n, 0.5, np.float32)), run(np.stack([half, half]), np.zeros(n, np.float32)))
+    orc.orc_lens_destroy(lens)

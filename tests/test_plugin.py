@@ -37,7 +37,7 @@ def fa():
               "fa_add_output", "fa_output_count", "fa_output", "fa_set_samples", "fa_set_aov", "fa_render", "fa_get_image",
               "fa_cook_operators", "fa_universe_destroy", "fa_node_exists", "fa_aov_shader_count", "fa_render_hint",
               "fa_filter_width_x1000", "fa_options", "fa_set_depths", "fa_set_depth_aov", "fa_add_late_output",
-              "fa_add_aov_shader", "fa_get_display_image", "fa_camera_create_ray", "fa_camera_reverse_ray"):
+              "fa_add_aov_shader", "fa_get_display_image", "fa_camera_create_ray", "fa_camera_reverse_ray", "fa_camera_set_matrix_keys"):
         getattr(lib, f).argtypes = None
     assert lib.fa_load_plugin(PLUGIN.encode()) == 4
     return lib
@@ -339,6 +339,70 @@ def test_frame_through_the_plugin_matches_the_oracle(fa, orc, monkeypatch):
         assert fa.fa_camera_reverse_ray(C.c_void_p(u), (C.c_float * 3)(*po), C.c_float(0.0), ps) == 1
         coeff = 1.0 / max(abs(float(np.float32(po[2])) * tan_fov), 1e-3)
         assert ps[0] == np.float32(float(np.float32(po[0])) * coeff) and ps[1] == np.float32(float(np.float32(po[1])) * coeff)
+    fa.fa_universe_destroy(C.c_void_p(u))
+
+
+@pytest.mark.gpu
+def test_moving_camera_through_the_plugin_matches_the_oracle(fa, orc, monkeypatch):
+    """The camera has matrix keys and every AOV sample its own lentil_time: the reference takes the sample to camera space
+    with AiWorldToCameraMatrix(camera, time) (src/lentil_filter.cpp:141-144).  lentil.so reads the keys at camera update,
+    hands them to the GPU path, filter_pixel captures the times; the frame equals the oracle's with the same keys."""
+    W, H, M, S = 48, 32, 9, 32
+    monkeypatch.setenv("LENTIL_SAMPLES_OVERRIDE", str(S))
+    fa.fa_messages_clear()
+    u, cam = _scene(fa, W, H, ["RGBA RGBA gaussian_filter driver_exr"])
+    fa.fa_node_set_int(C.c_void_p(cam), b"camera_type", 1)
+    fa.fa_node_set_int(C.c_void_p(cam), b"lens_model", 0)
+    keys = np.stack([np.eye(4, dtype=np.float32) for _ in range(3)])
+    keys[1, 3, 0], keys[2, 3, 0], keys[2, 3, 1] = 6.0, 15.0, -4.0
+    assert fa.fa_camera_set_matrix_keys(C.c_void_p(u), 3, keys.ctypes.data_as(C.c_void_p)) == 0
+    p, model, table, keep = common.po_setup(W, H, samples_override=S, focal_length=np.float32(35.0))
+    visits, cols = common.make_stream(p, W, H, M, f_hi=0.03)
+    n = W * H * M
+    times = np.random.default_rng(2).uniform(0.0, 1.0, n).astype(np.float32)
+    cols["raydir_time"] = cols["raydir_time"].copy()
+    cols["raydir_time"][:, 3] = times
+    pix = np.arange(n) // M
+    px = (pix % W).astype(np.int32); py = (pix // W).astype(np.int32)
+    rng = np.random.default_rng(5)
+    ox = rng.uniform(-0.5, 0.5, n).astype(np.float32); oy = rng.uniform(-0.5, 0.5, n).astype(np.float32)
+    invd = np.full(n, 1.0 / 9.0, np.float32)
+    fa.fa_set_samples(C.c_void_p(u), n, px.ctypes.data_as(C.c_void_p), py.ctypes.data_as(C.c_void_p), ox.ctypes.data_as(C.c_void_p),
+                      oy.ctypes.data_as(C.c_void_p), invd.ctypes.data_as(C.c_void_p))
+    zeros = np.zeros((n, 4), np.float32)
+    z4 = np.repeat(cols["pos_z"][:, 3:4], 4, axis=1).copy()
+    t4 = np.repeat(times[:, None], 4, axis=1).copy()
+    aov = {"RGBA": (AI_TYPE["RGBA"], cols["rgba"]), "P": (AI_TYPE["VECTOR"], cols["pos_z"]), "Z": (AI_TYPE["FLOAT"], z4),
+           "lentil_raydir": (AI_TYPE["RGB"], cols["raydir_time"]), "lentil_time": (AI_TYPE["FLOAT"], t4),
+           "volume": (AI_TYPE["RGB"], zeros), "transmission": (AI_TYPE["RGBA"], zeros), "lentil_ignore": (AI_TYPE["FLOAT"], zeros)}
+    keep_arrays = []
+    for name, (t, a) in aov.items():
+        a = np.ascontiguousarray(a, np.float32); keep_arrays.append(a)
+        fa.fa_set_aov(C.c_void_p(u), name.encode(), t, a.ctypes.data_as(C.c_void_p))
+    rc = fa.fa_render(C.c_void_p(u), 4, 16)
+    assert rc == 0 and fa.fa_error_count() == 0, _messages(fa)
+    got = np.zeros((H, W, 4), np.float32)
+    assert fa.fa_get_image(C.c_void_p(u), b"RGBA", got.ctypes.data_as(C.c_void_p)) == 0
+    # the oracle: RGBA, lentil_debug (no column), lentil_raydir -- the plugin's AOV order for this scene
+    kinds = [_abi.FILTER_GAUSSIAN, _abi.FILTER_CLOSEST_DEBUG, _abi.FILTER_GAUSSIAN]
+    ocols = dict(cols)
+    widen = lambda a: np.ascontiguousarray(np.concatenate([a[:, :3], np.ones((n, 1), np.float32)], 1), np.float32)
+    ocols["extra"] = [np.zeros_like(cols["rgba"]), widen(cols["raydir_time"])]
+    ovisits, okeep = capi.make_visits(ocols, visits_per_pixel=M, pixels_per_row=W)
+    lens = orc.orc_lens_create(C.byref(table))
+    ref = oracle_lib.Frame(orc, p, n_aovs=3, kinds=kinds)
+    ref.set_camera_motion(keys)
+    ref.run(lens, None, ovisits)
+    still = oracle_lib.Frame(orc, p, n_aovs=3, kinds=kinds)
+    still.run(lens, None, ovisits)
+    orc.orc_lens_destroy(lens)
+    want = ref.resolve(0).reshape(p.yres, p.xres, 4)[:H, :W]
+    other = still.resolve(0).reshape(p.yres, p.xres, 4)[:H, :W]
+    m = want != 0
+    assert np.array_equal(got != 0, m)
+    assert float(np.max(np.abs(got[m].astype(np.float64) - want[m]) / np.abs(want[m]))) < 1e-5
+    assert not np.array_equal(other != 0, m) or float(np.max(np.abs(other[m] - want[m]))) > 1e-2       # the keys matter
+    ref.close(); still.close()
     fa.fa_universe_destroy(C.c_void_p(u))
 
 
