@@ -483,6 +483,14 @@ def rank_details(b, dist, torch, dev, steps=3):
     return allr
 
 
+def scan_kernel_name(aovs):
+    """The scan kernel the library picks for a uniform stream of whole pixels (plan_scan in lentil_hip.hip)."""
+    dma = os.environ.get("LENTIL_SCAN_DMA", "1") != "0"
+    if aovs == 0:
+        return "scan_dma_kernel" if dma else "scan_uniform_kernel"
+    return "scan_dma_multi_kernel" if (dma and os.environ.get("LENTIL_SCAN_DMA_MULTI", "1") != "0") else "scan_uniform_multi_kernel"
+
+
 def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not args.emulate:
@@ -587,13 +595,12 @@ def main():
     n_total = workload.frame_visit_count(W, H, M) if not emulate else b.n_local        # all ranks
     value = n_total * r["steps"] / r["dt"] / 1e6
     ms_per_step, launches, launch_ms, launch_bytes, achieved = summarize(b, r, n_total, bytes_per_visit)
-    scan_kernel = "scan_dma_kernel" if (args.aovs == 0 and os.environ.get("LENTIL_SCAN_DMA", "1") != "0") else (
-        "scan_uniform_multi_kernel" if args.aovs else "scan_uniform_kernel")
+    scan_kernel = scan_kernel_name(args.aovs)
     workload_tag = "%s %s %dx%d M=%d samples=%d aovs=%d f_hi=%.3g" % (scan_kernel, args.lens, W, Hr, M, args.samples, 1 + args.aovs, args.f_hi)
     # bytes the scan requests per visit: four of the five base columns (raydir_time only for visits at infinite
     # depth) + the extra AOV columns, and per pixel one record stored (and, in the register-staged kernels, read first)
     rec_bytes = 4 * (((4 * (1 + args.aovs) + 1) + 7) // 8 * 8)
-    moved = 64 + 16 * args.aovs + (rec_bytes if scan_kernel == "scan_dma_kernel" else 2 * rec_bytes) / M
+    moved = 64 + 16 * args.aovs + (rec_bytes if scan_kernel.startswith("scan_dma") else 2 * rec_bytes) / M
     steps = r["steps"]
     out = {
         "metric": "bidir redistribution Msamples/s at 4K, double-gauss 50mm",
@@ -708,7 +715,7 @@ def main():
                 ms_c, l_c, lms_c, lb_c, ach_c = summarize(c, rc, n_c, bpv)
                 cfgs[name] = {"value": round(n_c * rc["steps"] / rc["dt"] / 1e6, 3), "unit": "Msamples/s", "ms_per_step": round(ms_c, 4),
                               "kernels_ms": {"scan": round(rc["scan"] / 4, 4), "draw": round(rc["draw"] / 4, 4), "resolve": round(rc["resolve"] / 4, 4)},
-                              "bytes_per_visit": bpv, "scan_frac_of_hbm_peak": round(ach_c / HBM_PEAK_GBS, 4),
+                              "scan_kernel": scan_kernel_name(kw["aovs"]), "bytes_per_visit": bpv, "scan_frac_of_hbm_peak": round(ach_c / HBM_PEAK_GBS, 4),
                               "whole_step_frac_of_hbm_peak": round(n_c * bpv / (ms_c * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                               "attempted_draws_per_step": rc["attempted"] // 4, "passes_streamed": rc["streamed"], "steps": 4}
                 c.close()

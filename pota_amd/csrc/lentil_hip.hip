@@ -96,6 +96,9 @@ struct lentil_hip_ctx {
   uint64_t early_cap_samples = 4ull << 20;   // LENTIL_EARLY_CAP_SAMPLES
   uint64_t max_pool_units = 1ull << 32;    // 16 GiB per pool at most (LENTIL_MAX_POOL_UNITS overrides)
   double mean_iters = 0.0;                   // Newton iterations per solve in the last pass (0: unknown)
+  double parked_frac = 0.0;                  // share of the last pass's solves that were parked for solve_slow_kernel
+  bool park_dry_seen = false;                // a live queue has been flooded with this lens (set_lens forgets it)
+  int park_dry_only = -1;                    // LENTIL_PARK_DRY_ONLY: 1 live queues too take only the last lanes of waves running dry, 0 never, -1 by parked_frac
   int slow_at = 20;                          // LENTIL_SLOW_AT: iterations after which a solve is parked (0: never)
  uint64_t slow_below = 8ull << 20;          // LENTIL_SLOW_BELOW: ... in chunks whose draw sum is below this
  int slow_from_round = 0;                   // LENTIL_SLOW_FROM_ROUND
@@ -165,6 +168,7 @@ struct lentil_hip_ctx {
   uint2 *d_tlc_tasks = nullptr;
   uint64_t tlc_res_cap = 0, tlc_off_cap = 0, tlc_tasks_cap = 0;
   double lens_housing_radius = 0.0;  // lens_aperture_housing_radius of the current table (focus search)
+  float4 *d_dummy = nullptr;          // ScanArgs::dummy
   float *d_cam_keys = nullptr;        // lentil_hip_set_camera_motion
   uint32_t n_cam_keys = 0;
   struct LentilUpload *upload = nullptr;   // lentil_upload.h: the visit stream handed over piece by piece
@@ -229,6 +233,7 @@ LENTIL_API int lentil_hip_create(int device, lentil_hip_ctx **out_ctx) {
   // one DevCounters per chunk + one shared (draw-log cursor)
   HIP_TRY(ctx, hipMalloc(&ctx->d_ctr, sizeof(DevCounters) * (ctx->n_chunks + 1)));
   HIP_TRY(ctx, hipHostMalloc((void **)&ctx->h_ctr_pinned, sizeof(DevCounters) * ctx->n_chunks, hipHostMallocDefault));
+  HIP_TRY(ctx, hipMalloc(&ctx->d_dummy, 64 * sizeof(float4)));
   HIP_TRY(ctx, hipMemsetAsync(ctx->d_ctr, 0, sizeof(DevCounters) * (ctx->n_chunks + 1), ctx->stream));
   ctx->chunks.resize(ctx->n_chunks);
   for (auto &ch : ctx->chunks) {
@@ -274,6 +279,7 @@ LENTIL_API int lentil_hip_create(int device, lentil_hip_ctx **out_ctx) {
   if (const char *e = getenv("LENTIL_STREAM")) ctx->stream_mode = !(e[0] == '0');
   if (const char *e = getenv("LENTIL_SCAN_DMA")) ctx->scan_dma = !(e[0] == '0');
   if (const char *e = getenv("LENTIL_SLOW_LIVE")) ctx->slow_live = !(e[0] == '0');
+  if (const char *e = getenv("LENTIL_PARK_DRY_ONLY")) ctx->park_dry_only = atoi(e);
   if (const char *e = getenv("LENTIL_OVERLAP_ROUNDS")) ctx->overlap_rounds = !(e[0] == '0');
   if (const char *e = getenv("LENTIL_DECOUPLE")) ctx->decouple = !(e[0] == '0');
   if (const char *e = getenv("LENTIL_CHAIN_STREAMS")) ctx->chain_streams = !(e[0] == '0');
@@ -308,6 +314,9 @@ LENTIL_API int lentil_hip_create(int device, lentil_hip_ctx **out_ctx) {
       HIP_TRY(ctx, hipStreamSynchronize(st));
     }
   }
+  // (the multi-AOV scan's ring can take all of a CU's LDS)
+  (void)hipFuncSetAttribute((const void *)scan_dma_multi_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  (void)hipGetLastError();
   *out_ctx = ctx;
   return LENTIL_OK;
 }
@@ -356,6 +365,7 @@ LENTIL_API int lentil_hip_destroy(lentil_hip_ctx *ctx) {
   (void)hipFree(ctx->d_terms);
   (void)hipFree(ctx->d_blade_sc);
   (void)hipFree(ctx->d_cam_keys);
+  (void)hipFree(ctx->d_dummy);
   (void)hipFree(ctx->F.acc);
   (void)hipFree(ctx->F.zkey);
   (void)hipFree(ctx->F.zkey_dbg);
@@ -474,6 +484,7 @@ LENTIL_API int lentil_hip_set_lens(lentil_hip_ctx *ctx, const lentil_lens_table 
     if ((uint64_t)t->out[i].first + t->out[i].count > t->n_terms) return fail(ctx, LENTIL_ERR_INVALID, "lens poly out of range");
   for (int i = 0; i < 4; ++i)
     if ((uint64_t)t->ap[i].first + t->ap[i].count > t->n_terms) return fail(ctx, LENTIL_ERR_INVALID, "lens poly out of range");
+  ctx->park_dry_seen = false; ctx->parked_frac = 0.0; ctx->mean_iters = 0.0;      // what the passes learnt about the previous lens
   std::vector<DevTerm> terms;
   DevLens h{};
   bool ok = true;
@@ -1204,8 +1215,33 @@ struct ScanPlan {
   uint64_t n_tiles = 0;
   bool multi = false;
   bool dma = false;       // scan_dma_kernel (beauty only, uniform weights)
+  bool dma_multi = false; // scan_dma_multi_kernel (extra gaussian AOVs, uniform weights)
   uint32_t M = 0;
 };
+
+// slots per wave (LENTIL_DMA_MULTI_RING: 2 or 3; no difference measured, the waves are not short of bytes in flight)
+static uint32_t dma_multi_ring(const lentil_hip_ctx *) {
+  static const int forced = getenv("LENTIL_DMA_MULTI_RING") ? atoi(getenv("LENTIL_DMA_MULTI_RING")) : 0;
+  return forced == 3 ? 3u : 2u;
+}
+// blocks per CU (LENTIL_DMA_MULTI_BLOCKS): two where the CU's LDS holds them and two solve blocks beside them
+static uint32_t dma_multi_blocks_per_cu(const lentil_hip_ctx *ctx) {
+  static const int forced = getenv("LENTIL_DMA_MULTI_BLOCKS") ? atoi(getenv("LENTIL_DMA_MULTI_BLOCKS")) : 0;
+  if (forced >= 1 && forced <= 4) return (uint32_t)forced;
+  const size_t one = (size_t)4 * dma_multi_wave_f4(ctx->V.n_extra, dma_multi_ring(ctx)) * 16 + 4 * kWaveQueueLds * sizeof(uint2);
+  return 2u * one + 2u * 10u * 1024u <= 160u * 1024u ? 2u : 1u;
+}
+static size_t dma_multi_lds(const lentil_hip_ctx *ctx) {
+  return (size_t)4 * dma_multi_wave_f4(ctx->V.n_extra, dma_multi_ring(ctx)) * 16 + 4 * kWaveQueueLds * sizeof(uint2);
+}
+
+// scan_dma_multi_kernel takes the stream: whole pixels of M <= 64 visits, uniform weights, gaussian AOVs only
+static bool dma_multi_applies(const lentil_hip_ctx *ctx) {
+  static const bool allowed = !(getenv("LENTIL_SCAN_DMA_MULTI") && getenv("LENTIL_SCAN_DMA_MULTI")[0] == '0');
+  const uint32_t M = ctx->V.visits_per_pixel;
+  return allowed && ctx->scan_dma && M > 0 && M <= 64 && ctx->V.n_extra > 0 && !ctx->V.inv_density && !ctx->F.zkey && !ctx->F.zkey_dbg &&
+         ctx->F.closest_mask == 0 && ctx->V.cam.n < 2 && ctx->V.n % M == 0 && dma_multi_lds(ctx) <= 160u * 1024u;
+}
 
 static int plan_scan(lentil_hip_ctx *ctx, ScanPlan &pl) {
   ScanArgs &sa = pl.sa;
@@ -1249,15 +1285,33 @@ static int plan_scan(lentil_hip_ctx *ctx, ScanPlan &pl) {
       pl.lds = dma_lds;
       pl.multi = false;
     }
+    // frames with extra AOVs, all of them gaussian: the LDS-DMA form of the multi-column scan (LENTIL_SCAN_DMA_MULTI=0: never)
+    const size_t dmam_lds = dma_multi_lds(ctx);
+    pl.dma_multi = dma_multi_applies(ctx);
+    if (pl.dma_multi) {
+      ppt = 64 / M;
+      // the sum lanes come in passes of 64 float4 of the group's records: a pixel fewer per group where that saves the
+      // second pass (nine visits, nine AOVs: 7 x 10 float4 = two passes, 6 x 10 = one; 3.19 against 3.39 ms)
+      const uint32_t q = ctx->F.stride / 4;
+      if (ppt * q > 64 && 64 / q >= 1 && 4 * (64 / q) >= 3 * ppt) ppt = 64 / q;
+      if (const char *e = getenv("LENTIL_DMA_MULTI_PPT")) { const uint32_t f = (uint32_t)atoi(e); if (f >= 1 && f <= 64 / M) ppt = f; }
+      sa.ppt = ppt;
+      sa.tv_pad = ppt * M;
+      pl.lds = dmam_lds;
+      pl.multi = false;
+      pl.dma = false;
+      sa.dummy = ctx->d_dummy;
+      sa.ring = dma_multi_ring(ctx);
+    }
     const uint64_t n_pixels = (ctx->V.n + M - 1) / M;
     pl.n_tiles = (n_pixels + ppt - 1) / ppt;
   }
   lentil_hip_ctx::DirRegion reg;
-  if (pl.dma) {
+  if (pl.dma || pl.dma_multi) {
     reg.x0 = ctx->V.pixel_x0; reg.y0 = ctx->V.pixel_y0; reg.row_stride = ctx->V.pixel_row_stride; reg.ppr = ctx->V.pixels_per_row;
     reg.npix = ctx->V.n / M;
   }
-  const int rc = prepare_direct(ctx, pl.dma ? &reg : nullptr);
+  const int rc = prepare_direct(ctx, (pl.dma || pl.dma_multi) ? &reg : nullptr);
   if (rc) return rc;
   sa.F = ctx->F;
   return LENTIL_OK;
@@ -1284,6 +1338,12 @@ static int launch_scan(lentil_hip_ctx *ctx, const ScanPlan &pl, const lentil_hip
     if (blocks > (uint64_t)ctx->num_cu * per_cu) blocks = (uint64_t)ctx->num_cu * per_cu;
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(scan_dma_kernel, dim3((unsigned)blocks), dim3(256), pl.lds, ctx->stream, sa);
+  } else if (pl.dma_multi) {
+    // persistent: a wave draws runs of 16 groups
+    blocks = (ch.tile_end - ch.tile_begin + 4 * kDmaMultiRun - 1) / (4 * kDmaMultiRun);
+    if (blocks > (uint64_t)ctx->num_cu * dma_multi_blocks_per_cu(ctx)) blocks = (uint64_t)ctx->num_cu * dma_multi_blocks_per_cu(ctx);
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(scan_dma_multi_kernel, dim3((unsigned)blocks), dim3(256), pl.lds, ctx->stream, sa);
   } else if (pl.M) {
     blocks = (ch.tile_end - ch.tile_begin + 3) / 4;
     if (blocks > max_blocks) blocks = max_blocks;
@@ -1327,7 +1387,10 @@ static int redistribute_streamed(lentil_hip_ctx *ctx, bool *streamed) {
   // frame: 114 ms against 135 ms; 15 M draws: 16.6 against 18.4 ms -- solve waves placed while the scan's are
   // resident keep running slower long after those have left, see launch_chunk_rounds), and so it is with extra
   // AOVs, whose scan kernel leaves the solve waves less room (config 4: 10.8 against 11.5 ms).
-  if (ctx->est_sum_total >= ctx->stream_below || ctx->V.n_extra) return LENTIL_OK;
+  // (LENTIL_STREAM_EXTRA=0: frames with extra AOVs take the chunked pass whatever their scan kernel)
+  static const bool stream_extra = !(getenv("LENTIL_STREAM_EXTRA") && getenv("LENTIL_STREAM_EXTRA")[0] == '0');
+  if (ctx->est_sum_total >= ctx->stream_below) return LENTIL_OK;
+  if (ctx->V.n_extra && !(stream_extra && dma_multi_applies(ctx))) return LENTIL_OK;
   lentil_hip_ctx::Chunk &ch = ctx->chunks[0];
   std::lock_guard<std::mutex> one_at_a_time(g_stream_mutex[ctx->device & 63]);
   DrawArgs da{};
@@ -1458,6 +1521,12 @@ static int redistribute_streamed(lentil_hip_ctx *ctx, bool *streamed) {
     if (live && !ctx->solve_b) b_blocks = 0;
   }
   da.slow_live = live ? 1 : 0;
+  // A live queue takes every solve that reaches slow_at iterations -- outliers, by the measure of the previous pass.  With
+  // a lens where such solves are not outliers (the petzval table: 3 % of all solves, 62 000 a frame, each a whole wave
+  // of the straggler kernel: 12 ms a frame against 10 chunked) only waves running dry park, and only their last lanes.
+  // (It stays that way for the lens: a pass that parks dry waves' lanes only says nothing about what a live queue would get.)
+  if (ctx->parked_frac > 1.0 / 256.0) ctx->park_dry_seen = true;
+  da.slow_dry_only = ctx->park_dry_only >= 0 ? ctx->park_dry_only : (ctx->park_dry_seen ? 1 : 0);
   da.slow_waves = live ? (uint32_t)ctx->num_cu : 0u;
   da.producers_done = &ctx->d_ctr->publishers_done;
   da.producers_total = (uint32_t)ctx->publish_waves;
@@ -1701,7 +1770,7 @@ static int redistribute_streamed(lentil_hip_ctx *ctx, bool *streamed) {
   } else {
     const uint64_t n_items = c.work_count < ctx->V.n ? c.work_count : ctx->V.n;
     ch.have_est = true; ch.est_items = n_items; ch.est_sum = c.sum_samples; ch.est_rounds = (int)c.rounds_used;
-    if (c.tries) ctx->mean_iters = (double)c.newton_iters / (double)c.tries;
+    if (c.tries) { ctx->mean_iters = (double)c.newton_iters / (double)c.tries; ctx->parked_frac = (double)c.slow_solves / (double)c.tries; }
     int rounds = blind_rounds;
     if (n_items && c.n_active[blind_rounds & 1] != 0) {
       ctx->h_ctr_valid = false;
@@ -1933,9 +2002,9 @@ LENTIL_API int lentil_hip_redistribute(lentil_hip_ctx *ctx) {
       for (int ci = 0; ci < C; ++ci) HIP_TRY(ctx, hipStreamSynchronize(ctx->chunks[ci].stream));
       ctx->h_ctr.assign(ctx->h_ctr_pinned, ctx->h_ctr_pinned + C);
       ctx->h_ctr_valid = true;
-      unsigned long long it = 0, tr = 0;
-      for (const DevCounters &k : ctx->h_ctr) { it += k.newton_iters; tr += k.tries; }
-      if (tr) ctx->mean_iters = (double)it / (double)tr;
+      unsigned long long it = 0, tr = 0, sl = 0;
+      for (const DevCounters &k : ctx->h_ctr) { it += k.newton_iters; tr += k.tries; sl += k.slow_solves; }
+      if (tr) { ctx->mean_iters = (double)it / (double)tr; ctx->parked_frac = (double)sl / (double)tr; }
     }
     for (int ci = 0; ci < C; ++ci) {
       lentil_hip_ctx::Chunk &ch = ctx->chunks[ci];

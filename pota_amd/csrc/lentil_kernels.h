@@ -235,6 +235,8 @@ struct ScanArgs {
   uint32_t range_cap, epoch;
   uint32_t end_ranges;             // waves of publish_kernel: end markers behind the last range
   uint32_t flush_each_tile;        // announce at the end of every tile (few items per pass: latency matters, atomics do not)
+  uint32_t ring;                   // scan_dma_multi_kernel: slots per wave
+  float4 *dummy;                   // scan_dma_multi_kernel: 64 x 16 B that lanes without a record store to
 };
 
 LD_DEV void visit_pixel(const VisitsDev &V, uint64_t v, int &px, int &py) {
@@ -683,14 +685,15 @@ __host__ __device__ constexpr uint32_t dma_wave_f4(uint32_t M) { return M * 64u 
 // every LDS read it can see while an LDS-DMA may be in flight -- which would wait for the groups behind this one too
 // (the caller has waited for exactly this group's DMAs).  The reads are waited for here: the compiler does not
 // track them.
+template <uint32_t kColBytes = 1024u>
 LD_DEV void lds_read_slot(const float4 *slot_lane, float4 &c0, float4 &c1, float4 &c2) {
   typedef float v4f __attribute__((ext_vector_type(4)));
   typedef const __attribute__((address_space(3))) void *lptr_t;
   const uint32_t addr = (uint32_t)(size_t)(lptr_t)(const void *)slot_lane;
   v4f x, y, z;
-  asm volatile("ds_read_b128 %0, %3\n\tds_read_b128 %1, %3 offset:1024\n\tds_read_b128 %2, %3 offset:2048\n\ts_waitcnt lgkmcnt(0)"
+  asm volatile("ds_read_b128 %0, %3\n\tds_read_b128 %1, %3 offset:%4\n\tds_read_b128 %2, %3 offset:%5\n\ts_waitcnt lgkmcnt(0)"
                : "=&v"(x), "=&v"(y), "=&v"(z)
-               : "v"(addr)
+               : "v"(addr), "n"(kColBytes), "n"(2u * kColBytes)
                : "memory");
   c0 = make_float4(x.x, x.y, x.z, x.w);
   c1 = make_float4(y.x, y.y, y.z, y.w);
@@ -803,6 +806,243 @@ __global__ __launch_bounds__(256) void scan_dma_kernel(ScanArgs a) {
     }
     if (lane == 0) tl_add(TL_SCAN_TILES, (uint32_t)(tile4_end - tile4));
   }
+  wq.finish(a);
+  scan_block_done(a);
+}
+
+// ---------------------------------------------------------------------------------------
+// K1+K2+K6 for frames with extra (gaussian) AOVs and a uniform footprint -- the LDS-DMA form of
+// scan_uniform_multi_kernel, as scan_dma_kernel is of scan_uniform_kernel: 80 + 16 K bytes per visit go from HBM
+// straight into LDS, the ordered sums are stored to FrameDev::dir whole (no record is read), and the kernel stays
+// under 100 VGPRs, so that two solve blocks per CU fit beside it: frames with extra AOVs can run streamed.
+//   group   ppt = 64 / M whole pixels = ppt * M <= 64 visits (M = visits per pixel): everything a pixel's sums need
+//           lies in one group.  Per group 4 + K columns of 1 KiB: pos_z, volume_ignore, transmission, rgba, extra[k].
+//   ring    R = 2 or 3 slots (ScanArgs::ring) of 4 + K columns (1 KiB + 16 B of padding each, kDmaMultiCol) per wave; groups g + 1 .. g + R - 1 are in flight while g is decided and summed,
+//           g + R is issued when g's slot is free.  vmcnt counts loads and stores in issue order, so the wait for group g names
+//           what was issued after its loads: the next group's columns and the record stores of the group before.
+//           (Every LDS read of a slot is inline assembly: the compiler puts vmcnt(0) before any LDS read it sees.)
+//   sums    lane (pixel, float4 j of its record) adds that pixel's M entries of AOV j in iterator order
+//           (src/lentil.h:938-955) from the raw columns, four entries per LDS round trip; which entries count comes
+//           from one ballot per group (a redistributed visit's entries count as +0 and add no weight).  j = n_aovs is
+//           the record's weight.  A group's records lie side by side in FrameDev::dir, so a pass of 64 lanes is ONE
+//           store instruction of 1 KiB without holes; lanes without a record write a scratch line, so that every
+//           pass is exactly one instruction: that keeps the vmcnt arithmetic exact.
+//   runs    a wave draws 16 groups at a time from DevCounters::tile_next.
+// ---------------------------------------------------------------------------------------
+LD_DEV float4 lds_read_f4(const float4 *p) {
+  typedef float v4f __attribute__((ext_vector_type(4)));
+  typedef const __attribute__((address_space(3))) void *lptr_t;
+  const uint32_t addr = (uint32_t)(size_t)(lptr_t)(const void *)p;
+  v4f x;
+  asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(x) : "v"(addr) : "memory");
+  return make_float4(x.x, x.y, x.z, x.w);
+}
+// four consecutive float4 with one wait (the ordered sums: a pixel's entries lie side by side)
+LD_DEV void lds_read_4f4(const float4 *p, float4 c[4]) {
+  typedef float v4f __attribute__((ext_vector_type(4)));
+  typedef const __attribute__((address_space(3))) void *lptr_t;
+  const uint32_t addr = (uint32_t)(size_t)(lptr_t)(const void *)p;
+  v4f x, y, z, w;
+  asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:16\n\tds_read_b128 %2, %4 offset:32\n\tds_read_b128 %3, %4 offset:48\n\t"
+               "s_waitcnt lgkmcnt(0)"
+               : "=&v"(x), "=&v"(y), "=&v"(z), "=&v"(w)
+               : "v"(addr)
+               : "memory");
+  c[0] = make_float4(x.x, x.y, x.z, x.w); c[1] = make_float4(y.x, y.y, y.z, y.w);
+  c[2] = make_float4(z.x, z.y, z.z, z.w); c[3] = make_float4(w.x, w.y, w.z, w.w);
+}
+// A global read the compiler does not track (waited for here): a load it can see makes it wait for vmcnt(0)
+// wherever the destination registers are written next, e.g. in the middle of the next group's DMAs.
+LD_DEV float4 global_read_f4_untracked(const float4 *p) {
+  typedef float v4f __attribute__((ext_vector_type(4)));
+  v4f x;
+  asm volatile("global_load_dwordx4 %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=&v"(x) : "v"(p) : "memory");
+  return make_float4(x.x, x.y, x.z, x.w);
+}
+LD_DEV void wait_vmcnt(uint32_t n) {       // n is wave-uniform; the instruction takes an immediate
+#define LENTIL_VMCNT_CASE(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); break;
+  switch (n) {
+    LENTIL_VMCNT_CASE(0) LENTIL_VMCNT_CASE(1) LENTIL_VMCNT_CASE(2) LENTIL_VMCNT_CASE(3) LENTIL_VMCNT_CASE(4)
+    LENTIL_VMCNT_CASE(5) LENTIL_VMCNT_CASE(6) LENTIL_VMCNT_CASE(7) LENTIL_VMCNT_CASE(8) LENTIL_VMCNT_CASE(9)
+    LENTIL_VMCNT_CASE(10) LENTIL_VMCNT_CASE(11) LENTIL_VMCNT_CASE(12) LENTIL_VMCNT_CASE(13) LENTIL_VMCNT_CASE(14)
+    LENTIL_VMCNT_CASE(15) LENTIL_VMCNT_CASE(16) LENTIL_VMCNT_CASE(17) LENTIL_VMCNT_CASE(18) LENTIL_VMCNT_CASE(19)
+    LENTIL_VMCNT_CASE(20) LENTIL_VMCNT_CASE(21) LENTIL_VMCNT_CASE(22) LENTIL_VMCNT_CASE(23) LENTIL_VMCNT_CASE(24)
+    LENTIL_VMCNT_CASE(25) LENTIL_VMCNT_CASE(26) LENTIL_VMCNT_CASE(27) LENTIL_VMCNT_CASE(28) LENTIL_VMCNT_CASE(29)
+    LENTIL_VMCNT_CASE(30) LENTIL_VMCNT_CASE(31) LENTIL_VMCNT_CASE(32) LENTIL_VMCNT_CASE(33) LENTIL_VMCNT_CASE(34)
+    LENTIL_VMCNT_CASE(35) LENTIL_VMCNT_CASE(36) LENTIL_VMCNT_CASE(37) LENTIL_VMCNT_CASE(38) LENTIL_VMCNT_CASE(39)
+    LENTIL_VMCNT_CASE(40) LENTIL_VMCNT_CASE(41) LENTIL_VMCNT_CASE(42) LENTIL_VMCNT_CASE(43) LENTIL_VMCNT_CASE(44)
+    LENTIL_VMCNT_CASE(45) LENTIL_VMCNT_CASE(46) LENTIL_VMCNT_CASE(47) LENTIL_VMCNT_CASE(48) LENTIL_VMCNT_CASE(49)
+    LENTIL_VMCNT_CASE(50) LENTIL_VMCNT_CASE(51) LENTIL_VMCNT_CASE(52) LENTIL_VMCNT_CASE(53) LENTIL_VMCNT_CASE(54)
+    LENTIL_VMCNT_CASE(55) LENTIL_VMCNT_CASE(56) LENTIL_VMCNT_CASE(57) LENTIL_VMCNT_CASE(58) LENTIL_VMCNT_CASE(59)
+    LENTIL_VMCNT_CASE(60) LENTIL_VMCNT_CASE(61) LENTIL_VMCNT_CASE(62) LENTIL_VMCNT_CASE(63)
+    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+  }
+#undef LENTIL_VMCNT_CASE
+}
+constexpr uint32_t kDmaMultiRun = 16;      // groups a wave draws at a time
+// A column of a slot is 64 float4 and one of padding: columns 1 KiB apart would put the sum lanes of one pixel -- same
+// entry, different AOV -- on the same LDS banks (nine ways at nine AOVs); 65 spreads them evenly.
+constexpr uint32_t kDmaMultiCol = 65;
+__host__ __device__ constexpr uint32_t dma_multi_wave_f4(uint32_t n_extra, uint32_t ring) { return ring * (4u + n_extra) * kDmaMultiCol; }
+
+__global__ __launch_bounds__(256) void scan_dma_multi_kernel(ScanArgs a) {
+  extern __shared__ float4 smem[];
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  const VisitsDev &V = a.V;
+  const uint32_t M = V.visits_per_pixel, K = V.n_extra, n_aovs = a.F.n_aovs;
+  const uint32_t n_cols = 4u + K;
+  const uint32_t ppt = a.ppt, TV = ppt * M;
+  constexpr uint32_t CS = kDmaMultiCol;
+  const uint32_t R = a.ring;                                        // slots per wave (2 or 3)
+  float4 *ring = smem + (size_t)wave * dma_multi_wave_f4(K, R);    // [R][n_cols][CS]
+  uint2 *qmem = reinterpret_cast<uint2 *>(smem + (size_t)4u * dma_multi_wave_f4(K, R));
+  WaveQueue wq;
+  wq.init(qmem + (size_t)wave * kWaveQueueLds);
+  __builtin_amdgcn_s_setprio(3);
+  const uint64_t n_pixels = V.n / M;
+  const uint64_t n_tiles = a.tile_end;
+  const uint32_t xres = a.P.xres, q = a.F.stride >> 2;
+  const float w_in = 1.0f * a.P.inverse_sample_density;
+  float4 *dir4 = reinterpret_cast<float4 *>(a.F.dir);
+  float4 *dummy = a.dummy + lane;                                   // where lanes without a record put their stores
+  const uint64_t v_last = V.n - 1;
+  // record stores per group: the sum lanes come in passes of 64 (pixel, float4 of the record) pairs, one instruction each
+  const uint32_t n_sum = ppt * q, passes = (n_sum + 63u) / 64u, store_ops = passes;
+
+  auto issue = [&](uint64_t tile, uint32_t si) {
+    const uint64_t v = tile * (uint64_t)TV + lane;
+    const uint64_t vl = (lane < TV && v < V.n) ? v : v_last;        // lanes past the group / the end re-read the last visit (unused)
+    float4 *slot = ring + (size_t)si * n_cols * CS;
+    lds_dma16(V.pos_z + vl, slot);
+    lds_dma16(V.volume_ignore + vl, slot + CS);
+    lds_dma16(V.transmission + vl, slot + 2u * CS);
+    lds_dma16(V.rgba + vl, slot + 3u * CS);
+    for (uint32_t k = 0; k < K; ++k) lds_dma16(V.extra[k] + vl, slot + (4u + k) * CS);
+  };
+
+#ifdef LENTIL_TIMELINE
+  uint64_t tacc[6] = {0, 0, 0, 0, 0, 0};
+#endif
+  while (true) {
+    uint32_t t0 = 0;
+    if (lane == 0) t0 = atomicAdd(&a.ctr->tile_next, kDmaMultiRun);
+    const uint64_t run0 = a.tile_begin + (uint64_t)__builtin_amdgcn_readfirstlane(t0);
+    if (run0 >= n_tiles) break;
+    const uint64_t run1 = run0 + kDmaMultiRun < n_tiles ? run0 + kDmaMultiRun : n_tiles;
+    for (uint32_t g = 0; g < R && run0 + g < run1; ++g) issue(run0 + g, g);
+    uint32_t si = 0;                                                // the slot of `tile`: (tile - run0) mod R
+    for (uint64_t tile = run0; tile < run1; ++tile) {
+      // what was issued after this group's loads: the columns of the R - 1 groups behind it, the record stores of the
+      // R - 1 groups before it
+      const uint32_t behind = (uint32_t)(run1 - 1u - tile) < R - 1u ? (uint32_t)(run1 - 1u - tile) : R - 1u;
+      const uint32_t before = (uint32_t)(tile - run0) < R - 1u ? (uint32_t)(tile - run0) : R - 1u;
+#ifdef LENTIL_TIMELINE
+      const uint64_t tp0 = clock64();
+#endif
+      wait_vmcnt(behind * n_cols + before * store_ops);
+#ifdef LENTIL_TIMELINE
+      const uint64_t tp1 = clock64();
+#endif
+      const float4 *slot = ring + (size_t)si * n_cols * CS;
+      const uint64_t pix0 = tile * ppt;
+      const uint64_t v = tile * (uint64_t)TV + lane;
+      const bool valid = lane < TV && v < V.n;
+      float4 pz, vi, tr;
+      lds_read_slot<CS * 16u>(slot + lane, pz, vi, tr);
+      bool flagged = false;
+      int samples = 0;
+      if (valid) {
+        // (no camera motion keys here: the host sends such streams to scan_uniform_multi_kernel)
+        flagged = visit_redistributes(a.P, a.lens_length, pz, vi, tr, a.P.inverse_sample_density,
+                                      [&]() { return global_read_f4_untracked(V.raydir_time + v); });
+        if (flagged)
+          samples = visit_prologue(a.P, a.lens_length, lds_read_f4(slot + 3u * CS + lane), pz,
+                                   global_read_f4_untracked(V.raydir_time + v), vi, tr, a.P.inverse_sample_density).samples;
+      }
+      // bit e: the group's entry e adds to its own pixel (weight w_in; the others count as +0 and add no weight)
+      const unsigned long long counts = __ballot(valid && !flagged);
+      const bool all_count = counts == __ballot(lane < TV) && tile * (uint64_t)TV + TV <= V.n;
+      wq.push(flagged, (uint32_t)v, (uint32_t)samples, a);
+#ifdef LENTIL_TIMELINE
+      const uint64_t tp2 = clock64();
+#endif
+      // ---- sums: lane (pixel, float4 of its record)
+      for (uint32_t pass = 0; pass < passes; ++pass) {
+        const uint32_t idx = pass * 64u + lane;
+        const uint32_t pi = idx / q, k = idx - pi * q;
+        const bool mine = idx < n_sum && pix0 + pi < n_pixels;
+        const uint32_t e0 = (mine ? pi : 0u) * M;
+        const float4 *col = slot + (3u + (k < n_aovs ? k : 0u)) * CS + e0;       // rgba, extra[k - 1]
+        const unsigned long long bits = counts >> e0;
+        float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+        float ws = 0.f;
+        auto add = [&](const float4 &c, bool on) {
+          // (an entry that does not count is +0: it changes no bit of the sum)
+          const float tx = sum.x + (c.x + 0.0f) * w_in, ty = sum.y + (c.y + 0.0f) * w_in;
+          const float tz = sum.z + (c.z + 0.0f) * w_in, tw = sum.w + (c.w + 0.0f) * w_in;
+          sum.x = on ? tx : sum.x; sum.y = on ? ty : sum.y; sum.z = on ? tz : sum.z; sum.w = on ? tw : sum.w;
+          ws = on ? ws + w_in : ws;
+        };
+        uint32_t j0 = 0;
+        if (all_count) {
+          // nearly every group: nothing of it is redistributed, every entry counts
+          for (; j0 + 4u <= M; j0 += 4u) {
+            float4 c[4];
+            lds_read_4f4(col + j0, c);
+#pragma unroll
+            for (uint32_t u = 0; u < 4u; ++u) {
+              sum.x += (c[u].x + 0.0f) * w_in; sum.y += (c[u].y + 0.0f) * w_in;
+              sum.z += (c[u].z + 0.0f) * w_in; sum.w += (c[u].w + 0.0f) * w_in;
+              ws += w_in;
+            }
+          }
+          for (; j0 < M; ++j0) {
+            const float4 c = lds_read_f4(col + j0);
+            sum.x += (c.x + 0.0f) * w_in; sum.y += (c.y + 0.0f) * w_in; sum.z += (c.z + 0.0f) * w_in; sum.w += (c.w + 0.0f) * w_in;
+            ws += w_in;
+          }
+        } else {
+          for (; j0 + 4u <= M; j0 += 4u) {
+            float4 c[4];
+            lds_read_4f4(col + j0, c);
+#pragma unroll
+            for (uint32_t u = 0; u < 4u; ++u) add(c[u], (bits >> (j0 + u)) & 1ull);
+          }
+          for (; j0 < M; ++j0) add(lds_read_f4(col + j0), (bits >> j0) & 1ull);
+        }
+        // the float4 after the AOVs holds the weight, what follows it (padding of the record) nothing
+        if (k == n_aovs) sum = make_float4(ws, 0.f, 0.f, 0.f);
+        else if (k > n_aovs) sum = make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 *dst = dummy;
+        if (mine) {
+          const uint64_t pp = pix0 + pi;
+          const int px = V.pixel_x0 + (int)(pp % V.pixels_per_row);
+          const int py = V.pixel_y0 + (int)(pp / V.pixels_per_row) * (int)V.pixel_row_stride;
+          dst = dir4 + ((uint64_t)px + (uint64_t)py * xres) * q + k;
+        }
+        *dst = sum;
+      }
+      // this group's slot is free (its values are summed): the group after the next goes there
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+      __builtin_amdgcn_wave_barrier();
+#ifdef LENTIL_TIMELINE
+      const uint64_t tp3 = clock64();
+#endif
+      if (tile + R < run1) issue(tile + R, si);
+      si = si + 1u == R ? 0u : si + 1u;
+#ifdef LENTIL_TIMELINE
+      const uint64_t tp4 = clock64();
+#endif
+      wq.end_tile(a);
+#ifdef LENTIL_TIMELINE
+      tacc[0] += tp1 - tp0; tacc[1] += tp2 - tp1; tacc[2] += tp3 - tp2; tacc[3] += tp4 - tp3; tacc[4] += clock64() - tp4; tacc[5] += 1;
+#endif
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+#ifdef LENTIL_TIMELINE
+  if (lane == 0) for (int i = 0; i < 6; ++i) dbg_add(20 + i, tacc[i]);
+#endif
   wq.finish(a);
   scan_block_done(a);
 }
@@ -1317,6 +1557,7 @@ struct DrawArgs {
   // the first accept does not wait for the stragglers (accept_item<1>).  Defaults (-1, -1, 1, 0): a queue per round.
   int32_t slow_q, slow_round, slow_close, slow_indirect;
   uint32_t unknown_credit;    // accept_item<1>: eighths of the known attempts' success rate credited to the unknown ones (0: none)
+  int32_t slow_dry_only;      // live queue: park as a plain round does (waves running dry, their last slow_max_lanes lanes)
   int32_t slow_crowd_stays;   // live queue: where more than slow_max_lanes lanes of a wave are past slow_at at once, none is parked
 };
 LD_DEV uint32_t slow_queue(const DrawArgs &a) { return a.slow_q >= 0 ? (uint32_t)a.slow_q : (uint32_t)a.parity; }
@@ -1447,8 +1688,13 @@ LD_DEV uint32_t solve_result(const lentil_params &P, const LensT &L, const Newto
 // kStream (first round of a streamed pass): the task queue is still being filled by the scan kernels while this
 // kernel runs.  A wave that needs work draws a ticket and polls its slot between Newton iterations; the queue is
 // complete once every wave of publish_kernel has signed off (DevCounters::publishers_done).
+// Three waves per SIMD (at most 168 VGPRs): the generated petzval code would take 174-179 and leave the SIMD with two --
+// a handful of values spilt outside the Newton loop costs less than the third wave brings.
+#ifndef LENTIL_SOLVE_ATTR
+#define LENTIL_SOLVE_ATTR __attribute__((amdgpu_waves_per_eu(3)))
+#endif
 template <class LensT, bool kTables, bool kChroma = false, bool kStream = false>
-__global__ __launch_bounds__(256) void solve_po_kernel(DrawArgs a) {
+__global__ __launch_bounds__(256) LENTIL_SOLVE_ATTR void solve_po_kernel(DrawArgs a) {
   __shared__ DevTerm s_terms[kTables ? kMaxTerms : 1];
   __shared__ DevLens s_k;
   __shared__ DevLens s_kc[kChroma ? 3 : 1];
@@ -1635,7 +1881,7 @@ __global__ __launch_bounds__(256) void solve_po_kernel(DrawArgs a) {
     // ... and only its last few lanes: a lens whose solves routinely take more than slow_at iterations (the petzval
     // table: heavy vignetting, thousands of such solves per round) would otherwise send them all to a kernel that
     // spends a wave on each (config 4: 17.5 ms per frame with that, 3 ms of it per solve_slow_kernel launch).
-    if (parking && (a.slow_live || (no_more && __builtin_popcountll(__ballot(busy)) <= a.slow_max_lanes))) {
+    if (parking && ((a.slow_live && !a.slow_dry_only) || (no_more && __builtin_popcountll(__ballot(busy)) <= a.slow_max_lanes))) {
       const bool park = busy && s.k >= a.slow_at;
       unsigned long long pmask = __ballot(park);
       // Live queue: outliers only.  Where many lanes of a wave are past slow_at at once it is not a straggler but the item:
