@@ -80,6 +80,7 @@ def parse():
     ap.add_argument("--aovs", type=int, default=0, help="extra (non-beauty) AOVs")
     ap.add_argument("--lens", default="double_gauss_50mm")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity-check", action="store_true", help="skip the oracle check of a sample of the workload")
     ap.add_argument("--no-pcie", action="store_true", help="skip the PCIe-inclusive measurement (upload from host memory + pass)")
     ap.add_argument("--no-second-regime", action="store_true")
     ap.add_argument("--no-configs", action="store_true", help="skip BASELINE.json's configs 2-4")
@@ -216,6 +217,53 @@ def cpu_baseline(args, p, table, M, tan_half_fov):
         "threads": threads, "logical_cpus": logical, "physical_cores": physical_cores(),
         "one_thread": {"value": round(v_one, 4), "unit": "Msamples/s", "sample": s_one},
     }
+
+
+def parity_check(args, p, table, M, tan_half_fov, device_index, torch):
+    """The same check as tests/ make, inside the bench run: a bounded sample of the timed workload (every row_step-th
+    image row of the same frame, ~10 s of oracle work) goes through the HIP path and through the oracle (fp32
+    buffers as the reference keeps them, fp64 shadows beside them); accepted draws are compared as (visit, attempt,
+    pixel) lists, bit for bit, radiance at 1e-5.  The timed pass itself is checked at full size by
+    tests/test_gpu_headline.py (66 s of oracle work: not inside a bench run)."""
+    import ctypes as C
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib
+    import common
+    from test_gpu_parity import check_frame, check_logs
+    from pota_amd import capi, workload
+
+    lib = oracle_lib.load()
+    W, H = args.width, args.height
+    n_aovs = 1 + args.aovs
+    # (every oracle thread has a frame of its own: fp32 + fp64 accumulators, ~60 B per pixel and AOV)
+    per_thread_gb = W * H * 60e-9 * n_aovs + 0.1
+    threads = max(1, min(os.cpu_count() or 1, 32, int(0.5 * common.host_memory_gb() / per_thread_gb)))
+    est_full = W * H * M * (0.1e-6 + args.f_hi * args.samples * 35e-6 * 1.1) * 1.5       # (shadow buffers, the draw log)
+    row_step = max(1, int(round(est_full / (10.0 * threads))))
+    rows = list(range(0, H, row_step))
+    n = len(rows) * W * M
+    cols = workload.generate(np, 0, n, W, H, M, f_hi=args.f_hi, focus_dist=150.0, tan_half_fov=tan_half_fov,
+                             n_extra=args.aovs, row_stride=row_step, row_offset=0)
+    visits, keep = capi.make_visits(cols, visits_per_pixel=M, pixels_per_row=W, pixel_row_stride=row_step)
+    ref = common.ThreadedOracle(lib, p, table, visits, n_threads=threads, n_aovs=n_aovs, row_visits=W * M)
+    ctx = capi.Context(device_index)
+    try:
+        ctx.set_params(p); ctx.set_lens(table); ctx.set_bokeh(None); ctx.alloc_frame(n_aovs); ctx.set_draw_log(1 << 24)
+        ctx.upload_visits(visits)
+        ctx.clear_frame(); ctx.redistribute(); ctx.resolve(); ctx.sync()
+        c = ctx.counters()
+        check_logs(ctx, ref)                       # AssertionError: caught by the caller, reported as ok = false
+        worst = check_frame(ctx, ref, n_aovs=n_aovs, tol=1e-5)
+        n_log = int(ctx.draw_log().shape[0])
+    finally:
+        ctx.close()
+        ref.close()
+    return {"ok": True, "accepted_draws_compared": n_log, "draw_lists_bit_identical": True, "max_rel_err": float("%.3g" % worst),
+            "tolerance": 1e-5, "redistributed_visits": int(c.redistributed_visits),
+            "sample": "every %d-th row of the timed %dx%d frame (%d visits), HIP path against the oracle" % (row_step, W, H, n),
+            "full_size": "tests/test_gpu_headline.py::test_headline_4k_streamed_vs_oracle (the timed streams, bit-identical "
+                         "draw lists, 1e-5 radiance) and ::test_config5_quarter_frame_chunked_vs_oracle"}
 
 
 def load_traffic(workload_tag):
@@ -729,6 +777,13 @@ def main():
         except Exception as e:      # the GPU number must still be reported
             out["cpu_baseline"] = {"value": None, "unit": "Msamples/s", "cores": 0, "kind": "port",
                                    "sample": "failed: %r" % (e,)}
+    if rank == 0 and world == 1 and not args.no_parity_check:
+        try:
+            out["parity_checked"] = parity_check(args, cpu_args[1], cpu_args[2], M, cpu_args[4], local_rank, torch)
+        except AssertionError as e:
+            out["parity_checked"] = {"ok": False, "error": str(e)[:300]}
+        except Exception as e:
+            out["parity_checked"] = {"ok": None, "error": "check did not run: %r" % (e,)}
     from pota_amd import distributed
     if distributed.PHASE_SECONDS:
         sys.stderr.write("[band timing, ms per step incl. warm-up steps] %s\n" % {k: round(v * 1e3 / (args.steps + args.warmup), 3)

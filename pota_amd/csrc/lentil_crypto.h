@@ -13,9 +13,10 @@
 // Here: the maps are open-addressed tables of `slots` (id bits, fp32 weight) pairs per pixel in HBM -- a pixel's
 // table is one or two 64-byte lines -- filled with atomicCAS on the id and atomicAdd on the weight.  The adds do not
 // ride in the draw kernels (whose register budgets are what the pass's speed hangs on): they are replayed after the
-// pass from what it leaves behind -- the redistribute decision, recomputed per visit (visit_redistributes, the very
-// function the scan uses), for the visits that stay in their pixel, and the pass's draw log (visit, pixel per accepted
-// draw; the log the parity tests compare with the oracle's in every mode of the pass) for the others.  The weight of
+// pass from what it leaves behind -- which visits it redistributed (the scan's work lists, as one bit per visit:
+// flag_bits_kernel; ragged streams recompute the decision with visit_redistributes, the function the scan uses), for
+// the visits that stay in their pixel, and the pass's draw log (visit, pixel per accepted draw; the log the parity
+// tests compare with the oracle's in every mode of the pass) for the others.  The weight of
 // a draw is the visit's inverse density times 1 / draw count, recomputed like load_work_visit does.
 #pragma once
 
@@ -40,6 +41,9 @@ struct LentilCrypto {
   uint64_t n_visits = 0;
   uint64_t visits_gen = 0;                  // lentil_hip_ctx::visits_gen when the columns were handed over
   std::vector<void *> owned;                // device columns of lentil_hip_upload_crypto
+  bool tables_clear = false;                // nothing has been added since lentil_hip_clear_frame
+  uint32_t *d_flag_bits = nullptr;          // one bit per visit of the stream: redistributed by the last pass (flag_bits_kernel)
+  uint64_t flag_words = 0;
   float *d_rank = nullptr;                  // download staging: np RGBA + np flags
   uint8_t *d_has = nullptr;
   // (whether the draw log is this module's own, and what the last pass needed, live in the context --
@@ -139,12 +143,28 @@ __global__ __launch_bounds__(256) void crypto_direct_owner_kernel(CryptoDev C, V
 // consecutive pixels of the stream.  All lanes first read the tile's visits the way they lie in memory (lane = visit:
 // the three columns the decision needs, then per cryptomatte AOV the visits' pairs as one flat range) into LDS, and
 // the tile's table lines likewise; then lane = pixel walks its visits out of LDS, in stream order, into its LDS copy
-// of the table; the tables go back as whole lines.  HBM-bound: 48 B per visit once, entries * 8 B per visit and AOV,
-// the table lines read and written once per AOV.
+// of the table; the tables go back as whole lines.  HBM-bound: one bit per visit (48 B without the bitmap), entries * 8 B
+// per visit and AOV, the table lines written once per AOV (and read first unless the frame was just cleared).
 struct CryptoTile {
   uint32_t tp;            // pixels per tile (= block size)
   uint32_t off_w, off_h, off_cw, off_k, off_wt, off_tot, off_pix;     // LDS offsets in 4-byte words
+  const uint32_t *flagged;     // bit v: visit v was redistributed by the pass (its work lists, flag_bits_kernel); null: decide here
 };
+
+// The visits the pass has redistributed, as a bitmap: one bit per visit from the scan's work lists instead of the three
+// columns (48 B per visit) the decision would have to read again.
+__global__ __launch_bounds__(256) void flag_bits_kernel(const uint2 *work, const DevCounters *ctr, uint64_t cap, uint32_t *bits) {
+  const uint64_t n = ctr->work_count < cap ? ctr->work_count : cap;
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const uint32_t v = work[i].x;
+    atomicOr(bits + (v >> 5), 1u << (v & 31u));
+  }
+}
+
+// kCleared: the tables hold nothing yet (a pass straight after lentil_hip_clear_frame, the usual one): their lines are
+// not read, only written.
+template <bool kCleared>
 __global__ __launch_bounds__(128) void crypto_direct_tile_kernel(CryptoDev C, VisitsDev V, lentil_params P, double lens_length,
                                                                  CryptoTile T) {
   extern __shared__ uint32_t crypto_lds[];
@@ -166,6 +186,13 @@ __global__ __launch_bounds__(128) void crypto_direct_tile_kernel(CryptoDev C, Vi
     __syncthreads();                       // the previous tile's LDS is done with
     // (three visits' columns in flight per lane before the first decision: at 6 waves per CU the loads of one
     // iteration alone do not cover the HBM latency)
+    if (T.flagged) {
+      for (uint32_t i = threadIdx.x; i < nv; i += blockDim.x) {
+        const uint64_t v = v0 + i;
+        const bool redistributed = (T.flagged[v >> 5] >> (v & 31u)) & 1u;
+        s_w[i] = redistributed ? __uint_as_float(kCryptoEmpty) : (V.inv_density ? V.inv_density[v] : P.inverse_sample_density);
+      }
+    } else
     for (uint32_t i0 = threadIdx.x; i0 < nv; i0 += 3u * blockDim.x) {
       float4 pz[3], vi[3], tr[3];
 #pragma unroll
@@ -205,7 +232,9 @@ __global__ __launch_bounds__(128) void crypto_direct_tile_kernel(CryptoDev C, Vi
         for (uint32_t i = threadIdx.x; i < nv * E; i += blockDim.x) { s_h[i] = __builtin_nontemporal_load(gh + i); s_cw[i] = __builtin_nontemporal_load(gw + i); }
       }
       // the tile's table lines: element (pixel j, slot s); the pixel of tile entry j from its stream position
-      if ((SL & 3u) == 0) {
+      if (kCleared) {
+        for (uint32_t i = threadIdx.x; i < np_tile * SP; i += blockDim.x) { s_k[i] = kCryptoEmpty; s_wt[i] = 0.0f; }
+      } else if ((SL & 3u) == 0) {
         const uint32_t QL = SL / 4;
 #pragma unroll 4
         for (uint32_t i = threadIdx.x; i < np_tile * QL; i += blockDim.x) {
@@ -225,7 +254,7 @@ __global__ __launch_bounds__(128) void crypto_direct_tile_kernel(CryptoDev C, Vi
           s_wt[j * SP + sl] = C.wts[at];
         }
       }
-      if (own) s_tot[threadIdx.x] = C.total[(uint64_t)c * C.np + pix];
+      if (own) s_tot[threadIdx.x] = kCleared ? 0.0f : C.total[(uint64_t)c * C.np + pix];
       __syncthreads();
       if (own) {
         uint32_t *K = s_k + threadIdx.x * SP;
@@ -278,7 +307,10 @@ __global__ __launch_bounds__(128) void crypto_direct_tile_kernel(CryptoDev C, Vi
 // accepted draws (src/lentil_filter.cpp:296 polynomial optics, :443 thin lens; with abb_chromatic every channel's
 // draw is a log record of its own, like it is an add of its own there) -- sample weight = inverse density / draws
 __global__ __launch_bounds__(256) void crypto_draws_kernel(CryptoDev C, VisitsDev V, lentil_params P, double lens_length,
-                                                           const lentil_draw_record *log, uint64_t n_log) {
+                                                           const lentil_draw_record *log, const unsigned long long *log_count, uint64_t log_cap) {
+  // (the pass's own count, read here: the host does not wait for the pass before it enqueues this; a log that did not
+  // fit is found out afterwards, and the frame is void then)
+  const uint64_t n_log = *log_count < log_cap ? *log_count : log_cap;
   const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
   for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_log; i += stride) {
     const uint32_t v = log[i].visit;
@@ -366,7 +398,7 @@ static void crypto_destroy(lentil_hip_ctx *ctx) {
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   crypto_free_columns(k);
   (void)hipFree(k->D.keys); (void)hipFree(k->D.wts); (void)hipFree(k->D.total); (void)hipFree(k->D.overflow);
-  (void)hipFree(k->d_rank); (void)hipFree(k->d_has);
+  (void)hipFree(k->d_rank); (void)hipFree(k->d_has); (void)hipFree(k->d_flag_bits);
   delete k;
   ctx->crypto = nullptr;
 }
@@ -396,6 +428,7 @@ LENTIL_API int lentil_hip_alloc_crypto(lentil_hip_ctx *ctx, uint32_t n_crypto, u
   HIP_TRY(ctx, hipMemsetAsync(k->D.wts, 0, cells * sizeof(float), ctx->stream));
   HIP_TRY(ctx, hipMemsetAsync(k->D.total, 0, (uint64_t)n_crypto * k->D.np * sizeof(float), ctx->stream));
   HIP_TRY(ctx, hipMemsetAsync(k->D.overflow, 0, sizeof(unsigned long long), ctx->stream));
+  k->tables_clear = true;
   return LENTIL_OK;
 }
 
@@ -408,6 +441,7 @@ static int crypto_clear(lentil_hip_ctx *ctx) {
   HIP_TRY(ctx, hipMemsetAsync(k->D.wts, 0, cells * sizeof(float), ctx->stream));
   HIP_TRY(ctx, hipMemsetAsync(k->D.total, 0, (uint64_t)k->D.n_crypto * k->D.np * sizeof(float), ctx->stream));
   HIP_TRY(ctx, hipMemsetAsync(k->D.overflow, 0, sizeof(unsigned long long), ctx->stream));
+  k->tables_clear = true;
   return LENTIL_OK;
 }
 
@@ -485,19 +519,8 @@ static int crypto_before_pass(lentil_hip_ctx *ctx) {
 static int crypto_after_pass(lentil_hip_ctx *ctx) {
   LentilCrypto *k = ctx->crypto;
   if (!k || !ctx->V.n) return LENTIL_OK;
-  unsigned long long n_log = 0;
-  HIP_TRY(ctx, hipMemcpyAsync(&n_log, (char *)(ctx->d_ctr + ctx->n_chunks) + offsetof(DevCounters, log_count), sizeof(n_log),
-                              hipMemcpyDeviceToHost, ctx->stream));
-  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-  if (n_log > ctx->log_cap) {
-    const uint64_t had = ctx->log_cap;
-    if (ctx->crypto_auto_log) {       // this module's own log: the next pass gets one that fits
-      (void)lentil_hip_set_draw_log(ctx, 0);
-      ctx->crypto_auto_log_hint = n_log + n_log / 4;
-    }
-    return fail(ctx, LENTIL_ERR_NOMEM, "the draw log (" + std::to_string(had) + " records) is too small for the cryptomatte AOVs of this pass (" +
-                                           std::to_string(n_log) + " accepted draws): clear the frame and redistribute again");
-  }
+  const unsigned long long *d_n_log =
+      reinterpret_cast<const unsigned long long *>((char *)(ctx->d_ctr + ctx->n_chunks) + offsetof(DevCounters, log_count));
   const double lens_length = ctx->have_lens ? ctx->hlens.length : 0.0;
   const unsigned blocks = (unsigned)ctx->num_cu * 8;
   // pixel-major streams whose pixels are all distinct (one pass per clear: the tables hold nothing yet that another
@@ -519,22 +542,56 @@ static int crypto_after_pass(lentil_hip_ctx *ctx) {
     if (lds <= 64 * 1024 && !(force && force[0] == '0')) {
       const uint64_t n_tiles = (ctx->V.n / M + T.tp - 1) / T.tp;
       const uint64_t max_blocks = (uint64_t)ctx->num_cu * 16;
-      hipLaunchKernelGGL(crypto_direct_tile_kernel, dim3((unsigned)(n_tiles < max_blocks ? n_tiles : max_blocks)), dim3(128), lds,
-                         ctx->stream, k->D, ctx->V, ctx->P, lens_length, T);
+      // which visits the pass redistributed: from its work lists (LENTIL_CRYPTO_FLAGS=0: decided again from the columns)
+      static const bool use_flags = !(getenv("LENTIL_CRYPTO_FLAGS") && getenv("LENTIL_CRYPTO_FLAGS")[0] == '0');
+      if (use_flags && ctx->V.n <= 0xFFFFFFFFull) {
+        const uint64_t words = (ctx->V.n + 31) / 32;
+        if (words > k->flag_words) {
+          if (k->d_flag_bits) (void)hipFree(k->d_flag_bits);
+          k->d_flag_bits = nullptr; k->flag_words = 0;
+          HIP_TRY(ctx, hipMalloc(&k->d_flag_bits, words * sizeof(uint32_t)));
+          k->flag_words = words;
+        }
+        HIP_TRY(ctx, hipMemsetAsync(k->d_flag_bits, 0, words * sizeof(uint32_t), ctx->stream));
+        for (int ci = 0; ci < ctx->n_chunks; ++ci) {
+          const lentil_hip_ctx::Chunk &ch = ctx->chunks[ci];
+          if (ch.v_end <= ch.v_begin) continue;
+          hipLaunchKernelGGL(flag_bits_kernel, dim3(64), dim3(256), 0, ctx->stream, ctx->d_work + ch.v_begin, ctx->d_ctr + ci,
+                             ch.v_end - ch.v_begin, k->d_flag_bits);
+        }
+        HIP_TRY(ctx, hipGetLastError());
+        T.flagged = k->d_flag_bits;
+      }
+      const dim3 grid((unsigned)(n_tiles < max_blocks ? n_tiles : max_blocks));
+      if (k->tables_clear)
+        hipLaunchKernelGGL(crypto_direct_tile_kernel<true>, grid, dim3(128), lds, ctx->stream, k->D, ctx->V, ctx->P, lens_length, T);
+      else
+        hipLaunchKernelGGL(crypto_direct_tile_kernel<false>, grid, dim3(128), lds, ctx->stream, k->D, ctx->V, ctx->P, lens_length, T);
     } else {
       hipLaunchKernelGGL(crypto_direct_owner_kernel, dim3(blocks), dim3(256), 0, ctx->stream, k->D, ctx->V, ctx->P, lens_length);
     }
   } else
     hipLaunchKernelGGL(crypto_direct_kernel, dim3(blocks), dim3(256), 0, ctx->stream, k->D, ctx->V, ctx->P, lens_length);
   HIP_TRY(ctx, hipGetLastError());
-  if (n_log) {
+  k->tables_clear = false;
+  if (ctx->log_cap) {
     hipLaunchKernelGGL(crypto_draws_kernel, dim3(blocks), dim3(256), 0, ctx->stream, k->D, ctx->V, ctx->P, lens_length,
-                       ctx->d_log, (uint64_t)n_log);
+                       ctx->d_log, d_n_log, (uint64_t)ctx->log_cap);
     HIP_TRY(ctx, hipGetLastError());
   }
-  unsigned long long full = 0;
+  unsigned long long full = 0, n_log = 0;
+  HIP_TRY(ctx, hipMemcpyAsync(&n_log, d_n_log, sizeof(n_log), hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(ctx, hipMemcpyAsync(&full, k->D.overflow, sizeof(full), hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  if (n_log > ctx->log_cap) {
+    const uint64_t had = ctx->log_cap;
+    if (ctx->crypto_auto_log) {       // this module's own log: the next pass gets one that fits
+      (void)lentil_hip_set_draw_log(ctx, 0);
+      ctx->crypto_auto_log_hint = n_log + n_log / 4;
+    }
+    return fail(ctx, LENTIL_ERR_NOMEM, "the draw log (" + std::to_string(had) + " records) is too small for the cryptomatte AOVs of this pass (" +
+                                           std::to_string(n_log) + " accepted draws): clear the frame and redistribute again");
+  }
   if (full)
     return fail(ctx, LENTIL_ERR_NOMEM, std::to_string(full) + " cryptomatte adds found their pixel's table full (" + std::to_string(k->D.slots) +
                                            " ids per pixel): allocate more slots (lentil_hip_alloc_crypto)");

@@ -138,6 +138,7 @@ struct lentil_hip_ctx {
   uint32_t unknown_credit = 7;        // LENTIL_UNKNOWN_CREDIT (0..8): DrawArgs::unknown_credit
   bool chain_streams = true;          // LENTIL_CHAIN_STREAMS=0: a decoupled pass keeps its accepts on the main stream
   hipEvent_t ev_solve = nullptr, ev_slow1 = nullptr;
+  bool streams_concurrent = false;      // pick_concurrent_streams: the streamed pass's four streams run their kernels side by side
   hipStream_t slow1_stream = nullptr;   // a decoupled pass's second-round straggler kernel (beside the first round's, which is still at work)
   bool decouple = true;              // LENTIL_DECOUPLE=0: a streamed pass's first accept waits for the first round's stragglers
   hipEvent_t ev_slow = nullptr, ev_round = nullptr;
@@ -210,6 +211,69 @@ static double host_ipow(double x, int e) {   // lens_ipow, src/lens.h:226-233
 
 LENTIL_API int lentil_hip_abi_version(void) { return LENTIL_ABI_VERSION; }
 
+// ---------------------------------------------------------------------------------------
+// A streamed pass keeps four kernels resident that hand work to one another -- scan (main stream), publish_kernel and
+// the straggler kernel (pub_stream), the persistent solve kernel (the first chunk's stream), the second round's
+// stragglers (slow1_stream).  The runtime multiplexes a process's streams onto a few hardware queues (GPU_MAX_HW_QUEUES,
+// 4 by default), and kernels of streams that share one run one after the other: the pass still ends (nothing in it waits
+// for a kernel submitted later), but publish_kernel behind the scan means the solves start when the scan has ended --
+// 3.4 ms for the headline frame instead of 2.3, seen for every context but the first one a process creates.  So the
+// four streams are chosen: a candidate is kept if a kernel on it runs while a kernel on each stream kept so far is
+// waiting for it (probe_wait_kernel / probe_set_kernel), else another stream is created -- the rejected ones stay
+// alive until the choice is made, so that the runtime hands out a different queue next.  LENTIL_STREAM_PROBE=0: take
+// the streams as they come.
+// ---------------------------------------------------------------------------------------
+static bool streams_run_together(lentil_hip_ctx *ctx, hipStream_t x, hipStream_t y, uint32_t *d_flag) {
+  uint32_t *d_seen = d_flag + 1;
+  if (hipMemsetAsync(d_flag, 0, 2 * sizeof(uint32_t), x) != hipSuccess) return false;
+  if (hipStreamSynchronize(x) != hipSuccess) return false;
+  hipLaunchKernelGGL(probe_wait_kernel, dim3(1), dim3(1), 0, x, d_flag, d_seen);
+  hipLaunchKernelGGL(probe_set_kernel, dim3(1), dim3(1), 0, y, d_flag);
+  (void)hipStreamSynchronize(x);
+  (void)hipStreamSynchronize(y);
+  uint32_t seen = 0;
+  if (hipMemcpy(&seen, d_seen, sizeof(seen), hipMemcpyDeviceToHost) != hipSuccess) return false;
+  (void)ctx;
+  return seen != 0u;
+}
+
+static int pick_concurrent_streams(lentil_hip_ctx *ctx) {
+  ctx->streams_concurrent = false;
+  if (const char *e = getenv("LENTIL_STREAM_PROBE")) if (e[0] == '0') return LENTIL_OK;
+  uint32_t *d_flag = nullptr;
+  HIP_TRY(ctx, hipMalloc(&d_flag, 2 * sizeof(uint32_t)));
+  hipStream_t *role[4] = {&ctx->stream, &ctx->chunks[0].stream, &ctx->pub_stream, &ctx->slow1_stream};
+  std::vector<hipStream_t> rejected;
+  bool all = true;
+  int created = 0;
+  for (int r = 1; r < 4; ++r) {
+    while (true) {
+      bool ok = true;
+      for (int q = 0; q < r && ok; ++q) ok = streams_run_together(ctx, *role[q], *role[r], d_flag);
+      if (ok) break;
+      if (created >= 12) { all = false; break; }       // (fewer than four hardware queues to be had: as they come)
+      rejected.push_back(*role[r]);
+      hipStream_t s = nullptr;
+      if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) { *role[r] = rejected.back(); rejected.pop_back(); all = false; break; }
+      *role[r] = s;
+      ++created;
+    }
+  }
+  for (hipStream_t s : rejected) (void)hipStreamDestroy(s);
+  (void)hipFree(d_flag);
+  (void)hipGetLastError();
+  ctx->streams_concurrent = all;
+  if (getenv("LENTIL_STREAM_DEBUG")) fprintf(stderr, "[stream] the pass's four streams run together: %d (%d streams tried beyond the first four)\n", (int)all, created);
+  return LENTIL_OK;
+}
+
+LENTIL_API int lentil_hip_streams_concurrent(lentil_hip_ctx *ctx, int *concurrent) {
+  CHECK_CTX(ctx);
+  if (!concurrent) return fail(ctx, LENTIL_ERR_INVALID, "concurrent is null");
+  *concurrent = ctx->streams_concurrent ? 1 : 0;
+  return LENTIL_OK;
+}
+
 LENTIL_API int lentil_hip_create(int device, lentil_hip_ctx **out_ctx) {
   if (!out_ctx) return fail(nullptr, LENTIL_ERR_INVALID, "out_ctx is null");
   *out_ctx = nullptr;
@@ -251,6 +315,7 @@ LENTIL_API int lentil_hip_create(int device, lentil_hip_ctx **out_ctx) {
   HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_solve, hipEventDisableTiming));
   HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_slow1, hipEventDisableTiming));
   HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->slow1_stream, hipStreamNonBlocking));
+  { const int rc = pick_concurrent_streams(ctx); if (rc) return rc; }
   if (const char *e = getenv("LENTIL_EARLY_RESOLVE")) ctx->early_resolve = atoi(e) != 0;
   if (const char *ft = getenv("LENTIL_FORCE_TABLES")) ctx->use_generated = !(ft[0] == '1');
   if (const char *fc = getenv("LENTIL_FIRST_CHUNK_FRAC")) {
@@ -1505,7 +1570,13 @@ static int redistribute_streamed(lentil_hip_ctx *ctx, bool *streamed) {
   const uint32_t slow_cap_all = da.slow_cap;
   da.slow_crowd_stays = ctx->crowd_stays_first;
   da.unknown_credit = ctx->unknown_credit;
-  if (decoupled) { da.slow_indirect = 1; da.slow_cap = slow_cap_all / 2u > (uint32_t)ctx->num_cu ? slow_cap_all / 2u - (uint32_t)ctx->num_cu : 0u; }      // (its end markers stay below the upper half)
+  // (one straggler wave per CU; LENTIL_SLOW_WAVES_PER_CU, up to 4 -- measured on config 4, whose rounds end in hundreds
+  // of parked solves at once: 9.15 / 9.18 / 9.35 / 9.46 ms with 1 / 2 / 3 / 4, the waves take from the solve kernel)
+  static const int slow_per_cu = getenv("LENTIL_SLOW_WAVES_PER_CU") ? atoi(getenv("LENTIL_SLOW_WAVES_PER_CU")) : 0;
+  if (ctx->parked_frac > 1.0 / 256.0) ctx->park_dry_seen = true;
+  const bool dry_only = ctx->park_dry_only >= 0 ? ctx->park_dry_only != 0 : ctx->park_dry_seen;
+  const uint32_t slow_waves_all = (uint32_t)ctx->num_cu * (slow_per_cu >= 1 && slow_per_cu <= 4 ? (uint32_t)slow_per_cu : 1u);
+  if (decoupled) { da.slow_indirect = 1; da.slow_cap = slow_cap_all / 2u > slow_waves_all ? slow_cap_all / 2u - slow_waves_all : 0u; }      // (its end markers stay below the upper half)
   const unsigned b_threads = live ? 192u : 256u;
   unsigned b_blocks;
   {
@@ -1525,9 +1596,8 @@ static int redistribute_streamed(lentil_hip_ctx *ctx, bool *streamed) {
   // a lens where such solves are not outliers (the petzval table: 3 % of all solves, 62 000 a frame, each a whole wave
   // of the straggler kernel: 12 ms a frame against 10 chunked) only waves running dry park, and only their last lanes.
   // (It stays that way for the lens: a pass that parks dry waves' lanes only says nothing about what a live queue would get.)
-  if (ctx->parked_frac > 1.0 / 256.0) ctx->park_dry_seen = true;
-  da.slow_dry_only = ctx->park_dry_only >= 0 ? ctx->park_dry_only : (ctx->park_dry_seen ? 1 : 0);
-  da.slow_waves = live ? (uint32_t)ctx->num_cu : 0u;
+  da.slow_dry_only = dry_only ? 1 : 0;
+  da.slow_waves = live ? slow_waves_all : 0u;
   da.producers_done = &ctx->d_ctr->publishers_done;
   da.producers_total = (uint32_t)ctx->publish_waves;
   pa.end_tasks = a_blocks * 4u + b_blocks * (b_threads / 64u);       // every first-round solve wave may hold one ticket past the last task

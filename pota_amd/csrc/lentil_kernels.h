@@ -211,6 +211,18 @@ LD_DEV uint32_t ld_coherent32(const void *p) {
   asm volatile("global_atomic_cmpswap %0, %1, %2, off sc0\n\ts_waitcnt vmcnt(0)" : "=&v"(old) : "v"(p), "v"(swap_cmp) : "memory");
   return old;
 }
+// Do two streams run kernels at the same time?  (lentil_hip_create, pick_concurrent_streams: streams that share one of
+// the runtime's hardware queues run their kernels one after the other.)  The waiting kernel gives up after 2 ms.
+__global__ void probe_wait_kernel(uint32_t *flag, uint32_t *seen) {
+  const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
+  while (ld_coherent32(flag) == 0u) {
+    if (__builtin_amdgcn_s_memrealtime() - t0 > 200000ull) { *seen = 0u; return; }
+    __builtin_amdgcn_s_sleep(32);
+  }
+  *seen = 1u;
+}
+__global__ void probe_set_kernel(uint32_t *flag) { (void)__hip_atomic_exchange(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
 constexpr uint32_t kEndCount = 0xFFu;       // Task::count of the end-of-queue markers behind the last task
 constexpr uint32_t kEndRange = 0x3FFu;      // ... and the count field of the end markers of the range queue
 // every wait on a queue slot is bounded: 250 ms of the 100 MHz real-time counter, then DevCounters::stuck (the
@@ -2210,6 +2222,16 @@ __global__ __launch_bounds__(256) void solve_thinlens_kernel(DrawArgs a) {
 // One 256-thread block per item; each step resolves 256 consecutive attempts (wave w: attempts
 // n + 64w .. n + 64w + 63) and ranks the successes across the four waves through LDS, so that exactly
 // the first `samples` successes in attempt order are accepted.
+// Draw-log slots for the lanes of `mask` (the calling lanes: all of them, no others): the first takes popcount(mask)
+// slots with one atomic, every lane gets its own by rank.
+LD_DEV unsigned long long wave_log_slots(unsigned long long *log_count, unsigned long long mask, uint32_t lane) {
+  const int first = __builtin_ctzll(mask);
+  unsigned long long base = 0;
+  if ((int)lane == first) base = atomicAdd(log_count, (unsigned long long)__builtin_popcountll(mask));
+  const uint32_t lo = (uint32_t)__shfl((int)(uint32_t)base, first), hi = (uint32_t)__shfl((int)(uint32_t)(base >> 32), first);
+  return (((unsigned long long)hi << 32) | lo) + (unsigned long long)__builtin_popcountll(mask & ((1ull << lane) - 1ull));
+}
+
 struct AcceptShared {
   uint32_t first_u[4];
   uint32_t nsucc[4];
@@ -2439,7 +2461,8 @@ LD_DEV AcceptResult accept_item(const DrawArgs &a, AcceptShared &sh, uint32_t it
         if (a.F.zkey) atomicMin(a.F.zkey + pix, zk);
         if (a.F.zkey_dbg) atomicMin(a.F.zkey_dbg + pix, zk);      // value.r = samples != 0 for every draw
         if (a.log_cap) {
-          const unsigned long long li = atomicAdd(a.log_count, 1ull);
+          // one returning atomic per wave step, not per draw: a million of them on ONE counter cost the pass 1.1 ms
+          const unsigned long long li = wave_log_slots(a.log_count, pmask0, lane);
           if (li < a.log_cap) { a.log[li].visit = h.visit; a.log[li].attempt = my_n; a.log[li].pixel = pix; }
         }
       }
@@ -2633,7 +2656,7 @@ LD_DEV AcceptResult accept_item_chroma(const DrawArgs &a, AcceptShared &sh, uint
         if (a.F.zkey) atomicMin(a.F.zkey + pix, zk);
         if (a.F.zkey_dbg) atomicMin(a.F.zkey_dbg + pix, zk);      // value.r = samples != 0 for every draw
         if (a.log_cap) {
-          const unsigned long long li = atomicAdd(a.log_count, 1ull);
+          const unsigned long long li = wave_log_slots(a.log_count, tmask, lane);
           if (li < a.log_cap) { a.log[li].visit = h.visit; a.log[li].attempt = my_n | (c << 30); a.log[li].pixel = pix; }
         }
       }
@@ -2975,7 +2998,7 @@ __global__ __launch_bounds__(256) void tl_chroma_walk_kernel(TlChromaArgs a) {
         if (a.F.zkey) atomicMin(a.F.zkey + pix, zk);
         if (a.F.zkey_dbg) atomicMin(a.F.zkey_dbg + pix, zk);
         if (a.log_cap) {
-          const unsigned long long li = atomicAdd(a.log_count, 1ull);
+          const unsigned long long li = wave_log_slots(a.log_count, tm, lane);
           if (li < a.log_cap) { a.log[li].visit = h.visit; a.log[li].attempt = my_n | ((uint32_t)(channel + 1) << 30); a.log[li].pixel = pix; }
         }
       }

@@ -266,3 +266,15 @@ def test_moving_camera_per_sample_time(orc, gpu_ctx_factory, n_keys, ragged):
     tp.gpu_run(ctx, p, table, visits)
     tp.check_logs(ctx, still)
     ref.close(); still.close()
+
+
+@pytest.mark.gpu
+def test_every_context_gets_streams_that_run_together(gpu_ctx_factory):
+    """lentil_hip_create picks the four streams a streamed pass keeps kernels resident on so that they do not share a
+    hardware queue (the runtime multiplexes streams onto GPU_MAX_HW_QUEUES queues, 4 by default): true for the first
+    context of a process by luck, for the later ones by the probe."""
+    import os
+    if os.environ.get("GPU_MAX_HW_QUEUES", "4").isdigit() and int(os.environ.get("GPU_MAX_HW_QUEUES", "4")) < 4:
+        pytest.skip("fewer than four hardware queues allowed")
+    ctxs = [gpu_ctx_factory() for _ in range(4)]
+    assert [c.streams_concurrent() for c in ctxs] == [True] * 4

@@ -34,9 +34,15 @@ def timed(ctx, reps=5):
     return best * 1e3
 
 
-for n_crypto in (0, 1, 3):
+for n_crypto in (0, -1, 1, 3):
     ctx = capi.Context(0); ctx.set_params(p); ctx.set_lens(table); ctx.alloc_frame(1)
     ctx.bind_visits(visits, kv)
+    if n_crypto < 0:
+        # the pass with a draw log and nothing else: what the log alone costs it
+        ctx.set_draw_log(4 << 20)
+        out["log_only"] = {"redistribute_ms": round(timed(ctx), 3), "streamed": int(ctx.counters().streamed), "timing": [round(x, 3) for x in ctx.last_timing()]}
+        ctx.close()
+        continue
     keepc = None
     if n_crypto:
         ctx.alloc_crypto(n_crypto, 16)
@@ -54,13 +60,13 @@ for n_crypto in (0, 1, 3):
     ms = timed(ctx)
     c = ctx.counters()
     key = "crypto_%d" % n_crypto
-    out[key] = {"redistribute_ms": round(ms, 3), "accepted_draws": int(c.accepted_draws)}
+    out[key] = {"redistribute_ms": round(ms, 3), "accepted_draws": int(c.accepted_draws), "streamed": int(c.streamed), "timing": [round(x, 3) for x in ctx.last_timing()]}
     if n_crypto:
         out[key]["added_ms"] = round(ms - out["crypto_0"]["redistribute_ms"], 3)
         out[key]["added_ms_per_aov"] = round((ms - out["crypto_0"]["redistribute_ms"]) / n_crypto, 3)
-        # algorithmic bytes of the replay: the visit columns the decision reads (pos_z, volume_ignore, transmission: 48 B)
-        # once, per AOV the visits' pairs (entries * 8 B) and the pixel's table lines read and written (slots * 8 B * 2)
-        alg = n * 48 + n_crypto * (n * ENTRIES * 8 + W * H * (16 * 8 * 2 + 8))
+        # algorithmic bytes of the replay: which visits were redistributed (a bit each), per AOV the visits' pairs
+        # (entries * 8 B) and the pixel's table lines (slots * 8 B + the total)
+        alg = n // 8 + n_crypto * (n * ENTRIES * 8 + W * H * (16 * 8 + 4))      # (one bit per visit; tables written, not read, after a clear)
         out[key]["replay_GBps_algorithmic"] = round(alg / max(ms - out["crypto_0"]["redistribute_ms"], 1e-6) / 1e6, 1)
         t0 = time.perf_counter(); img, has = ctx.download_crypto(0, 0); t1 = time.perf_counter()
         out[key]["rank_and_download_ms"] = round((t1 - t0) * 1e3, 2)

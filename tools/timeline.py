@@ -39,6 +39,7 @@ def main():
     ap.add_argument("--f-hi", type=float, default=2.0 ** -16)
     ap.add_argument("--lens", default="double_gauss_50mm")
     ap.add_argument("--aovs", type=int, default=0, help="extra AOVs (BASELINE config 4: --lens petzval_58mm --aovs 8)")
+    ap.add_argument("--log", type=int, default=0, help="draw log capacity (records)")
     ap.add_argument("--out", default="")
     args = ap.parse_args()
     if args.build:
@@ -56,7 +57,7 @@ def main():
     p, model, table, keep = common.po_setup(W, H, lens=args.lens, samples_override=args.samples)
     dev = torch.device("cuda:0")
     ctx = capi.Context(0)
-    ctx.set_params(p); ctx.set_lens(table); ctx.set_bokeh(None); ctx.alloc_frame(1 + args.aovs); ctx.set_draw_log(0)
+    ctx.set_params(p); ctx.set_lens(table); ctx.set_bokeh(None); ctx.alloc_frame(1 + args.aovs); ctx.set_draw_log(args.log)
     streams = []
     for seed in (0x5EED, 0xBEEF):
         cols = workload.generate(torch, 0, W * H * M, W, H, M, seed=seed, f_hi=args.f_hi, focus_dist=150.0,
