@@ -171,6 +171,7 @@ LENTIL_API int lentil_hip_allreduce(lentil_hip_ctx *ctx) {
   if (!ctx->have_frame) return fail(ctx, LENTIL_ERR_INVALID, "no frame allocated");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   int rc;
+  if (ctx->crypto) return fail(ctx, LENTIL_ERR_UNSUPPORTED, "cryptomatte AOVs travel with the tiled exchange only (lentil_hip_exchange_bands)");
   if ((rc = fold_direct(ctx, 0, ctx->F.np, true))) return rc;        // what the scan kept apart joins the sum
   untrust_touched(ctx);
   if (ctx->F.zkey || ctx->F.zkey_dbg) {
@@ -336,6 +337,12 @@ LENTIL_API int lentil_hip_exchange_bands(lentil_hip_ctx *ctx, const int32_t *bou
     if (r_end) return fail(ctx, LENTIL_ERR_HIP, std::string("ncclGroupEnd: ") + g_rccl.GetErrorString(r_end));
   }
   cm->last_sent = sent; cm->last_received = received;
+  // ---- cryptomatte maps: what this rank's draws added outside its band goes to the owners (lentil_crypto.h)
+  if (ctx->crypto) {
+    std::vector<int32_t> bands((size_t)(2 * world), 0);
+    for (int q = 0; q < world; ++q) band_of(q, bands[(size_t)(2 * q)], bands[(size_t)(2 * q + 1)]);
+    if ((rc = crypto_exchange_bands(ctx, bands.data(), lo, hi))) return rc;
+  }
   // ---- merge what arrived (senders in rank order: the merge of one sender's entries is not atomic against another's)
   for (int q = 0; q < world; ++q) {
     const In &i = in[(size_t)q];

@@ -56,28 +56,67 @@ LD_DEV uint32_t crypto_key_bits(float id) {
   return b == 0x80000000u ? 0u : b;
 }
 
+// map[key] += val for pixel pix of cryptomatte AOV c (key: crypto_key_bits), with atomics
+LD_DEV void crypto_table_add(const CryptoDev &C, uint32_t c, uint64_t pix, uint32_t key, float val) {
+  uint32_t *K = C.keys + ((uint64_t)c * C.np + pix) * C.slots;
+  float *Wt = C.wts + ((uint64_t)c * C.np + pix) * C.slots;
+  uint32_t s = (key * 2654435761u >> 16) % C.slots;
+  bool placed = false;
+  for (uint32_t i = 0; i < C.slots && !placed; ++i) {
+    uint32_t cur = __hip_atomic_load(K + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (cur == kCryptoEmpty) cur = atomicCAS(K + s, kCryptoEmpty, key);
+    if (cur == kCryptoEmpty || cur == key) { atomicAdd(Wt + s, val); placed = true; }
+    else s = s + 1u == C.slots ? 0u : s + 1u;
+  }
+  if (!placed) atomicAdd(C.overflow, 1ull);
+}
+
 // add_to_buffer_cryptomatte, src/lentil.h:814-819, for visit v and every cryptomatte AOV
 LD_DEV void crypto_add_visit(const CryptoDev &C, uint64_t pix, uint64_t v, float sample_weight) {
   for (uint32_t c = 0; c < C.n_crypto; ++c) {
     atomicAdd(C.total + (uint64_t)c * C.np + pix, sample_weight);                       // :815
-    uint32_t *K = C.keys + ((uint64_t)c * C.np + pix) * C.slots;
-    float *Wt = C.wts + ((uint64_t)c * C.np + pix) * C.slots;
     const float *h = C.hash[c] + v * C.entries, *w = C.weight[c] + v * C.entries;
     for (uint32_t e = 0; e < C.entries; ++e) {
       const float cw = w[e];
       if (__float_as_uint(cw) == kCryptoEmpty) continue;
-      const uint32_t key = crypto_key_bits(h[e]);
-      const float val = cw * sample_weight;                                             // :817
-      uint32_t s = (key * 2654435761u >> 16) % C.slots;
-      bool placed = false;
-      for (uint32_t i = 0; i < C.slots && !placed; ++i) {
-        uint32_t cur = __hip_atomic_load(K + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (cur == kCryptoEmpty) cur = atomicCAS(K + s, kCryptoEmpty, key);
-        if (cur == kCryptoEmpty || cur == key) { atomicAdd(Wt + s, val); placed = true; }
-        else s = s + 1u == C.slots ? 0u : s + 1u;
-      }
-      if (!placed) atomicAdd(C.overflow, 1ull);
+      crypto_table_add(C, c, pix, crypto_key_bits(h[e]), cw * sample_weight);           // :817
     }
+  }
+}
+
+// ---- between GPUs (lentil_hip_exchange_bands): what this rank's draws added to the maps of pixels in another rank's
+// band travels as a list of 16-byte records -- (pixel, AOV, id bits, weight) per map entry, (pixel, AOV | kCryptoTotal, 0,
+// total weight) per pixel and AOV -- and is added to the owner's tables there.
+constexpr uint32_t kCryptoTotal = 0x80000000u;
+// records of rows [p_begin, p_begin + n_pix): counted (out == nullptr) or written
+__global__ __launch_bounds__(256) void crypto_band_records_kernel(CryptoDev C, uint64_t p_begin, uint64_t n_pix, uint4 *out,
+                                                                  unsigned long long cap, unsigned long long *count) {
+  const uint64_t cells = n_pix * C.n_crypto;
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < cells; i += stride) {
+    const uint32_t c = (uint32_t)(i / n_pix);
+    const uint64_t pix = p_begin + (i - (uint64_t)c * n_pix);
+    const uint32_t *K = C.keys + ((uint64_t)c * C.np + pix) * C.slots;
+    const float *Wt = C.wts + ((uint64_t)c * C.np + pix) * C.slots;
+    const float total = C.total[(uint64_t)c * C.np + pix];
+    uint32_t n = total != 0.0f ? 1u : 0u;
+    for (uint32_t s = 0; s < C.slots; ++s) n += K[s] != kCryptoEmpty ? 1u : 0u;
+    if (!n) continue;
+    unsigned long long at = atomicAdd(count, (unsigned long long)n);
+    if (!out) continue;
+    if (total != 0.0f) { if (at < cap) out[at] = make_uint4((uint32_t)pix, c | kCryptoTotal, 0u, __float_as_uint(total)); ++at; }
+    for (uint32_t s = 0; s < C.slots; ++s)
+      if (K[s] != kCryptoEmpty) { if (at < cap) out[at] = make_uint4((uint32_t)pix, c, K[s], __float_as_uint(Wt[s])); ++at; }
+  }
+}
+__global__ __launch_bounds__(256) void crypto_merge_records_kernel(CryptoDev C, const uint4 *rec, uint64_t n) {
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const uint4 r = rec[i];
+    const uint32_t c = r.y & ~kCryptoTotal;
+    if (c >= C.n_crypto || r.x >= C.np) continue;
+    if (r.y & kCryptoTotal) atomicAdd(C.total + (uint64_t)c * C.np + r.x, __uint_as_float(r.w));
+    else crypto_table_add(C, c, r.x, r.z, __uint_as_float(r.w));
   }
 }
 
@@ -501,8 +540,8 @@ static int crypto_before_pass(lentil_hip_ctx *ctx) {
   if (!k) return LENTIL_OK;
   if (!k->have_columns || k->n_visits != ctx->V.n || k->visits_gen != ctx->visits_gen)
     return fail(ctx, LENTIL_ERR_INVALID, "the cryptomatte columns do not belong to the bound visit stream (lentil_hip_upload_crypto / _bind_crypto after the visits)");
-  if (ctx->comm || ctx->closest_deferred)
-    return fail(ctx, LENTIL_ERR_UNSUPPORTED, "cryptomatte AOVs are not exchanged between GPUs");
+  if (ctx->closest_deferred)
+    return fail(ctx, LENTIL_ERR_UNSUPPORTED, "cryptomatte AOVs travel with the tiled exchange only (lentil_hip_exchange_bands)");
   if (ctx->log_cap == 0) {
     // no log asked for by the caller: one sized from the last pass, or 4 Mi records (48 MB; LENTIL_CRYPTO_LOG overrides)
     uint64_t want = 4ull << 20;
@@ -592,6 +631,89 @@ static int crypto_after_pass(lentil_hip_ctx *ctx) {
     return fail(ctx, LENTIL_ERR_NOMEM, "the draw log (" + std::to_string(had) + " records) is too small for the cryptomatte AOVs of this pass (" +
                                            std::to_string(n_log) + " accepted draws): clear the frame and redistribute again");
   }
+  if (full)
+    return fail(ctx, LENTIL_ERR_NOMEM, std::to_string(full) + " cryptomatte adds found their pixel's table full (" + std::to_string(k->D.slots) +
+                                           " ids per pixel): allocate more slots (lentil_hip_alloc_crypto)");
+  return LENTIL_OK;
+}
+
+// lentil_hip_exchange_bands, behind the accumulators' exchange: bands[2 q], bands[2 q + 1] = rank q's rows; [lo, hi) =
+// the rows this rank's draws touched.  Counts first (one small all-gather), then one send / receive per pair, then the
+// arrivals are added in rank order.
+static int crypto_exchange_bands(lentil_hip_ctx *ctx, const int32_t *bands, int32_t lo, int32_t hi) {
+  LentilCrypto *k = ctx->crypto;
+  LentilComm *cm = ctx->comm;
+  if (!k || !cm) return LENTIL_OK;
+  const int world = cm->world, rank = cm->rank;
+  const uint32_t xres = ctx->P.xres;
+  const unsigned blocks = (unsigned)ctx->num_cu * 8;
+  int rc;
+  void *p;
+  if ((rc = comm_scratch(ctx, cm, (size_t)world * 12 + 0, (size_t)world * sizeof(unsigned long long), &p))) return rc;
+  unsigned long long *d_counts = (unsigned long long *)p;
+  HIP_TRY(ctx, hipMemsetAsync(d_counts, 0, (size_t)world * sizeof(unsigned long long), ctx->stream));
+  std::vector<int32_t> s_lo((size_t)world, 0), s_hi((size_t)world, 0);
+  for (int q = 0; q < world; ++q) {
+    if (q == rank) continue;
+    s_lo[(size_t)q] = lo > bands[2 * q] ? lo : bands[2 * q];
+    s_hi[(size_t)q] = hi < bands[2 * q + 1] ? hi : bands[2 * q + 1];
+    if (s_hi[(size_t)q] <= s_lo[(size_t)q]) continue;
+    hipLaunchKernelGGL(crypto_band_records_kernel, dim3(blocks), dim3(256), 0, ctx->stream, k->D, (uint64_t)s_lo[(size_t)q] * xres,
+                       (uint64_t)(s_hi[(size_t)q] - s_lo[(size_t)q]) * xres, (uint4 *)nullptr, 0ull, d_counts + q);
+  }
+  HIP_TRY(ctx, hipGetLastError());
+  std::vector<unsigned long long> n_out((size_t)world, 0);
+  HIP_TRY(ctx, hipMemcpyAsync(n_out.data(), d_counts, (size_t)world * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  // the lists themselves
+  std::vector<uint4 *> out((size_t)world, nullptr);
+  HIP_TRY(ctx, hipMemsetAsync(d_counts, 0, (size_t)world * sizeof(unsigned long long), ctx->stream));
+  for (int q = 0; q < world; ++q) {
+    if (!n_out[(size_t)q]) continue;
+    if ((rc = comm_scratch(ctx, cm, (size_t)q * 12 + 10, (size_t)n_out[(size_t)q] * sizeof(uint4), &p))) return rc;
+    out[(size_t)q] = (uint4 *)p;
+    hipLaunchKernelGGL(crypto_band_records_kernel, dim3(blocks), dim3(256), 0, ctx->stream, k->D, (uint64_t)s_lo[(size_t)q] * xres,
+                       (uint64_t)(s_hi[(size_t)q] - s_lo[(size_t)q]) * xres, out[(size_t)q], n_out[(size_t)q], d_counts + q);
+  }
+  HIP_TRY(ctx, hipGetLastError());
+  // who sends how much to whom: row r of the gathered matrix is rank r's list sizes per destination
+  std::vector<int64_t> mine((size_t)world, 0);
+  for (int q = 0; q < world; ++q) mine[(size_t)q] = (int64_t)n_out[(size_t)q];
+  HIP_TRY(ctx, hipMemcpyAsync(cm->d_meta_mine, mine.data(), (size_t)world * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream));
+  RCCL_TRY(ctx, g_rccl.AllGather(cm->d_meta_mine, cm->d_meta_all, (size_t)world, kNcclInt64, cm->comm, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(cm->h_meta_all, cm->d_meta_all, (size_t)world * (size_t)world * sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  std::vector<uint64_t> n_in((size_t)world, 0);
+  std::vector<uint4 *> in((size_t)world, nullptr);
+  for (int q = 0; q < world; ++q) {
+    if (q == rank) continue;
+    n_in[(size_t)q] = (uint64_t)cm->h_meta_all[(size_t)q * (size_t)world + (size_t)rank];
+    if (!n_in[(size_t)q]) continue;
+    if ((rc = comm_scratch(ctx, cm, (size_t)q * 12 + 11, (size_t)n_in[(size_t)q] * sizeof(uint4), &p))) return rc;
+    in[(size_t)q] = (uint4 *)p;
+  }
+  RCCL_TRY(ctx, g_rccl.GroupStart());
+  int g_err = 0;
+  for (int q = 0; q < world; ++q) {
+    if (q == rank) continue;
+    if (n_out[(size_t)q] && !g_err) g_err = g_rccl.Send(out[(size_t)q], (size_t)n_out[(size_t)q] * 16, kNcclUint8, q, cm->comm, ctx->stream);
+    if (n_in[(size_t)q] && !g_err) g_err = g_rccl.Recv(in[(size_t)q], (size_t)n_in[(size_t)q] * 16, kNcclUint8, q, cm->comm, ctx->stream);
+    cm->last_sent += n_out[(size_t)q] * 16ull; cm->last_received += n_in[(size_t)q] * 16ull;
+  }
+  {
+    const int r_end = g_rccl.GroupEnd();
+    if (g_err) return fail(ctx, LENTIL_ERR_HIP, std::string("ncclSend / ncclRecv (cryptomatte): ") + g_rccl.GetErrorString(g_err));
+    if (r_end) return fail(ctx, LENTIL_ERR_HIP, std::string("ncclGroupEnd (cryptomatte): ") + g_rccl.GetErrorString(r_end));
+  }
+  for (int q = 0; q < world; ++q) {
+    if (!n_in[(size_t)q]) continue;
+    hipLaunchKernelGGL(crypto_merge_records_kernel, dim3(blocks), dim3(256), 0, ctx->stream, k->D, in[(size_t)q], n_in[(size_t)q]);
+  }
+  HIP_TRY(ctx, hipGetLastError());
+  k->tables_clear = false;
+  unsigned long long full = 0;
+  HIP_TRY(ctx, hipMemcpyAsync(&full, k->D.overflow, sizeof(full), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   if (full)
     return fail(ctx, LENTIL_ERR_NOMEM, std::to_string(full) + " cryptomatte adds found their pixel's table full (" + std::to_string(k->D.slots) +
                                            " ids per pixel): allocate more slots (lentil_hip_alloc_crypto)");

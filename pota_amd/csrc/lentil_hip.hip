@@ -415,6 +415,7 @@ static void crypto_bind_uploaded(lentil_hip_ctx *ctx, uint32_t n_crypto, uint32_
 static int crypto_clear(lentil_hip_ctx *ctx);
 static int crypto_before_pass(lentil_hip_ctx *ctx);
 static int crypto_after_pass(lentil_hip_ctx *ctx);
+static int crypto_exchange_bands(lentil_hip_ctx *ctx, const int32_t *bands, int32_t lo, int32_t hi);
 
 LENTIL_API int lentil_hip_destroy(lentil_hip_ctx *ctx) {
   if (!ctx) return LENTIL_OK;

@@ -103,13 +103,13 @@ def test_oracle_crypto_conserves_weight(orc):
     orc.orc_lens_destroy(lens)
 
 
-def compare_tables(ctx, ref, n_crypto, np_, tol=TOL, exact_pixels=None):
+def compare_tables(ctx, ref, n_crypto, np_, tol=TOL, exact_pixels=None, pixels=None):
     """exact_pixels: pixels no draw landed on -- their sums are the pixel's own visits in stream order, added by one
-    lane: bit-identical to the sequential reference"""
+    lane: bit-identical to the sequential reference.  pixels: the ones to look at (default: all np_)"""
     worst = 0.0
     for a in range(n_crypto):
         ids, wts, tot = ctx.download_crypto_table(a)
-        for pix in range(np_):
+        for pix in (range(np_) if pixels is None else pixels):
             rk, rw, rtot = ref.crypto_pixel(a, pix)
             used = ids[pix] != 0xFFFFFFFF
             gk = ids[pix][used].view(np.float32)
@@ -251,10 +251,11 @@ def test_crypto_error_paths(orc, gpu_ctx_factory):
     ref.set_crypto(hashes, weights)
     ref.run(lens, None, visits)
     compare_tables(ctx, ref, 1, p.xres * p.yres)
-    # between GPUs the tables are not exchanged: a context set up for the deferred (multi-GPU) closest merge refuses
+    # between GPUs the tables travel with the tiled exchange only (tests/test_native_exchange.py): a context set up for
+    # the interleaved partition's deferred closest merge refuses
     ctx.set_closest_exchange(1, 0)
     ctx.clear_frame()
-    with pytest.raises(capi.LentilError, match="not exchanged"):
+    with pytest.raises(capi.LentilError, match="tiled exchange only"):
         ctx.redistribute()
     ctx.set_closest_exchange(0, 0)
     # the same visits bound anew: caches handed over for an earlier stream do not count, whatever its length

@@ -304,3 +304,52 @@ def test_real_rccl_world_size_one():
                 m = ref != 0
                 assert np.array_equal(got != 0, m)
                 assert float(np.max(np.abs(got[m] - ref[m]) / np.abs(ref[m]))) < 2 * TOL
+
+
+@pytest.mark.parametrize("world,bounds", [(2, None), (3, [0, 7, 30, 45])], ids=["2", "3-unequal"])
+def test_exchange_bands_carries_cryptomatte(orc, gpu_ctx_factory, fake_rccl, world, bounds):
+    """Cryptomatte AOVs across GPUs: what a rank's draws add to the id maps of pixels in another rank's band travels with
+    lentil_hip_exchange_bands (16-byte map-entry records) and is added to the owner's tables; every band's rows then
+    hold the whole-frame oracle's maps -- id sets exactly, weights and totals to 1e-5 -- two passes."""
+    import ctypes as C
+    import oracle_lib
+    from test_crypto import compare_tables, make_crypto_columns
+    W, H, M = 64, 45, 9
+    p, model, table, keep = common.po_setup(W, H, samples_override=48)
+    visits, cols = common.make_stream(p, W, H, M, f_hi=0.03)
+    n_crypto, entries = 2, 3
+    hashes, weights = make_crypto_columns(visits.n, W, M, n_crypto, entries)
+    lens = orc.orc_lens_create(C.byref(table))
+    ref = oracle_lib.Frame(orc, p, n_aovs=1, keep_log=False)
+    ref.set_crypto(hashes, weights)
+    ref.run(lens, None, visits)
+    assert ref.counters().accepted_draws > 3000
+    ctxs, keepalive, bands = _band_contexts(gpu_ctx_factory, p, table, W, H, M, world, bounds, 0.03, [0])
+    for rank, ctx in enumerate(ctxs):
+        v0, v1 = bands[rank][0] * W * M, min(bands[rank][1], H) * W * M
+        cv, keepc = capi.make_crypto_visits([np.ascontiguousarray(h[v0:v1]) for h in hashes],
+                                            [np.ascontiguousarray(w[v0:v1]) for w in weights])
+        ctx.alloc_crypto(n_crypto, 32)
+        ctx.upload_crypto(cv)
+        keepalive.append((cv, keepc))
+    uid = capi.Context.comm_unique_id()
+    reach = {}
+
+    def rank_fn(rank):
+        ctx = ctxs[rank]
+        ctx.comm_init(uid, rank, world)
+        for _ in range(2):
+            distributed.frame_step_bands_native(ctx, H, bounds)
+            ctx.sync()
+        lo, hi = ctx.touched_rows()
+        reach[rank] = max(bands[rank][0] - lo, hi - bands[rank][1])
+        ctx.comm_destroy()
+
+    _threads(rank_fn, world)
+    assert max(reach.values()) > 0            # draws did cross band boundaries
+    for rank in range(world):
+        b_lo, b_hi = bands[rank]
+        pixels = range(b_lo * p.xres, min(b_hi, p.yres) * p.xres)
+        compare_tables(ctxs[rank], ref, n_crypto, p.xres * p.yres, pixels=pixels)
+    ref.close()
+    orc.orc_lens_destroy(lens)
