@@ -248,6 +248,7 @@ struct ScanArgs {
   uint32_t end_ranges;             // waves of publish_kernel: end markers behind the last range
   uint32_t flush_each_tile;        // announce at the end of every tile (few items per pass: latency matters, atomics do not)
   uint32_t ring;                   // scan_dma_multi_kernel: slots per wave
+  uint32_t outside_in;             // scan_dma*_kernel: tiles from both ends of the range inwards (scan_order)
   float4 *dummy;                   // scan_dma_multi_kernel: 64 x 16 B that lanes without a record store to
 };
 
@@ -691,6 +692,20 @@ LD_DEV void lds_dma16(const float4 *g, float4 *lds_wave_base) {
   __builtin_amdgcn_global_load_lds((gptr_t)(const void *)g, (lptr_t)(void *)lds_wave_base, 16, 0, 2);
 }
 
+// Which run of `run` tiles the k-th draw from DevCounters::tile_next stands for (t = k * run, relative to tile_begin).
+// ScanArgs::outside_in: the runs alternate between the two ends of the range and meet in the middle.  A streamed pass
+// ends when the solves of the items found LAST have ended, and the items near the frame's top and bottom edge -- where the
+// lens vignettes: solves of 20-40 iterations, most of them failing, hundreds parked for the straggler kernel -- are the
+// slow ones: scanned first, they are through long before the scan is; what the scan finds last lies mid-frame.
+// (An experiment kept as a switch, off by default: the step does not change -- the parked solves are only served once the
+// scan's waves have made room for the straggler kernel's.)
+LD_DEV uint32_t scan_order(const ScanArgs &a, uint32_t t, uint32_t run) {
+  if (!a.outside_in) return t;
+  const uint32_t n_runs = (uint32_t)((a.tile_end - a.tile_begin + run - 1u) / run);
+  const uint32_t k = t / run;
+  return ((k & 1u) ? n_runs - 1u - (k >> 1) : (k >> 1)) * run;
+}
+
 __host__ __device__ constexpr uint32_t dma_wave_f4(uint32_t M) { return M * 64u + kDmaRing * 192u + 16u; }
 
 // The three columns of one ring slot, lane's visit.  In assembly because hipcc puts s_waitcnt vmcnt(0) in front of
@@ -747,8 +762,9 @@ __global__ __launch_bounds__(256) void scan_dma_kernel(ScanArgs a) {
   while (true) {
     uint32_t t4 = 0;
     if (lane == 0) t4 = atomicAdd(&a.ctr->tile_next, 4u);
-    const uint64_t tile4 = a.tile_begin + (uint64_t)__builtin_amdgcn_readfirstlane(t4);
-    if (tile4 >= n_tiles) break;
+    t4 = __builtin_amdgcn_readfirstlane(t4);
+    if (a.tile_begin + (uint64_t)t4 >= n_tiles) break;
+    const uint64_t tile4 = a.tile_begin + (uint64_t)scan_order(a, t4, 4u);
     const uint64_t tile4_end = tile4 + 4u < n_tiles ? tile4 + 4u : n_tiles;
     for (uint64_t tile = tile4; tile < tile4_end; ++tile) {
       const uint64_t pix0 = tile * 64u;
@@ -938,8 +954,9 @@ __global__ __launch_bounds__(256) void scan_dma_multi_kernel(ScanArgs a) {
   while (true) {
     uint32_t t0 = 0;
     if (lane == 0) t0 = atomicAdd(&a.ctr->tile_next, kDmaMultiRun);
-    const uint64_t run0 = a.tile_begin + (uint64_t)__builtin_amdgcn_readfirstlane(t0);
-    if (run0 >= n_tiles) break;
+    t0 = __builtin_amdgcn_readfirstlane(t0);
+    if (a.tile_begin + (uint64_t)t0 >= n_tiles) break;
+    const uint64_t run0 = a.tile_begin + (uint64_t)scan_order(a, t0, kDmaMultiRun);
     const uint64_t run1 = run0 + kDmaMultiRun < n_tiles ? run0 + kDmaMultiRun : n_tiles;
     for (uint32_t g = 0; g < R && run0 + g < run1; ++g) issue(run0 + g, g);
     uint32_t si = 0;                                                // the slot of `tile`: (tile - run0) mod R
@@ -2072,7 +2089,10 @@ struct CoopLens {
 
 // One 64-thread block = one wave; blocks pull parked solves until the queue is empty.  Launched blind after every
 // solve_po_kernel: with an empty queue a block returns before it stages anything.
-__global__ __launch_bounds__(64) void solve_slow_kernel(DrawArgs a) {
+#ifndef LENTIL_SLOW_ATTR
+#define LENTIL_SLOW_ATTR
+#endif
+__global__ __launch_bounds__(64) LENTIL_SLOW_ATTR void solve_slow_kernel(DrawArgs a) {
   __shared__ CoopShared sh;
   __shared__ uint32_t s_q;
   const uint32_t par = (uint32_t)a.parity, sq = slow_queue(a);
