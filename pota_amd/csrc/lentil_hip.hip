@@ -1370,7 +1370,9 @@ static int plan_scan(lentil_hip_ctx *ctx, ScanPlan &pl) {
       pl.multi = false;
       pl.dma = false;
       sa.dummy = ctx->d_dummy;
-      sa.ring = dma_multi_ring(ctx);
+      // (the column loads without the nontemporal hint: the 54-visit groups of nine-visit pixels do not end on 128-byte lines,
+      // and the line two groups share is then still in L2 for the second -- 3.05 against 3.16 ms alone; LENTIL_DMA_MULTI_NT=1)
+      sa.ring = dma_multi_ring(ctx) | ((getenv("LENTIL_DMA_MULTI_NT") && getenv("LENTIL_DMA_MULTI_NT")[0] == '1') ? 0u : 0x100u);
     }
     const uint64_t n_pixels = (ctx->V.n + M - 1) / M;
     pl.n_tiles = (n_pixels + ppt - 1) / ppt;
@@ -1393,7 +1395,8 @@ static int launch_scan(lentil_hip_ctx *ctx, const ScanPlan &pl, const lentil_hip
   // (LENTIL_SCAN_OUTSIDE_IN=1: a streamed pass scans the frame from its top and bottom edge inwards.  Measured neutral,
   // 2.32-2.33 ms either way: the parked solves of the edge items then come early, but the straggler kernel only gets its
   // registers when the scan's waves have left, scan_order in lentil_kernels.h)
-  static const bool outside_in = getenv("LENTIL_SCAN_OUTSIDE_IN") && getenv("LENTIL_SCAN_OUTSIDE_IN")[0] == '1';
+  const char *oi = getenv("LENTIL_SCAN_OUTSIDE_IN");
+  const bool outside_in = oi && oi[0] == '1';
   sa.outside_in = (outside_in && streamed_pass) ? 1u : 0u;
   sa.work = ctx->d_work + ch.v_begin;
   sa.work_cap = ch.v_end - ch.v_begin;

@@ -685,6 +685,11 @@ __global__ __launch_bounds__(256) void scan_uniform_kernel(ScanArgs a) {
 // ---------------------------------------------------------------------------------------
 constexpr uint32_t kDmaRing = 2;      // (3 slots: 79 KB per block at M = 9, two blocks then leave the solve kernel no LDS)
 
+LD_DEV void lds_dma16_cached(const float4 *g, float4 *lds_wave_base) {      // the same without the nontemporal hint
+  typedef const __attribute__((address_space(1))) void *gptr_t;
+  typedef __attribute__((address_space(3))) void *lptr_t;
+  __builtin_amdgcn_global_load_lds((gptr_t)(const void *)g, (lptr_t)(void *)lds_wave_base, 16, 0, 0);
+}
 LD_DEV void lds_dma16(const float4 *g, float4 *lds_wave_base) {
   // 64 lanes x 16 B -> lds_wave_base[lane]; aux 2 = nontemporal (read once)
   typedef const __attribute__((address_space(1))) void *gptr_t;
@@ -921,7 +926,7 @@ __global__ __launch_bounds__(256) void scan_dma_multi_kernel(ScanArgs a) {
   const uint32_t n_cols = 4u + K;
   const uint32_t ppt = a.ppt, TV = ppt * M;
   constexpr uint32_t CS = kDmaMultiCol;
-  const uint32_t R = a.ring;                                        // slots per wave (2 or 3)
+  const uint32_t R = a.ring & 0xFFu;                                // slots per wave (2 or 3)
   float4 *ring = smem + (size_t)wave * dma_multi_wave_f4(K, R);    // [R][n_cols][CS]
   uint2 *qmem = reinterpret_cast<uint2 *>(smem + (size_t)4u * dma_multi_wave_f4(K, R));
   WaveQueue wq;
@@ -941,6 +946,14 @@ __global__ __launch_bounds__(256) void scan_dma_multi_kernel(ScanArgs a) {
     const uint64_t v = tile * (uint64_t)TV + lane;
     const uint64_t vl = (lane < TV && v < V.n) ? v : v_last;        // lanes past the group / the end re-read the last visit (unused)
     float4 *slot = ring + (size_t)si * n_cols * CS;
+    if (a.ring & 0x100u) {
+      lds_dma16_cached(V.pos_z + vl, slot);
+      lds_dma16_cached(V.volume_ignore + vl, slot + CS);
+      lds_dma16_cached(V.transmission + vl, slot + 2u * CS);
+      lds_dma16_cached(V.rgba + vl, slot + 3u * CS);
+      for (uint32_t k = 0; k < K; ++k) lds_dma16_cached(V.extra[k] + vl, slot + (4u + k) * CS);
+      return;
+    }
     lds_dma16(V.pos_z + vl, slot);
     lds_dma16(V.volume_ignore + vl, slot + CS);
     lds_dma16(V.transmission + vl, slot + 2u * CS);

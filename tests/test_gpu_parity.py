@@ -962,7 +962,7 @@ def test_stragglers_finish_in_the_cooperative_kernel(orc, monkeypatch, slow_at, 
         ctx.close()
 
 
-@pytest.mark.parametrize("stream", ["1", "0"])
+@pytest.mark.parametrize("stream", ["1", "0", "outside-in"])
 def test_blind_passes_and_fallback(orc, monkeypatch, stream):
     """From the second pass on nothing waits for the scan on the host: buffers are sized from what the previous pass
     found and the device checks the real counts.  Streamed (default): one scan launch publishes items and tasks to
@@ -975,6 +975,9 @@ def test_blind_passes_and_fallback(orc, monkeypatch, stream):
     ref_l = common.run_oracle(orc, p, table, light)
     ref_h = common.run_oracle(orc, p, table, heavy)
     monkeypatch.setenv("LENTIL_CHUNKS", "3")
+    if stream == "outside-in":        # the streamed pass with its scan taking tiles from both ends of the frame inwards
+        monkeypatch.setenv("LENTIL_SCAN_OUTSIDE_IN", "1")
+        stream = "1"
     monkeypatch.setenv("LENTIL_STREAM", stream)
     per_pass = 1 if stream == "1" else 3        # a streamed pass is one "chunk"
     ctx = capi.Context(0)
