@@ -1599,6 +1599,7 @@ struct DrawArgs {
   // the first accept does not wait for the stragglers (accept_item<1>).  Defaults (-1, -1, 1, 0): a queue per round.
   int32_t slow_q, slow_round, slow_close, slow_indirect;
   uint32_t unknown_credit;    // accept_item<1>: eighths of the known attempts' success rate credited to the unknown ones (0: none)
+  int32_t slow_after_producers;   // first round of a streamed pass: park only once the scan and its publishers have ended
   int32_t slow_dry_only;      // live queue: park as a plain round does (waves running dry, their last slow_max_lanes lanes)
   int32_t slow_crowd_stays;   // live queue: where more than slow_max_lanes lanes of a wave are past slow_at at once, none is parked
 };
@@ -1796,6 +1797,8 @@ __global__ __launch_bounds__(256) LENTIL_SOLVE_ATTR void solve_po_kernel(DrawArg
   uint32_t st_iters = 0, st_tries = 0, st_rounds = 0;
   // (streamed pass: the draw sum is not known yet; the host decides from the previous pass and passes no queue otherwise)
   const bool parking = a.slow != nullptr && a.round >= a.slow_from_round && (kStream || a.ctr->sum_samples < a.slow_below);
+  bool producers_gone = false;
+  (void)producers_gone;
 
   while (true) {
     const unsigned long long busy_mask = __ballot(busy);
@@ -1923,7 +1926,17 @@ __global__ __launch_bounds__(256) LENTIL_SOLVE_ATTR void solve_po_kernel(DrawArg
     // ... and only its last few lanes: a lens whose solves routinely take more than slow_at iterations (the petzval
     // table: heavy vignetting, thousands of such solves per round) would otherwise send them all to a kernel that
     // spends a wave on each (config 4: 17.5 ms per frame with that, 3 ms of it per solve_slow_kernel launch).
-    if (parking && ((a.slow_live && !a.slow_dry_only) || (no_more && __builtin_popcountll(__ballot(busy)) <= a.slow_max_lanes))) {
+    // (slow_after_producers: nothing is parked while the scan still feeds the queue -- the straggler kernel's waves only
+    // find room on the chip when solve waves begin to leave, which is when the scan has ended; a solve parked before that
+    // just waits, while a slow solve in a lane of a wave that keeps refilling its other lanes costs that lane alone and
+    // is usually through by then.  Lane 0 looks every 16 rounds.)
+    if (kStream && a.slow_after_producers && !producers_gone && (st_rounds & 15u) == 0u) {
+      uint32_t pd = 0;
+      if (lane == 0) pd = ld_coherent32(a.producers_done);
+      producers_gone = (uint32_t)__builtin_amdgcn_readfirstlane(pd) >= a.producers_total;
+    }
+    if (parking && (!kStream || !a.slow_after_producers || producers_gone || no_more) &&
+        ((a.slow_live && !a.slow_dry_only) || (no_more && __builtin_popcountll(__ballot(busy)) <= a.slow_max_lanes))) {
       const bool park = busy && s.k >= a.slow_at;
       unsigned long long pmask = __ballot(park);
       // Live queue: outliers only.  Where many lanes of a wave are past slow_at at once it is not a straggler but the item:
