@@ -1469,7 +1469,13 @@ static int redistribute_streamed(lentil_hip_ctx *ctx, bool *streamed) {
   if (ctx->est_sum_total >= ctx->stream_below) return LENTIL_OK;
   if (ctx->V.n_extra && !(stream_extra && dma_multi_applies(ctx))) return LENTIL_OK;
   lentil_hip_ctx::Chunk &ch = ctx->chunks[0];
-  std::lock_guard<std::mutex> one_at_a_time(g_stream_mutex[ctx->device & 63]);
+  // One streamed pass per device at a time: the resident kernels of two of them could keep each other's scan off the chip.
+  // A context that finds another one's streamed pass in flight does not wait for it: its pass runs in the chunked form,
+  // whose kernels never wait for anything (LENTIL_STREAM_WAIT=1: wait, as rounds 2 did).
+  static const bool wait_for_turn = getenv("LENTIL_STREAM_WAIT") && getenv("LENTIL_STREAM_WAIT")[0] == '1';
+  std::unique_lock<std::mutex> one_at_a_time(g_stream_mutex[ctx->device & 63], std::defer_lock);
+  if (wait_for_turn) one_at_a_time.lock();
+  else if (!one_at_a_time.try_lock()) return LENTIL_OK;
   DrawArgs da{};
   init_draw_args(ctx, da);
   const uint64_t nch = (uint64_t)da.n_channels;

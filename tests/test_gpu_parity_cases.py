@@ -278,3 +278,40 @@ def test_every_context_gets_streams_that_run_together(gpu_ctx_factory):
         pytest.skip("fewer than four hardware queues allowed")
     ctxs = [gpu_ctx_factory() for _ in range(4)]
     assert [c.streams_concurrent() for c in ctxs] == [True] * 4
+
+
+@pytest.mark.gpu
+def test_two_contexts_pass_at_the_same_time(orc, gpu_ctx_factory):
+    """Two contexts on one device, driven from two threads: a streamed pass keeps kernels resident, so only one runs per
+    device at a time -- the other context does not wait for it, its pass takes the chunked form.  Every pass of both
+    equals the oracle, whichever form it took."""
+    import threading
+    W, H, M = 96, 64, 9
+    p, model, table, keep = common.po_setup(W, H, samples_override=48)
+    streams = [common.make_stream(p, W, H, M, f_hi=0.004, seed=s) for s in (0x5EED, 0xBEEF)]
+    refs = [common.run_oracle(orc, p, table, v) for v, _ in streams]
+    ctxs = [gpu_ctx_factory() for _ in range(2)]
+    errors, forms = [], [[], []]
+
+    def work(i):
+        try:
+            ctx = ctxs[i]
+            for k in range(6):
+                c = gpu_run(ctx, p, table, streams[i][0])
+                rc = refs[i].counters()
+                assert (c.redistributed_visits, c.attempted_draws, c.accepted_draws) == (
+                    rc.redistributed_visits, rc.attempted_draws, rc.accepted_draws)
+                forms[i].append(int(c.streamed))
+                check_logs(ctx, refs[i])
+                check_frame(ctx, refs[i])
+        except Exception as e:      # noqa: BLE001
+            errors.append((i, e))
+
+    th = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=300)
+    assert not errors, "context %d: %r" % errors[0]
+    assert not any(t.is_alive() for t in th)
+    assert sum(forms[0]) + sum(forms[1]) >= 1       # (the first pass of a context is never streamed)
