@@ -555,11 +555,12 @@ static int crypto_before_pass(lentil_hip_ctx *ctx) {
 }
 
 // ... and after it (on the main stream, behind everything the pass enqueued)
-static int crypto_after_pass(lentil_hip_ctx *ctx) {
+// The adds of the visits that stay in their own pixel, on stream `st` (behind the pass's scans: all this needs of the pass
+// is its work lists).  A streamed pass enqueues it on the context's spare stream as soon as its scan is, where there is
+// one (lentil_hip_ctx::aux_stream), so that it runs beside the draws: they leave HBM idle.
+static int crypto_enqueue_direct(lentil_hip_ctx *ctx, hipStream_t st) {
   LentilCrypto *k = ctx->crypto;
   if (!k || !ctx->V.n) return LENTIL_OK;
-  const unsigned long long *d_n_log =
-      reinterpret_cast<const unsigned long long *>((char *)(ctx->d_ctr + ctx->n_chunks) + offsetof(DevCounters, log_count));
   const double lens_length = ctx->have_lens ? ctx->hlens.length : 0.0;
   const unsigned blocks = (unsigned)ctx->num_cu * 8;
   // pixel-major streams whose pixels are all distinct (one pass per clear: the tables hold nothing yet that another
@@ -591,11 +592,11 @@ static int crypto_after_pass(lentil_hip_ctx *ctx) {
           HIP_TRY(ctx, hipMalloc(&k->d_flag_bits, words * sizeof(uint32_t)));
           k->flag_words = words;
         }
-        HIP_TRY(ctx, hipMemsetAsync(k->d_flag_bits, 0, words * sizeof(uint32_t), ctx->stream));
+        HIP_TRY(ctx, hipMemsetAsync(k->d_flag_bits, 0, words * sizeof(uint32_t), st));
         for (int ci = 0; ci < ctx->n_chunks; ++ci) {
           const lentil_hip_ctx::Chunk &ch = ctx->chunks[ci];
           if (ch.v_end <= ch.v_begin) continue;
-          hipLaunchKernelGGL(flag_bits_kernel, dim3(64), dim3(256), 0, ctx->stream, ctx->d_work + ch.v_begin, ctx->d_ctr + ci,
+          hipLaunchKernelGGL(flag_bits_kernel, dim3(64), dim3(256), 0, st, ctx->d_work + ch.v_begin, ctx->d_ctr + ci,
                              ch.v_end - ch.v_begin, k->d_flag_bits);
         }
         HIP_TRY(ctx, hipGetLastError());
@@ -603,16 +604,34 @@ static int crypto_after_pass(lentil_hip_ctx *ctx) {
       }
       const dim3 grid((unsigned)(n_tiles < max_blocks ? n_tiles : max_blocks));
       if (k->tables_clear)
-        hipLaunchKernelGGL(crypto_direct_tile_kernel<true>, grid, dim3(128), lds, ctx->stream, k->D, ctx->V, ctx->P, lens_length, T);
+        hipLaunchKernelGGL(crypto_direct_tile_kernel<true>, grid, dim3(128), lds, st, k->D, ctx->V, ctx->P, lens_length, T);
       else
-        hipLaunchKernelGGL(crypto_direct_tile_kernel<false>, grid, dim3(128), lds, ctx->stream, k->D, ctx->V, ctx->P, lens_length, T);
+        hipLaunchKernelGGL(crypto_direct_tile_kernel<false>, grid, dim3(128), lds, st, k->D, ctx->V, ctx->P, lens_length, T);
     } else {
-      hipLaunchKernelGGL(crypto_direct_owner_kernel, dim3(blocks), dim3(256), 0, ctx->stream, k->D, ctx->V, ctx->P, lens_length);
+      hipLaunchKernelGGL(crypto_direct_owner_kernel, dim3(blocks), dim3(256), 0, st, k->D, ctx->V, ctx->P, lens_length);
     }
   } else
-    hipLaunchKernelGGL(crypto_direct_kernel, dim3(blocks), dim3(256), 0, ctx->stream, k->D, ctx->V, ctx->P, lens_length);
+    hipLaunchKernelGGL(crypto_direct_kernel, dim3(blocks), dim3(256), 0, st, k->D, ctx->V, ctx->P, lens_length);
   HIP_TRY(ctx, hipGetLastError());
   k->tables_clear = false;
+  return LENTIL_OK;
+}
+
+static int crypto_after_pass(lentil_hip_ctx *ctx) {
+  LentilCrypto *k = ctx->crypto;
+  if (!k || !ctx->V.n) return LENTIL_OK;
+  const unsigned long long *d_n_log =
+      reinterpret_cast<const unsigned long long *>((char *)(ctx->d_ctr + ctx->n_chunks) + offsetof(DevCounters, log_count));
+  const double lens_length = ctx->have_lens ? ctx->hlens.length : 0.0;
+  const unsigned blocks = (unsigned)ctx->num_cu * 8;
+  if (ctx->crypto_direct_enqueued) {
+    // (the pass has put the own-pixel adds beside its draws: the draws' replay follows them)
+    HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_crypto, 0));
+    ctx->crypto_direct_enqueued = false;
+  } else {
+    const int rc = crypto_enqueue_direct(ctx, ctx->stream);
+    if (rc) return rc;
+  }
   if (ctx->log_cap) {
     hipLaunchKernelGGL(crypto_draws_kernel, dim3(blocks), dim3(256), 0, ctx->stream, k->D, ctx->V, ctx->P, lens_length,
                        ctx->d_log, d_n_log, (uint64_t)ctx->log_cap);

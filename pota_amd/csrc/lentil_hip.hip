@@ -138,6 +138,9 @@ struct lentil_hip_ctx {
   uint32_t unknown_credit = 7;        // LENTIL_UNKNOWN_CREDIT (0..8): DrawArgs::unknown_credit
   bool chain_streams = true;          // LENTIL_CHAIN_STREAMS=0: a decoupled pass keeps its accepts on the main stream
   hipEvent_t ev_solve = nullptr, ev_slow1 = nullptr;
+  hipStream_t aux_stream = nullptr;     // a fifth stream that runs beside the four (more than four hardware queues to be had), or null
+  hipEvent_t ev_crypto = nullptr;       // the cryptomatte own-pixel adds a streamed pass has put on aux_stream
+  bool crypto_direct_enqueued = false;
   bool streams_concurrent = false;      // pick_concurrent_streams: the streamed pass's four streams run their kernels side by side
   hipStream_t slow1_stream = nullptr;   // a decoupled pass's second-round straggler kernel (beside the first round's, which is still at work)
   bool decouple = true;              // LENTIL_DECOUPLE=0: a streamed pass's first accept waits for the first round's stragglers
@@ -259,11 +262,23 @@ static int pick_concurrent_streams(lentil_hip_ctx *ctx) {
       ++created;
     }
   }
+  // a spare one beside the four (the cryptomatte replay's first half runs there while the draws go on): only where the
+  // runtime has a fifth hardware queue to give (GPU_MAX_HW_QUEUES > 4)
+  if (all) {
+    for (int attempt = 0; attempt < 6 && !ctx->aux_stream; ++attempt) {
+      hipStream_t s = nullptr;
+      if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) break;
+      bool ok = true;
+      for (int q = 0; q < 4 && ok; ++q) ok = streams_run_together(ctx, *role[q], s, d_flag) && streams_run_together(ctx, s, *role[q], d_flag);
+      if (ok) ctx->aux_stream = s;
+      else rejected.push_back(s);
+    }
+  }
   for (hipStream_t s : rejected) (void)hipStreamDestroy(s);
   (void)hipFree(d_flag);
   (void)hipGetLastError();
   ctx->streams_concurrent = all;
-  if (getenv("LENTIL_STREAM_DEBUG")) fprintf(stderr, "[stream] the pass's four streams run together: %d (%d streams tried beyond the first four)\n", (int)all, created);
+  if (getenv("LENTIL_STREAM_DEBUG")) fprintf(stderr, "[stream] the pass's four streams run together: %d (%d streams tried beyond the first four), a fifth beside them: %d\n", (int)all, created, ctx->aux_stream ? 1 : 0);
   return LENTIL_OK;
 }
 
@@ -315,6 +330,7 @@ LENTIL_API int lentil_hip_create(int device, lentil_hip_ctx **out_ctx) {
   HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_solve, hipEventDisableTiming));
   HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_slow1, hipEventDisableTiming));
   HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->slow1_stream, hipStreamNonBlocking));
+  HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_crypto, hipEventDisableTiming));
   { const int rc = pick_concurrent_streams(ctx); if (rc) return rc; }
   if (const char *e = getenv("LENTIL_EARLY_RESOLVE")) ctx->early_resolve = atoi(e) != 0;
   if (const char *ft = getenv("LENTIL_FORCE_TABLES")) ctx->use_generated = !(ft[0] == '1');
@@ -419,6 +435,7 @@ static int crypto_clear(lentil_hip_ctx *ctx);
 static int crypto_before_pass(lentil_hip_ctx *ctx);
 static int crypto_after_pass(lentil_hip_ctx *ctx);
 static int crypto_exchange_bands(lentil_hip_ctx *ctx, const int32_t *bands, int32_t lo, int32_t hi);
+static int crypto_enqueue_direct(lentil_hip_ctx *ctx, hipStream_t st);
 
 LENTIL_API int lentil_hip_destroy(lentil_hip_ctx *ctx) {
   if (!ctx) return LENTIL_OK;
@@ -459,6 +476,8 @@ LENTIL_API int lentil_hip_destroy(lentil_hip_ctx *ctx) {
   if (ctx->ev_solve) (void)hipEventDestroy(ctx->ev_solve);
   if (ctx->ev_slow1) (void)hipEventDestroy(ctx->ev_slow1);
   if (ctx->slow1_stream) { (void)hipStreamSynchronize(ctx->slow1_stream); (void)hipStreamDestroy(ctx->slow1_stream); }
+  if (ctx->aux_stream) { (void)hipStreamSynchronize(ctx->aux_stream); (void)hipStreamDestroy(ctx->aux_stream); }
+  if (ctx->ev_crypto) (void)hipEventDestroy(ctx->ev_crypto);
   (void)hipFree(ctx->d_ctr);
   if (ctx->h_ctr_pinned) (void)hipHostFree(ctx->h_ctr_pinned);
   (void)hipFree(ctx->d_ranges);
@@ -1561,6 +1580,14 @@ static int redistribute_streamed(lentil_hip_ctx *ctx, bool *streamed) {
   HIP_TRY(ctx, hipEventRecord(ch.scanned, ctx->stream));
   HIP_TRY(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
   HIP_TRY(ctx, hipEventRecord(ctx->scans_done, ctx->stream));
+  // cryptomatte AOVs: the adds of the visits that stay in their pixel need the scan's work lists and nothing else of the
+  // pass -- beside the draws, on the spare stream, where the runtime has one (LENTIL_CRYPTO_OVERLAP=0: after the pass)
+  if (ctx->crypto && ctx->aux_stream && !(getenv("LENTIL_CRYPTO_OVERLAP") && getenv("LENTIL_CRYPTO_OVERLAP")[0] == '0')) {
+    HIP_TRY(ctx, hipStreamWaitEvent(ctx->aux_stream, ctx->scans_done, 0));
+    if ((rc = crypto_enqueue_direct(ctx, ctx->aux_stream))) return rc;
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_crypto, ctx->aux_stream));
+    ctx->crypto_direct_enqueued = true;
+  }
 
   // The publishers and A, resident beside the scan (the counters they poll were cleared by the memset ahead of
   // ev[0]).  Submitted AFTER what they wait for -- the scan, then the publishers: should the streams share a
@@ -1988,6 +2015,10 @@ LENTIL_API int lentil_hip_redistribute(lentil_hip_ctx *ctx) {
     return fail(ctx, LENTIL_ERR_UNSUPPORTED, "the lentil_debug AOV is exchanged between GPUs by lentil_hip_allreduce / _exchange_bands only");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   { const int rc = crypto_before_pass(ctx); if (rc) return rc; }
+  if (ctx->crypto_direct_enqueued) {       // (a pass that failed after it had enqueued them)
+    HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_crypto, 0));
+    ctx->crypto_direct_enqueued = false;
+  }
   ctx->resolved_valid = false;
   ctx->early_resolve_pending = false;
   ctx->late_resolve_done = false;
