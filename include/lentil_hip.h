@@ -431,7 +431,9 @@ int lentil_hip_exchange_bands(lentil_hip_ctx *ctx, const int32_t *bounds, int32_
 int lentil_hip_exchange_stats(lentil_hip_ctx *ctx, uint64_t *bytes_sent, uint64_t *bytes_received);
 /* *concurrent = 1 when the four HIP streams a streamed pass keeps kernels resident on run them side by side (they were
  * chosen so at lentil_hip_create: streams that share one of the runtime's hardware queues serialise, and the pass then
- * takes about 1.5 x as long), 0 when fewer than four hardware queues were to be had or LENTIL_STREAM_PROBE=0.
+ * takes about 1.5 x as long; 2: and a fifth one beside them, on which a pass with cryptomatte AOVs replays the own-pixel
+ * adds while its draws go on -- GPU_MAX_HW_QUEUES > 4), 0 when fewer than four hardware queues were to be had or
+ * LENTIL_STREAM_PROBE=0.
  * Instrumentation; no reference counterpart. */
 int lentil_hip_streams_concurrent(lentil_hip_ctx *ctx, int *concurrent);
 

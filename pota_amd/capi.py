@@ -392,9 +392,10 @@ class Context:
         return lo.value, hi.value
 
     def streams_concurrent(self):
+        """0: the pass's four streams share hardware queues, 1: they run side by side, 2: and a spare one beside them"""
         v = C.c_int(0)
         self._chk(self.lib.lentil_hip_streams_concurrent(self.h, C.byref(v)))
-        return bool(v.value)
+        return int(v.value)
 
     def exchange_stats(self):
         """(bytes sent, bytes received) by this rank in its last exchange_bands / allreduce"""

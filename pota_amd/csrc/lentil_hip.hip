@@ -285,7 +285,7 @@ static int pick_concurrent_streams(lentil_hip_ctx *ctx) {
 LENTIL_API int lentil_hip_streams_concurrent(lentil_hip_ctx *ctx, int *concurrent) {
   CHECK_CTX(ctx);
   if (!concurrent) return fail(ctx, LENTIL_ERR_INVALID, "concurrent is null");
-  *concurrent = ctx->streams_concurrent ? 1 : 0;
+  *concurrent = ctx->streams_concurrent ? (ctx->aux_stream ? 2 : 1) : 0;
   return LENTIL_OK;
 }
 

@@ -179,6 +179,9 @@ def test_crypto_tables_and_ranks_match_oracle(orc, gpu_ctx_factory, case, monkey
     cv, keepc = capi.make_crypto_visits(hashes, weights)
     lens = orc.orc_lens_create(C.byref(table)) if table is not None else None
     ctx = gpu_ctx_factory()
+    import os
+    if os.environ.get("LENTIL_EXPECT_SPARE_STREAM") == "1":      # (test_crypto_replay_beside_the_draws_...)
+        assert ctx.streams_concurrent() == 2
     ctx.set_params(p)
     if table is not None:
         ctx.set_lens(table)
@@ -584,3 +587,19 @@ def _abi_visits_layout(M, W):
     lay = _abi.Visits()
     lay.visits_per_pixel, lay.pixels_per_row, lay.pixel_row_stride = M, W, 1
     return lay
+
+
+@pytest.mark.gpu
+def test_crypto_replay_beside_the_draws_in_a_process_with_a_fifth_queue():
+    """With GPU_MAX_HW_QUEUES > 4 (read by the runtime when it initialises: a process of its own) a context finds a spare
+    stream beside the pass's four, and a streamed pass replays the own-pixel cryptomatte adds there while its draws go
+    on: the polynomial-optics case of test_crypto_tables_and_ranks_match_oracle, in such a process."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, GPU_MAX_HW_QUEUES="8", LENTIL_EXPECT_SPARE_STREAM="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-x", "-q", "-m", "gpu", "-k",
+                        "test_crypto_tables_and_ranks_match_oracle and po and not owner and not chromatic"], env=env, cwd=common.ROOT, stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:]
+    assert "1 passed" in r.stdout, r.stdout[-2000:]

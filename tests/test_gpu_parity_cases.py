@@ -277,7 +277,7 @@ def test_every_context_gets_streams_that_run_together(gpu_ctx_factory):
     if os.environ.get("GPU_MAX_HW_QUEUES", "4").isdigit() and int(os.environ.get("GPU_MAX_HW_QUEUES", "4")) < 4:
         pytest.skip("fewer than four hardware queues allowed")
     ctxs = [gpu_ctx_factory() for _ in range(4)]
-    assert [c.streams_concurrent() for c in ctxs] == [True] * 4
+    assert all(c.streams_concurrent() >= 1 for c in ctxs)
 
 
 @pytest.mark.gpu
