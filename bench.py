@@ -37,7 +37,12 @@ The printed JSON line also carries
   roofline     -- the HBM-bound scan kernel: algorithmic bytes (visits x 80 B) / its mean duration,
                   measured with HIP events on the library's stream, against 8 TB/s; `bytes_moved_per_visit` is
                   what the kernel actually requests (it does not read raydir_time unless a visit is at infinite
-                  depth, and stores a record per pixel); `whole_step_frac` relates the frame's bytes to the whole step
+                  depth, and stores a record per pixel); `whole_step_frac` relates the frame's bytes to the whole step;
+                  `frac` is the launch inside the timed pass, where the kernel shares its CUs with the solve waves that take
+                  its output as it comes; `alone` is the same kernel with the chip to itself (the chunked form of the pass,
+                  one chunk: LENTIL_STREAM=0 LENTIL_CHUNKS=1; N=1 only, --no-scan-alone skips it)
+  parity_checked -- the timed frame (or every n-th row of it, sized for ~10 s of oracle work) through the HIP path and
+                  through the oracle: accepted-draw lists bit for bit, radiance at 1e-5 (N=1 only)
   solve_fp64   -- the fp64-VALU-bound draw kernels: Newton lane-iterations x operations per iteration
                   (counted from the lens table) against the fp64 vector peak, per regime
   cpu_baseline -- the oracle (a port of the reference CPU path) timed on this box's host cores on a
@@ -81,6 +86,7 @@ def parse():
     ap.add_argument("--lens", default="double_gauss_50mm")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity-check", action="store_true", help="skip the oracle check of a sample of the workload")
+    ap.add_argument("--no-scan-alone", action="store_true", help="skip the measurement of the scan kernel with the chip to itself")
     ap.add_argument("--no-pcie", action="store_true", help="skip the PCIe-inclusive measurement (upload from host memory + pass)")
     ap.add_argument("--no-second-regime", action="store_true")
     ap.add_argument("--no-configs", action="store_true", help="skip BASELINE.json's configs 2-4")
@@ -744,6 +750,34 @@ def main():
     cpu_args = (args, b.p, b.table, M, b.tan_half_fov)
     b.close()
 
+    def scan_alone(Wc, Hc, lens, samples, aovs, bokeh, n_c, bpv):
+        """The same scan kernel with the chip to itself: the streamed pass makes it share its CUs with the solve waves that
+        take its output as it comes (roofline.frac is that launch).  Here: the chunked form of the pass, one chunk -- the
+        scan runs to its end before the first solve kernel starts; same streams, same kernel, measured the same way."""
+        saved = {k: os.environ.get(k) for k in ("LENTIL_STREAM", "LENTIL_CHUNKS")}
+        os.environ["LENTIL_STREAM"] = "0"; os.environ["LENTIL_CHUNKS"] = "1"
+        try:
+            c = Bench(torch, dist, dev, local_rank, 1, 0, Wc, Hc, Hc, M, lens, samples, aovs, args.f_hi, bokeh)
+            c.generate(args.f_hi)
+            for _ in range(2):
+                c.step()
+            rc = c.run(4, 1)
+            _, l_a, lms_a, lb_a, ach_a = summarize(c, rc, n_c, bpv)
+            c.close()
+            return {"avg_launch_ms": round(lms_a, 4), "achieved": round(ach_a, 1), "frac": round(ach_a / HBM_PEAK_GBS, 4),
+                    "launches_per_step": l_a, "how": "LENTIL_STREAM=0 LENTIL_CHUNKS=1: the scan ends before the solves start"}
+        except Exception as e:
+            return {"frac": None, "error": repr(e)}
+        finally:
+            for k, v in saved.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
+
+    if rank == 0 and world == 1 and not emulate and not args.no_scan_alone:
+        out["roofline"]["alone"] = scan_alone(W, H, args.lens, args.samples, args.aovs, args.bokeh_image, n_total, bytes_per_visit)
+
     if not args.no_configs and world == 1 and not emulate:
         # BASELINE.json's other single-GPU configurations, measured the same way (alternating streams)
         cfgs = {}
@@ -767,6 +801,8 @@ def main():
                               "whole_step_frac_of_hbm_peak": round(n_c * bpv / (ms_c * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                               "attempted_draws_per_step": rc["attempted"] // 4, "passes_streamed": rc["streamed"], "steps": 4}
                 c.close()
+                if not args.no_scan_alone:
+                    cfgs[name]["scan_alone"] = scan_alone(kw["W"], kw["H"], kw["lens"], kw["samples"], kw["aovs"], kw["bokeh"], n_c, bpv)
             except Exception as e:      # the headline number must still be reported
                 cfgs[name] = {"value": None, "error": repr(e)}
         out["configs"] = cfgs
