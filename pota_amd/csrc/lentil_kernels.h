@@ -2698,7 +2698,7 @@ LD_DEV AcceptResult accept_item_chroma(const DrawArgs &a, AcceptShared &sh, uint
         rmin = row < rmin ? row : rmin;
         rmax_p1 = row + 1u > rmax_p1 ? row + 1u : rmax_p1;
         s_pix[wave][(uint32_t)__builtin_popcountll(tmask & lt_mask)] = pix;
-        if (a.F.touched) a.F.touched[pix >> 6] = 1;
+        if (a.F.touched) a.F.touched[pix >> 6] = a.round ? 2 : 1;      // (as accept_item does: a later round's splats are resolved again)
         if (a.F.zkey) atomicMin(a.F.zkey + pix, zk);
         if (a.F.zkey_dbg) atomicMin(a.F.zkey_dbg + pix, zk);      // value.r = samples != 0 for every draw
         if (a.log_cap) {

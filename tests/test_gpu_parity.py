@@ -997,6 +997,23 @@ def test_blind_passes_and_fallback(orc, monkeypatch, stream):
         ctx.close()
 
 
+def test_chromatic_streamed_pass_resolves_what_later_rounds_add(orc, gpu_ctx_factory):
+    """abb_chromatic != 0 in a streamed pass (the second pass of a context): the frame is resolved beside the second round
+    and the groups later rounds splat into are resolved again -- their accepts must flag them as such.  (Found by the
+    seeded soak with another seed in round 3: accept_item_chroma flagged every round alike, the resolved image kept the
+    first round's values at pixels a later round added to.)"""
+    W, H, M = 59, 51, 4
+    p, model, table, keep = common.po_setup(W, H, aa=2, filter_width=1.0, samples_override=33, focus_dist=400.0, abb_chromatic=0.5)
+    visits, cols = common.make_stream(p, W, H, M, f_hi=0.004, n_extra=2, seed=0xA00A)
+    ref = common.run_oracle(orc, p, table, visits, n_aovs=3)
+    ctx = gpu_ctx_factory()
+    for again in range(3):
+        c = gpu_run(ctx, p, table, visits, n_aovs=3)
+        assert c.streamed == (1 if again else 0)
+        check_logs(ctx, ref)
+        check_frame(ctx, ref, n_aovs=3)
+
+
 def test_randomized_configurations_two_passes_each(orc):
     """Seeded soak over the knobs the fixed cases above hold still: frame sizes that are not multiples of the
     tile, visits per pixel, lens, compiled / table kernels, draw counts, extra AOVs, highlight fraction, focus
@@ -1004,7 +1021,7 @@ def test_randomized_configurations_two_passes_each(orc):
     enqueued blind) -- counters, accepted-draw lists and frames against the oracle both times.
     LENTIL_SOAK_CASES / LENTIL_SOAK_SEED run a longer or a different sequence."""
     import os
-    n_cases = int(os.environ.get("LENTIL_SOAK_CASES", "8"))
+    n_cases = int(os.environ.get("LENTIL_SOAK_CASES", "14"))      # (from case 8 on: bokeh images, chromatic aberration)
     rng = np.random.default_rng(int(os.environ.get("LENTIL_SOAK_SEED", "0x10E7"), 0))
     tex = np.load(os.path.join(common.ROOT, "tests", "golden", "example_bokeh_kernel_u8.npy")).astype(np.float32) / np.float32(255)
     tables = bokeh.build_tables(tex)
@@ -1043,7 +1060,10 @@ def test_randomized_configurations_two_passes_each(orc):
                     assert c.blind_chunks > 0, tag
                 check_logs(ctx, ref)
                 # chromatic draws: three splats per attempt, see test_po_chromatic_aberration for the wider bound
-                check_frame(ctx, ref, n_aovs=1 + n_extra)
+                try:
+                    check_frame(ctx, ref, n_aovs=1 + n_extra)
+                except AssertionError as e:
+                    raise AssertionError("%s, pass %d (streamed %d): %s" % (tag, again, int(c.streamed), e)) from e
         finally:
             ctx.close()
             if ob:
