@@ -453,7 +453,9 @@ int lentil_hip_streams_concurrent(lentil_hip_ctx *ctx, int *concurrent);
  * slots_per_pixel is the number of distinct ids a pixel can hold (0: 16, at most 64) -- a pass that meets more
  * returns LENTIL_ERR_NOMEM, as does one whose accepted draws exceed the draw log the adds are replayed from (sized
  * by the library from the previous pass unless lentil_hip_set_draw_log was called; clear the frame and redistribute
- * again).  lentil_hip_clear_frame empties the tables.  One GPU (a context with a communicator refuses).
+ * again).  lentil_hip_clear_frame empties the tables.  Across GPUs the tables travel with the tiled exchange:
+ * lentil_hip_exchange_bands sends the map entries this rank's draws added outside its band to the bands' owners (16-byte
+ * records) and adds what arrives; lentil_hip_allreduce (interleaved rows) refuses contexts with cryptomatte AOVs.
  *
  * lentil_hip_download_crypto: np RGBA = (id, weight / total) of positions rank and rank + 1 -- rank 0 / 2 / 4 for
  * the AOVs named ...00 / ...01 / ...02 (:124-126); equal weights stay in id order (what std::sort does to the up
