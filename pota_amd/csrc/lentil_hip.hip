@@ -1593,9 +1593,11 @@ static int redistribute_streamed(lentil_hip_ctx *ctx, bool *streamed) {
   // ev[0]).  Submitted AFTER what they wait for -- the scan, then the publishers: should the streams share a
   // hardware queue, each finds its producer ahead of it there.
   const unsigned a_blocks = (unsigned)ctx->num_cu * (unsigned)ctx->stream_blocks;
-  // Live straggler queue: solve_slow_kernel runs beside the solve kernels from the end of the scan on and takes the
-  // parked solves as they come (one wave per CU, on the publishers' stream behind them).  B then brings three waves
-  // per block instead of four: with A's two per SIMD that leaves one SIMD per CU room for a straggler wave (152 VGPRs).
+  // Live straggler queue: solve_slow_kernel is launched behind the publishers (who end with the scan) and takes the parked
+  // solves as they come, one wave per CU.  (Round 3, from the timeline: its waves are placed as the first solve waves
+  // leave -- the idle ones do at once when the publishers' end markers arrive --, not in the registers the scan gives
+  // back: a wave's registers are one contiguous range.  The second instance B, three waves per block so that a SIMD per
+  // CU kept room for a straggler wave, never got a task and is off: LENTIL_SOLVE_B.)
   const bool live = ctx->slow_live && da.slow != nullptr && P.cameraType == LENTIL_POLYNOMIAL_OPTICS;
   int blind_rounds = ctx->est_rounds_total < 2 ? 2 : (ctx->est_rounds_total > 6 ? 6 : ctx->est_rounds_total);
   if (const char *e = getenv("LENTIL_BLIND_ROUNDS")) { blind_rounds = atoi(e); if (blind_rounds < 1) blind_rounds = 1; if (blind_rounds > 8) blind_rounds = 8; }
