@@ -18,14 +18,14 @@ from test_gpu_parity import check_frame, check_logs
 pytestmark = pytest.mark.gpu
 
 
-def _device_stream(torch, p, W, H, M, seed, f_hi, v_begin, v_end, y0=0):
+def _device_stream(torch, p, W, H, M, seed, f_hi, v_begin, v_end, y0=0, n_extra=0):
     """The bench's generator on the device + the same arrays on the host (the oracle reads exactly what the GPU reads)."""
     dev = torch.device("cuda:0")
     cols = workload.generate(torch, v_begin, v_end, W, H, M, seed=seed, f_hi=f_hi, focus_dist=150.0,
-                             tan_half_fov=common.tan_half_fov(p), device=dev)
+                             tan_half_fov=common.tan_half_fov(p), device=dev, n_extra=n_extra)
     dv, dkeep = capi.make_visits(cols, visits_per_pixel=M, pixels_per_row=W, pixel_y0=y0, ptr=lambda t: t.data_ptr())
     torch.cuda.synchronize()
-    host = {k: (v.cpu().numpy() if k != "extra" else []) for k, v in cols.items()}
+    host = {k: (v.cpu().numpy() if k != "extra" else [e.cpu().numpy() for e in v]) for k, v in cols.items()}
     hv, hkeep = capi.make_visits(host, visits_per_pixel=M, pixels_per_row=W, pixel_y0=y0)
     return (dv, (cols, dkeep)), (hv, (host, hkeep))
 
@@ -35,13 +35,13 @@ def _oracle_threads(p, per_frame_gb):
     return int(max(2, min(32, os.cpu_count() or 2, (common.host_memory_gb() * 0.5) // per_frame_gb)))
 
 
-def _compare(ctx, ref, c, samples, n_visits, p):
+def _compare(ctx, ref, c, samples, n_visits, p, n_aovs=1):
     rc = ref.counters()
     assert (c.visits, c.redistributed_visits, c.attempted_draws, c.accepted_draws) == (
         n_visits, rc.redistributed_visits, rc.attempted_draws, rc.accepted_draws)
     assert c.worklist_overflow == 0
     check_logs(ctx, ref)                      # (visit, attempt, pixel) of every accepted draw, bit for bit
-    worst = check_frame(ctx, ref)             # accumulators, weights, resolved image (the early-resolved one): 1e-5
+    worst = check_frame(ctx, ref, n_aovs=n_aovs)      # accumulators, weights, resolved image (the early-resolved one): 1e-5
     # pixels no draw lands on only hold their own visits, added in iterator order: bit-exact
     touched = np.zeros(p.xres * p.yres, bool)
     touched[ref.log()[:, 2]] = True
@@ -49,6 +49,8 @@ def _compare(ctx, ref, c, samples, n_visits, p):
     assert np.array_equal(buf[~touched], ref.buffer(0)[~touched])
     assert np.array_equal(w[~touched], ref.weight()[~touched])
     assert np.array_equal(ctx.download_aov(0)[~touched], ref.resolve(0)[~touched])
+    for a in range(1, n_aovs):
+        assert np.array_equal(ctx.download_accum(a)[0][~touched], ref.buffer(a)[~touched]), a
     return worst, int(touched.sum())
 
 
@@ -112,5 +114,39 @@ def test_config5_quarter_frame_chunked_vs_oracle(orc, monkeypatch):
             worst, n_touched = _compare(ctx, ref, c, S, n, p)
             print("config 5 quarter frame, %s: %d items, %d accepted draws on %d pixels, max rel err %.2e"
                   % ("blind" if blind else "first pass", c.redistributed_visits, c.accepted_draws, n_touched, worst))
+    finally:
+        ctx.close()
+
+
+def test_config4_like_4k_nine_gaussian_aovs_streamed_vs_oracle(orc):
+    """BASELINE config 4's geometry -- petzval table, 3840x2160, 1024 draws, beauty + 8 AOVs -- with every AOV gaussian,
+    which is what takes scan_dma_multi_kernel and, from the second pass of a context on, the streamed pass: the whole
+    frame against the oracle, first pass (chunked) and two streamed ones.  (With closest-filtered AOVs among the eight the
+    register-staged scan runs: test_config4_4k_petzval_8_aovs.)"""
+    import torch
+    W, H, M, S, f_hi, K = 3840, 2160, 9, 1024, 2.0 ** -16, 8
+    n = W * H * M
+    per_thread_gb = W * H * (K + 1) * 60e-9 + 0.2
+    if common.host_memory_gb() < 2 * per_thread_gb + 40:
+        pytest.skip("not enough host memory for the oracle's nine-AOV frames")
+    p, model, table, keep = common.po_setup(W, H, lens="petzval_58mm", samples_override=S)
+    ctx = capi.Context(0)
+    try:
+        ctx.set_params(p); ctx.set_lens(table); ctx.set_bokeh(None)
+        assert ctx.lens_is_compiled()
+        ctx.alloc_frame(K + 1)
+        ctx.set_draw_log(1 << 21)
+        d, h = _device_stream(torch, p, W, H, M, 0x5EED, f_hi, 0, n, n_extra=K)
+        ref = common.ThreadedOracle(orc, p, table, h[0], _oracle_threads(p, per_thread_gb), n_aovs=K + 1)
+        del h
+        assert 900 < ref.counters().redistributed_visits < 1400
+        for want_streamed in (0, 1, 1):
+            ctx.bind_visits(*d)
+            ctx.clear_frame(); ctx.redistribute(); ctx.resolve(); ctx.sync()
+            c = ctx.counters()
+            assert c.streamed == want_streamed and c.fallback_chunks == 0, (c.streamed, c.fallback_chunks)
+            worst, n_touched = _compare(ctx, ref, c, S, n, p, n_aovs=K + 1)
+            print("nine AOVs %s: %d items, %d accepted draws on %d pixels, max rel err %.2e"
+                  % ("streamed" if want_streamed else "chunked", c.redistributed_visits, c.accepted_draws, n_touched, worst))
     finally:
         ctx.close()
