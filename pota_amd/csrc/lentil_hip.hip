@@ -1363,11 +1363,15 @@ static int plan_scan(lentil_hip_ctx *ctx, ScanPlan &pl) {
       const size_t wave_f4 = (size_t)ctx->F.n_aovs * kMultiPlane + 16 + (size_t)ppt * (ctx->F.stride / 4);
       pl.lds = 4 * wave_f4 * 16 + 4 * kWaveQueueLds * sizeof(uint2);
     }
-    const size_t dma_lds = (size_t)4 * dma_wave_f4(M) * 16 + 4 * kWaveQueueLds * sizeof(uint2);
+    // ring slots of scan_dma_kernel (LENTIL_DMA_RING; a streamed pass has one scan block per CU and LDS to spare)
+    uint32_t dma_ring = kDmaRing;
+    if (const char *e = getenv("LENTIL_DMA_RING")) { const int r = atoi(e); if (r >= 2 && r <= 8) dma_ring = (uint32_t)r; }
+    const size_t dma_lds = (size_t)4 * dma_wave_f4(M, dma_ring) * 16 + 4 * kWaveQueueLds * sizeof(uint2);
     pl.dma = ctx->scan_dma && ctx->V.n_extra == 0 && !ctx->V.inv_density && !ctx->F.zkey && !ctx->F.zkey_dbg && ctx->V.cam.n < 2 &&
              ctx->V.n % M == 0 && dma_lds <= 80u * 1024u;
     if (pl.dma) {
       ppt = 64;
+      sa.ring = dma_ring;
       sa.ppt = ppt;
       sa.tv_pad = ppt * M;
       pl.lds = dma_lds;

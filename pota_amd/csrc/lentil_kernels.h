@@ -711,7 +711,28 @@ LD_DEV uint32_t scan_order(const ScanArgs &a, uint32_t t, uint32_t run) {
   return ((k & 1u) ? n_runs - 1u - (k >> 1) : (k >> 1)) * run;
 }
 
-__host__ __device__ constexpr uint32_t dma_wave_f4(uint32_t M) { return M * 64u + kDmaRing * 192u + 16u; }
+LD_DEV void wait_vmcnt(uint32_t n) {       // n is wave-uniform; the instruction takes an immediate
+#define LENTIL_VMCNT_CASE(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); break;
+  switch (n) {
+    LENTIL_VMCNT_CASE(0) LENTIL_VMCNT_CASE(1) LENTIL_VMCNT_CASE(2) LENTIL_VMCNT_CASE(3) LENTIL_VMCNT_CASE(4)
+    LENTIL_VMCNT_CASE(5) LENTIL_VMCNT_CASE(6) LENTIL_VMCNT_CASE(7) LENTIL_VMCNT_CASE(8) LENTIL_VMCNT_CASE(9)
+    LENTIL_VMCNT_CASE(10) LENTIL_VMCNT_CASE(11) LENTIL_VMCNT_CASE(12) LENTIL_VMCNT_CASE(13) LENTIL_VMCNT_CASE(14)
+    LENTIL_VMCNT_CASE(15) LENTIL_VMCNT_CASE(16) LENTIL_VMCNT_CASE(17) LENTIL_VMCNT_CASE(18) LENTIL_VMCNT_CASE(19)
+    LENTIL_VMCNT_CASE(20) LENTIL_VMCNT_CASE(21) LENTIL_VMCNT_CASE(22) LENTIL_VMCNT_CASE(23) LENTIL_VMCNT_CASE(24)
+    LENTIL_VMCNT_CASE(25) LENTIL_VMCNT_CASE(26) LENTIL_VMCNT_CASE(27) LENTIL_VMCNT_CASE(28) LENTIL_VMCNT_CASE(29)
+    LENTIL_VMCNT_CASE(30) LENTIL_VMCNT_CASE(31) LENTIL_VMCNT_CASE(32) LENTIL_VMCNT_CASE(33) LENTIL_VMCNT_CASE(34)
+    LENTIL_VMCNT_CASE(35) LENTIL_VMCNT_CASE(36) LENTIL_VMCNT_CASE(37) LENTIL_VMCNT_CASE(38) LENTIL_VMCNT_CASE(39)
+    LENTIL_VMCNT_CASE(40) LENTIL_VMCNT_CASE(41) LENTIL_VMCNT_CASE(42) LENTIL_VMCNT_CASE(43) LENTIL_VMCNT_CASE(44)
+    LENTIL_VMCNT_CASE(45) LENTIL_VMCNT_CASE(46) LENTIL_VMCNT_CASE(47) LENTIL_VMCNT_CASE(48) LENTIL_VMCNT_CASE(49)
+    LENTIL_VMCNT_CASE(50) LENTIL_VMCNT_CASE(51) LENTIL_VMCNT_CASE(52) LENTIL_VMCNT_CASE(53) LENTIL_VMCNT_CASE(54)
+    LENTIL_VMCNT_CASE(55) LENTIL_VMCNT_CASE(56) LENTIL_VMCNT_CASE(57) LENTIL_VMCNT_CASE(58) LENTIL_VMCNT_CASE(59)
+    LENTIL_VMCNT_CASE(60) LENTIL_VMCNT_CASE(61) LENTIL_VMCNT_CASE(62) LENTIL_VMCNT_CASE(63)
+    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+  }
+#undef LENTIL_VMCNT_CASE
+}
+
+__host__ __device__ constexpr uint32_t dma_wave_f4(uint32_t M, uint32_t ring = kDmaRing) { return M * 64u + ring * 192u + 16u; }
 
 // The three columns of one ring slot, lane's visit.  In assembly because hipcc puts s_waitcnt vmcnt(0) in front of
 // every LDS read it can see while an LDS-DMA may be in flight -- which would wait for the groups behind this one too
@@ -737,10 +758,11 @@ __global__ __launch_bounds__(256) void scan_dma_kernel(ScanArgs a) {
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
   const VisitsDev &V = a.V;
   const uint32_t M = V.visits_per_pixel;
-  const uint32_t wave_f4 = dma_wave_f4(M);
+  const uint32_t R = a.ring >= 2u && a.ring <= 8u ? a.ring : kDmaRing;       // ring slots (ScanArgs::ring; 0: kDmaRing)
+  const uint32_t wave_f4 = dma_wave_f4(M, R);
   float4 *srgba = smem + (size_t)wave * wave_f4;                   // [M][64]
-  float4 *ring = srgba + (size_t)M * 64u;                          // [kDmaRing][3][64]
-  uint32_t *nskip = reinterpret_cast<uint32_t *>(ring + kDmaRing * 192u);   // [64]
+  float4 *ring = srgba + (size_t)M * 64u;                          // [R][3][64]
+  uint32_t *nskip = reinterpret_cast<uint32_t *>(ring + R * 192u);   // [64]
   uint2 *qmem = reinterpret_cast<uint2 *>(smem + (size_t)4u * wave_f4);
   WaveQueue wq;
   wq.init(qmem + (size_t)wave * kWaveQueueLds);
@@ -758,7 +780,7 @@ __global__ __launch_bounds__(256) void scan_dma_kernel(ScanArgs a) {
   auto issue_ring = [&](uint64_t v0, uint32_t g) {
     const uint64_t v = v0 + (uint64_t)g * 64u + lane;
     const uint64_t vl = v < V.n ? v : v_last;                      // lanes past the end re-read the last visit (unused)
-    float4 *slot = ring + (size_t)(g % kDmaRing) * 192u;
+    float4 *slot = ring + (size_t)(g % R) * 192u;
     lds_dma16(V.pos_z + vl, slot);
     lds_dma16(V.volume_ignore + vl, slot + 64);
     lds_dma16(V.transmission + vl, slot + 128);
@@ -778,16 +800,13 @@ __global__ __launch_bounds__(256) void scan_dma_kernel(ScanArgs a) {
         const uint64_t v = v0 + (uint64_t)g * 64u + lane;
         lds_dma16(V.rgba + (v < V.n ? v : v_last), srgba + (size_t)g * 64u);
       }
-      for (uint32_t g = 0; g < kDmaRing && g < M; ++g) issue_ring(v0, g);
+      for (uint32_t g = 0; g < R && g < M; ++g) issue_ring(v0, g);
       for (uint32_t g = 0; g < M; ++g) {
         // ring groups issued after g's: g+1 .. min(g + kDmaRing - 1, M - 1)
-        const uint32_t behind = (M - 1u - g) < (kDmaRing - 1u) ? (M - 1u - g) : (kDmaRing - 1u);
-        static_assert(kDmaRing <= 3, "one wait form per number of groups in flight behind the awaited one");
-        if (behind >= 2u) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        else if (behind == 1u) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const uint32_t behind = (M - 1u - g) < (R - 1u) ? (M - 1u - g) : (R - 1u);
+        wait_vmcnt(3u * behind);
         float4 pz, vi, tr;
-        lds_read_slot(ring + (size_t)(g % kDmaRing) * 192u + lane, pz, vi, tr);
+        lds_read_slot(ring + (size_t)(g % R) * 192u + lane, pz, vi, tr);
         const uint32_t e = g * 64u + lane;
         const uint64_t v = v0 + e;
         const bool valid = v < V.n;
@@ -806,10 +825,10 @@ __global__ __launch_bounds__(256) void scan_dma_kernel(ScanArgs a) {
           atomicAdd(&nskip[e / M], 1u);
         }
         wq.push(flagged, (uint32_t)v, (uint32_t)samples, a);
-        if (g + kDmaRing < M) {
+        if (g + R < M) {
           // the slot's values are in registers (the decision above has used them): refill it
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
-          issue_ring(v0, g + kDmaRing);
+          issue_ring(v0, g + R);
         }
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
@@ -891,26 +910,6 @@ LD_DEV float4 global_read_f4_untracked(const float4 *p) {
   v4f x;
   asm volatile("global_load_dwordx4 %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=&v"(x) : "v"(p) : "memory");
   return make_float4(x.x, x.y, x.z, x.w);
-}
-LD_DEV void wait_vmcnt(uint32_t n) {       // n is wave-uniform; the instruction takes an immediate
-#define LENTIL_VMCNT_CASE(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); break;
-  switch (n) {
-    LENTIL_VMCNT_CASE(0) LENTIL_VMCNT_CASE(1) LENTIL_VMCNT_CASE(2) LENTIL_VMCNT_CASE(3) LENTIL_VMCNT_CASE(4)
-    LENTIL_VMCNT_CASE(5) LENTIL_VMCNT_CASE(6) LENTIL_VMCNT_CASE(7) LENTIL_VMCNT_CASE(8) LENTIL_VMCNT_CASE(9)
-    LENTIL_VMCNT_CASE(10) LENTIL_VMCNT_CASE(11) LENTIL_VMCNT_CASE(12) LENTIL_VMCNT_CASE(13) LENTIL_VMCNT_CASE(14)
-    LENTIL_VMCNT_CASE(15) LENTIL_VMCNT_CASE(16) LENTIL_VMCNT_CASE(17) LENTIL_VMCNT_CASE(18) LENTIL_VMCNT_CASE(19)
-    LENTIL_VMCNT_CASE(20) LENTIL_VMCNT_CASE(21) LENTIL_VMCNT_CASE(22) LENTIL_VMCNT_CASE(23) LENTIL_VMCNT_CASE(24)
-    LENTIL_VMCNT_CASE(25) LENTIL_VMCNT_CASE(26) LENTIL_VMCNT_CASE(27) LENTIL_VMCNT_CASE(28) LENTIL_VMCNT_CASE(29)
-    LENTIL_VMCNT_CASE(30) LENTIL_VMCNT_CASE(31) LENTIL_VMCNT_CASE(32) LENTIL_VMCNT_CASE(33) LENTIL_VMCNT_CASE(34)
-    LENTIL_VMCNT_CASE(35) LENTIL_VMCNT_CASE(36) LENTIL_VMCNT_CASE(37) LENTIL_VMCNT_CASE(38) LENTIL_VMCNT_CASE(39)
-    LENTIL_VMCNT_CASE(40) LENTIL_VMCNT_CASE(41) LENTIL_VMCNT_CASE(42) LENTIL_VMCNT_CASE(43) LENTIL_VMCNT_CASE(44)
-    LENTIL_VMCNT_CASE(45) LENTIL_VMCNT_CASE(46) LENTIL_VMCNT_CASE(47) LENTIL_VMCNT_CASE(48) LENTIL_VMCNT_CASE(49)
-    LENTIL_VMCNT_CASE(50) LENTIL_VMCNT_CASE(51) LENTIL_VMCNT_CASE(52) LENTIL_VMCNT_CASE(53) LENTIL_VMCNT_CASE(54)
-    LENTIL_VMCNT_CASE(55) LENTIL_VMCNT_CASE(56) LENTIL_VMCNT_CASE(57) LENTIL_VMCNT_CASE(58) LENTIL_VMCNT_CASE(59)
-    LENTIL_VMCNT_CASE(60) LENTIL_VMCNT_CASE(61) LENTIL_VMCNT_CASE(62) LENTIL_VMCNT_CASE(63)
-    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-  }
-#undef LENTIL_VMCNT_CASE
 }
 constexpr uint32_t kDmaMultiRun = 16;      // groups a wave draws at a time
 // A column of a slot is 64 float4 and one of padding: columns 1 KiB apart would put the sum lanes of one pixel -- same
