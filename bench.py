@@ -587,7 +587,7 @@ def main():
     # single-GPU frame.  (Stacking N frames on top of each other would push the outer bands far off axis, where the
     # lens passes nothing and every visit burns its 5 x samples attempts.)
     frame_world = emulate[0] if emulate else world
-    strong = args.scaling == "strong" and not emulate
+    strong = args.scaling == "strong"          # (also under --emulate: rank r's band of the strong-scaled frame)
     if frame_world == 1:
         W, Hr = args.width, args.height
         H = Hr
