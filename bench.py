@@ -269,7 +269,7 @@ def parity_check(args, p, table, M, tan_half_fov, device_index, torch):
             "tolerance": 1e-5, "redistributed_visits": int(c.redistributed_visits),
             "sample": "every %d-th row of the timed %dx%d frame (%d visits), HIP path against the oracle" % (row_step, W, H, n),
             "full_size": "tests/test_gpu_headline.py::test_headline_4k_streamed_vs_oracle (the timed streams, bit-identical "
-                         "draw lists, 1e-5 radiance) and ::test_config5_quarter_frame_chunked_vs_oracle"}
+                         "draw lists, 1e-5 radiance) and ::test_config5_quarter_frame_vs_oracle"}
 
 
 def load_traffic(workload_tag):

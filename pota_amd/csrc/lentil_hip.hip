@@ -113,6 +113,7 @@ struct lentil_hip_ctx {
   // Streamed pass (polynomial optics, from the second pass of a context on): one scan launch that publishes its items
   // and their first-batch tasks itself, persistent solve waves that follow the task queue while the scan runs.
   bool stream_mode = true;                   // LENTIL_STREAM=0: chunked passes only
+  bool stream_below_set = false;             // LENTIL_STREAM_BELOW given: that number alone decides
   uint64_t stream_below = 5ull << 19;        // LENTIL_STREAM_BELOW: ... and for passes with at least this many draws (previous pass's count; 2.5 Mi: measured crossover between 1.2 M draws, streamed 2.6 vs 2.9 ms, and 3.1 M, 5.1 vs 4.9 ms)
   int stream_blocks = 2;                     // LENTIL_STREAM_BLOCKS: solve blocks per CU beside the scan (1 or 2)
   uint32_t epoch = 0;                        // tag of the current pass's task slots
@@ -367,7 +368,7 @@ LENTIL_API int lentil_hip_create(int device, lentil_hip_ctx **out_ctx) {
   if (const char *e = getenv("LENTIL_UNKNOWN_CREDIT")) { const int v = atoi(e); ctx->unknown_credit = (uint32_t)(v < 0 ? 0 : (v > 8 ? 8 : v)); }
   if (const char *e = getenv("LENTIL_CROWD_STAYS")) { ctx->crowd_stays_first = e[0] == '1'; ctx->crowd_stays_later = e[0] && e[1] == '1'; }
   if (const char *e = getenv("LENTIL_SOLVE_B")) ctx->solve_b = e[0] == '1';
-  if (const char *e = getenv("LENTIL_STREAM_BELOW")) ctx->stream_below = strtoull(e, nullptr, 10);
+  if (const char *e = getenv("LENTIL_STREAM_BELOW")) { ctx->stream_below = strtoull(e, nullptr, 10); ctx->stream_below_set = true; }
   if (const char *e = getenv("LENTIL_STREAM_BLOCKS")) ctx->stream_blocks = atoi(e);
   if (ctx->stream_blocks < 1) ctx->stream_blocks = 1;
   // Never three: three solve blocks per CU fill the register file (3 x 168 of 512 VGPRs per lane), and should they be
@@ -1489,7 +1490,13 @@ static int redistribute_streamed(lentil_hip_ctx *ctx, bool *streamed) {
   // AOVs, whose scan kernel leaves the solve waves less room (config 4: 10.8 against 11.5 ms).
   // (LENTIL_STREAM_EXTRA=0: frames with extra AOVs take the chunked pass whatever their scan kernel)
   static const bool stream_extra = !(getenv("LENTIL_STREAM_EXTRA") && getenv("LENTIL_STREAM_EXTRA")[0] == '0');
-  if (ctx->est_sum_total >= ctx->stream_below) return LENTIL_OK;
+  // (Round 3: ... or below one draw per 24 visits, whichever is more -- what streaming buys is the scan running beside the
+  // solves, and a frame whose scan is long against its draws gains most: BASELINE config 5, 8K with 9.3 M draws, 12.9 ms
+  // streamed against 16.3 chunked; 4K with 3.1 M draws 4.3 against 4.8 ms, with 6-48 M draws within +-5 % either way.)
+  {
+    const uint64_t by_visits = ctx->stream_below_set ? 0ull : ctx->V.n / 24ull;
+    if (ctx->est_sum_total >= (ctx->stream_below > by_visits ? ctx->stream_below : by_visits)) return LENTIL_OK;
+  }
   if (ctx->V.n_extra && !(stream_extra && dma_multi_applies(ctx))) return LENTIL_OK;
   lentil_hip_ctx::Chunk &ch = ctx->chunks[0];
   // One streamed pass per device at a time: the resident kernels of two of them could keep each other's scan off the chip.
