@@ -136,6 +136,8 @@ struct lentil_hip_ctx {
   bool slow_live = true;             // LENTIL_SLOW_LIVE=0: stragglers of a streamed pass wait for their round's solve kernel to end
   int crowd_stays_first = 0, crowd_stays_later = 0;    // LENTIL_CROWD_STAYS=ab (two digits): DrawArgs::slow_crowd_stays of a streamed pass's first / later rounds
   bool solve_b = false;              // LENTIL_SOLVE_B=1: the second solve launch behind the scan (its blocks only find room when the first launch's leave: measured idle)
+  uint32_t margin_low_rate = 10;      // LENTIL_BATCH_MARGIN_LOW_RATE (sixteenths, 0..16): DrawArgs::margin_low_rate
+  uint32_t batch_margin16 = 4;        // LENTIL_BATCH_MARGIN (sixteenths, 0..16): DrawArgs::batch_margin16
   uint32_t unknown_credit = 7;        // LENTIL_UNKNOWN_CREDIT (0..8): DrawArgs::unknown_credit
   bool chain_streams = true;          // LENTIL_CHAIN_STREAMS=0: a decoupled pass keeps its accepts on the main stream
   hipEvent_t ev_solve = nullptr, ev_slow1 = nullptr;
@@ -365,6 +367,8 @@ LENTIL_API int lentil_hip_create(int device, lentil_hip_ctx **out_ctx) {
   if (const char *e = getenv("LENTIL_OVERLAP_ROUNDS")) ctx->overlap_rounds = !(e[0] == '0');
   if (const char *e = getenv("LENTIL_DECOUPLE")) ctx->decouple = !(e[0] == '0');
   if (const char *e = getenv("LENTIL_CHAIN_STREAMS")) ctx->chain_streams = !(e[0] == '0');
+  if (const char *e = getenv("LENTIL_BATCH_MARGIN_LOW_RATE")) { const int v = atoi(e); ctx->margin_low_rate = (uint32_t)(v < 0 ? 0 : (v > 16 ? 16 : v)); }
+  if (const char *e = getenv("LENTIL_BATCH_MARGIN")) { const int v = atoi(e); ctx->batch_margin16 = (uint32_t)(v < 0 ? 0 : (v > 16 ? 16 : v)); }
   if (const char *e = getenv("LENTIL_UNKNOWN_CREDIT")) { const int v = atoi(e); ctx->unknown_credit = (uint32_t)(v < 0 ? 0 : (v > 8 ? 8 : v)); }
   if (const char *e = getenv("LENTIL_CROWD_STAYS")) { ctx->crowd_stays_first = e[0] == '1'; ctx->crowd_stays_later = e[0] && e[1] == '1'; }
   if (const char *e = getenv("LENTIL_SOLVE_B")) ctx->solve_b = e[0] == '1';
@@ -1218,6 +1222,8 @@ static void init_draw_args(lentil_hip_ctx *ctx, DrawArgs &da) {
   // a straggler is a solve well beyond what this lens usually takes: 1.3 x the mean iteration count of the previous
   // pass where that is above LENTIL_SLOW_AT (petzval table: ~25 iterations on average, 20 would park thousands)
   da.slow_at = ctx->slow_at;
+  da.batch_margin16 = ctx->batch_margin16;
+  da.margin_low_rate = ctx->margin_low_rate;
   if (ctx->slow_at > 0 && ctx->mean_iters > 0.0) {
     const int adaptive = (int)(1.3 * ctx->mean_iters + 0.5);
     if (adaptive > da.slow_at) da.slow_at = adaptive < 90 ? adaptive : 90;
