@@ -2760,7 +2760,8 @@ LD_DEV AcceptResult accept_item_chroma(const DrawArgs &a, AcceptShared &sh, uint
     const uint32_t remaining = S - (uint32_t)(count > 0 ? count : 0);
     unsigned long long need = count > 0 ? ((unsigned long long)remaining * n + (uint32_t)count - 1) / (uint32_t)count
                                         : (unsigned long long)(max_total - n);
-    need += need / 4 + 32;
+    const uint32_t m16 = (unsigned long long)(count > 0 ? count : 0) * 16ull < (unsigned long long)n * a.margin_low_rate ? 2u * a.batch_margin16 : a.batch_margin16;
+    need += (need * m16) / 16 + 32;       // (as accept_item)
     unsigned long long n_target = (unsigned long long)n + need;
     if (n_target > max_total) n_target = max_total;
     uint32_t new_hi = (uint32_t)n_target + retries;
