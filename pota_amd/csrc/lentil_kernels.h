@@ -1743,8 +1743,17 @@ __global__ __launch_bounds__(256) LENTIL_SOLVE_ATTR void solve_po_kernel(DrawArg
   __shared__ DevLens s_k;
   __shared__ DevLens s_kc[kChroma ? 3 : 1];
   __shared__ float s_cdfRow[kMaxBokehRows];
-  __shared__ uint64_t s_hdr[kStream ? 4 : 1][4];      // kStream: per wave, the header of the task being handed out
-  (void)s_hdr;
+  __shared__ uint64_t s_hdr[4][4];                    // per wave: the header of the task being handed out
+  // Batched start and end of the solves (round 4).  A solve's first step (tea<8> seed, aperture draw: ~250 instructions)
+  // and its last (transmittance polynomial, pupil tests, sensor -> pixel: ~250) used to run inside the round in which a
+  // lane needed them -- in steady state four lanes of 64 in nearly every round, i.e. 300 wave instructions per round
+  // for 6 % of the lanes (PMC, profiles/r04_pmc_solve_*: 1 952 vector instructions per round at 54.8 active lanes,
+  // the SIMDs' vector units 97 % busy: the kernel is bound by its instruction count).  Now the aperture draws of a
+  // task's 64 units are computed by all lanes at once when the wave takes the task (s_ap), and a finished solve leaves
+  // its state in the wave's queue (s_fin*), which all lanes empty together when it is full.
+  __shared__ double s_ap[4][64][2];
+  __shared__ double s_fin[4][6][64];                  // x, y, dx, dy, out[0], out[1]
+  __shared__ uint32_t s_fin_err[4][64], s_fin_res[4][64];      // error bits | channel << 8; result slot
   if (kTables) {
     const uint32_t nt = a.lens->n_terms;
     for (uint32_t i = threadIdx.x; i < nt; i += blockDim.x) s_terms[i] = a.terms[i];
@@ -1788,9 +1797,49 @@ __global__ __launch_bounds__(256) LENTIL_SOLVE_ATTR void solve_po_kernel(DrawArg
   uint32_t idle_naps = 1u;
   (void)ticket; (void)polls; (void)ticket_t0; (void)idle_naps;
   // per-lane solve
-  bool busy = false, need_init = false;
-  uint32_t m = 0, res_idx = 0, seed_a = 0, cur_chan_lane = 0;
+  bool busy = false;
+  uint32_t res_idx = 0, cur_chan_lane = 0;
   (void)cur_chan_lane;
+  const uint32_t wv = threadIdx.x >> 6;
+  uint32_t cur_pos = 0;        // wave-uniform: units of the current task handed out so far (index into s_ap)
+  uint32_t fin_n = 0;          // wave-uniform: finished solves waiting in s_fin
+  // the finished solves of the queue, one per lane: the tail of trace_ray_bw_po + sensor -> pixel (solve_result)
+  auto flush_finished = [&]() {
+    if (fin_n == 0u) return;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
+    if (lane < fin_n) {
+      NewtonState t;
+      t.x = s_fin[wv][0][lane]; t.y = s_fin[wv][1][lane]; t.dx = s_fin[wv][2][lane]; t.dy = s_fin[wv][3][lane];
+      t.out[0] = s_fin[wv][4][lane]; t.out[1] = s_fin[wv][5][lane]; t.out[2] = 0.0; t.out[3] = 0.0;
+      t.sqr_err = 0.0; t.sqr_ap_err = 0.0; t.k = 0;
+      const uint32_t ew = s_fin_err[wv][lane];
+      t.error = (int)(ew & 0xFFu);
+      LensT Lf = L;
+      if constexpr (kChroma) Lf.k = &s_kc[(ew >> 8) & 3u];
+      res[s_fin_res[wv][lane]] = solve_result(P, Lf, t);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+    __builtin_amdgcn_wave_barrier();
+    fin_n = 0u;
+  };
+  // a task has been taken (cur_* set, its header in s_hdr[wv]): the aperture draws of all its units at once --
+  // the reference's try with seed (seed_a, m), src/lentil.h:596-609
+  auto start_task = [&]() {
+    cur_pos = 0u;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
+    if (lane < cur_left) {
+      double ax = 0.0, ay = 0.0;
+      po_aperture_sample(P, a.bokeh, cdfRow, (uint32_t)s_hdr[wv][3], cur_m + lane, ax, ay);
+      s_ap[wv][lane][0] = ax; s_ap[wv][lane][1] = ay;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
+  };
   double target[3] = {0, 0, 1};
   double ap_x = 0.0, ap_y = 0.0;
   NewtonState s;
@@ -1844,14 +1893,11 @@ __global__ __launch_bounds__(256) LENTIL_SOLVE_ATTR void solve_po_kernel(DrawArg
           if (cur_left) {
             // the item's header, written by a publisher on another CU while this kernel runs: lane 0 fetches it with
             // atomics and parks it in the wave's LDS slot, where the lanes that take solves of this task pick it up
-            if (lane == 0) {
+            if (lane < 4u) {
               const uint64_t *hp = reinterpret_cast<const uint64_t *>(a.hdr + cur_item);
-              uint64_t *dst = s_hdr[threadIdx.x >> 6];
-              dst[0] = ld_coherent64(hp + 0); dst[1] = ld_coherent64(hp + 1); dst[2] = ld_coherent64(hp + 2); dst[3] = ld_coherent64(hp + 3);
+              s_hdr[wv][lane] = ld_coherent64(hp + lane);       // (four lanes, one round trip)
             }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
+            start_task();
           }
           if (cur_left == 0) continue;        // an item that did not fit left empty tasks
         } else {
@@ -1865,33 +1911,34 @@ __global__ __launch_bounds__(256) LENTIL_SOLVE_ATTR void solve_po_kernel(DrawArg
           cur_res = __builtin_amdgcn_readfirstlane(t.res_off);
           cur_left = __builtin_amdgcn_readfirstlane(t.count) & 0xFFu;
           if (kChroma) cur_chan = (__builtin_amdgcn_readfirstlane(t.count) >> 8) & 3u;
+          if (cur_left) {
+            if (lane < 4u) s_hdr[wv][lane] = reinterpret_cast<const uint64_t *>(a.hdr + cur_item)[lane];
+            start_task();
+          }
+          if (cur_left == 0) continue;
         }
       }
       uint32_t take = n_idle - filled;
       if (take > cur_left) take = cur_left;
       if (!busy && my_rank >= filled && my_rank < filled + take) {
         const uint32_t j = my_rank - filled;
-        m = cur_m + j;
         res_idx = cur_res + j;
-        if constexpr (kStream) {
-          // written by a publisher on another CU during this launch (wave-uniform: hdr_* were fetched with the task)
-          const uint64_t *hs = s_hdr[threadIdx.x >> 6];
-          target[0] = __longlong_as_double((long long)hs[0]);
-          target[1] = __longlong_as_double((long long)hs[1]);
-          target[2] = __longlong_as_double((long long)hs[2]);
-          seed_a = (uint32_t)hs[3];
-        } else {
-          const ItemHdr hd = a.hdr[cur_item];
-          target[0] = hd.tx; target[1] = hd.ty; target[2] = hd.tz;
-          seed_a = hd.seed_a;
-        }
+        // (kStream: written by a publisher on another CU during this launch; fetched with the task)
+        const uint64_t *hs = s_hdr[wv];
+        target[0] = __longlong_as_double((long long)hs[0]);
+        target[1] = __longlong_as_double((long long)hs[1]);
+        target[2] = __longlong_as_double((long long)hs[2]);
+        ap_x = s_ap[wv][cur_pos + j][0];
+        ap_y = s_ap[wv][cur_pos + j][1];
+        newton_init(s);
+        ++st_tries;
         busy = true;
-        need_init = true;
         if constexpr (kChroma) { L.k = &s_kc[cur_chan]; cur_chan_lane = cur_chan; }
       }
-      cur_m += take; cur_res += take; cur_left -= take; filled += take;
+      cur_pos += take; cur_res += take; cur_left -= take; filled += take;
     }
     if (inflight + filled == 0u) {
+      flush_finished();
       if (!kStream || no_more) break;
       // An idle wave polls its slot, nothing else -- and rarely: a thousand waves asking every microsecond keep the
       // L2 channel that holds the queue busy enough to hold up every DMA group of the scan that touches it
@@ -1902,22 +1949,29 @@ __global__ __launch_bounds__(256) LENTIL_SOLVE_ATTR void solve_po_kernel(DrawArg
     }
     idle_naps = 1u;
 
-    // aperture draw of the reference's try with seed (seed_a, m), src/lentil.h:596-609
-    if (busy && need_init) {
-      po_aperture_sample(P, a.bokeh, cdfRow, seed_a, m, ap_x, ap_y);
-      newton_init(s);
-      need_init = false;
-      ++st_tries;
-    }
     if (busy) { newton_iter(L, target, ap_x, ap_y, s); ++st_iters; }
     ++st_rounds;
 #ifdef LENTIL_TIMELINE
     { const uint32_t nb_ = (uint32_t)__builtin_popcountll(__ballot(busy)); if (lane == 0) tl_add(!kStream || a.round ? TL_ITERS_LATER : (a.instance ? TL_ITERS_B : TL_ITERS_A), nb_); }
 #endif
 
-    if (busy && !newton_continue(s)) {
-      res[res_idx] = solve_result(P, L, s);
-      busy = false;
+    {
+      // finished solves go to the wave's queue; the queue is emptied by all lanes together when the next ones do not fit
+      const bool fin = busy && !newton_continue(s);
+      const unsigned long long fmask = __ballot(fin);
+      if (fmask) {
+        const uint32_t nfin = (uint32_t)__builtin_popcountll(fmask);
+        if (fin_n + nfin > 64u) flush_finished();
+        if (fin) {
+          const uint32_t q = fin_n + (uint32_t)__builtin_popcountll(fmask & lt_mask);
+          s_fin[wv][0][q] = s.x; s_fin[wv][1][q] = s.y; s_fin[wv][2][q] = s.dx; s_fin[wv][3][q] = s.dy;
+          s_fin[wv][4][q] = s.out[0]; s_fin[wv][5][q] = s.out[1];
+          s_fin_err[wv][q] = ((uint32_t)s.error & 0xFFu) | ((kChroma ? cur_chan_lane : 0u) << 8);
+          s_fin_res[wv][q] = res_idx;
+          busy = false;
+        }
+        fin_n += nfin;
+      }
     }
     // Stragglers: about one solve in a thousand is still running after slow_at iterations and may need all 100.
     // Park its loop state for solve_slow_kernel (a whole wave per solve, ~4x less time per iteration) instead of
@@ -1981,6 +2035,7 @@ __global__ __launch_bounds__(256) LENTIL_SOLVE_ATTR void solve_po_kernel(DrawArg
       }
     }
   }
+  flush_finished();
   if (a.slow_live && a.slow && a.slow_close) {
     // Everything this wave parked has arrived.  The straggler queue is closed by whichever wave finds, on leaving, that
     // every wave that has begun has left and every task has been taken (and, streamed, published): no solve can be
