@@ -518,6 +518,12 @@ int lentil_hip_test_trace_bw_po(lentil_hip_ctx *ctx, uint64_t n, const double *t
                                 double *sensor_xy, int32_t *ok);
 int lentil_hip_test_aperture_sample(lentil_hip_ctx *ctx, uint64_t n, const uint32_t *a,
                                     const uint32_t *b, double *xy);
+/* Test hook, needs no GPU.  The scan decides `get_coc_thinlens(z) < 0.4` (src/lentil.h:674-692,
+ * src/lentil_filter.cpp:185-190) from the camera-space depth alone wherever that is certain; this returns the
+ * intervals it would use for `params`: out[0..1] / out[2..3] lower / upper ends of the (at most two) closed depth
+ * intervals on which the circle of confusion is certainly below 0.4, out[4..5] / out[6..7] those outside of which it is
+ * certainly not (an interval with lower > upper end is empty).  In between the kernel evaluates the function. */
+int lentil_hip_debug_scan_bands(const lentil_params *params, float out[8]);
 
 #ifdef __cplusplus
 }

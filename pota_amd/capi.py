@@ -24,7 +24,7 @@ EXPORTS = [
     "lentil_hip_pack_rows", "lentil_hip_merge_packed_rows", "lentil_hip_compact_rows", "lentil_hip_merge_sparse",
     "lentil_hip_get_counters", "lentil_hip_last_timing", "lentil_hip_last_launches", "lentil_hip_set_draw_log",
     "lentil_hip_download_draw_log", "lentil_hip_test_lt_sample_aperture",
-    "lentil_hip_test_trace_bw_po", "lentil_hip_test_aperture_sample",
+    "lentil_hip_test_trace_bw_po", "lentil_hip_test_aperture_sample", "lentil_hip_debug_scan_bands",
     "lentil_hip_lens_is_compiled", "lentil_hip_set_lens_mode",
     "lentil_hip_focus_search", "lentil_hip_test_y0_intersection",
     "lentil_hip_set_xor128_state", "lentil_hip_get_xor128_state",

@@ -405,6 +405,7 @@ LENTIL_API int lentil_hip_create(int device, lentil_hip_ctx **out_ctx) {
   }
   // (the multi-AOV scan's ring can take all of a CU's LDS)
   (void)hipFuncSetAttribute((const void *)scan_dma_multi_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  (void)hipFuncSetAttribute((const void *)scan_dma2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   (void)hipGetLastError();
   *out_ctx = ctx;
   return LENTIL_OK;
@@ -1303,6 +1304,62 @@ static int prepare_direct(lentil_hip_ctx *ctx, const lentil_hip_ctx::DirRegion *
   return LENTIL_OK;
 }
 
+// Where get_coc_thinlens(P, cz) < 0.4f (lentil_device.h; src/lentil.h:674-692, src/lentil_filter.cpp:185-190) is decided by cz
+// alone, for scan_dma2_kernel.  The kernel computes, in fp32, ifd = (-f * -fd) / (-f + -fd), isp = (-f * z) / (-f + z),
+// coc = |A (isp - ifd) / isp|.  In exact arithmetic 1 / isp = 1 / z - 1 / f, so coc = |A| |c0 - c1 / z| with c0 = 1 + ifd / f,
+// c1 = ifd: in u = 1 / z the set {coc < t} is ONE interval around the focus plane.  The fp32 evaluation differs from that by
+// a few 1e-7 relative, times |A| / 0.4 near the threshold (the subtraction isp - ifd carries isp's rounding): with
+// eps = 1e-3 + 1e-5 |A| the comparison with 0.4 (1 - eps) / 0.4 (1 + eps) is certain, and the strip in between -- a
+// few visits in 10^4 -- is left to the function.  Interval ends are rounded towards the uncertain side; |z| > 1e30 (where
+// -f * z overflows and the function returns NaN) is never "certainly below".
+static ScanBands scan_bands(const lentil_params &P) {
+  ScanBands B;
+  for (int i = 0; i < 2; ++i) { B.in_lo[i] = 1.0f; B.in_hi[i] = -1.0f; B.out_lo[i] = 1.0f; B.out_hi[i] = -1.0f; }
+  B.out_lo[0] = -INFINITY; B.out_hi[0] = INFINITY;       // nothing usable: every finite depth asks the function
+  float fd = (float)P.focus_distance, A = (float)P.aperture_radius;
+  if (P.cameraType == LENTIL_POLYNOMIAL_OPTICS) fd = (float)((double)fd / 10.0);
+  else A = (float)((double)A * 10.0);
+  const float f = P.focal_length;
+  const float ifd = (-f * -fd) / (-f + -fd);
+  const double a = std::fabs((double)A), c0 = 1.0 + (double)ifd / (double)f, c1 = (double)ifd;
+  if (!(a > 0.0) || !std::isfinite(a) || !std::isfinite(c0) || !std::isfinite(c1) || c1 == 0.0 || !(f > 0.0f)) return B;
+  const double eps = 1e-3 + 1e-5 * a;
+  if (!(eps < 0.25)) return B;
+  auto up = [](double v) { float r = (float)v; if ((double)r < v) r = std::nextafter(r, INFINITY); return r; };       // smallest float >= v
+  auto down = [](double v) { float r = (float)v; if ((double)r > v) r = std::nextafter(r, -INFINITY); return r; };    // largest float <= v
+  // z-intervals of {coc <= t}: u in [ua, ub], z = 1 / u
+  auto pieces = [&](double t, bool inner, float lo[2], float hi[2]) {
+    double ua = (c0 - t / a) / c1, ub = (c0 + t / a) / c1;
+    if (ua > ub) std::swap(ua, ub);
+    lo[0] = lo[1] = 1.0f; hi[0] = hi[1] = -1.0f;
+    const double big = inner ? 1e30 : (double)INFINITY;
+    if (ua > 0.0 || ub < 0.0) {
+      const double zl = 1.0 / ub, zh = 1.0 / ua;
+      lo[0] = inner ? up(std::max(zl, -big)) : down(zl);
+      hi[0] = inner ? down(std::min(zh, big)) : up(zh);
+    } else {
+      // the interval holds u = 0: everything beyond 1 / ua on the negative side, beyond 1 / ub on the positive side
+      if (ua < 0.0) { lo[0] = inner ? (float)-big : -INFINITY; hi[0] = inner ? down(1.0 / ua) : up(1.0 / ua); }
+      if (ub > 0.0) { lo[1] = inner ? up(1.0 / ub) : down(1.0 / ub); hi[1] = inner ? (float)big : INFINITY; }
+      if (!inner && (ua == 0.0 || ub == 0.0)) { lo[0] = -INFINITY; hi[0] = INFINITY; }
+    }
+  };
+  ScanBands R = B;
+  pieces(0.4 * (1.0 - eps), true, R.in_lo, R.in_hi);
+  pieces(0.4 * (1.0 + eps), false, R.out_lo, R.out_hi);
+  for (int i = 0; i < 2; ++i)
+    if (std::isnan(R.in_lo[i]) || std::isnan(R.in_hi[i]) || std::isnan(R.out_lo[i]) || std::isnan(R.out_hi[i])) return B;
+  return R;
+}
+
+// test hook (no GPU needed): the intervals scan_dma2_kernel would use for these parameters -- in_lo[2], in_hi[2], out_lo[2], out_hi[2]
+LENTIL_API int lentil_hip_debug_scan_bands(const lentil_params *P, float out[8]) {
+  if (!P || !out) return LENTIL_ERR_INVALID;
+  const ScanBands B = scan_bands(*P);
+  for (int i = 0; i < 2; ++i) { out[i] = B.in_lo[i]; out[2 + i] = B.in_hi[i]; out[4 + i] = B.out_lo[i]; out[6 + i] = B.out_hi[i]; }
+  return LENTIL_OK;
+}
+
 // How the bound visit stream is scanned: kernel, tile size, LDS.
 struct ScanPlan {
   ScanArgs sa{};
@@ -1310,6 +1367,7 @@ struct ScanPlan {
   uint64_t n_tiles = 0;
   bool multi = false;
   bool dma = false;       // scan_dma_kernel (beauty only, uniform weights)
+  bool dma2 = false;      // ... its pipelined form, scan_dma2_kernel (one block per CU)
   bool dma_multi = false; // scan_dma_multi_kernel (extra gaussian AOVs, uniform weights)
   uint32_t M = 0;
 };
@@ -1383,6 +1441,22 @@ static int plan_scan(lentil_hip_ctx *ctx, ScanPlan &pl) {
       sa.tv_pad = ppt * M;
       pl.lds = dma_lds;
       pl.multi = false;
+      // scan_dma2_kernel: tiles pipelined into one another (two rgba buffers per wave), one block per CU.  In a streamed pass
+      // the block must fit beside the resident solve blocks, or neither it nor they would ever end (LENTIL_SCAN_DMA2=0: never)
+      static const bool dma2_allowed = !(getenv("LENTIL_SCAN_DMA2") && getenv("LENTIL_SCAN_DMA2")[0] == '0');
+      const size_t dma2_lds = (size_t)4 * dma2_wave_f4(M) * 16 + 4 * kWaveQueueLds * sizeof(uint2);
+      const size_t solve_lds = (size_t)ctx->stream_blocks * ((ctx->use_generated && lentil_hip_lens_is_compiled(ctx)) ? 28u : 53u) * 1024u;
+      const uint64_t ppr = ctx->V.pixels_per_row;
+      pl.dma2 = dma2_allowed && M >= 2 && ppr >= 2 && ppr < (1ull << 31) && ctx->V.n / M < (1ull << 31) &&
+                dma2_lds + (ctx->stream_mode ? solve_lds : 0) + 1024u <= 160u * 1024u;
+      if (pl.dma2) {
+        pl.lds = dma2_lds;
+        sa.bands = scan_bands(ctx->P);
+        uint32_t sh = 0;
+        while ((2ull << sh) < ppr) ++sh;                 // 2^sh < ppr <= 2^(sh+1)
+        sa.ppr_shift = sh;
+        sa.ppr_magic = (uint32_t)(((1ull << (32 + sh)) + ppr - 1) / ppr);
+      }
     }
     // frames with extra AOVs, all of them gaussian: the LDS-DMA form of the multi-column scan (LENTIL_SCAN_DMA_MULTI=0: never)
     const size_t dmam_lds = dma_multi_lds(ctx);
@@ -1444,7 +1518,14 @@ static int launch_scan(lentil_hip_ctx *ctx, const ScanPlan &pl, const lentil_hip
     if (const char *e = getenv("LENTIL_DMA_BLOCKS")) per_cu = strtoull(e, nullptr, 10);
     if (blocks > (uint64_t)ctx->num_cu * per_cu) blocks = (uint64_t)ctx->num_cu * per_cu;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(scan_dma_kernel, dim3((unsigned)blocks), dim3(256), pl.lds, ctx->stream, sa);
+    if (pl.dma2) {
+      blocks = (ch.tile_end - ch.tile_begin + 15) / 16;
+      if (blocks > (uint64_t)ctx->num_cu) blocks = (uint64_t)ctx->num_cu;
+      if (blocks < 1) blocks = 1;
+      hipLaunchKernelGGL(scan_dma2_kernel, dim3((unsigned)blocks), dim3(256), pl.lds, ctx->stream, sa);
+    } else {
+      hipLaunchKernelGGL(scan_dma_kernel, dim3((unsigned)blocks), dim3(256), pl.lds, ctx->stream, sa);
+    }
   } else if (pl.dma_multi) {
     // persistent: a wave draws runs of 16 groups
     blocks = (ch.tile_end - ch.tile_begin + 4 * kDmaMultiRun - 1) / (4 * kDmaMultiRun);
@@ -2876,7 +2957,12 @@ LENTIL_API int lentil_hip_test_aperture_sample(lentil_hip_ctx *ctx, uint64_t n, 
 LENTIL_API int lentil_hip_debug_timeline(unsigned int *out, int reset) {
   if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_timeline), sizeof(unsigned int) * kTlSub * kTlChannels * kTlBuckets) != hipSuccess) return LENTIL_ERR_HIP;
   if (out && hipMemcpyFromSymbol(out + kTlSub * kTlChannels * kTlBuckets, HIP_SYMBOL(g_dbg), sizeof(unsigned long long) * 32) != hipSuccess) return LENTIL_ERR_HIP;
+  if (out && hipMemcpyFromSymbol(out + kTlSub * kTlChannels * kTlBuckets + 64, HIP_SYMBOL(g_span), sizeof(unsigned long long) * 64) != hipSuccess) return LENTIL_ERR_HIP;
   if (reset) {
+    void *sp = nullptr;
+    unsigned long long init[32][2];
+    for (int i = 0; i < 32; ++i) { init[i][0] = ~0ull; init[i][1] = 0ull; }
+    if (hipGetSymbolAddress(&sp, HIP_SYMBOL(g_span)) != hipSuccess || hipMemcpy(sp, init, sizeof(init), hipMemcpyHostToDevice) != hipSuccess) return LENTIL_ERR_HIP;
     void *q = nullptr;
     if (hipGetSymbolAddress(&q, HIP_SYMBOL(g_dbg)) != hipSuccess || hipMemset(q, 0, sizeof(unsigned long long) * 32) != hipSuccess) return LENTIL_ERR_HIP;
     void *p = nullptr;

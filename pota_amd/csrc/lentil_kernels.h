@@ -230,6 +230,14 @@ constexpr uint32_t kEndRange = 0x3FFu;      // ... and the count field of the en
 constexpr uint64_t kStuckTicks = 25000000ull;
 constexpr uint32_t kTaskTagShift = 10;    // Task::count bits 10..31: epoch of the pass that published the slot
 
+// get_coc_thinlens(P, cz) < 0.4f (src/lentil_filter.cpp:185-190), decided from cz where that is certain: the exact circle of
+// confusion is |A| |c0 - c1 / cz|, below 0.4 (1 - eps) on the `in` intervals and above 0.4 (1 + eps) outside the `out`
+// intervals (closed; an empty one has lo > hi); in between -- and where the host found nothing usable -- the function decides.
+struct ScanBands {
+  float in_lo[2], in_hi[2];
+  float out_lo[2], out_hi[2];
+};
+
 struct ScanArgs {
   lentil_params P;
   double lens_length;
@@ -250,6 +258,8 @@ struct ScanArgs {
   uint32_t ring;                   // scan_dma_multi_kernel: slots per wave
   uint32_t outside_in;             // scan_dma*_kernel: tiles from both ends of the range inwards (scan_order)
   float4 *dummy;                   // scan_dma_multi_kernel: 64 x 16 B that lanes without a record store to
+  ScanBands bands;                 // scan_dma2_kernel: where the circle-of-confusion test is decided by the depth alone
+  uint32_t ppr_magic, ppr_shift;   // scan_dma2_kernel: pixel / pixels_per_row = __umulhi(pixel, ppr_magic) >> ppr_shift
 };
 
 LD_DEV void visit_pixel(const VisitsDev &V, uint64_t v, int &px, int &py) {
@@ -284,10 +294,26 @@ LD_DEV void tl_add(int ch, uint32_t n) {
 }
 __device__ unsigned long long g_dbg[32];       // plain event counts (tools/timeline.py prints them)
 LD_DEV void dbg_add(int i, unsigned long long n) { atomicAdd(&g_dbg[i], n); }
+// ... and when every kernel of the pass begins and ends: first block in, last block out, in ticks of the same counter
+__device__ unsigned long long g_span[32][2];
+struct TlSpan {
+  int id;
+  LD_DEV explicit TlSpan(int i) : id(i) {
+    if (threadIdx.x == 0) {
+      const unsigned long long t = __builtin_amdgcn_s_memrealtime();
+      atomicMin(&g_span[id][0], t);
+    }
+  }
+  LD_DEV ~TlSpan() { if (threadIdx.x == 0) atomicMax(&g_span[id][1], (unsigned long long)__builtin_amdgcn_s_memrealtime()); }
+};
+#define LENTIL_TL_SPAN(ID) TlSpan tl_span_guard_(ID)
 #else
 LD_DEV void tl_add(int, uint32_t) {}
 LD_DEV void dbg_add(int, unsigned long long) {}
+#define LENTIL_TL_SPAN(ID) do {} while (0)
 #endif
+enum { SPAN_SCAN = 0, SPAN_PUBLISH, SPAN_SOLVE_R0, SPAN_SOLVE_R1, SPAN_SOLVE_R2, SPAN_SLOW_R0, SPAN_SLOW_R1, SPAN_SLOW_R2,
+       SPAN_ACCEPT0, SPAN_ACCEPT1, SPAN_ACCEPT2, SPAN_RESOLVE, SPAN_RESOLVE_TOUCHED, SPAN_CLEAR, SPAN_RESET, SPAN_PREP };
 enum { TL_SCAN_TILES = 0, TL_TASKS_PUBLISHED, TL_ITERS_A, TL_ITERS_B, TL_ITERS_LATER, TL_ITERS_SLOW, TL_ITEMS_ACCEPTED,
        TL_POLLS_EMPTY, TL_TASKS_TAKEN, TL_PARKED };
 
@@ -754,6 +780,7 @@ LD_DEV void lds_read_slot(const float4 *slot_lane, float4 &c0, float4 &c1, float
 }
 
 __global__ __launch_bounds__(256) void scan_dma_kernel(ScanArgs a) {
+  LENTIL_TL_SPAN(SPAN_SCAN);
   extern __shared__ float4 smem[];
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
   const VisitsDev &V = a.V;
@@ -863,6 +890,300 @@ __global__ __launch_bounds__(256) void scan_dma_kernel(ScanArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------
+// scan_dma2_kernel (round 4) -- scan_dma_kernel with the tiles of a wave pipelined into one another, and a third of
+// its vector instructions.  What the measurements said: with one block per CU -- all that fits
+// beside two resident solve blocks -- scan_dma_kernel takes 1.35-1.47 ms whether the solve waves beside it work or
+// sleep (two blocks per CU: 1.05): every tile ends with nothing in flight, and a wave alone on its SIMD has nobody to
+// cover the memory latency that follows.  And its 122 vector instructions per 64 visits are 0.24 ms of the chip's
+// vector issue time in a pass whose other tenant, the solves, is bound by exactly that.
+//   pipeline  the rgba column of the NEXT tile is requested group by group while this tile's groups are decided (a
+//             second rgba buffer: 2 M + 6 KiB of LDS per wave), and the ring of decision columns simply runs on into
+//             the next tile: in the steady state every step issues the same four DMAs -- ring group G + 2 (three
+//             columns), rgba group g of the next tile -- and waits for `vmcnt(5)`: the five LOADS issued behind the
+//             group it is about to read.  (Only loads are counted: they return in order among themselves; the two record
+//             stores of a tile's end may complete early or late -- the wait then merely includes a load or two more.)
+//   tiles     a wave's first 7/8 are its share of a static interleaved split (runs of four tiles; the next tile is known
+//             without asking anybody), the rest come from DevCounters::tile_next in runs of four (a returning atomic
+//             and a drained pipeline per run, where the CUs' different speeds need evening out).
+//   decision  visit_redistributes, with its two fp32 divisions (get_coc_thinlens < 0.4) replaced by comparisons of the
+//             camera-space depth with precomputed intervals wherever those decide it with certainty (ScanBands, host:
+//             scan_bands() -- the comparison of the exact circle of confusion with 0.4 (1 +- 1e-3)); a wave with a visit
+//             inside a band, at infinite depth under a skydome, or behind a moving camera calls the function itself.
+//   sums      as before (lane p adds pixel p's M entries in iterator order), the entries read with inline ds_read_b128
+//             (a load the compiler can see makes it wait for every DMA in flight), packed fp32 arithmetic, the record's
+//             linear index from a multiply-high instead of a division.
+// Same decisions, same sums bit for bit as scan_dma_kernel (tests: every parity case that runs a beauty-only frame).
+// ---------------------------------------------------------------------------------------
+__host__ __device__ constexpr uint32_t dma2_wave_f4(uint32_t M) { return 2u * M * 64u + 2u * 192u + 16u; }
+LD_DEV float4 lds_read_f4(const float4 *p);       // (below, with the other untracked reads)
+
+LD_DEV void dma2_col(const float4 *ubase, uint32_t lane16, float4 *lds_uniform) {
+  // 64 lanes x 16 B at ubase + lane -> lds_uniform[lane]; the base is wave-uniform (scalar registers), the lane part a
+  // 32-bit offset; aux 2 = nontemporal
+  typedef const __attribute__((address_space(1))) void *gptr_t;
+  typedef __attribute__((address_space(3))) void *lptr_t;
+  __builtin_amdgcn_global_load_lds((gptr_t)(const void *)(reinterpret_cast<const char *>(ubase) + lane16), (lptr_t)(void *)lds_uniform, 16, 0, 2);
+}
+// three consecutive float4 of the wave's LDS with one wait, in one asm block: nothing may touch the destination registers
+// between a read and the wait
+LD_DEV void lds_read_3f4(const float4 *p, float4 &c0, float4 &c1, float4 &c2) {
+  typedef float v4f __attribute__((ext_vector_type(4)));
+  typedef const __attribute__((address_space(3))) void *lptr_t;
+  const uint32_t addr = (uint32_t)(size_t)(lptr_t)(const void *)p;
+  v4f x, y, z;
+  asm volatile("ds_read_b128 %0, %3\n\tds_read_b128 %1, %3 offset:16\n\tds_read_b128 %2, %3 offset:32\n\ts_waitcnt lgkmcnt(0)"
+               : "=&v"(x), "=&v"(y), "=&v"(z)
+               : "v"(addr)
+               : "memory");
+  c0 = make_float4(x.x, x.y, x.z, x.w); c1 = make_float4(y.x, y.y, y.z, y.w); c2 = make_float4(z.x, z.y, z.z, z.w);
+}
+
+// get_coc_thinlens(P, cz) < 0.4f from cz alone: 1 = certainly, 0 = certainly not, 2 = ask the function
+LD_DEV int coc_below_by_bands(const ScanBands &B, float cz) {
+  const bool in0 = cz >= B.in_lo[0] && cz <= B.in_hi[0];
+  const bool in1 = cz >= B.in_lo[1] && cz <= B.in_hi[1];
+  const bool out0 = cz >= B.out_lo[0] && cz <= B.out_hi[0];
+  const bool out1 = cz >= B.out_lo[1] && cz <= B.out_hi[1];
+  if (in0 || in1) return 1;
+  if (out0 || out1) return 2;
+  return 0;       // (NaN, zero and the infinities come here: the function's NaN / infinity is "not below" as well)
+}
+
+__global__ __launch_bounds__(256) void scan_dma2_kernel(ScanArgs a) {
+  LENTIL_TL_SPAN(SPAN_SCAN);
+  extern __shared__ float4 smem[];
+  // (the wave's number as a scalar: tile numbers, LDS bases and every branch on them stay in scalar registers)
+  const uint32_t lane = threadIdx.x & 63u, wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const VisitsDev &V = a.V;
+  const uint32_t M = V.visits_per_pixel;
+  const uint32_t wave_f4 = dma2_wave_f4(M);
+  float4 *rg = smem + (size_t)wave * wave_f4;                      // [2][M][64]
+  float4 *ring = rg + (size_t)2u * M * 64u;                        // [2][3][64]
+  uint32_t *nskip = reinterpret_cast<uint32_t *>(ring + 384u);     // [64]
+  uint2 *qmem = reinterpret_cast<uint2 *>(smem + (size_t)4u * wave_f4);
+  WaveQueue wq;
+  wq.init(qmem + (size_t)wave * kWaveQueueLds);
+  __builtin_amdgcn_s_setprio(3);
+
+  const uint32_t lane16 = lane * 16u;
+  const uint32_t TV = 64u * M;                                     // visits per tile
+  const uint64_t full_end = (V.n / TV) < a.tile_end ? (V.n / TV) : a.tile_end;     // tiles whose 64 pixels all exist
+  const float w = 1.0f * a.P.inverse_sample_density;               // filter_weight * inv_density, lentil.h:949-953
+  float ws_full = 0.f;
+  for (uint32_t j = 0; j < M; ++j) ws_full += w;                   // the weight of a pixel none of whose visits is redistributed
+  float4 *dir4 = reinterpret_cast<float4 *>(a.F.dir);
+  const uint32_t xres = a.P.xres;
+  // decision constants (a resting camera: this kernel is not chosen otherwise)
+  const float mz0 = a.P.world_to_camera[0][2], mz1 = a.P.world_to_camera[1][2], mz2 = a.P.world_to_camera[2][2], mz3 = a.P.world_to_camera[3][2];
+  float scale = 1.0f;
+  if (a.P.unitModel == LENTIL_UNIT_MM) scale = 0.1f;
+  else if (a.P.unitModel == LENTIL_UNIT_DM) scale = 10.0f;
+  else if (a.P.unitModel == LENTIL_UNIT_M) scale = 100.0f;
+  const bool never = a.P.adaptive_sampling && a.P.inverse_sample_density > 0.2f;
+  const double inside_lens = a.lens_length * 0.1;
+  const bool po = a.P.cameraType == LENTIL_POLYNOMIAL_OPTICS;
+
+  nskip[lane] = 0u;
+  auto issue_ring = [&](uint64_t v_group, uint32_t slot) {
+    float4 *s = ring + (size_t)slot * 192u;
+    dma2_col(V.pos_z + v_group, lane16, s);
+    dma2_col(V.volume_ignore + v_group, lane16, s + 64);
+    dma2_col(V.transmission + v_group, lane16, s + 128);
+  };
+
+  // ---- one tile.  Its rgba column has been requested into rg[buf], its first two ring groups into slots par, par ^ 1.
+  // has_next: the tile that follows is `next_tile` -- its rgba goes to rg[buf ^ 1], its first ring groups behind this
+  // tile's last.
+  auto do_tile = [&](uint64_t tile, bool has_next, uint64_t next_tile, uint32_t buf, uint32_t par) {
+    const uint64_t v0 = tile * TV;
+    const uint64_t nv0 = next_tile * TV;
+    float4 *srgba = rg + (size_t)buf * M * 64u;
+    float4 *nrgba = rg + (size_t)(buf ^ 1u) * M * 64u;
+    bool tile_any = false;
+    for (uint32_t g = 0; g < M; ++g) {
+      if (has_next) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+      else if (g + 1u < M) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const uint32_t slot = (par + g) & 1u;
+      float4 pz, vi, tr;
+      lds_read_slot(ring + (size_t)slot * 192u + lane, pz, vi, tr);
+      // the slot's values are in registers: refill it, and ask for the next tile's rgba group
+      if (g + 2u < M) issue_ring(v0 + (uint64_t)(g + 2u) * 64u, slot);
+      else if (has_next) issue_ring(nv0 + (uint64_t)(g + 2u - M) * 64u, slot);
+      if (has_next) dma2_col(V.rgba + nv0 + (uint64_t)g * 64u, lane16, nrgba + (size_t)g * 64u);
+      // ---- the decision (visit_redistributes, src/lentil_filter.cpp:105-165,240)
+      const float wx = pz.x, wy = pz.y, wz = pz.z, depth = pz.w;
+      const bool small = fabsf(wx) < kAiEpsilon && fabsf(wy) < kAiEpsilon && fabsf(wz) < kAiEpsilon;
+      const bool far = (depth == kAiInfinite) || small;
+      const float cz = (wx * mz0 + wy * mz1 + wz * mz2 + mz3) * scale;
+      const int below = coc_below_by_bands(a.bands, cz);
+      bool flagged;
+      if (__ballot((far && a.P.enable_skydome) || below == 2) == 0ull) {
+        bool r = !never && !far;
+        if (fmaxf(fmaxf(vi.x, vi.y), vi.z) > 0.0f) r = false;
+        if (!a.P.enable_bidir_transmission && fmaxf(fmaxf(tr.x, tr.y), tr.z) > 0.0f) r = false;
+        if (vi.w > 0.0f) r = false;
+        if (below == 1) r = false;
+        if (po && (double)fabsf(cz) < inside_lens) r = false;
+        flagged = r;
+      } else {
+        const uint64_t v = v0 + (uint64_t)g * 64u + lane;
+        flagged = visit_redistributes(a.P, a.lens_length, pz, vi, tr, a.P.inverse_sample_density,
+                                      [&]() { return V.raydir_time[v]; }, V.cam);
+      }
+      if (__ballot(flagged)) {
+        // a few visits in 10^5: the draw count (same function as the draw kernels use); the visit adds nothing to its
+        // own pixel: +0 values (x + (+0) changes no bit, an accumulator is never -0), one weight fewer
+        tile_any = true;
+        const uint32_t e = g * 64u + lane;
+        const uint64_t v = v0 + e;
+        int samples = 0;
+        if (flagged) {
+          samples = visit_prologue(a.P, a.lens_length, lds_read_f4(srgba + e), pz, V.raydir_time[v], vi, tr, a.P.inverse_sample_density, V.cam).samples;
+          srgba[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+          atomicAdd(&nskip[e / M], 1u);
+        }
+        wq.push(flagged, (uint32_t)v, (uint32_t)samples, a);
+      }
+    }
+    // ---- the ordered sums of the tile's 64 pixels (filter_and_add_to_buffer_new, src/lentil.h:938-955)
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    v2f s01 = {0.f, 0.f}, s23 = {0.f, 0.f};
+    const v2f w2 = {w, w};
+    const float4 *mine = srgba + (size_t)lane * M;
+    uint32_t j = 0;
+    for (; j + 3u <= M; j += 3u) {
+      float4 c0, c1, c2;
+      lds_read_3f4(mine + j, c0, c1, c2);
+      v2f p;
+      p = (v2f){c0.x, c0.y} * w2; s01 += p; p = (v2f){c0.z, c0.w} * w2; s23 += p;
+      p = (v2f){c1.x, c1.y} * w2; s01 += p; p = (v2f){c1.z, c1.w} * w2; s23 += p;
+      p = (v2f){c2.x, c2.y} * w2; s01 += p; p = (v2f){c2.z, c2.w} * w2; s23 += p;
+    }
+    for (; j < M; ++j) {
+      const float4 c0 = lds_read_f4(mine + j);
+      v2f p;
+      p = (v2f){c0.x, c0.y} * w2; s01 += p; p = (v2f){c0.z, c0.w} * w2; s23 += p;
+    }
+    float ws = ws_full;
+    if (tile_any) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
+      // (the zeros the flagged visits left in the rgba tile were stored ahead of the sums' reads: LDS runs in order)
+      const uint32_t skipped = nskip[lane];
+      nskip[lane] = 0u;
+      ws = 0.f;
+      for (uint32_t q = 0; q < M - skipped; ++q) ws += w;
+    }
+    {
+      const uint32_t pix = (uint32_t)(tile * 64u) + lane;        // (the host checks that the stream has fewer than 2^32 pixels)
+      const uint32_t row = __umulhi(pix, a.ppr_magic) >> a.ppr_shift;     // pix / pixels_per_row
+      const uint32_t col = pix - row * V.pixels_per_row;
+      const int px = V.pixel_x0 + (int)col;
+      const int py = V.pixel_y0 + (int)row * (int)V.pixel_row_stride;
+      const uint64_t lin = (uint64_t)px + (uint64_t)py * xres;
+      dir4[lin * 2u] = make_float4(s01.x, s01.y, s23.x, s23.y);
+      dir4[lin * 2u + 1u] = make_float4(ws, 0.f, 0.f, 0.f);
+    }
+    if (tile_any) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+      __builtin_amdgcn_wave_barrier();
+      wq.end_tile(a);
+    }
+  };
+
+  // ---- a wave's tiles: runs of four, first its share of a static interleaved split, then what tile_next hands out
+  const uint64_t n_full = full_end > a.tile_begin ? full_end - a.tile_begin : 0ull;
+  const uint32_t n_runs = (uint32_t)((n_full + 3u) / 4u);
+  const uint32_t W = gridDim.x * 4u, gw = blockIdx.x * 4u + wave;
+  const uint32_t n_static = (uint32_t)(((uint64_t)n_runs * 7u / 8u) / W);       // runs per wave of the static part
+  // (ScanArgs::outside_in: the runs alternate between the two ends of the range and meet in the middle, scan_order)
+  auto run_first = [&](uint32_t r) { return a.tile_begin + (uint64_t)(a.outside_in ? ((r & 1u) ? n_runs - 1u - (r >> 1) : (r >> 1)) : r) * 4u; };
+  auto run_len = [&](uint64_t first) { return (uint32_t)(full_end - first < 4u ? full_end - first : 4u); };
+  uint32_t k = 0;
+  uint32_t buf = 0, par = 0;
+  while (true) {
+    // the next sequence of tiles: all static runs of this wave in one go, then one dynamic run at a time
+    uint32_t r;
+    bool is_static = k < n_static;
+    if (is_static) {
+      r = k * W + gw;
+    } else {
+      uint32_t t = 0;
+      if (lane == 0) t = atomicAdd(&a.ctr->tile_next, 1u);
+      r = W * n_static + (uint32_t)__builtin_amdgcn_readfirstlane(t);
+      if (r >= n_runs) break;
+    }
+    uint64_t tile = run_first(r);
+    uint32_t left = run_len(tile);
+    // prologue: this tile's rgba and first two ring groups, and everything landed
+    {
+      const uint64_t v0 = tile * TV;
+      for (uint32_t g = 0; g < M; ++g) dma2_col(V.rgba + v0 + (uint64_t)g * 64u, lane16, rg + (size_t)buf * M * 64u + (size_t)g * 64u);
+      issue_ring(v0, par);
+      if (M > 1u) issue_ring(v0 + 64u, par ^ 1u);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    while (true) {
+      // which tile follows?
+      bool has_next = false;
+      uint64_t next_tile = tile;
+      uint32_t next_left = 0;
+      if (left > 1u) { has_next = true; next_tile = tile + 1u; next_left = left - 1u; }
+      else if (is_static && k + 1u < n_static) {
+        has_next = true;
+        next_tile = run_first((k + 1u) * W + gw);
+        next_left = run_len(next_tile);
+      }
+      do_tile(tile, has_next, next_tile, buf, par);
+      if (lane == 0) tl_add(TL_SCAN_TILES, 1u);
+      buf ^= 1u;
+      par = (par + M) & 1u;
+      if (left == 1u && is_static) ++k;
+      if (!has_next) break;
+      tile = next_tile; left = next_left;
+    }
+  }
+  // the stream's last, partial tile (fewer than 64 pixels): one wave, straight from global memory
+  if (a.tile_end > full_end && blockIdx.x == 0 && wave == 0) {
+    const uint64_t tile = full_end;
+    const uint64_t n_pixels = V.n / M;
+    const uint64_t pix = tile * 64u + lane;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    float ws = 0.f;
+    for (uint32_t j = 0; j < M; ++j) {
+      const uint64_t v = pix * M + j;
+      const bool valid = pix < n_pixels;
+      bool flagged = false;
+      int samples = 0;
+      float4 c = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (valid) {
+        const float4 pz = V.pos_z[v], vi = V.volume_ignore[v], tr = V.transmission[v];
+        c = V.rgba[v];
+        flagged = visit_redistributes(a.P, a.lens_length, pz, vi, tr, a.P.inverse_sample_density, [&]() { return V.raydir_time[v]; }, V.cam);
+        if (flagged) samples = visit_prologue(a.P, a.lens_length, c, pz, V.raydir_time[v], vi, tr, a.P.inverse_sample_density, V.cam).samples;
+      }
+      if (valid && !flagged) { s.x += c.x * w; s.y += c.y * w; s.z += c.z * w; s.w += c.w * w; ws += w; }
+      wq.push(flagged, (uint32_t)v, (uint32_t)samples, a);
+    }
+    if (pix < n_pixels) {
+      const int px = V.pixel_x0 + (int)(pix % V.pixels_per_row);
+      const int py = V.pixel_y0 + (int)(pix / V.pixels_per_row) * (int)V.pixel_row_stride;
+      const uint64_t lin = (uint64_t)px + (uint64_t)py * xres;
+      dir4[lin * 2u] = s;
+      dir4[lin * 2u + 1u] = make_float4(ws, 0.f, 0.f, 0.f);
+    }
+    wq.end_tile(a);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  wq.finish(a);
+  scan_block_done(a);
+}
+
+// ---------------------------------------------------------------------------------------
 // K1+K2+K6 for frames with extra (gaussian) AOVs and a uniform footprint -- the LDS-DMA form of
 // scan_uniform_multi_kernel, as scan_dma_kernel is of scan_uniform_kernel: 80 + 16 K bytes per visit go from HBM
 // straight into LDS, the ordered sums are stored to FrameDev::dir whole (no record is read), and the kernel stays
@@ -918,6 +1239,7 @@ constexpr uint32_t kDmaMultiCol = 65;
 __host__ __device__ constexpr uint32_t dma_multi_wave_f4(uint32_t n_extra, uint32_t ring) { return ring * (4u + n_extra) * kDmaMultiCol; }
 
 __global__ __launch_bounds__(256) void scan_dma_multi_kernel(ScanArgs a) {
+  LENTIL_TL_SPAN(SPAN_SCAN);
   extern __shared__ float4 smem[];
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
   const VisitsDev &V = a.V;
@@ -1435,6 +1757,7 @@ struct PublishArgs {
 };
 
 __global__ __launch_bounds__(64) void publish_kernel(PublishArgs a) {
+  LENTIL_TL_SPAN(SPAN_PUBLISH);
   const uint32_t lane = threadIdx.x;
   while (true) {
     uint32_t t = 0;
@@ -1664,6 +1987,7 @@ LD_DEV void reset_round(DevCounters *c, uint32_t par) {
 // keep_pool: items of the accept that follows still read results out of this parity's pool (ItemProg::p_lo) while that
 // accept allocates the next batch's results in it: go on behind them
 __global__ void reset_round_kernel(DevCounters *c, uint32_t par, uint32_t keep_pool) {
+  LENTIL_TL_SPAN(SPAN_RESET);
   const unsigned long long used = c->pool_used[par];
   reset_round(c, par);
   if (keep_pool) c->pool_used[par] = used;
@@ -1739,6 +2063,7 @@ LD_DEV uint32_t solve_result(const lentil_params &P, const LensT &L, const Newto
 #endif
 template <class LensT, bool kTables, bool kChroma = false, bool kStream = false>
 __global__ __launch_bounds__(256) LENTIL_SOLVE_ATTR void solve_po_kernel(DrawArgs a) {
+  LENTIL_TL_SPAN(a.round == 0 ? SPAN_SOLVE_R0 : (a.round == 1 ? SPAN_SOLVE_R1 : SPAN_SOLVE_R2));
   __shared__ DevTerm s_terms[kTables ? kMaxTerms : 1];
   __shared__ DevLens s_k;
   __shared__ DevLens s_kc[kChroma ? 3 : 1];
@@ -2175,6 +2500,7 @@ struct CoopLens {
 #define LENTIL_SLOW_ATTR
 #endif
 __global__ __launch_bounds__(64) LENTIL_SLOW_ATTR void solve_slow_kernel(DrawArgs a) {
+  LENTIL_TL_SPAN(a.round == 0 ? SPAN_SLOW_R0 : (a.round == 1 ? SPAN_SLOW_R1 : SPAN_SLOW_R2));
   __shared__ CoopShared sh;
   __shared__ uint32_t s_q;
   const uint32_t par = (uint32_t)a.parity, sq = slow_queue(a);
@@ -2831,6 +3157,7 @@ LD_DEV AcceptResult accept_item_chroma(const DrawArgs &a, AcceptShared &sh, uint
 // kMode: accept_item's -- 1 for the first accept of a decoupled streamed pass, 2 for the one behind it, 0 otherwise.
 template <int kMode>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) void accept_kernel(DrawArgs a) {
+  LENTIL_TL_SPAN(kMode == 0 ? SPAN_ACCEPT0 : (kMode == 1 ? SPAN_ACCEPT1 : SPAN_ACCEPT2));
   __shared__ uint32_t s_item;
   __shared__ AcceptShared sh;
   const uint32_t par = (uint32_t)a.parity, nxt = par ^ 1u;
@@ -3321,6 +3648,7 @@ __global__ __launch_bounds__(256) void merge_keys_kernel(unsigned long long *min
 
 // clear_frame while FrameDev::touched is trusted: wipe the groups of 64 records that received splats, nothing else
 __global__ __launch_bounds__(256) void clear_touched_kernel(FrameDev F, uint64_t n_groups) {
+  LENTIL_TL_SPAN(SPAN_CLEAR);
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t q = F.stride >> 2;
   float4 *acc4 = reinterpret_cast<float4 *>(F.acc);
@@ -3408,6 +3736,7 @@ LD_DEV void resolve_group(const FrameDev &F, float *resolved, float4 *tile, uint
 // writes one planar RGBA image per AOV (what the imager copies into Arnold's buckets).  A wave takes 64 consecutive
 // pixels at a time.
 __global__ __launch_bounds__(256) void resolve_kernel(FrameDev F, float *resolved, uint64_t p_begin, uint64_t p_end) {
+  LENTIL_TL_SPAN(SPAN_RESOLVE);
   extern __shared__ float4 s_rec[];                       // [waves per block][64 * stride / 4]
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
   float4 *tile = s_rec + (size_t)wave * 64u * (F.stride >> 2);
@@ -3425,6 +3754,7 @@ __global__ __launch_bounds__(256) void resolve_kernel(FrameDev F, float *resolve
 // the headline frame's first round touches most groups, its second a few hundred).  A wave looks at 64 groups'
 // flags with one load and walks the set bits.
 __global__ __launch_bounds__(256) void resolve_touched_kernel(FrameDev F, float *resolved) {
+  LENTIL_TL_SPAN(SPAN_RESOLVE_TOUCHED);
   extern __shared__ float4 s_rec[];
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
   float4 *tile = s_rec + (size_t)wave * 64u * (F.stride >> 2);

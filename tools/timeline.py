@@ -80,10 +80,11 @@ def main():
                 raise
         dt = time.perf_counter() - t0
     c = ctx.counters()
-    raw = np.zeros(64 * 10 * 1024 + 64, np.uint32)
+    raw = np.zeros(64 * 10 * 1024 + 64 + 128, np.uint32)
     lib.lentil_hip_debug_timeline(raw.ctypes.data, 0)
     h = raw[:64 * 10 * 1024].reshape(64, 10, 1024).sum(axis=0)
-    dbg = raw[64 * 10 * 1024:].view(np.uint64)
+    dbg = raw[64 * 10 * 1024:64 * 10 * 1024 + 64].view(np.uint64)
+    span = raw[64 * 10 * 1024 + 64:].view(np.uint64).reshape(32, 2)
     tot = h.sum(axis=0)
     used = np.nonzero(tot)[0]
     lines = ["last pass: %.3f ms host time, streamed %d, timing ms %s" % (dt * 1e3, c.streamed, ctx.last_timing())]
@@ -100,6 +101,15 @@ def main():
             pub += int(h[1, b]); taken += int(h[8, b])
             lines.append("%7.0f " % (k * 20.48) + " ".join("%9d" % int(h[ch, b]) for ch in range(10)) + "   %d" % (pub - taken))
         lines.append("totals  " + " ".join("%9d" % int(h[ch].sum()) for ch in range(10)))
+    SPANS = ["scan", "publish", "solve r0 (A)", "solve r1", "solve r2+", "slow r0", "slow r1", "slow r2+", "accept<0>", "accept<1>",
+             "accept<2>", "resolve", "resolve_touched", "clear_touched", "reset_round", "prep"]
+    live = [(int(span[i, 0]), int(span[i, 1]), SPANS[i]) for i in range(len(SPANS)) if span[i, 1] > 0]
+    if live:
+        t0 = min(s for s, e, n in live)
+        lines.append("kernel spans (us from the first kernel's first block; first block in .. last block out):")
+        for s_, e_, n in sorted(live):
+            lines.append("  %-16s %8.1f .. %8.1f  (%7.1f)" % (n, (s_ - t0) / 100.0, (e_ - t0) / 100.0, (e_ - s_) / 100.0))
+        lines.append("  host: redistribute+resolve returned after %.1f us" % (dt * 1e6))
     lines.append("dbg: stragglers pixel/out/fail %d/%d/%d, ended <100 / at 100 iterations %d/%d" % tuple(int(x) for x in dbg[:5]))
     lines.append("dbg: first accept, items by unknown attempts 0 / 1-4 / 5-16 / 17-64 / 65-256 / >256: %s; unknown attempts %d; items with unknowns scheduling more %d"
                  % ([int(x) for x in dbg[8:14]], int(dbg[14]), int(dbg[15])))
