@@ -1225,6 +1225,10 @@ static void init_draw_args(lentil_hip_ctx *ctx, DrawArgs &da) {
   da.slow_at = ctx->slow_at;
   da.batch_margin16 = ctx->batch_margin16;
   da.margin_low_rate = ctx->margin_low_rate;
+  {
+    static const bool narrow = getenv("LENTIL_ACCEPT_WIDE") && getenv("LENTIL_ACCEPT_WIDE")[0] == '0';
+    da.accept_narrow = narrow ? 1 : 0;
+  }
   if (ctx->slow_at > 0 && ctx->mean_iters > 0.0) {
     const int adaptive = (int)(1.3 * ctx->mean_iters + 0.5);
     if (adaptive > da.slow_at) da.slow_at = adaptive < 90 ? adaptive : 90;
@@ -1541,7 +1545,7 @@ static int launch_scan(lentil_hip_ctx *ctx, const ScanPlan &pl, const lentil_hip
     blocks = (ch.v_end - ch.v_begin + 255) / 256;
     if (blocks > max_blocks) blocks = max_blocks;
     // runs of a pixel's visits are summed in their order (LENTIL_SCAN_RUNS=0: an atomic per visit and float, any order)
-    static const bool runs = !(getenv("LENTIL_SCAN_RUNS") && getenv("LENTIL_SCAN_RUNS")[0] == '0');
+    const bool runs = !(getenv("LENTIL_SCAN_RUNS") && getenv("LENTIL_SCAN_RUNS")[0] == '0');       // (read per launch: the tests switch it)
     if (runs) hipLaunchKernelGGL(scan_runs_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, sa);
     else hipLaunchKernelGGL(scan_ragged_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, sa);
   }
@@ -2326,6 +2330,13 @@ LENTIL_API int lentil_hip_redistribute(lentil_hip_ctx *ctx) {
     if (dropped)
       return fail(ctx, LENTIL_ERR_NOMEM, "the device dropped " + std::to_string(dropped) +
                                              " work items (work list, task queue or result pool too small): the frame is incomplete");
+    // closest-filtered AOVs: a candidate at |Z| == 0 or NaN makes the reference's result depend on the order of the candidates
+    // at that pixel (src/lentil.h:832-837, closest_key_of in lentil_kernels.h) -- refused, not approximated
+    unsigned int degenerate = 0;
+    for (const DevCounters &k : ctx->h_ctr) degenerate |= k.degenerate_depth;
+    if (degenerate && (ctx->F.zkey || ctx->F.zkey_dbg))
+      return fail(ctx, LENTIL_ERR_UNSUPPORTED, "a sample with depth (Z) 0 or NaN competes for a closest-filtered AOV: the reference's result there "
+                                               "depends on the order of the samples at the pixel (src/lentil.h:832-837); the pass is refused");
   }
   return crypto_after_pass(ctx);
 }

@@ -48,6 +48,8 @@ struct DevCounters {
   unsigned int scan_blocks_done, publishers_done;
   unsigned int n_ranges, range_head;   // work-list ranges the scan has handed to publish_kernel / tickets drawn on them
   unsigned int stuck, tile_next;       // a wave gave up waiting for its queue slot (kStuckTicks): the pass is void; scan_dma_kernel's tile cursor
+  // a candidate for a closest-filtered AOV came with |Z| == 0 or NaN (closest_key_of): the pass is refused, see there
+  unsigned int degenerate_depth, pad_;
 };
 
 // per-thread running row range -> one pair of atomics per wave
@@ -130,6 +132,17 @@ struct FrameDev {
 
 LD_DEV unsigned long long closest_key(float depth, uint32_t visit) {
   return ((unsigned long long)__float_as_uint(fabsf(depth)) << 32) | (unsigned long long)(0xFFFFFFFFu - visit);
+}
+// The key of a candidate (a pixel's own visit in a scan kernel, an item in an accept kernel).  The reference's z-buffer
+// (src/lentil.h:832-837: `abs(depth) <= zbuffer || zbuffer == 0`) uses 0 as "empty": in its sequential order a candidate at
+// |Z| == 0 wins and at once re-opens the pixel for whatever comes next, and a NaN written into an empty pixel is never
+// replaced -- outcomes that depend on the order of the candidates at a pixel, which a reduction over keys cannot give.  Such
+// a candidate is therefore flagged, and lentil_hip_redistribute refuses the pass (LENTIL_ERR_UNSUPPORTED) instead of
+// returning a frame that differs from the reference's: never a silently different image.  (A renderer's Z is neither for
+// anything in front of the camera; samples that hit nothing carry AI_INFINITE, which the keys order like the reference.)
+LD_DEV unsigned long long closest_key_of(DevCounters *ctr, float depth, uint32_t visit) {
+  if (!(fabsf(depth) > 0.0f)) ctr->degenerate_depth = 1u;
+  return closest_key(depth, visit);
 }
 
 struct ItemHdr {          // written by prep_items_kernel / publish_item; a 128-byte line of its own (streamed pass: never
@@ -316,6 +329,16 @@ enum { SPAN_SCAN = 0, SPAN_PUBLISH, SPAN_SOLVE_R0, SPAN_SOLVE_R1, SPAN_SOLVE_R2,
        SPAN_ACCEPT0, SPAN_ACCEPT1, SPAN_ACCEPT2, SPAN_RESOLVE, SPAN_RESOLVE_TOUCHED, SPAN_CLEAR, SPAN_RESET, SPAN_PREP };
 enum { TL_SCAN_TILES = 0, TL_TASKS_PUBLISHED, TL_ITERS_A, TL_ITERS_B, TL_ITERS_LATER, TL_ITERS_SLOW, TL_ITEMS_ACCEPTED,
        TL_POLLS_EMPTY, TL_TASKS_TAKEN, TL_PARKED };
+
+// lentil_debug (src/lentil_filter.cpp:209-212): the AOV's value, samples * redistribute, is taken BEFORE the "sample can't be
+// inside of lens" test clears redistribute (:240).  A visit that fails only that test therefore reaches the direct path
+// (src/lentil.h:938-955) with a non-zero value and competes for lentil_debug's own z-buffer (src/lentil.h:838-845) at its own
+// pixel, exactly like an accepted draw does.  True for such a visit: the decision with the lens test left out (lens length 0).
+template <class RaydirLoad>
+LD_DEV bool visit_feeds_debug_directly(const lentil_params &P, float4 pos_z, float4 volume_ignore, float4 transmission,
+                                       float inv_density, RaydirLoad load_raydir, const CamMotion &cm) {
+  return visit_redistributes(P, 0.0, pos_z, volume_ignore, transmission, inv_density, load_raydir, cm);
+}
 
 struct ItemVisit {
   uint32_t visit, samples;
@@ -635,11 +658,26 @@ __global__ __launch_bounds__(256) void scan_uniform_kernel(ScanArgs a) {
         for (uint32_t j = 0; j < M; ++j) {
           if (sw[lane * M + j] != 0.0f) {
             const uint64_t vv = v0 + (uint64_t)lane * M + j;
-            const unsigned long long key = closest_key(V.pos_z[vv].w, visit_gid(V, (uint32_t)vv));
+            const unsigned long long key = closest_key_of(a.ctr, V.pos_z[vv].w, visit_gid(V, (uint32_t)vv));
             if (key < kmin) kmin = key;
           }
         }
         if (kmin != ~0ull) atomicMin(a.F.zkey + lin, kmin);
+      }
+      if (a.F.zkey_dbg) {
+        // lentil_debug: own visits that failed nothing but the inside-the-lens test (visit_feeds_debug_directly)
+        unsigned long long kmin = ~0ull;
+        for (uint32_t j = 0; j < M; ++j) {
+          if (sw[lane * M + j] != 0.0f) {
+            const uint64_t vv = v0 + (uint64_t)lane * M + j;
+            const float invd = V.inv_density ? V.inv_density[vv] : a.P.inverse_sample_density;
+            if (visit_feeds_debug_directly(a.P, V.pos_z[vv], V.volume_ignore[vv], V.transmission[vv], invd, [&]() { return V.raydir_time[vv]; }, V.cam)) {
+              const unsigned long long key = closest_key_of(a.ctr, V.pos_z[vv].w, visit_gid(V, (uint32_t)vv));
+              if (key < kmin) kmin = key;
+            }
+          }
+        }
+        if (kmin != ~0ull) atomicMin(a.F.zkey_dbg + lin, kmin);
       }
     }
     // extra AOVs: same weights, one column at a time through the same staging area
@@ -1451,6 +1489,7 @@ __global__ __launch_bounds__(256) void scan_uniform_multi_kernel(ScanArgs a) {
     int samples = 0;
     float w = 0.f;
     float depth = 0.f;
+    bool feeds_dbg = false;       // lentil_debug: a visit that failed only the inside-the-lens test (visit_feeds_debug_directly)
     float4 val[LENTIL_MAX_AOVS];
     // the tile's pixel records (ppt * q float4; the first two per lane -- all of them at 9 visits per pixel and
     // 9 AOVs): requested together with the visit columns, used at the end of the step
@@ -1487,6 +1526,7 @@ __global__ __launch_bounds__(256) void scan_uniform_multi_kernel(ScanArgs a) {
       } else {
         w = 1.0f * invd;                                // filter_weight * inv_density, lentil.h:949-953
         val[0] = rgba;
+        if (a.F.zkey_dbg) feeds_dbg = visit_feeds_debug_directly(a.P, pz, vi, tr, invd, [&]() { return V.raydir_time[v]; }, V.cam);
       }
     }
     wq.push(flagged, (uint32_t)v, (uint32_t)samples, a);
@@ -1506,7 +1546,13 @@ __global__ __launch_bounds__(256) void scan_uniform_multi_kernel(ScanArgs a) {
       const uint64_t pp = pix0 + lane / M;
       const int px = V.pixel_x0 + (int)(pp % V.pixels_per_row);
       const int py = V.pixel_y0 + (int)(pp / V.pixels_per_row) * (int)V.pixel_row_stride;
-      atomicMin(a.F.zkey + ((uint64_t)px + (uint64_t)py * xres), closest_key(depth, visit_gid(V, (uint32_t)v)));
+      atomicMin(a.F.zkey + ((uint64_t)px + (uint64_t)py * xres), closest_key_of(a.ctr, depth, visit_gid(V, (uint32_t)v)));
+    }
+    if (a.F.zkey_dbg && valid && w != 0.0f && feeds_dbg) {
+      const uint64_t pp = pix0 + lane / M;
+      const int px = V.pixel_x0 + (int)(pp % V.pixels_per_row);
+      const int py = V.pixel_y0 + (int)(pp / V.pixels_per_row) * (int)V.pixel_row_stride;
+      atomicMin(a.F.zkey_dbg + ((uint64_t)px + (uint64_t)py * xres), closest_key_of(a.ctr, depth, visit_gid(V, (uint32_t)v)));
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
     __builtin_amdgcn_wave_barrier();
@@ -1597,7 +1643,9 @@ __global__ __launch_bounds__(256) void scan_ragged_kernel(ScanArgs a) {
         atomicAdd(d + 2, (rgba.z + 0.0f) * w);
         atomicAdd(d + 3, (rgba.w + 0.0f) * w);
         atomicAdd(a.F.wt(lin), w);
-        if (a.F.zkey) atomicMin(a.F.zkey + lin, closest_key(V.pos_z[v].w, visit_gid(V, (uint32_t)v)));
+        if (a.F.zkey) atomicMin(a.F.zkey + lin, closest_key_of(a.ctr, V.pos_z[v].w, visit_gid(V, (uint32_t)v)));
+        if (a.F.zkey_dbg && visit_feeds_debug_directly(a.P, pz, vi, tr, invd, [&]() { return V.raydir_time[v]; }, V.cam))
+          atomicMin(a.F.zkey_dbg + lin, closest_key_of(a.ctr, pz.w, visit_gid(V, (uint32_t)v)));
         for (uint32_t k = 0; k < V.n_extra; ++k) {
           if (a.F.closest_mask & (2u << k)) continue;
           const float4 c = V.extra[k][v];
@@ -1673,7 +1721,11 @@ __global__ __launch_bounds__(256) void scan_runs_kernel(ScanArgs a) {
         val = make_float4((rgba.x + 0.0f) * w, (rgba.y + 0.0f) * w, (rgba.z + 0.0f) * w, (rgba.w + 0.0f) * w);
         if (a.F.zkey) {
           const uint32_t px = pix & 0xFFFFu, py = pix >> 16;
-          atomicMin(a.F.zkey + ((uint64_t)px + (uint64_t)py * a.P.xres), closest_key(pz.w, visit_gid(V, (uint32_t)v)));
+          atomicMin(a.F.zkey + ((uint64_t)px + (uint64_t)py * a.P.xres), closest_key_of(a.ctr, pz.w, visit_gid(V, (uint32_t)v)));
+        }
+        if (a.F.zkey_dbg && visit_feeds_debug_directly(a.P, pz, vi, tr, invd, [&]() { return V.raydir_time[v]; }, V.cam)) {
+          const uint32_t px = pix & 0xFFFFu, py = pix >> 16;
+          atomicMin(a.F.zkey_dbg + ((uint64_t)px + (uint64_t)py * a.P.xres), closest_key_of(a.ctr, pz.w, visit_gid(V, (uint32_t)v)));
         }
       }
     }
@@ -1926,6 +1978,7 @@ struct DrawArgs {
   int32_t slow_after_producers;   // first round of a streamed pass: park only once the scan and its publishers have ended
   int32_t slow_dry_only;      // live queue: park as a plain round does (waves running dry, their last slow_max_lanes lanes)
   int32_t slow_crowd_stays;   // live queue: where more than slow_max_lanes lanes of a wave are past slow_at at once, none is parked
+  int32_t accept_narrow;      // accept kernels: 256-attempt steps (accept_item) where accept_item_wide would apply
 };
 LD_DEV uint32_t slow_queue(const DrawArgs &a) { return a.slow_q >= 0 ? (uint32_t)a.slow_q : (uint32_t)a.parity; }
 LD_DEV uint64_t slow_tag(const DrawArgs &a, uint64_t what) {
@@ -2721,6 +2774,21 @@ LD_DEV void count_same_pixel(const uint32_t *pix, uint32_t *cnt, uint32_t T, uin
   }
 }
 
+// The same from registers (accept_item_wide): lane d < T holds entry d of the wave's compacted pixel list; every entry is
+// broadcast with v_readlane -- three instructions per entry and no LDS round trip in the loop (the LDS version above waits
+// ~70 cycles per entry: 2 us per 64-draw slab).  Returns the count at the first lane of every pixel, 0 at the others.
+LD_DEV uint32_t count_same_pixel_reg(uint32_t mine, uint32_t T, uint32_t lane) {
+  uint32_t n = 0;
+  bool first = true;
+  for (uint32_t e = 0; e < T; ++e) {
+    const uint32_t p = (uint32_t)__builtin_amdgcn_readlane((int)mine, (int)e);
+    const bool same = p == mine;
+    n += same ? 1u : 0u;
+    first = first && !(same && e < lane);
+  }
+  return (lane < T && first) ? n : 0u;
+}
+
 // R(m) as the accept of an item finds it: the current batch in `res`, the batch before -- if the item carries one
 // (ItemProg::p_lo) -- in the other parity's pool, FAIL below that, "beyond" above.
 LD_DEV uint32_t result_at2(const uint32_t *res, const uint32_t *res_prev, const ItemProg &pg, uint32_t m) {
@@ -2728,6 +2796,44 @@ LD_DEV uint32_t result_at2(const uint32_t *res, const uint32_t *res_prev, const 
   if (m >= pg.m_lo) return res[pg.res_off + (m - pg.m_lo)];
   if (m >= pg.p_lo && m < pg.p_hi) return res_prev[pg.p_off + (m - pg.p_lo)];
   return kCodeFail;
+}
+
+// What an item's walk leaves for the next round: whether draws are still missing and attempts exist, and which R(m) the
+// next batch must cover (shared by accept_item and accept_item_wide).
+template <int kMode>
+LD_DEV void accept_next_batch(const DrawArgs &a, const ItemProg &pg, AcceptResult &r, uint32_t n, uint32_t acc, uint32_t uacc,
+                              uint32_t S, uint32_t max_total, uint32_t m_limit, uint32_t retries) {
+  if (kMode == 1 && uacc && a.unknown_credit) {
+    // What the next batch is sized from.  Counting every unknown attempt as a failure is safe and costly: unknowns come
+    // in clusters -- in a headline frame ten items near the frame's edge, where the lens vignettes, hold all of them,
+    // ~500 each (their solves run 20-40 iterations, are parked, and 83 % of them fail -- after which the attempt simply
+    // moves on to its next try and mostly succeeds) -- and the batches that pessimism sends those items are as slow as
+    // their first ones: thousands of parked solves for 256 straggler waves.  So the unknown attempts are credited with
+    // unknown_credit / 8 of the success rate of the item's known ones.  Where that is too generous by a few attempts
+    // the first batch's spare ones (DrawArgs::extra_const) make up for it; beyond that the item costs a third round.
+    const uint32_t known = n > uacc ? n - uacc : 1u;
+    const unsigned long long est = (unsigned long long)acc + ((unsigned long long)uacc * acc * a.unknown_credit) / (8ull * known);
+    acc = est < S ? (uint32_t)est : S;
+  }
+  r.more = acc < S && n < max_total && pg.m_hi < m_limit && pg.m_hi > 0;
+  r.new_lo = pg.m_hi;
+  r.new_hi = pg.m_hi;
+  if (r.more) {
+    // draws are still missing: schedule the next batch, sized from the item's own success rate so far
+    // (+25 % + 32; a surplus is simply never accepted, a shortfall costs another round)
+    const uint32_t remaining = S - acc;
+    unsigned long long need = acc ? ((unsigned long long)remaining * n + acc - 1) / acc : (unsigned long long)(max_total - n);
+    // (twice the margin where fewer than margin_low_rate / 16 of the item's attempts got through so far: with the petzval
+    // table, where a third of all attempts is vignetted, +25 % left some item short in every pass -- a third round, 0.4 ms
+    // of latency for a few thousand lane-iterations; config 4 8.65-8.8 against 9.2 ms, the other configurations unchanged)
+    const uint32_t m16 = (unsigned long long)acc * 16ull < (unsigned long long)n * a.margin_low_rate ? 2u * a.batch_margin16 : a.batch_margin16;
+    need += (need * m16) / 16 + 32;
+    unsigned long long n_target = (unsigned long long)n + need;
+    if (n_target > max_total) n_target = max_total;
+    uint32_t new_hi = (uint32_t)n_target + retries;
+    if (new_hi > m_limit) new_hi = m_limit;
+    r.new_hi = new_hi;
+  }
 }
 
 // Processes the current result batch of `item` (block-cooperative; must be called by all 256 threads).
@@ -2760,7 +2866,7 @@ LD_DEV AcceptResult accept_item(const DrawArgs &a, AcceptShared &sh, uint32_t it
     const ItemVisit h = load_item_visit(a, item, lens_length);
     const uint32_t S = h.samples, max_total = S * 5u, m_limit = max_total + retries;
     const float ae = h.I.add_energy, w = h.w;
-    const unsigned long long zk = (a.F.zkey || a.F.zkey_dbg) ? closest_key(h.I.depth, visit_gid(a.V, h.visit)) : 0ull;
+    const unsigned long long zk = (a.F.zkey || a.F.zkey_dbg) ? closest_key_of(a.ctr, h.I.depth, visit_gid(a.V, h.visit)) : 0ull;
     // per-item add table: gaussian AOVs' (value + add_energy) * w, then the weight itself
     uint32_t U = 1;
     for (uint32_t k = 0; k < a.F.n_aovs; ++k) if (!(a.F.closest_mask & (1u << k))) U += 4;
@@ -2930,38 +3036,313 @@ LD_DEV AcceptResult accept_item(const DrawArgs &a, AcceptShared &sh, uint32_t it
     r.prog = pg;
     r.prog.n_done = n; r.prog.accepted = acc; r.prog.last_ok = last_ok;
     r.prog.uacc = kMode == 1 ? uacc : 0u;
-    if (kMode == 1 && uacc && a.unknown_credit) {
-      // What the next batch is sized from.  Counting every unknown attempt as a failure is safe and costly: unknowns come
-      // in clusters -- in a headline frame ten items near the frame's edge, where the lens vignettes, hold all of them,
-      // ~500 each (their solves run 20-40 iterations, are parked, and 83 % of them fail -- after which the attempt simply
-      // moves on to its next try and mostly succeeds) -- and the batches that pessimism sends those items are as slow as
-      // their first ones: thousands of parked solves for 256 straggler waves.  So the unknown attempts are credited with
-      // unknown_credit / 8 of the success rate of the item's known ones.  Where that is too generous by a few attempts
-      // the first batch's spare ones (DrawArgs::extra_const) make up for it; beyond that the item costs a third round.
-      const uint32_t known = n > uacc ? n - uacc : 1u;
-      const unsigned long long est = (unsigned long long)acc + ((unsigned long long)uacc * acc * a.unknown_credit) / (8ull * known);
-      acc = est < S ? (uint32_t)est : S;
-    }
-    r.more = acc < S && n < max_total && pg.m_hi < m_limit && pg.m_hi > 0;
-    r.new_lo = pg.m_hi;
-    r.new_hi = pg.m_hi;
-    if (r.more) {
-      // draws are still missing: schedule the next batch, sized from the item's own success rate so far
-      // (+25 % + 32; a surplus is simply never accepted, a shortfall costs another round)
-      const uint32_t remaining = S - acc;
-      unsigned long long need = acc ? ((unsigned long long)remaining * n + acc - 1) / acc : (unsigned long long)(max_total - n);
-      // (twice the margin where fewer than margin_low_rate / 16 of the item's attempts got through so far: with the petzval
-      // table, where a third of all attempts is vignetted, +25 % left some item short in every pass -- a third round, 0.4 ms
-      // of latency for a few thousand lane-iterations; config 4 8.65-8.8 against 9.2 ms, the other configurations unchanged)
-      const uint32_t m16 = (unsigned long long)acc * 16ull < (unsigned long long)n * a.margin_low_rate ? 2u * a.batch_margin16 : a.batch_margin16;
-      need += (need * m16) / 16 + 32;
-      unsigned long long n_target = (unsigned long long)n + need;
-      if (n_target > max_total) n_target = max_total;
-      uint32_t new_hi = (uint32_t)n_target + retries;
-      if (new_hi > m_limit) new_hi = m_limit;
-      r.new_hi = new_hi;
-    }
+    accept_next_batch<kMode>(a, pg, r, n, acc, uacc, S, max_total, m_limit, retries);
     return r;
+}
+
+// ---- accept_item, wide (round 4) ------------------------------------------------------------------
+// The same walk with kWide x 256 attempts per step instead of 256: a first batch (samples + retries + spare <= 2 048
+// attempts) is ONE step.  accept_item above takes 13 us per 256-attempt step -- four block barriers, a round trip to the
+// result pool, the splat atomics of the step before in the way of the next step's loads -- and a dry walk before the real
+// one where the next round is waiting for its tasks: 85 us for an item of 1 024 draws, 190 us for the headline frame's
+// first accept, which stands between the first round's last solve and the second round's first (profiles/r04_*).  Here
+// the whole batch is fetched into LDS at once, every attempt is resolved there (three times over, LDS reads being what they
+// cost: once for the step's limit, once for the ranks, once to splat), ranks come from one prefix over the step's
+// 4 x kWide ballots, and the splats of a wave's kWide slabs follow one another without a block barrier in between.
+// Same decisions as accept_item, attempt for attempt (modes 0, 1, 2; gaussian, closest and debug AOVs; the draw log).
+constexpr int kWide = 8;
+struct AcceptWideShared {
+  uint32_t win[256 * kWide + kAcceptWinRetries];      // R(n .. n + 256 kWide - 1 + retries) of the step
+  uint32_t code[256 * kWide];                          // what ends every attempt of the step (wide_resolve), for the splats
+  unsigned long long m_succ[kWide * 4], m_unk[kWide * 4], m_succ1[kWide * 4];      // ballots per slab of 64 attempts
+  uint32_t before[3][kWide * 4];                       // exclusive prefix of the three masks' popcounts
+  uint32_t first_u[kWide * 4];
+  uint32_t limit, stalled, total[3], top;              // the step's outcome, from wave 0
+};
+
+template <int kMode>
+struct WideAttempt {
+  uint32_t code, code1;
+  bool unresolved, unk, seen1;
+};
+
+// one attempt's tries in the step's window (the loop of accept_item, src/lentil.h:592-648 as "first non-FAIL of R(n .. n + retries)")
+template <int kMode>
+LD_DEV WideAttempt<kMode> wide_resolve(const DrawArgs &a, const AcceptWideShared &ws, const ItemProg &pg, uint32_t my_i, uint32_t retries,
+                                       uint32_t m_limit) {
+  WideAttempt<kMode> r;
+  r.code = kCodeFail; r.code1 = kCodeFail; r.unresolved = false; r.unk = false; r.seen1 = false;
+  for (uint32_t t = 0; t <= retries; ++t) {
+    uint32_t c = ws.win[my_i + t];
+    if (c == kCodeBeyond) { r.unresolved = (pg.m_hi < m_limit); break; }
+    if (code_is_pending(c)) {
+      if (kMode == 1) { r.unk = true; break; }
+      if (kMode == 2) {
+        if (!r.seen1) { r.unk = true; r.seen1 = true; }
+        c = a.slow[c & 0x00FFFFFFu].result;            // the straggler is through
+      } else {
+        atomicAdd(&a.ctr->overflow, 1ull);               // a mark nobody is going to resolve: the pass is void
+        c = kCodeFail;
+      }
+    } else if (kMode == 2 && !r.seen1 && c != kCodeFail) {
+      r.code1 = c; r.seen1 = true;
+    }
+    if (c != kCodeFail) { r.code = c; break; }
+  }
+  return r;
+}
+
+// The lanes of the wave that hold the same value as this one (all 64 lanes call; `bits` = width of the values):
+// one ballot per bit.  What count_same_pixel finds with a 64-step loop per lane.
+LD_DEV unsigned long long match_any_bits(uint32_t v, uint32_t bits) {
+  unsigned long long peers = ~0ull;
+  for (uint32_t b = 0; b < bits; ++b) {
+    const bool set = (v >> b) & 1u;
+    const unsigned long long m = __ballot(set);
+    peers &= set ? m : ~m;
+  }
+  return peers;
+}
+
+// decided(r): called by all threads once the walk's outcome is known -- before the last step's draws are splatted, so that
+// the next round's tasks leave first (what accept_item needs a dry walk for).
+template <int kMode, class Decided>
+LD_DEV AcceptResult accept_item_wide(const DrawArgs &a, AcceptShared &sh, AcceptWideShared &ws, uint32_t item, const ItemProg pg,
+                                     const ItemVisit &h, const uint32_t *res, const uint32_t *res_prev, uint32_t &rmin, uint32_t &rmax_p1,
+                                     Decided &&decided) {
+  (void)item;
+  uint32_t(*s_pix)[64] = sh.pix;
+  float *s_val = sh.val;
+  uint32_t *s_off = sh.off;
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  const unsigned long long lt_mask = (1ull << lane) - 1ull;
+  const uint32_t retries = (uint32_t)a.retries;
+  const uint32_t S = h.samples, max_total = S * 5u, m_limit = max_total + retries;
+  const float ae = h.I.add_energy, w = h.w;
+  const unsigned long long zk = (a.F.zkey || a.F.zkey_dbg) ? closest_key_of(a.ctr, h.I.depth, visit_gid(a.V, h.visit)) : 0ull;
+  // per-item add table: gaussian AOVs' (value + add_energy) * w, then the weight itself
+  uint32_t U = 1;
+  for (uint32_t k = 0; k < a.F.n_aovs; ++k) if (!(a.F.closest_mask & (1u << k))) U += 4;
+#ifdef LENTIL_TIMELINE
+  unsigned long long tp_ = __builtin_amdgcn_s_memrealtime();
+#define LENTIL_PHASE(I) do { const unsigned long long t_ = __builtin_amdgcn_s_memrealtime(); if (threadIdx.x == 0) dbg_add(20 + (I), t_ - tp_); tp_ = t_; } while (0)
+#else
+#define LENTIL_PHASE(I) do {} while (0)
+#endif
+  block_sync_lds();          // (the add table and the masks of the item before)
+  LENTIL_PHASE(0);
+  if (threadIdx.x < a.F.n_aovs * 4u) {
+    const uint32_t k = threadIdx.x >> 2, c = threadIdx.x & 3u;
+    if (!(a.F.closest_mask & (1u << k))) {
+      uint32_t slot = 0;
+      for (uint32_t j = 0; j < k; ++j) if (!(a.F.closest_mask & (1u << j))) slot += 4;
+      const float4 v = k == 0 ? h.rgba : a.V.extra[k - 1][h.visit];
+      const float vc = c == 0 ? v.x : (c == 1 ? v.y : (c == 2 ? v.z : v.w));
+      s_val[slot + c] = (vc + ae) * w;
+      s_off[slot + c] = 4u * k + c;
+    }
+  }
+  if (threadIdx.x == 0) { s_val[U - 1] = w; s_off[U - 1] = 4u * a.F.n_aovs; }
+  const bool replay = kMode == 2 && pg.uacc != 0u;
+  uint32_t n = pg.n_done, acc = pg.accepted, last_ok = pg.last_ok;
+  uint32_t uacc = 0;               // mode 1: unknown attempts so far; mode 2: the same, replayed
+  uint32_t acc1 = 0;               // mode 2: known successes mode 1 counted so far
+  bool stalled = false;
+  // Lane (dd, ch) = (lane / U, lane % U) adds float ch of every (64 / U)-th draw of the wave's list: the division and the
+  // table entries once per item, not once per atomic
+  const uint32_t dpi = 64u / U;                                   // draws per atomic instruction
+  const uint32_t my_dd = lane / U, my_ch = lane - my_dd * U;
+  const bool adds = my_dd < dpi;
+  uint32_t pix_bits = 1;
+  while ((a.F.np - 1u) >> pix_bits) ++pix_bits;                  // width of a pixel index
+  constexpr uint32_t kStep = 256u * (uint32_t)kWide;
+  constexpr uint32_t kSlabs = (uint32_t)kWide * 4u;
+  static_assert(kSlabs <= 32, "one lane of wave 0 per slab");
+  while (!stalled && acc < S && n < max_total) {
+    // ---- the step's window
+    block_sync_lds();              // (the window and the masks of the step before, the add table)
+    const uint32_t span = max_total - n < kStep ? max_total - n : kStep;      // attempts of this step that exist at all
+    // slabs of 256 attempts that hold anything: what the batch covers (beyond m_hi every R(m) is "beyond", i.e. unresolved)
+    uint32_t jn = (span + 255u) / 256u;
+    {
+      const uint32_t covered = pg.m_hi > n ? pg.m_hi - n : 0u;      // attempts with at least their first try inside the batch
+      const uint32_t jc = covered / 256u + 1u;
+      if (jc < jn) jn = jc;
+    }
+    for (uint32_t i = threadIdx.x; i < jn * 256u + retries; i += 256u) ws.win[i] = result_at2(res, res_prev, pg, n + i);
+    if (threadIdx.x < kSlabs) { ws.first_u[threadIdx.x] = kStep; ws.m_succ[threadIdx.x] = 0ull; ws.m_unk[threadIdx.x] = 0ull; ws.m_succ1[threadIdx.x] = 0ull; }
+    block_sync_lds();
+    LENTIL_PHASE(1);
+    // ---- pass A: every attempt resolved once; per slab of 64 the ballots of the unresolved, the successes (modes 0, 2:
+    // final; mode 1: as far as known), the unknown attempts and mode 1's successes (mode 2's replay)
+#pragma unroll 1
+    for (uint32_t j = 0; j < jn; ++j) {
+      const uint32_t my_i = j * 256u + wave * 64u + lane;
+      const uint32_t my_n = n + my_i;
+      bool unres = false, succ = false, unk1 = false, succ1 = false;
+      if (my_i < span) {
+        const WideAttempt<kMode> r = wide_resolve<kMode>(a, ws, pg, my_i, retries, m_limit);
+        unres = r.unresolved;
+        succ = !unk_blocks<kMode>(r.unk) && r.code < kCodePendingBase;
+        const bool was1 = kMode == 2 && replay && my_n < pg.n_end1;
+        unk1 = kMode == 1 ? r.unk : (was1 && r.unk);
+        succ1 = was1 && !r.unk && r.code1 < kCodePendingBase;
+        ws.code[my_i] = r.code;
+      }
+      const unsigned long long umask = __ballot(unres);
+      const unsigned long long smask = __ballot(succ);
+      const unsigned long long u1mask = kMode != 0 ? __ballot(unk1) : 0ull;
+      const unsigned long long s1mask = kMode == 2 ? __ballot(succ1) : 0ull;
+      if (lane == 0) {
+        const uint32_t q = j * 4u + wave;
+        ws.first_u[q] = umask ? my_i + (uint32_t)__builtin_ctzll(umask) : kStep;
+        ws.m_succ[q] = smask; ws.m_unk[q] = u1mask; ws.m_succ1[q] = s1mask;
+      }
+    }
+    block_sync_lds();
+    // ---- wave 0: the step's limit (first unresolved attempt; all later ones are unresolved too), the ballots cut there,
+    // their prefix, the highest accepted attempt
+    if (wave == 0) {
+      const uint32_t q = lane < kSlabs ? lane : kSlabs - 1u;
+      uint32_t fu = lane < kSlabs ? ws.first_u[q] : kStep;
+      for (int off = 16; off > 0; off >>= 1) { const uint32_t o = __shfl_xor(fu, off); fu = o < fu ? o : fu; }
+      fu = (uint32_t)__builtin_amdgcn_readfirstlane((int)fu);
+      const uint32_t lim = fu < span ? fu : span;
+      const uint32_t start = q * 64u;
+      unsigned long long keep = 0ull;
+      if (lane < kSlabs && start < lim) keep = lim - start >= 64u ? ~0ull : ((1ull << (lim - start)) - 1ull);
+      const unsigned long long m0 = ws.m_succ[q] & keep, m1 = ws.m_unk[q] & keep, m2 = ws.m_succ1[q] & keep;
+      uint32_t tot[3];
+      uint32_t bef0 = 0;
+#pragma unroll
+      for (int kind = 0; kind < 3; ++kind) {
+        const uint32_t c = (uint32_t)__builtin_popcountll(kind == 0 ? m0 : (kind == 1 ? m1 : m2));
+        uint32_t incl = c;
+        for (int off = 1; off < 32; off <<= 1) { const uint32_t up = __shfl_up(incl, off); if ((int)lane >= off) incl += up; }
+        if (lane < kSlabs) ws.before[kind][lane] = incl - c;
+        if (kind == 0) bef0 = incl - c;
+        tot[kind] = (uint32_t)__shfl((int)incl, (int)kSlabs - 1);
+      }
+      // highest accepted attempt: the slab's successes with rank < S are its first (S - acc - before) ones
+      uint32_t top = 0u;
+      {
+        const uint32_t cnt_s = (uint32_t)__builtin_popcountll(m0);
+        const uint32_t room = acc + bef0 < S ? S - acc - bef0 : 0u;
+        if (lane < kSlabs && room && cnt_s) {
+          uint32_t pos = 63u - (uint32_t)__builtin_clzll(m0);
+          if (room < cnt_s) {
+            unsigned long long m = m0;
+            for (uint32_t b = 0; b < room; ++b) { pos = (uint32_t)__builtin_ctzll(m); m &= m - 1ull; }
+          }
+          top = n + start + pos;
+        }
+        for (int off = 16; off > 0; off >>= 1) { const uint32_t o = __shfl_xor(top, off); top = o > top ? o : top; }
+      }
+      if (lane < kSlabs) { ws.m_succ[q] = m0; ws.m_unk[q] = m1; ws.m_succ1[q] = m2; }
+      if (lane == 0) { ws.limit = lim; ws.stalled = fu < span ? 1u : 0u; ws.total[0] = tot[0]; ws.total[1] = tot[1]; ws.total[2] = tot[2]; ws.top = top; }
+    }
+    block_sync_lds();
+    LENTIL_PHASE(2);
+    const uint32_t limit = ws.limit;
+    if (ws.stalled) stalled = true;
+    const uint32_t total = ws.total[0], utotal = kMode != 0 ? ws.total[1] : 0u, total1 = kMode == 2 ? ws.total[2] : 0u;
+    const uint32_t taken = total < S - acc ? total : S - acc;
+    const uint32_t new_last_ok = taken ? ws.top : last_ok;
+    // ---- if this is the walk's last step: the decision about the item's next batch, which goes out before anything is splatted
+    {
+      const uint32_t n2 = n + limit, acc2 = acc + taken, uacc2 = uacc + utotal;
+      if (stalled || !(acc2 < S && n2 < max_total)) {
+        AcceptResult r;
+        r.samples = S;
+        r.prog = pg;
+        r.prog.n_done = n2; r.prog.accepted = acc2; r.prog.last_ok = new_last_ok;
+        r.prog.uacc = kMode == 1 ? uacc2 : 0u;
+        accept_next_batch<kMode>(a, pg, r, n2, acc2, uacc2, S, max_total, m_limit, retries);
+        LENTIL_PHASE(3);
+        decided(r);
+        LENTIL_PHASE(4);
+      }
+    }
+    // ---- pass B: what is splatted now
+    const uint32_t my_off = adds ? s_off[my_ch] : 0u;
+    const float my_val = adds ? s_val[my_ch] : 0.f;
+#pragma unroll 1
+    for (uint32_t j = 0; j < jn; ++j) {
+      const uint32_t my_i = j * 256u + wave * 64u + lane;
+      const uint32_t my_n = n + my_i;
+      const uint32_t q = j * 4u + wave;
+      const unsigned long long smask = ws.m_succ[q];
+      if (smask == 0ull) continue;      // (no success in this slab: nothing taken, nothing splatted)
+      const bool succ = (smask >> lane) & 1ull;
+      const uint32_t rank = acc + ws.before[0][q] + (uint32_t)__builtin_popcountll(smask & lt_mask);
+      const bool take = succ && rank < S;              // mode 1: among the first S *known* successes
+      bool splat = take;
+      if (kMode == 1) {
+        const unsigned long long u1mask = ws.m_unk[q];
+        const uint32_t ub = uacc + ws.before[1][q] + (uint32_t)__builtin_popcountll(u1mask & lt_mask);
+        splat = take && rank + ub < S;
+      } else if (kMode == 2) {
+        const unsigned long long u1mask = ws.m_unk[q], s1mask = ws.m_succ1[q];
+        const uint32_t ub = uacc + ws.before[1][q] + (uint32_t)__builtin_popcountll(u1mask & lt_mask);
+        const uint32_t rank1 = acc1 + ws.before[2][q] + (uint32_t)__builtin_popcountll(s1mask & lt_mask);
+        const bool succ1 = (s1mask >> lane) & 1ull;
+        splat = take && !(succ1 && rank1 + ub < S);    // mode 1 has added that one
+      }
+      const unsigned long long pmask0 = __ballot(splat);
+      if (pmask0 == 0ull) continue;
+      // Camera::add_to_buffer, src/lentil.h:827-830 -- transposed: the wave's accepted pixels go through
+      // LDS, then lane (dd, ch) adds float ch of accepted draw dd, dd + 64 / U, ...: consecutive lanes hit consecutive
+      // floats of one pixel record.  Draws of the slab on the same pixel are added as ONE atomic of count x value
+      // (count_same_pixel in accept_item; here from a match over the pixel index's bits).
+      const uint32_t pix = splat ? ws.code[my_i] : ((1u << pix_bits) | lane);      // (lanes without a draw: 64 values no pixel has)
+      const unsigned long long peers = match_any_bits(pix, pix_bits + 1u) & pmask0;
+      uint32_t slot = 0, cnt = 0;
+      const bool leader = splat && (uint32_t)__builtin_ctzll(peers) == lane;      // the first lane of every pixel
+      const unsigned long long lmask = __ballot(leader);
+      if (splat) {
+        const uint32_t row = pix / a.P.xres;
+        rmin = row < rmin ? row : rmin;
+        rmax_p1 = row + 1u > rmax_p1 ? row + 1u : rmax_p1;
+        if (a.F.touched) a.F.touched[pix >> 6] = a.round ? 2 : 1;      // (2: by a round after the first, see resolve_touched_kernel)
+        if (a.F.zkey) atomicMin(a.F.zkey + pix, zk);
+        if (a.F.zkey_dbg) atomicMin(a.F.zkey_dbg + pix, zk);      // value.r = samples != 0 for every draw
+        if (a.log_cap) {
+          const unsigned long long li = wave_log_slots(a.log_count, pmask0, lane);
+          if (li < a.log_cap) { a.log[li].visit = h.visit; a.log[li].attempt = my_n; a.log[li].pixel = pix; }
+        }
+      }
+      if (leader) {
+        slot = (uint32_t)__builtin_popcountll(lmask & lt_mask);
+        cnt = (uint32_t)__builtin_popcountll(peers);
+        s_pix[wave][slot] = pix;
+        sh.cnt[wave][slot] = cnt;
+      }
+      const uint32_t T = (uint32_t)__builtin_popcountll(lmask);       // distinct pixels of the slab
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
+      for (uint32_t d = my_dd; adds && d < T; d += dpi) {
+        const uint32_t c = sh.cnt[wave][d];
+        const uint32_t px_ = s_pix[wave][d];
+        atomicAdd(a.F.acc + (size_t)px_ * a.F.stride + my_off, (float)c * my_val);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+      __builtin_amdgcn_wave_barrier();
+    }
+    LENTIL_PHASE(5);
+    if (taken) { last_ok = new_last_ok; acc += taken; }
+    uacc += utotal;
+    if (kMode == 2) acc1 += total1;       // (mode 1 capped its count at S; beyond that rank1 >= S either way)
+    n += limit;
+  }
+  AcceptResult r;
+  r.samples = S;
+  r.prog = pg;
+  r.prog.n_done = n; r.prog.accepted = acc; r.prog.last_ok = last_ok;
+  r.prog.uacc = kMode == 1 ? uacc : 0u;
+  accept_next_batch<kMode>(a, pg, r, n, acc, uacc, S, max_total, m_limit, retries);
+  if (!(pg.accepted < S && pg.n_done < max_total)) decided(r);      // (an item whose walk has no step: nothing to look at)
+  return r;
 }
 
 // Chromatic mode (abb_chromatic != 0), src/lentil_filter.cpp:248-299: every attempt traces three
@@ -2984,7 +3365,7 @@ LD_DEV AcceptResult accept_item_chroma(const DrawArgs &a, AcceptShared &sh, uint
   const ItemVisit h = load_item_visit(a, item, lens_length);
   const uint32_t S = h.samples, max_total = S * 5u, m_limit = max_total + retries;
   const float ae = h.I.add_energy, w = h.w;
-  const unsigned long long zk = (a.F.zkey || a.F.zkey_dbg) ? closest_key(h.I.depth, visit_gid(a.V, h.visit)) : 0ull;
+  const unsigned long long zk = (a.F.zkey || a.F.zkey_dbg) ? closest_key_of(a.ctr, h.I.depth, visit_gid(a.V, h.visit)) : 0ull;
   uint32_t U = 1;
   for (uint32_t k = 0; k < a.F.n_aovs; ++k) if (!(a.F.closest_mask & (1u << k))) U += 4;
   if (threadIdx.x < a.F.n_aovs * 4u) {
@@ -3155,11 +3536,19 @@ LD_DEV AcceptResult accept_item_chroma(const DrawArgs &a, AcceptShared &sh, uint
 // (six waves per SIMD: beside four accept blocks per CU a SIMD then has room for a solve wave -- the next round's solves
 // run beside the accept that schedules them, DrawArgs::emit_live)
 // kMode: accept_item's -- 1 for the first accept of a decoupled streamed pass, 2 for the one behind it, 0 otherwise.
+#ifndef LENTIL_ACCEPT_EU
+#define LENTIL_ACCEPT_EU 6
+#endif
 template <int kMode>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) void accept_kernel(DrawArgs a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LENTIL_ACCEPT_EU, LENTIL_ACCEPT_EU))) void accept_kernel(DrawArgs a) {
   LENTIL_TL_SPAN(kMode == 0 ? SPAN_ACCEPT0 : (kMode == 1 ? SPAN_ACCEPT1 : SPAN_ACCEPT2));
   __shared__ uint32_t s_item;
   __shared__ AcceptShared sh;
+  __shared__ AcceptWideShared ws;
+#ifdef LENTIL_ACCEPT_PRIO
+  // the accept stands between two rounds of solves: beside the next round's solve and straggler waves its instructions go first
+  __builtin_amdgcn_s_setprio(LENTIL_ACCEPT_PRIO);
+#endif
   const uint32_t par = (uint32_t)a.parity, nxt = par ^ 1u;
   // (a streamed or blind pass whose buffers were too small: nothing is accepted, the host redoes the draws)
   const uint32_t n_active = (a.ctr->fallback || a.ctr->stuck) ? 0u : a.ctr->n_active[par];
@@ -3170,12 +3559,56 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
   // The next round's solve kernel is waiting for tasks (emit_live): a block takes its share of the items at once, finds
   // out what each of them still needs with a dry walk (a third of the real one's time: no splats) and hands those tasks
   // out before it splats anything -- the last tasks leave ~0.06 ms into the kernel instead of ~0.15 ms.
+  // (accept_item_wide needs no dry walk: it knows what an item needs before it splats the item's last step.)
   constexpr uint32_t kGroup = 8;
   __shared__ uint32_t s_emit_off[kGroup], s_emit_hi[kGroup], s_emitted[kGroup];
   const bool chroma = a.n_channels == 3;
-  const bool dry_first = a.emit_live && !chroma;
+  // (LENTIL_ACCEPT_WIDE=0 -> DrawArgs::accept_narrow: the 256-attempt steps of accept_item for everything)
+  const bool wide = !chroma && (uint32_t)a.retries <= kAcceptWinRetries && !a.accept_narrow;
+  const bool dry_first = a.emit_live && !chroma && !wide;
   uint32_t per = 1;
-  if (dry_first) { per = (n_active + gridDim.x - 1u) / gridDim.x; per = per < 1u ? 1u : (per > kGroup ? kGroup : per); }
+  if (dry_first || wide) { per = (n_active + gridDim.x - 1u) / gridDim.x; per = per < 1u ? 1u : (per > kGroup ? kGroup : per); }
+  const double lens_length = a.lens ? a.lens->length : 0.0;
+  // what thread 0 does with an item's outcome: progress record, the next round's list and tasks, the pass's totals
+  auto finish_item = [&](uint32_t item, const ItemProg &pg, const AcceptResult &r, bool emitted, uint32_t off, uint32_t emitted_hi) {
+    tl_add(TL_ITEMS_ACCEPTED, 1u);
+    if (kMode == 1) {
+      const uint32_t u = r.prog.uacc;
+      dbg_add(8 + (u == 0 ? 0 : (u <= 4 ? 1 : (u <= 16 ? 2 : (u <= 64 ? 3 : (u <= 256 ? 4 : 5))))), 1);
+      dbg_add(14, u);
+      if (u) dbg_add(15, r.more ? 1 : 0);
+    }
+    if (kMode == 2 && pg.uacc) { dbg_add(16, 1); dbg_add(17, r.more ? 1 : 0); dbg_add(18, r.prog.accepted); dbg_add(19, r.samples); }
+    if (kMode == 1 && r.prog.uacc != 0u) {
+      // met attempts whose solves are still parked: the next accept walks the item again, this batch beside the next
+      ItemProg np_ = pg;
+      np_.uacc = r.prog.uacc;
+      np_.n_end1 = r.prog.n_done;
+      np_.p_lo = pg.m_lo; np_.p_hi = pg.m_hi; np_.p_off = pg.res_off;
+      np_.m_lo = np_.m_hi = pg.m_hi; np_.res_off = 0;
+      if (!emitted && r.more) { emitted = emit_tasks(a, nxt, item, r.new_lo, r.new_hi, off); emitted_hi = r.new_hi; }
+      if (emitted) { np_.m_hi = emitted_hi; np_.res_off = off; }
+      a.prog[item] = np_;
+      const uint32_t slot = atomicAdd(&a.ctr->n_active[nxt], 1u);
+      a.active[nxt][slot] = item;
+    } else if (r.more) {
+      ItemProg np_ = r.prog;
+      np_.m_lo = r.new_lo; np_.m_hi = r.new_hi;
+      np_.uacc = 0; np_.p_lo = np_.p_hi = np_.p_off = 0; np_.n_end1 = 0;
+      if (emitted) np_.m_hi = emitted_hi;         // (the dry walk's word: the same, its view of the results being the same)
+      if (emitted || emit_tasks(a, nxt, item, r.new_lo, r.new_hi, off)) {
+        np_.res_off = off;
+        a.prog[item] = np_;
+        const uint32_t slot = atomicAdd(&a.ctr->n_active[nxt], 1u);
+        a.active[nxt][slot] = item;
+      }
+    } else {
+      // total_samples_taken when the reference's loop ends, src/lentil_filter.cpp:248
+      tot_attempted += ((int)r.prog.accepted >= (int)r.samples) ? (unsigned long long)r.prog.last_ok + 1ull
+                                                                 : (unsigned long long)r.samples * 5ull;
+      tot_accepted += chroma ? r.prog.splats : r.prog.accepted;
+    }
+  };
   while (true) {
     __syncthreads();
     if (threadIdx.x == 0) s_item = atomicAdd(&a.ctr->active_head[par], per);
@@ -3183,6 +3616,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
     const uint32_t ai0 = s_item;
     if (ai0 >= n_active) break;
     const uint32_t cnt = n_active - ai0 < per ? n_active - ai0 : per;
+    if (wide) {
+      for (uint32_t j = 0; j < cnt; ++j) {
+        const uint32_t item = a.active[par][ai0 + j];
+        const ItemProg pg = a.prog[item];
+#ifdef LENTIL_TIMELINE
+        const unsigned long long tm0_ = __builtin_amdgcn_s_memrealtime();
+#endif
+        const ItemVisit h = load_item_visit(a, item, lens_length);
+#ifdef LENTIL_TIMELINE
+        if (threadIdx.x == 0 && h.samples) { dbg_add(26, __builtin_amdgcn_s_memrealtime() - tm0_); dbg_add(27, 1); }
+#endif
+        (void)accept_item_wide<kMode>(a, sh, ws, item, pg, h, res, res_prev, rmin, rmax_p1,
+                                      [&](const AcceptResult &r) { if (threadIdx.x == 0) finish_item(item, pg, r, false, 0u, 0u); });
+      }
+      continue;
+    }
     if (dry_first) {
       for (uint32_t j = 0; j < cnt; ++j) {
         const uint32_t item = a.active[par][ai0 + j];
@@ -3197,52 +3646,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
       }
     }
     for (uint32_t j = 0; j < cnt; ++j) {
-    const uint32_t item = a.active[par][ai0 + j];
-    const ItemProg pg = a.prog[item];
-    const AcceptResult r = chroma ? accept_item_chroma(a, sh, item, pg, res, rmin, rmax_p1)
-                                  : accept_item<kMode>(a, sh, item, pg, res, res_prev, rmin, rmax_p1);
-    if (threadIdx.x == 0) tl_add(TL_ITEMS_ACCEPTED, 1u);
-    if (threadIdx.x == 0) {
-      bool emitted = dry_first && s_emitted[j] != 0u;
-      uint32_t off = dry_first ? s_emit_off[j] : 0u, emitted_hi = dry_first ? s_emit_hi[j] : 0u;
-      if (kMode == 1) {
-        const uint32_t u = r.prog.uacc;
-        dbg_add(8 + (u == 0 ? 0 : (u <= 4 ? 1 : (u <= 16 ? 2 : (u <= 64 ? 3 : (u <= 256 ? 4 : 5))))), 1);
-        dbg_add(14, u);
-        if (u) dbg_add(15, r.more ? 1 : 0);
-      }
-      if (kMode == 2 && pg.uacc) { dbg_add(16, 1); dbg_add(17, r.more ? 1 : 0); dbg_add(18, r.prog.accepted); dbg_add(19, r.samples); }
-      if (kMode == 1 && r.prog.uacc != 0u) {
-        // met attempts whose solves are still parked: the next accept walks the item again, this batch beside the next
-        ItemProg np_ = pg;
-        np_.uacc = r.prog.uacc;
-        np_.n_end1 = r.prog.n_done;
-        np_.p_lo = pg.m_lo; np_.p_hi = pg.m_hi; np_.p_off = pg.res_off;
-        np_.m_lo = np_.m_hi = pg.m_hi; np_.res_off = 0;
-        if (!emitted && r.more) { emitted = emit_tasks(a, nxt, item, r.new_lo, r.new_hi, off); emitted_hi = r.new_hi; }
-        if (emitted) { np_.m_hi = emitted_hi; np_.res_off = off; }
-        a.prog[item] = np_;
-        const uint32_t slot = atomicAdd(&a.ctr->n_active[nxt], 1u);
-        a.active[nxt][slot] = item;
-      } else if (r.more) {
-        ItemProg np_ = r.prog;
-        np_.m_lo = r.new_lo; np_.m_hi = r.new_hi;
-        np_.uacc = 0; np_.p_lo = np_.p_hi = np_.p_off = 0; np_.n_end1 = 0;
-        if (emitted) np_.m_hi = emitted_hi;         // (the dry walk's word: the same, its view of the results being the same)
-        if (emitted || emit_tasks(a, nxt, item, r.new_lo, r.new_hi, off)) {
-          np_.res_off = off;
-          a.prog[item] = np_;
-          const uint32_t slot = atomicAdd(&a.ctr->n_active[nxt], 1u);
-          a.active[nxt][slot] = item;
-        }
-      } else {
-        // total_samples_taken when the reference's loop ends, src/lentil_filter.cpp:248
-        tot_attempted += ((int)r.prog.accepted >= (int)r.samples) ? (unsigned long long)r.prog.last_ok + 1ull
-                                                                   : (unsigned long long)r.samples * 5ull;
-        tot_accepted += chroma ? r.prog.splats : r.prog.accepted;
-      }
-    }
-    __syncthreads();       // (s_emit_*[j] and the add table in `sh` are the block's)
+      const uint32_t item = a.active[par][ai0 + j];
+      const ItemProg pg = a.prog[item];
+      const AcceptResult r = chroma ? accept_item_chroma(a, sh, item, pg, res, rmin, rmax_p1)
+                                    : accept_item<kMode>(a, sh, item, pg, res, res_prev, rmin, rmax_p1);
+      if (threadIdx.x == 0)
+        finish_item(item, pg, r, dry_first && s_emitted[j] != 0u, dry_first ? s_emit_off[j] : 0u, dry_first ? s_emit_hi[j] : 0u);
+      __syncthreads();       // (s_emit_*[j] and the add table in `sh` are the block's)
     }
   }
   if (threadIdx.x == 0) {
@@ -3344,7 +3754,7 @@ __global__ __launch_bounds__(256) void tl_chroma_walk_kernel(TlChromaArgs a) {
     const ItemVisit h = load_work_visit(a.P, a.V, a.work[item], 0.0);
     const uint32_t S = h.samples, max_total = S * 5u;
     const float ae = h.I.add_energy, w = h.w;
-    const unsigned long long zk = (a.F.zkey || a.F.zkey_dbg) ? closest_key(h.I.depth, visit_gid(a.V, h.visit)) : 0ull;
+    const unsigned long long zk = (a.F.zkey || a.F.zkey_dbg) ? closest_key_of(a.ctr, h.I.depth, visit_gid(a.V, h.visit)) : 0ull;
     const uint32_t *res = a.res + a.att_off[item] * 3ull;
     // what an accepted draw adds (gaussian AOVs: (value + add_energy) * w per component, then the weight itself)
     uint32_t U = 1;

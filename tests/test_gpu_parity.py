@@ -720,6 +720,54 @@ def test_lentil_debug_aov(orc, gpu_ctx_factory):
     ref.close()
 
 
+@pytest.mark.parametrize("layout", ["uniform", "ragged_runs", "ragged_atomics"])
+def test_lentil_debug_visits_inside_the_lens(orc, gpu_ctx_factory, monkeypatch, layout):
+    """src/lentil_filter.cpp:209-212 takes lentil_debug's value, samples * redistribute, BEFORE :240 clears redistribute for
+    a sample inside the lens: such a visit reaches the direct path (src/lentil.h:938-955) with a non-zero count and competes
+    for the debug z-buffer (src/lentil.h:838-845) at its own pixel.  A stream with a few hundred visits at 5 % of the lens
+    length, through every scan kernel that serves frames with closest AOVs, against the oracle."""
+    if layout == "ragged_atomics":
+        monkeypatch.setenv("LENTIL_SCAN_RUNS", "0")
+    W, H, M = 64, 40, 9
+    kinds = [_abi.FILTER_GAUSSIAN, _abi.FILTER_CLOSEST_DEBUG, _abi.FILTER_CLOSEST]
+    p, model, table, keep = common.po_setup(W, H, samples_override=0)
+    visits, cols = common.make_stream(p, W, H, M, f_hi=0.03, n_extra=2)
+    n = cols["rgba"].shape[0]
+    rng = np.random.default_rng(23)
+    inside = rng.choice(n, 400, replace=False)
+    z_in = np.float32(float(table.lens_length) * 0.1 * 0.5)           # camera space is cm, the lens length mm
+    cols["pos_z"][inside, 0] = rng.uniform(-0.2, 0.2, inside.size).astype(np.float32) * z_in
+    cols["pos_z"][inside, 1] = rng.uniform(-0.2, 0.2, inside.size).astype(np.float32) * z_in
+    cols["pos_z"][inside, 2] = -z_in * rng.uniform(0.2, 1.9, inside.size).astype(np.float32)
+    cols["pos_z"][inside, 3] = -cols["pos_z"][inside, 2]
+    cols["extra"][0] = None
+    if layout != "uniform":
+        pix = np.arange(n, dtype=np.uint64) // M
+        cols["pixel"] = ((pix % W).astype(np.uint32) | ((pix // W).astype(np.uint32) << 16)).astype(np.uint32)
+    mk = dict(visits_per_pixel=M, pixels_per_row=W) if layout == "uniform" else dict(visits_per_pixel=0)
+    visits, keepv = capi.make_visits(cols, **mk)
+    ocols = dict(cols); ocols["extra"] = [np.zeros_like(cols["rgba"]), cols["extra"][1]]
+    ovisits, okeep = capi.make_visits(ocols, **mk)
+    lens = orc.orc_lens_create(C.byref(table))
+    ref = oracle_lib.Frame(orc, p, n_aovs=3, kinds=kinds, keep_log=True)
+    ref.run(lens, None, ovisits)
+    orc.orc_lens_destroy(lens)
+    ctx = gpu_ctx_factory()
+    gpu_run(ctx, p, table, visits, n_aovs=3, kinds=kinds)
+    check_logs(ctx, ref)
+    dbg, _ = ctx.download_accum(1)
+    rdbg = ref.buffer(1)
+    # the case exists in this stream: a pixel whose debug value comes from one of its OWN visits, not from a draw
+    drawn = np.zeros(rdbg.shape[0], bool)
+    drawn[ref.log()[:, 2]] = True
+    assert ((rdbg[:, 0] != 0) & ~drawn).sum() > 50
+    assert np.array_equal(dbg, rdbg)
+    assert np.array_equal(ctx.download_aov(1), ref.resolve(1))
+    own, _ = ctx.download_accum(2)
+    assert np.array_equal(own, ref.buffer(2))
+    ref.close()
+
+
 def test_po_ragged_pixels_and_inv_density(orc, gpu_ctx_factory):
     """Explicit per-visit pixel + per-visit inverse density (ragged footprints / adaptive sampling)."""
     W, H, M = 48, 32, 9

@@ -315,3 +315,37 @@ def test_two_contexts_pass_at_the_same_time(orc, gpu_ctx_factory):
     assert not errors, "context %d: %r" % errors[0]
     assert not any(t.is_alive() for t in th)
     assert sum(forms[0]) + sum(forms[1]) >= 1       # (the first pass of a context is never streamed)
+
+
+@pytest.mark.parametrize("what", ["zero", "negative_zero", "nan"])
+@pytest.mark.parametrize("ragged", [False, True])
+def test_degenerate_depths_and_closest_aovs(orc, gpu_ctx_factory, what, ragged):
+    """src/lentil.h:832-837 treats a z-buffer value of 0 as "empty": a sample at |Z| == 0 wins and re-opens the pixel, a NaN
+    written into an empty pixel is never replaced -- the reference's image then depends on the order of the samples at
+    that pixel.  The library does not approximate that: a pass in which such a sample competes for a closest-filtered AOV
+    is refused (LENTIL_ERR_UNSUPPORTED, closest_key_of in lentil_kernels.h).  The same stream with gaussian AOVs only --
+    where the depth of a sample that stays in its pixel is never looked at -- passes and equals the oracle."""
+    W, H, M = 48, 32, 9
+    p, model, table, keep = common.po_setup(W, H, samples_override=32)
+    visits, cols = common.make_stream(p, W, H, M, f_hi=0.02, n_extra=1)
+    n = cols["rgba"].shape[0]
+    rng = np.random.default_rng(3)
+    bad = rng.choice(n, 12, replace=False)
+    cols["pos_z"][bad, 3] = {"zero": np.float32(0.0), "negative_zero": np.float32(-0.0), "nan": np.float32(np.nan)}[what]
+    if ragged:
+        pix = np.arange(n, dtype=np.uint64) // M
+        cols["pixel"] = ((pix % W).astype(np.uint32) | ((pix // W).astype(np.uint32) << 16)).astype(np.uint32)
+        visits, keepv = capi.make_visits(cols, visits_per_pixel=0)
+    else:
+        visits, keepv = capi.make_visits(cols, visits_per_pixel=M, pixels_per_row=W)
+    ctx = gpu_ctx_factory()
+    with pytest.raises(capi.LentilError) as e:
+        gpu_run(ctx, p, table, visits, n_aovs=2, kinds=[0, 1])
+    assert e.value.code == -3 and "src/lentil.h:832-837" in str(e.value)
+    # gaussian AOVs only: nothing to refuse
+    ref = common.run_oracle(orc, p, table, visits, n_aovs=2)
+    ctx2 = gpu_ctx_factory()
+    c = gpu_run(ctx2, p, table, visits, n_aovs=2, kinds=[0, 0])
+    _same_counters(c, ref)
+    check_logs(ctx2, ref)
+    check_frame(ctx2, ref, n_aovs=2)

@@ -24,7 +24,8 @@ NAMES = ["tiles", "tasks_pub", "itersA", "itersB", "itersR2+", "slow_it", "items
 def build():
     import __graft_entry__ as g
     os.makedirs(os.path.dirname(SO), exist_ok=True)
-    subprocess.check_call([g.HIPCC] + g.HIP_FLAGS + ["-DLENTIL_TIMELINE", "-I", os.path.join(ROOT, "include"), "-o", SO,
+    extra = os.environ.get("LENTIL_TL_FLAGS", "").split()      # e.g. -DLENTIL_ACCEPT_EU=4
+    subprocess.check_call([g.HIPCC] + g.HIP_FLAGS + extra + ["-DLENTIL_TIMELINE", "-I", os.path.join(ROOT, "include"), "-o", SO,
                                                       os.path.join(ROOT, "pota_amd", "csrc", "lentil_hip.hip")])
     print("built", SO)
 
@@ -114,6 +115,11 @@ def main():
     lines.append("dbg: first accept, items by unknown attempts 0 / 1-4 / 5-16 / 17-64 / 65-256 / >256: %s; unknown attempts %d; items with unknowns scheduling more %d"
                  % ([int(x) for x in dbg[8:14]], int(dbg[14]), int(dbg[15])))
     lines.append("dbg: second accept, replayed items %d, of them still short %d, accepted %d of %d" % tuple(int(x) for x in dbg[16:20]))
+    if int(dbg[27]):
+        k = float(dbg[27]) * 100.0
+        lines.append("dbg: accept_item_wide, us per item (thread 0's clock): metadata %.1f | wait for the block %.1f, window %.1f, passes 1-2 + prefix %.1f, "
+                     "tops %.1f, decision (thread 0) %.1f, splats %.1f  (%d items)"
+                     % (dbg[26] / k, dbg[20] / k, dbg[21] / k, dbg[22] / k, dbg[23] / k, dbg[24] / k, dbg[25] / k, int(dbg[27])))
     txt = "\n".join(lines)
     print(txt)
     if args.out:
