@@ -1784,7 +1784,11 @@ static int redistribute_streamed(lentil_hip_ctx *ctx, bool *streamed) {
     //   straggler st.: publishers -> stragglers of round one -> of round two -> second accept -> later rounds' accepts
     //                  -> the resolve's second half -> counter read-back       (each behind the kernel it ends last)
     // The only cross-stream waits left on the critical path release kernels that then sit waiting for tasks anyway.
-    hipStream_t ps = ctx->pub_stream;
+    // (Round 4: everything from the second round's stragglers on sits on THEIR stream -- the second accept follows the kernel
+    // that ends last, solve_slow_kernel of round two, in-stream; what else it needs -- the second round's solves, the first
+    // accept, the first round's stragglers -- has ended before that kernel does, so those waits find their events fired.
+    // On the publishers' stream the accept came ~60 us after the stragglers' end: three cross-stream waits in a row.)
+    hipStream_t ps = ctx->slow1_stream;
     HIP_TRY(ctx, hipStreamWaitEvent(ch.stream, ctx->pub_done, 0));       // (both long past when A ends)
     HIP_TRY(ctx, hipStreamWaitEvent(ch.stream, ctx->scans_done, 0));
     HIP_TRY(ctx, hipEventRecord(ctx->ev_round, ch.stream));
@@ -1832,7 +1836,7 @@ static int redistribute_streamed(lentil_hip_ctx *ctx, bool *streamed) {
         HIP_TRY(ctx, hipStreamWaitEvent(ctx->slow1_stream, ctx->ev_round, 0));
         hipLaunchKernelGGL(solve_slow_kernel, dim3(d1.slow_waves), dim3(64), 0, ctx->slow1_stream, d1);
         HIP_TRY(ctx, hipEventRecord(ctx->ev_slow1, ctx->slow1_stream));
-        HIP_TRY(ctx, hipStreamWaitEvent(ps, ctx->ev_slow1, 0));
+        HIP_TRY(ctx, hipStreamWaitEvent(ps, ctx->ev_slow, 0));      // the first round's stragglers (publishers' stream)
       } else {
         hipLaunchKernelGGL(solve_slow_kernel, dim3(d1.slow_waves), dim3(64), 0, ps, d1);      // beside the round's solves
       }
