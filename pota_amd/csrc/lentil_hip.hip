@@ -109,6 +109,15 @@ struct lentil_hip_ctx {
   int solve_cap_blocks = 1;                  // LENTIL_EARLY_CAP_BLOCKS: solve blocks per CU while later chunks are scanned
   int accept_max_blocks = 4;                 // LENTIL_ACCEPT_BLOCKS: accept blocks per CU at most
   int accept_stream_blocks = 2;              // ... in a streamed pass, whose accepts share the CUs with the next round's solves
+  bool extend = false;                       // LENTIL_EXTEND=1: a streamed pass's first round appends the batches its items still need itself
+                                             // (ItemLive, lentil_kernels.h).  Built, correct, and measured slower: 2.30 against 2.00 ms, see there
+  bool lean_tail = true;                     // LENTIL_LEAN_TAIL=0: ... and its second round's kernels are always in flight
+  bool lean_ok = true;                       // the last streamed pass with extension left its first accept nothing to schedule
+  uint64_t n_lean_lost = 0;                  // passes whose lean tail had to run the second round after all
+  ItemLive *d_live = nullptr;                // ... one record per item of chunk 0
+  uint64_t live_cap = 0;
+  Task *d_ext_q = nullptr;                   // ... the queue of the batches it appends
+  uint64_t ext_q_cap = 0;
   int solve_max_blocks = 4;                  // LENTIL_SOLVE_BLOCKS: solve blocks per CU at most
   // Streamed pass (polynomial optics, from the second pass of a context on): one scan launch that publishes its items
   // and their first-batch tasks itself, persistent solve waves that follow the task queue while the scan runs.
@@ -357,6 +366,8 @@ LENTIL_API int lentil_hip_create(int device, lentil_hip_ctx **out_ctx) {
   if (const char *e = getenv("LENTIL_EARLY_CAP_BLOCKS")) ctx->solve_cap_blocks = atoi(e);
   if (ctx->solve_cap_blocks < 1) ctx->solve_cap_blocks = 1;
   if (const char *e = getenv("LENTIL_ACCEPT_BLOCKS")) ctx->accept_max_blocks = ctx->accept_stream_blocks = atoi(e);
+  if (const char *e = getenv("LENTIL_EXTEND")) ctx->extend = e[0] != '0';
+  if (const char *e = getenv("LENTIL_LEAN_TAIL")) ctx->lean_tail = e[0] != '0';
   if (ctx->accept_max_blocks < 1) ctx->accept_max_blocks = 1;
   if (const char *e = getenv("LENTIL_SOLVE_BLOCKS")) ctx->solve_max_blocks = atoi(e);
   if (ctx->solve_max_blocks < 1) ctx->solve_max_blocks = 1;
@@ -487,6 +498,8 @@ LENTIL_API int lentil_hip_destroy(lentil_hip_ctx *ctx) {
   (void)hipFree(ctx->d_ctr);
   if (ctx->h_ctr_pinned) (void)hipHostFree(ctx->h_ctr_pinned);
   (void)hipFree(ctx->d_ranges);
+  (void)hipFree(ctx->d_live);
+  (void)hipFree(ctx->d_ext_q);
   (void)hipFree(ctx->d_xor); (void)hipFree(ctx->d_tlc_res); (void)hipFree(ctx->d_tlc_off); (void)hipFree(ctx->d_tlc_tasks);
   (void)hipFree(ctx->d_log);
   for (auto &ev : ctx->ev) if (ev) (void)hipEventDestroy(ev);
@@ -1625,6 +1638,7 @@ static int redistribute_streamed(lentil_hip_ctx *ctx, bool *streamed) {
     HIP_TRY(ctx, hipMemsetAsync(ch.tasks[1], 0, ch.task_cap * sizeof(Task), ctx->stream));
     if (ctx->d_ranges) HIP_TRY(ctx, hipMemsetAsync(ctx->d_ranges, 0, ctx->range_cap * sizeof(uint64_t), ctx->stream));
     if (ch.slow) HIP_TRY(ctx, hipMemsetAsync(ch.slow, 0, ch.slow_cap * sizeof(SlowRec), ctx->stream));
+    if (ctx->d_ext_q) HIP_TRY(ctx, hipMemsetAsync(ctx->d_ext_q, 0, ctx->ext_q_cap * sizeof(Task), ctx->stream));
   }
   const uint32_t retries = (uint32_t)(P.vignetting_retries < 0 ? 0 : P.vignetting_retries);
   const bool few = ctx->est_sum_total < ctx->slow_below;
@@ -1756,6 +1770,29 @@ static int redistribute_streamed(lentil_hip_ctx *ctx, bool *streamed) {
   da.producers_done = &ctx->d_ctr->publishers_done;
   da.producers_total = (uint32_t)ctx->publish_waves;
   pa.end_tasks = a_blocks * 4u + b_blocks * (b_threads / 64u);       // every first-round solve wave may hold one ticket past the last task
+  // Extension (ItemLive, lentil_kernels.h): the first round's solve kernel appends the batches its items still need
+  const bool extend = ctx->extend && decoupled && nch == 1 && ctx->chain_streams;
+  if (extend) {
+    if (ch.item_cap > ctx->live_cap) {
+      if ((rc = grow(ctx, &ctx->d_live, ch.item_cap))) return rc;
+      ctx->live_cap = ch.item_cap;
+    }
+    if (ch.task_cap > ctx->ext_q_cap) {
+      if ((rc = grow(ctx, &ctx->d_ext_q, ch.task_cap))) return rc;
+      ctx->ext_q_cap = ch.task_cap;
+      HIP_TRY(ctx, hipMemsetAsync(ctx->d_ext_q, 0, ch.task_cap * sizeof(Task), ctx->stream));       // (slots are told by their tag)
+      HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    const unsigned keepers = a_blocks < (unsigned)ctx->num_cu ? a_blocks : (unsigned)ctx->num_cu;       // one block per CU stays
+    pub.live = ctx->d_live;
+    pub.ext_q = ctx->d_ext_q;
+    pub.ext_keepers = keepers * 4u;
+    da.live = ctx->d_live;
+    da.ext_q = ctx->d_ext_q;
+    da.ext_keeper_blocks = keepers;
+    da.ext_end_tasks = keepers * 4u;
+    da.ext_slack = 4u;
+  }
   HIP_TRY(ctx, hipStreamWaitEvent(ctx->pub_stream, ctx->ev[0], 0));
   hipLaunchKernelGGL(publish_kernel, dim3((unsigned)ctx->publish_waves), dim3(64), 0, ctx->pub_stream, pa);
   HIP_TRY(ctx, hipGetLastError());
@@ -1776,6 +1813,7 @@ static int redistribute_streamed(lentil_hip_ctx *ctx, bool *streamed) {
   const uint64_t acc_want = ctx->est_items_total + ctx->est_items_total / 4 + 1;
   const unsigned accept_blocks = (unsigned)(acc_want > acc_max ? acc_max : acc_want);
   hipStream_t tail = ctx->stream;       // the stream the pass's last kernels and its counter read-back are on
+  bool lean = false;                    // lean tail (below): no second round in flight
   if (decoupled && ctx->chain_streams) {
     // ---- the decoupled pass with its chain of kernels laid along streams: a dependency that crosses streams costs
     // 40-90 us (event, barrier packet, a queue waking up) where a kernel behind its predecessor on ONE stream costs ~2:
@@ -1792,9 +1830,11 @@ static int redistribute_streamed(lentil_hip_ctx *ctx, bool *streamed) {
     HIP_TRY(ctx, hipStreamWaitEvent(ch.stream, ctx->pub_done, 0));       // (both long past when A ends)
     HIP_TRY(ctx, hipStreamWaitEvent(ch.stream, ctx->scans_done, 0));
     HIP_TRY(ctx, hipEventRecord(ctx->ev_round, ch.stream));
+    const bool lean_pass = extend && ctx->lean_tail && ctx->lean_ok && blind_rounds <= 2;
     {
       DrawArgs d0 = da;
-      d0.emit_live = 1;
+      d0.emit_live = lean_pass ? 0 : 1;       // (lean tail: nobody is waiting for tasks)
+      d0.lean_defer = lean_pass ? 1 : 0;
       d0.end_tasks = (uint32_t)ctx->num_cu * 4u;
       hipLaunchKernelGGL(accept_kernel<1>, dim3(accept_blocks), dim3(256), 0, ch.stream, d0);
       HIP_TRY(ctx, hipGetLastError());
@@ -1807,6 +1847,31 @@ static int redistribute_streamed(lentil_hip_ctx *ctx, bool *streamed) {
       HIP_TRY(ctx, hipEventRecord(ctx->ev_res, rs));
       ctx->early_resolve_pending = true;
     }
+    // Lean tail (extension, ItemLive): the first round's solve kernel has appended what its items needed, so the first accept
+    // is expected to schedule nothing -- no second round's solve and straggler kernels, no waiting for them: the accept of the
+    // items that met parked solves follows the first accept on its stream, behind the first round's stragglers.  Should the
+    // first accept have scheduled tasks after all, that accept does nothing (DrawArgs::lean_gate) and the round is run below.
+    lean = lean_pass;
+    if (lean) {
+      hipStream_t ls = ch.stream;
+      da.parity = 1; da.round = 1;
+      HIP_TRY(ctx, hipStreamWaitEvent(ls, ctx->ev_slow, 0));      // the first round's stragglers
+      hipLaunchKernelGGL(reset_round_kernel, dim3(1), dim3(1), 0, ls, ctx->d_ctr, 0u, 1u);
+      {
+        DrawArgs d2 = da;
+        d2.lean_gate = 1;
+        d2.slow_indirect = 0; d2.slow_cap = slow_cap_all; d2.slow_live = 0;
+        hipLaunchKernelGGL(accept_kernel<2>, dim3(accept_blocks), dim3(256), 0, ls, d2);
+      }
+      HIP_TRY(ctx, hipGetLastError());
+      da.slow_indirect = 0; da.slow_cap = slow_cap_all; da.slow_live = 0;
+      if (ctx->early_resolve_pending) {
+        HIP_TRY(ctx, hipStreamWaitEvent(ls, ctx->ev_res, 0));
+        if ((rc = launch_resolve_half(ctx, ls, 1u))) return rc;
+        ctx->late_resolve_done = true;
+      }
+      tail = ls;
+    } else {
     for (int round = 1; round < blind_rounds; ++round) {
       da.parity = round & 1; da.round = round;
       DrawArgs d1 = da;
@@ -1860,6 +1925,7 @@ static int redistribute_streamed(lentil_hip_ctx *ctx, bool *streamed) {
       ctx->late_resolve_done = true;
     }
     tail = ps;
+    }
   } else {
   // B: the rest of the CUs' room, once the scan's waves have left
   da.instance = 1;
@@ -2003,6 +2069,30 @@ static int redistribute_streamed(lentil_hip_ctx *ctx, bool *streamed) {
     ch.have_est = true; ch.est_items = n_items; ch.est_sum = c.sum_samples; ch.est_rounds = (int)c.rounds_used;
     if (c.tries) { ctx->mean_iters = (double)c.newton_iters / (double)c.tries; ctx->parked_frac = (double)c.slow_solves / (double)c.tries; }
     int rounds = blind_rounds;
+    if (extend) ctx->lean_ok = c.n_tasks[1] == 0u;       // (what the next pass may count on)
+    if (lean && n_items && c.n_tasks[1] != 0u) {
+      // The lean tail's bet was lost: the first accept scheduled tasks, the accept behind it did nothing.  The round the
+      // ordinary way -- its solves (the queue is complete), their stragglers, the accept that was held back -- then whatever
+      // rounds follow.  (Rare: an item whose estimate in the solve kernel was too kind; ~0.3 ms.)
+      ctx->h_ctr_valid = false;
+      ctx->late_resolve_done = false;
+      da.parity = 1; da.round = 1;
+      da.producers_done = nullptr; da.producers_total = 0;
+      da.slow_live = 0; da.slow_indirect = 0; da.slow_q = -1; da.slow_round = -1; da.slow_close = 1;
+      da.emit_live = 0; da.lean_gate = 0; da.no_reset = 1;
+      {
+        DrawArgs dr = da;       // (its parked solves go to the upper half of the records: the lower half holds the first round's results)
+        if (dr.slow) { dr.slow = slow_base + slow_cap_all / 2u; dr.slow_cap = slow_cap_all - slow_cap_all / 2u; }
+        launch_solve(ctx, dr, ch.stream, (unsigned)ctx->num_cu);
+      }
+      hipLaunchKernelGGL(reset_round_kernel, dim3(1), dim3(1), 0, ch.stream, ctx->d_ctr, 0u, 1u);
+      hipLaunchKernelGGL(accept_kernel<2>, dim3(accept_blocks), dim3(256), 0, ch.stream, da);
+      HIP_TRY(ctx, hipGetLastError());
+      da.no_reset = 0;
+      if ((rc = finish_rounds(ctx, 0, da, 2, &rounds))) return rc;
+      if (rounds > ch.est_rounds) ch.est_rounds = rounds;
+      ++ctx->n_lean_lost;
+    } else
     if (n_items && c.n_active[blind_rounds & 1] != 0) {
       ctx->h_ctr_valid = false;
       ctx->late_resolve_done = false;

@@ -50,6 +50,10 @@ struct DevCounters {
   unsigned int stuck, tile_next;       // a wave gave up waiting for its queue slot (kStuckTicks): the pass is void; scan_dma_kernel's tile cursor
   // a candidate for a closest-filtered AOV came with |Z| == 0 or NaN (closest_key_of): the pass is refused, see there
   unsigned int degenerate_depth, pad_;
+  // Streamed pass with extension (ItemLive): items whose current batch is not complete yet / the task queue has its end
+  // markers / tasks and items the solve waves added themselves
+  unsigned int items_open, queue_final, ext_tasks, ext_items;
+  unsigned int ext_n, ext_head, pad2_[2];        // the extension's own task queue (DrawArgs::ext_q): tasks appended / tickets drawn
 };
 
 // per-thread running row range -> one pair of atomics per wave
@@ -169,6 +173,33 @@ struct ItemProg {         // 48 B, progress of an item across rounds
   uint32_t n_end1;        // attempts the first accept looked at
 };
 
+// Streamed pass, "extension" (round 4).  An item near the frame's edge loses attempts to draws that land outside the frame
+// and needs more than its first batch -- 33 of the headline frame's 1 168 items, 3 % more solves -- and the round that
+// used to serve them (first accept -> tasks -> solves -> their stragglers -> second accept) was 0.4 ms of latency at the
+// end of a 2 ms pass.  Now the first round's solve kernel looks after them itself: every result it delivers is counted per
+// item (one returning atomic per item and wave flush), and the wave that delivers the LAST result of an item's batch
+// compares the successes with what the item needs; if they fall short it appends the next batch's tasks to the very queue
+// it is working on -- sized like accept_next_batch would, from the item's own success rate -- and the item stays open.
+// The queue's end markers are written when the last publisher has signed off AND no item is open (whoever sees both).
+// The result pool holds 5 x samples + retries slots per item from the start, so an item's batches stay contiguous; the
+// first accept takes the batch's end from here.  What it then finds missing (an estimate that was too kind) still goes
+// the old way.  One 32-byte record per item, written through (another CU's waves read it while the kernel runs).
+// MEASURED (round 4, headline frame) AND OFF BY DEFAULT (LENTIL_EXTEND=1 switches it on): draw lists stay bit-identical, the
+// second round disappears (811 appended tasks, no item short in the accept) -- and the pass takes 2.30 ms instead of 2.00.
+// The second round was never idle time: the item found last by the scan needs its first batch (0.15 ms), the batch
+// behind it (0.15 ms) and that batch's slowest solves (100 Newton iterations: 0.25-0.35 ms on a straggler wave) one after
+// the other whoever schedules them, and the old layout runs the first accept of the other 1 100 items BESIDE that chain,
+// this one behind it.
+// The appended batches have a queue of their own (DrawArgs::ext_q), served by the solve kernel's first `ext_keeper_blocks`
+// blocks once the main queue has ended: the other blocks leave as they always did -- the straggler kernel's waves are only
+// placed when solve waves leave -- and the main queue's end does not wait for the items near the frame's edge.
+struct ItemLive {
+  unsigned long long cnt;        // results delivered so far: count (bits 0-20), pixels (21-41), outside the frame (42-62)
+  unsigned long long hi_s;       // R(m) issued so far: [0, m_hi) (low word), samples (high word)
+  uint32_t res_off, pad[3];
+};
+static_assert(sizeof(ItemLive) == 32, "ItemLive is 32 bytes");
+
 struct Task {             // up to 64 consecutive m of one item (and one wavelength channel)
   uint32_t item, m_base, res_off, count;   // count: bits 0-7 number of m, bits 8-9 channel
 };
@@ -195,6 +226,9 @@ struct StreamPub {
   ItemProg *prog;
   uint32_t *active0;
   Task *tasks0;
+  ItemLive *live;              // non-null: extension (ItemLive)
+  Task *ext_q;                 // ... its task queue and the waves that serve it (end markers)
+  uint32_t ext_keepers;
 };
 
 // Hand-off words are written with atomics as well (exchange, nothing returned): "8-byte agent-scope atomics on both
@@ -203,6 +237,9 @@ struct StreamPub {
 // with atomics, never saw).
 LD_DEV void st_agent64(void *p, uint64_t v) {
   (void)__hip_atomic_exchange(reinterpret_cast<uint64_t *>(p), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+LD_DEV void st_agent32(void *p, uint32_t v) {
+  (void)__hip_atomic_exchange(reinterpret_cast<uint32_t *>(p), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 // Reads of words another CU writes while this kernel runs are returning atomics (x | 0), not loads: an agent-scope
 // load (sc1) goes past this CU's L1 but is served by this XCD's L2, which may hold the line from before the other
@@ -390,9 +427,11 @@ LD_DEV void publish_item(const lentil_params &P, const VisitsDev &V, const Strea
   const uint32_t retries = (uint32_t)S.retries, nch = S.n_channels;
   const uint32_t count = first_batch_hi(wi.y, retries, S.extra_num, S.extra_const);
   const uint32_t nt = (count + 63u) / 64u;
-  const unsigned long long off = atomicAdd(&ctr->pool_used[0], (unsigned long long)count * nch);
+  // (extension: room for every R(m) the item can ever ask for, so that later batches lie behind the first)
+  const uint32_t reserve = S.live ? wi.y * 5u + retries : count;
+  const unsigned long long off = atomicAdd(&ctr->pool_used[0], (unsigned long long)reserve * nch);
   const uint32_t tb = atomicAdd(&ctr->n_tasks[0], nt * nch);
-  const bool ok = item < S.item_cap && off + (unsigned long long)count * nch <= S.pool_cap &&
+  const bool ok = item < S.item_cap && off + (unsigned long long)reserve * nch <= S.pool_cap &&
                   (unsigned long long)tb + nt * nch <= S.task_cap;
   if (!ok) ctr->fallback = 1ull;
   if (item < S.item_cap) {
@@ -413,6 +452,13 @@ LD_DEV void publish_item(const lentil_params &P, const VisitsDev &V, const Strea
     pg.res_off = (uint32_t)off;
     S.prog[item] = pg;
     S.active0[item] = item;
+    if (S.live && ok) {
+      ItemLive *L = S.live + item;
+      st_agent64(&L->cnt, 0ull);
+      st_agent64(&L->hi_s, (uint64_t)count | ((uint64_t)(wi.y & 0xFFFFu) << 32));
+      st_agent32(&L->res_off, (uint32_t)off);
+      atomicAdd(&ctr->items_open, 1u);
+    }
   }
   // the header must have arrived before a task that names the item can be seen
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1848,12 +1894,26 @@ __global__ __launch_bounds__(64) void publish_kernel(PublishArgs a) {
   uint32_t last = 0;
   if (lane == 0) last = atomicAdd(&a.ctr->publishers_done, 1u) == gridDim.x - 1u ? 1u : 0u;
   if (!__builtin_amdgcn_readfirstlane(last)) return;
-  // the last publisher: the task queue is complete.  One end marker for every solve wave that may hold a ticket.
+  // the last publisher: the task queue is complete -- unless items are still open (extension, ItemLive): then whoever
+  // closes the last of them writes the markers (live_close_queue)
+  // One end marker for every solve wave that may hold a ticket.
   const uint32_t n = ld_coherent32(&a.ctr->n_tasks[0]);
   for (uint32_t i = lane; i < a.end_tasks; i += 64u)
     if ((uint64_t)n + i < a.S.task_cap)
       st_agent64(reinterpret_cast<uint64_t *>(a.S.tasks0 + n + i) + 1,
                  (uint64_t)(kEndCount | (a.S.epoch << kTaskTagShift)) << 32);
+  // extension (ItemLive): its queue ends when no item is open any more -- now, or when a solve wave closes the last one
+  if (a.S.live) {
+    uint32_t open = 0;
+    if (lane == 0) open = ld_coherent32(&a.ctr->items_open);
+    if (__builtin_amdgcn_readfirstlane(open) != 0u) return;
+    if (lane == 0) st_agent32(&a.ctr->queue_final, 1u);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const uint32_t ne = ld_coherent32(&a.ctr->ext_n);
+    for (uint32_t i = lane; i < a.S.ext_keepers; i += 64u)
+      if ((uint64_t)ne + i < a.S.task_cap)
+        st_agent64(reinterpret_cast<uint64_t *>(a.S.ext_q + ne + i) + 1, (uint64_t)(kEndCount | (a.S.epoch << kTaskTagShift)) << 32);
+  }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1979,18 +2039,37 @@ struct DrawArgs {
   int32_t slow_dry_only;      // live queue: park as a plain round does (waves running dry, their last slow_max_lanes lanes)
   int32_t slow_crowd_stays;   // live queue: where more than slow_max_lanes lanes of a wave are past slow_at at once, none is parked
   int32_t accept_narrow;      // accept kernels: 256-attempt steps (accept_item) where accept_item_wide would apply
+  ItemLive *live;             // streamed pass with extension (ItemLive): the first round's solve kernel and the first accept
+  Task *ext_q;                // ... the queue of the batches it appends, served by its first ext_keeper_blocks blocks
+  uint32_t ext_keeper_blocks;
+  uint32_t ext_end_tasks;     // ... end markers behind that queue (one per wave of those blocks)
+  uint32_t ext_slack;         // ... successes beyond `samples` an item's results must show before it counts as served
+  // Lean tail of a streamed pass with extension: no second round's solve kernels are in flight.  The accept behind the first
+  // one (accept_kernel<2>) does nothing if the first one had to schedule tasks after all (n_tasks of its parity): the host then
+  // runs that round the ordinary way and this accept after it.
+  int32_t lean_gate;
+  int32_t lean_defer;         // ... and the first accept leaves an item that met parked solves to that accept whole: what it still
+                              // needs is decided there, from the stragglers' results
 };
 LD_DEV uint32_t slow_queue(const DrawArgs &a) { return a.slow_q >= 0 ? (uint32_t)a.slow_q : (uint32_t)a.parity; }
 LD_DEV uint64_t slow_tag(const DrawArgs &a, uint64_t what) {
   const uint32_t r = a.slow_round >= 0 ? (uint32_t)a.slow_round : (uint32_t)a.round;
   return ((uint64_t)((a.epoch << 8) | (r & 0xFFu)) << 32) | what;
 }
-LD_DEV void st_agent32(void *p, uint32_t v) {
-  (void)__hip_atomic_exchange(reinterpret_cast<uint32_t *>(p), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
 
 LD_DEV ItemVisit load_item_visit(const DrawArgs &a, uint32_t item, double lens_length) {
   return load_work_visit(a.P, a.V, a.work[item], lens_length);
+}
+
+// an item's progress record as an accept kernel takes it: with extension (ItemLive) the first round's batch ends where
+// the solve kernel's last appended batch does
+LD_DEV ItemProg load_prog(const DrawArgs &a, uint32_t item) {
+  ItemProg pg = a.prog[item];
+  if (a.live && a.round == 0) {
+    const uint32_t hi = (uint32_t)a.live[item].hi_s;       // (low word: the batch's end; flags sit in the high word)
+    if (hi > pg.m_hi && pg.m_hi != 0u) pg.m_hi = hi;
+  }
+  return pg;
 }
 
 // emit the solve tasks for m in [m_lo, m_hi) of `item` into the queues of round parity `par`
@@ -2103,6 +2182,100 @@ LD_DEV uint32_t solve_result(const lentil_params &P, const LensT &L, const Newto
   return po_sensor_to_pixel(P, sx, sy, pix) ? pix : kCodeOut;
 }
 
+// ---- extension (ItemLive): results delivered, batches closed, queues ended ----------------------------------------
+// One lane reports `cnt` results of `item`, `okc` of them pixels.  Returns 0, or 1 if that closed the LAST open item while
+// the publishers have all signed off: the caller's wave then writes the queue's end markers (live_close_queue).
+constexpr uint64_t kLiveEarly = 1ull << 62, kLiveClosed = 1ull << 63;     // ItemLive::hi_s flags
+constexpr uint32_t kLiveEarlyAt = 256u;                                    // results after which an item is first looked at
+LD_DEV bool cas64(unsigned long long *p, unsigned long long expect, unsigned long long desired) {
+  return atomicCAS(p, expect, desired) == expect;
+}
+// append R(m_hi .. new_hi) of `item` to the extension's queue (the caller has moved ItemLive::hi_s to new_hi)
+LD_DEV void live_emit(const DrawArgs &a, ItemLive *L, uint32_t item, uint32_t m_hi, uint32_t new_hi) {
+  const uint32_t count = new_hi - m_hi, nt = (count + 63u) / 64u;
+  const uint32_t tb = atomicAdd(&a.ctr->ext_n, nt);
+  const bool fits = (unsigned long long)tb + nt + a.ext_end_tasks <= a.task_cap;
+  if (!fits) atomicAdd(&a.ctr->overflow, 1ull);        // (the queue is as long as the main one: not reached; the pass would be void)
+  const uint32_t res0 = ld_coherent32(&L->res_off);
+  for (uint32_t t = 0; t < nt && fits; ++t) st_agent64(a.ext_q + tb + t, (uint64_t)item | ((uint64_t)(m_hi + t * 64u) << 32));
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  for (uint32_t t = 0; t < nt && fits; ++t) {
+    const uint32_t c = (count - t * 64u) < 64u ? (count - t * 64u) : 64u;
+    st_agent64(reinterpret_cast<uint64_t *>(a.ext_q + tb + t) + 1,
+               (uint64_t)(res0 + m_hi + t * 64u) | ((uint64_t)(c | (a.epoch << kTaskTagShift)) << 32));
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  atomicAdd(&a.ctr->ext_tasks, nt);
+  atomicAdd(&a.ctr->ext_items, 1u);
+}
+LD_DEV uint32_t live_deliver(const DrawArgs &a, uint32_t item, uint32_t cnt, uint32_t okc, uint32_t outc) {
+  ItemLive *L = a.live + item;
+  const unsigned long long old = atomicAdd(&L->cnt, (unsigned long long)cnt | ((unsigned long long)okc << 21) | ((unsigned long long)outc << 42));
+  const uint32_t done0 = (uint32_t)old & 0x1FFFFFu;
+  const uint32_t done = done0 + cnt, ok = ((uint32_t)(old >> 21) & 0x1FFFFFu) + okc, out = ((uint32_t)(old >> 42) & 0x1FFFFFu) + outc;
+  const unsigned long long hs = ld_coherent64(&L->hi_s);
+  const uint32_t m_hi = (uint32_t)hs, S = (uint32_t)(hs >> 32) & 0xFFFFu;
+  const uint32_t retries = (uint32_t)a.retries, m_limit = S * 5u + retries;
+  const uint32_t n = m_hi - retries;          // attempts the issued results cover
+  if (done != m_hi) {
+    // Not the batch's last result.  The first look at an item, after kLiveEarlyAt of its results: where those say that the
+    // batch will fall short -- an attempt is decided by the first of its tries that is not vignetted, a pixel or a point
+    // outside the frame, so about n * pixels / (pixels + outside) of n attempts succeed -- the rest is appended NOW, beside
+    // the batch, not behind it (behind it the items found last ended the pass 0.2 ms later).  Sized from the lower end of what
+    // the sample allows (two standard deviations), + 10 % + 32.
+    if (done0 < kLiveEarlyAt && done >= kLiveEarlyAt && !(hs & (kLiveEarly | kLiveClosed)) && ok + out >= 32u && m_hi < m_limit) {
+      const float k = (float)(ok + out), f = (float)ok / k;
+      float f_lo = f - 2.0f * sqrtf(f * (1.0f - f) / k);
+      if (f_lo < 0.02f) f_lo = 0.02f;
+      if ((float)n * f_lo < (float)(S + a.ext_slack)) {
+        float want = (float)(S + a.ext_slack) / f_lo;
+        want = want * 1.1f + 32.0f + (float)retries;
+        const uint32_t new_hi = want >= (float)m_limit ? m_limit : (uint32_t)want;
+        if (new_hi > m_hi && cas64(&L->hi_s, hs, (hs & 0xFFFFFFFF00000000ull) | (unsigned long long)new_hi | kLiveEarly))
+          live_emit(a, L, item, m_hi, new_hi);
+      }
+    }
+    return 0u;
+  }
+  // The batch is complete (parked solves are not known yet and count as neither pixel nor outside).  Served when the
+  // estimate is ext_slack beyond `samples`; else the next batch, sized like accept_next_batch does it.
+  uint32_t est = (ok + out) ? (uint32_t)(((unsigned long long)n * ok) / (ok + out)) : 0u;
+  {
+    // ... less the attempts all of whose tries are vignetted (a share f of the results fails in the lens or is still parked: f to
+    // the power of retries + 1 of the attempts), and 1 % for what the counts cannot know
+    const float f = done ? (float)(done - ok - out) / (float)done : 0.0f;
+    float lost = 1.0f;
+    for (uint32_t t = 0; t <= retries && t < 32u; ++t) lost *= f;
+    const float e2 = (float)est * (1.0f - lost) - 0.01f * (float)S;
+    est = e2 > 0.0f ? (uint32_t)e2 : 0u;
+  }
+  if (est < S + a.ext_slack && m_hi < m_limit) {
+    const uint32_t remaining = S + a.ext_slack - est;
+    unsigned long long need = est ? ((unsigned long long)remaining * n + est - 1u) / est : (unsigned long long)(m_limit - m_hi);
+    need += need / 4u + 32u;
+    unsigned long long hi2 = (unsigned long long)m_hi + need;
+    if (hi2 > m_limit) hi2 = m_limit;
+    if (cas64(&L->hi_s, hs, (hs & 0xFFFFFFFF00000000ull) | hi2)) live_emit(a, L, item, m_hi, (uint32_t)hi2);
+    return 0u;                              // the item stays open (or somebody else has just moved its end)
+  }
+  // served (or out of attempts): the item is closed -- unless its end has just been moved
+  if (!cas64(&L->hi_s, hs, hs | kLiveClosed)) return 0u;
+  const uint32_t open_before = atomicSub(&a.ctr->items_open, 1u);
+  if (open_before != 1u) return 0u;
+  return ld_coherent32(a.producers_done) >= a.producers_total ? 1u : 0u;
+}
+// all lanes of a wave: the end markers behind the extension's task queue
+LD_DEV void live_close_queue(const DrawArgs &a, uint32_t lane) {
+  if (lane == 0) st_agent32(&a.ctr->queue_final, 1u);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  uint32_t n = 0;
+  if (lane == 0) n = ld_coherent32(&a.ctr->ext_n);
+  n = (uint32_t)__builtin_amdgcn_readfirstlane((int)n);
+  for (uint32_t i = lane; i < a.ext_end_tasks; i += 64u)
+    if ((uint64_t)n + i < a.task_cap)
+      st_agent64(reinterpret_cast<uint64_t *>(a.ext_q + n + i) + 1, (uint64_t)(kEndCount | (a.epoch << kTaskTagShift)) << 32);
+}
+
 // ---- solve, polynomial optics ------------------------------------------------------------------
 // kChroma: tasks carry a wavelength channel (src/lentil_filter.cpp:255-268); every lane then reads the lens
 // header through its own pointer into three LDS copies that differ in the lambda powers only.
@@ -2132,6 +2305,7 @@ __global__ __launch_bounds__(256) LENTIL_SOLVE_ATTR void solve_po_kernel(DrawArg
   __shared__ double s_ap[4][64][2];
   __shared__ double s_fin[4][6][64];                  // x, y, dx, dy, out[0], out[1]
   __shared__ uint32_t s_fin_err[4][64], s_fin_res[4][64];      // error bits | channel << 8; result slot
+  __shared__ uint32_t s_fin_item[4][64];                       // extension (ItemLive): whose result it is
   if (kTables) {
     const uint32_t nt = a.lens->n_terms;
     for (uint32_t i = threadIdx.x; i < nt; i += blockDim.x) s_terms[i] = a.terms[i];
@@ -2176,9 +2350,17 @@ __global__ __launch_bounds__(256) LENTIL_SOLVE_ATTR void solve_po_kernel(DrawArg
   (void)ticket; (void)polls; (void)ticket_t0; (void)idle_naps;
   // per-lane solve
   bool busy = false;
-  uint32_t res_idx = 0, cur_chan_lane = 0;
+  uint32_t res_idx = 0, cur_chan_lane = 0, my_item = 0;
   (void)cur_chan_lane;
   const uint32_t wv = threadIdx.x >> 6;
+  // extension (ItemLive): the first round of a streamed pass counts what it delivers per item and appends batches itself
+  const bool extend = kStream && !kChroma && a.live != nullptr && a.round == 0;
+  bool close_queue = false;      // this wave closed the last open item: it writes the queue's end markers
+  const bool keeper = extend && blockIdx.x < a.ext_keeper_blocks;
+  bool on_ext = false;
+  const Task *tq = a.tasks[(uint32_t)a.parity];
+  unsigned int *tq_head = &a.ctr->task_head[(uint32_t)a.parity];
+  (void)keeper; (void)on_ext; (void)tq; (void)tq_head;
   uint32_t cur_pos = 0;        // wave-uniform: units of the current task handed out so far (index into s_ap)
   uint32_t fin_n = 0;          // wave-uniform: finished solves waiting in s_fin
   // the finished solves of the queue, one per lane: the tail of trace_ray_bw_po + sensor -> pixel (solve_result)
@@ -2187,6 +2369,8 @@ __global__ __launch_bounds__(256) LENTIL_SOLVE_ATTR void solve_po_kernel(DrawArg
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
+    bool fin_ok = false, fin_out = false;
+    uint32_t fin_item = 0;
     if (lane < fin_n) {
       NewtonState t;
       t.x = s_fin[wv][0][lane]; t.y = s_fin[wv][1][lane]; t.dx = s_fin[wv][2][lane]; t.dy = s_fin[wv][3][lane];
@@ -2196,11 +2380,31 @@ __global__ __launch_bounds__(256) LENTIL_SOLVE_ATTR void solve_po_kernel(DrawArg
       t.error = (int)(ew & 0xFFu);
       LensT Lf = L;
       if constexpr (kChroma) Lf.k = &s_kc[(ew >> 8) & 3u];
-      res[s_fin_res[wv][lane]] = solve_result(P, Lf, t);
+      const uint32_t code = solve_result(P, Lf, t);
+      res[s_fin_res[wv][lane]] = code;
+      fin_ok = code < kCodePendingBase;
+      fin_out = code == kCodeOut;
+      fin_item = s_fin_item[wv][lane];
+    }
+    if (extend) {
+      // per item of the queue: how many results, how many of them pixels / outside the frame (usually one or two items)
+      unsigned long long todo = __ballot(lane < fin_n);
+      const unsigned long long okm = __ballot(lane < fin_n && fin_ok), outm = __ballot(lane < fin_n && fin_out);
+      while (todo) {
+        const int leader = __builtin_ctzll(todo);
+        const uint32_t it = (uint32_t)__builtin_amdgcn_readlane((int)fin_item, leader);
+        const unsigned long long same = __ballot(lane < fin_n && fin_item == it) & todo;
+        uint32_t r = 0;
+        if ((int)lane == leader)
+          r = live_deliver(a, it, (uint32_t)__builtin_popcountll(same), (uint32_t)__builtin_popcountll(same & okm), (uint32_t)__builtin_popcountll(same & outm));
+        if (__ballot(r != 0u)) close_queue = true;
+        todo &= ~same;
+      }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
     __builtin_amdgcn_wave_barrier();
     fin_n = 0u;
+    if (close_queue) { live_close_queue(a, lane); close_queue = false; }       // (wherever the flush was called from)
   };
   // a task has been taken (cur_* set, its header in s_hdr[wv]): the aperture draws of all its units at once --
   // the reference's try with seed (seed_a, m), src/lentil.h:596-609
@@ -2240,14 +2444,14 @@ __global__ __launch_bounds__(256) LENTIL_SOLVE_ATTR void solve_po_kernel(DrawArg
         if constexpr (kStream) {
           if (ticket == kNoTicket) {
             uint32_t q = 0;
-            if (lane == 0) q = atomicAdd(&a.ctr->task_head[par], 1u);
+            if (lane == 0) q = atomicAdd(tq_head, 1u);
             ticket = __builtin_amdgcn_readfirstlane(q);
             polls = 0;
             ticket_t0 = __builtin_amdgcn_s_memrealtime();
           }
           if (ticket >= a.task_cap) { no_more = true; break; }
           uint64_t w1 = 0;
-          if (lane == 0) w1 = ld_coherent64(reinterpret_cast<const uint64_t *>(tasks + ticket) + 1);
+          if (lane == 0) w1 = ld_coherent64(reinterpret_cast<const uint64_t *>(tq + ticket) + 1);
           const uint32_t w1_hi = __builtin_amdgcn_readfirstlane((uint32_t)(w1 >> 32));
           if ((w1_hi >> kTaskTagShift) != a.epoch) {
             if (lane == 0) tl_add(TL_POLLS_EMPTY, 1u);
@@ -2258,9 +2462,14 @@ __global__ __launch_bounds__(256) LENTIL_SOLVE_ATTR void solve_po_kernel(DrawArg
             }
             break;
           }
-          if ((w1_hi & 0xFFu) == kEndCount) { no_more = true; break; }      // behind the last task
+          if ((w1_hi & 0xFFu) == kEndCount) {      // behind the last task
+            // (extension: the first blocks of the launch go on with the queue of the batches the solve waves append)
+            if (keeper && !on_ext) { on_ext = true; tq = a.ext_q; tq_head = &a.ctr->ext_head; ticket = kNoTicket; continue; }
+            no_more = true;
+            break;
+          }
           uint64_t w0 = 0;
-          if (lane == 0) w0 = ld_coherent64(reinterpret_cast<const uint64_t *>(tasks + ticket));
+          if (lane == 0) w0 = ld_coherent64(reinterpret_cast<const uint64_t *>(tq + ticket));
           cur_item = __builtin_amdgcn_readfirstlane((uint32_t)w0);
           cur_m = __builtin_amdgcn_readfirstlane((uint32_t)(w0 >> 32));
           cur_res = __builtin_amdgcn_readfirstlane((uint32_t)w1);
@@ -2311,10 +2520,14 @@ __global__ __launch_bounds__(256) LENTIL_SOLVE_ATTR void solve_po_kernel(DrawArg
         newton_init(s);
         ++st_tries;
         busy = true;
+        my_item = cur_item;
         if constexpr (kChroma) { L.k = &s_kc[cur_chan]; cur_chan_lane = cur_chan; }
       }
       cur_pos += take; cur_res += take; cur_left -= take; filled += take;
     }
+    // (extension: an item's batch is judged when its last result is DELIVERED -- a wave that found no work for its idle lanes
+    // delivers what it holds at once, however little: the SIMD has nothing better to do then)
+    if (extend && fin_n && filled < n_idle) flush_finished();
     if (inflight + filled == 0u) {
       flush_finished();
       if (!kStream || no_more) break;
@@ -2322,7 +2535,7 @@ __global__ __launch_bounds__(256) LENTIL_SOLVE_ATTR void solve_po_kernel(DrawArg
       // L2 channel that holds the queue busy enough to hold up every DMA group of the scan that touches it
       // (measured: scan 0.95 -> 2.6 ms beside 1024 idle waves polling every ~2 us).  4 us, doubling to 30 us.
       for (uint32_t i = 0; i < idle_naps; ++i) __builtin_amdgcn_s_sleep(127);
-      if (idle_naps < 8u) idle_naps <<= 1;
+      if (idle_naps < (on_ext ? 2u : 8u)) idle_naps <<= 1;       // (the extension's queue: a few hundred tasks, latency is all)
       continue;
     }
     idle_naps = 1u;
@@ -2346,6 +2559,7 @@ __global__ __launch_bounds__(256) LENTIL_SOLVE_ATTR void solve_po_kernel(DrawArg
           s_fin[wv][4][q] = s.out[0]; s_fin[wv][5][q] = s.out[1];
           s_fin_err[wv][q] = ((uint32_t)s.error & 0xFFu) | ((kChroma ? cur_chan_lane : 0u) << 8);
           s_fin_res[wv][q] = res_idx;
+          s_fin_item[wv][q] = my_item;
           busy = false;
         }
         fin_n += nfin;
@@ -2379,6 +2593,7 @@ __global__ __launch_bounds__(256) LENTIL_SOLVE_ATTR void solve_po_kernel(DrawArg
       // their lanes they cost the wave a few iterations more.  The crowd thins out by itself, what stays is parked.
       if (a.slow_live && a.slow_crowd_stays && __builtin_popcountll(pmask) > a.slow_max_lanes) pmask = 0ull;
       if (pmask) {
+        bool parked_closed = false;
         const uint32_t sq = slow_queue(a);
         uint32_t base = 0;
         if (lane == (uint32_t)__builtin_ctzll(pmask)) base = atomicAdd(&a.ctr->n_slow[sq], (uint32_t)__builtin_popcountll(pmask));
@@ -2402,6 +2617,8 @@ __global__ __launch_bounds__(256) LENTIL_SOLVE_ATTR void solve_po_kernel(DrawArg
             if (a.slow_indirect) st_agent32(res + res_idx, kCodePendingBase | slot);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             st_agent64(d + 15, slow_tag(a, kSlowRecord));
+            // (extension: a parked solve is delivered -- as a failure, for what the item's batch is judged by)
+            if (extend && live_deliver(a, my_item, 1u, 0u, 0u)) parked_closed = true;
           } else {
             d[0] = target[0]; d[1] = target[1]; d[2] = target[2]; d[3] = ap_x; d[4] = ap_y;
             d[5] = s.x; d[6] = s.y; d[7] = s.dx; d[8] = s.dy; d[9] = s.sqr_err; d[10] = s.sqr_ap_err;
@@ -2410,10 +2627,13 @@ __global__ __launch_bounds__(256) LENTIL_SOLVE_ATTR void solve_po_kernel(DrawArg
           }
           busy = false;
         }
+        if (__ballot(parked_closed)) close_queue = true;
       }
     }
+    if (close_queue) { live_close_queue(a, lane); close_queue = false; }
   }
   flush_finished();
+  if (close_queue) { live_close_queue(a, lane); close_queue = false; }
   if (a.slow_live && a.slow && a.slow_close) {
     // Everything this wave parked has arrived.  The straggler queue is closed by whichever wave finds, on leaving, that
     // every wave that has begun has left and every task has been taken (and, streamed, published): no solve can be
@@ -2427,7 +2647,8 @@ __global__ __launch_bounds__(256) LENTIL_SOLVE_ATTR void solve_po_kernel(DrawArg
       const uint32_t begun = ld_coherent32(&a.ctr->waves_started[par]);
       const uint32_t taken = ld_coherent32(&a.ctr->task_head[par]);
       const uint32_t published = kStream ? ld_coherent32(&a.ctr->n_tasks[par]) : n_tasks;
-      const bool complete = !kStream || ld_coherent32(a.producers_done) >= a.producers_total;
+      const bool complete = !kStream || (ld_coherent32(a.producers_done) >= a.producers_total &&
+                                         (!extend || ld_coherent32(&a.ctr->queue_final) != 0u));
       close = (done == begun && complete && taken >= published) ? 1u : 0u;
     }
     if (__builtin_amdgcn_readfirstlane(close)) {
@@ -3537,7 +3758,7 @@ LD_DEV AcceptResult accept_item_chroma(const DrawArgs &a, AcceptShared &sh, uint
 // run beside the accept that schedules them, DrawArgs::emit_live)
 // kMode: accept_item's -- 1 for the first accept of a decoupled streamed pass, 2 for the one behind it, 0 otherwise.
 #ifndef LENTIL_ACCEPT_EU
-#define LENTIL_ACCEPT_EU 6
+#define LENTIL_ACCEPT_EU 5
 #endif
 template <int kMode>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LENTIL_ACCEPT_EU, LENTIL_ACCEPT_EU))) void accept_kernel(DrawArgs a) {
@@ -3550,6 +3771,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LENTIL_ACCE
   __builtin_amdgcn_s_setprio(LENTIL_ACCEPT_PRIO);
 #endif
   const uint32_t par = (uint32_t)a.parity, nxt = par ^ 1u;
+  if (a.lean_gate && a.ctr->n_tasks[par] != 0u) return;       // (tasks nobody has solved yet: DrawArgs::lean_gate)
   // (a streamed or blind pass whose buffers were too small: nothing is accepted, the host redoes the draws)
   const uint32_t n_active = (a.ctr->fallback || a.ctr->stuck) ? 0u : a.ctr->n_active[par];
   if (blockIdx.x == 0 && threadIdx.x == 0 && n_active) atomicMax(&a.ctr->rounds_used, (unsigned long long)(a.round + 1));
@@ -3586,7 +3808,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LENTIL_ACCE
       np_.n_end1 = r.prog.n_done;
       np_.p_lo = pg.m_lo; np_.p_hi = pg.m_hi; np_.p_off = pg.res_off;
       np_.m_lo = np_.m_hi = pg.m_hi; np_.res_off = 0;
-      if (!emitted && r.more) { emitted = emit_tasks(a, nxt, item, r.new_lo, r.new_hi, off); emitted_hi = r.new_hi; }
+      if (!emitted && r.more && !a.lean_defer) { emitted = emit_tasks(a, nxt, item, r.new_lo, r.new_hi, off); emitted_hi = r.new_hi; }
       if (emitted) { np_.m_hi = emitted_hi; np_.res_off = off; }
       a.prog[item] = np_;
       const uint32_t slot = atomicAdd(&a.ctr->n_active[nxt], 1u);
@@ -3619,7 +3841,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LENTIL_ACCE
     if (wide) {
       for (uint32_t j = 0; j < cnt; ++j) {
         const uint32_t item = a.active[par][ai0 + j];
-        const ItemProg pg = a.prog[item];
+        const ItemProg pg = load_prog(a, item);
 #ifdef LENTIL_TIMELINE
         const unsigned long long tm0_ = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -3635,7 +3857,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LENTIL_ACCE
     if (dry_first) {
       for (uint32_t j = 0; j < cnt; ++j) {
         const uint32_t item = a.active[par][ai0 + j];
-        const ItemProg pg = a.prog[item];
+        const ItemProg pg = load_prog(a, item);
         const AcceptResult rd = accept_item<kMode>(a, sh, item, pg, res, res_prev, rmin, rmax_p1, true);
         if (threadIdx.x == 0) {
           uint32_t off = 0;
@@ -3647,7 +3869,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LENTIL_ACCE
     }
     for (uint32_t j = 0; j < cnt; ++j) {
       const uint32_t item = a.active[par][ai0 + j];
-      const ItemProg pg = a.prog[item];
+      const ItemProg pg = load_prog(a, item);
       const AcceptResult r = chroma ? accept_item_chroma(a, sh, item, pg, res, rmin, rmax_p1)
                                     : accept_item<kMode>(a, sh, item, pg, res, res_prev, rmin, rmax_p1);
       if (threadIdx.x == 0)
