@@ -1462,10 +1462,11 @@ static int plan_scan(lentil_hip_ctx *ctx, ScanPlan &pl) {
       // the block must fit beside the resident solve blocks, or neither it nor they would ever end (LENTIL_SCAN_DMA2=0: never)
       static const bool dma2_allowed = !(getenv("LENTIL_SCAN_DMA2") && getenv("LENTIL_SCAN_DMA2")[0] == '0');
       const size_t dma2_lds = (size_t)4 * dma2_wave_f4(M) * 16 + 4 * kWaveQueueLds * sizeof(uint2);
-      const size_t solve_lds = (size_t)ctx->stream_blocks * ((ctx->use_generated && lentil_hip_lens_is_compiled(ctx)) ? 28u : 53u) * 1024u;
+      // (static LDS of solve_po_kernel<.., kStream>, tools/kernel_resources.py: 28.2 KB compiled, 52.2 KB with the table interpreter)
+      const size_t solve_lds = (size_t)ctx->stream_blocks * ((ctx->use_generated && lentil_hip_lens_is_compiled(ctx)) ? 29184u : 53760u);
       const uint64_t ppr = ctx->V.pixels_per_row;
       pl.dma2 = dma2_allowed && M >= 2 && ppr >= 2 && ppr < (1ull << 31) && ctx->V.n / M < (1ull << 31) &&
-                dma2_lds + (ctx->stream_mode ? solve_lds : 0) + 1024u <= 160u * 1024u;
+                dma2_lds + (ctx->stream_mode ? solve_lds : 0) <= 160u * 1024u;
       if (pl.dma2) {
         pl.lds = dma2_lds;
         sa.bands = scan_bands(ctx->P);
