@@ -47,7 +47,8 @@ The printed JSON line also carries
                   (counted from the lens table) against the fp64 vector peak, per regime
   cpu_baseline -- the oracle (a port of the reference CPU path) timed on this box's host cores on a
                   bounded row sample of the same workload (rank 0, N=1 only): all threads and one thread
-  configs      -- BASELINE.json's configs 2, 3 and 4 measured the same way (N=1 only; --no-configs skips them).
+  configs      -- BASELINE.json's configs 2, 3 and 4 measured the same way (N=1 only; --no-configs skips them), each with a
+                  parity_checked of its own (~5 s of oracle work on every n-th row of that config's frame).
 """
 import argparse
 import json
@@ -225,37 +226,44 @@ def cpu_baseline(args, p, table, M, tan_half_fov):
     }
 
 
-def parity_check(args, p, table, M, tan_half_fov, device_index, torch):
-    """The same check as tests/ make, inside the bench run: a bounded sample of the timed workload (every row_step-th
-    image row of the same frame, ~10 s of oracle work) goes through the HIP path and through the oracle (fp32
+def parity_check(W, H, M, samples, aovs, f_hi, p, table, tan_half_fov, device_index, torch, bokeh_tables=None, budget_s=10.0,
+                 full_size=None):
+    """The same check as tests/ make, inside the bench run: a bounded sample of a timed workload (every row_step-th
+    image row of the same frame, ~budget_s of oracle work) goes through the HIP path and through the oracle (fp32
     buffers as the reference keeps them, fp64 shadows beside them); accepted draws are compared as (visit, attempt,
-    pixel) lists, bit for bit, radiance at 1e-5.  The timed pass itself is checked at full size by
-    tests/test_gpu_headline.py (66 s of oracle work: not inside a bench run)."""
+    pixel) lists, bit for bit, radiance at 1e-5.  The timed passes themselves are checked at full size by
+    tests/test_gpu_headline.py (a minute or more of oracle work each: not inside a bench run)."""
     import ctypes as C
     import numpy as np
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib
     import common
     from test_gpu_parity import check_frame, check_logs
-    from pota_amd import capi, workload
+    from pota_amd import _abi, capi, workload
 
     lib = oracle_lib.load()
-    W, H = args.width, args.height
-    n_aovs = 1 + args.aovs
+    n_aovs = 1 + aovs
     # (every oracle thread has a frame of its own: fp32 + fp64 accumulators, ~60 B per pixel and AOV)
     per_thread_gb = W * H * 60e-9 * n_aovs + 0.1
     threads = max(1, min(os.cpu_count() or 1, 32, int(0.5 * common.host_memory_gb() / per_thread_gb)))
-    est_full = W * H * M * (0.1e-6 + args.f_hi * args.samples * 35e-6 * 1.1) * 1.5       # (shadow buffers, the draw log)
-    row_step = max(1, int(round(est_full / (10.0 * threads))))
+    est_full = W * H * M * (0.1e-6 + f_hi * samples * 35e-6 * 1.1) * 1.5       # (shadow buffers, the draw log)
+    row_step = max(1, int(round(est_full / (budget_s * threads))))
     rows = list(range(0, H, row_step))
     n = len(rows) * W * M
-    cols = workload.generate(np, 0, n, W, H, M, f_hi=args.f_hi, focus_dist=150.0, tan_half_fov=tan_half_fov,
-                             n_extra=args.aovs, row_stride=row_step, row_offset=0)
+    cols = workload.generate(np, 0, n, W, H, M, f_hi=f_hi, focus_dist=150.0, tan_half_fov=tan_half_fov,
+                             n_extra=aovs, row_stride=row_step, row_offset=0)
     visits, keep = capi.make_visits(cols, visits_per_pixel=M, pixels_per_row=W, pixel_row_stride=row_step)
-    ref = common.ThreadedOracle(lib, p, table, visits, n_threads=threads, n_aovs=n_aovs, row_visits=W * M)
+    ob = None
+    if bokeh_tables is not None:
+        bt = _abi.BokehTable()
+        bt.x, bt.y = bokeh_tables["x"], bokeh_tables["y"]
+        for k in ("cdfRow", "rowIndices", "cdfColumn", "columnIndices"):
+            setattr(bt, k, bokeh_tables[k].ctypes.data)
+        ob = lib.orc_bokeh_from_tables(C.byref(bt))
+    ref = common.ThreadedOracle(lib, p, table, visits, n_threads=threads, n_aovs=n_aovs, row_visits=W * M, bokeh=ob)
     ctx = capi.Context(device_index)
     try:
-        ctx.set_params(p); ctx.set_lens(table); ctx.set_bokeh(None); ctx.alloc_frame(n_aovs); ctx.set_draw_log(1 << 24)
+        ctx.set_params(p); ctx.set_lens(table); ctx.set_bokeh(bokeh_tables); ctx.alloc_frame(n_aovs); ctx.set_draw_log(1 << 24)
         ctx.upload_visits(visits)
         ctx.clear_frame(); ctx.redistribute(); ctx.resolve(); ctx.sync()
         c = ctx.counters()
@@ -265,11 +273,24 @@ def parity_check(args, p, table, M, tan_half_fov, device_index, torch):
     finally:
         ctx.close()
         ref.close()
+        if ob:
+            lib.orc_bokeh_destroy(ob)
     return {"ok": True, "accepted_draws_compared": n_log, "draw_lists_bit_identical": True, "max_rel_err": float("%.3g" % worst),
             "tolerance": 1e-5, "redistributed_visits": int(c.redistributed_visits),
             "sample": "every %d-th row of the timed %dx%d frame (%d visits), HIP path against the oracle" % (row_step, W, H, n),
-            "full_size": "tests/test_gpu_headline.py::test_headline_4k_streamed_vs_oracle (the timed streams, bit-identical "
+            "full_size": full_size or
+                         "tests/test_gpu_headline.py::test_headline_4k_streamed_vs_oracle (the timed streams, bit-identical "
                          "draw lists, 1e-5 radiance) and ::test_config5_quarter_frame_vs_oracle"}
+
+
+def checked(fn, *a, **kw):
+    """parity_check's verdict as a JSON object, whatever happens inside it"""
+    try:
+        return fn(*a, **kw)
+    except AssertionError as e:
+        return {"ok": False, "error": str(e)[:300]}
+    except Exception as e:
+        return {"ok": None, "error": "check did not run: %r" % (e,)}
 
 
 def load_traffic(workload_tag):
@@ -305,6 +326,7 @@ class Bench:
         if bokeh_image:
             p.bokeh_enable_image = 1
         self.p, self.model = p, model
+        self.bokeh_tables = None
         self.table, self.keep = lens_io.make_lens_table(model.spec)
         self.flops = lens_io.newton_iteration_flops(model.spec)
         self.tan_half_fov = float(p.sensor_width) * 0.5 / float(p.focal_length)
@@ -314,7 +336,8 @@ class Bench:
         if bokeh_image:
             from pota_amd import bokeh
             tex = np.load(os.path.join(ROOT, "tests", "golden", "example_bokeh_kernel_u8.npy")).astype(np.float32) / np.float32(255)
-            ctx.set_bokeh(bokeh.build_tables(tex))
+            self.bokeh_tables = bokeh.build_tables(tex)
+            ctx.set_bokeh(self.bokeh_tables)
         ctx.alloc_frame(1 + aovs)
         self.ctx = ctx
         self.engine = distributed.HipEngine(ctx, rows=p.yres)
@@ -748,6 +771,7 @@ def main():
         except Exception as e:      # the GPU number must still be reported
             out["pcie_inclusive"] = {"value": None, "error": repr(e)}
     cpu_args = (args, b.p, b.table, M, b.tan_half_fov)
+    cpu_bokeh = b.bokeh_tables
     b.close()
 
     def scan_alone(Wc, Hc, lens, samples, aovs, bokeh, n_c, bpv):
@@ -800,7 +824,16 @@ def main():
                               "scan_kernel": scan_kernel_name(kw["aovs"]), "bytes_per_visit": bpv, "scan_frac_of_hbm_peak": round(ach_c / HBM_PEAK_GBS, 4),
                               "whole_step_frac_of_hbm_peak": round(n_c * bpv / (ms_c * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                               "attempted_draws_per_step": rc["attempted"] // 4, "passes_streamed": rc["streamed"], "steps": 4}
+                pc = (c.p, c.table, c.tan_half_fov, c.bokeh_tables)
                 c.close()
+                if not args.no_parity_check:
+                    test = {"config2": "test_config2_1080p_256_draws_vs_oracle", "config3": "test_config3_4k_512_draws_aperture_image_vs_oracle",
+                            "config4": "test_config4_like_4k_nine_gaussian_aovs_streamed_vs_oracle (and, with two closest-filtered "
+                                       "AOVs, ::test_config4_4k_petzval_two_closest_aovs_vs_oracle)"}[name[:7]]
+                    cfgs[name]["parity_checked"] = checked(
+                        parity_check, kw["W"], kw["H"], M, kw["samples"], kw["aovs"], args.f_hi, pc[0], pc[1], pc[2], local_rank, torch,
+                        bokeh_tables=pc[3], budget_s=5.0,
+                        full_size="tests/test_gpu_headline.py::%s: the whole frame, every pass of the bench's order" % test)
                 if not args.no_scan_alone:
                     cfgs[name]["scan_alone"] = scan_alone(kw["W"], kw["H"], kw["lens"], kw["samples"], kw["aovs"], kw["bokeh"], n_c, bpv)
             except Exception as e:      # the headline number must still be reported
@@ -814,12 +847,8 @@ def main():
             out["cpu_baseline"] = {"value": None, "unit": "Msamples/s", "cores": 0, "kind": "port",
                                    "sample": "failed: %r" % (e,)}
     if rank == 0 and world == 1 and not args.no_parity_check:
-        try:
-            out["parity_checked"] = parity_check(args, cpu_args[1], cpu_args[2], M, cpu_args[4], local_rank, torch)
-        except AssertionError as e:
-            out["parity_checked"] = {"ok": False, "error": str(e)[:300]}
-        except Exception as e:
-            out["parity_checked"] = {"ok": None, "error": "check did not run: %r" % (e,)}
+        out["parity_checked"] = checked(parity_check, args.width, args.height, M, args.samples, args.aovs, args.f_hi, cpu_args[1],
+                                        cpu_args[2], cpu_args[4], local_rank, torch, bokeh_tables=cpu_bokeh)
     from pota_amd import distributed
     if distributed.PHASE_SECONDS:
         sys.stderr.write("[band timing, ms per step incl. warm-up steps] %s\n" % {k: round(v * 1e3 / (args.steps + args.warmup), 3)

@@ -892,14 +892,41 @@ ORC_API void orc_frame_set_camera_motion(OrcFrame *F, uint32_t n_keys, const flo
   F->cam_keys.assign(world_to_camera, world_to_camera + (size_t)F->n_cam_keys * 16);
 }
 
-ORC_API void orc_frame_merge(OrcFrame *dst, const OrcFrame *src) {   /* per-thread private buffers summed */
-  for (uint32_t a = 0; a < dst->n_aovs; a++)
+/* `src` holds the visits that FOLLOW dst's in the stream's order (ThreadedOracle merges its threads' frames in that order).
+ * Gaussian AOVs add up.  A closest AOV (add_to_buffer's z-test, src/lentil.h:832-837, one zbuffer for all of them) keeps,
+ * over nonzero depths, the LAST candidate of the smallest |Z|: src's survivor replaces dst's when its |Z| <= dst's or dst
+ * has none -- what the sequential walk leaves.  (A candidate of |Z| == 0 re-opens the pixel for whatever comes next; a
+ * stream with one cannot be split over threads this way, and the callers' generators have none.)  lentil_debug's own
+ * z-buffer is not merged: single-threaded frames only. */
+ORC_API void orc_frame_merge(OrcFrame *dst, const OrcFrame *src) {
+  bool any_closest = false;
+  for (uint32_t a = 0; a < dst->n_aovs; a++) {
+    if (dst->kind[a] == LENTIL_FILTER_CLOSEST) { any_closest = true; continue; }
     for (size_t i = 0; i < dst->buffer[a].size(); i++) dst->buffer[a][i] += src->buffer[a][i];
+  }
   for (size_t i = 0; i < dst->weight.size(); i++) dst->weight[i] += src->weight[i];
   if (dst->shadow && src->shadow) {   /* the exact sums add up exactly where the partial sums do (gaussian AOVs) */
-    for (uint32_t a = 0; a < dst->n_aovs; a++)
+    for (uint32_t a = 0; a < dst->n_aovs; a++) {
+      if (dst->kind[a] == LENTIL_FILTER_CLOSEST) continue;
       for (size_t i = 0; i < dst->buffer64[a].size(); i++) dst->buffer64[a][i] += src->buffer64[a][i];
+    }
     for (size_t i = 0; i < dst->weight64.size(); i++) dst->weight64[i] += src->weight64[i];
+  }
+  if (any_closest) {
+    const size_t np = dst->zbuffer.size();
+    for (size_t px = 0; px < np; px++) {
+      if (src->zvisit[px] == 0xFFFFFFFFu) continue;                                   /* src never wrote here */
+      if (!(dst->zvisit[px] == 0xFFFFFFFFu || src->zbuffer[px] <= dst->zbuffer[px])) continue;
+      for (uint32_t a = 0; a < dst->n_aovs; a++) {
+        if (dst->kind[a] != LENTIL_FILTER_CLOSEST) continue;
+        for (int c = 0; c < 4; c++) {
+          dst->buffer[a][px * 4 + c] = src->buffer[a][px * 4 + c];
+          if (dst->shadow && src->shadow) dst->buffer64[a][px * 4 + c] = src->buffer64[a][px * 4 + c];
+        }
+      }
+      dst->zbuffer[px] = src->zbuffer[px];
+      dst->zvisit[px] = src->zvisit[px];
+    }
   }
   dst->ctr.visits += src->ctr.visits;
   dst->ctr.redistributed_visits += src->ctr.redistributed_visits;

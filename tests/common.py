@@ -50,9 +50,9 @@ def make_stream(p, width, height, M, f_hi, n_extra=0, seed=0x5EED, v_end=None, *
     return visits, cols
 
 
-def run_oracle(lib, p, table, visits, n_aovs=1, bokeh=None, keep_log=True):
+def run_oracle(lib, p, table, visits, n_aovs=1, bokeh=None, keep_log=True, kinds=None):
     lens = lib.orc_lens_create(C.byref(table)) if table is not None else None
-    fr = oracle_lib.Frame(lib, p, n_aovs=n_aovs, keep_log=keep_log)
+    fr = oracle_lib.Frame(lib, p, n_aovs=n_aovs, kinds=kinds, keep_log=keep_log)
     fr.run(lens, bokeh, visits)
     if lens:
         lib.orc_lens_destroy(lens)

@@ -35,13 +35,13 @@ def _oracle_threads(p, per_frame_gb):
     return int(max(2, min(32, os.cpu_count() or 2, (common.host_memory_gb() * 0.5) // per_frame_gb)))
 
 
-def _compare(ctx, ref, c, samples, n_visits, p, n_aovs=1):
+def _compare(ctx, ref, c, samples, n_visits, p, n_aovs=1, kinds=None):
     rc = ref.counters()
     assert (c.visits, c.redistributed_visits, c.attempted_draws, c.accepted_draws) == (
         n_visits, rc.redistributed_visits, rc.attempted_draws, rc.accepted_draws)
     assert c.worklist_overflow == 0
     check_logs(ctx, ref)                      # (visit, attempt, pixel) of every accepted draw, bit for bit
-    worst = check_frame(ctx, ref, n_aovs=n_aovs)      # accumulators, weights, resolved image (the early-resolved one): 1e-5
+    worst = check_frame(ctx, ref, n_aovs=n_aovs, kinds=kinds)      # accumulators, weights, resolved image (the early-resolved one): 1e-5
     # pixels no draw lands on only hold their own visits, added in iterator order: bit-exact
     touched = np.zeros(p.xres * p.yres, bool)
     touched[ref.log()[:, 2]] = True
@@ -50,8 +50,93 @@ def _compare(ctx, ref, c, samples, n_visits, p, n_aovs=1):
     assert np.array_equal(w[~touched], ref.weight()[~touched])
     assert np.array_equal(ctx.download_aov(0)[~touched], ref.resolve(0)[~touched])
     for a in range(1, n_aovs):
-        assert np.array_equal(ctx.download_accum(a)[0][~touched], ref.buffer(a)[~touched]), a
+        if kinds is not None and kinds[a] != 0:
+            # a closest-filtered AOV is a copy of one candidate's value (src/lentil.h:832-837): the whole frame bit for bit
+            assert np.array_equal(ctx.download_aov(a), ref.resolve(a)), a
+        else:
+            assert np.array_equal(ctx.download_accum(a)[0][~touched], ref.buffer(a)[~touched]), a
     return worst, int(touched.sum())
+
+
+def _timed_config_vs_oracle(orc, name, W, H, lens, S, n_extra=0, kinds=None, bokeh_image=False, seeds=(0x5EED, 0xBEEF)):
+    """One of bench.py's `configs` entries as the bench runs it -- Bench.generate's two seeded streams, two set-up passes,
+    then alternating streams -- with every pass compared with the oracle over the whole frame."""
+    import ctypes as C
+    import os
+    import torch
+    from pota_amd import _abi, bokeh
+    M, f_hi = 9, 2.0 ** -16
+    n = W * H * M
+    n_aovs = 1 + n_extra
+    has_closest = bool(kinds) and any(k != 0 for k in kinds)
+    per_thread_gb = W * H * n_aovs * 60e-9 + 0.2
+    if common.host_memory_gb() < 2 * per_thread_gb + 30:
+        pytest.skip("not enough host memory for the oracle's frames")
+    kw = dict(bokeh_enable_image=1) if bokeh_image else {}
+    p, model, table, keep = common.po_setup(W, H, lens=lens, samples_override=S, **kw)
+    tables = ob = None
+    if bokeh_image:
+        tex = np.load(os.path.join(common.ROOT, "tests", "golden", "example_bokeh_kernel_u8.npy")).astype(np.float32) / np.float32(255)
+        tables = bokeh.build_tables(tex)
+        bt = _abi.BokehTable()
+        bt.x, bt.y = tables["x"], tables["y"]
+        for k in ("cdfRow", "rowIndices", "cdfColumn", "columnIndices"):
+            setattr(bt, k, tables[k].ctypes.data)
+        ob = orc.orc_bokeh_from_tables(C.byref(bt))
+    ctx = capi.Context(0)
+    try:
+        ctx.set_params(p); ctx.set_lens(table); ctx.set_bokeh(tables)
+        assert ctx.lens_is_compiled()
+        ctx.alloc_frame(n_aovs, kinds)
+        ctx.set_draw_log(1 << 21)
+        streams, refs = [], []
+        for seed in seeds:
+            d, h = _device_stream(torch, p, W, H, M, seed, f_hi, 0, n, n_extra=n_extra)
+            streams.append(d)
+            refs.append(common.ThreadedOracle(orc, p, table, h[0], _oracle_threads(p, per_thread_gb), n_aovs=n_aovs,
+                                              kinds=kinds, bokeh=ob))
+            del h
+        seen_streamed = 0
+        for k, i in enumerate((0, 1, 0, 1)):
+            dv, dkeep = streams[i % len(streams)]
+            ctx.bind_visits(dv, dkeep)
+            ctx.clear_frame(); ctx.redistribute(); ctx.resolve(); ctx.sync()
+            c = ctx.counters()
+            # (the first pass of a context looks at its scans; with extra AOVs the streamed pass is scan_dma_multi_kernel's,
+            # which takes gaussian AOVs only -- closest-filtered ones keep the chunked form, blind from the second pass on)
+            want = 1 if (k and not has_closest) else 0
+            assert c.fallback_chunks == 0 and c.streamed == want, (k, c.streamed, c.fallback_chunks)
+            seen_streamed += c.streamed
+            worst, n_touched = _compare(ctx, refs[i % len(refs)], c, S, n, p, n_aovs=n_aovs, kinds=kinds)
+            print("%s, pass %d (%s): %d items, %d accepted draws on %d pixels, max rel err %.2e"
+                  % (name, k, "streamed" if c.streamed else "chunked", c.redistributed_visits, c.accepted_draws, n_touched, worst))
+        assert seen_streamed == (0 if has_closest else 3)
+    finally:
+        ctx.close()
+        for r in refs:
+            r.close()
+        if ob:
+            orc.orc_bokeh_destroy(ob)
+
+
+def test_config2_1080p_256_draws_vs_oracle(orc):
+    """BASELINE config 2 (double-gauss 50mm, 1920x1080, 256 draws, beauty only) as bench.py's `configs` entry runs it."""
+    _timed_config_vs_oracle(orc, "config 2", 1920, 1080, "double_gauss_50mm", 256)
+
+
+def test_config3_4k_512_draws_aperture_image_vs_oracle(orc):
+    """BASELINE config 3 (double-gauss 50mm + the aperture image's CDF draws, src/imagebokeh.h:341-412; 3840x2160, 512
+    draws) as bench.py's `configs` entry runs it."""
+    _timed_config_vs_oracle(orc, "config 3", 3840, 2160, "double_gauss_50mm", 512, bokeh_image=True)
+
+
+def test_config4_4k_petzval_two_closest_aovs_vs_oracle(orc):
+    """BASELINE config 4 (petzval, 3840x2160, 1024 draws, beauty + 8 AOVs) at full size with two of the eight
+    closest-filtered (Camera::add_to_buffer's z-test, src/lentil.h:832-837): the register-staged scan, the key plane, the
+    gather -- every pass against the oracle, the closest AOVs bit for bit over the whole frame.  One stream (the oracle's
+    nine-AOV frames are what bounds this test), replayed as the bench's passes are."""
+    _timed_config_vs_oracle(orc, "config 4 (two closest AOVs)", 3840, 2160, "petzval_58mm", 1024, n_extra=8,
+                            kinds=[0, 0, 1, 0, 0, 0, 1, 0, 0], seeds=(0x5EED,))
 
 
 def test_headline_4k_streamed_vs_oracle(orc):

@@ -420,6 +420,33 @@ def test_threaded_oracle_equals_the_single_thread_one(orc):
     thr.close()
 
 
+def test_threaded_oracle_merges_closest_aovs_in_stream_order(orc):
+    """orc_frame_merge with closest-filtered AOVs among the frame's: the threads' survivors merged in stream order leave
+    what one thread walking the stream leaves (src/lentil.h:832-837 over nonzero depths: the last candidate of the smallest
+    |Z|), bit for bit -- values, z-buffer and the visit that wrote it."""
+    import common
+    import oracle_lib
+    W, H, M = 48, 40, 9
+    kinds = [0, 1, 0, 1]
+    p, model, table, keep = common.po_setup(W, H, samples_override=32)
+    visits, cols = common.make_stream(p, W, H, M, f_hi=0.01, n_extra=3)
+    one = common.run_oracle(orc, p, table, visits, n_aovs=4, kinds=kinds)
+    for n_threads in (2, 5, 7):
+        thr = common.ThreadedOracle(orc, p, table, visits, n_threads, n_aovs=4, kinds=kinds)
+        assert np.array_equal(common.sort_log(one.log()), common.sort_log(thr.log()))
+        for a in (1, 3):
+            assert np.array_equal(one.buffer(a), thr.buffer(a)), (n_threads, a)
+            assert np.array_equal(one.resolve(a), thr.resolve(a)), (n_threads, a)
+        assert np.array_equal(one.zbuffer(), thr.zbuffer())
+        assert np.array_equal(one.zvisit(), thr.zvisit())
+        for a in (0, 2):
+            assert np.allclose(one.buffer(a), thr.buffer(a), rtol=2e-6, atol=0)
+        # (draws carry candidates across thread boundaries: some pixel's survivor comes from another thread's range)
+        thr.close()
+    assert (one.zvisit() != 0xFFFFFFFF).sum() >= W * H
+    one.close()
+
+
 def test_oracle_camera_motion_interpolates_the_keys(orc):
     """orc_frame_set_camera_motion: a visit at lentil_time t sees ((b - a) * f) + a of the two keys around t; two equal
     keys are the static camera; times outside the shutter clamp."""
