@@ -134,6 +134,11 @@ struct lentil_hip_ctx {
   int est_rounds_total = 3;
   uint32_t last_streamed = 0;
   uint64_t n_stuck = 0;                      // streamed passes whose waves gave up waiting (redone the chunked way)
+  // ... of which had accepted draws by then: the frame is wiped and the whole pass run again, chunked (lentil_hip_redistribute)
+  uint64_t n_stall_redone = 0;
+  bool stall_redo = false;                   // redistribute_streamed -> lentil_hip_redistribute
+  int inject_stall_at = 0;                   // LENTIL_INJECT_STALL=k: the context's k-th streamed pass stalls after its first accept (tests)
+  uint64_t n_streamed = 0;
   int last_rounds = 0;
   uint32_t last_blind = 0, last_fallback = 0;
   uint32_t last_scan_launches = 0;
@@ -345,6 +350,7 @@ LENTIL_API int lentil_hip_create(int device, lentil_hip_ctx **out_ctx) {
   HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_crypto, hipEventDisableTiming));
   { const int rc = pick_concurrent_streams(ctx); if (rc) return rc; }
   if (const char *e = getenv("LENTIL_EARLY_RESOLVE")) ctx->early_resolve = atoi(e) != 0;
+  if (const char *e = getenv("LENTIL_INJECT_STALL")) ctx->inject_stall_at = atoi(e);
   if (const char *ft = getenv("LENTIL_FORCE_TABLES")) ctx->use_generated = !(ft[0] == '1');
   if (const char *fc = getenv("LENTIL_FIRST_CHUNK_FRAC")) {
     const double f = atof(fc);
@@ -1589,6 +1595,11 @@ static int redistribute_streamed(lentil_hip_ctx *ctx, bool *streamed) {
   if (!ctx->stream_mode || P.cameraType != LENTIL_POLYNOMIAL_OPTICS || !ctx->have_total_est || ctx->V.n == 0)
     return LENTIL_OK;
   if (ctx->V.n > 0xFFFFFFF0ull) return LENTIL_OK;
+  // Only into a frame that has been cleared since its last pass (every caller's order: clear, redistribute, resolve): a
+  // streamed pass whose waves give up waiting after draws have been accepted is recovered by wiping the frame and running
+  // the pass again, which must not cost an earlier pass's sums.  A second pass into the same frame takes the chunked form,
+  // whose kernels never wait for one another.
+  if (!ctx->cleared_since_pass) return LENTIL_OK;
   // Streaming pays where the scan is most of the pass.  With many draws the chunked pass is ahead (highlight-heavy
   // frame: 114 ms against 135 ms; 15 M draws: 16.6 against 18.4 ms -- solve waves placed while the scan's are
   // resident keep running slower long after those have left, see launch_chunk_rounds), and so it is with extra
@@ -1613,6 +1624,8 @@ static int redistribute_streamed(lentil_hip_ctx *ctx, bool *streamed) {
   else if (!one_at_a_time.try_lock()) return LENTIL_OK;
   DrawArgs da{};
   init_draw_args(ctx, da);
+  ++ctx->n_streamed;
+  da.inject_stall = (ctx->inject_stall_at > 0 && ctx->n_streamed == (uint64_t)ctx->inject_stall_at) ? 1 : 0;
   const uint64_t nch = (uint64_t)da.n_channels;
   uint64_t items = 2 * ctx->est_items_total + 4096;
   if (items > ctx->V.n) items = ctx->V.n;
@@ -2044,8 +2057,16 @@ static int redistribute_streamed(lentil_hip_ctx *ctx, bool *streamed) {
       fprintf(stderr, "[stream] stragglers: live %d waves_done %u/%u (round 1: %u) parked %u/%u heads %u/%u cap %u waves %u rounds_used %llu\n", (int)live,
               c.waves_done[0], c.waves_started[0], c.waves_done[1], c.n_slow[0], c.n_slow[1], c.slow_head[0], c.slow_head[1],
               da.slow_cap, da.slow_waves, c.rounds_used);
-    if (c.stuck && c.rounds_used)
-      return fail(ctx, LENTIL_ERR_HIP, "streamed pass stalled after its first accept: the frame holds a part of the pass (clear it and run the pass again)");
+    if (c.stuck && c.rounds_used) {
+      // Stalled with draws already accepted: the frame holds a part of the pass.  It held nothing before (the gate at the
+      // top), so lentil_hip_redistribute wipes it and runs the whole pass again in the chunked form.
+      ++ctx->n_stuck;
+      ctx->stall_redo = true;
+      ctx->h_ctr_valid = false;
+      ctx->late_resolve_done = false;
+      *streamed = true;
+      return LENTIL_OK;
+    }
     if (c.stuck) {
       ++ctx->n_stuck;
       HIP_TRY(ctx, hipMemsetAsync((char *)ctx->d_ctr + offsetof(DevCounters, stuck), 0, sizeof(unsigned int), ch.stream));
@@ -2197,8 +2218,34 @@ LENTIL_API int lentil_hip_get_xor128_state(lentil_hip_ctx *ctx, uint32_t state[4
   return LENTIL_OK;
 }
 
+static int redistribute_pass(lentil_hip_ctx *ctx);
+
 LENTIL_API int lentil_hip_redistribute(lentil_hip_ctx *ctx) {
   CHECK_CTX(ctx);
+  ctx->stall_redo = false;
+  int rc = redistribute_pass(ctx);
+  if (rc || !ctx->stall_redo) return rc;
+  // A streamed pass gave up waiting (kStuckTicks) after its first accept had added draws to the frame.  Every kernel of the
+  // pass has left by now (they all watch DevCounters::stuck); the frame was clear before the pass, so: clear it again --
+  // accumulators through the splat flags, direct sums, cryptomatte -- and run the whole pass once more, chunked.
+  ctx->stall_redo = false;
+  ++ctx->n_stall_redone;
+  if (getenv("LENTIL_STREAM_DEBUG")) fprintf(stderr, "[stream] stalled after the first accept: frame wiped, pass run again chunked\n");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  for (hipStream_t st : {ctx->stream, ctx->chunks[0].stream, ctx->pub_stream, ctx->slow1_stream, ctx->aux_stream})
+    if (st) HIP_TRY(ctx, hipStreamSynchronize(st));
+  HIP_TRY(ctx, hipMemsetAsync((char *)ctx->d_ctr + offsetof(DevCounters, stuck), 0, sizeof(unsigned int), ctx->stream));
+  if ((rc = lentil_hip_clear_frame(ctx))) return rc;
+  const bool stream_mode = ctx->stream_mode;
+  ctx->stream_mode = false;
+  rc = redistribute_pass(ctx);
+  ctx->stream_mode = stream_mode;
+  if (rc) return rc;
+  ++ctx->last_fallback;          // (lentil_counters::fallback_chunks: the pass was redone; ::streamed is 0)
+  return LENTIL_OK;
+}
+
+static int redistribute_pass(lentil_hip_ctx *ctx) {
   if (!ctx->have_params || !ctx->have_frame || !ctx->have_visits)
     return fail(ctx, LENTIL_ERR_INVALID, "redistribute needs set_params, alloc_frame and visits");
   const lentil_params &P = ctx->P;
@@ -2241,6 +2288,7 @@ LENTIL_API int lentil_hip_redistribute(lentil_hip_ctx *ctx) {
   } else {
     const int rc = redistribute_streamed(ctx, &streamed);
     if (rc) return rc;
+    if (ctx->stall_redo) return LENTIL_OK;       // (lentil_hip_redistribute wipes the frame and calls again)
   }
   if (!streamed && ctx->V.n) {
     // ---- scans: all chunks back to back on the main stream

@@ -2039,6 +2039,9 @@ struct DrawArgs {
   int32_t slow_dry_only;      // live queue: park as a plain round does (waves running dry, their last slow_max_lanes lanes)
   int32_t slow_crowd_stays;   // live queue: where more than slow_max_lanes lanes of a wave are past slow_at at once, none is parked
   int32_t accept_narrow;      // accept kernels: 256-attempt steps (accept_item) where accept_item_wide would apply
+  // test hook (LENTIL_INJECT_STALL): the first accept of a streamed pass never closes the queue it feeds, so the second round's
+  // resident solve waves give up after kStuckTicks -- a pass stalled with draws already accepted, which the host must recover
+  int32_t inject_stall;
   ItemLive *live;             // streamed pass with extension (ItemLive): the first round's solve kernel and the first accept
   Task *ext_q;                // ... the queue of the batches it appends, served by its first ext_keeper_blocks blocks
   uint32_t ext_keeper_blocks;
@@ -3882,7 +3885,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LENTIL_ACCE
     if (tot_accepted) atomicAdd(&a.ctr->accepted, tot_accepted);
   }
   flush_row_range(a.ctr, rmin, rmax_p1);
-  if (a.emit_live && threadIdx.x < 64u) {
+  if (a.emit_live && threadIdx.x < 64u && !a.inject_stall) {
     // everything this block emitted has arrived; the last block puts the end markers behind the queue
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     uint32_t last = 0;

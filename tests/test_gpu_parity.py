@@ -1045,6 +1045,33 @@ def test_blind_passes_and_fallback(orc, monkeypatch, stream):
         ctx.close()
 
 
+@pytest.mark.parametrize("size", ["small", "large"])
+def test_streamed_pass_that_stalls_after_its_first_accept_is_run_again(orc, monkeypatch, size):
+    """A streamed pass whose resident waves give up waiting (kStuckTicks) AFTER the first accept has added draws to the frame
+    must not cost the frame: it is wiped and the whole pass run again in the chunked form.  LENTIL_INJECT_STALL=k makes the
+    k-th streamed pass of a context stall exactly there (its first accept never closes the queue the second round's solve
+    waves poll).  Passes: chunked (first of the context), streamed, streamed + stalled -> redone, streamed again -- every one
+    against the oracle; the redone one reports streamed = 0, fallback_chunks = 1."""
+    W, H, M, S, f_hi = (96, 64, 9, 48, 0.002) if size == "small" else (1280, 720, 9, 256, 2.0 ** -13)
+    p, model, table, keep = common.po_setup(W, H, samples_override=S)
+    visits, keepv = common.make_stream(p, W, H, M, f_hi=f_hi)
+    ref = common.run_oracle(orc, p, table, visits) if size == "small" else common.ThreadedOracle(orc, p, table, visits, 8)
+    monkeypatch.setenv("LENTIL_INJECT_STALL", "2")
+    ctx = capi.Context(0)
+    try:
+        for k, (streamed, fb) in enumerate(((0, 0), (1, 0), (0, 1), (1, 0))):
+            c = gpu_run(ctx, p, table, visits)
+            rc = ref.counters()
+            assert (c.streamed, c.fallback_chunks) == (streamed, fb), (k, c.streamed, c.fallback_chunks)
+            assert (c.redistributed_visits, c.attempted_draws, c.accepted_draws) == (
+                rc.redistributed_visits, rc.attempted_draws, rc.accepted_draws)
+            check_logs(ctx, ref)
+            check_frame(ctx, ref)
+    finally:
+        ctx.close()
+        ref.close()
+
+
 def test_chromatic_streamed_pass_resolves_what_later_rounds_add(orc, gpu_ctx_factory):
     """abb_chromatic != 0 in a streamed pass (the second pass of a context): the frame is resolved beside the second round
     and the groups later rounds splat into are resolved again -- their accepts must flag them as such.  (Found by the
