@@ -429,6 +429,10 @@ int lentil_hip_exchange_bands(lentil_hip_ctx *ctx, const int32_t *bounds, int32_
  * winner keys included) or lentil_hip_allreduce (ring traffic of the reduced buffers); either pointer may be NULL.
  * Instrumentation for the scaling bench; no reference counterpart. */
 int lentil_hip_exchange_stats(lentil_hip_ctx *ctx, uint64_t *bytes_sent, uint64_t *bytes_received);
+/* lentil_hip_exchange_bands(sparse != 0) since the communicator was made: exchanges that ran in the fixed-capacity form
+ * (every message's size known to both ends beforehand, no host wait between compaction and merge) and directed pairs whose
+ * entries did not fit their message and followed as whole rows; either pointer may be NULL.  Instrumentation. */
+int lentil_hip_exchange_counts(lentil_hip_ctx *ctx, uint64_t *fixed_form, uint64_t *pairs_overflowed);
 /* *concurrent = 1 when the four HIP streams a streamed pass keeps kernels resident on run them side by side (they were
  * chosen so at lentil_hip_create: streams that share one of the runtime's hardware queues serialise, and the pass then
  * takes about 1.5 x as long; 2: and a fifth one beside them, on which a pass with cryptomatte AOVs replays the own-pixel

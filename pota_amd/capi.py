@@ -31,7 +31,7 @@ EXPORTS = [
     "lentil_hip_host_alloc", "lentil_hip_host_free", "lentil_hip_visits_begin", "lentil_hip_visits_append",
     "lentil_hip_visits_wait", "lentil_hip_visits_end",
     "lentil_hip_comm_unique_id", "lentil_hip_comm_init", "lentil_hip_comm_destroy", "lentil_hip_allreduce",
-    "lentil_hip_exchange_bands", "lentil_hip_exchange_stats", "lentil_hip_streams_concurrent",
+    "lentil_hip_exchange_bands", "lentil_hip_exchange_stats", "lentil_hip_exchange_counts", "lentil_hip_streams_concurrent",
     "lentil_hip_alloc_crypto", "lentil_hip_upload_crypto", "lentil_hip_bind_crypto", "lentil_hip_download_crypto",
     "lentil_hip_download_crypto_table", "lentil_hip_visits_begin_crypto", "lentil_hip_visits_append_crypto",
 ]
@@ -127,6 +127,7 @@ def load_library():
         "lentil_hip_allreduce": (i, [vp]),
         "lentil_hip_exchange_bands": (i, [vp, vp, C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
         "lentil_hip_exchange_stats": (i, [vp, C.POINTER(u64), C.POINTER(u64)]),
+        "lentil_hip_exchange_counts": (i, [vp, C.POINTER(u64), C.POINTER(u64)]),
         "lentil_hip_streams_concurrent": (i, [vp, C.POINTER(C.c_int)]),
     }
     for name, (res, args) in sig.items():
@@ -401,6 +402,12 @@ class Context:
         """(bytes sent, bytes received) by this rank in its last exchange_bands / allreduce"""
         a, b = C.c_uint64(), C.c_uint64()
         self._chk(self.lib.lentil_hip_exchange_stats(self.h, C.byref(a), C.byref(b)))
+        return int(a.value), int(b.value)
+
+    def exchange_counts(self):
+        """(exchange_bands calls that ran in the fixed-capacity form, directed pairs whose entries overflowed their message)"""
+        a, b = C.c_uint64(), C.c_uint64()
+        self._chk(self.lib.lentil_hip_exchange_counts(self.h, C.byref(a), C.byref(b)))
         return int(a.value), int(b.value)
 
     def touched_rows(self):

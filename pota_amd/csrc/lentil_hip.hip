@@ -2611,22 +2611,23 @@ static int merge_rows_impl(lentil_hip_ctx *ctx, uint32_t row_begin, uint32_t n_r
   return fail(ctx, LENTIL_ERR_UNSUPPORTED, "frames with a lentil_debug AOV are exchanged by lentil_hip_exchange_bands / _allreduce only")
 
 static int compact_rows_impl(lentil_hip_ctx *ctx, uint32_t row_begin, uint32_t n_rows, void *dev_idx, void *dev_vals,
-                             void *dev_keys, void *dev_keys_dbg, uint32_t capacity, uint32_t *count);
+                             void *dev_keys, void *dev_keys_dbg, uint32_t capacity, uint32_t *count, unsigned int *d_count_own);
 
 LENTIL_API int lentil_hip_compact_rows(lentil_hip_ctx *ctx, uint32_t row_begin, uint32_t n_rows, void *dev_idx,
                                        void *dev_vals, void *dev_keys, uint32_t capacity, uint32_t *count) {
   CHECK_CTX(ctx);
   LENTIL_NO_DEBUG_AOV(ctx);
-  return compact_rows_impl(ctx, row_begin, n_rows, dev_idx, dev_vals, dev_keys, nullptr, capacity, count);
+  return compact_rows_impl(ctx, row_begin, n_rows, dev_idx, dev_vals, dev_keys, nullptr, capacity, count, nullptr);
 }
 
+// `d_count_own`: the count goes to a word of the caller's (zeroed by the caller) and stays on the device -- nothing waits
 static int compact_rows_impl(lentil_hip_ctx *ctx, uint32_t row_begin, uint32_t n_rows, void *dev_idx, void *dev_vals,
-                             void *dev_keys, void *dev_keys_dbg, uint32_t capacity, uint32_t *count) {
+                             void *dev_keys, void *dev_keys_dbg, uint32_t capacity, uint32_t *count, unsigned int *d_count_own) {
   CHECK_CTX(ctx);
   int rc = check_rows(ctx, row_begin, n_rows);
   if (rc) return rc;
-  if (!count) return fail(ctx, LENTIL_ERR_INVALID, "count is null");
-  *count = 0;
+  if (!count && !d_count_own) return fail(ctx, LENTIL_ERR_INVALID, "count is null");
+  if (count) *count = 0;
   if (!n_rows) return LENTIL_OK;
   if (!dev_idx || !dev_vals) return fail(ctx, LENTIL_ERR_INVALID, "dev_idx / dev_vals is null");
   if (ctx->F.zkey && !dev_keys) return fail(ctx, LENTIL_ERR_INVALID, "the frame has closest-filtered AOVs: dev_keys is required");
@@ -2635,8 +2636,8 @@ static int compact_rows_impl(lentil_hip_ctx *ctx, uint32_t row_begin, uint32_t n
   const uint64_t p_begin = (uint64_t)row_begin * ctx->P.xres, n_pix = (uint64_t)n_rows * ctx->P.xres;
   if ((rc = fold_direct(ctx, p_begin, p_begin + n_pix, false))) return rc;
   // the shared slot of the counter block (draw-log cursor) is free between passes
-  unsigned int *d_count = reinterpret_cast<unsigned int *>(&ctx->d_ctr[ctx->n_chunks].overflow);
-  HIP_TRY(ctx, hipMemsetAsync(d_count, 0, sizeof(unsigned int), ctx->stream));
+  unsigned int *d_count = d_count_own ? d_count_own : reinterpret_cast<unsigned int *>(&ctx->d_ctr[ctx->n_chunks].overflow);
+  if (!d_count_own) HIP_TRY(ctx, hipMemsetAsync(d_count, 0, sizeof(unsigned int), ctx->stream));
   uint64_t blocks = (n_pix + 255) / 256;
   const uint64_t max_blocks = (uint64_t)ctx->num_cu * 8;
   if (blocks > max_blocks) blocks = max_blocks;
@@ -2644,6 +2645,7 @@ static int compact_rows_impl(lentil_hip_ctx *ctx, uint32_t row_begin, uint32_t n
                      (uint32_t *)dev_idx, (float *)dev_vals, ctx->F.zkey ? (unsigned long long *)dev_keys : nullptr,
                      ctx->F.zkey_dbg ? (unsigned long long *)dev_keys_dbg : nullptr, capacity, d_count);
   HIP_TRY(ctx, hipGetLastError());
+  if (d_count_own) return LENTIL_OK;
   unsigned int n = 0;
   HIP_TRY(ctx, hipMemcpyAsync(&n, d_count, sizeof(n), hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -2652,7 +2654,7 @@ static int compact_rows_impl(lentil_hip_ctx *ctx, uint32_t row_begin, uint32_t n
 }
 
 static int merge_sparse_impl(lentil_hip_ctx *ctx, uint32_t row_begin, uint32_t n_rows, uint32_t n, const void *dev_idx,
-                             const void *dev_vals, const void *dev_keys, const void *dev_keys_dbg);
+                             const void *dev_vals, const void *dev_keys, const void *dev_keys_dbg, const uint32_t *n_dev = nullptr);
 
 LENTIL_API int lentil_hip_merge_sparse(lentil_hip_ctx *ctx, uint32_t row_begin, uint32_t n_rows, uint32_t n,
                                        const void *dev_idx, const void *dev_vals, const void *dev_keys) {
@@ -2661,8 +2663,9 @@ LENTIL_API int lentil_hip_merge_sparse(lentil_hip_ctx *ctx, uint32_t row_begin, 
   return merge_sparse_impl(ctx, row_begin, n_rows, n, dev_idx, dev_vals, dev_keys, nullptr);
 }
 
+// `n_dev`: n is the capacity of the arrays and the entry count is read from *n_dev by the kernels (above n: nothing merged)
 static int merge_sparse_impl(lentil_hip_ctx *ctx, uint32_t row_begin, uint32_t n_rows, uint32_t n, const void *dev_idx,
-                             const void *dev_vals, const void *dev_keys, const void *dev_keys_dbg) {
+                             const void *dev_vals, const void *dev_keys, const void *dev_keys_dbg, const uint32_t *n_dev) {
   ctx->resolved_valid = false;         // (what an early resolve left in d_resolved no longer describes the frame)
   CHECK_CTX(ctx);
   int rc = check_rows(ctx, row_begin, n_rows);
@@ -2678,18 +2681,18 @@ static int merge_sparse_impl(lentil_hip_ctx *ctx, uint32_t row_begin, uint32_t n
   if (blocks > max_blocks) blocks = max_blocks;
   hipLaunchKernelGGL(merge_sparse_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, ctx->F, n, (const uint32_t *)dev_idx,
                      (const float *)dev_vals, ctx->F.zkey ? (const unsigned long long *)dev_keys : nullptr,
-                     ctx->F.zkey_dbg ? (const unsigned long long *)dev_keys_dbg : nullptr);
+                     ctx->F.zkey_dbg ? (const unsigned long long *)dev_keys_dbg : nullptr, n_dev, n);
   HIP_TRY(ctx, hipGetLastError());
   uint64_t kb = ((uint64_t)n + 255) / 256;
   if (kb > max_blocks) kb = max_blocks;
   if (ctx->F.zkey) {
     hipLaunchKernelGGL(merge_sparse_keys_kernel, dim3((unsigned)kb), dim3(256), 0, ctx->stream, ctx->F.zkey, ctx->F.np, n,
-                       (const uint32_t *)dev_idx, (const unsigned long long *)dev_keys);
+                       (const uint32_t *)dev_idx, (const unsigned long long *)dev_keys, n_dev, n);
     HIP_TRY(ctx, hipGetLastError());
   }
   if (ctx->F.zkey_dbg) {
     hipLaunchKernelGGL(merge_sparse_keys_kernel, dim3((unsigned)kb), dim3(256), 0, ctx->stream, ctx->F.zkey_dbg, ctx->F.np, n,
-                       (const uint32_t *)dev_idx, (const unsigned long long *)dev_keys_dbg);
+                       (const uint32_t *)dev_idx, (const unsigned long long *)dev_keys_dbg, n_dev, n);
     HIP_TRY(ctx, hipGetLastError());
   }
   if (ctx->dirty_known) {       // the entries lie in rows [row_begin, row_begin + n_rows), the sender's compact_rows range

@@ -4217,8 +4217,12 @@ __global__ __launch_bounds__(256) void compact_rows_kernel(FrameDev F, uint64_t 
 }
 
 // the receiving side: entries of ONE sender (every pixel at most once), launches of different senders are ordered
+// (n_dev: the entry count is the message's own header word, read here -- the host never learns it before the merge; a
+// count above `cap` means the sender's entries did not fit and the rows follow whole, lentil_comm.h)
 __global__ __launch_bounds__(256) void merge_sparse_kernel(FrameDev F, uint32_t n, const uint32_t *idx, const float *vals,
-                                                           const unsigned long long *keys, const unsigned long long *keys_dbg) {
+                                                           const unsigned long long *keys, const unsigned long long *keys_dbg,
+                                                           const uint32_t *n_dev, uint32_t cap) {
+  if (n_dev) { const uint32_t c = *n_dev; n = c <= cap ? c : 0u; }
   const uint32_t used = 4u * F.n_aovs + 1u;
   const uint64_t total = (uint64_t)n * used;
   const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
@@ -4241,7 +4245,9 @@ __global__ __launch_bounds__(256) void merge_sparse_kernel(FrameDev F, uint32_t 
 }
 
 __global__ __launch_bounds__(256) void merge_sparse_keys_kernel(unsigned long long *mine, uint64_t np, uint32_t n,
-                                                                const uint32_t *idx, const unsigned long long *keys) {
+                                                                const uint32_t *idx, const unsigned long long *keys,
+                                                                const uint32_t *n_dev, uint32_t cap) {
+  if (n_dev) { const uint32_t c = *n_dev; n = c <= cap ? c : 0u; }
   const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
   for (uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += stride) {
     const uint64_t p = idx[e];

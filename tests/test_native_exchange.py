@@ -81,7 +81,7 @@ def test_exchange_bands_matches_the_whole_frame(orc, gpu_ctx_factory, fake_rccl,
     whole.P = p
     ctxs, keepalive, bands = _band_contexts(gpu_ctx_factory, p, table, W, H, M, world, bounds, f_hi, kinds)
     uid = capi.Context.comm_unique_id()
-    got = {}
+    got, counts = {}, {}
 
     def rank_fn(rank):
         ctx = ctxs[rank]
@@ -89,16 +89,69 @@ def test_exchange_bands_matches_the_whole_frame(orc, gpu_ctx_factory, fake_rccl,
         for _ in range(2):
             got[rank] = distributed.frame_step_bands_native(ctx, H, bounds)
             ctx.sync()
+        counts[rank] = ctx.exchange_counts()
         ctx.comm_destroy()
 
     _threads(rank_fn, world)
     reach = 0
     for rank in range(world):
         assert got[rank] == bands[rank]
+        # (sparse: the fixed-capacity form, whose messages are sized before the pass -- at these frame sizes a message holds
+        # every pixel of its band, nothing overflows; whole rows: the sized form)
+        assert counts[rank] == ((2, 0) if sparse else (0, 0))
         lo, hi = ctxs[rank].touched_rows()
         reach = max(reach, bands[rank][0] - lo, hi - bands[rank][1])
         _compare_with_whole(ctxs[rank], whole, kinds, rows=bands[rank])
     assert reach > 0
+
+
+@pytest.mark.parametrize("world,bounds", [(2, None), (4, [0, 6, 20, 33, 45])], ids=["2", "4"])
+def test_exchange_bands_fixed_form_overflow_and_adaptation(orc, gpu_ctx_factory, fake_rccl, world, bounds):
+    """The fixed-capacity form of lentil_hip_exchange_bands (exchange_bands_fixed, lentil_comm.h): a message's capacity is
+    what both of its ends derive from the pair's previous message.  Run in a child process with LENTIL_EXCHANGE_CAP_FIRST=8 (read
+    once per process), so first messages are too small for what the draws scatter over a neighbour's band: those pairs must
+    detect it from the header alone (nothing merged), send the region's rows whole, and size the next message to fit --
+    every exchange's band against the whole-frame context."""
+    import subprocess
+    import sys
+    import textwrap
+    code = textwrap.dedent("""
+        import sys, threading, numpy as np
+        sys.path.insert(0, %r)
+        import common, oracle_lib
+        from pota_amd import capi, distributed
+        from test_gpu_parity import _compare_with_whole, gpu_run
+        from test_native_exchange import _band_contexts, _threads
+        world, bounds = %d, %r
+        W, H, M, kinds = 64, 45, 9, [0, 1, 0]
+        p, model, table, keep = common.po_setup(W, H, samples_override=48)
+        visits, cols = common.make_stream(p, W, H, M, f_hi=0.03, n_extra=2)
+        whole = capi.Context(0)
+        gpu_run(whole, p, table, visits, n_aovs=3, kinds=kinds)
+        whole.P = p
+        ctxs, keepalive, bands = _band_contexts(lambda: capi.Context(0), p, table, W, H, M, world, bounds, 0.03, kinds)
+        uid = capi.Context.comm_unique_id()
+        counts = {}
+        def rank_fn(rank):
+            ctx = ctxs[rank]
+            ctx.comm_init(uid, rank, world)
+            counts[rank] = []
+            for k in range(3):
+                distributed.frame_step_bands_native(ctx, H, bounds)
+                ctx.sync()
+                counts[rank].append(ctx.exchange_counts())
+                _compare_with_whole(ctx, whole, kinds, rows=bands[rank])
+            ctx.comm_destroy()
+        _threads(rank_fn, world)
+        first = sum(counts[r][0][1] for r in range(world))
+        later = sum(counts[r][2][1] - counts[r][0][1] for r in range(world))
+        assert all(counts[r][2][0] == 3 for r in range(world)), counts
+        assert first >= 2 and later == 0, counts      # overflowed at first (seen by both ends of a pair), sized to fit afterwards
+        print("OVERFLOWED", first)
+        """) % (os.path.join(common.ROOT, "tests"), world, bounds)
+    env = dict(os.environ, LENTIL_EXCHANGE_CAP_FIRST="8", LENTIL_RCCL_LIB=FAKE)
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "OVERFLOWED" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
 
 
 def test_allreduce_matches_the_whole_frame(orc, gpu_ctx_factory, fake_rccl):
