@@ -261,13 +261,17 @@ int lentil_hip_alloc_frame(lentil_hip_ctx *ctx, uint32_t n_aovs, const uint8_t *
 
 /* A moving camera.  The reference asks Arnold for the matrix at every AOV sample's own time:
  * AiWorldToCameraMatrix(camera_node, lentil_time) (src/lentil_filter.cpp:141-144).  Here the caller hands over n_keys
- * world-to-camera matrices (row-vector convention like lentil_params::world_to_camera) at equidistant shutter-relative
- * times 0 ... 1 -- the camera's matrix keys, or samples of AiWorldToCameraMatrix at those times -- and every visit uses
- * the component-wise interpolation ((b - a) * f) + a of the two keys around its lentil_time (raydir_time column, .w;
- * clamped to [0, 1]).  n_keys <= 1 or NULL: the static matrix of lentil_params again.  With keys the scan reads the
- * raydir_time column for every visit (80 instead of 64 bytes moved per visit) and runs register-staged. */
+ * world-to-camera matrices (row-vector convention like lentil_params::world_to_camera) at equidistant times over the
+ * camera's shutter, shutter_start + k / (n_keys - 1) * (shutter_end - shutter_start) -- samples of AiWorldToCameraMatrix
+ * at those absolute times -- and every visit uses the component-wise interpolation ((b - a) * f) + a of the two keys around
+ * its lentil_time (raydir_time column, .w: Arnold's absolute sample time, inside the shutter; times outside it clamp to the
+ * first / last key).  n_keys <= 1 or NULL: the static matrix of lentil_params again.  With keys the scan reads the
+ * raydir_time column for every visit (80 instead of 64 bytes moved per visit) and runs register-staged.
+ * set_camera_shutter: the shutter interval the keys span (Arnold's camera.shutter_start / .shutter_end; a centred shutter
+ * is -0.25 ... 0.25); 0 ... 1 until set.  shutter_end must be greater than shutter_start. */
 #define LENTIL_MAX_MOTION_KEYS 16
 int lentil_hip_set_camera_motion(lentil_hip_ctx *ctx, uint32_t n_keys, const float *world_to_camera);
+int lentil_hip_set_camera_shutter(lentil_hip_ctx *ctx, float shutter_start, float shutter_end);
 
 /* Camera::logarithmic_focus_search (src/lentil.h:1445-1460; called per camera update at :1632): the sensor
  * shift, among the 20 001 candidates of logarithmic_values() (src/lens.h:395-407), whose axial ray crosses

@@ -850,6 +850,9 @@ struct OrcFrame {
    * component-wise AiLerp form ((b - a) * t) + a is what this oracle and the HIP path share. */
   std::vector<float> cam_keys;
   uint32_t n_cam_keys = 0;
+  /* the keys span the camera's shutter [cam_t0, t1] (orc_frame_set_camera_shutter; 0 ... 1 unless set): lentil_time is Arnold's
+   * absolute sample time (src/lentil_filter.cpp:141-143 hands it to AiWorldToCameraMatrix as it is) */
+  float cam_t0 = 0.0f, cam_inv_dt = 1.0f;
 };
 
 ORC_API OrcFrame *orc_frame_create(uint32_t xres, uint32_t yres, uint32_t n_aovs, const uint8_t *kind,
@@ -890,6 +893,11 @@ ORC_API uint64_t orc_frame_log(const OrcFrame *F, lentil_draw_record *out, uint6
 ORC_API void orc_frame_set_camera_motion(OrcFrame *F, uint32_t n_keys, const float *world_to_camera) {
   F->n_cam_keys = n_keys >= 2 ? n_keys : 0;
   F->cam_keys.assign(world_to_camera, world_to_camera + (size_t)F->n_cam_keys * 16);
+}
+
+ORC_API void orc_frame_set_camera_shutter(OrcFrame *F, float shutter_start, float shutter_end) {
+  F->cam_t0 = shutter_start;
+  F->cam_inv_dt = 1.0f / (shutter_end - shutter_start);
 }
 
 /* `src` holds the visits that FOLLOW dst's in the stream's order (ThreadedOracle merges its threads' frames in that order).
@@ -1146,7 +1154,7 @@ static void do_visit(const lentil_params *P, const OrcLens *L, const OrcBokeh *B
 
   float cs[3];
   if (F->n_cam_keys >= 2) {                                                         /* :141-143, per-sample camera time */
-    float t = V->raydir_time[v * 4 + 3];
+    float t = (V->raydir_time[v * 4 + 3] - F->cam_t0) * F->cam_inv_dt;
     t = t < 0.0f ? 0.0f : (t > 1.0f ? 1.0f : t);
     const float sc = t * (float)(F->n_cam_keys - 1);
     uint32_t i0 = (uint32_t)sc;

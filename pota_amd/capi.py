@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("LENTIL_HIP_LIB") or os.path.join(_PKG, "liblentil_hip
 
 EXPORTS = [
     "lentil_hip_abi_version", "lentil_hip_create", "lentil_hip_destroy", "lentil_hip_last_error",
-    "lentil_hip_set_params", "lentil_hip_set_lens", "lentil_hip_set_bokeh", "lentil_hip_alloc_frame", "lentil_hip_set_camera_motion",
+    "lentil_hip_set_params", "lentil_hip_set_lens", "lentil_hip_set_bokeh", "lentil_hip_alloc_frame", "lentil_hip_set_camera_motion", "lentil_hip_set_camera_shutter",
     "lentil_hip_upload_visits", "lentil_hip_bind_visits", "lentil_hip_clear_frame",
     "lentil_hip_redistribute", "lentil_hip_resolve", "lentil_hip_sync", "lentil_hip_download_aov",
     "lentil_hip_download_accum", "lentil_hip_accum_buffer", "lentil_hip_stream",
@@ -74,6 +74,7 @@ def load_library():
         "lentil_hip_set_bokeh": (i, [vp, C.POINTER(_abi.BokehTable)]),
         "lentil_hip_alloc_frame": (i, [vp, u32, vp]),
         "lentil_hip_set_camera_motion": (i, [vp, u32, vp]),
+        "lentil_hip_set_camera_shutter": (i, [vp, C.c_float, C.c_float]),
         "lentil_hip_upload_visits": (i, [vp, C.POINTER(_abi.Visits)]),
         "lentil_hip_bind_visits": (i, [vp, C.POINTER(_abi.Visits)]),
         "lentil_hip_clear_frame": (i, [vp]),
@@ -256,8 +257,12 @@ class Context:
         self.n_aovs = n_aovs
 
     # --- visits
+    def set_camera_shutter(self, start, end):
+        """the absolute times of the first and the last camera matrix key (Arnold's shutter_start / shutter_end); 0 ... 1 until set"""
+        self._chk(self.lib.lentil_hip_set_camera_shutter(self.h, float(start), float(end)))
+
     def set_camera_motion(self, keys):
-        """[n, 4, 4] world-to-camera matrices at shutter-relative times 0 ... 1 (None / one key: the static matrix)"""
+        """[n, 4, 4] world-to-camera matrices at equidistant times over the shutter (None / one key: the static matrix)"""
         if keys is None:
             self._chk(self.lib.lentil_hip_set_camera_motion(self.h, 0, None))
             return

@@ -551,6 +551,17 @@ static int crypto_before_pass(lentil_hip_ctx *ctx) {
     if (rc) return rc;
     ctx->crypto_auto_log = want;
   }
+  // one bit per visit for crypto_enqueue_direct (which runs while the pass is in flight: it must not allocate)
+  if (ctx->V.n <= 0xFFFFFFFFull) {
+    const uint64_t words = (ctx->V.n + 31) / 32;
+    if (words > k->flag_words) {
+      HIP_TRY(ctx, hipSetDevice(ctx->device));
+      if (k->d_flag_bits) (void)hipFree(k->d_flag_bits);
+      k->d_flag_bits = nullptr; k->flag_words = 0;
+      HIP_TRY(ctx, hipMalloc(&k->d_flag_bits, words * sizeof(uint32_t)));
+      k->flag_words = words;
+    }
+  }
   return LENTIL_OK;
 }
 
@@ -585,13 +596,10 @@ static int crypto_enqueue_direct(lentil_hip_ctx *ctx, hipStream_t st) {
       // which visits the pass redistributed: from its work lists (LENTIL_CRYPTO_FLAGS=0: decided again from the columns)
       static const bool use_flags = !(getenv("LENTIL_CRYPTO_FLAGS") && getenv("LENTIL_CRYPTO_FLAGS")[0] == '0');
       if (use_flags && ctx->V.n <= 0xFFFFFFFFull) {
+        // (sized by crypto_before_pass: nothing is allocated or freed while the pass's kernels are being enqueued -- hipFree
+        // waits for the device, and the publishers and solves of a streamed pass are launched after this)
         const uint64_t words = (ctx->V.n + 31) / 32;
-        if (words > k->flag_words) {
-          if (k->d_flag_bits) (void)hipFree(k->d_flag_bits);
-          k->d_flag_bits = nullptr; k->flag_words = 0;
-          HIP_TRY(ctx, hipMalloc(&k->d_flag_bits, words * sizeof(uint32_t)));
-          k->flag_words = words;
-        }
+        if (words > k->flag_words) return fail(ctx, LENTIL_ERR_INVALID, "cryptomatte: the redistributed-visit flags were not sized for this stream");
         HIP_TRY(ctx, hipMemsetAsync(k->d_flag_bits, 0, words * sizeof(uint32_t), st));
         for (int ci = 0; ci < ctx->n_chunks; ++ci) {
           const lentil_hip_ctx::Chunk &ch = ctx->chunks[ci];

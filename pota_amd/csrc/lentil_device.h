@@ -635,14 +635,18 @@ LD_DEV void v3norm(float &x, float &y, float &z) {    // AiV3Normalize
 // lentil_params::world_to_camera, at equidistant shutter-relative times 0 ... 1; a visit's matrix is the component-wise
 // interpolation ((b - a) * f) + a of the two keys around its lentil_time (src/lentil_filter.cpp:141-144).  n < 2: the
 // static matrix of the parameters.
+// The keys lie at t0 + k / (n - 1) * (t1 - t0) of the camera's shutter [t0, t1] (lentil_hip_set_camera_shutter; 0 ... 1 unless
+// set): a visit's lentil_time is Arnold's absolute sample time, (time - t0) * inv_dt its place between the first and the last key.
 struct CamMotion {
   const float *keys;
   uint32_t n;
+  float t0, inv_dt;
 };
 // column `c` of the visit's matrix (what one camera-space coordinate needs), rows 0..3
 LD_DEV void cam_column(const lentil_params &P, const CamMotion &cm, float time, int c, float col[4]) {
   if (cm.n < 2u) { for (int r = 0; r < 4; ++r) col[r] = P.world_to_camera[r][c]; return; }
-  float t = time < 0.0f ? 0.0f : (time > 1.0f ? 1.0f : time);
+  float t = (time - cm.t0) * cm.inv_dt;
+  t = t < 0.0f ? 0.0f : (t > 1.0f ? 1.0f : t);
   const float sc = t * (float)(cm.n - 1u);
   uint32_t i0 = (uint32_t)sc;
   if (i0 > cm.n - 2u) i0 = cm.n - 2u;
@@ -664,7 +668,7 @@ struct VisitInfo {
 // everything that only feeds the draw count.  `raydir` is only read for visits at infinite depth.
 template <class RaydirLoad>
 LD_DEV bool visit_redistributes(const lentil_params &P, double lens_length, float4 pos_z, float4 volume_ignore,
-                                float4 transmission, float inv_density, RaydirLoad load_raydir, const CamMotion &cm = CamMotion{nullptr, 0u}) {
+                                float4 transmission, float inv_density, RaydirLoad load_raydir, const CamMotion &cm = CamMotion{nullptr, 0u, 0.0f, 1.0f}) {
   bool redistribute = true;
   if (P.adaptive_sampling) { if (inv_density > 0.2f) redistribute = false; }
   float wx = pos_z.x, wy = pos_z.y, wz = pos_z.z;
@@ -697,7 +701,7 @@ LD_DEV bool visit_redistributes(const lentil_params &P, double lens_length, floa
 // camera-space position of a visit (the part of visit_prologue below that the item header needs; same arithmetic)
 template <class RaydirLoad>
 LD_DEV void visit_camera_space(const lentil_params &P, float4 pos_z, RaydirLoad load_raydir, float cs[3],
-                               const CamMotion &cm = CamMotion{nullptr, 0u}) {
+                               const CamMotion &cm = CamMotion{nullptr, 0u, 0.0f, 1.0f}) {
   float wx = pos_z.x, wy = pos_z.y, wz = pos_z.z;
   const float depth = pos_z.w;
   const bool small = fabsf(wx) < kAiEpsilon && fabsf(wy) < kAiEpsilon && fabsf(wz) < kAiEpsilon;
@@ -723,7 +727,7 @@ LD_DEV void visit_camera_space(const lentil_params &P, float4 pos_z, RaydirLoad 
 
 LD_DEV VisitInfo visit_prologue(const lentil_params &P, double lens_length, float4 rgba, float4 pos_z,
                                 float4 raydir_time, float4 volume_ignore, float4 transmission,
-                                float inv_density, const CamMotion &cm = CamMotion{nullptr, 0u}) {
+                                float inv_density, const CamMotion &cm = CamMotion{nullptr, 0u, 0.0f, 1.0f}) {
   VisitInfo I;
   bool redistribute = true;
   if (P.adaptive_sampling) { if (inv_density > 0.2f) redistribute = false; }

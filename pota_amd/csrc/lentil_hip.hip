@@ -191,6 +191,7 @@ struct lentil_hip_ctx {
   double lens_housing_radius = 0.0;  // lens_aperture_housing_radius of the current table (focus search)
   float4 *d_dummy = nullptr;          // ScanArgs::dummy
   float *d_cam_keys = nullptr;        // lentil_hip_set_camera_motion
+  float shutter_t0 = 0.0f, shutter_inv_dt = 1.0f;     // lentil_hip_set_camera_shutter: the keys' first time, 1 / (last - first)
   uint32_t n_cam_keys = 0;
   struct LentilUpload *upload = nullptr;   // lentil_upload.h: the visit stream handed over piece by piece
   struct LentilComm *comm = nullptr; // lentil_comm.h: this context's RCCL communicator, if one was asked for
@@ -710,6 +711,17 @@ LENTIL_API int lentil_hip_set_camera_motion(lentil_hip_ctx *ctx, uint32_t n_keys
   return LENTIL_OK;
 }
 
+LENTIL_API int lentil_hip_set_camera_shutter(lentil_hip_ctx *ctx, float shutter_start, float shutter_end) {
+  CHECK_CTX(ctx);
+  if (!(shutter_end > shutter_start)) return fail(ctx, LENTIL_ERR_INVALID, "set_camera_shutter: shutter_end must lie after shutter_start");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));        // (no pass is reading the old range)
+  ctx->shutter_t0 = shutter_start;
+  ctx->shutter_inv_dt = 1.0f / (shutter_end - shutter_start);       // fp32, as the oracle forms it (orc_frame_set_camera_shutter)
+  apply_camera_motion(ctx);
+  return LENTIL_OK;
+}
+
 LENTIL_API int lentil_hip_alloc_frame(lentil_hip_ctx *ctx, uint32_t n_aovs, const uint8_t *kind) {
   CHECK_CTX(ctx);
   ctx->resolved_valid = false;         // (what an early resolve left in d_resolved no longer describes the frame)
@@ -794,6 +806,8 @@ static int check_visits(lentil_hip_ctx *ctx, const lentil_visits *v) {
 static void apply_camera_motion(lentil_hip_ctx *ctx) {
   ctx->V.cam.keys = ctx->n_cam_keys >= 2 ? ctx->d_cam_keys : nullptr;
   ctx->V.cam.n = ctx->n_cam_keys >= 2 ? ctx->n_cam_keys : 0u;
+  ctx->V.cam.t0 = ctx->shutter_t0;
+  ctx->V.cam.inv_dt = ctx->shutter_inv_dt;
 }
 
 static void to_dev(VisitsDev &d, const lentil_visits *v) {
@@ -813,7 +827,7 @@ static void to_dev(VisitsDev &d, const lentil_visits *v) {
   d.pixel = v->pixel;
   d.inv_density = v->inv_density;
   d.id_base = 0;
-  d.cam = CamMotion{nullptr, 0u};
+  d.cam = CamMotion{nullptr, 0u, 0.0f, 1.0f};
 }
 
 static int ensure_worklist(lentil_hip_ctx *ctx, uint64_t n) {
@@ -1712,7 +1726,8 @@ static int redistribute_streamed(lentil_hip_ctx *ctx, bool *streamed) {
   HIP_TRY(ctx, hipEventRecord(ctx->scans_done, ctx->stream));
   // cryptomatte AOVs: the adds of the visits that stay in their pixel need the scan's work lists and nothing else of the
   // pass -- beside the draws, on the spare stream, where the runtime has one (LENTIL_CRYPTO_OVERLAP=0: after the pass)
-  if (ctx->crypto && ctx->aux_stream && !(getenv("LENTIL_CRYPTO_OVERLAP") && getenv("LENTIL_CRYPTO_OVERLAP")[0] == '0')) {
+  static const bool crypto_overlap = !(getenv("LENTIL_CRYPTO_OVERLAP") && getenv("LENTIL_CRYPTO_OVERLAP")[0] == '0');
+  if (ctx->crypto && ctx->aux_stream && crypto_overlap) {
     HIP_TRY(ctx, hipStreamWaitEvent(ctx->aux_stream, ctx->scans_done, 0));
     if ((rc = crypto_enqueue_direct(ctx, ctx->aux_stream))) return rc;
     HIP_TRY(ctx, hipEventRecord(ctx->ev_crypto, ctx->aux_stream));

@@ -1718,8 +1718,13 @@ __global__ __launch_bounds__(256) void scan_ragged_kernel(ScanArgs a) {
 // lane of its first visit, from values the wave staged in LDS with coalesced loads, and lands in the pixel record as one
 // atomic add per float: on a cleared record that is the sequential sum, bit for bit (a pixel is filtered once per
 // frame, so its record meets one run).  A run that leaves the wave's 64 visits is followed into the next ones (their
-// own lanes see that they continue a run and add nothing).  A stream without runs degenerates to a visit per run:
-// what scan_ragged_kernel does.
+// own lanes see that they continue a run and add nothing) -- for kRunFollow more groups of 64: a single lane walking a
+// run of thousands of visits (a degenerate pixel column, very high AA) would serialise the scan, so the part of a run
+// further in than that is summed per group of 64, in order, by the group's first lane and added as one term per group
+// (a run of up to 320 visits, AA 17, is the reference's sequential sum bit for bit; a longer one is a blocked sum of the
+// same terms, closer to the exact sum than the sequential one and inside the 1e-5 bar).  A stream without runs
+// degenerates to a visit per run: what scan_ragged_kernel does.
+constexpr uint64_t kRunFollow = 4;
 __global__ __launch_bounds__(256) void scan_runs_kernel(ScanArgs a) {
   const VisitsDev &V = a.V;
   __shared__ uint2 s_queue[4 * kWaveQueueLds];
@@ -1751,6 +1756,17 @@ __global__ __launch_bounds__(256) void scan_runs_kernel(ScanArgs a) {
     if (lane == 0) prev = v > 0 ? V.pixel[v - 1] : kNoPixel;      // (a run may have begun in the chunk before)
     if (v == 0) prev = kNoPixel;
     const bool start = valid && pix != prev;
+    // (the run's first lane covers its own group of 64 and the kRunFollow after it: a visit whose run began before that)
+    bool beyond = false;
+    if (valid && !start && (v >> 6) > kRunFollow) {
+      const uint64_t edge = ((v >> 6) - kRunFollow) << 6;          // first visit of the earliest group an owner could sit in
+      beyond = V.pixel[edge - 1] == pix && V.pixel[edge] == pix;
+      // (two probes first: all but the visits of a long run stop here.  A stream may bring a pixel back in several runs --
+      // captured samples in arbitrary order --, so what decides is that every visit in between is the pixel's as well)
+      if (beyond)
+        for (uint64_t u = v - 1; u > edge; --u)
+          if (V.pixel[u] != pix) { beyond = false; break; }
+    }
     bool flagged = false;
     int samples = 0;
     float w = 0.f;
@@ -1813,7 +1829,9 @@ __global__ __launch_bounds__(256) void scan_runs_kernel(ScanArgs a) {
         if (j == 64u) {
           // the run goes on beyond this wave's visits
           const float4 *col = k ? V.extra[k - 1] : V.rgba;
-          for (uint64_t u = a.v_begin + g * 64ull + 64ull; u < V.n && V.pixel[u] == pix; ++u) {
+          const uint64_t u0 = a.v_begin + g * 64ull + 64ull;
+          const uint64_t u1 = (u0 + kRunFollow * 64ull) < V.n ? (u0 + kRunFollow * 64ull) : V.n;
+          for (uint64_t u = u0; u < u1 && V.pixel[u] == pix; ++u) {
             float wu;
             const float4 c = own(u, col, wu);
             sum.x += c.x; sum.y += c.y; sum.z += c.z; sum.w += c.w;
@@ -1822,6 +1840,19 @@ __global__ __launch_bounds__(256) void scan_runs_kernel(ScanArgs a) {
         }
         float *d = reinterpret_cast<float *>(a.F.aov(lin, k));
         // (a visit that adds nothing left +0; an accumulator is never -0: adding the sum to a cleared record stores it)
+        atomicAdd(d + 0, sum.x); atomicAdd(d + 1, sum.y); atomicAdd(d + 2, sum.z); atomicAdd(d + 3, sum.w);
+        if (k == 0) atomicAdd(a.F.wt(lin), ws);
+      } else if (beyond && lane == 0u) {
+        // (what an owner covers ends on a group boundary, so the visits of a run beyond it begin at lane 0 of their group
+        // and are contiguous: lane 0 sums this group's part in order and adds it as one term)
+        float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+        float ws = 0.f;
+        for (uint32_t j = 0; j < 64u && s_pix[wave][j] == pix; ++j) {
+          const float4 c = s_val[wave][j];
+          sum.x += c.x; sum.y += c.y; sum.z += c.z; sum.w += c.w;
+          ws += s_w[wave][j];
+        }
+        float *d = reinterpret_cast<float *>(a.F.aov(lin, k));
         atomicAdd(d + 0, sum.x); atomicAdd(d + 1, sum.y); atomicAdd(d + 2, sum.z); atomicAdd(d + 3, sum.w);
         if (k == 0) atomicAdd(a.F.wt(lin), ws);
       }

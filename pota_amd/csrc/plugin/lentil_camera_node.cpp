@@ -199,13 +199,18 @@ void LentilCamera::setup(AtUniverse *universe) {
     return;
   }
   P.lambda_bw = (float)lambda_um;
+  // The reference asks for the matrix at every sample's own time, AiWorldToCameraMatrix(camera_node, lentil_time)
+  // (src/lentil_filter.cpp:141-144) -- Arnold's absolute sample time, which lies inside the camera's shutter
+  // [shutter_start, shutter_end] (0 ... 1, a centred -0.25 ... 0.25, ...).  The GPU path gets the matrix sampled at
+  // equidistant times over exactly that interval and interpolates per visit (lentil_hip_set_camera_motion / _shutter); a
+  // shutter of zero length has one time and one matrix.
+  shutter_start = AiNodeGetFlt(camera_node, AtString("shutter_start"));
+  shutter_end = AiNodeGetFlt(camera_node, AtString("shutter_end"));
   AtMatrix w2c;
-  AiWorldToCameraMatrix(camera_node, 0.0f, w2c);
+  AiWorldToCameraMatrix(camera_node, shutter_start, w2c);
   memcpy(P.world_to_camera, w2c.data, sizeof P.world_to_camera);
-  // A moving camera: the reference asks for the matrix at every sample's own time (src/lentil_filter.cpp:141-144); the
-  // GPU path gets the camera's matrix at its key times and interpolates per visit (lentil_hip_set_camera_motion)
   motion_keys.clear();
-  {
+  if (shutter_end > shutter_start) {
     int nkeys = 1;
     if (AtArray *ma = AiNodeGetArray(camera_node, AtString("matrix"))) nkeys = (int)AiArrayGetNumKeys(ma);
     if (nkeys > LENTIL_MAX_MOTION_KEYS) {
@@ -214,7 +219,7 @@ void LentilCamera::setup(AtUniverse *universe) {
     }
     for (int k = 0; nkeys >= 2 && k < nkeys; ++k) {
       AtMatrix mk;
-      AiWorldToCameraMatrix(camera_node, (float)k / (float)(nkeys - 1), mk);
+      AiWorldToCameraMatrix(camera_node, shutter_start + ((float)k / (float)(nkeys - 1)) * (shutter_end - shutter_start), mk);
       motion_keys.insert(motion_keys.end(), &mk.data[0][0], &mk.data[0][0] + 16);
     }
   }
@@ -338,6 +343,7 @@ void LentilCamera::setup(AtUniverse *universe) {
     return false;
   };
   if (!gpu && !check(lentil_hip_create(0, &gpu), "lentil_hip_create")) return;
+  if (!motion_keys.empty() && !check(lentil_hip_set_camera_shutter(gpu, shutter_start, shutter_end), "lentil_hip_set_camera_shutter")) return;
   if (!check(lentil_hip_set_camera_motion(gpu, (uint32_t)(motion_keys.size() / 16), motion_keys.empty() ? nullptr : motion_keys.data()),
              "lentil_hip_set_camera_motion")) return;
   if (!check(lentil_hip_set_params(gpu, &P), "set_params")) return;

@@ -50,7 +50,8 @@ struct LentilCamera {
   lentil_stage *stage = nullptr;
   lentil_imager *imager = nullptr;
   int stage_slots = 0;
-  std::vector<float> motion_keys;           // world-to-camera at the camera's matrix key times (16 floats each; empty: static)
+  std::vector<float> motion_keys;           // world-to-camera sampled over the shutter (16 floats each; empty: static)
+  float shutter_start = 0.0f, shutter_end = 0.0f;     // the camera's shutter: where the AOV samples' lentil_time values lie
   std::atomic<int> next_slot{0};
   std::atomic<uint64_t> slot_generation{0};   // advanced by every setup(): render threads that outlive a camera update take a new slot
 

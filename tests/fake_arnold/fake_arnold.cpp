@@ -282,7 +282,12 @@ void AiWorldToCameraMatrix(const AtNode *node, float time, AtMatrix &out) {
   if (!a || a->mats.size() < 16) return;
   const int n = a->nkeys;
   if (n < 2) { memcpy(out.data, a->mats.data(), 64); return; }
-  float t = time < 0.f ? 0.f : (time > 1.f ? 1.f : time);
+  // `time` is absolute; the array's keys lie at equidistant times over the node's motion range (motion_start ... motion_end,
+  // 0 ... 1 unless set, as in Arnold)
+  float ms = AiNodeGetFlt(node, AtString("motion_start")), me = AiNodeGetFlt(node, AtString("motion_end"));
+  if (!(me > ms)) { ms = 0.f; me = 1.f; }
+  float t = (time - ms) / (me - ms);
+  t = t < 0.f ? 0.f : (t > 1.f ? 1.f : t);
   const float sc = t * (float)(n - 1);
   int i0 = (int)sc;
   if (i0 > n - 2) i0 = n - 2;

@@ -74,6 +74,7 @@ def load():
         "orc_crypto_pixel": (i, [vp, u32, u64, vp, vp, i, C.POINTER(f)]),
         "orc_frame_merge": (None, [vp, vp]),
         "orc_frame_set_camera_motion": (None, [vp, u32, vp]),
+        "orc_frame_set_camera_shutter": (None, [vp, C.c_float, C.c_float]),
         "orc_redistribute": (i, [C.POINTER(_abi.Params), vp, vp, vp, C.POINTER(_abi.Visits), u64, u64]),
         "orc_resolve": (None, [vp, u32, vp]),
         "orc_inverse_sample_density": (f, [i, f, i, C.POINTER(i)]),
@@ -156,6 +157,9 @@ class Frame:
         hp = (C.c_void_p * n)(*[h.ctypes.data for h in self._crypto_keep[0]])
         wp = (C.c_void_p * n)(*[w.ctypes.data for w in self._crypto_keep[1]])
         self.lib.orc_frame_set_crypto(self.h, n, self._crypto_keep[0][0].shape[1], C.cast(hp, C.c_void_p), C.cast(wp, C.c_void_p))
+
+    def set_camera_shutter(self, start, end):
+        self.lib.orc_frame_set_camera_shutter(self.h, float(start), float(end))
 
     def set_camera_motion(self, keys):
         """[n, 4, 4] world-to-camera matrices at shutter-relative times 0 ... 1"""

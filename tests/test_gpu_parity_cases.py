@@ -225,8 +225,9 @@ def _moving_camera_keys(n_keys):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n_keys,ragged", [(2, False), (5, False), (3, True)])
-def test_moving_camera_per_sample_time(orc, gpu_ctx_factory, n_keys, ragged):
+@pytest.mark.parametrize("n_keys,ragged,shutter", [(2, False, None), (5, False, None), (3, True, None), (5, False, (-0.25, 0.25)),
+                                                   (3, True, (0.0, 0.5))])
+def test_moving_camera_per_sample_time(orc, gpu_ctx_factory, n_keys, ragged, shutter):
     """Every AOV sample is taken to camera space with the matrix of its own time -- AiWorldToCameraMatrix(camera,
     lentil_time), src/lentil_filter.cpp:141-144: matrix keys over the shutter (lentil_hip_set_camera_motion), the
     lentil_time column deciding between them per visit.  Oracle and HIP path on the same keys and times: accepted-draw
@@ -237,7 +238,10 @@ def test_moving_camera_per_sample_time(orc, gpu_ctx_factory, n_keys, ragged):
     visits, cols = common.make_stream(p, W, H, M, f_hi=0.02)
     cols["raydir_time"] = cols["raydir_time"].copy()
     rng = np.random.default_rng(11)
-    cols["raydir_time"][:, 3] = rng.uniform(-0.1, 1.1, visits.n).astype(np.float32)        # incl. times outside the shutter (clamped)
+    # lentil_time is Arnold's absolute sample time; the keys span the camera's shutter (lentil_hip_set_camera_shutter; 0 ... 1
+    # unless set -- a centred shutter is -0.25 ... 0.25).  Incl. times outside the shutter (clamped to the first / last key)
+    s0, s1 = shutter if shutter else (0.0, 1.0)
+    cols["raydir_time"][:, 3] = rng.uniform(s0 - 0.1 * (s1 - s0), s1 + 0.1 * (s1 - s0), visits.n).astype(np.float32)
     if ragged:
         pix = np.arange(visits.n) // M
         cols["pixel"] = ((pix % W) | ((pix // W) << 16)).astype(np.uint32)
@@ -248,6 +252,8 @@ def test_moving_camera_per_sample_time(orc, gpu_ctx_factory, n_keys, ragged):
     lens = orc.orc_lens_create(C.byref(table))
     ref = oracle_lib.Frame(orc, p, n_aovs=1, keep_log=True)
     ref.set_camera_motion(keys)
+    if shutter:
+        ref.set_camera_shutter(*shutter)
     ref.run(lens, None, visits)
     still = oracle_lib.Frame(orc, p, n_aovs=1, keep_log=True)
     still.run(lens, None, visits)
@@ -256,6 +262,8 @@ def test_moving_camera_per_sample_time(orc, gpu_ctx_factory, n_keys, ragged):
     assert not np.array_equal(common.sort_log(ref.log()), common.sort_log(still.log()))
     ctx = gpu_ctx_factory()
     ctx.set_camera_motion(keys)
+    if shutter:
+        ctx.set_camera_shutter(*shutter)
     for _ in range(2):                     # second pass: blind / streamed
         c = tp.gpu_run(ctx, p, table, visits)
         rc = ref.counters()
@@ -266,6 +274,50 @@ def test_moving_camera_per_sample_time(orc, gpu_ctx_factory, n_keys, ragged):
     tp.gpu_run(ctx, p, table, visits)
     tp.check_logs(ctx, still)
     ref.close(); still.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("run_len", [200, 320, 321, 1500])
+def test_ragged_stream_with_a_long_same_pixel_run(orc, gpu_ctx_factory, run_len):
+    """scan_runs_kernel (ragged streams: runs of one pixel's samples in iterator order): the run's first lane sums its own 64
+    visits and the 256 after them in order; visits further into a run than that add themselves (kRunFollow, ADVICE round 3:
+    one lane must not walk a run of thousands).  Runs up to 320 visits stay bit-exact sequential sums; longer ones are inside
+    1e-5.  One pixel gets a run of `run_len` visits starting at an odd offset, the rest of the stream keeps 9 per pixel;
+    an extra gaussian AOV rides along."""
+    import test_gpu_parity as tp
+    W, H, M = 64, 48, 9
+    p, model, table, keep = common.po_setup(W, H, samples_override=48)
+    visits, cols = common.make_stream(p, W, H, M, f_hi=0.02, n_extra=1)
+    n = visits.n
+    pix = np.arange(n) // M
+    first = 37 * M + 5                      # the long run begins mid-pixel, mid-wave
+    target = pix[first]
+    pix[first:first + run_len] = target
+    # (the pixels the run swallowed keep their remaining visits as shorter runs; pixel `target` appears in ONE run)
+    pix[first - 5:first] = target
+    cols["pixel"] = ((pix % W) | ((pix // W) << 16)).astype(np.uint32)
+    visits, keepv = capi.make_visits(cols, visits_per_pixel=0)
+    lens = orc.orc_lens_create(C.byref(table))
+    ref = oracle_lib.Frame(orc, p, n_aovs=2, keep_log=True)
+    ref.run(lens, None, visits)
+    orc.orc_lens_destroy(lens)
+    ctx = gpu_ctx_factory()
+    for _ in range(2):
+        c = tp.gpu_run(ctx, p, table, visits, n_aovs=2)
+        rc = ref.counters()
+        assert (c.redistributed_visits, c.attempted_draws, c.accepted_draws) == (rc.redistributed_visits, rc.attempted_draws, rc.accepted_draws)
+        tp.check_logs(ctx, ref)
+        tp.check_frame(ctx, ref, n_aovs=2)
+        touched = np.zeros(p.xres * p.yres, bool)
+        touched[ref.log()[:, 2]] = True
+        lin = int(target % W) + int(target // W) * p.xres
+        buf, w = ctx.download_accum(0)
+        if not touched[lin] and run_len + 5 <= 320:
+            assert np.array_equal(buf[lin], ref.buffer(0)[lin]) and w[lin] == ref.weight()[lin]        # the sequential sum, bit for bit
+        others = ~touched
+        others[lin] = False
+        assert np.array_equal(buf[others], ref.buffer(0)[others])
+    ref.close()
 
 
 @pytest.mark.gpu

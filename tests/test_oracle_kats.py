@@ -457,11 +457,13 @@ def test_oracle_camera_motion_interpolates_the_keys(orc):
     visits, cols = common.make_stream(p, W, H, M, f_hi=0.03)
     lens = orc.orc_lens_create(C.byref(table))
 
-    def run(keys, times):
+    def run(keys, times, shutter=None):
         cols["raydir_time"][:, 3] = times
         f = oracle_lib.Frame(orc, p, n_aovs=1, keep_log=True)
         if keys is not None:
             f.set_camera_motion(keys)
+        if shutter is not None:
+            f.set_camera_shutter(*shutter)
         f.run(lens, None, visits)
         log = common.sort_log(f.log())
         f.close()
@@ -479,4 +481,12 @@ def test_oracle_camera_motion_interpolates_the_keys(orc):
     half = moved.copy(); half[3, 0] = 10.0
     assert np.array_equal(run(np.stack([ident, moved]), np.full(n, 0.5, np.float32)), run(np.stack([half, half]), np.zeros(n, np.float32)))
     assert np.array_equal(run(np.stack([ident, half, moved]), np.full(n, 0.5, np.float32)), run(np.stack([half, half]), np.zeros(n, np.float32)))
+    # lentil_time is Arnold's absolute sample time and the keys span the camera's shutter (orc_frame_set_camera_shutter): a centred
+    # shutter -0.25 ... 0.25 has the first key at -0.25, the last at 0.25 and their mean at 0
+    centred = (-0.25, 0.25)
+    assert np.array_equal(run(np.stack([ident, moved]), np.full(n, -0.25, np.float32), centred), still)
+    assert np.array_equal(run(np.stack([ident, moved]), np.full(n, 0.25, np.float32), centred), at_end)
+    assert np.array_equal(run(np.stack([ident, moved]), np.full(n, 0.9, np.float32), centred), at_end)        # beyond the shutter: last key
+    assert np.array_equal(run(np.stack([ident, moved]), np.zeros(n, np.float32), centred), run(np.stack([half, half]), np.zeros(n, np.float32)))
+    assert not np.array_equal(run(np.stack([ident, moved]), np.zeros(n, np.float32), centred), still)         # (under 0 ... 1 time 0 is key 0)
     orc.orc_lens_destroy(lens)

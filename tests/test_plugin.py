@@ -342,11 +342,29 @@ def test_frame_through_the_plugin_matches_the_oracle(fa, orc, monkeypatch):
     fa.fa_universe_destroy(C.c_void_p(u))
 
 
+def _fake_matrix_at(keys, time, motion):
+    """tests/fake_arnold's AiWorldToCameraMatrix in numpy, operation for operation (fp32)"""
+    f32 = np.float32
+    ms, me = (f32(motion[0]), f32(motion[1])) if motion else (f32(0), f32(1))
+    t = (f32(time) - ms) / (me - ms)
+    t = f32(min(max(t, f32(0)), f32(1)))
+    n = keys.shape[0]
+    sc = f32(t * f32(n - 1))
+    i0 = min(int(sc), n - 2)
+    f = f32(sc - f32(i0))
+    return ((keys[i0 + 1] - keys[i0]) * f + keys[i0]).astype(np.float32)
+
+
 @pytest.mark.gpu
-def test_moving_camera_through_the_plugin_matches_the_oracle(fa, orc, monkeypatch):
+@pytest.mark.parametrize("shutter,motion", [((0.0, 1.0), None), ((-0.25, 0.25), (-0.5, 0.5)), ((0.0, 0.5), None)],
+                         ids=["0..1", "centred", "0..0.5"])
+def test_moving_camera_through_the_plugin_matches_the_oracle(fa, orc, monkeypatch, shutter, motion):
     """The camera has matrix keys and every AOV sample its own lentil_time: the reference takes the sample to camera space
-    with AiWorldToCameraMatrix(camera, time) (src/lentil_filter.cpp:141-144).  lentil.so reads the keys at camera update,
-    hands them to the GPU path, filter_pixel captures the times; the frame equals the oracle's with the same keys."""
+    with AiWorldToCameraMatrix(camera, time) (src/lentil_filter.cpp:141-144), `time` being Arnold's absolute sample time
+    inside the camera's shutter.  lentil.so samples the matrix over [shutter_start, shutter_end] at camera update, hands
+    keys and interval to the GPU path, filter_pixel captures the times; the frame equals the oracle's on the same samples of
+    the matrix.  "centred": shutter -0.25 ... 0.25 on a camera whose keys span the motion range -0.5 ... 0.5 -- negative
+    times, keys outside the shutter (a 0 ... 1 assumption collapses these onto key 0)."""
     W, H, M, S = 48, 32, 9, 32
     monkeypatch.setenv("LENTIL_SAMPLES_OVERRIDE", str(S))
     fa.fa_messages_clear()
@@ -356,10 +374,19 @@ def test_moving_camera_through_the_plugin_matches_the_oracle(fa, orc, monkeypatc
     keys = np.stack([np.eye(4, dtype=np.float32) for _ in range(3)])
     keys[1, 3, 0], keys[2, 3, 0], keys[2, 3, 1] = 6.0, 15.0, -4.0
     assert fa.fa_camera_set_matrix_keys(C.c_void_p(u), 3, keys.ctypes.data_as(C.c_void_p)) == 0
+    fa.fa_node_set_flt(C.c_void_p(cam), b"shutter_start", C.c_float(shutter[0]))
+    fa.fa_node_set_flt(C.c_void_p(cam), b"shutter_end", C.c_float(shutter[1]))
+    if motion:
+        fa.fa_node_set_flt(C.c_void_p(cam), b"motion_start", C.c_float(motion[0]))
+        fa.fa_node_set_flt(C.c_void_p(cam), b"motion_end", C.c_float(motion[1]))
+    # what the plugin samples: the camera's three keys, at equidistant times over the shutter
+    f32 = np.float32
+    sampled = np.stack([_fake_matrix_at(keys, f32(shutter[0]) + (f32(k) / f32(2)) * (f32(shutter[1]) - f32(shutter[0])), motion)
+                        for k in range(3)])
     p, model, table, keep = common.po_setup(W, H, samples_override=S, focal_length=np.float32(35.0))
     visits, cols = common.make_stream(p, W, H, M, f_hi=0.03)
     n = W * H * M
-    times = np.random.default_rng(2).uniform(0.0, 1.0, n).astype(np.float32)
+    times = np.random.default_rng(2).uniform(shutter[0], shutter[1], n).astype(np.float32)
     cols["raydir_time"] = cols["raydir_time"].copy()
     cols["raydir_time"][:, 3] = times
     pix = np.arange(n) // M
@@ -391,7 +418,8 @@ def test_moving_camera_through_the_plugin_matches_the_oracle(fa, orc, monkeypatc
     ovisits, okeep = capi.make_visits(ocols, visits_per_pixel=M, pixels_per_row=W)
     lens = orc.orc_lens_create(C.byref(table))
     ref = oracle_lib.Frame(orc, p, n_aovs=3, kinds=kinds)
-    ref.set_camera_motion(keys)
+    ref.set_camera_motion(sampled)
+    ref.set_camera_shutter(*shutter)
     ref.run(lens, None, ovisits)
     still = oracle_lib.Frame(orc, p, n_aovs=3, kinds=kinds)
     still.run(lens, None, ovisits)
