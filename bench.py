@@ -564,6 +564,8 @@ def scan_kernel_name(aovs):
     """The scan kernel the library picks for a uniform stream of whole pixels (plan_scan in lentil_hip.hip)."""
     dma = os.environ.get("LENTIL_SCAN_DMA", "1") != "0"
     if aovs == 0:
+        if dma and os.environ.get("LENTIL_SCAN_DMA2", "1") != "0":
+            return "scan_dma2_kernel"       # (round 4: tiles pipelined into one another, one block per CU)
         return "scan_dma_kernel" if dma else "scan_uniform_kernel"
     return "scan_dma_multi_kernel" if (dma and os.environ.get("LENTIL_SCAN_DMA_MULTI", "1") != "0") else "scan_uniform_multi_kernel"
 

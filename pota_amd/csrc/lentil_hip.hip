@@ -1750,10 +1750,15 @@ static int redistribute_streamed(lentil_hip_ctx *ctx, bool *streamed) {
   // end markers from its last block), a kStream solve kernel -- one block per CU, which fits beside four accept blocks
   // -- takes them as they come, the straggler kernel beside both.  Launched AFTER the accept, so that a profiler that
   // serialises kernels runs them in an order that completes.
-  const bool overlap = live && ctx->overlap_rounds && blind_rounds >= 2;
+  // (Round 4: also in passes that park nothing -- more draws than LENTIL_SLOW_BELOW, BASELINE config 5 on one GPU: 4 560 items
+  // x 2 048 draws --, whose first accept takes 0.65 ms and whose second round used to wait for all of it: 11.7 -> see DESIGN
+  // section 5.  No straggler kernels there, just the accept feeding the resident second-round solves.  LENTIL_OVERLAP_HEAVY=0: off.)
+  static const bool overlap_heavy_ok = !(getenv("LENTIL_OVERLAP_HEAVY") && getenv("LENTIL_OVERLAP_HEAVY")[0] == '0');
+  const bool overlap_plain = !live && overlap_heavy_ok && da.slow == nullptr && nch == 1 && P.cameraType == LENTIL_POLYNOMIAL_OPTICS;
+  const bool overlap = (live || overlap_plain) && ctx->overlap_rounds && blind_rounds >= 2;
   // ... and the first accept does not wait for the first round's stragglers either (accept_item<1> / <2>): one
   // straggler queue and one solve_slow_kernel launch for both rounds, closed by the second round's solve kernel.
-  const bool decoupled = overlap && ctx->decouple && nch == 1;
+  const bool decoupled = live && overlap && ctx->decouple && nch == 1;
   // (A queue and a solve_slow_kernel launch per round, as ever: ONE kernel for both rounds would wait for end markers from
   // kernels submitted after it -- the first accept, the second round's solves -- and where two of the pass's streams share
   // a hardware queue, the default with the runtime's 4, those sit behind it in that queue: 250 ms, then the chunked redo.
@@ -2019,6 +2024,20 @@ static int redistribute_streamed(lentil_hip_ctx *ctx, bool *streamed) {
         HIP_TRY(ctx, hipEventRecord(ctx->ev_slow, ctx->pub_stream));
         HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_slow, 0));
       }
+    } else if (overlap && round == 1) {
+      // nothing parks in this pass: the second round's resident solves beside the first accept, released by what that
+      // accept itself waited for, fed by its tagged task slots and closed by its last block's end markers
+      DrawArgs d1 = da;
+      d1.slow_after_producers = 0;
+      d1.no_reset = 1;
+      d1.producers_done = &ctx->d_ctr->accept_done[0];
+      d1.producers_total = accept_blocks;
+      HIP_TRY(ctx, hipStreamWaitEvent(ch.stream, ctx->ev_round, 0));
+      launch_solve_po<true>(ctx, d1, ch.stream, (unsigned)ctx->num_cu);
+      HIP_TRY(ctx, hipGetLastError());
+      HIP_TRY(ctx, hipEventRecord(ch.done, ch.stream));
+      HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ch.done, 0));
+      hipLaunchKernelGGL(reset_round_kernel, dim3(1), dim3(1), 0, ctx->stream, ctx->d_ctr, 0u, 0u);
     } else {
       launch_solve(ctx, da, ctx->stream, (unsigned)ctx->num_cu);
     }
