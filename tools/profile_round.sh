@@ -25,8 +25,9 @@ unset LENTIL_STREAM LENTIL_CHUNKS
 # (the tags bench.py looks for in profiles/pmc_scan_latest.json: its workload_tag)
 W1="scan_dma2_kernel double_gauss_50mm 3840x2160 M=9 samples=1024 aovs=1 f_hi=1.53e-05"
 W4="scan_dma_multi_kernel petzval_58mm 3840x2160 M=9 samples=1024 aovs=9 f_hi=1.53e-05"
-python3 tools/profile_summary.py $TAG   /tmp/${TAG}_stats   /tmp/${TAG}_fetch   /tmp/${TAG}_write   --workload "$W1" > $O/summary_headline.txt 2>&1
 python3 tools/profile_summary.py ${TAG}c4 /tmp/${TAG}c4_stats /tmp/${TAG}c4_fetch /tmp/${TAG}c4_write --workload "$W4" > $O/summary_config4.txt 2>&1
+# (the headline last: profiles/pmc_scan_latest.json, which step 6's bench line reads for roofline.traffic, is the last one written)
+python3 tools/profile_summary.py $TAG   /tmp/${TAG}_stats   /tmp/${TAG}_fetch   /tmp/${TAG}_write   --workload "$W1" > $O/summary_headline.txt 2>&1
 find /tmp/${TAG}_stats -name "*kernel_stats.csv" -exec cp {} $O/profiles/${TAG}_rocprofv3_kernel_stats_full.csv \;
 # the scan kernel's launches one by one (first two of a context: the half-frame launches of its first, chunked pass)
 python3 - "$TAG" > $O/profiles/${TAG}_scan_launches.txt <<'PY'
