@@ -54,6 +54,8 @@ GPU_MAX_HW_QUEUES=8 python3 tools/crypto_rate.py > $O/profiles/${TAG}_crypto_rat
 C5="bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-second-regime --no-configs --no-pcie --no-parity-check --no-scan-alone --width 7680 --height 4320 --samples 2048"
 python3 $C5 2>/dev/null | tail -1 > $O/profiles/${TAG}_config5_one_gpu_streamed.json
 LENTIL_STREAM=0 python3 $C5 2>/dev/null | tail -1 > $O/profiles/${TAG}_config5_one_gpu_chunked.json
-# 6. the bench line as the driver runs it
+# 6. single bands of the multi-GPU frames, each alone on this GPU
+bash tools/emulate_bands.sh > $O/profiles/${TAG}_emulated_bands.txt 2>&1
+# 7. the bench line as the driver runs it
 python3 bench.py --steps 20 --warmup 3 > $O/profiles/${TAG}_bench_line.json 2> $O/bench.err
 ls -la $O/profiles
