@@ -209,7 +209,7 @@ def test_visit_capture_from_concurrent_threads():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("streaming", [False, True], ids=["staged", "streamed-upload"])
-def test_imager_buckets_match_the_direct_pipeline(gpu_ctx_factory, streaming):
+def test_imager_buckets_match_the_direct_pipeline(orc, gpu_ctx_factory, streaming):
     """driver_process_bucket (src/lentil_imager.cpp:66-193): buckets requested from several threads; the
     GPU pass runs once; the assembled frame equals the one the C-ABI pipeline delivers directly.
     "streamed-upload": the stage sends its visits to the GPU in page-locked blocks while they are appended
@@ -229,6 +229,17 @@ def test_imager_buckets_match_the_direct_pipeline(gpu_ctx_factory, streaming):
     want = [direct.download_aov(a).reshape(p.yres, p.xres, 4) for a in range(3)]
     n_draws = direct.counters().accepted_draws
     assert n_draws > 1000
+    # ... which is the oracle's frame (so the buckets below are compared with the reference's restatement, not only with
+    # another run of the same kernels): accepted draws bit-identical, accumulators and resolved AOVs at 1e-5
+    import oracle_lib
+    from test_gpu_parity import check_frame
+    lens = orc.orc_lens_create(C.byref(table))
+    ref = oracle_lib.Frame(orc, p, n_aovs=3, kinds=kinds, keep_log=True)
+    ref.run(lens, None, visits)
+    orc.orc_lens_destroy(lens)
+    direct.sync()
+    check_frame(direct, ref, n_aovs=3, kinds=kinds)
+    ref.close()
 
     ctx = gpu_ctx_factory()
     ctx.set_params(p); ctx.set_lens(table); ctx.set_bokeh(None); ctx.alloc_frame(3, kinds)
