@@ -1614,6 +1614,10 @@ static int redistribute_streamed(lentil_hip_ctx *ctx, bool *streamed) {
   // the pass again, which must not cost an earlier pass's sums.  A second pass into the same frame takes the chunked form,
   // whose kernels never wait for one another.
   if (!ctx->cleared_since_pass) return LENTIL_OK;
+  // A context whose resident waves have given up waiting before (250 ms each time, then the redo) stops trying: at once
+  // where lentil_hip_create found its streams sharing hardware queues (GPU_MAX_HW_QUEUES below 4: a kernel then sits behind
+  // the one it waits for, every pass), after the third time anywhere else (a profiler that serialises kernels, a crowded GPU).
+  if (ctx->n_stuck >= (ctx->streams_concurrent ? 3u : 1u)) return LENTIL_OK;
   // Streaming pays where the scan is most of the pass.  With many draws the chunked pass is ahead (highlight-heavy
   // frame: 114 ms against 135 ms; 15 M draws: 16.6 against 18.4 ms -- solve waves placed while the scan's are
   // resident keep running slower long after those have left, see launch_chunk_rounds), and so it is with extra

@@ -6,6 +6,7 @@ sequential reference).  The oracle also keeps an fp64 shadow accumulation, so th
 side against the exact sum can be told apart.
 """
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -1070,6 +1071,47 @@ def test_streamed_pass_that_stalls_after_its_first_accept_is_run_again(orc, monk
     finally:
         ctx.close()
         ref.close()
+
+
+@pytest.mark.parametrize("queues", ["1", "2"])
+def test_passes_under_a_runtime_with_few_hardware_queues(queues):
+    """GPU_MAX_HW_QUEUES=1 / 2 (read by the ROCm runtime when it initialises, hence a child process): the streams of a
+    streamed pass then share hardware queues and its resident kernels can sit behind the ones they wait for.
+    lentil_hip_create's probe sees that (lentil_hip_streams_concurrent = 0) and the context takes the chunked form; whatever
+    form runs, four passes in a row -- first of the context, then blind ones -- must give the oracle's frame."""
+    import subprocess
+    import sys
+    import textwrap
+    code = textwrap.dedent("""
+        import sys, numpy as np
+        sys.path.insert(0, %r)
+        import common, oracle_lib
+        from pota_amd import capi
+        from test_gpu_parity import check_frame, check_logs, gpu_run
+        W, H, M = 320, 180, 9
+        p, model, table, keep = common.po_setup(W, H, samples_override=96)
+        visits, keepv = common.make_stream(p, W, H, M, f_hi=2.0 ** -11)
+        orc = oracle_lib.load()
+        ref = common.ThreadedOracle(orc, p, table, visits, 8)
+        ctx = capi.Context(0)
+        forms = []
+        for k in range(4):
+            c = gpu_run(ctx, p, table, visits)
+            rc = ref.counters()
+            assert (c.redistributed_visits, c.attempted_draws, c.accepted_draws) == (rc.redistributed_visits, rc.attempted_draws, rc.accepted_draws)
+            check_logs(ctx, ref)
+            check_frame(ctx, ref)
+            forms.append((int(c.streamed), int(c.fallback_chunks)))
+        print("FORMS", ctx.streams_concurrent(), forms)
+        # a pass whose waves gave up waiting (250 ms, then redone: fallback_chunks) is the last streamed one of such a context
+        stalled = [i for i, f in enumerate(forms) if f[1]]
+        assert len(stalled) <= 1 and all(f == (0, 0) for f in (forms[stalled[0] + 1:] if stalled else [])), forms
+        ctx.close()
+        """) % (os.path.join(common.ROOT, "tests"),)
+    env = dict(os.environ, GPU_MAX_HW_QUEUES=queues)
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "FORMS" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+    print(r.stdout.strip().splitlines()[-1])
 
 
 def test_chromatic_streamed_pass_resolves_what_later_rounds_add(orc, gpu_ctx_factory):
