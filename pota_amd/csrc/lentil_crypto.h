@@ -56,11 +56,18 @@ LD_DEV uint32_t crypto_key_bits(float id) {
   return b == 0x80000000u ? 0u : b;
 }
 
+// where the probing for `key` starts in a table of `slots` entries (a power of two takes the mask: a 32-bit modulo by a
+// run-time divisor is ~40 instructions, and the own-pixel kernel does one per map entry of every visit)
+LD_DEV uint32_t crypto_first_slot(uint32_t key, uint32_t slots) {
+  const uint32_t h = key * 2654435761u >> 16;
+  return (slots & (slots - 1u)) == 0u ? (h & (slots - 1u)) : h % slots;
+}
+
 // map[key] += val for pixel pix of cryptomatte AOV c (key: crypto_key_bits), with atomics
 LD_DEV void crypto_table_add(const CryptoDev &C, uint32_t c, uint64_t pix, uint32_t key, float val) {
   uint32_t *K = C.keys + ((uint64_t)c * C.np + pix) * C.slots;
   float *Wt = C.wts + ((uint64_t)c * C.np + pix) * C.slots;
-  uint32_t s = (key * 2654435761u >> 16) % C.slots;
+  uint32_t s = crypto_first_slot(key, C.slots);
   bool placed = false;
   for (uint32_t i = 0; i < C.slots && !placed; ++i) {
     uint32_t cur = __hip_atomic_load(K + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -162,7 +169,7 @@ __global__ __launch_bounds__(256) void crypto_direct_owner_kernel(CryptoDev C, V
           const float cw = w[e];
           if (__float_as_uint(cw) == kCryptoEmpty) continue;
           const uint32_t key = crypto_key_bits(h[e]);
-          uint32_t s = (key * 2654435761u >> 16) % C.slots;
+          uint32_t s = crypto_first_slot(key, C.slots);
           bool placed = false;
           for (uint32_t i = 0; i < C.slots && !placed; ++i) {
             const uint32_t cur = K[s];
@@ -307,7 +314,7 @@ __global__ __launch_bounds__(128) void crypto_direct_tile_kernel(CryptoDev C, Vi
             const float cw = s_cw[(threadIdx.x * M + m) * E + e];
             if (__float_as_uint(cw) == kCryptoEmpty) continue;
             const uint32_t key = crypto_key_bits(s_h[(threadIdx.x * M + m) * E + e]);
-            uint32_t sl = (key * 2654435761u >> 16) % SL;
+            uint32_t sl = crypto_first_slot(key, SL);
             bool placed = false;
             for (uint32_t i = 0; i < SL && !placed; ++i) {
               const uint32_t cur = K[sl];
