@@ -48,7 +48,15 @@ python3 tools/timeline.py --lens petzval_58mm --aovs 8 --passes 5 --out $O/profi
 python3 tools/timeline.py --width 7680 --height 4320 --samples 2048 --passes 4 --out $O/profiles/${TAG}_timeline_config5.txt > /dev/null 2>&1
 # 4. cryptomatte replay
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/${TAG}_cr -- python3 tools/crypto_rate.py > $O/crypto_stats.log 2>&1
-find /tmp/${TAG}_cr -name "*kernel_stats.csv" -exec sh -c 'grep -E "Name|crypto_|flag_bits" "$1" | cut -d, -f1-8 > '$O/profiles/${TAG}_crypto_kernels.txt _ {} \;
+python3 - /tmp/${TAG}_cr $O/profiles/${TAG}_crypto_kernels.txt <<'PY'
+import csv, glob, sys
+f = glob.glob(sys.argv[1] + "/**/*kernel_stats.csv", recursive=True)
+with open(sys.argv[2], "w") as out:
+    out.write("# rocprofv3 --kernel-trace --stats of tools/crypto_rate.py: the pass without cryptomatte AOVs, with a draw log only, with one and with three\n")
+    for r in (csv.DictReader(open(f[0])) if f else []):
+        if "crypto_" in r["Name"] or "flag_bits" in r["Name"]:
+            out.write("%-40s calls %4s  avg %10.1f us  min %10.1f  max %10.1f\n" % (r["Name"].split("(")[0][:40], r["Calls"], float(r["AverageNs"]) / 1e3, float(r["MinNs"]) / 1e3, float(r["MaxNs"]) / 1e3))
+PY
 GPU_MAX_HW_QUEUES=8 python3 tools/crypto_rate.py > $O/profiles/${TAG}_crypto_rate.json 2> $O/crypto_rate.err
 # 5. config 5 on one GPU, streamed and chunked
 C5="bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-second-regime --no-configs --no-pcie --no-parity-check --no-scan-alone --width 7680 --height 4320 --samples 2048"
