@@ -35,7 +35,9 @@ passes that re-cut the row bands from the ranks' pass times.
 
 The printed JSON line also carries
   roofline     -- the HBM-bound scan kernel: algorithmic bytes (visits x 80 B) / its mean duration,
-                  measured with HIP events on the library's stream, against 8 TB/s; `bytes_moved_per_visit` is
+                  measured with HIP events on the library's stream -- the start / stop events of the launch itself
+                  (hipExtLaunchKernelGGL) in a streamed pass: events recorded *around* the launch read ~90 us more than
+                  rocprofv3's kernel trace, the marker behind the scan waits for the command processor -- against 8 TB/s; `bytes_moved_per_visit` is
                   what the kernel actually requests (it does not read raydir_time unless a visit is at infinite
                   depth, and stores a record per pixel); `whole_step_frac` relates the frame's bytes to the whole step;
                   `frac` is the launch inside the timed pass, where the kernel shares its CUs with the solve waves that take
