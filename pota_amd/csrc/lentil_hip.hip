@@ -290,9 +290,14 @@ static int pick_concurrent_streams(lentil_hip_ctx *ctx) {
   // a spare one beside the four (the cryptomatte replay's first half runs there while the draws go on): only where the
   // runtime has a fifth hardware queue to give (GPU_MAX_HW_QUEUES > 4)
   if (all) {
+    // (lowest priority: what runs there -- the cryptomatte replay's own-pixel kernel, thousands of 41 KB blocks -- must not
+    // stand between the pass's latency-bound tail kernels and the CU slots its blocks give back; LENTIL_AUX_PRIO=0: default priority)
+    int prio_least = 0, prio_greatest = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
+    const bool low = !(getenv("LENTIL_AUX_PRIO") && getenv("LENTIL_AUX_PRIO")[0] == '0');
     for (int attempt = 0; attempt < 6 && !ctx->aux_stream; ++attempt) {
       hipStream_t s = nullptr;
-      if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) break;
+      if ((low ? hipStreamCreateWithPriority(&s, hipStreamNonBlocking, prio_least) : hipStreamCreateWithFlags(&s, hipStreamNonBlocking)) != hipSuccess) break;
       bool ok = true;
       for (int q = 0; q < 4 && ok; ++q) ok = streams_run_together(ctx, *role[q], s, d_flag) && streams_run_together(ctx, s, *role[q], d_flag);
       if (ok) ctx->aux_stream = s;
