@@ -79,6 +79,11 @@ struct LentilComm {
   std::vector<int64_t> hist_out, hist_in;
   uint32_t *h_hdr = nullptr;                     // pinned: [world] headers to send, [world] sent (read back), [world] received
   uint64_t n_fixed = 0, n_fixed_overflow = 0;    // exchanges in that form / directed pairs whose entries did not fit
+  // An exchange in that form that returned an error on this rank.  Its peers' histories have moved on (or will, once their
+  // receives time out or complete) while this rank's have not, so the two ends of a pair would size their next message
+  // differently: every later exchange on this communicator is refused at once instead of posting sends and receives of
+  // unequal length (round-4 ADVICE).  Destroy and re-create the communicators on all ranks.
+  bool poisoned = false;
 };
 
 // One message of the fixed-capacity form, ONE send per directed pair: 4 header words {entries found, capacity, first row,
@@ -410,7 +415,7 @@ LENTIL_API int lentil_hip_exchange_bands(lentil_hip_ctx *ctx, const int32_t *bou
   if (band_hi) *band_hi = b_hi;
   int rc;
   int32_t lo = 0, hi = 0;
-  if ((rc = lentil_hip_touched_rows(ctx, &lo, &hi))) return rc;
+  if ((rc = lentil_hip_touched_rows(ctx, &lo, &hi))) { if (sparse) cm->poisoned = true; return rc; }      // (the peers go on without this rank's message)
   const uint32_t used = 4u * ctx->F.n_aovs + 1u;
   const bool keys = ctx->F.zkey != nullptr, dkeys = ctx->F.zkey_dbg != nullptr;
   if ((keys || dkeys) && ctx->closest_deferred)
@@ -419,7 +424,14 @@ LENTIL_API int lentil_hip_exchange_bands(lentil_hip_ctx *ctx, const int32_t *bou
   // (LENTIL_EXCHANGE_FIXED=0: the sized form below, whose sends carry exactly the entries found -- and whose host waits for
   // every count; sparse == 0, whole rows always, is that form too)
   static const bool fixed_form = !(getenv("LENTIL_EXCHANGE_FIXED") && getenv("LENTIL_EXCHANGE_FIXED")[0] == '0');
-  if (sparse && fixed_form) return exchange_bands_fixed(ctx, cm, bounds, visit_rows, b_lo, b_hi, lo, hi);
+  if (sparse && fixed_form) {
+    if (cm->poisoned)
+      return fail(ctx, LENTIL_ERR_INVALID, "tiled exchange: an earlier exchange on this communicator failed on this rank; its message "
+                                           "sizes no longer agree with its peers' (lentil_hip_comm_destroy / _comm_init on every rank)");
+    rc = exchange_bands_fixed(ctx, cm, bounds, visit_rows, b_lo, b_hi, lo, hi);
+    if (rc) cm->poisoned = true;
+    return rc;
+  }
 
   // ---- what this rank added to every other band, and the form it will travel in
   struct Out { int form = 0; int32_t s_lo = 0, s_hi = 0; uint32_t *idx = nullptr; float *vals = nullptr; unsigned long long *k = nullptr, *kd = nullptr; float *packed = nullptr; };

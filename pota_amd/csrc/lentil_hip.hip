@@ -1295,6 +1295,10 @@ static void init_draw_args(lentil_hip_ctx *ctx, DrawArgs &da) {
 // FrameDev::touched stops being the whole truth about `acc` (something other than a splat is written there): the
 // flags are reset, the next clear wipes the rows it knows to be dirty -- or everything
 static void untrust_touched(lentil_hip_ctx *ctx) {
+  // (every caller is about to put something other than a pass's splats into `acc` -- merges, the exchange, a fold: the frame
+  // is no longer "cleared and untouched", so a streamed pass into it could not be wiped and redone after a stall, and
+  // prepare_direct must not take the splat flags for the whole truth; round-4 ADVICE)
+  ctx->cleared_since_pass = false;
   if (!ctx->F.touched) return;
   (void)hipMemsetAsync(ctx->d_touched, 0, (ctx->F.np + 63) / 64, ctx->stream);
   ctx->F.touched = nullptr;

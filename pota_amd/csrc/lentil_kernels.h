@@ -3820,7 +3820,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LENTIL_ACCE
   __shared__ uint32_t s_emit_off[kGroup], s_emit_hi[kGroup], s_emitted[kGroup];
   const bool chroma = a.n_channels == 3;
   // (LENTIL_ACCEPT_WIDE=0 -> DrawArgs::accept_narrow: the 256-attempt steps of accept_item for everything)
-  const bool wide = !chroma && (uint32_t)a.retries <= kAcceptWinRetries && !a.accept_narrow;
+  // (... and for records wider than one wave: accept_item_wide's lane (draw, float) layout serves 64 / U draws per atomic
+  // instruction, which is none at U = 65 -- sixteen gaussian AOVs, LENTIL_MAX_AOVS; accept_item loops over draw x float)
+  uint32_t add_floats = 1;
+  for (uint32_t k = 0; k < a.F.n_aovs; ++k) if (!(a.F.closest_mask & (1u << k))) add_floats += 4;
+  const bool wide = !chroma && (uint32_t)a.retries <= kAcceptWinRetries && !a.accept_narrow && add_floats <= 64u;
   const bool dry_first = a.emit_live && !chroma && !wide;
   uint32_t per = 1;
   if (dry_first || wide) { per = (n_active + gridDim.x - 1u) / gridDim.x; per = per < 1u ? 1u : (per > kGroup ? kGroup : per); }

@@ -213,13 +213,15 @@ void LentilCamera::setup(AtUniverse *universe) {
   if (shutter_end > shutter_start) {
     int nkeys = 1;
     if (AtArray *ma = AiNodeGetArray(camera_node, AtString("matrix"))) nkeys = (int)AiArrayGetNumKeys(ma);
-    if (nkeys > LENTIL_MAX_MOTION_KEYS) {
-      AiMsgWarning("[LENTIL] the camera has %d matrix keys, the redistribution samples %d over the shutter", nkeys, LENTIL_MAX_MOTION_KEYS);
-      nkeys = LENTIL_MAX_MOTION_KEYS;
-    }
-    for (int k = 0; nkeys >= 2 && k < nkeys; ++k) {
+    // A moving camera (two keys or more) is sampled LENTIL_MAX_MOTION_KEYS times over the shutter, whatever its own key
+    // count: the camera's keys span its MOTION range, which need not be the shutter (two keys over 0 ... 1 under a centred
+    // shutter -0.25 ... 0.25: clamped before 0, linear after), so its knots fall between samples taken at `nkeys`
+    // equidistant times; sixteen samples bound the deviation from AiWorldToCameraMatrix(camera, time) to one sixteenth of
+    // the shutter around each knot (round-4 ADVICE).
+    const int ns = nkeys >= 2 ? LENTIL_MAX_MOTION_KEYS : 1;
+    for (int k = 0; ns >= 2 && k < ns; ++k) {
       AtMatrix mk;
-      AiWorldToCameraMatrix(camera_node, shutter_start + ((float)k / (float)(nkeys - 1)) * (shutter_end - shutter_start), mk);
+      AiWorldToCameraMatrix(camera_node, shutter_start + ((float)k / (float)(ns - 1)) * (shutter_end - shutter_start), mk);
       motion_keys.insert(motion_keys.end(), &mk.data[0][0], &mk.data[0][0] + 16);
     }
   }

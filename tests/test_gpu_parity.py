@@ -229,6 +229,24 @@ def test_petzval_8_aovs(orc, gpu_ctx_factory):
     check_frame(ctx, ref, n_aovs=9)
 
 
+@pytest.mark.parametrize("n_aovs", [15, 16])
+def test_the_widest_records(orc, gpu_ctx_factory, n_aovs):
+    """LENTIL_MAX_AOVS gaussian AOVs: an accepted draw adds 4 * 16 + 1 = 65 floats, one more than a wave has lanes --
+    the wide accept's (draw, float) lane layout has no room for that record and the narrow form takes it (round-4
+    ADVICE: with 16 all-gaussian AOVs no splat was issued).  15 AOVs (61 floats) is the widest record the wide form serves."""
+    W, H, M = 40, 28, 9
+    p, model, table, keep = common.po_setup(W, H, samples_override=40)
+    visits, cols = common.make_stream(p, W, H, M, f_hi=0.02, n_extra=n_aovs - 1)
+    ref = common.run_oracle(orc, p, table, visits, n_aovs=n_aovs)
+    ctx = gpu_ctx_factory()
+    c = gpu_run(ctx, p, table, visits, n_aovs=n_aovs)
+    rc = ref.counters()
+    assert rc.accepted_draws > 0
+    assert (c.attempted_draws, c.accepted_draws) == (rc.attempted_draws, rc.accepted_draws)
+    check_logs(ctx, ref)
+    check_frame(ctx, ref, n_aovs=n_aovs)
+
+
 @pytest.mark.parametrize("ragged", [False, True])
 def test_closest_filter_aovs(orc, gpu_ctx_factory, ragged):
     """closest-original AOVs (e.g. P, N, Z; src/lentil.h:832-837): per pixel the candidate with the

@@ -356,33 +356,50 @@ def _fake_matrix_at(keys, time, motion):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("shutter,motion", [((0.0, 1.0), None), ((-0.25, 0.25), (-0.5, 0.5)), ((0.0, 0.5), None)],
-                         ids=["0..1", "centred", "0..0.5"])
-def test_moving_camera_through_the_plugin_matches_the_oracle(fa, orc, monkeypatch, shutter, motion):
+@pytest.mark.parametrize("shutter,motion,n_cam_keys", [((0.0, 1.0), None, 3), ((-0.25, 0.25), (-0.5, 0.5), 3), ((0.0, 0.5), None, 3),
+                                                       ((-0.25, 0.25), (0.0, 1.0), 2)],
+                         ids=["0..1", "centred", "0..0.5", "knot-inside-the-shutter"])
+def test_moving_camera_through_the_plugin_matches_the_oracle(fa, orc, monkeypatch, shutter, motion, n_cam_keys):
     """The camera has matrix keys and every AOV sample its own lentil_time: the reference takes the sample to camera space
     with AiWorldToCameraMatrix(camera, time) (src/lentil_filter.cpp:141-144), `time` being Arnold's absolute sample time
     inside the camera's shutter.  lentil.so samples the matrix over [shutter_start, shutter_end] at camera update, hands
     keys and interval to the GPU path, filter_pixel captures the times; the frame equals the oracle's on the same samples of
     the matrix.  "centred": shutter -0.25 ... 0.25 on a camera whose keys span the motion range -0.5 ... 0.5 -- negative
-    times, keys outside the shutter (a 0 ... 1 assumption collapses these onto key 0)."""
+    times, keys outside the shutter (a 0 ... 1 assumption collapses these onto key 0).
+    "knot-inside-the-shutter" (ADVICE round 4): two keys over the motion range 0 ... 1 under a centred shutter -- the camera
+    stands still before time 0 and moves after it, a knot that no equidistant sample over the shutter hits; the sixteen
+    samples the plugin takes keep the interpolated matrix within a sixteenth of the shutter's motion of the renderer's."""
     W, H, M, S = 48, 32, 9, 32
     monkeypatch.setenv("LENTIL_SAMPLES_OVERRIDE", str(S))
     fa.fa_messages_clear()
     u, cam = _scene(fa, W, H, ["RGBA RGBA gaussian_filter driver_exr"])
     fa.fa_node_set_int(C.c_void_p(cam), b"camera_type", 1)
     fa.fa_node_set_int(C.c_void_p(cam), b"lens_model", 0)
-    keys = np.stack([np.eye(4, dtype=np.float32) for _ in range(3)])
-    keys[1, 3, 0], keys[2, 3, 0], keys[2, 3, 1] = 6.0, 15.0, -4.0
-    assert fa.fa_camera_set_matrix_keys(C.c_void_p(u), 3, keys.ctypes.data_as(C.c_void_p)) == 0
+    keys = np.stack([np.eye(4, dtype=np.float32) for _ in range(n_cam_keys)])
+    if n_cam_keys == 3:
+        keys[1, 3, 0], keys[2, 3, 0], keys[2, 3, 1] = 6.0, 15.0, -4.0
+    else:
+        keys[1, 3, 0], keys[1, 3, 1] = 15.0, -4.0
+    assert fa.fa_camera_set_matrix_keys(C.c_void_p(u), n_cam_keys, keys.ctypes.data_as(C.c_void_p)) == 0
     fa.fa_node_set_flt(C.c_void_p(cam), b"shutter_start", C.c_float(shutter[0]))
     fa.fa_node_set_flt(C.c_void_p(cam), b"shutter_end", C.c_float(shutter[1]))
     if motion:
         fa.fa_node_set_flt(C.c_void_p(cam), b"motion_start", C.c_float(motion[0]))
         fa.fa_node_set_flt(C.c_void_p(cam), b"motion_end", C.c_float(motion[1]))
-    # what the plugin samples: the camera's three keys, at equidistant times over the shutter
+    # what the plugin samples: the renderer's matrix at LENTIL_MAX_MOTION_KEYS equidistant times over the shutter
     f32 = np.float32
-    sampled = np.stack([_fake_matrix_at(keys, f32(shutter[0]) + (f32(k) / f32(2)) * (f32(shutter[1]) - f32(shutter[0])), motion)
-                        for k in range(3)])
+    NS = 16
+    sampled = np.stack([_fake_matrix_at(keys, f32(shutter[0]) + (f32(k) / f32(NS - 1)) * (f32(shutter[1]) - f32(shutter[0])), motion)
+                        for k in range(NS)])
+    # ... and how far the blend of those samples is from the renderer's own matrix at any time of the shutter: nothing
+    # where the camera's knots lie on samples or outside the shutter, at most one sample interval's motion at a knot between
+    tt = np.linspace(shutter[0], shutter[1], 997).astype(np.float32)
+    sc = (tt - f32(shutter[0])) / (f32(shutter[1]) - f32(shutter[0])) * f32(NS - 1)
+    i0 = np.minimum(sc.astype(np.int64), NS - 2)
+    blend = sampled[i0] + (sampled[i0 + 1] - sampled[i0]) * (sc - i0)[:, None, None]
+    true = np.stack([_fake_matrix_at(keys, t, motion) for t in tt])
+    moved = float(np.abs(sampled[-1] - sampled[0]).max())
+    assert float(np.abs(blend - true).max()) <= moved / (NS - 1) + 1e-4
     p, model, table, keep = common.po_setup(W, H, samples_override=S, focal_length=np.float32(35.0))
     visits, cols = common.make_stream(p, W, H, M, f_hi=0.03)
     n = W * H * M

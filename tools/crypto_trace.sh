@@ -1,5 +1,7 @@
 #!/bin/bash
 # per-launch durations of the cryptomatte replay kernels (rocprofv3 --kernel-trace over tools/crypto_rate.py), both own-pixel kernels
+# (the runtime reads it when the profiler's preloaded library initialises it -- before the program's own os.environ.setdefault runs)
+export GPU_MAX_HW_QUEUES=8
 export HSA_ENABLE_COREDUMP=0 TMPDIR=/tmp
 R=$(cd "$(dirname "$0")/.." && pwd)
 cd /tmp

@@ -1,6 +1,8 @@
 #!/bin/bash
 # The kernels of the LAST streamed pass of a short bench run, from rocprofv3 --kernel-trace of the production library: start, end
 # and the gap to the previous kernel's end (us, relative to the pass's first kernel).  usage: tools/pass_sequence.sh [bench flags]
+# (the runtime reads it when the profiler's preloaded library initialises it -- before the program's own os.environ.setdefault runs)
+export GPU_MAX_HW_QUEUES=8
 export HSA_ENABLE_COREDUMP=0 TMPDIR=/tmp
 R=$(cd "$(dirname "$0")/.." && pwd)
 cd /tmp; rm -rf /tmp/pseq

@@ -1,6 +1,8 @@
 #!/bin/bash
 # PMC passes over the accept kernel of the headline frame in the chunked form (one chunk)
 cd "$(dirname "$0")/.."
+# (the runtime reads it when the profiler's preloaded library initialises it -- before the program's own os.environ.setdefault runs)
+export GPU_MAX_HW_QUEUES=8
 export TMPDIR=/tmp LENTIL_STREAM=0 LENTIL_CHUNKS=1
 TAG=${1:-x}; O=gpurun_out/pmc_accept_$TAG; mkdir -p $O
 B="bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-second-regime --no-configs --no-pcie --no-parity-check --no-scan-alone"

@@ -1,6 +1,8 @@
 #!/bin/bash
 # PMC passes over the cryptomatte replay kernels (tools/crypto_rate.py: headline frame, 1 and 3 cryptomatte AOVs)
 cd "$(dirname "$0")/.."
+# (the runtime reads it when the profiler's preloaded library initialises it -- before the program's own os.environ.setdefault runs)
+export GPU_MAX_HW_QUEUES=8
 export TMPDIR=/tmp LENTIL_CRYPTO_OVERLAP=0
 O=gpurun_out/pmc_crypto; mkdir -p $O
 SET1="SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT"

@@ -9,6 +9,8 @@ cd "$(dirname "$0")/.."
 TAG=${1:-rXX}
 O=gpurun_out/$TAG; mkdir -p $O/profiles
 export TMPDIR=/tmp
+# (the runtime reads it when the profiler's preloaded library initialises it -- before bench.py's own os.environ.setdefault runs)
+export GPU_MAX_HW_QUEUES=8
 B="bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-second-regime --no-configs --no-pcie --no-parity-check --no-scan-alone"
 B4="$B --lens petzval_58mm --aovs 8"                       # BASELINE config 4
 # 1. per-kernel durations of the headline command and of config 4 (the program straight after --)
