@@ -709,7 +709,11 @@ def main():
         },
         "exchange": exchange, "ranks_joined": ranks_joined,
         "passes": {"timed": steps, "streamed": r["streamed"], "chunks_enqueued_blind": r["blind_chunks"],
-                   "chunks_redone_after_a_short_estimate": r["redone"], "solve_accept_rounds_max": r.get("rounds_max")},
+                   "chunks_redone_after_a_short_estimate": r["redone"], "solve_accept_rounds_max": r.get("rounds_max"),
+                   # first batches sized from the lens and the frame (lentil_hip_batch_model_stats, whole life of the context):
+                   # passes that ran with no second round of solves in flight, how many of those needed one after all
+                   "first_batch_model": dict(zip(("calibrations", "lean_passes", "lean_passes_lost", "margin_sixteenths"),
+                                                 b.ctx.batch_model_stats()))},
         "kernels_ms": {"scan": round(r["scan"] / steps, 4), "draw": round(r["draw"] / steps, 4), "resolve": round(r["resolve"] / steps, 4)},
         "roofline": {
             "kernel": scan_kernel, "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,

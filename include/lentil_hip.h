@@ -500,6 +500,18 @@ int lentil_hip_last_timing(lentil_hip_ctx *ctx, float ms[3]);
 /* kernel launches of the last redistribute: n[0] scan launches (one per chunk of the visit stream; ms[0]
  * of last_timing covers all of them), n[1] solve/accept rounds of the chunk that needed most. */
 int lentil_hip_last_launches(lentil_hip_ctx *ctx, uint32_t n[2]);
+/* First batches sized from the lens and the frame (round 5).  The reference's loop (src/lentil_filter.cpp:248-299) keeps
+ * tracing until `samples` draws of a sample have landed inside the frame, at most 5 x samples attempts of up to
+ * vignetting_retries + 1 tries each (src/lentil.h:592-648); this library computes every trace once, in batches, and sizes a
+ * sample's FIRST batch from a calibration of the lens (where its rays land, which it vignettes) so that a streamed pass needs
+ * no second round of traces.  No result depends on it: surplus traces are never looked at, a shortfall is served by further
+ * rounds.  stats[0] calibrations run, [1] passes that ran without a second round in flight, [2] ... of which needed one
+ * after all, [3] sixteenths by which the model's margin has been widened since the camera set-up last changed.
+ * debug_batch_estimate: the model's answer for n camera-space points (cm, z < 0 in front of the camera) and a draw count:
+ * out[n][4] = share of the passing aperture points that land well inside the frame, share that land inside it, share the lens
+ * vignettes, traces in the first batch.  LENTIL_ERR_INVALID without a polynomial-optics lens and parameters. */
+int lentil_hip_batch_model_stats(lentil_hip_ctx *ctx, uint64_t stats[4]);
+int lentil_hip_debug_batch_estimate(lentil_hip_ctx *ctx, uint64_t n, const float *cs_xyz, uint32_t samples, float *out);
 int lentil_hip_set_draw_log(lentil_hip_ctx *ctx, uint64_t capacity); /* 0 disables */
 int lentil_hip_download_draw_log(lentil_hip_ctx *ctx, lentil_draw_record *out, uint64_t capacity,
                                  uint64_t *n_records);

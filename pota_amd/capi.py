@@ -23,6 +23,7 @@ EXPORTS = [
     "lentil_hip_touched_rows", "lentil_hip_merge_rows", "lentil_hip_resolve_rows",
     "lentil_hip_pack_rows", "lentil_hip_merge_packed_rows", "lentil_hip_compact_rows", "lentil_hip_merge_sparse",
     "lentil_hip_get_counters", "lentil_hip_last_timing", "lentil_hip_last_launches", "lentil_hip_set_draw_log",
+    "lentil_hip_batch_model_stats", "lentil_hip_debug_batch_estimate",
     "lentil_hip_download_draw_log", "lentil_hip_test_lt_sample_aperture",
     "lentil_hip_test_trace_bw_po", "lentil_hip_test_aperture_sample", "lentil_hip_debug_scan_bands",
     "lentil_hip_lens_is_compiled", "lentil_hip_set_lens_mode",
@@ -98,6 +99,8 @@ def load_library():
         "lentil_hip_get_counters": (i, [vp, C.POINTER(_abi.Counters)]),
         "lentil_hip_last_timing": (i, [vp, C.POINTER(C.c_float)]),
         "lentil_hip_last_launches": (i, [vp, C.POINTER(C.c_uint32)]),
+        "lentil_hip_batch_model_stats": (i, [vp, C.POINTER(C.c_uint64)]),
+        "lentil_hip_debug_batch_estimate": (i, [vp, C.c_uint64, vp, C.c_uint32, vp]),
         "lentil_hip_alloc_crypto": (i, [vp, u32, u32]),
         "lentil_hip_upload_crypto": (i, [vp, C.POINTER(_abi.CryptoVisits)]),
         "lentil_hip_bind_crypto": (i, [vp, C.POINTER(_abi.CryptoVisits)]),
@@ -459,6 +462,20 @@ class Context:
         n = (C.c_uint32 * 2)()
         self._chk(self.lib.lentil_hip_last_launches(self.h, n))
         return int(n[0]), int(n[1])
+
+    def batch_model_stats(self):
+        """(calibrations, lean passes, lean passes that needed a second round after all, margin sixteenths)"""
+        n = (C.c_uint64 * 4)()
+        self._chk(self.lib.lentil_hip_batch_model_stats(self.h, n))
+        return tuple(int(x) for x in n)
+
+    def debug_batch_estimate(self, cs_xyz, samples):
+        """[n, 4]: share well inside the frame, share inside, share vignetted, first batch -- for camera-space points [n, 3]"""
+        import numpy as np
+        cs = np.ascontiguousarray(cs_xyz, np.float32)
+        out = np.zeros((cs.shape[0], 4), np.float32)
+        self._chk(self.lib.lentil_hip_debug_batch_estimate(self.h, cs.shape[0], cs.ctypes.data, int(samples), out.ctypes.data))
+        return out
 
     # --- cryptomatte AOVs
     def alloc_crypto(self, n_crypto, slots_per_pixel=0):

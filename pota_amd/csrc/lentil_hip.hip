@@ -115,6 +115,24 @@ struct lentil_hip_ctx {
   bool lean_tail = true;                     // LENTIL_LEAN_TAIL=0: ... and its second round's kernels are always in flight
   bool lean_ok = true;                       // the last streamed pass with extension left its first accept nothing to schedule
   uint64_t n_lean_lost = 0;                  // passes whose lean tail had to run the second round after all
+  // First batches from the lens and the frame (lentil_batch_model.h): the calibration table, what it was built for, and how
+  // the bets on it went.  LENTIL_PREDICT=0: every item starts with samples + retries + spare, as before round 5.
+  // Streamed pass, beauty-only frames (scan_dma2_kernel): per cent of the CUs that get a scan block.  The others hold three
+  // resident solve blocks instead of two: the pass is bound by the solves' fp64 issue slots and the scan's HBM bytes at the
+  // same time, and a CU that does both does the solves at two waves per SIMD with the scan's waves in between.
+  // LENTIL_SCAN_CUS_PCT.
+  int scan_cus_pct = 100;
+  bool predict = true;
+  float4 *d_bm_land = nullptr;
+  float4 *d_bm_box = nullptr;
+  uint32_t *d_bm_npass = nullptr;
+  bool bm_valid = false;
+  uint64_t bm_lens_sig = 0, bm_bokeh_sig = 0; // what the calibration was traced through (FNV-1a of lens header + terms / of the aperture tables)
+  uint32_t bm_nx = 17, bm_ny = 11, bm_nz = 9; // LENTIL_PREDICT_GRID=nx,ny,nz
+  float bm_fx0 = 0, bm_fx_step = 0, bm_fy0 = 0, bm_fy_step = 0, bm_u0 = 0, bm_u_step = 0;
+  uint32_t bm_margin16 = 0;                  // sixteenths the model's margin has been widened by (a lost bet adds one, at most 4)
+  uint32_t bm_since_loss = 0;
+  uint64_t n_bm_built = 0, n_lean = 0;       // calibrations run / passes that ran with the lean tail
   ItemLive *d_live = nullptr;                // ... one record per item of chunk 0
   uint64_t live_cap = 0;
   Task *d_ext_q = nullptr;                   // ... the queue of the batches it appends
@@ -389,6 +407,12 @@ LENTIL_API int lentil_hip_create(int device, lentil_hip_ctx **out_ctx) {
   if (const char *e = getenv("LENTIL_ACCEPT_BLOCKS")) ctx->accept_max_blocks = ctx->accept_stream_blocks = atoi(e);
   if (const char *e = getenv("LENTIL_EXTEND")) ctx->extend = e[0] != '0';
   if (const char *e = getenv("LENTIL_LEAN_TAIL")) ctx->lean_tail = e[0] != '0';
+  if (const char *e = getenv("LENTIL_PREDICT")) ctx->predict = e[0] != '0';
+  if (const char *e = getenv("LENTIL_SCAN_CUS_PCT")) { ctx->scan_cus_pct = atoi(e); if (ctx->scan_cus_pct < 25) ctx->scan_cus_pct = 25; if (ctx->scan_cus_pct > 100) ctx->scan_cus_pct = 100; }
+  if (const char *e = getenv("LENTIL_PREDICT_GRID")) {
+    unsigned a = 0, b = 0, c = 0;
+    if (sscanf(e, "%u,%u,%u", &a, &b, &c) == 3 && a >= 2 && b >= 2 && c >= 2 && a <= 64 && b <= 64 && c <= 32) { ctx->bm_nx = a; ctx->bm_ny = b; ctx->bm_nz = c; }
+  }
   if (ctx->accept_max_blocks < 1) ctx->accept_max_blocks = 1;
   if (const char *e = getenv("LENTIL_SOLVE_BLOCKS")) ctx->solve_max_blocks = atoi(e);
   if (ctx->solve_max_blocks < 1) ctx->solve_max_blocks = 1;
@@ -522,6 +546,7 @@ LENTIL_API int lentil_hip_destroy(lentil_hip_ctx *ctx) {
   if (ctx->h_ctr_pinned) (void)hipHostFree(ctx->h_ctr_pinned);
   (void)hipFree(ctx->d_ranges);
   (void)hipFree(ctx->d_live);
+  (void)hipFree(ctx->d_bm_land); (void)hipFree(ctx->d_bm_box); (void)hipFree(ctx->d_bm_npass);
   (void)hipFree(ctx->d_ext_q);
   (void)hipFree(ctx->d_xor); (void)hipFree(ctx->d_tlc_res); (void)hipFree(ctx->d_tlc_off); (void)hipFree(ctx->d_tlc_tasks);
   (void)hipFree(ctx->d_log);
@@ -535,6 +560,12 @@ LENTIL_API const char *lentil_hip_last_error(const lentil_hip_ctx *ctx) {
   return ctx ? ctx->err.c_str() : g_err.c_str();
 }
 
+static uint64_t fnv1a(const void *data, size_t n, uint64_t h = 0xcbf29ce484222325ull) {
+  const unsigned char *b = static_cast<const unsigned char *>(data);
+  for (size_t i = 0; i < n; ++i) { h ^= b[i]; h *= 0x100000001b3ull; }
+  return h;
+}
+
 LENTIL_API int lentil_hip_set_params(lentil_hip_ctx *ctx, const lentil_params *p) {
   CHECK_CTX(ctx);
   if (!p) return fail(ctx, LENTIL_ERR_INVALID, "params is null");
@@ -545,6 +576,8 @@ LENTIL_API int lentil_hip_set_params(lentil_hip_ctx *ctx, const lentil_params *p
     return fail(ctx, LENTIL_ERR_INVALID, "samples_override out of range");
   if (ctx->have_frame && (p->xres != ctx->P.xres || p->yres != ctx->P.yres))
     return fail(ctx, LENTIL_ERR_INVALID, "xres/yres changed after alloc_frame");
+  // (the calibration of the first-batch model holds for the parameters it was traced with)
+  if (!ctx->have_params || memcmp(&ctx->P, p, sizeof(lentil_params)) != 0) { ctx->bm_valid = false; ctx->bm_margin16 = 0; ctx->lean_ok = true; }
   ctx->P = *p;
   ctx->have_params = true;
   // polygonal apertures: the corner angles' sin / cos from this host's libm (DevBokeh::blade_sc)
@@ -668,6 +701,14 @@ LENTIL_API int lentil_hip_set_lens(lentil_hip_ctx *ctx, const lentil_lens_table 
   HIP_TRY(ctx, hipMemcpyAsync(ctx->d_terms, terms.data(), sizeof(DevTerm) * terms.size(), hipMemcpyHostToDevice, ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   ctx->have_lens = true;
+  {
+    // (the first-batch model was traced through one lens: the same table set again -- every frame, by a caller that sets
+    // everything up per frame -- keeps it)
+    DevLens hz = h;
+    for (int e = 0; e <= kMaxExp; ++e) hz.lambda_pow[e] = 0.0;       // (the wavelength belongs to the parameters)
+    const uint64_t sig = fnv1a(&hz, sizeof hz, fnv1a(terms.data(), terms.size() * sizeof(DevTerm)));
+    if (sig != ctx->bm_lens_sig) { ctx->bm_lens_sig = sig; ctx->bm_valid = false; ctx->bm_margin16 = 0; ctx->lean_ok = true; }
+  }
   return LENTIL_OK;
 }
 
@@ -691,6 +732,14 @@ LENTIL_API int lentil_hip_set_bokeh(lentil_hip_ctx *ctx, const lentil_bokeh_tabl
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   free_bokeh(ctx);
+  {
+    uint64_t sig = 0;
+    if (b && b->x > 0 && b->y > 0 && b->x == b->y && b->cdfRow && b->rowIndices && b->cdfColumn && b->columnIndices) {
+      const size_t ny_ = (size_t)b->y, nn_ = (size_t)b->x * b->y;
+      sig = fnv1a(b->cdfRow, ny_ * 4, fnv1a(b->rowIndices, ny_ * 4, fnv1a(b->cdfColumn, nn_ * 4, fnv1a(b->columnIndices, nn_ * 4)))) | 1ull;
+    }
+    if (sig != ctx->bm_bokeh_sig) { ctx->bm_bokeh_sig = sig; ctx->bm_valid = false; ctx->bm_margin16 = 0; ctx->lean_ok = true; }
+  }
   if (!b) return LENTIL_OK;
   if (b->x <= 0 || b->y <= 0 || b->x != b->y || !b->cdfRow || !b->rowIndices || !b->cdfColumn || !b->columnIndices)
     return fail(ctx, LENTIL_ERR_INVALID, "bokeh table must be square with all four arrays");
@@ -1584,6 +1633,11 @@ static int launch_scan(lentil_hip_ctx *ctx, const ScanPlan &pl, const lentil_hip
       blocks = (ch.tile_end - ch.tile_begin + 15) / 16;
       if (blocks > (uint64_t)ctx->num_cu) blocks = (uint64_t)ctx->num_cu;
       if (blocks < 1) blocks = 1;
+      // (a streamed pass may leave some CUs without a scanning block: those take a third resident solve block, scan_cus_pct;
+      // the blocks that do not scan are launched all the same and leave at once, see the kernel)
+      sa.skip_blocks = 0;
+      if (streamed_pass && ctx->scan_cus_pct < 100 && blocks == (uint64_t)ctx->num_cu)
+        sa.skip_blocks = (uint32_t)(blocks - ((uint64_t)ctx->num_cu * (uint64_t)ctx->scan_cus_pct + 99) / 100);
       if (own_events) hipExtLaunchKernelGGL(scan_dma2_kernel, dim3((unsigned)blocks), dim3(256), pl.lds, ctx->stream, ctx->ev_scan_k[0], ctx->ev_scan_k[1], 0, sa);
       else hipLaunchKernelGGL(scan_dma2_kernel, dim3((unsigned)blocks), dim3(256), pl.lds, ctx->stream, sa);
     } else {
@@ -1611,7 +1665,7 @@ static int launch_scan(lentil_hip_ctx *ctx, const ScanPlan &pl, const lentil_hip
     else hipLaunchKernelGGL(scan_ragged_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, sa);
   }
   HIP_TRY(ctx, hipGetLastError());
-  if (blocks_out) *blocks_out = (unsigned)blocks;
+  if (blocks_out) *blocks_out = (unsigned)blocks - (pl.dma && pl.dma2 ? sa.skip_blocks : 0u);
   return LENTIL_OK;
 }
 
@@ -1630,6 +1684,50 @@ static int launch_scan(lentil_hip_ctx *ctx, const ScanPlan &pl, const lentil_hip
 // Buffers are sized from the previous pass (twice what it found); an item that does not fit raises
 // DevCounters::fallback, the accept kernel then does nothing and the host redoes the draws with exact sizes.
 // ---------------------------------------------------------------------------------------
+// ---- first batches from the lens and the frame (lentil_batch_model.h) ---------------------------------------------
+// The calibration: bm_nx x bm_ny x bm_nz targets over the frame's field of view and inverse
+// depths from infinity to a quarter of the focus distance, kBmK aperture points each, on the context's stream ahead of the
+// pass that first needs it (~0.4 M traces through the table interpreter: a few milliseconds, once per camera set-up).
+static int ensure_batch_model(lentil_hip_ctx *ctx) {
+  if (ctx->bm_valid) return LENTIL_OK;
+  const lentil_params &P = ctx->P;
+  if (!ctx->have_lens || P.cameraType != LENTIL_POLYNOMIAL_OPTICS) return LENTIL_OK;
+  if (!(P.focal_length > 0.0f) || !(P.sensor_width > 0.0) || !(P.focus_distance > 0.0)) return LENTIL_OK;
+  const size_t nodes = (size_t)ctx->bm_nx * ctx->bm_ny * ctx->bm_nz;
+  if (!ctx->d_bm_land) {
+    HIP_TRY(ctx, hipMalloc(&ctx->d_bm_land, nodes * kBmK * sizeof(float4)));
+    HIP_TRY(ctx, hipMalloc(&ctx->d_bm_box, nodes * sizeof(float4)));
+    HIP_TRY(ctx, hipMalloc(&ctx->d_bm_npass, nodes * sizeof(uint32_t)));
+  }
+  const float thx = (float)(P.sensor_width * 0.5 / (double)P.focal_length) * 0.97f;       // (the rim beyond is extrapolated, batch_estimate)
+  const float thy = thx * (float)P.yres_without_region / (float)P.xres_without_region;
+  ctx->bm_fx0 = -thx; ctx->bm_fx_step = 2.0f * thx / (float)(ctx->bm_nx - 1);
+  ctx->bm_fy0 = -thy; ctx->bm_fy_step = 2.0f * thy / (float)(ctx->bm_ny - 1);
+  const float fd_cm = (float)(P.focus_distance / 10.0);              // (polynomial optics: focus_distance is in mm)
+  ctx->bm_u0 = 1.0e-6f; ctx->bm_u_step = (4.0f / fd_cm - ctx->bm_u0) / (float)(ctx->bm_nz - 1);
+  BatchModelArgs a{};
+  a.P = P; a.lens = ctx->d_lens; a.terms = ctx->d_terms; a.bokeh = ctx->bokeh;
+  a.land = ctx->d_bm_land; a.box = ctx->d_bm_box; a.npass = ctx->d_bm_npass;
+  a.fx0 = ctx->bm_fx0; a.fx_step = ctx->bm_fx_step; a.fy0 = ctx->bm_fy0; a.fy_step = ctx->bm_fy_step;
+  a.u0 = ctx->bm_u0; a.u_step = ctx->bm_u_step;
+  a.nx = ctx->bm_nx; a.ny = ctx->bm_ny; a.nz = ctx->bm_nz;
+  hipLaunchKernelGGL(batch_model_kernel, dim3((unsigned)nodes), dim3(256), 0, ctx->stream, a);
+  HIP_TRY(ctx, hipGetLastError());
+  ctx->bm_valid = true;
+  ++ctx->n_bm_built;
+  return LENTIL_OK;
+}
+static BatchModelDev batch_model_dev(const lentil_hip_ctx *ctx) {
+  BatchModelDev m{};
+  m.land = ctx->d_bm_land; m.box = ctx->d_bm_box; m.npass = ctx->d_bm_npass;
+  m.fx0 = ctx->bm_fx0; m.fx_inv = 1.0f / ctx->bm_fx_step; m.fy0 = ctx->bm_fy0; m.fy_inv = 1.0f / ctx->bm_fy_step;
+  m.u0 = ctx->bm_u0; m.u_inv = 1.0f / ctx->bm_u_step;
+  m.nx = ctx->bm_nx; m.ny = ctx->bm_ny; m.nz = ctx->bm_nz;
+  m.margin16 = ctx->bm_margin16;
+  m.xres = (float)ctx->P.xres; m.yres = (float)ctx->P.yres;
+  return m;
+}
+
 static int redistribute_streamed(lentil_hip_ctx *ctx, bool *streamed) {
   *streamed = false;
   const lentil_params &P = ctx->P;
@@ -1747,10 +1845,12 @@ static int redistribute_streamed(lentil_hip_ctx *ctx, bool *streamed) {
   if (!few) da.slow = nullptr;              // parking is for passes with few draws (DrawArgs::slow_below)
 
   unsigned scan_blocks = 0;
+  // the first-batch model's calibration, should the camera set-up have changed: on the main stream, ahead of the event the
+  // publishers (who read the table) wait for
+  if (ctx->predict && !ctx->extend && nch == 1 && (rc = ensure_batch_model(ctx))) return rc;
   // (the scan's start for lentil_hip_last_timing: the host work since the pass began -- sizing, the plan -- is not the kernel's)
   HIP_TRY(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
   if ((rc = launch_scan(ctx, plan, ch, ctx->d_ctr, &scan_blocks, true))) return rc;
-  (void)scan_blocks;
   ctx->last_scan_launches = 1;
   HIP_TRY(ctx, hipEventRecord(ch.scanned, ctx->stream));
   HIP_TRY(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
@@ -1768,7 +1868,9 @@ static int redistribute_streamed(lentil_hip_ctx *ctx, bool *streamed) {
   // The publishers and A, resident beside the scan (the counters they poll were cleared by the memset ahead of
   // ev[0]).  Submitted AFTER what they wait for -- the scan, then the publishers: should the streams share a
   // hardware queue, each finds its producer ahead of it there.
-  const unsigned a_blocks = (unsigned)ctx->num_cu * (unsigned)ctx->stream_blocks;
+  unsigned a_blocks = (unsigned)ctx->num_cu * (unsigned)ctx->stream_blocks;
+  // CUs the scan leaves alone (scan_cus_pct) have registers for one more resident solve block
+  if (scan_blocks && scan_blocks < (unsigned)ctx->num_cu && plan.dma2 && ctx->stream_blocks == 2) a_blocks += (unsigned)ctx->num_cu - scan_blocks;
   // Live straggler queue: solve_slow_kernel is launched behind the publishers (who end with the scan) and takes the parked
   // solves as they come, one wave per CU.  (Round 3, from the timeline: its waves are placed as the first solve waves
   // leave -- the idle ones do at once when the publishers' end markers arrive --, not in the registers the scan gives
@@ -1837,6 +1939,11 @@ static int redistribute_streamed(lentil_hip_ctx *ctx, bool *streamed) {
   pa.end_tasks = a_blocks * 4u + b_blocks * (b_threads / 64u);       // every first-round solve wave may hold one ticket past the last task
   // Extension (ItemLive, lentil_kernels.h): the first round's solve kernel appends the batches its items still need
   const bool extend = ctx->extend && decoupled && nch == 1 && ctx->chain_streams;
+  // First batches from the lens and the frame (lentil_batch_model.h): every item is published with the traces it is expected
+  // to need, so that the first accept finds nothing to schedule and the pass can do without a second round (lean tail, below)
+  const bool predict = ctx->predict && !extend && decoupled && nch == 1 && ctx->chain_streams;
+  if (predict && ctx->bm_valid) pub.model = batch_model_dev(ctx);        // (calibrated ahead of the scan, above)
+  const bool predicted = predict && pub.model.land != nullptr;
   if (extend) {
     if (ch.item_cap > ctx->live_cap) {
       if ((rc = grow(ctx, &ctx->d_live, ch.item_cap))) return rc;
@@ -1895,7 +2002,7 @@ static int redistribute_streamed(lentil_hip_ctx *ctx, bool *streamed) {
     HIP_TRY(ctx, hipStreamWaitEvent(ch.stream, ctx->pub_done, 0));       // (both long past when A ends)
     HIP_TRY(ctx, hipStreamWaitEvent(ch.stream, ctx->scans_done, 0));
     HIP_TRY(ctx, hipEventRecord(ctx->ev_round, ch.stream));
-    const bool lean_pass = extend && ctx->lean_tail && ctx->lean_ok && blind_rounds <= 2;
+    const bool lean_pass = (extend || predicted) && ctx->lean_tail && ctx->lean_ok && blind_rounds <= 2;
     {
       DrawArgs d0 = da;
       d0.emit_live = lean_pass ? 0 : 1;       // (lean tail: nobody is waiting for tasks)
@@ -2157,6 +2264,18 @@ static int redistribute_streamed(lentil_hip_ctx *ctx, bool *streamed) {
     if (c.tries) { ctx->mean_iters = (double)c.newton_iters / (double)c.tries; ctx->parked_frac = (double)c.slow_solves / (double)c.tries; }
     int rounds = blind_rounds;
     if (extend) ctx->lean_ok = c.n_tasks[1] == 0u;       // (what the next pass may count on)
+    if (lean) ++ctx->n_lean;
+    // A pass whose first batches came from the model and left an item short all the same: the model's margin widens for the
+    // passes that follow (the item is served by further rounds as ever); with the margin at its cap the context stops
+    // betting on the lean tail until its camera set-up changes.
+    const bool short_after_all = predicted && n_items && (c.n_tasks[1] != 0u || (lean && c.n_active[blind_rounds & 1] != 0u));
+    if (short_after_all) {
+      // (a pass that loses only now and then keeps betting: the margin comes back down after 16 passes without a loss)
+      ctx->bm_since_loss = 0;
+      if (ctx->bm_margin16 >= 4u) ctx->lean_ok = false;
+      else ctx->bm_margin16 += 1u;
+    }
+    if (predicted && !short_after_all && ++ctx->bm_since_loss >= 16u && ctx->bm_margin16 > 0u) { --ctx->bm_margin16; ctx->bm_since_loss = 0; }
     if (lean && n_items && c.n_tasks[1] != 0u) {
       // The lean tail's bet was lost: the first accept scheduled tasks, the accept behind it did nothing.  The round the
       // ordinary way -- its solves (the queue is complete), their stragglers, the accept that was held back -- then whatever
@@ -2185,6 +2304,9 @@ static int redistribute_streamed(lentil_hip_ctx *ctx, bool *streamed) {
       ctx->late_resolve_done = false;
       if ((rc = finish_rounds(ctx, 0, da, blind_rounds, &rounds))) return rc;
       if (rounds > ch.est_rounds) ch.est_rounds = rounds;
+      if (lean) ++ctx->n_lean_lost;
+    } else if (lean) {
+      rounds = 1;       // one round of solves: the accept behind the first one only waited for that round's parked solves
     }
     ctx->last_rounds = rounds;
   }
@@ -3033,6 +3155,52 @@ static int dev_alloc(lentil_hip_ctx *ctx, size_t n, T **dst, std::vector<void *>
   tmp.push_back(*dst);
   return LENTIL_OK;
 }
+
+LENTIL_API int lentil_hip_batch_model_stats(lentil_hip_ctx *ctx, uint64_t stats[4]) {
+  CHECK_CTX(ctx);
+  if (!stats) return fail(ctx, LENTIL_ERR_INVALID, "stats is null");
+  stats[0] = ctx->n_bm_built; stats[1] = ctx->n_lean; stats[2] = ctx->n_lean_lost; stats[3] = ctx->bm_margin16;
+  return LENTIL_OK;
+}
+
+// one wave per point: what publish_kernel's waves compute for an item there
+__global__ __launch_bounds__(64) void batch_estimate_kernel(BatchModelDev M, uint64_t n, const float *cs, uint32_t samples, uint32_t retries,
+                                                            uint32_t extra_num, uint32_t extra_const, float *out) {
+  const uint64_t i = blockIdx.x;
+  if (i >= n) return;
+  const uint32_t plain = first_batch_hi(samples, retries, extra_num, extra_const);
+  const BatchEstimate e = batch_estimate(M, cs[3 * i], cs[3 * i + 1], cs[3 * i + 2], threadIdx.x);
+  if (threadIdx.x == 0) {
+    out[4 * i] = e.q_strict; out[4 * i + 1] = e.q; out[4 * i + 2] = e.fail;
+    out[4 * i + 3] = (float)batch_from_estimate(e, samples, retries, plain, M.margin16);
+  }
+}
+
+LENTIL_API int lentil_hip_debug_batch_estimate(lentil_hip_ctx *ctx, uint64_t n, const float *cs_xyz, uint32_t samples, float *out) {
+  CHECK_CTX(ctx);
+  if (!cs_xyz || !out) return fail(ctx, LENTIL_ERR_INVALID, "null argument");
+  if (!ctx->have_params || !ctx->have_lens || ctx->P.cameraType != LENTIL_POLYNOMIAL_OPTICS)
+    return fail(ctx, LENTIL_ERR_INVALID, "the first-batch model needs polynomial-optics parameters and a lens");
+  if (!n) return LENTIL_OK;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  int rc;
+  if ((rc = ensure_batch_model(ctx))) return rc;
+  if (!ctx->bm_valid) return fail(ctx, LENTIL_ERR_INVALID, "no first-batch model for these parameters");
+  std::vector<void *> tmp;
+  float *d_cs = nullptr, *d_out = nullptr;
+  if ((rc = dev_copy_in(ctx, cs_xyz, (size_t)n * 3, &d_cs, tmp)) == LENTIL_OK && (rc = dev_alloc(ctx, (size_t)n * 4, &d_out, tmp)) == LENTIL_OK) {
+    const uint32_t retries = (uint32_t)(ctx->P.vignetting_retries < 0 ? 0 : ctx->P.vignetting_retries);
+    hipLaunchKernelGGL(batch_estimate_kernel, dim3((unsigned)n), dim3(64), 0, ctx->stream, batch_model_dev(ctx), n, d_cs, samples, retries,
+                       ctx->extra_num, ctx->extra_const, d_out);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e == hipSuccess) e = hipMemcpy(out, d_out, (size_t)n * 4 * sizeof(float), hipMemcpyDeviceToHost);
+    if (e != hipSuccess) rc = fail(ctx, LENTIL_ERR_HIP, std::string("batch estimate: ") + hipGetErrorString(e));
+  }
+  for (void *p : tmp) (void)hipFree(p);
+  return rc;
+}
+
 struct TmpFree {
   std::vector<void *> v;
   ~TmpFree() { for (void *p : v) (void)hipFree(p); }

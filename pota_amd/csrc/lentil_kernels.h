@@ -11,6 +11,7 @@
 //   resolve_kernel     K7: weight normalisation.
 #pragma once
 #include "lentil_device.h"
+#include "lentil_batch_model.h"
 #include "generated/lens_registry.h"
 
 using namespace lentil;
@@ -229,6 +230,7 @@ struct StreamPub {
   ItemLive *live;              // non-null: extension (ItemLive)
   Task *ext_q;                 // ... its task queue and the waves that serve it (end markers)
   uint32_t ext_keepers;
+  BatchModelDev model;         // land non-null: first batches sized from the lens and the frame (lentil_batch_model.h)
 };
 
 // Hand-off words are written with atomics as well (exchange, nothing returned): "8-byte agent-scope atomics on both
@@ -310,6 +312,7 @@ struct ScanArgs {
   float4 *dummy;                   // scan_dma_multi_kernel: 64 x 16 B that lanes without a record store to
   ScanBands bands;                 // scan_dma2_kernel: where the circle-of-confusion test is decided by the depth alone
   uint32_t ppr_magic, ppr_shift;   // scan_dma2_kernel: pixel / pixels_per_row = __umulhi(pixel, ppr_magic) >> ppr_shift
+  uint32_t skip_blocks;            // scan_dma2_kernel: blocks at the front of the grid that leave at once (see there)
 };
 
 LD_DEV void visit_pixel(const VisitsDev &V, uint64_t v, int &px, int &py) {
@@ -423,9 +426,9 @@ LD_DEV uint32_t first_batch_hi(uint32_t samples, uint32_t retries, uint32_t extr
 // the tasks of its first batch.  An item that does not fit (item buffers, result pool, task queue: sized from the
 // previous pass) raises DevCounters::fallback -- the host then redoes the draws of the pass with exact sizes -- and
 // still fills the task slots it reserved (with empty tasks), so that no ticket waits for a slot that never comes.
-LD_DEV void publish_item(const lentil_params &P, const VisitsDev &V, const StreamPub &S, DevCounters *ctr, uint32_t item, uint2 wi) {
+LD_DEV void publish_item(const lentil_params &P, const VisitsDev &V, const StreamPub &S, DevCounters *ctr, uint32_t item, uint2 wi,
+                         uint32_t count, const float cs[3]) {
   const uint32_t retries = (uint32_t)S.retries, nch = S.n_channels;
-  const uint32_t count = first_batch_hi(wi.y, retries, S.extra_num, S.extra_const);
   const uint32_t nt = (count + 63u) / 64u;
   // (extension: room for every R(m) the item can ever ask for, so that later batches lie behind the first)
   const uint32_t reserve = S.live ? wi.y * 5u + retries : count;
@@ -435,9 +438,7 @@ LD_DEV void publish_item(const lentil_params &P, const VisitsDev &V, const Strea
                   (unsigned long long)tb + nt * nch <= S.task_cap;
   if (!ok) ctr->fallback = 1ull;
   if (item < S.item_cap) {
-    float cs[3];
     const uint32_t v = wi.x;
-    visit_camera_space(P, V.pos_z[v], [&]() { return V.raydir_time[v]; }, cs, V.cam);
     int px, py;
     visit_pixel(V, v, px, py);
     const ItemHdr hd = make_item_hdr(P, cs, px, py);
@@ -1037,6 +1038,11 @@ __global__ __launch_bounds__(256) void scan_dma2_kernel(ScanArgs a) {
   LENTIL_TL_SPAN(SPAN_SCAN);
   extern __shared__ float4 smem[];
   // (the wave's number as a scalar: tile numbers, LDS bases and every branch on them stay in scalar registers)
+  // ScanArgs::skip_blocks: the first blocks of the grid leave at once -- their CUs' registers and LDS go to a third resident
+  // solve block (lentil_hip.hip, scan_cus_pct).  They are part of the grid, not left out of it, so that whichever of the two
+  // kernels the dispatcher places first, every block that does scan finds a CU with room: a CU holds either this kernel's
+  // block and two solve blocks or three solve blocks, and the blocks that leave free exactly the CUs the others need.
+  if (blockIdx.x < a.skip_blocks) { scan_block_done(a); return; }
   const uint32_t lane = threadIdx.x & 63u, wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const VisitsDev &V = a.V;
   const uint32_t M = V.visits_per_pixel;
@@ -1181,7 +1187,7 @@ __global__ __launch_bounds__(256) void scan_dma2_kernel(ScanArgs a) {
   // ---- a wave's tiles: runs of four, first its share of a static interleaved split, then what tile_next hands out
   const uint64_t n_full = full_end > a.tile_begin ? full_end - a.tile_begin : 0ull;
   const uint32_t n_runs = (uint32_t)((n_full + 3u) / 4u);
-  const uint32_t W = gridDim.x * 4u, gw = blockIdx.x * 4u + wave;
+  const uint32_t W = (gridDim.x - a.skip_blocks) * 4u, gw = (blockIdx.x - a.skip_blocks) * 4u + wave;
   const uint32_t n_static = (uint32_t)(((uint64_t)n_runs * 7u / 8u) / W);       // runs per wave of the static part
   // (ScanArgs::outside_in: the runs alternate between the two ends of the range and meet in the middle, scan_order)
   auto run_first = [&](uint32_t r) { return a.tile_begin + (uint64_t)(a.outside_in ? ((r & 1u) ? n_runs - 1u - (r >> 1) : (r >> 1)) : r) * 4u; };
@@ -1231,7 +1237,7 @@ __global__ __launch_bounds__(256) void scan_dma2_kernel(ScanArgs a) {
     }
   }
   // the stream's last, partial tile (fewer than 64 pixels): one wave, straight from global memory
-  if (a.tile_end > full_end && blockIdx.x == 0 && wave == 0) {
+  if (a.tile_end > full_end && blockIdx.x == a.skip_blocks && wave == 0) {
     const uint64_t tile = full_end;
     const uint64_t n_pixels = V.n / M;
     const uint64_t pix = tile * 64u + lane;
@@ -1913,11 +1919,30 @@ __global__ __launch_bounds__(64) void publish_kernel(PublishArgs a) {
     if (over) break;
     const uint32_t base = (uint32_t)rec, n = (uint32_t)(rec >> 32) & ((1u << kTaskTagShift) - 1u);
     if (n == kEndRange) break;                                  // behind the last range
-    for (uint32_t i = lane; i < n; i += 64u) {
-      const uint32_t item = base + i;
-      if ((uint64_t)item >= a.work_cap) continue;
-      const uint64_t wi = ld_coherent64(a.work + item);         // written through by the scan before the range record
-      publish_item(a.P, a.V, a.S, a.ctr, item, make_uint2((uint32_t)wi, (uint32_t)(wi >> 32)));
+    for (uint32_t i0 = 0; i0 < n; i0 += 64u) {
+      const uint32_t item = base + i0 + lane;
+      const bool mine = i0 + lane < n && (uint64_t)item < a.work_cap;
+      uint64_t wi = 0;
+      if (mine) wi = ld_coherent64(a.work + item);              // written through by the scan before the range record
+      float cs[3] = {0.0f, 0.0f, 0.0f};
+      if (mine) {
+        const uint32_t v = (uint32_t)wi;
+        visit_camera_space(a.P, a.V.pos_z[v], [&]() { return a.V.raydir_time[v]; }, cs, a.V.cam);
+      }
+      const uint32_t samples = (uint32_t)(wi >> 32);
+      uint32_t count = first_batch_hi(samples, (uint32_t)a.S.retries, a.S.extra_num, a.S.extra_const);
+      if (a.S.model.land) {
+        // the first batch from the lens and the frame: the wave looks at its items one after the other, all lanes on one item
+        unsigned long long todo = __ballot(mine);
+        while (todo) {
+          const int j = __builtin_ctzll(todo);
+          todo &= todo - 1ull;
+          const float x = __shfl(cs[0], j), y = __shfl(cs[1], j), z = __shfl(cs[2], j);
+          const BatchEstimate e = batch_estimate(a.S.model, x, y, z, lane);
+          if ((int)lane == j) count = batch_from_estimate(e, samples, (uint32_t)a.S.retries, count, a.S.model.margin16);
+        }
+      }
+      if (mine) publish_item(a.P, a.V, a.S, a.ctr, item, make_uint2((uint32_t)wi, samples), count, cs);
     }
   }
   // everything this wave published has arrived (publish_item waits for its stores); sign off

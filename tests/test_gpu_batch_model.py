@@ -1,0 +1,144 @@
+"""First batches sized from the lens and the frame (pota_amd/csrc/lentil_batch_model.h; round 5).
+
+The reference traces an item until `samples` of its draws have landed inside the frame, at most 5 x samples attempts
+(src/lentil_filter.cpp:248-299).  The library computes every trace once, in batches; since round 5 a streamed pass sizes an
+item's first batch from a calibration of the lens so that no second round of traces is needed.  Checked here: what the
+model promises against what the oracle says every item needed, and that a pass which runs that way still leaves the
+oracle's frame, draw for draw.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import common
+from pota_amd import capi, workload
+from test_gpu_parity import check_frame, check_logs, gpu_run
+
+pytestmark = pytest.mark.gpu
+
+
+def items_stream(p, W, H, px, py, depth_cm, seed=7):
+    """One highlight visit per (px, py, depth): the workload's pinhole mapping, ragged layout (explicit pixel)."""
+    n = len(px)
+    rng = np.random.default_rng(seed)
+    f32 = np.float32
+    thx = f32(common.tan_half_fov(p))
+    thy = f32(thx * f32(H) / f32(W))
+    fx = (px.astype(f32) + rng.random(n, dtype=f32)) * f32(2.0 / W) - f32(1.0)
+    fy = f32(1.0) - (py.astype(f32) + rng.random(n, dtype=f32)) * f32(2.0 / H)
+    d = depth_cm.astype(f32)
+    X, Y, Z = fx * thx * d, fy * thy * d, -d
+    dist = np.sqrt(X * X + Y * Y + Z * Z).astype(f32)
+    z0 = np.zeros(n, f32)
+    rad = np.full(n, workload.HIGHLIGHT_RADIANCE, f32)
+    cols = {
+        "rgba": np.ascontiguousarray(np.stack([rad, rad, rad, z0 + 1], 1)),
+        "pos_z": np.ascontiguousarray(np.stack([X, Y, Z, dist], 1)),
+        "raydir_time": np.ascontiguousarray(np.stack([X / dist, Y / dist, Z / dist, z0], 1)),
+        "volume_ignore": np.zeros((n, 4), f32), "transmission": np.zeros((n, 4), f32),
+        "pixel": (px.astype(np.uint32) | (py.astype(np.uint32) << 16)),
+    }
+    return cols
+
+
+@pytest.mark.parametrize("lens", ["double_gauss_50mm", "petzval_58mm"])
+def test_first_batch_model_against_the_oracle(orc, gpu_ctx_factory, lens):
+    """Items all over a 1920 x 1080 frame, a third of them within 80 pixels of its edge, depths on both sides of the focus
+    plane.  The oracle's accepted-draw log says how many attempts every item made; the model's first batch must hold every
+    trace those attempts looked at (attempts + vignetting_retries) for all but a stray item, without asking for more than
+    a fifth beyond what was needed in total -- and the plain batch for the items that need nothing more."""
+    W, H, S = 1920, 1080, 128
+    p, model, table, keep = common.po_setup(W, H, lens=lens, samples_override=S)
+    rng = np.random.default_rng(3)
+    n = 600
+    px = rng.integers(0, W, n)
+    py = rng.integers(0, H, n)
+    edge = rng.random(n) < 0.35
+    side = rng.integers(0, 4, n)
+    off = rng.integers(0, 80, n)
+    px = np.where(edge & (side == 0), off, np.where(edge & (side == 1), W - 1 - off, px))
+    py = np.where(edge & (side == 2), off, np.where(edge & (side == 3), H - 1 - off, py))
+    fd = float(p.focus_distance) / 10.0
+    u = rng.random(n)
+    depth = np.where(rng.random(n) < 0.5, (u * 0.4 + 0.35) * fd, (u * 2.4 + 1.6) * fd)
+    cols = items_stream(p, W, H, px, py, depth)
+    visits, kv = capi.make_visits(cols)
+    ref = common.ThreadedOracle(orc, p, table, visits, 8, row_visits=n // 16)
+    log = ref.log()
+    rc = ref.counters()
+    assert rc.redistributed_visits == n
+    acc = np.bincount(log[:, 0], minlength=n)
+    last = np.zeros(n, np.int64)
+    np.maximum.at(last, log[:, 0], log[:, 1].astype(np.int64))
+    retries = int(p.vignetting_retries)
+    need = np.where(acc < S, 5 * S, last + 1)                      # attempts made
+    looked_at = np.minimum(need + retries, 5 * S + retries)          # R(m) those attempts may have read
+    ctx = gpu_ctx_factory()
+    ctx.set_params(p)
+    ctx.set_lens(table)
+    cs = cols["pos_z"][:, :3]
+    est = ctx.debug_batch_estimate(cs, S)
+    batch = est[:, 3].astype(np.int64)
+    plain = S + retries + 16
+    assert int(batch.min()) >= plain and int(batch.max()) <= 5 * S + retries
+    short = batch < looked_at
+    detail = "; ".join("px %d py %d z %.0f need %d batch %d q %.3f strict %.3f fail %.3f true %.3f" % (
+        px[i], py[i], -depth[i], need[i], batch[i], est[i, 1], est[i, 0], est[i, 2], (acc[i] / need[i])) for i in np.nonzero(short)[0][:12])
+    assert int(short.sum()) <= max(1, n // 200), "items the model leaves short: %d of %d: %s" % (int(short.sum()), n, detail)
+    # (the traces a batch holds beyond the item's own attempts + retries are what the model costs)
+    # (128 draws: four standard deviations of the count are a quarter of the batch at a rate of one half)
+    assert float(batch.sum()) <= 1.3 * float(looked_at.sum()), (int(batch.sum()), int(looked_at.sum()))
+    # items whose every attempt succeeded at once are, nearly all, promised just that
+    easy = need == S
+    assert float((batch[easy] == plain).mean()) > (0.85 if lens == "double_gauss_50mm" else 0.0)
+    assert ctx.batch_model_stats()[0] == 1
+    # the same set-up again keeps the calibration; another lens does not
+    ctx.set_params(p); ctx.set_lens(table)
+    ctx.debug_batch_estimate(cs[:4], S)
+    assert ctx.batch_model_stats()[0] == 1
+    other = "petzval_58mm" if lens == "double_gauss_50mm" else "double_gauss_50mm"
+    p2, m2, t2, k2 = common.po_setup(W, H, lens=other, samples_override=S)
+    ctx.set_params(p2); ctx.set_lens(t2)
+    ctx.debug_batch_estimate(cs[:4], S)
+    assert ctx.batch_model_stats()[0] == 2
+    ref.close()
+
+
+@pytest.mark.parametrize("predict", ["1", "0"])
+def test_streamed_pass_without_a_second_round(orc, monkeypatch, predict):
+    """1280 x 720, 256 draws, highlights rare enough for the streamed form.  First pass of the context: chunked.  From the
+    second on the pass is streamed, its items' first batches come from the model and no second round of solves is in
+    flight behind the first accept (lean tail): one round reported, nothing lost, and the frame is the oracle's draw for
+    draw.  LENTIL_PREDICT=0: the plain first batches and the second round, as before -- same frame."""
+    W, H, M, S, f_hi = 1280, 720, 9, 256, 2.0 ** -13
+    monkeypatch.setenv("LENTIL_PREDICT", predict)
+    p, model, table, keep = common.po_setup(W, H, samples_override=S)
+    streams = [common.make_stream(p, W, H, M, f_hi=f_hi, seed=s) for s in (0x5EED, 0xBEEF)]
+    refs = [common.ThreadedOracle(orc, p, table, v, 8) for v, _ in streams]
+    ctx = capi.Context(0)
+    try:
+        rounds = []
+        for k in range(5):
+            visits, ref = streams[k % 2][0], refs[k % 2]
+            c = gpu_run(ctx, p, table, visits)
+            rc = ref.counters()
+            assert c.streamed == (1 if k else 0)
+            assert (c.redistributed_visits, c.attempted_draws, c.accepted_draws) == (
+                rc.redistributed_visits, rc.attempted_draws, rc.accepted_draws)
+            assert rc.attempted_draws > rc.accepted_draws        # some items do lose attempts to the frame's edge
+            check_logs(ctx, ref)
+            check_frame(ctx, ref)
+            rounds.append(ctx.last_launches()[1])
+        built, lean, lost, margin = ctx.batch_model_stats()
+        if predict == "1":
+            # (the first streamed pass still enqueues as many rounds as the chunked first pass needed; it is the model's
+            # batches that make the passes after it lean)
+            assert built == 1 and lean >= 3, (built, lean, lost, margin, rounds)
+            assert lost == 0 and rounds[-3:] == [1, 1, 1], (lost, margin, rounds)
+        else:
+            assert (built, lean) == (0, 0) and min(rounds[1:]) >= 2, (built, lean, rounds)
+    finally:
+        ctx.close()
+        for r in refs:
+            r.close()

@@ -12,11 +12,14 @@ import csv, sys
 rows = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].split("(")[0].replace("void ", "")[:48], r.get("Stream_Id", r.get("Queue_Id", "")))
         for r in csv.DictReader(open(sys.argv[1]))]
 rows.sort()
-# the last pass: from the last clear_touched_kernel on
-i0 = max(i for i, r in enumerate(rows) if "clear_touched" in r[2])
-t0 = rows[i0][0]
-last_end = None
-print("%-50s %9s %9s %8s  queue" % ("kernel", "start us", "end us", "dur us"))
-for s, e, n, q in rows[i0:]:
-    print("%-50s %9.1f %9.1f %8.1f  %s" % (n, (s - t0) / 1e3, (e - t0) / 1e3, (e - s) / 1e3, q))
+# the last PASSES passes (default 1): each from its clear_touched_kernel on
+import os
+clears = [i for i, r in enumerate(rows) if "clear_touched" in r[2]]
+n_pass = int(os.environ.get("PASSES", "1"))
+for k, i0 in enumerate(clears[-n_pass:]):
+    i1 = clears[clears.index(i0) + 1] if clears.index(i0) + 1 < len(clears) else len(rows)
+    t0 = rows[i0][0]
+    print("%-50s %9s %9s %8s  queue" % ("kernel", "start us", "end us", "dur us"))
+    for s, e, n, q in rows[i0:i1]:
+        print("%-50s %9.1f %9.1f %8.1f  %s" % (n, (s - t0) / 1e3, (e - t0) / 1e3, (e - s) / 1e3, q))
 PY
