@@ -270,7 +270,8 @@ def parity_check(W, H, M, samples, aovs, f_hi, p, table, tan_half_fov, device_in
         ctx.clear_frame(); ctx.redistribute(); ctx.resolve(); ctx.sync()
         c = ctx.counters()
         check_logs(ctx, ref)                       # AssertionError: caught by the caller, reported as ok = false
-        worst = check_frame(ctx, ref, n_aovs=n_aovs, tol=1e-5)
+        st = {}
+        worst = check_frame(ctx, ref, n_aovs=n_aovs, tol=1e-5, stats=st)
         n_log = int(ctx.draw_log().shape[0])
     finally:
         ctx.close()
@@ -278,11 +279,28 @@ def parity_check(W, H, M, samples, aovs, f_hi, p, table, tan_half_fov, device_in
         if ob:
             lib.orc_bokeh_destroy(ob)
     return {"ok": True, "accepted_draws_compared": n_log, "draw_lists_bit_identical": True, "max_rel_err": float("%.3g" % worst),
+            # max_rel_err is against the exact (fp64) sums the oracle keeps beside its buffers; the next figure is against the
+            # oracle's own fp32 buffers and images -- the reference CPU imager's numbers as it would write them -- and the one
+            # after it says how far those are themselves from the exact sums (sequential fp32 summation)
+            "max_rel_err_vs_fp32_oracle": float("%.3g" % st.get("vs_fp32", float("nan"))),
+            "fp32_oracle_own_rounding": float("%.3g" % st.get("fp32_own", float("nan"))),
             "tolerance": 1e-5, "redistributed_visits": int(c.redistributed_visits),
             "sample": "every %d-th row of the timed %dx%d frame (%d visits), HIP path against the oracle" % (row_step, W, H, n),
             "full_size": full_size or
                          "tests/test_gpu_headline.py::test_headline_4k_streamed_vs_oracle (the timed streams, bit-identical "
                          "draw lists, 1e-5 radiance) and ::test_config5_quarter_frame_vs_oracle"}
+
+
+def power_cap_watts():
+    """the package power cap as rocm-smi reports it (a child process; None where it cannot be read)"""
+    import re
+    import subprocess
+    try:
+        txt = subprocess.run(["rocm-smi", "--showmaxpower"], capture_output=True, text=True, timeout=20).stdout
+        m = re.search(r"Max Graphics Package Power \(W\):\s*([0-9.]+)", txt)
+        return float(m.group(1)) if m else None
+    except Exception:      # noqa: BLE001
+        return None
 
 
 def checked(fn, *a, **kw):
@@ -335,6 +353,15 @@ class Bench:
         ctx = capi.Context(local_rank)
         ctx.set_params(p)
         ctx.set_lens(self.table)
+        # a lens without a kernel built into the library gets one at run time (lentil_lens_jit.h): the timed passes use it
+        try:
+            ctx.lens_jit_wait(600.0)
+        except Exception as e:      # noqa: BLE001  (the table interpreter serves the lens; the line says so)
+            sys.stderr.write("bench.py: %r\n" % (e,))
+        st, sec = ctx.lens_jit_status()
+        self.lens_kernel = {"kind": {0: "built into the library" if ctx.lens_is_compiled() else "table interpreter", 1: "table interpreter (still compiling)",
+                                     2: "specialised at run time (hiprtc)", -1: "table interpreter (run-time compilation failed)"}.get(st, str(st)),
+                            "compile_seconds": round(sec, 1)}
         if bokeh_image:
             from pota_amd import bokeh
             tex = np.load(os.path.join(ROOT, "tests", "golden", "example_bokeh_kernel_u8.npy")).astype(np.float32) / np.float32(255)
@@ -672,7 +699,19 @@ def main():
         for _ in range(2):
             b.step()
         torch.cuda.synchronize()
+    # what this box delivers, before and after the timed steps (rank 0's GPU; the probe's kernels run ~10 ms on the library's stream)
+    box = None
+    if rank == 0:
+        box = checked(b.ctx.box_probe)
     r = b.run(args.steps, args.warmup)
+    if rank == 0 and isinstance(box, dict) and "error" not in box:
+        after = checked(b.ctx.box_probe)
+        if isinstance(after, dict) and "error" not in after:
+            box["after_the_timed_steps"] = {k: after[k] for k in ("fp64_mul_add_tflops", "shader_clock_mhz_under_fp64", "copy_gbs", "read_gbs")}
+        box["power_cap_w"] = power_cap_watts()
+        box["note"] = ("measured in this run by lentil_hip_box_probe: dependent fp64 multiply/add chains at three waves per SIMD (the solves' "
+                       "arithmetic, no FMA; ceiling = CUs x 4 SIMDs x 16 lanes x clock), clock64() against the 100 MHz counter under that load, "
+                       "a 512 MiB float4 copy (bytes read + written) and read-only stream; for putting timings of different boxes side by side")
     n_total = workload.frame_visit_count(W, H, M) if not emulate else b.n_local        # all ranks
     value = n_total * r["steps"] / r["dt"] / 1e6
     ms_per_step, launches, launch_ms, launch_bytes, achieved = summarize(b, r, n_total, bytes_per_visit)
@@ -707,6 +746,7 @@ def main():
                             % (world, (" at rows %s (balanced by pass time)" % b.bounds) if b.bounds else "") if tiled else
                             "rows%%%d + allreduce" % world),
         },
+        "box": box,
         "exchange": exchange, "ranks_joined": ranks_joined,
         "passes": {"timed": steps, "streamed": r["streamed"], "chunks_enqueued_blind": r["blind_chunks"],
                    "chunks_redone_after_a_short_estimate": r["redone"], "solve_accept_rounds_max": r.get("rounds_max"),
@@ -816,7 +856,10 @@ def main():
         for name, kw in (
                 ("config2_double_gauss_1920x1080_256_draws", dict(W=1920, H=1080, lens="double_gauss_50mm", samples=256, aovs=0, bokeh=False)),
                 ("config3_double_gauss_bokeh_image_3840x2160_512_draws", dict(W=3840, H=2160, lens="double_gauss_50mm", samples=512, aovs=0, bokeh=True)),
-                ("config4_petzval_3840x2160_1024_draws_9_aovs", dict(W=3840, H=2160, lens="petzval_58mm", samples=1024, aovs=8, bokeh=False))):
+                ("config4_petzval_3840x2160_1024_draws_9_aovs", dict(W=3840, H=2160, lens="petzval_58mm", samples=1024, aovs=8, bokeh=False)),
+                # config 4's other half, "anamorphic": a table with a cylindrical front element and NO kernel built into the library --
+                # its solve kernels are emitted and compiled at run time (lens_kernel says which kernel the timed passes ran)
+                ("config4_anamorphic_petzval_3840x2160_1024_draws_9_aovs", dict(W=3840, H=2160, lens="anamorphic_petzval_58mm", samples=1024, aovs=8, bokeh=False))):
             try:
                 c = Bench(torch, dist, dev, local_rank, 1, 0, kw["W"], kw["H"], kw["H"], M, kw["lens"], kw["samples"], kw["aovs"],
                           args.f_hi, kw["bokeh"])
@@ -831,13 +874,16 @@ def main():
                               "kernels_ms": {"scan": round(rc["scan"] / 4, 4), "draw": round(rc["draw"] / 4, 4), "resolve": round(rc["resolve"] / 4, 4)},
                               "scan_kernel": scan_kernel_name(kw["aovs"]), "bytes_per_visit": bpv, "scan_frac_of_hbm_peak": round(ach_c / HBM_PEAK_GBS, 4),
                               "whole_step_frac_of_hbm_peak": round(n_c * bpv / (ms_c * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                              "attempted_draws_per_step": rc["attempted"] // 4, "passes_streamed": rc["streamed"], "steps": 4}
+                              "attempted_draws_per_step": rc["attempted"] // 4, "passes_streamed": rc["streamed"], "steps": 4,
+                              "lens_kernel": c.lens_kernel}
                 pc = (c.p, c.table, c.tan_half_fov, c.bokeh_tables)
                 c.close()
                 if not args.no_parity_check:
                     test = {"config2": "test_config2_1080p_256_draws_vs_oracle", "config3": "test_config3_4k_512_draws_aperture_image_vs_oracle",
                             "config4": "test_config4_like_4k_nine_gaussian_aovs_streamed_vs_oracle (and, with two closest-filtered "
                                        "AOVs, ::test_config4_4k_petzval_two_closest_aovs_vs_oracle)"}[name[:7]]
+                    if "anamorphic" in name:
+                        test = "(this lens: tests/test_gpu_lens_jit.py, interpreter against run-time kernel bit for bit, and the bounded sample here)"
                     cfgs[name]["parity_checked"] = checked(
                         parity_check, kw["W"], kw["H"], M, kw["samples"], kw["aovs"], args.f_hi, pc[0], pc[1], pc[2], local_rank, torch,
                         bokeh_tables=pc[3], budget_s=5.0,

@@ -257,6 +257,21 @@ int lentil_hip_set_bokeh(lentil_hip_ctx *ctx, const lentil_bokeh_table *bokeh);
  * 1 = always interpret the table (parity tests compare the two). */
 int lentil_hip_lens_is_compiled(lentil_hip_ctx *ctx);
 int lentil_hip_set_lens_mode(lentil_hip_ctx *ctx, int mode);
+/* A table that has no kernel compiled into the library gets one at run time -- the reference compiles every lens into the plugin
+ * (include/auto_generated_lens_includes/load_lt_sample_aperture.h:4-47, used at src/lentil.h:1308): lentil_hip_set_lens starts a
+ * thread that emits the lens's straight-line code, compiles it with hiprtc and keeps the code object in a cache on disk
+ * (LENTIL_JIT_CACHE, default ~/.cache/lentil_hip); passes run the table interpreter until it is there.  Same results bit for
+ * bit.  status: *state 0 nothing to compile (compiled-in lens, thin lens, LENTIL_LENS_JIT=0), 1 compiling, 2 the specialised
+ * kernel is in use, -1 compilation failed (the interpreter keeps serving the lens); *compile_seconds: what the compilation took
+ * (0 from the cache).  wait: blocks until the state is no longer 1 (timeout_seconds <= 0: no limit); an error if it failed.
+ * debug_lens_jit_source: the emitted lens code (tests compare it with tools/gen_lens_code.py's). */
+int lentil_hip_lens_jit_status(lentil_hip_ctx *ctx, int *state, double *compile_seconds);
+int lentil_hip_lens_jit_wait(lentil_hip_ctx *ctx, double timeout_seconds);
+int lentil_hip_debug_lens_jit_source(lentil_hip_ctx *ctx, char *buf, uint64_t capacity, uint64_t *length);
+/* ... and without a context or a GPU (hiprtc cross-compiles): pack the table, emit the lens code and, compile != 0, compile the
+ * four solve kernels; the emitted source and the compiler's log are copied out (truncated to the capacities). */
+int lentil_hip_debug_lens_jit_compile(const lentil_lens_table *t, int compile, char *source, uint64_t source_capacity,
+                                      uint64_t *source_length, char *log, uint64_t log_capacity, double *seconds, uint64_t *code_bytes);
 int lentil_hip_alloc_frame(lentil_hip_ctx *ctx, uint32_t n_aovs, const uint8_t *aov_filter_kind);
 
 /* A moving camera.  The reference asks Arnold for the matrix at every AOV sample's own time:
@@ -444,6 +459,14 @@ int lentil_hip_exchange_counts(lentil_hip_ctx *ctx, uint64_t *fixed_form, uint64
  * LENTIL_STREAM_PROBE=0.
  * Instrumentation; no reference counterpart. */
 int lentil_hip_streams_concurrent(lentil_hip_ctx *ctx, int *concurrent);
+/* What this GPU delivers right now, for putting timings of different boxes side by side (bench.py's `box` block; no reference
+ * counterpart).  Three short kernels on the context's stream, ~10 ms in all:
+ *   probe[0]  fp64 multiply / add rate of dependent chains, three waves per SIMD on every CU -- the form of the Newton solves
+ *             (no FMA) -- in TFLOP/s; [1] the shader clock it ran at, MHz (clock64() against the 100 MHz real-time counter);
+ *   probe[2]  float4 copy, GB/s read + written; [3] float4 read-only stream, GB/s;
+ *   probe[4]  hardware queues the runtime multiplexes this process's streams onto (GPU_MAX_HW_QUEUES as the library sees it;
+ *             0: unset, the runtime's default of 4); [5] compute units. */
+int lentil_hip_box_probe(lentil_hip_ctx *ctx, double probe[6]);
 
 /* --- cryptomatte AOVs ------------------------------------------------------------------
  * The reference keeps a std::map<float, float> id -> weight and a total weight per pixel for every ranked

@@ -23,7 +23,8 @@ EXPORTS = [
     "lentil_hip_touched_rows", "lentil_hip_merge_rows", "lentil_hip_resolve_rows",
     "lentil_hip_pack_rows", "lentil_hip_merge_packed_rows", "lentil_hip_compact_rows", "lentil_hip_merge_sparse",
     "lentil_hip_get_counters", "lentil_hip_last_timing", "lentil_hip_last_launches", "lentil_hip_set_draw_log",
-    "lentil_hip_batch_model_stats", "lentil_hip_debug_batch_estimate",
+    "lentil_hip_batch_model_stats", "lentil_hip_debug_batch_estimate", "lentil_hip_box_probe",
+    "lentil_hip_lens_jit_status", "lentil_hip_lens_jit_wait", "lentil_hip_debug_lens_jit_source", "lentil_hip_debug_lens_jit_compile",
     "lentil_hip_download_draw_log", "lentil_hip_test_lt_sample_aperture",
     "lentil_hip_test_trace_bw_po", "lentil_hip_test_aperture_sample", "lentil_hip_debug_scan_bands",
     "lentil_hip_lens_is_compiled", "lentil_hip_set_lens_mode",
@@ -100,6 +101,12 @@ def load_library():
         "lentil_hip_last_timing": (i, [vp, C.POINTER(C.c_float)]),
         "lentil_hip_last_launches": (i, [vp, C.POINTER(C.c_uint32)]),
         "lentil_hip_batch_model_stats": (i, [vp, C.POINTER(C.c_uint64)]),
+        "lentil_hip_box_probe": (i, [vp, C.POINTER(C.c_double)]),
+        "lentil_hip_lens_jit_status": (i, [vp, C.POINTER(C.c_int), C.POINTER(C.c_double)]),
+        "lentil_hip_lens_jit_wait": (i, [vp, C.c_double]),
+        "lentil_hip_debug_lens_jit_compile": (i, [vp, i, C.c_char_p, C.c_uint64, C.POINTER(C.c_uint64), C.c_char_p, C.c_uint64,
+                                                  C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
+        "lentil_hip_debug_lens_jit_source": (i, [vp, C.c_char_p, C.c_uint64, C.POINTER(C.c_uint64)]),
         "lentil_hip_debug_batch_estimate": (i, [vp, C.c_uint64, vp, C.c_uint32, vp]),
         "lentil_hip_alloc_crypto": (i, [vp, u32, u32]),
         "lentil_hip_upload_crypto": (i, [vp, C.POINTER(_abi.CryptoVisits)]),
@@ -195,6 +202,18 @@ def make_visits(cols, visits_per_pixel=0, pixels_per_row=0, pixel_x0=0, pixel_y0
     if cols.get("inv_density") is not None:
         v.inv_density = ptr(cols["inv_density"])
     return v, cols
+
+
+def lens_jit_compile(table, compile=True):
+    """(rc, emitted source, compiler log, seconds, code bytes) -- no context, no GPU (lentil_hip_debug_lens_jit_compile)"""
+    lib = load_library()
+    n = C.c_uint64(0)
+    lib.lentil_hip_debug_lens_jit_compile(C.byref(table), 0, None, 0, C.byref(n), None, 0, None, None)
+    src = C.create_string_buffer(int(n.value) + 1)
+    log = C.create_string_buffer(1 << 16)
+    sec, nb = C.c_double(0.0), C.c_uint64(0)
+    rc = lib.lentil_hip_debug_lens_jit_compile(C.byref(table), 1 if compile else 0, src, int(n.value) + 1, None, log, 1 << 16, C.byref(sec), C.byref(nb))
+    return int(rc), src.value.decode(), log.value.decode(errors="replace"), float(sec.value), int(nb.value)
 
 
 class Context:
@@ -462,6 +481,29 @@ class Context:
         n = (C.c_uint32 * 2)()
         self._chk(self.lib.lentil_hip_last_launches(self.h, n))
         return int(n[0]), int(n[1])
+
+    def lens_jit_status(self):
+        """(state, compile seconds): 0 nothing to compile, 1 compiling, 2 specialised kernel in use, -1 failed"""
+        st, sec = C.c_int(0), C.c_double(0.0)
+        self._chk(self.lib.lentil_hip_lens_jit_status(self.h, C.byref(st), C.byref(sec)))
+        return int(st.value), float(sec.value)
+
+    def lens_jit_wait(self, timeout_seconds=0.0):
+        self._chk(self.lib.lentil_hip_lens_jit_wait(self.h, float(timeout_seconds)))
+
+    def lens_jit_source(self):
+        n = C.c_uint64(0)
+        self._chk(self.lib.lentil_hip_debug_lens_jit_source(self.h, None, 0, C.byref(n)))
+        buf = C.create_string_buffer(int(n.value) + 1)
+        self._chk(self.lib.lentil_hip_debug_lens_jit_source(self.h, buf, int(n.value) + 1, None))
+        return buf.value.decode()
+
+    def box_probe(self):
+        """what the GPU delivers right now: fp64 chain rate, shader clock, copy / read bandwidth, hardware queues, CUs"""
+        p = (C.c_double * 6)()
+        self._chk(self.lib.lentil_hip_box_probe(self.h, p))
+        return {"fp64_mul_add_tflops": round(p[0], 2), "shader_clock_mhz_under_fp64": round(p[1], 1), "copy_gbs": round(p[2], 1),
+                "read_gbs": round(p[3], 1), "gpu_max_hw_queues": int(p[4]), "compute_units": int(p[5])}
 
     def batch_model_stats(self):
         """(calibrations, lean passes, lean passes that needed a second round after all, margin sixteenths)"""

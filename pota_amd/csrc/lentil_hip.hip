@@ -3,6 +3,7 @@
 #include <hip/hip_ext.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -13,6 +14,9 @@
 #include <vector>
 
 #include "lentil_kernels.h"
+#include "lentil_closest_replay.h"
+#include "lentil_lens_jit.h"
+#include "generated/embedded_sources.inc"
 
 #define LENTIL_API extern "C" __attribute__((visibility("default")))
 
@@ -34,6 +38,14 @@ struct lentil_hip_ctx {
   DevTerm *d_terms = nullptr;
   bool have_lens = false;
   unsigned long long lens_hash = 0;   // FNV-1a of the base table, matches gen::Lens_*::kTableHash
+  // Run-time specialisation for a table without a compiled-in kernel (lentil_lens_jit.h): the shared entry of the table's hash,
+  // and this device's module once the code object has arrived
+  std::vector<DevTerm> h_terms;       // the packed table as lentil_hip_set_lens built it (the emitter's input)
+  bool jit_enabled = true;            // LENTIL_LENS_JIT=0: the interpreter for every table without a compiled-in kernel
+  std::shared_ptr<lentil_jit::Entry> jit;
+  hipModule_t jit_module = nullptr;
+  hipFunction_t jit_fn[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
+  bool jit_loaded = false, jit_load_failed = false;
   bool use_generated = true;          // LENTIL_FORCE_TABLES=1 forces the table interpreter
 
   DevBokeh bokeh{};
@@ -52,6 +64,12 @@ struct lentil_hip_ctx {
   // FrameDev::touched (see there): the allocation; F.touched is set while it is trusted
   uint8_t *d_touched = nullptr;
   bool cleared_since_pass = false;     // clear_frame / alloc_frame, and no redistribute since
+  // closest-filtered AOVs with candidates at depth 0 / NaN (lentil_closest_replay.h): the pass raised
+  // DevCounters::degenerate_depth; a draw log the library set up for the replay itself (no caller asked for one)
+  bool degenerate_seen = false;
+  bool closest_auto_log = false;
+  uint64_t closest_auto_log_cap = 0;
+  uint64_t n_degenerate_replays = 0;
   struct DirRegion {
     int32_t x0 = 0, y0 = 0; uint32_t row_stride = 0, ppr = 0; uint64_t npix = 0;
     bool operator==(const DirRegion &o) const { return x0 == o.x0 && y0 == o.y0 && row_stride == o.row_stride && ppr == o.ppr && npix == o.npix; }
@@ -122,6 +140,7 @@ struct lentil_hip_ctx {
   // same time, and a CU that does both does the solves at two waves per SIMD with the scan's waves in between.
   // LENTIL_SCAN_CUS_PCT.
   int scan_cus_pct = 100;
+  unsigned last_scan_skipped = 0;             // blocks of the last scan launch that left at once (scan_dma2_kernel, ScanArgs::skip_blocks)
   bool predict = true;
   float4 *d_bm_land = nullptr;
   float4 *d_bm_box = nullptr;
@@ -408,6 +427,7 @@ LENTIL_API int lentil_hip_create(int device, lentil_hip_ctx **out_ctx) {
   if (const char *e = getenv("LENTIL_EXTEND")) ctx->extend = e[0] != '0';
   if (const char *e = getenv("LENTIL_LEAN_TAIL")) ctx->lean_tail = e[0] != '0';
   if (const char *e = getenv("LENTIL_PREDICT")) ctx->predict = e[0] != '0';
+  if (const char *e = getenv("LENTIL_LENS_JIT")) ctx->jit_enabled = e[0] != '0';
   if (const char *e = getenv("LENTIL_SCAN_CUS_PCT")) { ctx->scan_cus_pct = atoi(e); if (ctx->scan_cus_pct < 25) ctx->scan_cus_pct = 25; if (ctx->scan_cus_pct > 100) ctx->scan_cus_pct = 100; }
   if (const char *e = getenv("LENTIL_PREDICT_GRID")) {
     unsigned a = 0, b = 0, c = 0;
@@ -546,6 +566,7 @@ LENTIL_API int lentil_hip_destroy(lentil_hip_ctx *ctx) {
   if (ctx->h_ctr_pinned) (void)hipHostFree(ctx->h_ctr_pinned);
   (void)hipFree(ctx->d_ranges);
   (void)hipFree(ctx->d_live);
+  if (ctx->jit_module) (void)hipModuleUnload(ctx->jit_module);
   (void)hipFree(ctx->d_bm_land); (void)hipFree(ctx->d_bm_box); (void)hipFree(ctx->d_bm_npass);
   (void)hipFree(ctx->d_ext_q);
   (void)hipFree(ctx->d_xor); (void)hipFree(ctx->d_tlc_res); (void)hipFree(ctx->d_tlc_off); (void)hipFree(ctx->d_tlc_tasks);
@@ -640,6 +661,70 @@ static bool pack_terms(const lentil_lens_table *t, const lentil_poly &p, int der
   return true;
 }
 
+// ---- run-time lens specialisation (lentil_lens_jit.h) -----------------------------------------------------------------
+static const std::vector<std::string> &jit_flags() {
+  // (the flags __graft_entry__.build() compiles the library with: same arithmetic, same code generation)
+  static const std::vector<std::string> f = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off",
+                                              "-fhip-fp32-correctly-rounded-divide-sqrt", "-munsafe-fp-atomics"};
+  return f;
+}
+static uint64_t jit_source_hash() {
+  static const uint64_t h = [] {
+    uint64_t v = lentil_jit::fnv("lentil-jit-1", 12);
+    for (const lentil_jit::Source &s : kEmbeddedSources) v = lentil_jit::fnv(s.text, strlen(s.text), v);
+    for (const std::string &f : jit_flags()) v = lentil_jit::fnv(f.data(), f.size(), v);
+    return v;
+  }();
+  return h;
+}
+static bool lens_is_compiled_in(unsigned long long hash) {
+#define LENTIL_HASH_MATCH(NAME) if (hash == gen::Lens_##NAME::kTableHash) return true;
+  LENTIL_GENERATED_LENSES(LENTIL_HASH_MATCH)
+#undef LENTIL_HASH_MATCH
+  return false;
+}
+// the table's entry: looked up, loaded from the cache on disk, or handed to a compiling thread
+static void jit_request(lentil_hip_ctx *ctx) {
+  if (ctx->jit_module) { (void)hipModuleUnload(ctx->jit_module); ctx->jit_module = nullptr; }
+  ctx->jit.reset();
+  ctx->jit_loaded = ctx->jit_load_failed = false;
+  if (!ctx->jit_enabled || lens_is_compiled_in(ctx->lens_hash)) return;
+  std::lock_guard<std::mutex> lock(lentil_jit::registry_mutex());
+  auto &reg = lentil_jit::registry();
+  auto it = reg.find(ctx->lens_hash);
+  if (it != reg.end()) { ctx->jit = it->second; return; }
+  auto e = std::make_shared<lentil_jit::Entry>();
+  reg[ctx->lens_hash] = e;
+  ctx->jit = e;
+  const std::string path = lentil_jit::cache_path(ctx->lens_hash, jit_source_hash());
+  if (lentil_jit::cache_load(path, e->co)) { e->from_cache = true; e->state.store(lentil_jit::Entry::kReady); return; }
+  const std::string src = lentil_jit::lens_jit_emit(ctx->hlens, ctx->h_terms, ctx->lens_hash);
+  std::thread([e, src, path]() {
+    const auto t0 = std::chrono::steady_clock::now();
+    std::vector<lentil_jit::Source> sources(std::begin(kEmbeddedSources), std::end(kEmbeddedSources));
+    const bool ok = lentil_jit::compile(sources, src, jit_flags(), e->co, e->log);
+    e->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (ok) lentil_jit::cache_store(path, e->co);
+    if (!ok && getenv("LENTIL_STREAM_DEBUG")) fprintf(stderr, "[lens jit] compilation failed:\n%s\n", e->log.c_str());
+    e->state.store(ok ? lentil_jit::Entry::kReady : lentil_jit::Entry::kFailed);
+  }).detach();
+}
+// the compiled kernels for this context's device, once the code object is there (null: not yet / not at all)
+static hipFunction_t jit_function(lentil_hip_ctx *ctx, bool chroma, bool stream) {
+  if (!ctx->jit || !ctx->use_generated || ctx->jit_load_failed) return nullptr;
+  if (!ctx->jit_loaded) {
+    if (ctx->jit->state.load() != lentil_jit::Entry::kReady) return nullptr;
+    (void)hipSetDevice(ctx->device);
+    bool ok = hipModuleLoadData(&ctx->jit_module, ctx->jit->co.code.data()) == hipSuccess;
+    for (int c = 0; c < 2 && ok; ++c)
+      for (int s2 = 0; s2 < 2 && ok; ++s2)
+        ok = hipModuleGetFunction(&ctx->jit_fn[c][s2], ctx->jit_module, ctx->jit->co.name[c][s2].c_str()) == hipSuccess;
+    if (!ok) { (void)hipGetLastError(); ctx->jit_load_failed = true; return nullptr; }
+    ctx->jit_loaded = true;
+  }
+  return ctx->jit_fn[chroma ? 1 : 0][stream ? 1 : 0];
+}
+
 LENTIL_API int lentil_hip_set_lens(lentil_hip_ctx *ctx, const lentil_lens_table *t) {
   CHECK_CTX(ctx);
   if (!t || !t->terms) return fail(ctx, LENTIL_ERR_INVALID, "lens table is null");
@@ -707,9 +792,85 @@ LENTIL_API int lentil_hip_set_lens(lentil_hip_ctx *ctx, const lentil_lens_table 
     DevLens hz = h;
     for (int e = 0; e <= kMaxExp; ++e) hz.lambda_pow[e] = 0.0;       // (the wavelength belongs to the parameters)
     const uint64_t sig = fnv1a(&hz, sizeof hz, fnv1a(terms.data(), terms.size() * sizeof(DevTerm)));
-    if (sig != ctx->bm_lens_sig) { ctx->bm_lens_sig = sig; ctx->bm_valid = false; ctx->bm_margin16 = 0; ctx->lean_ok = true; }
+    const bool changed = sig != ctx->bm_lens_sig;
+    if (changed) { ctx->bm_lens_sig = sig; ctx->bm_valid = false; ctx->bm_margin16 = 0; ctx->lean_ok = true; }
+    // (the same table set again keeps its specialised kernel too)
+    if (changed || (!ctx->jit && ctx->jit_enabled)) { ctx->h_terms = terms; jit_request(ctx); }
   }
   return LENTIL_OK;
+}
+
+LENTIL_API int lentil_hip_lens_jit_status(lentil_hip_ctx *ctx, int *state, double *compile_seconds) {
+  CHECK_CTX(ctx);
+  int st = 0;
+  if (ctx->jit) st = ctx->jit->state.load();
+  if (st == lentil_jit::Entry::kReady && ctx->jit_load_failed) st = lentil_jit::Entry::kFailed;
+  if (state) *state = st;
+  if (compile_seconds) *compile_seconds = (ctx->jit && st != lentil_jit::Entry::kCompiling && !ctx->jit->from_cache) ? ctx->jit->seconds : 0.0;
+  return LENTIL_OK;
+}
+
+LENTIL_API int lentil_hip_lens_jit_wait(lentil_hip_ctx *ctx, double timeout_seconds) {
+  CHECK_CTX(ctx);
+  if (!ctx->jit) return LENTIL_OK;
+  const auto t0 = std::chrono::steady_clock::now();
+  while (ctx->jit->state.load() == lentil_jit::Entry::kCompiling) {
+    if (timeout_seconds > 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_seconds)
+      return fail(ctx, LENTIL_ERR_INVALID, "the lens kernel is still being compiled");
+    std::this_thread::sleep_for(std::chrono::milliseconds(20));
+  }
+  if (ctx->jit->state.load() == lentil_jit::Entry::kFailed)
+    return fail(ctx, LENTIL_ERR_HIP, "run-time compilation of the lens kernel failed (the table interpreter keeps serving the lens): " +
+                                         ctx->jit->log.substr(0, 600));
+  return LENTIL_OK;
+}
+
+LENTIL_API int lentil_hip_debug_lens_jit_source(lentil_hip_ctx *ctx, char *buf, uint64_t capacity, uint64_t *length) {
+  CHECK_CTX(ctx);
+  if (!ctx->have_lens) return fail(ctx, LENTIL_ERR_INVALID, "no lens table set");
+  const std::string src = lentil_jit::lens_jit_emit(ctx->hlens, ctx->h_terms.empty() ? std::vector<DevTerm>() : ctx->h_terms, ctx->lens_hash);
+  if (length) *length = src.size();
+  if (buf && capacity) { const size_t n = src.size() < capacity - 1 ? src.size() : (size_t)capacity - 1; memcpy(buf, src.data(), n); buf[n] = 0; }
+  return LENTIL_OK;
+}
+
+// Context-free (no GPU needed: hiprtc cross-compiles): the table packed as lentil_hip_set_lens packs it, the lens code emitted,
+// and -- compile != 0 -- the four solve kernels compiled.  The emitted source goes to `source` (capacity bytes, NUL-terminated,
+// truncated if longer; *source_length its full length), the compiler's log likewise.  LENTIL_OK, LENTIL_ERR_UNSUPPORTED for a
+// table the library cannot hold, LENTIL_ERR_HIP when the compilation fails.
+LENTIL_API int lentil_hip_debug_lens_jit_compile(const lentil_lens_table *t, int compile, char *source, uint64_t source_capacity,
+                                                 uint64_t *source_length, char *log, uint64_t log_capacity, double *seconds,
+                                                 uint64_t *code_bytes) {
+  if (!t || !t->terms) return LENTIL_ERR_INVALID;
+  std::vector<DevTerm> terms;
+  DevLens h{};
+  bool ok = true;
+  for (int i = 0; i < 5; ++i) ok &= pack_terms(t, t->out[i], -1, terms, h.first[P_OUT_X + i], h.count[P_OUT_X + i]);
+  for (int i = 0; i < 4; ++i) ok &= pack_terms(t, t->ap[i], -1, terms, h.first[P_AP_X + i], h.count[P_AP_X + i]);
+  for (int i = 0; i < 2; ++i)
+    for (int j = 0; j < 2; ++j) {
+      ok &= pack_terms(t, t->ap[i], 2 + j, terms, h.first[P_DAP_00 + i * 2 + j], h.count[P_DAP_00 + i * 2 + j]);
+      ok &= pack_terms(t, t->out[2 + i], j, terms, h.first[P_DOUT_00 + i * 2 + j], h.count[P_DOUT_00 + i * 2 + j]);
+    }
+  if (!ok || terms.size() > (size_t)kMaxTerms) return LENTIL_ERR_UNSUPPORTED;
+  const std::string src = lentil_jit::lens_jit_emit(h, terms, 0ull);
+  auto put = [](const std::string &text, char *buf, uint64_t cap, uint64_t *len) {
+    if (len) *len = text.size();
+    if (buf && cap) { const size_t n = text.size() < cap - 1 ? text.size() : (size_t)cap - 1; memcpy(buf, text.data(), n); buf[n] = 0; }
+  };
+  put(src, source, source_capacity, source_length);
+  if (seconds) *seconds = 0.0;
+  if (code_bytes) *code_bytes = 0;
+  if (!compile) return LENTIL_OK;
+  lentil_jit::CodeObject co;
+  std::string lg;
+  const auto t0 = std::chrono::steady_clock::now();
+  std::vector<lentil_jit::Source> sources(std::begin(kEmbeddedSources), std::end(kEmbeddedSources));
+  const bool cok = lentil_jit::compile(sources, src, jit_flags(), co, lg);
+  if (seconds) *seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  put(lg, log, log_capacity, nullptr);
+  if (code_bytes) *code_bytes = co.code.size();
+  return cok ? LENTIL_OK : LENTIL_ERR_HIP;
 }
 
 LENTIL_API int lentil_hip_set_lens_mode(lentil_hip_ctx *ctx, int mode) {
@@ -1026,6 +1187,14 @@ static void launch_solve_po(lentil_hip_ctx *ctx, const DrawArgs &da, hipStream_t
   }
   LENTIL_GENERATED_LENSES(LENTIL_LAUNCH_GEN)
 #undef LENTIL_LAUNCH_GEN
+  if (!launched) {
+    // a kernel specialised for this table at run time (lentil_lens_jit.h), once its code object is there
+    if (hipFunction_t fn = jit_function(ctx, chroma, kStream)) {
+      DrawArgs args = da;
+      void *params[] = {&args};
+      launched = hipModuleLaunchKernel(fn, blocks, 1, 1, threads, 1, 1, 0, st, params, nullptr) == hipSuccess;
+    }
+  }
   if (!launched) {
     if (chroma) hipLaunchKernelGGL((solve_po_kernel<LdsLens, true, true, kStream>), dim3(blocks), dim3(threads), 0, st, da);
     else hipLaunchKernelGGL((solve_po_kernel<LdsLens, true, false, kStream>), dim3(blocks), dim3(threads), 0, st, da);
@@ -1665,7 +1834,8 @@ static int launch_scan(lentil_hip_ctx *ctx, const ScanPlan &pl, const lentil_hip
     else hipLaunchKernelGGL(scan_ragged_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, sa);
   }
   HIP_TRY(ctx, hipGetLastError());
-  if (blocks_out) *blocks_out = (unsigned)blocks - (pl.dma && pl.dma2 ? sa.skip_blocks : 0u);
+  if (blocks_out) *blocks_out = (unsigned)blocks;
+  ctx->last_scan_skipped = (pl.dma && pl.dma2) ? sa.skip_blocks : 0u;
   return LENTIL_OK;
 }
 
@@ -1870,7 +2040,8 @@ static int redistribute_streamed(lentil_hip_ctx *ctx, bool *streamed) {
   // hardware queue, each finds its producer ahead of it there.
   unsigned a_blocks = (unsigned)ctx->num_cu * (unsigned)ctx->stream_blocks;
   // CUs the scan leaves alone (scan_cus_pct) have registers for one more resident solve block
-  if (scan_blocks && scan_blocks < (unsigned)ctx->num_cu && plan.dma2 && ctx->stream_blocks == 2) a_blocks += (unsigned)ctx->num_cu - scan_blocks;
+  if (ctx->last_scan_skipped && ctx->stream_blocks == 2) a_blocks += ctx->last_scan_skipped;
+  (void)scan_blocks;
   // Live straggler queue: solve_slow_kernel is launched behind the publishers (who end with the scan) and takes the parked
   // solves as they come, one wave per CU.  (Round 3, from the timeline: its waves are placed as the first solve waves
   // leave -- the idle ones do at once when the publishers' end markers arrive --, not in the registers the scan gives
@@ -2406,9 +2577,107 @@ LENTIL_API int lentil_hip_get_xor128_state(lentil_hip_ctx *ctx, uint32_t state[4
 }
 
 static int redistribute_pass(lentil_hip_ctx *ctx);
+static int redistribute_impl(lentil_hip_ctx *ctx);
+
+// Closest-filtered AOVs after a pass that met candidates at depth 0 / NaN: lentil_closest_replay.h.  Returns LENTIL_OK with
+// *need_log set when the pass kept no (complete) draw log to replay from.
+static int closest_degenerate_replay(lentil_hip_ctx *ctx, bool *need_log) {
+  *need_log = false;
+  const int C = ctx->n_chunks;
+  unsigned long long n_log = 0;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  HIP_TRY(ctx, hipMemcpy(&n_log, (char *)(ctx->d_ctr + C) + offsetof(DevCounters, log_count), sizeof n_log, hipMemcpyDeviceToHost));
+  unsigned long long accepted = 0;
+  for (const DevCounters &k : ctx->h_ctr) accepted += k.accepted;
+  if (!ctx->d_log || n_log > ctx->log_cap || (accepted && n_log < accepted)) { *need_log = true; return LENTIL_OK; }
+  ReplayArgs a{};
+  a.P = ctx->P; a.lens_length = ctx->have_lens ? ctx->hlens.length : 0.0; a.V = ctx->V; a.F = ctx->F;
+  a.log = ctx->d_log; a.n_log = n_log;
+  uint8_t *flag = nullptr; uint32_t *head = nullptr; unsigned int *count = nullptr; ReplayNode *nodes = nullptr;
+  int rc = LENTIL_OK;
+  hipError_t e = hipMalloc(&flag, ctx->F.np);
+  if (e == hipSuccess) e = hipMalloc(&head, ctx->F.np * sizeof(uint32_t));
+  if (e == hipSuccess) e = hipMalloc(&count, sizeof(unsigned int));
+  if (e == hipSuccess) e = hipMemsetAsync(flag, 0, ctx->F.np, ctx->stream);
+  if (e == hipSuccess) e = hipMemsetAsync(head, 0xFF, ctx->F.np * sizeof(uint32_t), ctx->stream);
+  if (e == hipSuccess) e = hipMemsetAsync(count, 0, sizeof(unsigned int), ctx->stream);
+  a.flag = flag; a.head = head; a.n_nodes = count;
+  const dim3 grid((unsigned)ctx->num_cu * 8), block(256);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(replay_mark_visits_kernel, grid, block, 0, ctx->stream, a);
+    if (n_log) hipLaunchKernelGGL(replay_mark_log_kernel, grid, block, 0, ctx->stream, a);
+    // the lists: counted, then filled
+    hipLaunchKernelGGL(replay_push_visits_kernel, grid, block, 0, ctx->stream, a);
+    if (n_log) hipLaunchKernelGGL(replay_push_log_kernel, grid, block, 0, ctx->stream, a);
+    e = hipGetLastError();
+  }
+  unsigned int n_nodes = 0;
+  if (e == hipSuccess) e = hipMemcpyAsync(&n_nodes, count, sizeof n_nodes, hipMemcpyDeviceToHost, ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  if (e == hipSuccess && n_nodes) {
+    e = hipMalloc(&nodes, (size_t)n_nodes * sizeof(ReplayNode));
+    if (e == hipSuccess) e = hipMemsetAsync(count, 0, sizeof(unsigned int), ctx->stream);
+    a.nodes = nodes; a.node_cap = n_nodes;
+    if (e == hipSuccess) {
+      hipLaunchKernelGGL(replay_push_visits_kernel, grid, block, 0, ctx->stream, a);
+      if (n_log) hipLaunchKernelGGL(replay_push_log_kernel, grid, block, 0, ctx->stream, a);
+      hipLaunchKernelGGL(replay_resolve_kernel, grid, block, 0, ctx->stream, a);
+      // the winners' values once more, from the keys as they stand now
+      if (ctx->F.zkey_dbg) hipLaunchKernelGGL(debug_gather_kernel, grid, block, 0, ctx->stream, ctx->F, ctx->V, ctx->P, a.lens_length);
+      if (ctx->F.zkey) hipLaunchKernelGGL(closest_gather_kernel, grid, block, 0, ctx->stream, ctx->F, ctx->V);
+      e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  }
+  (void)hipFree(flag); (void)hipFree(head); (void)hipFree(count); (void)hipFree(nodes);
+  if (e != hipSuccess) rc = fail(ctx, LENTIL_ERR_HIP, std::string("closest-AOV replay: ") + hipGetErrorString(e));
+  if (rc == LENTIL_OK) { ctx->resolved_valid = false; ++ctx->n_degenerate_replays; }
+  return rc;
+}
 
 LENTIL_API int lentil_hip_redistribute(lentil_hip_ctx *ctx) {
   CHECK_CTX(ctx);
+  ctx->stall_redo = false;
+  ctx->degenerate_seen = false;
+  const bool clean_entry = ctx->cleared_since_pass;
+  // (a context whose frames have needed the replay before keeps a draw log from the start: no pass is run twice again)
+  if (ctx->closest_auto_log && ctx->log_cap == 0 && (ctx->F.zkey || ctx->F.zkey_dbg)) {
+    const int rc0 = lentil_hip_set_draw_log(ctx, ctx->closest_auto_log_cap);
+    if (rc0) return rc0;
+  }
+  int rc = redistribute_impl(ctx);
+  if (rc || !ctx->degenerate_seen) return rc;
+  // ---- candidates at depth 0 / NaN compete for a closest-filtered AOV: their pixels are replayed in visit order
+  if (ctx->comm || ctx->closest_deferred)
+    return fail(ctx, LENTIL_ERR_UNSUPPORTED, "a sample with depth (Z) 0 or NaN competes for a closest-filtered AOV: the reference's result there "
+                                             "depends on the order of the samples at the pixel (src/lentil.h:832-837), which the exchange "
+                                             "between GPUs does not keep; the pass is refused");
+  bool need_log = false;
+  if ((rc = closest_degenerate_replay(ctx, &need_log))) return rc;
+  if (!need_log) return LENTIL_OK;
+  // no (complete) draw log to replay from.  The frame held nothing before this pass: a log sized from the pass's counters,
+  // the frame wiped, the pass once more -- and a log from the start in every later pass of this context.
+  if (!clean_entry)
+    return fail(ctx, LENTIL_ERR_UNSUPPORTED, "a sample with depth (Z) 0 or NaN competes for a closest-filtered AOV and the pass kept no complete draw "
+                                             "log to replay its pixel's samples from (src/lentil.h:832-837): set one with lentil_hip_set_draw_log "
+                                             "(capacity >= the pass's accepted draws), or clear the frame before the pass");
+  unsigned long long accepted = 0;
+  for (const DevCounters &k : ctx->h_ctr) accepted += k.accepted;
+  ctx->closest_auto_log = true;
+  ctx->closest_auto_log_cap = accepted + accepted / 4 + (1ull << 20);
+  if ((rc = lentil_hip_set_draw_log(ctx, ctx->closest_auto_log_cap))) return rc;
+  if ((rc = lentil_hip_clear_frame(ctx))) return rc;
+  ctx->degenerate_seen = false;
+  if ((rc = redistribute_impl(ctx))) return rc;
+  if (!ctx->degenerate_seen) return LENTIL_OK;
+  if ((rc = closest_degenerate_replay(ctx, &need_log))) return rc;
+  if (need_log) return fail(ctx, LENTIL_ERR_NOMEM, "closest-AOV replay: the draw log did not hold the pass's accepted draws");
+  return LENTIL_OK;
+}
+
+// one pass, with the recovery of a streamed pass that stalled after its first accept
+static int redistribute_impl(lentil_hip_ctx *ctx) {
   ctx->stall_redo = false;
   int rc = redistribute_pass(ctx);
   if (rc || !ctx->stall_redo) return rc;
@@ -2662,12 +2931,11 @@ static int redistribute_pass(lentil_hip_ctx *ctx) {
       return fail(ctx, LENTIL_ERR_NOMEM, "the device dropped " + std::to_string(dropped) +
                                              " work items (work list, task queue or result pool too small): the frame is incomplete");
     // closest-filtered AOVs: a candidate at |Z| == 0 or NaN makes the reference's result depend on the order of the candidates
-    // at that pixel (src/lentil.h:832-837, closest_key_of in lentil_kernels.h) -- refused, not approximated
+    // at that pixel (src/lentil.h:832-837, closest_key_of in lentil_kernels.h)
     unsigned int degenerate = 0;
     for (const DevCounters &k : ctx->h_ctr) degenerate |= k.degenerate_depth;
-    if (degenerate && (ctx->F.zkey || ctx->F.zkey_dbg))
-      return fail(ctx, LENTIL_ERR_UNSUPPORTED, "a sample with depth (Z) 0 or NaN competes for a closest-filtered AOV: the reference's result there "
-                                               "depends on the order of the samples at the pixel (src/lentil.h:832-837); the pass is refused");
+    // (lentil_hip_redistribute replays those pixels' candidates in visit order, lentil_closest_replay.h)
+    ctx->degenerate_seen = degenerate && (ctx->F.zkey || ctx->F.zkey_dbg);
   }
   return crypto_after_pass(ctx);
 }
@@ -3153,6 +3421,89 @@ template <typename T>
 static int dev_alloc(lentil_hip_ctx *ctx, size_t n, T **dst, std::vector<void *> &tmp) {
   HIP_TRY(ctx, hipMalloc((void **)dst, n * sizeof(T)));
   tmp.push_back(*dst);
+  return LENTIL_OK;
+}
+
+// ---- lentil_hip_box_probe: what the box delivers (see lentil_hip.h) ---------------------------------------------------
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void probe_fp64_kernel(double *sink, uint32_t rounds, unsigned long long *clk) {
+  // eight independent multiply-add chains per lane (the solves interleave about as many): v_mul_f64 / v_add_f64, no FMA
+  double a0 = 1.0 + threadIdx.x * 1e-9, a1 = a0 + 1e-9, a2 = a0 + 2e-9, a3 = a0 + 3e-9, a4 = a0 + 4e-9, a5 = a0 + 5e-9, a6 = a0 + 6e-9, a7 = a0 + 7e-9;
+  const double m = 1.0000000001, c = 1e-12;
+  const unsigned long long t0 = clock64(), r0 = __builtin_amdgcn_s_memrealtime();
+  for (uint32_t i = 0; i < rounds; ++i) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      a0 = a0 * m; a1 = a1 * m; a2 = a2 * m; a3 = a3 * m; a4 = a4 * m; a5 = a5 * m; a6 = a6 * m; a7 = a7 * m;
+      a0 = a0 + c; a1 = a1 + c; a2 = a2 + c; a3 = a3 + c; a4 = a4 + c; a5 = a5 + c; a6 = a6 + c; a7 = a7 + c;
+    }
+  }
+  const unsigned long long t1 = clock64(), r1 = __builtin_amdgcn_s_memrealtime();
+  const double s = ((a0 + a1) + (a2 + a3)) + ((a4 + a5) + (a6 + a7));
+  if (s == 12345.678) sink[0] = s;          // (keeps the chains)
+  if (blockIdx.x == 0 && threadIdx.x == 0) { clk[0] = t1 - t0; clk[1] = r1 - r0; }
+}
+__global__ __launch_bounds__(256) void probe_copy_kernel(const float4 *src, float4 *dst, uint64_t n) {
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+__global__ __launch_bounds__(256) void probe_read_kernel(const float4 *src, float *sink, uint64_t n) {
+  float acc = 0.f;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+    const float4 v = nt_load(src + i);
+    acc += (v.x + v.y) + (v.z + v.w);
+  }
+  if (acc == 12345.678f) sink[0] = acc;
+}
+
+LENTIL_API int lentil_hip_box_probe(lentil_hip_ctx *ctx, double probe[6]) {
+  CHECK_CTX(ctx);
+  if (!probe) return fail(ctx, LENTIL_ERR_INVALID, "probe is null");
+  for (int i = 0; i < 6; ++i) probe[i] = 0.0;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  const uint64_t n4 = (512ull << 20) / 16;             // 512 MiB each way: beyond every cache
+  float4 *a = nullptr, *b = nullptr;
+  unsigned long long *clk = nullptr;
+  HIP_TRY(ctx, hipMalloc(&a, n4 * 16));
+  hipError_t e = hipMalloc(&b, n4 * 16);
+  if (e == hipSuccess) e = hipMalloc(&clk, 2 * sizeof(unsigned long long));
+  hipEvent_t ev[2] = {nullptr, nullptr};
+  if (e == hipSuccess) e = hipEventCreate(&ev[0]);
+  if (e == hipSuccess) e = hipEventCreate(&ev[1]);
+  auto timed = [&](auto &&launch, int reps, float &best_ms) {
+    best_ms = 1e30f;
+    for (int r = 0; r < reps && e == hipSuccess; ++r) {
+      e = hipEventRecord(ev[0], ctx->stream);
+      launch();
+      if (e == hipSuccess) e = hipGetLastError();
+      if (e == hipSuccess) e = hipEventRecord(ev[1], ctx->stream);
+      if (e == hipSuccess) e = hipEventSynchronize(ev[1]);
+      float ms = 0.f;
+      if (e == hipSuccess) e = hipEventElapsedTime(&ms, ev[0], ev[1]);
+      if (e == hipSuccess && ms < best_ms) best_ms = ms;
+    }
+  };
+  if (e == hipSuccess) e = hipMemsetAsync(a, 0, n4 * 16, ctx->stream);
+  if (e == hipSuccess) e = hipMemsetAsync(b, 0, n4 * 16, ctx->stream);
+  const unsigned blocks = (unsigned)ctx->num_cu * 3u;       // three 256-thread blocks per CU: three waves per SIMD
+  const uint32_t rounds = 4096;
+  float ms = 0.f;
+  unsigned long long h_clk[2] = {0, 0};
+  // (the first launch brings the clocks up; the best of the following three counts)
+  timed([&]() { hipLaunchKernelGGL(probe_fp64_kernel, dim3(blocks), dim3(256), 0, ctx->stream, reinterpret_cast<double *>(b), rounds, clk); }, 4, ms);
+  if (e == hipSuccess) e = hipMemcpy(h_clk, clk, sizeof h_clk, hipMemcpyDeviceToHost);
+  if (e == hipSuccess && ms > 0.f) {
+    probe[0] = (double)blocks * 256.0 * (double)rounds * 128.0 / ((double)ms * 1e-3) / 1e12;
+    if (h_clk[1]) probe[1] = (double)h_clk[0] / (double)h_clk[1] * 100.0;
+  }
+  timed([&]() { hipLaunchKernelGGL(probe_copy_kernel, dim3((unsigned)ctx->num_cu * 8u), dim3(256), 0, ctx->stream, a, b, n4); }, 3, ms);
+  if (e == hipSuccess && ms > 0.f) probe[2] = 2.0 * (double)n4 * 16.0 / ((double)ms * 1e-3) / 1e9;
+  timed([&]() { hipLaunchKernelGGL(probe_read_kernel, dim3((unsigned)ctx->num_cu * 8u), dim3(256), 0, ctx->stream, a, reinterpret_cast<float *>(b), n4); }, 3, ms);
+  if (e == hipSuccess && ms > 0.f) probe[3] = (double)n4 * 16.0 / ((double)ms * 1e-3) / 1e9;
+  probe[4] = getenv("GPU_MAX_HW_QUEUES") ? atof(getenv("GPU_MAX_HW_QUEUES")) : 0.0;
+  probe[5] = (double)ctx->num_cu;
+  if (ev[0]) (void)hipEventDestroy(ev[0]);
+  if (ev[1]) (void)hipEventDestroy(ev[1]);
+  (void)hipFree(a); (void)hipFree(b); (void)hipFree(clk);
+  if (e != hipSuccess) return fail(ctx, LENTIL_ERR_HIP, std::string("box probe: ") + hipGetErrorString(e));
   return LENTIL_OK;
 }
 

@@ -39,9 +39,13 @@ def gpu_run(ctx, p, table, visits, n_aovs=1, bokeh_tables=None, log_cap=1 << 22,
     return c
 
 
-def check_frame(ctx, ref, n_aovs=1, tol=TOL, kinds=None):
-    """accumulators + weight + resolved image vs oracle; returns the worst relative error."""
+def check_frame(ctx, ref, n_aovs=1, tol=TOL, kinds=None, stats=None):
+    """accumulators + weight + resolved image vs oracle; returns the worst relative error.
+    stats (a dict, optional) receives the two figures a report should carry beside it: `vs_fp32`, the worst
+    |gpu - oracle_fp32| / |oracle_fp32| over buffers and resolved images -- the reference CPU imager's own fp32 numbers, what
+    BASELINE.json's north_star names -- and `fp32_own`, how far those fp32 numbers are themselves from the exact sums."""
     worst = 0.0
+    vs32, own32 = 0.0, 0.0
     rw = ref.weight()
     rw64 = ref.weight64()
     for a in range(n_aovs):
@@ -58,6 +62,11 @@ def check_frame(ctx, ref, n_aovs=1, tol=TOL, kinds=None):
         # pile up: up to 1.3e-5)
         d32 = np.abs(buf[m].astype(np.float64) - rb[m].astype(np.float64))
         own = np.abs(rb[m].astype(np.float64) - exact[m])
+        if m.any():
+            nz = np.abs(rb[m].astype(np.float64)) > 0
+            if nz.any():
+                vs32 = max(vs32, float(np.max(d32[nz] / np.abs(rb[m].astype(np.float64))[nz])))
+            own32 = max(own32, float(np.max(own / np.abs(exact[m]))))
         assert bool(np.all(d32 <= tol * np.abs(exact[m]) + own)), "fp32 buffers: worst excess %.3e" % float(
             np.max((d32 - own) / np.abs(exact[m])))
         if a == 0:
@@ -76,10 +85,16 @@ def check_frame(ctx, ref, n_aovs=1, tol=TOL, kinds=None):
             ximg = np.where(wz[:, None], exact / np.where(wz, rw64, 1.0)[:, None], exact)
         own_i = np.abs(rimg[mi].astype(np.float64) - ximg[mi])
         di = np.abs(img[mi].astype(np.float64) - rimg[mi])
+        if mi.any():
+            vs32 = max(vs32, float(np.max(di / np.abs(rimg[mi]))))
+            own32 = max(own32, float(np.max(own_i / np.abs(rimg[mi]))))
         ei = float(np.max(np.abs(img[mi].astype(np.float64) - ximg[mi]) / np.abs(rimg[mi]))) if mi.any() else 0.0
         worst = max(worst, ei)
         assert bool(np.all(di <= tol * np.abs(rimg[mi]) + own_i)), "fp32 image: worst excess %.3e" % float(
             np.max((di - own_i) / np.abs(rimg[mi])))
+    if stats is not None:
+        stats["vs_fp32"] = max(stats.get("vs_fp32", 0.0), vs32)
+        stats["fp32_own"] = max(stats.get("fp32_own", 0.0), own32)
     assert worst < tol, "max relative error %.3e" % worst
     return worst
 

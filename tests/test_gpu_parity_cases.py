@@ -13,7 +13,7 @@ import pytest
 
 import common
 import oracle_lib
-from pota_amd import capi, workload
+from pota_amd import _abi, capi, workload
 from test_gpu_parity import _band_parity_at_full_geometry, check_frame, check_logs, gpu_run
 
 pytestmark = pytest.mark.gpu
@@ -369,35 +369,57 @@ def test_two_contexts_pass_at_the_same_time(orc, gpu_ctx_factory):
     assert sum(forms[0]) + sum(forms[1]) >= 1       # (the first pass of a context is never streamed)
 
 
-@pytest.mark.parametrize("what", ["zero", "negative_zero", "nan"])
-@pytest.mark.parametrize("ragged", [False, True])
-def test_degenerate_depths_and_closest_aovs(orc, gpu_ctx_factory, what, ragged):
-    """src/lentil.h:832-837 treats a z-buffer value of 0 as "empty": a sample at |Z| == 0 wins and re-opens the pixel, a NaN
-    written into an empty pixel is never replaced -- the reference's image then depends on the order of the samples at
-    that pixel.  The library does not approximate that: a pass in which such a sample competes for a closest-filtered AOV
-    is refused (LENTIL_ERR_UNSUPPORTED, closest_key_of in lentil_kernels.h).  The same stream with gaussian AOVs only --
-    where the depth of a sample that stays in its pixel is never looked at -- passes and equals the oracle."""
+@pytest.mark.parametrize("what", ["zero", "negative_zero", "nan", "mixed"])
+@pytest.mark.parametrize("ragged,own_log", [(False, True), (True, True), (False, False)], ids=["uniform", "ragged", "no-log"])
+def test_degenerate_depths_and_closest_aovs(orc, gpu_ctx_factory, what, ragged, own_log):
+    """src/lentil.h:832-837 treats a z-buffer value of 0 as "empty": a sample at |Z| == 0 wins and re-opens the pixel -- the next
+    sample replaces it whatever its depth --, a NaN written into an open pixel is never replaced and is ignored anywhere else:
+    at a pixel that sees such a sample the reference's image depends on the ORDER of the samples there.  Round 4 refused such a
+    pass; since round 5 the library replays those pixels in visit order (lentil_closest_replay.h) and the frame equals the
+    single-threaded oracle's: closest-filtered AOV and lentil_debug bit for bit, gaussian AOVs as ever.  Degenerate depths on
+    samples that stay in their pixel AND on redistributed ones (whose draws carry the depth to every pixel they land on),
+    two bad samples in one pixel, a bad sample as a pixel's first and as its last; "mixed": zeros and NaNs side by side.
+    "no-log": the caller set no draw log -- the library sets one up, wipes the frame and runs the pass again."""
     W, H, M = 48, 32, 9
     p, model, table, keep = common.po_setup(W, H, samples_override=32)
-    visits, cols = common.make_stream(p, W, H, M, f_hi=0.02, n_extra=1)
+    visits, cols = common.make_stream(p, W, H, M, f_hi=0.02, n_extra=2)
     n = cols["rgba"].shape[0]
     rng = np.random.default_rng(3)
-    bad = rng.choice(n, 12, replace=False)
-    cols["pos_z"][bad, 3] = {"zero": np.float32(0.0), "negative_zero": np.float32(-0.0), "nan": np.float32(np.nan)}[what]
+    hi = np.nonzero(cols["rgba"][:, 0] > 2.0)[0]
+    bad = np.concatenate([rng.choice(n, 14, replace=False), rng.choice(hi, min(5, hi.size), replace=False),
+                          np.array([0, M - 1, 5 * M, 5 * M + 1, 77 * M + 4, 77 * M + 5, 77 * M + 6])])      # first / last of a pixel, neighbours
+    vals = {"zero": [np.float32(0.0)], "negative_zero": [np.float32(-0.0)], "nan": [np.float32(np.nan)],
+            "mixed": [np.float32(0.0), np.float32(np.nan), np.float32(-0.0)]}[what]
+    cols["pos_z"][bad, 3] = np.array([vals[i % len(vals)] for i in range(bad.size)], np.float32)
+    layout = dict(visits_per_pixel=M, pixels_per_row=W)
     if ragged:
         pix = np.arange(n, dtype=np.uint64) // M
         cols["pixel"] = ((pix % W).astype(np.uint32) | ((pix // W).astype(np.uint32) << 16)).astype(np.uint32)
-        visits, keepv = capi.make_visits(cols, visits_per_pixel=0)
-    else:
-        visits, keepv = capi.make_visits(cols, visits_per_pixel=M, pixels_per_row=W)
+        layout = dict(visits_per_pixel=0)
+    kinds = [_abi.FILTER_GAUSSIAN, _abi.FILTER_CLOSEST, _abi.FILTER_CLOSEST_DEBUG]
+    # (lentil_debug has no visit column; the oracle reads every column: a dummy one there, its values are ignored)
+    gcols = dict(cols); gcols["extra"] = [cols["extra"][0], None]
+    visits, keepv = capi.make_visits(gcols, **layout)
+    ocols = dict(cols); ocols["extra"] = [cols["extra"][0], np.zeros_like(cols["rgba"])]
+    ovisits, okeep = capi.make_visits(ocols, **layout)
+    lens = orc.orc_lens_create(C.byref(table))
+    ref = oracle_lib.Frame(orc, p, n_aovs=3, kinds=kinds, keep_log=True)
+    ref.run(lens, None, ovisits)
+    orc.orc_lens_destroy(lens)
     ctx = gpu_ctx_factory()
-    with pytest.raises(capi.LentilError) as e:
-        gpu_run(ctx, p, table, visits, n_aovs=2, kinds=[0, 1])
-    assert e.value.code == -3 and "src/lentil.h:832-837" in str(e.value)
-    # gaussian AOVs only: nothing to refuse
-    ref = common.run_oracle(orc, p, table, visits, n_aovs=2)
+    for _ in range(2):          # (twice: the second pass of a context runs blind / streamed, and "no-log" keeps its log by then)
+        c = gpu_run(ctx, p, table, visits, n_aovs=3, kinds=kinds, log_cap=(1 << 22) if own_log else 0)
+        _same_counters(c, ref)
+        if own_log:
+            check_logs(ctx, ref)
+        check_frame(ctx, ref, n_aovs=3, kinds=kinds)
+        for a in (1, 2):        # the closest-filtered planes: the oracle's values, bit for bit
+            assert np.array_equal(ctx.download_aov(a).view(np.uint32), ref.resolve(a).view(np.uint32))
+    ref.close()
+    # gaussian AOVs only: the depth of a sample is never looked at
+    ref = common.run_oracle(orc, p, table, ovisits, n_aovs=3)
     ctx2 = gpu_ctx_factory()
-    c = gpu_run(ctx2, p, table, visits, n_aovs=2, kinds=[0, 0])
+    c = gpu_run(ctx2, p, table, ovisits, n_aovs=3, kinds=[0, 0, 0])
     _same_counters(c, ref)
     check_logs(ctx2, ref)
-    check_frame(ctx2, ref, n_aovs=2)
+    check_frame(ctx2, ref, n_aovs=3)
