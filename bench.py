@@ -680,7 +680,12 @@ def main():
     if tiled and (world > 1 or force_dist) and not args.bounds and os.environ.get("LENTIL_REBALANCE", "1") != "0":
         # calibration (untimed set-up, before the warm-up steps): three passes, the first with even bands, each followed
         # by an all-gather of the ranks' pass times (scan + draws, HIP events) and a re-cut of the bands
-        b.bounds = b.distributed.even_bounds(world, H)
+        # (the first cut from the cost model of the frame's edges, not the even one: LENTIL_REBALANCE_START=even restores that)
+        b.bounds = (b.distributed.even_bounds(world, H) if os.environ.get("LENTIL_REBALANCE_START", "model") == "even"
+                    else b.distributed.modelled_bounds(world, H))
+        if b.bounds != b.distributed.even_bounds(world, H):
+            b.set_band()
+            b.generate(args.f_hi)
         for it in range(3):
             b.step()
             a_, b_, c_ = b.ctx.last_timing()

@@ -139,6 +139,7 @@ struct lentil_hip_ctx {
   // resident solve blocks instead of two: the pass is bound by the solves' fp64 issue slots and the scan's HBM bytes at the
   // same time, and a CU that does both does the solves at two waves per SIMD with the scan's waves in between.
   // LENTIL_SCAN_CUS_PCT.
+  double longest_pass_ms = 0.0;              // the longest streamed pass of this context so far (host time; sizes the stuck time-out)
   int scan_cus_pct = 100;
   unsigned last_scan_skipped = 0;             // blocks of the last scan launch that left at once (scan_dma2_kernel, ScanArgs::skip_blocks)
   bool predict = true;
@@ -1969,6 +1970,19 @@ static int redistribute_streamed(lentil_hip_ctx *ctx, bool *streamed) {
   }
   const uint32_t retries = (uint32_t)(P.vignetting_retries < 0 ? 0 : P.vignetting_retries);
   const bool few = ctx->est_sum_total < ctx->slow_below;
+  // How long a resident wave waits for its queue slot before it declares the pass stuck (the host then redoes the pass the
+  // chunked way).  A wave may rightly wait for a whole scan -- its slot gets its end marker when the scan ends --, so: 250 ms
+  // while nothing is known, else sixteen times the longest pass this context has seen, at least 30 ms (round 5: a stall,
+  // rare as it is, then costs tens of milliseconds and not a quarter of a second; LENTIL_STUCK_MS overrides).
+  uint64_t stuck_ticks = 0;
+  {
+    static const double forced_ms = getenv("LENTIL_STUCK_MS") ? atof(getenv("LENTIL_STUCK_MS")) : 0.0;
+    double ms = ctx->longest_pass_ms > 0.0 ? 16.0 * ctx->longest_pass_ms : 250.0;
+    if (ms < 30.0) ms = 30.0;
+    if (ms > 250.0) ms = 250.0;
+    if (forced_ms > 0.0) ms = forced_ms;
+    stuck_ticks = (uint64_t)(ms * 1.0e5);
+  }
 
   PublishArgs pa{};
   pa.P = P;
@@ -1999,6 +2013,8 @@ static int redistribute_streamed(lentil_hip_ctx *ctx, bool *streamed) {
   plan.sa.end_ranges = (uint32_t)ctx->publish_waves;
   plan.sa.flush_each_tile = ctx->est_items_total < (1u << 16) ? 1u : 0u;
   pa.ctr = ctx->d_ctr;
+  pa.stuck_ticks = stuck_ticks;
+  da.stuck_ticks = stuck_ticks;
   pa.work = ctx->d_work;
   pa.work_cap = ctx->V.n;
   pa.ranges = ctx->d_ranges;
@@ -2015,6 +2031,8 @@ static int redistribute_streamed(lentil_hip_ctx *ctx, bool *streamed) {
   if (!few) da.slow = nullptr;              // parking is for passes with few draws (DrawArgs::slow_below)
 
   unsigned scan_blocks = 0;
+  const auto pass_t0 = std::chrono::steady_clock::now();
+  const bool calibrates_now = ctx->predict && !ctx->bm_valid;       // (this pass's host time holds the calibration kernel's)
   // the first-batch model's calibration, should the camera set-up have changed: on the main stream, ahead of the event the
   // publishers (who read the table) wait for
   if (ctx->predict && !ctx->extend && nch == 1 && (rc = ensure_batch_model(ctx))) return rc;
@@ -2173,7 +2191,8 @@ static int redistribute_streamed(lentil_hip_ctx *ctx, bool *streamed) {
     HIP_TRY(ctx, hipStreamWaitEvent(ch.stream, ctx->pub_done, 0));       // (both long past when A ends)
     HIP_TRY(ctx, hipStreamWaitEvent(ch.stream, ctx->scans_done, 0));
     HIP_TRY(ctx, hipEventRecord(ctx->ev_round, ch.stream));
-    const bool lean_pass = (extend || predicted) && ctx->lean_tail && ctx->lean_ok && blind_rounds <= 2;
+    // (LENTIL_INJECT_STALL stalls the second round's resident solve waves: that pass keeps its second round in flight)
+    const bool lean_pass = (extend || predicted) && ctx->lean_tail && ctx->lean_ok && blind_rounds <= 2 && !da.inject_stall;
     {
       DrawArgs d0 = da;
       d0.emit_live = lean_pass ? 0 : 1;       // (lean tail: nobody is waiting for tasks)
@@ -2368,6 +2387,11 @@ static int redistribute_streamed(lentil_hip_ctx *ctx, bool *streamed) {
   const int C = ctx->n_chunks;
   HIP_TRY(ctx, hipMemcpyAsync(ctx->h_ctr_pinned, ctx->d_ctr, sizeof(DevCounters) * C, hipMemcpyDeviceToHost, tail));
   HIP_TRY(ctx, hipStreamSynchronize(tail));
+  {
+    // (host time from the pass's first launch to its counters: an upper bound of every wait inside it)
+    const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - pass_t0).count();
+    if (!calibrates_now && ms > ctx->longest_pass_ms && ms < 200.0) ctx->longest_pass_ms = ms;
+  }
   if (tail != ctx->stream) {
     // everything the pass enqueued anywhere is behind the read-back that has just arrived; what the caller enqueues on
     // the context's stream next (resolve, downloads, the next pass) follows the main stream's own last kernel

@@ -1889,6 +1889,7 @@ struct PublishArgs {
   const uint64_t *ranges;
   uint32_t range_cap;
   uint32_t end_tasks;      // solve waves of the first round (both launches)
+  uint64_t stuck_ticks;    // how long a wave waits for a queue slot before it declares the pass stuck (100 MHz ticks; 0: kStuckTicks)
 };
 
 __global__ __launch_bounds__(64) void publish_kernel(PublishArgs a) {
@@ -1908,7 +1909,7 @@ __global__ __launch_bounds__(64) void publish_kernel(PublishArgs a) {
       rec = ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(rec >> 32)) << 32) |
             (uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)rec);
       if (((uint32_t)(rec >> 32) >> kTaskTagShift) == a.S.epoch) break;
-      if (__builtin_amdgcn_s_memrealtime() - t0 > kStuckTicks) {
+      if (__builtin_amdgcn_s_memrealtime() - t0 > (a.stuck_ticks ? a.stuck_ticks : kStuckTicks)) {
         if (lane == 0) atomicCAS(&a.ctr->stuck, 0u, 1u | (ticket << 2));      // (the first to give up is the one worth knowing)
         over = true;
         break;
@@ -2106,6 +2107,7 @@ struct DrawArgs {
   // Lean tail of a streamed pass with extension: no second round's solve kernels are in flight.  The accept behind the first
   // one (accept_kernel<2>) does nothing if the first one had to schedule tasks after all (n_tasks of its parity): the host then
   // runs that round the ordinary way and this accept after it.
+  uint64_t stuck_ticks;       // how long a resident wave waits for a queue slot before it declares the pass stuck (0: kStuckTicks)
   int32_t lean_gate;
   int32_t lean_defer;         // ... and the first accept leaves an item that met parked solves to that accept whole: what it still
                               // needs is decided there, from the stragglers' results
@@ -2515,7 +2517,7 @@ __global__ __launch_bounds__(256) LENTIL_SOLVE_ATTR void solve_po_kernel(DrawArg
           if ((w1_hi >> kTaskTagShift) != a.epoch) {
             if (lane == 0) tl_add(TL_POLLS_EMPTY, 1u);
             // nothing there (yet): back to the solves in flight (an idle wave naps, below)
-            if (__builtin_amdgcn_s_memrealtime() - ticket_t0 > kStuckTicks) {
+            if (__builtin_amdgcn_s_memrealtime() - ticket_t0 > (a.stuck_ticks ? a.stuck_ticks : kStuckTicks)) {
               if (lane == 0) atomicCAS(&a.ctr->stuck, 0u, 2u | (ticket << 2));      // the host redoes the pass chunk by chunk
               no_more = true;
             }
@@ -2899,7 +2901,7 @@ __global__ __launch_bounds__(64) LENTIL_SLOW_ATTR void solve_slow_kernel(DrawArg
         if (lane == 0) tag = ld_coherent64(src + 15);
         tag = ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(tag >> 32)) << 32) | (uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)tag);
         if ((tag >> 32) == (slow_tag(a, 0) >> 32) && (uint32_t)tag != 0u) break;
-        if (__builtin_amdgcn_s_memrealtime() - t0 > kStuckTicks) { if (lane == 0) atomicCAS(&a.ctr->stuck, 0u, 3u | ((q & 0xFFFFFu) << 2) | ((uint32_t)a.round << 24)); over = true; break; }
+        if (__builtin_amdgcn_s_memrealtime() - t0 > (a.stuck_ticks ? a.stuck_ticks : kStuckTicks)) { if (lane == 0) atomicCAS(&a.ctr->stuck, 0u, 3u | ((q & 0xFFFFFu) << 2) | ((uint32_t)a.round << 24)); over = true; break; }
         for (uint32_t i = 0; i < naps; ++i) __builtin_amdgcn_s_sleep(64);
         if (naps < 8u) naps <<= 1;
       }

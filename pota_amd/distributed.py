@@ -235,6 +235,37 @@ def even_bounds(world, visit_rows):
     return [visit_rows * r // world for r in range(world + 1)]
 
 
+def modelled_bounds(world, visit_rows, edge_rows=None, edge_weight=1.4):
+    """Band boundaries from a cost model instead of the even split -- where the calibration passes START, so that the first
+    cut is already near the level one (round 5).  The model: a row costs 1, plus
+    edge_weight * (1 - d / edge_rows) within edge_rows of the frame's top or bottom edge (d = rows to that edge).  Rows
+    near an edge hold the items whose circle of confusion reaches over it: they lose attempts to the outside of the
+    frame and trace at the largest field angles (slower Newton solves).  Measured on one MI355X running single bands of
+    the 4K frame (profiles/r04_emulated_bands.txt): 0.89 ms for an outer band of 270 rows against 0.68 ms for a middle
+    one -- the outer band carries 84 rows' worth of extra cost, which edge_rows = 5.5 % of the frame's height (120 rows
+    at 2160) and edge_weight = 1.4 reproduce.  Pure function: every rank computes the same cut."""
+    n = int(visit_rows)
+    if world <= 1 or n < 2 * world:
+        return even_bounds(world, n)
+    er = float(edge_rows) if edge_rows else max(1.0, 0.055 * n)
+    # cumulative cost in closed form per row is not worth it: a few thousand rows, summed once
+    cost = [1.0 + edge_weight * max(0.0, 1.0 - min(y + 0.5, n - y - 0.5) / er) for y in range(n)]
+    total = sum(cost)
+    bounds, acc, y = [0], 0.0, 0
+    for k in range(1, world):
+        target = total * k / world
+        while y < n and acc + cost[y] <= target:
+            acc += cost[y]
+            y += 1
+        bounds.append(y)
+    bounds.append(n)
+    for k in range(1, world + 1):        # (every band at least one row)
+        bounds[k] = max(bounds[k], bounds[k - 1] + 1)
+    for k in range(world - 1, 0, -1):
+        bounds[k] = min(bounds[k], bounds[k + 1] - 1)
+    return bounds
+
+
 def band_of(rank, world, visit_rows, frame_rows, bounds=None):
     """Rows [lo, hi) of the frame owned by `rank`: consecutive visit rows, split evenly or at `bounds` (world + 1
     ascending rows, bounds[0] = 0, bounds[world] = visit_rows); the last band also owns the rows beyond the visits

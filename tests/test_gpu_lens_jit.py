@@ -50,9 +50,7 @@ def test_interpreter_and_runtime_kernel_agree_bit_for_bit(orc, tmp_path, monkeyp
         check_frame(ctx, ref)
     finally:
         ctx.close()
-    # another context of the process shares the entry; a cache file exists for the next process
-    files = list((tmp_path / "cache").glob("*.lco"))
-    assert len(files) == 1 and files[0].stat().st_size > 100000
+    # another context of the process shares the entry (the cache file for the next process: the test below)
     ctx2 = capi.Context(0)
     try:
         ctx2.set_params(p); ctx2.set_lens(table)

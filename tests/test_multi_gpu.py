@@ -496,6 +496,33 @@ def test_rebalance_equalises_the_modelled_cost():
     assert tiny[0] == 0 and tiny[-1] == 30 and all(b - a >= 4 for a, b in zip(tiny, tiny[1:]))
 
 
+def test_modelled_bounds_level_the_measured_band_times():
+    """The cut the calibration starts from (distributed.modelled_bounds): with the cost model's own numbers -- a row near the
+    frame's top or bottom edge costs up to 2.4 rows -- the eight bands of the 4K frame carry equal modelled cost, the outer
+    ones are the shortest, and the model reproduces the measured ratio of an outer to a middle even band (0.89 / 0.68 ms,
+    profiles/r04_emulated_bands.txt)."""
+    from pota_amd import distributed
+    H, G = 2160, 8
+    b = distributed.modelled_bounds(G, H)
+    assert b[0] == 0 and b[-1] == H and len(b) == G + 1 and all(y > x for x, y in zip(b, b[1:]))
+    er, w = 0.055 * H, 1.4
+    cost = [1.0 + w * max(0.0, 1.0 - min(y + 0.5, H - y - 0.5) / er) for y in range(H)]
+    per_band = [sum(cost[b[k]:b[k + 1]]) for k in range(G)]
+    assert max(per_band) / min(per_band) < 1.02
+    heights = [b[k + 1] - b[k] for k in range(G)]
+    assert heights[0] == min(heights) and heights[-1] == min(heights[-1], heights[0] + 1) and heights[3] > heights[0]
+    even = distributed.even_bounds(G, H)
+    outer, middle = sum(cost[even[0]:even[1]]), sum(cost[even[3]:even[4]])
+    assert abs(outer / middle - 0.89 / 0.68) < 0.03
+    # symmetric, deterministic, and sane where there is nothing to model
+    assert [H - x for x in reversed(b)] == b or max(abs((H - x) - y) for x, y in zip(reversed(b), b)) <= 1
+    assert distributed.modelled_bounds(1, H) == [0, H]
+    assert distributed.modelled_bounds(4, 6) == distributed.even_bounds(4, 6)
+    for world, rows in [(2, 9), (8, 64), (3, 100), (8, 4320)]:
+        m = distributed.modelled_bounds(world, rows)
+        assert m[0] == 0 and m[-1] == rows and all(y > x for x, y in zip(m, m[1:]))
+
+
 def test_row_partition_covers_frame():
     from pota_amd import distributed, workload
     H = 37
