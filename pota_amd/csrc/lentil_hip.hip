@@ -140,7 +140,8 @@ struct lentil_hip_ctx {
   // same time, and a CU that does both does the solves at two waves per SIMD with the scan's waves in between.
   // LENTIL_SCAN_CUS_PCT.
   double longest_pass_ms = 0.0;              // the longest streamed pass of this context so far (host time; sizes the stuck time-out)
-  int scan_cus_pct = 100;
+  int scan_cus_pct = 84;                     // (100 / 92 / 84 / 76: 2.10 / 2.12 / 2.02 / 2.04 ms, means of four runs of 60 steps on one box)
+  int scan_cus_pct_multi = 100;              // ... for frames with extra AOV columns (scan_dma_multi_kernel): LENTIL_SCAN_CUS_PCT_MULTI
   unsigned last_scan_skipped = 0;             // blocks of the last scan launch that left at once (scan_dma2_kernel, ScanArgs::skip_blocks)
   bool predict = true;
   float4 *d_bm_land = nullptr;
@@ -429,6 +430,7 @@ LENTIL_API int lentil_hip_create(int device, lentil_hip_ctx **out_ctx) {
   if (const char *e = getenv("LENTIL_LEAN_TAIL")) ctx->lean_tail = e[0] != '0';
   if (const char *e = getenv("LENTIL_PREDICT")) ctx->predict = e[0] != '0';
   if (const char *e = getenv("LENTIL_LENS_JIT")) ctx->jit_enabled = e[0] != '0';
+  if (const char *e = getenv("LENTIL_SCAN_CUS_PCT_MULTI")) { ctx->scan_cus_pct_multi = atoi(e); if (ctx->scan_cus_pct_multi < 25) ctx->scan_cus_pct_multi = 25; if (ctx->scan_cus_pct_multi > 100) ctx->scan_cus_pct_multi = 100; }
   if (const char *e = getenv("LENTIL_SCAN_CUS_PCT")) { ctx->scan_cus_pct = atoi(e); if (ctx->scan_cus_pct < 25) ctx->scan_cus_pct = 25; if (ctx->scan_cus_pct > 100) ctx->scan_cus_pct = 100; }
   if (const char *e = getenv("LENTIL_PREDICT_GRID")) {
     unsigned a = 0, b = 0, c = 0;
@@ -1786,6 +1788,7 @@ static int launch_scan(lentil_hip_ctx *ctx, const ScanPlan &pl, const lentil_hip
   sa.v_begin = ch.v_begin; sa.v_end = ch.v_end;
   const uint64_t max_blocks = (uint64_t)ctx->num_cu * 8;
   uint64_t blocks;
+  unsigned multi_skipped = 0;
   // (a streamed pass's single launch: timed by its own dispatch, lentil_hip_last_timing; LENTIL_SCAN_EVENTS=0: by the events around it)
   static const bool scan_events = !(getenv("LENTIL_SCAN_EVENTS") && getenv("LENTIL_SCAN_EVENTS")[0] == '0');
   const bool own_events = streamed_pass && scan_events && (pl.dma || pl.dma_multi);
@@ -1806,7 +1809,8 @@ static int launch_scan(lentil_hip_ctx *ctx, const ScanPlan &pl, const lentil_hip
       // (a streamed pass may leave some CUs without a scanning block: those take a third resident solve block, scan_cus_pct;
       // the blocks that do not scan are launched all the same and leave at once, see the kernel)
       sa.skip_blocks = 0;
-      if (streamed_pass && ctx->scan_cus_pct < 100 && blocks == (uint64_t)ctx->num_cu)
+      // (only where the pass is bound by its solves: 1080p with 256 draws -- 73 k draws a frame -- is not, 0.74 against 0.71 ms)
+      if (streamed_pass && ctx->scan_cus_pct < 100 && blocks == (uint64_t)ctx->num_cu && ctx->est_sum_total >= (1ull << 19))
         sa.skip_blocks = (uint32_t)(blocks - ((uint64_t)ctx->num_cu * (uint64_t)ctx->scan_cus_pct + 99) / 100);
       if (own_events) hipExtLaunchKernelGGL(scan_dma2_kernel, dim3((unsigned)blocks), dim3(256), pl.lds, ctx->stream, ctx->ev_scan_k[0], ctx->ev_scan_k[1], 0, sa);
       else hipLaunchKernelGGL(scan_dma2_kernel, dim3((unsigned)blocks), dim3(256), pl.lds, ctx->stream, sa);
@@ -1819,6 +1823,14 @@ static int launch_scan(lentil_hip_ctx *ctx, const ScanPlan &pl, const lentil_hip
     blocks = (ch.tile_end - ch.tile_begin + 4 * kDmaMultiRun - 1) / (4 * kDmaMultiRun);
     if (blocks > (uint64_t)ctx->num_cu * dma_multi_blocks_per_cu(ctx)) blocks = (uint64_t)ctx->num_cu * dma_multi_blocks_per_cu(ctx);
     if (blocks < 1) blocks = 1;
+    // (scan_cus_pct: this kernel's blocks draw all their tiles from one counter, so fewer of them is all it takes -- the CUs
+    // left alone hold a third resident solve block)
+    multi_skipped = 0;
+    if (streamed_pass && ctx->scan_cus_pct_multi < 100 && blocks == (uint64_t)ctx->num_cu && dma_multi_blocks_per_cu(ctx) == 1) {
+      const uint64_t keep = ((uint64_t)ctx->num_cu * (uint64_t)ctx->scan_cus_pct_multi + 99) / 100;
+      multi_skipped = (unsigned)(blocks - keep);
+      blocks = keep;
+    }
     if (own_events) hipExtLaunchKernelGGL(scan_dma_multi_kernel, dim3((unsigned)blocks), dim3(256), pl.lds, ctx->stream, ctx->ev_scan_k[0], ctx->ev_scan_k[1], 0, sa);
     else hipLaunchKernelGGL(scan_dma_multi_kernel, dim3((unsigned)blocks), dim3(256), pl.lds, ctx->stream, sa);
   } else if (pl.M) {
@@ -1836,7 +1848,7 @@ static int launch_scan(lentil_hip_ctx *ctx, const ScanPlan &pl, const lentil_hip
   }
   HIP_TRY(ctx, hipGetLastError());
   if (blocks_out) *blocks_out = (unsigned)blocks;
-  ctx->last_scan_skipped = (pl.dma && pl.dma2) ? sa.skip_blocks : 0u;
+  ctx->last_scan_skipped = (pl.dma && pl.dma2) ? sa.skip_blocks : (pl.dma_multi ? multi_skipped : 0u);
   return LENTIL_OK;
 }
 
