@@ -751,7 +751,7 @@ def main():
                             % (world, (" at rows %s (balanced by pass time)" % b.bounds) if b.bounds else "") if tiled else
                             "rows%%%d + allreduce" % world),
         },
-        "box": box,
+        "box": box, "streams_concurrent": b.ctx.streams_concurrent(),
         "exchange": exchange, "ranks_joined": ranks_joined,
         "passes": {"timed": steps, "streamed": r["streamed"], "chunks_enqueued_blind": r["blind_chunks"],
                    "chunks_redone_after_a_short_estimate": r["redone"], "solve_accept_rounds_max": r.get("rounds_max"),
@@ -803,6 +803,25 @@ def main():
                 c5.close()
             except Exception as e:
                 out.setdefault("configs", {})[name] = {"value": None, "error": repr(e)}
+
+    if rank == 0 and world == 1 and not emulate and not args.no_configs and os.environ.get("GPU_MAX_HW_QUEUES") != "4":
+        # The same headline pass in a process whose runtime keeps its default of four hardware queues (a renderer that loads the
+        # plugin sets nothing): a child process, because the runtime reads the variable when it initialises.  lentil_hip_create
+        # probes whether the pass's streams run side by side there; where they do not, the pass takes its chunked form.
+        try:
+            import subprocess
+            env = dict(os.environ, GPU_MAX_HW_QUEUES="4")
+            cmd = [sys.executable, os.path.abspath(__file__), "--steps", "10", "--warmup", "3", "--no-cpu-baseline", "--no-second-regime",
+                   "--no-configs", "--no-pcie", "--no-parity-check", "--no-scan-alone", "--width", str(args.width), "--height", str(args.height),
+                   "--samples", str(args.samples), "--lens", args.lens, "--aovs", str(args.aovs)]
+            line = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600).stdout.strip().splitlines()[-1]
+            d4 = json.loads(line)
+            out["runtime_default_hw_queues"] = {
+                "GPU_MAX_HW_QUEUES": 4, "ms_per_step": d4["ms_per_step"], "value": d4["value"], "passes": d4["passes"],
+                "streams_concurrent": d4.get("streams_concurrent"),
+                "note": "the headline workload in a child process with the runtime's default of four hardware queues (INTEGRATION.md section 3a)"}
+        except Exception as e:      # noqa: BLE001
+            out["runtime_default_hw_queues"] = {"ms_per_step": None, "error": repr(e)}
 
     if not args.no_second_regime and world == 1:
         f2 = 1.6e-3

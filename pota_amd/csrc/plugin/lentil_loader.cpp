@@ -10,8 +10,9 @@ void registerLentilImager(AtNodeLib *node);
 void registerLentilOperator(AtNodeLib *node);
 
 node_loader {
-  // (The pass keeps four HIP streams busy and uses a fifth where the runtime has one: GPU_MAX_HW_QUEUES=8 in the renderer's
-  // launch environment, INTEGRATION.md.  Not set from here: setenv in a plugin races with getenv on the host's other threads.)
+  // (Nothing is asked of the renderer's environment: the pass keeps four HIP streams busy, the runtime's default of four hardware
+  // queues holds them, and lentil_hip_create probes that they do run side by side -- a context whose streams do not takes the
+  // chunked form of the pass.  A process with other busy GPU streams may want GPU_MAX_HW_QUEUES=8: INTEGRATION.md section 3a.)
   typedef void (*Register)(AtNodeLib *);
   static const Register nodes[] = {registerLentilCamera, registerLentilFilter, registerLentilImager, registerLentilOperator};
   if (i < 0 || i >= (int)(sizeof nodes / sizeof nodes[0])) return false;
