@@ -292,15 +292,19 @@ def parity_check(W, H, M, samples, aovs, f_hi, p, table, tan_half_fov, device_in
 
 
 def power_cap_watts():
-    """the package power cap as rocm-smi reports it (a child process; None where it cannot be read)"""
-    import re
-    import subprocess
-    try:
-        txt = subprocess.run(["rocm-smi", "--showmaxpower"], capture_output=True, text=True, timeout=20).stdout
-        m = re.search(r"Max Graphics Package Power \(W\):\s*([0-9.]+)", txt)
-        return float(m.group(1)) if m else None
-    except Exception:      # noqa: BLE001
-        return None
+    """the package power cap from sysfs (hwmon power1_cap, microwatts); None where it cannot be read.  (No child process: under
+    rocprofv3 a `#!/usr/bin/env python3` tool such as rocm-smi would be an exec behind the profiler's preloaded library.)"""
+    import glob
+    best = None
+    for p in glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*/power1_cap"):
+        try:
+            with open(p) as f:
+                w = int(f.read().strip()) / 1e6
+            if w > 0 and (best is None or w > best):
+                best = w
+        except (OSError, ValueError):
+            pass
+    return best
 
 
 def checked(fn, *a, **kw):

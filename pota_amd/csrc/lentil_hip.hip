@@ -144,6 +144,7 @@ struct lentil_hip_ctx {
   int scan_cus_pct_multi = 100;              // ... for frames with extra AOV columns (scan_dma_multi_kernel): LENTIL_SCAN_CUS_PCT_MULTI
   unsigned last_scan_skipped = 0;             // blocks of the last scan launch that left at once (scan_dma2_kernel, ScanArgs::skip_blocks)
   bool predict = true;
+  uint64_t predict_max_draws = 1536;         // LENTIL_PREDICT_MAX_DRAWS: mean draws per item up to which a pass sizes first batches from the model
   float4 *d_bm_land = nullptr;
   float4 *d_bm_box = nullptr;
   uint32_t *d_bm_npass = nullptr;
@@ -429,6 +430,7 @@ LENTIL_API int lentil_hip_create(int device, lentil_hip_ctx **out_ctx) {
   if (const char *e = getenv("LENTIL_EXTEND")) ctx->extend = e[0] != '0';
   if (const char *e = getenv("LENTIL_LEAN_TAIL")) ctx->lean_tail = e[0] != '0';
   if (const char *e = getenv("LENTIL_PREDICT")) ctx->predict = e[0] != '0';
+  if (const char *e = getenv("LENTIL_PREDICT_MAX_DRAWS")) ctx->predict_max_draws = strtoull(e, nullptr, 10);
   if (const char *e = getenv("LENTIL_LENS_JIT")) ctx->jit_enabled = e[0] != '0';
   if (const char *e = getenv("LENTIL_SCAN_CUS_PCT_MULTI")) { ctx->scan_cus_pct_multi = atoi(e); if (ctx->scan_cus_pct_multi < 25) ctx->scan_cus_pct_multi = 25; if (ctx->scan_cus_pct_multi > 100) ctx->scan_cus_pct_multi = 100; }
   if (const char *e = getenv("LENTIL_SCAN_CUS_PCT")) { ctx->scan_cus_pct = atoi(e); if (ctx->scan_cus_pct < 25) ctx->scan_cus_pct = 25; if (ctx->scan_cus_pct > 100) ctx->scan_cus_pct = 100; }
@@ -2142,7 +2144,11 @@ static int redistribute_streamed(lentil_hip_ctx *ctx, bool *streamed) {
   const bool extend = ctx->extend && decoupled && nch == 1 && ctx->chain_streams;
   // First batches from the lens and the frame (lentil_batch_model.h): every item is published with the traces it is expected
   // to need, so that the first accept finds nothing to schedule and the pass can do without a second round (lean tail, below)
-  const bool predict = ctx->predict && !extend && decoupled && nch == 1 && ctx->chain_streams;
+  // (Not for items with very many draws each -- BASELINE config 5's 2 048: their first accept is long, 0.3-0.65 ms, and the
+  // second round that runs beside it is all but free, while its traces inside the first round are throughput; the bands of
+  // that frame, each alone on one GPU, took 5-19 % longer with the lean tail: profiles/r05_emulated_bands.txt.)
+  const bool few_draws_per_item = ctx->est_items_total == 0 || ctx->est_sum_total / ctx->est_items_total <= ctx->predict_max_draws;
+  const bool predict = ctx->predict && !extend && decoupled && nch == 1 && ctx->chain_streams && few_draws_per_item;
   if (predict && ctx->bm_valid) pub.model = batch_model_dev(ctx);        // (calibrated ahead of the scan, above)
   const bool predicted = predict && pub.model.land != nullptr;
   if (extend) {

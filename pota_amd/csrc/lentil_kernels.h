@@ -1184,26 +1184,43 @@ __global__ __launch_bounds__(256) void scan_dma2_kernel(ScanArgs a) {
     }
   };
 
-  // ---- a wave's tiles: runs of four, first its share of a static interleaved split, then what tile_next hands out
+  // ---- a wave's tiles: runs of four, claimed from DevCounters::tile_next in SEQUENCES that shrink as the scan goes on
+  // (round 5; until then 7/8 of the runs were split statically between the waves of the grid, which made the scan depend on
+  // every one of its blocks being resident at once: a block the dispatcher had not placed -- its CU full of resident solve
+  // blocks -- kept its share of the frame unscanned while the solve waves waited for the scan's end: a pass stuck for good,
+  // seen as the odd 250 ms time-out.  Now any subset of the blocks finishes the frame.)
+  // With R = runs per wave: a ticket of level 0 stands for R/2 runs, of level 1 for R/4, then R/8, R/16, then single runs;
+  // every level hands out one ticket per wave of the grid, and a ticket's runs lie W runs apart (ticket t of a level: runs
+  // base + t, base + t + W, ...), so that the waves still move through the frame side by side, in scan order, and a
+  // sequence is one pipelined chain of tiles as the static share was: a wave pays the bubble between two sequences five
+  // times and then once per single run, on the last sixteenth of the frame.
   const uint64_t n_full = full_end > a.tile_begin ? full_end - a.tile_begin : 0ull;
   const uint32_t n_runs = (uint32_t)((n_full + 3u) / 4u);
-  const uint32_t W = (gridDim.x - a.skip_blocks) * 4u, gw = (blockIdx.x - a.skip_blocks) * 4u + wave;
-  const uint32_t n_static = (uint32_t)(((uint64_t)n_runs * 7u / 8u) / W);       // runs per wave of the static part
+  const uint32_t W = (gridDim.x - a.skip_blocks) * 4u;
+  const uint32_t R = n_runs / W;
+  // (scalars, not arrays: everything here is wave-uniform and should stay in SGPRs)
+  const uint32_t n_lvl = (R >= 2u ? 1u : 0u) + (R >= 4u ? 1u : 0u) + (R >= 8u ? 1u : 0u) + (R >= 16u ? 1u : 0u);
+  const uint32_t lb1 = (R >> 1) * W, lb2 = lb1 + (R >> 2) * W, lb3 = lb2 + (R >> 3) * W, lb4 = lb3 + (R >> 4) * W;
   // (ScanArgs::outside_in: the runs alternate between the two ends of the range and meet in the middle, scan_order)
   auto run_first = [&](uint32_t r) { return a.tile_begin + (uint64_t)(a.outside_in ? ((r & 1u) ? n_runs - 1u - (r >> 1) : (r >> 1)) : r) * 4u; };
   auto run_len = [&](uint64_t first) { return (uint32_t)(full_end - first < 4u ? full_end - first : 4u); };
-  uint32_t k = 0;
   uint32_t buf = 0, par = 0;
   while (true) {
-    // the next sequence of tiles: all static runs of this wave in one go, then one dynamic run at a time
-    uint32_t r;
-    bool is_static = k < n_static;
-    if (is_static) {
-      r = k * W + gw;
+    // the next sequence of runs (nothing of this wave's is in flight here: the returning atomic does not disturb the
+    // counted waits inside a sequence)
+    uint32_t t = 0;
+    if (lane == 0) t = atomicAdd(&a.ctr->tile_next, 1u);
+    t = (uint32_t)__builtin_amdgcn_readfirstlane(t);
+    uint32_t r, runs_left, stride;
+    if (t < n_lvl * W) {
+      const uint32_t l = t / W;
+      r = (l == 0u ? 0u : (l == 1u ? lb1 : (l == 2u ? lb2 : lb3))) + (t - l * W);
+      runs_left = R >> (l + 1u);
+      stride = W;
     } else {
-      uint32_t t = 0;
-      if (lane == 0) t = atomicAdd(&a.ctr->tile_next, 1u);
-      r = W * n_static + (uint32_t)__builtin_amdgcn_readfirstlane(t);
+      r = lb4 + (t - n_lvl * W);
+      runs_left = 1u;
+      stride = 0u;
       if (r >= n_runs) break;
     }
     uint64_t tile = run_first(r);
@@ -1222,16 +1239,16 @@ __global__ __launch_bounds__(256) void scan_dma2_kernel(ScanArgs a) {
       uint64_t next_tile = tile;
       uint32_t next_left = 0;
       if (left > 1u) { has_next = true; next_tile = tile + 1u; next_left = left - 1u; }
-      else if (is_static && k + 1u < n_static) {
+      else if (runs_left > 1u) {
         has_next = true;
-        next_tile = run_first((k + 1u) * W + gw);
+        next_tile = run_first(r + stride);
         next_left = run_len(next_tile);
       }
       do_tile(tile, has_next, next_tile, buf, par);
       if (lane == 0) tl_add(TL_SCAN_TILES, 1u);
       buf ^= 1u;
       par = (par + M) & 1u;
-      if (left == 1u && is_static) ++k;
+      if (left == 1u) { r += stride; --runs_left; }
       if (!has_next) break;
       tile = next_tile; left = next_left;
     }
@@ -1892,7 +1909,12 @@ struct PublishArgs {
   uint64_t stuck_ticks;    // how long a wave waits for a queue slot before it declares the pass stuck (100 MHz ticks; 0: kStuckTicks)
 };
 
-__global__ __launch_bounds__(64) void publish_kernel(PublishArgs a) {
+// (At most 64 VGPRs: a publisher wave must fit into what a CU has left beside two resident solve blocks and a scanning block --
+// 512 - 2 x 168 - 96 = 80 registers per SIMD lane -- whichever of the pass's kernels the dispatcher places first; with the
+// first-batch model's blend inlined the kernel took 108, and a pass whose publishers found no room anywhere waited for them
+// until its time-out: the odd stalled pass of round 5's first sessions.  The publishers are latency-bound on their atomics:
+// spilling a few values costs them nothing that shows.)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8))) void publish_kernel(PublishArgs a) {
   LENTIL_TL_SPAN(SPAN_PUBLISH);
   const uint32_t lane = threadIdx.x;
   while (true) {
