@@ -306,6 +306,15 @@ __global__ __launch_bounds__(128) void crypto_direct_tile_kernel(CryptoDev C, Vi
         uint32_t *K = s_k + threadIdx.x * SP;
         float *Wt = s_wt + threadIdx.x * SP;
         float total = s_tot[threadIdx.x];
+        // The pixel's visits mostly carry the same few ids (one object covers the pixel): the two ids met last are kept in
+        // registers with their slot and the slot's running weight, so that a pair whose id is one of them costs one add instead
+        // of a chain of dependent LDS reads and writes (probe, compare, read-modify-write) -- which is what this kernel's waves
+        // spent 60 % of their cycles waiting for (profiles/r04_pmc_crypto.txt).  A slot's weight still receives the same adds in
+        // the same order (it is loaded when the id enters the registers, written back when it leaves them): bit for bit the
+        // sequential sums, as asserted by tests/test_crypto.py.
+        uint32_t k0 = kCryptoEmpty, k1 = kCryptoEmpty, s0 = 0, s1 = 0;
+        float a0 = 0.0f, a1 = 0.0f;
+        bool newer0 = false;                 // which of the two was used last
         for (uint32_t m = 0; m < M; ++m) {
           const float w = s_w[threadIdx.x * M + m];
           if (__float_as_uint(w) == kCryptoEmpty) continue;
@@ -314,17 +323,37 @@ __global__ __launch_bounds__(128) void crypto_direct_tile_kernel(CryptoDev C, Vi
             const float cw = s_cw[(threadIdx.x * M + m) * E + e];
             if (__float_as_uint(cw) == kCryptoEmpty) continue;
             const uint32_t key = crypto_key_bits(s_h[(threadIdx.x * M + m) * E + e]);
+            if (key == kCryptoEmpty) {
+              // (an id whose bits are the "free slot" pattern -- a NaN: as ever, its weight lands in the first free slot of its
+              // probe sequence, which no register holds)
+              uint32_t sl = crypto_first_slot(key, SL);
+              bool placed = false;
+              for (uint32_t i = 0; i < SL && !placed; ++i) {
+                if (K[sl] == kCryptoEmpty) { Wt[sl] += cw * w; placed = true; }
+                else sl = sl + 1u == SL ? 0u : sl + 1u;
+              }
+              if (!placed) atomicAdd(C.overflow, 1ull);
+              continue;
+            }
+            if (key == k0) { a0 += cw * w; newer0 = true; continue; }                        // :817
+            if (key == k1) { a1 += cw * w; newer0 = false; continue; }
+            // another id: the older of the two leaves the registers, this one is looked up (or entered) in the table
+            if (newer0) { if (k1 != kCryptoEmpty) Wt[s1] = a1; } else { if (k0 != kCryptoEmpty) Wt[s0] = a0; }
             uint32_t sl = crypto_first_slot(key, SL);
             bool placed = false;
             for (uint32_t i = 0; i < SL && !placed; ++i) {
               const uint32_t cur = K[sl];
               if (cur == kCryptoEmpty) K[sl] = key;
-              if (cur == kCryptoEmpty || cur == key) { Wt[sl] += cw * w; placed = true; }    // :817
+              if (cur == kCryptoEmpty || cur == key) placed = true;
               else sl = sl + 1u == SL ? 0u : sl + 1u;
             }
-            if (!placed) atomicAdd(C.overflow, 1ull);
+            if (!placed) { atomicAdd(C.overflow, 1ull); if (newer0) k1 = kCryptoEmpty; else k0 = kCryptoEmpty; continue; }
+            const float acc = Wt[sl] + cw * w;
+            if (newer0) { k1 = key; s1 = sl; a1 = acc; newer0 = false; } else { k0 = key; s0 = sl; a0 = acc; newer0 = true; }
           }
         }
+        if (k0 != kCryptoEmpty) Wt[s0] = a0;
+        if (k1 != kCryptoEmpty) Wt[s1] = a1;
         s_tot[threadIdx.x] = total;
       }
       __syncthreads();
@@ -334,6 +363,9 @@ __global__ __launch_bounds__(128) void crypto_direct_tile_kernel(CryptoDev C, Vi
           const uint32_t j = i / QL, sl = (i - j * QL) * 4;
           const uint64_t at = ((uint64_t)c * C.np + s_pix[j]) * SL + sl;
           const uint32_t *sk = s_k + j * SP + sl; const float *sw = s_wt + j * SP + sl;
+          // (straight after a clear the table holds "free" everywhere already: four free slots need not be written again --
+          // most of a pixel's sixteen are, and the lines this kernel writes are half of what it moves)
+          if (kCleared && (sk[0] & sk[1] & sk[2] & sk[3]) == kCryptoEmpty) continue;
           *reinterpret_cast<uint4 *>(C.keys + at) = make_uint4(sk[0], sk[1], sk[2], sk[3]);
           *reinterpret_cast<float4 *>(C.wts + at) = make_float4(sw[0], sw[1], sw[2], sw[3]);
         }
@@ -599,7 +631,9 @@ static int crypto_enqueue_direct(lentil_hip_ctx *ctx, hipStream_t st) {
     const char *force = getenv("LENTIL_CRYPTO_TILE");
     if (lds <= 64 * 1024 && !(force && force[0] == '0')) {
       const uint64_t n_tiles = (ctx->V.n / M + T.tp - 1) / T.tp;
-      const uint64_t max_blocks = (uint64_t)ctx->num_cu * 16;
+      // (LENTIL_CRYPTO_TILE_BLOCKS: blocks per CU of the launch -- the kernel walks the tiles with its grid's stride)
+      static const int tile_blocks = getenv("LENTIL_CRYPTO_TILE_BLOCKS") ? atoi(getenv("LENTIL_CRYPTO_TILE_BLOCKS")) : 0;
+      const uint64_t max_blocks = (uint64_t)ctx->num_cu * (uint64_t)(tile_blocks >= 1 && tile_blocks <= 64 ? tile_blocks : ctx->crypto_tile_blocks);
       // which visits the pass redistributed: from its work lists (LENTIL_CRYPTO_FLAGS=0: decided again from the columns)
       static const bool use_flags = !(getenv("LENTIL_CRYPTO_FLAGS") && getenv("LENTIL_CRYPTO_FLAGS")[0] == '0');
       if (use_flags && ctx->V.n <= 0xFFFFFFFFull) {

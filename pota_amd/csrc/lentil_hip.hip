@@ -143,6 +143,7 @@ struct lentil_hip_ctx {
   int scan_cus_pct = 84;                     // (100 / 92 / 84 / 76: 2.10 / 2.12 / 2.02 / 2.04 ms, means of four runs of 60 steps on one box)
   int scan_cus_pct_multi = 100;              // ... for frames with extra AOV columns (scan_dma_multi_kernel): LENTIL_SCAN_CUS_PCT_MULTI
   unsigned last_scan_skipped = 0;             // blocks of the last scan launch that left at once (scan_dma2_kernel, ScanArgs::skip_blocks)
+  int crypto_tile_blocks = 16;               // blocks per CU of crypto_direct_tile_kernel (LENTIL_CRYPTO_TILE_BLOCKS)
   bool predict = true;
   uint64_t predict_max_draws = 1536;         // LENTIL_PREDICT_MAX_DRAWS: mean draws per item up to which a pass sizes first batches from the model
   float4 *d_bm_land = nullptr;

@@ -36,7 +36,8 @@ def timed(ctx, reps=5):
     return best * 1e3
 
 
-for n_crypto in (0, -1, 1, 3):
+ONLY = os.environ.get("LENTIL_CRYPTO_RATE_ONLY")         # e.g. "0,1": just those variants (for a kernel trace of one of them)
+for n_crypto in ([int(x) for x in ONLY.split(",")] if ONLY else (0, -1, 1, 3)):
     ctx = capi.Context(0); ctx.set_params(p); ctx.set_lens(table); ctx.alloc_frame(1)
     ctx.bind_visits(visits, kv)
     if n_crypto < 0:
