@@ -1909,12 +1909,12 @@ struct PublishArgs {
   uint64_t stuck_ticks;    // how long a wave waits for a queue slot before it declares the pass stuck (100 MHz ticks; 0: kStuckTicks)
 };
 
-// (At most 64 VGPRs: a publisher wave must fit into what a CU has left beside two resident solve blocks and a scanning block --
-// 512 - 2 x 168 - 96 = 80 registers per SIMD lane -- whichever of the pass's kernels the dispatcher places first; with the
-// first-batch model's blend inlined the kernel took 108, and a pass whose publishers found no room anywhere waited for them
-// until its time-out: the odd stalled pass of round 5's first sessions.  The publishers are latency-bound on their atomics:
-// spilling a few values costs them nothing that shows.)
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8))) void publish_kernel(PublishArgs a) {
+// (At most 96 VGPRs: a publisher wave must fit into what a CU has left beside two resident solve blocks and a scanning block --
+// 512 - 2 x 168 - 80 = 96 registers per SIMD lane -- whichever of the pass's kernels the dispatcher places first; with the
+// first-batch model's blend inlined the kernel took 108, i.e. 112, and a pass whose publishers found no room anywhere waited
+// for them until its time-out: the odd stalled pass of round 5's first sessions.  Capped at 64 it spilt 45 registers into
+// the blend's inner loop and the publishers fell 0.3 ms behind the scan: the first round then ended 0.14 ms later.)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5))) void publish_kernel(PublishArgs a) {
   LENTIL_TL_SPAN(SPAN_PUBLISH);
   const uint32_t lane = threadIdx.x;
   while (true) {
@@ -1960,7 +1960,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8))) void pu
         while (todo) {
           const int j = __builtin_ctzll(todo);
           todo &= todo - 1ull;
-          const float x = __shfl(cs[0], j), y = __shfl(cs[1], j), z = __shfl(cs[2], j);
+          // (read as scalars: the cell, its eight node indices and weights then live in SGPRs, not in sixteen VGPRs)
+          const float x = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cs[0]), j));
+          const float y = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cs[1]), j));
+          const float z = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cs[2]), j));
           const BatchEstimate e = batch_estimate(a.S.model, x, y, z, lane);
           if ((int)lane == j) count = batch_from_estimate(e, samples, (uint32_t)a.S.retries, count, a.S.model.margin16);
         }
