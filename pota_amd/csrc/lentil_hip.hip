@@ -1873,7 +1873,7 @@ static int launch_scan(lentil_hip_ctx *ctx, const ScanPlan &pl, const lentil_hip
 // ---- first batches from the lens and the frame (lentil_batch_model.h) ---------------------------------------------
 // The calibration: bm_nx x bm_ny x bm_nz targets over the frame's field of view and inverse
 // depths from infinity to a quarter of the focus distance, kBmK aperture points each, on the context's stream ahead of the
-// pass that first needs it (~0.4 M traces through the table interpreter: a few milliseconds, once per camera set-up).
+// pass that first needs it (~0.43 M traces through the table interpreter: ~11 ms, once per camera set-up).
 static int ensure_batch_model(lentil_hip_ctx *ctx) {
   if (ctx->bm_valid) return LENTIL_OK;
   const lentil_params &P = ctx->P;
