@@ -235,6 +235,10 @@ int lentil_hip_abi_version(void);
 int lentil_hip_create(int device, lentil_hip_ctx **out_ctx);
 int lentil_hip_destroy(lentil_hip_ctx *ctx);
 const char *lentil_hip_last_error(const lentil_hip_ctx *ctx);
+/* Diagnostics, no counterpart in the reference: why the last streamed pass of this context that was redone the chunked way
+ * (lentil_counters::fallback_chunks) gave up -- which buffer bound or which waiting wave, with the pass's sizes.  "" if none
+ * was.  The redo is invisible in the results (the frame is the reference's either way); it costs time. */
+const char *lentil_hip_last_redo_note(const lentil_hip_ctx *ctx);
 
 /* --- setup (once per render) -------------------------------------------------------
  * set_params : Camera::get_lentil_camera_params + camera_model_specific_setup results

@@ -14,7 +14,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("LENTIL_HIP_LIB") or os.path.join(_PKG, "liblentil_hip.so")   # override: A/B runs of two builds
 
 EXPORTS = [
-    "lentil_hip_abi_version", "lentil_hip_create", "lentil_hip_destroy", "lentil_hip_last_error",
+    "lentil_hip_abi_version", "lentil_hip_create", "lentil_hip_destroy", "lentil_hip_last_error", "lentil_hip_last_redo_note",
     "lentil_hip_set_params", "lentil_hip_set_lens", "lentil_hip_set_bokeh", "lentil_hip_alloc_frame", "lentil_hip_set_camera_motion", "lentil_hip_set_camera_shutter",
     "lentil_hip_upload_visits", "lentil_hip_bind_visits", "lentil_hip_clear_frame",
     "lentil_hip_redistribute", "lentil_hip_resolve", "lentil_hip_sync", "lentil_hip_download_aov",
@@ -71,6 +71,7 @@ def load_library():
         "lentil_hip_create": (i, [i, C.POINTER(vp)]),
         "lentil_hip_destroy": (i, [vp]),
         "lentil_hip_last_error": (C.c_char_p, [vp]),
+        "lentil_hip_last_redo_note": (C.c_char_p, [vp]),
         "lentil_hip_set_params": (i, [vp, C.POINTER(_abi.Params)]),
         "lentil_hip_set_lens": (i, [vp, C.POINTER(_abi.LensTable)]),
         "lentil_hip_set_bokeh": (i, [vp, C.POINTER(_abi.BokehTable)]),
@@ -466,6 +467,10 @@ class Context:
         s = C.c_void_p()
         self._chk(self.lib.lentil_hip_stream(self.h, C.byref(s)))
         return s.value
+
+    def last_redo_note(self):
+        """Why the last streamed pass that was redone the chunked way gave up ("" if none was)."""
+        return (self.lib.lentil_hip_last_redo_note(self.h) or b"").decode()
 
     def counters(self):
         c = _abi.Counters()

@@ -23,7 +23,16 @@
 // =======================================================================================
 // host side
 // =======================================================================================
+// LENTIL_HOST_TRACE=n: host time stamps of the first n passes' calls, printed by lentil_hip_sync (development aid: where a
+// step's time goes between the device's last kernel and its next first one)
+struct HostTrace {
+  std::vector<std::pair<const char *, int64_t>> marks;
+  int passes_left = -1;
+};
+static int host_trace_passes() { static const int n = getenv("LENTIL_HOST_TRACE") ? atoi(getenv("LENTIL_HOST_TRACE")) : 0; return n; }
+
 struct lentil_hip_ctx {
+  HostTrace trace;
   int device = 0;
   hipStream_t stream = nullptr;
   hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -183,6 +192,7 @@ struct lentil_hip_ctx {
   uint64_t n_streamed = 0;
   int last_rounds = 0;
   uint32_t last_blind = 0, last_fallback = 0;
+  std::string redo_note;                     // why the last streamed pass that was redone gave up (lentil_hip_last_redo_note)
   uint32_t last_scan_launches = 0;
   // rows that may be non-zero since the last clear_frame (only trusted when dirty_known)
   int32_t dirty_lo = 0, dirty_hi = 0;
@@ -268,6 +278,23 @@ static int fail(lentil_hip_ctx *ctx, int code, const std::string &msg) {
   } while (0)
 #define CHECK_CTX(ctx) \
   if (!(ctx)) return fail(nullptr, LENTIL_ERR_INVALID, "null context")
+
+static inline void ht_mark(lentil_hip_ctx *ctx, const char *what) {
+  if (!host_trace_passes()) return;
+  if (ctx->trace.passes_left < 0) ctx->trace.passes_left = host_trace_passes();
+  if (ctx->trace.passes_left == 0) return;
+  ctx->trace.marks.emplace_back(what, (int64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(
+                                          std::chrono::steady_clock::now().time_since_epoch()).count());
+}
+static void ht_dump(lentil_hip_ctx *ctx) {
+  if (!host_trace_passes() || ctx->trace.marks.empty()) return;
+  const int64_t t0 = ctx->trace.marks.front().second;
+  fprintf(stderr, "[host trace]");
+  for (const auto &m : ctx->trace.marks) fprintf(stderr, " %s %.1f", m.first, (double)(m.second - t0) * 1.0e-3);
+  fprintf(stderr, " (us; epoch %.1f)\n", (double)t0 * 1.0e-3);
+  ctx->trace.marks.clear();
+  if (ctx->trace.passes_left > 0) --ctx->trace.passes_left;
+}
 
 static double host_ipow(double x, int e) {   // lens_ipow, src/lens.h:226-233
   if (e == 0) return 1.0;
@@ -585,6 +612,10 @@ LENTIL_API int lentil_hip_destroy(lentil_hip_ctx *ctx) {
 
 LENTIL_API const char *lentil_hip_last_error(const lentil_hip_ctx *ctx) {
   return ctx ? ctx->err.c_str() : g_err.c_str();
+}
+
+LENTIL_API const char *lentil_hip_last_redo_note(const lentil_hip_ctx *ctx) {
+  return ctx ? ctx->redo_note.c_str() : "";
 }
 
 static uint64_t fnv1a(const void *data, size_t n, uint64_t h = 0xcbf29ce484222325ull) {
@@ -1136,6 +1167,8 @@ LENTIL_API int lentil_hip_upload_visits(lentil_hip_ctx *ctx, const lentil_visits
 
 LENTIL_API int lentil_hip_clear_frame(lentil_hip_ctx *ctx) {
   CHECK_CTX(ctx);
+  if (!ctx->trace.marks.empty()) { ht_mark(ctx, "next_clear"); ht_dump(ctx); }
+  ht_mark(ctx, "clear{");
   ctx->resolved_valid = false;         // (what an early resolve left in d_resolved no longer describes the frame)
   if (!ctx->have_frame) return fail(ctx, LENTIL_ERR_INVALID, "no frame allocated");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -1170,6 +1203,7 @@ LENTIL_API int lentil_hip_clear_frame(lentil_hip_ctx *ctx) {
   ctx->dirty_lo = ctx->dirty_hi = 0;
   ctx->dirty_known = true;      // clean frame: nothing is dirty
   ctx->pass_pending = false;
+  ht_mark(ctx, "}clear");
   return LENTIL_OK;
 }
 
@@ -2047,6 +2081,7 @@ static int redistribute_streamed(lentil_hip_ctx *ctx, bool *streamed) {
 
   unsigned scan_blocks = 0;
   const auto pass_t0 = std::chrono::steady_clock::now();
+  ht_mark(ctx, "first_launch");
   const bool calibrates_now = ctx->predict && !ctx->bm_valid;       // (this pass's host time holds the calibration kernel's)
   // the first-batch model's calibration, should the camera set-up have changed: on the main stream, ahead of the event the
   // publishers (who read the table) wait for
@@ -2212,19 +2247,39 @@ static int redistribute_streamed(lentil_hip_ctx *ctx, bool *streamed) {
     HIP_TRY(ctx, hipEventRecord(ctx->ev_round, ch.stream));
     // (LENTIL_INJECT_STALL stalls the second round's resident solve waves: that pass keeps its second round in flight)
     const bool lean_pass = (extend || predicted) && ctx->lean_tail && ctx->lean_ok && blind_rounds <= 2 && !da.inject_stall;
+    // (lean tail: no next round's solve waves share the CUs with the first accept -- a block per item, as many as fit)
+    unsigned accept1_blocks = accept_blocks;
+    if (lean_pass) {
+      static const int lean_blocks = getenv("LENTIL_ACCEPT_LEAN_BLOCKS") ? atoi(getenv("LENTIL_ACCEPT_LEAN_BLOCKS")) : 5;
+      const uint64_t m = (uint64_t)ctx->num_cu * (uint64_t)(lean_blocks < 1 ? 1 : (lean_blocks > 6 ? 6 : lean_blocks));
+      const unsigned b = (unsigned)(acc_want > m ? m : acc_want);
+      if (b > accept1_blocks) accept1_blocks = b;
+    }
+    const bool resolves_early = ctx->early_resolve && ctx->F.dir && ctx->F.touched && ctx->n_chunks >= 2 && !ctx->comm && !ctx->closest_deferred;
+    // Lean tail: the frame's resolve does not wait for the first accept.  The whole frame is resolved behind the scan -- the
+    // pixels' own sums are complete then, the HBM is idle and the solve waves do not need it --, the groups of pixels the
+    // first accept's draws land in are resolved again behind it (about half of a headline frame's groups: half the bytes
+    // of the whole frame, which used to stand there), the few groups of the last accept once more at the end.
+    static const bool after_scan_env = !(getenv("LENTIL_RESOLVE_AFTER_SCAN") && getenv("LENTIL_RESOLVE_AFTER_SCAN")[0] == '0');
+    const bool resolve_after_scan = lean_pass && resolves_early && after_scan_env;
+    if (resolve_after_scan) {
+      hipStream_t rs = ctx->chunks[1].stream;
+      HIP_TRY(ctx, hipStreamWaitEvent(rs, ctx->scans_done, 0));
+      if ((rc = launch_resolve_half(ctx, rs, 0u))) return rc;
+    }
     {
       DrawArgs d0 = da;
       d0.emit_live = lean_pass ? 0 : 1;       // (lean tail: nobody is waiting for tasks)
       d0.lean_defer = lean_pass ? 1 : 0;
       d0.end_tasks = (uint32_t)ctx->num_cu * 4u;
-      hipLaunchKernelGGL(accept_kernel<1>, dim3(accept_blocks), dim3(256), 0, ch.stream, d0);
+      hipLaunchKernelGGL(accept_kernel<1>, dim3(accept1_blocks), dim3(256), 0, ch.stream, d0);
       HIP_TRY(ctx, hipGetLastError());
     }
     HIP_TRY(ctx, hipEventRecord(ctx->ev_acc1, ch.stream));
-    if (ctx->early_resolve && ctx->F.dir && ctx->F.touched && ctx->n_chunks >= 2 && !ctx->comm && !ctx->closest_deferred) {
+    if (resolves_early) {
       hipStream_t rs = ctx->chunks[1].stream;
       HIP_TRY(ctx, hipStreamWaitEvent(rs, ctx->ev_acc1, 0));
-      if ((rc = launch_resolve_half(ctx, rs, 0u))) return rc;
+      if ((rc = launch_resolve_half(ctx, rs, resolve_after_scan ? 1u : 0u))) return rc;
       HIP_TRY(ctx, hipEventRecord(ctx->ev_res, rs));
       ctx->early_resolve_pending = true;
     }
@@ -2248,11 +2303,12 @@ static int redistribute_streamed(lentil_hip_ctx *ctx, bool *streamed) {
       da.slow_indirect = 0; da.slow_cap = slow_cap_all; da.slow_live = 0;
       if (ctx->early_resolve_pending) {
         HIP_TRY(ctx, hipStreamWaitEvent(ls, ctx->ev_res, 0));
-        if ((rc = launch_resolve_half(ctx, ls, 1u))) return rc;
+        if ((rc = launch_resolve_half(ctx, ls, 2u))) return rc;
         ctx->late_resolve_done = true;
       }
       tail = ls;
     } else {
+    static const bool overlap_accept = getenv("LENTIL_OVERLAP_ACCEPT") && getenv("LENTIL_OVERLAP_ACCEPT")[0] == '1';
     for (int round = 1; round < blind_rounds; ++round) {
       da.parity = round & 1; da.round = round;
       DrawArgs d1 = da;
@@ -2265,7 +2321,15 @@ static int redistribute_streamed(lentil_hip_ctx *ctx, bool *streamed) {
         d1.producers_total = accept_blocks;
         d1.slow = slow_base + slow_cap_all / 2u;
         d1.slow_cap = slow_cap_all - slow_cap_all / 2u - d1.slow_waves;
-        HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_round, 0));
+        // Round 5: the second round's resident solve and straggler kernels start BEHIND the first accept, not beside it.  Beside
+        // it they were waiting -- holding registers and LDS -- for end markers that the accept's LAST block writes, and about one
+        // such pass in 25 found only an eighth (or seven eighths) of the accept's blocks ever begun: whole XCDs' shares of the
+        // grid stayed undispatched until the waiting waves gave up (250 ms, then the redo; lentil_hip_last_redo_note: "accept
+        // blocks done 64 begun 64" of 512).  The blocks that did run had served every item, so nothing was wrong but the wait.
+        // A kernel of a pass may spin only on kernels that hold all the resources they will ever need.  What this costs is the
+        // head start of the second round's solves (~0.1 ms of a pass that has a second round at all; the lean tail has none).
+        // LENTIL_OVERLAP_ACCEPT=1: beside it, as rounds 3 and 4 had it.
+        HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, overlap_accept ? ctx->ev_round : ctx->ev_acc1, 0));
         launch_solve_po<true>(ctx, d1, ctx->stream, (unsigned)ctx->num_cu);
       } else {
         d1.producers_done = nullptr; d1.producers_total = 0;
@@ -2279,7 +2343,7 @@ static int redistribute_streamed(lentil_hip_ctx *ctx, bool *streamed) {
       if (round == 1) {
         // (on a stream of its own: the first round's straggler kernel, ahead of everything on `ps`, is at work for another
         // ~0.25 ms -- its last records come when A ends -- and this round's parked solves need not wait for it)
-        HIP_TRY(ctx, hipStreamWaitEvent(ctx->slow1_stream, ctx->ev_round, 0));
+        HIP_TRY(ctx, hipStreamWaitEvent(ctx->slow1_stream, overlap_accept ? ctx->ev_round : ctx->ev_acc1, 0));
         hipLaunchKernelGGL(solve_slow_kernel, dim3(d1.slow_waves), dim3(64), 0, ctx->slow1_stream, d1);
         HIP_TRY(ctx, hipEventRecord(ctx->ev_slow1, ctx->slow1_stream));
         HIP_TRY(ctx, hipStreamWaitEvent(ps, ctx->ev_slow, 0));      // the first round's stragglers (publishers' stream)
@@ -2302,7 +2366,7 @@ static int redistribute_streamed(lentil_hip_ctx *ctx, bool *streamed) {
     da.slow_live = 0;
     if (ctx->early_resolve_pending) {
       HIP_TRY(ctx, hipStreamWaitEvent(ps, ctx->ev_res, 0));
-      if ((rc = launch_resolve_half(ctx, ps, 1u))) return rc;
+      if ((rc = launch_resolve_half(ctx, ps, 2u))) return rc;
       ctx->late_resolve_done = true;
     }
     tail = ps;
@@ -2399,13 +2463,15 @@ static int redistribute_streamed(lentil_hip_ctx *ctx, bool *streamed) {
     // the resolve's second half behind the last accept enqueued blind (should the host have to add rounds, or redo
     // the draws, lentil_hip_redistribute runs it once more)
     HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_res, 0));
-    if ((rc = launch_resolve_half(ctx, ctx->stream, 1u))) return rc;
+    if ((rc = launch_resolve_half(ctx, ctx->stream, 2u))) return rc;
     ctx->late_resolve_done = true;
   }
   }
   const int C = ctx->n_chunks;
+  ht_mark(ctx, "all_launched");
   HIP_TRY(ctx, hipMemcpyAsync(ctx->h_ctr_pinned, ctx->d_ctr, sizeof(DevCounters) * C, hipMemcpyDeviceToHost, tail));
   HIP_TRY(ctx, hipStreamSynchronize(tail));
+  ht_mark(ctx, "tail_synced");
   {
     // (host time from the pass's first launch to its counters: an upper bound of every wait inside it)
     const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - pass_t0).count();
@@ -2423,6 +2489,25 @@ static int redistribute_streamed(lentil_hip_ctx *ctx, bool *streamed) {
   const DevCounters c = ctx->h_ctr[0];
   ch.was_blind = true;
   if (c.fallback || c.stuck) {
+    {
+      // what made the pass give up, kept for lentil_hip_last_redo_note(): `fallback` bits 1 items, 2 result pool, 4 task queue,
+      // 8 a wave's pending flushes, 16 range queue, 32 the blind preparation's bounds; `stuck` = (ticket << 2) | who waited (1 a
+      // publisher, 2 a resident solve wave, 3 a straggler wave)
+      char note[768];
+      snprintf(note, sizeof note,
+               "epoch %u: fallback 0x%llx stuck 0x%x (timeout %.0f ms)%s%s | items %llu/%u tasks %u/%u pool %llu/%llu ranges %u/%u | "
+               "scan blocks done %u publishers done %u rounds_used %llu | first batches %s, margin16 %u, blind passes before %u | "
+               "the wave that gave up: round %u parity %u, its queue's n_tasks %u head %u, accept blocks done %u begun %u, slot word 0x%x (epoch tag 0x%x), block %u",
+               ctx->epoch, (unsigned long long)c.fallback, c.stuck, (double)stuck_ticks * 1.0e-5,
+               c.stuck ? " waited: " : "", c.stuck ? ((c.stuck & 3u) == 1 ? "publisher" : (c.stuck & 3u) == 2 ? "resident solve wave" : "straggler wave") : "",
+               (unsigned long long)c.work_count, pub.item_cap, c.n_tasks[0], pub.task_cap, (unsigned long long)c.pool_used[0],
+               (unsigned long long)pub.pool_cap, c.n_ranges, plan.sa.range_cap, c.scan_blocks_done, c.publishers_done,
+               (unsigned long long)c.rounds_used, predicted ? "modelled" : "plain", ctx->bm_margin16, ctx->last_blind - 1u,
+               c.stuck_info[0], c.stuck_info[1], c.stuck_info[2], c.stuck_info[7], c.stuck_info[3], c.stuck_info[4], c.stuck_info[5],
+               c.stuck_info[5] >> kTaskTagShift, c.stuck_info[6]);
+      ctx->redo_note = note;
+      if (getenv("LENTIL_STREAM_DEBUG")) fprintf(stderr, "[stream] note: %s\n", note);
+    }
     if (getenv("LENTIL_STREAM_DEBUG"))
       fprintf(stderr, "[stream] redo: who %u ticket %u epoch %u range_head %u pubs_done %u scan_done %u | fallback %llu stuck %u | items %llu (cap %u) tasks %u (cap %u) pool %llu (cap %llu) ranges %u (cap %u)\n",
               c.stuck & 3u, c.stuck >> 2, ctx->epoch, c.range_head, c.publishers_done, c.scan_blocks_done, c.fallback, c.stuck, c.work_count, pub.item_cap, c.n_tasks[0], pub.task_cap, c.pool_used[0], (unsigned long long)pub.pool_cap,
@@ -2689,7 +2774,9 @@ LENTIL_API int lentil_hip_redistribute(lentil_hip_ctx *ctx) {
     const int rc0 = lentil_hip_set_draw_log(ctx, ctx->closest_auto_log_cap);
     if (rc0) return rc0;
   }
+  ht_mark(ctx, "pass{");
   int rc = redistribute_impl(ctx);
+  ht_mark(ctx, "}pass");
   if (rc || !ctx->degenerate_seen) return rc;
   // ---- candidates at depth 0 / NaN compete for a closest-filtered AOV: their pixels are replayed in visit order
   if (ctx->comm || ctx->closest_deferred)
@@ -2949,7 +3036,7 @@ static int redistribute_pass(lentil_hip_ctx *ctx) {
     if (ctx->F.dir && ctx->F.touched && !ctx->last_fallback) {
       if (!ctx->late_resolve_done) {
         HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_res, 0));
-        const int rc = launch_resolve_half(ctx, ctx->stream, 1u);
+        const int rc = launch_resolve_half(ctx, ctx->stream, 2u);
         if (rc) return rc;
       }
       ctx->resolved_valid = true;
@@ -3035,6 +3122,7 @@ static int resolve_range(lentil_hip_ctx *ctx, uint64_t p_begin, uint64_t p_end) 
 }
 
 // one half of a whole-frame resolve on `st`: everything (only_touched = 0) or the groups that received draws
+// only_touched: 0 the whole frame; 1 / 2 the 64-pixel groups whose splat flag is at least that (1: any round's draws, 2: a later round's)
 static int launch_resolve_half(lentil_hip_ctx *ctx, hipStream_t st, uint32_t only_touched) {
   const size_t lds = (size_t)4 * 64 * ctx->F.stride * sizeof(float);
   if (only_touched) {
@@ -3042,7 +3130,7 @@ static int launch_resolve_half(lentil_hip_ctx *ctx, hipStream_t st, uint32_t onl
     uint64_t blocks = (chunks + 3) / 4;
     const uint64_t max_blocks = (uint64_t)ctx->num_cu * 8;
     if (blocks > max_blocks) blocks = max_blocks;
-    hipLaunchKernelGGL(resolve_touched_kernel, dim3((unsigned)blocks), dim3(256), lds, st, ctx->F, ctx->d_resolved);
+    hipLaunchKernelGGL(resolve_touched_kernel, dim3((unsigned)blocks), dim3(256), lds, st, ctx->F, ctx->d_resolved, only_touched);
   } else {
     // (few waves per CU: the second round's solves and parked solves are a chain of latencies on the same SIMDs, and
     // this kernel has that whole round to finish in)
@@ -3060,6 +3148,7 @@ static int launch_resolve_half(lentil_hip_ctx *ctx, hipStream_t st, uint32_t onl
 LENTIL_API int lentil_hip_resolve(lentil_hip_ctx *ctx) {
   CHECK_CTX(ctx);
   if (!ctx->have_frame) return fail(ctx, LENTIL_ERR_INVALID, "no frame allocated");
+  ht_mark(ctx, "resolve");
   if (ctx->resolved_valid) {          // the pass resolved the frame on its way (nothing has touched it since)
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
@@ -3304,7 +3393,10 @@ LENTIL_API int lentil_hip_touched_rows(lentil_hip_ctx *ctx, int32_t *row_lo, int
 LENTIL_API int lentil_hip_sync(lentil_hip_ctx *ctx) {
   CHECK_CTX(ctx);
   HIP_TRY(ctx, hipSetDevice(ctx->device));
+  ht_mark(ctx, "sync{");
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  ht_mark(ctx, "}sync");
+  ht_dump(ctx);
   return LENTIL_OK;
 }
 

@@ -55,6 +55,10 @@ struct DevCounters {
   // markers / tasks and items the solve waves added themselves
   unsigned int items_open, queue_final, ext_tasks, ext_items;
   unsigned int ext_n, ext_head, pad2_[2];        // the extension's own task queue (DrawArgs::ext_q): tasks appended / tickets drawn
+  // diagnostics of a stall (lentil_hip_last_redo_note): accept blocks that have begun, per round parity; what the wave that
+  // gave up first saw -- round, parity, the queue's n_tasks, accept_done[0], accept_started[0], its slot's tag word, block
+  unsigned int accept_started[2];
+  unsigned int stuck_info[8];
 };
 
 // per-thread running row range -> one pair of atomics per wave
@@ -436,7 +440,10 @@ LD_DEV void publish_item(const lentil_params &P, const VisitsDev &V, const Strea
   const uint32_t tb = atomicAdd(&ctr->n_tasks[0], nt * nch);
   const bool ok = item < S.item_cap && off + (unsigned long long)reserve * nch <= S.pool_cap &&
                   (unsigned long long)tb + nt * nch <= S.task_cap;
-  if (!ok) ctr->fallback = 1ull;
+  // (which bound it was, for lentil_hip_last_redo_note: 1 items, 2 result pool, 4 task queue)
+  if (!ok) atomicOr(&ctr->fallback, (item < S.item_cap ? 0ull : 1ull) |
+                                    (off + (unsigned long long)reserve * nch <= S.pool_cap ? 0ull : 2ull) |
+                                    ((unsigned long long)tb + nt * nch <= S.task_cap ? 0ull : 4ull));
   if (item < S.item_cap) {
     const uint32_t v = wi.x;
     int px, py;
@@ -512,7 +519,7 @@ struct WaveQueue {
       if (a.ranges) {
         atomicAdd(&a.ctr->n_active[0], n);
         if (n_pend < kWavePending) q[kWaveQueue + n_pend] = make_uint2((uint32_t)base, n);
-        else a.ctr->fallback = 1ull;       // (a flush holds more than 64 entries, a tile fewer than 16 x 64 visits)
+        else atomicOr(&a.ctr->fallback, 8ull);   // (a flush holds more than 64 entries, a tile fewer than 16 x 64 visits)
       }
     }
     if (a.ranges && n_pend < kWavePending) ++n_pend;
@@ -560,7 +567,7 @@ struct WaveQueue {
       if (k + lane < a.range_cap)
         st_agent64(a.ranges + k + lane, (uint64_t)pr.x | ((uint64_t)(pr.y | (a.epoch << kTaskTagShift)) << 32));
       else
-        a.ctr->fallback = 1ull;
+        atomicOr(&a.ctr->fallback, 16ull);
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
     __builtin_amdgcn_wave_barrier();
@@ -2224,7 +2231,7 @@ __global__ __launch_bounds__(256) void prep_items_kernel(DrawArgs a) {
     const uint64_t units = nch * (4ull * sum_samples + (uint64_t)(3 * a.retries + 32) * n);
     const uint64_t tasks = units / 64 + 2 * n + 64;
     if (n > a.n_items || units > a.pool_cap || tasks > a.task_cap) {
-      if (i == 0) { a.ctr->fallback = 1ull; a.ctr->n_active[0] = 0u; }
+      if (i == 0) { a.ctr->fallback = 32ull; a.ctr->n_active[0] = 0u; }
       return;
     }
     n_items = n;
@@ -2543,7 +2550,12 @@ __global__ __launch_bounds__(256) LENTIL_SOLVE_ATTR void solve_po_kernel(DrawArg
             if (lane == 0) tl_add(TL_POLLS_EMPTY, 1u);
             // nothing there (yet): back to the solves in flight (an idle wave naps, below)
             if (__builtin_amdgcn_s_memrealtime() - ticket_t0 > (a.stuck_ticks ? a.stuck_ticks : kStuckTicks)) {
-              if (lane == 0) atomicCAS(&a.ctr->stuck, 0u, 2u | (ticket << 2));      // the host redoes the pass chunk by chunk
+              if (lane == 0 && atomicCAS(&a.ctr->stuck, 0u, 2u | (ticket << 2)) == 0u) {      // the host redoes the pass chunk by chunk
+                unsigned int *si = a.ctr->stuck_info;
+                si[0] = (uint32_t)a.round; si[1] = par; si[2] = ld_coherent32(&a.ctr->n_tasks[par]);
+                si[3] = ld_coherent32(&a.ctr->accept_done[0]); si[4] = ld_coherent32(&a.ctr->accept_started[0]);
+                si[5] = w1_hi; si[6] = blockIdx.x; si[7] = ld_coherent32(&a.ctr->task_head[par]);
+              }
               no_more = true;
             }
             break;
@@ -3028,7 +3040,10 @@ struct AcceptShared {
   uint32_t cnt[4][64];                      // draws of this wave step on the same pixel, at the first of them (0 at the others)
   float val[4 * LENTIL_MAX_AOVS + 1];      // what one accepted draw of the item adds, float by float
   uint32_t off[4 * LENTIL_MAX_AOVS + 1];   // ... and where inside the pixel record
-  uint32_t rwin[3][256 + 64];              // R(n .. n + 255 + retries) of the step, per wavelength channel (stage_results)
+  // R(n .. n + 255 + retries) of the step, per wavelength channel (stage_results): accept_item / accept_item_chroma only --
+  // it lies in AcceptWideShared::win, which those forms do not use (3.8 KB less LDS per block: five accept blocks fit a CU
+  // beside a straggler wave's 41 KB, and a headline frame's ~1 200 items are all resident at once)
+  uint32_t (*rwin)[256 + 64];
   uint32_t nunk[4], nsucc1[4];             // accept_item<1, 2>: unknown attempts / mode 1's known successes per wave
 };
 // accept_item<1>: an attempt that met a pending mark is no success (yet); modes 0 and 2 have resolved it
@@ -3852,15 +3867,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LENTIL_ACCE
   __shared__ uint32_t s_item;
   __shared__ AcceptShared sh;
   __shared__ AcceptWideShared ws;
+  static_assert(sizeof(ws.win) >= 3 * (256 + 64) * sizeof(uint32_t), "AcceptShared::rwin lies in AcceptWideShared::win");
+  if (threadIdx.x == 0) sh.rwin = reinterpret_cast<uint32_t (*)[256 + 64]>(ws.win);      // (the loop below begins with a barrier)
 #ifdef LENTIL_ACCEPT_PRIO
   // the accept stands between two rounds of solves: beside the next round's solve and straggler waves its instructions go first
   __builtin_amdgcn_s_setprio(LENTIL_ACCEPT_PRIO);
 #endif
   const uint32_t par = (uint32_t)a.parity, nxt = par ^ 1u;
+  if (threadIdx.x == 0) atomicAdd(&a.ctr->accept_started[par], 1u);
   if (a.lean_gate && a.ctr->n_tasks[par] != 0u) return;       // (tasks nobody has solved yet: DrawArgs::lean_gate)
   // (a streamed or blind pass whose buffers were too small: nothing is accepted, the host redoes the draws)
   const uint32_t n_active = (a.ctr->fallback || a.ctr->stuck) ? 0u : a.ctr->n_active[par];
-  if (blockIdx.x == 0 && threadIdx.x == 0 && n_active) atomicMax(&a.ctr->rounds_used, (unsigned long long)(a.round + 1));
+  // (every block says so, not block 0 alone: a pass that stalls with a part of this grid never begun -- block 0 perhaps among it --
+  // must still know that draws were added, or its recovery adds them a second time)
+  if (threadIdx.x == 0 && n_active) atomicMax(&a.ctr->rounds_used, (unsigned long long)(a.round + 1));
   const uint32_t *res = a.pool[par], *res_prev = a.pool[nxt];
   unsigned long long tot_attempted = 0, tot_accepted = 0;
   uint32_t rmin = 0x7FFFFFFFu, rmax_p1 = 0u;       // rows this thread's accepted draws went to
@@ -4479,9 +4499,10 @@ __global__ __launch_bounds__(256) void resolve_kernel(FrameDev F, float *resolve
 
 // The second half of a resolve that ran early -- behind the pass's first accept, while its later rounds were still
 // adding draws (see lentil_hip_redistribute): just the 64-pixel groups a later round's draw was splatted into (flag 2;
-// the headline frame's first round touches most groups, its second a few hundred).  A wave looks at 64 groups'
-// flags with one load and walks the set bits.
-__global__ __launch_bounds__(256) void resolve_touched_kernel(FrameDev F, float *resolved) {
+// the headline frame's first round touches about half of the groups, its second a few hundred).  A wave looks at 64 groups'
+// flags with one load and walks the set bits.  (min_flag 1: every group that received a draw -- the pass whose whole-frame
+// resolve ran behind the scan, before any accept, see redistribute_streamed.)
+__global__ __launch_bounds__(256) void resolve_touched_kernel(FrameDev F, float *resolved, uint32_t min_flag) {
   LENTIL_TL_SPAN(SPAN_RESOLVE_TOUCHED);
   extern __shared__ float4 s_rec[];
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
@@ -4492,7 +4513,7 @@ __global__ __launch_bounds__(256) void resolve_touched_kernel(FrameDev F, float 
   const uint64_t wave_stride = (uint64_t)gridDim.x * (blockDim.x >> 6);
   for (uint64_t ch = wave_global; ch < n_chunks; ch += wave_stride) {
     const uint64_t g = ch * 64ull + lane;
-    unsigned long long mask = __ballot(g < n_groups && F.touched[g] >= 2);
+    unsigned long long mask = __ballot(g < n_groups && F.touched[g] >= min_flag);
     while (mask) {
       const uint32_t b = (uint32_t)__builtin_ctzll(mask);
       mask &= mask - 1ull;

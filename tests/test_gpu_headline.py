@@ -105,7 +105,7 @@ def _timed_config_vs_oracle(orc, name, W, H, lens, S, n_extra=0, kinds=None, bok
             # (the first pass of a context looks at its scans; with extra AOVs the streamed pass is scan_dma_multi_kernel's,
             # which takes gaussian AOVs only -- closest-filtered ones keep the chunked form, blind from the second pass on)
             want = 1 if (k and not has_closest) else 0
-            assert c.fallback_chunks == 0 and c.streamed == want, (k, c.streamed, c.fallback_chunks)
+            assert c.fallback_chunks == 0 and c.streamed == want, (k, c.streamed, c.fallback_chunks, ctx.last_redo_note())
             seen_streamed += c.streamed
             worst, n_touched = _compare(ctx, refs[i % len(refs)], c, S, n, p, n_aovs=n_aovs, kinds=kinds)
             print("%s, pass %d (%s): %d items, %d accepted draws on %d pixels, max rel err %.2e"
@@ -166,7 +166,7 @@ def test_headline_4k_streamed_vs_oracle(orc):
             ctx.bind_visits(dv, dkeep)
             ctx.clear_frame(); ctx.redistribute(); ctx.resolve(); ctx.sync()
             c = ctx.counters()
-            assert c.streamed == want_streamed and c.fallback_chunks == 0, (i, c.streamed, c.fallback_chunks)
+            assert c.streamed == want_streamed and c.fallback_chunks == 0, (i, c.streamed, c.fallback_chunks, ctx.last_redo_note())
             worst, n_touched = _compare(ctx, refs[i], c, S, n, p)
             print("stream %d %s: %d items, %d accepted draws on %d pixels, max rel err %.2e"
                   % (i, "streamed" if want_streamed else "chunked", c.redistributed_visits, c.accepted_draws, n_touched, worst))
@@ -234,7 +234,7 @@ def test_config4_like_4k_nine_gaussian_aovs_streamed_vs_oracle(orc):
             ctx.bind_visits(*d)
             ctx.clear_frame(); ctx.redistribute(); ctx.resolve(); ctx.sync()
             c = ctx.counters()
-            assert c.streamed == want_streamed and c.fallback_chunks == 0, (c.streamed, c.fallback_chunks)
+            assert c.streamed == want_streamed and c.fallback_chunks == 0, (c.streamed, c.fallback_chunks, ctx.last_redo_note())
             worst, n_touched = _compare(ctx, ref, c, S, n, p, n_aovs=K + 1)
             print("nine AOVs %s: %d items, %d accepted draws on %d pixels, max rel err %.2e"
                   % ("streamed" if want_streamed else "chunked", c.redistributed_visits, c.accepted_draws, n_touched, worst))
