@@ -131,6 +131,7 @@ struct lentil_hip_ctx {
  uint64_t slow_below = 8ull << 20;          // LENTIL_SLOW_BELOW: ... in chunks whose draw sum is below this
  int slow_from_round = 0;                   // LENTIL_SLOW_FROM_ROUND
   int slow_max_lanes = 4;                    // LENTIL_SLOW_MAX_LANES
+  int slow_prio = 0;                         // LENTIL_SLOW_PRIO: instruction priority of the straggler kernel's waves (0-3)
   bool blind = true;                         // LENTIL_BLIND=0: always wait for a chunk's scan before sizing its draw rounds
   uint32_t extra_num = 0, extra_const = 16;  // LENTIL_EXTRA_256THS / LENTIL_EXTRA_CONST: first-batch over-provisioning (16 spare attempts: what a decoupled first accept's guess about its unknown attempts may be off by, accept_item<1>)
   uint64_t extra_below = 8ull << 20;         // LENTIL_EXTRA_BELOW: ... while a chunk's draw sum is below this
@@ -228,6 +229,12 @@ struct lentil_hip_ctx {
   uint32_t visit_id_base = 0;
   DevCounters *d_ctr = nullptr;
   std::vector<DevCounters> h_ctr;    // the chunks' counters as read back at the end of the last (blind) pass
+  DevCounters *d_ctr_host = nullptr;     // the pinned staging block as the device addresses it (report_counters_kernel)
+  uint32_t *h_seq = nullptr;             // ... the sequence number behind its records: the pass whose counters they are
+  uint32_t seq = 0;
+  bool spin_readback = false;            // LENTIL_SPIN_READBACK=1: the counters by a kernel into pinned memory, the host polls a sequence
+                                         // number (measured: 1.992 against 1.993 ms, four runs each on one box -- hipStreamSynchronize
+                                         // already spins; off)
   DevCounters *h_ctr_pinned = nullptr;   // staging for that read-back (pinned: an asynchronous copy at the end of each chunk's stream)
   bool h_ctr_valid = false;
   lentil_draw_record *d_log = nullptr;
@@ -409,7 +416,12 @@ LENTIL_API int lentil_hip_create(int device, lentil_hip_ctx **out_ctx) {
   if (ctx->n_chunks > 16) ctx->n_chunks = 16;
   // one DevCounters per chunk + one shared (draw-log cursor)
   HIP_TRY(ctx, hipMalloc(&ctx->d_ctr, sizeof(DevCounters) * (ctx->n_chunks + 1)));
-  HIP_TRY(ctx, hipHostMalloc((void **)&ctx->h_ctr_pinned, sizeof(DevCounters) * ctx->n_chunks, hipHostMallocDefault));
+  // (+ one record's room behind them for the sequence number of report_counters_kernel)
+  HIP_TRY(ctx, hipHostMalloc((void **)&ctx->h_ctr_pinned, sizeof(DevCounters) * (ctx->n_chunks + 1), hipHostMallocDefault));
+  memset(ctx->h_ctr_pinned, 0, sizeof(DevCounters) * (ctx->n_chunks + 1));
+  ctx->h_seq = reinterpret_cast<uint32_t *>(ctx->h_ctr_pinned + ctx->n_chunks);
+  if (hipHostGetDevicePointer((void **)&ctx->d_ctr_host, ctx->h_ctr_pinned, 0) != hipSuccess) { ctx->d_ctr_host = nullptr; (void)hipGetLastError(); }
+  if (const char *e = getenv("LENTIL_SPIN_READBACK")) ctx->spin_readback = atoi(e) != 0;
   HIP_TRY(ctx, hipMalloc(&ctx->d_dummy, 64 * sizeof(float4)));
   HIP_TRY(ctx, hipMemsetAsync(ctx->d_ctr, 0, sizeof(DevCounters) * (ctx->n_chunks + 1), ctx->stream));
   ctx->chunks.resize(ctx->n_chunks);
@@ -446,6 +458,7 @@ LENTIL_API int lentil_hip_create(int device, lentil_hip_ctx **out_ctx) {
   if (const char *e = getenv("LENTIL_SLOW_BELOW")) ctx->slow_below = strtoull(e, nullptr, 10);
   if (const char *e = getenv("LENTIL_SLOW_FROM_ROUND")) ctx->slow_from_round = atoi(e);
   if (const char *e = getenv("LENTIL_SLOW_MAX_LANES")) ctx->slow_max_lanes = atoi(e);
+  if (const char *e = getenv("LENTIL_SLOW_PRIO")) ctx->slow_prio = atoi(e);
   if (const char *e = getenv("LENTIL_BLIND")) ctx->blind = !(e[0] == '0');
   if (const char *e = getenv("LENTIL_EXTRA_256THS")) ctx->extra_num = (uint32_t)strtoul(e, nullptr, 10);
   if (const char *e = getenv("LENTIL_EXTRA_CONST")) ctx->extra_const = (uint32_t)strtoul(e, nullptr, 10);
@@ -1246,7 +1259,7 @@ static void launch_solve_po(lentil_hip_ctx *ctx, const DrawArgs &da, hipStream_t
 // just to find nothing to do, and hold up this chunk's accept meanwhile)
 static void launch_slow(lentil_hip_ctx *ctx, const DrawArgs &da, hipStream_t st) {
   if (da.P.cameraType == LENTIL_POLYNOMIAL_OPTICS && da.slow && da.round >= da.slow_from_round)
-    hipLaunchKernelGGL(solve_slow_kernel, dim3((unsigned)ctx->num_cu * 4), dim3(64), 0, st, da);
+    hipLaunchKernelGGL(solve_slow_kernel, dim3((unsigned)ctx->num_cu * 4), dim3(64), coop_lds_bytes(ctx->hlens.n_terms), st, da);
 }
 
 static void launch_solve(lentil_hip_ctx *ctx, const DrawArgs &da, hipStream_t st, unsigned blocks) {
@@ -1543,6 +1556,7 @@ static void init_draw_args(lentil_hip_ctx *ctx, DrawArgs &da) {
   da.slow_below = ctx->slow_below;
   da.slow_from_round = ctx->slow_from_round;
   da.slow_max_lanes = ctx->slow_max_lanes;
+  da.slow_prio = ctx->slow_prio;
   da.extra_num = ctx->extra_num; da.extra_const = ctx->extra_const; da.extra_below = ctx->extra_below;
   da.log = ctx->d_log;
   da.log_cap = ctx->log_cap;
@@ -2214,7 +2228,7 @@ static int redistribute_streamed(lentil_hip_ctx *ctx, bool *streamed) {
   HIP_TRY(ctx, hipEventRecord(ctx->pub_done, ctx->pub_stream));
   if (live) {
     // (behind the publishers on their stream: they end with the scan, whose registers this kernel's waves need)
-    hipLaunchKernelGGL(solve_slow_kernel, dim3(da.slow_waves), dim3(64), 0, ctx->pub_stream, da);
+    hipLaunchKernelGGL(solve_slow_kernel, dim3(da.slow_waves), dim3(64), coop_lds_bytes(ctx->hlens.n_terms), ctx->pub_stream, da);
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipEventRecord(ctx->ev_slow, ctx->pub_stream));
   }
@@ -2250,17 +2264,23 @@ static int redistribute_streamed(lentil_hip_ctx *ctx, bool *streamed) {
     // (lean tail: no next round's solve waves share the CUs with the first accept -- a block per item, as many as fit)
     unsigned accept1_blocks = accept_blocks;
     if (lean_pass) {
-      static const int lean_blocks = getenv("LENTIL_ACCEPT_LEAN_BLOCKS") ? atoi(getenv("LENTIL_ACCEPT_LEAN_BLOCKS")) : 5;
-      const uint64_t m = (uint64_t)ctx->num_cu * (uint64_t)(lean_blocks < 1 ? 1 : (lean_blocks > 6 ? 6 : lean_blocks));
-      const unsigned b = (unsigned)(acc_want > m ? m : acc_want);
-      if (b > accept1_blocks) accept1_blocks = b;
+      // (measured, same box, headline: 2 / 4 / 5 blocks per CU -> 2.00 / 2.00-2.24 / 2.08-2.30 ms: with more blocks than the
+      // stragglers' LDS leaves room for, every third run sits in a mode 0.25 ms slower.  The knob stays; the default is round 4's.)
+      static const int lean_blocks = getenv("LENTIL_ACCEPT_LEAN_BLOCKS") ? atoi(getenv("LENTIL_ACCEPT_LEAN_BLOCKS")) : 0;
+      if (lean_blocks >= 1) {
+        const uint64_t m = (uint64_t)ctx->num_cu * (uint64_t)(lean_blocks > 6 ? 6 : lean_blocks);
+        const unsigned b = (unsigned)(acc_want > m ? m : acc_want);
+        if (b > accept1_blocks) accept1_blocks = b;
+      }
     }
     const bool resolves_early = ctx->early_resolve && ctx->F.dir && ctx->F.touched && ctx->n_chunks >= 2 && !ctx->comm && !ctx->closest_deferred;
-    // Lean tail: the frame's resolve does not wait for the first accept.  The whole frame is resolved behind the scan -- the
-    // pixels' own sums are complete then, the HBM is idle and the solve waves do not need it --, the groups of pixels the
-    // first accept's draws land in are resolved again behind it (about half of a headline frame's groups: half the bytes
-    // of the whole frame, which used to stand there), the few groups of the last accept once more at the end.
-    static const bool after_scan_env = !(getenv("LENTIL_RESOLVE_AFTER_SCAN") && getenv("LENTIL_RESOLVE_AFTER_SCAN")[0] == '0');
+    // Lean tail, an option: the frame's resolve does not wait for the first accept.  The whole frame is resolved behind the scan
+    // -- the pixels' own sums are complete then, the HBM is idle and the solve waves do not need it --, the groups of pixels
+    // the first accept's draws land in are resolved again behind it (about half of a headline frame's groups: 86 us where
+    // the whole frame takes 130), the few groups of the last accept once more at the end.
+    // (LENTIL_RESOLVE_AFTER_SCAN=1; off by default: measured on the headline, same box, 2.00-2.01 ms with it and 1.98-2.00
+    // without -- the resolve is not what the pass ends on, the stragglers and the accept behind them are)
+    static const bool after_scan_env = getenv("LENTIL_RESOLVE_AFTER_SCAN") && getenv("LENTIL_RESOLVE_AFTER_SCAN")[0] == '1';
     const bool resolve_after_scan = lean_pass && resolves_early && after_scan_env;
     if (resolve_after_scan) {
       hipStream_t rs = ctx->chunks[1].stream;
@@ -2344,11 +2364,11 @@ static int redistribute_streamed(lentil_hip_ctx *ctx, bool *streamed) {
         // (on a stream of its own: the first round's straggler kernel, ahead of everything on `ps`, is at work for another
         // ~0.25 ms -- its last records come when A ends -- and this round's parked solves need not wait for it)
         HIP_TRY(ctx, hipStreamWaitEvent(ctx->slow1_stream, overlap_accept ? ctx->ev_round : ctx->ev_acc1, 0));
-        hipLaunchKernelGGL(solve_slow_kernel, dim3(d1.slow_waves), dim3(64), 0, ctx->slow1_stream, d1);
+        hipLaunchKernelGGL(solve_slow_kernel, dim3(d1.slow_waves), dim3(64), coop_lds_bytes(ctx->hlens.n_terms), ctx->slow1_stream, d1);
         HIP_TRY(ctx, hipEventRecord(ctx->ev_slow1, ctx->slow1_stream));
         HIP_TRY(ctx, hipStreamWaitEvent(ps, ctx->ev_slow, 0));      // the first round's stragglers (publishers' stream)
       } else {
-        hipLaunchKernelGGL(solve_slow_kernel, dim3(d1.slow_waves), dim3(64), 0, ps, d1);      // beside the round's solves
+        hipLaunchKernelGGL(solve_slow_kernel, dim3(d1.slow_waves), dim3(64), coop_lds_bytes(ctx->hlens.n_terms), ps, d1);      // beside the round's solves
       }
       HIP_TRY(ctx, hipStreamWaitEvent(ps, ctx->ev_solve, 0));
       if (round == 1) {
@@ -2419,7 +2439,7 @@ static int redistribute_streamed(lentil_hip_ctx *ctx, bool *streamed) {
         HIP_TRY(ctx, hipGetLastError());
         HIP_TRY(ctx, hipEventRecord(ch.done, ch.stream));
         HIP_TRY(ctx, hipStreamWaitEvent(ctx->pub_stream, ctx->ev_round, 0));
-        hipLaunchKernelGGL(solve_slow_kernel, dim3(d1.slow_waves), dim3(64), 0, ctx->pub_stream, d1);
+        hipLaunchKernelGGL(solve_slow_kernel, dim3(d1.slow_waves), dim3(64), coop_lds_bytes(ctx->hlens.n_terms), ctx->pub_stream, d1);
         HIP_TRY(ctx, hipEventRecord(ctx->ev_slow, ctx->pub_stream));
         HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ch.done, 0));
         HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_slow, 0));      // (decoupled: behind the first round's straggler kernel too)
@@ -2431,7 +2451,7 @@ static int redistribute_streamed(lentil_hip_ctx *ctx, bool *streamed) {
         HIP_TRY(ctx, hipEventRecord(ctx->ev_round, ctx->stream));
         launch_solve_po<false>(ctx, da, ctx->stream, (unsigned)ctx->num_cu);
         HIP_TRY(ctx, hipStreamWaitEvent(ctx->pub_stream, ctx->ev_round, 0));
-        hipLaunchKernelGGL(solve_slow_kernel, dim3(da.slow_waves), dim3(64), 0, ctx->pub_stream, da);
+        hipLaunchKernelGGL(solve_slow_kernel, dim3(da.slow_waves), dim3(64), coop_lds_bytes(ctx->hlens.n_terms), ctx->pub_stream, da);
         HIP_TRY(ctx, hipEventRecord(ctx->ev_slow, ctx->pub_stream));
         HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_slow, 0));
       }
@@ -2469,8 +2489,28 @@ static int redistribute_streamed(lentil_hip_ctx *ctx, bool *streamed) {
   }
   const int C = ctx->n_chunks;
   ht_mark(ctx, "all_launched");
-  HIP_TRY(ctx, hipMemcpyAsync(ctx->h_ctr_pinned, ctx->d_ctr, sizeof(DevCounters) * C, hipMemcpyDeviceToHost, tail));
-  HIP_TRY(ctx, hipStreamSynchronize(tail));
+  bool have_counters = false;
+  if (ctx->spin_readback && ctx->d_ctr_host) {
+    // The counters by a kernel into the host's copy and a sequence number behind them; the host polls that number.  (A copy
+    // command's completion reaches the waiting thread ~40 us after the device is through: signal, interrupt, wake-up.)
+    const uint32_t seq = ++ctx->seq ? ctx->seq : ++ctx->seq;
+    hipLaunchKernelGGL(report_counters_kernel, dim3(1), dim3(256), 0, tail, reinterpret_cast<const uint32_t *>(ctx->d_ctr),
+                       reinterpret_cast<uint32_t *>(ctx->d_ctr_host), (uint32_t)(sizeof(DevCounters) * C / sizeof(uint32_t)),
+                       reinterpret_cast<uint32_t *>(ctx->d_ctr_host + C), seq);
+    HIP_TRY(ctx, hipGetLastError());
+    const auto spin_t0 = std::chrono::steady_clock::now();
+    uint32_t spins = 0;
+    while (true) {
+      if (__atomic_load_n(ctx->h_seq, __ATOMIC_ACQUIRE) == seq) { have_counters = true; break; }
+      __builtin_ia32_pause();
+      if ((++spins & 0xFFFu) == 0u &&
+          std::chrono::duration<double>(std::chrono::steady_clock::now() - spin_t0).count() > 2.0) break;      // (then the plain way)
+    }
+  }
+  if (!have_counters) {
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_ctr_pinned, ctx->d_ctr, sizeof(DevCounters) * C, hipMemcpyDeviceToHost, tail));
+    HIP_TRY(ctx, hipStreamSynchronize(tail));
+  }
   ht_mark(ctx, "tail_synced");
   {
     // (host time from the pass's first launch to its counters: an upper bound of every wait inside it)
@@ -2482,6 +2522,7 @@ static int redistribute_streamed(lentil_hip_ctx *ctx, bool *streamed) {
     // the context's stream next (resolve, downloads, the next pass) follows the main stream's own last kernel
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   }
+  ht_mark(ctx, "main_synced");
   ctx->h_ctr.assign(ctx->h_ctr_pinned, ctx->h_ctr_pinned + C);
   ctx->h_ctr_valid = true;
   ctx->last_streamed = 1;

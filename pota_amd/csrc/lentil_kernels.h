@@ -277,6 +277,18 @@ __global__ void probe_wait_kernel(uint32_t *flag, uint32_t *seen) {
   }
   *seen = 1u;
 }
+// The pass's counters straight into the host's (pinned, device-visible) copy, then a sequence number behind them: the host
+// reads them as soon as they have crossed the bus, without a copy command's completion signal and the wake-up behind it
+// (redistribute_streamed; ~40 us of a 2 ms pass).  One block.
+__global__ __launch_bounds__(256) void report_counters_kernel(const uint32_t *src, uint32_t *host_dst, uint32_t n_words,
+                                                              uint32_t *host_seq, uint32_t seq) {
+  for (uint32_t i = threadIdx.x; i < n_words; i += blockDim.x)
+    __hip_atomic_store(host_dst + i, __hip_atomic_load(src + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_store(host_seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 __global__ void probe_set_kernel(uint32_t *flag) { (void)__hip_atomic_exchange(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 constexpr uint32_t kEndCount = 0xFFu;       // Task::count of the end-of-queue markers behind the last task
@@ -2085,6 +2097,7 @@ struct DrawArgs {
   uint32_t slow_cap;
   int32_t slow_at;         // Newton iterations after which a solve counts as a straggler
   int32_t slow_max_lanes;  // a dry wave parks only when at most this many of its lanes are still busy
+  int32_t slow_prio;       // s_setprio of the straggler kernel's waves (their chains of iterations end the pass; LENTIL_SLOW_PRIO)
   int32_t round;           // solve/accept round of the chunk (0 = first batch)
   int32_t slow_from_round; // parking starts with this round: the first round's own ramp-down hides most of its stragglers
   uint64_t slow_below;     // ... in chunks whose draw sum is below this (where the end of a round is what costs;
@@ -2777,10 +2790,10 @@ __global__ __launch_bounds__(256) LENTIL_SOLVE_ATTR void solve_po_kernel(DrawArg
 // Same operations in the same order as LdsLens / the generated code, so the iteration sequence of a parked
 // solve continues unchanged; the sequential pupil transforms that follow are computed redundantly by all lanes.
 constexpr int kCoopPolys = 14;
+// (Round 5: the term table, the products and the index list are sized by the lens at launch -- 306 / 408 terms for the two
+// benchmark tables, 9-12 KB a wave where kMaxTerms = 1536 made it 41 KB: a CU has room for several straggler waves beside
+// two resident solve blocks and the accept's, coop_lds_bytes.)
 struct CoopShared {
-  DevTerm terms[kMaxTerms];
-  double prod[kMaxTerms];
-  uint16_t idx[kMaxTerms];      // term ids of the polynomials an iteration needs, in evaluation order
   double pw[64];                // [var][e]
   double sum[16];
   double lambda_pow[3][kMaxExp + 1];
@@ -2799,8 +2812,16 @@ LD_DEV double ipow_lane(double x, uint32_t e) {     // lens_ipow for a per-lane 
   return p;
 }
 
+inline __host__ __device__ size_t coop_lds_bytes(uint32_t n_terms) {
+  const size_t nt = ((size_t)n_terms + 7u) & ~(size_t)7u;
+  return nt * (sizeof(DevTerm) + sizeof(double) + sizeof(uint16_t));
+}
+
 struct CoopLens {
   CoopShared *sh;
+  DevTerm *terms;        // [n_terms] the lens table (dynamic LDS)
+  double *prod;          // [n_terms] the iteration's products, in evaluation order
+  uint16_t *idx;         // [n_terms] term ids of the polynomials an iteration needs, in evaluation order
   const double *lp;      // lambda powers of this solve's wavelength channel (LDS)
 
   LD_DEV void eval_bw(const double v[4], double pred_ap[2], double Jap[4], double out[4], double Jout[4]) const {
@@ -2813,27 +2834,27 @@ struct CoopLens {
     __syncthreads();
     const uint32_t nn = sh->n_needed;
     for (uint32_t j = lane; j < nn; j += 64u) {
-      const DevTerm t = sh->terms[sh->idx[j]];
+      const DevTerm t = terms[idx[j]];
       double term = t.c;
       term = term * sh->pw[t.e & 15u];
       term = term * sh->pw[16u + ((t.e >> 4) & 15u)];
       term = term * sh->pw[32u + ((t.e >> 8) & 15u)];
       term = term * sh->pw[48u + ((t.e >> 12) & 15u)];
       term = term * lp[(t.e >> 16) & 15u];
-      sh->prod[j] = term;
+      prod[j] = term;
     }
     __syncthreads();
     if (lane < (uint32_t)kCoopPolys) {
       const uint32_t f = sh->first[lane], c = sh->count[lane];
       double sum = 0.0;
       if (c) {
-        sum = sh->prod[f];
+        sum = prod[f];
         uint32_t i = 1;
         for (; i + 4u <= c; i += 4u) {
-          const double p0 = sh->prod[f + i], p1 = sh->prod[f + i + 1], p2 = sh->prod[f + i + 2], p3 = sh->prod[f + i + 3];
+          const double p0 = prod[f + i], p1 = prod[f + i + 1], p2 = prod[f + i + 2], p3 = prod[f + i + 3];
           sum = sum + p0; sum = sum + p1; sum = sum + p2; sum = sum + p3;
         }
-        for (; i < c; ++i) sum = sum + sh->prod[f + i];
+        for (; i < c; ++i) sum = sum + prod[f + i];
       }
       sh->sum[lane] = sum;
     }
@@ -2848,7 +2869,7 @@ struct CoopLens {
     const uint32_t first = sh->k.first[P_OUT_T], count = sh->k.count[P_OUT_T];
     double sum = 0.0;
     for (uint32_t i = 0; i < count; ++i) {
-      const DevTerm t = sh->terms[first + i];
+      const DevTerm t = terms[first + i];
       const uint32_t e = __builtin_amdgcn_readfirstlane(t.e);
       double term = t.c;
 #pragma unroll
@@ -2873,8 +2894,12 @@ struct CoopLens {
 #endif
 __global__ __launch_bounds__(64) LENTIL_SLOW_ATTR void solve_slow_kernel(DrawArgs a) {
   LENTIL_TL_SPAN(a.round == 0 ? SPAN_SLOW_R0 : (a.round == 1 ? SPAN_SLOW_R1 : SPAN_SLOW_R2));
+  if (a.slow_prio == 1) __builtin_amdgcn_s_setprio(1);
+  else if (a.slow_prio == 2) __builtin_amdgcn_s_setprio(2);
+  else if (a.slow_prio >= 3) __builtin_amdgcn_s_setprio(3);
   __shared__ CoopShared sh;
   __shared__ uint32_t s_q;
+  extern __shared__ __align__(16) unsigned char s_coop[];      // coop_lds_bytes(n_terms)
   const uint32_t par = (uint32_t)a.parity, sq = slow_queue(a);
   uint32_t n_slow = a.slow_live ? 0xFFFFFFFFu : a.ctr->n_slow[sq];
   if (!a.slow_live) {
@@ -2883,7 +2908,13 @@ __global__ __launch_bounds__(64) LENTIL_SLOW_ATTR void solve_slow_kernel(DrawArg
   }
   const uint32_t lane = threadIdx.x;
   const uint32_t nt = a.lens->n_terms;
-  for (uint32_t i = lane; i < nt; i += 64u) sh.terms[i] = a.terms[i];
+  const uint32_t nt_pad = (nt + 7u) & ~7u;
+  CoopLens L;
+  L.sh = &sh;
+  L.terms = reinterpret_cast<DevTerm *>(s_coop);
+  L.prod = reinterpret_cast<double *>(L.terms + nt_pad);
+  L.idx = reinterpret_cast<uint16_t *>(L.prod + nt_pad);
+  for (uint32_t i = lane; i < nt; i += 64u) L.terms[i] = a.terms[i];
   if (lane == 0) sh.k = *a.lens;
   {
     // the polynomials an iteration needs, in the order eval_bw hands them out: lane p looks after polynomial p
@@ -2905,7 +2936,7 @@ __global__ __launch_bounds__(64) LENTIL_SLOW_ATTR void solve_slow_kernel(DrawArg
     if (lane < (uint32_t)kCoopPolys) {
       const uint32_t start = incl - c;
       sh.first[lane] = start; sh.count[lane] = c;
-      for (uint32_t i = 0; i < c; ++i) sh.idx[start + i] = (uint16_t)(f + i);
+      for (uint32_t i = 0; i < c; ++i) L.idx[start + i] = (uint16_t)(f + i);
       if (lane == (uint32_t)kCoopPolys - 1u) sh.n_needed = incl;
     }
   }
@@ -2916,8 +2947,6 @@ __global__ __launch_bounds__(64) LENTIL_SLOW_ATTR void solve_slow_kernel(DrawArg
       sh.lambda_pow[lane][e] = a.n_channels == 3 ? (e == 0 ? 1.0 : (e == 1 ? lam : ipow_u(lam, e))) : a.lens->lambda_pow[e];
   }
   __syncthreads();
-  CoopLens L;
-  L.sh = &sh;
   unsigned long long iters = 0, solves = 0;
   while (true) {
     __syncthreads();

@@ -1096,11 +1096,17 @@ def test_streamed_pass_that_stalls_after_its_first_accept_is_run_again(orc, monk
         for k, (streamed, fb) in enumerate(((0, 0), (1, 0), (0, 1), (1, 0))):
             c = gpu_run(ctx, p, table, visits)
             rc = ref.counters()
-            assert (c.streamed, c.fallback_chunks) == (streamed, fb), (k, c.streamed, c.fallback_chunks)
+            assert (c.streamed, c.fallback_chunks) == (streamed, fb), (k, c.streamed, c.fallback_chunks, ctx.last_redo_note())
             assert (c.redistributed_visits, c.attempted_draws, c.accepted_draws) == (
                 rc.redistributed_visits, rc.attempted_draws, rc.accepted_draws)
             check_logs(ctx, ref)
             check_frame(ctx, ref)
+            # why a pass was redone stays readable: who gave up waiting, and that draws had been added by then
+            note = ctx.last_redo_note()
+            if k < 2:
+                assert note == ""
+            else:
+                assert "resident solve wave" in note and "rounds_used 1" in note and "round 1 parity 1" in note, note
     finally:
         ctx.close()
         ref.close()
