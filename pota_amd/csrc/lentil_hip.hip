@@ -221,7 +221,7 @@ struct lentil_hip_ctx {
   bool early_resolve_pending = false;    // the early half of this pass is enqueued (ev_res marks its end)
   bool late_resolve_done = false;    // ... and so is the second half, behind the last accept
   bool resolved_valid = false;       // d_resolved holds the frame as it is
-  hipEvent_t ev_acc1 = nullptr, ev_res = nullptr;
+  hipEvent_t ev_acc1 = nullptr, ev_res = nullptr, ev_b = nullptr;
   hipStream_t pub_stream = nullptr;  // streamed pass: publish_kernel, then the live straggler kernel
   hipEvent_t pub_done = nullptr;
   bool pass_pending = false;         // a redistribute ran whose rows have not been asked for yet
@@ -438,6 +438,7 @@ LENTIL_API int lentil_hip_create(int device, lentil_hip_ctx **out_ctx) {
   HIP_TRY(ctx, hipEventCreate(&ctx->ev_scan_k[1]));
   HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->pub_done, hipEventDisableTiming));
   HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_acc1, hipEventDisableTiming));
+  HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_b, hipEventDisableTiming));
   HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_res, hipEventDisableTiming));
   HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_solve, hipEventDisableTiming));
   HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_slow1, hipEventDisableTiming));
@@ -602,6 +603,7 @@ LENTIL_API int lentil_hip_destroy(lentil_hip_ctx *ctx) {
   if (ctx->ev_scan_k[0]) (void)hipEventDestroy(ctx->ev_scan_k[0]);
   if (ctx->ev_scan_k[1]) (void)hipEventDestroy(ctx->ev_scan_k[1]);
   if (ctx->ev_acc1) (void)hipEventDestroy(ctx->ev_acc1);
+  if (ctx->ev_b) (void)hipEventDestroy(ctx->ev_b);
   if (ctx->ev_res) (void)hipEventDestroy(ctx->ev_res);
   if (ctx->ev_solve) (void)hipEventDestroy(ctx->ev_solve);
   if (ctx->ev_slow1) (void)hipEventDestroy(ctx->ev_slow1);
@@ -2160,7 +2162,9 @@ static int redistribute_streamed(lentil_hip_ctx *ctx, bool *streamed) {
   const bool dry_only = ctx->park_dry_only >= 0 ? ctx->park_dry_only != 0 : ctx->park_dry_seen;
   const uint32_t slow_waves_all = (uint32_t)ctx->num_cu * (slow_per_cu >= 1 && slow_per_cu <= 4 ? (uint32_t)slow_per_cu : 1u);
   if (decoupled) { da.slow_indirect = 1; da.slow_cap = slow_cap_all / 2u > slow_waves_all ? slow_cap_all / 2u - slow_waves_all : 0u; }      // (its end markers stay below the upper half)
-  const unsigned b_threads = live ? 192u : 256u;
+  static const int b_threads_env = getenv("LENTIL_SOLVE_B_THREADS") ? atoi(getenv("LENTIL_SOLVE_B_THREADS")) : 0;
+  const unsigned b_threads = (b_threads_env == 64 || b_threads_env == 128 || b_threads_env == 192 || b_threads_env == 256) ? (unsigned)b_threads_env
+                                                                                                                         : (live ? 192u : 256u);
   unsigned b_blocks;
   {
     int b_per_cu = live ? 3 - ctx->stream_blocks : ctx->solve_max_blocks - ctx->stream_blocks;
@@ -2256,6 +2260,17 @@ static int redistribute_streamed(lentil_hip_ctx *ctx, bool *streamed) {
     // accept, the first round's stragglers -- has ended before that kernel does, so those waits find their events fired.
     // On the publishers' stream the accept came ~60 us after the stragglers' end: three cross-stream waits in a row.)
     hipStream_t ps = ctx->slow1_stream;
+    if (b_blocks) {
+      // LENTIL_SOLVE_B=1: a third solve block per CU (three waves: one SIMD stays the straggler wave's) behind the scan on its
+      // stream -- it starts when the scan's waves have left, finds the queue complete and never waits; the first accept waits
+      // for it as for A
+      DrawArgs db = da;
+      db.instance = 1;
+      launch_solve_po<true>(ctx, db, ctx->stream, b_blocks, b_threads);
+      HIP_TRY(ctx, hipGetLastError());
+      HIP_TRY(ctx, hipEventRecord(ctx->ev_b, ctx->stream));
+      HIP_TRY(ctx, hipStreamWaitEvent(ch.stream, ctx->ev_b, 0));
+    }
     HIP_TRY(ctx, hipStreamWaitEvent(ch.stream, ctx->pub_done, 0));       // (both long past when A ends)
     HIP_TRY(ctx, hipStreamWaitEvent(ch.stream, ctx->scans_done, 0));
     HIP_TRY(ctx, hipEventRecord(ctx->ev_round, ch.stream));
