@@ -2104,6 +2104,14 @@ static int redistribute_streamed(lentil_hip_ctx *ctx, bool *streamed) {
   if (ctx->predict && !ctx->extend && nch == 1 && (rc = ensure_batch_model(ctx))) return rc;
   // (the scan's start for lentil_hip_last_timing: the host work since the pass began -- sizing, the plan -- is not the kernel's)
   HIP_TRY(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
+  {
+    static const bool a_first = getenv("LENTIL_A_FIRST") && getenv("LENTIL_A_FIRST")[0] == '1';
+    if (a_first && ctx->streams_concurrent && ctx->slow_live) {
+      hipLaunchKernelGGL(wait_waves_kernel, dim3(1), dim3(1), 0, ctx->stream, ctx->d_ctr,
+                         (uint32_t)ctx->num_cu * (uint32_t)ctx->stream_blocks * 4u, (uint64_t)30000);      // (0.3 ms at most)
+      HIP_TRY(ctx, hipGetLastError());
+    }
+  }
   if ((rc = launch_scan(ctx, plan, ch, ctx->d_ctr, &scan_blocks, true))) return rc;
   ctx->last_scan_launches = 1;
   HIP_TRY(ctx, hipEventRecord(ch.scanned, ctx->stream));

@@ -289,6 +289,14 @@ __global__ __launch_bounds__(256) void report_counters_kernel(const uint32_t *sr
   if (threadIdx.x == 0) __hip_atomic_store(host_seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+// LENTIL_A_FIRST=1 (experiment): ahead of a streamed pass's scan on its stream -- the scan's blocks are dispatched when the
+// resident solve kernel's waves have their registers (waves_started), so that those lie in one piece at the bottom of
+// every SIMD's file and what the scan's waves give back is one piece too (a third solve block fits it, LENTIL_SOLVE_B).
+__global__ void wait_waves_kernel(const DevCounters *ctr, uint32_t want, uint64_t max_ticks) {
+  const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
+  while (ld_coherent32(&ctr->waves_started[0]) < want && __builtin_amdgcn_s_memrealtime() - t0 < max_ticks) __builtin_amdgcn_s_sleep(8);
+}
+
 __global__ void probe_set_kernel(uint32_t *flag) { (void)__hip_atomic_exchange(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 constexpr uint32_t kEndCount = 0xFFu;       // Task::count of the end-of-queue markers behind the last task
