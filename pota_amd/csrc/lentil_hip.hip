@@ -2360,8 +2360,8 @@ static int redistribute_streamed(lentil_hip_ctx *ctx, bool *streamed) {
       d1.slow_indirect = 0;
       if (round == 1) {
         d1.no_reset = 1;
-        d1.producers_done = &ctx->d_ctr->accept_done[0];
-        d1.producers_total = accept_blocks;
+        d1.producers_done = &ctx->d_ctr->accept_final[0];      // (set behind the queue's end markers)
+        d1.producers_total = 1u;
         d1.slow = slow_base + slow_cap_all / 2u;
         d1.slow_cap = slow_cap_all - slow_cap_all / 2u - d1.slow_waves;
         // Round 5: the second round's resident solve and straggler kernels start BEHIND the first accept, not beside it.  Beside
@@ -2453,8 +2453,8 @@ static int redistribute_streamed(lentil_hip_ctx *ctx, bool *streamed) {
         DrawArgs d1 = da;
         d1.slow_after_producers = 0;
         d1.no_reset = 1;
-        d1.producers_done = &ctx->d_ctr->accept_done[0];
-        d1.producers_total = accept_blocks;
+        d1.producers_done = &ctx->d_ctr->accept_final[0];      // (set behind the queue's end markers)
+        d1.producers_total = 1u;
         d1.slow_crowd_stays = ctx->crowd_stays_later;
         if (decoupled) { d1.slow_indirect = 0; d1.slow = slow_base + slow_cap_all / 2u; d1.slow_cap = slow_cap_all - slow_cap_all / 2u - d1.slow_waves; }
         HIP_TRY(ctx, hipStreamWaitEvent(ch.stream, ctx->ev_round, 0));
@@ -2484,8 +2484,8 @@ static int redistribute_streamed(lentil_hip_ctx *ctx, bool *streamed) {
       DrawArgs d1 = da;
       d1.slow_after_producers = 0;
       d1.no_reset = 1;
-      d1.producers_done = &ctx->d_ctr->accept_done[0];
-      d1.producers_total = accept_blocks;
+      d1.producers_done = &ctx->d_ctr->accept_final[0];      // (set behind the queue's end markers)
+      d1.producers_total = 1u;
       HIP_TRY(ctx, hipStreamWaitEvent(ch.stream, ctx->ev_round, 0));
       launch_solve_po<true>(ctx, d1, ch.stream, (unsigned)ctx->num_cu);
       HIP_TRY(ctx, hipGetLastError());

@@ -59,6 +59,9 @@ struct DevCounters {
   // gave up first saw -- round, parity, the queue's n_tasks, accept_done[0], accept_started[0], its slot's tag word, block
   unsigned int accept_started[2];
   unsigned int stuck_info[8];
+  // items an accept with DrawArgs::emit_live has finished / its queue has its end markers (what the solve kernel beside it
+  // waits for does not depend on blocks of the accept that have not begun)
+  unsigned int accept_items_done[2], accept_final[2];
 };
 
 // per-thread running row range -> one pair of atomics per wave
@@ -2229,6 +2232,7 @@ LD_DEV void reset_round(DevCounters *c, uint32_t par) {
   c->n_tasks[par] = 0; c->task_head[par] = 0; c->n_active[par] = 0; c->active_head[par] = 0;
   c->pool_used[par] = 0;
   c->n_slow[par] = 0; c->slow_head[par] = 0; c->waves_done[par] = 0; c->waves_started[par] = 0; c->accept_done[par] = 0;
+  c->accept_items_done[par] = 0; c->accept_final[par] = 0;
 }
 // keep_pool: items of the accept that follows still read results out of this parity's pool (ItemProg::p_lo) while that
 // accept allocates the next batch's results in it: go on behind them
@@ -3978,6 +3982,34 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LENTIL_ACCE
       tot_accepted += chroma ? r.prog.splats : r.prog.accepted;
     }
   };
+  // emit_live: the end markers behind the next round's task queue, by the first 64 threads of whichever block finds the
+  // queue complete -- the block that finishes the pass's last item, not the grid's last block: the solve kernel that waits
+  // for them must not depend on blocks of this grid that have not been dispatched ("a stall found and removed")
+  __shared__ uint32_t s_write_end;
+  auto write_end_markers = [&]() {
+    if (threadIdx.x < 64u) {
+      const uint32_t n = ld_coherent32(&a.ctr->n_tasks[nxt]);
+      for (uint32_t i = threadIdx.x; i < a.end_tasks; i += 64u)
+        if ((uint64_t)n + i < a.task_cap)
+          st_agent64(reinterpret_cast<uint64_t *>(a.tasks[nxt] + n + i) + 1, (uint64_t)(kEndCount | (a.epoch << kTaskTagShift)) << 32);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (threadIdx.x == 0) st_agent32(&a.ctr->accept_final[par], 1u);
+    }
+  };
+  auto ticket_done = [&](uint32_t cnt) {
+    if constexpr (kMode == 2) { (void)cnt; return; }       // (the accept behind the stragglers feeds nobody beside it)
+    if (!a.emit_live || a.inject_stall) return;
+    __syncthreads();                         // (thread 0 has finished the ticket's items: their tasks are counted in n_tasks)
+    if (threadIdx.x == 0) s_write_end = (atomicAdd(&a.ctr->accept_items_done[par], cnt) + cnt == n_active) ? 1u : 0u;
+    __syncthreads();
+    if (s_write_end) write_end_markers();
+  };
+  if (kMode != 2 && a.emit_live && !a.inject_stall && n_active == 0u) {
+    // nothing to accept: whichever block comes first closes the queue
+    if (threadIdx.x == 0) s_write_end = atomicAdd(&a.ctr->accept_items_done[par], 1u) == 0u ? 1u : 0u;
+    __syncthreads();
+    if (s_write_end) write_end_markers();
+  }
   while (true) {
     __syncthreads();
     if (threadIdx.x == 0) s_item = atomicAdd(&a.ctr->active_head[par], per);
@@ -3999,6 +4031,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LENTIL_ACCE
         (void)accept_item_wide<kMode>(a, sh, ws, item, pg, h, res, res_prev, rmin, rmax_p1,
                                       [&](const AcceptResult &r) { if (threadIdx.x == 0) finish_item(item, pg, r, false, 0u, 0u); });
       }
+      ticket_done(cnt);
       continue;
     }
     if (dry_first) {
@@ -4023,23 +4056,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LENTIL_ACCE
         finish_item(item, pg, r, dry_first && s_emitted[j] != 0u, dry_first ? s_emit_off[j] : 0u, dry_first ? s_emit_hi[j] : 0u);
       __syncthreads();       // (s_emit_*[j] and the add table in `sh` are the block's)
     }
+    ticket_done(cnt);
   }
   if (threadIdx.x == 0) {
     if (tot_attempted) atomicAdd(&a.ctr->attempted, tot_attempted);
     if (tot_accepted) atomicAdd(&a.ctr->accepted, tot_accepted);
   }
   flush_row_range(a.ctr, rmin, rmax_p1);
-  if (a.emit_live && threadIdx.x < 64u && !a.inject_stall) {
+  if (kMode != 2 && a.emit_live && threadIdx.x < 64u && !a.inject_stall) {
     // everything this block emitted has arrived; the last block puts the end markers behind the queue
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     uint32_t last = 0;
     if (threadIdx.x == 0) last = atomicAdd(&a.ctr->accept_done[par], 1u) == gridDim.x - 1u ? 1u : 0u;
-    if (__builtin_amdgcn_readfirstlane(last)) {
-      const uint32_t n = ld_coherent32(&a.ctr->n_tasks[nxt]);
-      for (uint32_t i = threadIdx.x; i < a.end_tasks; i += 64u)
-        if ((uint64_t)n + i < a.task_cap)
-          st_agent64(reinterpret_cast<uint64_t *>(a.tasks[nxt] + n + i) + 1, (uint64_t)(kEndCount | (a.epoch << kTaskTagShift)) << 32);
-    }
+    // (the grid's last block writes them once more -- same slots, same words: n_tasks has not moved since the last item)
+    if (__builtin_amdgcn_readfirstlane(last)) write_end_markers();
   }
 }
 
