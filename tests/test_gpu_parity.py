@@ -1106,7 +1106,8 @@ def test_streamed_pass_that_stalls_after_its_first_accept_is_run_again(orc, monk
             if k < 2:
                 assert note == ""
             else:
-                assert "resident solve wave" in note and "rounds_used 1" in note and "round 1 parity 1" in note, note
+                # (the second round's resident solve wave; with LENTIL_OVERLAP_ACCEPT=1 its straggler wave may give up first)
+                assert ("resident solve wave" in note or "straggler wave" in note) and "rounds_used 1" in note, note
     finally:
         ctx.close()
         ref.close()
