@@ -491,6 +491,11 @@ class Bench:
             if k.worklist_overflow:
                 raise SystemExit("bench.py: the device dropped work (worklist_overflow = %d): results incomplete" % k.worklist_overflow)
             acc["streamed"] += int(k.streamed); acc["blind_chunks"] += int(k.blind_chunks); acc["redone"] += int(k.fallback_chunks)
+            if int(k.fallback_chunks):
+                # why (lentil_hip_last_redo_note): a pass redone costs time, never results -- but a bench line should say so
+                acc.setdefault("redo_notes", [])
+                if len(acc["redo_notes"]) < 3:
+                    acc["redo_notes"].append(self.ctx.last_redo_note())
             acc["iters"] += int(k.newton_iterations); acc["attempted"] += int(k.attempted_draws)
             acc["lane_rounds"] += int(k.lane_rounds); acc["tries"] += int(k.tries); acc["slow"] += int(k.slow_solves)
             acc["accepted"] += int(k.accepted_draws); acc["redistributed"] += int(k.redistributed_visits)
@@ -759,6 +764,7 @@ def main():
         "exchange": exchange, "ranks_joined": ranks_joined,
         "passes": {"timed": steps, "streamed": r["streamed"], "chunks_enqueued_blind": r["blind_chunks"],
                    "chunks_redone_after_a_short_estimate": r["redone"], "solve_accept_rounds_max": r.get("rounds_max"),
+                   "redo_notes": r.get("redo_notes", []),
                    # first batches sized from the lens and the frame (lentil_hip_batch_model_stats, whole life of the context):
                    # passes that ran with no second round of solves in flight, how many of those needed one after all
                    "first_batch_model": dict(zip(("calibrations", "lean_passes", "lean_passes_lost", "margin_sixteenths"),

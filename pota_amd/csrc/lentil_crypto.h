@@ -42,6 +42,8 @@ struct LentilCrypto {
   uint64_t visits_gen = 0;                  // lentil_hip_ctx::visits_gen when the columns were handed over
   std::vector<void *> owned;                // device columns of lentil_hip_upload_crypto
   bool tables_clear = false;                // nothing has been added since lentil_hip_clear_frame
+  bool clear_pending = false;               // ... and the tables have not been wiped yet either: crypto_flush_clear, or a pass whose
+                                            // own-pixel kernel writes every line whole (crypto_direct_tile_kernel<2>)
   uint32_t *d_flag_bits = nullptr;          // one bit per visit of the stream: redistributed by the last pass (flag_bits_kernel)
   uint64_t flag_words = 0;
   float *d_rank = nullptr;                  // download staging: np RGBA + np flags
@@ -208,9 +210,12 @@ __global__ __launch_bounds__(256) void flag_bits_kernel(const uint2 *work, const
   }
 }
 
-// kCleared: the tables hold nothing yet (a pass straight after lentil_hip_clear_frame, the usual one): their lines are
-// not read, only written.
-template <bool kCleared>
+// kTables 1: the tables hold nothing yet (a pass straight after lentil_hip_clear_frame, the usual one): their lines are
+// not read, only written -- and quads of free slots not even that.  kTables 2 (round 5): the same pass when the clear itself
+// was put off (LentilCrypto::clear_pending) and the stream covers every pixel of the frame -- every line is written whole,
+// free slots and all, and the 1.06 GB per AOV that the clear would have written (0.16 ms ahead of the scan) are not.
+// kTables 0: lines are read, added to, written.
+template <int kTables>
 __global__ __launch_bounds__(128) void crypto_direct_tile_kernel(CryptoDev C, VisitsDev V, lentil_params P, double lens_length,
                                                                  CryptoTile T) {
   extern __shared__ uint32_t crypto_lds[];
@@ -221,6 +226,7 @@ __global__ __launch_bounds__(128) void crypto_direct_tile_kernel(CryptoDev C, Vi
   float *s_wt = reinterpret_cast<float *>(crypto_lds + T.off_wt);      // [tp][slots + 1]
   float *s_tot = reinterpret_cast<float *>(crypto_lds + T.off_tot);    // [tp]
   uint32_t *s_pix = crypto_lds + T.off_pix;                            // [tp] frame pixel of the tile's entries
+  constexpr bool kCleared = kTables != 0;
   const uint32_t M = V.visits_per_pixel, E = C.entries, SL = C.slots, SP = SL + 1u;
   const uint64_t n_pix = V.n / M;
   const uint64_t n_tiles = (n_pix + T.tp - 1) / T.tp;
@@ -365,7 +371,7 @@ __global__ __launch_bounds__(128) void crypto_direct_tile_kernel(CryptoDev C, Vi
           const uint32_t *sk = s_k + j * SP + sl; const float *sw = s_wt + j * SP + sl;
           // (straight after a clear the table holds "free" everywhere already: four free slots need not be written again --
           // most of a pixel's sixteen are, and the lines this kernel writes are half of what it moves)
-          if (kCleared && (sk[0] & sk[1] & sk[2] & sk[3]) == kCryptoEmpty) continue;
+          if (kTables == 1 && (sk[0] & sk[1] & sk[2] & sk[3]) == kCryptoEmpty) continue;
           *reinterpret_cast<uint4 *>(C.keys + at) = make_uint4(sk[0], sk[1], sk[2], sk[3]);
           *reinterpret_cast<float4 *>(C.wts + at) = make_float4(sw[0], sw[1], sw[2], sw[3]);
         }
@@ -514,12 +520,39 @@ LENTIL_API int lentil_hip_alloc_crypto(lentil_hip_ctx *ctx, uint32_t n_crypto, u
 static int crypto_clear(lentil_hip_ctx *ctx) {
   LentilCrypto *k = ctx->crypto;
   if (!k) return LENTIL_OK;
+  // Round 5, an option: the wipe of the tables (1.06 GB per AOV at sixteen ids per pixel: 0.16 ms ahead of the pass's scan) is put off.
+  // The usual next thing is a pass over a stream that covers the whole frame, whose own-pixel kernel then writes every line
+  // whole instead of finding it wiped (crypto_direct_tile_kernel<2>); anything else that looks at the tables first wipes them
+  // then (crypto_flush_clear).
+  // (Measured, same box, headline frame, clear + pass: +1.39-1.47 ms for one AOV and +1.26 per AOV for three either way --
+  // the lines the kernel then writes whole cost what the wipe cost; the pass alone reads +1.36 / +1.24 instead of +1.07 / +1.05.
+  // Off; LENTIL_CRYPTO_LAZY_CLEAR=1 turns it on.)
+  static const bool lazy = getenv("LENTIL_CRYPTO_LAZY_CLEAR") && getenv("LENTIL_CRYPTO_LAZY_CLEAR")[0] == '1';
+  if (lazy) {
+    HIP_TRY(ctx, hipMemsetAsync(k->D.overflow, 0, sizeof(unsigned long long), ctx->stream));
+    k->tables_clear = true;
+    k->clear_pending = true;
+    return LENTIL_OK;
+  }
+  k->clear_pending = false;
   const uint64_t cells = (uint64_t)k->D.n_crypto * k->D.np * k->D.slots;
   HIP_TRY(ctx, hipMemsetAsync(k->D.keys, 0xFF, cells * sizeof(uint32_t), ctx->stream));
   HIP_TRY(ctx, hipMemsetAsync(k->D.wts, 0, cells * sizeof(float), ctx->stream));
   HIP_TRY(ctx, hipMemsetAsync(k->D.total, 0, (uint64_t)k->D.n_crypto * k->D.np * sizeof(float), ctx->stream));
   HIP_TRY(ctx, hipMemsetAsync(k->D.overflow, 0, sizeof(unsigned long long), ctx->stream));
   k->tables_clear = true;
+  return LENTIL_OK;
+}
+
+// the wipe lentil_hip_clear_frame put off, on stream `st` (ahead of whatever reads or adds to the tables there)
+static int crypto_flush_clear(lentil_hip_ctx *ctx, hipStream_t st) {
+  LentilCrypto *k = ctx->crypto;
+  if (!k || !k->clear_pending) return LENTIL_OK;
+  const uint64_t cells = (uint64_t)k->D.n_crypto * k->D.np * k->D.slots;
+  HIP_TRY(ctx, hipMemsetAsync(k->D.keys, 0xFF, cells * sizeof(uint32_t), st));
+  HIP_TRY(ctx, hipMemsetAsync(k->D.wts, 0, cells * sizeof(float), st));
+  HIP_TRY(ctx, hipMemsetAsync(k->D.total, 0, (uint64_t)k->D.n_crypto * k->D.np * sizeof(float), st));
+  k->clear_pending = false;
   return LENTIL_OK;
 }
 
@@ -613,6 +646,18 @@ static int crypto_enqueue_direct(lentil_hip_ctx *ctx, hipStream_t st) {
   if (!k || !ctx->V.n) return LENTIL_OK;
   const double lens_length = ctx->have_lens ? ctx->hlens.length : 0.0;
   const unsigned blocks = (unsigned)ctx->num_cu * 8;
+  // a wipe that was put off: the tile kernel can stand in for it where its owner lanes write every line of the frame
+  bool whole_lines = false;
+  if (k->clear_pending) {
+    const VisitsDev &V = ctx->V;
+    const bool whole_frame = V.visits_per_pixel && V.n == (uint64_t)k->D.np * V.visits_per_pixel &&
+                             V.pixels_per_row == (uint32_t)ctx->P.xres && V.pixel_x0 <= 0 && V.pixel_y0 <= 0 && V.pixel_row_stride <= 1;
+    const char *force = getenv("LENTIL_CRYPTO_TILE");
+    const size_t lds_words = (size_t)((128u * V.visits_per_pixel + 3u) & ~3u) + 2u * ((128u * V.visits_per_pixel * k->D.entries + 3u) & ~3u) +
+                             2u * 128u * (k->D.slots + 1u) + 2u * 128u;
+    whole_lines = whole_frame && k->tables_clear && (k->D.slots & 3u) == 0u && lds_words * 4u <= 64u * 1024u && !(force && force[0] == '0');
+    if (!whole_lines) { const int rc = crypto_flush_clear(ctx, st); if (rc) return rc; }
+  }
   // pixel-major streams whose pixels are all distinct (one pass per clear: the tables hold nothing yet that another
   // lane could be adding to): owner lanes, no atomics
   if (ctx->V.visits_per_pixel && ctx->V.n % ctx->V.visits_per_pixel == 0) {
@@ -652,10 +697,13 @@ static int crypto_enqueue_direct(lentil_hip_ctx *ctx, hipStream_t st) {
         T.flagged = k->d_flag_bits;
       }
       const dim3 grid((unsigned)(n_tiles < max_blocks ? n_tiles : max_blocks));
-      if (k->tables_clear)
-        hipLaunchKernelGGL(crypto_direct_tile_kernel<true>, grid, dim3(128), lds, st, k->D, ctx->V, ctx->P, lens_length, T);
+      if (whole_lines)
+        hipLaunchKernelGGL(crypto_direct_tile_kernel<2>, grid, dim3(128), lds, st, k->D, ctx->V, ctx->P, lens_length, T);
+      else if (k->tables_clear)
+        hipLaunchKernelGGL(crypto_direct_tile_kernel<1>, grid, dim3(128), lds, st, k->D, ctx->V, ctx->P, lens_length, T);
       else
-        hipLaunchKernelGGL(crypto_direct_tile_kernel<false>, grid, dim3(128), lds, st, k->D, ctx->V, ctx->P, lens_length, T);
+        hipLaunchKernelGGL(crypto_direct_tile_kernel<0>, grid, dim3(128), lds, st, k->D, ctx->V, ctx->P, lens_length, T);
+      if (whole_lines) k->clear_pending = false;
     } else {
       hipLaunchKernelGGL(crypto_direct_owner_kernel, dim3(blocks), dim3(256), 0, st, k->D, ctx->V, ctx->P, lens_length);
     }
@@ -716,6 +764,7 @@ static int crypto_exchange_bands(lentil_hip_ctx *ctx, const int32_t *bands, int3
   const uint32_t xres = ctx->P.xres;
   const unsigned blocks = (unsigned)ctx->num_cu * 8;
   int rc;
+  if ((rc = crypto_flush_clear(ctx, ctx->stream))) return rc;      // (a frame cleared and exchanged without a pass)
   void *p;
   if ((rc = comm_scratch(ctx, cm, (size_t)world * 12 + 0, (size_t)world * sizeof(unsigned long long), &p))) return rc;
   unsigned long long *d_counts = (unsigned long long *)p;
@@ -800,6 +849,7 @@ LENTIL_API int lentil_hip_download_crypto(lentil_hip_ctx *ctx, uint32_t crypto, 
   if (!host_rgba) return fail(ctx, LENTIL_ERR_INVALID, "host_rgba is null");
   LentilCrypto *k = ctx->crypto;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
+  { const int rc_ = crypto_flush_clear(ctx, ctx->stream); if (rc_) return rc_; }
   hipLaunchKernelGGL(crypto_rank_kernel, dim3((unsigned)ctx->num_cu * 8), dim3(256), 0, ctx->stream, k->D, crypto, rank,
                      reinterpret_cast<float4 *>(k->d_rank), k->d_has);
   HIP_TRY(ctx, hipGetLastError());
@@ -816,6 +866,7 @@ LENTIL_API int lentil_hip_download_crypto_table(lentil_hip_ctx *ctx, uint32_t cr
   LentilCrypto *k = ctx->crypto;
   if (slots_per_pixel) *slots_per_pixel = k->D.slots;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
+  { const int rc_ = crypto_flush_clear(ctx, ctx->stream); if (rc_) return rc_; }
   const uint64_t cells = k->D.np * k->D.slots;
   if (host_id_bits) HIP_TRY(ctx, hipMemcpyAsync(host_id_bits, k->D.keys + crypto * cells, cells * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
   if (host_weight) HIP_TRY(ctx, hipMemcpyAsync(host_weight, k->D.wts + crypto * cells, cells * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
