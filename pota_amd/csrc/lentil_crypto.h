@@ -527,7 +527,8 @@ static int crypto_clear(lentil_hip_ctx *ctx) {
   // (Measured, same box, headline frame, clear + pass: +1.39-1.47 ms for one AOV and +1.26 per AOV for three either way --
   // the lines the kernel then writes whole cost what the wipe cost; the pass alone reads +1.36 / +1.24 instead of +1.07 / +1.05.
   // Off; LENTIL_CRYPTO_LAZY_CLEAR=1 turns it on.)
-  static const bool lazy = getenv("LENTIL_CRYPTO_LAZY_CLEAR") && getenv("LENTIL_CRYPTO_LAZY_CLEAR")[0] == '1';
+  const char *lazy_env = getenv("LENTIL_CRYPTO_LAZY_CLEAR");      // (read per call: the tests switch it)
+  const bool lazy = lazy_env && lazy_env[0] == '1';
   if (lazy) {
     HIP_TRY(ctx, hipMemsetAsync(k->D.overflow, 0, sizeof(unsigned long long), ctx->stream));
     k->tables_clear = true;

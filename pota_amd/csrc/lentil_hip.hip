@@ -1559,6 +1559,7 @@ static void init_draw_args(lentil_hip_ctx *ctx, DrawArgs &da) {
   da.slow_from_round = ctx->slow_from_round;
   da.slow_max_lanes = ctx->slow_max_lanes;
   da.slow_prio = ctx->slow_prio;
+  { const char *e = getenv("LENTIL_DISPATCH_PROBE"); da.dispatch_probe = (e && e[0] == '1') ? 1 : 0; }
   da.extra_num = ctx->extra_num; da.extra_const = ctx->extra_const; da.extra_below = ctx->extra_below;
   da.log = ctx->d_log;
   da.log_cap = ctx->log_cap;
@@ -2351,7 +2352,8 @@ static int redistribute_streamed(lentil_hip_ctx *ctx, bool *streamed) {
       }
       tail = ls;
     } else {
-    static const bool overlap_accept = getenv("LENTIL_OVERLAP_ACCEPT") && getenv("LENTIL_OVERLAP_ACCEPT")[0] == '1';
+    const char *overlap_env = getenv("LENTIL_OVERLAP_ACCEPT");      // (read per pass: the tests switch it)
+    const bool overlap_accept = overlap_env && overlap_env[0] == '1';
     for (int round = 1; round < blind_rounds; ++round) {
       da.parity = round & 1; da.round = round;
       DrawArgs d1 = da;
@@ -2552,6 +2554,18 @@ static int redistribute_streamed(lentil_hip_ctx *ctx, bool *streamed) {
   ++ctx->last_blind;
   const DevCounters c = ctx->h_ctr[0];
   ch.was_blind = true;
+  if (c.probe_snap[0]) {
+    // LENTIL_DISPATCH_PROBE: the first accept's last item was finished while blocks of its grid had not begun
+    char buf[640];
+    int n = snprintf(buf, sizeof buf, "[probe] epoch %u: accept blocks begun %u of %u when the last item was done; per XCD begun:", ctx->epoch, c.probe_snap[33], c.probe_snap[34]);
+    for (int x = 0; x < 8; ++x) n += snprintf(buf + n, sizeof buf - n, " %u", c.probe_snap[1 + x]);
+    const char *kinds[3] = {"second round's solve waves resident", "second round's straggler waves resident", "first round's straggler waves resident"};
+    for (int k = 0; k < 3; ++k) {
+      n += snprintf(buf + n, sizeof buf - n, " | %s:", kinds[k]);
+      for (int x = 0; x < 8; ++x) n += snprintf(buf + n, sizeof buf - n, " %u", c.probe_snap[9 + 8 * k + x]);
+    }
+    fprintf(stderr, "%s\n", buf);
+  }
   if (c.fallback || c.stuck) {
     {
       // what made the pass give up, kept for lentil_hip_last_redo_note(): `fallback` bits 1 items, 2 result pool, 4 task queue,

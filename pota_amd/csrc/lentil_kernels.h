@@ -62,7 +62,14 @@ struct DevCounters {
   // items an accept with DrawArgs::emit_live has finished / its queue has its end markers (what the solve kernel beside it
   // waits for does not depend on blocks of the accept that have not begun)
   unsigned int accept_items_done[2], accept_final[2];
+  // LENTIL_DISPATCH_PROBE=1 in a library built with -DLENTIL_PROBE_BUILD (development aid, tools/dispatch_probe.sh): per XCD, blocks of the first accept that have begun and waves of the second
+  // round's solve kernel / its stragglers / the first round's stragglers that are resident; and what those read when the
+  // accept's last item was finished with blocks of its grid still not begun (lentil_hip_last_redo_note prints it)
+  unsigned int probe_accept_xcc[8], probe_res_xcc[3][8];
+  unsigned int probe_snap[1 + 8 + 24 + 2];
 };
+
+LD_DEV uint32_t xcc_id() { return (uint32_t)__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u; }      // HW_REG_XCC_ID[3:0]
 
 // per-thread running row range -> one pair of atomics per wave
 LD_DEV void flush_row_range(DevCounters *ctr, uint32_t rmin, uint32_t rmax_p1) {
@@ -2109,6 +2116,7 @@ struct DrawArgs {
   int32_t slow_at;         // Newton iterations after which a solve counts as a straggler
   int32_t slow_max_lanes;  // a dry wave parks only when at most this many of its lanes are still busy
   int32_t slow_prio;       // s_setprio of the straggler kernel's waves (their chains of iterations end the pass; LENTIL_SLOW_PRIO)
+  int32_t dispatch_probe;  // LENTIL_DISPATCH_PROBE: DevCounters::probe_*
   int32_t round;           // solve/accept round of the chunk (0 = first batch)
   int32_t slow_from_round; // parking starts with this round: the first round's own ramp-down hides most of its stragglers
   uint64_t slow_below;     // ... in chunks whose draw sum is below this (where the end of a round is what costs;
@@ -2456,6 +2464,9 @@ __global__ __launch_bounds__(256) LENTIL_SOLVE_ATTR void solve_po_kernel(DrawArg
   const uint32_t lane = lane_id();
   const unsigned long long lt_mask = (1ull << lane) - 1ull;
   if (a.slow_live && a.slow && lane == 0) atomicAdd(&a.ctr->waves_started[par], 1u);
+#ifdef LENTIL_PROBE_BUILD
+  if (kStream && a.dispatch_probe && a.round == 1 && lane == 0) atomicAdd(&a.ctr->probe_res_xcc[0][xcc_id()], 1u);
+#endif
 
   // wave-uniform cursor into the current task
   uint32_t cur_item = 0, cur_m = 0, cur_res = 0, cur_left = 0, cur_chan = 0;
@@ -2757,6 +2768,9 @@ __global__ __launch_bounds__(256) LENTIL_SOLVE_ATTR void solve_po_kernel(DrawArg
   }
   flush_finished();
   if (close_queue) { live_close_queue(a, lane); close_queue = false; }
+#ifdef LENTIL_PROBE_BUILD
+  if (kStream && a.dispatch_probe && a.round == 1 && lane == 0) atomicSub(&a.ctr->probe_res_xcc[0][xcc_id()], 1u);
+#endif
   if (a.slow_live && a.slow && a.slow_close) {
     // Everything this wave parked has arrived.  The straggler queue is closed by whichever wave finds, on leaving, that
     // every wave that has begun has left and every task has been taken (and, streamed, published): no solve can be
@@ -2906,6 +2920,11 @@ struct CoopLens {
 #endif
 __global__ __launch_bounds__(64) LENTIL_SLOW_ATTR void solve_slow_kernel(DrawArgs a) {
   LENTIL_TL_SPAN(a.round == 0 ? SPAN_SLOW_R0 : (a.round == 1 ? SPAN_SLOW_R1 : SPAN_SLOW_R2));
+#ifdef LENTIL_PROBE_BUILD
+  const uint32_t probe_xcc = a.dispatch_probe ? xcc_id() : 0u;
+  const uint32_t probe_kind = a.round == 0 ? 2u : 1u;      // (the first round's stragglers / the second's)
+  if (a.dispatch_probe && threadIdx.x == 0) atomicAdd(&a.ctr->probe_res_xcc[probe_kind][probe_xcc], 1u);
+#endif
   if (a.slow_prio == 1) __builtin_amdgcn_s_setprio(1);
   else if (a.slow_prio == 2) __builtin_amdgcn_s_setprio(2);
   else if (a.slow_prio >= 3) __builtin_amdgcn_s_setprio(3);
@@ -3024,6 +3043,9 @@ __global__ __launch_bounds__(64) LENTIL_SLOW_ATTR void solve_slow_kernel(DrawArg
   if (lane == 0) {
     if (iters) atomicAdd(&a.ctr->newton_iters, iters);
     if (solves) atomicAdd(&a.ctr->slow_solves, solves);
+#ifdef LENTIL_PROBE_BUILD
+    if (a.dispatch_probe) atomicSub(&a.ctr->probe_res_xcc[probe_kind][probe_xcc], 1u);
+#endif
   }
 }
 
@@ -3916,6 +3938,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LENTIL_ACCE
 #endif
   const uint32_t par = (uint32_t)a.parity, nxt = par ^ 1u;
   if (threadIdx.x == 0) atomicAdd(&a.ctr->accept_started[par], 1u);
+#ifdef LENTIL_PROBE_BUILD
+  if (a.dispatch_probe && kMode == 1 && threadIdx.x == 0) atomicAdd(&a.ctr->probe_accept_xcc[xcc_id()], 1u);
+#endif
   if (a.lean_gate && a.ctr->n_tasks[par] != 0u) return;       // (tasks nobody has solved yet: DrawArgs::lean_gate)
   // (a streamed or blind pass whose buffers were too small: nothing is accepted, the host redoes the draws)
   const uint32_t n_active = (a.ctr->fallback || a.ctr->stuck) ? 0u : a.ctr->n_active[par];
@@ -4003,6 +4028,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LENTIL_ACCE
     if (threadIdx.x == 0) s_write_end = (atomicAdd(&a.ctr->accept_items_done[par], cnt) + cnt == n_active) ? 1u : 0u;
     __syncthreads();
     if (s_write_end) write_end_markers();
+#ifdef LENTIL_PROBE_BUILD
+    if (s_write_end && a.dispatch_probe && kMode == 1 && threadIdx.x == 0) {
+      // the pass's last item is done: has every block of this grid begun?  If not, who is resident where
+      const uint32_t begun = ld_coherent32(&a.ctr->accept_started[par]);
+      if (begun < gridDim.x && ld_coherent32(&a.ctr->probe_snap[0]) == 0u) {
+        unsigned int *sn = a.ctr->probe_snap;
+        for (int x = 0; x < 8; ++x) sn[1 + x] = ld_coherent32(&a.ctr->probe_accept_xcc[x]);
+        for (int k = 0; k < 3; ++k) for (int x = 0; x < 8; ++x) sn[9 + 8 * k + x] = ld_coherent32(&a.ctr->probe_res_xcc[k][x]);
+        sn[33] = begun; sn[34] = gridDim.x;
+        sn[0] = 1u;
+      }
+    }
+#endif
   };
   if (kMode != 2 && a.emit_live && !a.inject_stall && n_active == 0u) {
     // nothing to accept: whichever block comes first closes the queue

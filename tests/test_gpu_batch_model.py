@@ -105,13 +105,21 @@ def test_first_batch_model_against_the_oracle(orc, gpu_ctx_factory, lens):
     ref.close()
 
 
-@pytest.mark.parametrize("predict", ["1", "0"])
+@pytest.mark.parametrize("predict", ["1", "0", "0-overlap"])
 def test_streamed_pass_without_a_second_round(orc, monkeypatch, predict):
     """1280 x 720, 256 draws, highlights rare enough for the streamed form.  First pass of the context: chunked.  From the
     second on the pass is streamed, its items' first batches come from the model and no second round of solves is in
     flight behind the first accept (lean tail): one round reported, nothing lost, and the frame is the oracle's draw for
     draw.  LENTIL_PREDICT=0: the plain first batches and the second round, as before -- same frame."""
     W, H, M, S, f_hi = 1280, 720, 9, 256, 2.0 ** -13
+    overlap = predict == "0-overlap"
+    if overlap:
+        # the second round's resident kernels beside the first accept, as in rounds 3-4 (LENTIL_OVERLAP_ACCEPT=1): the queue's end
+        # markers come from the block that finishes the last item -- same frame.  (Should such a pass still stall -- that order
+        # is not the default because it could -- it is redone, says so, and must still give the oracle's frame.)
+        predict = "0"
+        monkeypatch.setenv("LENTIL_OVERLAP_ACCEPT", "1")
+    redone = 0
     monkeypatch.setenv("LENTIL_PREDICT", predict)
     p, model, table, keep = common.po_setup(W, H, samples_override=S)
     streams = [common.make_stream(p, W, H, M, f_hi=f_hi, seed=s) for s in (0x5EED, 0xBEEF)]
@@ -123,7 +131,11 @@ def test_streamed_pass_without_a_second_round(orc, monkeypatch, predict):
             visits, ref = streams[k % 2][0], refs[k % 2]
             c = gpu_run(ctx, p, table, visits)
             rc = ref.counters()
-            assert c.streamed == (1 if k else 0)
+            if overlap and k and c.streamed == 0:
+                assert c.fallback_chunks == 1 and "stuck" in ctx.last_redo_note(), ctx.last_redo_note()
+                redone += 1
+            else:
+                assert c.streamed == (1 if k else 0), ctx.last_redo_note()
             assert (c.redistributed_visits, c.attempted_draws, c.accepted_draws) == (
                 rc.redistributed_visits, rc.attempted_draws, rc.accepted_draws)
             assert rc.attempted_draws > rc.accepted_draws        # some items do lose attempts to the frame's edge
@@ -137,7 +149,7 @@ def test_streamed_pass_without_a_second_round(orc, monkeypatch, predict):
             assert built == 1 and lean >= 3, (built, lean, lost, margin, rounds)
             assert lost == 0 and rounds[-3:] == [1, 1, 1], (lost, margin, rounds)
         else:
-            assert (built, lean) == (0, 0) and min(rounds[1:]) >= 2, (built, lean, rounds)
+            assert (built, lean) == (0, 0) and (redone or min(rounds[1:]) >= 2), (built, lean, rounds)
     finally:
         ctx.close()
         for r in refs:
