@@ -1,0 +1,18 @@
+#!/bin/bash
+cd "$(dirname "$0")/../.."
+O=gpurun_out/r05s42; mkdir -p $O
+export GPU_MAX_HW_QUEUES=8
+B="python3 bench.py --steps 12 --warmup 4 --no-cpu-baseline --no-second-regime --no-configs --no-pcie --no-parity-check --no-scan-alone"
+run() { echo -n "$1 | $2 -> "; env $1 $B $2 2>/dev/null | tail -1 | python3 -c 'import json,sys; d=json.loads(sys.stdin.read()); print(d["ms_per_step"], d["kernels_ms"], d["passes"]["chunks_redone_after_a_short_estimate"], d["passes"]["first_batch_model"]["lean_passes_lost"])'; }
+C4="--lens petzval_58mm --aovs 8"
+for rep in 1 2; do
+  run "X=0" "$C4"
+  run "LENTIL_A_FIRST=1" "$C4"
+  run "LENTIL_A_FIRST=1 LENTIL_SOLVE_B=1" "$C4"
+  run "LENTIL_A_FIRST=1 LENTIL_SOLVE_B=1 LENTIL_SOLVE_B_THREADS=256" "$C4"
+  run "X=0" "--steps 40"
+  run "LENTIL_A_FIRST=1" "--steps 40"
+  run "LENTIL_A_FIRST=1 LENTIL_SOLVE_B=1" "--steps 40"
+done > $O/ab.txt 2>&1
+LENTIL_A_FIRST=1 LENTIL_SOLVE_B=1 python3 tools/timeline.py --lens petzval_58mm --aovs 8 --passes 5 --out $O/timeline_c4_afirst_b.txt > $O/tl_b.log 2>&1
+LENTIL_A_FIRST=1 LENTIL_SOLVE_B=1 LENTIL_SOLVE_B_THREADS=256 python3 tools/timeline.py --lens petzval_58mm --aovs 8 --passes 5 --out $O/timeline_c4_afirst_b256.txt > $O/tl_b256.log 2>&1
