@@ -538,6 +538,12 @@ int lentil_hip_last_launches(lentil_hip_ctx *ctx, uint32_t n[2]);
  * out[n][4] = share of the passing aperture points that land well inside the frame, share that land inside it, share the lens
  * vignettes, traces in the first batch.  LENTIL_ERR_INVALID without a polynomial-optics lens and parameters. */
 int lentil_hip_batch_model_stats(lentil_hip_ctx *ctx, uint64_t stats[4]);
+/* What the streamed passes of ALL contexts of this process have met (no context needed): stats[0] streamed passes begun,
+ * [1] passes whose resident waves gave up waiting (the stuck time-out; the pass is then redone in the chunked form and its
+ * result is the same), [2] ... of which were asked for (LENTIL_INJECT_STALL), [3] passes wiped and run again because draws
+ * had been accepted by then.  A stall costs time, never results -- so nothing else would ever show one: the GPU test
+ * session asserts stats[1] == stats[2] when it ends (tests/conftest.py). */
+int lentil_hip_process_stats(uint64_t stats[4]);
 int lentil_hip_debug_batch_estimate(lentil_hip_ctx *ctx, uint64_t n, const float *cs_xyz, uint32_t samples, float *out);
 int lentil_hip_set_draw_log(lentil_hip_ctx *ctx, uint64_t capacity); /* 0 disables */
 int lentil_hip_download_draw_log(lentil_hip_ctx *ctx, lentil_draw_record *out, uint64_t capacity,

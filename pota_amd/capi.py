@@ -23,7 +23,7 @@ EXPORTS = [
     "lentil_hip_touched_rows", "lentil_hip_merge_rows", "lentil_hip_resolve_rows",
     "lentil_hip_pack_rows", "lentil_hip_merge_packed_rows", "lentil_hip_compact_rows", "lentil_hip_merge_sparse",
     "lentil_hip_get_counters", "lentil_hip_last_timing", "lentil_hip_last_launches", "lentil_hip_set_draw_log",
-    "lentil_hip_batch_model_stats", "lentil_hip_debug_batch_estimate", "lentil_hip_box_probe",
+    "lentil_hip_batch_model_stats", "lentil_hip_process_stats", "lentil_hip_debug_batch_estimate", "lentil_hip_box_probe",
     "lentil_hip_lens_jit_status", "lentil_hip_lens_jit_wait", "lentil_hip_debug_lens_jit_source", "lentil_hip_debug_lens_jit_compile",
     "lentil_hip_download_draw_log", "lentil_hip_test_lt_sample_aperture",
     "lentil_hip_test_trace_bw_po", "lentil_hip_test_aperture_sample", "lentil_hip_debug_scan_bands",
@@ -39,6 +39,16 @@ EXPORTS = [
 ]
 
 _lib = None
+
+
+def process_stats():
+    """(streamed passes begun, passes that hit the stuck time-out, ... of which injected, passes wiped and run again) -- all contexts of this process"""
+    lib = load_library()
+    n = (C.c_uint64 * 4)()
+    rc = lib.lentil_hip_process_stats(n)
+    if rc:
+        raise RuntimeError("lentil_hip_process_stats: %d" % rc)
+    return tuple(int(x) for x in n)
 
 
 class LentilError(RuntimeError):
@@ -102,6 +112,7 @@ def load_library():
         "lentil_hip_last_timing": (i, [vp, C.POINTER(C.c_float)]),
         "lentil_hip_last_launches": (i, [vp, C.POINTER(C.c_uint32)]),
         "lentil_hip_batch_model_stats": (i, [vp, C.POINTER(C.c_uint64)]),
+        "lentil_hip_process_stats": (i, [C.POINTER(C.c_uint64)]),
         "lentil_hip_box_probe": (i, [vp, C.POINTER(C.c_double)]),
         "lentil_hip_lens_jit_status": (i, [vp, C.POINTER(C.c_int), C.POINTER(C.c_double)]),
         "lentil_hip_lens_jit_wait": (i, [vp, C.c_double]),

@@ -3,6 +3,7 @@
 #include <hip/hip_ext.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -150,6 +151,7 @@ struct lentil_hip_ctx {
   // same time, and a CU that does both does the solves at two waves per SIMD with the scan's waves in between.
   // LENTIL_SCAN_CUS_PCT.
   double longest_pass_ms = 0.0;              // the longest streamed pass of this context so far (host time; sizes the stuck time-out)
+  uint64_t longest_pass_visits = 0, longest_pass_sum = 0;      // ... and how large that pass was (visits, draws expected)
   int scan_cus_pct = 84;                     // (100 / 92 / 84 / 76: 2.10 / 2.12 / 2.02 / 2.04 ms, means of four runs of 60 steps on one box)
   int scan_cus_pct_multi = 100;              // ... for frames with extra AOV columns (scan_dma_multi_kernel): LENTIL_SCAN_CUS_PCT_MULTI
   unsigned last_scan_skipped = 0;             // blocks of the last scan launch that left at once (scan_dma2_kernel, ScanArgs::skip_blocks)
@@ -272,6 +274,12 @@ static void apply_camera_motion(lentil_hip_ctx *ctx);
 // output, and the waves of two such passes can fill the CUs' register files between them before either scan is
 // placed (contexts driven from several threads; across processes the bounded wait and the chunked redo catch it).
 static std::mutex g_stream_mutex[64];
+
+// What every context of this process has seen (lentil_hip_process_stats): streamed passes begun, passes whose resident waves hit
+// the stuck time-out, how many of those were asked for (LENTIL_INJECT_STALL), passes redone after draws had been accepted.  A
+// stalled pass is redone and its result is correct -- which is exactly why it needs a number somebody can assert on: the
+// GPU suite's session ends with "no stall that was not injected" (tests/conftest.py).
+static std::atomic<uint64_t> g_stat_streamed{0}, g_stat_stuck{0}, g_stat_stuck_injected{0}, g_stat_redone{0};
 
 static int fail(lentil_hip_ctx *ctx, int code, const std::string &msg) {
   if (ctx) ctx->err = msg; else g_err = msg;
@@ -714,21 +722,49 @@ static bool pack_terms(const lentil_lens_table *t, const lentil_poly &p, int der
 }
 
 // ---- run-time lens specialisation (lentil_lens_jit.h) -----------------------------------------------------------------
-static const std::vector<std::string> &jit_flags() {
-  // (the flags __graft_entry__.build() compiles the library with: same arithmetic, same code generation)
-  static const std::vector<std::string> f = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off",
-                                              "-fhip-fp32-correctly-rounded-divide-sqrt", "-munsafe-fp-atomics"};
+// The flags the library itself was built with (kBuildFlags, written into generated/embedded_sources.inc by
+// __graft_entry__.build() from its own HIP_FLAGS: same arithmetic, same code generation, same -D set), for the architecture
+// of the context's device.
+static std::vector<std::string> jit_flags(const std::string &arch) {
+  std::vector<std::string> f = {"--offload-arch=" + arch};
+  for (const char *b : kBuildFlags) f.push_back(b);
   return f;
 }
-static uint64_t jit_source_hash() {
-  static const uint64_t h = [] {
-    uint64_t v = lentil_jit::fnv("lentil-jit-1", 12);
-    for (const lentil_jit::Source &s : kEmbeddedSources) v = lentil_jit::fnv(s.text, strlen(s.text), v);
-    for (const std::string &f : jit_flags()) v = lentil_jit::fnv(f.data(), f.size(), v);
-    return v;
-  }();
-  return h;
+// the layouts the run-time kernels share with this library, checked inside their translation unit
+static std::string jit_layout_checks() {
+  char b[512];
+  snprintf(b, sizeof b,
+           "static_assert(sizeof(DrawArgs) == %zu, \"DrawArgs differs from the library's\");\n"
+           "static_assert(sizeof(DevCounters) == %zu, \"DevCounters differs from the library's\");\n"
+           "static_assert(sizeof(SlowRec) == %zu && sizeof(Task) == %zu && sizeof(ItemProg) == %zu, \"queue records differ from the library's\");\n",
+           sizeof(DrawArgs), sizeof(DevCounters), sizeof(SlowRec), sizeof(Task), sizeof(ItemProg));
+  return b;
 }
+static std::string device_arch(int device) {
+  hipDeviceProp_t pr;
+  if (hipGetDeviceProperties(&pr, device) != hipSuccess) { (void)hipGetLastError(); return "gfx950"; }
+  std::string a = pr.gcnArchName;
+  const size_t c = a.find(':');        // (target features -- sramecc, xnack -- stay the compiler's defaults, as in the library's build)
+  if (c != std::string::npos) a.resize(c);
+  return a.empty() ? std::string("gfx950") : a;
+}
+// what a cached code object must have been built from: the kernel sources, the flags, the architecture, the compiler
+static uint64_t jit_source_hash(const std::string &arch) {
+  static const uint64_t base = [] {
+    uint64_t v = lentil_jit::fnv("lentil-jit-2", 12);
+    for (const lentil_jit::Source &s : kEmbeddedSources) v = lentil_jit::fnv(s.text, strlen(s.text), v);
+    for (const char *f : kBuildFlags) v = lentil_jit::fnv(f, strlen(f), v);
+    const std::string chk = jit_layout_checks();
+    v = lentil_jit::fnv(chk.data(), chk.size(), v);
+    int ver[2] = {0, 0};
+    lentil_jit::Rtc &r = lentil_jit::rtc();
+    if (r.Version) (void)r.Version(&ver[0], &ver[1]);
+    return lentil_jit::fnv(ver, sizeof ver, v);
+  }();
+  return lentil_jit::fnv(arch.data(), arch.size(), base);
+}
+// (the library going away -- process exit, dlclose of the plugin: no compilation may still be running inside it)
+__attribute__((destructor)) static void lentil_jit_teardown() { lentil_jit::join_all(); }
 static bool lens_is_compiled_in(unsigned long long hash) {
 #define LENTIL_HASH_MATCH(NAME) if (hash == gen::Lens_##NAME::kTableHash) return true;
   LENTIL_GENERATED_LENSES(LENTIL_HASH_MATCH)
@@ -741,25 +777,45 @@ static void jit_request(lentil_hip_ctx *ctx) {
   ctx->jit.reset();
   ctx->jit_loaded = ctx->jit_load_failed = false;
   if (!ctx->jit_enabled || lens_is_compiled_in(ctx->lens_hash)) return;
+  // everything that reads the environment or the device happens here, on the caller's thread (the host may call setenv
+  // while a compilation runs): the architecture, hiprtc's binding, the cache directory, the debug switch
+  const std::string arch = device_arch(ctx->device);
+  (void)lentil_jit::rtc();
+  const bool debug = getenv("LENTIL_STREAM_DEBUG") != nullptr;
+  const uint64_t key = lentil_jit::fnv(arch.data(), arch.size(), ctx->lens_hash);       // (one entry per table and architecture)
   std::lock_guard<std::mutex> lock(lentil_jit::registry_mutex());
   auto &reg = lentil_jit::registry();
-  auto it = reg.find(ctx->lens_hash);
+  auto it = reg.find(key);
   if (it != reg.end()) { ctx->jit = it->second; return; }
   auto e = std::make_shared<lentil_jit::Entry>();
-  reg[ctx->lens_hash] = e;
+  reg[key] = e;
   ctx->jit = e;
-  const std::string path = lentil_jit::cache_path(ctx->lens_hash, jit_source_hash());
+  const std::string path = lentil_jit::cache_file(lentil_jit::cache_dir(true), ctx->lens_hash, jit_source_hash(arch));
   if (lentil_jit::cache_load(path, e->co)) { e->from_cache = true; e->state.store(lentil_jit::Entry::kReady); return; }
   const std::string src = lentil_jit::lens_jit_emit(ctx->hlens, ctx->h_terms, ctx->lens_hash);
-  std::thread([e, src, path]() {
-    const auto t0 = std::chrono::steady_clock::now();
-    std::vector<lentil_jit::Source> sources(std::begin(kEmbeddedSources), std::end(kEmbeddedSources));
-    const bool ok = lentil_jit::compile(sources, src, jit_flags(), e->co, e->log);
-    e->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-    if (ok) lentil_jit::cache_store(path, e->co);
-    if (!ok && getenv("LENTIL_STREAM_DEBUG")) fprintf(stderr, "[lens jit] compilation failed:\n%s\n", e->log.c_str());
-    e->state.store(ok ? lentil_jit::Entry::kReady : lentil_jit::Entry::kFailed);
-  }).detach();
+  const std::vector<std::string> flags = jit_flags(arch);
+  const std::string checks = jit_layout_checks();
+  lentil_jit::Entry *ep = e.get();       // (the registry keeps the entry alive for as long as the library is mapped)
+  try {
+    e->worker = std::thread([ep, src, path, flags, checks, debug]() {
+      bool ok = false;
+      try {
+        const auto t0 = std::chrono::steady_clock::now();
+        std::vector<lentil_jit::Source> sources(std::begin(kEmbeddedSources), std::end(kEmbeddedSources));
+        ok = lentil_jit::compile(sources, src, flags, ep->co, ep->log, checks);
+        ep->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        if (ok) lentil_jit::cache_store(path, ep->co);
+        if (!ok && debug) fprintf(stderr, "[lens jit] compilation failed:\n%s\n", ep->log.c_str());
+      } catch (...) {       // (bad_alloc in a string or vector: the interpreter keeps serving the lens)
+        ok = false;
+        try { ep->log = "run-time compilation threw an exception"; } catch (...) {}
+      }
+      ep->state.store(ok ? lentil_jit::Entry::kReady : lentil_jit::Entry::kFailed);
+    });
+  } catch (...) {           // (no thread to be had)
+    e->log = "could not start the compilation thread";
+    e->state.store(lentil_jit::Entry::kFailed);
+  }
 }
 // the compiled kernels for this context's device, once the code object is there (null: not yet / not at all)
 static hipFunction_t jit_function(lentil_hip_ctx *ctx, bool chroma, bool stream) {
@@ -918,7 +974,7 @@ LENTIL_API int lentil_hip_debug_lens_jit_compile(const lentil_lens_table *t, int
   std::string lg;
   const auto t0 = std::chrono::steady_clock::now();
   std::vector<lentil_jit::Source> sources(std::begin(kEmbeddedSources), std::end(kEmbeddedSources));
-  const bool cok = lentil_jit::compile(sources, src, jit_flags(), co, lg);
+  const bool cok = lentil_jit::compile(sources, src, jit_flags("gfx950"), co, lg, jit_layout_checks());
   if (seconds) *seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   put(lg, log, log_capacity, nullptr);
   if (code_bytes) *code_bytes = co.code.size();
@@ -2005,6 +2061,7 @@ static int redistribute_streamed(lentil_hip_ctx *ctx, bool *streamed) {
   DrawArgs da{};
   init_draw_args(ctx, da);
   ++ctx->n_streamed;
+  g_stat_streamed.fetch_add(1, std::memory_order_relaxed);
   da.inject_stall = (ctx->inject_stall_at > 0 && ctx->n_streamed == (uint64_t)ctx->inject_stall_at) ? 1 : 0;
   const uint64_t nch = (uint64_t)da.n_channels;
   uint64_t items = 2 * ctx->est_items_total + 4096;
@@ -2043,9 +2100,16 @@ static int redistribute_streamed(lentil_hip_ctx *ctx, bool *streamed) {
   uint64_t stuck_ticks = 0;
   {
     static const double forced_ms = getenv("LENTIL_STUCK_MS") ? atof(getenv("LENTIL_STUCK_MS")) : 0.0;
-    double ms = ctx->longest_pass_ms > 0.0 ? 16.0 * ctx->longest_pass_ms : 250.0;
-    if (ms < 30.0) ms = 30.0;
-    if (ms > 250.0) ms = 250.0;
+    // (the estimate comes from earlier passes: it holds for a pass no larger than the one that set it -- more visits, or a
+    // quarter more draws expected, and nothing is known again: 250 ms -- and every time-out this context has hit doubles it,
+    // so that a slow box, a shared GPU or a profiler does not turn into a run of false stalls, each a wipe and a chunked redo)
+    double ms = 250.0;
+    if (ctx->longest_pass_ms > 0.0 && ctx->V.n <= ctx->longest_pass_visits &&
+        ctx->est_sum_total <= ctx->longest_pass_sum + ctx->longest_pass_sum / 4) {
+      ms = 16.0 * ctx->longest_pass_ms * (double)(1u << (ctx->n_stuck < 4 ? ctx->n_stuck : 4));
+      if (ms < 30.0) ms = 30.0;
+      if (ms > 250.0) ms = 250.0;
+    }
     if (forced_ms > 0.0) ms = forced_ms;
     stuck_ticks = (uint64_t)(ms * 1.0e5);
   }
@@ -2540,7 +2604,9 @@ static int redistribute_streamed(lentil_hip_ctx *ctx, bool *streamed) {
   {
     // (host time from the pass's first launch to its counters: an upper bound of every wait inside it)
     const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - pass_t0).count();
-    if (!calibrates_now && ms > ctx->longest_pass_ms && ms < 200.0) ctx->longest_pass_ms = ms;
+    if (!calibrates_now && ms > ctx->longest_pass_ms && ms < 200.0) {
+      ctx->longest_pass_ms = ms; ctx->longest_pass_visits = ctx->V.n; ctx->longest_pass_sum = ctx->est_sum_total;
+    }
   }
   if (tail != ctx->stream) {
     // everything the pass enqueued anywhere is behind the read-back that has just arrived; what the caller enqueues on
@@ -2606,6 +2672,10 @@ static int redistribute_streamed(lentil_hip_ctx *ctx, bool *streamed) {
       fprintf(stderr, "[stream] stragglers: live %d waves_done %u/%u (round 1: %u) parked %u/%u heads %u/%u cap %u waves %u rounds_used %llu\n", (int)live,
               c.waves_done[0], c.waves_started[0], c.waves_done[1], c.n_slow[0], c.n_slow[1], c.slow_head[0], c.slow_head[1],
               da.slow_cap, da.slow_waves, c.rounds_used);
+    if (c.stuck) {
+      g_stat_stuck.fetch_add(1, std::memory_order_relaxed);
+      if (da.inject_stall) g_stat_stuck_injected.fetch_add(1, std::memory_order_relaxed);
+    }
     if (c.stuck && c.rounds_used) {
       // Stalled with draws already accepted: the frame holds a part of the pass.  It held nothing before (the gate at the
       // top), so lentil_hip_redistribute wipes it and runs the whole pass again in the chunked form.
@@ -2852,6 +2922,9 @@ LENTIL_API int lentil_hip_redistribute(lentil_hip_ctx *ctx) {
     const int rc0 = lentil_hip_set_draw_log(ctx, ctx->closest_auto_log_cap);
     if (rc0) return rc0;
   }
+  // (per-pass host state the pass advances: should the pass be run a second time below, it starts from the same state)
+  uint32_t xor_entry[4];
+  memcpy(xor_entry, ctx->xor_state, sizeof xor_entry);
   ht_mark(ctx, "pass{");
   int rc = redistribute_impl(ctx);
   ht_mark(ctx, "}pass");
@@ -2861,15 +2934,17 @@ LENTIL_API int lentil_hip_redistribute(lentil_hip_ctx *ctx) {
     return fail(ctx, LENTIL_ERR_UNSUPPORTED, "a sample with depth (Z) 0 or NaN competes for a closest-filtered AOV: the reference's result there "
                                              "depends on the order of the samples at the pixel (src/lentil.h:832-837), which the exchange "
                                              "between GPUs does not keep; the pass is refused");
+  // The replay walks ONE pass's candidates -- the bound visits and this pass's draw log -- in visit order: a frame that already
+  // held an earlier pass's candidates (no clear in between) cannot be replayed from them, with or without a log.
+  if (!clean_entry)
+    return fail(ctx, LENTIL_ERR_UNSUPPORTED, "a sample with depth (Z) 0 or NaN competes for a closest-filtered AOV in a frame that was not cleared "
+                                             "before this pass: the reference's result depends on the order of ALL candidates at the pixel "
+                                             "(src/lentil.h:832-837), and an earlier pass's are gone; clear the frame before the pass");
   bool need_log = false;
   if ((rc = closest_degenerate_replay(ctx, &need_log))) return rc;
   if (!need_log) return LENTIL_OK;
   // no (complete) draw log to replay from.  The frame held nothing before this pass: a log sized from the pass's counters,
   // the frame wiped, the pass once more -- and a log from the start in every later pass of this context.
-  if (!clean_entry)
-    return fail(ctx, LENTIL_ERR_UNSUPPORTED, "a sample with depth (Z) 0 or NaN competes for a closest-filtered AOV and the pass kept no complete draw "
-                                             "log to replay its pixel's samples from (src/lentil.h:832-837): set one with lentil_hip_set_draw_log "
-                                             "(capacity >= the pass's accepted draws), or clear the frame before the pass");
   unsigned long long accepted = 0;
   for (const DevCounters &k : ctx->h_ctr) accepted += k.accepted;
   ctx->closest_auto_log = true;
@@ -2877,7 +2952,12 @@ LENTIL_API int lentil_hip_redistribute(lentil_hip_ctx *ctx) {
   if ((rc = lentil_hip_set_draw_log(ctx, ctx->closest_auto_log_cap))) return rc;
   if ((rc = lentil_hip_clear_frame(ctx))) return rc;
   ctx->degenerate_seen = false;
+  memcpy(ctx->xor_state, xor_entry, sizeof xor_entry);       // (thin lens, abb_chromatic > 0: the same colour channels as the first run)
   if ((rc = redistribute_impl(ctx))) return rc;
+  // (counters and timing describe the second run; that there were two is reported like any pass that was redone)
+  ++ctx->last_fallback;
+  ctx->redo_note = "the pass was run twice: candidates at depth 0 / NaN compete for a closest-filtered AOV and the first run kept no draw log "
+                   "to replay their pixels from (lentil_closest_replay.h); later passes of this context keep one from the start";
   if (!ctx->degenerate_seen) return LENTIL_OK;
   if ((rc = closest_degenerate_replay(ctx, &need_log))) return rc;
   if (need_log) return fail(ctx, LENTIL_ERR_NOMEM, "closest-AOV replay: the draw log did not hold the pass's accepted draws");
@@ -2894,6 +2974,7 @@ static int redistribute_impl(lentil_hip_ctx *ctx) {
   // accumulators through the splat flags, direct sums, cryptomatte -- and run the whole pass once more, chunked.
   ctx->stall_redo = false;
   ++ctx->n_stall_redone;
+  g_stat_redone.fetch_add(1, std::memory_order_relaxed);
   if (getenv("LENTIL_STREAM_DEBUG")) fprintf(stderr, "[stream] stalled after the first accept: frame wiped, pass run again chunked\n");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   for (hipStream_t st : {ctx->stream, ctx->chunks[0].stream, ctx->pub_stream, ctx->slow1_stream, ctx->aux_stream})
@@ -3717,6 +3798,12 @@ LENTIL_API int lentil_hip_box_probe(lentil_hip_ctx *ctx, double probe[6]) {
   if (ev[1]) (void)hipEventDestroy(ev[1]);
   (void)hipFree(a); (void)hipFree(b); (void)hipFree(clk);
   if (e != hipSuccess) return fail(ctx, LENTIL_ERR_HIP, std::string("box probe: ") + hipGetErrorString(e));
+  return LENTIL_OK;
+}
+
+LENTIL_API int lentil_hip_process_stats(uint64_t stats[4]) {
+  if (!stats) return LENTIL_ERR_INVALID;
+  stats[0] = g_stat_streamed.load(); stats[1] = g_stat_stuck.load(); stats[2] = g_stat_stuck_injected.load(); stats[3] = g_stat_redone.load();
   return LENTIL_OK;
 }
 

@@ -13,12 +13,14 @@
 //   hiprtc            (bound at run time: dlopen, like RCCL) compiles solve_po_kernel<GenLens<Lens_rt>, ...> -- the four
 //                     instances a pass can launch -- from the library's own kernel sources, which ride inside the .so
 //                     (generated/embedded_sources.inc, written by __graft_entry__.build());
-//   a cache           of code objects on disk, keyed by the table's hash and the hash of the sources and flags;
-//   a thread          per compilation: lentil_hip_set_lens returns at once, passes run the interpreter until the code object is
+//   a cache           of code objects on disk, in a directory private to the caller, keyed by the table's hash and the hash of
+//                     the sources, the flags, the compiler's version and the device's architecture; every file checksummed;
+//   a thread          per compilation (owned by the table's entry, joined when the library goes away): lentil_hip_set_lens returns at once, passes run the interpreter until the code object is
 //                     there (~15 s the first time a table is seen, milliseconds from the cache) and the compiled kernel after.
 // Bit-identical results either way (tests/test_gpu_lens_jit.py); LENTIL_LENS_JIT=0 switches it off.
 #pragma once
 #include <dlfcn.h>
+#include <fcntl.h>
 #include <sys/stat.h>
 #include <unistd.h>
 
@@ -247,6 +249,7 @@ struct Rtc {
   int (*GetCodeSize)(void *, size_t *) = nullptr;
   int (*GetCode)(void *, char *) = nullptr;
   int (*DestroyProgram)(void **) = nullptr;
+  int (*Version)(int *, int *) = nullptr;
   bool ok = false;
 };
 static inline Rtc &rtc() {
@@ -262,7 +265,7 @@ static inline Rtc &rtc() {
     if (!r.lib) return;
 #define LENTIL_RTC_SYM(F) *(void **)(&r.F) = dlsym(r.lib, "hiprtc" #F)
     LENTIL_RTC_SYM(CreateProgram); LENTIL_RTC_SYM(AddNameExpression); LENTIL_RTC_SYM(CompileProgram); LENTIL_RTC_SYM(GetProgramLogSize);
-    LENTIL_RTC_SYM(GetProgramLog); LENTIL_RTC_SYM(GetLoweredName); LENTIL_RTC_SYM(GetCodeSize); LENTIL_RTC_SYM(GetCode); LENTIL_RTC_SYM(DestroyProgram);
+    LENTIL_RTC_SYM(GetProgramLog); LENTIL_RTC_SYM(GetLoweredName); LENTIL_RTC_SYM(GetCodeSize); LENTIL_RTC_SYM(GetCode); LENTIL_RTC_SYM(DestroyProgram); LENTIL_RTC_SYM(Version);
 #undef LENTIL_RTC_SYM
     r.ok = r.CreateProgram && r.AddNameExpression && r.CompileProgram && r.GetProgramLogSize && r.GetProgramLog && r.GetLoweredName &&
            r.GetCodeSize && r.GetCode && r.DestroyProgram;
@@ -289,8 +292,10 @@ struct CodeObject {
 struct Source { const char *name; const char *text; };
 
 // sources: the library's own headers (embedded_sources.inc); lens_src: lens_jit_emit's output
+// checks: lines appended to the translation unit (static_asserts that the structs the kernels share with the library have the
+// library's own sizes: a kernel built from other sources or macros would otherwise agree with it by layout only)
 static inline bool compile(const std::vector<Source> &sources, const std::string &lens_src, const std::vector<std::string> &flags,
-                           CodeObject &out, std::string &log) {
+                           CodeObject &out, std::string &log, const std::string &checks = std::string()) {
   Rtc &r = rtc();
   if (!r.ok) { log = "hiprtc is not available (libhiprtc.so)"; return false; }
   std::vector<std::string> texts;
@@ -315,7 +320,7 @@ static inline bool compile(const std::vector<Source> &sources, const std::string
   names.push_back("stdint.h"); bodies.push_back(kStdint);
   names.push_back("stddef.h"); bodies.push_back(kEmpty);
   names.push_back("hip/hip_runtime.h"); bodies.push_back(kEmpty);
-  std::string tu = "#include \"lentil_kernels.h\"\n";
+  std::string tu = "#include \"lentil_kernels.h\"\n" + checks;
   for (int c = 0; c < 2; ++c)
     for (int s = 0; s < 2; ++s) tu += std::string("template __global__ void ") + kInstance[c][s] + "(DrawArgs);\n";
   void *prog = nullptr;
@@ -344,28 +349,54 @@ static inline bool compile(const std::vector<Source> &sources, const std::string
   return ok;
 }
 
-// ---- the cache on disk: <dir>/<table hash>_<source hash>.lco = "LCO1", 4 x (u32 length, name), u64 size, code ----------------
-static inline std::string cache_dir() {
-  if (const char *e = getenv("LENTIL_JIT_CACHE")) return e;
+// ---- the cache on disk: <dir>/<table hash>_<source hash>.lco = "LCO2", u64 checksum, 4 x (u32 length, name), u64 size, code ------
+// The directory is the caller's own and nobody else's: LENTIL_JIT_CACHE, $XDG_CACHE_HOME/lentil_hip, $HOME/.cache/lentil_hip, or
+// /tmp/lentil_hip_<uid>; created 0700, and used only if it is a directory (not a link) that the caller owns and that neither its
+// group nor others can write to.  Without such a directory there is no disk cache (every process compiles for itself).  A file is
+// loaded only if it is a regular file with the same owner and permissions and its checksum (FNV-1a over names and code) holds:
+// what is read here is handed to hipModuleLoadData and runs on the GPU inside the render.
+static inline std::string cache_dir_wanted() {
+  if (const char *e = getenv("LENTIL_JIT_CACHE")) if (e[0]) return e;
   if (const char *e = getenv("XDG_CACHE_HOME")) if (e[0]) return std::string(e) + "/lentil_hip";
   if (const char *e = getenv("HOME")) if (e[0]) return std::string(e) + "/.cache/lentil_hip";
-  return "/tmp/lentil_hip_cache";
+  return "/tmp/lentil_hip_" + std::to_string((unsigned long long)geteuid());
 }
-static inline void mkdirs(const std::string &p) {
-  for (size_t i = 1; i <= p.size(); ++i)
-    if (i == p.size() || p[i] == '/') (void)mkdir(p.substr(0, i).c_str(), 0755);
+static inline bool private_to_caller(const struct stat &st) { return st.st_uid == geteuid() && (st.st_mode & (S_IWGRP | S_IWOTH)) == 0; }
+// the directory if it can be trusted (created on the way when `create`), "" otherwise
+static inline std::string cache_dir(bool create) {
+  const std::string p = cache_dir_wanted();
+  if (p.empty()) return "";
+  if (create)
+    for (size_t i = 1; i <= p.size(); ++i)
+      if (i == p.size() || p[i] == '/') (void)mkdir(p.substr(0, i).c_str(), 0700);      // (parents that exist keep their modes)
+  struct stat st;
+  if (lstat(p.c_str(), &st) != 0 || !S_ISDIR(st.st_mode) || !private_to_caller(st)) return "";
+  return p;
 }
-static inline std::string cache_path(uint64_t table_hash, uint64_t source_hash) {
+static inline std::string cache_file(const std::string &dir, uint64_t table_hash, uint64_t source_hash) {
+  if (dir.empty()) return "";
   char b[64];
   snprintf(b, sizeof b, "/%016llx_%016llx.lco", (unsigned long long)table_hash, (unsigned long long)source_hash);
-  return cache_dir() + b;
+  return dir + b;
+}
+static inline uint64_t code_checksum(const CodeObject &co) {
+  uint64_t h = fnv("lco2", 4);
+  for (int c = 0; c < 2; ++c)
+    for (int s = 0; s < 2; ++s) h = fnv(co.name[c][s].data(), co.name[c][s].size(), h);
+  return fnv(co.code.data(), co.code.size(), h);
 }
 static inline bool cache_load(const std::string &path, CodeObject &out) {
-  FILE *f = fopen(path.c_str(), "rb");
-  if (!f) return false;
+  if (path.empty()) return false;
+  const int fd = open(path.c_str(), O_RDONLY | O_NOFOLLOW | O_CLOEXEC);
+  if (fd < 0) return false;
+  struct stat st;
+  if (fstat(fd, &st) != 0 || !S_ISREG(st.st_mode) || !private_to_caller(st)) { close(fd); return false; }
+  FILE *f = fdopen(fd, "rb");
+  if (!f) { close(fd); return false; }
   bool ok = false;
   char magic[4];
-  if (fread(magic, 1, 4, f) == 4 && memcmp(magic, "LCO1", 4) == 0) {
+  uint64_t sum = 0;
+  if (fread(magic, 1, 4, f) == 4 && memcmp(magic, "LCO2", 4) == 0 && fread(&sum, 8, 1, f) == 1) {
     ok = true;
     for (int c = 0; c < 2 && ok; ++c)
       for (int s = 0; s < 2 && ok; ++s) {
@@ -376,16 +407,21 @@ static inline bool cache_load(const std::string &path, CodeObject &out) {
     uint64_t cs = 0;
     ok = ok && fread(&cs, 8, 1, f) == 1 && cs > 0 && cs < (1ull << 30);
     if (ok) { out.code.resize(cs); ok = fread(out.code.data(), 1, cs, f) == cs; }
+    ok = ok && code_checksum(out) == sum;
   }
   fclose(f);
+  if (!ok) { out.code.clear(); for (int c = 0; c < 2; ++c) for (int s = 0; s < 2; ++s) out.name[c][s].clear(); }
   return ok;
 }
 static inline void cache_store(const std::string &path, const CodeObject &co) {
-  mkdirs(cache_dir());
+  if (path.empty()) return;
   const std::string tmp = path + ".tmp" + std::to_string((long long)getpid());
-  FILE *f = fopen(tmp.c_str(), "wb");
-  if (!f) return;
-  bool ok = fwrite("LCO1", 1, 4, f) == 4;
+  const int fd = open(tmp.c_str(), O_WRONLY | O_CREAT | O_EXCL | O_NOFOLLOW | O_CLOEXEC, 0600);
+  if (fd < 0) return;
+  FILE *f = fdopen(fd, "wb");
+  if (!f) { close(fd); (void)remove(tmp.c_str()); return; }
+  const uint64_t sum = code_checksum(co);
+  bool ok = fwrite("LCO2", 1, 4, f) == 4 && fwrite(&sum, 8, 1, f) == 1;
   for (int c = 0; c < 2 && ok; ++c)
     for (int s = 0; s < 2 && ok; ++s) {
       const uint32_t n = (uint32_t)co.name[c][s].size();
@@ -406,8 +442,23 @@ struct Entry {
   std::string log;
   double seconds = 0.0;
   bool from_cache = false;
-};      // (the worker thread is detached and holds a reference of its own: an entry outlives whoever asked for it)
-static inline std::mutex &registry_mutex() { static std::mutex m; return m; }
-static inline std::map<uint64_t, std::shared_ptr<Entry>> &registry() { static std::map<uint64_t, std::shared_ptr<Entry>> r; return r; }
+  std::thread worker;       // the compilation, if one was started: joined by join_all() (library teardown) -- never detached
+};
+// (both live for as long as the library is mapped and are never destroyed: the teardown hook below walks them after the
+// process's static destructors may already have run)
+static inline std::mutex &registry_mutex() { static std::mutex *m = new std::mutex; return *m; }
+static inline std::map<uint64_t, std::shared_ptr<Entry>> &registry() { static auto *r = new std::map<uint64_t, std::shared_ptr<Entry>>; return *r; }
+// Waits for every compilation still running.  Called when the library goes away (a destructor function of the .so: process
+// exit and dlclose) -- a compiling thread is inside libhiprtc / comgr and this library's own code, neither of which may be
+// unmapped or torn down under it.  hiprtc has no way to cancel a compilation; the wait is its remaining seconds.
+static inline void join_all() {
+  std::vector<std::shared_ptr<Entry>> all;
+  {
+    std::lock_guard<std::mutex> lock(registry_mutex());
+    for (auto &kv : registry()) all.push_back(kv.second);
+  }
+  for (auto &e : all)
+    if (e->worker.joinable() && e->worker.get_id() != std::this_thread::get_id()) e->worker.join();
+}
 
 }  // namespace lentil_jit

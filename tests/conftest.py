@@ -17,6 +17,18 @@ def pytest_configure(config):
 def _built():
     import __graft_entry__ as g
     g.build()
+    yield
+    # A streamed pass whose resident waves give up waiting is run again and its result is right -- so nothing but this would
+    # ever fail on a stall: at the end of the session every time-out the library counted must be one a test asked for
+    # (LENTIL_INJECT_STALL).  (Contexts are closed by now; the count is the process's.)
+    try:
+        from pota_amd import capi
+        streamed, stuck, injected, redone = capi.process_stats()
+    except Exception:          # (no library: the tests that need it have said so)
+        return
+    assert stuck == injected, ("%d of this session's %d streamed passes hit the stuck time-out without a test asking for it "
+                               "(%d asked for; %d passes wiped and run again): a stall -- see lentil_hip_last_redo_note"
+                               % (stuck - injected, streamed, injected, redone))
 
 
 @pytest.fixture(scope="session")

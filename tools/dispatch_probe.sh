@@ -10,11 +10,8 @@ SO=pota_amd/_ab/liblentil_hip_probe.so
 if [ "$1" = "build" ]; then
   mkdir -p pota_amd/_ab
   python3 - <<'PY'
-import subprocess, os
 import __graft_entry__ as g
-root = os.getcwd()
-subprocess.check_call([g.HIPCC] + g.HIP_FLAGS + ["-DLENTIL_PROBE_BUILD", "-I", os.path.join(root, "include"), "-o", "pota_amd/_ab/liblentil_hip_probe.so",
-                       os.path.join(root, "pota_amd", "csrc", "lentil_hip.hip")])
+g.hip_variant("pota_amd/_ab/liblentil_hip_probe.so", defines=["-DLENTIL_PROBE_BUILD"])
 print("built pota_amd/_ab/liblentil_hip_probe.so")
 PY
   exit $?

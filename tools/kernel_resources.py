@@ -8,8 +8,9 @@ import __graft_entry__ as g
 
 def main():
     src = os.path.join(ROOT, "pota_amd", "csrc", "lentil_hip.hip")
+    g.write_embedded()       # (generated/embedded_sources.inc from the sources as they are)
     with tempfile.TemporaryDirectory() as d:
-        cmd = [g.HIPCC] + g.HIP_FLAGS + ["-I", os.path.join(ROOT, "include"), "-Rpass-analysis=kernel-resource-usage",
+        cmd = [g.HIPCC] + g.HIP_FLAGS + ["-I", os.path.join(ROOT, "include"), "-Rpass-analysis=kernel-resource-usage"] + sys.argv[1:] + [
                                          src, "-o", os.path.join(d, "t.so")]
         err = subprocess.run(cmd, stderr=subprocess.PIPE, text=True).stderr
     rows, cur = [], None

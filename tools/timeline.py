@@ -25,8 +25,7 @@ def build():
     import __graft_entry__ as g
     os.makedirs(os.path.dirname(SO), exist_ok=True)
     extra = os.environ.get("LENTIL_TL_FLAGS", "").split()      # e.g. -DLENTIL_ACCEPT_EU=4
-    subprocess.check_call([g.HIPCC] + g.HIP_FLAGS + extra + ["-DLENTIL_TIMELINE", "-I", os.path.join(ROOT, "include"), "-o", SO,
-                                                      os.path.join(ROOT, "pota_amd", "csrc", "lentil_hip.hip")])
+    g.hip_variant(SO, defines=[f for f in extra if f.startswith("-D")] + ["-DLENTIL_TIMELINE"], extra=[f for f in extra if not f.startswith("-D")])
     print("built", SO)
 
 
