@@ -173,9 +173,11 @@ def pcie_inclusive(b):
 
 
 def cpu_baseline(args, p, table, M, tan_half_fov):
-    """Oracle ("port" of the reference CPU path) on a bounded sample: every row_step-th image row of
-    the same frame, threaded over rows with per-thread private accumulators merged at the end; then the
-    same on one thread over a tenth of those rows."""
+    """Oracle ("port" of the reference CPU path) on a bounded sample: every row_step-th image row of the same frame, on ALL of
+    this box's logical CPUs (orc_redistribute_threads: the rows cut into one contiguous range per thread, one shared frame --
+    a visit that stays in its pixel is added by the thread that owns the row, the accepted draws are kept as records and added
+    in visit order at the end; no per-thread frames, so the thread count is not bounded by memory); then the same on one thread
+    over a fraction of those rows."""
     import ctypes as C
     import numpy as np
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -185,9 +187,13 @@ def cpu_baseline(args, p, table, M, tan_half_fov):
     lib = oracle_lib.load()
     W, H = args.width, args.height
     logical = os.cpu_count() or 1
-    threads = max(1, min(logical, 32))
+    try:
+        usable = len(os.sched_getaffinity(0))          # (a container may see fewer CPUs than the box has)
+    except (AttributeError, OSError):
+        usable = logical
+    threads = max(1, min(usable, 512))
 
-    def timed(n_threads, budget_s):
+    def timed(n_threads, budget_s, repeats):
         # bound the CPU work: ~0.1 us per scanned visit, ~35 us per draw attempt per core
         est_full = W * H * M * (0.1e-6 + args.f_hi * args.samples * 35e-6 * 1.1)
         row_step = args.cpu_row_step or max(1, int(round(est_full / (budget_s * n_threads))))
@@ -197,33 +203,29 @@ def cpu_baseline(args, p, table, M, tan_half_fov):
                                  n_extra=args.aovs, row_stride=row_step, row_offset=0)
         visits, keep = capi.make_visits(cols, visits_per_pixel=M, pixels_per_row=W, pixel_row_stride=row_step)
         lens = lib.orc_lens_create(C.byref(table))
-        frames = [oracle_lib.Frame(lib, p, n_aovs=1 + args.aovs, shadow=False) for _ in range(n_threads)]
-        bounds = [int(round(i * len(rows) / n_threads)) * W * M for i in range(n_threads + 1)]
-
-        def work(i):
-            frames[i].run(lens, None, visits, bounds[i], bounds[i + 1])
-
-        t0 = time.perf_counter()
-        ts = [threading.Thread(target=work, args=(i,)) for i in range(n_threads)]
-        for t in ts:
-            t.start()
-        for t in ts:
-            t.join()
-        for f in frames[1:]:
-            lib.orc_frame_merge(frames[0].h, f.h)
-        dt = time.perf_counter() - t0
-        c = frames[0].counters()
+        best = None
+        for _ in range(repeats):
+            frame = oracle_lib.Frame(lib, p, n_aovs=1 + args.aovs, shadow=False)
+            t0 = time.perf_counter()
+            if n_threads == 1:
+                frame.run(lens, None, visits)
+            elif not frame.run_threads(lens, None, visits, n_threads, W * M):
+                raise RuntimeError("orc_redistribute_threads does not take this workload")
+            dt = time.perf_counter() - t0
+            c = frame.counters()
+            frame.close()
+            if best is None or dt < best[0]:
+                best = (dt, c)
         lib.orc_lens_destroy(lens)
-        for f in frames:
-            f.close()
-        return n / dt / 1e6, "every %d-th row of the same %dx%d frame: %d visits, %d redistributed, %d draw attempts, %.1f s" % (
-            row_step, W, H, n, c.redistributed_visits, c.attempted_draws, dt)
+        dt, c = best
+        return n / dt / 1e6, "every %d-th row of the same %dx%d frame: %d visits, %d redistributed, %d draw attempts, %.2f s (best of %d)" % (
+            row_step, W, H, n, c.redistributed_visits, c.attempted_draws, dt, repeats)
 
-    v_all, s_all = timed(threads, 20.0)
-    v_one, s_one = timed(1, 6.0)
+    v_all, s_all = timed(threads, 20.0, 3)
+    v_one, s_one = timed(1, 6.0, 1)
     return {
         "value": round(v_all, 4), "unit": "Msamples/s", "cores": threads, "kind": "port", "sample": s_all,
-        "threads": threads, "logical_cpus": logical, "physical_cores": physical_cores(),
+        "threads": threads, "logical_cpus": logical, "usable_cpus": usable, "physical_cores": physical_cores(),
         "one_thread": {"value": round(v_one, 4), "unit": "Msamples/s", "sample": s_one},
     }
 
@@ -245,9 +247,8 @@ def parity_check(W, H, M, samples, aovs, f_hi, p, table, tan_half_fov, device_in
 
     lib = oracle_lib.load()
     n_aovs = 1 + aovs
-    # (every oracle thread has a frame of its own: fp32 + fp64 accumulators, ~60 B per pixel and AOV)
-    per_thread_gb = W * H * 60e-9 * n_aovs + 0.1
-    threads = max(1, min(os.cpu_count() or 1, 32, int(0.5 * common.host_memory_gb() / per_thread_gb)))
+    # (one shared oracle frame whatever the thread count: orc_redistribute_threads)
+    threads = max(1, min(os.cpu_count() or 1, 64))
     est_full = W * H * M * (0.1e-6 + f_hi * samples * 35e-6 * 1.1) * 1.5       # (shadow buffers, the draw log)
     row_step = max(1, int(round(est_full / (budget_s * threads))))
     rows = list(range(0, H, row_step))
@@ -472,36 +473,37 @@ class Bench:
         return {"ok": self.native, "max_abs_diff_over_max_rank0": rel}
 
     def run(self, steps, warmup):
+        """W warm-up steps, then K timed steps between two synchronisations.  Nothing inside the timed loop waits for the
+        device: a step is clear -> pass -> resolve, enqueued; the library looks at a pass's end (did everything fit? is
+        more work needed?) when the context is next observed, and a pass whose frame is cleared before that is counted in
+        `abandoned_incomplete` if it had needed more work (lentil_hip_pass_totals).  Should any timed pass have been
+        abandoned incomplete, the measurement is repeated with every pass waiting for its own end (set_async(0)) and THAT
+        is reported -- `timed_loop` in the result says which."""
+        r = self._run(steps, warmup)
+        if r["abandoned_incomplete"]:
+            self.ctx.set_async(False)
+            try:
+                r2 = self._run(steps, warmup)
+            finally:
+                self.ctx.set_async(True)
+            r2["timed_loop"] = ("every pass waited for its own end: %d of the %d pipelined passes had been cleared away while they "
+                                "still needed work" % (r["abandoned_incomplete"], steps))
+            return r2
+        return r
+
+    def _run(self, steps, warmup):
         torch, dist = self.torch, self.dist
         for _ in range(warmup):
             self.step()
+        self.ctx.sync()                                # (observes the warm-up passes: their ends are looked at, untimed)
+        self.ctx.pass_totals(reset=True)
         if self.world > 1:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        acc = {"scan": 0.0, "draw": 0.0, "resolve": 0.0, "streamed": 0, "blind_chunks": 0, "redone": 0, "iters": 0,
-               "attempted": 0, "accepted": 0, "redistributed": 0, "scan_launches": 0, "lane_rounds": 0, "tries": 0, "slow": 0}
         for _ in range(steps):
             self.step()
-            # HIP-event times of this step's kernels (the call waits for the step's stream work, which
-            # the step would have to finish anyway before the next clear)
-            a, b, c = self.ctx.last_timing()
-            acc["scan"] += a; acc["draw"] += b; acc["resolve"] += c
-            k = self.ctx.counters()
-            if k.worklist_overflow:
-                raise SystemExit("bench.py: the device dropped work (worklist_overflow = %d): results incomplete" % k.worklist_overflow)
-            acc["streamed"] += int(k.streamed); acc["blind_chunks"] += int(k.blind_chunks); acc["redone"] += int(k.fallback_chunks)
-            if int(k.fallback_chunks):
-                # why (lentil_hip_last_redo_note): a pass redone costs time, never results -- but a bench line should say so
-                acc.setdefault("redo_notes", [])
-                if len(acc["redo_notes"]) < 3:
-                    acc["redo_notes"].append(self.ctx.last_redo_note())
-            acc["iters"] += int(k.newton_iterations); acc["attempted"] += int(k.attempted_draws)
-            acc["lane_rounds"] += int(k.lane_rounds); acc["tries"] += int(k.tries); acc["slow"] += int(k.slow_solves)
-            acc["accepted"] += int(k.accepted_draws); acc["redistributed"] += int(k.redistributed_visits)
-            ll = self.ctx.last_launches()
-            acc["scan_launches"] += max(1, ll[0])
-            acc["rounds_max"] = max(acc.get("rounds_max", 0), int(ll[1]))
+        self.ctx.sync()                                # the last pass's end, and whatever it left to do: inside the timed region
         if self.world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -510,6 +512,23 @@ class Bench:
             t = torch.tensor([dt], dtype=torch.float64, device=self.dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
+        # per-pass counters and HIP-event times, summed by the library as it looked at each pass's end
+        k = self.ctx.pass_totals(reset=True)
+        if int(k.passes) != steps:
+            raise SystemExit("bench.py: %d timed steps but the library accounted for %d passes" % (steps, int(k.passes)))
+        if k.worklist_overflow:
+            raise SystemExit("bench.py: the device dropped work (worklist_overflow = %d): results incomplete" % k.worklist_overflow)
+        acc = {"scan": float(k.scan_ms), "draw": float(k.draw_ms), "resolve": float(k.resolve_ms), "streamed": int(k.streamed),
+               "blind_chunks": int(k.blind_chunks), "redone": int(k.fallback_chunks), "iters": int(k.newton_iterations),
+               "attempted": int(k.attempted_draws), "accepted": int(k.accepted_draws), "redistributed": int(k.redistributed_visits),
+               "scan_launches": int(k.scan_launches), "lane_rounds": int(k.lane_rounds), "tries": int(k.tries), "slow": int(k.slow_solves),
+               "rounds_max": int(k.rounds_max), "deferred": int(k.deferred), "abandoned": int(k.abandoned),
+               "abandoned_incomplete": int(k.abandoned_incomplete),
+               "timed_loop": "pipelined: no host wait inside the loop, every pass's end looked at by the library afterwards"
+                             if int(k.deferred) else "every pass waited for its own end"}
+        if int(k.fallback_chunks):
+            # why (lentil_hip_last_redo_note): a pass redone costs time, never results -- but a bench line should say so
+            acc["redo_notes"] = [self.ctx.last_redo_note()]
         acc["dt"] = dt
         acc["steps"] = steps
         return acc
@@ -765,6 +784,10 @@ def main():
         "passes": {"timed": steps, "streamed": r["streamed"], "chunks_enqueued_blind": r["blind_chunks"],
                    "chunks_redone_after_a_short_estimate": r["redone"], "solve_accept_rounds_max": r.get("rounds_max"),
                    "redo_notes": r.get("redo_notes", []),
+                   # the asynchronous end of a pass (include/lentil_hip.h, lentil_hip_set_async): passes that returned before their
+                   # end was known, those whose frame was cleared before anybody observed it, and how many of those had still needed work
+                   "timed_loop": r.get("timed_loop"), "ends_deferred": r.get("deferred"), "abandoned": r.get("abandoned"),
+                   "abandoned_incomplete": r.get("abandoned_incomplete"),
                    # first batches sized from the lens and the frame (lentil_hip_batch_model_stats, whole life of the context):
                    # passes that ran with no second round of solves in flight, how many of those needed one after all
                    "first_batch_model": dict(zip(("calibrations", "lean_passes", "lean_passes_lost", "margin_sixteenths"),

@@ -219,6 +219,24 @@ typedef struct lentil_counters {
   uint64_t streamed;             /* 1: the pass ran streamed (one scan launch feeding persistent solve waves; counts as one blind chunk) */
 } lentil_counters;
 
+/* Sums over the passes whose end has been looked at since the last reset (lentil_hip_pass_totals): what a caller that pipelines
+ * frames reads once, after the frames, instead of lentil_hip_get_counters / _last_timing after every pass (each of which waits
+ * for the pass).  Times are HIP-event times as lentil_hip_last_timing reports them. */
+typedef struct lentil_pass_totals {
+  uint64_t passes;               /* lentil_hip_redistribute calls accounted for */
+  uint64_t streamed;             /* ... that ran streamed */
+  uint64_t blind_chunks, fallback_chunks;      /* as lentil_counters, summed */
+  uint64_t deferred;             /* passes that returned before their end was known (asynchronous end) */
+  uint64_t abandoned;            /* ... whose frame was cleared before anybody observed it */
+  uint64_t abandoned_incomplete; /* ... and which still needed work at that point (a second round, a redo): the frame nobody
+                                  * looked at was not complete.  Their kernel times are in the sums all the same. */
+  uint64_t visits, redistributed_visits, attempted_draws, accepted_draws, worklist_overflow;
+  uint64_t newton_iterations, tries, lane_rounds, slow_solves;
+  uint64_t scan_launches;
+  uint64_t rounds_max;           /* most solve/accept rounds any of the passes needed */
+  double scan_ms, draw_ms, resolve_ms;
+} lentil_pass_totals;
+
 /* one accepted draw, for index-parity tests: (visit, attempt n, linear pixel) */
 typedef struct lentil_draw_record {
   uint32_t visit;
@@ -356,6 +374,12 @@ int lentil_hip_sync(lentil_hip_ctx *ctx);
  *                    filter_weight_buffer (xres*yres); either pointer may be NULL */
 int lentil_hip_download_aov(lentil_hip_ctx *ctx, uint32_t aov, float *host_rgba);
 int lentil_hip_download_accum(lentil_hip_ctx *ctx, uint32_t aov, float *host_rgba, float *host_weight);
+/* download_records : every AOV's accumulators and the weight in ONE copy, as the device keeps them: xres*yres records of
+ *                    *stride floats -- AOV a's RGBA at floats 4a .. 4a+3, the weight at float 4 * n_aovs, padding behind it.
+ *                    host_records holds capacity_floats floats (LENTIL_ERR_INVALID if that is fewer than xres*yres * stride;
+ *                    host_records NULL: only *stride is set).  download_accum copies this whole block per call and picks
+ *                    one AOV's columns: a caller that looks at all AOVs of a 4K frame wants this instead. */
+int lentil_hip_download_records(lentil_hip_ctx *ctx, float *host_records, uint64_t capacity_floats, uint32_t *stride);
 
 /* Thin lens with abb_chromatic > 0 (src/lentil_filter.cpp:393-406): every attempt that passes the optical
  * vignetting test draws its colour channel from xor128 (src/global.h:22-27), whose state the reference
@@ -544,6 +568,21 @@ int lentil_hip_batch_model_stats(lentil_hip_ctx *ctx, uint64_t stats[4]);
  * had been accepted by then.  A stall costs time, never results -- so nothing else would ever show one: the GPU test
  * session asserts stats[1] == stats[2] when it ends (tests/conftest.py). */
 int lentil_hip_process_stats(uint64_t stats[4]);
+/* The asynchronous end of a pass (round 6).  lentil_hip_redistribute no longer ends with the host waiting for the device: a
+ * streamed pass returns once its kernels are enqueued, and whether it needs more work (buffers that were too small, a draw
+ * batch that fell short, a wave that gave up waiting) is found out by the next call that OBSERVES the context -- every entry
+ * point except lentil_hip_clear_frame, _bind_visits, _redistribute and _resolve: that call waits for the pass, does what is
+ * left and only then proceeds, so lentil_hip_sync, the downloads, _get_counters, _last_timing ... return what they always
+ * returned (an error of the pass -- LENTIL_ERR_NOMEM for dropped work -- is reported by that call).  A caller that pipelines
+ * frames (clear, redistribute, resolve, clear, ...) keeps the device fed instead: the next frame's clear and scan are
+ * enqueued while the pass still runs.  Clearing a frame that nobody has observed abandons its pass: the counters are still read
+ * (lentil_hip_pass_totals; they size the next passes), work it still needed is not done, and totals.abandoned_incomplete says
+ * so.  The visit columns of a pass must stay valid until the pass has been observed or its frame cleared AND the device has
+ * passed it (lentil_hip_sync).  At most two passes are in flight unobserved; a third waits for the oldest.
+ * set_async(0): every lentil_hip_redistribute waits for its own end, as before round 6 (also LENTIL_ASYNC_END=0).
+ * pass_totals: waits for nothing but the events of passes already observed or abandoned; reset != 0 zeroes the sums afterwards. */
+int lentil_hip_set_async(lentil_hip_ctx *ctx, int on);
+int lentil_hip_pass_totals(lentil_hip_ctx *ctx, lentil_pass_totals *out, int reset);
 int lentil_hip_debug_batch_estimate(lentil_hip_ctx *ctx, uint64_t n, const float *cs_xyz, uint32_t samples, float *out);
 int lentil_hip_set_draw_log(lentil_hip_ctx *ctx, uint64_t capacity); /* 0 disables */
 int lentil_hip_download_draw_log(lentil_hip_ctx *ctx, lentil_draw_record *out, uint64_t capacity,

@@ -47,6 +47,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <thread>
 #include <vector>
 
 #include "../include/lentil_hip.h"
@@ -816,6 +817,22 @@ ORC_API void orc_abb_coma_perturb(const float dir_from_lens[3], const float ray_
  * The frame: buffers of Camera::setup_filter (src/lentil.h:1096-1121) and the whole
  * filter_pixel visit loop (src/lentil_filter.cpp:91-451) over a visit stream.
  * ===================================================================================== */
+/* orc_redistribute_threads (below): what a worker thread keeps for itself while the frame's buffers are shared -- its counters,
+ * its part of the draw log, and the accepted draws themselves, which are NOT added by the worker (another thread's rows) but
+ * kept as records and added, thread after thread = in visit order, when all workers are through. */
+struct OrcDeferredDraw {
+  uint32_t pixel, visit;
+  float add_energy, weight;
+  uint32_t chan;                  /* rgb_weight: 0 white; 1, 2, 3: three-fold into r, g, b alone (abb_chromatic > 0) */
+};
+struct OrcWorker {
+  lentil_counters ctr;
+  std::vector<lentil_draw_record> log;
+  std::vector<OrcDeferredDraw> draws;
+  uint32_t cur_visit = 0;
+};
+static thread_local OrcWorker *tl_worker = nullptr;
+
 struct OrcFrame {
   uint32_t xres, yres, n_aovs;
   uint8_t kind[LENTIL_MAX_AOVS];
@@ -854,6 +871,11 @@ struct OrcFrame {
    * absolute sample time (src/lentil_filter.cpp:141-143 hands it to AiWorldToCameraMatrix as it is) */
   float cam_t0 = 0.0f, cam_inv_dt = 1.0f;
 };
+
+/* the counters / draw log / current visit of whoever runs do_visit: the frame's own, or the worker thread's */
+static inline lentil_counters &ctr_of(OrcFrame *F) { return tl_worker ? tl_worker->ctr : F->ctr; }
+static inline std::vector<lentil_draw_record> &log_of(OrcFrame *F) { return tl_worker ? tl_worker->log : F->log; }
+static inline uint32_t &cur_visit_of(OrcFrame *F) { return tl_worker ? tl_worker->cur_visit : F->cur_visit; }
 
 ORC_API OrcFrame *orc_frame_create(uint32_t xres, uint32_t yres, uint32_t n_aovs, const uint8_t *kind,
                                    int keep_log) {
@@ -1113,7 +1135,7 @@ static inline void add_to_buffer(OrcFrame *F, uint32_t aov, uint32_t px, const f
         if (F->shadow) F->buffer64[aov][(size_t)px * 4 + c] = value[c];
       }
       F->zbuffer[px] = std::abs(depth);
-      F->zvisit[px] = F->cur_visit;
+      F->zvisit[px] = cur_visit_of(F);
     }
   } else if (F->kind[aov] == LENTIL_FILTER_CLOSEST_DEBUG) {       /* aov.name == lentil_debug, src/lentil.h:838-845 */
     if ((std::abs(depth) <= F->zbuffer_debug[px]) || F->zbuffer_debug[px] == 0.0) {
@@ -1136,7 +1158,7 @@ static void do_visit(const lentil_params *P, const OrcLens *L, const OrcBokeh *B
   const double xres = (double)P->xres, yres = (double)P->yres;
   const double frame_aspect_ratio_without_region = (double)P->xres_without_region / (double)P->yres_without_region;
   bool redistribute = true;
-  F->cur_visit = (uint32_t)v;
+  cur_visit_of(F) = (uint32_t)v;
   if (P->adaptive_sampling) { if (inverse_sample_density > 0.2) redistribute = false; }   /* :108-113 */
 
   float sample[4] = {V->rgba[v * 4], V->rgba[v * 4 + 1], V->rgba[v * 4 + 2], V->rgba[v * 4 + 3]};
@@ -1209,7 +1231,7 @@ static void do_visit(const lentil_params *P, const OrcLens *L, const OrcBokeh *B
   if (P->cameraType == LENTIL_POLYNOMIAL_OPTICS)
     if (std::abs(cs[2]) < (L->k.lens_length * 0.1)) redistribute = false;           /* :240 */
 
-  F->ctr.visits++;
+  ctr_of(F).visits++;
   if (!redistribute) {                                                              /* :243-246 / :306-309 */
     const uint32_t pixelnumber = P->xres * py + px;                                 /* lentil.h:945 */
     for (uint32_t a = 0; a < F->n_aovs; a++)
@@ -1218,13 +1240,13 @@ static void do_visit(const lentil_params *P, const OrcLens *L, const OrcBokeh *B
       add_to_buffer_cryptomatte(F->crypto[c], pixelnumber, crypto_cache[c], inverse_sample_density);
     return;
   }
-  F->ctr.redistributed_visits++;
+  ctr_of(F).redistributed_visits++;
 
   if (P->cameraType == LENTIL_POLYNOMIAL_OPTICS) {
     for (int count = 0; count < samples && total_samples_taken < max_total_samples; ++count, ++total_samples_taken) {
       double sensor_position[2] = {0, 0};
       const double target[3] = {-(double)cs[0] * 10.0, -(double)cs[1] * 10.0, -(double)cs[2] * 10.0};  /* :271 */
-      F->ctr.attempted_draws++;
+      ctr_of(F).attempted_draws++;
       float lambda_per_sample = P->lambda_bw;                                                           /* :254, 0.55 */
       for (int channel = -1; channel <= 1; channel++) {                                                 /* :255-268 */
         float rgb_weight[3] = {1.0f, 1.0f, 1.0f};
@@ -1250,14 +1272,18 @@ static void do_visit(const lentil_params *P, const OrcLens *L, const OrcBokeh *B
             (pixel1 != pixel1)) { --count; continue; }                                                  /* :282-287 */
         const int ix = floor(pixel0), iy = floor(pixel1);
         const unsigned pixelnumber = ix + (iy * P->xres);                                               /* :290, lentil.h:958-960 */
+        if (tl_worker) {        /* a worker of orc_redistribute_threads: the draw is kept, and added when its turn comes */
+          tl_worker->draws.push_back({pixelnumber, (uint32_t)v, fitted_bidir_add_energy, 1.0f * inverse_sample_density * inv_samples,
+                                      (uint32_t)(P->abb_chromatic > 0.0 ? channel + 2 : 0)});
+        } else
         for (uint32_t a = 0; a < F->n_aovs; a++)                                                        /* :295-298 */
           add_to_buffer(F, a, pixelnumber, aov_values[a], fitted_bidir_add_energy, depth,
                         1.0f * inverse_sample_density * inv_samples, rgb_weight);
         for (uint32_t c = 0; c < F->crypto.size(); c++)                                                 /* :296 */
           add_to_buffer_cryptomatte(F->crypto[c], pixelnumber, crypto_cache[c], inverse_sample_density * inv_samples);
-        F->ctr.accepted_draws++;
+        ctr_of(F).accepted_draws++;
         /* chromatic mode: the channel (0..2) rides in the attempt's top two bits */
-        if (F->keep_log) F->log.push_back({(uint32_t)v, total_samples_taken | ((uint32_t)(P->abb_chromatic != 0.0 ? channel + 1 : 0) << 30),
+        if (F->keep_log) log_of(F).push_back({(uint32_t)v, total_samples_taken | ((uint32_t)(P->abb_chromatic != 0.0 ? channel + 1 : 0) << 30),
                                            pixelnumber});
       }
     }
@@ -1267,7 +1293,7 @@ static void do_visit(const lentil_params *P, const OrcLens *L, const OrcBokeh *B
   /* ---- ThinLens, src/lentil_filter.cpp:303-447.  abb_chromatic > 0 draws every attempt's channel from xor128
    * (:397): OrcFrame::xor_state, advanced in this function's visit order ---- */
   for (int count = 0; count < samples && total_samples_taken < max_total_samples; ++count, ++total_samples_taken) {
-    F->ctr.attempted_draws++;
+    ctr_of(F).attempted_draws++;
     unsigned int seed = orc_tea8((uint32_t)(px * py + px), total_samples_taken);
     const float focal_length = P->focal_length;
     float image_dist_samplepos = (-focal_length * cs[2]) / (-focal_length + cs[2]);
@@ -1364,14 +1390,17 @@ static void do_visit(const lentil_params *P, const OrcLens *L, const OrcBokeh *B
     if ((pixel_x >= xres) || (pixel_x < 0) || (pixel_y >= yres) || (pixel_y < 0)) { --count; continue; }  /* :429-432 */
     const int ix = floor(pixel_x), iy = floor(pixel_y);
     const unsigned pixelnumber = ix + (iy * P->xres);                                                     /* :434 */
+    if (tl_worker) {          /* (thin lens without abb_chromatic > 0: rgb_weight is white) */
+      tl_worker->draws.push_back({pixelnumber, (uint32_t)v, fitted_bidir_add_energy, 1.0f * inverse_sample_density * inv_samples, 0u});
+    } else
     for (uint32_t a = 0; a < F->n_aovs; a++)                                                              /* :442-445 */
       add_to_buffer(F, a, pixelnumber, aov_values[a], fitted_bidir_add_energy, depth,
                     1.0f * inverse_sample_density * inv_samples, rgb_weight);
     for (uint32_t c = 0; c < F->crypto.size(); c++)                                                       /* :443 */
       add_to_buffer_cryptomatte(F->crypto[c], pixelnumber, crypto_cache[c], inverse_sample_density * inv_samples);
-    F->ctr.accepted_draws++;
+    ctr_of(F).accepted_draws++;
     /* chromatic mode: the channel (0..2) rides in the attempt's top two bits, as on the polynomial-optics path */
-    if (F->keep_log) F->log.push_back({(uint32_t)v, total_samples_taken | ((uint32_t)(P->abb_chromatic > 0.0 ? channel + 1 : 0) << 30),
+    if (F->keep_log) log_of(F).push_back({(uint32_t)v, total_samples_taken | ((uint32_t)(P->abb_chromatic > 0.0 ? channel + 1 : 0) << 30),
                                        pixelnumber});
   }
 }
@@ -1398,6 +1427,95 @@ ORC_API int orc_redistribute(const lentil_params *P, const OrcLens *L, const Orc
     visit_pixel(V, v, &px, &py);
     const float inv_density = V->inv_density ? V->inv_density[v] : P->inverse_sample_density;
     do_visit(P, L, B, F, V, v, px, py, inv_density);
+  }
+  return 0;
+}
+
+/* The same visits, [v_begin, v_end), over n_threads threads and ONE frame (test infrastructure and bench.py's cpu_baseline: no
+ * counterpart in the reference, whose render threads share the buffers and race).  The range is cut where pixel
+ * rows end (row_visits visits per row: a uniform stream), so a visit that stays in its pixel (src/lentil.h:938-955) is
+ * added by the one thread that owns the pixel, in iterator order -- bit for bit what a single thread leaves there.  A draw
+ * lands anywhere: the worker keeps it as a record, and the records are added thread after thread, which is visit order,
+ * once all workers are through.  A pixel's fp32 sum then takes its own visits first and the draws after them -- another
+ * order than the single-threaded walk's, inside the 1e-5 bar like every other (the fp64 shadows are exact either way);
+ * counters and the draw log are the single-threaded ones.  Closest-filtered AOVs: the last candidate of the smallest |Z|
+ * wins whatever the order the candidates are met in (zvisit says who holds the pixel); a stream with a candidate of |Z| == 0
+ * cannot be split this way (orc_frame_merge's note).  Not for lentil_debug, cryptomatte, or thin lens with abb_chromatic > 0
+ * (one xor128 stream in visit order): LENTIL_ERR_UNSUPPORTED.
+ * Memory: one frame, whatever n_threads -- the per-thread frames of the Python-level merge were 60 B per pixel and AOV each. */
+ORC_API int orc_redistribute_threads(const lentil_params *P, const OrcLens *L, const OrcBokeh *B, OrcFrame *F,
+                                     const lentil_visits *V, uint64_t v_begin, uint64_t v_end, uint32_t n_threads,
+                                     uint64_t row_visits) {
+  if (P->cameraType == LENTIL_POLYNOMIAL_OPTICS && !L) return LENTIL_ERR_UNSUPPORTED;
+  if (P->bokeh_enable_image && !B) return LENTIL_ERR_INVALID;
+  if (!F->crypto.empty() || (P->cameraType == LENTIL_THINLENS && P->abb_chromatic > 0.0f) || !row_visits) return LENTIL_ERR_UNSUPPORTED;
+  for (uint32_t a = 0; a < F->n_aovs; a++) if (F->kind[a] == LENTIL_FILTER_CLOSEST_DEBUG) return LENTIL_ERR_UNSUPPORTED;
+  const uint64_t n = v_end > v_begin ? v_end - v_begin : 0;
+  const uint64_t rows = (n + row_visits - 1) / row_visits;
+  if (n_threads < 1) n_threads = 1;
+  if ((uint64_t)n_threads > rows) n_threads = (uint32_t)(rows ? rows : 1);
+  std::vector<OrcWorker> workers(n_threads);
+  std::vector<uint64_t> bound(n_threads + 1);
+  for (uint32_t i = 0; i <= n_threads; i++) {
+    const uint64_t r = (uint64_t)((double)i * (double)rows / (double)n_threads + 0.5);
+    bound[i] = std::min(v_end, v_begin + r * row_visits);
+  }
+  bound[0] = v_begin; bound[n_threads] = v_end;
+  auto work = [&](uint32_t i) {
+    OrcWorker &w = workers[i];
+    memset(&w.ctr, 0, sizeof w.ctr);
+    tl_worker = &w;
+    for (uint64_t v = bound[i]; v < bound[i + 1]; v++) {
+      int px, py;
+      visit_pixel(V, v, &px, &py);
+      const float inv_density = V->inv_density ? V->inv_density[v] : P->inverse_sample_density;
+      do_visit(P, L, B, F, V, v, px, py, inv_density);
+    }
+    tl_worker = nullptr;
+  };
+  {
+    std::vector<std::thread> ts;
+    for (uint32_t i = 1; i < n_threads; i++) ts.emplace_back(work, i);
+    work(0);
+    for (std::thread &t : ts) t.join();
+  }
+  /* the draws, in visit order */
+  for (uint32_t i = 0; i < n_threads; i++) {
+    OrcWorker &w = workers[i];
+    F->ctr.visits += w.ctr.visits; F->ctr.redistributed_visits += w.ctr.redistributed_visits;
+    F->ctr.attempted_draws += w.ctr.attempted_draws; F->ctr.accepted_draws += w.ctr.accepted_draws;
+    if (F->keep_log) F->log.insert(F->log.end(), w.log.begin(), w.log.end());
+    for (const OrcDeferredDraw &d : w.draws) {
+      const uint64_t v = d.visit;
+      const float depth = V->pos_z[v * 4 + 3];
+      float rgbw[3] = {1.0f, 1.0f, 1.0f};
+      if (d.chan) { rgbw[0] = rgbw[1] = rgbw[2] = 0.0f; rgbw[d.chan - 1] = 3.0f; }
+      for (uint32_t a = 0; a < F->n_aovs; a++) {
+        const float *val = a == 0 ? &V->rgba[v * 4] : &V->extra[a - 1][v * 4];
+        if (F->kind[a] == LENTIL_FILTER_CLOSEST) {
+          /* Camera::add_to_buffer's z-test (src/lentil.h:832-837) met out of order: a pixel's own candidates of LATER visits are
+           * in already -- the survivor is the candidate of the smallest |Z|, the latest of equals */
+          const uint32_t px = d.pixel;
+          const float z = std::abs(depth);
+          const bool none = F->zvisit[px] == 0xFFFFFFFFu;
+          if (none || z < F->zbuffer[px] || (z == F->zbuffer[px] && d.visit > F->zvisit[px])) {
+            for (uint32_t b = 0; b < F->n_aovs; b++) {
+              if (F->kind[b] != LENTIL_FILTER_CLOSEST) continue;
+              const float *vb = b == 0 ? &V->rgba[v * 4] : &V->extra[b - 1][v * 4];
+              for (int c = 0; c < 4; c++) {
+                F->buffer[b][(size_t)px * 4 + c] = vb[c];
+                if (F->shadow) F->buffer64[b][(size_t)px * 4 + c] = vb[c];
+              }
+            }
+            F->zbuffer[px] = z;
+            F->zvisit[px] = d.visit;
+          }
+        } else {
+          add_to_buffer(F, a, d.pixel, val, d.add_energy, depth, d.weight, rgbw);
+        }
+      }
+    }
+    std::vector<OrcDeferredDraw>().swap(w.draws);
   }
   return 0;
 }

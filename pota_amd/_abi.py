@@ -92,5 +92,13 @@ class Counters(C.Structure):
                 ("blind_chunks", C.c_uint64), ("fallback_chunks", C.c_uint64), ("streamed", C.c_uint64)]
 
 
+class PassTotals(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in (
+        "passes", "streamed", "blind_chunks", "fallback_chunks", "deferred", "abandoned", "abandoned_incomplete",
+        "visits", "redistributed_visits", "attempted_draws", "accepted_draws", "worklist_overflow",
+        "newton_iterations", "tries", "lane_rounds", "slow_solves", "scan_launches", "rounds_max")] + [
+        ("scan_ms", C.c_double), ("draw_ms", C.c_double), ("resolve_ms", C.c_double)]
+
+
 class DrawRecord(C.Structure):
     _fields_ = [("visit", C.c_uint32), ("attempt", C.c_uint32), ("pixel", C.c_uint32)]

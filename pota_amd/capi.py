@@ -18,12 +18,12 @@ EXPORTS = [
     "lentil_hip_set_params", "lentil_hip_set_lens", "lentil_hip_set_bokeh", "lentil_hip_alloc_frame", "lentil_hip_set_camera_motion", "lentil_hip_set_camera_shutter",
     "lentil_hip_upload_visits", "lentil_hip_bind_visits", "lentil_hip_clear_frame",
     "lentil_hip_redistribute", "lentil_hip_resolve", "lentil_hip_sync", "lentil_hip_download_aov",
-    "lentil_hip_download_accum", "lentil_hip_accum_buffer", "lentil_hip_stream",
+    "lentil_hip_download_accum", "lentil_hip_download_records", "lentil_hip_accum_buffer", "lentil_hip_stream",
     "lentil_hip_set_closest_exchange", "lentil_hip_zkey_buffer", "lentil_hip_closest_gather",
     "lentil_hip_touched_rows", "lentil_hip_merge_rows", "lentil_hip_resolve_rows",
     "lentil_hip_pack_rows", "lentil_hip_merge_packed_rows", "lentil_hip_compact_rows", "lentil_hip_merge_sparse",
     "lentil_hip_get_counters", "lentil_hip_last_timing", "lentil_hip_last_launches", "lentil_hip_set_draw_log",
-    "lentil_hip_batch_model_stats", "lentil_hip_process_stats", "lentil_hip_debug_batch_estimate", "lentil_hip_box_probe",
+    "lentil_hip_batch_model_stats", "lentil_hip_process_stats", "lentil_hip_set_async", "lentil_hip_pass_totals", "lentil_hip_debug_batch_estimate", "lentil_hip_box_probe",
     "lentil_hip_lens_jit_status", "lentil_hip_lens_jit_wait", "lentil_hip_debug_lens_jit_source", "lentil_hip_debug_lens_jit_compile",
     "lentil_hip_download_draw_log", "lentil_hip_test_lt_sample_aperture",
     "lentil_hip_test_trace_bw_po", "lentil_hip_test_aperture_sample", "lentil_hip_debug_scan_bands",
@@ -96,6 +96,7 @@ def load_library():
         "lentil_hip_sync": (i, [vp]),
         "lentil_hip_download_aov": (i, [vp, u32, vp]),
         "lentil_hip_download_accum": (i, [vp, u32, vp, vp]),
+        "lentil_hip_download_records": (i, [vp, vp, u64, C.POINTER(u32)]),
         "lentil_hip_accum_buffer": (i, [vp, C.POINTER(vp), C.POINTER(u64)]),
         "lentil_hip_stream": (i, [vp, C.POINTER(vp)]),
         "lentil_hip_set_closest_exchange": (i, [vp, i, u32]),
@@ -113,6 +114,8 @@ def load_library():
         "lentil_hip_last_launches": (i, [vp, C.POINTER(C.c_uint32)]),
         "lentil_hip_batch_model_stats": (i, [vp, C.POINTER(C.c_uint64)]),
         "lentil_hip_process_stats": (i, [C.POINTER(C.c_uint64)]),
+        "lentil_hip_set_async": (i, [vp, i]),
+        "lentil_hip_pass_totals": (i, [vp, C.POINTER(_abi.PassTotals), i]),
         "lentil_hip_box_probe": (i, [vp, C.POINTER(C.c_double)]),
         "lentil_hip_lens_jit_status": (i, [vp, C.POINTER(C.c_int), C.POINTER(C.c_double)]),
         "lentil_hip_lens_jit_wait": (i, [vp, C.c_double]),
@@ -339,6 +342,14 @@ class Context:
         self._chk(self.lib.lentil_hip_download_accum(self.h, aov, buf.ctypes.data, w.ctypes.data))
         return buf, w
 
+    def download_records(self):
+        """[n_pixels, stride] fp32: every AOV's accumulators (floats 4a .. 4a+3) and the weight (float 4 * n_aovs) in one copy"""
+        st = C.c_uint32(0)
+        self._chk(self.lib.lentil_hip_download_records(self.h, None, 0, C.byref(st)))
+        rec = np.empty((self.n_pixels, int(st.value)), np.float32)
+        self._chk(self.lib.lentil_hip_download_records(self.h, rec.ctypes.data, rec.size, C.byref(st)))
+        return rec
+
     def accum_buffer(self):
         p, n = C.c_void_p(), C.c_uint64()
         self._chk(self.lib.lentil_hip_accum_buffer(self.h, C.byref(p), C.byref(n)))
@@ -487,6 +498,16 @@ class Context:
         c = _abi.Counters()
         self._chk(self.lib.lentil_hip_get_counters(self.h, C.byref(c)))
         return c
+
+    def set_async(self, on):
+        """the asynchronous end of a pass (include/lentil_hip.h): off = every redistribute waits for its own end"""
+        self._chk(self.lib.lentil_hip_set_async(self.h, 1 if on else 0))
+
+    def pass_totals(self, reset=False):
+        """sums over the passes looked at since the last reset (observes the context: waits for what is in flight)"""
+        t = _abi.PassTotals()
+        self._chk(self.lib.lentil_hip_pass_totals(self.h, C.byref(t), 1 if reset else 0))
+        return t
 
     def last_timing(self):
         ms = (C.c_float * 3)()

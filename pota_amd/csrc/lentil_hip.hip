@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
 #include <mutex>
 #include <new>
 #include <string>
@@ -31,6 +32,23 @@ struct HostTrace {
   int passes_left = -1;
 };
 static int host_trace_passes() { static const int n = getenv("LENTIL_HOST_TRACE") ? atoi(getenv("LENTIL_HOST_TRACE")) : 0; return n; }
+
+// What the end of a streamed pass needs to know of its beginning (redistribute_streamed -> streamed_finish; kept in
+// lentil_hip_ctx::Inflight while the pass's end is pending).
+struct StreamTail {
+  hipStream_t tail = nullptr;         // the stream the pass's last kernels and its counter read-back are on
+  std::chrono::steady_clock::time_point pass_t0;
+  bool calibrates_now = false, predicted = false, lean = false, extend = false, live = false, inject = false;
+  int blind_rounds = 2;
+  DrawArgs da{};
+  SlowRec *slow_base = nullptr;
+  uint32_t slow_cap_all = 0;
+  unsigned accept_blocks = 0;
+  uint32_t item_cap = 0, task_cap = 0, range_cap = 0;
+  uint64_t pool_cap = 0, stuck_ticks = 0;
+  bool deferred = false;              // the pass's end was left to whoever observes it next
+  bool did_more = false;              // streamed_finish had to enqueue more work (rounds, a redo): the frame moved on
+};
 
 struct lentil_hip_ctx {
   HostTrace trace;
@@ -260,6 +278,39 @@ struct lentil_hip_ctx {
   float *d_cam_keys = nullptr;        // lentil_hip_set_camera_motion
   float shutter_t0 = 0.0f, shutter_inv_dt = 1.0f;     // lentil_hip_set_camera_shutter: the keys' first time, 1 / (last - first)
   uint32_t n_cam_keys = 0;
+  // ---- the asynchronous end of a streamed pass (round 6; lentil_hip_set_async, LENTIL_ASYNC_END=0 switches it off) ---------------
+  // lentil_hip_redistribute used to end with the host waiting for the pass's counters (did everything fit?  did the lean tail's
+  // bet hold?  did a wave give up waiting?) -- and the GPU then idled until the host had come round to the next frame's clear and
+  // scan: 55-133 us of a 2 ms step, depending on the box's host.  Now a streamed pass with the lean tail returns once its kernels
+  // and the copy of its counters are enqueued; the verdict is read by whichever call next OBSERVES the frame or the counters
+  // (sync, downloads, get_counters, last_timing, every set-up call: CHECK_CTX) -- that call waits for the pass, and if the pass needs
+  // more work (a lost bet, buffers that were too small, a stall) does that work then, so the observer sees exactly what it saw
+  // before.  clear_frame / bind_visits / redistribute / resolve do not observe: a caller that pipelines frames (clear, pass,
+  // resolve, next clear ...) keeps the GPU fed.  A pass whose frame is cleared away before anybody looked at it is ABANDONED: its
+  // counters are still read (estimates for the next pass, lentil_hip_pass_totals), but work it still needed is not done -- nobody can
+  // see that frame any more; pass_totals.abandoned_incomplete counts such passes.  At most two passes are in flight unobserved.
+  bool async_end = true;
+  struct Slot {                       // what a pass needs of its own while another pass is being enqueued: events, the counters' landing block
+    hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev_scan_k[2] = {nullptr, nullptr};
+    hipEvent_t ev_tail = nullptr;     // behind the counters' copy on the pass's tail stream
+    DevCounters *h_ctr_pinned = nullptr;
+    bool timing_open = false;         // a pass used these events and its times are not in the totals yet
+    bool timed_draw = false, timed_resolve = false, scan_kernel_timed = false;
+  } slots[3];
+  int slot = 0;
+  struct Inflight {                   // a streamed pass whose end nobody has looked at
+    int slot = 0;
+    bool abandoned = false;           // its frame has been cleared since
+    bool resolve_requested = false;   // lentil_hip_resolve was called behind it
+    StreamTail t;
+    VisitsDev V{};                    // the stream it ran on (bind_visits may have moved on)
+    bool have_visits = false;
+  };
+  std::deque<Inflight> inflight;
+  bool holds_turn = false;            // this context owns g_stream_owner[device]
+  lentil_pass_totals totals{};
+  std::vector<std::string> notes;     // redo notes since the totals were last reset (at most 8 kept)
   struct LentilUpload *upload = nullptr;   // lentil_upload.h: the visit stream handed over piece by piece
   struct LentilComm *comm = nullptr; // lentil_comm.h: this context's RCCL communicator, if one was asked for
   struct LentilCrypto *crypto = nullptr;   // lentil_crypto.h: cryptomatte AOVs, if any were allocated
@@ -268,12 +319,43 @@ struct lentil_hip_ctx {
 };
 
 static thread_local std::string g_err;
+static std::atomic<lentil_hip_ctx *> g_stream_owner[64];
+// (an owner, not a mutex: a pass whose end is left to its next observer keeps the device's turn beyond the call that started
+// it -- possibly to be given back from another thread --, and a later pass of the SAME context, which follows it on the same
+// streams, needs no turn of its own)
+static void release_turn(lentil_hip_ctx *ctx);
+struct DeviceTurn {
+  lentil_hip_ctx *ctx;
+  bool taken = false, kept = false;
+  explicit DeviceTurn(lentil_hip_ctx *c) : ctx(c) {}
+  bool take(bool wait);
+  void keep() { kept = true; }
+  ~DeviceTurn();
+};
+bool DeviceTurn::take(bool wait) {
+  if (ctx->holds_turn) return true;
+  std::atomic<lentil_hip_ctx *> &o = g_stream_owner[ctx->device & 63];
+  lentil_hip_ctx *none = nullptr;
+  while (!o.compare_exchange_strong(none, ctx)) {
+    if (!wait) return false;
+    none = nullptr;
+    std::this_thread::sleep_for(std::chrono::microseconds(50));
+  }
+  taken = true;
+  ctx->holds_turn = true;
+  return true;
+}
+static void release_turn(lentil_hip_ctx *ctx) {
+  if (!ctx->holds_turn || !ctx->inflight.empty()) return;
+  g_stream_owner[ctx->device & 63].store(nullptr);
+  ctx->holds_turn = false;
+}
+DeviceTurn::~DeviceTurn() { if (taken && !kept) release_turn(ctx); }
 static void apply_camera_motion(lentil_hip_ctx *ctx);
 
 // One streamed pass at a time per device and process: its solve waves are resident while they wait for the scan's
 // output, and the waves of two such passes can fill the CUs' register files between them before either scan is
 // placed (contexts driven from several threads; across processes the bounded wait and the chunked redo catch it).
-static std::mutex g_stream_mutex[64];
 
 // What every context of this process has seen (lentil_hip_process_stats): streamed passes begun, passes whose resident waves hit
 // the stuck time-out, how many of those were asked for (LENTIL_INJECT_STALL), passes redone after draws had been accepted.  A
@@ -291,8 +373,21 @@ static int fail(lentil_hip_ctx *ctx, int code, const std::string &msg) {
     if (e_ != hipSuccess)                                                                    \
       return fail(ctx, LENTIL_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_));   \
   } while (0)
-#define CHECK_CTX(ctx) \
+static int settle(lentil_hip_ctx *ctx);
+static void harvest_ready(lentil_hip_ctx *ctx);
+static int resolve_range(lentil_hip_ctx *ctx, uint64_t p_begin, uint64_t p_end);
+// Every entry point observes the context's last pass -- waits for it, finishes what it left open (settle) -- except the four a
+// caller pipelines frames with (clear_frame, bind_visits, redistribute, resolve: CHECK_CTX_PIPELINED) and the pure getters.
+#define CHECK_CTX_PIPELINED(ctx) \
   if (!(ctx)) return fail(nullptr, LENTIL_ERR_INVALID, "null context")
+#define CHECK_CTX(ctx)                                                     \
+  do {                                                                     \
+    if (!(ctx)) return fail(nullptr, LENTIL_ERR_INVALID, "null context"); \
+    if (!(ctx)->inflight.empty()) {                                        \
+      const int rc_settle_ = settle(ctx);                                  \
+      if (rc_settle_) return rc_settle_;                                   \
+    }                                                                      \
+  } while (0)
 
 static inline void ht_mark(lentil_hip_ctx *ctx, const char *what) {
   if (!host_trace_passes()) return;
@@ -430,6 +525,25 @@ LENTIL_API int lentil_hip_create(int device, lentil_hip_ctx **out_ctx) {
   ctx->h_seq = reinterpret_cast<uint32_t *>(ctx->h_ctr_pinned + ctx->n_chunks);
   if (hipHostGetDevicePointer((void **)&ctx->d_ctr_host, ctx->h_ctr_pinned, 0) != hipSuccess) { ctx->d_ctr_host = nullptr; (void)hipGetLastError(); }
   if (const char *e = getenv("LENTIL_SPIN_READBACK")) ctx->spin_readback = atoi(e) != 0;
+  if (const char *e = getenv("LENTIL_ASYNC_END")) ctx->async_end = e[0] != '0';
+  HIP_TRY(ctx, hipEventCreate(&ctx->ev_scan_k[0]));
+  HIP_TRY(ctx, hipEventCreate(&ctx->ev_scan_k[1]));
+  // the slots of the asynchronous end (lentil_hip_ctx::Slot): slot 0 holds what has just been created, 1 and 2 their own
+  for (int si = 0; si < 3; ++si) {
+    lentil_hip_ctx::Slot &sl = ctx->slots[si];
+    if (si == 0) {
+      for (int i = 0; i < 5; ++i) sl.ev[i] = ctx->ev[i];
+      sl.ev_scan_k[0] = ctx->ev_scan_k[0]; sl.ev_scan_k[1] = ctx->ev_scan_k[1];
+      sl.h_ctr_pinned = ctx->h_ctr_pinned;
+    } else {
+      for (int i = 0; i < 5; ++i) HIP_TRY(ctx, hipEventCreate(&sl.ev[i]));
+      HIP_TRY(ctx, hipEventCreate(&sl.ev_scan_k[0]));
+      HIP_TRY(ctx, hipEventCreate(&sl.ev_scan_k[1]));
+      HIP_TRY(ctx, hipHostMalloc((void **)&sl.h_ctr_pinned, sizeof(DevCounters) * (ctx->n_chunks + 1), hipHostMallocDefault));
+      memset(sl.h_ctr_pinned, 0, sizeof(DevCounters) * (ctx->n_chunks + 1));
+    }
+    HIP_TRY(ctx, hipEventCreateWithFlags(&sl.ev_tail, hipEventDisableTiming));
+  }
   HIP_TRY(ctx, hipMalloc(&ctx->d_dummy, 64 * sizeof(float4)));
   HIP_TRY(ctx, hipMemsetAsync(ctx->d_ctr, 0, sizeof(DevCounters) * (ctx->n_chunks + 1), ctx->stream));
   ctx->chunks.resize(ctx->n_chunks);
@@ -442,8 +556,6 @@ LENTIL_API int lentil_hip_create(int device, lentil_hip_ctx **out_ctx) {
   HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->pub_stream, hipStreamNonBlocking));
   HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_slow, hipEventDisableTiming));
   HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_round, hipEventDisableTiming));
-  HIP_TRY(ctx, hipEventCreate(&ctx->ev_scan_k[0]));
-  HIP_TRY(ctx, hipEventCreate(&ctx->ev_scan_k[1]));
   HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->pub_done, hipEventDisableTiming));
   HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_acc1, hipEventDisableTiming));
   HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_b, hipEventDisableTiming));
@@ -576,6 +688,11 @@ static int crypto_enqueue_direct(lentil_hip_ctx *ctx, hipStream_t st);
 
 LENTIL_API int lentil_hip_destroy(lentil_hip_ctx *ctx) {
   if (!ctx) return LENTIL_OK;
+  (void)hipSetDevice(ctx->device);
+  // passes nobody has looked at: the device must be through with them before their buffers go; their verdicts no longer matter
+  for (const lentil_hip_ctx::Inflight &in : ctx->inflight) (void)hipEventSynchronize(ctx->slots[in.slot].ev[2]);
+  ctx->inflight.clear();
+  release_turn(ctx);
   (void)lentil_hip_comm_destroy(ctx);
   (void)hipSetDevice(ctx->device);
   upload_destroy(ctx);
@@ -608,8 +725,13 @@ LENTIL_API int lentil_hip_destroy(lentil_hip_ctx *ctx) {
   if (ctx->pub_done) (void)hipEventDestroy(ctx->pub_done);
   if (ctx->ev_slow) (void)hipEventDestroy(ctx->ev_slow);
   if (ctx->ev_round) (void)hipEventDestroy(ctx->ev_round);
-  if (ctx->ev_scan_k[0]) (void)hipEventDestroy(ctx->ev_scan_k[0]);
-  if (ctx->ev_scan_k[1]) (void)hipEventDestroy(ctx->ev_scan_k[1]);
+  for (lentil_hip_ctx::Slot &sl : ctx->slots) {
+    for (hipEvent_t e : sl.ev) if (e) (void)hipEventDestroy(e);
+    if (sl.ev_scan_k[0]) (void)hipEventDestroy(sl.ev_scan_k[0]);
+    if (sl.ev_scan_k[1]) (void)hipEventDestroy(sl.ev_scan_k[1]);
+    if (sl.ev_tail) (void)hipEventDestroy(sl.ev_tail);
+    if (sl.h_ctr_pinned) (void)hipHostFree(sl.h_ctr_pinned);
+  }
   if (ctx->ev_acc1) (void)hipEventDestroy(ctx->ev_acc1);
   if (ctx->ev_b) (void)hipEventDestroy(ctx->ev_b);
   if (ctx->ev_res) (void)hipEventDestroy(ctx->ev_res);
@@ -619,7 +741,6 @@ LENTIL_API int lentil_hip_destroy(lentil_hip_ctx *ctx) {
   if (ctx->aux_stream) { (void)hipStreamSynchronize(ctx->aux_stream); (void)hipStreamDestroy(ctx->aux_stream); }
   if (ctx->ev_crypto) (void)hipEventDestroy(ctx->ev_crypto);
   (void)hipFree(ctx->d_ctr);
-  if (ctx->h_ctr_pinned) (void)hipHostFree(ctx->h_ctr_pinned);
   (void)hipFree(ctx->d_ranges);
   (void)hipFree(ctx->d_live);
   if (ctx->jit_module) (void)hipModuleUnload(ctx->jit_module);
@@ -627,8 +748,7 @@ LENTIL_API int lentil_hip_destroy(lentil_hip_ctx *ctx) {
   (void)hipFree(ctx->d_ext_q);
   (void)hipFree(ctx->d_xor); (void)hipFree(ctx->d_tlc_res); (void)hipFree(ctx->d_tlc_off); (void)hipFree(ctx->d_tlc_tasks);
   (void)hipFree(ctx->d_log);
-  for (auto &ev : ctx->ev) if (ev) (void)hipEventDestroy(ev);
-  if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+  if (ctx->stream) (void)hipStreamDestroy(ctx->stream);       // (ctx->ev[]: one of the slots' sets, destroyed with them above)
   delete ctx;
   return LENTIL_OK;
 }
@@ -1176,7 +1296,7 @@ static int ensure_worklist(lentil_hip_ctx *ctx, uint64_t n) {
 }
 
 LENTIL_API int lentil_hip_bind_visits(lentil_hip_ctx *ctx, const lentil_visits *v) {
-  CHECK_CTX(ctx);
+  CHECK_CTX_PIPELINED(ctx);
   int rc = check_visits(ctx, v);
   if (rc) return rc;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -1184,6 +1304,8 @@ LENTIL_API int lentil_hip_bind_visits(lentil_hip_ctx *ctx, const lentil_visits *
   // one on the stream (the caller keeps the columns it bound alive until the pass that reads them is done, as ever)
   const bool frees = !ctx->owned_visit_mem.empty() || ctx->upload != nullptr ||
                      !(v->n <= ctx->work_cap && ctx->d_work);
+  // (a pass whose end is still open keeps the stream it ran on -- Inflight::V --; memory of that stream about to be freed: it is looked at first)
+  if (frees && !ctx->inflight.empty() && (rc = settle(ctx))) return rc;
   if (frees) HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   free_visits(ctx);
   upload_release(ctx, true);
@@ -1237,7 +1359,9 @@ LENTIL_API int lentil_hip_upload_visits(lentil_hip_ctx *ctx, const lentil_visits
 }
 
 LENTIL_API int lentil_hip_clear_frame(lentil_hip_ctx *ctx) {
-  CHECK_CTX(ctx);
+  CHECK_CTX_PIPELINED(ctx);
+  // a pass nobody has looked at: its frame goes -- abandoned (its counters are still read, what it lacked is no longer done)
+  if (!ctx->inflight.empty()) { ctx->inflight.back().abandoned = true; harvest_ready(ctx); }
   if (!ctx->trace.marks.empty()) { ht_mark(ctx, "next_clear"); ht_dump(ctx); }
   ht_mark(ctx, "clear{");
   ctx->resolved_valid = false;         // (what an early resolve left in d_resolved no longer describes the frame)
@@ -2021,8 +2145,204 @@ static BatchModelDev batch_model_dev(const lentil_hip_ctx *ctx) {
   return m;
 }
 
-static int redistribute_streamed(lentil_hip_ctx *ctx, bool *streamed) {
+// The end of a streamed pass: its counters have arrived in `pinned`.  What they say -- everything fitted?  the lean tail's bet
+// held?  nobody gave up waiting? -- and, where not, the work that is left (can_fix; false for a pass whose frame has been
+// cleared since: its verdict is only counted).  Sizes the next pass from what this one found.
+static int streamed_finish(lentil_hip_ctx *ctx, StreamTail &t, const DevCounters *pinned, bool can_fix, bool *streamed) {
+  const int C = ctx->n_chunks;
+  lentil_hip_ctx::Chunk &ch = ctx->chunks[0];
+  DrawArgs &da = t.da;
+  const bool predicted = t.predicted, lean = t.lean, extend = t.extend, live = t.live;
+  const int blind_rounds = t.blind_rounds;
+  SlowRec *const slow_base = t.slow_base;
+  const uint32_t slow_cap_all = t.slow_cap_all;
+  const unsigned accept_blocks = t.accept_blocks;
+  int rc;
+  (void)live;
+  ctx->h_ctr.assign(pinned, pinned + C);
+  ctx->h_ctr_valid = true;
+  ctx->last_streamed = 1;
+  const DevCounters c = ctx->h_ctr[0];
+  ch.was_blind = true;
+  if (c.probe_snap[0]) {
+    // LENTIL_DISPATCH_PROBE: the first accept's last item was finished while blocks of its grid had not begun
+    char buf[640];
+    int n = snprintf(buf, sizeof buf, "[probe] epoch %u: accept blocks begun %u of %u when the last item was done; per XCD begun:", ctx->epoch, c.probe_snap[33], c.probe_snap[34]);
+    for (int x = 0; x < 8; ++x) n += snprintf(buf + n, sizeof buf - n, " %u", c.probe_snap[1 + x]);
+    const char *kinds[3] = {"second round's solve waves resident", "second round's straggler waves resident", "first round's straggler waves resident"};
+    for (int k = 0; k < 3; ++k) {
+      n += snprintf(buf + n, sizeof buf - n, " | %s:", kinds[k]);
+      for (int x = 0; x < 8; ++x) n += snprintf(buf + n, sizeof buf - n, " %u", c.probe_snap[9 + 8 * k + x]);
+    }
+    fprintf(stderr, "%s\n", buf);
+  }
+  if (c.fallback || c.stuck) {
+    {
+      // what made the pass give up, kept for lentil_hip_last_redo_note(): `fallback` bits 1 items, 2 result pool, 4 task queue,
+      // 8 a wave's pending flushes, 16 range queue, 32 the blind preparation's bounds; `stuck` = (ticket << 2) | who waited (1 a
+      // publisher, 2 a resident solve wave, 3 a straggler wave)
+      char note[768];
+      snprintf(note, sizeof note,
+               "epoch %u: fallback 0x%llx stuck 0x%x (timeout %.0f ms)%s%s | items %llu/%u tasks %u/%u pool %llu/%llu ranges %u/%u | "
+               "scan blocks done %u publishers done %u rounds_used %llu | first batches %s, margin16 %u, blind passes before %u | "
+               "the wave that gave up: round %u parity %u, its queue's n_tasks %u head %u, accept blocks done %u begun %u, slot word 0x%x (epoch tag 0x%x), block %u",
+               ctx->epoch, (unsigned long long)c.fallback, c.stuck, (double)t.stuck_ticks * 1.0e-5,
+               c.stuck ? " waited: " : "", c.stuck ? ((c.stuck & 3u) == 1 ? "publisher" : (c.stuck & 3u) == 2 ? "resident solve wave" : "straggler wave") : "",
+               (unsigned long long)c.work_count, t.item_cap, c.n_tasks[0], t.task_cap, (unsigned long long)c.pool_used[0],
+               (unsigned long long)t.pool_cap, c.n_ranges, t.range_cap, c.scan_blocks_done, c.publishers_done,
+               (unsigned long long)c.rounds_used, predicted ? "modelled" : "plain", ctx->bm_margin16, ctx->last_blind - 1u,
+               c.stuck_info[0], c.stuck_info[1], c.stuck_info[2], c.stuck_info[7], c.stuck_info[3], c.stuck_info[4], c.stuck_info[5],
+               c.stuck_info[5] >> kTaskTagShift, c.stuck_info[6]);
+      ctx->redo_note = note;
+      if (getenv("LENTIL_STREAM_DEBUG")) fprintf(stderr, "[stream] note: %s\n", note);
+    }
+    if (getenv("LENTIL_STREAM_DEBUG"))
+      fprintf(stderr, "[stream] redo: who %u ticket %u epoch %u range_head %u pubs_done %u scan_done %u | fallback %llu stuck %u | items %llu (cap %u) tasks %u (cap %u) pool %llu (cap %llu) ranges %u (cap %u)\n",
+              c.stuck & 3u, c.stuck >> 2, ctx->epoch, c.range_head, c.publishers_done, c.scan_blocks_done, c.fallback, c.stuck, c.work_count, t.item_cap, c.n_tasks[0], t.task_cap, c.pool_used[0], (unsigned long long)t.pool_cap,
+              c.n_ranges, t.range_cap);
+    if (getenv("LENTIL_STREAM_DEBUG")) {
+      HIP_TRY(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
+      HIP_TRY(ctx, hipEventSynchronize(ctx->ev[2]));
+      float ms_scan = 0.f, ms_all = 0.f;
+      (void)hipEventElapsedTime(&ms_scan, ctx->ev[0], ctx->ev[1]);
+      (void)hipEventElapsedTime(&ms_all, ctx->ev[0], ctx->ev[2]);
+      fprintf(stderr, "[stream] scan %.3f ms, pass until the read-back %.3f ms\n", ms_scan, ms_all);
+    }
+    if (getenv("LENTIL_STREAM_DEBUG"))
+      fprintf(stderr, "[stream] queues: n_tasks %u/%u task_head %u/%u n_active %u/%u active_head %u/%u accept_done %u/%u pool_used %llu/%llu\n",
+              c.n_tasks[0], c.n_tasks[1], c.task_head[0], c.task_head[1], c.n_active[0], c.n_active[1], c.active_head[0], c.active_head[1],
+              c.accept_done[0], c.accept_done[1], c.pool_used[0], c.pool_used[1]);
+    if (getenv("LENTIL_STREAM_DEBUG"))
+      fprintf(stderr, "[stream] stragglers: live %d waves_done %u/%u (round 1: %u) parked %u/%u heads %u/%u cap %u waves %u rounds_used %llu\n", (int)live,
+              c.waves_done[0], c.waves_started[0], c.waves_done[1], c.n_slow[0], c.n_slow[1], c.slow_head[0], c.slow_head[1],
+              da.slow_cap, da.slow_waves, c.rounds_used);
+    if (c.stuck) {
+      g_stat_stuck.fetch_add(1, std::memory_order_relaxed);
+      if (t.inject) g_stat_stuck_injected.fetch_add(1, std::memory_order_relaxed);
+    }
+    if (ctx->notes.size() < 8) ctx->notes.push_back(ctx->redo_note);
+    if (!can_fix) {
+      // abandoned: the frame this pass wrote into has been cleared since; what it lacked is counted, not done
+      if (c.stuck) ++ctx->n_stuck;
+      ++ctx->last_fallback;
+      ++ctx->totals.abandoned_incomplete;
+      ctx->last_rounds = (int)c.rounds_used;
+      if (!c.stuck) {
+        // (the scan and the publishers counted everything they met, whether or not it fitted: the next pass is sized from that)
+        const uint64_t n_items = c.work_count < ctx->V.n ? c.work_count : ctx->V.n;
+        ctx->have_total_est = true;
+        ctx->est_items_total = n_items; ctx->est_sum_total = c.sum_samples;
+      }
+      for (int ci = 0; ci < C; ++ci) ctx->chunks[ci].have_est = false;
+      *streamed = true;
+      return LENTIL_OK;
+    }
+    t.did_more = true;
+    if (c.stuck && c.rounds_used) {
+      // Stalled with draws already accepted: the frame holds a part of the pass.  It held nothing before (the gate at the
+      // top), so lentil_hip_redistribute wipes it and runs the whole pass again in the chunked form.
+      ++ctx->n_stuck;
+      ctx->stall_redo = true;
+      ctx->h_ctr_valid = false;
+      ctx->late_resolve_done = false;
+      *streamed = true;
+      return LENTIL_OK;
+    }
+    if (c.stuck) {
+      ++ctx->n_stuck;
+      HIP_TRY(ctx, hipMemsetAsync((char *)ctx->d_ctr + offsetof(DevCounters, stuck), 0, sizeof(unsigned int), ch.stream));
+    }
+    // did not fit: nothing was accepted.  Fresh queues, then the draws again the plain way, sized from the counters
+    ctx->h_ctr_valid = false;
+    ctx->late_resolve_done = false;
+    ++ctx->last_fallback;
+    HIP_TRY(ctx, hipMemsetAsync((char *)ctx->d_ctr + offsetof(DevCounters, n_tasks), 0,
+                                offsetof(DevCounters, inv_row_min) - offsetof(DevCounters, n_tasks), ch.stream));
+    HIP_TRY(ctx, hipMemsetAsync((char *)ctx->d_ctr + offsetof(DevCounters, fallback), 0, sizeof(unsigned long long), ch.stream));
+    DrawArgs db{};
+    init_draw_args(ctx, db);
+    if ((rc = enqueue_chunk_draws(ctx, 0, db, 3))) return rc;
+    HIP_TRY(ctx, hipStreamSynchronize(ch.stream));
+    int rounds = 3;
+    if (ch.n_items) { if ((rc = finish_rounds(ctx, 0, db, 3, &rounds))) return rc; }
+    ch.est_rounds = rounds;
+    ctx->last_rounds = rounds;
+  } else {
+    const uint64_t n_items = c.work_count < ctx->V.n ? c.work_count : ctx->V.n;
+    ch.have_est = true; ch.est_items = n_items; ch.est_sum = c.sum_samples; ch.est_rounds = (int)c.rounds_used;
+    if (c.tries) { ctx->mean_iters = (double)c.newton_iters / (double)c.tries; ctx->parked_frac = (double)c.slow_solves / (double)c.tries; }
+    int rounds = blind_rounds;
+    if (extend) ctx->lean_ok = c.n_tasks[1] == 0u;       // (what the next pass may count on)
+    if (lean) ++ctx->n_lean;
+    // A pass whose first batches came from the model and left an item short all the same: the model's margin widens for the
+    // passes that follow (the item is served by further rounds as ever); with the margin at its cap the context stops
+    // betting on the lean tail until its camera set-up changes.
+    const bool short_after_all = predicted && n_items && (c.n_tasks[1] != 0u || (lean && c.n_active[blind_rounds & 1] != 0u));
+    // (an abandoned pass: what it still needed is counted, not done -- nobody can see its frame any more)
+    const bool open_end = n_items && ((lean && c.n_tasks[1] != 0u) || c.n_active[blind_rounds & 1] != 0);
+    if (open_end && !can_fix) {
+      ++ctx->totals.abandoned_incomplete;
+      if (ctx->notes.size() < 8) ctx->notes.push_back("abandoned before its end was looked at: the first accept had scheduled another round (lean tail's bet lost)");
+    } else if (open_end) {
+      t.did_more = true;
+    }
+    if (short_after_all) {
+      // (a pass that loses only now and then keeps betting: the margin comes back down after 16 passes without a loss)
+      ctx->bm_since_loss = 0;
+      if (ctx->bm_margin16 >= 4u) ctx->lean_ok = false;
+      else ctx->bm_margin16 += 1u;
+    }
+    if (predicted && !short_after_all && ++ctx->bm_since_loss >= 16u && ctx->bm_margin16 > 0u) { --ctx->bm_margin16; ctx->bm_since_loss = 0; }
+    if (!can_fix && open_end) {
+      if (lean) ++ctx->n_lean_lost;
+      rounds = (int)c.rounds_used + 1;
+    } else
+    if (lean && n_items && c.n_tasks[1] != 0u) {
+      // The lean tail's bet was lost: the first accept scheduled tasks, the accept behind it did nothing.  The round the
+      // ordinary way -- its solves (the queue is complete), their stragglers, the accept that was held back -- then whatever
+      // rounds follow.  (Rare: an item whose estimate in the solve kernel was too kind; ~0.3 ms.)
+      ctx->h_ctr_valid = false;
+      ctx->late_resolve_done = false;
+      da.parity = 1; da.round = 1;
+      da.producers_done = nullptr; da.producers_total = 0;
+      da.slow_live = 0; da.slow_indirect = 0; da.slow_q = -1; da.slow_round = -1; da.slow_close = 1;
+      da.emit_live = 0; da.lean_gate = 0; da.no_reset = 1;
+      {
+        DrawArgs dr = da;       // (its parked solves go to the upper half of the records: the lower half holds the first round's results)
+        if (dr.slow) { dr.slow = slow_base + slow_cap_all / 2u; dr.slow_cap = slow_cap_all - slow_cap_all / 2u; }
+        launch_solve(ctx, dr, ch.stream, (unsigned)ctx->num_cu);
+      }
+      hipLaunchKernelGGL(reset_round_kernel, dim3(1), dim3(1), 0, ch.stream, ctx->d_ctr, 0u, 1u);
+      hipLaunchKernelGGL(accept_kernel<2>, dim3(accept_blocks), dim3(256), 0, ch.stream, da);
+      HIP_TRY(ctx, hipGetLastError());
+      da.no_reset = 0;
+      if ((rc = finish_rounds(ctx, 0, da, 2, &rounds))) return rc;
+      if (rounds > ch.est_rounds) ch.est_rounds = rounds;
+      ++ctx->n_lean_lost;
+    } else
+    if (n_items && c.n_active[blind_rounds & 1] != 0) {
+      ctx->h_ctr_valid = false;
+      ctx->late_resolve_done = false;
+      if ((rc = finish_rounds(ctx, 0, da, blind_rounds, &rounds))) return rc;
+      if (rounds > ch.est_rounds) ch.est_rounds = rounds;
+      if (lean) ++ctx->n_lean_lost;
+    } else if (lean) {
+      rounds = 1;       // one round of solves: the accept behind the first one only waited for that round's parked solves
+    }
+    ctx->last_rounds = rounds;
+  }
+  ctx->have_total_est = true;
+  ctx->est_items_total = ch.est_items; ctx->est_sum_total = ch.est_sum; ctx->est_rounds_total = ch.est_rounds;
+  // (should the next pass run chunked, its chunks look at their scans first: this pass knows nothing about them)
+  for (int ci = 0; ci < C; ++ci) ctx->chunks[ci].have_est = false;
+  *streamed = true;
+  return LENTIL_OK;
+}
+
+
+static int redistribute_streamed(lentil_hip_ctx *ctx, bool *streamed, bool *deferred) {
   *streamed = false;
+  *deferred = false;
   const lentil_params &P = ctx->P;
   if (!ctx->stream_mode || P.cameraType != LENTIL_POLYNOMIAL_OPTICS || !ctx->have_total_est || ctx->V.n == 0)
     return LENTIL_OK;
@@ -2055,9 +2375,8 @@ static int redistribute_streamed(lentil_hip_ctx *ctx, bool *streamed) {
   // A context that finds another one's streamed pass in flight does not wait for it: its pass runs in the chunked form,
   // whose kernels never wait for anything (LENTIL_STREAM_WAIT=1: wait, as rounds 2 did).
   static const bool wait_for_turn = getenv("LENTIL_STREAM_WAIT") && getenv("LENTIL_STREAM_WAIT")[0] == '1';
-  std::unique_lock<std::mutex> one_at_a_time(g_stream_mutex[ctx->device & 63], std::defer_lock);
-  if (wait_for_turn) one_at_a_time.lock();
-  else if (!one_at_a_time.try_lock()) return LENTIL_OK;
+  DeviceTurn turn(ctx);
+  if (!turn.take(wait_for_turn)) return LENTIL_OK;
   DrawArgs da{};
   init_draw_args(ctx, da);
   ++ctx->n_streamed;
@@ -2578,6 +2897,11 @@ static int redistribute_streamed(lentil_hip_ctx *ctx, bool *streamed) {
   }
   const int C = ctx->n_chunks;
   ht_mark(ctx, "all_launched");
+  StreamTail t;
+  t.tail = tail; t.pass_t0 = pass_t0; t.calibrates_now = calibrates_now; t.predicted = predicted; t.lean = lean; t.extend = extend;
+  t.live = live; t.inject = da.inject_stall != 0; t.blind_rounds = blind_rounds; t.da = da; t.slow_base = slow_base;
+  t.slow_cap_all = slow_cap_all; t.accept_blocks = accept_blocks; t.item_cap = pub.item_cap; t.task_cap = pub.task_cap;
+  t.range_cap = plan.sa.range_cap; t.pool_cap = pub.pool_cap; t.stuck_ticks = stuck_ticks;
   bool have_counters = false;
   if (ctx->spin_readback && ctx->d_ctr_host) {
     // The counters by a kernel into the host's copy and a sequence number behind them; the host polls that number.  (A copy
@@ -2596,11 +2920,37 @@ static int redistribute_streamed(lentil_hip_ctx *ctx, bool *streamed) {
           std::chrono::duration<double>(std::chrono::steady_clock::now() - spin_t0).count() > 2.0) break;      // (then the plain way)
     }
   }
-  if (!have_counters) {
+  if (!have_counters)
     HIP_TRY(ctx, hipMemcpyAsync(ctx->h_ctr_pinned, ctx->d_ctr, sizeof(DevCounters) * C, hipMemcpyDeviceToHost, tail));
-    HIP_TRY(ctx, hipStreamSynchronize(tail));
+  // The asynchronous end (lentil_hip_ctx::async_end): the lean tail is the pass that expects to have nothing left to do, and the
+  // frame takes nothing but gaussian splats (closest-filtered AOVs, lentil_debug and cryptomatte have host steps behind the pass).
+  // Everything of the pass is behind `tail` by now (the lean tail's accepts wait for the scan, the publishers, the stragglers
+  // and the early resolve); the context's own stream waits for it in turn, so whatever the caller enqueues next follows the pass.
+  const bool defer = ctx->async_end && lean && !have_counters && !ctx->spin_readback && !ctx->crypto && !ctx->F.zkey && !ctx->F.zkey_dbg &&
+                     !ctx->comm && !ctx->closest_deferred && !da.inject_stall && !host_trace_passes() && ctx->inflight.size() < 2;
+  if (defer) {
+    lentil_hip_ctx::Slot &sl = ctx->slots[ctx->slot];
+    HIP_TRY(ctx, hipEventRecord(sl.ev_tail, tail));
+    if (tail != ctx->stream) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, sl.ev_tail, 0));
+    t.deferred = true;
+    lentil_hip_ctx::Inflight in;
+    in.slot = ctx->slot; in.t = t; in.V = ctx->V; in.have_visits = ctx->have_visits;
+    ctx->inflight.push_back(in);
+    turn.keep();                  // (the device's turn stays this context's until the pass has been looked at)
+    ctx->last_streamed = 1;
+    ++ctx->last_blind;
+    *deferred = true;
+    *streamed = true;
+    return LENTIL_OK;
   }
+  if (!have_counters) HIP_TRY(ctx, hipStreamSynchronize(tail));
   ht_mark(ctx, "tail_synced");
+  if (tail != ctx->stream) {
+    // everything the pass enqueued anywhere is behind the read-back that has just arrived; what the caller enqueues on
+    // the context's stream next (resolve, downloads, the next pass) follows the main stream's own last kernel
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  ht_mark(ctx, "main_synced");
   {
     // (host time from the pass's first launch to its counters: an upper bound of every wait inside it)
     const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - pass_t0).count();
@@ -2608,161 +2958,8 @@ static int redistribute_streamed(lentil_hip_ctx *ctx, bool *streamed) {
       ctx->longest_pass_ms = ms; ctx->longest_pass_visits = ctx->V.n; ctx->longest_pass_sum = ctx->est_sum_total;
     }
   }
-  if (tail != ctx->stream) {
-    // everything the pass enqueued anywhere is behind the read-back that has just arrived; what the caller enqueues on
-    // the context's stream next (resolve, downloads, the next pass) follows the main stream's own last kernel
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-  }
-  ht_mark(ctx, "main_synced");
-  ctx->h_ctr.assign(ctx->h_ctr_pinned, ctx->h_ctr_pinned + C);
-  ctx->h_ctr_valid = true;
-  ctx->last_streamed = 1;
   ++ctx->last_blind;
-  const DevCounters c = ctx->h_ctr[0];
-  ch.was_blind = true;
-  if (c.probe_snap[0]) {
-    // LENTIL_DISPATCH_PROBE: the first accept's last item was finished while blocks of its grid had not begun
-    char buf[640];
-    int n = snprintf(buf, sizeof buf, "[probe] epoch %u: accept blocks begun %u of %u when the last item was done; per XCD begun:", ctx->epoch, c.probe_snap[33], c.probe_snap[34]);
-    for (int x = 0; x < 8; ++x) n += snprintf(buf + n, sizeof buf - n, " %u", c.probe_snap[1 + x]);
-    const char *kinds[3] = {"second round's solve waves resident", "second round's straggler waves resident", "first round's straggler waves resident"};
-    for (int k = 0; k < 3; ++k) {
-      n += snprintf(buf + n, sizeof buf - n, " | %s:", kinds[k]);
-      for (int x = 0; x < 8; ++x) n += snprintf(buf + n, sizeof buf - n, " %u", c.probe_snap[9 + 8 * k + x]);
-    }
-    fprintf(stderr, "%s\n", buf);
-  }
-  if (c.fallback || c.stuck) {
-    {
-      // what made the pass give up, kept for lentil_hip_last_redo_note(): `fallback` bits 1 items, 2 result pool, 4 task queue,
-      // 8 a wave's pending flushes, 16 range queue, 32 the blind preparation's bounds; `stuck` = (ticket << 2) | who waited (1 a
-      // publisher, 2 a resident solve wave, 3 a straggler wave)
-      char note[768];
-      snprintf(note, sizeof note,
-               "epoch %u: fallback 0x%llx stuck 0x%x (timeout %.0f ms)%s%s | items %llu/%u tasks %u/%u pool %llu/%llu ranges %u/%u | "
-               "scan blocks done %u publishers done %u rounds_used %llu | first batches %s, margin16 %u, blind passes before %u | "
-               "the wave that gave up: round %u parity %u, its queue's n_tasks %u head %u, accept blocks done %u begun %u, slot word 0x%x (epoch tag 0x%x), block %u",
-               ctx->epoch, (unsigned long long)c.fallback, c.stuck, (double)stuck_ticks * 1.0e-5,
-               c.stuck ? " waited: " : "", c.stuck ? ((c.stuck & 3u) == 1 ? "publisher" : (c.stuck & 3u) == 2 ? "resident solve wave" : "straggler wave") : "",
-               (unsigned long long)c.work_count, pub.item_cap, c.n_tasks[0], pub.task_cap, (unsigned long long)c.pool_used[0],
-               (unsigned long long)pub.pool_cap, c.n_ranges, plan.sa.range_cap, c.scan_blocks_done, c.publishers_done,
-               (unsigned long long)c.rounds_used, predicted ? "modelled" : "plain", ctx->bm_margin16, ctx->last_blind - 1u,
-               c.stuck_info[0], c.stuck_info[1], c.stuck_info[2], c.stuck_info[7], c.stuck_info[3], c.stuck_info[4], c.stuck_info[5],
-               c.stuck_info[5] >> kTaskTagShift, c.stuck_info[6]);
-      ctx->redo_note = note;
-      if (getenv("LENTIL_STREAM_DEBUG")) fprintf(stderr, "[stream] note: %s\n", note);
-    }
-    if (getenv("LENTIL_STREAM_DEBUG"))
-      fprintf(stderr, "[stream] redo: who %u ticket %u epoch %u range_head %u pubs_done %u scan_done %u | fallback %llu stuck %u | items %llu (cap %u) tasks %u (cap %u) pool %llu (cap %llu) ranges %u (cap %u)\n",
-              c.stuck & 3u, c.stuck >> 2, ctx->epoch, c.range_head, c.publishers_done, c.scan_blocks_done, c.fallback, c.stuck, c.work_count, pub.item_cap, c.n_tasks[0], pub.task_cap, c.pool_used[0], (unsigned long long)pub.pool_cap,
-              c.n_ranges, plan.sa.range_cap);
-    if (getenv("LENTIL_STREAM_DEBUG")) {
-      HIP_TRY(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
-      HIP_TRY(ctx, hipEventSynchronize(ctx->ev[2]));
-      float ms_scan = 0.f, ms_all = 0.f;
-      (void)hipEventElapsedTime(&ms_scan, ctx->ev[0], ctx->ev[1]);
-      (void)hipEventElapsedTime(&ms_all, ctx->ev[0], ctx->ev[2]);
-      fprintf(stderr, "[stream] scan %.3f ms, pass until the read-back %.3f ms\n", ms_scan, ms_all);
-    }
-    if (getenv("LENTIL_STREAM_DEBUG"))
-      fprintf(stderr, "[stream] queues: n_tasks %u/%u task_head %u/%u n_active %u/%u active_head %u/%u accept_done %u/%u pool_used %llu/%llu\n",
-              c.n_tasks[0], c.n_tasks[1], c.task_head[0], c.task_head[1], c.n_active[0], c.n_active[1], c.active_head[0], c.active_head[1],
-              c.accept_done[0], c.accept_done[1], c.pool_used[0], c.pool_used[1]);
-    if (getenv("LENTIL_STREAM_DEBUG"))
-      fprintf(stderr, "[stream] stragglers: live %d waves_done %u/%u (round 1: %u) parked %u/%u heads %u/%u cap %u waves %u rounds_used %llu\n", (int)live,
-              c.waves_done[0], c.waves_started[0], c.waves_done[1], c.n_slow[0], c.n_slow[1], c.slow_head[0], c.slow_head[1],
-              da.slow_cap, da.slow_waves, c.rounds_used);
-    if (c.stuck) {
-      g_stat_stuck.fetch_add(1, std::memory_order_relaxed);
-      if (da.inject_stall) g_stat_stuck_injected.fetch_add(1, std::memory_order_relaxed);
-    }
-    if (c.stuck && c.rounds_used) {
-      // Stalled with draws already accepted: the frame holds a part of the pass.  It held nothing before (the gate at the
-      // top), so lentil_hip_redistribute wipes it and runs the whole pass again in the chunked form.
-      ++ctx->n_stuck;
-      ctx->stall_redo = true;
-      ctx->h_ctr_valid = false;
-      ctx->late_resolve_done = false;
-      *streamed = true;
-      return LENTIL_OK;
-    }
-    if (c.stuck) {
-      ++ctx->n_stuck;
-      HIP_TRY(ctx, hipMemsetAsync((char *)ctx->d_ctr + offsetof(DevCounters, stuck), 0, sizeof(unsigned int), ch.stream));
-    }
-    // did not fit: nothing was accepted.  Fresh queues, then the draws again the plain way, sized from the counters
-    ctx->h_ctr_valid = false;
-    ctx->late_resolve_done = false;
-    ++ctx->last_fallback;
-    HIP_TRY(ctx, hipMemsetAsync((char *)ctx->d_ctr + offsetof(DevCounters, n_tasks), 0,
-                                offsetof(DevCounters, inv_row_min) - offsetof(DevCounters, n_tasks), ch.stream));
-    HIP_TRY(ctx, hipMemsetAsync((char *)ctx->d_ctr + offsetof(DevCounters, fallback), 0, sizeof(unsigned long long), ch.stream));
-    DrawArgs db{};
-    init_draw_args(ctx, db);
-    if ((rc = enqueue_chunk_draws(ctx, 0, db, 3))) return rc;
-    HIP_TRY(ctx, hipStreamSynchronize(ch.stream));
-    int rounds = 3;
-    if (ch.n_items) { if ((rc = finish_rounds(ctx, 0, db, 3, &rounds))) return rc; }
-    ch.est_rounds = rounds;
-    ctx->last_rounds = rounds;
-  } else {
-    const uint64_t n_items = c.work_count < ctx->V.n ? c.work_count : ctx->V.n;
-    ch.have_est = true; ch.est_items = n_items; ch.est_sum = c.sum_samples; ch.est_rounds = (int)c.rounds_used;
-    if (c.tries) { ctx->mean_iters = (double)c.newton_iters / (double)c.tries; ctx->parked_frac = (double)c.slow_solves / (double)c.tries; }
-    int rounds = blind_rounds;
-    if (extend) ctx->lean_ok = c.n_tasks[1] == 0u;       // (what the next pass may count on)
-    if (lean) ++ctx->n_lean;
-    // A pass whose first batches came from the model and left an item short all the same: the model's margin widens for the
-    // passes that follow (the item is served by further rounds as ever); with the margin at its cap the context stops
-    // betting on the lean tail until its camera set-up changes.
-    const bool short_after_all = predicted && n_items && (c.n_tasks[1] != 0u || (lean && c.n_active[blind_rounds & 1] != 0u));
-    if (short_after_all) {
-      // (a pass that loses only now and then keeps betting: the margin comes back down after 16 passes without a loss)
-      ctx->bm_since_loss = 0;
-      if (ctx->bm_margin16 >= 4u) ctx->lean_ok = false;
-      else ctx->bm_margin16 += 1u;
-    }
-    if (predicted && !short_after_all && ++ctx->bm_since_loss >= 16u && ctx->bm_margin16 > 0u) { --ctx->bm_margin16; ctx->bm_since_loss = 0; }
-    if (lean && n_items && c.n_tasks[1] != 0u) {
-      // The lean tail's bet was lost: the first accept scheduled tasks, the accept behind it did nothing.  The round the
-      // ordinary way -- its solves (the queue is complete), their stragglers, the accept that was held back -- then whatever
-      // rounds follow.  (Rare: an item whose estimate in the solve kernel was too kind; ~0.3 ms.)
-      ctx->h_ctr_valid = false;
-      ctx->late_resolve_done = false;
-      da.parity = 1; da.round = 1;
-      da.producers_done = nullptr; da.producers_total = 0;
-      da.slow_live = 0; da.slow_indirect = 0; da.slow_q = -1; da.slow_round = -1; da.slow_close = 1;
-      da.emit_live = 0; da.lean_gate = 0; da.no_reset = 1;
-      {
-        DrawArgs dr = da;       // (its parked solves go to the upper half of the records: the lower half holds the first round's results)
-        if (dr.slow) { dr.slow = slow_base + slow_cap_all / 2u; dr.slow_cap = slow_cap_all - slow_cap_all / 2u; }
-        launch_solve(ctx, dr, ch.stream, (unsigned)ctx->num_cu);
-      }
-      hipLaunchKernelGGL(reset_round_kernel, dim3(1), dim3(1), 0, ch.stream, ctx->d_ctr, 0u, 1u);
-      hipLaunchKernelGGL(accept_kernel<2>, dim3(accept_blocks), dim3(256), 0, ch.stream, da);
-      HIP_TRY(ctx, hipGetLastError());
-      da.no_reset = 0;
-      if ((rc = finish_rounds(ctx, 0, da, 2, &rounds))) return rc;
-      if (rounds > ch.est_rounds) ch.est_rounds = rounds;
-      ++ctx->n_lean_lost;
-    } else
-    if (n_items && c.n_active[blind_rounds & 1] != 0) {
-      ctx->h_ctr_valid = false;
-      ctx->late_resolve_done = false;
-      if ((rc = finish_rounds(ctx, 0, da, blind_rounds, &rounds))) return rc;
-      if (rounds > ch.est_rounds) ch.est_rounds = rounds;
-      if (lean) ++ctx->n_lean_lost;
-    } else if (lean) {
-      rounds = 1;       // one round of solves: the accept behind the first one only waited for that round's parked solves
-    }
-    ctx->last_rounds = rounds;
-  }
-  ctx->have_total_est = true;
-  ctx->est_items_total = ch.est_items; ctx->est_sum_total = ch.est_sum; ctx->est_rounds_total = ch.est_rounds;
-  // (should the next pass run chunked, its chunks look at their scans first: this pass knows nothing about them)
-  for (int ci = 0; ci < C; ++ci) ctx->chunks[ci].have_est = false;
-  *streamed = true;
-  return LENTIL_OK;
+  return streamed_finish(ctx, t, ctx->h_ctr_pinned, true, streamed);
 }
 
 // Thin lens with abb_chromatic > 0 (kernels: tl_chroma_*): scan, the work list put into visit order on the host, every
@@ -2854,6 +3051,12 @@ LENTIL_API int lentil_hip_get_xor128_state(lentil_hip_ctx *ctx, uint32_t state[4
 
 static int redistribute_pass(lentil_hip_ctx *ctx);
 static int redistribute_impl(lentil_hip_ctx *ctx);
+static int pass_finish(lentil_hip_ctx *ctx);
+static int redistribute_top(lentil_hip_ctx *ctx);
+static void harvest_ready(lentil_hip_ctx *ctx);
+static int begin_slot(lentil_hip_ctx *ctx);
+static int redo_after_stall(lentil_hip_ctx *ctx);
+static void account_pass(lentil_hip_ctx *ctx);
 
 // Closest-filtered AOVs after a pass that met candidates at depth 0 / NaN: lentil_closest_replay.h.  Returns LENTIL_OK with
 // *need_log set when the pass kept no (complete) draw log to replay from.
@@ -2913,7 +3116,17 @@ static int closest_degenerate_replay(lentil_hip_ctx *ctx, bool *need_log) {
 }
 
 LENTIL_API int lentil_hip_redistribute(lentil_hip_ctx *ctx) {
-  CHECK_CTX(ctx);
+  CHECK_CTX_PIPELINED(ctx);
+  // A pass nobody has looked at and whose frame has NOT been cleared since: this one adds to the same frame -- it observes.
+  // (Abandoned passes wait their turn: begin_slot looks at the oldest when its slot comes round, harvest_ready at those that are through.)
+  if (!ctx->inflight.empty() && !ctx->inflight.back().abandoned) { const int rc0 = settle(ctx); if (rc0) return rc0; }
+  harvest_ready(ctx);
+  const int rc1 = redistribute_top(ctx);
+  if (rc1 == LENTIL_OK && (ctx->inflight.empty() || ctx->inflight.back().slot != ctx->slot)) account_pass(ctx);      // (a deferred pass is accounted when its end is known)
+  return rc1;
+}
+
+static int redistribute_top(lentil_hip_ctx *ctx) {
   ctx->stall_redo = false;
   ctx->degenerate_seen = false;
   const bool clean_entry = ctx->cleared_since_pass;
@@ -2964,11 +3177,168 @@ LENTIL_API int lentil_hip_redistribute(lentil_hip_ctx *ctx) {
   return LENTIL_OK;
 }
 
+
+// ---- the asynchronous end of a pass: slots, the look at a pass's end, the totals ------------------------------------------
+// one slot's kernel times into the totals, once its last event has passed (blocking: wait for it)
+static void flush_timing(lentil_hip_ctx *ctx, int si, bool blocking) {
+  lentil_hip_ctx::Slot &sl = ctx->slots[si];
+  if (!sl.timing_open) return;
+  const bool cur = si == ctx->slot;
+  if (cur) { sl.timed_draw = ctx->timed_draw; sl.timed_resolve = ctx->timed_resolve; sl.scan_kernel_timed = ctx->scan_kernel_timed; }
+  const bool timed_draw = sl.timed_draw, timed_resolve = sl.timed_resolve, scan_k = sl.scan_kernel_timed;
+  if (!timed_draw) { if (!cur) sl.timing_open = false; return; }      // (a pass that failed before its end: nothing to read)
+  hipEvent_t last = timed_resolve ? sl.ev[4] : sl.ev[2];
+  if (!blocking && hipEventQuery(last) != hipSuccess) { (void)hipGetLastError(); return; }
+  if (hipEventSynchronize(last) != hipSuccess) { (void)hipGetLastError(); sl.timing_open = false; return; }
+  float a = 0.f, b = 0.f, c = 0.f, k = 0.f;
+  if (hipEventElapsedTime(&a, sl.ev[0], sl.ev[1]) != hipSuccess || hipEventElapsedTime(&b, sl.ev[1], sl.ev[2]) != hipSuccess) { (void)hipGetLastError(); a = b = 0.f; }
+  if (scan_k && hipEventElapsedTime(&k, sl.ev_scan_k[0], sl.ev_scan_k[1]) == hipSuccess && k > 0.f && k <= a) { b += a - k; a = k; }
+  else (void)hipGetLastError();
+  if (timed_resolve && hipEventElapsedTime(&c, sl.ev[3], sl.ev[4]) != hipSuccess) { (void)hipGetLastError(); c = 0.f; }
+  ctx->totals.scan_ms += a; ctx->totals.draw_ms += b; ctx->totals.resolve_ms += c;
+  sl.timing_open = false;
+}
+
+// a pass's counters and launch figures into the totals (ctx->h_ctr, last_*: the pass that has just been looked at)
+static void account_pass(lentil_hip_ctx *ctx) {
+  lentil_pass_totals &T = ctx->totals;
+  ++T.passes;
+  T.streamed += ctx->last_streamed; T.blind_chunks += ctx->last_blind; T.fallback_chunks += ctx->last_fallback;
+  T.visits += ctx->have_visits ? ctx->V.n : 0;
+  if (ctx->h_ctr_valid)
+    for (const DevCounters &k : ctx->h_ctr) {
+      T.redistributed_visits += k.redistributed; T.attempted_draws += k.attempted; T.accepted_draws += k.accepted;
+      T.worklist_overflow += k.overflow; T.newton_iterations += k.newton_iters; T.tries += k.tries; T.lane_rounds += k.lane_rounds;
+      T.slow_solves += k.slow_solves;
+    }
+  T.scan_launches += ctx->last_scan_launches ? ctx->last_scan_launches : 1u;
+  if ((uint64_t)ctx->last_rounds > T.rounds_max) T.rounds_max = (uint64_t)ctx->last_rounds;
+}
+
+// The oldest pass in flight: waits for it, reads its verdict, and -- unless its frame has been cleared since -- does what the
+// pass left open, exactly as lentil_hip_redistribute did while it still waited itself.
+static int harvest_front(lentil_hip_ctx *ctx) {
+  lentil_hip_ctx::Inflight in = ctx->inflight.front();
+  ctx->inflight.pop_front();
+  lentil_hip_ctx::Slot &sl = ctx->slots[in.slot];
+  int rc = LENTIL_OK;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  {
+    const hipError_t e = hipEventSynchronize(sl.ev[2]);        // (on the context's stream behind ev_tail: counters copied, every kernel of the pass through)
+    if (e != hipSuccess) { release_turn(ctx); return fail(ctx, LENTIL_ERR_HIP, std::string("waiting for a pass's end: ") + hipGetErrorString(e)); }
+  }
+  {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, sl.ev[0], sl.ev[2]) == hipSuccess) {
+      const double m = (double)ms + 0.3;      // (+ what the host needs to enqueue a pass: the estimate used to be host time)
+      if (!in.t.calibrates_now && m > ctx->longest_pass_ms && m < 200.0) { ctx->longest_pass_ms = m; ctx->longest_pass_visits = in.V.n; ctx->longest_pass_sum = ctx->est_sum_total; }
+    } else (void)hipGetLastError();
+  }
+  const bool can_fix = !in.abandoned;
+  // (the per-pass host fields describe the pass being looked at)
+  ctx->last_blind = 1; ctx->last_fallback = 0; ctx->last_rounds = 0; ctx->last_scan_launches = 1; ctx->last_streamed = 1;
+  ctx->h_ctr_valid = false;
+  std::swap(ctx->V, in.V);
+  std::swap(ctx->have_visits, in.have_visits);
+  bool streamed = true;
+  ctx->stall_redo = false;
+  rc = streamed_finish(ctx, in.t, sl.h_ctr_pinned, can_fix, &streamed);
+  if (rc == LENTIL_OK && can_fix) {
+    if (ctx->stall_redo) rc = redo_after_stall(ctx);
+    if (rc == LENTIL_OK && in.t.did_more) {
+      // the frame moved on behind the resolve the pass had enqueued on its way
+      ctx->resolved_valid = false;
+      ctx->early_resolve_pending = false;
+      (void)hipEventRecord(sl.ev[2], ctx->stream);       // (the pass's end for the totals' times: behind the extra work; the slot's own event, whichever slot is current)
+    }
+    if (rc == LENTIL_OK) rc = pass_finish(ctx);
+    if (rc == LENTIL_OK && in.resolve_requested && !ctx->resolved_valid) rc = resolve_range(ctx, 0, ctx->F.np);
+  }
+  ctx->stall_redo = false;
+  ++ctx->totals.deferred;
+  if (in.abandoned) ++ctx->totals.abandoned;
+  if (rc == LENTIL_OK) account_pass(ctx);
+  std::swap(ctx->V, in.V);
+  std::swap(ctx->have_visits, in.have_visits);
+  flush_timing(ctx, in.slot, false);
+  release_turn(ctx);
+  return rc;
+}
+
+// every pass in flight, oldest first (the observer's side of the asynchronous end)
+static int settle(lentil_hip_ctx *ctx) {
+  int rc = LENTIL_OK;
+  while (!ctx->inflight.empty()) {
+    const int r = harvest_front(ctx);
+    if (r != LENTIL_OK && rc == LENTIL_OK) rc = r;
+  }
+  return rc;
+}
+
+// abandoned passes the device is through with: looked at without waiting (their verdicts size the next pass)
+static void harvest_ready(lentil_hip_ctx *ctx) {
+  while (!ctx->inflight.empty() && ctx->inflight.front().abandoned) {
+    if (hipEventQuery(ctx->slots[ctx->inflight.front().slot].ev[2]) != hipSuccess) { (void)hipGetLastError(); return; }
+    (void)harvest_front(ctx);
+  }
+}
+
+// a pass begins: the next slot's events and counter block become the context's (a pass still in flight on it is looked at first)
+static int begin_slot(lentil_hip_ctx *ctx) {
+  lentil_hip_ctx::Slot &cur = ctx->slots[ctx->slot];
+  cur.timed_draw = ctx->timed_draw; cur.timed_resolve = ctx->timed_resolve; cur.scan_kernel_timed = ctx->scan_kernel_timed;
+  if (ctx->spin_readback) {        // (LENTIL_SPIN_READBACK: one block, addressed by the device -- no rotation, no asynchronous end)
+    flush_timing(ctx, ctx->slot, true);
+    ctx->timed_draw = ctx->timed_resolve = false; ctx->scan_kernel_timed = false;
+    cur.timing_open = true;
+    return LENTIL_OK;
+  }
+  const int next = (ctx->slot + 1) % 3;
+  // (at most two passes in flight unobserved: with two there already this one waits for the older -- the device still has the newer to work on)
+  while (ctx->inflight.size() >= 2 || (!ctx->inflight.empty() && ctx->inflight.front().slot == next)) {
+    const int rc = harvest_front(ctx);
+    if (rc) return rc;
+  }
+  flush_timing(ctx, ctx->slot, false);       // (saves the context's flags into the slot it leaves, whether or not its events have passed)
+  ctx->slot = -1;                             // (no slot is current while the next one's last pass -- three passes ago -- is flushed from its own flags)
+  flush_timing(ctx, next, true);              // its events are about to be recorded again
+  ctx->slot = next;
+  lentil_hip_ctx::Slot &n = ctx->slots[next];
+  for (int i = 0; i < 5; ++i) ctx->ev[i] = n.ev[i];
+  ctx->ev_scan_k[0] = n.ev_scan_k[0]; ctx->ev_scan_k[1] = n.ev_scan_k[1];
+  ctx->h_ctr_pinned = n.h_ctr_pinned;
+  ctx->timed_draw = ctx->timed_resolve = false; ctx->scan_kernel_timed = false;
+  n.timing_open = true;
+  return LENTIL_OK;
+}
+
+LENTIL_API int lentil_hip_set_async(lentil_hip_ctx *ctx, int on) {
+  CHECK_CTX(ctx);
+  ctx->async_end = on != 0;
+  return LENTIL_OK;
+}
+
+LENTIL_API int lentil_hip_pass_totals(lentil_hip_ctx *ctx, lentil_pass_totals *out, int reset) {
+  CHECK_CTX(ctx);
+  if (!out) return fail(ctx, LENTIL_ERR_INVALID, "out is null");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  for (int si = 0; si < 3; ++si) flush_timing(ctx, si, true);
+  ctx->slots[ctx->slot].timing_open = false;       // (the current pass's times are in: not a second time when its slot is left)
+  *out = ctx->totals;
+  if (reset) { ctx->totals = lentil_pass_totals{}; ctx->notes.clear(); }
+  return LENTIL_OK;
+}
+
 // one pass, with the recovery of a streamed pass that stalled after its first accept
 static int redistribute_impl(lentil_hip_ctx *ctx) {
   ctx->stall_redo = false;
   int rc = redistribute_pass(ctx);
   if (rc || !ctx->stall_redo) return rc;
+  return redo_after_stall(ctx);
+}
+
+static int redo_after_stall(lentil_hip_ctx *ctx) {
+  int rc;
   // A streamed pass gave up waiting (kStuckTicks) after its first accept had added draws to the frame.  Every kernel of the
   // pass has left by now (they all watch DevCounters::stuck); the frame was clear before the pass, so: clear it again --
   // accumulators through the splat flags, direct sums, cryptomatte -- and run the whole pass once more, chunked.
@@ -3016,6 +3386,7 @@ static int redistribute_pass(lentil_hip_ctx *ctx) {
   const int C = ctx->n_chunks;
   if (ctx->pass_pending) ctx->dirty_known = false;   // an earlier pass's rows were never asked for: unknown until a full clear
   ctx->pass_pending = true;
+  { const int rc = begin_slot(ctx); if (rc) return rc; }      // (this pass's own events and counter block)
   HIP_TRY(ctx, hipMemsetAsync(ctx->d_ctr, 0, sizeof(DevCounters) * (C + 1), ctx->stream));
   HIP_TRY(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
   ctx->last_rounds = 0;
@@ -3025,14 +3396,14 @@ static int redistribute_pass(lentil_hip_ctx *ctx) {
   ctx->last_streamed = 0;
   for (auto &ch : ctx->chunks) ch.heavy_pending = false;
   ctx->last_scan_launches = 0;
-  bool streamed = false;
+  bool streamed = false, deferred = false;
   const bool tl_chroma = P.cameraType == LENTIL_THINLENS && P.abb_chromatic > 0.0f;
   if (tl_chroma) {
     if (ctx->V.n) { const int rc = redistribute_tl_chroma(ctx); if (rc) return rc; }
     else { HIP_TRY(ctx, hipEventRecord(ctx->ev[1], ctx->stream)); HIP_TRY(ctx, hipEventRecord(ctx->scans_done, ctx->stream)); }
     streamed = true;          // (nothing of the chunked form below runs)
   } else {
-    const int rc = redistribute_streamed(ctx, &streamed);
+    const int rc = redistribute_streamed(ctx, &streamed, &deferred);
     if (rc) return rc;
     if (ctx->stall_redo) return LENTIL_OK;       // (lentil_hip_redistribute wipes the frame and calls again)
   }
@@ -3205,6 +3576,13 @@ static int redistribute_pass(lentil_hip_ctx *ctx) {
   }
   HIP_TRY(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
   ctx->timed_draw = true;
+  if (deferred) return LENTIL_OK;      // (the pass's end is looked at by its next observer: harvest_front -> pass_finish)
+  return pass_finish(ctx);
+}
+
+// what a pass's counters say once they are known: dropped work, candidates the closest-filtered AOVs cannot order
+static int pass_finish(lentil_hip_ctx *ctx) {
+  const int C = ctx->n_chunks;
   // A work list, task queue or result pool that was too small drops work on the device (DevCounters::overflow):
   // that is an incomplete frame, not a result
   if (ctx->V.n) {
@@ -3305,8 +3683,10 @@ static int launch_resolve_half(lentil_hip_ctx *ctx, hipStream_t st, uint32_t onl
 }
 
 LENTIL_API int lentil_hip_resolve(lentil_hip_ctx *ctx) {
-  CHECK_CTX(ctx);
+  CHECK_CTX_PIPELINED(ctx);
   if (!ctx->have_frame) return fail(ctx, LENTIL_ERR_INVALID, "no frame allocated");
+  // (behind a pass whose end is open: should that pass turn out to need more work, its observer resolves again)
+  if (!ctx->inflight.empty() && !ctx->inflight.back().abandoned) ctx->inflight.back().resolve_requested = true;
   ht_mark(ctx, "resolve");
   if (ctx->resolved_valid) {          // the pass resolved the frame on its way (nothing has touched it since)
     HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -3587,6 +3967,23 @@ LENTIL_API int lentil_hip_download_accum(lentil_hip_ctx *ctx, uint32_t aov, floa
     if (host_rgba) memcpy(host_rgba + p * 4, tmp.data() + p * rec + 4u * aov, 16);
     if (host_weight) host_weight[p] = tmp[p * rec + 4u * ctx->F.n_aovs];
   }
+  return LENTIL_OK;
+}
+
+LENTIL_API int lentil_hip_download_records(lentil_hip_ctx *ctx, float *host_records, uint64_t capacity_floats, uint32_t *stride) {
+  CHECK_CTX(ctx);
+  if (!ctx->have_frame) return fail(ctx, LENTIL_ERR_INVALID, "no frame allocated");
+  if (stride) *stride = ctx->F.stride;
+  if (!host_records) return LENTIL_OK;
+  const uint64_t n = ctx->F.np * ctx->F.stride;
+  if (capacity_floats < n) return fail(ctx, LENTIL_ERR_INVALID, "download_records: the host block is smaller than xres * yres * stride floats");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  {
+    const int rc = fold_direct(ctx, 0, ctx->F.np, true);
+    if (rc) return rc;
+  }
+  HIP_TRY(ctx, hipMemcpyAsync(host_records, ctx->F.acc, n * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   return LENTIL_OK;
 }
 

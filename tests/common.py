@@ -74,11 +74,14 @@ def rel_err(a, b, floor=1e-30):
 
 
 class ThreadedOracle:
-    """The oracle over a whole (large) stream, threaded over contiguous visit ranges that end on pixel-row
-    boundaries, every thread with private accumulators (the reference's own threads share theirs and race,
-    SURVEY 3.4) merged at the end.  A pixel that only receives its own visits is summed by one thread in
-    iterator order -- bit for bit what a single thread leaves there; where draws land, the per-thread
-    partial sums add up in thread order (inside the 1e-5 bar, and the fp64 shadows add up exactly)."""
+    """The oracle over a whole (large) stream, threaded over contiguous visit ranges that end on pixel-row boundaries.
+
+    One frame, shared (oracle/lentil_oracle.cpp: orc_redistribute_threads): a visit that stays in its pixel is added by the one
+    thread that owns the pixel's row, in iterator order -- bit for bit what a single thread leaves there; the accepted draws
+    are kept as records by the threads and added afterwards in visit order (inside the 1e-5 bar, and the fp64 shadows add
+    up exactly).  (The reference's own threads share their buffers and race)  Streams that form does not take
+    (lentil_debug, cryptomatte, thin-lens abb_chromatic > 0) fall back to one private frame per thread, merged in thread order
+    -- 60 B per pixel, AOV and thread, which is what used to bound the thread count of every 4K test."""
 
     def __init__(self, lib, p, table, visits, n_threads, n_aovs=1, kinds=None, bokeh=None, row_visits=None):
         import threading
@@ -88,6 +91,21 @@ class ThreadedOracle:
         rv = int(row_visits or (visits.pixels_per_row * visits.visits_per_pixel))
         rows = (n + rv - 1) // rv
         n_threads = max(1, min(n_threads, rows))
+        shared = oracle_lib.Frame(lib, p, n_aovs=n_aovs, kinds=kinds, keep_log=True)
+        try:
+            taken = rv > 0 and shared.run_threads(lens, bokeh, visits, max(n_threads, min(os.cpu_count() or 1, rows, 64)), rv)
+        except Exception:
+            shared.close()
+            if lens:
+                lib.orc_lens_destroy(lens)
+            raise
+        if taken:
+            if lens:
+                lib.orc_lens_destroy(lens)
+            self.frames = [shared]
+            self._log = shared.log()
+            return
+        shared.close()
         bounds = [min(n, int(round(i * rows / n_threads)) * rv) for i in range(n_threads + 1)]
         self.frames = [oracle_lib.Frame(lib, p, n_aovs=n_aovs, kinds=kinds, keep_log=True) for _ in range(n_threads)]
         errs = []

@@ -11,6 +11,8 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+    config.addinivalue_line("markers", "gpu_soak: seeded soaks / randomised sweeps / child-process runs on a GPU -- not part of -m gpu "
+                                       "(whose run has a time limit): tools/soak.sh runs them")
 
 
 @pytest.fixture(scope="session", autouse=True)

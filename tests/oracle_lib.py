@@ -76,6 +76,7 @@ def load():
         "orc_frame_set_camera_motion": (None, [vp, u32, vp]),
         "orc_frame_set_camera_shutter": (None, [vp, C.c_float, C.c_float]),
         "orc_redistribute": (i, [C.POINTER(_abi.Params), vp, vp, vp, C.POINTER(_abi.Visits), u64, u64]),
+        "orc_redistribute_threads": (i, [C.POINTER(_abi.Params), vp, vp, vp, C.POINTER(_abi.Visits), u64, u64, u32, u64]),
         "orc_resolve": (None, [vp, u32, vp]),
         "orc_inverse_sample_density": (f, [i, f, i, C.POINTER(i)]),
         "orc_filter_closest_complete": (None, [i, vp, vp, i, vp]),
@@ -114,6 +115,17 @@ class Frame:
         rc = self.lib.orc_redistribute(C.byref(self.params), lens, bokeh, self.h, C.byref(visits), v0, v1)
         if rc:
             raise RuntimeError("oracle redistribute rc=%d" % rc)
+
+    def run_threads(self, lens, bokeh, visits, n_threads, row_visits, v0=0, v1=None):
+        """the same visits over n_threads threads into this one frame (orc_redistribute_threads): own-pixel sums by the thread
+        that owns the rows, the draws added afterwards in visit order.  Returns False where that form does not apply."""
+        v1 = visits.n if v1 is None else v1
+        rc = self.lib.orc_redistribute_threads(C.byref(self.params), lens, bokeh, self.h, C.byref(visits), v0, v1, int(n_threads), int(row_visits))
+        if rc == _abi.ERR_UNSUPPORTED:
+            return False
+        if rc:
+            raise RuntimeError("oracle redistribute (threads) rc=%d" % rc)
+        return True
 
     def buffer(self, aov=0):
         return np.ctypeslib.as_array(self.lib.orc_frame_buffer(self.h, aov), (self.np, 4)).copy()

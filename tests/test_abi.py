@@ -41,9 +41,9 @@ def test_struct_layouts_match_the_header():
 #include <stdio.h>
 #include "lentil_hip.h"
 int main(void) {
-  printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(lentil_params), sizeof(lentil_term), sizeof(lentil_poly),
+  printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(lentil_params), sizeof(lentil_term), sizeof(lentil_poly),
          sizeof(lentil_lens_table), sizeof(lentil_bokeh_table), sizeof(lentil_visits), sizeof(lentil_counters),
-         sizeof(lentil_draw_record), sizeof(lentil_crypto_visits));
+         sizeof(lentil_draw_record), sizeof(lentil_crypto_visits), sizeof(lentil_pass_totals));
   return 0;
 }'''
     with tempfile.TemporaryDirectory() as d:
@@ -53,7 +53,7 @@ int main(void) {
         subprocess.check_call(["gcc", "-std=c99", "-I", os.path.join(common.ROOT, "include"), c, "-o", exe])
         sizes = [int(v) for v in subprocess.check_output([exe]).split()]
     mine = [C.sizeof(t) for t in (_abi.Params, _abi.Term, _abi.Poly, _abi.LensTable, _abi.BokehTable, _abi.Visits,
-                                  _abi.Counters, _abi.DrawRecord, _abi.CryptoVisits)]
+                                  _abi.Counters, _abi.DrawRecord, _abi.CryptoVisits, _abi.PassTotals)]
     assert sizes == mine
 
 

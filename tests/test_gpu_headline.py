@@ -31,8 +31,10 @@ def _device_stream(torch, p, W, H, M, seed, f_hi, v_begin, v_end, y0=0, n_extra=
 
 
 def _oracle_threads(p, per_frame_gb):
+    """(common.ThreadedOracle keeps ONE frame whatever the thread count -- orc_redistribute_threads; per_frame_gb only bounds
+    the fallback with a private frame per thread, which none of this file's streams takes)"""
     import os
-    return int(max(2, min(32, os.cpu_count() or 2, (common.host_memory_gb() * 0.5) // per_frame_gb)))
+    return int(max(2, min(64, os.cpu_count() or 2)))
 
 
 def _compare(ctx, ref, c, samples, n_visits, p, n_aovs=1, kinds=None):
@@ -45,7 +47,8 @@ def _compare(ctx, ref, c, samples, n_visits, p, n_aovs=1, kinds=None):
     # pixels no draw lands on only hold their own visits, added in iterator order: bit-exact
     touched = np.zeros(p.xres * p.yres, bool)
     touched[ref.log()[:, 2]] = True
-    buf, w = ctx.download_accum(0)
+    rec = ctx.download_records()              # every AOV's accumulators and the weight, one copy
+    buf, w = rec[:, 0:4], rec[:, 4 * n_aovs]
     assert np.array_equal(buf[~touched], ref.buffer(0)[~touched])
     assert np.array_equal(w[~touched], ref.weight()[~touched])
     assert np.array_equal(ctx.download_aov(0)[~touched], ref.resolve(0)[~touched])
@@ -54,7 +57,7 @@ def _compare(ctx, ref, c, samples, n_visits, p, n_aovs=1, kinds=None):
             # a closest-filtered AOV is a copy of one candidate's value (src/lentil.h:832-837): the whole frame bit for bit
             assert np.array_equal(ctx.download_aov(a), ref.resolve(a)), a
         else:
-            assert np.array_equal(ctx.download_accum(a)[0][~touched], ref.buffer(a)[~touched]), a
+            assert np.array_equal(rec[:, 4 * a:4 * a + 4][~touched], ref.buffer(a)[~touched]), a
     return worst, int(touched.sum())
 
 

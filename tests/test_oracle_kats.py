@@ -414,8 +414,8 @@ def test_threaded_oracle_equals_the_single_thread_one(orc):
     assert touched.any() and not touched.all()
     assert np.array_equal(one.buffer(0)[~touched], thr.buffer(0)[~touched])
     assert np.array_equal(one.weight()[~touched], thr.weight()[~touched])
-    assert np.allclose(one.buffer(0), thr.buffer(0), rtol=2e-6, atol=0)
-    assert np.allclose(one.buffer64(0), thr.buffer64(0), rtol=1e-13, atol=0)
+    assert np.allclose(one.buffer(0), thr.buffer(0), rtol=8e-6, atol=0)       # (fp32 sums of the same terms in another order)
+    assert np.allclose(one.buffer64(0), thr.buffer64(0), rtol=1e-12, atol=0)
     assert np.allclose(one.weight64(), thr.weight64(), rtol=1e-13, atol=0)
     thr.close()
 
@@ -440,7 +440,12 @@ def test_threaded_oracle_merges_closest_aovs_in_stream_order(orc):
         assert np.array_equal(one.zbuffer(), thr.zbuffer())
         assert np.array_equal(one.zvisit(), thr.zvisit())
         for a in (0, 2):
-            assert np.allclose(one.buffer(a), thr.buffer(a), rtol=2e-6, atol=0)
+            # (another summation order -- a pixel's own visits first, then the draws in visit order: both sides are fp32 sums of
+            # the same terms, each within a few 1e-6 of the exact one the shadows hold)
+            assert np.allclose(one.buffer(a), thr.buffer(a), rtol=8e-6, atol=0)
+            ex = one.buffer64(a)
+            m = ex != 0
+            assert float(np.max(np.abs(thr.buffer(a)[m] - ex[m]) / np.abs(ex[m]))) < 1e-5
         # (draws carry candidates across thread boundaries: some pixel's survivor comes from another thread's range)
         thr.close()
     assert (one.zvisit() != 0xFFFFFFFF).sum() >= W * H
