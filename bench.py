@@ -968,6 +968,16 @@ def main():
     if used_rccl:
         dist.destroy_process_group()
     if rank == 0:
+        # What explains the number rides INSIDE `roofline` (a reader that keeps that object whole and only the names of the other
+        # keys still has it): the box probe -- fp64 chain rate, clock, copy / read bandwidth, queues -- and the pass's kernel times;
+        # and `roofline` / `cpu_baseline` are the LAST keys of the line, so that a tail of the output holds them.
+        out["roofline"]["box"] = out.get("box")
+        out["roofline"]["kernels_ms"] = out.get("kernels_ms")
+        out["roofline"]["ms_per_step"] = out.get("ms_per_step")
+        out["roofline"]["timed_loop"] = (out.get("passes") or {}).get("timed_loop")
+        for key in ("parity_checked", "roofline", "cpu_baseline"):
+            if key in out:
+                out[key] = out.pop(key)
         # the single JSON line is the last thing on stdout (RCCL prints a banner of its own)
         sys.stdout.flush()
         print(json.dumps(out), flush=True)

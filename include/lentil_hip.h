@@ -568,6 +568,9 @@ int lentil_hip_batch_model_stats(lentil_hip_ctx *ctx, uint64_t stats[4]);
  * had been accepted by then.  A stall costs time, never results -- so nothing else would ever show one: the GPU test
  * session asserts stats[1] == stats[2] when it ends (tests/conftest.py). */
 int lentil_hip_process_stats(uint64_t stats[4]);
+/* ... and what the waves that gave up saw (lentil_hip_last_redo_note's text, one line per pass, the first eight that were not
+ * asked for), NUL-terminated, truncated to capacity. */
+int lentil_hip_process_stall_notes(char *buf, uint64_t capacity);
 /* The asynchronous end of a pass (round 6).  lentil_hip_redistribute no longer ends with the host waiting for the device: a
  * streamed pass returns once its kernels are enqueued, and whether it needs more work (buffers that were too small, a draw
  * batch that fell short, a wave that gave up waiting) is found out by the next call that OBSERVES the context -- every entry

@@ -23,7 +23,7 @@ EXPORTS = [
     "lentil_hip_touched_rows", "lentil_hip_merge_rows", "lentil_hip_resolve_rows",
     "lentil_hip_pack_rows", "lentil_hip_merge_packed_rows", "lentil_hip_compact_rows", "lentil_hip_merge_sparse",
     "lentil_hip_get_counters", "lentil_hip_last_timing", "lentil_hip_last_launches", "lentil_hip_set_draw_log",
-    "lentil_hip_batch_model_stats", "lentil_hip_process_stats", "lentil_hip_set_async", "lentil_hip_pass_totals", "lentil_hip_debug_batch_estimate", "lentil_hip_box_probe",
+    "lentil_hip_batch_model_stats", "lentil_hip_process_stats", "lentil_hip_process_stall_notes", "lentil_hip_set_async", "lentil_hip_pass_totals", "lentil_hip_debug_batch_estimate", "lentil_hip_box_probe",
     "lentil_hip_lens_jit_status", "lentil_hip_lens_jit_wait", "lentil_hip_debug_lens_jit_source", "lentil_hip_debug_lens_jit_compile",
     "lentil_hip_download_draw_log", "lentil_hip_test_lt_sample_aperture",
     "lentil_hip_test_trace_bw_po", "lentil_hip_test_aperture_sample", "lentil_hip_debug_scan_bands",
@@ -49,6 +49,14 @@ def process_stats():
     if rc:
         raise RuntimeError("lentil_hip_process_stats: %d" % rc)
     return tuple(int(x) for x in n)
+
+
+def process_stall_notes():
+    """the redo notes of this process's passes that hit the stuck time-out unasked (lentil_hip_process_stall_notes)"""
+    lib = load_library()
+    buf = C.create_string_buffer(1 << 14)
+    lib.lentil_hip_process_stall_notes(buf, 1 << 14)
+    return buf.value.decode(errors="replace")
 
 
 class LentilError(RuntimeError):
@@ -114,6 +122,7 @@ def load_library():
         "lentil_hip_last_launches": (i, [vp, C.POINTER(C.c_uint32)]),
         "lentil_hip_batch_model_stats": (i, [vp, C.POINTER(C.c_uint64)]),
         "lentil_hip_process_stats": (i, [C.POINTER(C.c_uint64)]),
+        "lentil_hip_process_stall_notes": (i, [C.c_char_p, C.c_uint64]),
         "lentil_hip_set_async": (i, [vp, i]),
         "lentil_hip_pass_totals": (i, [vp, C.POINTER(_abi.PassTotals), i]),
         "lentil_hip_box_probe": (i, [vp, C.POINTER(C.c_double)]),

@@ -290,6 +290,11 @@ struct lentil_hip_ctx {
   // counters are still read (estimates for the next pass, lentil_hip_pass_totals), but work it still needed is not done -- nobody can
   // see that frame any more; pass_totals.abandoned_incomplete counts such passes.  At most two passes are in flight unobserved.
   bool async_end = true;
+  // accept_kernel<3> (lentil_kernels.h) as the lean tail's first accept: LENTIL_READY_ACCEPT=0 restores round 5's pair, LENTIL_READY_ACCEPT_BLOCKS
+  // its blocks per CU; LENTIL_RESOLVE_AFTER_SCAN=0 / 1 decides where the whole-frame resolve runs whatever the accept (-1: with accept_kernel<3>)
+  bool ready_accept = true;
+  int ready_blocks = 4;
+  int resolve_after_scan = -1;
   struct Slot {                       // what a pass needs of its own while another pass is being enqueued: events, the counters' landing block
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev_scan_k[2] = {nullptr, nullptr};
@@ -362,6 +367,10 @@ static void apply_camera_motion(lentil_hip_ctx *ctx);
 // stalled pass is redone and its result is correct -- which is exactly why it needs a number somebody can assert on: the
 // GPU suite's session ends with "no stall that was not injected" (tests/conftest.py).
 static std::atomic<uint64_t> g_stat_streamed{0}, g_stat_stuck{0}, g_stat_stuck_injected{0}, g_stat_redone{0};
+// ... and what the waves that gave up left behind (lentil_hip_process_stall_notes): the redo notes of the passes counted in
+// g_stat_stuck that nobody asked for, the first eight of them
+static std::mutex g_stall_notes_mutex;
+static std::vector<std::string> g_stall_notes;
 
 static int fail(lentil_hip_ctx *ctx, int code, const std::string &msg) {
   if (ctx) ctx->err = msg; else g_err = msg;
@@ -526,6 +535,9 @@ LENTIL_API int lentil_hip_create(int device, lentil_hip_ctx **out_ctx) {
   if (hipHostGetDevicePointer((void **)&ctx->d_ctr_host, ctx->h_ctr_pinned, 0) != hipSuccess) { ctx->d_ctr_host = nullptr; (void)hipGetLastError(); }
   if (const char *e = getenv("LENTIL_SPIN_READBACK")) ctx->spin_readback = atoi(e) != 0;
   if (const char *e = getenv("LENTIL_ASYNC_END")) ctx->async_end = e[0] != '0';
+  if (const char *e = getenv("LENTIL_READY_ACCEPT")) ctx->ready_accept = e[0] != '0';
+  if (const char *e = getenv("LENTIL_READY_ACCEPT_BLOCKS")) { ctx->ready_blocks = atoi(e); if (ctx->ready_blocks < 1) ctx->ready_blocks = 1; if (ctx->ready_blocks > 6) ctx->ready_blocks = 6; }
+  if (const char *e = getenv("LENTIL_RESOLVE_AFTER_SCAN")) ctx->resolve_after_scan = e[0] == '1' ? 1 : 0;
   HIP_TRY(ctx, hipEventCreate(&ctx->ev_scan_k[0]));
   HIP_TRY(ctx, hipEventCreate(&ctx->ev_scan_k[1]));
   // the slots of the asynchronous end (lentil_hip_ctx::Slot): slot 0 holds what has just been created, 1 and 2 their own
@@ -642,6 +654,7 @@ LENTIL_API int lentil_hip_create(int device, lentil_hip_ctx **out_ctx) {
       hipLaunchKernelGGL(accept_kernel<0>, dim3(wg), dim3(256), 0, st, w);
       hipLaunchKernelGGL(accept_kernel<1>, dim3(wg), dim3(256), 0, st, w);
       hipLaunchKernelGGL(accept_kernel<2>, dim3(wg), dim3(256), 0, st, w);
+      hipLaunchKernelGGL(accept_kernel<3>, dim3(wg), dim3(256), 0, st, w);
       HIP_TRY(ctx, hipGetLastError());
       HIP_TRY(ctx, hipStreamSynchronize(st));
     }
@@ -2219,6 +2232,11 @@ static int streamed_finish(lentil_hip_ctx *ctx, StreamTail &t, const DevCounters
     if (c.stuck) {
       g_stat_stuck.fetch_add(1, std::memory_order_relaxed);
       if (t.inject) g_stat_stuck_injected.fetch_add(1, std::memory_order_relaxed);
+      else {
+        std::lock_guard<std::mutex> lock(g_stall_notes_mutex);
+        if (g_stall_notes.size() < 8) g_stall_notes.push_back(ctx->redo_note + (t.deferred ? " | end deferred" : " | end awaited") + (can_fix ? "" : ", abandoned") +
+                                                              " | frame " + std::to_string(ctx->P.xres) + "x" + std::to_string(ctx->P.yres) + ", " + std::to_string(ctx->V.n) + " visits");
+      }
     }
     if (ctx->notes.size() < 8) ctx->notes.push_back(ctx->redo_note);
     if (!can_fix) {
@@ -2618,6 +2636,22 @@ static int redistribute_streamed(lentil_hip_ctx *ctx, bool *streamed, bool *defe
     da.ext_end_tasks = keepers * 4u;
     da.ext_slack = 4u;
   }
+  // The lean tail (below): known before anything is launched -- the solve and straggler kernels count parked solves per item for
+  // accept_kernel<3> (DrawArgs::item_ready) in such a pass.
+  // (LENTIL_INJECT_STALL stalls the second round's resident solve waves: that pass keeps its second round in flight)
+  const bool lean_pass = decoupled && ctx->chain_streams && (extend || predicted) && ctx->lean_tail && ctx->lean_ok && blind_rounds <= 2 &&
+                         !da.inject_stall;
+  // Round 6: the first accept takes the items whose parked solves are through, whole, and leaves the others to the accept behind
+  // the stragglers (accept_kernel<3>; LENTIL_READY_ACCEPT=0: round 5's pair of accepts, the first splatting what is certain of
+  // every item, the second replaying nearly every item).  For frames the wide walk serves: <= 64 retries, records of <= 64 floats.
+  bool ready_accept = false;
+  {
+    const bool off = !ctx->ready_accept;
+    uint32_t add_floats = 1;
+    for (uint32_t k = 0; k < ctx->F.n_aovs; ++k) if (!(ctx->F.closest_mask & (1u << k))) add_floats += 4;
+    ready_accept = lean_pass && !off && live && retries <= kAcceptWinRetries && !da.accept_narrow && add_floats <= 64u && nch == 1;
+  }
+  da.item_ready = ready_accept ? 1 : 0;
   HIP_TRY(ctx, hipStreamWaitEvent(ctx->pub_stream, ctx->ev[0], 0));
   hipLaunchKernelGGL(publish_kernel, dim3((unsigned)ctx->publish_waves), dim3(64), 0, ctx->pub_stream, pa);
   HIP_TRY(ctx, hipGetLastError());
@@ -2666,11 +2700,14 @@ static int redistribute_streamed(lentil_hip_ctx *ctx, bool *streamed, bool *defe
     HIP_TRY(ctx, hipStreamWaitEvent(ch.stream, ctx->pub_done, 0));       // (both long past when A ends)
     HIP_TRY(ctx, hipStreamWaitEvent(ch.stream, ctx->scans_done, 0));
     HIP_TRY(ctx, hipEventRecord(ctx->ev_round, ch.stream));
-    // (LENTIL_INJECT_STALL stalls the second round's resident solve waves: that pass keeps its second round in flight)
-    const bool lean_pass = (extend || predicted) && ctx->lean_tail && ctx->lean_ok && blind_rounds <= 2 && !da.inject_stall;
     // (lean tail: no next round's solve waves share the CUs with the first accept -- a block per item, as many as fit)
     unsigned accept1_blocks = accept_blocks;
-    if (lean_pass) {
+    if (ready_accept) {
+      // accept_kernel<3> waits for nothing and is what stands between the solve kernel's end and the touched groups' resolve:
+      // a block per item where that many fit (4 per CU: 4 x 20.7 KB of LDS beside a straggler wave's 10, 16 waves of <= 96 registers)
+      const uint64_t m = (uint64_t)ctx->num_cu * (uint64_t)ctx->ready_blocks;
+      accept1_blocks = (unsigned)(acc_want > m ? m : acc_want);
+    } else if (lean_pass) {
       // (measured, same box, headline: 2 / 4 / 5 blocks per CU -> 2.00 / 2.00-2.24 / 2.08-2.30 ms: with more blocks than the
       // stragglers' LDS leaves room for, every third run sits in a mode 0.25 ms slower.  The knob stays; the default is round 4's.)
       static const int lean_blocks = getenv("LENTIL_ACCEPT_LEAN_BLOCKS") ? atoi(getenv("LENTIL_ACCEPT_LEAN_BLOCKS")) : 0;
@@ -2687,8 +2724,10 @@ static int redistribute_streamed(lentil_hip_ctx *ctx, bool *streamed, bool *defe
     // the whole frame takes 130), the few groups of the last accept once more at the end.
     // (LENTIL_RESOLVE_AFTER_SCAN=1; off by default: measured on the headline, same box, 2.00-2.01 ms with it and 1.98-2.00
     // without -- the resolve is not what the pass ends on, the stragglers and the accept behind them are)
-    static const bool after_scan_env = getenv("LENTIL_RESOLVE_AFTER_SCAN") && getenv("LENTIL_RESOLVE_AFTER_SCAN")[0] == '1';
-    const bool resolve_after_scan = lean_pass && resolves_early && after_scan_env;
+    // (Round 6, with accept_kernel<3>: on -- the accept behind the stragglers now has a few items where it had nearly all of them,
+    // so the whole-frame resolve would be what the pass ends on; behind the scan it is under the solves, and behind the first
+    // accept only the groups its draws reached are left.  LENTIL_RESOLVE_AFTER_SCAN=0 / 1 decides whatever the accept.)
+    const bool resolve_after_scan = lean_pass && resolves_early && (ctx->resolve_after_scan >= 0 ? ctx->resolve_after_scan == 1 : ready_accept);
     if (resolve_after_scan) {
       hipStream_t rs = ctx->chunks[1].stream;
       HIP_TRY(ctx, hipStreamWaitEvent(rs, ctx->scans_done, 0));
@@ -2699,7 +2738,8 @@ static int redistribute_streamed(lentil_hip_ctx *ctx, bool *streamed, bool *defe
       d0.emit_live = lean_pass ? 0 : 1;       // (lean tail: nobody is waiting for tasks)
       d0.lean_defer = lean_pass ? 1 : 0;
       d0.end_tasks = (uint32_t)ctx->num_cu * 4u;
-      hipLaunchKernelGGL(accept_kernel<1>, dim3(accept1_blocks), dim3(256), 0, ch.stream, d0);
+      if (ready_accept) hipLaunchKernelGGL(accept_kernel<3>, dim3(accept1_blocks), dim3(256), 0, ch.stream, d0);
+      else hipLaunchKernelGGL(accept_kernel<1>, dim3(accept1_blocks), dim3(256), 0, ch.stream, d0);
       HIP_TRY(ctx, hipGetLastError());
     }
     HIP_TRY(ctx, hipEventRecord(ctx->ev_acc1, ch.stream));
@@ -4201,6 +4241,17 @@ LENTIL_API int lentil_hip_box_probe(lentil_hip_ctx *ctx, double probe[6]) {
 LENTIL_API int lentil_hip_process_stats(uint64_t stats[4]) {
   if (!stats) return LENTIL_ERR_INVALID;
   stats[0] = g_stat_streamed.load(); stats[1] = g_stat_stuck.load(); stats[2] = g_stat_stuck_injected.load(); stats[3] = g_stat_redone.load();
+  return LENTIL_OK;
+}
+
+LENTIL_API int lentil_hip_process_stall_notes(char *buf, uint64_t capacity) {
+  if (!buf || !capacity) return LENTIL_ERR_INVALID;
+  std::lock_guard<std::mutex> lock(g_stall_notes_mutex);
+  std::string all;
+  for (const std::string &n : g_stall_notes) all += n + "\n";
+  const size_t k = all.size() < capacity - 1 ? all.size() : (size_t)capacity - 1;
+  memcpy(buf, all.data(), k);
+  buf[k] = 0;
   return LENTIL_OK;
 }
 

@@ -169,8 +169,14 @@ struct ItemHdr {          // written by prep_items_kernel / publish_item; a 128-
   double tx, ty, tz;      // PO: -P_cs * 10 (src/lentil_filter.cpp:271); thin lens: P_cs (floats, exactly)
   uint32_t seed_a;        // (unsigned)(px*py+px)
   int32_t px_py;          // px | py << 16
-  uint32_t pad[24];
+  // DrawArgs::item_ready (streamed pass, lean tail): solves of this item parked for solve_slow_kernel so far / finished by it.
+  // Zeroed by publish_item with the header; the solve kernel counts a solve when it parks it, the straggler wave when its result is
+  // in the record; accept_kernel<3> -- behind the solve kernel, beside the stragglers -- takes an item whose two counts agree and
+  // leaves the others to the accept behind the stragglers.
+  uint32_t parked, parked_done;
+  uint32_t pad[22];
 };
+static_assert(sizeof(ItemHdr) == 128, "ItemHdr is a 128-byte line");
 
 struct ItemProg {         // 48 B, progress of an item across rounds
   uint32_t n_done;        // attempts resolved so far (all earlier attempts are final)
@@ -484,6 +490,7 @@ LD_DEV void publish_item(const lentil_params &P, const VisitsDev &V, const Strea
     st_agent64(d + 1, (uint64_t)__double_as_longlong(hd.ty));
     st_agent64(d + 2, (uint64_t)__double_as_longlong(hd.tz));
     st_agent64(d + 3, (uint64_t)hd.seed_a | ((uint64_t)(uint32_t)hd.px_py << 32));
+    st_agent64(d + 4, 0ull);          // ItemHdr::parked / parked_done
     ItemProg pg{};
     pg.m_lo = 0;
     pg.m_hi = ok ? count : 0u;
@@ -2173,6 +2180,7 @@ struct DrawArgs {
   // runs that round the ordinary way and this accept after it.
   uint64_t stuck_ticks;       // how long a resident wave waits for a queue slot before it declares the pass stuck (0: kStuckTicks)
   int32_t lean_gate;
+  int32_t item_ready;         // streamed pass, lean tail: parked solves are counted per item (ItemHdr::parked / parked_done) for accept_kernel<3>
   int32_t lean_defer;         // ... and the first accept leaves an item that met parked solves to that accept whole: what it still
                               // needs is decided there, from the stragglers' results
 };
@@ -2746,6 +2754,11 @@ __global__ __launch_bounds__(256) LENTIL_SOLVE_ATTR void solve_po_kernel(DrawArg
             for (int i = 0; i < 11; ++i) st_agent64(d + i, (uint64_t)__double_as_longlong(pay[i]));
             st_agent64(d + 11, (uint64_t)(uint32_t)s.k | ((uint64_t)(uint32_t)s.error << 32));
             st_agent64(d + 12, (uint64_t)res_idx | ((uint64_t)chan_word << 32));
+            if (a.item_ready && a.slow_indirect) {
+              // whose solve it is, for the straggler wave that finishes it; counted with the item before the record is published
+              st_agent64(d + 13, (uint64_t)my_item << 32);
+              atomicAdd(&a.hdr[my_item].parked, 1u);
+            }
             // the first accept may look at this result before the straggler is through: it finds the mark (and, behind
             // it, where the result will be); the straggler's result never overwrites it
             if (a.slow_indirect) st_agent32(res + res_idx, kCodePendingBase | slot);
@@ -3004,7 +3017,7 @@ __global__ __launch_bounds__(64) LENTIL_SLOW_ATTR void solve_slow_kernel(DrawArg
       }
       if (over || (uint32_t)tag == (uint32_t)kSlowEnd) break;
       uint64_t wv = 0;
-      if (lane < 13u) wv = ld_coherent64(src + lane);
+      if (lane < 14u) wv = ld_coherent64(src + lane);
       auto word = [&](int i) { return ((uint64_t)(uint32_t)__shfl((int)(wv >> 32), i) << 32) | (uint64_t)(uint32_t)__shfl((int)(uint32_t)wv, i); };
       r.tx = __longlong_as_double((long long)word(0)); r.ty = __longlong_as_double((long long)word(1)); r.tz = __longlong_as_double((long long)word(2));
       r.ap_x = __longlong_as_double((long long)word(3)); r.ap_y = __longlong_as_double((long long)word(4));
@@ -3014,6 +3027,7 @@ __global__ __launch_bounds__(64) LENTIL_SLOW_ATTR void solve_slow_kernel(DrawArg
       const uint64_t w11 = word(11), w12 = word(12);
       r.k = (int32_t)(uint32_t)w11; r.error = (int32_t)(uint32_t)(w11 >> 32);
       r.res_idx = (uint32_t)w12; r.chan = (uint32_t)(w12 >> 32);
+      r.pad[0] = (uint32_t)(word(13) >> 32);        // the item (DrawArgs::item_ready)
     } else {
       r = a.slow[q];
     }
@@ -3035,8 +3049,14 @@ __global__ __launch_bounds__(64) LENTIL_SLOW_ATTR void solve_slow_kernel(DrawArg
     if (lane == 0) dbg_add(3 + (s.k >= 100 ? 1 : 0), 1);                                          // ... ended before / at 100 iterations
     if (lane == 0) {
       // (the record says which pool: one queue may serve two rounds, DrawArgs::slow_q)
-      if (r.chan & kSlowIndirectBit) st_agent32(&a.slow[q].result, code);
-      else a.pool[a.slow_live ? ((r.chan & kSlowParBit) ? 1u : 0u) : par][r.res_idx] = code;
+      if (r.chan & kSlowIndirectBit) {
+        st_agent32(&a.slow[q].result, code);
+        if (a.item_ready && a.slow_live) {
+          // the result first, then the count that tells accept_kernel<3> that the item's parked solves are all through
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          atomicAdd(&a.hdr[r.pad[0]].parked_done, 1u);
+        }
+      } else a.pool[a.slow_live ? ((r.chan & kSlowParBit) ? 1u : 0u) : par][r.res_idx] = code;
     }
     ++solves;
   }
@@ -3304,7 +3324,7 @@ LD_DEV AcceptResult accept_item(const DrawArgs &a, AcceptShared &sh, uint32_t it
             if (kMode == 1) { unk = true; break; }
             if (kMode == 2) {
               if (!seen1) { unk = true; seen1 = true; }
-              c = a.slow[c & 0x00FFFFFFu].result;            // the straggler is through
+              c = ld_coherent32(&a.slow[c & 0x00FFFFFFu].result);      // the straggler is through (its kernel may still run: accept_kernel<3>)
             } else {
               atomicAdd(&a.ctr->overflow, 1ull);               // a mark nobody is going to resolve: the pass is void
               c = kCodeFail;
@@ -3464,7 +3484,7 @@ LD_DEV WideAttempt<kMode> wide_resolve(const DrawArgs &a, const AcceptWideShared
       if (kMode == 1) { r.unk = true; break; }
       if (kMode == 2) {
         if (!r.seen1) { r.unk = true; r.seen1 = true; }
-        c = a.slow[c & 0x00FFFFFFu].result;            // the straggler is through
+        c = ld_coherent32(&a.slow[c & 0x00FFFFFFu].result);      // the straggler is through (its kernel may still run: accept_kernel<3>)
       } else {
         atomicAdd(&a.ctr->overflow, 1ull);               // a mark nobody is going to resolve: the pass is void
         c = kCodeFail;
@@ -3926,8 +3946,16 @@ LD_DEV AcceptResult accept_item_chroma(const DrawArgs &a, AcceptShared &sh, uint
 #endif
 template <int kMode>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LENTIL_ACCEPT_EU, LENTIL_ACCEPT_EU))) void accept_kernel(DrawArgs a) {
-  LENTIL_TL_SPAN(kMode == 0 ? SPAN_ACCEPT0 : (kMode == 1 ? SPAN_ACCEPT1 : SPAN_ACCEPT2));
-  __shared__ uint32_t s_item;
+  LENTIL_TL_SPAN(kMode == 0 ? SPAN_ACCEPT0 : (kMode == 2 ? SPAN_ACCEPT2 : SPAN_ACCEPT1));
+  // kMode 3 (round 6): the first accept of a lean streamed pass that neither waits for the round's parked solves nor splats
+  // around them.  It runs behind the solve kernel and BESIDE the straggler kernel, takes every item whose parked solves are all
+  // through (ItemHdr::parked == parked_done) and walks it once, with final results -- mode 2's walk for an item that carries
+  // nothing over -- and leaves the others untouched on the next accept's list (mode 2, behind the stragglers).  Nothing is
+  // walked twice (mode 1 splatted what was certain of nearly every item and mode 2 then replayed nearly every item: 134 us
+  // behind the stragglers for a headline frame); what is left for the accept behind the stragglers is the items whose
+  // stragglers were still at work when this kernel came to them.  It never waits for anything.
+  constexpr int kWalk = kMode == 3 ? 2 : kMode;
+  __shared__ uint32_t s_item, s_ready;
   __shared__ AcceptShared sh;
   __shared__ AcceptWideShared ws;
   static_assert(sizeof(ws.win) >= 3 * (256 + 64) * sizeof(uint32_t), "AcceptShared::rwin lies in AcceptWideShared::win");
@@ -4066,17 +4094,35 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LENTIL_ACCE
 #ifdef LENTIL_TIMELINE
         if (threadIdx.x == 0 && h.samples) { dbg_add(26, __builtin_amdgcn_s_memrealtime() - tm0_); dbg_add(27, 1); }
 #endif
-        (void)accept_item_wide<kMode>(a, sh, ws, item, pg, h, res, res_prev, rmin, rmax_p1,
+        if constexpr (kMode == 3) {
+          if (threadIdx.x == 0) {
+            const uint64_t w = ld_coherent64(reinterpret_cast<const uint64_t *>(a.hdr + item) + 4);
+            const bool ready = (uint32_t)w == (uint32_t)(w >> 32);
+            s_ready = ready ? 1u : 0u;
+            if (!ready) { const uint32_t slot = atomicAdd(&a.ctr->n_active[nxt], 1u); a.active[nxt][slot] = item; }      // (its progress record stays as published)
+          }
+          __syncthreads();
+          const bool ready = s_ready != 0u;
+          __syncthreads();
+          if (!ready) continue;
+        }
+        (void)accept_item_wide<kWalk>(a, sh, ws, item, pg, h, res, res_prev, rmin, rmax_p1,
                                       [&](const AcceptResult &r) { if (threadIdx.x == 0) finish_item(item, pg, r, false, 0u, 0u); });
       }
       ticket_done(cnt);
+      continue;
+    }
+    if constexpr (kMode == 3) {
+      // (the host launches this mode for frames the wide walk serves; anything else goes to the accept behind the stragglers whole)
+      if (threadIdx.x == 0)
+        for (uint32_t j = 0; j < cnt; ++j) { const uint32_t slot = atomicAdd(&a.ctr->n_active[nxt], 1u); a.active[nxt][slot] = a.active[par][ai0 + j]; }
       continue;
     }
     if (dry_first) {
       for (uint32_t j = 0; j < cnt; ++j) {
         const uint32_t item = a.active[par][ai0 + j];
         const ItemProg pg = load_prog(a, item);
-        const AcceptResult rd = accept_item<kMode>(a, sh, item, pg, res, res_prev, rmin, rmax_p1, true);
+        const AcceptResult rd = accept_item<kWalk>(a, sh, item, pg, res, res_prev, rmin, rmax_p1, true);
         if (threadIdx.x == 0) {
           uint32_t off = 0;
           s_emitted[j] = (rd.more && emit_tasks(a, nxt, item, rd.new_lo, rd.new_hi, off)) ? 1u : 0u;
@@ -4089,7 +4135,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LENTIL_ACCE
       const uint32_t item = a.active[par][ai0 + j];
       const ItemProg pg = load_prog(a, item);
       const AcceptResult r = chroma ? accept_item_chroma(a, sh, item, pg, res, rmin, rmax_p1)
-                                    : accept_item<kMode>(a, sh, item, pg, res, res_prev, rmin, rmax_p1);
+                                    : accept_item<kWalk>(a, sh, item, pg, res, res_prev, rmin, rmax_p1);
       if (threadIdx.x == 0)
         finish_item(item, pg, r, dry_first && s_emitted[j] != 0u, dry_first ? s_emit_off[j] : 0u, dry_first ? s_emit_hi[j] : 0u);
       __syncthreads();       // (s_emit_*[j] and the add table in `sh` are the block's)
@@ -4607,11 +4653,49 @@ __global__ __launch_bounds__(256) void resolve_kernel(FrameDev F, float *resolve
 // the headline frame's first round touches about half of the groups, its second a few hundred).  A wave looks at 64 groups'
 // flags with one load and walks the set bits.  (min_flag 1: every group that received a draw -- the pass whose whole-frame
 // resolve ran behind the scan, before any accept, see redistribute_streamed.)
+// (Round 6: within a flagged group only the pixels a draw reached are written again -- resolve_touched_group.)
+// One flagged 64-pixel group of a frame whose untouched state is resolved already (the whole-frame resolve ran earlier in the
+// pass, from the pixels' own sums alone or with an earlier round's draws): the group's splat records are read (coalesced), and
+// only the pixels that hold a draw -- a record whose weight is not zero: every draw adds its weight -- fetch their own sums,
+// normalise and store.  A 4K headline frame's draws reach about half of the groups and an eighth of the pixels.
+LD_DEV void resolve_touched_group(const FrameDev &F, float *resolved, float4 *tile, uint64_t p0, uint32_t n_pix, uint32_t lane) {
+  const uint32_t q = F.stride >> 2;
+  const float4 *acc4 = reinterpret_cast<const float4 *>(F.acc);
+  const float4 *dir4 = reinterpret_cast<const float4 *>(F.dir);
+  const uint32_t n4 = n_pix * q;
+  for (uint32_t i = lane; i < n4; i += 64u) tile[i] = acc4[p0 * q + i];
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
+  if (lane < n_pix) {
+    const float *rec = reinterpret_cast<const float *>(tile + (size_t)lane * q);
+    if (rec[4u * F.n_aovs] != 0.0f) {
+      float wt = rec[4u * F.n_aovs];
+      if (dir4) wt += reinterpret_cast<const float *>(dir4 + (p0 + lane) * q)[4u * F.n_aovs];
+      const float inv = wt != 0.0f ? 1.0f / wt : 1.0f;      // AtRGBA /= float multiplies by 1.0f/f
+      for (uint32_t a = 0; a < F.n_aovs; ++a) {
+        float4 c = tile[(size_t)lane * q + a];
+        if (dir4) { const float4 d = dir4[(p0 + lane) * q + a]; c.x += d.x; c.y += d.y; c.z += d.z; c.w += d.w; }
+        if (F.closest_mask & (1u << a)) {
+          c.w = 1.0f;                                      // closest: (r, g, b, 1), src/lentil_imager.cpp:181-186
+        } else if (wt != 0.0f) {
+          c.x *= inv; c.y *= inv; c.z *= inv; c.w *= inv;
+        }
+        reinterpret_cast<float4 *>(resolved)[(uint64_t)a * F.np + p0 + lane] = c;
+      }
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+  __builtin_amdgcn_wave_barrier();
+}
+
 __global__ __launch_bounds__(256) void resolve_touched_kernel(FrameDev F, float *resolved, uint32_t min_flag) {
   LENTIL_TL_SPAN(SPAN_RESOLVE_TOUCHED);
   extern __shared__ float4 s_rec[];
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
   float4 *tile = s_rec + (size_t)wave * 64u * (F.stride >> 2);
+  // (per pixel only where the record's weight tells: gaussian AOVs alone -- a closest-filtered AOV's value is not a sum)
+  const bool per_pixel = F.closest_mask == 0u && F.dir != nullptr;
   const uint64_t n_groups = (F.np + 63ull) / 64ull;
   const uint64_t n_chunks = (n_groups + 63ull) / 64ull;
   const uint64_t wave_global = (uint64_t)blockIdx.x * (blockDim.x >> 6) + wave;
@@ -4623,7 +4707,9 @@ __global__ __launch_bounds__(256) void resolve_touched_kernel(FrameDev F, float 
       const uint32_t b = (uint32_t)__builtin_ctzll(mask);
       mask &= mask - 1ull;
       const uint64_t p0 = (ch * 64ull + b) * 64ull;
-      resolve_group(F, resolved, tile, p0, (uint32_t)((F.np - p0) < 64ull ? (F.np - p0) : 64ull), lane);
+      const uint32_t n_pix = (uint32_t)((F.np - p0) < 64ull ? (F.np - p0) : 64ull);
+      if (per_pixel) resolve_touched_group(F, resolved, tile, p0, n_pix, lane);
+      else resolve_group(F, resolved, tile, p0, n_pix, lane);
     }
   }
 }

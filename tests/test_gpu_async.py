@@ -90,11 +90,12 @@ def test_pipelined_frames_do_all_their_work(orc, asynchronous):
             s[2].close()
 
 
-def test_a_deferred_pass_that_needs_its_draws_redone(orc):
+@pytest.mark.parametrize("observed", [True, False])
+def test_a_deferred_pass_that_needs_its_draws_redone(orc, observed):
     """light, light, then a stream with sixty times the highlights: the pass sized from the light one does not fit and returns
-    before anybody knows.  (a) Observed -- after OTHER visits have been bound, which is what a pipelining caller does first --
-    it is redone with exact sizes on the visits it ran on and gives the oracle's frame.  (b) Cleared away instead, it is counted
-    as abandoned incomplete, and the same heavy stream run behind it -- sized from the abandoned pass's counters -- is whole."""
+    before anybody knows.  Observed -- after OTHER visits have been bound, which is what a pipelining caller does first -- it is
+    redone with exact sizes on the visits it ran on and gives the oracle's frame.  Cleared away instead, it is counted as
+    abandoned incomplete, and the same heavy stream run behind it -- sized from the abandoned pass's counters -- is whole."""
     W, H, M, S = 96, 64, 9, 48
     ctx, p, table, keep, streams = _setup(orc, W, H, M, S, 0.002, 0.12)
     (light, _, ref_l, _, _), (heavy, _, ref_h, _, _) = streams
@@ -103,30 +104,30 @@ def test_a_deferred_pass_that_needs_its_draws_redone(orc):
             _frame(ctx, light)
         ctx.sync()
         ctx.pass_totals(reset=True)
-        # (a)
-        _frame(ctx, heavy)
-        ctx.bind_visits(light)                     # the caller moves on ...
-        c = ctx.counters()                         # ... and only then observes: the heavy pass's end
-        rc = ref_h.counters()
-        assert (c.redistributed_visits, c.attempted_draws, c.accepted_draws) == (rc.redistributed_visits, rc.attempted_draws, rc.accepted_draws)
-        assert c.fallback_chunks >= 1 and c.worklist_overflow == 0
-        check_logs(ctx, ref_h)
-        check_frame(ctx, ref_h)
-        t = ctx.pass_totals(reset=True)
-        assert int(t.passes) == 1 and int(t.deferred) == 1 and int(t.abandoned) == 0 and int(t.fallback_chunks) >= 1
-        # (b) the context is sized for the heavy stream now: light passes shrink the estimate again, then heavy unobserved
-        for _ in range(2):
-            _frame(ctx, light)
-        ctx.sync()
-        ctx.pass_totals(reset=True)
-        _frame(ctx, heavy)                         # does not fit, nobody looks
-        _frame(ctx, heavy)                         # its clear abandons the first; sized from the light passes too: redone when observed
-        _frame(ctx, heavy)                         # sized from the abandoned passes' counters: fits
-        t = ctx.pass_totals(reset=True)
-        assert int(t.passes) == 3 and int(t.abandoned) == 2 and int(t.abandoned_incomplete) >= 1, (
-            int(t.passes), int(t.abandoned), int(t.abandoned_incomplete))
-        check_logs(ctx, ref_h)
-        check_frame(ctx, ref_h)
+        if observed:
+            _frame(ctx, heavy)
+            ctx.bind_visits(light)                     # the caller moves on ...
+            c = ctx.counters()                         # ... and only then observes: the heavy pass's end
+            rc = ref_h.counters()
+            assert (c.redistributed_visits, c.attempted_draws, c.accepted_draws) == (rc.redistributed_visits, rc.attempted_draws, rc.accepted_draws)
+            assert c.fallback_chunks >= 1 and c.worklist_overflow == 0
+            check_logs(ctx, ref_h)
+            check_frame(ctx, ref_h)
+            t = ctx.pass_totals(reset=True)
+            assert int(t.passes) == 1 and int(t.deferred) == 1 and int(t.abandoned) == 0 and int(t.fallback_chunks) >= 1
+        else:
+            _frame(ctx, heavy)                         # does not fit, nobody looks
+            _frame(ctx, heavy)                         # its clear abandons the first; sized from the light passes or from the first one's counters
+            ctx.sync()                                 # (observes the second: whatever it needed is done)
+            _frame(ctx, heavy)                         # sized from what the heavy passes found: fits
+            t = ctx.pass_totals(reset=True)
+            assert int(t.passes) == 3 and int(t.abandoned) == 1 and int(t.abandoned_incomplete) == 1, (
+                int(t.passes), int(t.abandoned), int(t.abandoned_incomplete))
+            assert int(t.worklist_overflow) == 0
+            check_logs(ctx, ref_h)
+            check_frame(ctx, ref_h)
+            c = ctx.counters()
+            assert c.fallback_chunks == 0 and c.streamed == 1
     finally:
         ctx.close()
         ref_l.close()

@@ -120,6 +120,7 @@ def test_streamed_pass_without_a_second_round(orc, monkeypatch, predict):
         predict = "0"
         monkeypatch.setenv("LENTIL_OVERLAP_ACCEPT", "1")
     redone = 0
+    stuck_before = capi.process_stats()[1]
     monkeypatch.setenv("LENTIL_PREDICT", predict)
     p, model, table, keep = common.po_setup(W, H, samples_override=S)
     streams = [common.make_stream(p, W, H, M, f_hi=f_hi, seed=s) for s in (0x5EED, 0xBEEF)]
@@ -154,3 +155,7 @@ def test_streamed_pass_without_a_second_round(orc, monkeypatch, predict):
         ctx.close()
         for r in refs:
             r.close()
+        if overlap:
+            # (a stall under LENTIL_OVERLAP_ACCEPT=1 is this test's to tolerate, not the session's: tests/conftest.py)
+            import stalls
+            stalls.tolerated += capi.process_stats()[1] - stuck_before
