@@ -151,6 +151,7 @@ struct lentil_hip_ctx {
  int slow_from_round = 0;                   // LENTIL_SLOW_FROM_ROUND
   int slow_max_lanes = 4;                    // LENTIL_SLOW_MAX_LANES
   int slow_prio = 0;                         // LENTIL_SLOW_PRIO: instruction priority of the straggler kernel's waves (0-3)
+  int slow_waves_per_cu = 0;                 // LENTIL_SLOW_WAVES_PER_CU: straggler waves per CU of a streamed pass (0: one)
   bool blind = true;                         // LENTIL_BLIND=0: always wait for a chunk's scan before sizing its draw rounds
   uint32_t extra_num = 0, extra_const = 16;  // LENTIL_EXTRA_256THS / LENTIL_EXTRA_CONST: first-batch over-provisioning (16 spare attempts: what a decoupled first accept's guess about its unknown attempts may be off by, accept_item<1>)
   uint64_t extra_below = 8ull << 20;         // LENTIL_EXTRA_BELOW: ... while a chunk's draw sum is below this
@@ -592,6 +593,7 @@ LENTIL_API int lentil_hip_create(int device, lentil_hip_ctx **out_ctx) {
   if (const char *e = getenv("LENTIL_SLOW_FROM_ROUND")) ctx->slow_from_round = atoi(e);
   if (const char *e = getenv("LENTIL_SLOW_MAX_LANES")) ctx->slow_max_lanes = atoi(e);
   if (const char *e = getenv("LENTIL_SLOW_PRIO")) ctx->slow_prio = atoi(e);
+  if (const char *e = getenv("LENTIL_SLOW_WAVES_PER_CU")) ctx->slow_waves_per_cu = atoi(e);
   if (const char *e = getenv("LENTIL_BLIND")) ctx->blind = !(e[0] == '0');
   if (const char *e = getenv("LENTIL_EXTRA_256THS")) ctx->extra_num = (uint32_t)strtoul(e, nullptr, 10);
   if (const char *e = getenv("LENTIL_EXTRA_CONST")) ctx->extra_const = (uint32_t)strtoul(e, nullptr, 10);
@@ -2567,7 +2569,7 @@ static int redistribute_streamed(lentil_hip_ctx *ctx, bool *streamed, bool *defe
   da.unknown_credit = ctx->unknown_credit;
   // (one straggler wave per CU; LENTIL_SLOW_WAVES_PER_CU, up to 4 -- measured on config 4, whose rounds end in hundreds
   // of parked solves at once: 9.15 / 9.18 / 9.35 / 9.46 ms with 1 / 2 / 3 / 4, the waves take from the solve kernel)
-  static const int slow_per_cu = getenv("LENTIL_SLOW_WAVES_PER_CU") ? atoi(getenv("LENTIL_SLOW_WAVES_PER_CU")) : 0;
+  const int slow_per_cu = ctx->slow_waves_per_cu;
   if (ctx->parked_frac > 1.0 / 256.0) ctx->park_dry_seen = true;
   const bool dry_only = ctx->park_dry_only >= 0 ? ctx->park_dry_only != 0 : ctx->park_dry_seen;
   const uint32_t slow_waves_all = (uint32_t)ctx->num_cu * (slow_per_cu >= 1 && slow_per_cu <= 4 ? (uint32_t)slow_per_cu : 1u);

@@ -4099,7 +4099,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LENTIL_ACCE
             const uint64_t w = ld_coherent64(reinterpret_cast<const uint64_t *>(a.hdr + item) + 4);
             const bool ready = (uint32_t)w == (uint32_t)(w >> 32);
             s_ready = ready ? 1u : 0u;
-            if (!ready) { const uint32_t slot = atomicAdd(&a.ctr->n_active[nxt], 1u); a.active[nxt][slot] = item; }      // (its progress record stays as published)
+            if (!ready) {
+              // to the accept behind the stragglers, whole: this round's batch becomes "the batch before" -- that accept runs with the
+              // other parity, its own pool empty for this item (accept_item<1> hands an item over the same way, minus the replay)
+              ItemProg np_ = pg;
+              np_.uacc = 0; np_.n_end1 = 0;
+              np_.p_lo = pg.m_lo; np_.p_hi = pg.m_hi; np_.p_off = pg.res_off;
+              np_.m_lo = np_.m_hi = pg.m_hi; np_.res_off = 0;
+              a.prog[item] = np_;
+              const uint32_t slot = atomicAdd(&a.ctr->n_active[nxt], 1u);
+              a.active[nxt][slot] = item;
+            }
           }
           __syncthreads();
           const bool ready = s_ready != 0u;
@@ -4115,7 +4125,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LENTIL_ACCE
     if constexpr (kMode == 3) {
       // (the host launches this mode for frames the wide walk serves; anything else goes to the accept behind the stragglers whole)
       if (threadIdx.x == 0)
-        for (uint32_t j = 0; j < cnt; ++j) { const uint32_t slot = atomicAdd(&a.ctr->n_active[nxt], 1u); a.active[nxt][slot] = a.active[par][ai0 + j]; }
+        for (uint32_t j = 0; j < cnt; ++j) {
+          const uint32_t item = a.active[par][ai0 + j];
+          const ItemProg pg = load_prog(a, item);
+          ItemProg np_ = pg;
+          np_.uacc = 0; np_.n_end1 = 0;
+          np_.p_lo = pg.m_lo; np_.p_hi = pg.m_hi; np_.p_off = pg.res_off;
+          np_.m_lo = np_.m_hi = pg.m_hi; np_.res_off = 0;
+          a.prog[item] = np_;
+          const uint32_t slot = atomicAdd(&a.ctr->n_active[nxt], 1u);
+          a.active[nxt][slot] = item;
+        }
       continue;
     }
     if (dry_first) {

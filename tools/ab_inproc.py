@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """A/B of environment settings on ONE box in ONE process: the headline frame (or --width/--height/--samples/--lens/--aovs), one
-context per setting (created under that setting's environment -- knobs the library reads in lentil_hip_create or per pass; a knob
-it caches in a function static cannot be varied this way), the two resident visit streams shared, the settings' timed runs
-interleaved rep by rep (boxes drift by a few per cent over a minute; runs a second apart do not).
+context per setting and repetition (created under that setting's environment -- knobs the library reads in lentil_hip_create or per
+pass; a knob it caches in a function static cannot be varied this way -- warmed up, timed, destroyed), the two resident visit
+streams shared, the settings' timed runs interleaved rep by rep (boxes drift by a few per cent over a minute; runs a second
+apart do not).
     python3 tools/ab_inproc.py [--reps 6] [--steps 30] "LENTIL_X=1 LENTIL_Y=0" "LENTIL_X=0" ...      ("" = the defaults)
 Prints every run and, per setting, mean / median / min of ms per step and of the event-timed kernels."""
 import argparse
@@ -47,26 +48,29 @@ def main():
                 else:
                     os.environ[k] = v
 
-    benches = []
-    for text in a.settings:
-        with Env(env_of(text)):
-            b = bench.Bench(torch, None, dev, 0, 1, 0, a.width, a.height, a.height, 9, a.lens, a.samples, a.aovs, a.f_hi, False)
-            if benches:
-                b.streams, b.i_stream = benches[0].streams, 0
-            else:
-                b.generate(a.f_hi)
-            for _ in range(3):                      # the context's first passes size its buffers
-                b.step()
-            b.ctx.sync()
-        benches.append(b)
+    # One context at a time: a context's streams are spread over the runtime's hardware queues as they are created, and the
+    # streams of several live contexts end up sharing queues -- the later contexts' passes then run with less overlap (seen: the
+    # same setting 2.0 ms as the first context of a process and 2.4 ms as its fourth).  So: create, warm up, time, destroy.
+    streams = None
     rows = {t: [] for t in a.settings}
     for rep in range(a.reps):
-        for text, b in zip(a.settings, benches):
+        for text in a.settings:
             with Env(env_of(text)):
+                b = bench.Bench(torch, None, dev, 0, 1, 0, a.width, a.height, a.height, 9, a.lens, a.samples, a.aovs, a.f_hi, False)
+                if streams is None:
+                    b.generate(a.f_hi)
+                    streams = b.streams
+                else:
+                    b.streams, b.i_stream = streams, 0
+                for _ in range(3):                      # the context's first passes size its buffers
+                    b.step()
+                b.ctx.sync()
                 r = b.run(a.steps, a.warmup)
+                b.streams = []
+                b.ctx.close()
             ms = r["dt"] / r["steps"] * 1e3
-            rows[text].append((ms, r["scan"] / r["steps"], r["draw"] / r["steps"], r["resolve"] / r["steps"], r.get("rounds_max"), r.get("redone")))
-            print("rep %d  %-60s %.4f ms   scan %.4f draw %.4f resolve %.4f  rounds %s redone %s" % ((rep, text or "(defaults)") + rows[text][-1]), flush=True)
+            rows[text].append((ms, r["scan"] / r["steps"], r["draw"] / r["steps"], r["resolve"] / r["steps"], r.get("rounds_max"), r.get("redone"), r.get("slow", 0) // r["steps"]))
+            print("rep %d  %-60s %.4f ms   scan %.4f draw %.4f resolve %.4f  rounds %s redone %s parked %s" % ((rep, text or "(defaults)") + rows[text][-1]), flush=True)
     print()
     for text in a.settings:
         ms = [x[0] for x in rows[text]]
@@ -74,10 +78,6 @@ def main():
         print("%-60s ms/step mean %.4f median %.4f min %.4f max %.4f | scan+draw mean %.4f | outside the kernels %.4f"
               % (text or "(defaults)", statistics.mean(ms), statistics.median(ms), min(ms), max(ms), statistics.mean(kern),
                  statistics.mean(ms) - statistics.mean(kern)))
-    for b in benches[1:]:
-        b.streams = []
-    for b in benches:
-        b.close()
 
 
 if __name__ == "__main__":
