@@ -291,6 +291,14 @@ struct lentil_hip_ctx {
   // counters are still read (estimates for the next pass, lentil_hip_pass_totals), but work it still needed is not done -- nobody can
   // see that frame any more; pass_totals.abandoned_incomplete counts such passes.  At most two passes are in flight unobserved.
   bool async_end = true;
+  // clear_frame's wipe of the splatted groups off the main stream (round 6; LENTIL_CLEAR_OFFSTREAM=0: on it, as before): a streamed
+  // pass's scan neither reads nor writes the splat accumulators -- the pixels' own sums go to FrameDev::dir --, so the wipe (20-25 us
+  // of HBM writes for a 4K frame) runs on the stream of the pass's solve and accept kernels, beside the scan; the first accept
+  // follows it in stream order, the early resolve waits for ev_clear, and every other consumer of the frame joins it first
+  // (join_clear: CHECK_CTX, lentil_hip_resolve, every pass that is not the streamed one).
+  bool clear_offstream = true;
+  bool clear_pending = false;
+  hipEvent_t ev_pre_clear = nullptr, ev_clear = nullptr;
   // accept_kernel<3> (lentil_kernels.h) as the lean tail's first accept: LENTIL_READY_ACCEPT=0 restores round 5's pair, LENTIL_READY_ACCEPT_BLOCKS
   // its blocks per CU; LENTIL_RESOLVE_AFTER_SCAN=0 / 1 decides where the whole-frame resolve runs whatever the accept (-1: with accept_kernel<3>)
   bool ready_accept = true;
@@ -357,6 +365,7 @@ static void release_turn(lentil_hip_ctx *ctx) {
   ctx->holds_turn = false;
 }
 DeviceTurn::~DeviceTurn() { if (taken && !kept) release_turn(ctx); }
+
 static void apply_camera_motion(lentil_hip_ctx *ctx);
 
 // One streamed pass at a time per device and process: its solve waves are resident while they wait for the scan's
@@ -384,6 +393,7 @@ static int fail(lentil_hip_ctx *ctx, int code, const std::string &msg) {
       return fail(ctx, LENTIL_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_));   \
   } while (0)
 static int settle(lentil_hip_ctx *ctx);
+static int join_clear(lentil_hip_ctx *ctx);
 static void harvest_ready(lentil_hip_ctx *ctx);
 static int resolve_range(lentil_hip_ctx *ctx, uint64_t p_begin, uint64_t p_end);
 // Every entry point observes the context's last pass -- waits for it, finishes what it left open (settle) -- except the four a
@@ -397,7 +407,20 @@ static int resolve_range(lentil_hip_ctx *ctx, uint64_t p_begin, uint64_t p_end);
       const int rc_settle_ = settle(ctx);                                  \
       if (rc_settle_) return rc_settle_;                                   \
     }                                                                      \
+    if ((ctx)->clear_pending) {                                            \
+      const int rc_join_ = join_clear(ctx);                                \
+      if (rc_join_) return rc_join_;                                       \
+    }                                                                      \
   } while (0)
+
+// the context's stream behind a wipe that clear_frame put on another stream (lentil_hip_ctx::clear_offstream)
+static int join_clear(lentil_hip_ctx *ctx) {
+  if (!ctx->clear_pending) return LENTIL_OK;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_clear, 0));
+  ctx->clear_pending = false;
+  return LENTIL_OK;
+}
 
 static inline void ht_mark(lentil_hip_ctx *ctx, const char *what) {
   if (!host_trace_passes()) return;
@@ -536,6 +559,9 @@ LENTIL_API int lentil_hip_create(int device, lentil_hip_ctx **out_ctx) {
   if (hipHostGetDevicePointer((void **)&ctx->d_ctr_host, ctx->h_ctr_pinned, 0) != hipSuccess) { ctx->d_ctr_host = nullptr; (void)hipGetLastError(); }
   if (const char *e = getenv("LENTIL_SPIN_READBACK")) ctx->spin_readback = atoi(e) != 0;
   if (const char *e = getenv("LENTIL_ASYNC_END")) ctx->async_end = e[0] != '0';
+  if (const char *e = getenv("LENTIL_CLEAR_OFFSTREAM")) ctx->clear_offstream = e[0] != '0';
+  HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_pre_clear, hipEventDisableTiming));
+  HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_clear, hipEventDisableTiming));
   if (const char *e = getenv("LENTIL_READY_ACCEPT")) ctx->ready_accept = e[0] != '0';
   if (const char *e = getenv("LENTIL_READY_ACCEPT_BLOCKS")) { ctx->ready_blocks = atoi(e); if (ctx->ready_blocks < 1) ctx->ready_blocks = 1; if (ctx->ready_blocks > 6) ctx->ready_blocks = 6; }
   if (const char *e = getenv("LENTIL_RESOLVE_AFTER_SCAN")) ctx->resolve_after_scan = e[0] == '1' ? 1 : 0;
@@ -740,6 +766,8 @@ LENTIL_API int lentil_hip_destroy(lentil_hip_ctx *ctx) {
   if (ctx->pub_done) (void)hipEventDestroy(ctx->pub_done);
   if (ctx->ev_slow) (void)hipEventDestroy(ctx->ev_slow);
   if (ctx->ev_round) (void)hipEventDestroy(ctx->ev_round);
+  if (ctx->ev_pre_clear) (void)hipEventDestroy(ctx->ev_pre_clear);
+  if (ctx->ev_clear) (void)hipEventDestroy(ctx->ev_clear);
   for (lentil_hip_ctx::Slot &sl : ctx->slots) {
     for (hipEvent_t e : sl.ev) if (e) (void)hipEventDestroy(e);
     if (sl.ev_scan_k[0]) (void)hipEventDestroy(sl.ev_scan_k[0]);
@@ -1390,10 +1418,23 @@ LENTIL_API int lentil_hip_clear_frame(lentil_hip_ctx *ctx) {
     uint64_t blocks = (n_groups + 255) / 256;
     const uint64_t max_blocks = (uint64_t)ctx->num_cu * 4;
     if (blocks > max_blocks) blocks = max_blocks;
-    hipLaunchKernelGGL(clear_touched_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, ctx->F, n_groups);
+    hipStream_t cs = ctx->stream;
+    const bool off = ctx->clear_offstream && ctx->streams_concurrent && ctx->stream_mode && !ctx->chunks.empty() && ctx->chunks[0].stream && !ctx->clear_pending;
+    if (off) {
+      // behind everything the main stream holds so far (the last pass's tail is on this very stream already), beside what it gets next
+      cs = ctx->chunks[0].stream;
+      HIP_TRY(ctx, hipEventRecord(ctx->ev_pre_clear, ctx->stream));
+      HIP_TRY(ctx, hipStreamWaitEvent(cs, ctx->ev_pre_clear, 0));
+    }
+    hipLaunchKernelGGL(clear_touched_kernel, dim3((unsigned)blocks), dim3(256), 0, cs, ctx->F, n_groups);
     HIP_TRY(ctx, hipGetLastError());
+    if (off) {
+      HIP_TRY(ctx, hipEventRecord(ctx->ev_clear, cs));
+      ctx->clear_pending = true;
+    }
     ctx->F.touched = nullptr;
   } else {
+  { const int rcj = join_clear(ctx); if (rcj) return rcj; }
   uint64_t p0 = 0, p1 = ctx->F.np;
   if (ctx->dirty_known && !ctx->pass_pending) {
     p0 = (uint64_t)(ctx->dirty_lo < 0 ? 0 : ctx->dirty_lo) * ctx->P.xres;
@@ -2414,6 +2455,9 @@ static int redistribute_streamed(lentil_hip_ctx *ctx, bool *streamed, bool *defe
   ScanPlan plan;
   if ((rc = plan_scan(ctx, plan))) return rc;
   da.F = ctx->F;                // (plan_scan decides where the direct sums go and whether splats are flagged)
+  // the wipe clear_frame left on the chunk stream (clear_offstream) rides beside the scan only where the scan leaves the splat
+  // accumulators alone: own sums to FrameDev::dir, splats flagged
+  if (ctx->clear_pending && !(ctx->F.dir && ctx->F.touched) && (rc = join_clear(ctx))) return rc;
   ch.tile_begin = 0; ch.tile_end = plan.n_tiles;
   ch.v_begin = 0; ch.v_end = ctx->V.n;
   for (int ci = 1; ci < ctx->n_chunks; ++ci) {
@@ -2732,6 +2776,7 @@ static int redistribute_streamed(lentil_hip_ctx *ctx, bool *streamed, bool *defe
     const bool resolve_after_scan = lean_pass && resolves_early && (ctx->resolve_after_scan >= 0 ? ctx->resolve_after_scan == 1 : ready_accept);
     if (resolve_after_scan) {
       hipStream_t rs = ctx->chunks[1].stream;
+      if (ctx->clear_pending) HIP_TRY(ctx, hipStreamWaitEvent(rs, ctx->ev_clear, 0));      // (it reads the accumulators clear_frame is wiping on the chunk stream)
       HIP_TRY(ctx, hipStreamWaitEvent(rs, ctx->scans_done, 0));
       if ((rc = launch_resolve_half(ctx, rs, 0u))) return rc;
     }
@@ -2842,6 +2887,7 @@ static int redistribute_streamed(lentil_hip_ctx *ctx, bool *streamed, bool *defe
     tail = ps;
     }
   } else {
+  if ((rc = join_clear(ctx))) return rc;       // (this form's accepts are on the main stream)
   // B: the rest of the CUs' room, once the scan's waves have left
   da.instance = 1;
   if (b_blocks) launch_solve_po<true>(ctx, da, ctx->stream, b_blocks, b_threads);
@@ -2939,6 +2985,7 @@ static int redistribute_streamed(lentil_hip_ctx *ctx, bool *streamed, bool *defe
   }
   const int C = ctx->n_chunks;
   ht_mark(ctx, "all_launched");
+  ctx->clear_pending = false;       // (every stream of the pass is behind the wipe by now, and the main stream will be behind the pass)
   StreamTail t;
   t.tail = tail; t.pass_t0 = pass_t0; t.calibrates_now = calibrates_now; t.predicted = predicted; t.lean = lean; t.extend = extend;
   t.live = live; t.inject = da.inject_stall != 0; t.blind_rounds = blind_rounds; t.da = da; t.slow_base = slow_base;
@@ -3441,6 +3488,7 @@ static int redistribute_pass(lentil_hip_ctx *ctx) {
   bool streamed = false, deferred = false;
   const bool tl_chroma = P.cameraType == LENTIL_THINLENS && P.abb_chromatic > 0.0f;
   if (tl_chroma) {
+    { const int rc = join_clear(ctx); if (rc) return rc; }
     if (ctx->V.n) { const int rc = redistribute_tl_chroma(ctx); if (rc) return rc; }
     else { HIP_TRY(ctx, hipEventRecord(ctx->ev[1], ctx->stream)); HIP_TRY(ctx, hipEventRecord(ctx->scans_done, ctx->stream)); }
     streamed = true;          // (nothing of the chunked form below runs)
@@ -3449,6 +3497,7 @@ static int redistribute_pass(lentil_hip_ctx *ctx) {
     if (rc) return rc;
     if (ctx->stall_redo) return LENTIL_OK;       // (lentil_hip_redistribute wipes the frame and calls again)
   }
+  if (!streamed) { const int rc = join_clear(ctx); if (rc) return rc; }
   if (!streamed && ctx->V.n) {
     // ---- scans: all chunks back to back on the main stream
     ScanPlan plan;
@@ -3729,6 +3778,7 @@ LENTIL_API int lentil_hip_resolve(lentil_hip_ctx *ctx) {
   if (!ctx->have_frame) return fail(ctx, LENTIL_ERR_INVALID, "no frame allocated");
   // (behind a pass whose end is open: should that pass turn out to need more work, its observer resolves again)
   if (!ctx->inflight.empty() && !ctx->inflight.back().abandoned) ctx->inflight.back().resolve_requested = true;
+  { const int rcj = join_clear(ctx); if (rcj) return rcj; }
   ht_mark(ctx, "resolve");
   if (ctx->resolved_valid) {          // the pass resolved the frame on its way (nothing has touched it since)
     HIP_TRY(ctx, hipSetDevice(ctx->device));
