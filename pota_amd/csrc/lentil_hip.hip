@@ -303,6 +303,12 @@ struct lentil_hip_ctx {
   // its blocks per CU; LENTIL_RESOLVE_AFTER_SCAN=0 / 1 decides where the whole-frame resolve runs whatever the accept (-1: with accept_kernel<3>)
   bool ready_accept = true;
   int ready_blocks = 4;
+  // ... and that accept BESIDE the first round's solves (accept_kernel<4>, DrawArgs::early_accept): LENTIL_EARLY_ACCEPT=0 keeps it behind
+  // them (accept_kernel<3>); LENTIL_EARLY_ACCEPT_BLOCKS its blocks per CU (1: a wave per SIMD beside two solve waves)
+  bool early_accept = true;
+  int early_blocks = 1;
+  uint64_t *d_ready = nullptr;       // the queue of completed items (tagged slots, one per item)
+  uint64_t ready_cap = 0;
   int resolve_after_scan = -1;
   struct Slot {                       // what a pass needs of its own while another pass is being enqueued: events, the counters' landing block
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -565,6 +571,8 @@ LENTIL_API int lentil_hip_create(int device, lentil_hip_ctx **out_ctx) {
   if (const char *e = getenv("LENTIL_READY_ACCEPT")) ctx->ready_accept = e[0] != '0';
   if (const char *e = getenv("LENTIL_READY_ACCEPT_BLOCKS")) { ctx->ready_blocks = atoi(e); if (ctx->ready_blocks < 1) ctx->ready_blocks = 1; if (ctx->ready_blocks > 6) ctx->ready_blocks = 6; }
   if (const char *e = getenv("LENTIL_RESOLVE_AFTER_SCAN")) ctx->resolve_after_scan = e[0] == '1' ? 1 : 0;
+  if (const char *e = getenv("LENTIL_EARLY_ACCEPT")) ctx->early_accept = e[0] != '0';
+  if (const char *e = getenv("LENTIL_EARLY_ACCEPT_BLOCKS")) { ctx->early_blocks = atoi(e); if (ctx->early_blocks < 1) ctx->early_blocks = 1; if (ctx->early_blocks > 4) ctx->early_blocks = 4; }
   HIP_TRY(ctx, hipEventCreate(&ctx->ev_scan_k[0]));
   HIP_TRY(ctx, hipEventCreate(&ctx->ev_scan_k[1]));
   // the slots of the asynchronous end (lentil_hip_ctx::Slot): slot 0 holds what has just been created, 1 and 2 their own
@@ -683,6 +691,7 @@ LENTIL_API int lentil_hip_create(int device, lentil_hip_ctx **out_ctx) {
       hipLaunchKernelGGL(accept_kernel<1>, dim3(wg), dim3(256), 0, st, w);
       hipLaunchKernelGGL(accept_kernel<2>, dim3(wg), dim3(256), 0, st, w);
       hipLaunchKernelGGL(accept_kernel<3>, dim3(wg), dim3(256), 0, st, w);
+      hipLaunchKernelGGL(accept_kernel<4>, dim3(wg), dim3(256), 0, st, w);
       HIP_TRY(ctx, hipGetLastError());
       HIP_TRY(ctx, hipStreamSynchronize(st));
     }
@@ -785,6 +794,7 @@ LENTIL_API int lentil_hip_destroy(lentil_hip_ctx *ctx) {
   if (ctx->ev_crypto) (void)hipEventDestroy(ctx->ev_crypto);
   (void)hipFree(ctx->d_ctr);
   (void)hipFree(ctx->d_ranges);
+  (void)hipFree(ctx->d_ready);
   (void)hipFree(ctx->d_live);
   if (ctx->jit_module) (void)hipModuleUnload(ctx->jit_module);
   (void)hipFree(ctx->d_bm_land); (void)hipFree(ctx->d_bm_box); (void)hipFree(ctx->d_bm_npass);
@@ -2471,6 +2481,7 @@ static int redistribute_streamed(lentil_hip_ctx *ctx, bool *streamed, bool *defe
     HIP_TRY(ctx, hipMemsetAsync(ch.tasks[0], 0, ch.task_cap * sizeof(Task), ctx->stream));
     HIP_TRY(ctx, hipMemsetAsync(ch.tasks[1], 0, ch.task_cap * sizeof(Task), ctx->stream));
     if (ctx->d_ranges) HIP_TRY(ctx, hipMemsetAsync(ctx->d_ranges, 0, ctx->range_cap * sizeof(uint64_t), ctx->stream));
+    if (ctx->d_ready) HIP_TRY(ctx, hipMemsetAsync(ctx->d_ready, 0, ctx->ready_cap * sizeof(uint64_t), ctx->stream));
     if (ch.slow) HIP_TRY(ctx, hipMemsetAsync(ch.slow, 0, ch.slow_cap * sizeof(SlowRec), ctx->stream));
     if (ctx->d_ext_q) HIP_TRY(ctx, hipMemsetAsync(ctx->d_ext_q, 0, ctx->ext_q_cap * sizeof(Task), ctx->stream));
   }
@@ -2698,11 +2709,38 @@ static int redistribute_streamed(lentil_hip_ctx *ctx, bool *streamed, bool *defe
     ready_accept = lean_pass && !off && live && retries <= kAcceptWinRetries && !da.accept_narrow && add_floats <= 64u && nch == 1;
   }
   da.item_ready = ready_accept ? 1 : 0;
+  // ... and beside the solves (accept_kernel<4>): the queue of completed items, a slot per item
+  const bool early = ready_accept && ctx->early_accept && ctx->slow1_stream != nullptr && !b_blocks;
+  if (early) {
+    if (ch.item_cap > ctx->ready_cap) {
+      if ((rc = grow(ctx, &ctx->d_ready, ch.item_cap))) return rc;
+      ctx->ready_cap = ch.item_cap;
+      HIP_TRY(ctx, hipMemsetAsync(ctx->d_ready, 0, ch.item_cap * sizeof(uint64_t), ctx->stream));       // (slots are told by their tag)
+      HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    da.early_accept = 1;
+    da.ready_q = ctx->d_ready;
+    da.ready_cap = (uint32_t)(ctx->ready_cap < 0xFFFFFFF0ull ? ctx->ready_cap : 0xFFFFFFF0ull);
+  }
   HIP_TRY(ctx, hipStreamWaitEvent(ctx->pub_stream, ctx->ev[0], 0));
   hipLaunchKernelGGL(publish_kernel, dim3((unsigned)ctx->publish_waves), dim3(64), 0, ctx->pub_stream, pa);
   HIP_TRY(ctx, hipGetLastError());
   HIP_TRY(ctx, hipEventRecord(ctx->pub_done, ctx->pub_stream));
-  if (live) {
+  if (live && early) {
+    // the stragglers on a stream of their own, the first accept behind the publishers on theirs: both start when the scan's
+    // registers and LDS are free, the accept takes the completed items as the solve kernel (launched below) delivers them
+    HIP_TRY(ctx, hipStreamWaitEvent(ctx->slow1_stream, ctx->pub_done, 0));
+    hipLaunchKernelGGL(solve_slow_kernel, dim3(da.slow_waves), dim3(64), coop_lds_bytes(ctx->hlens.n_terms), ctx->slow1_stream, da);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_slow, ctx->slow1_stream));
+    if (ctx->clear_pending) HIP_TRY(ctx, hipStreamWaitEvent(ctx->pub_stream, ctx->ev_clear, 0));      // (it splats into what clear_frame is wiping)
+    DrawArgs d0 = da;
+    d0.emit_live = 0; d0.lean_defer = 1;
+    d0.end_tasks = (uint32_t)ctx->num_cu * 4u;
+    hipLaunchKernelGGL(accept_kernel<4>, dim3((unsigned)ctx->num_cu * (unsigned)ctx->early_blocks), dim3(256), 0, ctx->pub_stream, d0);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_acc1, ctx->pub_stream));
+  } else if (live) {
     // (behind the publishers on their stream: they end with the scan, whose registers this kernel's waves need)
     hipLaunchKernelGGL(solve_slow_kernel, dim3(da.slow_waves), dim3(64), coop_lds_bytes(ctx->hlens.n_terms), ctx->pub_stream, da);
     HIP_TRY(ctx, hipGetLastError());
@@ -2780,7 +2818,10 @@ static int redistribute_streamed(lentil_hip_ctx *ctx, bool *streamed, bool *defe
       HIP_TRY(ctx, hipStreamWaitEvent(rs, ctx->scans_done, 0));
       if ((rc = launch_resolve_half(ctx, rs, 0u))) return rc;
     }
-    {
+    if (early) {
+      // (the first accept is at work beside the solve kernel already -- accept_kernel<4>, above; what follows on this stream follows it)
+      HIP_TRY(ctx, hipStreamWaitEvent(ch.stream, ctx->ev_acc1, 0));
+    } else {
       DrawArgs d0 = da;
       d0.emit_live = lean_pass ? 0 : 1;       // (lean tail: nobody is waiting for tasks)
       d0.lean_defer = lean_pass ? 1 : 0;
@@ -2788,8 +2829,8 @@ static int redistribute_streamed(lentil_hip_ctx *ctx, bool *streamed, bool *defe
       if (ready_accept) hipLaunchKernelGGL(accept_kernel<3>, dim3(accept1_blocks), dim3(256), 0, ch.stream, d0);
       else hipLaunchKernelGGL(accept_kernel<1>, dim3(accept1_blocks), dim3(256), 0, ch.stream, d0);
       HIP_TRY(ctx, hipGetLastError());
+      HIP_TRY(ctx, hipEventRecord(ctx->ev_acc1, ch.stream));
     }
-    HIP_TRY(ctx, hipEventRecord(ctx->ev_acc1, ch.stream));
     if (resolves_early) {
       hipStream_t rs = ctx->chunks[1].stream;
       HIP_TRY(ctx, hipStreamWaitEvent(rs, ctx->ev_acc1, 0));
@@ -2810,11 +2851,13 @@ static int redistribute_streamed(lentil_hip_ctx *ctx, bool *streamed, bool *defe
       {
         DrawArgs d2 = da;
         d2.lean_gate = 1;
+        d2.early_accept = 0;          // (every kernel that wrote its results has ended: plain loads)
         d2.slow_indirect = 0; d2.slow_cap = slow_cap_all; d2.slow_live = 0;
         hipLaunchKernelGGL(accept_kernel<2>, dim3(accept_blocks), dim3(256), 0, ls, d2);
       }
       HIP_TRY(ctx, hipGetLastError());
       da.slow_indirect = 0; da.slow_cap = slow_cap_all; da.slow_live = 0;
+      da.early_accept = 0;          // (whatever the host launches behind this pass's kernels reads results they have finished writing)
       if (ctx->early_resolve_pending) {
         HIP_TRY(ctx, hipStreamWaitEvent(ls, ctx->ev_res, 0));
         if ((rc = launch_resolve_half(ctx, ls, 2u))) return rc;

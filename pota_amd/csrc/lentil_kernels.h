@@ -67,6 +67,9 @@ struct DevCounters {
   // accept's last item was finished with blocks of its grid still not begun (lentil_hip_last_redo_note prints it)
   unsigned int probe_accept_xcc[8], probe_res_xcc[3][8];
   unsigned int probe_snap[1 + 8 + 24 + 2];
+  // DrawArgs::early_accept: items whose first batch is complete (every result delivered, parked solves counted as delivered),
+  // pushed by the solve wave that delivered the last one / tickets drawn on that queue by accept_kernel<4>
+  unsigned int n_ready, ready_head;
 };
 
 LD_DEV uint32_t xcc_id() { return (uint32_t)__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u; }      // HW_REG_XCC_ID[3:0]
@@ -174,7 +177,11 @@ struct ItemHdr {          // written by prep_items_kernel / publish_item; a 128-
   // in the record; accept_kernel<3> -- behind the solve kernel, beside the stragglers -- takes an item whose two counts agree and
   // leaves the others to the accept behind the stragglers.
   uint32_t parked, parked_done;
-  uint32_t pad[22];
+  // DrawArgs::early_accept: results the item's first batch holds (one per try and channel) / results delivered so far.  One
+  // 8-byte word: the solve wave that delivers results adds to the high half with ONE returning atomic and reads the low half
+  // from what it returns; the wave whose add makes the two equal pushes the item onto the ready queue.
+  uint32_t issued, delivered;
+  uint32_t pad[20];
 };
 static_assert(sizeof(ItemHdr) == 128, "ItemHdr is a 128-byte line");
 
@@ -491,6 +498,7 @@ LD_DEV void publish_item(const lentil_params &P, const VisitsDev &V, const Strea
     st_agent64(d + 2, (uint64_t)__double_as_longlong(hd.tz));
     st_agent64(d + 3, (uint64_t)hd.seed_a | ((uint64_t)(uint32_t)hd.px_py << 32));
     st_agent64(d + 4, 0ull);          // ItemHdr::parked / parked_done
+    st_agent64(d + 5, ok ? (uint64_t)count * nch : 0ull);      // ItemHdr::issued / delivered
     ItemProg pg{};
     pg.m_lo = 0;
     pg.m_hi = ok ? count : 0u;
@@ -2180,6 +2188,15 @@ struct DrawArgs {
   // runs that round the ordinary way and this accept after it.
   uint64_t stuck_ticks;       // how long a resident wave waits for a queue slot before it declares the pass stuck (0: kStuckTicks)
   int32_t lean_gate;
+  // Round 6, the first accept BESIDE the first round's solves (accept_kernel<4>): the solve kernel writes its results through
+  // (agent-scope atomics, like every other word another CU reads while a kernel runs), counts them per item
+  // (ItemHdr::delivered) and pushes an item whose batch is complete onto `ready_q` (tagged slots, never cleared); the accept
+  // -- launched behind the publishers, when the scan's LDS and registers are free -- draws tickets on that queue and walks the
+  // items as they come, with the solve kernel still at work on the others.  What is left when the last solve wave exits is
+  // the items completed last, not the whole frame's accept.
+  int32_t early_accept;
+  uint32_t ready_cap;
+  uint64_t *ready_q;
   int32_t item_ready;         // streamed pass, lean tail: parked solves are counted per item (ItemHdr::parked / parked_done) for accept_kernel<3>
   int32_t lean_defer;         // ... and the first accept leaves an item that met parked solves to that accept whole: what it still
                               // needs is decided there, from the stragglers' results
@@ -2188,6 +2205,17 @@ LD_DEV uint32_t slow_queue(const DrawArgs &a) { return a.slow_q >= 0 ? (uint32_t
 LD_DEV uint64_t slow_tag(const DrawArgs &a, uint64_t what) {
   const uint32_t r = a.slow_round >= 0 ? (uint32_t)a.slow_round : (uint32_t)a.round;
   return ((uint64_t)((a.epoch << 8) | (r & 0xFFu)) << 32) | what;
+}
+
+// DrawArgs::early_accept: `cnt` results of `item` have been written through (and waited for); the item whose batch is complete with
+// them goes onto the ready queue.  Called by one lane.
+LD_DEV void ready_deliver(const DrawArgs &a, uint32_t item, uint32_t cnt) {
+  const unsigned long long old = atomicAdd(reinterpret_cast<unsigned long long *>(&a.hdr[item].issued), (unsigned long long)cnt << 32);
+  const uint32_t issued = (uint32_t)old, delivered = (uint32_t)(old >> 32) + cnt;
+  if (issued != 0u && delivered == issued) {
+    const uint32_t slot = atomicAdd(&a.ctr->n_ready, 1u);
+    if (slot < a.ready_cap) st_agent64(a.ready_q + slot, (uint64_t)item | ((uint64_t)((a.epoch << 8) | 1u) << 32));
+  }
 }
 
 LD_DEV ItemVisit load_item_visit(const DrawArgs &a, uint32_t item, double lens_length) {
@@ -2492,6 +2520,7 @@ __global__ __launch_bounds__(256) LENTIL_SOLVE_ATTR void solve_po_kernel(DrawArg
   const uint32_t wv = threadIdx.x >> 6;
   // extension (ItemLive): the first round of a streamed pass counts what it delivers per item and appends batches itself
   const bool extend = kStream && !kChroma && a.live != nullptr && a.round == 0;
+  const bool early = kStream && !kChroma && a.early_accept != 0 && a.round == 0;       // accept_kernel<4> beside this kernel (DrawArgs::early_accept)
   bool close_queue = false;      // this wave closed the last open item: it writes the queue's end markers
   const bool keeper = extend && blockIdx.x < a.ext_keeper_blocks;
   bool on_ext = false;
@@ -2518,10 +2547,23 @@ __global__ __launch_bounds__(256) LENTIL_SOLVE_ATTR void solve_po_kernel(DrawArg
       LensT Lf = L;
       if constexpr (kChroma) Lf.k = &s_kc[(ew >> 8) & 3u];
       const uint32_t code = solve_result(P, Lf, t);
-      res[s_fin_res[wv][lane]] = code;
+      if (early) st_agent32(res + s_fin_res[wv][lane], code);      // (read by accept_kernel<4> on another CU while this kernel runs)
+      else res[s_fin_res[wv][lane]] = code;
       fin_ok = code < kCodePendingBase;
       fin_out = code == kCodeOut;
       fin_item = s_fin_item[wv][lane];
+    }
+    if (early) {
+      // every result of this flush is out before any of them is counted; then per item of the queue (usually one or two)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      unsigned long long todo = __ballot(lane < fin_n);
+      while (todo) {
+        const int leader = __builtin_ctzll(todo);
+        const uint32_t it = (uint32_t)__builtin_amdgcn_readlane((int)fin_item, leader);
+        const unsigned long long same = __ballot(lane < fin_n && fin_item == it) & todo;
+        if ((int)lane == leader) ready_deliver(a, it, (uint32_t)__builtin_popcountll(same));
+        todo &= ~same;
+      }
     }
     if (extend) {
       // per item of the queue: how many results, how many of them pixels / outside the frame (usually one or two items)
@@ -2764,6 +2806,9 @@ __global__ __launch_bounds__(256) LENTIL_SOLVE_ATTR void solve_po_kernel(DrawArg
             if (a.slow_indirect) st_agent32(res + res_idx, kCodePendingBase | slot);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             st_agent64(d + 15, slow_tag(a, kSlowRecord));
+            // (early accept: a parked solve is delivered -- its mark is in the pool; whether its result is in by the time the
+            // accept comes to the item is ItemHdr::parked / parked_done's business)
+            if (early) ready_deliver(a, my_item, 1u);
             // (extension: a parked solve is delivered -- as a failure, for what the item's batch is judged by)
             if (extend && live_deliver(a, my_item, 1u, 0u, 0u)) parked_closed = true;
           } else {
@@ -3574,6 +3619,33 @@ LD_DEV AcceptResult accept_item_wide(const DrawArgs &a, AcceptShared &sh, Accept
       const uint32_t jc = covered / 256u + 1u;
       if (jc < jn) jn = jc;
     }
+    if (a.early_accept) {
+      // accept_kernel<4>: the solve kernel that wrote these results is still running on other CUs -- they were written through
+      // with agent-scope atomics and are read with returning atomics (ld_coherent*: an L2 of this XCD may hold the line from
+      // before), two results at a time where the batch lies in one piece (an item's first batch always does)
+      const uint32_t count = jn * 256u + retries;
+      if (pg.p_hi == pg.p_lo && n >= pg.m_lo) {
+        const uint32_t e0 = pg.res_off + (n - pg.m_lo), odd = e0 & 1u;
+        for (uint32_t j = threadIdx.x; 2u * j < count + odd; j += 256u) {
+          const uint32_t e = e0 - odd + 2u * j;                      // even: an 8-byte word of the pool
+          uint32_t lo, hi;
+          if ((uint64_t)e + 1u < a.pool_cap) { const uint64_t w = ld_coherent64(res + e); lo = (uint32_t)w; hi = (uint32_t)(w >> 32); }
+          else { lo = ld_coherent32(res + e); hi = kCodeBeyond; }
+          const uint32_t i1 = 2u * j + 1u - odd;                    // window index of the word's upper half (the lower: i1 - 1)
+          if (i1 >= 1u && i1 - 1u < count) ws.win[i1 - 1u] = n + (i1 - 1u) >= pg.m_hi ? kCodeBeyond : lo;
+          if (i1 < count) ws.win[i1] = n + i1 >= pg.m_hi ? kCodeBeyond : hi;
+        }
+      } else {
+        for (uint32_t i = threadIdx.x; i < count; i += 256u) {
+          const uint32_t m = n + i;
+          uint32_t c = kCodeFail;
+          if (m >= pg.m_hi) c = kCodeBeyond;
+          else if (m >= pg.m_lo) c = ld_coherent32(res + pg.res_off + (m - pg.m_lo));
+          else if (m >= pg.p_lo && m < pg.p_hi) c = ld_coherent32(res_prev + pg.p_off + (m - pg.p_lo));
+          ws.win[i] = c;
+        }
+      }
+    } else
     for (uint32_t i = threadIdx.x; i < jn * 256u + retries; i += 256u) ws.win[i] = result_at2(res, res_prev, pg, n + i);
     if (threadIdx.x < kSlabs) { ws.first_u[threadIdx.x] = kStep; ws.m_succ[threadIdx.x] = 0ull; ws.m_unk[threadIdx.x] = 0ull; ws.m_succ1[threadIdx.x] = 0ull; }
     block_sync_lds();
@@ -3954,7 +4026,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LENTIL_ACCE
   // walked twice (mode 1 splatted what was certain of nearly every item and mode 2 then replayed nearly every item: 134 us
   // behind the stragglers for a headline frame); what is left for the accept behind the stragglers is the items whose
   // stragglers were still at work when this kernel came to them.  It never waits for anything.
-  constexpr int kWalk = kMode == 3 ? 2 : kMode;
+  // kMode 4: mode 3 BESIDE the solve kernel (DrawArgs::early_accept): launched behind the publishers, it draws tickets on the queue
+  // of items whose first batch is complete -- pushed by the solve wave that delivered the item's last result -- and walks each
+  // as it comes; its last block leaves when the pass's last item is through, a walk or two behind the solve kernel's last wave
+  // instead of a whole accept (160-190 us for a 4K headline frame).  It waits for the solve kernel (resident since the pass
+  // began, holding everything it will ever need), never for the stragglers: an item with a parked solve still out goes to the
+  // accept behind them, as in mode 3.
+  constexpr int kWalk = (kMode == 3 || kMode == 4) ? 2 : kMode;
   __shared__ uint32_t s_item, s_ready;
   __shared__ AcceptShared sh;
   __shared__ AcceptWideShared ws;
@@ -4078,14 +4156,47 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LENTIL_ACCE
   }
   while (true) {
     __syncthreads();
-    if (threadIdx.x == 0) s_item = atomicAdd(&a.ctr->active_head[par], per);
-    __syncthreads();
-    const uint32_t ai0 = s_item;
-    if (ai0 >= n_active) break;
-    const uint32_t cnt = n_active - ai0 < per ? n_active - ai0 : per;
+    uint32_t ai0 = 0, ready_item = 0;
+    if constexpr (kMode == 4) {
+      // a ticket on the ready queue; its slot is filled when the item it will hold is complete
+      if (threadIdx.x == 0) {
+        uint32_t item = 0xFFFFFFFFu;
+        const uint32_t ticket = atomicAdd(&a.ctr->ready_head, 1u);
+        if (ticket < n_active && ticket < a.ready_cap) {
+          const uint32_t tag = (a.epoch << 8) | 1u;
+          const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
+          uint32_t naps = 1u, polls = 0u;
+          while (true) {
+            const uint64_t w = ld_coherent64(a.ready_q + ticket);
+            if ((uint32_t)(w >> 32) == tag) { item = (uint32_t)w; break; }
+            if ((++polls & 15u) == 0u && (ld_coherent32(&a.ctr->stuck) != 0u || ld_coherent64(&a.ctr->fallback) != 0ull)) break;      // the pass is void
+            if (__builtin_amdgcn_s_memrealtime() - t0 > (a.stuck_ticks ? a.stuck_ticks : kStuckTicks)) {
+              if (atomicCAS(&a.ctr->stuck, 0u, 2u | (ticket << 2)) == 0u) {
+                unsigned int *si = a.ctr->stuck_info;
+                si[0] = 0xACCu; si[1] = par; si[2] = ld_coherent32(&a.ctr->n_ready); si[3] = n_active; si[4] = ld_coherent32(&a.ctr->ready_head);
+                si[5] = (uint32_t)(w >> 32); si[6] = blockIdx.x; si[7] = ld_coherent32(&a.ctr->task_head[par]);
+              }
+              break;
+            }
+            for (uint32_t i = 0; i < naps; ++i) __builtin_amdgcn_s_sleep(64);
+            if (naps < 8u) naps <<= 1;
+          }
+        }
+        s_item = item;
+      }
+      __syncthreads();
+      if (s_item == 0xFFFFFFFFu) break;
+      ready_item = s_item;
+    } else {
+      if (threadIdx.x == 0) s_item = atomicAdd(&a.ctr->active_head[par], per);
+      __syncthreads();
+      ai0 = s_item;
+      if (ai0 >= n_active) break;
+    }
+    const uint32_t cnt = kMode == 4 ? 1u : (n_active - ai0 < per ? n_active - ai0 : per);
     if (wide) {
       for (uint32_t j = 0; j < cnt; ++j) {
-        const uint32_t item = a.active[par][ai0 + j];
+        const uint32_t item = kMode == 4 ? ready_item : a.active[par][ai0 + j];
         const ItemProg pg = load_prog(a, item);
 #ifdef LENTIL_TIMELINE
         const unsigned long long tm0_ = __builtin_amdgcn_s_memrealtime();
@@ -4094,7 +4205,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LENTIL_ACCE
 #ifdef LENTIL_TIMELINE
         if (threadIdx.x == 0 && h.samples) { dbg_add(26, __builtin_amdgcn_s_memrealtime() - tm0_); dbg_add(27, 1); }
 #endif
-        if constexpr (kMode == 3) {
+        if constexpr (kMode == 3 || kMode == 4) {
           if (threadIdx.x == 0) {
             const uint64_t w = ld_coherent64(reinterpret_cast<const uint64_t *>(a.hdr + item) + 4);
             const bool ready = (uint32_t)w == (uint32_t)(w >> 32);
@@ -4122,11 +4233,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LENTIL_ACCE
       ticket_done(cnt);
       continue;
     }
-    if constexpr (kMode == 3) {
-      // (the host launches this mode for frames the wide walk serves; anything else goes to the accept behind the stragglers whole)
+    if constexpr (kMode == 3 || kMode == 4) {
+      // (the host launches these modes for frames the wide walk serves; anything else goes to the accept behind the stragglers whole)
       if (threadIdx.x == 0)
         for (uint32_t j = 0; j < cnt; ++j) {
-          const uint32_t item = a.active[par][ai0 + j];
+          const uint32_t item = kMode == 4 ? ready_item : a.active[par][ai0 + j];
           const ItemProg pg = load_prog(a, item);
           ItemProg np_ = pg;
           np_.uacc = 0; np_.n_end1 = 0;
