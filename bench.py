@@ -940,7 +940,7 @@ def main():
                             "config4": "test_config4_like_4k_nine_gaussian_aovs_streamed_vs_oracle (and, with two closest-filtered "
                                        "AOVs, ::test_config4_4k_petzval_two_closest_aovs_vs_oracle)"}[name[:7]]
                     if "anamorphic" in name:
-                        test = "(this lens: tests/test_gpu_lens_jit.py, interpreter against run-time kernel bit for bit, and the bounded sample here)"
+                        test = "test_config4_anamorphic_4k_nine_aovs_runtime_kernel_vs_oracle"
                     cfgs[name]["parity_checked"] = checked(
                         parity_check, kw["W"], kw["H"], M, kw["samples"], kw["aovs"], args.f_hi, pc[0], pc[1], pc[2], local_rank, torch,
                         bokeh_tables=pc[3], budget_s=5.0,

@@ -302,10 +302,17 @@ struct lentil_hip_ctx {
   // accept_kernel<3> (lentil_kernels.h) as the lean tail's first accept: LENTIL_READY_ACCEPT=0 restores round 5's pair, LENTIL_READY_ACCEPT_BLOCKS
   // its blocks per CU; LENTIL_RESOLVE_AFTER_SCAN=0 / 1 decides where the whole-frame resolve runs whatever the accept (-1: with accept_kernel<3>)
   bool ready_accept = true;
-  int ready_blocks = 4;
+  int ready_blocks = 2;              // (2 / 3 / 4 per CU: 2.011 / 2.013 / 2.013 ms, eight interleaved 60-step runs each on one box: gpurun_out/r06s05)
   // ... and that accept BESIDE the first round's solves (accept_kernel<4>, DrawArgs::early_accept): LENTIL_EARLY_ACCEPT=0 keeps it behind
   // them (accept_kernel<3>); LENTIL_EARLY_ACCEPT_BLOCKS its blocks per CU (1: a wave per SIMD beside two solve waves)
-  bool early_accept = true;
+  // MEASURED AND OFF BY DEFAULT (LENTIL_EARLY_ACCEPT=1 switches it on): frames bit-identical (tests pass with it on), and the pass
+  // 2.33 ms against 2.01 on one box (gpurun_out/r06s07: six interleaved 60-step runs each).  The accept's 160 us do move under the
+  // solve kernel -- and cost more than they were: the solve kernel runs 1.62-1.65 ms where it took 1.47-1.51 (its results go out as
+  // write-through atomics and every flush waits for them and for a returning atomic per item; the accept's waves take issue slots and
+  // memory-side atomic bandwidth from it), the straggler waves -- 152 registers -- find no room on a SIMD that holds two solve waves
+  // AND an accept wave, so the parked solves start when the solve waves leave and end 210-270 us behind them (170 without), and the
+  // accept behind the stragglers gets the items that met them: 95 us where it took 33.
+  bool early_accept = false;
   int early_blocks = 1;
   uint64_t *d_ready = nullptr;       // the queue of completed items (tagged slots, one per item)
   uint64_t ready_cap = 0;
@@ -2627,7 +2634,13 @@ static int redistribute_streamed(lentil_hip_ctx *ctx, bool *streamed, bool *defe
   const int slow_per_cu = ctx->slow_waves_per_cu;
   if (ctx->parked_frac > 1.0 / 256.0) ctx->park_dry_seen = true;
   const bool dry_only = ctx->park_dry_only >= 0 ? ctx->park_dry_only != 0 : ctx->park_dry_seen;
-  const uint32_t slow_waves_all = (uint32_t)ctx->num_cu * (slow_per_cu >= 1 && slow_per_cu <= 4 ? (uint32_t)slow_per_cu : 1u);
+  // (Round 6: four per CU where parked solves are the outliers they are meant to be -- beauty-only frames, the live queue.  The
+  // straggler kernel had become what the pass ends on: 2 300 parked solves of a headline frame, 27 000 iterations at ~3 us each,
+  // are 320 us of work for 256 waves and half of it was still to do when the solve kernel's last wave left; with 1 024 waves
+  // it ends with the solve kernel but for the solves that run all 100 iterations.  2.011 -> 1.989 ms, eight interleaved runs of
+  // 60 steps each, gpurun_out/r06s05.  Config 4 parks dry waves' lanes only and keeps one.)
+  const uint32_t slow_default = (nch == 1 && ctx->V.n_extra == 0 && !dry_only) ? 4u : 1u;
+  const uint32_t slow_waves_all = (uint32_t)ctx->num_cu * (slow_per_cu >= 1 && slow_per_cu <= 4 ? (uint32_t)slow_per_cu : slow_default);
   if (decoupled) { da.slow_indirect = 1; da.slow_cap = slow_cap_all / 2u > slow_waves_all ? slow_cap_all / 2u - slow_waves_all : 0u; }      // (its end markers stay below the upper half)
   static const int b_threads_env = getenv("LENTIL_SOLVE_B_THREADS") ? atoi(getenv("LENTIL_SOLVE_B_THREADS")) : 0;
   const unsigned b_threads = (b_threads_env == 64 || b_threads_env == 128 || b_threads_env == 192 || b_threads_env == 256) ? (unsigned)b_threads_env

@@ -61,7 +61,8 @@ def _compare(ctx, ref, c, samples, n_visits, p, n_aovs=1, kinds=None):
     return worst, int(touched.sum())
 
 
-def _timed_config_vs_oracle(orc, name, W, H, lens, S, n_extra=0, kinds=None, bokeh_image=False, seeds=(0x5EED, 0xBEEF)):
+def _timed_config_vs_oracle(orc, name, W, H, lens, S, n_extra=0, kinds=None, bokeh_image=False, seeds=(0x5EED, 0xBEEF),
+                            passes=(0, 1, 0, 1), runtime_kernel=False):
     """One of bench.py's `configs` entries as the bench runs it -- Bench.generate's two seeded streams, two set-up passes,
     then alternating streams -- with every pass compared with the oracle over the whole frame."""
     import ctypes as C
@@ -89,7 +90,14 @@ def _timed_config_vs_oracle(orc, name, W, H, lens, S, n_extra=0, kinds=None, bok
     ctx = capi.Context(0)
     try:
         ctx.set_params(p); ctx.set_lens(table); ctx.set_bokeh(tables)
-        assert ctx.lens_is_compiled()
+        if runtime_kernel:
+            # a table with no kernel built into the library: its solve kernels are emitted and compiled at run time (lentil_lens_jit.h;
+            # seconds from the cache on disk, ~15 s the first time on a box) -- the passes below must run THEM, not the interpreter
+            assert not ctx.lens_is_compiled()
+            ctx.lens_jit_wait(600.0)
+            assert ctx.lens_jit_status()[0] == 2, ctx.lens_jit_status()
+        else:
+            assert ctx.lens_is_compiled()
         ctx.alloc_frame(n_aovs, kinds)
         ctx.set_draw_log(1 << 21)
         streams, refs = [], []
@@ -100,7 +108,7 @@ def _timed_config_vs_oracle(orc, name, W, H, lens, S, n_extra=0, kinds=None, bok
                                               kinds=kinds, bokeh=ob))
             del h
         seen_streamed = 0
-        for k, i in enumerate((0, 1, 0, 1)):
+        for k, i in enumerate(passes):
             dv, dkeep = streams[i % len(streams)]
             ctx.bind_visits(dv, dkeep)
             ctx.clear_frame(); ctx.redistribute(); ctx.resolve(); ctx.sync()
@@ -113,7 +121,7 @@ def _timed_config_vs_oracle(orc, name, W, H, lens, S, n_extra=0, kinds=None, bok
             worst, n_touched = _compare(ctx, refs[i % len(refs)], c, S, n, p, n_aovs=n_aovs, kinds=kinds)
             print("%s, pass %d (%s): %d items, %d accepted draws on %d pixels, max rel err %.2e"
                   % (name, k, "streamed" if c.streamed else "chunked", c.redistributed_visits, c.accepted_draws, n_touched, worst))
-        assert seen_streamed == (0 if has_closest else 3)
+        assert seen_streamed == (0 if has_closest else len(passes) - 1)
     finally:
         ctx.close()
         for r in refs:
@@ -139,7 +147,16 @@ def test_config4_4k_petzval_two_closest_aovs_vs_oracle(orc):
     gather -- every pass against the oracle, the closest AOVs bit for bit over the whole frame.  One stream (the oracle's
     nine-AOV frames are what bounds this test), replayed as the bench's passes are."""
     _timed_config_vs_oracle(orc, "config 4 (two closest AOVs)", 3840, 2160, "petzval_58mm", 1024, n_extra=8,
-                            kinds=[0, 0, 1, 0, 0, 0, 1, 0, 0], seeds=(0x5EED,))
+                            kinds=[0, 0, 1, 0, 0, 0, 1, 0, 0], seeds=(0x5EED,), passes=(0, 0))      # (first pass, then the blind form it keeps)
+
+
+def test_config4_anamorphic_4k_nine_aovs_runtime_kernel_vs_oracle(orc):
+    """BASELINE config 4's other half, "anamorphic": anamorphic_petzval_58mm -- a cylindrical outer pupil (src/lens.h:156-221,
+    cylinderToCs / csToCylinder), no kernel of it built into the library -- at the full 3840x2160 / 1024 draws / beauty + 8
+    gaussian AOVs, through the solve kernels the library compiles for the table at run time: the whole frame against the
+    oracle, the context's first pass (chunked) and a streamed one."""
+    _timed_config_vs_oracle(orc, "config 4 (anamorphic, run-time kernel)", 3840, 2160, "anamorphic_petzval_58mm", 1024, n_extra=8,
+                            seeds=(0x5EED,), passes=(0, 0), runtime_kernel=True)
 
 
 def test_headline_4k_streamed_vs_oracle(orc):
