@@ -571,6 +571,32 @@ int lentil_hip_process_stats(uint64_t stats[4]);
 /* ... and what the waves that gave up saw (lentil_hip_last_redo_note's text, one line per pass, the first eight that were not
  * asked for), NUL-terminated, truncated to capacity. */
 int lentil_hip_process_stall_notes(char *buf, uint64_t capacity);
+/* Occlusion probes (round 6).  The reference asks the renderer, before every backward trace, whether anything stands between the
+ * sample and the point of the aperture the trace is to go through -- AiTraceProbe along the segment from the sample's world
+ * position to cam_to_world * (-aperture * 0.1 / unit) (src/lentil.h:613-629; thin lens: to cam_to_world * (lens / unit),
+ * src/lentil_filter.cpp:356-375) -- and a try that is occluded fails like one the lens vignettes (samples the skydome supplied are
+ * exempt).  The GPU has no scene.  With a probe set, a pass runs in its round-by-round form, and in every round, once the
+ * round's traces are solved and before any of them is accepted, the library hands the host ONE list of segments -- one per try
+ * of the round that got through the lens (whether it landed in the frame or not: an occluded try hands its attempt on to the
+ * next try) -- and the host answers one byte per segment, non-zero = occluded; the accept then treats those tries as failed.
+ * Results are what the reference computes with the same probe (oracle: orc_frame_set_probe; tests/test_gpu_probe.py).
+ *   fn(user, n, segments, occluded): called from the thread that called lentil_hip_redistribute, once per round and chunk;
+ *   it may spread the n probes over threads of its own.  origin / target are world-space points; the reference's ray is
+ *   AiMakeRay(AI_RAY_SHADOW, origin, normalize(target - origin), |target - origin|).
+ *   camera_to_world: 16 floats, row-vector convention like lentil_params::world_to_camera (AiCameraToWorldMatrix); NULL: the
+ *   inverse of params.world_to_camera (of every motion key, where lentil_hip_set_camera_motion has set keys), computed in fp64.
+ *   fn == NULL switches probing off.  Not with abb_chromatic != 0 (LENTIL_ERR_UNSUPPORTED from the pass): the reference draws a
+ *   thin-lens attempt's colour channel AFTER its probe, from one generator in visit order.
+ * Cost: INTEGRATION.md section 3c (the list travels over PCIe: 24 B out and 1 B back per try that got through the lens). */
+typedef struct lentil_probe_segment {
+  float origin[3];   /* the sample, world space */
+  float target[3];   /* the point on the aperture, world space */
+} lentil_probe_segment;
+typedef void (*lentil_probe_fn)(void *user, uint64_t n, const lentil_probe_segment *segments, uint8_t *occluded);
+int lentil_hip_set_occlusion_probe(lentil_hip_ctx *ctx, lentil_probe_fn fn, void *user, const float *camera_to_world);
+/* stats[0] segments handed to the callback since the context was created, [1] of them answered "occluded", [2] callback calls */
+int lentil_hip_probe_stats(lentil_hip_ctx *ctx, uint64_t stats[3]);
+
 /* The asynchronous end of a pass (round 6).  lentil_hip_redistribute no longer ends with the host waiting for the device: a
  * streamed pass returns once its kernels are enqueued, and whether it needs more work (buffers that were too small, a draw
  * batch that fell short, a wave that gave up waiting) is found out by the next call that OBSERVES the context -- every entry

@@ -654,9 +654,79 @@ ORC_API void orc_po_aperture_sample(const lentil_params *P, const OrcBokeh *B, u
   }
 }
 
+/* the inverse of a 4x4 matrix by cofactors, in fp64, rounded to float at the end (what stands in for AiCameraToWorldMatrix where the
+ * caller gives none: the SDK's own inverse is not in the reference tree; the HIP library computes the same, lentil_hip.hip) */
+static void invert4x4(const float m_[16], float out[16]) {
+  double m[16], inv[16];
+  for (int i = 0; i < 16; i++) m[i] = m_[i];
+  inv[0] = m[5] * m[10] * m[15] - m[5] * m[11] * m[14] - m[9] * m[6] * m[15] + m[9] * m[7] * m[14] + m[13] * m[6] * m[11] - m[13] * m[7] * m[10];
+  inv[4] = -m[4] * m[10] * m[15] + m[4] * m[11] * m[14] + m[8] * m[6] * m[15] - m[8] * m[7] * m[14] - m[12] * m[6] * m[11] + m[12] * m[7] * m[10];
+  inv[8] = m[4] * m[9] * m[15] - m[4] * m[11] * m[13] - m[8] * m[5] * m[15] + m[8] * m[7] * m[13] + m[12] * m[5] * m[11] - m[12] * m[7] * m[9];
+  inv[12] = -m[4] * m[9] * m[14] + m[4] * m[10] * m[13] + m[8] * m[5] * m[14] - m[8] * m[6] * m[13] - m[12] * m[5] * m[10] + m[12] * m[6] * m[9];
+  inv[1] = -m[1] * m[10] * m[15] + m[1] * m[11] * m[14] + m[9] * m[2] * m[15] - m[9] * m[3] * m[14] - m[13] * m[2] * m[11] + m[13] * m[3] * m[10];
+  inv[5] = m[0] * m[10] * m[15] - m[0] * m[11] * m[14] - m[8] * m[2] * m[15] + m[8] * m[3] * m[14] + m[12] * m[2] * m[11] - m[12] * m[3] * m[10];
+  inv[9] = -m[0] * m[9] * m[15] + m[0] * m[11] * m[13] + m[8] * m[1] * m[15] - m[8] * m[3] * m[13] - m[12] * m[1] * m[11] + m[12] * m[3] * m[9];
+  inv[13] = m[0] * m[9] * m[14] - m[0] * m[10] * m[13] - m[8] * m[1] * m[14] + m[8] * m[2] * m[13] + m[12] * m[1] * m[10] - m[12] * m[2] * m[9];
+  inv[2] = m[1] * m[6] * m[15] - m[1] * m[7] * m[14] - m[5] * m[2] * m[15] + m[5] * m[3] * m[14] + m[13] * m[2] * m[7] - m[13] * m[3] * m[6];
+  inv[6] = -m[0] * m[6] * m[15] + m[0] * m[7] * m[14] + m[4] * m[2] * m[15] - m[4] * m[3] * m[14] - m[12] * m[2] * m[7] + m[12] * m[3] * m[6];
+  inv[10] = m[0] * m[5] * m[15] - m[0] * m[7] * m[13] - m[4] * m[1] * m[15] + m[4] * m[3] * m[13] + m[12] * m[1] * m[7] - m[12] * m[3] * m[5];
+  inv[14] = -m[0] * m[5] * m[14] + m[0] * m[6] * m[13] + m[4] * m[1] * m[14] - m[4] * m[2] * m[13] - m[12] * m[1] * m[6] + m[12] * m[2] * m[5];
+  inv[3] = -m[1] * m[6] * m[11] + m[1] * m[7] * m[10] + m[5] * m[2] * m[11] - m[5] * m[3] * m[10] - m[9] * m[2] * m[7] + m[9] * m[3] * m[6];
+  inv[7] = m[0] * m[6] * m[11] - m[0] * m[7] * m[10] - m[4] * m[2] * m[11] + m[4] * m[3] * m[10] + m[8] * m[2] * m[7] - m[8] * m[3] * m[6];
+  inv[11] = -m[0] * m[5] * m[11] + m[0] * m[7] * m[9] + m[4] * m[1] * m[11] - m[4] * m[3] * m[9] - m[8] * m[1] * m[7] + m[8] * m[3] * m[5];
+  inv[15] = m[0] * m[5] * m[10] - m[0] * m[6] * m[9] - m[4] * m[1] * m[10] + m[4] * m[2] * m[9] + m[8] * m[1] * m[6] - m[8] * m[2] * m[5];
+  double det = m[0] * inv[0] + m[1] * inv[4] + m[2] * inv[8] + m[3] * inv[12];
+  det = det != 0.0 ? 1.0 / det : 0.0;
+  for (int i = 0; i < 16; i++) out[i] = (float)(inv[i] * det);
+}
+
+/* one try's probe, src/lentil.h:613-629 (polynomial optics: lens_point = (-aperture * 0.1, 0)) and src/lentil_filter.cpp:356-375 (thin
+ * lens: lens_point = lens): the point in world space -- AtVector /= float multiplies by 1.0f / f (SDK, recalled) -- and the
+ * renderer's answer */
+struct OrcProbeCtx {
+  lentil_probe_fn fn;
+  void *user;
+  const float (*cam_to_world)[4];
+  const float *sample_pos_ws;
+  bool sample_is_from_skydome;
+  int unit_model;
+};
+static inline void probe_target(const float c2w[4][4], int unit_model, const float lens_point[3], float out[3]) {
+  float v[3] = {lens_point[0], lens_point[1], lens_point[2]};
+  float div = 1.0f;
+  switch (unit_model) {
+    case LENTIL_UNIT_MM: div = 0.1f; break;
+    case LENTIL_UNIT_CM: div = 1.0f; break;
+    case LENTIL_UNIT_DM: div = 10.0f; break;
+    case LENTIL_UNIT_M: div = 100.0f; break;
+  }
+  const float c = 1.0f / div;
+  v[0] *= c; v[1] *= c; v[2] *= c;
+  out[0] = v[0] * c2w[0][0] + v[1] * c2w[1][0] + v[2] * c2w[2][0] + c2w[3][0];      /* AiM4PointByMatrixMult, as m4_point below */
+  out[1] = v[0] * c2w[0][1] + v[1] * c2w[1][1] + v[2] * c2w[2][1] + c2w[3][1];
+  out[2] = v[0] * c2w[0][2] + v[1] * c2w[1][2] + v[2] * c2w[2][2] + c2w[3][2];
+}
+static inline bool probe_occluded(const OrcProbeCtx *pc, const float lens_point[3]) {
+  if (!pc || !pc->fn || pc->sample_is_from_skydome) return false;
+  lentil_probe_segment s;
+  for (int i = 0; i < 3; i++) s.origin[i] = pc->sample_pos_ws[i];
+  probe_target(pc->cam_to_world, pc->unit_model, lens_point, s.target);
+  uint8_t occ = 0;
+  pc->fn(pc->user, 1, &s, &occ);
+  return occ != 0;
+}
+
+static int trace_ray_bw_po_probed(const lentil_params *P, const OrcLens *L, const OrcBokeh *B,
+                                  const double target[3], double sensor_position[2], int px, int py,
+                                  int total_samples_taken, float lambda_in, int *tries_out, const OrcProbeCtx *pc);
 ORC_API int orc_trace_ray_bw_po(const lentil_params *P, const OrcLens *L, const OrcBokeh *B,
                                 const double target[3], double sensor_position[2], int px, int py,
                                 int total_samples_taken, float lambda_in, int *tries_out) {
+  return trace_ray_bw_po_probed(P, L, B, target, sensor_position, px, py, total_samples_taken, lambda_in, tries_out, nullptr);
+}
+static int trace_ray_bw_po_probed(const lentil_params *P, const OrcLens *L, const OrcBokeh *B,
+                                  const double target[3], double sensor_position[2], int px, int py,
+                                  int total_samples_taken, float lambda_in, int *tries_out, const OrcProbeCtx *pc) {
   int tries = 0;
   bool ray_succes = false;
   double sensor[5] = {0, 0, 0, 0, lambda_in};
@@ -665,7 +735,11 @@ ORC_API int orc_trace_ray_bw_po(const lentil_params *P, const OrcLens *L, const 
   while (ray_succes == false && tries <= P->vignetting_retries) {
     if (!P->enable_dof) aperture[0] = aperture[1] = 0.0;
     else orc_po_aperture_sample(P, B, (uint32_t)(px * py + px), (uint32_t)(total_samples_taken + tries), aperture);
-    /* AiTraceProbe == false (SURVEY section 7 "Occlusion probe"), src/lentil.h:613-629 */
+    /* raytrace for scene/geometrical occlusions along the ray, src/lentil.h:613-629 (no probe set: AiTraceProbe == false) */
+    if (pc) {
+      const float lens_point[3] = {(float)(-aperture[0] * 0.1), (float)(-aperture[1] * 0.1), 0.0f};
+      if (probe_occluded(pc, lens_point)) { ++tries; continue; }
+    }
     sensor[0] = sensor[1] = 0.0;
     float transmittance = orc_lt_sample_aperture(L, target, aperture, sensor, out, lambda_in, nullptr);
     if (transmittance <= 0) { ++tries; continue; }
@@ -870,6 +944,15 @@ struct OrcFrame {
   /* the keys span the camera's shutter [cam_t0, t1] (orc_frame_set_camera_shutter; 0 ... 1 unless set): lentil_time is Arnold's
    * absolute sample time (src/lentil_filter.cpp:141-143 hands it to AiWorldToCameraMatrix as it is) */
   float cam_t0 = 0.0f, cam_inv_dt = 1.0f;
+  /* AiTraceProbe (src/lentil.h:613-629, src/lentil_filter.cpp:356-375): the renderer's answer to "is anything between the sample
+   * and this point of the aperture", as a callback (orc_frame_set_probe; include/lentil_hip.h: lentil_probe_fn) called one
+   * segment at a time where the reference calls AiTraceProbe; null: nothing ever is (every fixture before round 6).
+   * cam_to_world: AiCameraToWorldMatrix -- given, or the inverse of world_to_camera (of each motion key) in fp64. */
+  lentil_probe_fn probe = nullptr;
+  void *probe_user = nullptr;
+  bool have_c2w = false;
+  float cam_to_world[4][4];
+  std::vector<float> c2w_keys;
 };
 
 /* the counters / draw log / current visit of whoever runs do_visit: the frame's own, or the worker thread's */
@@ -915,6 +998,33 @@ ORC_API uint64_t orc_frame_log(const OrcFrame *F, lentil_draw_record *out, uint6
 ORC_API void orc_frame_set_camera_motion(OrcFrame *F, uint32_t n_keys, const float *world_to_camera) {
   F->n_cam_keys = n_keys >= 2 ? n_keys : 0;
   F->cam_keys.assign(world_to_camera, world_to_camera + (size_t)F->n_cam_keys * 16);
+}
+
+/* the occlusion probe (OrcFrame::probe): fn null switches it off; camera_to_world 16 floats (n_keys > 1: one matrix per motion key,
+ * as many as orc_frame_set_camera_motion got) or null for the inverses of the world-to-camera matrices */
+ORC_API void orc_frame_set_probe(OrcFrame *F, lentil_probe_fn fn, void *user, const float *camera_to_world, uint32_t n_keys) {
+  F->probe = fn;
+  F->probe_user = user;
+  F->have_c2w = false;
+  F->c2w_keys.clear();
+  if (camera_to_world && n_keys <= 1) { memcpy(F->cam_to_world, camera_to_world, sizeof F->cam_to_world); F->have_c2w = true; }
+  else if (camera_to_world) F->c2w_keys.assign(camera_to_world, camera_to_world + (size_t)n_keys * 16);
+}
+
+/* An analytic occluder for the tests (a lentil_probe_fn): user -> {cx, cy, cz, r} floats; a segment is occluded when it passes
+ * through the sphere.  Plain fp32-in, fp64 arithmetic: the same answers whoever calls it, any number of threads. */
+ORC_API void orc_sphere_occluder(void *user, uint64_t n, const lentil_probe_segment *seg, uint8_t *occluded) {
+  const float *sp = static_cast<const float *>(user);
+  for (uint64_t i = 0; i < n; i++) {
+    const double o[3] = {seg[i].origin[0], seg[i].origin[1], seg[i].origin[2]};
+    const double d[3] = {seg[i].target[0] - o[0], seg[i].target[1] - o[1], seg[i].target[2] - o[2]};
+    const double c[3] = {sp[0] - o[0], sp[1] - o[1], sp[2] - o[2]};
+    const double dd = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
+    double t = dd > 0.0 ? (c[0] * d[0] + c[1] * d[1] + c[2] * d[2]) / dd : 0.0;
+    t = t < 0.0 ? 0.0 : (t > 1.0 ? 1.0 : t);
+    const double q[3] = {c[0] - t * d[0], c[1] - t * d[1], c[2] - t * d[2]};
+    occluded[i] = (q[0] * q[0] + q[1] * q[1] + q[2] * q[2]) < (double)sp[3] * (double)sp[3] ? 1 : 0;
+  }
 }
 
 ORC_API void orc_frame_set_camera_shutter(OrcFrame *F, float shutter_start, float shutter_end) {
@@ -1167,14 +1277,17 @@ static void do_visit(const lentil_params *P, const OrcLens *L, const OrcBokeh *B
   const float *raydir = &V->raydir_time[v * 4];
   const bool small = std::abs(sample_pos_ws[0]) < AI_EPSILON_F && std::abs(sample_pos_ws[1]) < AI_EPSILON_F &&
                      std::abs(sample_pos_ws[2]) < AI_EPSILON_F;      /* AiV3IsSmall */
+  bool sample_is_from_skydome = false;                                 /* :119: exempt from the occlusion probe */
   if ((depth == AI_INFINITE_F || small) && P->enable_skydome) {       /* :122-129 */
     if (raydir[0] == 0 && raydir[1] == 0 && raydir[2] == 0) redistribute = false;
     else for (int i = 0; i < 3; i++) sample_pos_ws[i] = raydir[i] * (float)99999999.0;  /* AtVector * float */
+    sample_is_from_skydome = true;
   }
-  if ((depth == AI_INFINITE_F || small) && !P->enable_skydome) redistribute = false;   /* :130-133 */
+  if ((depth == AI_INFINITE_F || small) && !P->enable_skydome) { redistribute = false; sample_is_from_skydome = true; }   /* :130-133 */
   if (maxrgb(&V->volume_ignore[v * 4]) > 0.0) redistribute = false;                 /* :135-137 */
 
   float cs[3];
+  float c2w[4][4];                                                                  /* :142, AiCameraToWorldMatrix at the sample's time */
   if (F->n_cam_keys >= 2) {                                                         /* :141-143, per-sample camera time */
     float t = (V->raydir_time[v * 4 + 3] - F->cam_t0) * F->cam_inv_dt;
     t = t < 0.0f ? 0.0f : (t > 1.0f ? 1.0f : t);
@@ -1186,9 +1299,25 @@ static void do_visit(const lentil_params *P, const OrcLens *L, const OrcBokeh *B
     float m[4][4];
     for (int r = 0; r < 4; r++) for (int c = 0; c < 4; c++) m[r][c] = ((kb[r * 4 + c] - ka[r * 4 + c]) * f) + ka[r * 4 + c];
     m4_point(m, sample_pos_ws, cs);
+    if (F->probe && F->c2w_keys.size() == (size_t)F->n_cam_keys * 16) {
+      const float *ia = &F->c2w_keys[(size_t)i0 * 16], *ib = ia + 16;
+      for (int r = 0; r < 4; r++) for (int c = 0; c < 4; c++) c2w[r][c] = ((ib[r * 4 + c] - ia[r * 4 + c]) * f) + ia[r * 4 + c];
+    } else if (F->probe) {
+      /* no camera-to-world keys given: the inverse of each world-to-camera key, blended like the keys themselves (what the HIP
+       * library does with the keys it inverts on the host) */
+      float ia[16], ib[16];
+      invert4x4(ka, ia); invert4x4(kb, ib);
+      for (int r = 0; r < 4; r++) for (int c = 0; c < 4; c++) c2w[r][c] = ((ib[r * 4 + c] - ia[r * 4 + c]) * f) + ia[r * 4 + c];
+    }
   } else {
     m4_point(P->world_to_camera, sample_pos_ws, cs);                                /* :144 */
+    if (F->probe) {
+      if (F->have_c2w) memcpy(c2w, F->cam_to_world, sizeof c2w);
+      else invert4x4(&P->world_to_camera[0][0], &c2w[0][0]);
+    }
   }
+  OrcProbeCtx probe_ctx{F->probe, F->probe_user, c2w, sample_pos_ws, sample_is_from_skydome, P->unitModel};
+  const OrcProbeCtx *pc = F->probe ? &probe_ctx : nullptr;
   switch (P->unitModel) {                                                           /* :145-150 */
     /* AtVector::operator*=(float): the double literals narrow to float at the call */
     case LENTIL_UNIT_MM: for (int i = 0; i < 3; i++) cs[i] *= 0.1f; break;
@@ -1262,8 +1391,8 @@ static void do_visit(const lentil_params *P, const OrcLens *L, const OrcBokeh *B
             lambda_per_sample = lerpf(P->abb_chromatic, 0.55, 0.85);
           }
         } else if (P->abb_chromatic == 0.0 && channel > -1) continue;
-        if (!orc_trace_ray_bw_po(P, L, B, target, sensor_position, px, py, (int)total_samples_taken,
-                                 lambda_per_sample, nullptr)) { --count; continue; }
+        if (!trace_ray_bw_po_probed(P, L, B, target, sensor_position, px, py, (int)total_samples_taken,
+                                    lambda_per_sample, nullptr, pc)) { --count; continue; }
         const double s0 = sensor_position[0] / (P->sensor_width * 0.5);                                 /* :276 */
         const double s1 = sensor_position[1] / (P->sensor_width * 0.5) * frame_aspect_ratio_without_region;
         const double pixel0 = (((s0 + 1.0) / 2.0) * P->xres_without_region) - P->region_min_x;          /* :277-278 */
@@ -1333,7 +1462,8 @@ static void do_visit(const lentil_params *P, const OrcLens *L, const OrcBokeh *B
     float tmp[3] = {samplepos_image_point[0] - lens[0], samplepos_image_point[1] - lens[1], samplepos_image_point[2] - lens[2]};
     float dir_from_lens_to_image_sample[3];
     v3norm(tmp, dir_from_lens_to_image_sample);                                             /* :344 */
-    /* probe == false (:356-375) */
+    /* raytrace for scene/geometrical occlusions along the ray, :356-375 (no probe set: AiTraceProbe == false) */
+    if (pc && probe_occluded(pc, lens)) { --count; continue; }
     if (P->optical_vignetting_distance > 0.0) {                                             /* :379-386, lens.h:529-543 */
       float t2[3] = {perturbed[0] - lens[0], perturbed[1] - lens[1], perturbed[2] - lens[2]};
       v3norm(t2, dir_lens_to_P);

@@ -23,7 +23,7 @@ EXPORTS = [
     "lentil_hip_touched_rows", "lentil_hip_merge_rows", "lentil_hip_resolve_rows",
     "lentil_hip_pack_rows", "lentil_hip_merge_packed_rows", "lentil_hip_compact_rows", "lentil_hip_merge_sparse",
     "lentil_hip_get_counters", "lentil_hip_last_timing", "lentil_hip_last_launches", "lentil_hip_set_draw_log",
-    "lentil_hip_batch_model_stats", "lentil_hip_process_stats", "lentil_hip_process_stall_notes", "lentil_hip_set_async", "lentil_hip_pass_totals", "lentil_hip_debug_batch_estimate", "lentil_hip_box_probe",
+    "lentil_hip_batch_model_stats", "lentil_hip_process_stats", "lentil_hip_process_stall_notes", "lentil_hip_set_async", "lentil_hip_pass_totals", "lentil_hip_set_occlusion_probe", "lentil_hip_probe_stats", "lentil_hip_debug_batch_estimate", "lentil_hip_box_probe",
     "lentil_hip_lens_jit_status", "lentil_hip_lens_jit_wait", "lentil_hip_debug_lens_jit_source", "lentil_hip_debug_lens_jit_compile",
     "lentil_hip_download_draw_log", "lentil_hip_test_lt_sample_aperture",
     "lentil_hip_test_trace_bw_po", "lentil_hip_test_aperture_sample", "lentil_hip_debug_scan_bands",
@@ -124,6 +124,8 @@ def load_library():
         "lentil_hip_process_stats": (i, [C.POINTER(C.c_uint64)]),
         "lentil_hip_process_stall_notes": (i, [C.c_char_p, C.c_uint64]),
         "lentil_hip_set_async": (i, [vp, i]),
+        "lentil_hip_set_occlusion_probe": (i, [vp, vp, vp, vp]),
+        "lentil_hip_probe_stats": (i, [vp, C.POINTER(C.c_uint64)]),
         "lentil_hip_pass_totals": (i, [vp, C.POINTER(_abi.PassTotals), i]),
         "lentil_hip_box_probe": (i, [vp, C.POINTER(C.c_double)]),
         "lentil_hip_lens_jit_status": (i, [vp, C.POINTER(C.c_int), C.POINTER(C.c_double)]),
@@ -507,6 +509,18 @@ class Context:
         c = _abi.Counters()
         self._chk(self.lib.lentil_hip_get_counters(self.h, C.byref(c)))
         return c
+
+    def set_occlusion_probe(self, fn, user=None, camera_to_world=None):
+        """fn: address of a lentil_probe_fn (C function; None switches probing off); user: address handed back to it;
+        camera_to_world: [4, 4] fp32 (row-vector convention) or None for the inverse of the world-to-camera matrix"""
+        self._probe_keep = (np.ascontiguousarray(camera_to_world, np.float32) if camera_to_world is not None else None)
+        self._chk(self.lib.lentil_hip_set_occlusion_probe(self.h, fn, user, self._probe_keep.ctypes.data if self._probe_keep is not None else None))
+
+    def probe_stats(self):
+        """(segments probed, of them occluded, callback calls) since the context was created"""
+        n = (C.c_uint64 * 3)()
+        self._chk(self.lib.lentil_hip_probe_stats(self.h, n))
+        return tuple(int(x) for x in n)
 
     def set_async(self, on):
         """the asynchronous end of a pass (include/lentil_hip.h): off = every redistribute waits for its own end"""

@@ -338,6 +338,20 @@ struct lentil_hip_ctx {
   bool holds_turn = false;            // this context owns g_stream_owner[device]
   lentil_pass_totals totals{};
   std::vector<std::string> notes;     // redo notes since the totals were last reset (at most 8 kept)
+  // occlusion probes (lentil_hip_set_occlusion_probe): the renderer's callback, AiCameraToWorldMatrix (given, or the fp64 inverse of the
+  // world-to-camera matrix / of every motion key), the list buffers (device, and pinned host copies the callback reads and fills)
+  lentil_probe_fn probe_fn = nullptr;
+  void *probe_user = nullptr;
+  bool probe_c2w_given = false;
+  float probe_c2w[16];
+  std::vector<float> h_cam_keys;              // lentil_hip_set_camera_motion's keys, kept for their inverses
+  float *d_c2w_keys = nullptr;
+  lentil_probe_segment *d_probe_seg = nullptr, *h_probe_seg = nullptr;
+  uint32_t *d_probe_idx = nullptr;
+  uint8_t *d_probe_occ = nullptr, *h_probe_occ = nullptr;
+  unsigned int *d_probe_count = nullptr;
+  uint64_t probe_cap = 0;
+  uint64_t n_probes = 0, n_probes_occluded = 0, n_probe_calls = 0;     // since the context was created (lentil_hip_probe_stats)
   struct LentilUpload *upload = nullptr;   // lentil_upload.h: the visit stream handed over piece by piece
   struct LentilComm *comm = nullptr; // lentil_comm.h: this context's RCCL communicator, if one was asked for
   struct LentilCrypto *crypto = nullptr;   // lentil_crypto.h: cryptomatte AOVs, if any were allocated
@@ -406,6 +420,7 @@ static int fail(lentil_hip_ctx *ctx, int code, const std::string &msg) {
       return fail(ctx, LENTIL_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_));   \
   } while (0)
 static int settle(lentil_hip_ctx *ctx);
+static int probe_round(lentil_hip_ctx *ctx, const DrawArgs &da, hipStream_t st);
 static int join_clear(lentil_hip_ctx *ctx);
 static void harvest_ready(lentil_hip_ctx *ctx);
 static int resolve_range(lentil_hip_ctx *ctx, uint64_t p_begin, uint64_t p_end);
@@ -802,6 +817,10 @@ LENTIL_API int lentil_hip_destroy(lentil_hip_ctx *ctx) {
   (void)hipFree(ctx->d_ctr);
   (void)hipFree(ctx->d_ranges);
   (void)hipFree(ctx->d_ready);
+  (void)hipFree(ctx->d_c2w_keys); (void)hipFree(ctx->d_probe_seg); (void)hipFree(ctx->d_probe_idx); (void)hipFree(ctx->d_probe_occ);
+  (void)hipFree(ctx->d_probe_count);
+  if (ctx->h_probe_seg) (void)hipHostFree(ctx->h_probe_seg);
+  if (ctx->h_probe_occ) (void)hipHostFree(ctx->h_probe_occ);
   (void)hipFree(ctx->d_live);
   if (ctx->jit_module) (void)hipModuleUnload(ctx->jit_module);
   (void)hipFree(ctx->d_bm_land); (void)hipFree(ctx->d_bm_box); (void)hipFree(ctx->d_bm_npass);
@@ -1220,8 +1239,120 @@ LENTIL_API int lentil_hip_set_camera_motion(lentil_hip_ctx *ctx, uint32_t n_keys
     if (!ctx->d_cam_keys) HIP_TRY(ctx, hipMalloc(&ctx->d_cam_keys, sizeof(float) * 16 * LENTIL_MAX_MOTION_KEYS));
     HIP_TRY(ctx, hipMemcpy(ctx->d_cam_keys, w2c, sizeof(float) * 16 * n_keys, hipMemcpyHostToDevice));
     ctx->n_cam_keys = n_keys;
+    ctx->h_cam_keys.assign(w2c, w2c + (size_t)16 * n_keys);       // (the occlusion probe's camera-to-world keys are their inverses)
   }
   apply_camera_motion(ctx);
+  return LENTIL_OK;
+}
+
+// ---- occlusion probes (include/lentil_hip.h; kernels: probe_list_kernel / probe_apply_kernel) ---------------------------------
+// the inverse of a 4x4 matrix by cofactors in fp64, rounded to float at the end: AiCameraToWorldMatrix where the caller gives none
+// (the oracle computes the same: oracle/lentil_oracle.cpp, invert4x4)
+static void invert4x4(const float m_[16], float out[16]) {
+  double m[16], inv[16];
+  for (int i = 0; i < 16; i++) m[i] = m_[i];
+  inv[0] = m[5] * m[10] * m[15] - m[5] * m[11] * m[14] - m[9] * m[6] * m[15] + m[9] * m[7] * m[14] + m[13] * m[6] * m[11] - m[13] * m[7] * m[10];
+  inv[4] = -m[4] * m[10] * m[15] + m[4] * m[11] * m[14] + m[8] * m[6] * m[15] - m[8] * m[7] * m[14] - m[12] * m[6] * m[11] + m[12] * m[7] * m[10];
+  inv[8] = m[4] * m[9] * m[15] - m[4] * m[11] * m[13] - m[8] * m[5] * m[15] + m[8] * m[7] * m[13] + m[12] * m[5] * m[11] - m[12] * m[7] * m[9];
+  inv[12] = -m[4] * m[9] * m[14] + m[4] * m[10] * m[13] + m[8] * m[5] * m[14] - m[8] * m[6] * m[13] - m[12] * m[5] * m[10] + m[12] * m[6] * m[9];
+  inv[1] = -m[1] * m[10] * m[15] + m[1] * m[11] * m[14] + m[9] * m[2] * m[15] - m[9] * m[3] * m[14] - m[13] * m[2] * m[11] + m[13] * m[3] * m[10];
+  inv[5] = m[0] * m[10] * m[15] - m[0] * m[11] * m[14] - m[8] * m[2] * m[15] + m[8] * m[3] * m[14] + m[12] * m[2] * m[11] - m[12] * m[3] * m[10];
+  inv[9] = -m[0] * m[9] * m[15] + m[0] * m[11] * m[13] + m[8] * m[1] * m[15] - m[8] * m[3] * m[13] - m[12] * m[1] * m[11] + m[12] * m[3] * m[9];
+  inv[13] = m[0] * m[9] * m[14] - m[0] * m[10] * m[13] - m[8] * m[1] * m[14] + m[8] * m[2] * m[13] + m[12] * m[1] * m[10] - m[12] * m[2] * m[9];
+  inv[2] = m[1] * m[6] * m[15] - m[1] * m[7] * m[14] - m[5] * m[2] * m[15] + m[5] * m[3] * m[14] + m[13] * m[2] * m[7] - m[13] * m[3] * m[6];
+  inv[6] = -m[0] * m[6] * m[15] + m[0] * m[7] * m[14] + m[4] * m[2] * m[15] - m[4] * m[3] * m[14] - m[12] * m[2] * m[7] + m[12] * m[3] * m[6];
+  inv[10] = m[0] * m[5] * m[15] - m[0] * m[7] * m[13] - m[4] * m[1] * m[15] + m[4] * m[3] * m[13] + m[12] * m[1] * m[7] - m[12] * m[3] * m[5];
+  inv[14] = -m[0] * m[5] * m[14] + m[0] * m[6] * m[13] + m[4] * m[1] * m[14] - m[4] * m[2] * m[13] - m[12] * m[1] * m[6] + m[12] * m[2] * m[5];
+  inv[3] = -m[1] * m[6] * m[11] + m[1] * m[7] * m[10] + m[5] * m[2] * m[11] - m[5] * m[3] * m[10] - m[9] * m[2] * m[7] + m[9] * m[3] * m[6];
+  inv[7] = m[0] * m[6] * m[11] - m[0] * m[7] * m[10] - m[4] * m[2] * m[11] + m[4] * m[3] * m[10] + m[8] * m[2] * m[7] - m[8] * m[3] * m[6];
+  inv[11] = -m[0] * m[5] * m[11] + m[0] * m[7] * m[9] + m[4] * m[1] * m[11] - m[4] * m[3] * m[9] - m[8] * m[1] * m[7] + m[8] * m[3] * m[5];
+  inv[15] = m[0] * m[5] * m[10] - m[0] * m[6] * m[9] - m[4] * m[1] * m[10] + m[4] * m[2] * m[9] + m[8] * m[1] * m[6] - m[8] * m[2] * m[5];
+  double det = m[0] * inv[0] + m[1] * inv[4] + m[2] * inv[8] + m[3] * inv[12];
+  det = det != 0.0 ? 1.0 / det : 0.0;
+  for (int i = 0; i < 16; i++) out[i] = (float)(inv[i] * det);
+}
+
+LENTIL_API int lentil_hip_set_occlusion_probe(lentil_hip_ctx *ctx, lentil_probe_fn fn, void *user, const float *camera_to_world) {
+  CHECK_CTX(ctx);
+  ctx->probe_fn = fn;
+  ctx->probe_user = user;
+  ctx->probe_c2w_given = fn != nullptr && camera_to_world != nullptr;
+  if (ctx->probe_c2w_given) memcpy(ctx->probe_c2w, camera_to_world, sizeof ctx->probe_c2w);
+  return LENTIL_OK;
+}
+
+LENTIL_API int lentil_hip_probe_stats(lentil_hip_ctx *ctx, uint64_t stats[3]) {
+  CHECK_CTX(ctx);
+  if (!stats) return fail(ctx, LENTIL_ERR_INVALID, "stats is null");
+  stats[0] = ctx->n_probes; stats[1] = ctx->n_probes_occluded; stats[2] = ctx->n_probe_calls;
+  return LENTIL_OK;
+}
+
+// One round's probes, between its solves (and stragglers) and its accept, on the round's stream: list, callback, apply.  The
+// host waits twice -- for the list and, inside the callback, for the renderer.
+static int probe_round(lentil_hip_ctx *ctx, const DrawArgs &da, hipStream_t st) {
+  if (!ctx->probe_fn) return LENTIL_OK;
+  ProbeArgs pr{};
+  if (ctx->probe_c2w_given) memcpy(pr.c2w, ctx->probe_c2w, sizeof pr.c2w);
+  else invert4x4(&ctx->P.world_to_camera[0][0], &pr.c2w[0][0]);
+  if (ctx->n_cam_keys >= 2 && ctx->h_cam_keys.size() == (size_t)16 * ctx->n_cam_keys) {
+    float inv[16 * LENTIL_MAX_MOTION_KEYS];
+    for (uint32_t k = 0; k < ctx->n_cam_keys; ++k) invert4x4(&ctx->h_cam_keys[(size_t)16 * k], inv + 16 * k);
+    if (!ctx->d_c2w_keys) HIP_TRY(ctx, hipMalloc(&ctx->d_c2w_keys, sizeof(float) * 16 * LENTIL_MAX_MOTION_KEYS));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_c2w_keys, inv, sizeof(float) * 16 * ctx->n_cam_keys, hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));       // (`inv` is on this function's stack)
+    pr.c2w_keys = ctx->d_c2w_keys;
+  }
+  if (!ctx->d_probe_count) HIP_TRY(ctx, hipMalloc(&ctx->d_probe_count, sizeof(unsigned int)));
+  const dim3 grid((unsigned)ctx->num_cu * 4u), block(256);
+  for (int attempt = 0; attempt < 2; ++attempt) {
+    if (ctx->probe_cap == 0) {
+      const uint64_t cap = 1ull << 20;
+      HIP_TRY(ctx, hipMalloc(&ctx->d_probe_seg, cap * sizeof(lentil_probe_segment)));
+      HIP_TRY(ctx, hipMalloc(&ctx->d_probe_idx, cap * sizeof(uint32_t)));
+      HIP_TRY(ctx, hipMalloc(&ctx->d_probe_occ, cap));
+      HIP_TRY(ctx, hipHostMalloc((void **)&ctx->h_probe_seg, cap * sizeof(lentil_probe_segment), hipHostMallocDefault));
+      HIP_TRY(ctx, hipHostMalloc((void **)&ctx->h_probe_occ, cap, hipHostMallocDefault));
+      ctx->probe_cap = cap;
+    }
+    pr.seg = ctx->d_probe_seg; pr.idx = ctx->d_probe_idx; pr.cap = (uint32_t)(ctx->probe_cap < 0xFFFFFFF0ull ? ctx->probe_cap : 0xFFFFFFF0ull);
+    pr.count = ctx->d_probe_count; pr.occluded = ctx->d_probe_occ;
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_probe_count, 0, sizeof(unsigned int), st));
+    hipLaunchKernelGGL(probe_list_kernel, grid, block, 0, st, da, pr);
+    HIP_TRY(ctx, hipGetLastError());
+    unsigned int n = 0;
+    HIP_TRY(ctx, hipMemcpyAsync(&n, ctx->d_probe_count, sizeof n, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    if ((uint64_t)n > ctx->probe_cap) {
+      // the list did not fit: buffers for what the kernel counted, and once more
+      if (attempt) return fail(ctx, LENTIL_ERR_NOMEM, "occlusion probes: the list outgrew its buffers twice");
+      (void)hipFree(ctx->d_probe_seg); (void)hipFree(ctx->d_probe_idx); (void)hipFree(ctx->d_probe_occ);
+      (void)hipHostFree(ctx->h_probe_seg); (void)hipHostFree(ctx->h_probe_occ);
+      ctx->d_probe_seg = nullptr; ctx->d_probe_idx = nullptr; ctx->d_probe_occ = nullptr; ctx->h_probe_seg = nullptr; ctx->h_probe_occ = nullptr;
+      const uint64_t cap = (uint64_t)n + (uint64_t)n / 4 + 4096;
+      HIP_TRY(ctx, hipMalloc(&ctx->d_probe_seg, cap * sizeof(lentil_probe_segment)));
+      HIP_TRY(ctx, hipMalloc(&ctx->d_probe_idx, cap * sizeof(uint32_t)));
+      HIP_TRY(ctx, hipMalloc(&ctx->d_probe_occ, cap));
+      HIP_TRY(ctx, hipHostMalloc((void **)&ctx->h_probe_seg, cap * sizeof(lentil_probe_segment), hipHostMallocDefault));
+      HIP_TRY(ctx, hipHostMalloc((void **)&ctx->h_probe_occ, cap, hipHostMallocDefault));
+      ctx->probe_cap = cap;
+      continue;
+    }
+    if (n == 0) return LENTIL_OK;
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_probe_seg, ctx->d_probe_seg, (size_t)n * sizeof(lentil_probe_segment), hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    memset(ctx->h_probe_occ, 0, n);
+    ctx->probe_fn(ctx->probe_user, n, ctx->h_probe_seg, ctx->h_probe_occ);
+    uint64_t occ = 0;
+    for (unsigned int i = 0; i < n; ++i) occ += ctx->h_probe_occ[i] ? 1u : 0u;
+    ctx->n_probes += n; ctx->n_probes_occluded += occ; ++ctx->n_probe_calls;
+    if (occ) {
+      HIP_TRY(ctx, hipMemcpyAsync(ctx->d_probe_occ, ctx->h_probe_occ, n, hipMemcpyHostToDevice, st));
+      hipLaunchKernelGGL(probe_apply_kernel, grid, block, 0, st, da, pr, (uint32_t)n);
+      HIP_TRY(ctx, hipGetLastError());
+    }
+    return LENTIL_OK;
+  }
   return LENTIL_OK;
 }
 
@@ -1597,6 +1728,7 @@ static int finish_rounds(lentil_hip_ctx *ctx, int ci, DrawArgs &da, int first_ro
     if (n_act == 0) break;
     da.parity = round & 1; da.round = round;
     launch_solve(ctx, da, ch.stream, 256);
+    { const int rcp = probe_round(ctx, da, ch.stream); if (rcp) return rcp; }
     hipLaunchKernelGGL(accept_kernel<0>, dim3(n_act < 512u ? n_act : 512u), dim3(256), 0, ch.stream, da);
     HIP_TRY(ctx, hipGetLastError());
   }
@@ -1656,6 +1788,7 @@ static int launch_chunk_rounds(lentil_hip_ctx *ctx, int ci, DrawArgs &da, uint64
     // full grid it reaches the CUs first and the solve kernel's blocks are placed around it -- the slow start that
     // costs that kernel 10 % for its whole life (see above).  A quarter block per CU trickles along beside the solve
     // instead and is done before it (heavy regime: 119.2 -> 114.5 ms per frame).
+    { const int rcp = probe_round(ctx, da, ch.stream); if (rcp) return rcp; }      // (occlusion probes: the host answers between the solves and the accept)
     unsigned ab = accept_blocks;
     if (round == 0 && heavy && ci + 1 < ctx->n_chunks) {
       const unsigned lim = (unsigned)ctx->num_cu / 4u > 0u ? (unsigned)ctx->num_cu / 4u : 1u;
@@ -1764,6 +1897,7 @@ static int enqueue_chunk_draws(lentil_hip_ctx *ctx, int ci, DrawArgs &da, int bl
     hipLaunchKernelGGL(prep_items_kernel, dim3((unsigned)((ni + 255) / 256)), dim3(256), 0, ch.stream, da);
     launch_solve(ctx, da, ch.stream, (unsigned)max_blocks);
     if (i0 == 0) HIP_TRY(ctx, hipStreamWaitEvent(ch.stream, ctx->scans_done, 0));   // see launch_chunk_rounds
+    if ((rc = probe_round(ctx, da, ch.stream))) return rc;
     hipLaunchKernelGGL(accept_kernel<0>, dim3((unsigned)ctx->num_cu * 2), dim3(256), 0, ch.stream, da);
     HIP_TRY(ctx, hipGetLastError());
     int rounds = 0;
@@ -2425,6 +2559,7 @@ static int redistribute_streamed(lentil_hip_ctx *ctx, bool *streamed, bool *defe
   if (!ctx->stream_mode || P.cameraType != LENTIL_POLYNOMIAL_OPTICS || !ctx->have_total_est || ctx->V.n == 0)
     return LENTIL_OK;
   if (ctx->V.n > 0xFFFFFFF0ull) return LENTIL_OK;
+  if (ctx->probe_fn) return LENTIL_OK;       // (occlusion probes: the host answers between a round's solves and its accept -- the round-by-round form)
   // Only into a frame that has been cleared since its last pass (every caller's order: clear, redistribute, resolve): a
   // streamed pass whose waves give up waiting after draws have been accepted is recovered by wiping the frame and running
   // the pass again, which must not cost an earlier pass's sums.  A second pass into the same frame takes the chunked form,
@@ -3517,6 +3652,9 @@ static int redistribute_pass(lentil_hip_ctx *ctx) {
   for (uint32_t k = 1; k < ctx->F.n_aovs; ++k)
     if (ctx->V.n && !ctx->V.extra[k - 1] && !(ctx->F.debug_mask & (1u << k)))
       return fail(ctx, LENTIL_ERR_INVALID, "an extra AOV column is null");
+  if (ctx->probe_fn && P.abb_chromatic != 0.0f)
+    return fail(ctx, LENTIL_ERR_UNSUPPORTED, "occlusion probes with abb_chromatic != 0: the reference draws an attempt's colour channel behind its probe, from "
+                                             "one generator in visit order (src/lentil_filter.cpp:356-406); not built");
   if (ctx->F.debug_mask && ctx->closest_deferred && !ctx->comm)
     return fail(ctx, LENTIL_ERR_UNSUPPORTED, "the lentil_debug AOV is exchanged between GPUs by lentil_hip_allreduce / _exchange_bands only");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -3810,8 +3948,8 @@ static int resolve_range(lentil_hip_ctx *ctx, uint64_t p_begin, uint64_t p_end) 
 static int launch_resolve_half(lentil_hip_ctx *ctx, hipStream_t st, uint32_t only_touched) {
   const size_t lds = (size_t)4 * 64 * ctx->F.stride * sizeof(float);
   if (only_touched) {
-    const uint64_t chunks = ((ctx->F.np + 63) / 64 + 63) / 64;         // 64 groups of 64 pixels per wave
-    uint64_t blocks = (chunks + 3) / 4;
+    const uint64_t chunks = ((ctx->F.np + 63) / 64 + 63) / 64;         // 64 groups of 64 pixels per block, dealt round its waves
+    uint64_t blocks = chunks;
     const uint64_t max_blocks = (uint64_t)ctx->num_cu * 8;
     if (blocks > max_blocks) blocks = max_blocks;
     hipLaunchKernelGGL(resolve_touched_kernel, dim3((unsigned)blocks), dim3(256), lds, st, ctx->F, ctx->d_resolved, only_touched);

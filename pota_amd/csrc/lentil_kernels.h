@@ -4289,6 +4289,112 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LENTIL_ACCE
 }
 
 // ---------------------------------------------------------------------------------------
+// Occlusion probes (include/lentil_hip.h, lentil_hip_set_occlusion_probe; src/lentil.h:613-629, src/lentil_filter.cpp:356-375).
+// Between a round's solves and its accept: probe_list_kernel walks the round's tasks and, for every try whose result is not FAIL
+// (it got through the lens; whether it landed in the frame or not), writes the segment the reference would probe -- from the
+// sample's world position to cam_to_world * (lens point / unit) -- and where the try's result lives; the host answers a byte
+// per segment; probe_apply_kernel turns the occluded tries' results into FAIL, which is what an occluded try is to the walk
+// (polynomial optics: tries++, the attempt's next try is looked at; thin lens: the attempt is lost).  Samples the skydome
+// supplied are exempt (sample_is_from_skydome, src/lentil_filter.cpp:119-133) and never listed.
+// ---------------------------------------------------------------------------------------
+struct ProbeArgs {
+  lentil_probe_segment *seg;
+  uint32_t *idx;                 // index into the round's result pool
+  uint32_t cap;
+  unsigned int *count;
+  const uint8_t *occluded;
+  float c2w[4][4];               // AiCameraToWorldMatrix (static camera)
+  const float *c2w_keys;         // a moving camera: one per motion key, blended like the world-to-camera keys (CamMotion)
+};
+
+LD_DEV void probe_target(const lentil_params &P, const float c2w[4][4], float lx, float ly, float lz, float out[3]) {
+  float div = 1.0f;
+  if (P.unitModel == LENTIL_UNIT_MM) div = 0.1f;
+  else if (P.unitModel == LENTIL_UNIT_DM) div = 10.0f;
+  else if (P.unitModel == LENTIL_UNIT_M) div = 100.0f;
+  const float c = 1.0f / div;                  // AtVector /= float multiplies by 1.0f / f (SDK, recalled)
+  const float vx = lx * c, vy = ly * c, vz = lz * c;
+  out[0] = vx * c2w[0][0] + vy * c2w[1][0] + vz * c2w[2][0] + c2w[3][0];      // AiM4PointByMatrixMult
+  out[1] = vx * c2w[0][1] + vy * c2w[1][1] + vz * c2w[2][1] + c2w[3][1];
+  out[2] = vx * c2w[0][2] + vy * c2w[1][2] + vz * c2w[2][2] + c2w[3][2];
+}
+
+__global__ __launch_bounds__(256) void probe_list_kernel(DrawArgs a, ProbeArgs pr) {
+  const uint32_t par = (uint32_t)a.parity;
+  const uint32_t n_tasks = a.ctr->n_tasks[par] < a.task_cap ? a.ctr->n_tasks[par] : a.task_cap;
+  const uint32_t lane = threadIdx.x & 63u;
+  const unsigned long long lt_mask = (1ull << lane) - 1ull;
+  const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
+  const bool po = a.P.cameraType == LENTIL_POLYNOMIAL_OPTICS;
+  for (uint32_t q = wave; q < n_tasks; q += n_waves) {
+    const Task t = a.tasks[par][q];
+    const uint32_t cnt = t.count & 0xFFu;
+    const uint32_t code = lane < cnt ? a.pool[par][t.res_off + lane] : kCodeFail;
+    bool want = code != kCodeFail && !code_is_pending(code);
+    float org[3] = {0.f, 0.f, 0.f}, tgt[3] = {0.f, 0.f, 0.f};
+    if (__ballot(want)) {
+      const ItemHdr hd = a.hdr[t.item];
+      const uint32_t v = a.work[t.item].x;
+      const float4 pos_z = a.V.pos_z[v];
+      const float4 raydir_time = a.V.raydir_time[v];
+      const bool small = fabsf(pos_z.x) < kAiEpsilon && fabsf(pos_z.y) < kAiEpsilon && fabsf(pos_z.z) < kAiEpsilon;
+      const bool from_skydome = ((double)pos_z.w == (double)kAiInfinite) || small;      // (an item at infinity exists only with enable_skydome)
+      if (from_skydome) want = false;
+      if (want) {
+        float c2w[4][4];
+        const CamMotion &cm = a.V.cam;
+        if (cm.n >= 2u && pr.c2w_keys) {
+          float tt = (raydir_time.w - cm.t0) * cm.inv_dt;
+          tt = tt < 0.0f ? 0.0f : (tt > 1.0f ? 1.0f : tt);
+          const float sc = tt * (float)(cm.n - 1u);
+          uint32_t i0 = (uint32_t)sc;
+          if (i0 > cm.n - 2u) i0 = cm.n - 2u;
+          const float f = sc - (float)i0;
+          const float *ka = pr.c2w_keys + (size_t)i0 * 16u, *kb = ka + 16;
+          for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) c2w[r][c] = ((kb[r * 4 + c] - ka[r * 4 + c]) * f) + ka[r * 4 + c];
+        } else {
+          for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) c2w[r][c] = pr.c2w[r][c];
+        }
+        org[0] = pos_z.x; org[1] = pos_z.y; org[2] = pos_z.z;
+        const uint32_t m = t.m_base + lane;
+        if (po) {
+          double ax = 0.0, ay = 0.0;
+          po_aperture_sample(a.P, a.bokeh, a.bokeh.cdfRow, hd.seed_a, m, ax, ay);
+          probe_target(a.P, c2w, (float)(-ax * 0.1), (float)(-ay * 0.1), 0.0f, tgt);       // src/lentil.h:614
+        } else {
+          const float cs[3] = {(float)hd.tx, (float)hd.ty, (float)hd.tz};
+          TlRay ray;
+          if (thinlens_ray(a.P, a.bokeh, a.bokeh.cdfRow, cs, hd.px_py & 0xFFFF, hd.px_py >> 16, m, ray)) probe_target(a.P, c2w, ray.lx, ray.ly, 0.0f, tgt);
+          else want = false;       // (the optical vignetting test failed it: its result is not a pixel anyway)
+        }
+      }
+    }
+    const unsigned long long wmask = __ballot(want);
+    if (wmask) {
+      uint32_t base = 0;
+      if (lane == (uint32_t)__builtin_ctzll(wmask)) base = atomicAdd(pr.count, (unsigned int)__builtin_popcountll(wmask));
+      base = __shfl(base, __builtin_ctzll(wmask));
+      const uint32_t slot = base + (uint32_t)__builtin_popcountll(wmask & lt_mask);
+      if (want && slot < pr.cap) {
+        lentil_probe_segment sg;
+        sg.origin[0] = org[0]; sg.origin[1] = org[1]; sg.origin[2] = org[2];
+        sg.target[0] = tgt[0]; sg.target[1] = tgt[1]; sg.target[2] = tgt[2];
+        pr.seg[slot] = sg;
+        pr.idx[slot] = t.res_off + lane;
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void probe_apply_kernel(DrawArgs a, ProbeArgs pr, uint32_t n) {
+  uint32_t *res = a.pool[(uint32_t)a.parity];
+  const uint32_t stride = gridDim.x * blockDim.x;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+    if (pr.occluded[i]) res[pr.idx[i]] = kCodeFail;
+}
+
+// ---------------------------------------------------------------------------------------
 // Thin lens with abb_chromatic > 0 (src/lentil_filter.cpp:393-406): every attempt that survives the optical
 // vignetting test draws its colour channel from xor128 (src/global.h:22-27) -- ONE generator state for the whole
 // process upstream, so the channel of an attempt depends on how many such attempts every earlier visit made, and
@@ -4829,14 +4935,18 @@ __global__ __launch_bounds__(256) void resolve_touched_kernel(FrameDev F, float 
   const bool per_pixel = F.closest_mask == 0u && F.dir != nullptr;
   const uint64_t n_groups = (F.np + 63ull) / 64ull;
   const uint64_t n_chunks = (n_groups + 63ull) / 64ull;
-  const uint64_t wave_global = (uint64_t)blockIdx.x * (blockDim.x >> 6) + wave;
-  const uint64_t wave_stride = (uint64_t)gridDim.x * (blockDim.x >> 6);
-  for (uint64_t ch = wave_global; ch < n_chunks; ch += wave_stride) {
+  // (Round 6: a chunk of 64 flags per BLOCK, its flagged groups dealt round the block's four waves -- a wave used to walk all of
+  // a chunk's flagged groups one after the other, a load round trip each: 32 of them for a headline frame, 90 us of latency
+  // on a quarter of the waves the launch has.)
+  const uint32_t wpb = blockDim.x >> 6;
+  for (uint64_t ch = blockIdx.x; ch < n_chunks; ch += gridDim.x) {
     const uint64_t g = ch * 64ull + lane;
     unsigned long long mask = __ballot(g < n_groups && F.touched[g] >= min_flag);
+    uint32_t k = 0;
     while (mask) {
       const uint32_t b = (uint32_t)__builtin_ctzll(mask);
       mask &= mask - 1ull;
+      if ((k++ % wpb) != wave) continue;
       const uint64_t p0 = (ch * 64ull + b) * 64ull;
       const uint32_t n_pix = (uint32_t)((F.np - p0) < 64ull ? (F.np - p0) : 64ull);
       if (per_pixel) resolve_touched_group(F, resolved, tile, p0, n_pix, lane);

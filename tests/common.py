@@ -83,7 +83,7 @@ class ThreadedOracle:
     (lentil_debug, cryptomatte, thin-lens abb_chromatic > 0) fall back to one private frame per thread, merged in thread order
     -- 60 B per pixel, AOV and thread, which is what used to bound the thread count of every 4K test."""
 
-    def __init__(self, lib, p, table, visits, n_threads, n_aovs=1, kinds=None, bokeh=None, row_visits=None):
+    def __init__(self, lib, p, table, visits, n_threads, n_aovs=1, kinds=None, bokeh=None, row_visits=None, probe=None):
         import threading
         self.lib = lib
         lens = lib.orc_lens_create(C.byref(table)) if table is not None else None
@@ -92,6 +92,8 @@ class ThreadedOracle:
         rows = (n + rv - 1) // rv
         n_threads = max(1, min(n_threads, rows))
         shared = oracle_lib.Frame(lib, p, n_aovs=n_aovs, kinds=kinds, keep_log=True)
+        if probe is not None:          # (fn address, user address[, camera_to_world]): the occlusion probe, oracle_lib.Frame.set_probe
+            shared.set_probe(*probe)
         try:
             taken = rv > 0 and shared.run_threads(lens, bokeh, visits, max(n_threads, min(os.cpu_count() or 1, rows, 64)), rv)
         except Exception:
@@ -108,6 +110,9 @@ class ThreadedOracle:
         shared.close()
         bounds = [min(n, int(round(i * rows / n_threads)) * rv) for i in range(n_threads + 1)]
         self.frames = [oracle_lib.Frame(lib, p, n_aovs=n_aovs, kinds=kinds, keep_log=True) for _ in range(n_threads)]
+        if probe is not None:
+            for f in self.frames:
+                f.set_probe(*probe)
         errs = []
 
         def work(i):

@@ -34,6 +34,31 @@ def _built():
                                % (stuck - injected - stalls.tolerated, streamed, injected + stalls.tolerated, redone, capi.process_stall_notes()))
 
 
+@pytest.fixture(autouse=True)
+def _no_unasked_stall(request):
+    """A streamed pass whose waves give up waiting is redone and right, so only this makes the test that met it fail: every
+    stuck time-out the library counts during a test must be one the test asked for (LENTIL_INJECT_STALL) or said it tolerates
+    (tests/stalls.py)."""
+    if request.node.get_closest_marker("gpu") is None and request.node.get_closest_marker("gpu_soak") is None:
+        yield
+        return
+    import stalls
+    from pota_amd import capi
+    try:
+        before = capi.process_stats()
+    except Exception:          # noqa: BLE001
+        yield
+        return
+    tol0 = stalls.tolerated
+    yield
+    after = capi.process_stats()
+    unasked = (after[1] - before[1]) - (after[2] - before[2]) - (stalls.tolerated - tol0)
+    if unasked > 0:
+        stalls.tolerated += unasked          # (reported here: the session's closing assertion need not repeat it)
+        pytest.fail("%d streamed pass(es) of this test hit the stuck time-out unasked.  What the waves that gave up saw:\n%s"
+                    % (unasked, capi.process_stall_notes()))
+
+
 @pytest.fixture(scope="session")
 def orc():
     import oracle_lib

@@ -74,6 +74,7 @@ def load():
         "orc_crypto_pixel": (i, [vp, u32, u64, vp, vp, i, C.POINTER(f)]),
         "orc_frame_merge": (None, [vp, vp]),
         "orc_frame_set_camera_motion": (None, [vp, u32, vp]),
+        "orc_frame_set_probe": (None, [vp, vp, vp, vp, u32]),
         "orc_frame_set_camera_shutter": (None, [vp, C.c_float, C.c_float]),
         "orc_redistribute": (i, [C.POINTER(_abi.Params), vp, vp, vp, C.POINTER(_abi.Visits), u64, u64]),
         "orc_redistribute_threads": (i, [C.POINTER(_abi.Params), vp, vp, vp, C.POINTER(_abi.Visits), u64, u64, u32, u64]),
@@ -95,6 +96,11 @@ def load():
         fn.restype = res
         fn.argtypes = args
     return L
+
+
+def sphere_occluder(lib):
+    """address of orc_sphere_occluder, an analytic lentil_probe_fn: user -> four floats (centre, radius)"""
+    return C.cast(lib.orc_sphere_occluder, C.c_void_p).value
 
 
 def darr(*vals):
@@ -169,6 +175,12 @@ class Frame:
         hp = (C.c_void_p * n)(*[h.ctypes.data for h in self._crypto_keep[0]])
         wp = (C.c_void_p * n)(*[w.ctypes.data for w in self._crypto_keep[1]])
         self.lib.orc_frame_set_crypto(self.h, n, self._crypto_keep[0][0].shape[1], C.cast(hp, C.c_void_p), C.cast(wp, C.c_void_p))
+
+    def set_probe(self, fn, user=None, camera_to_world=None):
+        """the occlusion probe (include/lentil_hip.h: lentil_probe_fn) as the address of a C function, e.g. sphere_occluder()"""
+        self._probe_keep = np.ascontiguousarray(camera_to_world, np.float32) if camera_to_world is not None else None
+        n = 0 if self._probe_keep is None else (1 if self._probe_keep.ndim == 2 else self._probe_keep.shape[0])
+        self.lib.orc_frame_set_probe(self.h, fn, user, self._probe_keep.ctypes.data if self._probe_keep is not None else None, n)
 
     def set_camera_shutter(self, start, end):
         self.lib.orc_frame_set_camera_shutter(self.h, float(start), float(end))
