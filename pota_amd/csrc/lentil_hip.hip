@@ -152,6 +152,7 @@ struct lentil_hip_ctx {
   int slow_max_lanes = 4;                    // LENTIL_SLOW_MAX_LANES
   int slow_prio = 0;                         // LENTIL_SLOW_PRIO: instruction priority of the straggler kernel's waves (0-3)
   int slow_waves_per_cu = 0;                 // LENTIL_SLOW_WAVES_PER_CU: straggler waves per CU of a streamed pass (0: one)
+  int slow_nap_max = 0;                      // LENTIL_SLOW_NAP_MAX: DrawArgs::slow_nap_max
   bool blind = true;                         // LENTIL_BLIND=0: always wait for a chunk's scan before sizing its draw rounds
   uint32_t extra_num = 0, extra_const = 16;  // LENTIL_EXTRA_256THS / LENTIL_EXTRA_CONST: first-batch over-provisioning (16 spare attempts: what a decoupled first accept's guess about its unknown attempts may be off by, accept_item<1>)
   uint64_t extra_below = 8ull << 20;         // LENTIL_EXTRA_BELOW: ... while a chunk's draw sum is below this
@@ -650,6 +651,7 @@ LENTIL_API int lentil_hip_create(int device, lentil_hip_ctx **out_ctx) {
   if (const char *e = getenv("LENTIL_SLOW_MAX_LANES")) ctx->slow_max_lanes = atoi(e);
   if (const char *e = getenv("LENTIL_SLOW_PRIO")) ctx->slow_prio = atoi(e);
   if (const char *e = getenv("LENTIL_SLOW_WAVES_PER_CU")) ctx->slow_waves_per_cu = atoi(e);
+  if (const char *e = getenv("LENTIL_SLOW_NAP_MAX")) ctx->slow_nap_max = atoi(e);
   if (const char *e = getenv("LENTIL_BLIND")) ctx->blind = !(e[0] == '0');
   if (const char *e = getenv("LENTIL_EXTRA_256THS")) ctx->extra_num = (uint32_t)strtoul(e, nullptr, 10);
   if (const char *e = getenv("LENTIL_EXTRA_CONST")) ctx->extra_const = (uint32_t)strtoul(e, nullptr, 10);
@@ -1946,6 +1948,7 @@ static void init_draw_args(lentil_hip_ctx *ctx, DrawArgs &da) {
   da.slow_from_round = ctx->slow_from_round;
   da.slow_max_lanes = ctx->slow_max_lanes;
   da.slow_prio = ctx->slow_prio;
+  da.slow_nap_max = ctx->slow_nap_max;
   { const char *e = getenv("LENTIL_DISPATCH_PROBE"); da.dispatch_probe = (e && e[0] == '1') ? 1 : 0; }
   da.extra_num = ctx->extra_num; da.extra_const = ctx->extra_const; da.extra_below = ctx->extra_below;
   da.log = ctx->d_log;

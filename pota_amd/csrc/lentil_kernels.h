@@ -2130,6 +2130,7 @@ struct DrawArgs {
   uint32_t slow_cap;
   int32_t slow_at;         // Newton iterations after which a solve counts as a straggler
   int32_t slow_max_lanes;  // a dry wave parks only when at most this many of its lanes are still busy
+  int32_t slow_nap_max;    // an idle straggler wave sleeps 1.7 us x 1, 2, 4 ... up to this many between polls of its queue slot (0: 8)
   int32_t slow_prio;       // s_setprio of the straggler kernel's waves (their chains of iterations end the pass; LENTIL_SLOW_PRIO)
   int32_t dispatch_probe;  // LENTIL_DISPATCH_PROBE: DevCounters::probe_*
   int32_t round;           // solve/accept round of the chunk (0 = first batch)
@@ -3058,7 +3059,9 @@ __global__ __launch_bounds__(64) LENTIL_SLOW_ATTR void solve_slow_kernel(DrawArg
         if ((tag >> 32) == (slow_tag(a, 0) >> 32) && (uint32_t)tag != 0u) break;
         if (__builtin_amdgcn_s_memrealtime() - t0 > (a.stuck_ticks ? a.stuck_ticks : kStuckTicks)) { if (lane == 0) atomicCAS(&a.ctr->stuck, 0u, 3u | ((q & 0xFFFFFu) << 2) | ((uint32_t)a.round << 24)); over = true; break; }
         for (uint32_t i = 0; i < naps; ++i) __builtin_amdgcn_s_sleep(64);
-        if (naps < 8u) naps <<= 1;
+        // (every idle wave's poll is a returning atomic at the memory side: a thousand of them every few microseconds are felt
+        // by the solve kernel's own queue traffic -- DrawArgs::slow_nap_max)
+        if (naps < (a.slow_nap_max ? (uint32_t)a.slow_nap_max : 8u)) naps <<= 1;
       }
       if (over || (uint32_t)tag == (uint32_t)kSlowEnd) break;
       uint64_t wv = 0;

@@ -50,10 +50,18 @@ def make_stream(p, width, height, M, f_hi, n_extra=0, seed=0x5EED, v_end=None, *
     return visits, cols
 
 
-def run_oracle(lib, p, table, visits, n_aovs=1, bokeh=None, keep_log=True, kinds=None):
+def run_oracle(lib, p, table, visits, n_aovs=1, bokeh=None, keep_log=True, kinds=None, threads=None):
+    """The oracle over a stream, into one frame.  threads: 1 = the single-threaded walk, visit after visit (src/lentil_filter.cpp's
+    own order); None = over this machine's CPUs where the stream is a uniform one of some size and the frame has no lentil_debug
+    AOV (orc_redistribute_threads: counters, draw log and every pixel no draw reaches are the single-threaded walk's bit for
+    bit, the draws are added in visit order behind the pixels' own visits -- inside the 1e-5 bar every comparison of draws'
+    sums is made at), else single-threaded."""
     lens = lib.orc_lens_create(C.byref(table)) if table is not None else None
     fr = oracle_lib.Frame(lib, p, n_aovs=n_aovs, kinds=kinds, keep_log=keep_log)
-    fr.run(lens, bokeh, visits)
+    n_threads = threads if threads is not None else (min(os.cpu_count() or 1, 32) if int(visits.n) >= 20000 else 1)
+    rv = int(visits.pixels_per_row) * int(visits.visits_per_pixel)
+    if not (n_threads > 1 and rv > 0 and fr.run_threads(lens, bokeh, visits, n_threads, rv)):
+        fr.run(lens, bokeh, visits)
     if lens:
         lib.orc_lens_destroy(lens)
     return fr

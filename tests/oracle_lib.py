@@ -133,6 +133,14 @@ class Frame:
             raise RuntimeError("oracle redistribute (threads) rc=%d" % rc)
         return True
 
+    def run_auto(self, lens, bokeh, visits):
+        """run_threads over this machine's CPUs where that form takes the stream (a uniform one), else run: for tests whose
+        comparisons of draws' sums are made at the 1e-5 bar anyway (counters, draw log, untouched pixels: identical either way)"""
+        rv = int(visits.pixels_per_row) * int(visits.visits_per_pixel)
+        n = min(os.cpu_count() or 1, 32)
+        if not (n > 1 and rv > 0 and int(visits.n) >= 20000 and self.run_threads(lens, bokeh, visits, n, rv)):
+            self.run(lens, bokeh, visits)
+
     def buffer(self, aov=0):
         return np.ctypeslib.as_array(self.lib.orc_frame_buffer(self.h, aov), (self.np, 4)).copy()
 

@@ -315,7 +315,7 @@ def test_closest_filter_aovs(orc, gpu_ctx_factory, ragged):
         visits, keepv = capi.make_visits(cols, visits_per_pixel=0)
     lens = orc.orc_lens_create(C.byref(table))
     ref = oracle_lib.Frame(orc, p, n_aovs=4, kinds=kinds, keep_log=True)
-    ref.run(lens, None, visits)
+    ref.run_auto(lens, None, visits)
     orc.orc_lens_destroy(lens)
     ctx = gpu_ctx_factory()
     gpu_run(ctx, p, table, visits, n_aovs=4, kinds=kinds)
@@ -650,7 +650,7 @@ def test_po_chromatic_aberration(orc, gpu_ctx_factory, chroma, lens_mode, overri
     visits, cols = common.make_stream(p, W, H, M, f_hi=0.03, n_extra=2)
     lens = orc.orc_lens_create(C.byref(table))
     ref = oracle_lib.Frame(orc, p, n_aovs=3, kinds=kinds, keep_log=True)
-    ref.run(lens, None, visits)
+    ref.run_auto(lens, None, visits)
     orc.orc_lens_destroy(lens)
     rc = ref.counters()
     assert rc.accepted_draws > 2 * rc.attempted_draws            # nearly three splats per attempt

@@ -254,9 +254,9 @@ def test_moving_camera_per_sample_time(orc, gpu_ctx_factory, n_keys, ragged, shu
     ref.set_camera_motion(keys)
     if shutter:
         ref.set_camera_shutter(*shutter)
-    ref.run(lens, None, visits)
+    ref.run_auto(lens, None, visits)
     still = oracle_lib.Frame(orc, p, n_aovs=1, keep_log=True)
-    still.run(lens, None, visits)
+    still.run_auto(lens, None, visits)
     orc.orc_lens_destroy(lens)
     assert ref.counters().redistributed_visits > 100
     assert not np.array_equal(common.sort_log(ref.log()), common.sort_log(still.log()))
@@ -299,7 +299,7 @@ def test_ragged_stream_with_a_long_same_pixel_run(orc, gpu_ctx_factory, run_len)
     visits, keepv = capi.make_visits(cols, visits_per_pixel=0)
     lens = orc.orc_lens_create(C.byref(table))
     ref = oracle_lib.Frame(orc, p, n_aovs=2, keep_log=True)
-    ref.run(lens, None, visits)
+    ref.run_auto(lens, None, visits)
     orc.orc_lens_destroy(lens)
     ctx = gpu_ctx_factory()
     for _ in range(2):

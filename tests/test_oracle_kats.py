@@ -402,7 +402,7 @@ def test_threaded_oracle_equals_the_single_thread_one(orc):
     W, H, M = 48, 40, 9
     p, model, table, keep = common.po_setup(W, H, samples_override=32)
     visits, cols = common.make_stream(p, W, H, M, f_hi=0.01)
-    one = common.run_oracle(orc, p, table, visits)
+    one = common.run_oracle(orc, p, table, visits, threads=1)
     thr = common.ThreadedOracle(orc, p, table, visits, 5)
     a, b = one.counters(), thr.counters()
     assert (a.visits, a.redistributed_visits, a.attempted_draws, a.accepted_draws) == (
@@ -430,7 +430,7 @@ def test_threaded_oracle_merges_closest_aovs_in_stream_order(orc):
     kinds = [0, 1, 0, 1]
     p, model, table, keep = common.po_setup(W, H, samples_override=32)
     visits, cols = common.make_stream(p, W, H, M, f_hi=0.01, n_extra=3)
-    one = common.run_oracle(orc, p, table, visits, n_aovs=4, kinds=kinds)
+    one = common.run_oracle(orc, p, table, visits, n_aovs=4, kinds=kinds, threads=1)
     for n_threads in (2, 5, 7):
         thr = common.ThreadedOracle(orc, p, table, visits, n_threads, n_aovs=4, kinds=kinds)
         assert np.array_equal(common.sort_log(one.log()), common.sort_log(thr.log()))
