@@ -2118,6 +2118,14 @@ static bool dma_multi_applies(const lentil_hip_ctx *ctx) {
          ctx->F.closest_mask == 0 && ctx->V.cam.n < 2 && ctx->V.n % M == 0 && dma_multi_lds(ctx) <= 160u * 1024u;
 }
 
+// static LDS of one resident solve block of a streamed pass (solve_po_kernel<.., kStream>; tools/kernel_resources.py): 28.2 KB for a
+// lens that runs as straight-line code -- built into the library, or specialised at run time once its code object is there --,
+// 52.2 KB with the table interpreter
+static size_t solve_block_lds(lentil_hip_ctx *ctx) {
+  const bool straight = ctx->use_generated && (lentil_hip_lens_is_compiled(ctx) || jit_function(ctx, false, true) != nullptr);
+  return straight ? 29184u : 53760u;
+}
+
 static int plan_scan(lentil_hip_ctx *ctx, ScanPlan &pl) {
   ScanArgs &sa = pl.sa;
   sa.P = ctx->P;
@@ -2168,7 +2176,7 @@ static int plan_scan(lentil_hip_ctx *ctx, ScanPlan &pl) {
       static const bool dma2_allowed = !(getenv("LENTIL_SCAN_DMA2") && getenv("LENTIL_SCAN_DMA2")[0] == '0');
       const size_t dma2_lds = (size_t)4 * dma2_wave_f4(M) * 16 + 4 * kWaveQueueLds * sizeof(uint2);
       // (static LDS of solve_po_kernel<.., kStream>, tools/kernel_resources.py: 28.2 KB compiled, 52.2 KB with the table interpreter)
-      const size_t solve_lds = (size_t)ctx->stream_blocks * ((ctx->use_generated && lentil_hip_lens_is_compiled(ctx)) ? 29184u : 53760u);
+      const size_t solve_lds = (size_t)ctx->stream_blocks * solve_block_lds(ctx);
       const uint64_t ppr = ctx->V.pixels_per_row;
       pl.dma2 = dma2_allowed && M >= 2 && ppr >= 2 && ppr < (1ull << 31) && ctx->V.n / M < (1ull << 31) &&
                 dma2_lds + (ctx->stream_mode ? solve_lds : 0) <= 160u * 1024u;
@@ -2404,7 +2412,19 @@ static int streamed_finish(lentil_hip_ctx *ctx, StreamTail &t, const DevCounters
                c.stuck_info[0], c.stuck_info[1], c.stuck_info[2], c.stuck_info[7], c.stuck_info[3], c.stuck_info[4], c.stuck_info[5],
                c.stuck_info[5] >> kTaskTagShift, c.stuck_info[6]);
       ctx->redo_note = note;
-      if (getenv("LENTIL_STREAM_DEBUG")) fprintf(stderr, "[stream] note: %s\n", note);
+      if (c.stuck && (c.stuck & 3u) == 1u && ctx->d_ranges) {
+        // a publisher gave up on its range slot: what the slot holds now (every kernel of the pass has left), the slots around the
+        // cursor and the queue's counters as the host reads them -- a record that IS there was written and not seen
+        const uint32_t tk = c.stuck >> 2;
+        uint64_t w[4] = {0, 0, 0, 0};
+        if ((uint64_t)tk + 2 < ctx->range_cap)
+          (void)hipMemcpy(w, ctx->d_ranges + (tk ? tk - 1 : 0), sizeof w, hipMemcpyDeviceToHost);
+        char more[256];
+        snprintf(more, sizeof more, " | range slots from %u on (host read-back): %016llx %016llx %016llx %016llx, range_head %u",
+                 tk ? tk - 1 : 0, (unsigned long long)w[0], (unsigned long long)w[1], (unsigned long long)w[2], (unsigned long long)w[3], c.range_head);
+        ctx->redo_note += more;
+      }
+      if (getenv("LENTIL_STREAM_DEBUG")) fprintf(stderr, "[stream] note: %s\n", ctx->redo_note.c_str());
     }
     if (getenv("LENTIL_STREAM_DEBUG"))
       fprintf(stderr, "[stream] redo: who %u ticket %u epoch %u range_head %u pubs_done %u scan_done %u | fallback %llu stuck %u | items %llu (cap %u) tasks %u (cap %u) pool %llu (cap %llu) ranges %u (cap %u)\n",
@@ -2734,9 +2754,20 @@ static int redistribute_streamed(lentil_hip_ctx *ctx, bool *streamed, bool *defe
   // The publishers and A, resident beside the scan (the counters they poll were cleared by the memset ahead of
   // ev[0]).  Submitted AFTER what they wait for -- the scan, then the publishers: should the streams share a
   // hardware queue, each finds its producer ahead of it there.
-  unsigned a_blocks = (unsigned)ctx->num_cu * (unsigned)ctx->stream_blocks;
+  // As many resident solve blocks per CU as leave a scan block its LDS.  (Round 6: the table interpreter's blocks hold 52 KB each --
+  // two of them and an 80 KB scan_dma_kernel block do not fit a CU's 160 KB, and where the dispatcher placed the solve blocks
+  // first no scan block ever found room: the resident waves waited for a scan that could not start until a publisher gave up,
+  // 250 ms, then the redo.  That was the "odd stalled pass" of small frames run through the interpreter -- every test that runs
+  // its second pass with lentil_hip_set_lens_mode(ctx, 1) --, found when the library began to count its stalls.  plan_scan only
+  // budgeted for scan_dma2_kernel.)
+  unsigned a_per_cu = (unsigned)ctx->stream_blocks;
+  {
+    const size_t solve_lds = solve_block_lds(ctx);
+    while (a_per_cu > 1u && plan.lds + 512u + (size_t)a_per_cu * solve_lds > 160u * 1024u) --a_per_cu;
+  }
+  unsigned a_blocks = (unsigned)ctx->num_cu * a_per_cu;
   // CUs the scan leaves alone (scan_cus_pct) have registers for one more resident solve block
-  if (ctx->last_scan_skipped && ctx->stream_blocks == 2) a_blocks += ctx->last_scan_skipped;
+  if (ctx->last_scan_skipped && a_per_cu == 2u) a_blocks += ctx->last_scan_skipped;
   (void)scan_blocks;
   // Live straggler queue: solve_slow_kernel is launched behind the publishers (who end with the scan) and takes the parked
   // solves as they come, one wave per CU.  (Round 3, from the timeline: its waves are placed as the first solve waves
