@@ -7,6 +7,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
+#include <thread>
+#include <vector>
 
 #include "../generated/lens_tables_host.h"
 
@@ -98,6 +101,31 @@ void registerLentilCamera(AtNodeLib *node) {
 LentilCamera::~LentilCamera() {
   release_gpu();
   if (host_lens) lentil_host_lens_destroy(host_lens);
+}
+
+// The occlusion probe of the backward traces (src/lentil.h:613-629, src/lentil_filter.cpp:356-375): the library hands over the
+// segment of every try of a round that got through the lens (include/lentil_hip.h, lentil_hip_set_occlusion_probe); each is
+// probed the way the reference probes it -- AiMakeRay(AI_RAY_SHADOW, sample, normalize(lens point - sample), distance) and
+// AiTraceProbe -- over the machine's threads, a shader-globals object per thread.
+static void arnold_probe(void *, uint64_t n, const lentil_probe_segment *seg, uint8_t *occluded) {
+  auto run = [&](uint64_t lo, uint64_t hi) {
+    AtShaderGlobals *sg = AiShaderGlobals();
+    for (uint64_t i = lo; i < hi; ++i) {
+      const AtVector o(seg[i].origin[0], seg[i].origin[1], seg[i].origin[2]), t(seg[i].target[0], seg[i].target[1], seg[i].target[2]);
+      const AtVector dir = AiV3Normalize(t - o);
+      const AtRay ray = AiMakeRay(AI_RAY_SHADOW, o, &dir, AiV3Dist(t, o), sg);
+      occluded[i] = AiTraceProbe(ray, sg) ? 1 : 0;
+    }
+    AiShaderGlobalsDestroy(sg);
+  };
+  unsigned nt = std::thread::hardware_concurrency();
+  if (nt > 64) nt = 64;
+  if (n < (1u << 14) || nt < 2) { run(0, n); return; }
+  std::vector<std::thread> th;
+  const uint64_t per = (n + nt - 1) / nt;
+  for (unsigned k = 0; k < nt && (uint64_t)k * per < n; ++k)
+    th.emplace_back(run, (uint64_t)k * per, std::min(n, (uint64_t)(k + 1) * per));
+  for (std::thread &t : th) t.join();
 }
 
 void LentilCamera::release_gpu() {
@@ -354,6 +382,18 @@ void LentilCamera::setup(AtUniverse *universe) {
   std::vector<uint8_t> kinds;
   for (const lentil_aov_plan &a : aovs) kinds.push_back((uint8_t)lentil_aov_frame_kind(&a));
   if (!check(lentil_hip_alloc_frame(gpu, (uint32_t)aovs.size(), kinds.data()), "alloc_frame")) return;
+  // scene occlusion along every backward trace, as the reference asks the renderer (LENTIL_OCCLUSION_PROBES=0: none; the
+  // camera-to-world matrices are the inverses of the world-to-camera keys above).  Not with a thin lens's chromatic
+  // aberration, whose colour draw the reference orders behind the probe (the library refuses the pair): said once, not probed.
+  {
+    const char *op = getenv("LENTIL_OCCLUSION_PROBES");
+    bool probes = !(op && op[0] == '0');
+    if (probes && P.abb_chromatic != 0.0f) {
+      AiMsgWarning("[LENTIL BIDIRECTIONAL] abb_chromatic is set: scene occlusion along the redistributed rays is not probed");
+      probes = false;
+    }
+    if (!check(lentil_hip_set_occlusion_probe(gpu, probes ? arnold_probe : nullptr, nullptr, nullptr), "set_occlusion_probe")) return;
+  }
   if (imager) { lentil_imager_destroy(imager); imager = nullptr; }
   if (stage) { lentil_stage_destroy(stage); stage = nullptr; }
   stage_slots = 256;

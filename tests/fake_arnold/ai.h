@@ -289,6 +289,26 @@ AI_API void AiDriverInitialize(AtNode *node, bool supports_multiple_outputs);
 AI_API void AiWorldToCameraMatrix(const AtNode *node, float time, AtMatrix &out);
 AI_API void AiCameraToWorldMatrix(const AtNode *node, float time, AtMatrix &out);
 
+// ---- ray probes (ai_ray.h, ai_shaderglobals.h, ai_vector.h): what the occlusion probe of the backward trace needs
+// (src/lentil.h:613-629).  AiV3Normalize / AiV3Dist are inline in the SDK; here they are functions of the stand-in so that
+// the plugin and the test's own segment walker (fa_probe_segments) run the same machine code.
+struct AtShaderGlobals;
+#define AI_RAY_UNDEFINED 0x00
+#define AI_RAY_CAMERA 0x01
+#define AI_RAY_SHADOW 0x02
+struct AtRay {
+  uint8_t type;
+  AtVector origin, dir;
+  float mindist, maxdist;
+};
+inline AtVector operator-(const AtVector &a, const AtVector &b) { return AtVector(a.x - b.x, a.y - b.y, a.z - b.z); }
+AI_API AtVector AiV3Normalize(const AtVector &a);
+AI_API float AiV3Dist(const AtVector &a, const AtVector &b);
+AI_API AtShaderGlobals *AiShaderGlobals();
+AI_API void AiShaderGlobalsDestroy(AtShaderGlobals *sg);
+AI_API AtRay AiMakeRay(uint8_t type, const AtVector &origin, const AtVector *dir, float maxdist, const AtShaderGlobals *sg);
+AI_API bool AiTraceProbe(const AtRay &ray, const AtShaderGlobals *sg);
+
 // ---- iterators -------------------------------------------------------------------------------------------------
 AI_API bool AiAOVSampleIteratorGetNext(AtAOVSampleIterator *iter);
 AI_API bool AiAOVSampleIteratorGetNextDepth(AtAOVSampleIterator *iter);

@@ -297,6 +297,49 @@ void AiWorldToCameraMatrix(const AtNode *node, float time, AtMatrix &out) {
 }
 void AiCameraToWorldMatrix(const AtNode *, float, AtMatrix &out) { identity(out); }
 
+// ---- ray probes: the stand-in's whole scene is one sphere (fa_set_sphere_occluder; radius <= 0: nothing).  A probe along
+// origin + t * dir, 0 <= t <= maxdist, is occluded when the segment passes through it -- the closest point of the segment to
+// the centre lies inside, in fp64 from the ray's fp32 members (the formula of oracle/lentil_oracle.cpp's orc_sphere_occluder,
+// there on the segment's end points).
+struct AtShaderGlobals { int unused; };
+static float g_sphere[4] = {0.f, 0.f, 0.f, 0.f};
+static std::atomic<uint64_t> g_probes{0}, g_probe_hits{0};
+AtVector AiV3Normalize(const AtVector &a) {
+  const float len = sqrtf(a.x * a.x + a.y * a.y + a.z * a.z);
+  if (len == 0.f) return AtVector(0.f, 0.f, 0.f);
+  const float inv = 1.0f / len;
+  return AtVector(a.x * inv, a.y * inv, a.z * inv);
+}
+float AiV3Dist(const AtVector &a, const AtVector &b) {
+  const float x = a.x - b.x, y = a.y - b.y, z = a.z - b.z;
+  return sqrtf(x * x + y * y + z * z);
+}
+AtShaderGlobals *AiShaderGlobals() { return new AtShaderGlobals(); }
+void AiShaderGlobalsDestroy(AtShaderGlobals *sg) { delete sg; }
+AtRay AiMakeRay(uint8_t type, const AtVector &origin, const AtVector *dir, float maxdist, const AtShaderGlobals *) {
+  AtRay r;
+  r.type = type;
+  r.origin = origin;
+  r.dir = dir ? *dir : AtVector(0.f, 0.f, 0.f);
+  r.mindist = 0.f;
+  r.maxdist = maxdist;
+  return r;
+}
+bool AiTraceProbe(const AtRay &ray, const AtShaderGlobals *) {
+  g_probes.fetch_add(1, std::memory_order_relaxed);
+  if (!(g_sphere[3] > 0.f)) return false;
+  const double o[3] = {ray.origin.x, ray.origin.y, ray.origin.z};
+  const double d[3] = {(double)ray.dir.x * (double)ray.maxdist, (double)ray.dir.y * (double)ray.maxdist, (double)ray.dir.z * (double)ray.maxdist};
+  const double c[3] = {g_sphere[0] - o[0], g_sphere[1] - o[1], g_sphere[2] - o[2]};
+  const double dd = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
+  double t = dd > 0.0 ? (c[0] * d[0] + c[1] * d[1] + c[2] * d[2]) / dd : 0.0;
+  t = t < 0.0 ? 0.0 : (t > 1.0 ? 1.0 : t);
+  const double q[3] = {c[0] - t * d[0], c[1] - t * d[1], c[2] - t * d[2]};
+  const bool hit = (q[0] * q[0] + q[1] * q[1] + q[2] * q[2]) < (double)g_sphere[3] * (double)g_sphere[3];
+  if (hit) g_probe_hits.fetch_add(1, std::memory_order_relaxed);
+  return hit;
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // iterators
 // ---------------------------------------------------------------------------------------------------------------
@@ -616,6 +659,26 @@ FA_API int fa_get_display_image(AtUniverse *u, const char *aov, float *dst) {
 }
 // the camera node's own entry points, through its method table (what Arnold calls per camera sample):
 // in = sx, sy, dsx, dsy, lensx, lensy, relative_time; out = origin, dir, dOdx, dOdy, dDdx, dDdy, weight (21 floats)
+// the scene's occluder (process-wide, like the render the SDK's AiShaderGlobals() belongs to), the probes counted
+FA_API void fa_set_sphere_occluder(float cx, float cy, float cz, float r) { g_sphere[0] = cx; g_sphere[1] = cy; g_sphere[2] = cz; g_sphere[3] = r; }
+FA_API void fa_probe_counts(uint64_t out[2], int reset) {
+  out[0] = g_probes.load(); out[1] = g_probe_hits.load();
+  if (reset) { g_probes.store(0); g_probe_hits.store(0); }
+}
+// A lentil_probe_fn (include/lentil_hip.h) for the oracle's side of a plugin test: every segment probed the way the plugin's
+// callback probes it (pota_amd/csrc/plugin/lentil_camera_node.cpp, arnold_probe) -- AiMakeRay(AI_RAY_SHADOW, origin,
+// normalize(target - origin), dist(target, origin)) then AiTraceProbe.
+struct FaSegment { float origin[3], target[3]; };
+FA_API void fa_probe_segments(void *, uint64_t n, const FaSegment *seg, uint8_t *occluded) {
+  AtShaderGlobals *sg = AiShaderGlobals();
+  for (uint64_t i = 0; i < n; ++i) {
+    const AtVector o(seg[i].origin[0], seg[i].origin[1], seg[i].origin[2]), t(seg[i].target[0], seg[i].target[1], seg[i].target[2]);
+    const AtVector dir = AiV3Normalize(t - o);
+    const AtRay ray = AiMakeRay(AI_RAY_SHADOW, o, &dir, AiV3Dist(t, o), sg);
+    occluded[i] = AiTraceProbe(ray, sg) ? 1 : 0;
+  }
+  AiShaderGlobalsDestroy(sg);
+}
 FA_API int fa_camera_create_ray(AtUniverse *u, const float in[7], float out[21], int tid) {
   if (!u->camera || !u->camera->e->m || u->camera->e->node_type != AI_NODE_CAMERA) return -1;
   const AtCameraNodeMethods *cm = (const AtCameraNodeMethods *)u->camera->e->m->dmethods;

@@ -568,3 +568,93 @@ def test_cryptomatte_frame_through_the_plugin_matches_the_oracle(fa, orc, monkey
     assert float(np.max(np.abs(got[m].astype(np.float64) - want[m]) / np.abs(want[m]))) < 1e-5
     ref.close()
     fa.fa_universe_destroy(C.c_void_p(u))
+
+
+@pytest.mark.gpu
+def test_scene_occlusion_through_the_plugin_matches_the_oracle(fa, orc, monkeypatch):
+    """The renderer's scene holds an occluder (the stand-in SDK's analytic sphere behind AiTraceProbe): the camera node hands
+    the library a probe callback that asks the renderer the reference's question per try -- AiMakeRay(AI_RAY_SHADOW, sample,
+    normalize(lens point - sample), distance) and AiTraceProbe (src/lentil.h:613-629) -- and the frame that comes out of the
+    imager is the oracle's with the same question asked through the same SDK calls (fa_probe_segments), not the unoccluded
+    one.  LENTIL_OCCLUSION_PROBES=0 renders the unoccluded frame."""
+    W, H, M, S = 64, 48, 9, 48
+    monkeypatch.setenv("LENTIL_SAMPLES_OVERRIDE", str(S))
+    p, model, table, keep = common.po_setup(W, H, samples_override=S, focal_length=np.float32(35.0))
+    visits, cols = common.make_stream(p, W, H, M, f_hi=0.03)
+    n = W * H * M
+    pix = np.arange(n) // M
+    px = (pix % W).astype(np.int32); py = (pix // W).astype(np.int32)
+    rng = np.random.default_rng(11)
+    ox = rng.uniform(-0.5, 0.5, n).astype(np.float32); oy = rng.uniform(-0.5, 0.5, n).astype(np.float32)
+    invd = np.full(n, 1.0 / 9.0, np.float32)
+    zeros = np.zeros((n, 4), np.float32)
+    z4 = np.repeat(cols["pos_z"][:, 3:4], 4, axis=1).copy()
+    aov = {"RGBA": (AI_TYPE["RGBA"], cols["rgba"]), "P": (AI_TYPE["VECTOR"], cols["pos_z"]), "Z": (AI_TYPE["FLOAT"], z4),
+           "lentil_raydir": (AI_TYPE["RGB"], cols["raydir_time"]), "lentil_time": (AI_TYPE["FLOAT"], zeros),
+           "volume": (AI_TYPE["RGB"], zeros), "transmission": (AI_TYPE["RGBA"], zeros), "lentil_ignore": (AI_TYPE["FLOAT"], zeros)}
+    keep_arrays = [np.ascontiguousarray(a, np.float32) for _, a in aov.values()]
+    fa.fa_set_sphere_occluder.argtypes = [C.c_float] * 4
+    fa.fa_set_sphere_occluder.restype = None
+    fa.fa_probe_counts.argtypes = [C.c_void_p, C.c_int]
+    fa.fa_probe_counts.restype = None
+    counts = (C.c_uint64 * 2)()
+
+    def render(sphere):
+        fa.fa_messages_clear()
+        fa.fa_set_sphere_occluder(*[float(v) for v in sphere])
+        fa.fa_probe_counts(counts, 1)
+        u, cam = _scene(fa, W, H, ["RGBA RGBA gaussian_filter driver_exr"])
+        fa.fa_node_set_int(C.c_void_p(cam), b"camera_type", 1)
+        fa.fa_node_set_int(C.c_void_p(cam), b"lens_model", 0)
+        fa.fa_set_samples(C.c_void_p(u), n, px.ctypes.data_as(C.c_void_p), py.ctypes.data_as(C.c_void_p), ox.ctypes.data_as(C.c_void_p),
+                          oy.ctypes.data_as(C.c_void_p), invd.ctypes.data_as(C.c_void_p))
+        for (name, (t, _)), a in zip(aov.items(), keep_arrays):
+            fa.fa_set_aov(C.c_void_p(u), name.encode(), t, a.ctypes.data_as(C.c_void_p))
+        rc = fa.fa_render(C.c_void_p(u), 4, 16)
+        assert rc == 0 and fa.fa_error_count() == 0, _messages(fa)
+        img = np.zeros((H, W, 4), np.float32)
+        assert fa.fa_get_image(C.c_void_p(u), b"RGBA", img.ctypes.data_as(C.c_void_p)) == 0
+        fa.fa_universe_destroy(C.c_void_p(u))
+        fa.fa_probe_counts(counts, 0)
+        return img, int(counts[0]), int(counts[1])
+
+    def oracle(probe):
+        # AOVs in the plugin's order: RGBA, lentil_debug (own z-buffer, no column), lentil_raydir (RGB widened with alpha 1)
+        kinds = [_abi.FILTER_GAUSSIAN, _abi.FILTER_CLOSEST_DEBUG, _abi.FILTER_GAUSSIAN]
+        ocols = dict(cols)
+        widen = lambda a: np.ascontiguousarray(np.concatenate([a[:, :3], np.ones((n, 1), np.float32)], 1), np.float32)
+        ocols["extra"] = [np.zeros_like(cols["rgba"]), widen(cols["raydir_time"])]
+        ovisits, okeep = capi.make_visits(ocols, visits_per_pixel=M, pixels_per_row=W)
+        lens = orc.orc_lens_create(C.byref(table))
+        ref = oracle_lib.Frame(orc, p, n_aovs=3, kinds=kinds, keep_log=True)
+        if probe:
+            ref.set_probe(C.cast(fa.fa_probe_segments, C.c_void_p).value, None)
+        ref.run(lens, None, ovisits)
+        orc.orc_lens_destroy(lens)
+        want = ref.resolve(0).reshape(p.yres, p.xres, 4)[:H, :W].copy()
+        c = ref.counters()
+        ref.close()
+        return want, (int(c.attempted_draws), int(c.accepted_draws))
+
+    def same(got, want):
+        m = want != 0
+        return np.array_equal(got != 0, m) and float(np.max(np.abs(got[m].astype(np.float64) - want[m]) / np.abs(want[m]))) < 1e-5
+
+    sphere = (6.0, 2.0, -70.0, 9.0)          # beside the axis, between the lens and the far highlights (cm, camera at the origin)
+    try:
+        got, probed, hits = render(sphere)
+        assert probed > 1000 and 0 < hits < probed, (probed, hits)
+        fa.fa_set_sphere_occluder(*[float(v) for v in sphere])
+        want, wc = oracle(True)
+        free, fc = oracle(False)
+        assert wc != fc                        # the occluder bites ...
+        assert same(got, want) and not same(got, free)
+        # ... a scene without one probes and finds nothing: the unoccluded frame
+        got0, probed0, hits0 = render((0.0, 0.0, 0.0, 0.0))
+        assert probed0 > 1000 and hits0 == 0 and same(got0, free)
+        # ... and probing switched off asks nothing, occluder or not
+        monkeypatch.setenv("LENTIL_OCCLUSION_PROBES", "0")
+        got1, probed1, _ = render(sphere)
+        assert probed1 == 0 and same(got1, free)
+    finally:
+        fa.fa_set_sphere_occluder(0.0, 0.0, 0.0, 0.0)
