@@ -1249,7 +1249,7 @@ LENTIL_API int lentil_hip_set_camera_motion(lentil_hip_ctx *ctx, uint32_t n_keys
 
 // ---- occlusion probes (include/lentil_hip.h; kernels: probe_list_kernel / probe_apply_kernel) ---------------------------------
 // the inverse of a 4x4 matrix by cofactors in fp64, rounded to float at the end: AiCameraToWorldMatrix where the caller gives none
-// (the oracle computes the same: oracle/lentil_oracle.cpp, invert4x4)
+// (the oracle computes the same: the test oracle's invert4x4)
 static void invert4x4(const float m_[16], float out[16]) {
   double m[16], inv[16];
   for (int i = 0; i < 16; i++) m[i] = m_[i];
