@@ -3020,7 +3020,14 @@ static int redistribute_streamed(lentil_hip_ctx *ctx, bool *streamed, bool *defe
   }
   HIP_TRY(ctx, hipStreamWaitEvent(ch.stream, ctx->ev[0], 0));
   da.instance = 0;
-  launch_solve_po<true>(ctx, da, ch.stream, a_blocks);
+  // (a fused pass: instance A runs scan_solve_kernel as well, without the scan -- one copy of the solve loop's code on the chip;
+  // LENTIL_FUSED_A=0: solve_po_kernel as ever)
+  static const bool fused_a = !(getenv("LENTIL_FUSED_A") && getenv("LENTIL_FUSED_A")[0] == '0');
+  if (fused && fused_a) {
+    if (!launch_scan_solve(ctx, fused_kind, plan.sa, da, ch.stream, a_blocks, sizeof(SolveLds<false, false>))) return fail(ctx, LENTIL_ERR_UNSUPPORTED, "scan_solve_kernel: no kernel for this lens");
+  } else {
+    launch_solve_po<true>(ctx, da, ch.stream, a_blocks);
+  }
   HIP_TRY(ctx, hipGetLastError());
   HIP_TRY(ctx, hipEventRecord(ch.done, ch.stream));
 

@@ -2922,16 +2922,21 @@ __global__ __launch_bounds__(256) LENTIL_SOLVE_ATTR void scan_solve_kernel(ScanA
   extern __shared__ float4 smem[];
   if (s.V.n == 0) return;          // (lentil_hip_create's empty launch: the queue's scratch memory)
   uint32_t t0 = 0;
-  if (threadIdx.x == 0) {
+  if (threadIdx.x == 0 && a.instance == 2) {
     t0 = (uint32_t)__builtin_amdgcn_s_memrealtime() | 1u;
     const uint32_t first = atomicCAS(&s.ctr->scan_t0, 0u, t0);
     if (first) t0 = first;
   }
-  if constexpr (kScan == 2) scan_dma2_body(s); else scan_dma_multi_body(s);
-  __builtin_amdgcn_s_setprio(0);
-  // (scan_block_done has waited for this block's stores and met at a barrier; the staging area is free)
-  if (threadIdx.x == 0) atomicMax(&s.ctr->scan_dt, (uint32_t)__builtin_amdgcn_s_memrealtime() - t0);
-  __syncthreads();
+  // (DrawArgs::instance 2: the blocks that scan first.  The pass's resident solve blocks -- instance 0, launched with a solve block's
+  // LDS -- run THIS kernel too and skip the scan: one copy of the Newton loop's ~20 KB of code in the instruction cache two CUs share,
+  // not the scan kernel's copy beside solve_po_kernel's.)
+  if (a.instance == 2) {
+    if constexpr (kScan == 2) scan_dma2_body(s); else scan_dma_multi_body(s);
+    __builtin_amdgcn_s_setprio(0);
+    // (scan_block_done has waited for this block's stores and met at a barrier; the staging area is free)
+    if (threadIdx.x == 0) atomicMax(&s.ctr->scan_dt, (uint32_t)__builtin_amdgcn_s_memrealtime() - t0);
+    __syncthreads();
+  }
   solve_po_body<LensT, false, false, true>(a, *reinterpret_cast<SolveLds<false, false> *>(smem));
 }
 

@@ -14,11 +14,12 @@ pytestmark = pytest.mark.gpu
 @pytest.mark.parametrize("lens", ["petzval_58mm", "double_gauss_50mm"])
 @pytest.mark.parametrize("knob", ["default", "0"])
 def test_frames_with_aov_columns(orc, monkeypatch, lens, knob):
-    """BASELINE config 4's shape at 1280 x 720: three gaussian AOVs beside the beauty, 256 draws.  The default fuses such frames."""
+    """BASELINE config 4's shape at 1280 x 720: eight gaussian AOVs beside the beauty (one scan block per CU, as the fused form needs),
+    256 draws.  The default fuses such frames."""
     if knob != "default":
         monkeypatch.setenv("LENTIL_FUSED_SCAN", knob)
-    _timed_config_vs_oracle(orc, "fused scan, %s, 3 AOV columns, LENTIL_FUSED_SCAN=%s" % (lens, knob), 1280, 720, lens, 256, n_extra=3,
-                            kinds=[0, 0, 0, 0], passes=(0, 1, 0), expect_form=(3, 1 if knob == "default" else 0))
+    _timed_config_vs_oracle(orc, "fused scan, %s, 8 AOV columns, LENTIL_FUSED_SCAN=%s" % (lens, knob), 1280, 720, lens, 256, n_extra=8,
+                            kinds=[0] * 9, passes=(0, 1, 0), expect_form=(3, 1 if knob == "default" else 0))
 
 
 @pytest.mark.parametrize("lens", ["double_gauss_50mm", "petzval_58mm"])
