@@ -551,12 +551,6 @@ int lentil_hip_last_timing(lentil_hip_ctx *ctx, float ms[3]);
 /* kernel launches of the last redistribute: n[0] scan launches (one per chunk of the visit stream; ms[0]
  * of last_timing covers all of them), n[1] solve/accept rounds of the chunk that needed most. */
 int lentil_hip_last_launches(lentil_hip_ctx *ctx, uint32_t n[2]);
-/* How the last streamed pass scanned (round 6): form[0] the scan kernel -- 0 none of the LDS-DMA forms, 1 scan_dma_kernel, 2
- * scan_dma2_kernel, 3 scan_dma_multi_kernel --, form[1] = 1 if the scan's waves stayed on the chip and went on as solve waves
- * (scan_solve_kernel: the third resident solve wave per SIMD; LENTIL_FUSED_SCAN=0 never, 1 frames with extra AOV columns, 2 every
- * streamed pass of a lens compiled into the library), form[2] blocks of the scan's grid that did not scan.  All zero when the last
- * pass was not streamed. */
-int lentil_hip_last_scan_form(lentil_hip_ctx *ctx, uint32_t form[3]);
 /* First batches sized from the lens and the frame (round 5).  The reference's loop (src/lentil_filter.cpp:248-299) keeps
  * tracing until `samples` draws of a sample have landed inside the frame, at most 5 x samples attempts of up to
  * vignetting_retries + 1 tries each (src/lentil.h:592-648); this library computes every trace once, in batches, and sizes a

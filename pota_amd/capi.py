@@ -22,7 +22,7 @@ EXPORTS = [
     "lentil_hip_set_closest_exchange", "lentil_hip_zkey_buffer", "lentil_hip_closest_gather",
     "lentil_hip_touched_rows", "lentil_hip_merge_rows", "lentil_hip_resolve_rows",
     "lentil_hip_pack_rows", "lentil_hip_merge_packed_rows", "lentil_hip_compact_rows", "lentil_hip_merge_sparse",
-    "lentil_hip_get_counters", "lentil_hip_last_timing", "lentil_hip_last_launches", "lentil_hip_last_scan_form", "lentil_hip_set_draw_log",
+    "lentil_hip_get_counters", "lentil_hip_last_timing", "lentil_hip_last_launches", "lentil_hip_set_draw_log",
     "lentil_hip_batch_model_stats", "lentil_hip_process_stats", "lentil_hip_process_stall_notes", "lentil_hip_set_async", "lentil_hip_pass_totals", "lentil_hip_set_occlusion_probe", "lentil_hip_probe_stats", "lentil_hip_debug_batch_estimate", "lentil_hip_box_probe",
     "lentil_hip_lens_jit_status", "lentil_hip_lens_jit_wait", "lentil_hip_debug_lens_jit_source", "lentil_hip_debug_lens_jit_compile",
     "lentil_hip_download_draw_log", "lentil_hip_test_lt_sample_aperture",
@@ -120,7 +120,6 @@ def load_library():
         "lentil_hip_get_counters": (i, [vp, C.POINTER(_abi.Counters)]),
         "lentil_hip_last_timing": (i, [vp, C.POINTER(C.c_float)]),
         "lentil_hip_last_launches": (i, [vp, C.POINTER(C.c_uint32)]),
-        "lentil_hip_last_scan_form": (i, [vp, C.POINTER(C.c_uint32)]),
         "lentil_hip_batch_model_stats": (i, [vp, C.POINTER(C.c_uint64)]),
         "lentil_hip_process_stats": (i, [C.POINTER(C.c_uint64)]),
         "lentil_hip_process_stall_notes": (i, [C.c_char_p, C.c_uint64]),
@@ -542,12 +541,6 @@ class Context:
         n = (C.c_uint32 * 2)()
         self._chk(self.lib.lentil_hip_last_launches(self.h, n))
         return int(n[0]), int(n[1])
-
-    def last_scan_form(self):
-        """(scan kernel form 0-3, 1 if the scan's waves went on as solve waves, blocks that did not scan) of the last streamed pass"""
-        n = (C.c_uint32 * 3)()
-        self._chk(self.lib.lentil_hip_last_scan_form(self.h, n))
-        return int(n[0]), int(n[1]), int(n[2])
 
     def lens_jit_status(self):
         """(state, compile seconds): 0 nothing to compile, 1 compiling, 2 specialised kernel in use, -1 failed"""

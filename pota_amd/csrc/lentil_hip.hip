@@ -224,11 +224,6 @@ struct lentil_hip_ctx {
   bool overlap_rounds = true;        // LENTIL_OVERLAP_ROUNDS=0: a streamed pass's second round starts after its first accept has ended
   bool slow_live = true;             // LENTIL_SLOW_LIVE=0: stragglers of a streamed pass wait for their round's solve kernel to end
   int crowd_stays_first = 0, crowd_stays_later = 0;    // LENTIL_CROWD_STAYS=ab (two digits): DrawArgs::slow_crowd_stays of a streamed pass's first / later rounds
-  // LENTIL_FUSED_SCAN: the scan's waves of a streamed pass stay and solve (scan_solve_kernel, lentil_kernels.h): 0 never, 1 frames with
-  // extra AOV columns (scan_dma_multi_kernel's: BASELINE config 4), 2 every streamed pass whose lens is compiled into the library
-  int fused_scan = 1;
-  unsigned last_scan_kind = 0;       // 1 scan_dma_kernel, 2 scan_dma2_kernel, 3 scan_dma_multi_kernel (lentil_hip_last_scan_form)
-  bool last_scan_fused = false;      // the pass in flight / last looked at: its scan has no events of its own (DevCounters::scan_dt)
   bool solve_b = false;              // LENTIL_SOLVE_B=1: the second solve launch behind the scan (its blocks only find room when the first launch's leave: measured idle)
   uint32_t margin_low_rate = 10;      // LENTIL_BATCH_MARGIN_LOW_RATE (sixteenths, 0..16): DrawArgs::margin_low_rate
   uint32_t batch_margin16 = 4;        // LENTIL_BATCH_MARGIN (sixteenths, 0..16): DrawArgs::batch_margin16
@@ -272,7 +267,7 @@ struct lentil_hip_ctx {
   // launch -- the marker behind the scan is only processed once the command processor gets round to that queue again,
   // with four other queues of the pass busy.
   hipEvent_t ev_scan_k[2] = {nullptr, nullptr};
-  int scan_kernel_timed = 0;            // 0: the events round the scan launch | 1: the launch's own events | 2: DevCounters::scan_dt (scan_solve_kernel)
+  bool scan_kernel_timed = false;
   // thin lens with abb_chromatic > 0: the xor128 state the colour channels are drawn from (src/global.h:22-27), handed
   // from pass to pass, and the pass's buffers
   uint32_t xor_state[4] = {123456789u, 362436069u, 521288629u, 88675123u};
@@ -329,7 +324,7 @@ struct lentil_hip_ctx {
     hipEvent_t ev_tail = nullptr;     // behind the counters' copy on the pass's tail stream
     DevCounters *h_ctr_pinned = nullptr;
     bool timing_open = false;         // a pass used these events and its times are not in the totals yet
-    bool timed_draw = false, timed_resolve = false; int scan_kernel_timed = 0;
+    bool timed_draw = false, timed_resolve = false, scan_kernel_timed = false;
   } slots[3];
   int slot = 0;
   struct Inflight {                   // a streamed pass whose end nobody has looked at
@@ -692,7 +687,6 @@ LENTIL_API int lentil_hip_create(int device, lentil_hip_ctx **out_ctx) {
   if (const char *e = getenv("LENTIL_UNKNOWN_CREDIT")) { const int v = atoi(e); ctx->unknown_credit = (uint32_t)(v < 0 ? 0 : (v > 8 ? 8 : v)); }
   if (const char *e = getenv("LENTIL_CROWD_STAYS")) { ctx->crowd_stays_first = e[0] == '1'; ctx->crowd_stays_later = e[0] && e[1] == '1'; }
   if (const char *e = getenv("LENTIL_SOLVE_B")) ctx->solve_b = e[0] == '1';
-  if (const char *e = getenv("LENTIL_FUSED_SCAN")) { ctx->fused_scan = atoi(e); if (ctx->fused_scan < 0 || ctx->fused_scan > 2) ctx->fused_scan = 1; }
   if (const char *e = getenv("LENTIL_STREAM_BELOW")) { ctx->stream_below = strtoull(e, nullptr, 10); ctx->stream_below_set = true; }
   if (const char *e = getenv("LENTIL_STREAM_BLOCKS")) ctx->stream_blocks = atoi(e);
   if (ctx->stream_blocks < 1) ctx->stream_blocks = 1;
@@ -729,21 +723,6 @@ LENTIL_API int lentil_hip_create(int device, lentil_hip_ctx **out_ctx) {
   // (the multi-AOV scan's ring can take all of a CU's LDS)
   (void)hipFuncSetAttribute((const void *)scan_dma_multi_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   (void)hipFuncSetAttribute((const void *)scan_dma2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  {
-    // scan_solve_kernel: the same LDS, and -- it spills a few registers like the solve kernel it ends in -- one empty launch on the
-    // main stream, so that the queue's scratch memory is not sized behind a pass's resident waves (see the accept kernels above)
-    ScanArgs ws{};
-    DrawArgs wd{};
-    ws.ctr = ctx->d_ctr; wd.ctr = ctx->d_ctr;
-#define LENTIL_WARM_FUSED(NAME)                                                                                                     \
-    (void)hipFuncSetAttribute((const void *)scan_solve_kernel<GenLens<gen::Lens_##NAME>, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-    (void)hipFuncSetAttribute((const void *)scan_solve_kernel<GenLens<gen::Lens_##NAME>, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-    hipLaunchKernelGGL((scan_solve_kernel<GenLens<gen::Lens_##NAME>, 2>), dim3((unsigned)ctx->num_cu), dim3(256), 100 * 1024, ctx->stream, ws, wd);     \
-    hipLaunchKernelGGL((scan_solve_kernel<GenLens<gen::Lens_##NAME>, 3>), dim3((unsigned)ctx->num_cu), dim3(256), 100 * 1024, ctx->stream, ws, wd);
-    if (ctx->fused_scan) { LENTIL_GENERATED_LENSES(LENTIL_WARM_FUSED) }
-#undef LENTIL_WARM_FUSED
-    (void)hipStreamSynchronize(ctx->stream);
-  }
   (void)hipGetLastError();
   *out_ctx = ctx;
   return LENTIL_OK;
@@ -1604,6 +1583,7 @@ LENTIL_API int lentil_hip_clear_frame(lentil_hip_ctx *ctx) {
       ctx->clear_pending = true;
     }
     ctx->F.touched = nullptr;
+    ctx->F.touched_px = nullptr;
   } else {
   { const int rcj = join_clear(ctx); if (rcj) return rcj; }
   uint64_t p0 = 0, p1 = ctx->F.np;
@@ -1661,29 +1641,6 @@ static void launch_solve_po(lentil_hip_ctx *ctx, const DrawArgs &da, hipStream_t
     if (chroma) hipLaunchKernelGGL((solve_po_kernel<LdsLens, true, true, kStream>), dim3(blocks), dim3(threads), 0, st, da);
     else hipLaunchKernelGGL((solve_po_kernel<LdsLens, true, false, kStream>), dim3(blocks), dim3(threads), 0, st, da);
   }
-}
-
-// scan_solve_kernel for the lens of the context, should it be one of those compiled into the library (no chromatic channels): the
-// scan of a streamed pass whose waves go on as solve waves.  kind: 2 = scan_dma2_kernel's body, 3 = scan_dma_multi_kernel's.
-static bool fused_scan_lens(const lentil_hip_ctx *ctx) {
-  bool found = false;
-#define LENTIL_FUSED_HAS(NAME) if (ctx->use_generated && ctx->lens_hash == gen::Lens_##NAME::kTableHash) found = true;
-  LENTIL_GENERATED_LENSES(LENTIL_FUSED_HAS)
-#undef LENTIL_FUSED_HAS
-  return found;
-}
-static_assert(sizeof(ScanArgs) + sizeof(DrawArgs) + 16 <= 4096, "scan_solve_kernel's arguments exceed a kernel's argument segment");
-static bool launch_scan_solve(lentil_hip_ctx *ctx, int kind, const ScanArgs &sa, const DrawArgs &da, hipStream_t st, unsigned blocks, size_t lds) {
-  bool launched = false;
-#define LENTIL_LAUNCH_FUSED(NAME)                                                                          \
-  if (!launched && ctx->use_generated && ctx->lens_hash == gen::Lens_##NAME::kTableHash) {                \
-    if (kind == 2) hipLaunchKernelGGL((scan_solve_kernel<GenLens<gen::Lens_##NAME>, 2>), dim3(blocks), dim3(256), lds, st, sa, da); \
-    else hipLaunchKernelGGL((scan_solve_kernel<GenLens<gen::Lens_##NAME>, 3>), dim3(blocks), dim3(256), lds, st, sa, da); \
-    launched = true;                                                                                     \
-  }
-  LENTIL_GENERATED_LENSES(LENTIL_LAUNCH_FUSED)
-#undef LENTIL_LAUNCH_FUSED
-  return launched;
 }
 
 // stragglers parked by the solve kernel: one wave each (blind launch; an empty queue costs a few microseconds)
@@ -2001,6 +1958,10 @@ static void init_draw_args(lentil_hip_ctx *ctx, DrawArgs &da) {
   da.slow_q = -1; da.slow_round = -1; da.slow_close = 1; da.slow_indirect = 0;      // a straggler queue per round
 }
 
+// FrameDev::touched and ::touched_px share one allocation: a byte per 64-pixel group, then (256-byte aligned) a byte per pixel
+static inline uint64_t touched_px_offset(uint64_t np) { return (((np + 63) / 64) + 255) & ~(uint64_t)255; }
+static inline uint64_t touched_bytes(uint64_t np) { return touched_px_offset(np) + np; }
+
 // FrameDev::touched stops being the whole truth about `acc` (something other than a splat is written there): the
 // flags are reset, the next clear wipes the rows it knows to be dirty -- or everything
 static void untrust_touched(lentil_hip_ctx *ctx) {
@@ -2009,8 +1970,9 @@ static void untrust_touched(lentil_hip_ctx *ctx) {
   // prepare_direct must not take the splat flags for the whole truth; round-4 ADVICE)
   ctx->cleared_since_pass = false;
   if (!ctx->F.touched) return;
-  (void)hipMemsetAsync(ctx->d_touched, 0, (ctx->F.np + 63) / 64, ctx->stream);
+  (void)hipMemsetAsync(ctx->d_touched, 0, touched_bytes(ctx->F.np), ctx->stream);
   ctx->F.touched = nullptr;
+  ctx->F.touched_px = nullptr;
 }
 
 // ---- FrameDev::dir bookkeeping ---------------------------------------------------------------------------
@@ -2057,11 +2019,12 @@ static int prepare_direct(lentil_hip_ctx *ctx, const lentil_hip_ctx::DirRegion *
     if (ctx->cleared_since_pass) {
       // `acc` is all zeros and this pass only splats into it
       if (!ctx->d_touched) {
-        const uint64_t n = (ctx->F.np + 63) / 64;
+        const uint64_t n = touched_bytes(ctx->F.np);
         HIP_TRY(ctx, hipMalloc(&ctx->d_touched, n));
         HIP_TRY(ctx, hipMemsetAsync(ctx->d_touched, 0, n, ctx->stream));
       }
       ctx->F.touched = ctx->d_touched;
+      ctx->F.touched_px = ctx->d_touched + touched_px_offset(ctx->F.np);
     }
   } else {
     untrust_touched(ctx);
@@ -2288,7 +2251,7 @@ static int launch_scan(lentil_hip_ctx *ctx, const ScanPlan &pl, const lentil_hip
   // (a streamed pass's single launch: timed by its own dispatch, lentil_hip_last_timing; LENTIL_SCAN_EVENTS=0: by the events around it)
   static const bool scan_events = !(getenv("LENTIL_SCAN_EVENTS") && getenv("LENTIL_SCAN_EVENTS")[0] == '0');
   const bool own_events = streamed_pass && scan_events && (pl.dma || pl.dma_multi);
-  ctx->scan_kernel_timed = own_events ? 1 : 0;
+  ctx->scan_kernel_timed = own_events;
   if (pl.dma) {
     // persistent, every wave draws four tiles at a time
     blocks = (ch.tile_end - ch.tile_begin + 15) / 16;
@@ -2780,23 +2743,11 @@ static int redistribute_streamed(lentil_hip_ctx *ctx, bool *streamed, bool *defe
       HIP_TRY(ctx, hipGetLastError());
     }
   }
-  // Round 6: the scan's waves stay and solve (scan_solve_kernel, lentil_kernels.h) -- the third resident solve wave per SIMD that no
-  // launch behind the scan ever got.  Where the lens is compiled into the library, the scan is one of the two LDS-DMA forms with
-  // one block per CU whose staging area holds a solve block's LDS, and nothing else of the pass needs the scan's END as an event
-  // on its stream early (cryptomatte's own-pixel adds do).  Launched further down, when the solve waves' arguments are complete.
-  const int fused_kind = (plan.dma && plan.dma2) ? 2 : (plan.dma_multi ? 3 : 0);
-  const bool fused = fused_kind != 0 && (ctx->fused_scan == 2 || (ctx->fused_scan == 1 && fused_kind == 3)) && nch == 1 && fused_scan_lens(ctx) &&
-                     !ctx->crypto && !ctx->extend && ctx->streams_concurrent && ctx->chain_streams && plan.lds >= sizeof(SolveLds<false, false>) &&
-                     (fused_kind != 3 || dma_multi_blocks_per_cu(ctx) == 1) && !da.inject_stall;
-  ctx->last_scan_fused = fused;
-  ctx->last_scan_kind = fused_kind ? (unsigned)fused_kind : (plan.dma ? 1u : 0u);
-  if (!fused) {
-    if ((rc = launch_scan(ctx, plan, ch, ctx->d_ctr, &scan_blocks, true))) return rc;
-    HIP_TRY(ctx, hipEventRecord(ch.scanned, ctx->stream));
-    HIP_TRY(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
-    HIP_TRY(ctx, hipEventRecord(ctx->scans_done, ctx->stream));
-  }
+  if ((rc = launch_scan(ctx, plan, ch, ctx->d_ctr, &scan_blocks, true))) return rc;
   ctx->last_scan_launches = 1;
+  HIP_TRY(ctx, hipEventRecord(ch.scanned, ctx->stream));
+  HIP_TRY(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
+  HIP_TRY(ctx, hipEventRecord(ctx->scans_done, ctx->stream));
   // cryptomatte AOVs: the adds of the visits that stay in their pixel need the scan's work lists and nothing else of the
   // pass -- beside the draws, on the spare stream, where the runtime has one (LENTIL_CRYPTO_OVERLAP=0: after the pass)
   static const bool crypto_overlap = !(getenv("LENTIL_CRYPTO_OVERLAP") && getenv("LENTIL_CRYPTO_OVERLAP")[0] == '0');
@@ -2823,16 +2774,8 @@ static int redistribute_streamed(lentil_hip_ctx *ctx, bool *streamed, bool *defe
   }
   unsigned a_blocks = (unsigned)ctx->num_cu * a_per_cu;
   // CUs the scan leaves alone (scan_cus_pct) have registers for one more resident solve block
-  if (!fused && ctx->last_scan_skipped && a_per_cu == 2u) a_blocks += ctx->last_scan_skipped;
+  if (ctx->last_scan_skipped && a_per_cu == 2u) a_blocks += ctx->last_scan_skipped;
   (void)scan_blocks;
-  // (the fused scan: three 168-register blocks fill a CU's SIMDs to 504 of 512 -- a publisher wave, 88, then finds no room beside
-  // them; sixteen CU slots are left free, each with room for eight publishers, wherever the dispatcher leaves them)
-  unsigned fused_blocks = 0;
-  if (fused) {
-    fused_blocks = (unsigned)ctx->num_cu;
-    const unsigned keep_free = ((unsigned)ctx->publish_waves + 3u) / 4u;
-    if (a_per_cu >= 2u && a_blocks > keep_free + (unsigned)ctx->num_cu) a_blocks -= keep_free;
-  }
   // Live straggler queue: solve_slow_kernel is launched behind the publishers (who end with the scan) and takes the parked
   // solves as they come, one wave per CU.  (Round 3, from the timeline: its waves are placed as the first solve waves
   // leave -- the idle ones do at once when the publishers' end markers arrive --, not in the registers the scan gives
@@ -2906,7 +2849,7 @@ static int redistribute_streamed(lentil_hip_ctx *ctx, bool *streamed, bool *defe
   da.slow_waves = live ? slow_waves_all : 0u;
   da.producers_done = &ctx->d_ctr->publishers_done;
   da.producers_total = (uint32_t)ctx->publish_waves;
-  pa.end_tasks = a_blocks * 4u + b_blocks * (b_threads / 64u) + fused_blocks * 4u;       // every first-round solve wave may hold one ticket past the last task
+  pa.end_tasks = a_blocks * 4u + b_blocks * (b_threads / 64u);       // every first-round solve wave may hold one ticket past the last task
   // Extension (ItemLive, lentil_kernels.h): the first round's solve kernel appends the batches its items still need
   const bool extend = ctx->extend && decoupled && nch == 1 && ctx->chain_streams;
   // First batches from the lens and the frame (lentil_batch_model.h): every item is published with the traces it is expected
@@ -2968,32 +2911,6 @@ static int redistribute_streamed(lentil_hip_ctx *ctx, bool *streamed, bool *defe
     da.ready_q = ctx->d_ready;
     da.ready_cap = (uint32_t)(ctx->ready_cap < 0xFFFFFFF0ull ? ctx->ready_cap : 0xFFFFFFF0ull);
   }
-  if (fused) {
-    // scan_solve_kernel on the main stream, where the scan would be: the scan's arguments as launch_scan sets them, the solve
-    // waves' as instance A's (a third instance: nothing of the round's queues is reset by it)
-    ScanArgs sa = plan.sa;
-    const char *oi = getenv("LENTIL_SCAN_OUTSIDE_IN");
-    sa.outside_in = (oi && oi[0] == '1') ? 1u : 0u;
-    sa.work = ctx->d_work + ch.v_begin;
-    sa.work_cap = ch.v_end - ch.v_begin;
-    sa.ctr = ctx->d_ctr;
-    sa.tile_begin = ch.tile_begin; sa.tile_end = ch.tile_end;
-    sa.v_begin = ch.v_begin; sa.v_end = ch.v_end;
-    sa.skip_blocks = 0;
-    // (a scan kept off some CUs, scan_cus_pct: those blocks solve from the start)
-    if (fused_kind == 2 && ctx->scan_cus_pct < 100 && ctx->est_sum_total >= (1ull << 19))
-      sa.skip_blocks = (uint32_t)(fused_blocks - ((uint64_t)ctx->num_cu * (uint64_t)ctx->scan_cus_pct + 99) / 100);
-    ctx->last_scan_skipped = sa.skip_blocks;
-    ctx->scan_kernel_timed = 2;
-    DrawArgs df = da;
-    df.instance = 2;
-    df.no_reset = 1;
-    if (!launch_scan_solve(ctx, fused_kind, sa, df, ctx->stream, fused_blocks, plan.lds)) return fail(ctx, LENTIL_ERR_UNSUPPORTED, "scan_solve_kernel: no kernel for this lens");
-    HIP_TRY(ctx, hipGetLastError());
-    HIP_TRY(ctx, hipEventRecord(ch.scanned, ctx->stream));
-    HIP_TRY(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
-    HIP_TRY(ctx, hipEventRecord(ctx->scans_done, ctx->stream));
-  }
   HIP_TRY(ctx, hipStreamWaitEvent(ctx->pub_stream, ctx->ev[0], 0));
   hipLaunchKernelGGL(publish_kernel, dim3((unsigned)ctx->publish_waves), dim3(64), 0, ctx->pub_stream, pa);
   HIP_TRY(ctx, hipGetLastError());
@@ -3020,14 +2937,7 @@ static int redistribute_streamed(lentil_hip_ctx *ctx, bool *streamed, bool *defe
   }
   HIP_TRY(ctx, hipStreamWaitEvent(ch.stream, ctx->ev[0], 0));
   da.instance = 0;
-  // (a fused pass: instance A runs scan_solve_kernel as well, without the scan -- one copy of the solve loop's code on the chip;
-  // LENTIL_FUSED_A=0: solve_po_kernel as ever)
-  static const bool fused_a = !(getenv("LENTIL_FUSED_A") && getenv("LENTIL_FUSED_A")[0] == '0');
-  if (fused && fused_a) {
-    if (!launch_scan_solve(ctx, fused_kind, plan.sa, da, ch.stream, a_blocks, sizeof(SolveLds<false, false>))) return fail(ctx, LENTIL_ERR_UNSUPPORTED, "scan_solve_kernel: no kernel for this lens");
-  } else {
-    launch_solve_po<true>(ctx, da, ch.stream, a_blocks);
-  }
+  launch_solve_po<true>(ctx, da, ch.stream, a_blocks);
   HIP_TRY(ctx, hipGetLastError());
   HIP_TRY(ctx, hipEventRecord(ch.done, ch.stream));
 
@@ -3094,15 +3004,7 @@ static int redistribute_streamed(lentil_hip_ctx *ctx, bool *streamed, bool *defe
     if (resolve_after_scan) {
       hipStream_t rs = ctx->chunks[1].stream;
       if (ctx->clear_pending) HIP_TRY(ctx, hipStreamWaitEvent(rs, ctx->ev_clear, 0));      // (it reads the accumulators clear_frame is wiping on the chunk stream)
-      if (fused) {
-        // (no event marks the scan's end inside scan_solve_kernel: a one-thread kernel waits for the scan blocks' sign-off -- blocks
-        // that are resident or will be whatever this kernel does; should it give up, the pass is void like any stalled one)
-        HIP_TRY(ctx, hipStreamWaitEvent(rs, ctx->ev[0], 0));
-        hipLaunchKernelGGL(wait_scan_done_kernel, dim3(1), dim3(1), 0, rs, ctx->d_ctr, (uint32_t)fused_blocks, stuck_ticks);
-        HIP_TRY(ctx, hipGetLastError());
-      } else {
-        HIP_TRY(ctx, hipStreamWaitEvent(rs, ctx->scans_done, 0));
-      }
+      HIP_TRY(ctx, hipStreamWaitEvent(rs, ctx->scans_done, 0));
       if ((rc = launch_resolve_half(ctx, rs, 0u))) return rc;
     }
     if (early) {
@@ -3604,19 +3506,14 @@ static void flush_timing(lentil_hip_ctx *ctx, int si, bool blocking) {
   if (!sl.timing_open) return;
   const bool cur = si == ctx->slot;
   if (cur) { sl.timed_draw = ctx->timed_draw; sl.timed_resolve = ctx->timed_resolve; sl.scan_kernel_timed = ctx->scan_kernel_timed; }
-  const bool timed_draw = sl.timed_draw, timed_resolve = sl.timed_resolve; const int scan_k = sl.scan_kernel_timed;
+  const bool timed_draw = sl.timed_draw, timed_resolve = sl.timed_resolve, scan_k = sl.scan_kernel_timed;
   if (!timed_draw) { if (!cur) sl.timing_open = false; return; }      // (a pass that failed before its end: nothing to read)
   hipEvent_t last = timed_resolve ? sl.ev[4] : sl.ev[2];
   if (!blocking && hipEventQuery(last) != hipSuccess) { (void)hipGetLastError(); return; }
   if (hipEventSynchronize(last) != hipSuccess) { (void)hipGetLastError(); sl.timing_open = false; return; }
   float a = 0.f, b = 0.f, c = 0.f, k = 0.f;
   if (hipEventElapsedTime(&a, sl.ev[0], sl.ev[1]) != hipSuccess || hipEventElapsedTime(&b, sl.ev[1], sl.ev[2]) != hipSuccess) { (void)hipGetLastError(); a = b = 0.f; }
-  if (scan_k == 2) {
-    // (scan_solve_kernel: the scan's share of its kernel by the device's clock; the counters' copy lies ahead of ev[2])
-    k = (float)sl.h_ctr_pinned[0].scan_dt * 1.0e-5f;
-    const float ab = a + b;
-    if (k > 0.f && k <= ab) { a = k; b = ab - k; }
-  } else if (scan_k && hipEventElapsedTime(&k, sl.ev_scan_k[0], sl.ev_scan_k[1]) == hipSuccess && k > 0.f && k <= a) { b += a - k; a = k; }
+  if (scan_k && hipEventElapsedTime(&k, sl.ev_scan_k[0], sl.ev_scan_k[1]) == hipSuccess && k > 0.f && k <= a) { b += a - k; a = k; }
   else (void)hipGetLastError();
   if (timed_resolve && hipEventElapsedTime(&c, sl.ev[3], sl.ev[4]) != hipSuccess) { (void)hipGetLastError(); c = 0.f; }
   ctx->totals.scan_ms += a; ctx->totals.draw_ms += b; ctx->totals.resolve_ms += c;
@@ -3713,7 +3610,7 @@ static int begin_slot(lentil_hip_ctx *ctx) {
   cur.timed_draw = ctx->timed_draw; cur.timed_resolve = ctx->timed_resolve; cur.scan_kernel_timed = ctx->scan_kernel_timed;
   if (ctx->spin_readback) {        // (LENTIL_SPIN_READBACK: one block, addressed by the device -- no rotation, no asynchronous end)
     flush_timing(ctx, ctx->slot, true);
-    ctx->timed_draw = ctx->timed_resolve = false; ctx->scan_kernel_timed = 0;
+    ctx->timed_draw = ctx->timed_resolve = false; ctx->scan_kernel_timed = false;
     cur.timing_open = true;
     return LENTIL_OK;
   }
@@ -3731,7 +3628,7 @@ static int begin_slot(lentil_hip_ctx *ctx) {
   for (int i = 0; i < 5; ++i) ctx->ev[i] = n.ev[i];
   ctx->ev_scan_k[0] = n.ev_scan_k[0]; ctx->ev_scan_k[1] = n.ev_scan_k[1];
   ctx->h_ctr_pinned = n.h_ctr_pinned;
-  ctx->timed_draw = ctx->timed_resolve = false; ctx->scan_kernel_timed = 0;
+  ctx->timed_draw = ctx->timed_resolve = false; ctx->scan_kernel_timed = false;
   n.timing_open = true;
   return LENTIL_OK;
 }
@@ -3817,7 +3714,7 @@ static int redistribute_pass(lentil_hip_ctx *ctx) {
   HIP_TRY(ctx, hipMemsetAsync(ctx->d_ctr, 0, sizeof(DevCounters) * (C + 1), ctx->stream));
   HIP_TRY(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
   ctx->last_rounds = 0;
-  ctx->scan_kernel_timed = 0;
+  ctx->scan_kernel_timed = false;
   ctx->h_ctr_valid = false;
   ctx->last_blind = ctx->last_fallback = 0;
   ctx->last_streamed = 0;
@@ -4476,10 +4373,7 @@ LENTIL_API int lentil_hip_last_timing(lentil_hip_ctx *ctx, float ms[3]) {
   if (ctx->timed_draw) {
     HIP_TRY(ctx, hipEventElapsedTime(&ms[0], ctx->ev[0], ctx->ev[1]));
     HIP_TRY(ctx, hipEventElapsedTime(&ms[1], ctx->ev[1], ctx->ev[2]));
-    if (ctx->scan_kernel_timed == 2) {
-      const float k = (float)ctx->slots[ctx->slot].h_ctr_pinned[0].scan_dt * 1.0e-5f, ab = ms[0] + ms[1];
-      if (k > 0.f && k <= ab) { ms[0] = k; ms[1] = ab - k; }
-    } else if (ctx->scan_kernel_timed) {
+    if (ctx->scan_kernel_timed) {
       // the scan launch by its own start / stop events; the draws: the rest of scan start -> end of the draws
       float k = 0.f;
       if (hipEventElapsedTime(&k, ctx->ev_scan_k[0], ctx->ev_scan_k[1]) == hipSuccess && k > 0.f && k <= ms[0]) {
@@ -4489,14 +4383,6 @@ LENTIL_API int lentil_hip_last_timing(lentil_hip_ctx *ctx, float ms[3]) {
     }
   }
   if (ctx->timed_resolve) HIP_TRY(ctx, hipEventElapsedTime(&ms[2], ctx->ev[3], ctx->ev[4]));
-  return LENTIL_OK;
-}
-
-LENTIL_API int lentil_hip_last_scan_form(lentil_hip_ctx *ctx, uint32_t form[3]) {
-  CHECK_CTX(ctx);
-  if (!form) return fail(ctx, LENTIL_ERR_INVALID, "form is null");
-  form[0] = form[1] = form[2] = 0u;
-  if (ctx->last_streamed) { form[0] = ctx->last_scan_kind; form[1] = ctx->last_scan_fused ? 1u : 0u; form[2] = ctx->last_scan_skipped; }
   return LENTIL_OK;
 }
 

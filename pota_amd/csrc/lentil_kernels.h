@@ -54,8 +54,7 @@ struct DevCounters {
   // Streamed pass with extension (ItemLive): items whose current batch is not complete yet / the task queue has its end
   // markers / tasks and items the solve waves added themselves
   unsigned int items_open, queue_final, ext_tasks, ext_items;
-  unsigned int ext_n, ext_head;                  // the extension's own task queue (DrawArgs::ext_q): tasks appended / tickets drawn
-  unsigned int scan_t0, scan_dt;                 // scan_solve_kernel: the first block's start (100 MHz ticks | 1) and the longest start -> end of scanning
+  unsigned int ext_n, ext_head, pad2_[2];        // the extension's own task queue (DrawArgs::ext_q): tasks appended / tickets drawn
   // diagnostics of a stall (lentil_hip_last_redo_note): accept blocks that have begun, per round parity; what the wave that
   // gave up first saw -- round, parity, the queue's n_tasks, accept_done[0], accept_started[0], its slot's tag word, block
   unsigned int accept_started[2];
@@ -139,6 +138,10 @@ struct FrameDev {
   // resolve then reads `acc` only where something was splatted -- 2 % of the frame in the scan-dominated regime --
   // and the next clear wipes only that.
   uint8_t *touched;
+  // ... and one byte per pixel record, set with the group's (same values; non-null together with `touched`): behind the pass's
+  // whole-frame resolve only the pixels a draw reached are resolved again, and the next clear wipes only those -- a petzval
+  // frame's draws reach every 64-pixel group and an eighth of the pixels (round 6: resolve_touched_kernel 386 -> see DESIGN 4.2c).
+  uint8_t *touched_px;
   uint32_t stride;   // floats per record
   // closest-filter AOVs (src/lentil.h:832-837): per pixel the winning candidate as one 64-bit key,
   // (bits of |Z|) << 32 | (0xFFFFFFFF - visit), reduced with atomicMin: smallest depth wins, equal depths
@@ -319,19 +322,6 @@ __global__ __launch_bounds__(256) void report_counters_kernel(const uint32_t *sr
 __global__ void wait_waves_kernel(const DevCounters *ctr, uint32_t want, uint64_t max_ticks) {
   const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
   while (ld_coherent32(&ctr->waves_started[0]) < want && __builtin_amdgcn_s_memrealtime() - t0 < max_ticks) __builtin_amdgcn_s_sleep(8);
-}
-
-// scan_solve_kernel has no end of its scan that a stream could wait for: the whole-frame resolve behind the scan waits here for the
-// scan blocks' sign-off (scan_block_done).  Bounded like every wait of the pass: on giving up, the pass is void (DevCounters::stuck).
-__global__ void wait_scan_done_kernel(DevCounters *ctr, uint32_t want, uint64_t max_ticks) {
-  const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
-  uint32_t naps = 1u;
-  while (ld_coherent32(&ctr->scan_blocks_done) < want) {
-    if (ld_coherent32(&ctr->stuck) != 0u) return;
-    if (__builtin_amdgcn_s_memrealtime() - t0 > (max_ticks ? max_ticks : 25000000ull)) { atomicCAS(&ctr->stuck, 0u, 1u | (0x3FFFFFu << 2)); return; }
-    for (uint32_t i = 0; i < naps; ++i) __builtin_amdgcn_s_sleep(64);
-    if (naps < 8u) naps <<= 1;
-  }
 }
 
 __global__ void probe_set_kernel(uint32_t *flag) { (void)__hip_atomic_exchange(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -1100,7 +1090,7 @@ LD_DEV int coc_below_by_bands(const ScanBands &B, float cz) {
   return 0;       // (NaN, zero and the infinities come here: the function's NaN / infinity is "not below" as well)
 }
 
-LD_DEV void scan_dma2_body(const ScanArgs &a) {
+__global__ __launch_bounds__(256) void scan_dma2_kernel(ScanArgs a) {
   LENTIL_TL_SPAN(SPAN_SCAN);
   extern __shared__ float4 smem[];
   // (the wave's number as a scalar: tile numbers, LDS bases and every branch on them stay in scalar registers)
@@ -1411,7 +1401,7 @@ constexpr uint32_t kDmaMultiRun = 16;      // groups a wave draws at a time
 constexpr uint32_t kDmaMultiCol = 65;
 __host__ __device__ constexpr uint32_t dma_multi_wave_f4(uint32_t n_extra, uint32_t ring) { return ring * (4u + n_extra) * kDmaMultiCol; }
 
-LD_DEV void scan_dma_multi_body(const ScanArgs &a) {
+__global__ __launch_bounds__(256) void scan_dma_multi_kernel(ScanArgs a) {
   LENTIL_TL_SPAN(SPAN_SCAN);
   extern __shared__ float4 smem[];
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
@@ -1582,10 +1572,6 @@ LD_DEV void scan_dma_multi_body(const ScanArgs &a) {
   wq.finish(a);
   scan_block_done(a);
 }
-// (the two LDS-DMA scans are device functions with kernels round them: scan_solve_kernel, behind solve_po_kernel, runs the same
-// bodies and then turns its waves into solve waves)
-__global__ __launch_bounds__(256) void scan_dma2_kernel(ScanArgs a) { scan_dma2_body(a); }
-__global__ __launch_bounds__(256) void scan_dma_multi_kernel(ScanArgs a) { scan_dma_multi_body(a); }
 
 // K1+K2+K6 for ragged footprints (explicit per-visit pixel): lane per visit, fp32 atomics for the
 // direct accumulation.
@@ -2468,28 +2454,14 @@ LD_DEV void live_close_queue(const DrawArgs &a, uint32_t lane) {
 #ifndef LENTIL_SOLVE_ATTR
 #define LENTIL_SOLVE_ATTR __attribute__((amdgpu_waves_per_eu(3)))
 #endif
-// The block's LDS as one struct: solve_po_kernel keeps it as a static __shared__ object; scan_solve_kernel (below), whose waves
-// scan first and solve afterwards, lays it over the scan's dynamic staging area once that is no longer needed.
-template <bool kTables, bool kChroma>
-struct SolveLds {
-  DevTerm terms[kTables ? kMaxTerms : 1];
-  DevLens k;
-  DevLens kc[kChroma ? 3 : 1];
-  float cdfRow[kMaxBokehRows];
-  uint64_t hdr[4][4];                    // per wave: the header of the task being handed out
-  double ap[4][64][2];                   // batched start of the solves (see solve_po_body)
-  double fin[4][6][64];                  // x, y, dx, dy, out[0], out[1]
-  uint32_t fin_err[4][64], fin_res[4][64];      // error bits | channel << 8; result slot
-  uint32_t fin_item[4][64];                     // extension (ItemLive): whose result it is
-};
-template <class LensT, bool kTables, bool kChroma, bool kStream>
-LD_DEV void solve_po_body(const DrawArgs &a, SolveLds<kTables, kChroma> &S_) {
+template <class LensT, bool kTables, bool kChroma = false, bool kStream = false>
+__global__ __launch_bounds__(256) LENTIL_SOLVE_ATTR void solve_po_kernel(DrawArgs a) {
   LENTIL_TL_SPAN(a.round == 0 ? SPAN_SOLVE_R0 : (a.round == 1 ? SPAN_SOLVE_R1 : SPAN_SOLVE_R2));
-  auto &s_terms = S_.terms;
-  DevLens &s_k = S_.k;
-  auto &s_kc = S_.kc;
-  auto &s_cdfRow = S_.cdfRow;
-  auto &s_hdr = S_.hdr;
+  __shared__ DevTerm s_terms[kTables ? kMaxTerms : 1];
+  __shared__ DevLens s_k;
+  __shared__ DevLens s_kc[kChroma ? 3 : 1];
+  __shared__ float s_cdfRow[kMaxBokehRows];
+  __shared__ uint64_t s_hdr[4][4];                    // per wave: the header of the task being handed out
   // Batched start and end of the solves (round 4).  A solve's first step (tea<8> seed, aperture draw: ~250 instructions)
   // and its last (transmittance polynomial, pupil tests, sensor -> pixel: ~250) used to run inside the round in which a
   // lane needed them -- in steady state four lanes of 64 in nearly every round, i.e. 300 wave instructions per round
@@ -2497,11 +2469,10 @@ LD_DEV void solve_po_body(const DrawArgs &a, SolveLds<kTables, kChroma> &S_) {
   // the SIMDs' vector units 97 % busy: the kernel is bound by its instruction count).  Now the aperture draws of a
   // task's 64 units are computed by all lanes at once when the wave takes the task (s_ap), and a finished solve leaves
   // its state in the wave's queue (s_fin*), which all lanes empty together when it is full.
-  auto &s_ap = S_.ap;
-  auto &s_fin = S_.fin;
-  auto &s_fin_err = S_.fin_err;
-  auto &s_fin_res = S_.fin_res;
-  auto &s_fin_item = S_.fin_item;
+  __shared__ double s_ap[4][64][2];
+  __shared__ double s_fin[4][6][64];                  // x, y, dx, dy, out[0], out[1]
+  __shared__ uint32_t s_fin_err[4][64], s_fin_res[4][64];      // error bits | channel << 8; result slot
+  __shared__ uint32_t s_fin_item[4][64];                       // extension (ItemLive): whose result it is
   if (kTables) {
     const uint32_t nt = a.lens->n_terms;
     for (uint32_t i = threadIdx.x; i < nt; i += blockDim.x) s_terms[i] = a.terms[i];
@@ -2898,46 +2869,6 @@ LD_DEV void solve_po_body(const DrawArgs &a, SolveLds<kTables, kChroma> &S_) {
     if (tr64) atomicAdd(&a.ctr->tries, tr64);
     if (rd64) atomicAdd(&a.ctr->lane_rounds, rd64);
   }
-}
-template <class LensT, bool kTables, bool kChroma = false, bool kStream = false>
-__global__ __launch_bounds__(256) LENTIL_SOLVE_ATTR void solve_po_kernel(DrawArgs a) {
-  __shared__ SolveLds<kTables, kChroma> S_;
-  solve_po_body<LensT, kTables, kChroma, kStream>(a, S_);
-}
-
-// ---- scan, then solve: the third resident solve wave per SIMD of a streamed pass (round 6) -------------------------------------
-// A streamed pass keeps two solve blocks per CU resident beside the scan's block (2 x 168 + 80 of a SIMD's 512 registers), and when
-// the scan's waves leave, what they give back is not handed to a third solve block: a block launched behind the scan is not placed
-// while the resident ones are there (rounds 3-5: LENTIL_SOLVE_B did 0-6 % of the iterations; tools/micro/vgpr_alloc.hip asks the
-// dispatcher directly).  For a pass whose solves run on for milliseconds after the scan -- BASELINE config 4: 0.6 ms of scan, 6 ms
-// of petzval solves at two waves per SIMD, 10-11 G lane-iterations/s where three waves reach 15.8 -- that is a third of the chip's
-// fp64 issue slots idle.  So the scan's waves do not leave: this kernel is the scan's body followed by the solve kernel's, compiled
-// for the solve kernel's 168 registers (which the scan's block can afford: 3 x 168 = 504), its LDS the scan's dynamic staging area
-// with the solve block's struct laid over it afterwards.  A wave that has scanned its last tile draws tickets on the task queue like
-// any wave of instance A; the publishers count its waves among those that may hold a ticket (PublishArgs::end_tasks).  The scan's
-// duration, which no event brackets any more, is taken with the device's clock: DevCounters::scan_t0 / scan_dt.
-// kScan: 2 = scan_dma2_body, 3 = scan_dma_multi_body
-template <class LensT, int kScan>
-__global__ __launch_bounds__(256) LENTIL_SOLVE_ATTR void scan_solve_kernel(ScanArgs s, DrawArgs a) {
-  extern __shared__ float4 smem[];
-  if (s.V.n == 0) return;          // (lentil_hip_create's empty launch: the queue's scratch memory)
-  uint32_t t0 = 0;
-  if (threadIdx.x == 0 && a.instance == 2) {
-    t0 = (uint32_t)__builtin_amdgcn_s_memrealtime() | 1u;
-    const uint32_t first = atomicCAS(&s.ctr->scan_t0, 0u, t0);
-    if (first) t0 = first;
-  }
-  // (DrawArgs::instance 2: the blocks that scan first.  The pass's resident solve blocks -- instance 0, launched with a solve block's
-  // LDS -- run THIS kernel too and skip the scan: one copy of the Newton loop's ~20 KB of code in the instruction cache two CUs share,
-  // not the scan kernel's copy beside solve_po_kernel's.)
-  if (a.instance == 2) {
-    if constexpr (kScan == 2) scan_dma2_body(s); else scan_dma_multi_body(s);
-    __builtin_amdgcn_s_setprio(0);
-    // (scan_block_done has waited for this block's stores and met at a barrier; the staging area is free)
-    if (threadIdx.x == 0) atomicMax(&s.ctr->scan_dt, (uint32_t)__builtin_amdgcn_s_memrealtime() - t0);
-    __syncthreads();
-  }
-  solve_po_body<LensT, false, false, true>(a, *reinterpret_cast<SolveLds<false, false> *>(smem));
 }
 
 // ---- stragglers: one wave per solve ----------------------------------------------------------------
@@ -3517,7 +3448,7 @@ LD_DEV AcceptResult accept_item(const DrawArgs &a, AcceptShared &sh, uint32_t it
         rmin = row < rmin ? row : rmin;
         rmax_p1 = row + 1u > rmax_p1 ? row + 1u : rmax_p1;
         s_pix[wave][(uint32_t)__builtin_popcountll(pmask0 & lt_mask)] = pix;
-        if (a.F.touched) a.F.touched[pix >> 6] = a.round ? 2 : 1;      // (2: by a round after the first, see resolve_touched_kernel)
+        if (a.F.touched) { a.F.touched[pix >> 6] = a.round ? 2 : 1; a.F.touched_px[pix] = a.round ? 2 : 1; }      // (2: by a round after the first, see resolve_touched_kernel)
         if (a.F.zkey) atomicMin(a.F.zkey + pix, zk);
         if (a.F.zkey_dbg) atomicMin(a.F.zkey_dbg + pix, zk);      // value.r = samples != 0 for every draw
         if (a.log_cap) {
@@ -3856,7 +3787,7 @@ LD_DEV AcceptResult accept_item_wide(const DrawArgs &a, AcceptShared &sh, Accept
         const uint32_t row = pix / a.P.xres;
         rmin = row < rmin ? row : rmin;
         rmax_p1 = row + 1u > rmax_p1 ? row + 1u : rmax_p1;
-        if (a.F.touched) a.F.touched[pix >> 6] = a.round ? 2 : 1;      // (2: by a round after the first, see resolve_touched_kernel)
+        if (a.F.touched) { a.F.touched[pix >> 6] = a.round ? 2 : 1; a.F.touched_px[pix] = a.round ? 2 : 1; }      // (2: by a round after the first, see resolve_touched_kernel)
         if (a.F.zkey) atomicMin(a.F.zkey + pix, zk);
         if (a.F.zkey_dbg) atomicMin(a.F.zkey_dbg + pix, zk);      // value.r = samples != 0 for every draw
         if (a.log_cap) {
@@ -4018,7 +3949,7 @@ LD_DEV AcceptResult accept_item_chroma(const DrawArgs &a, AcceptShared &sh, uint
         rmin = row < rmin ? row : rmin;
         rmax_p1 = row + 1u > rmax_p1 ? row + 1u : rmax_p1;
         s_pix[wave][(uint32_t)__builtin_popcountll(tmask & lt_mask)] = pix;
-        if (a.F.touched) a.F.touched[pix >> 6] = a.round ? 2 : 1;      // (as accept_item does: a later round's splats are resolved again)
+        if (a.F.touched) { a.F.touched[pix >> 6] = a.round ? 2 : 1; a.F.touched_px[pix] = a.round ? 2 : 1; }      // (as accept_item does: a later round's splats are resolved again)
         if (a.F.zkey) atomicMin(a.F.zkey + pix, zk);
         if (a.F.zkey_dbg) atomicMin(a.F.zkey_dbg + pix, zk);      // value.r = samples != 0 for every draw
         if (a.log_cap) {
@@ -4634,7 +4565,7 @@ __global__ __launch_bounds__(256) void tl_chroma_walk_kernel(TlChromaArgs a) {
         s_pix[wave][slot] = pix;
         s_ch[wave][slot] = (uint32_t)(channel + 1);
         s_key[wave][slot] = (pix << 2) | (uint32_t)(channel + 1);       // (frames of up to 2^30 pixels)
-        if (a.F.touched) a.F.touched[pix >> 6] = 1;
+        if (a.F.touched) { a.F.touched[pix >> 6] = 1; a.F.touched_px[pix] = 1; }
         if (a.F.zkey) atomicMin(a.F.zkey + pix, zk);
         if (a.F.zkey_dbg) atomicMin(a.F.zkey_dbg + pix, zk);
         if (a.log_cap) {
@@ -4877,7 +4808,11 @@ __global__ __launch_bounds__(256) void clear_touched_kernel(FrameDev F, uint64_t
       m &= m - 1ull;
       const uint64_t p0 = (g0 + b) * 64u;
       const uint64_t n_pix = (F.np - p0) < 64ull ? (F.np - p0) : 64ull;
-      for (uint32_t i = lane; i < n_pix * q; i += 64u) acc4[p0 * q + i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      // (a lane per pixel: the records a draw reached -- their flags -- and nothing else of the group)
+      if (lane < n_pix && F.touched_px[p0 + lane] != 0) {
+        F.touched_px[p0 + lane] = 0;
+        for (uint32_t j = 0; j < q; ++j) acc4[(p0 + lane) * q + j] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
     }
   }
 }
@@ -4971,35 +4906,27 @@ __global__ __launch_bounds__(256) void resolve_kernel(FrameDev F, float *resolve
 // pass, from the pixels' own sums alone or with an earlier round's draws): the group's splat records are read (coalesced), and
 // only the pixels that hold a draw -- a record whose weight is not zero: every draw adds its weight -- fetch their own sums,
 // normalise and store.  A 4K headline frame's draws reach about half of the groups and an eighth of the pixels.
-LD_DEV void resolve_touched_group(const FrameDev &F, float *resolved, float4 *tile, uint64_t p0, uint32_t n_pix, uint32_t lane) {
+LD_DEV void resolve_touched_group(const FrameDev &F, float *resolved, uint64_t p0, uint32_t n_pix, uint32_t lane, uint32_t min_flag) {
   const uint32_t q = F.stride >> 2;
   const float4 *acc4 = reinterpret_cast<const float4 *>(F.acc);
   const float4 *dir4 = reinterpret_cast<const float4 *>(F.dir);
-  const uint32_t n4 = n_pix * q;
-  for (uint32_t i = lane; i < n4; i += 64u) tile[i] = acc4[p0 * q + i];
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
-  if (lane < n_pix) {
-    const float *rec = reinterpret_cast<const float *>(tile + (size_t)lane * q);
-    if (rec[4u * F.n_aovs] != 0.0f) {
-      float wt = rec[4u * F.n_aovs];
-      if (dir4) wt += reinterpret_cast<const float *>(dir4 + (p0 + lane) * q)[4u * F.n_aovs];
-      const float inv = wt != 0.0f ? 1.0f / wt : 1.0f;      // AtRGBA /= float multiplies by 1.0f/f
-      for (uint32_t a = 0; a < F.n_aovs; ++a) {
-        float4 c = tile[(size_t)lane * q + a];
-        if (dir4) { const float4 d = dir4[(p0 + lane) * q + a]; c.x += d.x; c.y += d.y; c.z += d.z; c.w += d.w; }
-        if (F.closest_mask & (1u << a)) {
-          c.w = 1.0f;                                      // closest: (r, g, b, 1), src/lentil_imager.cpp:181-186
-        } else if (wt != 0.0f) {
-          c.x *= inv; c.y *= inv; c.z *= inv; c.w *= inv;
-        }
-        reinterpret_cast<float4 *>(resolved)[(uint64_t)a * F.np + p0 + lane] = c;
+  // (a lane per pixel: its flag -- one coalesced 64-byte read per group --, and only a flagged pixel reads its records)
+  if (lane < n_pix && F.touched_px[p0 + lane] >= min_flag) {
+    const uint64_t p = p0 + lane;
+    float wt = reinterpret_cast<const float *>(acc4 + p * q)[4u * F.n_aovs];
+    if (dir4) wt += reinterpret_cast<const float *>(dir4 + p * q)[4u * F.n_aovs];
+    const float inv = wt != 0.0f ? 1.0f / wt : 1.0f;      // AtRGBA /= float multiplies by 1.0f/f
+    for (uint32_t a = 0; a < F.n_aovs; ++a) {
+      float4 c = acc4[p * q + a];
+      if (dir4) { const float4 d = dir4[p * q + a]; c.x += d.x; c.y += d.y; c.z += d.z; c.w += d.w; }
+      if (F.closest_mask & (1u << a)) {
+        c.w = 1.0f;                                      // closest: (r, g, b, 1), src/lentil_imager.cpp:181-186
+      } else if (wt != 0.0f) {
+        c.x *= inv; c.y *= inv; c.z *= inv; c.w *= inv;
       }
+      reinterpret_cast<float4 *>(resolved)[(uint64_t)a * F.np + p] = c;
     }
   }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
-  __builtin_amdgcn_wave_barrier();
 }
 
 __global__ __launch_bounds__(256) void resolve_touched_kernel(FrameDev F, float *resolved, uint32_t min_flag) {
@@ -5025,7 +4952,7 @@ __global__ __launch_bounds__(256) void resolve_touched_kernel(FrameDev F, float 
       if ((k++ % wpb) != wave) continue;
       const uint64_t p0 = (ch * 64ull + b) * 64ull;
       const uint32_t n_pix = (uint32_t)((F.np - p0) < 64ull ? (F.np - p0) : 64ull);
-      if (per_pixel) resolve_touched_group(F, resolved, tile, p0, n_pix, lane);
+      if (per_pixel) resolve_touched_group(F, resolved, p0, n_pix, lane, min_flag);
       else resolve_group(F, resolved, tile, p0, n_pix, lane);
     }
   }

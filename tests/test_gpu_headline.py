@@ -62,7 +62,7 @@ def _compare(ctx, ref, c, samples, n_visits, p, n_aovs=1, kinds=None):
 
 
 def _timed_config_vs_oracle(orc, name, W, H, lens, S, n_extra=0, kinds=None, bokeh_image=False, seeds=(0x5EED, 0xBEEF),
-                            passes=(0, 1, 0, 1), runtime_kernel=False, expect_form=None):
+                            passes=(0, 1, 0, 1), runtime_kernel=False):
     """One of bench.py's `configs` entries as the bench runs it -- Bench.generate's two seeded streams, two set-up passes,
     then alternating streams -- with every pass compared with the oracle over the whole frame."""
     import ctypes as C
@@ -118,9 +118,6 @@ def _timed_config_vs_oracle(orc, name, W, H, lens, S, n_extra=0, kinds=None, bok
             want = 1 if (k and not has_closest) else 0
             assert c.fallback_chunks == 0 and c.streamed == want, (k, c.streamed, c.fallback_chunks, ctx.last_redo_note())
             seen_streamed += c.streamed
-            if expect_form is not None and c.streamed:
-                # (scan kernel, did its waves stay to solve: lentil_hip_last_scan_form)
-                assert ctx.last_scan_form()[:2] == tuple(expect_form), (k, ctx.last_scan_form())
             worst, n_touched = _compare(ctx, refs[i % len(refs)], c, S, n, p, n_aovs=n_aovs, kinds=kinds)
             print("%s, pass %d (%s): %d items, %d accepted draws on %d pixels, max rel err %.2e"
                   % (name, k, "streamed" if c.streamed else "chunked", c.redistributed_visits, c.accepted_draws, n_touched, worst))
