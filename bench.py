@@ -633,7 +633,7 @@ def main():
         spawn_ranks(args)
     import torch
     import torch.distributed as dist
-    from pota_amd import workload
+    from pota_amd import capi, workload
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -784,6 +784,9 @@ def main():
         "passes": {"timed": steps, "streamed": r["streamed"], "chunks_enqueued_blind": r["blind_chunks"],
                    "chunks_redone_after_a_short_estimate": r["redone"], "solve_accept_rounds_max": r.get("rounds_max"),
                    "redo_notes": r.get("redo_notes", []),
+                   # the whole process so far (lentil_hip_process_stats): streamed passes begun, those whose resident waves hit the
+                   # stuck time-out (each wiped and run again: right, and late), how many of those a test asked for, passes redone
+                   "process": dict(zip(("streamed", "stuck", "stuck_asked_for", "redone"), capi.process_stats())),
                    # the asynchronous end of a pass (include/lentil_hip.h, lentil_hip_set_async): passes that returned before their
                    # end was known, those whose frame was cleared before anybody observed it, and how many of those had still needed work
                    "timed_loop": r.get("timed_loop"), "ends_deferred": r.get("deferred"), "abandoned": r.get("abandoned"),

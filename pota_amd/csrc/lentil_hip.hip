@@ -3055,7 +3055,7 @@ static int redistribute_streamed(lentil_hip_ctx *ctx, bool *streamed, bool *defe
       tail = ls;
     } else {
     const char *overlap_env = getenv("LENTIL_OVERLAP_ACCEPT");      // (read per pass: the tests switch it)
-    const bool overlap_accept = overlap_env && overlap_env[0] == '1';
+    const bool overlap_accept = !(overlap_env && overlap_env[0] == '0');
     for (int round = 1; round < blind_rounds; ++round) {
       da.parity = round & 1; da.round = round;
       DrawArgs d1 = da;
@@ -3075,7 +3075,12 @@ static int redistribute_streamed(lentil_hip_ctx *ctx, bool *streamed, bool *defe
         // blocks done 64 begun 64" of 512).  The blocks that did run had served every item, so nothing was wrong but the wait.
         // A kernel of a pass may spin only on kernels that hold all the resources they will ever need.  What this costs is the
         // head start of the second round's solves (~0.1 ms of a pass that has a second round at all; the lean tail has none).
-        // LENTIL_OVERLAP_ACCEPT=1: beside it, as rounds 3 and 4 had it.
+        // Round 6: beside it again, by default.  Since the end markers of an emitting accept are written by the block that finishes
+        // the pass's LAST ITEM (DevCounters::accept_items_done), not by the grid's last block, a share of the grid that is never
+        // dispatched keeps nobody waiting; soaked with the dispatch probe's build armed (tools/sessions_r06/r06_session26.sh: 1 600
+        // passes with a second round in flight -- config 5's bands, the headline without the first-batch model --, no stall, no
+        // probe event; profiles/r06_overlap_accept_soak.txt) and worth 13 % of a config-5 band's pass.  LENTIL_OVERLAP_ACCEPT=0:
+        // behind it.
         HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, overlap_accept ? ctx->ev_round : ctx->ev_acc1, 0));
         launch_solve_po<true>(ctx, d1, ctx->stream, (unsigned)ctx->num_cu);
       } else {
