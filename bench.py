@@ -92,6 +92,7 @@ def parse():
     ap.add_argument("--no-scan-alone", action="store_true", help="skip the measurement of the scan kernel with the chip to itself")
     ap.add_argument("--no-pcie", action="store_true", help="skip the PCIe-inclusive measurement (upload from host memory + pass)")
     ap.add_argument("--no-second-regime", action="store_true")
+    ap.add_argument("--no-clock-trace", action="store_true", help="skip roofline.clock_in_pass (the sampler loop behind the timed steps)")
     ap.add_argument("--no-configs", action="store_true", help="skip BASELINE.json's configs 2-4")
     ap.add_argument("--same-frame", action="store_true", help="replay ONE visit stream (development aid; the default alternates two)")
     ap.add_argument("--cpu-row-step", type=int, default=0, help="CPU baseline samples every n-th row (0 = auto)")
@@ -745,6 +746,16 @@ def main():
         box["note"] = ("measured in this run by lentil_hip_box_probe: dependent fp64 multiply/add chains at three waves per SIMD (the solves' "
                        "arithmetic, no FMA; ceiling = CUs x 4 SIMDs x 16 lanes x clock), clock64() against the 100 MHz counter under that load, "
                        "a 512 MiB float4 copy (bytes read + written) and read-only stream; for putting timings of different boxes side by side")
+    # the clock those steps ran at: a short loop of its own with a one-wave sampler beside it (tools/clock_trace.py; never the
+    # timed loop) -- box.shader_clock_mhz_under_fp64 is what the chip settles at after 15 ms of steady fp64 load, a 2-ms pass gets less
+    clock_in_pass = None
+    if rank == 0 and world == 1 and not args.no_clock_trace:
+        try:
+            sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools"))
+            import clock_trace
+            clock_in_pass = clock_trace.clock_in_pass(b, r["dt"] / r["steps"] * 1e3)
+        except Exception as e:      # a measuring aid: the line is reported without it
+            clock_in_pass = {"error": repr(e)}
     n_total = workload.frame_visit_count(W, H, M) if not emulate else b.n_local        # all ranks
     value = n_total * r["steps"] / r["dt"] / 1e6
     ms_per_step, launches, launch_ms, launch_bytes, achieved = summarize(b, r, n_total, bytes_per_visit)
@@ -975,6 +986,7 @@ def main():
         # keys still has it): the box probe -- fp64 chain rate, clock, copy / read bandwidth, queues -- and the pass's kernel times;
         # and `roofline` / `cpu_baseline` are the LAST keys of the line, so that a tail of the output holds them.
         out["roofline"]["box"] = out.get("box")
+        out["roofline"]["clock_in_pass"] = clock_in_pass
         out["roofline"]["kernels_ms"] = out.get("kernels_ms")
         out["roofline"]["ms_per_step"] = out.get("ms_per_step")
         out["roofline"]["timed_loop"] = (out.get("passes") or {}).get("timed_loop")
