@@ -78,3 +78,19 @@ def test_product_path_does_not_import_the_oracle():
             if f.endswith((".py", ".h", ".hip", ".cpp")):
                 txt = open(os.path.join(root, f), errors="ignore").read()
                 assert "liblentil_oracle" not in txt and "oracle_lib" not in txt and "oracle/" not in txt, f
+
+
+def test_measuring_aids_build_and_load():
+    """tools/micro/libclock_sampler.so (built by __graft_entry__.build(): the one-wave clock sampler bench.py runs beside a short loop for
+    roofline.clock_in_pass) loads and exports what tools/clock_trace.py binds; bench.py knows the switch that leaves it out."""
+    so = os.path.join(common.ROOT, "tools", "micro", "libclock_sampler.so")
+    assert os.path.exists(so), "build() did not produce tools/micro/libclock_sampler.so"
+    lib = C.CDLL(so)
+    for n in ("sampler_start", "sampler_stamp", "sampler_read"):
+        assert hasattr(lib, n), n
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("clock_trace", os.path.join(common.ROOT, "tools", "clock_trace.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert callable(mod.clock_in_pass) and callable(mod.trace_steps)
+    assert "--no-clock-trace" in open(os.path.join(common.ROOT, "bench.py")).read()
