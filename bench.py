@@ -92,6 +92,7 @@ def parse():
     ap.add_argument("--no-scan-alone", action="store_true", help="skip the measurement of the scan kernel with the chip to itself")
     ap.add_argument("--no-pcie", action="store_true", help="skip the PCIe-inclusive measurement (upload from host memory + pass)")
     ap.add_argument("--no-second-regime", action="store_true")
+    ap.add_argument("--no-sustained", action="store_true", help="skip roofline.sustained (350 untimed + 200 timed steps behind the timed ones)")
     ap.add_argument("--no-clock-trace", action="store_true", help="skip roofline.clock_in_pass (the sampler loop behind the timed steps)")
     ap.add_argument("--no-configs", action="store_true", help="skip BASELINE.json's configs 2-4")
     ap.add_argument("--same-frame", action="store_true", help="replay ONE visit stream (development aid; the default alternates two)")
@@ -756,6 +757,28 @@ def main():
             clock_in_pass = clock_trace.clock_in_pass(b, r["dt"] / r["steps"] * 1e3)
         except Exception as e:      # a measuring aid: the line is reported without it
             clock_in_pass = {"error": repr(e)}
+    # ... and the same workload again after 350 untimed steps (0.7 s).  The chip's power management moves between regimes over tenths
+    # of a second to seconds: on most boxes an idle chip's first 0.4 s of passes run at ~2.0 GHz in the solve phase (2.0 ms a step)
+    # and then settle at ~2.25 GHz (1.86 ms); a chip that has been loaded for some seconds may sit at 2.0 GHz for good
+    # (tools/sustained.py, profiles/r06_sustained.txt).  W warm-up steps and K timed ones (`value`: 3 + 20 as the driver runs it, 46 ms)
+    # see whichever regime the chip is in; this second figure, timed the same way, is reported beside it in roofline.sustained --
+    # never as `value` -- with the clock in the pass for both.
+    sustained = None
+    if rank == 0 and world == 1 and not args.no_sustained and not emulate:
+        try:
+            for _ in range(350):
+                b.step()
+            rs = b.run(200, 0)
+            ms_s = rs["dt"] / rs["steps"] * 1e3
+            sustained = {"ms_per_step": round(ms_s, 4), "steps": 200, "untimed_steps_before": 350,
+                         "kernels_ms": {"scan": round(rs["scan"] / rs["steps"], 4), "draw": round(rs["draw"] / rs["steps"], 4)},
+                         "passes": {"streamed": rs["streamed"], "redone": rs["redone"], "rounds_max": rs.get("rounds_max")}}
+            if isinstance(clock_in_pass, dict) and "error" not in clock_in_pass:
+                import clock_trace
+                c2 = clock_trace.clock_in_pass(b, ms_s)
+                sustained["clock_in_pass"] = {k: c2[k] for k in ("mean_mhz", "middle_half_of_a_step_mhz")}
+        except Exception as e:      # a second figure: the line is reported without it
+            sustained = {"error": repr(e)}
     n_total = workload.frame_visit_count(W, H, M) if not emulate else b.n_local        # all ranks
     value = n_total * r["steps"] / r["dt"] / 1e6
     ms_per_step, launches, launch_ms, launch_bytes, achieved = summarize(b, r, n_total, bytes_per_visit)
@@ -987,6 +1010,14 @@ def main():
         # and `roofline` / `cpu_baseline` are the LAST keys of the line, so that a tail of the output holds them.
         out["roofline"]["box"] = out.get("box")
         out["roofline"]["clock_in_pass"] = clock_in_pass
+        if isinstance(sustained, dict) and "ms_per_step" in sustained:
+            sustained["value"] = round(n_total / (sustained["ms_per_step"] * 1e-3) / 1e6, 3)
+            sustained["unit"] = "Msamples/s"
+            sustained["whole_step_frac"] = round(b.n_local * bytes_per_visit / (sustained["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
+            sustained["note"] = ("the same workload after 350 more untimed steps (0.7 s), timed the same way: the chip's power management moves between "
+                                 "a ~2.0 GHz and a ~2.25 GHz regime of the solve phase over tenths of a second to seconds (1.86-2.00 ms a step; "
+                                 "profiles/r06_sustained.txt, DESIGN.md section 4.2c); compare the two clock_in_pass blocks")
+        out["roofline"]["sustained"] = sustained
         out["roofline"]["kernels_ms"] = out.get("kernels_ms")
         out["roofline"]["ms_per_step"] = out.get("ms_per_step")
         out["roofline"]["timed_loop"] = (out.get("passes") or {}).get("timed_loop")
