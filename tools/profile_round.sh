@@ -45,9 +45,9 @@ for d, name in (("/tmp/%s_stats" % tag, "headline"), ("/tmp/%sc4_stats" % tag, "
 PY
 cp profiles/${TAG}_kernel_stats.csv profiles/${TAG}c4_kernel_stats.csv profiles/${TAG}_pmc_scan.json profiles/${TAG}c4_pmc_scan.json profiles/pmc_scan_latest.json $O/profiles/ 2>/dev/null
 # 3. timelines of one streamed pass (instrumented build)
-python3 tools/timeline.py --passes 7 --out $O/profiles/${TAG}_timeline_headline.txt > /dev/null 2>&1
-python3 tools/timeline.py --lens petzval_58mm --aovs 8 --passes 5 --out $O/profiles/${TAG}_timeline_config4.txt > /dev/null 2>&1
-python3 tools/timeline.py --width 7680 --height 4320 --samples 2048 --passes 4 --out $O/profiles/${TAG}_timeline_config5.txt > /dev/null 2>&1
+python3 tools/timeline.py --passes 7 --out $O/profiles/${TAG}_timeline_headline.txt > $O/timeline_headline.log 2>&1
+python3 tools/timeline.py --lens petzval_58mm --aovs 8 --passes 5 --out $O/profiles/${TAG}_timeline_config4.txt > $O/timeline_config4.log 2>&1
+python3 tools/timeline.py --width 7680 --height 4320 --samples 2048 --passes 4 --out $O/profiles/${TAG}_timeline_config5.txt > $O/timeline_config5.log 2>&1
 # 4. cryptomatte replay
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/${TAG}_cr -- python3 tools/crypto_rate.py > $O/crypto_stats.log 2>&1
 python3 - /tmp/${TAG}_cr $O/profiles/${TAG}_crypto_kernels.txt <<'PY'
